@@ -1,0 +1,1552 @@
+/* TEST INFRASTRUCTURE -- see blasr_oracle.h.  Plain-C restatement of the
+ * reference algorithms on BLASR's refine path.  Written for clarity, not speed.
+ * Reference citations are file:line under the reference checkout.
+ *
+ * Third-party algorithm restated here: libstdc++'s std::sort (GCC 11.4.0,
+ * bits/stl_algo.h introsort: median-of-3 quicksort to runs of <= 16, heapsort
+ * after 2*floor(log2 n) levels, final insertion sort).  SDPAlign.h:256 sorts a
+ * fragment list that can hold duplicate (x,y) keys of different `length`, and
+ * which duplicate survives the following de-duplication is decided by that
+ * schedule, so it is cloned exactly (bo_introsort_xy).
+ */
+#include "blasr_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define INF_INT INT_MAX /* defs.h:15-17 */
+#define MAX_BAND_SIZE 250 /* GuidedAlign.h:29 */
+
+/* ------------------------------------------------------------------------- */
+/* Nucleotide code tables (NucConversion.h:7-41 TwoBit, :48-86 ThreeBit,     */
+/* :88-121 IsACTG), rebuilt from their defining property.                     */
+/* ------------------------------------------------------------------------- */
+static int g_two[256], g_three[256], g_isactg[256], g_tables_ready;
+
+static void init_tables(void) {
+  if (g_tables_ready) return;
+  for (int i = 0; i < 256; i++) {
+    g_two[i] = 255;
+    g_three[i] = 255;
+    g_isactg[i] = 0;
+  }
+  for (int i = 0; i < 8; i++) g_two[i] = i & 3;
+  for (int i = 0; i < 4; i++) {
+    g_three[i] = i;
+    g_isactg[i] = 1;
+  }
+  g_three[4] = 4;
+  g_three['$'] = 5;
+  const char *acgt = "ACGT";
+  for (int i = 0; i < 4; i++) {
+    int u = acgt[i], l = acgt[i] + 32;
+    g_two[u] = g_two[l] = i;
+    g_three[u] = g_three[l] = i;
+    g_isactg[u] = g_isactg[l] = 1;
+  }
+  /* IUPAC ambiguity codes that ThreeBit maps to 4 ('N'). */
+  const char *nUpper = "BDHKMNRSUVWY_";
+  for (const char *p = nUpper; *p; p++) g_three[(int)*p] = 4;
+  const char *nLower = "bdhkmnrsuvwxy";
+  for (const char *p = nLower; *p; p++) g_three[(int)*p] = 4;
+  g_tables_ready = 1;
+}
+
+typedef struct {
+  int m[5][5];
+  int ins, del, affineOpen, affineExtend;
+} score_fn;
+
+static void make_score_fn(score_fn *fn, const int *matrix25, int ins, int del, int affOpen,
+                          int affExt) {
+  init_tables();
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) fn->m[i][j] = matrix25[i * 5 + j];
+  fn->ins = ins;
+  fn->del = del;
+  fn->affineOpen = affOpen;
+  fn->affineExtend = affExt;
+}
+
+/* DistanceMatrixScoreFunction<DNASequence,FASTQSequence>::Match
+ * (DistanceMatrixScoreFunction.h:99-104): matrix[query][ref]. */
+static int match_score(const score_fn *fn, unsigned char tc, unsigned char qc) {
+  return fn->m[g_three[qc]][g_three[tc]];
+}
+
+/* ------------------------------------------------------------------------- */
+/* Alignment container (datastructures/alignment/Alignment.h:17-41).         */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t q, t, len;
+} block_t;
+typedef struct {
+  int seq, len;
+} gap_t;
+typedef struct {
+  gap_t *g;
+  int n, cap;
+} gaplist_t;
+typedef struct {
+  uint32_t qPos, tPos;
+  block_t *blocks;
+  int nBlocks, blockCap;
+  gaplist_t *gaps;
+  int nGaps, gapCap;
+  int score, nCells, nMatch, nMismatch, nIns, nDel;
+  float pct;
+} aln_t;
+
+static void aln_init(aln_t *a) { memset(a, 0, sizeof(*a)); }
+static void aln_free(aln_t *a) {
+  free(a->blocks);
+  for (int i = 0; i < a->nGaps; i++) free(a->gaps[i].g);
+  free(a->gaps);
+  aln_init(a);
+}
+static void aln_push_block(aln_t *a, block_t b) {
+  if (a->nBlocks == a->blockCap) {
+    a->blockCap = a->blockCap ? a->blockCap * 2 : 64;
+    a->blocks = (block_t *)realloc(a->blocks, sizeof(block_t) * a->blockCap);
+  }
+  a->blocks[a->nBlocks++] = b;
+}
+static gaplist_t *aln_push_gaplist(aln_t *a) {
+  if (a->nGaps == a->gapCap) {
+    a->gapCap = a->gapCap ? a->gapCap * 2 : 64;
+    a->gaps = (gaplist_t *)realloc(a->gaps, sizeof(gaplist_t) * a->gapCap);
+  }
+  gaplist_t *g = &a->gaps[a->nGaps++];
+  g->g = NULL;
+  g->n = g->cap = 0;
+  return g;
+}
+static void gaplist_push(gaplist_t *l, int seq, int len) {
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 4;
+    l->g = (gap_t *)realloc(l->g, sizeof(gap_t) * l->cap);
+  }
+  l->g[l->n].seq = seq;
+  l->g[l->n].len = len;
+  l->n++;
+}
+
+/* Path.h:4-21 (the arrows this path produces). */
+enum { A_DIAG, A_UP, A_LEFT, A_INS_UP, A_INS_OPEN, A_INS_CLOSE, A_DEL_LEFT, A_DEL_OPEN, A_DEL_CLOSE, A_NONE = 12 };
+
+/* Alignment::ArrowPathToAlignment (Alignment.h:190-254): RLE of a forward
+ * arrow path into blocks (runs of Diagonal) and one gap list per inter-block
+ * slot; gap list 0 is the leading one; a list that reaches the end of the
+ * path is emptied. */
+static void arrow_path_to_alignment(aln_t *a, const unsigned char *path, int n) {
+  int q = 0, t = 0, i = 0, beforeFirst = 1;
+  while (i < n) {
+    if (!beforeFirst && path[i] == A_DIAG) {
+      block_t b = {(uint32_t)q, (uint32_t)t, 0};
+      while (i < n && path[i] == A_DIAG) {
+        b.len++;
+        i++;
+        t++;
+        q++;
+      }
+      aln_push_block(a, b);
+    }
+    gaplist_t *gl = aln_push_gaplist(a);
+    while (i < n && (path[i] == A_LEFT || path[i] == A_UP)) {
+      int start = i;
+      if (path[i] == A_LEFT) {
+        while (i < n && path[i] == A_LEFT) {
+          t++;
+          i++;
+        }
+        gaplist_push(gl, BO_GAP_QUERY, i - start);
+      } else {
+        while (i < n && path[i] == A_UP) {
+          q++;
+          i++;
+        }
+        gaplist_push(gl, BO_GAP_TARGET, i - start);
+      }
+    }
+    if (i == n) gl->n = 0;
+    beforeFirst = 0;
+  }
+}
+
+/* RemoveAlignmentPrefixGaps (AlignmentUtils.h:620-644). */
+static void remove_prefix_gaps(aln_t *a) {
+  if (a->nGaps == 0) return;
+  int tStart = 0, qStart = 0;
+  for (int g = 0; g < a->gaps[0].n; g++) {
+    if (a->gaps[0].g[g].seq == BO_GAP_TARGET)
+      qStart += a->gaps[0].g[g].len;
+    else
+      tStart += a->gaps[0].g[g].len;
+  }
+  for (int b = 0; b < a->nBlocks; b++) {
+    a->blocks[b].q -= qStart;
+    a->blocks[b].t -= tStart;
+  }
+  a->gaps[0].n = 0;
+  a->tPos += tStart;
+  a->qPos += qStart;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ComputeAlignmentStats (AlignmentUtils.h:535-584) over the column strings   */
+/* of CreateAlignmentStrings (:390-533) and ComputeAlignmentScore (:60-124).  */
+/* The strings are materialised as two byte arrays ('-' = gap), as there.     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  unsigned char *q, *t;
+  int n, cap;
+} cols_t;
+static void cols_push(cols_t *c, unsigned char qc, unsigned char tc) {
+  if (c->n == c->cap) {
+    c->cap = c->cap ? c->cap * 2 : 1024;
+    c->q = (unsigned char *)realloc(c->q, c->cap);
+    c->t = (unsigned char *)realloc(c->t, c->cap);
+  }
+  c->q[c->n] = qc;
+  c->t[c->n] = tc;
+  c->n++;
+}
+
+static void compute_alignment_stats(aln_t *a, const unsigned char *query, const unsigned char *text,
+                                    const score_fn *fn, int useAffine) {
+  cols_t c = {0, 0, 0, 0};
+  uint32_t q = a->qPos, t = a->tPos;
+  if (a->nBlocks > 0) {
+    if (a->nGaps == 0) {
+      /* AlignmentUtils.h:408-446: offset of the first block spelled out. */
+      if (a->blocks[0].q > 0 || a->blocks[0].t > 0) {
+        uint32_t qp = a->blocks[0].q, tp = a->blocks[0].t;
+        int common = (int)qp;
+        if ((uint32_t)common > tp) common = (int)tp;
+        for (int g = 0; g < common; g++) cols_push(&c, query[q++], text[t++]);
+        tp -= common;
+        qp -= common;
+        for (uint32_t p = 0; p < tp; p++) cols_push(&c, '-', text[t++]);
+        for (uint32_t p = 0; p < qp; p++) cols_push(&c, query[q++], '-');
+      }
+    } else {
+      for (int gi = 0; gi < a->gaps[0].n; gi++)
+        for (int gp = 0; gp < a->gaps[0].g[gi].len; gp++) {
+          if (a->gaps[0].g[gi].seq == BO_GAP_QUERY)
+            cols_push(&c, '-', text[t++]);
+          else
+            cols_push(&c, query[q++], '-');
+        }
+    }
+    for (int b = 0; b < a->nBlocks; b++) {
+      for (uint32_t bl = 0; bl < a->blocks[b].len; bl++) cols_push(&c, query[q++], text[t++]);
+      if (b == a->nBlocks - 1) continue;
+      if (a->nGaps > 0) {
+        gaplist_t *gl = &a->gaps[b + 1];
+        for (int gi = 0; gi < gl->n; gi++)
+          for (int gp = 0; gp < gl->g[gi].len; gp++) {
+            if (gl->g[gi].seq == BO_GAP_QUERY)
+              cols_push(&c, '-', text[t++]);
+            else
+              cols_push(&c, query[q++], '-');
+          }
+      } else {
+        /* AlignmentUtils.h:494-529: no gap list -> query surplus, then text
+         * surplus, then the common part as aligned columns. */
+        int qGap = (int)(a->blocks[b + 1].q - a->blocks[b].q - a->blocks[b].len);
+        int tGap = (int)(a->blocks[b + 1].t - a->blocks[b].t - a->blocks[b].len);
+        if (qGap > 0 || tGap > 0) {
+          int common = qGap;
+          if (qGap > tGap) common = tGap;
+          tGap -= common;
+          qGap -= common;
+          for (int g = 0; g < qGap; g++) cols_push(&c, query[q++], '-');
+          for (int g = 0; g < tGap; g++) cols_push(&c, '-', text[t++]);
+          for (int g = 0; g < common; g++) cols_push(&c, query[q++], text[t++]);
+        }
+      }
+    }
+  }
+  int nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0, tp = 0, qp = 0;
+  for (int i = 0; i < c.n; i++) {
+    if (c.t[i] != '-' && c.q[i] != '-') {
+      if (g_three[c.t[i]] == g_three[c.q[i]])
+        nMatch++;
+      else
+        nMismatch++;
+      tp++;
+      qp++;
+    } else if (c.t[i] == '-' && c.q[i] != '-') {
+      nIns++;
+      qp++;
+    } else if (c.q[i] == '-' && c.t[i] != '-') {
+      nDel++;
+      tp++;
+    }
+  }
+  float pct = 0;
+  if (tp + qp > 0 && c.n + c.n > 0) pct = (float)((nMatch * 2.0) / (double)(c.n + c.n) * 100);
+  /* ComputeAlignmentScore(string) AlignmentUtils.h:60-124 */
+  int score = 0;
+  for (int i = 0; i < c.n; i++) {
+    if (c.q[i] != '-' && c.t[i] != '-') {
+      score += fn->m[g_three[c.q[i]]][g_three[c.t[i]]];
+    } else if (useAffine) {
+      int gapEnd = i;
+      while (gapEnd < c.n && (c.q[gapEnd] == '-' || c.t[gapEnd] == '-')) ++gapEnd;
+      int gapLength = gapEnd - i;
+      int affineScore = gapLength * fn->affineExtend + fn->affineOpen;
+      int gapScore = (c.q[gapEnd - 1] == '-') ? fn->del * gapLength : fn->ins * gapLength;
+      score += (gapScore < affineScore) ? gapScore : affineScore;
+      i = gapEnd - 1;
+    } else {
+      if (c.q[i] == '-' && c.t[i] != '-')
+        score += fn->del;
+      else if (c.q[i] != '-' && c.t[i] == '-')
+        score += fn->ins;
+      else
+        score += fn->m[4][4];
+    }
+  }
+  a->score = score;
+  a->nMatch = nMatch;
+  a->nMismatch = nMismatch;
+  a->nIns = nIns;
+  a->nDel = nDel;
+  a->pct = pct;
+  free(c.q);
+  free(c.t);
+}
+
+/* ------------------------------------------------------------------------- */
+/* SWAlign, Global mode (SWAlign.h:19-389): boundary del*c / ins*r (:49-64),  */
+/* arrow priority Diagonal, Up, Left (:196-207), traceback (q,t)->(0,0)       */
+/* (:231-238, :324-353).                                                      */
+/* ------------------------------------------------------------------------- */
+static int sw_align_global(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                           const score_fn *fn, aln_t *out) {
+  int nRows = qlen + 1, nCols = tlen + 1;
+  int *S = (int *)calloc((size_t)nRows * nCols, sizeof(int));
+  unsigned char *P = (unsigned char *)malloc((size_t)nRows * nCols);
+  memset(P, A_NONE, (size_t)nRows * nCols);
+  for (int c = 0; c < nCols; c++) {
+    S[c] = fn->del * c;
+    P[c] = A_LEFT;
+  }
+  for (int r = 0; r < nRows; r++) {
+    S[(size_t)r * nCols] = fn->ins * r;
+    P[(size_t)r * nCols] = A_UP;
+  }
+  P[0] = A_DIAG;
+  for (int r = 0; r < qlen; r++)
+    for (int c = 0; c < tlen; c++) {
+      int m = match_score(fn, t[c], q[r]) + S[(size_t)r * nCols + c];
+      int qGap = S[(size_t)r * nCols + c + 1] + fn->ins;
+      int tGap = S[(size_t)(r + 1) * nCols + c] + fn->del;
+      int mn = m < qGap ? m : qGap;
+      if (tGap < mn) mn = tGap;
+      S[(size_t)(r + 1) * nCols + c + 1] = mn;
+      P[(size_t)(r + 1) * nCols + c + 1] = (mn == m) ? A_DIAG : (mn == qGap) ? A_UP : A_LEFT;
+    }
+  int r = qlen, c = tlen, n = 0;
+  unsigned char *path = (unsigned char *)malloc((size_t)qlen + tlen + 2);
+  while (r > 0 || c > 0) {
+    unsigned char a = P[(size_t)r * nCols + c];
+    path[n++] = a;
+    if (a == A_DIAG) {
+      r--;
+      c--;
+    } else if (a == A_UP)
+      r--;
+    else if (a == A_LEFT)
+      c--;
+  }
+  for (int i = 0; i < n / 2; i++) {
+    unsigned char tmp = path[i];
+    path[i] = path[n - 1 - i];
+    path[n - 1 - i] = tmp;
+  }
+  if (n > 0) arrow_path_to_alignment(out, path, n);
+  int score = S[(size_t)qlen * nCols + tlen];
+  free(path);
+  free(S);
+  free(P);
+  return score;
+}
+
+/* ------------------------------------------------------------------------- */
+/* libstdc++ std::sort clone on fragments keyed by (x,y)                      */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t x, y, weight, length;
+  int index, chainPrev, cost, above;
+  uint32_t chainLength;
+} frag_t; /* sdp/SDPFragment.h:5-17 */
+
+static int frag_less_xy(const frag_t *a, const frag_t *b) { /* SDPFragment.h:60-67 */
+  if (a->x < b->x) return 1;
+  if (a->x == b->x) return a->y < b->y;
+  return 0;
+}
+
+static void is_swap(frag_t *a, frag_t *b) {
+  frag_t t = *a;
+  *a = *b;
+  *b = t;
+}
+static void is_adjust_heap(frag_t *first, long hole, long len, frag_t value) {
+  long top = hole, child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (frag_less_xy(&first[child], &first[child - 1])) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;
+  while (hole > top && frag_less_xy(&first[parent], &value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+static void is_heapsort(frag_t *first, frag_t *last) {
+  long len = last - first;
+  if (len >= 2) {
+    long parent = (len - 2) / 2;
+    for (;;) {
+      frag_t v = first[parent];
+      is_adjust_heap(first, parent, len, v);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    frag_t v = *last;
+    *last = *first;
+    is_adjust_heap(first, 0, last - first, v);
+  }
+}
+static void is_median_to_first(frag_t *result, frag_t *a, frag_t *b, frag_t *c) {
+  if (frag_less_xy(a, b)) {
+    if (frag_less_xy(b, c))
+      is_swap(result, b);
+    else if (frag_less_xy(a, c))
+      is_swap(result, c);
+    else
+      is_swap(result, a);
+  } else if (frag_less_xy(a, c))
+    is_swap(result, a);
+  else if (frag_less_xy(b, c))
+    is_swap(result, c);
+  else
+    is_swap(result, b);
+}
+static frag_t *is_partition(frag_t *first, frag_t *last, frag_t *pivot) {
+  for (;;) {
+    while (frag_less_xy(first, pivot)) ++first;
+    --last;
+    while (frag_less_xy(pivot, last)) --last;
+    if (!(first < last)) return first;
+    is_swap(first, last);
+    ++first;
+  }
+}
+static void is_loop(frag_t *first, frag_t *last, long depth) {
+  while (last - first > 16) {
+    if (depth == 0) {
+      is_heapsort(first, last);
+      return;
+    }
+    --depth;
+    frag_t *mid = first + (last - first) / 2;
+    is_median_to_first(first, first + 1, mid, last - 1);
+    frag_t *cut = is_partition(first + 1, last, first);
+    is_loop(cut, last, depth);
+    last = cut;
+  }
+}
+static void is_unguarded_linear_insert(frag_t *last) {
+  frag_t val = *last;
+  frag_t *next = last - 1;
+  while (frag_less_xy(&val, next)) {
+    *last = *next;
+    last = next;
+    --next;
+  }
+  *last = val;
+}
+static void is_insertion_sort(frag_t *first, frag_t *last) {
+  if (first == last) return;
+  for (frag_t *i = first + 1; i != last; ++i) {
+    if (frag_less_xy(i, first)) {
+      frag_t val = *i;
+      memmove(first + 1, first, (size_t)(i - first) * sizeof(frag_t));
+      *first = val;
+    } else
+      is_unguarded_linear_insert(i);
+  }
+}
+static void introsort_frags(frag_t *first, long n) {
+  if (n <= 0) return;
+  frag_t *last = first + n;
+  long lg = 0;
+  for (long m = n; m > 1; m >>= 1) lg++;
+  is_loop(first, last, lg * 2);
+  if (n > 16) {
+    is_insertion_sort(first, first + 16);
+    for (frag_t *i = first + 16; i != last; ++i) is_unguarded_linear_insert(i);
+  } else
+    is_insertion_sort(first, last);
+}
+
+void bo_introsort_xy(int *xyl, int n) {
+  frag_t *f = (frag_t *)calloc(n > 0 ? n : 1, sizeof(frag_t));
+  for (int i = 0; i < n; i++) {
+    f[i].x = xyl[3 * i];
+    f[i].y = xyl[3 * i + 1];
+    f[i].length = xyl[3 * i + 2];
+  }
+  introsort_frags(f, n);
+  for (int i = 0; i < n; i++) {
+    xyl[3 * i] = (int)f[i].x;
+    xyl[3 * i + 1] = (int)f[i].y;
+    xyl[3 * i + 2] = (int)f[i].length;
+  }
+  free(f);
+}
+
+/* ------------------------------------------------------------------------- */
+/* SDPLongestCommonSubsequence (sdp/SparseDynamicProgramming.h:70-322)        */
+/* ------------------------------------------------------------------------- */
+
+/* IndelPenalty (SparseDynamicProgramming.h:27-53) */
+static int indel_penalty(int x1, int y1, int x2, int y2, int insertion, int deletion) {
+  int drift = (x1 - y1) - (x2 - y2);
+  if (drift > 0) return (int)((1.0 * drift) * insertion);
+  if (drift < 0) return (int)((-1.0 * drift) * deletion);
+  return 0;
+}
+
+static int cmp_frag_yx(const void *pa, const void *pb) { /* SDPFragment.h:69-76 */
+  const frag_t *a = (const frag_t *)pa, *b = (const frag_t *)pb;
+  if (a->y != b->y) return a->y < b->y ? -1 : 1;
+  if (a->x != b->x) return a->x < b->x ? -1 : 1;
+  return 0;
+}
+static int cmp_frag_xy(const void *pa, const void *pb) {
+  const frag_t *a = (const frag_t *)pa, *b = (const frag_t *)pb;
+  if (a->x != b->x) return a->x < b->x ? -1 : 1;
+  if (a->y != b->y) return a->y < b->y ? -1 : 1;
+  return 0;
+}
+
+/* The sweep's ordered set (SDPSet<Fragment>, sdp/SDPSet.h) keyed by
+ * Fragment::operator< = (diag = y - x, then x) (SDPFragment.h:78-91); kept as
+ * a sorted array of fragment indices. */
+typedef struct {
+  int *v;
+  int n, cap;
+} iset_t;
+static void iset_insert_at(iset_t *s, int pos, int val) {
+  if (s->n == s->cap) {
+    s->cap = s->cap ? s->cap * 2 : 256;
+    s->v = (int *)realloc(s->v, sizeof(int) * s->cap);
+  }
+  memmove(s->v + pos + 1, s->v + pos, sizeof(int) * (size_t)(s->n - pos));
+  s->v[pos] = val;
+  s->n++;
+}
+static void iset_erase_at(iset_t *s, int pos) {
+  memmove(s->v + pos, s->v + pos + 1, sizeof(int) * (size_t)(s->n - pos - 1));
+  s->n--;
+}
+static int frag_less_diag(const frag_t *a, const frag_t *b) {
+  int da = (int)(a->y - a->x), db = (int)b->y - (int)b->x;
+  if (da < db) return 1;
+  if (da == db) return a->x < b->x;
+  return 0;
+}
+/* first position whose element is not less than f */
+static int sweep_lower_bound(const iset_t *s, const frag_t *F, const frag_t *f) {
+  int lo = 0, hi = s->n;
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    if (frag_less_diag(&F[s->v[mid]], f))
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+/* column set (SDPSet<SDPColumn>, sdp/SDPColumn.h): sorted by col */
+typedef struct {
+  int *col, *opt;
+  int n, cap;
+} cset_t;
+static int cset_lower_bound(const cset_t *s, int col) {
+  int lo = 0, hi = s->n;
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    if (s->col[mid] < col)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+static int sdp_lcs(uint32_t queryLength, frag_t *F, int nF, uint32_t fragmentLength, int insertion,
+                   int deletion, int match, int alignType, int **chainOut) {
+  *chainOut = NULL;
+  if (nF < 1) return 0;
+  qsort(F, nF, sizeof(frag_t), cmp_frag_xy); /* :78 (keys unique -> order unique) */
+  for (int i = 0; i < nF; i++) F[i].index = i;
+  /* StoreAbove :55-68 */
+  qsort(F, nF, sizeof(frag_t), cmp_frag_yx);
+  for (int i = 1; i < nF; i++)
+    if (F[i - 1].x <= F[i].x && F[i - 1].x + F[i - 1].length > F[i].x && F[i - 1].y < F[i].y)
+      F[i].above = F[i - 1].index;
+  qsort(F, nF, sizeof(frag_t), cmp_frag_xy);
+
+  iset_t sweep = {0, 0, 0};
+  cset_t cols = {0, 0, 0, 0};
+  uint32_t sweepRow = F[0].x;
+  int fSweep = 0, fTrail = 0;
+  uint32_t maxChainLength = 0;
+  int maxChainFragment = -1, minFragmentCost = INF_INT, minFragmentIndex = -1;
+  for (; sweepRow < queryLength + fragmentLength; sweepRow++) {
+    int startF = fSweep;
+    while (fSweep < nF && F[fSweep].x == sweepRow) {
+      frag_t *f = &F[fSweep];
+      int cp = INF_INT, cl = INF_INT, ca = INF_INT, foundPrev = 0;
+      int cpFrag = -1, clFrag = -1, aboveIndex = -1;
+      /* colSet.Predecessor: largest column <= f.y (SDPSet.h:94-119) */
+      if (cols.n > 0) {
+        int pos = cset_lower_bound(&cols, (int)f->y);
+        int have = 0;
+        if (pos < cols.n && cols.col[pos] == (int)f->y)
+          have = 1;
+        else if (pos > 0) {
+          pos--;
+          have = 1;
+        }
+        if (have) {
+          cpFrag = cols.opt[pos];
+          const frag_t *p = &F[cpFrag];
+          cp = p->cost + (int)sqrt(abs((int)(f->x + f->y) - (int)(p->x + p->y))) - (int)f->length;
+          foundPrev = 1;
+        }
+      }
+      /* sweepSet.Predecessor: greatest element below (diag,x) */
+      if (sweep.n > 0) {
+        int pos = sweep_lower_bound(&sweep, F, f);
+        if (pos > 0) {
+          clFrag = sweep.v[pos - 1];
+          const frag_t *p = &F[clFrag];
+          int ov = (int)(fragmentLength - (f->y - p->y)) * match;
+          if (ov > 0) ov = 0;
+          cl = p->cost + ov + indel_penalty((int)f->x, (int)f->y, (int)p->x, (int)p->y, insertion, deletion);
+          foundPrev = 1;
+        }
+      }
+      if (f->above >= 0) {
+        aboveIndex = f->above;
+        const frag_t *p = &F[aboveIndex];
+        ca = (int)((uint32_t)p->cost +
+                   (fragmentLength - (uint32_t)(int)(f->y - p->y)) * (uint32_t)match +
+                   (uint32_t)indel_penalty((int)f->x, (int)f->y, (int)p->x, (int)p->y, insertion,
+                                           deletion));
+        foundPrev = 1;
+      }
+      int minCost = cl < ca ? cl : ca;
+      if (cp < minCost) minCost = cp;
+      if (foundPrev && (alignType == BO_GLOBAL || (alignType == BO_LOCAL && minCost < 0))) {
+        f->cost = (int)((uint32_t)minCost - f->weight);
+        if (minCost == cp)
+          f->chainPrev = cpFrag;
+        else if (minCost == cl)
+          f->chainPrev = clFrag;
+        else if (minCost == ca)
+          f->chainPrev = aboveIndex;
+        f->chainLength = F[f->chainPrev].chainLength + 1;
+      } else {
+        f->chainPrev = -1;
+        f->chainLength = 1;
+        if (alignType == BO_GLOBAL)
+          f->cost = (int)((f->x + f->y) * (uint32_t)deletion + fragmentLength * (uint32_t)match - f->weight);
+        else
+          f->cost = (int)(fragmentLength * (uint32_t)match - f->weight);
+      }
+      if (minFragmentCost > f->cost) {
+        minFragmentCost = f->cost;
+        minFragmentIndex = fSweep;
+      }
+      if (f->chainLength > maxChainLength) {
+        maxChainLength = f->chainLength;
+        maxChainFragment = fSweep;
+      }
+      fSweep++;
+    }
+    for (int i = startF; i < fSweep; i++) {
+      int pos = sweep_lower_bound(&sweep, F, &F[i]);
+      iset_insert_at(&sweep, pos, i);
+    }
+    if (sweepRow >= fragmentLength + 1) {
+      uint32_t trailRow = sweepRow - fragmentLength - 1;
+      while (fTrail < nF && F[fTrail].x == trailRow) {
+        frag_t *f = &F[fTrail];
+        int pos = cset_lower_bound(&cols, (int)f->y);
+        int member = (pos < cols.n && cols.col[pos] == (int)f->y);
+        int store = 0;
+        if (member) {
+          if (F[cols.opt[pos]].cost < f->cost) store = 1; /* :260-267, sic */
+        } else
+          store = 1;
+        if (store) {
+          if (member)
+            cols.opt[pos] = fTrail;
+          else {
+            if (cols.n == cols.cap) {
+              cols.cap = cols.cap ? cols.cap * 2 : 256;
+              cols.col = (int *)realloc(cols.col, sizeof(int) * cols.cap);
+              cols.opt = (int *)realloc(cols.opt, sizeof(int) * cols.cap);
+            }
+            memmove(cols.col + pos + 1, cols.col + pos, sizeof(int) * (size_t)(cols.n - pos));
+            memmove(cols.opt + pos + 1, cols.opt + pos, sizeof(int) * (size_t)(cols.n - pos));
+            cols.col[pos] = (int)f->y;
+            cols.opt[pos] = fTrail;
+            cols.n++;
+          }
+          /* Successor needs size >= 2 (SDPSet.h:72-87); delete costlier ones */
+          int del = 0;
+          while (cols.n - del >= 2 && pos + 1 + del < cols.n && F[cols.opt[pos + 1 + del]].cost > f->cost)
+            del++;
+          if (del) {
+            memmove(cols.col + pos + 1, cols.col + pos + 1 + del, sizeof(int) * (size_t)(cols.n - pos - 1 - del));
+            memmove(cols.opt + pos + 1, cols.opt + pos + 1 + del, sizeof(int) * (size_t)(cols.n - pos - 1 - del));
+            cols.n -= del;
+          }
+        }
+        int sp = sweep_lower_bound(&sweep, F, f);
+        if (sp < sweep.n && sweep.v[sp] == fTrail) iset_erase_at(&sweep, sp);
+        ++fTrail;
+      }
+    }
+  }
+  if (alignType == BO_LOCAL) maxChainFragment = minFragmentIndex;
+  int n = 0, cap = 64;
+  int *chain = (int *)malloc(sizeof(int) * cap);
+  while (maxChainFragment != -1) {
+    if (n == cap) {
+      cap *= 2;
+      chain = (int *)realloc(chain, sizeof(int) * cap);
+    }
+    chain[n++] = maxChainFragment;
+    maxChainFragment = F[maxChainFragment].chainPrev;
+  }
+  for (int i = 0; i < n / 2; i++) {
+    int tmp = chain[i];
+    chain[i] = chain[n - 1 - i];
+    chain[n - 1 - i] = tmp;
+  }
+  free(sweep.v);
+  free(cols.col);
+  free(cols.opt);
+  *chainOut = chain;
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Tuples (tuples/DNATuple.h:308-359, TupleList.h:98-126, TupleMatching.h:37-61)*/
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t tuple;
+  uint32_t pos;
+} ptuple_t;
+static int cmp_ptuple(const void *pa, const void *pb) { /* DNATuple.h:147-154 */
+  const ptuple_t *a = (const ptuple_t *)pa, *b = (const ptuple_t *)pb;
+  if (a->tuple != b->tuple) return a->tuple < b->tuple ? -1 : 1;
+  if (a->pos != b->pos) return a->pos < b->pos ? -1 : 1;
+  return 0;
+}
+/* all k-mers whose k bases are ACGT; first base in the least-significant bits */
+static int sequence_to_tuple_list(const unsigned char *s, uint32_t n, int k, ptuple_t **out) {
+  ptuple_t *v = (ptuple_t *)malloc(sizeof(ptuple_t) * (n ? n : 1));
+  int cnt = 0;
+  if (k >= 1 && n >= (uint32_t)k) {
+    uint32_t run = 0;
+    uint64_t tup = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (g_isactg[s[i]]) {
+        run++;
+        tup >>= 2;
+        tup += ((uint64_t)g_two[s[i]]) << (2 * (k - 1));
+        if (run >= (uint32_t)k) {
+          v[cnt].tuple = tup;
+          v[cnt].pos = i + 1 - k;
+          cnt++;
+        }
+      } else {
+        run = 0;
+        tup = 0;
+      }
+    }
+  }
+  *out = v;
+  return cnt;
+}
+
+typedef struct {
+  frag_t *v;
+  int n, cap;
+} fvec_t;
+static void fvec_push(fvec_t *fv, uint32_t x, uint32_t y, uint32_t weight, uint32_t length) {
+  if (fv->n == fv->cap) {
+    fv->cap = fv->cap ? fv->cap * 2 : 1024;
+    fv->v = (frag_t *)realloc(fv->v, sizeof(frag_t) * fv->cap);
+  }
+  frag_t *f = &fv->v[fv->n++];
+  memset(f, 0, sizeof(*f));
+  f->x = x;
+  f->y = y;
+  f->weight = weight;
+  f->length = length;
+  f->above = -1;
+}
+
+/* StoreMatchingPositions (TupleMatching.h:37-61): note ThreeBit (not IsACTG)
+ * decides k-mer validity on the query side; identical on ACGTN input. */
+static void store_matching_positions(const unsigned char *qs, uint32_t qn, int k, const ptuple_t *tl,
+                                     int tn, int maxMatches, uint32_t xOff, uint32_t yOff,
+                                     uint32_t weight, uint32_t length, fvec_t *out) {
+  if (k < 1 || qn < (uint32_t)k) return;
+  uint32_t run = 0;
+  uint64_t tup = 0;
+  for (uint32_t i = 0; i < qn; i++) {
+    if (g_three[qs[i]] <= 3) {
+      run++;
+      tup >>= 2;
+      tup += ((uint64_t)g_two[qs[i]]) << (2 * (k - 1));
+      if (run >= (uint32_t)k) {
+        uint32_t s = i + 1 - k;
+        int lo = 0, hi = tn;
+        while (lo < hi) {
+          int mid = (lo + hi) / 2;
+          if (tl[mid].tuple < tup)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        int end = lo;
+        while (end < tn && tl[end].tuple == tup) end++;
+        if (maxMatches == 0 || end - lo <= maxMatches)
+          for (int j = lo; j < end; j++) fvec_push(out, s + xOff, tl[j].pos + yOff, weight, length);
+      }
+    } else {
+      run = 0;
+      tup = 0;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* SDPAlign (SDPAlign.h:95-626)                                               */
+/* ------------------------------------------------------------------------- */
+#define SDP_DETAILED_WORD_SIZE 5 /* SDPAlign.h:19 */
+
+static uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+static int sdp_align(const unsigned char *query, uint32_t qLen, const unsigned char *target,
+                     uint32_t tLen, const score_fn *fn, int wordSize, int sdpIns, int sdpDel,
+                     float indelRate, aln_t *alignment, int alignType, int detailed,
+                     int extendFront, int sdpPrefixLength, int recurse, int noRecurseUnder,
+                     int maxMatchesPerPosition) {
+  int smallWordSize = wordSize < SDP_DETAILED_WORD_SIZE ? wordSize : SDP_DETAILED_WORD_SIZE;
+  /* :148-182 prefix / whole / suffix partition */
+  uint32_t prefixLength = umin(tLen, (uint32_t)sdpPrefixLength);
+  uint32_t suffixLength = umin(tLen - prefixLength, (uint32_t)sdpPrefixLength);
+  uint32_t middleLength = tLen - prefixLength - suffixLength;
+  uint32_t suffixPos = prefixLength + middleLength;
+  uint32_t qPrefixLength = umin(qLen, (uint32_t)sdpPrefixLength);
+  uint32_t qSuffixLength = umin(qLen - qPrefixLength, (uint32_t)sdpPrefixLength);
+  uint32_t qMiddleLength = qLen - qPrefixLength - qSuffixLength;
+  uint32_t qSuffixPos = qPrefixLength + qMiddleLength;
+
+  ptuple_t *tp, *tsf, *tm;
+  int ntp = sequence_to_tuple_list(target, prefixLength, smallWordSize, &tp);
+  int nts = sequence_to_tuple_list(target + suffixPos, suffixLength, smallWordSize, &tsf);
+  int ntm = sequence_to_tuple_list(target, tLen, wordSize, &tm);
+  qsort(tp, ntp, sizeof(ptuple_t), cmp_ptuple);
+  qsort(tsf, nts, sizeof(ptuple_t), cmp_ptuple);
+  qsort(tm, ntm, sizeof(ptuple_t), cmp_ptuple);
+
+  /* :200-242: prefix, middle, suffix fragments concatenated in that order */
+  fvec_t fr = {0, 0, 0};
+  store_matching_positions(query, qPrefixLength, smallWordSize, tp, ntp, maxMatchesPerPosition, 0, 0,
+                           wordSize, smallWordSize, &fr);
+  store_matching_positions(query, qLen, wordSize, tm, ntm, maxMatchesPerPosition, 0, 0, wordSize,
+                           wordSize, &fr);
+  store_matching_positions(query + qSuffixPos, qSuffixLength, smallWordSize, tsf, nts,
+                           maxMatchesPerPosition, qSuffixPos, suffixPos, wordSize, smallWordSize, &fr);
+  free(tp);
+  free(tsf);
+  free(tm);
+
+  /* :256-269 std::sort + keep first of each (x,y) */
+  introsort_frags(fr.v, fr.n);
+  {
+    int f = 0, cur = 0;
+    while (f + 1 <= fr.n) {
+      fr.v[cur] = fr.v[f];
+      while (f < fr.n && fr.v[cur].x == fr.v[f].x && fr.v[cur].y == fr.v[f].y) f++;
+      cur++;
+    }
+    fr.n = cur;
+  }
+  alignment->qPos = 0;
+  alignment->tPos = 0;
+  if (fr.n == 0) {
+    free(fr.v);
+    return 0;
+  }
+  int *chain;
+  int nChain = sdp_lcs(qLen, fr.v, fr.n, (uint32_t)wordSize, sdpIns, sdpDel, fn->m[0][0], alignType, &chain);
+
+  /* :308-335 merge +1/+1 runs into blocks */
+  block_t *cb = (block_t *)malloc(sizeof(block_t) * (nChain ? nChain : 1));
+  int ncb = 0;
+  for (int f = 0; f < nChain; f++) {
+    int startF = f;
+    while (f < nChain - 1 && fr.v[chain[f]].x == fr.v[chain[f + 1]].x - 1 &&
+           fr.v[chain[f]].y == fr.v[chain[f + 1]].y - 1)
+      f++;
+    cb[ncb].q = fr.v[chain[startF]].x;
+    cb[ncb].t = fr.v[chain[startF]].y;
+    cb[ncb].len = fr.v[chain[f]].x + fr.v[chain[f]].length - fr.v[chain[startF]].x;
+    ncb++;
+  }
+  free(chain);
+  free(fr.v);
+  /* :349-357 trim overlaps */
+  for (int b = 0; b + 1 < ncb; b++) {
+    if (cb[b].q + cb[b].len > cb[b + 1].q) cb[b].len = cb[b + 1].q - cb[b].q;
+    if (cb[b].t + cb[b].len > cb[b + 1].t) cb[b].len = cb[b + 1].t - cb[b].t;
+  }
+  /* :372-413 drop zero-length and off-diagonal blocks */
+  unsigned char *good = (unsigned char *)malloc(ncb ? ncb : 1);
+  for (int b = 0; b < ncb; b++) good[b] = cb[b].len != 0;
+  for (int b = 1; b + 1 < ncb; b++) {
+    int prevDiag = abs(((int)cb[b].t - (int)cb[b].q) - ((int)cb[b - 1].t - (int)cb[b - 1].q));
+    int prevDist = (int)umin(cb[b].t - cb[b - 1].t, cb[b].q - cb[b - 1].q);
+    int nextDiag = abs(((int)cb[b + 1].t - (int)cb[b + 1].q) - ((int)cb[b].t - (int)cb[b].q));
+    int nextDist = (int)umin(cb[b + 1].t - cb[b].t, cb[b + 1].q - cb[b].q);
+    if (prevDist * indelRate < prevDiag && nextDist * indelRate < nextDiag) good[b] = 0;
+  }
+  {
+    int w = 0;
+    for (int b = 0; b < ncb; b++)
+      if (good[b]) cb[w++] = cb[b];
+    ncb = w;
+  }
+  free(good);
+
+  if (ncb > 0) {
+    /* :423-474 front fill */
+    if (cb[0].q > 0 && cb[0].t > 0 && (alignType == BO_GLOBAL || extendFront)) {
+      uint32_t fq = cb[0].q, ft = cb[0].t;
+      aln_t front;
+      aln_init(&front);
+      if (recurse == 0 && fq * ft < (uint32_t)noRecurseUnder)
+        sw_align_global(query, (int)fq, target, (int)ft, fn, &front);
+      else if (recurse != 0)
+        /* :445-456: smithWatermanAlignType (EndAnchored = 6) lands in the
+         * maxMatchesPerPosition slot */
+        sdp_align(query, fq, target, ft, fn, wordSize - 4 > 5 ? wordSize - 4 : 5, sdpIns, sdpDel,
+                  indelRate, &front, BO_GLOBAL, detailed, extendFront, sdpPrefixLength, recurse - 1,
+                  noRecurseUnder, BO_END_ANCHORED);
+      for (int i = 0; i < front.nBlocks; i++) {
+        block_t b = front.blocks[i];
+        b.t += front.tPos;
+        b.q += front.qPos;
+        aln_push_block(alignment, b);
+      }
+      aln_free(&front);
+    }
+    /* :481-536 between consecutive blocks */
+    for (int b = 0; b + 1 < ncb; b++) {
+      aln_push_block(alignment, cb[b]);
+      uint32_t qOff = cb[b].q + cb[b].len, tOff = cb[b].t + cb[b].len;
+      uint32_t fq = cb[b + 1].q - qOff, ft = cb[b + 1].t - tOff;
+      if (fq > 0 && ft > 0 && detailed) {
+        aln_t frag;
+        aln_init(&frag);
+        if (fq * ft < (uint32_t)noRecurseUnder)
+          sw_align_global(query + qOff, (int)fq, target + tOff, (int)ft, fn, &frag);
+        else if (recurse != 0)
+          sdp_align(query + qOff, fq, target + tOff, ft, fn, wordSize - 4 > 5 ? wordSize - 4 : 5,
+                    sdpIns, sdpDel, indelRate, &frag, BO_GLOBAL, detailed, 0, 0, recurse - 1,
+                    noRecurseUnder, 0);
+        for (int i = 0; i < frag.nBlocks; i++) {
+          block_t nb = frag.blocks[i];
+          nb.q += qOff;
+          nb.t += tOff;
+          aln_push_block(alignment, nb);
+        }
+        aln_free(&frag);
+      }
+    }
+    /* :537-600 last block; tail fill only when extendFront */
+    if (alignType == BO_GLOBAL || alignType == BO_LOCAL) {
+      int last = ncb - 1;
+      aln_push_block(alignment, cb[last]);
+      if (alignType == BO_GLOBAL || extendFront) {
+        uint32_t qOff = cb[last].q + cb[last].len, tOff = cb[last].t + cb[last].len;
+        uint32_t fq = qLen - qOff, ft = tLen - tOff;
+        if (fq > 0 && ft > 0 && extendFront) {
+          aln_t frag;
+          aln_init(&frag);
+          if (recurse == 0 && fq * ft < (uint32_t)noRecurseUnder)
+            sw_align_global(query + qOff, (int)fq, target + tOff, (int)ft, fn, &frag);
+          else if (recurse != 0)
+            sdp_align(query + qOff, fq, target + tOff, ft, fn, wordSize / 2 > 5 ? wordSize / 2 : 5,
+                      sdpIns, sdpDel, indelRate, &frag, BO_GLOBAL, detailed, extendFront,
+                      sdpPrefixLength, recurse - 1, noRecurseUnder, maxMatchesPerPosition);
+          for (int i = 0; i < frag.nBlocks; i++) {
+            block_t nb = frag.blocks[i];
+            nb.q += qOff;
+            nb.t += tOff;
+            aln_push_block(alignment, nb);
+          }
+          aln_free(&frag);
+        }
+      }
+    }
+  }
+  free(cb);
+  /* :602-610 */
+  if (alignType == BO_LOCAL && alignment->nBlocks > 0) {
+    alignment->tPos = alignment->blocks[0].t;
+    alignment->qPos = alignment->blocks[0].q;
+    for (int b = 0; b < alignment->nBlocks; b++) {
+      alignment->blocks[b].q -= alignment->qPos;
+      alignment->blocks[b].t -= alignment->tPos;
+    }
+  }
+  /* :624 ComputeAlignmentScore(alignment, ...) (AlignmentUtils.h:127-169), no gap lists */
+  int score = 0;
+  for (int b = 0; b < alignment->nBlocks; b++) {
+    uint32_t q = alignment->qPos + alignment->blocks[b].q, t = alignment->tPos + alignment->blocks[b].t;
+    for (uint32_t l = 0; l < alignment->blocks[b].len; l++, q++, t++)
+      score += match_score(fn, target[t], query[q]);
+  }
+  return score;
+}
+
+/* ------------------------------------------------------------------------- */
+/* AlignmentToGuide (GuidedAlign.h:104-259), StoreMatrixOffsets (:94-101)     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int q, t, tPre, tPost;
+  unsigned int matrixOffset;
+} guide_row;
+
+static int imin(int a, int b) { return a < b ? a : b; }
+
+static int alignment_to_guide(const block_t *blocks, int nBlocks, int bandSize, guide_row **out) {
+  *out = NULL;
+  if (nBlocks == 0) return 0;
+  int tStart = (int)blocks[0].t, qStart = (int)blocks[0].q;
+  int qEnd = (int)(blocks[nBlocks - 1].q + blocks[nBlocks - 1].len);
+  int n = qEnd - qStart + 1;
+  guide_row *g = (guide_row *)calloc(n, sizeof(guide_row));
+  g[0].t = tStart - 1;
+  g[0].q = qStart - 1;
+  int drift = abs(tStart - qStart);
+  g[0].tPost = drift > bandSize ? drift : bandSize;
+  g[0].tPre = 0;
+  int gi = 1;
+  for (int b = 0; b < nBlocks; b++) {
+    for (uint32_t bp = 0; bp < blocks[b].len; bp++) {
+      g[gi].t = (int)(blocks[b].t + bp);
+      g[gi].q = (int)(blocks[b].q + bp);
+      int reach = g[gi].t - (g[gi - 1].t - g[gi - 1].tPre);
+      if (bp == 0) {
+        g[gi].tPre = reach;
+        g[gi].tPost = bandSize + abs(drift);
+      } else {
+        g[gi].tPre = imin(bandSize, reach);
+        g[gi].tPost = imin(MAX_BAND_SIZE, bandSize);
+      }
+      gi++;
+    }
+    if (b < nBlocks - 1) {
+      int qGap = (int)(blocks[b + 1].q - (blocks[b].q + blocks[b].len));
+      int tGap = (int)(blocks[b + 1].t - (blocks[b].t + blocks[b].len));
+      /* ComputeDrift (AlignmentUtils.h:586-600) */
+      {
+        int tg = tGap, qg = qGap, common = 0;
+        if (tg > 0 && qg > 0) common = abs(tg - qg);
+        tg -= common;
+        qg -= common;
+        drift = tg - qg;
+      }
+      int diagonalLength = imin(qGap, tGap);
+      int qPos = (int)(blocks[b].q + blocks[b].len), tPos = (int)(blocks[b].t + blocks[b].len);
+      int qE = (int)blocks[b + 1].q;
+      for (int d = 0; d < diagonalLength; d++, tPos++, qPos++) {
+        g[gi].t = tPos;
+        g[gi].q = qPos;
+        g[gi].tPre = imin(MAX_BAND_SIZE, g[gi].t - (g[gi - 1].t - g[gi - 1].tPre));
+        g[gi].tPost = imin(MAX_BAND_SIZE, bandSize + abs(drift));
+        gi++;
+      }
+      while (qPos < qE) {
+        g[gi].t = tPos;
+        g[gi].q = qPos;
+        qPos++;
+        g[gi].tPre = imin(MAX_BAND_SIZE, g[gi].t - (g[gi - 1].t - g[gi - 1].tPre));
+        g[gi].tPost = imin(MAX_BAND_SIZE, bandSize + abs(drift));
+        gi++;
+      }
+    }
+  }
+  unsigned int cur = 0;
+  for (int r = 0; r < n; r++) {
+    g[r].matrixOffset = g[r].tPre + cur;
+    cur += (unsigned)(g[r].tPre + g[r].tPost + 1);
+  }
+  *out = g;
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* AffineGuidedAlign (AffineGuidedAlign.h:31-488)                             */
+/* ------------------------------------------------------------------------- */
+static int cell_index(const guide_row *g, int nRows, int row, int col) {
+  /* GetBufferIndexFunctor (GuidedAlign.h:45-79) without the "index++"
+   * shortcut: a cell exists iff col lies in the row's [t-tPre, t+tPost]. */
+  if (row < 0 || row >= nRows) return -1;
+  if (col <= g[row].t && g[row].t - col <= g[row].tPre) return (int)g[row].matrixOffset - (g[row].t - col);
+  if (col > g[row].t && col - g[row].t <= g[row].tPost) return (int)g[row].matrixOffset + (col - g[row].t);
+  return -1;
+}
+
+static int affine_guided_align(const unsigned char *qSeq, const unsigned char *tSeq,
+                               const block_t *guideBlocks, int nGuideBlocks, const score_fn *fn,
+                               int bandSize, aln_t *alignment) {
+  guide_row *g;
+  int nRows = alignment_to_guide(guideBlocks, nGuideBlocks, bandSize, &g);
+  if (nRows == 0) return 0;
+  long nElem = 0;
+  for (int r = 0; r < nRows; r++) nElem += g[r].tPre + g[r].tPost + 1;
+  int *S = (int *)calloc(nElem, sizeof(int));
+  int *I = (int *)malloc(nElem * sizeof(int));
+  int *D = (int *)malloc(nElem * sizeof(int));
+  unsigned char *PS = (unsigned char *)malloc(nElem), *PI = (unsigned char *)malloc(nElem),
+                *PD = (unsigned char *)malloc(nElem);
+  for (long i = 0; i < nElem; i++) {
+    I[i] = D[i] = fn->affineOpen; /* :107-116, sic: open, not infinity */
+    PS[i] = PI[i] = PD[i] = A_NONE;
+  }
+  int qStart = g[1].q, tStart = g[1].t;
+  int qEnd = g[nRows - 1].q + 1, tEnd = g[nRows - 1].t + 1;
+  /* :166-208 corner + deletion row */
+  {
+    int c0 = cell_index(g, nRows, 0, tStart - 1);
+    S[c0] = 0;
+    PS[c0] = A_NONE;
+    for (int t = tStart; t < tStart + g[0].tPost; t++) {
+      int cur = cell_index(g, nRows, 0, t), del = cell_index(g, nRows, 0, t - 1);
+      if (del >= 0) {
+        S[cur] = S[del] + fn->del;
+        D[cur] = fn->affineOpen;
+        PD[cur] = A_DEL_OPEN;
+        I[cur] = fn->affineOpen;
+        PI[cur] = A_INS_OPEN;
+        PS[cur] = A_LEFT;
+      }
+    }
+  }
+  /* :213-235 (stripe initialisation) is overwritten by the main loop below with
+   * values computed from the same predecessors, so it is not restated. */
+  for (int q = qStart; q < qEnd; q++) {
+    int qi = q - qStart + 1;
+    for (int t = g[qi].t - g[qi].tPre; t < g[qi].t + g[qi].tPost + 1; t++) {
+      if (t < -1) continue;
+      if (t >= tEnd) continue;
+      int mi = cell_index(g, nRows, qi - 1, t - 1), ii = cell_index(g, nRows, qi - 1, t),
+          di = cell_index(g, nRows, qi, t - 1), cur = cell_index(g, nRows, qi, t);
+      int matchScore = INF_INT, insScore = INF_INT, insExt = INF_INT, delScore = INF_INT, delExt = INF_INT;
+      if (mi >= 0) matchScore = S[mi] + match_score(fn, tSeq[t], qSeq[q]);
+      if (ii >= 0) {
+        insScore = S[ii] + fn->ins;
+        insExt = I[ii] + fn->affineExtend;
+      }
+      if (di >= 0) {
+        delScore = S[di] + fn->del;
+        delExt = D[di] + fn->affineExtend;
+      }
+      int mn = matchScore;
+      if (insScore < mn) mn = insScore;
+      if (delScore < mn) mn = delScore;
+      if (insExt < mn) mn = insExt;
+      if (delExt < mn) mn = delExt;
+      S[cur] = mn;
+      if (mn == INF_INT)
+        PS[cur] = A_NONE;
+      else if (mn == matchScore)
+        PS[cur] = A_DIAG;
+      else if (mn == delScore)
+        PS[cur] = A_LEFT;
+      else if (mn == insScore)
+        PS[cur] = A_UP;
+      else if (mn == insExt)
+        PS[cur] = A_INS_CLOSE;
+      else
+        PS[cur] = A_DEL_CLOSE;
+      int openScore = (int)((unsigned)mn + (unsigned)fn->affineOpen);
+      if (openScore < insExt) {
+        PI[cur] = A_INS_OPEN;
+        I[cur] = openScore;
+      } else {
+        PI[cur] = A_INS_UP;
+        I[cur] = insExt;
+      }
+      if (openScore < delExt) {
+        PD[cur] = A_DEL_OPEN;
+        D[cur] = openScore;
+      } else {
+        PD[cur] = A_DEL_LEFT;
+        D[cur] = delExt;
+      }
+    }
+  }
+  /* :377-468 traceback */
+  int q = qEnd - 1, t = tEnd - 1, n = 0, ok = 1;
+  enum { M_MATCH, M_INS, M_DEL } cur = M_MATCH;
+  unsigned char *path = (unsigned char *)malloc((size_t)(qEnd - qStart) + (tEnd - tStart) + 4);
+  while (q >= qStart || t >= tStart) {
+    int idx = cell_index(g, nRows, q - qStart + 1, t);
+    if (idx < 0) {
+      ok = 0;
+      break;
+    }
+    if (cur == M_MATCH) {
+      unsigned char a = PS[idx];
+      if (a == A_DIAG) {
+        path[n++] = A_DIAG;
+        q--;
+        t--;
+      } else if (a == A_UP) {
+        path[n++] = A_UP;
+        q--;
+      } else if (a == A_LEFT) {
+        path[n++] = A_LEFT;
+        t--;
+      } else if (a == A_INS_CLOSE) {
+        path[n++] = A_UP;
+        cur = M_INS;
+        q--;
+      } else if (a == A_DEL_CLOSE) {
+        t--;
+        path[n++] = A_LEFT;
+        cur = M_DEL;
+      } else {
+        ok = 0;
+        break;
+      }
+    } else if (cur == M_INS) {
+      unsigned char a = PI[idx];
+      if (a == A_INS_OPEN)
+        cur = M_MATCH;
+      else if (a == A_INS_UP) {
+        q--;
+        path[n++] = A_UP;
+      } else {
+        ok = 0;
+        break;
+      }
+    } else {
+      unsigned char a = PD[idx];
+      if (a == A_DEL_OPEN)
+        cur = M_MATCH;
+      else if (a == A_DEL_LEFT) {
+        t--;
+        path[n++] = A_LEFT;
+      } else {
+        ok = 0;
+        break;
+      }
+    }
+  }
+  for (int i = 0; i < n / 2; i++) {
+    unsigned char tmp = path[i];
+    path[i] = path[n - 1 - i];
+    path[n - 1 - i] = tmp;
+  }
+  alignment->nCells = (int)nElem;
+  alignment->qPos = qStart;
+  alignment->tPos = tStart;
+  arrow_path_to_alignment(alignment, path, n);
+  remove_prefix_gaps(alignment);
+  int last = cell_index(g, nRows, qEnd - 1 - qStart + 1, tEnd - 1);
+  int score = last >= 0 ? S[last] : 0;
+  alignment->score = score;
+  free(path);
+  free(S);
+  free(I);
+  free(D);
+  free(PS);
+  free(PI);
+  free(PD);
+  free(g);
+  return ok ? score : INT_MIN;
+}
+
+/* ------------------------------------------------------------------------- */
+/* flat-array entry points                                                    */
+/* ------------------------------------------------------------------------- */
+static int flatten(const aln_t *a, int *blocks, int blockCap, int *nBlocks, int *gapCounts,
+                   int gapListCap, int *nGapLists, int *gapItems, int gapItemCap, int *nGapItems) {
+  *nBlocks = a->nBlocks;
+  if (a->nBlocks > blockCap) return -1;
+  for (int b = 0; b < a->nBlocks; b++) {
+    blocks[3 * b] = (int)a->blocks[b].q;
+    blocks[3 * b + 1] = (int)a->blocks[b].t;
+    blocks[3 * b + 2] = (int)a->blocks[b].len;
+  }
+  if (nGapLists) {
+    *nGapLists = a->nGaps;
+    if (a->nGaps > gapListCap) return -2;
+    int n = 0;
+    for (int g = 0; g < a->nGaps; g++) {
+      gapCounts[g] = a->gaps[g].n;
+      for (int i = 0; i < a->gaps[g].n; i++) {
+        if (n >= gapItemCap) return -3;
+        gapItems[2 * n] = a->gaps[g].g[i].seq;
+        gapItems[2 * n + 1] = a->gaps[g].g[i].len;
+        n++;
+      }
+    }
+    *nGapItems = n;
+  }
+  return 0;
+}
+
+static void unflatten(aln_t *a, int qPos, int tPos, const int *blocks, int nBlocks,
+                      const int *gapCounts, int nGapLists, const int *gapItems) {
+  aln_init(a);
+  a->qPos = qPos;
+  a->tPos = tPos;
+  for (int b = 0; b < nBlocks; b++) {
+    block_t bl = {(uint32_t)blocks[3 * b], (uint32_t)blocks[3 * b + 1], (uint32_t)blocks[3 * b + 2]};
+    aln_push_block(a, bl);
+  }
+  int n = 0;
+  for (int g = 0; g < nGapLists; g++) {
+    gaplist_t *gl = aln_push_gaplist(a);
+    for (int i = 0; i < gapCounts[g]; i++) {
+      gaplist_push(gl, gapItems[2 * n], gapItems[2 * n + 1]);
+      n++;
+      gl = &a->gaps[g];
+    }
+  }
+}
+
+int bo_sdp_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                 const int *matrix25, int ins, int del, int affOpen, int affExt, int wordSize,
+                 int sdpIns, int sdpDel, float indelRate, int alignType, int detailed,
+                 int extendFront, int sdpPrefixLength, int recurse, int noRecurseUnder,
+                 int maxPerPos, int *outQPos, int *outTPos, int *blocks, int blockCap,
+                 int *nBlocks) {
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, affOpen, affExt);
+  aln_t a;
+  aln_init(&a);
+  int score = sdp_align(q, (uint32_t)qlen, t, (uint32_t)tlen, &fn, wordSize, sdpIns, sdpDel,
+                        indelRate, &a, alignType, detailed, extendFront, sdpPrefixLength, recurse,
+                        noRecurseUnder, maxPerPos);
+  *outQPos = (int)a.qPos;
+  *outTPos = (int)a.tPos;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, 0, 0, 0, 0, 0, 0);
+  aln_free(&a);
+  return rc ? INT_MIN : score;
+}
+
+int bo_sdp_chain(int queryLength, const int *xyl, int nFrag, int fragmentLength, int ins, int del,
+                 int match, int alignType, int *chain, int cap) {
+  init_tables();
+  frag_t *F = (frag_t *)calloc(nFrag > 0 ? nFrag : 1, sizeof(frag_t));
+  for (int i = 0; i < nFrag; i++) {
+    F[i].x = xyl[3 * i];
+    F[i].y = xyl[3 * i + 1];
+    F[i].length = xyl[3 * i + 2];
+    F[i].weight = fragmentLength;
+    F[i].above = -1;
+  }
+  int *c;
+  int n = sdp_lcs((uint32_t)queryLength, F, nFrag, (uint32_t)fragmentLength, ins, del, match, alignType, &c);
+  for (int i = 0; i < n && i < cap; i++) chain[i] = c[i];
+  free(c);
+  free(F);
+  return n;
+}
+
+int bo_sw_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                const int *matrix25, int ins, int del, int alignType, int *outQPos, int *outTPos,
+                int *blocks, int blockCap, int *nBlocks) {
+  if (alignType != BO_GLOBAL) return INT_MIN;
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, 0, 0);
+  aln_t a;
+  aln_init(&a);
+  int score = sw_align_global(q, qlen, t, tlen, &fn, &a);
+  *outQPos = (int)a.qPos;
+  *outTPos = (int)a.tPos;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, 0, 0, 0, 0, 0, 0);
+  aln_free(&a);
+  return rc ? INT_MIN : score;
+}
+
+int bo_alignment_to_guide(const int *blocks, int nBlocks, int bandSize, int *rows, int rowCap,
+                          int *nCells) {
+  block_t *b = (block_t *)malloc(sizeof(block_t) * (nBlocks ? nBlocks : 1));
+  for (int i = 0; i < nBlocks; i++) {
+    b[i].q = blocks[3 * i];
+    b[i].t = blocks[3 * i + 1];
+    b[i].len = blocks[3 * i + 2];
+  }
+  guide_row *g;
+  int n = alignment_to_guide(b, nBlocks, bandSize, &g);
+  int cells = 0;
+  for (int r = 0; r < n; r++) {
+    cells += g[r].tPre + g[r].tPost + 1;
+    if (r < rowCap) {
+      rows[5 * r] = g[r].q;
+      rows[5 * r + 1] = g[r].t;
+      rows[5 * r + 2] = g[r].tPre;
+      rows[5 * r + 3] = g[r].tPost;
+      rows[5 * r + 4] = (int)g[r].matrixOffset;
+    }
+  }
+  *nCells = cells;
+  free(g);
+  free(b);
+  return n;
+}
+
+int bo_affine_guided_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                           const int *guideBlocks, int nGuideBlocks, const int *matrix25, int ins,
+                           int del, int affOpen, int affExt, int bandSize, int *outQPos,
+                           int *outTPos, int *blocks, int blockCap, int *nBlocks, int *gapCounts,
+                           int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                           int *nGapItems, int *stats, float *pct) {
+  (void)qlen;
+  (void)tlen;
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, affOpen, affExt);
+  block_t *gb = (block_t *)malloc(sizeof(block_t) * (nGuideBlocks ? nGuideBlocks : 1));
+  for (int i = 0; i < nGuideBlocks; i++) {
+    gb[i].q = guideBlocks[3 * i];
+    gb[i].t = guideBlocks[3 * i + 1];
+    gb[i].len = guideBlocks[3 * i + 2];
+  }
+  aln_t a;
+  aln_init(&a);
+  int dp = affine_guided_align(q, t, gb, nGuideBlocks, &fn, bandSize, &a);
+  free(gb);
+  stats[0] = dp;
+  stats[1] = a.nCells;
+  compute_alignment_stats(&a, q, t, &fn, 1);
+  stats[2] = a.score;
+  stats[3] = a.nMatch;
+  stats[4] = a.nMismatch;
+  stats[5] = a.nIns;
+  stats[6] = a.nDel;
+  *pct = a.pct;
+  *outQPos = (int)a.qPos;
+  *outTPos = (int)a.tPos;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+  aln_free(&a);
+  return rc;
+}
+
+void bo_compute_alignment_stats(const unsigned char *q, const unsigned char *t, int qPos, int tPos,
+                                const int *blocks, int nBlocks, const int *gapCounts,
+                                int nGapLists, const int *gapItems, const int *matrix25, int ins,
+                                int del, int affOpen, int affExt, int useAffine, int *stats,
+                                float *pct) {
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, affOpen, affExt);
+  aln_t a;
+  unflatten(&a, qPos, tPos, blocks, nBlocks, gapCounts, nGapLists, gapItems);
+  compute_alignment_stats(&a, q, t, &fn, useAffine);
+  stats[0] = a.score;
+  stats[1] = a.nMatch;
+  stats[2] = a.nMismatch;
+  stats[3] = a.nIns;
+  stats[4] = a.nDel;
+  *pct = a.pct;
+  aln_free(&a);
+}
+
+/* AlignIntervals' SDP step (Blasr.cpp:1716-1724) followed by RefineAlignment's
+ * guided branch (Blasr.cpp:850-914) for one candidate window. */
+int bo_refine_candidate(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                        const int *matrix25, int ins, int del, int affOpen, int affExt,
+                        int wordSize, int sdpIns, int sdpDel, float indelRate, int sdpPrefixLength,
+                        int recurse, int noRecurseUnder, int bandSize, int *out, float *pct,
+                        int *outQPos, int *outTPos, int *blocks, int blockCap, int *nBlocks,
+                        int *gapCounts, int gapListCap, int *nGapLists, int *gapItems,
+                        int gapItemCap, int *nGapItems) {
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, affOpen, affExt);
+  aln_t sdp;
+  aln_init(&sdp);
+  out[0] = sdp_align(q, (uint32_t)qlen, t, (uint32_t)tlen, &fn, wordSize, sdpIns, sdpDel, indelRate,
+                     &sdp, BO_LOCAL, 1, 0, sdpPrefixLength, recurse, noRecurseUnder, 0);
+  compute_alignment_stats(&sdp, q, t, &fn, 1);
+  out[1] = sdp.score;
+  out[2] = (int)sdp.qPos;
+  out[3] = (int)sdp.tPos;
+  out[4] = sdp.nBlocks;
+  *nBlocks = 0;
+  if (nGapLists) *nGapLists = 0;
+  if (nGapItems) *nGapItems = 0;
+  for (int i = 5; i < 12; i++) out[i] = 0;
+  *pct = 0;
+  *outQPos = (int)sdp.qPos;
+  *outTPos = (int)sdp.tPos;
+  int rc = 0;
+  if (sdp.nBlocks > 0) {
+    /* Blasr.cpp:850-859: sequences trimmed to the SDP extent */
+    const unsigned char *ts = t + sdp.tPos, *qs = q + sdp.qPos;
+    aln_t ref;
+    aln_init(&ref);
+    out[5] = affine_guided_align(qs, ts, sdp.blocks, sdp.nBlocks, &fn, bandSize, &ref);
+    out[6] = ref.nCells;
+    compute_alignment_stats(&ref, qs, ts, &fn, 1);
+    out[7] = ref.score;
+    out[8] = ref.nMatch;
+    out[9] = ref.nMismatch;
+    out[10] = ref.nIns;
+    out[11] = ref.nDel;
+    *pct = ref.pct;
+    /* Blasr.cpp:905-914: window-relative start of the refined alignment */
+    *outQPos = (int)(sdp.qPos + ref.qPos);
+    *outTPos = (int)(sdp.tPos + ref.tPos);
+    rc = flatten(&ref, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+    aln_free(&ref);
+  }
+  aln_free(&sdp);
+  return rc;
+}

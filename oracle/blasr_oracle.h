@@ -1,0 +1,87 @@
+/* TEST INFRASTRUCTURE -- CPU restatement ("oracle") of BLASR's per-read refine
+ * stage.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (blasr_amd/, include/blasr_hip.h) never
+ * does.  Every function cites the reference file:line it restates (paths are
+ * relative to the reference checkout, e.g. /root/reference).
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every entry point
+ * below against oracle/_ref/libblasr_ref.so (the reference's own templates,
+ * compiled from /root/reference by oracle/Makefile) on seeded inputs, and
+ * tests/golden/ holds vectors generated from that library.
+ *
+ * The flat-array entry points deliberately share their signatures with the
+ * ref_* functions of oracle/ref_harness.cpp so that one ctypes prototype
+ * drives both.
+ */
+#ifndef BLASR_ORACLE_H_
+#define BLASR_ORACLE_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AlignmentType values used on the path (AlignmentUtils.h:14-58). */
+enum { BO_LOCAL = 0, BO_GLOBAL = 1, BO_END_ANCHORED = 6 };
+/* Gap::GapSeq (AlignmentGapList.h:11): Query = gap in the query (deletion,
+ * arrow Left), Target = gap in the target (insertion, arrow Up). */
+enum { BO_GAP_QUERY = 0, BO_GAP_TARGET = 1 };
+
+/* SDPAlign (SDPAlign.h:95-626) incl. recursion, SWAlign gap fills, chaining. */
+int bo_sdp_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                 const int *matrix25, int ins, int del, int affOpen, int affExt, int wordSize,
+                 int sdpIns, int sdpDel, float indelRate, int alignType, int detailed,
+                 int extendFront, int sdpPrefixLength, int recurse, int noRecurseUnder,
+                 int maxPerPos, int *outQPos, int *outTPos, int *blocks, int blockCap,
+                 int *nBlocks);
+
+/* SDPLongestCommonSubsequence (sdp/SparseDynamicProgramming.h:70-322). */
+int bo_sdp_chain(int queryLength, const int *xyl, int nFrag, int fragmentLength, int ins, int del,
+                 int match, int alignType, int *chain, int cap);
+
+/* SWAlign (SWAlign.h:19-389), Global mode only. */
+int bo_sw_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                const int *matrix25, int ins, int del, int alignType, int *outQPos, int *outTPos,
+                int *blocks, int blockCap, int *nBlocks);
+
+/* AlignmentToGuide + StoreMatrixOffsets + ComputeMatrixNElem (GuidedAlign.h:83-259). */
+int bo_alignment_to_guide(const int *blocks, int nBlocks, int bandSize, int *rows, int rowCap,
+                          int *nCells);
+
+/* AffineGuidedAlign (AffineGuidedAlign.h:31-488) + ComputeAlignmentStats, as
+ * RefineAlignment does (Blasr.cpp:862-878). */
+int bo_affine_guided_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                           const int *guideBlocks, int nGuideBlocks, const int *matrix25, int ins,
+                           int del, int affOpen, int affExt, int bandSize, int *outQPos,
+                           int *outTPos, int *blocks, int blockCap, int *nBlocks, int *gapCounts,
+                           int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                           int *nGapItems, int *stats, float *pct);
+
+/* ComputeAlignmentStats (AlignmentUtils.h:535-584). */
+void bo_compute_alignment_stats(const unsigned char *q, const unsigned char *t, int qPos, int tPos,
+                                const int *blocks, int nBlocks, const int *gapCounts,
+                                int nGapLists, const int *gapItems, const int *matrix25, int ins,
+                                int del, int affOpen, int affExt, int useAffine, int *stats,
+                                float *pct);
+
+/* libstdc++ (GCC 11.4) std::sort schedule on (x,y,len) triplets keyed by (x,y);
+ * exposed so the tie behaviour of SDPAlign.h:256 can be tested directly. */
+void bo_introsort_xy(int *xyl, int n);
+
+/* The whole refine stage for one candidate, as AlignIntervals + RefineAlignment
+ * run it with default parameters (Blasr.cpp:1716-1724, 850-914):
+ * SDPAlign(Local) -> ComputeAlignmentStats -> AffineGuidedAlign -> stats.
+ * out[0..11] = sdpScore, sdpStatsScore, sdpQPos, sdpTPos, nSdpBlocks, dpScore,
+ * nCells, score, nMatch, nMismatch, nIns, nDel; qPos/tPos are window-relative. */
+int bo_refine_candidate(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                        const int *matrix25, int ins, int del, int affOpen, int affExt,
+                        int wordSize, int sdpIns, int sdpDel, float indelRate, int sdpPrefixLength,
+                        int recurse, int noRecurseUnder, int bandSize, int *out, float *pct,
+                        int *outQPos, int *outTPos, int *blocks, int blockCap, int *nBlocks,
+                        int *gapCounts, int gapListCap, int *nGapLists, int *gapItems,
+                        int gapItemCap, int *nGapItems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
