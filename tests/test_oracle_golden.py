@@ -1,0 +1,55 @@
+"""The CPU oracle (oracle/blasr_oracle.c) against golden vectors produced by
+the reference itself (tests/golden/make_golden.py).  Bit-exact: integer work."""
+import numpy as np
+
+from blasr_testlib import GLOBAL, LOCAL
+from golden_cases import REFINE_KEYS, first_difference, golden_cases, guide_digest
+
+
+def test_sdp_align_matches_reference(oracle, golden):
+    for c in golden_cases(golden):
+        r = oracle.sdp_align(c.q, c.t, c.sc, c.sp)
+        assert (r["score"], r["qPos"], r["tPos"]) == (c.sdp_score, c.sdp_qpos, c.sdp_tpos), c.name
+        assert np.array_equal(r["blocks"], c.sdp_blocks), c.name
+
+
+def test_sdp_stats_match_reference(oracle, golden):
+    for c in golden_cases(golden):
+        s = oracle.compute_alignment_stats(c.q, c.t, c.sdp_qpos, c.sdp_tpos, c.sdp_blocks, sc=c.sc)
+        got = [s["score"], s["nMatch"], s["nMismatch"], s["nIns"], s["nDel"]]
+        assert got == list(c.sdp_stats), c.name
+        assert s["pct"] == np.float32(c.sdp_pct), c.name
+
+
+def test_guide_matches_reference(oracle, golden):
+    for c in golden_cases(golden):
+        if not c.has_refine:
+            continue
+        rows, ncells = oracle.alignment_to_guide(c.sdp_blocks, c.band)
+        assert np.array_equal(guide_digest(rows, ncells), c.guide_digest), c.name
+
+
+def test_affine_guided_align_matches_reference(oracle, golden):
+    n = 0
+    for c in golden_cases(golden):
+        if not c.has_refine:
+            continue
+        got = oracle.affine_guided_align(c.qs, c.ts, c.sdp_blocks, c.sc, c.band)
+        assert first_difference(got, c.expected_refine(), REFINE_KEYS) is None, c.name
+        n += 1
+    assert n >= 18
+
+
+def test_sw_align_matches_reference(oracle, golden):
+    for i in range(int(golden["n_sw"][0])):
+        r = oracle.sw_align(golden["sw%02d_q" % i], golden["sw%02d_t" % i])
+        assert r["score"] == int(golden["sw%02d_score" % i][0])
+        assert np.array_equal(r["blocks"], golden["sw%02d_blocks" % i].reshape(-1, 3))
+
+
+def test_chain_matches_reference(oracle, golden):
+    for i in range(int(golden["n_chain"][0])):
+        xyl = golden["ch%02d_xyl" % i]
+        qlen, k = (int(v) for v in golden["ch%02d_par" % i])
+        assert np.array_equal(oracle.sdp_chain(qlen, xyl, k, align_type=LOCAL), golden["ch%02d_local" % i])
+        assert np.array_equal(oracle.sdp_chain(qlen, xyl, k, align_type=GLOBAL), golden["ch%02d_global" % i])
