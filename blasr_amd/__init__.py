@@ -1,0 +1,20 @@
+"""blasr_amd -- MI355X-native refine stage of the BLASR long-read mapper.
+
+The product is ``libblasr_hip.so`` (hand-written HIP for gfx950 behind the C
+ABI of ``include/blasr_hip.h``).  This package is the thin Python host side
+used by the tests and ``bench.py``: ctypes bindings plus helpers that mirror
+the reference's call surface (``RefineAlignments``, alignment/Blasr.cpp:2164).
+It contains no CPU implementation of the algorithms and never imports
+``oracle/``: if the HIP library or a gfx950 device is missing, calls raise.
+"""
+from .hip import (  # noqa: F401
+    BlasrHipError,
+    Context,
+    LIB_PATH,
+    RefineBatch,
+    RefineResult,
+    ScoreParams,
+    load_library,
+)
+
+__all__ = ["BlasrHipError", "Context", "LIB_PATH", "RefineBatch", "RefineResult", "ScoreParams", "load_library"]

@@ -1,0 +1,496 @@
+// blasr_hip_api.hip -- the extern "C" boundary declared in include/blasr_hip.h.
+// Host-side only: context, grow-only device workspace, batch planning and the
+// kernel sequence of one refine call.  There is deliberately no CPU path here:
+// without a gfx950 device every entry point returns BLASR_HIP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/blasr_hip.h"
+#include "refine_kernels.h"
+
+using namespace blasr_hip;
+
+static_assert(sizeof(RefineResult) == sizeof(blasr_hip_refine_result), "result record layout");
+static_assert(offsetof(RefineResult, ops_off) == offsetof(blasr_hip_refine_result, ops_off), "result record layout");
+
+struct blasr_hip_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  char *workspace = nullptr;
+  size_t workspaceBytes = 0;
+  int64_t workspaceLimit = 48ll << 30;
+  std::string lastError;
+  float ms[4] = {0, 0, 0, 0};
+  int64_t counters[3] = {0, 0, 0};
+};
+
+namespace {
+
+int fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->lastError = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? BLASR_HIP_ERR_NOMEM : BLASR_HIP_ERR_HIP,       \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                                 \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_workspace(blasr_hip_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->workspaceBytes) return BLASR_HIP_OK;
+  if ((int64_t)bytes > ctx->workspaceLimit)
+    return fail(ctx, BLASR_HIP_ERR_NOMEM, "workspace of %zu bytes exceeds the limit of %lld", bytes,
+                (long long)ctx->workspaceLimit);
+  if (ctx->workspace) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->workspace));
+    ctx->workspace = nullptr;
+    ctx->workspaceBytes = 0;
+  }
+  // grow with head-room so that steady-state batches do not reallocate
+  size_t want = std::min<size_t>((size_t)ctx->workspaceLimit, bytes + bytes / 8);
+  if (hipMalloc((void **)&ctx->workspace, want) != hipSuccess) {
+    (void)hipGetLastError();
+    want = bytes;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->workspace, want));
+  }
+  ctx->workspaceBytes = want;
+  return BLASR_HIP_OK;
+}
+
+// the scan formulation of the deletion dependency (refine_kernels.hip) needs
+// open >= 0 and del >= ext >= 0; scores must stay far from the kInf sentinel
+int check_score_domain(blasr_hip_ctx *ctx, const blasr_hip_score_params *sc, int64_t longest) {
+  if (sc->affine_open < 0 || sc->affine_extend < 0 || sc->del < sc->affine_extend)
+    return fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
+                "unsupported gap costs: need affine_open >= 0 and del >= affine_extend >= 0 (got open=%d ext=%d del=%d)",
+                sc->affine_open, sc->affine_extend, sc->del);
+  int64_t mx = std::max<int64_t>({llabs((long long)sc->ins), llabs((long long)sc->del),
+                                  llabs((long long)sc->affine_open), llabs((long long)sc->affine_extend)});
+  for (int i = 0; i < 25; i++) mx = std::max<int64_t>(mx, llabs((long long)sc->matrix[i]));
+  if (mx * (longest + 66) >= (1ll << 27))
+    return fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "score magnitude %lld x length %lld overflows the 32-bit DP range",
+                (long long)mx, (long long)longest);
+  return BLASR_HIP_OK;
+}
+
+struct Plan {
+  std::vector<int64_t> arrowOff, rowOff, arenaOff;
+  struct Chunk {
+    int first, count;
+    size_t bytes;
+    std::vector<int32_t> wideTasks;
+    std::vector<int64_t> wideRingOff;
+    std::vector<int32_t> wideRingSize;
+    size_t wideBytes;
+  };
+  std::vector<Chunk> chunks;
+};
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_abi_version(void) { return BLASR_HIP_ABI_VERSION; }
+
+int blasr_hip_create(int device, blasr_hip_ctx **out) {
+  if (!out) return BLASR_HIP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+    (void)hipGetLastError();
+    return BLASR_HIP_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BLASR_HIP_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BLASR_HIP_ERR_NO_DEVICE;  // kernels are gfx950-only
+  blasr_hip_ctx *ctx = new blasr_hip_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return BLASR_HIP_ERR_HIP;
+  }
+  *out = ctx;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_destroy(blasr_hip_ctx *ctx) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  if (ctx->workspace) (void)hipFree(ctx->workspace);
+  delete ctx;
+  return BLASR_HIP_OK;
+}
+
+const char *blasr_hip_last_error(const blasr_hip_ctx *ctx) { return ctx ? ctx->lastError.c_str() : "null context"; }
+
+int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes) {
+  if (!ctx || bytes < (1 << 20)) return BLASR_HIP_ERR_INVALID;
+  ctx->workspaceLimit = bytes;
+  return BLASR_HIP_OK;
+}
+
+void *blasr_hip_stream(blasr_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; i++) ms[i] = ctx->ms[i];
+  for (int i = 0; i < 3; i++) counters[i] = ctx->counters[i];
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b, int32_t band,
+                            const blasr_hip_score_params *score, blasr_hip_refine_result *results,
+                            uint32_t *ops, int64_t opsCapacity, int64_t *opsUsed) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !score || b->n < 0 || band < 0 || opsCapacity < 0) return fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
+  if (opsUsed) *opsUsed = 0;
+  for (int i = 0; i < 4; i++) ctx->ms[i] = 0;
+  for (int i = 0; i < 3; i++) ctx->counters[i] = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !b->blocks || !b->blk_off || !b->n_blocks ||
+      !results || (!ops && opsCapacity > 0))
+    return fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  RefineBatchView view;
+  view.n = n;
+  view.seq = b->seq;
+  view.q_off = b->q_off;
+  view.q_len = b->q_len;
+  view.t_off = b->t_off;
+  view.t_len = b->t_len;
+  view.blocks = b->blocks;
+  view.blk_off = b->blk_off;
+  view.n_blocks = b->n_blocks;
+
+  // ---- fixed part of the workspace -----------------------------------------
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t oGeo = carve(sizeof(TaskGeometry) * n);
+  const size_t oArrowOff = carve(sizeof(int64_t) * n), oRowOff = carve(sizeof(int64_t) * n),
+               oArenaOff = carve(sizeof(int64_t) * n);
+  const size_t oOpsStart = carve(sizeof(int32_t) * n), oDp = carve(sizeof(int32_t) * n);
+  const size_t oMatrix = carve(sizeof(int32_t) * 25), oTotal = carve(sizeof(int64_t));
+  const size_t oWideTasks = carve(sizeof(int32_t) * n), oWideOff = carve(sizeof(int64_t) * n),
+               oWideSize = carve(sizeof(int32_t) * n);
+  const size_t fixedBytes = off;
+  // first make room for the fixed part + a modest variable part; grown below once the geometry is known
+  int rc = ensure_workspace(ctx, fixedBytes);
+  if (rc) return rc;
+
+  hipEvent_t ev[8];
+  for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+  auto destroyEvents = [&]() {
+    for (auto &e : ev) (void)hipEventDestroy(e);
+  };
+
+  // ---- geometry -------------------------------------------------------------
+  TaskGeometry *dGeo = reinterpret_cast<TaskGeometry *>(ctx->workspace + oGeo);
+  HIP_TRY(ctx, hipEventRecord(ev[0], st));
+  launch_geometry(view, band, 0, n, dGeo, st);
+  HIP_TRY(ctx, hipEventRecord(ev[1], st));
+  std::vector<TaskGeometry> geo(n);
+  HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo, sizeof(TaskGeometry) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev[0], ev[1]);
+    ctx->ms[0] = t;
+  }
+
+  int64_t longest = 0, totalCells = 0, totalRows = 0, totalSpan = 0;
+  for (int i = 0; i < n; i++) {
+    longest = std::max<int64_t>(longest, (int64_t)geo[i].rows + geo[i].tSpan);
+    if (geo[i].status == 0) {
+      totalCells += geo[i].cells;
+      totalRows += geo[i].rows;
+      totalSpan += geo[i].tSpan;
+    }
+  }
+  rc = check_score_domain(ctx, score, longest);
+  if (rc) {
+    destroyEvents();
+    return rc;
+  }
+
+  // ---- plan: contiguous chunks of candidates that fit the workspace ----------
+  Plan plan;
+  plan.arrowOff.resize(n);
+  plan.rowOff.resize(n);
+  plan.arenaOff.resize(n);
+  const size_t budget = (size_t)ctx->workspaceLimit > fixedBytes + (64u << 20) ? (size_t)ctx->workspaceLimit - fixedBytes
+                                                                                : (64u << 20);
+  {
+    Plan::Chunk cur;
+    cur.first = 0;
+    cur.count = 0;
+    cur.bytes = 0;
+    cur.wideBytes = 0;
+    size_t arrowB = 0, rowB = 0, arenaB = 0;
+    auto flush = [&](int nextFirst) {
+      // arrows | rowTab | arena | wide rings, each section 256-aligned
+      cur.bytes = align_up(arrowB, 256) + align_up(rowB, 256) + align_up(arenaB, 256) + cur.wideBytes;
+      plan.chunks.push_back(cur);
+      cur = Plan::Chunk();
+      cur.first = nextFirst;
+      cur.count = 0;
+      cur.bytes = 0;
+      cur.wideBytes = 0;
+      arrowB = rowB = arenaB = 0;
+    };
+    for (int i = 0; i < n; i++) {
+      size_t a = 0, r = 0, ar = 0, w = 0;
+      int ringSize = 0;
+      if (geo[i].status == 0) {
+        a = align_up((size_t)geo[i].cells, 64);
+        r = sizeof(int2) * ((size_t)geo[i].rows + 1);
+        ar = sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
+        if (geo[i].maxWidth > kLdsMaxWidth) {
+          ringSize = 2048;
+          while (ringSize < geo[i].maxWidth + 64) ringSize *= 2;
+          w = align_up((size_t)ringSize * 9, 256);
+        }
+      }
+      const size_t need = a + r + ar + w + 1024;
+      if (cur.count > 0 && arrowB + rowB + arenaB + cur.wideBytes + need > budget) flush(i);
+      if (need > budget) {
+        destroyEvents();
+        return fail(ctx, BLASR_HIP_ERR_NOMEM, "candidate %d alone needs %zu bytes of workspace", i, need);
+      }
+      plan.arrowOff[i] = (int64_t)arrowB;
+      plan.rowOff[i] = (int64_t)(rowB / sizeof(int2));
+      plan.arenaOff[i] = (int64_t)(arenaB / sizeof(uint32_t));
+      arrowB += a;
+      rowB += r;
+      arenaB += ar;
+      if (ringSize) {
+        cur.wideTasks.push_back(i);
+        cur.wideRingOff.push_back((int64_t)cur.wideBytes);
+        cur.wideRingSize.push_back(ringSize);
+        cur.wideBytes += w;
+      }
+      cur.count++;
+    }
+    if (cur.count > 0) flush(n);
+  }
+  size_t maxChunk = 0;
+  for (auto &c : plan.chunks) maxChunk = std::max(maxChunk, c.bytes);
+  const size_t oVar = fixedBytes;
+  if (fixedBytes + maxChunk > ctx->workspaceBytes) {
+    // the geometry lives in the old allocation: it is already on the host, re-upload after growing
+    rc = ensure_workspace(ctx, fixedBytes + maxChunk);
+    if (rc) {
+      destroyEvents();
+      return rc;
+    }
+    dGeo = reinterpret_cast<TaskGeometry *>(ctx->workspace + oGeo);
+    HIP_TRY(ctx, hipMemcpyAsync(dGeo, geo.data(), sizeof(TaskGeometry) * n, hipMemcpyHostToDevice, st));
+  }
+  char *ws = ctx->workspace;
+  int64_t *dArrowOff = reinterpret_cast<int64_t *>(ws + oArrowOff);
+  int64_t *dRowOff = reinterpret_cast<int64_t *>(ws + oRowOff);
+  int64_t *dArenaOff = reinterpret_cast<int64_t *>(ws + oArenaOff);
+  int32_t *dOpsStart = reinterpret_cast<int32_t *>(ws + oOpsStart);
+  int32_t *dDp = reinterpret_cast<int32_t *>(ws + oDp);
+  int32_t *dMatrix = reinterpret_cast<int32_t *>(ws + oMatrix);
+  int64_t *dTotal = reinterpret_cast<int64_t *>(ws + oTotal);
+  int32_t *dWideTasks = reinterpret_cast<int32_t *>(ws + oWideTasks);
+  int64_t *dWideOff = reinterpret_cast<int64_t *>(ws + oWideOff);
+  int32_t *dWideSize = reinterpret_cast<int32_t *>(ws + oWideSize);
+  HIP_TRY(ctx, hipMemcpyAsync(dArrowOff, plan.arrowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dRowOff, plan.rowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dArenaOff, plan.arenaOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dMatrix, score->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(dTotal, 0, sizeof(int64_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(dDp, 0, sizeof(int32_t) * n, st));
+
+  RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
+  float msFill = 0, msTrace = 0, msCompact = 0;
+  for (auto &c : plan.chunks) {
+    // section bases inside the variable part
+    size_t arrowB = 0, rowB = 0, arenaB = 0;
+    for (int i = c.first; i < c.first + c.count; i++)
+      if (geo[i].status == 0) {
+        arrowB += align_up((size_t)geo[i].cells, 64);
+        rowB += sizeof(int2) * ((size_t)geo[i].rows + 1);
+        arenaB += sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
+      }
+    char *pArrows = ws + oVar;
+    char *pRows = pArrows + align_up(arrowB, 256);
+    char *pArena = pRows + align_up(rowB, 256);
+    char *pWide = pArena + align_up(arenaB, 256);
+
+    FillArgs fa;
+    fa.first = c.first;
+    fa.count = c.count;
+    fa.band = band;
+    fa.ins = score->ins;
+    fa.del = score->del;
+    fa.open = score->affine_open;
+    fa.ext = score->affine_extend;
+    fa.matrix = dMatrix;
+    fa.geo = dGeo;
+    fa.arrows = reinterpret_cast<uint8_t *>(pArrows);
+    fa.arrowOff = dArrowOff;
+    fa.rowTab = reinterpret_cast<int2 *>(pRows);
+    fa.rowOff = dRowOff;
+    fa.dpScore = dDp;
+    fa.wideTasks = dWideTasks;
+    fa.wideRingOff = dWideOff;
+    fa.wideRingSize = dWideSize;
+    fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
+    HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    launch_fill(view, fa, false, st);
+    if (!c.wideTasks.empty()) {
+      const int nw = (int)c.wideTasks.size();
+      HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
+      FillArgs fw = fa;
+      fw.count = nw;
+      launch_fill(view, fw, true, st);
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[3], st));
+
+    TraceArgs ta;
+    ta.first = c.first;
+    ta.count = c.count;
+    ta.ins = score->ins;
+    ta.del = score->del;
+    ta.open = score->affine_open;
+    ta.ext = score->affine_extend;
+    ta.matrix = dMatrix;
+    ta.geo = dGeo;
+    ta.arrows = fa.arrows;
+    ta.arrowOff = dArrowOff;
+    ta.rowTab = fa.rowTab;
+    ta.rowOff = dRowOff;
+    ta.dpScore = dDp;
+    ta.arena = reinterpret_cast<uint32_t *>(pArena);
+    ta.arenaOff = dArenaOff;
+    ta.opsStart = dOpsStart;
+    ta.results = dResults;
+    launch_traceback(view, ta, st);
+    HIP_TRY(ctx, hipEventRecord(ev[4], st));
+    launch_scan_ops(dResults, c.first, c.count, opsCapacity, dTotal, st);
+    launch_compact_ops(dResults, c.first, c.count, ta.arena, dArenaOff, dOpsStart, ops, st);
+    HIP_TRY(ctx, hipEventRecord(ev[5], st));
+    // the next chunk reuses the variable part: wait (also collects the timings)
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev[2], ev[3]);
+    msFill += t;
+    (void)hipEventElapsedTime(&t, ev[3], ev[4]);
+    msTrace += t;
+    (void)hipEventElapsedTime(&t, ev[4], ev[5]);
+    msCompact += t;
+    ctx->counters[2] += 1;
+  }
+  int64_t total = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&total, dTotal, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  destroyEvents();
+  ctx->ms[1] = msFill;
+  ctx->ms[2] = msTrace;
+  ctx->ms[3] = msCompact;
+  ctx->counters[0] = totalCells;
+  // algorithmic bytes of the fill: 1 B/cell arrows out, bases in, 8 B/row record out
+  int64_t seqBytes = totalRows + totalSpan;
+  ctx->counters[1] = totalCells + seqBytes + 8 * totalRows;
+  if (opsUsed) *opsUsed = total;
+  if (total > opsCapacity)
+    return fail(ctx, BLASR_HIP_ERR_CAPACITY, "ops arena too small: need %lld, have %lld", (long long)total,
+                (long long)opsCapacity);
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b, int32_t band,
+                          const blasr_hip_score_params *score, blasr_hip_refine_result *results, uint32_t *ops,
+                          int64_t opsCapacity, int64_t *opsUsed) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !score || b->n < 0) return fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
+  if (opsUsed) *opsUsed = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int64_t seqBytes = 0, nBlocksTotal = 0;
+  for (int i = 0; i < n; i++) {
+    if (b->q_len[i] < 0 || b->t_len[i] < 0 || b->q_off[i] < 0 || b->t_off[i] < 0 || b->n_blocks[i] < 0 || b->blk_off[i] < 0)
+      return fail(ctx, BLASR_HIP_ERR_INVALID, "negative length or offset in candidate %d", i);
+    seqBytes = std::max<int64_t>(seqBytes, std::max(b->q_off[i] + b->q_len[i], b->t_off[i] + b->t_len[i]));
+    nBlocksTotal = std::max<int64_t>(nBlocksTotal, b->blk_off[i] + b->n_blocks[i]);
+  }
+  struct Dev {
+    void *p = nullptr;
+    ~Dev() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  Dev dSeq, dQOff, dQLen, dTOff, dTLen, dBlocks, dBlkOff, dNBlocks, dRes, dOps;
+  auto up = [&](Dev &d, const void *src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(&d.p, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  HIP_TRY(ctx, up(dSeq, b->seq, (size_t)seqBytes));
+  HIP_TRY(ctx, up(dQOff, b->q_off, sizeof(int64_t) * n));
+  HIP_TRY(ctx, up(dQLen, b->q_len, sizeof(int32_t) * n));
+  HIP_TRY(ctx, up(dTOff, b->t_off, sizeof(int64_t) * n));
+  HIP_TRY(ctx, up(dTLen, b->t_len, sizeof(int32_t) * n));
+  HIP_TRY(ctx, up(dBlocks, b->blocks, sizeof(int32_t) * 3 * (size_t)nBlocksTotal));
+  HIP_TRY(ctx, up(dBlkOff, b->blk_off, sizeof(int64_t) * n));
+  HIP_TRY(ctx, up(dNBlocks, b->n_blocks, sizeof(int32_t) * n));
+  HIP_TRY(ctx, hipMalloc(&dRes.p, sizeof(blasr_hip_refine_result) * n));
+  HIP_TRY(ctx, hipMalloc(&dOps.p, std::max<size_t>(sizeof(uint32_t) * (size_t)opsCapacity, 16)));
+  blasr_hip_refine_batch db;
+  db.n = n;
+  db.seq = (const uint8_t *)dSeq.p;
+  db.q_off = (const int64_t *)dQOff.p;
+  db.q_len = (const int32_t *)dQLen.p;
+  db.t_off = (const int64_t *)dTOff.p;
+  db.t_len = (const int32_t *)dTLen.p;
+  db.blocks = (const int32_t *)dBlocks.p;
+  db.blk_off = (const int64_t *)dBlkOff.p;
+  db.n_blocks = (const int32_t *)dNBlocks.p;
+  int64_t used = 0;
+  int rc = blasr_hip_refine_device(ctx, &db, band, score, (blasr_hip_refine_result *)dRes.p, (uint32_t *)dOps.p,
+                                   opsCapacity, &used);
+  if (opsUsed) *opsUsed = used;
+  if (rc != BLASR_HIP_OK && rc != BLASR_HIP_ERR_CAPACITY) return rc;
+  HIP_TRY(ctx, hipMemcpy(results, dRes.p, sizeof(blasr_hip_refine_result) * n, hipMemcpyDeviceToHost));
+  const int64_t copyOps = std::min(used, opsCapacity);
+  if (copyOps > 0) HIP_TRY(ctx, hipMemcpy(ops, dOps.p, sizeof(uint32_t) * (size_t)copyOps, hipMemcpyDeviceToHost));
+  return rc;
+}
+
+}  // extern "C"

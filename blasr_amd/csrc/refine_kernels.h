@@ -1,0 +1,91 @@
+// Internal interface between the C-ABI host layer (blasr_hip.cpp) and the
+// gfx950 kernels (refine_kernels.hip).  Not installed; the public surface is
+// include/blasr_hip.h.
+#ifndef BLASR_AMD_REFINE_KERNELS_H_
+#define BLASR_AMD_REFINE_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blasr_hip {
+
+// mirrors blasr_hip_refine_batch (device pointers)
+struct RefineBatchView {
+  int32_t n;
+  const uint8_t *seq;
+  const int64_t *q_off;
+  const int32_t *q_len;
+  const int64_t *t_off;
+  const int32_t *t_len;
+  const int32_t *blocks;
+  const int64_t *blk_off;
+  const int32_t *n_blocks;
+};
+
+// must stay layout-identical to blasr_hip_refine_result
+struct RefineResult {
+  int32_t status, q_pos, t_pos, dp_score, n_cells, score, n_match, n_mismatch, n_ins, n_del, n_ops, reserved;
+  int64_t ops_off;
+};
+
+enum { TASK_EMPTY_GUIDE = 1, TASK_BAD_GUIDE = 2, TASK_BAD_PATH = 4, TASK_OPS_OVERFLOW = 8 };
+enum { OP_M = 0, OP_I = 1, OP_D = 2 };
+
+// per-candidate band geometry (geometry_kernel)
+struct TaskGeometry {
+  int64_t cells;     // ComputeMatrixNElem (GuidedAlign.h:83-92)
+  int32_t rows;      // guide.size() - 1 = aligned query length
+  int32_t maxWidth;  // widest guide row (tPre + tPost + 1)
+  int32_t status;    // TASK_* bits
+  int32_t tSpan;     // tEnd - tStart: target columns the path can cross
+};
+
+constexpr int kLdsRing = 1024;              // columns held per wavefront in LDS
+constexpr int kLdsMaxWidth = kLdsRing - 64;  // widest row the LDS kernel accepts
+
+struct FillArgs {
+  int first, count;  // candidates [first, first+count) of the batch (LDS variant)
+  int band;
+  int ins, del, open, ext;
+  const int32_t *matrix;  // 25 ints, [query][target]
+  const TaskGeometry *geo;
+  uint8_t *arrows;          // packed arrows, 1 byte per band cell
+  const int64_t *arrowOff;  // per candidate
+  int2 *rowTab;             // per row: {matrix offset of the row's first cell, first column}
+  const int64_t *rowOff;
+  int32_t *dpScore;
+  // global-ring variant: candidates whose rows are too wide for LDS
+  const int32_t *wideTasks;
+  const int64_t *wideRingOff;
+  const int32_t *wideRingSize;
+  uint8_t *wideRings;
+};
+
+struct TraceArgs {
+  int first, count;
+  int ins, del, open, ext;
+  const int32_t *matrix;
+  const TaskGeometry *geo;
+  const uint8_t *arrows;
+  const int64_t *arrowOff;
+  const int2 *rowTab;
+  const int64_t *rowOff;
+  const int32_t *dpScore;
+  uint32_t *arena;  // per-candidate worst-case op space, filled from the back
+  const int64_t *arenaOff;
+  int32_t *opsStart;
+  RefineResult *results;
+};
+
+void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
+                     hipStream_t stream);
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, hipStream_t stream);
+void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
+// *total holds the op count of all candidates before `first` on entry and including them on exit
+void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,
+                     hipStream_t stream);
+void launch_compact_ops(const RefineResult *results, int first, int count, const uint32_t *arena,
+                        const int64_t *arenaOff, const int32_t *opsStart, uint32_t *ops, hipStream_t stream);
+
+}  // namespace blasr_hip
+#endif

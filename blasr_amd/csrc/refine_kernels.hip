@@ -1,0 +1,631 @@
+// refine_kernels.hip -- gfx950 kernels for BLASR's guided affine refinement.
+//
+// What the reference does per candidate (one CPU thread, one call):
+//   AlignmentToGuide + StoreMatrixOffsets   GuidedAlign.h:94-259
+//   AffineGuidedAlign fill + traceback      AffineGuidedAlign.h:31-488
+//   ArrowPathToAlignment                    datastructures/alignment/Alignment.h:190-254
+//   RemoveAlignmentPrefixGaps               AlignmentUtils.h:620-644
+//   ComputeAlignmentStats (affine form)     AlignmentUtils.h:535-584, :60-124
+//
+// How it is laid out here (MI355X, wave64):
+//   geometry_kernel  one wavefront per candidate: rows of the ragged band are
+//                    derived 64 at a time with lane = row (block lookup by
+//                    ballot + mbcnt, band start by a wave prefix-max, matrix
+//                    offsets by a wave prefix-sum); emits nCells / widest row.
+//   fill_kernel      one wavefront per candidate, lane = band column.  A row is
+//                    one pass: the vertical/diagonal candidates are elementwise,
+//                    the horizontal (deletion) dependency is closed with two
+//                    DPP prefix-min scans, so a whole row costs O(1) wave
+//                    instructions instead of a serial sweep.  Score rows
+//                    (S and affine-insert I) live in an LDS ring indexed by
+//                    target column; only the 1-byte packed arrows (3 bits S,
+//                    1 bit I, 1 bit D) and an 8-byte row record go to HBM.
+//   traceback_kernel one lane per candidate: walks the packed arrows backwards,
+//                    run-length encodes the path and accumulates the statistics.
+//   scan / compact   exclusive scan of op counts and a coalesced copy of the
+//                    per-candidate op runs into the caller's arena.
+// Integer DP: no MFMA anywhere.  Results are bit-identical to the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "refine_kernels.h"
+
+namespace blasr_hip {
+
+// ---------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+// lane i receives lane i-1; lane 0 receives `edge` (DPP wave_shr:1)
+__device__ __forceinline__ int wave_shr1(int v, int edge) { return dpp<0x138, 0xf>(edge, v); }
+
+// inclusive prefix-min over the 64 lanes: row_shr 1,2,4,8 then row_bcast15/31
+__device__ __forceinline__ int wave_prefix_min(int v) {
+  v = min(v, dpp<0x111, 0xf>(v, v));
+  v = min(v, dpp<0x112, 0xf>(v, v));
+  v = min(v, dpp<0x114, 0xf>(v, v));
+  v = min(v, dpp<0x118, 0xf>(v, v));
+  v = min(v, dpp<0x142, 0xa>(v, v));
+  v = min(v, dpp<0x143, 0xc>(v, v));
+  return v;
+}
+__device__ __forceinline__ int wave_prefix_max(int v) {
+  v = max(v, dpp<0x111, 0xf>(v, v));
+  v = max(v, dpp<0x112, 0xf>(v, v));
+  v = max(v, dpp<0x114, 0xf>(v, v));
+  v = max(v, dpp<0x118, 0xf>(v, v));
+  v = max(v, dpp<0x142, 0xa>(v, v));
+  v = max(v, dpp<0x143, 0xc>(v, v));
+  return v;
+}
+// inclusive prefix-sum (Hillis-Steele needs the shifted value to be 0 where no source lane exists)
+__device__ __forceinline__ unsigned wave_prefix_sum(unsigned v) {
+  v += (unsigned)dpp<0x111, 0xf>(0, (int)v);
+  v += (unsigned)dpp<0x112, 0xf>(0, (int)v);
+  v += (unsigned)dpp<0x114, 0xf>(0, (int)v);
+  v += (unsigned)dpp<0x118, 0xf>(0, (int)v);
+  v += (unsigned)dpp<0x142, 0xa>(0, (int)v);
+  v += (unsigned)dpp<0x143, 0xc>(0, (int)v);
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_prefix_max(v), 63); }
+
+// NucConversion.h:48-86 (ThreeBit) on the supported alphabet: ACGT -> 0..3, else N = 4
+__device__ __forceinline__ int base_code(unsigned c) {
+  c &= 0xdfu;  // fold case
+  int code = 4;
+  code = (c == 'A') ? 0 : code;
+  code = (c == 'C') ? 1 : code;
+  code = (c == 'G') ? 2 : code;
+  code = (c == 'T') ? 3 : code;
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// Guide geometry (AlignmentToGuide, GuidedAlign.h:104-259) for 64 rows at once.
+// Row r (1..Q) belongs to query position qStart + r - 1.  Per row:
+//   t      centre column (guide[r].t)
+//   lo     first column  = t - tPre;  lo_r = max(t_r - cap_r, lo_{r-1})  because
+//          tPre = min(cap, t_r - lo_{r-1})   (:160-173, :216, :245)
+//   hi     last column   = t + tPost
+// cap is "none" on the first row of a block (:161-165), bandSize inside a block
+// (:173), MAX_BAND_SIZE on gap rows (:216, :245).
+// ---------------------------------------------------------------------------
+struct GuideCursor {
+  const int32_t *blocks;  // (q,t,len) triplets
+  int nBlocks;
+  int qStart, tStart, Q, band;
+  int nextBlock;  // first block whose first row is >= the next group's first row
+  int loCarry;    // lo of the row preceding the next group
+  unsigned cellCarry;  // matrix cells in all rows before the next group
+};
+
+__device__ __forceinline__ void guide_begin(GuideCursor &g, const int32_t *blocks, int nBlocks, int band) {
+  g.blocks = blocks;
+  g.nBlocks = nBlocks;
+  g.band = band;
+  g.qStart = blocks[0];
+  g.tStart = blocks[1];
+  g.Q = blocks[3 * (nBlocks - 1)] + blocks[3 * (nBlocks - 1) + 2] - g.qStart;
+  g.nextBlock = 0;
+  g.loCarry = g.tStart - 1;  // row 0: t = tStart-1, tPre = 0 (:126-135)
+  int drift = abs(g.tStart - g.qStart);
+  int tPost0 = drift > band ? drift : band;
+  g.cellCarry = (unsigned)(tPost0 + 1);
+}
+__device__ __forceinline__ int guide_row0_tpost(const GuideCursor &g) {
+  int drift = abs(g.tStart - g.qStart);
+  return drift > g.band ? drift : g.band;
+}
+
+// Rows r0 .. r0+63 (lane i <-> row r0+i).  flagScratch: 64 bytes of LDS private to the wave.
+__device__ __forceinline__ void guide_group(GuideCursor &g, int r0, unsigned char *flagScratch, int &tOut,
+                                            int &loOut, int &hiOut, unsigned &rowStartOut) {
+  const int lane = lane_id();
+  const int r = r0 + lane;
+  const bool rowValid = r <= g.Q;
+  // which blocks start inside this group?  (a block of length >= 1 owns >= 1 row, so <= 64 of them)
+  flagScratch[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int bCand = g.nextBlock + lane;
+  int rb = INT32_MAX;
+  if (bCand < g.nBlocks) rb = g.blocks[3 * bCand] - g.qStart + 1;
+  bool starts = rb < r0 + 64;
+  if (starts) flagScratch[rb - r0] = 1;
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long startMask = __ballot(flagScratch[lane] != 0);
+  __builtin_amdgcn_wave_barrier();
+  // number of block starts at rows <= mine -> my block index
+  unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+  int bi = g.nextBlock - 1 + __popcll(startMask & le);
+  g.nextBlock += __popcll(__ballot(starts));
+
+  int t = 0, cap = 0, tPost = 0;
+  if (rowValid) {
+    const int qpos = g.qStart + r - 1;
+    const int bq = g.blocks[3 * bi], bt = g.blocks[3 * bi + 1], bl = g.blocks[3 * bi + 2];
+    const int off = qpos - bq;
+    if (off < bl) {
+      t = bt + off;
+      if (off == 0) {
+        // first row of a block: tPre = reach (uncapped), tPost = band + |drift of the gap before| (:161-165)
+        int drift;
+        if (bi == 0) {
+          drift = abs(g.tStart - g.qStart);
+        } else {
+          const int pq = g.blocks[3 * (bi - 1)], pt = g.blocks[3 * (bi - 1) + 1], pl = g.blocks[3 * (bi - 1) + 2];
+          drift = abs((bt - (pt + pl)) - (bq - (pq + pl)));  // ComputeDrift = tGap - qGap (AlignmentUtils.h:586-600)
+        }
+        cap = -1;  // none
+        tPost = g.band + drift;
+      } else {
+        cap = g.band;
+        tPost = min(250, g.band);
+      }
+    } else {
+      // gap rows between block bi and bi+1 (:193-250): min(qGap,tGap) diagonal rows, then straight down
+      const int nq = g.blocks[3 * (bi + 1)], nt = g.blocks[3 * (bi + 1) + 1];
+      const int qGap = nq - (bq + bl), tGap = nt - (bt + bl);
+      const int diagLen = max(min(qGap, tGap), 0);
+      const int gi = off - bl;
+      t = bt + bl + min(gi, diagLen);
+      cap = 250;
+      tPost = min(250, g.band + abs(tGap - qGap));
+    }
+  }
+  // lo_r = max over rows j <= r of (t_j - cap_j), seeded with the carried lo
+  int reachFloor = (rowValid && cap >= 0) ? t - cap : INT32_MIN;
+  int lo = max(wave_prefix_max(reachFloor), g.loCarry);
+  int hi = t + tPost;
+  unsigned len = rowValid ? (unsigned)(hi - lo + 1) : 0u;
+  unsigned incl = wave_prefix_sum(len);
+  rowStartOut = g.cellCarry + incl - len;
+  // carries for the next group
+  int lastLane = min(63, g.Q - r0);
+  g.loCarry = __builtin_amdgcn_readlane(lo, lastLane < 0 ? 0 : lastLane);
+  g.cellCarry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+  tOut = t;
+  loOut = lo;
+  hiOut = hi;
+}
+
+// ---------------------------------------------------------------------------
+// geometry_kernel: validation + nCells + widest row, one wavefront per candidate
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, int band, int first, int count,
+                                                         TaskGeometry *geo) {
+  __shared__ unsigned char flagScratch[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (idx >= count) return;
+  const int task = first + idx;
+  const int nBlocks = batch.n_blocks[task];
+  TaskGeometry out;
+  out.rows = 0;
+  out.cells = 0;
+  out.maxWidth = 0;
+  out.status = 0;
+  out.tSpan = 0;
+  if (nBlocks <= 0) {
+    out.status = TASK_EMPTY_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
+  }
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const int qLen = batch.q_len[task], tLen = batch.t_len[task];
+  // validation: blocks ordered, non-overlapping in q and t, positive length, inside both sequences
+  bool bad = false;
+  for (int b = lane; b < nBlocks; b += 64) {
+    int q = blocks[3 * b], t = blocks[3 * b + 1], l = blocks[3 * b + 2];
+    if (q < 0 || t < 0 || l <= 0 || q + l > qLen || t + l > tLen) bad = true;
+    if (b + 1 < nBlocks) {
+      int nq = blocks[3 * b + 3], nt = blocks[3 * b + 4];
+      if (nq < q + l || nt < t + l) bad = true;
+    }
+  }
+  if (__ballot(bad) != 0ull) {
+    out.status = TASK_BAD_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
+  }
+  GuideCursor g;
+  guide_begin(g, blocks, nBlocks, band);
+  int widest = guide_row0_tpost(g) + 1;
+  for (int r0 = 1; r0 <= g.Q; r0 += 64) {
+    int t, lo, hi;
+    unsigned rs;
+    guide_group(g, r0, flagScratch[wave], t, lo, hi, rs);
+    int w = (r0 + lane <= g.Q) ? hi - lo + 1 : 0;
+    widest = max(widest, wave_max(w));
+  }
+  out.rows = g.Q;
+  out.cells = (int64_t)g.cellCarry;
+  out.maxWidth = widest;
+  out.tSpan = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2] - g.tStart;
+  if (lane == 0) geo[task] = out;
+}
+
+// ---------------------------------------------------------------------------
+// fill_kernel
+// ---------------------------------------------------------------------------
+constexpr int kInf = 1 << 29;  // "no predecessor"; real scores stay below 2^27 (checked on the host)
+
+// packed arrow byte: bits 0-2 S arrow, bit 3 I arrow (1 = extend), bit 4 D arrow (1 = extend)
+enum { AR_DIAG = 0, AR_UP = 1, AR_LEFT = 2, AR_INS_CLOSE = 3, AR_DEL_CLOSE = 4, AR_NONE = 7 };
+
+template <bool kGlobalRing>
+__global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillArgs args) {
+  // per-wave LDS: score ring {S,I} by column, target-code ring, 64-byte scratch
+  __shared__ int2 ldsRing[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
+  __shared__ unsigned char ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
+  __shared__ unsigned char flagScratch[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (idx >= args.count) return;
+  const int task = kGlobalRing ? args.wideTasks[idx] : args.first + idx;
+  const TaskGeometry geo = args.geo[task];
+  if (geo.status != 0) return;
+  if (!kGlobalRing && geo.maxWidth > kLdsMaxWidth) return;  // handled by the global-ring launch
+
+  int2 *ring;
+  unsigned char *ringT;
+  int ringMask;
+  if (kGlobalRing) {
+    const int64_t off = args.wideRingOff[idx];
+    ringMask = args.wideRingSize[idx] - 1;
+    ring = reinterpret_cast<int2 *>(args.wideRings + off);
+    ringT = reinterpret_cast<unsigned char *>(ring + (ringMask + 1));
+  } else {
+    ring = ldsRing[wave];
+    ringT = ldsT[wave];
+    ringMask = kLdsRing - 1;
+  }
+
+  const uint8_t *qSeq = batch.seq + batch.q_off[task];
+  const uint8_t *tSeq = batch.seq + batch.t_off[task];
+  const int tLen = batch.t_len[task];
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const int nBlocks = batch.n_blocks[task];
+  uint8_t *arrows = args.arrows + args.arrowOff[task];
+  int2 *rowTab = args.rowTab + args.rowOff[task];
+
+  const int insC = args.ins, delC = args.del, openC = args.open, extC = args.ext;
+
+  GuideCursor g;
+  guide_begin(g, blocks, nBlocks, args.band);
+  const int qStart = g.qStart, tStart = g.tStart, Q = g.Q;
+  const int lastBlk = nBlocks - 1;
+  const int tEnd = blocks[3 * lastBlk + 1] + blocks[3 * lastBlk + 2];  // guide[last].t + 1
+
+  // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open ----
+  int plo = tStart - 1;
+  int phi = plo + guide_row0_tpost(g);
+  int tLoaded = plo < 0 ? 0 : plo;  // columns < tLoaded of the target are staged in ringT
+  for (int c0 = plo; c0 <= phi; c0 += 64) {
+    int c = c0 + lane;
+    if (c <= phi) ring[c & ringMask] = make_int2((c - plo) * delC, openC);
+  }
+  if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  int finalScore = 0;
+  for (int r0 = 1; r0 <= Q; r0 += 64) {
+    int tV, loV, hiV;
+    unsigned rsV;
+    guide_group(g, r0, flagScratch[wave], tV, loV, hiV, rsV);
+    const int nRows = min(64, Q - r0 + 1);
+    if (lane < nRows) rowTab[r0 + lane] = make_int2((int)rsV, loV);
+    // query codes of these 64 rows
+    int qCodeV = 4;
+    if (lane < nRows) qCodeV = base_code(qSeq[qStart + r0 - 1 + lane]);
+
+    for (int i = 0; i < nRows; i++) {
+      const int lo = __builtin_amdgcn_readlane(loV, i);
+      const int hi = __builtin_amdgcn_readlane(hiV, i);
+      const unsigned rowStart = (unsigned)__builtin_amdgcn_readlane((int)rsV, i);
+      const int qc = __builtin_amdgcn_readlane(qCodeV, i);
+      const int hiC = min(hi, tEnd - 1);  // cells with t >= tEnd are skipped (:268-269)
+      // stage target codes up to hiC
+      while (tLoaded <= hiC) {
+        int c = tLoaded + lane;
+        if (c < tLen) ringT[c & ringMask] = (unsigned char)base_code(tSeq[c]);
+        tLoaded += 64;
+        if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      const int m0 = args.matrix[qc * 5 + 0], m1 = args.matrix[qc * 5 + 1], m2 = args.matrix[qc * 5 + 2],
+                m3 = args.matrix[qc * 5 + 3], m4 = args.matrix[qc * 5 + 4];
+      uint8_t *arrowRow = arrows + rowStart - lo;
+
+      int carryA = kInf, carryB = kInf, carryS = kInf, carryDiag = 0;
+      for (int cb = lo; cb <= hiC; cb += 64) {
+        const int c = cb + lane;
+        const bool active = c <= hiC;
+        const int2 up = ring[c & ringMask];
+        int sd = ring[(c - 1) & ringMask].x;
+        if (cb > lo) sd = (lane == 0) ? carryDiag : sd;  // column cb-1 was overwritten by the previous chunk
+        const int tc = (c >= 0) ? (int)ringT[c & ringMask] : 4;
+        const bool upValid = (c >= plo) && (c <= phi);
+        const bool diagValid = (c - 1 >= plo) && (c - 1 <= phi);
+        int m = m4;
+        m = (tc == 0) ? m0 : m;
+        m = (tc == 1) ? m1 : m;
+        m = (tc == 2) ? m2 : m;
+        m = (tc == 3) ? m3 : m;
+        const int matchS = diagValid ? sd + m : kInf;
+        const int insS = upValid ? up.x + insC : kInf;
+        const int insE = upValid ? up.y + extC : kInf;
+        int v = min(matchS, min(insS, insE));
+        v = active ? v : kInf;
+        // horizontal closure: S[c] = min(V[c], min_{k<c} V[k] + min((c-k)*del, open + (c-k)*ext))
+        const int ia = wave_prefix_min(v - lane * delC);
+        const int ib = wave_prefix_min(v - lane * extC);
+        const int ea = min(wave_shr1(ia, kInf), carryA);
+        const int eb = min(wave_shr1(ib, kInf), carryB);
+        const int delExt = eb + lane * extC + openC;  // = D[c-1] + ext
+        const int s = min(v, min(ea + lane * delC, delExt));
+        const int delS = wave_shr1(s, carryS) + delC;  // S[c-1] + del (kInf-ish when c-1 is outside the row)
+        int arrow = AR_DEL_CLOSE;
+        arrow = (s == insE) ? AR_INS_CLOSE : arrow;
+        arrow = (s == insS) ? AR_UP : arrow;
+        arrow = (s == delS) ? AR_LEFT : arrow;
+        arrow = (s == matchS) ? AR_DIAG : arrow;
+        const int openS = s + openC;
+        const bool insExtends = !(openS < insE);
+        const bool delExtends = !(openS < delExt);
+        const int iNew = insExtends ? insE : openS;
+        if (active) {
+          ring[c & ringMask] = make_int2(s, iNew);
+          arrowRow[c] = (uint8_t)(arrow | (insExtends ? 8 : 0) | (delExtends ? 16 : 0));
+        }
+        if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        carryDiag = __builtin_amdgcn_readlane(up.x, 63);
+        carryS = __builtin_amdgcn_readlane(s, 63);
+        carryA = min(carryA, __builtin_amdgcn_readlane(ia, 63)) + 64 * delC;
+        carryB = min(carryB, __builtin_amdgcn_readlane(ib, 63)) + 64 * extC;
+        if (r0 + i == Q && c == tEnd - 1) finalScore = s;
+      }
+      plo = lo;
+      phi = hi;
+    }
+  }
+  // only the lane that owned cell (Q, tEnd-1) holds a non-zero value: a wave sum publishes it
+  int fs = finalScore;
+  for (int off = 32; off > 0; off >>= 1) fs += __shfl_xor(fs, off);
+  if (lane == 0) args.dpScore[task] = fs;
+}
+
+template __global__ void fill_kernel<false>(RefineBatchView, FillArgs);
+template __global__ void fill_kernel<true>(RefineBatchView, FillArgs);
+
+// ---------------------------------------------------------------------------
+// traceback_kernel: one lane per candidate (AffineGuidedAlign.h:377-468), fused with
+// ArrowPathToAlignment (RLE), RemoveAlignmentPrefixGaps and ComputeAlignmentStats.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, TraceArgs args) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= args.count) return;
+  const int task = args.first + idx;
+  const TaskGeometry geo = args.geo[task];
+  RefineResult res;
+  res.status = geo.status;
+  res.q_pos = res.t_pos = res.dp_score = res.n_cells = res.score = 0;
+  res.n_match = res.n_mismatch = res.n_ins = res.n_del = res.n_ops = 0;
+  res.reserved = 0;
+  res.ops_off = 0;
+  if (geo.status != 0) {
+    args.results[task] = res;
+    args.opsStart[task] = 0;
+    return;
+  }
+  const uint8_t *qSeq = batch.seq + batch.q_off[task];
+  const uint8_t *tSeq = batch.seq + batch.t_off[task];
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const int nBlocks = batch.n_blocks[task];
+  const int qStart = blocks[0], tStart = blocks[1];
+  const int Q = geo.rows;
+  const int tEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+  const uint8_t *arrows = args.arrows + args.arrowOff[task];
+  const int2 *rowTab = args.rowTab + args.rowOff[task];
+  uint32_t *arena = args.arena + args.arenaOff[task];
+  const int cap = Q + (tEnd - tStart) + 2;
+
+  int w = cap;  // ops are written backwards: arena[w .. cap) is the forward op list
+  int curType = -1, curLen = 0;
+  bool seenM = false;
+  int matchSum = 0, nMatch = 0, nMismatch = 0;
+  int r = Q, c = tEnd - 1, state = 0;  // 0 = match matrix, 1 = affine ins, 2 = affine del
+  int rowR = -1;
+  int2 row = make_int2(0, 0);
+  int status = 0;
+  int guard = 2 * cap + 8;
+  auto emit = [&](int type) {
+    if (type == curType) {
+      curLen++;
+      return;
+    }
+    if (curLen > 0) {
+      if (curType == OP_M) seenM = true;
+      if (seenM) arena[--w] = ((uint32_t)curLen << 2) | (uint32_t)curType;  // gaps behind the last block are dropped
+    }
+    curType = type;
+    curLen = 1;
+  };
+  while ((r >= 1 || c >= tStart) && guard-- > 0) {
+    if (r == 0) {
+      // deletion row: arrows are Left down to tStart-1 (:178-208)
+      emit(OP_D);
+      c--;
+      continue;
+    }
+    if (rowR != r) {
+      row = rowTab[r];
+      rowR = r;
+    }
+    const unsigned a = arrows[(unsigned)row.x + (unsigned)(c - row.y)];
+    if (state == 0) {
+      const unsigned s = a & 7u;
+      if (s == AR_DIAG) {
+        const int qc = base_code(qSeq[qStart + r - 1]);
+        const int tc = base_code(tSeq[c]);
+        matchSum += args.matrix[qc * 5 + tc];
+        if (qc == tc) nMatch++; else nMismatch++;
+        emit(OP_M);
+        r--;
+        c--;
+      } else if (s == AR_UP) {
+        emit(OP_I);
+        r--;
+      } else if (s == AR_LEFT) {
+        emit(OP_D);
+        c--;
+      } else if (s == AR_INS_CLOSE) {
+        emit(OP_I);
+        r--;
+        state = 1;
+      } else if (s == AR_DEL_CLOSE) {
+        emit(OP_D);
+        c--;
+        state = 2;
+      } else {
+        status = TASK_BAD_PATH;
+        break;
+      }
+    } else if (state == 1) {
+      if (a & 8u) {
+        emit(OP_I);
+        r--;
+      } else {
+        state = 0;
+      }
+    } else {
+      if (a & 16u) {
+        emit(OP_D);
+        c--;
+      } else {
+        state = 0;
+      }
+    }
+  }
+  if (guard <= 0) status = TASK_BAD_PATH;
+  emit(-2);  // flush the last run
+  // RemoveAlignmentPrefixGaps: leading gap runs fold into qPos / tPos
+  int leadI = 0, leadD = 0;
+  while (w < cap && (arena[w] & 3u) != OP_M) {
+    if ((arena[w] & 3u) == OP_I) leadI += (int)(arena[w] >> 2); else leadD += (int)(arena[w] >> 2);
+    w++;
+  }
+  // ComputeAlignmentScore, affine form (AlignmentUtils.h:77-100): one penalty per maximal gap run
+  int nIns = 0, nDel = 0, gapScore = 0;
+  for (int i = w; i < cap;) {
+    if ((arena[i] & 3u) == OP_M) {
+      i++;
+      continue;
+    }
+    int runLen = 0, lastType = OP_I;
+    while (i < cap && (arena[i] & 3u) != OP_M) {
+      const int len = (int)(arena[i] >> 2);
+      lastType = (int)(arena[i] & 3u);
+      if (lastType == OP_I) nIns += len; else nDel += len;
+      runLen += len;
+      i++;
+    }
+    const int linear = (lastType == OP_D ? args.del : args.ins) * runLen;
+    const int affine = runLen * args.ext + args.open;
+    gapScore += (linear < affine) ? linear : affine;
+  }
+  res.status = status;
+  res.q_pos = qStart + (w < cap ? leadI : 0);
+  res.t_pos = tStart + (w < cap ? leadD : 0);
+  res.dp_score = args.dpScore[task];
+  res.n_cells = (int32_t)geo.cells;
+  res.score = matchSum + gapScore;
+  res.n_match = nMatch;
+  res.n_mismatch = nMismatch;
+  res.n_ins = nIns;
+  res.n_del = nDel;
+  res.n_ops = cap - w;
+  args.results[task] = res;
+  args.opsStart[task] = w;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of n_ops over a range of candidates (single workgroup) and
+// the coalesced copy of each candidate's op run into the caller's arena
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_ops_kernel(RefineResult *results, int first, int count,
+                                                          int64_t capacity, int64_t *total) {
+  const int64_t base = *total;  // ops of the candidates before `first`
+  __shared__ int64_t partial[1024];
+  const int tid = threadIdx.x;
+  const int per = (count + 1023) / 1024;
+  const int lo = min(count, tid * per), hi = min(count, lo + per);
+  int64_t sum = 0;
+  for (int i = lo; i < hi; i++) sum += results[first + i].n_ops;
+  partial[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int64_t v = tid >= off ? partial[tid - off] : 0;
+    __syncthreads();
+    partial[tid] += v;
+    __syncthreads();
+  }
+  int64_t run = base + partial[tid] - sum;
+  for (int i = lo; i < hi; i++) {
+    RefineResult &r = results[first + i];
+    r.ops_off = run;
+    if (run + r.n_ops > capacity) r.status |= TASK_OPS_OVERFLOW;
+    run += r.n_ops;
+  }
+  if (tid == 1023) *total = base + partial[1023];
+}
+
+__global__ __launch_bounds__(256) void compact_ops_kernel(const RefineResult *results, int first, int count,
+                                                            const uint32_t *arena, const int64_t *arenaOff,
+                                                            const int32_t *opsStart, uint32_t *ops) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= count) return;
+  const RefineResult r = results[first + idx];
+  if (r.status & TASK_OPS_OVERFLOW) return;
+  const uint32_t *src = arena + arenaOff[first + idx] + opsStart[first + idx];
+  uint32_t *dst = ops + r.ops_off;
+  for (int i = lane; i < r.n_ops; i += 64) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------
+void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
+                     hipStream_t stream) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
+}
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, hipStream_t stream) {
+  if (args.count <= 0) return;
+  if (globalRing)
+    hipLaunchKernelGGL(fill_kernel<true>, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
+  else
+    hipLaunchKernelGGL(fill_kernel<false>, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
+}
+void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
+  if (args.count <= 0) return;
+  hipLaunchKernelGGL(traceback_kernel, dim3((args.count + 63) / 64), dim3(64), 0, stream, batch, args);
+}
+void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(scan_ops_kernel, dim3(1), dim3(1024), 0, stream, results, first, count, capacity, total);
+}
+void launch_compact_ops(const RefineResult *results, int first, int count, const uint32_t *arena,
+                        const int64_t *arenaOff, const int32_t *opsStart, uint32_t *ops, hipStream_t stream) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(compact_ops_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, results, first, count, arena,
+                     arenaOff, opsStart, ops);
+}
+
+}  // namespace blasr_hip

@@ -1,0 +1,275 @@
+"""ctypes binding of include/blasr_hip.h.
+
+Host-side mirror of the reference's refine call surface:
+
+* ``RefineBatch``  collects what RefineAlignment hands to AffineGuidedAlign per
+  candidate (alignment/Blasr.cpp:850-867): the trimmed query, the trimmed
+  target window and the candidate's SDP blocks.
+* ``Context.refine``  runs the batch on the GPU and returns, per candidate,
+  what RefineAlignment copies back (Blasr.cpp:888-914): qPos/tPos, blocks,
+  gaps, score, nCells and the statistics.
+
+No algorithm lives here -- only packing/unpacking.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblasr_hip.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+TASK_EMPTY_GUIDE, TASK_BAD_GUIDE, TASK_BAD_PATH, TASK_OPS_OVERFLOW = 1, 2, 4, 8
+OP_M, OP_I, OP_D = 0, 1, 2
+GAP_QUERY, GAP_TARGET = 0, 1  # Gap::GapSeq, AlignmentGapList.h:11
+
+EXPORTS = [
+    "blasr_hip_abi_version", "blasr_hip_create", "blasr_hip_destroy", "blasr_hip_last_error",
+    "blasr_hip_set_workspace_limit", "blasr_hip_stream", "blasr_hip_refine_device", "blasr_hip_refine_host",
+    "blasr_hip_refine_last_timing",
+]
+
+# SMRTDistanceMatrix (ScoreMatrices.h:22-28): the matrix Blasr.cpp installs at :807-809
+SMRT_MATRIX = np.array(
+    [[-5, 6, 6, 6, 0], [6, -5, 6, 6, 0], [6, 6, -5, 6, 0], [6, 6, 6, -5, 0], [0, 0, 0, 0, 0]], dtype=np.int32)
+
+
+class BlasrHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("blasr_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class _ScoreParams(C.Structure):
+    _fields_ = [("matrix", C.c_int32 * 25), ("ins", C.c_int32), ("del_", C.c_int32),
+                ("affine_open", C.c_int32), ("affine_extend", C.c_int32)]
+
+
+class _RefineBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("blocks", C.c_void_p), ("blk_off", C.c_void_p),
+                ("n_blocks", C.c_void_p)]
+
+
+RESULT_DTYPE = np.dtype([
+    ("status", "<i4"), ("q_pos", "<i4"), ("t_pos", "<i4"), ("dp_score", "<i4"), ("n_cells", "<i4"),
+    ("score", "<i4"), ("n_match", "<i4"), ("n_mismatch", "<i4"), ("n_ins", "<i4"), ("n_del", "<i4"),
+    ("n_ops", "<i4"), ("reserved", "<i4"), ("ops_off", "<i8")])
+assert RESULT_DTYPE.itemsize == 56
+
+
+class ScoreParams:
+    """InitializeScoreFunction + SMRTDistanceMatrix defaults (MappingParameters.h:587-592, :338-342)."""
+
+    def __init__(self, matrix=None, ins=5, dele=5, affine_open=50, affine_extend=0):
+        self.matrix = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(5, 5)
+        self.ins, self.dele, self.affine_open, self.affine_extend = ins, dele, affine_open, affine_extend
+
+    def as_struct(self):
+        s = _ScoreParams()
+        for i, v in enumerate(self.matrix.reshape(-1)):
+            s.matrix[i] = int(v)
+        s.ins, s.del_, s.affine_open, s.affine_extend = self.ins, self.dele, self.affine_open, self.affine_extend
+        return s
+
+
+_lib = None
+
+
+def load_library():
+    """Load libblasr_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BlasrHipError(ERR_NO_DEVICE, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                                % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.blasr_hip_last_error.restype = C.c_char_p
+        lib.blasr_hip_stream.restype = C.c_void_p
+        for name in ("blasr_hip_refine_device", "blasr_hip_refine_host"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_RefineBatch), C.c_int32, C.POINTER(_ScoreParams),
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.blasr_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.blasr_hip_destroy.argtypes = [C.c_void_p]
+        lib.blasr_hip_last_error.argtypes = [C.c_void_p]
+        lib.blasr_hip_stream.argtypes = [C.c_void_p]
+        lib.blasr_hip_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
+        lib.blasr_hip_refine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        _lib = lib
+    return _lib
+
+
+class RefineBatch:
+    """Structure-of-arrays batch of refine candidates (host memory)."""
+
+    def __init__(self):
+        self._seq, self._blocks = [], []
+        self.q_off, self.q_len, self.t_off, self.t_len, self.blk_off, self.n_blocks = [], [], [], [], [], []
+        self._seq_bytes = 0
+        self._n_blocks = 0
+
+    def __len__(self):
+        return len(self.q_off)
+
+    def add(self, query, target, guide_blocks):
+        """query/target: ASCII uint8 arrays (already trimmed as Blasr.cpp:850-859 does);
+        guide_blocks: (n,3) int array of (qPos, tPos, length)."""
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        t = np.ascontiguousarray(target, dtype=np.uint8)
+        b = np.ascontiguousarray(guide_blocks, dtype=np.int32).reshape(-1, 3)
+        self.q_off.append(self._seq_bytes)
+        self.q_len.append(len(q))
+        self._seq_bytes += len(q)
+        self.t_off.append(self._seq_bytes)
+        self.t_len.append(len(t))
+        self._seq_bytes += len(t)
+        self._seq += [q, t]
+        self.blk_off.append(self._n_blocks)
+        self.n_blocks.append(len(b))
+        self._n_blocks += len(b)
+        self._blocks.append(b)
+
+    def arrays(self):
+        seq = np.concatenate(self._seq) if self._seq else np.zeros(0, np.uint8)
+        blocks = np.concatenate(self._blocks).reshape(-1) if self._blocks else np.zeros(0, np.int32)
+        return dict(seq=np.ascontiguousarray(seq), q_off=np.array(self.q_off, np.int64),
+                    q_len=np.array(self.q_len, np.int32), t_off=np.array(self.t_off, np.int64),
+                    t_len=np.array(self.t_len, np.int32), blocks=np.ascontiguousarray(blocks, dtype=np.int32),
+                    blk_off=np.array(self.blk_off, np.int64), n_blocks=np.array(self.n_blocks, np.int32))
+
+    def ops_bound(self):
+        """Upper bound of ops: a path has at most qLen + tLen steps."""
+        return int(sum(self.q_len) + sum(self.t_len) + 2 * len(self))
+
+
+class RefineResult:
+    """One refined candidate, in the reference's own terms."""
+
+    def __init__(self, rec, ops):
+        self.status = int(rec["status"])
+        self.qPos, self.tPos = int(rec["q_pos"]), int(rec["t_pos"])
+        self.dpScore, self.nCells, self.score = int(rec["dp_score"]), int(rec["n_cells"]), int(rec["score"])
+        self.nMatch, self.nMismatch = int(rec["n_match"]), int(rec["n_mismatch"])
+        self.nIns, self.nDel = int(rec["n_ins"]), int(rec["n_del"])
+        self.ops = ops  # uint32 array, (len << 2) | type
+
+    @property
+    def pctSimilarity(self):
+        # AlignmentUtils.h:566-577: nMatch*2.0 / (2 * alignment columns) * 100, stored as float
+        cols = self.nMatch + self.nMismatch + self.nIns + self.nDel
+        if cols == 0:
+            return np.float32(0)
+        return np.float32((self.nMatch * 2.0) / (cols + cols) * 100)
+
+    def blocks_and_gaps(self):
+        """Rebuild Alignment.blocks / Alignment.gaps (Alignment.h:190-254 conventions):
+        blocks relative to (qPos,tPos); gaps[0] empty, gaps[i+1] between block i and i+1,
+        last list empty."""
+        blocks, gap_counts, gap_items = [], [0], []
+        q = t = 0
+        types, lens = self.ops & 3, self.ops >> 2
+        for ty, ln in zip(types.tolist(), lens.tolist()):
+            if ty == OP_M:
+                blocks.append((q, t, ln))
+                gap_counts.append(0)
+                q += ln
+                t += ln
+            elif ty == OP_I:
+                gap_items.append((GAP_TARGET, ln))
+                gap_counts[-1] += 1
+                q += ln
+            else:
+                gap_items.append((GAP_QUERY, ln))
+                gap_counts[-1] += 1
+                t += ln
+        if not blocks:
+            gap_counts = [0] if self.status == 0 else []
+        return (np.array(blocks, np.int32).reshape(-1, 3), np.array(gap_counts, np.int32),
+                np.array(gap_items, np.int32).reshape(-1, 2))
+
+    def as_dict(self):
+        blocks, gc, gi = self.blocks_and_gaps()
+        return dict(qPos=self.qPos, tPos=self.tPos, dpScore=self.dpScore, nCells=self.nCells, score=self.score,
+                    nMatch=self.nMatch, nMismatch=self.nMismatch, nIns=self.nIns, nDel=self.nDel,
+                    pct=float(self.pctSimilarity), blocks=blocks, gapCounts=gc, gapItems=gi)
+
+
+class Context:
+    """One blasr_hip_ctx (one per host thread, like MappingBuffers)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.blasr_hip_create(device, C.byref(h))
+        if rc != OK:
+            raise BlasrHipError(rc, "blasr_hip_create(device=%d) failed: no usable gfx950 device" % device)
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.blasr_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != OK and rc not in allow:
+            raise BlasrHipError(rc, self.lib.blasr_hip_last_error(self.handle).decode())
+
+    @property
+    def stream(self):
+        return self.lib.blasr_hip_stream(self.handle)
+
+    def set_workspace_limit(self, nbytes):
+        self._check(self.lib.blasr_hip_set_workspace_limit(self.handle, int(nbytes)))
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int64 * 3)()
+        self._check(self.lib.blasr_hip_refine_last_timing(self.handle, ms, cnt))
+        return dict(geometry_ms=ms[0], fill_ms=ms[1], traceback_ms=ms[2], compact_ms=ms[3], cells=cnt[0],
+                    fill_bytes=cnt[1], fill_launches=cnt[2])
+
+    def refine(self, batch, band=16, score=None, ops_capacity=None):
+        """RefineAlignments for a host batch; returns a list of RefineResult."""
+        score = score or ScoreParams()
+        n = len(batch)
+        if n == 0:
+            return []
+        a = batch.arrays()
+        sb = _RefineBatch()
+        sb.n = n
+        for k in ("seq", "q_off", "q_len", "t_off", "t_len", "blocks", "blk_off", "n_blocks"):
+            setattr(sb, k, a[k].ctypes.data)
+        cap = batch.ops_bound() if ops_capacity is None else int(ops_capacity)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        ops = np.zeros(max(cap, 1), dtype=np.uint32)
+        used = C.c_int64(0)
+        sc = score.as_struct()
+        rc = self.lib.blasr_hip_refine_host(self.handle, C.byref(sb), band, C.byref(sc), results.ctypes.data,
+                                            ops.ctypes.data, cap, C.byref(used))
+        self._check(rc)
+        out = []
+        for i in range(n):
+            r = results[i]
+            o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
+            out.append(RefineResult(r, o))
+        return out
+
+    def refine_device(self, dev_ptrs, n, band, score, results_ptr, ops_ptr, ops_capacity):
+        """Device-resident variant: dev_ptrs maps the blasr_hip_refine_batch field names to raw
+        device addresses (e.g. torch tensors' data_ptr()).  Returns ops used."""
+        sb = _RefineBatch()
+        sb.n = n
+        for k in ("seq", "q_off", "q_len", "t_off", "t_len", "blocks", "blk_off", "n_blocks"):
+            setattr(sb, k, int(dev_ptrs[k]))
+        used = C.c_int64(0)
+        sc = score.as_struct()
+        rc = self.lib.blasr_hip_refine_device(self.handle, C.byref(sb), band, C.byref(sc), C.c_void_p(results_ptr),
+                                              C.c_void_p(ops_ptr), int(ops_capacity), C.byref(used))
+        self._check(rc)
+        return used.value

@@ -1,0 +1,162 @@
+/* blasr_hip.h -- C ABI of the MI355X refine stage (libblasr_hip.so).
+ *
+ * The reference (mchaisso/blasr) has no FFI: its refine stage is a set of
+ * header templates instantiated inside alignment/Blasr.cpp and called once per
+ * candidate interval from one pthread.  This library replaces exactly those
+ * calls with batch entry points, so that N host threads (or one driver) hand
+ * over ARRAYS of candidates:
+ *
+ *   blasr_hip_refine_*      replaces the body of RefineAlignment's guided
+ *                           branch, alignment/Blasr.cpp:850-914, i.e.
+ *                           AffineGuidedAlign (AffineGuidedAlign.h:561-578 ->
+ *                           :31-488) + ComputeAlignmentStats
+ *                           (AlignmentUtils.h:535-584), called per candidate
+ *                           by RefineAlignments (Blasr.cpp:2164-2181)
+ *   blasr_hip_sdp_*         replaces SDPAlign + ComputeAlignmentStats in
+ *                           AlignIntervals, alignment/Blasr.cpp:1716-1724
+ *
+ * Conventions: plain C, fixed-width integers, no STL/torch types; every
+ * function returns a status (0 = ok, < 0 = error, see blasr_hip_status);
+ * per-candidate problems are reported in the result record's `status`, never
+ * by abort()/exit() as the reference does.  One context per host thread: a
+ * context owns a HIP stream and a grow-only device workspace (the analogue of
+ * the per-thread MappingBuffers, Blasr.cpp:318-369).  There is NO CPU
+ * fallback: every entry point fails with BLASR_HIP_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ *
+ * Sequences are ASCII, one byte per base, as the reference's DNASequence
+ * (DNASequence.h:16-24).  A/C/G/T (either case) are codes 0..3, everything
+ * else is N (code 4); score matrices are indexed [query code][target code]
+ * like DistanceMatrixScoreFunction::Match (DistanceMatrixScoreFunction.h:99-104).
+ */
+#ifndef BLASR_HIP_H_
+#define BLASR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLASR_HIP_ABI_VERSION 1
+
+typedef struct blasr_hip_ctx blasr_hip_ctx;
+
+enum blasr_hip_status {
+  BLASR_HIP_OK = 0,
+  BLASR_HIP_ERR_INVALID = -1,     /* bad argument */
+  BLASR_HIP_ERR_NO_DEVICE = -2,   /* no usable gfx950 device */
+  BLASR_HIP_ERR_HIP = -3,         /* a HIP runtime call failed (see blasr_hip_last_error) */
+  BLASR_HIP_ERR_NOMEM = -4,       /* device workspace could not grow */
+  BLASR_HIP_ERR_UNSUPPORTED = -5, /* parameters outside the kernel's domain */
+  BLASR_HIP_ERR_CAPACITY = -6     /* caller-provided output arena too small */
+};
+
+/* per-candidate status bits in result records */
+enum {
+  BLASR_HIP_TASK_OK = 0,
+  BLASR_HIP_TASK_EMPTY_GUIDE = 1, /* no guide blocks: the reference returns 0 and leaves the
+                                     candidate untouched (AffineGuidedAlign.h:151-155) */
+  BLASR_HIP_TASK_BAD_GUIDE = 2,   /* guide blocks not monotone / outside the sequences: the
+                                     reference would run off its buffers or assert */
+  BLASR_HIP_TASK_BAD_PATH = 4,    /* traceback met NoArrow: reference prints "path has gone
+                                     awry" and exit(1)s (AffineGuidedAlign.h:394-408) */
+  BLASR_HIP_TASK_OPS_OVERFLOW = 8 /* ops arena exhausted; counts are valid, ops are not */
+};
+
+/* DistanceMatrixScoreFunction + BaseScoreFunction fields that reach the
+ * kernels (DistanceMatrixScoreFunction.h:10-46, BaseScoreFunction.h:4-26). */
+typedef struct blasr_hip_score_params {
+  int32_t matrix[25]; /* [query][target], codes A C G T N; default SMRTDistanceMatrix */
+  int32_t ins;        /* params.insertion  (5)  */
+  int32_t del;        /* params.deletion   (5)  */
+  int32_t affine_open;   /* params.affineOpen   (50) */
+  int32_t affine_extend; /* params.affineExtend (0)  */
+} blasr_hip_score_params;
+
+/* A batch of refine candidates, structure-of-arrays.  For candidate i:
+ *   query  = seq[q_off[i] .. q_off[i]+q_len[i])   (qSeq  of Blasr.cpp:856-859)
+ *   target = seq[t_off[i] .. t_off[i]+t_len[i])   (tSeq  of Blasr.cpp:850-853)
+ *   guide  = blocks[3*blk_off[i] .. ) n_blocks[i] triplets (qPos,tPos,length),
+ *            the candidate's Alignment.blocks in the coordinates of query/target
+ * All pointers are DEVICE pointers for the *_device entry points and HOST
+ * pointers for the *_host ones. */
+typedef struct blasr_hip_refine_batch {
+  int32_t n;
+  const uint8_t *seq;
+  const int64_t *q_off;
+  const int32_t *q_len;
+  const int64_t *t_off;
+  const int32_t *t_len;
+  const int32_t *blocks;
+  const int64_t *blk_off;
+  const int32_t *n_blocks;
+} blasr_hip_refine_batch;
+
+/* One record per candidate: everything RefineAlignment copies back into the
+ * T_AlignmentCandidate (Blasr.cpp:888-914).  The base-by-base alignment is
+ * returned as run-length ops (see below) from which blocks[] and gaps[][] are
+ * rebuilt 1:1. */
+typedef struct blasr_hip_refine_result {
+  int32_t status;     /* BLASR_HIP_TASK_* bits */
+  int32_t q_pos;      /* refinedAlignment.qPos (after RemoveAlignmentPrefixGaps) */
+  int32_t t_pos;      /* refinedAlignment.tPos */
+  int32_t dp_score;   /* value AffineGuidedAlign returns: S[qEnd-1][tEnd-1] */
+  int32_t n_cells;    /* alignment.nCells (AffineGuidedAlign.h:470) */
+  int32_t score;      /* ComputeAlignmentStats score (affine form) -- the printed one */
+  int32_t n_match;
+  int32_t n_mismatch;
+  int32_t n_ins;
+  int32_t n_del;
+  int32_t n_ops;      /* number of ops of this candidate */
+  int32_t reserved;
+  int64_t ops_off;    /* first op of this candidate in the ops arena */
+} blasr_hip_refine_result;
+
+/* op = (length << 2) | type; forward order, first and last op are always M. */
+enum { BLASR_HIP_OP_M = 0, /* block: `length` aligned columns */
+       BLASR_HIP_OP_I = 1, /* Gap::Target, arrow Up: `length` query bases unaligned */
+       BLASR_HIP_OP_D = 2  /* Gap::Query, arrow Left: `length` target bases unaligned */ };
+#define BLASR_HIP_OP_TYPE(op) ((op) & 3u)
+#define BLASR_HIP_OP_LEN(op) ((op) >> 2)
+
+/* ---- context ---------------------------------------------------------- */
+int blasr_hip_abi_version(void);
+/* Creates a context on HIP device `device`; fails unless it is a gfx950. */
+int blasr_hip_create(int device, blasr_hip_ctx **ctx);
+int blasr_hip_destroy(blasr_hip_ctx *ctx);
+/* Human-readable text of the last failure on this context (never NULL). */
+const char *blasr_hip_last_error(const blasr_hip_ctx *ctx);
+/* Upper bound for the grow-only device workspace, bytes (default 48 GiB);
+ * larger batches are processed in several waves of kernels. */
+int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes);
+/* The context's stream as a hipStream_t (void* to keep HIP out of this header). */
+void *blasr_hip_stream(blasr_hip_ctx *ctx);
+
+/* ---- refine: AffineGuidedAlign + ComputeAlignmentStats ---------------- */
+/* band = params.bandSize (16 after MakeSane, MappingParameters.h).
+ * results: n records; ops: arena of ops_capacity uint32; *ops_used receives
+ * the number of ops written (host pointer, may be NULL).  Supported domain:
+ * affine_open >= 0, del >= affine_extend >= 0 (else ERR_UNSUPPORTED).
+ * Device variant: batch pointers, results and ops are device memory; work is
+ * enqueued on the context's stream and completed before return. */
+int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *batch, int32_t band,
+                            const blasr_hip_score_params *score,
+                            blasr_hip_refine_result *results, uint32_t *ops,
+                            int64_t ops_capacity, int64_t *ops_used);
+/* Host variant: uploads the batch, runs the device variant, downloads. */
+int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *batch, int32_t band,
+                          const blasr_hip_score_params *score, blasr_hip_refine_result *results,
+                          uint32_t *ops, int64_t ops_capacity, int64_t *ops_used);
+
+/* Timing of the kernels of the last refine call on this context, measured
+ * with HIP events on the context's stream: ms[0] = guide geometry,
+ * ms[1] = band fill (dominant), ms[2] = traceback+stats, ms[3] = op compaction;
+ * counters[0] = band cells filled, counters[1] = algorithmic bytes of the fill
+ * (DESIGN.md), counters[2] = fill kernel launches. */
+int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

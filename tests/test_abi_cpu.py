@@ -1,0 +1,80 @@
+"""CPU-side checks of the C ABI: the shared library loads, exports every symbol
+include/blasr_hip.h declares, and refuses to run without a gfx950 device (there
+is no CPU fallback to fall into)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blasr_amd
+from blasr_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "blasr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blasr_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = blasr_amd.load_library()
+    names = _declared_functions()
+    assert len(names) >= 9
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(hip.EXPORTS) == names
+    assert lib.blasr_hip_abi_version() == 1
+
+
+def test_result_record_layout_matches_header():
+    text = open(os.path.join(ROOT, "include", "blasr_hip.h")).read()
+    body = text[text.index("typedef struct blasr_hip_refine_result {"):text.index("} blasr_hip_refine_result;")]
+    fields = re.findall(r"int(32|64)_t\s+([a-z_]+);", body)
+    assert [f[1] for f in fields] == list(hip.RESULT_DTYPE.names)
+    assert sum(int(f[0]) // 8 for f in fields) == hip.RESULT_DTYPE.itemsize
+
+
+def test_no_device_is_a_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(blasr_amd.BlasrHipError) as e:
+        blasr_amd.Context(0)
+    assert e.value.code == hip.ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped path must not import, link or shell out to oracle/."""
+    pkg = os.path.join(ROOT, "blasr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                code = "\n".join(l for l in src.splitlines() if "never imports" not in l and "no CPU" not in l)
+                assert "libblasr_oracle" not in code and "blasr_oracle.h" not in code, f
+                assert "oracle/" not in code or f == "__init__.py", f
+
+
+def test_batch_packing_roundtrip():
+    b = blasr_amd.RefineBatch()
+    b.add(np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ACGTT", np.uint8), [[0, 0, 4]])
+    b.add(np.frombuffer(b"GG", np.uint8), np.frombuffer(b"GGA", np.uint8), [[0, 0, 1], [1, 1, 1]])
+    a = b.arrays()
+    assert a["seq"].tobytes() == b"ACGTACGTTGGGGA"
+    assert a["q_off"].tolist() == [0, 9] and a["t_off"].tolist() == [4, 11]
+    assert a["blk_off"].tolist() == [0, 1] and a["n_blocks"].tolist() == [1, 2]
+    assert a["blocks"].tolist() == [0, 0, 4, 0, 0, 1, 1, 1, 1]
+    assert b.ops_bound() == 4 + 5 + 2 + 3 + 4
+
+
+def test_ops_decode_to_blocks_and_gaps():
+    rec = np.zeros(1, dtype=hip.RESULT_DTYPE)[0]
+    ops = np.array([(5 << 2) | 0, (2 << 2) | 1, (1 << 2) | 2, (3 << 2) | 0], dtype=np.uint32)
+    blocks, gc, gi = blasr_amd.RefineResult(rec, ops).blocks_and_gaps()
+    assert blocks.tolist() == [[0, 0, 5], [7, 6, 3]]
+    assert gc.tolist() == [0, 2, 0]
+    assert gi.tolist() == [[hip.GAP_TARGET, 2], [hip.GAP_QUERY, 1]]

@@ -1,0 +1,160 @@
+"""Parity of the HIP refine path (through the C ABI) with the reference:
+golden vectors made by the reference itself and randomised comparison with the
+CPU oracle.  Bit-exact: every field, every block, every gap."""
+import numpy as np
+import pytest
+
+import blasr_amd
+from blasr_amd import hip, synth
+from blasr_testlib import SMRT_MATRIX
+from golden_cases import REFINE_KEYS, first_difference, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = blasr_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _score(sc):
+    return blasr_amd.ScoreParams(sc.matrix, sc.ins, sc.dele, sc.affine_open, sc.affine_extend)
+
+
+def test_golden_vectors_one_by_one(ctx, golden):
+    n = 0
+    for c in golden_cases(golden):
+        if not c.has_refine:
+            continue
+        b = blasr_amd.RefineBatch()
+        b.add(c.qs, c.ts, c.sdp_blocks)
+        got = ctx.refine(b, band=c.band, score=_score(c.sc))[0]
+        assert got.status == 0, c.name
+        assert first_difference(got.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
+        n += 1
+    assert n >= 18
+
+
+def test_golden_vectors_as_one_batch(ctx, golden):
+    cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
+             and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
+    b = blasr_amd.RefineBatch()
+    for c in cases:
+        b.add(c.qs, c.ts, c.sdp_blocks)
+    for c, got in zip(cases, ctx.refine(b)):
+        assert first_difference(got.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
+
+
+def test_chunked_workspace_gives_identical_results(golden):
+    cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
+             and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
+    b = blasr_amd.RefineBatch()
+    for c in cases:
+        b.add(c.qs, c.ts, c.sdp_blocks)
+    small = blasr_amd.Context(0)
+    small.set_workspace_limit(8 << 20)  # forces several kernel waves
+    got = small.refine(b)
+    assert small.last_timing()["fill_launches"] > 1
+    for c, g in zip(cases, got):
+        assert first_difference(g.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
+    small.close()
+
+
+def test_random_pairs_against_oracle(ctx, oracle):
+    rng = np.random.default_rng(101)
+    b, want = blasr_amd.RefineBatch(), []
+    for it in range(48):
+        kind = it % 6
+        big = {1: ("ins", int(rng.integers(100, 700))), 2: ("del", int(rng.integers(100, 1400)))}.get(kind)
+        nrun = int(rng.integers(5, 60)) if kind == 3 else None
+        flank = (0, 0) if kind == 4 else (0, 200)
+        er = dict(ins=0.0, dele=0.0, sub=0.0) if kind == 5 else dict(ins=0.11, dele=0.04, sub=0.01)
+        q, t = synth.make_pair(rng, int(rng.integers(100, 5000)), flank=flank, big_indel=big, n_run=nrun, **er)
+        s = oracle.sdp_align(q, t)
+        if len(s["blocks"]) == 0:
+            continue
+        bl = s["blocks"]
+        qs = q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]]
+        ts = t[s["tPos"]: s["tPos"] + bl[-1, 1] + bl[-1, 2]]
+        b.add(qs, ts, bl)
+        want.append(oracle.affine_guided_align(qs, ts, bl))
+    got = ctx.refine(b)
+    assert len(got) == len(want) >= 40
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.status == 0, i
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
+
+
+def test_parameter_variety_against_oracle(ctx, oracle):
+    """Absolute guides (tStart != 0), several bands, asymmetric matrices, gap costs."""
+    rng = np.random.default_rng(102)
+    for it in range(40):
+        q, t = synth.make_pair(rng, int(rng.integers(30, 1500)), flank=(0, int(rng.integers(0, 100))),
+                               ins=float(rng.uniform(0, 0.15)), dele=float(rng.uniform(0, 0.1)),
+                               sub=float(rng.uniform(0, 0.05)))
+        m = SMRT_MATRIX.copy()
+        if it % 3 == 0:
+            m = rng.integers(-6, 8, size=(5, 5)).astype(np.int32)
+            m[np.arange(4), np.arange(4)] = -rng.integers(1, 8, size=4)
+        ext = int(rng.integers(0, 3))
+        sc = blasr_amd.ScoreParams(m, ins=int(rng.integers(1, 9)), dele=int(rng.integers(ext, 9)),
+                                   affine_open=int(rng.integers(0, 60)), affine_extend=ext)
+        from blasr_testlib import ScoreParams as OSc
+        osc = OSc(m, sc.ins, sc.dele, sc.affine_open, sc.affine_extend)
+        s = oracle.sdp_align(q, t, osc)
+        if len(s["blocks"]) == 0:
+            continue
+        bl = s["blocks"].copy()
+        bl[:, 0] += s["qPos"]
+        bl[:, 1] += s["tPos"]
+        band = int(rng.choice([4, 16, 30]))
+        b = blasr_amd.RefineBatch()
+        b.add(q, t, bl)
+        got = ctx.refine(b, band=band, score=sc)[0]
+        want = oracle.affine_guided_align(q, t, bl, osc, band)
+        assert got.status == 0
+        assert first_difference(got.as_dict(), want, REFINE_KEYS) is None, it
+
+
+def test_long_reads_against_oracle(ctx, oracle):
+    rng = np.random.default_rng(103)
+    b, want = blasr_amd.RefineBatch(), []
+    for qlen, er in ((10000, dict(ins=0.11, dele=0.04, sub=0.01)), (30000, dict(ins=0.10, dele=0.05, sub=0.01))):
+        q, t = synth.make_pair(rng, qlen, flank=(0, 500), **er)
+        s = oracle.sdp_align(q, t)
+        bl = s["blocks"]
+        qs = q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]]
+        ts = t[s["tPos"]: s["tPos"] + bl[-1, 1] + bl[-1, 2]]
+        b.add(qs, ts, bl)
+        want.append(oracle.affine_guided_align(qs, ts, bl))
+    for g, w in zip(ctx.refine(b), want):
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None
+
+
+def test_degenerate_candidates(ctx):
+    b = blasr_amd.RefineBatch()
+    acgt = np.frombuffer(b"ACGTACGTACGTACGTAAAA", np.uint8)
+    b.add(acgt, acgt, np.zeros((0, 3), np.int32))         # empty guide (AffineGuidedAlign.h:151-155)
+    b.add(acgt, acgt, [[0, 0, 8], [4, 9, 4]])             # overlapping blocks in q
+    b.add(acgt, acgt, [[0, 0, 30]])                       # runs past both sequences
+    b.add(acgt, acgt, [[0, 0, 20]])                       # fine: one block
+    got = ctx.refine(b)
+    assert got[0].status == hip.TASK_EMPTY_GUIDE and len(got[0].ops) == 0
+    assert got[1].status == hip.TASK_BAD_GUIDE
+    assert got[2].status == hip.TASK_BAD_GUIDE
+    assert got[3].status == 0 and got[3].nMatch == 20 and got[3].score == -100 and got[3].dpScore == -100
+    assert got[3].ops.tolist() == [(20 << 2) | hip.OP_M]
+
+
+def test_unsupported_gap_costs_are_rejected(ctx):
+    b = blasr_amd.RefineBatch()
+    acgt = np.frombuffer(b"ACGTACGTACGT", np.uint8)
+    b.add(acgt, acgt, [[0, 0, 12]])
+    with pytest.raises(blasr_amd.BlasrHipError) as e:
+        ctx.refine(b, score=blasr_amd.ScoreParams(dele=1, affine_extend=3))
+    assert e.value.code == hip.ERR_UNSUPPORTED
+    with pytest.raises(blasr_amd.BlasrHipError) as e:
+        ctx.refine(b, ops_capacity=0)
+    assert e.value.code == hip.ERR_CAPACITY
