@@ -246,8 +246,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   plan.arrowOff.resize(n);
   plan.rowOff.resize(n);
   plan.arenaOff.resize(n);
-  const size_t budget = (size_t)ctx->workspaceLimit > fixedBytes + (64u << 20) ? (size_t)ctx->workspaceLimit - fixedBytes
-                                                                                : (64u << 20);
+  const size_t budget = (size_t)ctx->workspaceLimit > fixedBytes + (1u << 20) ? (size_t)ctx->workspaceLimit - fixedBytes
+                                                                               : (1u << 20);
   {
     Plan::Chunk cur;
     cur.first = 0;

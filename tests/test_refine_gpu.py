@@ -54,7 +54,7 @@ def test_chunked_workspace_gives_identical_results(golden):
     for c in cases:
         b.add(c.qs, c.ts, c.sdp_blocks)
     small = blasr_amd.Context(0)
-    small.set_workspace_limit(8 << 20)  # forces several kernel waves
+    small.set_workspace_limit(3 << 20)  # forces several kernel waves
     got = small.refine(b)
     assert small.last_timing()["fill_launches"] > 1
     for c, g in zip(cases, got):
