@@ -112,3 +112,108 @@ def make_pair(rng, qlen, ins=0.11, dele=0.04, sub=0.01, flank=(0, 200), big_inde
         at = int(rng.integers(0, max(1, len(target) - n_run)))
         target[at:at + n_run] = ord("N")
     return np.ascontiguousarray(read), np.ascontiguousarray(target)
+
+
+# ---------------------------------------------------------------------------
+# Bulk workload for bench.py (torch, runs on the GPU so that 1 Gbase of reads
+# is generated in seconds; the same code runs on CPU tensors for the tests).
+# ---------------------------------------------------------------------------
+def make_refine_workload(n_reads, read_len, seed, device, genome_len=ECOLI_K12_LENGTH, ins=0.11, dele=0.04,
+                         sub=0.01, slab=4096):
+    """Refine-stage inputs for `n_reads` synthetic PacBio-like reads.
+
+    Per read: a `read_len` window of an i.i.d. genome (either strand) is pushed
+    through the error channel of `mutate`.  The candidate handed to the refine
+    stage is what RefineAlignment builds at alignment/Blasr.cpp:850-859: query
+    and target trimmed to the extent of the guide, guide blocks relative to the
+    first block.  The guide is the simulated alignment itself (every ungapped
+    run of the true path is one block), i.e. the block structure SDPAlign +
+    SWAlign gap filling recovers; bench.py states this in its `data` field.
+
+    Returns a dict of torch tensors laid out as blasr_hip_refine_batch wants:
+    seq (uint8 pool), q_off/t_off (int64), q_len/t_len (int32), blocks (int32,
+    3 per block), blk_off (int64), n_blocks (int32).
+    """
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.int64, device=device)
+    genome = torch.randint(0, 4, (genome_len,), generator=gen, device=device, dtype=torch.int64)
+    q_parts, t_parts, blk_parts = [], [], []
+    q_len_all, t_len_all, nblk_all = [], [], []
+    L = read_len
+    ar = torch.arange(L, device=device)
+    for s0 in range(0, n_reads, slab):
+        n = min(slab, n_reads - s0)
+        pos = torch.randint(0, genome_len - L, (n,), generator=gen, device=device)
+        strand = torch.randint(0, 2, (n,), generator=gen, device=device)
+        idx = pos[:, None] + ar[None, :]
+        idx = torch.where(strand[:, None] == 1, pos[:, None] + (L - 1 - ar)[None, :], idx)
+        tmpl = genome[idx]
+        tmpl = torch.where(strand[:, None] == 1, comp[tmpl], tmpl)  # [n, L] codes 0..3
+        u = torch.rand((n, L), generator=gen, device=device)
+        keep = u >= dele
+        do_sub = keep & (u < dele + sub)
+        shift = torch.randint(1, 4, (n, L), generator=gen, device=device)
+        base = torch.where(do_sub, (tmpl + shift) & 3, tmpl)
+        if ins > 0:
+            v = torch.rand((n, L), generator=gen, device=device).clamp_min(1e-12)
+            k = torch.floor(torch.log(v) / np.log(ins)).to(torch.int64)  # P(K >= j) = ins**j
+        else:
+            k = torch.zeros((n, L), dtype=torch.int64, device=device)
+        emit = keep.to(torch.int64) + k
+        qpos = torch.cumsum(emit, dim=1) - emit  # read position of each kept template base
+        rlen = emit.sum(dim=1)
+        # ungapped runs of kept bases
+        prev_ok = torch.zeros_like(keep)
+        prev_ok[:, 1:] = keep[:, :-1] & (k[:, :-1] == 0)
+        start = keep & ~prev_ok
+        nxt_ok = torch.zeros_like(keep)
+        nxt_ok[:, :-1] = keep[:, 1:] & (k[:, :-1] == 0)
+        end = keep & ~nxt_ok
+        nblk = start.sum(dim=1)
+        srow, scol = torch.nonzero(start, as_tuple=True)
+        erow, ecol = torch.nonzero(end, as_tuple=True)
+        bq = qpos[srow, scol]
+        bt = scol
+        bl = ecol - scol + 1
+        # trim to the guide extent: first block start .. last block end (Blasr.cpp:850-859)
+        blk_off = torch.cumsum(nblk, 0) - nblk
+        first_q, first_t = bq[blk_off], bt[blk_off]
+        last = blk_off + nblk - 1
+        last_qe, last_te = bq[last] + bl[last], bt[last] + bl[last]
+        q_len = last_qe - first_q
+        t_len = last_te - first_t
+        # read pool of this slab
+        roff = torch.cumsum(rlen, 0) - rlen
+        total = int(rlen.sum())
+        reads = torch.randint(0, 4, (total,), generator=gen, device=device)
+        krow, kcol = torch.nonzero(keep, as_tuple=True)
+        reads[roff[krow] + qpos[krow, kcol]] = base[krow, kcol]
+        # gather the trimmed query / target slices
+        qo = torch.cumsum(q_len, 0) - q_len
+        qi = torch.repeat_interleave(roff + first_q - qo, q_len) + torch.arange(int(q_len.sum()), device=device)
+        q_parts.append(acgt[reads[qi]])
+        to = torch.cumsum(t_len, 0) - t_len
+        rows = torch.repeat_interleave(torch.arange(n, device=device), t_len)
+        cols = torch.arange(int(t_len.sum()), device=device) - torch.repeat_interleave(to - first_t, t_len)
+        t_parts.append(acgt[tmpl[rows, cols]])
+        brow = srow
+        blk_parts.append(torch.stack([bq - first_q[brow], bt - first_t[brow], bl], dim=1).to(torch.int32))
+        q_len_all.append(q_len)
+        t_len_all.append(t_len)
+        nblk_all.append(nblk)
+    q_len = torch.cat(q_len_all)
+    t_len = torch.cat(t_len_all)
+    nblk = torch.cat(nblk_all)
+    qpool, tpool = torch.cat(q_parts), torch.cat(t_parts)
+    q_off = torch.cumsum(q_len, 0) - q_len
+    t_off = torch.cumsum(t_len, 0) - t_len + qpool.numel()
+    return dict(seq=torch.cat([qpool, tpool]).contiguous(), q_off=q_off.to(torch.int64).contiguous(),
+                q_len=q_len.to(torch.int32).contiguous(), t_off=t_off.to(torch.int64).contiguous(),
+                t_len=t_len.to(torch.int32).contiguous(),
+                blocks=torch.cat(blk_parts).reshape(-1).contiguous(),
+                blk_off=(torch.cumsum(nblk, 0) - nblk).to(torch.int64).contiguous(),
+                n_blocks=nblk.to(torch.int32).contiguous())
