@@ -332,6 +332,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   HIP_TRY(ctx, hipMemsetAsync(dTotal, 0, sizeof(int64_t), st));
   HIP_TRY(ctx, hipMemsetAsync(dDp, 0, sizeof(int32_t) * n, st));
 
+  bool packedMatrix = true;  // every entry fits a signed byte -> packed row lookup in the fill kernel
+  for (int i = 0; i < 25; i++) packedMatrix = packedMatrix && score->matrix[i] >= -128 && score->matrix[i] <= 127;
   RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
   float msFill = 0, msTrace = 0, msCompact = 0;
   for (auto &c : plan.chunks) {
@@ -368,7 +370,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRingSize = dWideSize;
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
-    launch_fill(view, fa, false, st);
+    launch_fill(view, fa, false, packedMatrix, st);
     if (!c.wideTasks.empty()) {
       const int nw = (int)c.wideTasks.size();
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
@@ -376,7 +378,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       FillArgs fw = fa;
       fw.count = nw;
-      launch_fill(view, fw, true, st);
+      launch_fill(view, fw, true, packedMatrix, st);
     }
     HIP_TRY(ctx, hipEventRecord(ev[3], st));
 

@@ -40,7 +40,7 @@ struct TaskGeometry {
   int32_t tSpan;     // tEnd - tStart: target columns the path can cross
 };
 
-constexpr int kLdsRing = 1024;              // columns held per wavefront in LDS
+constexpr int kLdsRing = 512;               // columns held per wavefront in LDS
 constexpr int kLdsMaxWidth = kLdsRing - 64;  // widest row the LDS kernel accepts
 
 struct FillArgs {
@@ -79,7 +79,8 @@ struct TraceArgs {
 
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
                      hipStream_t stream);
-void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, hipStream_t stream);
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool packedMatrix,
+                 hipStream_t stream);
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
 // *total holds the op count of all candidates before `first` on entry and including them on exit
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,

@@ -259,9 +259,82 @@ constexpr int kInf = 1 << 29;  // "no predecessor"; real scores stay below 2^27 
 // packed arrow byte: bits 0-2 S arrow, bit 3 I arrow (1 = extend), bit 4 D arrow (1 = extend)
 enum { AR_DIAG = 0, AR_UP = 1, AR_LEFT = 2, AR_INS_CLOSE = 3, AR_DEL_CLOSE = 4, AR_NONE = 7 };
 
-template <bool kGlobalRing>
+// Two inclusive 64-lane prefix-min scans, interleaved so that each DPP read of a
+// just-written VGPR has its two wait states covered by the other chain + s_nop.
+__device__ __forceinline__ void wave_prefix_min2(int &a, int &b) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b));
+}
+// lane i receives lane i+1; lane 63 receives `edge` (DPP wave_shl:1)
+__device__ __forceinline__ int wave_shl1(int v, int edge) { return dpp<0x130, 0xf>(edge, v); }
+
+struct RowConsts {
+  int insC, delC, openC, extC;
+  int laneDel, laneExt;  // lane * del, lane * ext
+};
+struct ChunkCarry {
+  int a, b, s;  // running horizontal minima (del chain, affine chain) and S of the previous chunk's last lane
+};
+
+// One 64-column chunk of one row.  upS/upI = S and I of the row above at this
+// lane's column, diagS = S of the row above at column-1, m = substitution score.
+// Returns S, the new I and the packed arrow byte.
+__device__ __forceinline__ void row_chunk(const RowConsts &k, ChunkCarry &carry, bool active, bool upValid,
+                                          bool diagValid, int upS, int upI, int diagS, int m, int &sOut, int &iOut,
+                                          int &arrowOut) {
+  const int matchS = diagValid ? diagS + m : kInf;
+  const int insS = upValid ? upS + k.insC : kInf;
+  const int insE = upValid ? upI + k.extC : kInf;
+  int v = min(matchS, min(insS, insE));
+  v = active ? v : kInf;
+  // horizontal closure: S[c] = min(V[c], min_{j<c} V[j] + min((c-j)*del, open + (c-j)*ext))
+  int ia = v - k.laneDel, ib = v - k.laneExt;
+  wave_prefix_min2(ia, ib);
+  const int ea = min(wave_shr1(ia, kInf), carry.a);
+  const int eb = min(wave_shr1(ib, kInf), carry.b);
+  const int delExt = eb + k.laneExt + k.openC;  // = D[c-1] + ext
+  const int s = min(v, min(ea + k.laneDel, delExt));
+  const int delS = wave_shr1(s, carry.s) + k.delC;  // S[c-1] + del
+  int arrow = AR_DEL_CLOSE;
+  arrow = (s == insE) ? AR_INS_CLOSE : arrow;
+  arrow = (s == insS) ? AR_UP : arrow;
+  arrow = (s == delS) ? AR_LEFT : arrow;
+  arrow = (s == matchS) ? AR_DIAG : arrow;
+  const int openS = s + k.openC;
+  const bool insExtends = !(openS < insE);
+  const bool delExtends = !(openS < delExt);
+  iOut = insExtends ? insE : openS;
+  sOut = s;
+  arrowOut = arrow | (insExtends ? 8 : 0) | (delExtends ? 16 : 0);
+  carry.s = __builtin_amdgcn_readlane(s, 63);
+  carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.delC;
+  carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.extC;
+}
+
+// kPacked: every score-matrix entry fits int8, so one row of the matrix is a
+// packed dword and the per-lane lookup is a v_bfe_i32 on (target code * 8).
+template <bool kGlobalRing, bool kPacked>
 __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillArgs args) {
-  // per-wave LDS: score ring {S,I} by column, target-code ring, 64-byte scratch
+  // per-wave LDS: target-code ring (always), score ring {S,I} by column (rows wider than 64 only)
   __shared__ int2 ldsRing[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
   __shared__ unsigned char ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
   __shared__ unsigned char flagScratch[4][64];
@@ -296,7 +369,24 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   uint8_t *arrows = args.arrows + args.arrowOff[task];
   int2 *rowTab = args.rowTab + args.rowOff[task];
 
-  const int insC = args.ins, delC = args.del, openC = args.open, extC = args.ext;
+  RowConsts k;
+  k.insC = args.ins;
+  k.delC = args.del;
+  k.openC = args.open;
+  k.extC = args.ext;
+  k.laneDel = lane * k.delC;
+  k.laneExt = lane * k.extC;
+  // the 5x5 matrix lives in one VGPR (lane i = entry i); packed form: lane q = bytes of row q, lane 8+q = N column
+  int matV = lane < 25 ? args.matrix[lane] : 0;
+  if (kPacked) {
+    const int q5 = (lane < 5 ? lane : 0) * 5;
+    const int b0 = __builtin_amdgcn_ds_bpermute((q5 + 0) * 4, matV) & 0xff;
+    const int b1 = __builtin_amdgcn_ds_bpermute((q5 + 1) * 4, matV) & 0xff;
+    const int b2 = __builtin_amdgcn_ds_bpermute((q5 + 2) * 4, matV) & 0xff;
+    const int b3 = __builtin_amdgcn_ds_bpermute((q5 + 3) * 4, matV) & 0xff;
+    const int nCol = __builtin_amdgcn_ds_bpermute(((lane >= 8 && lane < 13 ? lane - 8 : 0) * 5 + 4) * 4, matV);
+    matV = (lane >= 8) ? nCol : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+  }
 
   GuideCursor g;
   guide_begin(g, blocks, nBlocks, args.band);
@@ -307,12 +397,18 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open ----
   int plo = tStart - 1;
   int phi = plo + guide_row0_tpost(g);
-  int tLoaded = plo < 0 ? 0 : plo;  // columns < tLoaded of the target are staged in ringT
-  for (int c0 = plo; c0 <= phi; c0 += 64) {
-    int c = c0 + lane;
-    if (c <= phi) ring[c & ringMask] = make_int2((c - plo) * delC, openC);
+  int tLoaded = plo < 0 ? 0 : plo;  // target columns < tLoaded are staged in ringT
+  // S and I of the previous row: in registers (lane j = column plo + j) while that row is <= 64 wide,
+  // otherwise in the ring
+  int prevS = lane * k.delC, prevI = k.openC;
+  bool prevInRegs = (phi - plo) < 64;
+  if (!prevInRegs) {
+    for (int c0 = plo; c0 <= phi; c0 += 64) {
+      int c = c0 + lane;
+      if (c <= phi) ring[c & ringMask] = make_int2((c - plo) * k.delC, k.openC);
+    }
+    if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
   int finalScore = 0;
   for (int r0 = 1; r0 <= Q; r0 += 64) {
@@ -331,65 +427,99 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
       const unsigned rowStart = (unsigned)__builtin_amdgcn_readlane((int)rsV, i);
       const int qc = __builtin_amdgcn_readlane(qCodeV, i);
       const int hiC = min(hi, tEnd - 1);  // cells with t >= tEnd are skipped (:268-269)
-      // stage target codes up to hiC
+      // stage target codes (as code * 8) up to hiC
       while (tLoaded <= hiC) {
         int c = tLoaded + lane;
-        if (c < tLen) ringT[c & ringMask] = (unsigned char)base_code(tSeq[c]);
+        if (c < tLen) ringT[c & ringMask] = (unsigned char)(base_code(tSeq[c]) * 8);
         tLoaded += 64;
         if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      const int m0 = args.matrix[qc * 5 + 0], m1 = args.matrix[qc * 5 + 1], m2 = args.matrix[qc * 5 + 2],
-                m3 = args.matrix[qc * 5 + 3], m4 = args.matrix[qc * 5 + 4];
-      uint8_t *arrowRow = arrows + rowStart - lo;
-
-      int carryA = kInf, carryB = kInf, carryS = kInf, carryDiag = 0;
-      for (int cb = lo; cb <= hiC; cb += 64) {
-        const int c = cb + lane;
-        const bool active = c <= hiC;
-        const int2 up = ring[c & ringMask];
-        int sd = ring[(c - 1) & ringMask].x;
-        if (cb > lo) sd = (lane == 0) ? carryDiag : sd;  // column cb-1 was overwritten by the previous chunk
-        const int tc = (c >= 0) ? (int)ringT[c & ringMask] : 4;
-        const bool upValid = (c >= plo) && (c <= phi);
-        const bool diagValid = (c - 1 >= plo) && (c - 1 <= phi);
-        int m = m4;
-        m = (tc == 0) ? m0 : m;
-        m = (tc == 1) ? m1 : m;
-        m = (tc == 2) ? m2 : m;
-        m = (tc == 3) ? m3 : m;
-        const int matchS = diagValid ? sd + m : kInf;
-        const int insS = upValid ? up.x + insC : kInf;
-        const int insE = upValid ? up.y + extC : kInf;
-        int v = min(matchS, min(insS, insE));
-        v = active ? v : kInf;
-        // horizontal closure: S[c] = min(V[c], min_{k<c} V[k] + min((c-k)*del, open + (c-k)*ext))
-        const int ia = wave_prefix_min(v - lane * delC);
-        const int ib = wave_prefix_min(v - lane * extC);
-        const int ea = min(wave_shr1(ia, kInf), carryA);
-        const int eb = min(wave_shr1(ib, kInf), carryB);
-        const int delExt = eb + lane * extC + openC;  // = D[c-1] + ext
-        const int s = min(v, min(ea + lane * delC, delExt));
-        const int delS = wave_shr1(s, carryS) + delC;  // S[c-1] + del (kInf-ish when c-1 is outside the row)
-        int arrow = AR_DEL_CLOSE;
-        arrow = (s == insE) ? AR_INS_CLOSE : arrow;
-        arrow = (s == insS) ? AR_UP : arrow;
-        arrow = (s == delS) ? AR_LEFT : arrow;
-        arrow = (s == matchS) ? AR_DIAG : arrow;
-        const int openS = s + openC;
-        const bool insExtends = !(openS < insE);
-        const bool delExtends = !(openS < delExt);
-        const int iNew = insExtends ? insE : openS;
-        if (active) {
-          ring[c & ringMask] = make_int2(s, iNew);
-          arrowRow[c] = (uint8_t)(arrow | (insExtends ? 8 : 0) | (delExtends ? 16 : 0));
-        }
-        if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        carryDiag = __builtin_amdgcn_readlane(up.x, 63);
-        carryS = __builtin_amdgcn_readlane(s, 63);
-        carryA = min(carryA, __builtin_amdgcn_readlane(ia, 63)) + 64 * delC;
-        carryB = min(carryB, __builtin_amdgcn_readlane(ib, 63)) + 64 * extC;
-        if (r0 + i == Q && c == tEnd - 1) finalScore = s;
+      int m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4, mPacked = 0;
+      if (kPacked) {
+        mPacked = __builtin_amdgcn_readlane(matV, qc);
+        m4 = __builtin_amdgcn_readlane(matV, qc + 8);
+      } else {
+        m0 = __builtin_amdgcn_readlane(matV, qc * 5 + 0);
+        m1 = __builtin_amdgcn_readlane(matV, qc * 5 + 1);
+        m2 = __builtin_amdgcn_readlane(matV, qc * 5 + 2);
+        m3 = __builtin_amdgcn_readlane(matV, qc * 5 + 3);
+        m4 = __builtin_amdgcn_readlane(matV, qc * 5 + 4);
       }
+      auto subst = [&](int tc8) {
+        int m;
+        if (kPacked) {
+          m = __builtin_amdgcn_sbfe(mPacked, tc8, 8);
+        } else {
+          m = m3;
+          m = (tc8 == 0) ? m0 : m;
+          m = (tc8 == 8) ? m1 : m;
+          m = (tc8 == 16) ? m2 : m;
+        }
+        return (tc8 == 32) ? m4 : m;
+      };
+      uint8_t *arrowRow = arrows + rowStart - lo;
+      const bool curSingle = (hiC - lo) < 64;
+      ChunkCarry carry;
+      carry.a = carry.b = carry.s = kInf;
+
+      if (prevInRegs && curSingle) {
+        // ---- register path: the row above is shifted into place with DPP ----
+        const int c = lo + lane;
+        const int shift = lo - plo;  // >= 0
+        int upS, upI, diagS;
+        if (shift == 1) {
+          upS = wave_shl1(prevS, 0);
+          upI = wave_shl1(prevI, 0);
+          diagS = prevS;
+        } else if (shift == 0) {
+          upS = prevS;
+          upI = prevI;
+          diagS = wave_shr1(prevS, 0);
+        } else {
+          upS = __builtin_amdgcn_ds_bpermute((lane + shift) * 4, prevS);
+          upI = __builtin_amdgcn_ds_bpermute((lane + shift) * 4, prevI);
+          diagS = __builtin_amdgcn_ds_bpermute((lane + shift - 1) * 4, prevS);
+        }
+        const int tc8 = (int)ringT[c & ringMask];
+        int s, iNew, arrow;
+        row_chunk(k, carry, c <= hiC, c <= phi, (c - 1 <= phi) && (c > plo), upS, upI, diagS, subst(tc8), s, iNew,
+                  arrow);
+        if (c <= hiC) arrowRow[c] = (uint8_t)arrow;
+        prevS = s;
+        prevI = iNew;
+        if (r0 + i == Q && c == tEnd - 1) finalScore = s;
+      } else {
+        // ---- ring path: rows wider than one wavefront ----
+        if (prevInRegs) {
+          const int c = plo + lane;
+          if (c <= phi) ring[c & ringMask] = make_int2(prevS, prevI);
+          if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        int carryDiag = 0;
+        for (int cb = lo; cb <= hiC; cb += 64) {
+          const int c = cb + lane;
+          const bool active = c <= hiC;
+          const int2 up = ring[c & ringMask];
+          int sd = ring[(c - 1) & ringMask].x;
+          if (cb > lo) sd = (lane == 0) ? carryDiag : sd;  // column cb-1 was overwritten by the previous chunk
+          const int tc8 = (int)ringT[c & ringMask];
+          int s, iNew, arrow;
+          row_chunk(k, carry, active, c <= phi, (c - 1 <= phi) && (c > plo), up.x, up.y, sd, subst(tc8), s, iNew,
+                    arrow);
+          if (active) {
+            ring[c & ringMask] = make_int2(s, iNew);
+            arrowRow[c] = (uint8_t)arrow;
+          }
+          if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          carryDiag = __builtin_amdgcn_readlane(up.x, 63);
+          if (cb == lo) {
+            prevS = s;
+            prevI = iNew;
+          }
+          if (r0 + i == Q && c == tEnd - 1) finalScore = s;
+        }
+      }
+      prevInRegs = curSingle;
       plo = lo;
       phi = hi;
     }
@@ -400,8 +530,10 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   if (lane == 0) args.dpScore[task] = fs;
 }
 
-template __global__ void fill_kernel<false>(RefineBatchView, FillArgs);
-template __global__ void fill_kernel<true>(RefineBatchView, FillArgs);
+template __global__ void fill_kernel<false, true>(RefineBatchView, FillArgs);
+template __global__ void fill_kernel<false, false>(RefineBatchView, FillArgs);
+template __global__ void fill_kernel<true, true>(RefineBatchView, FillArgs);
+template __global__ void fill_kernel<true, false>(RefineBatchView, FillArgs);
 
 // ---------------------------------------------------------------------------
 // traceback_kernel: one lane per candidate (AffineGuidedAlign.h:377-468), fused with
@@ -606,12 +738,21 @@ void launch_geometry(const RefineBatchView &batch, int band, int first, int coun
   if (count <= 0) return;
   hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
 }
-void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, hipStream_t stream) {
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool packedMatrix,
+                 hipStream_t stream) {
   if (args.count <= 0) return;
-  if (globalRing)
-    hipLaunchKernelGGL(fill_kernel<true>, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
-  else
-    hipLaunchKernelGGL(fill_kernel<false>, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
+  const dim3 grid((args.count + 3) / 4), block(256);
+  if (globalRing) {
+    if (packedMatrix)
+      hipLaunchKernelGGL((fill_kernel<true, true>), grid, block, 0, stream, batch, args);
+    else
+      hipLaunchKernelGGL((fill_kernel<true, false>), grid, block, 0, stream, batch, args);
+  } else {
+    if (packedMatrix)
+      hipLaunchKernelGGL((fill_kernel<false, true>), grid, block, 0, stream, batch, args);
+    else
+      hipLaunchKernelGGL((fill_kernel<false, false>), grid, block, 0, stream, batch, args);
+  }
 }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
   if (args.count <= 0) return;
