@@ -275,7 +275,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         ar = sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
         if (geo[i].maxWidth > kLdsMaxWidth) {
           ringSize = 2048;
-          while (ringSize < geo[i].maxWidth + 64) ringSize *= 2;
+          while (ringSize < 2 * geo[i].maxWidth + 128) ringSize *= 2;
           w = align_up((size_t)ringSize * 9, 256);
         }
       }

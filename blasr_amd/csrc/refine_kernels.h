@@ -40,8 +40,10 @@ struct TaskGeometry {
   int32_t tSpan;     // tEnd - tStart: target columns the path can cross
 };
 
-constexpr int kLdsRing = 512;               // columns held per wavefront in LDS
-constexpr int kLdsMaxWidth = kLdsRing - 64;  // widest row the LDS kernel accepts
+constexpr int kLdsRing = 512;    // {S,I} columns held per wavefront in LDS (rows wider than one wavefront only)
+constexpr int kLdsRingT = 1024;  // target codes held per wavefront in LDS, staged one row ahead
+// widest row the LDS kernel accepts: the code ring must span two consecutive rows plus the look-ahead
+constexpr int kLdsMaxWidth = (kLdsRingT - 128) / 2;
 
 struct FillArgs {
   int first, count;  // candidates [first, first+count) of the batch (LDS variant)

@@ -298,6 +298,7 @@ struct ChunkCarry {
 // One 64-column chunk of one row.  upS/upI = S and I of the row above at this
 // lane's column, diagS = S of the row above at column-1, m = substitution score.
 // Returns S, the new I and the packed arrow byte.
+template <bool kOnlyChunk>
 __device__ __forceinline__ void row_chunk(const RowConsts &k, ChunkCarry &carry, bool active, bool upValid,
                                           bool diagValid, int upS, int upI, int diagS, int m, int &sOut, int &iOut,
                                           int &arrowOut) {
@@ -309,11 +310,14 @@ __device__ __forceinline__ void row_chunk(const RowConsts &k, ChunkCarry &carry,
   // horizontal closure: S[c] = min(V[c], min_{j<c} V[j] + min((c-j)*del, open + (c-j)*ext))
   int ia = v - k.laneDel, ib = v - k.laneExt;
   wave_prefix_min2(ia, ib);
-  const int ea = min(wave_shr1(ia, kInf), carry.a);
-  const int eb = min(wave_shr1(ib, kInf), carry.b);
+  int ea = wave_shr1(ia, kInf), eb = wave_shr1(ib, kInf);
+  if (!kOnlyChunk) {
+    ea = min(ea, carry.a);
+    eb = min(eb, carry.b);
+  }
   const int delExt = eb + k.laneExt + k.openC;  // = D[c-1] + ext
   const int s = min(v, min(ea + k.laneDel, delExt));
-  const int delS = wave_shr1(s, carry.s) + k.delC;  // S[c-1] + del
+  const int delS = wave_shr1(s, kOnlyChunk ? kInf : carry.s) + k.delC;  // S[c-1] + del
   int arrow = AR_DEL_CLOSE;
   arrow = (s == insE) ? AR_INS_CLOSE : arrow;
   arrow = (s == insS) ? AR_UP : arrow;
@@ -325,9 +329,11 @@ __device__ __forceinline__ void row_chunk(const RowConsts &k, ChunkCarry &carry,
   iOut = insExtends ? insE : openS;
   sOut = s;
   arrowOut = arrow | (insExtends ? 8 : 0) | (delExtends ? 16 : 0);
-  carry.s = __builtin_amdgcn_readlane(s, 63);
-  carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.delC;
-  carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.extC;
+  if (!kOnlyChunk) {
+    carry.s = __builtin_amdgcn_readlane(s, 63);
+    carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.delC;
+    carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.extC;
+  }
 }
 
 // kPacked: every score-matrix entry fits int8, so one row of the matrix is a
@@ -336,7 +342,7 @@ template <bool kGlobalRing, bool kPacked>
 __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillArgs args) {
   // per-wave LDS: target-code ring (always), score ring {S,I} by column (rows wider than 64 only)
   __shared__ int2 ldsRing[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
-  __shared__ unsigned char ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
+  __shared__ unsigned char ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRingT];
   __shared__ unsigned char flagScratch[4][64];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -349,16 +355,17 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
 
   int2 *ring;
   unsigned char *ringT;
-  int ringMask;
+  int ringMask, ringMaskT;
   if (kGlobalRing) {
     const int64_t off = args.wideRingOff[idx];
-    ringMask = args.wideRingSize[idx] - 1;
+    ringMask = ringMaskT = args.wideRingSize[idx] - 1;
     ring = reinterpret_cast<int2 *>(args.wideRings + off);
     ringT = reinterpret_cast<unsigned char *>(ring + (ringMask + 1));
   } else {
     ring = ldsRing[wave];
     ringT = ldsT[wave];
     ringMask = kLdsRing - 1;
+    ringMaskT = kLdsRingT - 1;
   }
 
   const uint8_t *qSeq = batch.seq + batch.q_off[task];
@@ -421,18 +428,29 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
     int qCodeV = 4;
     if (lane < nRows) qCodeV = base_code(qSeq[qStart + r0 - 1 + lane]);
 
+    // target codes (as code * 8) are staged one row ahead of their use, so the LDS read of a row's
+    // codes is issued while the previous row is being computed
+    auto stageT = [&](int upTo) {
+      while (tLoaded <= upTo) {
+        int c = tLoaded + lane;
+        if (c < tLen) ringT[c & ringMaskT] = (unsigned char)(base_code(tSeq[c]) * 8);
+        tLoaded += 64;
+        if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    };
+    stageT(min(__builtin_amdgcn_readlane(hiV, 0), tEnd - 1));
+    int tc8Next = (int)ringT[(__builtin_amdgcn_readlane(loV, 0) + lane) & ringMaskT];
+
     for (int i = 0; i < nRows; i++) {
       const int lo = __builtin_amdgcn_readlane(loV, i);
       const int hi = __builtin_amdgcn_readlane(hiV, i);
       const unsigned rowStart = (unsigned)__builtin_amdgcn_readlane((int)rsV, i);
       const int qc = __builtin_amdgcn_readlane(qCodeV, i);
       const int hiC = min(hi, tEnd - 1);  // cells with t >= tEnd are skipped (:268-269)
-      // stage target codes (as code * 8) up to hiC
-      while (tLoaded <= hiC) {
-        int c = tLoaded + lane;
-        if (c < tLen) ringT[c & ringMask] = (unsigned char)(base_code(tSeq[c]) * 8);
-        tLoaded += 64;
-        if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int tc8Cur = tc8Next;  // first 64 columns of this row, fetched one row ahead
+      if (i + 1 < nRows) {
+        stageT(min(__builtin_amdgcn_readlane(hiV, i + 1), tEnd - 1));
+        tc8Next = (int)ringT[(__builtin_amdgcn_readlane(loV, i + 1) + lane) & ringMaskT];
       }
       int m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4, mPacked = 0;
       if (kPacked) {
@@ -480,14 +498,12 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
           upI = __builtin_amdgcn_ds_bpermute((lane + shift) * 4, prevI);
           diagS = __builtin_amdgcn_ds_bpermute((lane + shift - 1) * 4, prevS);
         }
-        const int tc8 = (int)ringT[c & ringMask];
         int s, iNew, arrow;
-        row_chunk(k, carry, c <= hiC, c <= phi, (c - 1 <= phi) && (c > plo), upS, upI, diagS, subst(tc8), s, iNew,
-                  arrow);
+        row_chunk<true>(k, carry, c <= hiC, c <= phi, (c - 1 <= phi) && (c > plo), upS, upI, diagS, subst(tc8Cur), s,
+                        iNew, arrow);
         if (c <= hiC) arrowRow[c] = (uint8_t)arrow;
         prevS = s;
         prevI = iNew;
-        if (r0 + i == Q && c == tEnd - 1) finalScore = s;
       } else {
         // ---- ring path: rows wider than one wavefront ----
         if (prevInRegs) {
@@ -502,10 +518,10 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
           const int2 up = ring[c & ringMask];
           int sd = ring[(c - 1) & ringMask].x;
           if (cb > lo) sd = (lane == 0) ? carryDiag : sd;  // column cb-1 was overwritten by the previous chunk
-          const int tc8 = (int)ringT[c & ringMask];
+          const int tc8 = (cb == lo) ? tc8Cur : (int)ringT[c & ringMaskT];
           int s, iNew, arrow;
-          row_chunk(k, carry, active, c <= phi, (c - 1 <= phi) && (c > plo), up.x, up.y, sd, subst(tc8), s, iNew,
-                    arrow);
+          row_chunk<false>(k, carry, active, c <= phi, (c - 1 <= phi) && (c > plo), up.x, up.y, sd, subst(tc8), s,
+                           iNew, arrow);
           if (active) {
             ring[c & ringMask] = make_int2(s, iNew);
             arrowRow[c] = (uint8_t)arrow;
@@ -516,7 +532,6 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
             prevS = s;
             prevI = iNew;
           }
-          if (r0 + i == Q && c == tEnd - 1) finalScore = s;
         }
       }
       prevInRegs = curSingle;
@@ -524,7 +539,13 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
       phi = hi;
     }
   }
-  // only the lane that owned cell (Q, tEnd-1) holds a non-zero value: a wave sum publishes it
+  // DP score = S[Q][tEnd-1] (AffineGuidedAlign.h:481-483): the last row is still in registers or in the ring
+  if (prevInRegs) {
+    if (plo + lane == tEnd - 1) finalScore = prevS;
+  } else {
+    if (lane == 0) finalScore = ring[(tEnd - 1) & ringMask].x;
+  }
+  // only one lane holds a non-zero value: a wave sum publishes it
   int fs = finalScore;
   for (int off = 32; off > 0; off >>= 1) fs += __shfl_xor(fs, off);
   if (lane == 0) args.dpScore[task] = fs;
