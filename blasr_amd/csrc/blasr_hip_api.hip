@@ -235,6 +235,10 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       totalSpan += geo[i].tSpan;
     }
   }
+  int64_t scoreMagnitude = std::max<int64_t>({llabs((long long)score->ins), llabs((long long)score->del),
+                                              llabs((long long)score->affine_open),
+                                              llabs((long long)score->affine_extend)});
+  for (int i = 0; i < 25; i++) scoreMagnitude = std::max<int64_t>(scoreMagnitude, llabs((long long)score->matrix[i]));
   rc = check_score_domain(ctx, score, longest);
   if (rc) {
     destroyEvents();
@@ -276,7 +280,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         if (geo[i].maxWidth > kLdsMaxWidth) {
           ringSize = 2048;
           while (ringSize < 2 * geo[i].maxWidth + 128) ringSize *= 2;
-          w = align_up((size_t)ringSize * 9, 256);
+          w = align_up((size_t)ringSize * 12, 256);
         }
       }
       const size_t need = a + r + ar + w + 1024;
@@ -332,8 +336,10 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   HIP_TRY(ctx, hipMemsetAsync(dTotal, 0, sizeof(int64_t), st));
   HIP_TRY(ctx, hipMemsetAsync(dDp, 0, sizeof(int32_t) * n, st));
 
-  bool packedMatrix = true;  // every entry fits a signed byte -> packed row lookup in the fill kernel
-  for (int i = 0; i < 25; i++) packedMatrix = packedMatrix && score->matrix[i] >= -128 && score->matrix[i] <= 127;
+  // The tagged-key fill variant needs byte-sized matrix entries, ext < del and |score| < 2^24;
+  // anything else runs the compare-based variant (same results, more instructions per cell).
+  bool fast = score->affine_extend < score->del && scoreMagnitude * (longest + 66) < (1ll << 24);
+  for (int i = 0; i < 25; i++) fast = fast && score->matrix[i] >= -128 && score->matrix[i] <= 127;
   RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
   float msFill = 0, msTrace = 0, msCompact = 0;
   for (auto &c : plan.chunks) {
@@ -370,7 +376,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRingSize = dWideSize;
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
-    launch_fill(view, fa, false, packedMatrix, st);
+    launch_fill(view, fa, false, fast, st);
     if (!c.wideTasks.empty()) {
       const int nw = (int)c.wideTasks.size();
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
@@ -378,7 +384,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       FillArgs fw = fa;
       fw.count = nw;
-      launch_fill(view, fw, true, packedMatrix, st);
+      launch_fill(view, fw, true, fast, st);
     }
     HIP_TRY(ctx, hipEventRecord(ev[3], st));
 

@@ -40,8 +40,8 @@ struct TaskGeometry {
   int32_t tSpan;     // tEnd - tStart: target columns the path can cross
 };
 
-constexpr int kLdsRing = 512;    // {S,I} columns held per wavefront in LDS (rows wider than one wavefront only)
-constexpr int kLdsRingT = 1024;  // target codes held per wavefront in LDS, staged one row ahead
+constexpr int kLdsRing = 256;   // {S,I} columns held per wavefront in LDS (rows wider than one wavefront only)
+constexpr int kLdsRingT = 512;  // target-ring dwords held per wavefront in LDS, staged one row ahead
 // widest row the LDS kernel accepts: the code ring must span two consecutive rows plus the look-ahead
 constexpr int kLdsMaxWidth = (kLdsRingT - 128) / 2;
 
@@ -81,7 +81,7 @@ struct TraceArgs {
 
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
                      hipStream_t stream);
-void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool packedMatrix,
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool fast,
                  hipStream_t stream);
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
 // *total holds the op count of all candidates before `first` on entry and including them on exit

@@ -254,10 +254,12 @@ __global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, in
 // ---------------------------------------------------------------------------
 // fill_kernel
 // ---------------------------------------------------------------------------
-constexpr int kInf = 1 << 29;  // "no predecessor"; real scores stay below 2^27 (checked on the host)
-
-// packed arrow byte: bits 0-2 S arrow, bit 3 I arrow (1 = extend), bit 4 D arrow (1 = extend)
-enum { AR_DIAG = 0, AR_UP = 1, AR_LEFT = 2, AR_INS_CLOSE = 3, AR_DEL_CLOSE = 4, AR_NONE = 7 };
+// Packed arrow byte written per band cell:
+//   bits 0-2  S arrow as its PRIORITY in AffineGuidedAlign.h:326-341:
+//             0 Diagonal, 1 Left (del), 2 Up (ins), 3 AffineInsClose, 4 AffineDelClose
+//   bit 3     affine-insert matrix: 1 = AffineInsOpen, 0 = AffineInsUp   (:357-364)
+//   bit 4     affine-delete matrix: 1 = AffineDelOpen, 0 = AffineDelLeft (:366-373)
+enum { AR_DIAG = 0, AR_LEFT = 1, AR_UP = 2, AR_INS_CLOSE = 3, AR_DEL_CLOSE = 4, AR_I_OPEN = 8, AR_D_OPEN = 16 };
 
 // Two inclusive 64-lane prefix-min scans, interleaved so that each DPP read of a
 // just-written VGPR has its two wait states covered by the other chain + s_nop.
@@ -287,62 +289,98 @@ __device__ __forceinline__ void wave_prefix_min2(int &a, int &b) {
 // lane i receives lane i+1; lane 63 receives `edge` (DPP wave_shl:1)
 __device__ __forceinline__ int wave_shl1(int v, int edge) { return dpp<0x130, 0xf>(edge, v); }
 
+// Scores are carried scaled by kScale with the low bits free for a tag, so that ONE
+// integer min yields both the minimum and, on ties, the reference's arrow priority:
+// key = score * 32 + priority.  Needs ext < del (then S == S[c-1]+del exactly when S equals
+// the linear-gap chain value) and |score| < 2^24; other parameter
+// sets run the compare-based variant (kFast = false) on unscaled scores.
+constexpr int kShift = 5;
+constexpr int kTagMask = 31;
+
+template <bool kFast>
 struct RowConsts {
-  int insC, delC, openC, extC;
-  int laneDel, laneExt;  // lane * del, lane * ext
+  int inf;                // "no predecessor"
+  int ins, del, open, ext;  // unscaled (compare variant) or scaled by 32 (fast variant)
+  int laneDel, laneExt;   // lane * del, lane * ext (same scaling)
 };
 struct ChunkCarry {
-  int a, b, s;  // running horizontal minima (del chain, affine chain) and S of the previous chunk's last lane
+  int a, b, s;  // horizontal minima entering this chunk (del chain, affine chain) and S of the last lane before it
 };
 
-// One 64-column chunk of one row.  upS/upI = S and I of the row above at this
-// lane's column, diagS = S of the row above at column-1, m = substitution score.
-// Returns S, the new I and the packed arrow byte.
-template <bool kOnlyChunk>
-__device__ __forceinline__ void row_chunk(const RowConsts &k, ChunkCarry &carry, bool active, bool upValid,
-                                          bool diagValid, int upS, int upI, int diagS, int m, int &sOut, int &iOut,
-                                          int &arrowOut) {
-  const int matchS = diagValid ? diagS + m : kInf;
-  const int insS = upValid ? upS + k.insC : kInf;
-  const int insE = upValid ? upI + k.extC : kInf;
-  int v = min(matchS, min(insS, insE));
-  v = active ? v : kInf;
-  // horizontal closure: S[c] = min(V[c], min_{j<c} V[j] + min((c-j)*del, open + (c-j)*ext))
-  int ia = v - k.laneDel, ib = v - k.laneExt;
-  wave_prefix_min2(ia, ib);
-  int ea = wave_shr1(ia, kInf), eb = wave_shr1(ib, kInf);
-  if (!kOnlyChunk) {
-    ea = min(ea, carry.a);
-    eb = min(eb, carry.b);
-  }
-  const int delExt = eb + k.laneExt + k.openC;  // = D[c-1] + ext
-  const int s = min(v, min(ea + k.laneDel, delExt));
-  const int delS = wave_shr1(s, kOnlyChunk ? kInf : carry.s) + k.delC;  // S[c-1] + del
-  int arrow = AR_DEL_CLOSE;
-  arrow = (s == insE) ? AR_INS_CLOSE : arrow;
-  arrow = (s == insS) ? AR_UP : arrow;
-  arrow = (s == delS) ? AR_LEFT : arrow;
-  arrow = (s == matchS) ? AR_DIAG : arrow;
-  const int openS = s + k.openC;
-  const bool insExtends = !(openS < insE);
-  const bool delExtends = !(openS < delExt);
-  iOut = insExtends ? insE : openS;
-  sOut = s;
-  arrowOut = arrow | (insExtends ? 8 : 0) | (delExtends ? 16 : 0);
-  if (!kOnlyChunk) {
-    carry.s = __builtin_amdgcn_readlane(s, 63);
-    carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.delC;
-    carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.extC;
+// One 64-column chunk of one row.  upS/upI = S and I of the row above at this lane's column,
+// diagS = S of the row above at column-1 (all "inf" where that cell does not exist),
+// m = substitution score (unscaled).  Returns S and the new I for the active lanes (inf elsewhere)
+// and the packed arrow byte.
+template <bool kFast, bool kOnlyChunk>
+__device__ __forceinline__ void row_chunk(const RowConsts<kFast> &k, ChunkCarry &carry, bool active, int upS, int upI,
+                                          int diagS, int m, int &sOut, int &iOut, int &arrowOut) {
+  if (kFast) {
+    const int matchK = (m << kShift) + diagS;        // tag 0 = Diagonal
+    const int insSK = upS + (k.ins + AR_UP);          // tag 2 = Up
+    const int insEK = upI + (k.ext + AR_INS_CLOSE);   // tag 3 = AffineInsClose
+    const int vKey = min(matchK, min(insSK, insEK));
+    int v = vKey & ~kTagMask;
+    v = active ? v : k.inf;
+    int ia = v - k.laneDel, ib = v - k.laneExt;
+    wave_prefix_min2(ia, ib);
+    int ea = wave_shr1(ia, k.inf), eb = wave_shr1(ib, k.inf);
+    if (!kOnlyChunk) {
+      ea = min(ea, carry.a);
+      eb = min(eb, carry.b);
+    }
+    const int aK = ea + (k.laneDel + AR_LEFT);                // S[c-1] + del, tag 1 = Left
+    const int bK = eb + (k.laneExt + k.open + AR_DEL_CLOSE);  // D[c-1] + ext, tag 4 = AffineDelClose
+    const int sKey = min(vKey, min(aK, bK));
+    const int s = sKey & ~kTagMask;
+    // I = (S + open < I_up + ext) ? open : extend -- ties extend, so "open" carries the larger tag
+    const int openKey = s + (k.open + AR_I_OPEN);
+    const int iKey = min(openKey, insEK & ~kTagMask);
+    const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
+    arrowOut = (sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN));
+    sOut = active ? s : k.inf;
+    iOut = active ? (iKey & ~kTagMask) : k.inf;
+    if (!kOnlyChunk) {
+      carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.del;
+      carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.ext;
+    }
+  } else {
+    const int matchS = diagS + m, insS = upS + k.ins, insE = upI + k.ext;
+    int v = min(matchS, min(insS, insE));
+    v = active ? v : k.inf;
+    int ia = v - k.laneDel, ib = v - k.laneExt;
+    wave_prefix_min2(ia, ib);
+    int ea = wave_shr1(ia, k.inf), eb = wave_shr1(ib, k.inf);
+    if (!kOnlyChunk) {
+      ea = min(ea, carry.a);
+      eb = min(eb, carry.b);
+    }
+    const int delExt = eb + k.laneExt + k.open;  // = D[c-1] + ext
+    const int s = min(v, min(ea + k.laneDel, delExt));
+    const int delS = wave_shr1(s, kOnlyChunk ? k.inf : carry.s) + k.del;  // S[c-1] + del
+    int arrow = AR_DEL_CLOSE;
+    arrow = (s == insE) ? AR_INS_CLOSE : arrow;
+    arrow = (s == insS) ? AR_UP : arrow;
+    arrow = (s == delS) ? AR_LEFT : arrow;
+    arrow = (s == matchS) ? AR_DIAG : arrow;
+    const int openS = s + k.open;
+    const bool insOpens = openS < insE, delOpens = openS < delExt;
+    arrowOut = arrow | (insOpens ? AR_I_OPEN : 0) | (delOpens ? AR_D_OPEN : 0);
+    sOut = active ? s : k.inf;
+    iOut = active ? (insOpens ? openS : insE) : k.inf;
+    if (!kOnlyChunk) {
+      carry.s = __builtin_amdgcn_readlane(s, 63);
+      carry.a = min(carry.a, __builtin_amdgcn_readlane(ia, 63)) + 64 * k.del;
+      carry.b = min(carry.b, __builtin_amdgcn_readlane(ib, 63)) + 64 * k.ext;
+    }
   }
 }
 
-// kPacked: every score-matrix entry fits int8, so one row of the matrix is a
-// packed dword and the per-lane lookup is a v_bfe_i32 on (target code * 8).
-template <bool kGlobalRing, bool kPacked>
+template <bool kGlobalRing, bool kFast>
 __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillArgs args) {
-  // per-wave LDS: target-code ring (always), score ring {S,I} by column (rows wider than 64 only)
+  // per-wave LDS: target ring (one dword per target column: the column of the score matrix, packed,
+  // or the base code), {S,I} ring by column (only rows wider than one wavefront go through it)
   __shared__ int2 ldsRing[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRing];
-  __shared__ unsigned char ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRingT];
+  __shared__ uint32_t ldsT[kGlobalRing ? 1 : 4][kGlobalRing ? 1 : kLdsRingT];
   __shared__ unsigned char flagScratch[4][64];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -354,13 +392,13 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   if (!kGlobalRing && geo.maxWidth > kLdsMaxWidth) return;  // handled by the global-ring launch
 
   int2 *ring;
-  unsigned char *ringT;
+  uint32_t *ringT;
   int ringMask, ringMaskT;
   if (kGlobalRing) {
     const int64_t off = args.wideRingOff[idx];
     ringMask = ringMaskT = args.wideRingSize[idx] - 1;
     ring = reinterpret_cast<int2 *>(args.wideRings + off);
-    ringT = reinterpret_cast<unsigned char *>(ring + (ringMask + 1));
+    ringT = reinterpret_cast<uint32_t *>(ring + (ringMask + 1));
   } else {
     ring = ldsRing[wave];
     ringT = ldsT[wave];
@@ -376,24 +414,25 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   uint8_t *arrows = args.arrows + args.arrowOff[task];
   int2 *rowTab = args.rowTab + args.rowOff[task];
 
-  RowConsts k;
-  k.insC = args.ins;
-  k.delC = args.del;
-  k.openC = args.open;
-  k.extC = args.ext;
-  k.laneDel = lane * k.delC;
-  k.laneExt = lane * k.extC;
-  // the 5x5 matrix lives in one VGPR (lane i = entry i); packed form: lane q = bytes of row q, lane 8+q = N column
-  int matV = lane < 25 ? args.matrix[lane] : 0;
-  if (kPacked) {
-    const int q5 = (lane < 5 ? lane : 0) * 5;
-    const int b0 = __builtin_amdgcn_ds_bpermute((q5 + 0) * 4, matV) & 0xff;
-    const int b1 = __builtin_amdgcn_ds_bpermute((q5 + 1) * 4, matV) & 0xff;
-    const int b2 = __builtin_amdgcn_ds_bpermute((q5 + 2) * 4, matV) & 0xff;
-    const int b3 = __builtin_amdgcn_ds_bpermute((q5 + 3) * 4, matV) & 0xff;
-    const int nCol = __builtin_amdgcn_ds_bpermute(((lane >= 8 && lane < 13 ? lane - 8 : 0) * 5 + 4) * 4, matV);
-    matV = (lane >= 8) ? nCol : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-  }
+  RowConsts<kFast> k;
+  const int sc = kFast ? kShift : 0;
+  k.inf = kFast ? (1 << 30) : (1 << 29);
+  k.ins = args.ins << sc;
+  k.del = args.del << sc;
+  k.open = args.open << sc;
+  k.ext = args.ext << sc;
+  k.laneDel = lane * k.del;
+  k.laneExt = lane * k.ext;
+  // the 5x5 matrix lives in one VGPR: lane i = entry i  ([query][target])
+  const int matV = lane < 25 ? args.matrix[lane] : 0;
+  // fast variant: per target code, the matrix column for queries A,C,G,T packed into one dword
+  auto packedColumn = [&](int tcode) {
+    const int b0 = __builtin_amdgcn_ds_bpermute((0 * 5 + tcode) * 4, matV) & 0xff;
+    const int b1 = __builtin_amdgcn_ds_bpermute((1 * 5 + tcode) * 4, matV) & 0xff;
+    const int b2 = __builtin_amdgcn_ds_bpermute((2 * 5 + tcode) * 4, matV) & 0xff;
+    const int b3 = __builtin_amdgcn_ds_bpermute((3 * 5 + tcode) * 4, matV) & 0xff;
+    return (uint32_t)(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+  };
 
   GuideCursor g;
   guide_begin(g, blocks, nBlocks, args.band);
@@ -405,19 +444,19 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   int plo = tStart - 1;
   int phi = plo + guide_row0_tpost(g);
   int tLoaded = plo < 0 ? 0 : plo;  // target columns < tLoaded are staged in ringT
-  // S and I of the previous row: in registers (lane j = column plo + j) while that row is <= 64 wide,
-  // otherwise in the ring
-  int prevS = lane * k.delC, prevI = k.openC;
+  // S and I of the previous row: in registers (lane j = column plo + j, "inf" beyond the row) while
+  // that row is <= 64 wide, otherwise in the ring
   bool prevInRegs = (phi - plo) < 64;
+  int prevS = (plo + lane <= phi) ? k.laneDel : k.inf;
+  int prevI = (plo + lane <= phi) ? k.open : k.inf;
   if (!prevInRegs) {
     for (int c0 = plo; c0 <= phi; c0 += 64) {
       int c = c0 + lane;
-      if (c <= phi) ring[c & ringMask] = make_int2((c - plo) * k.delC, k.openC);
+      if (c <= phi) ring[c & ringMask] = make_int2((c - plo) * k.del, k.open);
     }
     if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 
-  int finalScore = 0;
   for (int r0 = 1; r0 <= Q; r0 += 64) {
     int tV, loV, hiV;
     unsigned rsV;
@@ -428,18 +467,19 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
     int qCodeV = 4;
     if (lane < nRows) qCodeV = base_code(qSeq[qStart + r0 - 1 + lane]);
 
-    // target codes (as code * 8) are staged one row ahead of their use, so the LDS read of a row's
-    // codes is issued while the previous row is being computed
+    // The target ring is staged one row ahead of its use, so the LDS read of a row's entries is
+    // issued while the previous row is being computed.
     auto stageT = [&](int upTo) {
       while (tLoaded <= upTo) {
         int c = tLoaded + lane;
-        if (c < tLen) ringT[c & ringMaskT] = (unsigned char)(base_code(tSeq[c]) * 8);
+        int code = (c < tLen) ? base_code(tSeq[c]) : 4;
+        ringT[c & ringMaskT] = kFast ? packedColumn(code) : (uint32_t)code;
         tLoaded += 64;
         if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     };
     stageT(min(__builtin_amdgcn_readlane(hiV, 0), tEnd - 1));
-    int tc8Next = (int)ringT[(__builtin_amdgcn_readlane(loV, 0) + lane) & ringMaskT];
+    uint32_t tNext = ringT[(__builtin_amdgcn_readlane(loV, 0) + lane) & ringMaskT];
 
     for (int i = 0; i < nRows; i++) {
       const int lo = __builtin_amdgcn_readlane(loV, i);
@@ -447,63 +487,52 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
       const unsigned rowStart = (unsigned)__builtin_amdgcn_readlane((int)rsV, i);
       const int qc = __builtin_amdgcn_readlane(qCodeV, i);
       const int hiC = min(hi, tEnd - 1);  // cells with t >= tEnd are skipped (:268-269)
-      const int tc8Cur = tc8Next;  // first 64 columns of this row, fetched one row ahead
+      const uint32_t tCur = tNext;  // first 64 columns of this row, fetched one row ahead
       if (i + 1 < nRows) {
         stageT(min(__builtin_amdgcn_readlane(hiV, i + 1), tEnd - 1));
-        tc8Next = (int)ringT[(__builtin_amdgcn_readlane(loV, i + 1) + lane) & ringMaskT];
+        tNext = ringT[(__builtin_amdgcn_readlane(loV, i + 1) + lane) & ringMaskT];
       }
-      int m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4, mPacked = 0;
-      if (kPacked) {
-        mPacked = __builtin_amdgcn_readlane(matV, qc);
-        m4 = __builtin_amdgcn_readlane(matV, qc + 8);
-      } else {
-        m0 = __builtin_amdgcn_readlane(matV, qc * 5 + 0);
-        m1 = __builtin_amdgcn_readlane(matV, qc * 5 + 1);
-        m2 = __builtin_amdgcn_readlane(matV, qc * 5 + 2);
-        m3 = __builtin_amdgcn_readlane(matV, qc * 5 + 3);
-        m4 = __builtin_amdgcn_readlane(matV, qc * 5 + 4);
-      }
-      auto subst = [&](int tc8) {
-        int m;
-        if (kPacked) {
-          m = __builtin_amdgcn_sbfe(mPacked, tc8, 8);
+      // substitution score of this row's query base against a target-ring entry at column c
+      auto subst = [&](uint32_t tEntry, int c) -> int {
+        if (kFast) {
+          if (qc < 4) return (int)__builtin_amdgcn_sbfe((int)tEntry, qc * 8, 8);
+          // query N (rare): the packed column has no N row; read the base again
+          const int tcode = (c >= 0 && c < tLen) ? base_code(tSeq[c]) : 4;
+          return __builtin_amdgcn_ds_bpermute((20 + tcode) * 4, matV);
         } else {
-          m = m3;
-          m = (tc8 == 0) ? m0 : m;
-          m = (tc8 == 8) ? m1 : m;
-          m = (tc8 == 16) ? m2 : m;
+          return __builtin_amdgcn_ds_bpermute((qc * 5 + (int)tEntry) * 4, matV);
         }
-        return (tc8 == 32) ? m4 : m;
       };
-      uint8_t *arrowRow = arrows + rowStart - lo;
+      uint8_t *arrowRow = arrows + rowStart;  // + (column - lo)
       const bool curSingle = (hiC - lo) < 64;
       ChunkCarry carry;
-      carry.a = carry.b = carry.s = kInf;
+      carry.a = carry.b = carry.s = k.inf;
 
       if (prevInRegs && curSingle) {
         // ---- register path: the row above is shifted into place with DPP ----
-        const int c = lo + lane;
         const int shift = lo - plo;  // >= 0
         int upS, upI, diagS;
         if (shift == 1) {
-          upS = wave_shl1(prevS, 0);
-          upI = wave_shl1(prevI, 0);
+          upS = wave_shl1(prevS, k.inf);
+          upI = wave_shl1(prevI, k.inf);
           diagS = prevS;
         } else if (shift == 0) {
           upS = prevS;
           upI = prevI;
-          diagS = wave_shr1(prevS, 0);
+          diagS = wave_shr1(prevS, k.inf);
         } else {
+          const bool upOk = lane + shift < 64, diagOk = lane + shift - 1 < 64;
           upS = __builtin_amdgcn_ds_bpermute((lane + shift) * 4, prevS);
           upI = __builtin_amdgcn_ds_bpermute((lane + shift) * 4, prevI);
           diagS = __builtin_amdgcn_ds_bpermute((lane + shift - 1) * 4, prevS);
+          upS = upOk ? upS : k.inf;
+          upI = upOk ? upI : k.inf;
+          diagS = diagOk ? diagS : k.inf;
         }
-        int s, iNew, arrow;
-        row_chunk<true>(k, carry, c <= hiC, c <= phi, (c - 1 <= phi) && (c > plo), upS, upI, diagS, subst(tc8Cur), s,
-                        iNew, arrow);
-        if (c <= hiC) arrowRow[c] = (uint8_t)arrow;
-        prevS = s;
-        prevI = iNew;
+        int arrow;
+        row_chunk<kFast, true>(k, carry, lane <= hiC - lo, upS, upI, diagS, subst(tCur, lo + lane), prevS, prevI,
+                               arrow);
+        if (lane <= hiC - lo) arrowRow[lane] = (uint8_t)arrow;
       } else {
         // ---- ring path: rows wider than one wavefront ----
         if (prevInRegs) {
@@ -515,19 +544,23 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
         for (int cb = lo; cb <= hiC; cb += 64) {
           const int c = cb + lane;
           const bool active = c <= hiC;
-          const int2 up = ring[c & ringMask];
+          int2 up = ring[c & ringMask];
           int sd = ring[(c - 1) & ringMask].x;
           if (cb > lo) sd = (lane == 0) ? carryDiag : sd;  // column cb-1 was overwritten by the previous chunk
-          const int tc8 = (cb == lo) ? tc8Cur : (int)ringT[c & ringMaskT];
+          carryDiag = __builtin_amdgcn_readlane(up.x, 63);
+          // ring entries outside the previous row's columns are stale
+          const bool upValid = c <= phi, diagValid = (c - 1 <= phi) && (c > plo);
+          up.x = upValid ? up.x : k.inf;
+          up.y = upValid ? up.y : k.inf;
+          sd = diagValid ? sd : k.inf;
+          const uint32_t tEntry = (cb == lo) ? tCur : ringT[c & ringMaskT];
           int s, iNew, arrow;
-          row_chunk<false>(k, carry, active, c <= phi, (c - 1 <= phi) && (c > plo), up.x, up.y, sd, subst(tc8), s,
-                           iNew, arrow);
+          row_chunk<kFast, false>(k, carry, active, up.x, up.y, sd, subst(tEntry, c), s, iNew, arrow);
           if (active) {
             ring[c & ringMask] = make_int2(s, iNew);
-            arrowRow[c] = (uint8_t)arrow;
+            arrowRow[c - lo] = (uint8_t)arrow;
           }
           if (kGlobalRing) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          carryDiag = __builtin_amdgcn_readlane(up.x, 63);
           if (cb == lo) {
             prevS = s;
             prevI = iNew;
@@ -540,10 +573,11 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
     }
   }
   // DP score = S[Q][tEnd-1] (AffineGuidedAlign.h:481-483): the last row is still in registers or in the ring
+  int finalScore = 0;
   if (prevInRegs) {
-    if (plo + lane == tEnd - 1) finalScore = prevS;
+    if (plo + lane == tEnd - 1) finalScore = prevS >> sc;
   } else {
-    if (lane == 0) finalScore = ring[(tEnd - 1) & ringMask].x;
+    if (lane == 0) finalScore = ring[(tEnd - 1) & ringMask].x >> sc;
   }
   // only one lane holds a non-zero value: a wave sum publishes it
   int fs = finalScore;
@@ -650,18 +684,18 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
         break;
       }
     } else if (state == 1) {
-      if (a & 8u) {
+      if (a & AR_I_OPEN) {
+        state = 0;
+      } else {
         emit(OP_I);
         r--;
-      } else {
-        state = 0;
       }
     } else {
-      if (a & 16u) {
+      if (a & AR_D_OPEN) {
+        state = 0;
+      } else {
         emit(OP_D);
         c--;
-      } else {
-        state = 0;
       }
     }
   }
@@ -759,17 +793,17 @@ void launch_geometry(const RefineBatchView &batch, int band, int first, int coun
   if (count <= 0) return;
   hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
 }
-void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool packedMatrix,
+void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool fast,
                  hipStream_t stream) {
   if (args.count <= 0) return;
   const dim3 grid((args.count + 3) / 4), block(256);
   if (globalRing) {
-    if (packedMatrix)
+    if (fast)
       hipLaunchKernelGGL((fill_kernel<true, true>), grid, block, 0, stream, batch, args);
     else
       hipLaunchKernelGGL((fill_kernel<true, false>), grid, block, 0, stream, batch, args);
   } else {
-    if (packedMatrix)
+    if (fast)
       hipLaunchKernelGGL((fill_kernel<false, true>), grid, block, 0, stream, batch, args);
     else
       hipLaunchKernelGGL((fill_kernel<false, false>), grid, block, 0, stream, batch, args);
