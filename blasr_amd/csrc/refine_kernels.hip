@@ -20,8 +20,9 @@
 //                    (S and affine-insert I) live in an LDS ring indexed by
 //                    target column; only the 1-byte packed arrows (3 bits S,
 //                    1 bit I, 1 bit D) and an 8-byte row record go to HBM.
-//   traceback_kernel one lane per candidate: walks the packed arrows backwards,
-//                    run-length encodes the path and accumulates the statistics.
+//   traceback_kernel one lane per candidate: walks the packed arrows backwards with the
+//                    arrow bytes prefetched four rows ahead, run-length encodes the path.
+//   stats_kernel     one wavefront per candidate, lane = op: ComputeAlignmentStats.
 //   scan / compact   exclusive scan of op counts and a coalesced copy of the
 //                    per-candidate op runs into the caller's arena.
 // Integer DP: no MFMA anywhere.  Results are bit-identical to the reference.
@@ -592,31 +593,47 @@ template __global__ void fill_kernel<true, false>(RefineBatchView, FillArgs);
 
 // ---------------------------------------------------------------------------
 // traceback_kernel: one lane per candidate (AffineGuidedAlign.h:377-468), fused with
-// ArrowPathToAlignment (RLE), RemoveAlignmentPrefixGaps and ComputeAlignmentStats.
+// ArrowPathToAlignment (RLE, Alignment.h:190-254) and RemoveAlignmentPrefixGaps.
+//
+// The walk is a chain of dependent byte loads, so it is organised around memory
+// latency: the outer loop advances one DP row per iteration (every arrow except
+// Left/AffineDelLeft moves up exactly one row), and the arrow bytes of a row are
+// fetched as an 8-byte window four rows before the path gets there (the path
+// drifts at most one column per row, so a window ending at the current column
+// still covers it), the row records eight rows ahead.  The loop is unrolled by 8
+// so that every window / record lives in a statically named register and the
+// compiler can wait with counted vmcnt instead of draining all loads.
 // ---------------------------------------------------------------------------
+constexpr int kTbWin = 8;  // bytes per prefetched arrow window
+
+__device__ __forceinline__ uint64_t load_window(const uint8_t *p) {
+  // unaligned 8-byte load (global memory allows it); p stays inside the candidate's arrow slab
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
 __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, TraceArgs args) {
   const int idx = blockIdx.x * 64 + threadIdx.x;
-  if (idx >= args.count) return;
-  const int task = args.first + idx;
+  const bool inRange = idx < args.count;
+  const int task = args.first + (inRange ? idx : 0);
   const TaskGeometry geo = args.geo[task];
-  RefineResult res;
-  res.status = geo.status;
-  res.q_pos = res.t_pos = res.dp_score = res.n_cells = res.score = 0;
-  res.n_match = res.n_mismatch = res.n_ins = res.n_del = res.n_ops = 0;
-  res.reserved = 0;
-  res.ops_off = 0;
-  if (geo.status != 0) {
+  bool alive = inRange && geo.status == 0;
+  if (inRange && geo.status != 0) {
+    RefineResult res;
+    res.status = geo.status;
+    res.q_pos = res.t_pos = res.dp_score = res.n_cells = res.score = 0;
+    res.n_match = res.n_mismatch = res.n_ins = res.n_del = res.n_ops = 0;
+    res.reserved = 0;
+    res.ops_off = 0;
     args.results[task] = res;
     args.opsStart[task] = 0;
-    return;
   }
-  const uint8_t *qSeq = batch.seq + batch.q_off[task];
-  const uint8_t *tSeq = batch.seq + batch.t_off[task];
   const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
-  const int nBlocks = batch.n_blocks[task];
-  const int qStart = blocks[0], tStart = blocks[1];
-  const int Q = geo.rows;
-  const int tEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+  const int nBlocks = alive ? batch.n_blocks[task] : 1;
+  const int qStart = alive ? blocks[0] : 0, tStart = alive ? blocks[1] : 0;
+  const int Q = alive ? geo.rows : 0;
+  const int tEnd = alive ? blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2] : 0;
   const uint8_t *arrows = args.arrows + args.arrowOff[task];
   const int2 *rowTab = args.rowTab + args.rowOff[task];
   uint32_t *arena = args.arena + args.arenaOff[task];
@@ -625,12 +642,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   int w = cap;  // ops are written backwards: arena[w .. cap) is the forward op list
   int curType = -1, curLen = 0;
   bool seenM = false;
-  int matchSum = 0, nMatch = 0, nMismatch = 0;
-  int r = Q, c = tEnd - 1, state = 0;  // 0 = match matrix, 1 = affine ins, 2 = affine del
-  int rowR = -1;
-  int2 row = make_int2(0, 0);
+  int c = tEnd - 1, state = 0;  // 0 = match matrix, 1 = affine ins, 2 = affine del
   int status = 0;
-  int guard = 2 * cap + 8;
   auto emit = [&](int type) {
     if (type == curType) {
       curLen++;
@@ -643,102 +656,189 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
     curType = type;
     curLen = 1;
   };
-  while ((r >= 1 || c >= tStart) && guard-- > 0) {
-    if (r == 0) {
-      // deletion row: arrows are Left down to tStart-1 (:178-208)
-      emit(OP_D);
-      c--;
-      continue;
-    }
-    if (rowR != r) {
-      row = rowTab[r];
-      rowR = r;
-    }
-    const unsigned a = arrows[(unsigned)row.x + (unsigned)(c - row.y)];
-    if (state == 0) {
-      const unsigned s = a & 7u;
-      if (s == AR_DIAG) {
-        const int qc = base_code(qSeq[qStart + r - 1]);
-        const int tc = base_code(tSeq[c]);
-        matchSum += args.matrix[qc * 5 + tc];
-        if (qc == tc) nMatch++; else nMismatch++;
-        emit(OP_M);
-        r--;
-        c--;
-      } else if (s == AR_UP) {
-        emit(OP_I);
-        r--;
-      } else if (s == AR_LEFT) {
-        emit(OP_D);
-        c--;
-      } else if (s == AR_INS_CLOSE) {
-        emit(OP_I);
-        r--;
-        state = 1;
-      } else if (s == AR_DEL_CLOSE) {
-        emit(OP_D);
-        c--;
-        state = 2;
-      } else {
-        status = TASK_BAD_PATH;
-        break;
-      }
-    } else if (state == 1) {
-      if (a & AR_I_OPEN) {
-        state = 0;
-      } else {
-        emit(OP_I);
-        r--;
-      }
-    } else {
-      if (a & AR_D_OPEN) {
-        state = 0;
-      } else {
-        emit(OP_D);
-        c--;
+
+  // slot k of RT holds the record of row Q-k' (k' = k mod 8), slot k of W/CB the window of row Q-k' (k' mod 4)
+  int2 RT[8];
+  uint64_t W[4];
+  int CB[4];
+#pragma unroll
+  for (int j = 0; j < 8; j++) RT[j] = (alive && Q - j >= 1) ? rowTab[Q - j] : make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    CB[j] = max(c - (kTbWin - 1), RT[j].y);
+    W[j] = (alive && Q - j >= 1) ? load_window(arrows + (unsigned)RT[j].x + (unsigned)(CB[j] - RT[j].y)) : 0ull;
+  }
+
+  for (int k0 = 0; __any(alive); k0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = Q - (k0 + j);
+      if (alive && r >= 1) {
+        uint64_t win = W[j & 3];
+        int cb = CB[j & 3];
+        const int2 row = RT[j];  // {matrix offset of the row, first column}
+        // all moves inside row r
+        int guard = (tEnd - tStart) + 8;
+        for (;;) {
+          if (c < cb || c >= cb + kTbWin) {  // the path left the prefetched window (long deletion): fetch on demand
+            cb = max(c - (kTbWin - 1), row.y);
+            win = load_window(arrows + (unsigned)row.x + (unsigned)(cb - row.y));
+          }
+          const unsigned a = (unsigned)(win >> ((c - cb) * 8)) & 0xffu;
+          if (state == 0) {
+            const unsigned s = a & 7u;
+            if (s == AR_DIAG) {
+              emit(OP_M);
+              c--;
+              break;
+            } else if (s == AR_UP) {
+              emit(OP_I);
+              break;
+            } else if (s == AR_INS_CLOSE) {
+              emit(OP_I);
+              state = 1;
+              break;
+            } else if (s == AR_LEFT) {
+              emit(OP_D);
+              c--;
+            } else if (s == AR_DEL_CLOSE) {
+              emit(OP_D);
+              c--;
+              state = 2;
+            } else {
+              status = TASK_BAD_PATH;
+              alive = false;
+              break;
+            }
+          } else if (state == 1) {
+            if (a & AR_I_OPEN) {
+              state = 0;
+            } else {
+              emit(OP_I);
+              break;
+            }
+          } else {
+            if (a & AR_D_OPEN) {
+              state = 0;
+            } else {
+              emit(OP_D);
+              c--;
+            }
+          }
+          if (--guard < 0) {
+            status = TASK_BAD_PATH;
+            alive = false;
+            break;
+          }
+        }
+        // the path is now in row r-1.  Prefetch the window of row r-4 and the record of row r-8
+        // into the slots this row just vacated.
+        if (r - 4 >= 1) {
+          const int2 ahead = RT[(j + 4) & 7];
+          CB[j & 3] = max(c - (kTbWin - 1), ahead.y);
+          W[j & 3] = load_window(arrows + (unsigned)ahead.x + (unsigned)(CB[j & 3] - ahead.y));
+        }
+        if (r - 8 >= 1) RT[j] = rowTab[r - 8];
+        if (r == 1 && alive) {
+          // row 0 (the deletion row, :178-208): Left arrows down to column tStart-1; the walk ends when
+          // q < qStart and t < tStart
+          while (c >= tStart) {
+            emit(OP_D);
+            c--;
+          }
+          alive = false;
+        }
       }
     }
   }
-  if (guard <= 0) status = TASK_BAD_PATH;
-  emit(-2);  // flush the last run
-  // RemoveAlignmentPrefixGaps: leading gap runs fold into qPos / tPos
-  int leadI = 0, leadD = 0;
-  while (w < cap && (arena[w] & 3u) != OP_M) {
-    if ((arena[w] & 3u) == OP_I) leadI += (int)(arena[w] >> 2); else leadD += (int)(arena[w] >> 2);
-    w++;
-  }
-  // ComputeAlignmentScore, affine form (AlignmentUtils.h:77-100): one penalty per maximal gap run
-  int nIns = 0, nDel = 0, gapScore = 0;
-  for (int i = w; i < cap;) {
-    if ((arena[i] & 3u) == OP_M) {
-      i++;
-      continue;
+  if (inRange && geo.status == 0) {
+    emit(-2);  // flush the last run
+    // RemoveAlignmentPrefixGaps (AlignmentUtils.h:620-644): leading gap runs fold into qPos / tPos
+    int leadI = 0, leadD = 0;
+    while (w < cap && (arena[w] & 3u) != OP_M) {
+      if ((arena[w] & 3u) == OP_I) leadI += (int)(arena[w] >> 2); else leadD += (int)(arena[w] >> 2);
+      w++;
     }
-    int runLen = 0, lastType = OP_I;
-    while (i < cap && (arena[i] & 3u) != OP_M) {
-      const int len = (int)(arena[i] >> 2);
-      lastType = (int)(arena[i] & 3u);
-      if (lastType == OP_I) nIns += len; else nDel += len;
-      runLen += len;
-      i++;
-    }
-    const int linear = (lastType == OP_D ? args.del : args.ins) * runLen;
-    const int affine = runLen * args.ext + args.open;
-    gapScore += (linear < affine) ? linear : affine;
+    RefineResult res;
+    res.status = status;
+    res.q_pos = qStart + (w < cap ? leadI : 0);
+    res.t_pos = tStart + (w < cap ? leadD : 0);
+    res.dp_score = args.dpScore[task];
+    res.n_cells = (int32_t)geo.cells;
+    res.score = res.n_match = res.n_mismatch = res.n_ins = res.n_del = 0;  // stats_kernel
+    res.n_ops = cap - w;
+    res.reserved = 0;
+    res.ops_off = 0;
+    args.results[task] = res;
+    args.opsStart[task] = w;
   }
-  res.status = status;
-  res.q_pos = qStart + (w < cap ? leadI : 0);
-  res.t_pos = tStart + (w < cap ? leadD : 0);
-  res.dp_score = args.dpScore[task];
-  res.n_cells = (int32_t)geo.cells;
-  res.score = matchSum + gapScore;
-  res.n_match = nMatch;
-  res.n_mismatch = nMismatch;
-  res.n_ins = nIns;
-  res.n_del = nDel;
-  res.n_ops = cap - w;
-  args.results[task] = res;
-  args.opsStart[task] = w;
+}
+
+// ---------------------------------------------------------------------------
+// stats_kernel: ComputeAlignmentStats, affine form (AlignmentUtils.h:535-584 with
+// ComputeAlignmentScore :60-124), one wavefront per candidate, lane = op.
+// The walk over the alignment columns is replaced by prefix sums over the op list.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_kernel(RefineBatchView batch, TraceArgs args) {
+  __shared__ int matrix[25];
+  if (threadIdx.x < 25) matrix[threadIdx.x] = args.matrix[threadIdx.x];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= args.count) return;
+  const int task = args.first + idx;
+  RefineResult res = args.results[task];
+  if (res.status & (TASK_EMPTY_GUIDE | TASK_BAD_GUIDE)) return;
+  const uint8_t *qSeq = batch.seq + batch.q_off[task];
+  const uint8_t *tSeq = batch.seq + batch.t_off[task];
+  const uint32_t *ops = args.arena + args.arenaOff[task] + args.opsStart[task];
+  const int nOps = res.n_ops;
+  int qBase = res.q_pos, tBase = res.t_pos;
+  int matchSum = 0, nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0, gapScore = 0;
+  for (int c0 = 0; c0 < nOps; c0 += 64) {
+    const int i = c0 + lane;
+    const uint32_t op = i < nOps ? ops[i] : 0u;
+    const int ty = (int)(op & 3u), len = (int)(op >> 2);
+    const unsigned qAdv = ty != OP_D ? (unsigned)len : 0u, tAdv = ty != OP_I ? (unsigned)len : 0u;
+    const unsigned qIncl = wave_prefix_sum(qAdv), tIncl = wave_prefix_sum(tAdv);
+    if (ty == OP_M) {
+      const uint8_t *qp = qSeq + qBase + (int)(qIncl - qAdv), *tp = tSeq + tBase + (int)(tIncl - tAdv);
+      for (int j = 0; j < len; j++) {
+        const int qc = base_code(qp[j]), tc = base_code(tp[j]);
+        matchSum += matrix[qc * 5 + tc];
+        if (qc == tc) nMatch++; else nMismatch++;  // ThreeBit equality: N against N counts as a match
+      }
+    } else if (i < nOps) {
+      if (ty == OP_I) nIns += len; else nDel += len;
+      if ((ops[i + 1] & 3u) == OP_M) {
+        // last op of a maximal gap run (the op list ends with a block, so i+1 exists): one penalty per run,
+        // linear cost of the run's LAST column type against open + len * extend
+        int runLen = len;
+        for (int b = i - 1; b >= 0 && (ops[b] & 3u) != OP_M; b--) runLen += (int)(ops[b] >> 2);
+        const int linear = (ty == OP_D ? args.del : args.ins) * runLen;
+        const int affine = runLen * args.ext + args.open;
+        gapScore += (linear < affine) ? linear : affine;
+      }
+    }
+    qBase += (int)__builtin_amdgcn_readlane((int)qIncl, 63);
+    tBase += (int)__builtin_amdgcn_readlane((int)tIncl, 63);
+  }
+  int score = matchSum + gapScore;
+  for (int off = 32; off > 0; off >>= 1) {
+    score += __shfl_xor(score, off);
+    nMatch += __shfl_xor(nMatch, off);
+    nMismatch += __shfl_xor(nMismatch, off);
+    nIns += __shfl_xor(nIns, off);
+    nDel += __shfl_xor(nDel, off);
+  }
+  if (lane == 0) {
+    res.score = score;
+    res.n_match = nMatch;
+    res.n_mismatch = nMismatch;
+    res.n_ins = nIns;
+    res.n_del = nDel;
+    args.results[task] = res;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -812,6 +912,7 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
   if (args.count <= 0) return;
   hipLaunchKernelGGL(traceback_kernel, dim3((args.count + 63) / 64), dim3(64), 0, stream, batch, args);
+  hipLaunchKernelGGL(stats_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
 }
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,
                      hipStream_t stream) {
