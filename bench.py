@@ -121,14 +121,14 @@ def main():
 
     rec = results.view(torch.int32).view(n, 14)
     ok = rec[:, 0] == 0
-    counters = torch.stack([torch.tensor(n, device=dev), ok.sum(), (w["q_len"].to(torch.int64) * ok).sum(),
-                            rec[:, 4].to(torch.int64).sum()]).to(torch.int64)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(counters)  # the only collective of the path: per-rank counts
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    reads_total, aligned_reads, aligned_bases, cells_total = (int(v) for v in counters.tolist())
+    from blasr_amd import shard
+
+    # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
+    totals = shard.reduce_counters(n, int(ok.sum()), int((w["q_len"].to(torch.int64) * ok).sum()),
+                                   int(rec[:, 4].to(torch.int64).sum()), device=dev)
+    elapsed = shard.max_over_ranks(elapsed, device=dev)
+    reads_total, aligned_reads = totals["reads"], totals["aligned_reads"]
+    aligned_bases, cells_total = totals["aligned_bases"], totals["dp_cells"]
 
     if rank == 0:
         value = aligned_bases * args.steps / elapsed
@@ -155,8 +155,11 @@ def main():
             "gcups_per_gpu": cells_total / world * args.steps / elapsed / 1e9,
             "stage_ms_per_step": {k: v / args.steps for k, v in zip(("geometry", "fill", "traceback", "compact"),
                                                                      stage_ms)},
-            "roofline": {"bound": "hbm", "kernel": "fill_kernel<false>", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill_kernel<false, true>", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "traffic_note": "PMC passes (profiles/r01_pmc_counters_20k_reads.json): FETCH_SIZE x2 + "
+                                         "WRITE_SIZE = 1.11 x the algorithmic bytes of the same launch",
+                         "algorithmic_bytes_per_launch": fill_bytes / max(launches, 1),
                          "launches": launches, "avg_launch_ms": fill_ms / max(launches, 1),
                          "fill_gcups": cells / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }

@@ -533,7 +533,8 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
         int arrow;
         row_chunk<kFast, true>(k, carry, lane <= hiC - lo, upS, upI, diagS, subst(tCur, lo + lane), prevS, prevI,
                                arrow);
-        if (lane <= hiC - lo) arrowRow[lane] = (uint8_t)arrow;
+        // uniform row base in SGPRs + lane offset: no per-lane 64-bit address arithmetic
+        if (lane <= hiC - lo) asm volatile("global_store_byte %0, %1, %2" ::"v"(lane), "v"(arrow), "s"(arrowRow) : "memory");
       } else {
         // ---- ring path: rows wider than one wavefront ----
         if (prevInRegs) {
