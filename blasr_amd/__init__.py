@@ -14,7 +14,8 @@ from .hip import (  # noqa: F401
     RefineBatch,
     RefineResult,
     ScoreParams,
+    SdpParams,
     load_library,
 )
 
-__all__ = ["BlasrHipError", "Context", "LIB_PATH", "RefineBatch", "RefineResult", "ScoreParams", "load_library"]
+__all__ = ["BlasrHipError", "Context", "LIB_PATH", "RefineBatch", "RefineResult", "ScoreParams", "SdpParams", "load_library"]

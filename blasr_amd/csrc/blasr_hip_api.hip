@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/blasr_hip.h"
+#include "ctx.h"
 #include "refine_kernels.h"
 
 using namespace blasr_hip;
@@ -19,20 +20,10 @@ using namespace blasr_hip;
 static_assert(sizeof(RefineResult) == sizeof(blasr_hip_refine_result), "result record layout");
 static_assert(offsetof(RefineResult, ops_off) == offsetof(blasr_hip_refine_result, ops_off), "result record layout");
 
-struct blasr_hip_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  char *workspace = nullptr;
-  size_t workspaceBytes = 0;
-  int64_t workspaceLimit = 48ll << 30;
-  std::string lastError;
-  float ms[4] = {0, 0, 0, 0};
-  int64_t counters[3] = {0, 0, 0};
-};
-
 namespace {
+}  // namespace
 
-int fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
+int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -41,14 +32,9 @@ int fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) ctx->lastError = buf;
   return code;
 }
+#define fail blasr_hip_fail
 
-#define HIP_TRY(ctx, expr)                                                                        \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess)                                                                         \
-      return fail(ctx, e_ == hipErrorOutOfMemory ? BLASR_HIP_ERR_NOMEM : BLASR_HIP_ERR_HIP,       \
-                  "%s failed: %s", #expr, hipGetErrorString(e_));                                 \
-  } while (0)
+namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -138,6 +124,7 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     (void)hipStreamDestroy(ctx->stream);
   }
   if (ctx->workspace) (void)hipFree(ctx->workspace);
+  for (auto &sl : ctx->slabs) (void)hipFree(sl.first);
   delete ctx;
   return BLASR_HIP_OK;
 }

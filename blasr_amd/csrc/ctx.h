@@ -1,0 +1,36 @@
+// The context behind blasr_hip_ctx (shared by the refine and SDP host layers).
+#ifndef BLASR_AMD_CTX_H_
+#define BLASR_AMD_CTX_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+struct blasr_hip_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  char *workspace = nullptr;
+  size_t workspaceBytes = 0;
+  int64_t workspaceLimit = 48ll << 30;
+  std::string lastError;
+  float ms[4] = {0, 0, 0, 0};
+  int64_t counters[3] = {0, 0, 0};
+  float sdpMs[4] = {0, 0, 0, 0};
+  int64_t sdpCounters[3] = {0, 0, 0};
+  // grow-only slabs for the SDP stage's variable-size intermediates (bump-allocated per call)
+  std::vector<std::pair<char *, size_t>> slabs;
+};
+
+int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                            \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return blasr_hip_fail(ctx, e_ == hipErrorOutOfMemory ? BLASR_HIP_ERR_NOMEM : BLASR_HIP_ERR_HIP, \
+                            "%s failed: %s", #expr, hipGetErrorString(e_));                           \
+  } while (0)
+
+#endif

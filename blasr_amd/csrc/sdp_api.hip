@@ -1,0 +1,498 @@
+// sdp_api.hip -- host side of blasr_hip_sdp_*: the level-by-level orchestration of the SDP
+// kernels (sdp_kernels.hip).  SDPAlign's recursion (SDPAlign.h:445-456, :509-520) is run as
+// successive waves of kernels; all variable-size intermediates live in stream-ordered device
+// allocations sized from device-side scans.  No CPU algorithm here: only planning and launches.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/blasr_hip.h"
+#include "ctx.h"
+#include "sdp_kernels.h"
+
+using namespace blasr_hip;
+
+static_assert(sizeof(SdpResult) == sizeof(blasr_hip_sdp_result), "result record layout");
+
+namespace {
+
+// Bump allocator over the context's grow-only device slabs (hipMalloc'd once, reused by every call:
+// the analogue of MappingBuffers' "grow to the high-water mark and keep", Blasr.cpp:313-369).
+struct Arena {
+  blasr_hip_ctx *ctx;
+  hipStream_t st;
+  size_t slab = 0, offset = 0;
+  hipError_t err = hipSuccess;
+  int count = 0;
+  Arena(blasr_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {}
+  template <typename T>
+  T *get(size_t n) {
+    const size_t bytes = (std::max<size_t>(n * sizeof(T), 256) + 255) / 256 * 256;
+    while (slab < ctx->slabs.size() && offset + bytes > ctx->slabs[slab].second) {
+      slab++;
+      offset = 0;
+    }
+    if (slab == ctx->slabs.size()) {
+      const size_t want = std::max<size_t>(bytes, (size_t)256 << 20);
+      char *p = nullptr;
+      hipError_t e = hipMalloc((void **)&p, want);
+      if (e != hipSuccess) {
+        err = e;
+        return nullptr;
+      }
+      ctx->slabs.push_back(std::make_pair(p, want));
+      offset = 0;
+    }
+    char *p = ctx->slabs[slab].first + offset;
+    offset += bytes;
+    const int idx = count++;
+    if (const char *poison = getenv("BLASR_HIP_POISON")) {  // developer aid: make reads of unwritten memory visible
+      const char *lo = getenv("BLASR_HIP_POISON_LO"), *hi = getenv("BLASR_HIP_POISON_HI");
+      if ((!lo || idx >= atoi(lo)) && (!hi || idx < atoi(hi))) (void)hipMemsetAsync(p, atoi(poison), bytes, st);
+    }
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct Counters {
+  unsigned long long pool, sw, child;
+  int32_t overflow, pad;
+};
+
+int bits_for(uint64_t v) {
+  int b = 1;
+  while (b < 64 && (v >> b) != 0) b++;
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; i++) ms[i] = ctx->sdpMs[i];
+  for (int i = 0; i < 3; i++) counters[i] = ctx->sdpCounters[i];
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
+                         const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                         int64_t blocksCap, int64_t *blocksUsed) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !sp || !score || b->n < 0 || blocksCap < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
+  if (blocksUsed) *blocksUsed = 0;
+  for (int i = 0; i < 4; i++) ctx->sdpMs[i] = 0;
+  for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
+  if ((sp->align_type != 0 && sp->align_type != 1) || sp->detailed != 1 || sp->extend_front != 0 ||
+      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
+                          "SDP parameters outside the device domain (align_type Local/Global, detailed=1, "
+                          "extend_front=0, 1 <= word_size <= 16)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  Arena arena(ctx, st);
+  hipEvent_t evA, evB;
+  HIP_TRY(ctx, hipEventCreate(&evA));
+  HIP_TRY(ctx, hipEventCreate(&evB));
+  float phaseMs[4] = {0, 0, 0, 0};
+  auto tick = [&]() { (void)hipEventRecord(evA, st); };
+  auto tock = [&](int phase) {
+    (void)hipEventRecord(evB, st);
+    (void)hipEventSynchronize(evB);
+    float t = 0;
+    (void)hipEventElapsedTime(&t, evA, evB);
+    phaseMs[phase] += t;
+  };
+#define ARENA_CHECK()                                                                                        \
+  do {                                                                                                       \
+    if (arena.err != hipSuccess) {                                                                           \
+      (void)hipEventDestroy(evA);                                                                            \
+      (void)hipEventDestroy(evB);                                                                            \
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "device allocation failed: %s", hipGetErrorString(arena.err)); \
+    }                                                                                                        \
+  } while (0)
+
+  // ---- level 0 tasks from the batch (lengths are needed on the host to plan) ----
+  std::vector<int64_t> qOff(n), tOff(n);
+  std::vector<int32_t> qLen(n), tLen(n);
+  HIP_TRY(ctx, hipMemcpyAsync(qOff.data(), b->q_off, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(tOff.data(), b->t_off, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), b->q_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), b->t_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<SdpTask> top(n);
+  for (int i = 0; i < n; i++) {
+    if (qLen[i] < 0 || tLen[i] < 0 || qLen[i] >= (1 << 24) || tLen[i] >= (1 << 24)) {
+      (void)hipEventDestroy(evA);
+      (void)hipEventDestroy(evB);
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "candidate %d: sequence length outside [0, 2^24)", i);
+    }
+    SdpTask &t = top[i];
+    t.qOff = qOff[i];
+    t.tOff = tOff[i];
+    t.qLen = qLen[i];
+    t.tLen = tLen[i];
+    t.k = sp->word_size;
+    t.type = sp->align_type;
+    t.prefix = sp->prefix_length;
+    t.recurse = sp->recurse;
+    t.maxPerPos = sp->max_per_position;
+    t.top = i;
+    t.qOrg = 0;
+    t.tOrg = 0;
+  }
+  SdpTask *dTop = arena.get<SdpTask>(n);
+  int32_t *dMatrix = arena.get<int32_t>(32);
+  Counters *dCounters = arena.get<Counters>(1);
+  ARENA_CHECK();
+  HIP_TRY(ctx, hipMemcpyAsync(dTop, top.data(), sizeof(SdpTask) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dMatrix, score->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
+
+  SdpParams prm;
+  prm.sdpIns = sp->sdp_ins;
+  prm.sdpDel = sp->sdp_del;
+  prm.indelRate = sp->indel_rate;
+  prm.noRecurseUnder = sp->recurse_over;
+  prm.match = score->matrix[0];
+  prm.ins = score->ins;
+  prm.del = score->del;
+
+  struct LevelOut {
+    uint64_t *poolKeys, *poolVals;
+    int64_t poolCount;
+    SwTask *sw;
+    int64_t swCount;
+  };
+  std::vector<LevelOut> outs;
+  const SdpTask *dTasks = dTop;
+  int nTasks = n;
+  int k = sp->word_size;
+  int64_t totalInvocations = 0, totalFrags = 0;
+
+  for (int level = 0; nTasks > 0; level++) {
+    totalInvocations += nTasks;
+    SdpLevelArrays lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.n = nTasks;
+    lv.tasks = dTasks;
+    // ---- k-mer keys of the targets, sorted per task ----
+    tick();
+    int64_t *sizes = arena.get<int64_t>(nTasks + 1);
+    int64_t *keyOff = arena.get<int64_t>(nTasks + 1);
+    ARENA_CHECK();
+    HIP_TRY(ctx, hipMemsetAsync(sizes + nTasks, 0, sizeof(int64_t), st));
+    launch_sdp_gather_sizes(lv, 0, sizes, st);
+    size_t tmpBytes = 0;
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, tmpBytes, sizes, keyOff, (int64_t)0, (size_t)nTasks + 1,
+                                         rocprim::plus<int64_t>(), st));
+    void *tmp = arena.get<char>(tmpBytes);
+    ARENA_CHECK();
+    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, keyOff, (int64_t)0, (size_t)nTasks + 1,
+                                         rocprim::plus<int64_t>(), st));
+    int64_t totalKeys = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&totalKeys, keyOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (totalKeys >= (1ll << 32)) {
+      (void)hipEventDestroy(evA);
+      (void)hipEventDestroy(evB);
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld target bases in one level",
+                            (long long)totalKeys);
+    }
+    uint64_t *keysIn = arena.get<uint64_t>((size_t)totalKeys);
+    uint64_t *keysOut = arena.get<uint64_t>((size_t)totalKeys);
+    ARENA_CHECK();
+    lv.keyOff = keyOff;
+    lv.keys = keysIn;
+    launch_sdp_keys(lv, b->seq, st);
+    launch_sdp_sort_keys(lv, keysOut, st);
+    tock(0);
+
+    // ---- fragments ----
+    tick();
+    lv.nRaw = arena.get<int32_t>((size_t)3 * nTasks);
+    lv.nFrag = arena.get<int32_t>(nTasks);
+    lv.chainEnd = arena.get<int32_t>(nTasks);
+    int64_t *fragOff = arena.get<int64_t>(nTasks + 1);
+    ARENA_CHECK();
+    launch_sdp_match(lv, b->seq, false, st);
+    launch_sdp_gather_sizes(lv, 1, sizes, st);
+    HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, fragOff, (int64_t)0, (size_t)nTasks + 1,
+                                         rocprim::plus<int64_t>(), st));
+    int64_t nFragTotal = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nFragTotal, fragOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (nFragTotal >= (1ll << 31)) {
+      (void)hipEventDestroy(evA);
+      (void)hipEventDestroy(evB);
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld fragments in one level",
+                            (long long)nFragTotal);
+    }
+    totalFrags += nFragTotal;
+    const size_t nf = (size_t)std::max<int64_t>(nFragTotal, 1);
+    lv.fragOff = fragOff;
+    lv.raw = arena.get<Frag>(nf);
+    lv.frags = arena.get<Frag>(nf);
+    lv.yxKeys = arena.get<uint64_t>(nf);
+    lv.yxIdx = arena.get<uint32_t>(nf);
+    uint64_t *yxKeysOut = arena.get<uint64_t>(nf);
+    uint32_t *yxIdxOut = arena.get<uint32_t>(nf);
+    lv.cost = arena.get<int32_t>(nf);
+    lv.chainPrev = arena.get<int32_t>(nf);
+    lv.chainLen = arena.get<int32_t>(nf);
+    lv.predCl = arena.get<int32_t>(nf);
+    lv.above = arena.get<int32_t>(nf);
+    lv.colCol = arena.get<int32_t>(nf + 64);
+    lv.colOpt = arena.get<int32_t>(nf + 64);
+    lv.scratchA = arena.get<int32_t>(nf);
+    lv.scratchB = arena.get<int32_t>(3 * nf);
+    ARENA_CHECK();
+    launch_sdp_match(lv, b->seq, true, st);
+    launch_sdp_order(lv, st);
+    launch_sdp_yx_keys(lv, st);
+    launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);
+    launch_sdp_above_predcl(lv, st);
+    tock(1);
+
+    // ---- chain ----
+    tick();
+    launch_sdp_chain(lv, prm, st);
+    tock(2);
+    if (level == 0 && getenv("BLASR_HIP_SDP_DEBUG")) {
+      // developer aid: dump the fragments and chain state of candidate 0 (level 0)
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      int32_t nf0 = 0, end0 = 0;
+      (void)hipMemcpy(&nf0, lv.nFrag, 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&end0, lv.chainEnd, 4, hipMemcpyDeviceToHost);
+      std::vector<Frag> hf(std::max(nf0, 1));
+      std::vector<int32_t> hc(std::max(nf0, 1)), hp(std::max(nf0, 1)), hcl(std::max(nf0, 1)), hab(std::max(nf0, 1));
+      (void)hipMemcpy(hf.data(), lv.frags, sizeof(Frag) * nf0, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hc.data(), lv.cost, 4 * nf0, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hp.data(), lv.chainPrev, 4 * nf0, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hcl.data(), lv.predCl, 4 * nf0, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hab.data(), lv.above, 4 * nf0, hipMemcpyDeviceToHost);
+      FILE *fp = fopen(getenv("BLASR_HIP_SDP_DEBUG"), "w");
+      if (fp) {
+        fprintf(fp, "%d %d\n", nf0, end0);
+        for (int i = 0; i < nf0; i++)
+          fprintf(fp, "%u %u %u %d %d %d %d\n", hf[i].x, hf[i].y, hf[i].len, hc[i], hp[i], hcl[i], hab[i]);
+        fclose(fp);
+      }
+    }
+
+    // ---- blocks, gap-fill jobs, next level ----
+    tick();
+    SdpEmit e;
+    e.poolCap = nFragTotal;
+    e.swCap = nFragTotal;
+    e.childCap = nFragTotal;
+    e.poolKeys = arena.get<uint64_t>(nf);
+    e.poolVals = arena.get<uint64_t>(nf);
+    e.sw = arena.get<SwTask>(nf);
+    e.children = arena.get<SdpTask>(nf);
+    ARENA_CHECK();
+    HIP_TRY(ctx, hipMemsetAsync(dCounters, 0, sizeof(Counters), st));
+    e.poolCount = &dCounters->pool;
+    e.swCount = &dCounters->sw;
+    e.childCount = &dCounters->child;
+    e.overflow = &dCounters->overflow;
+    launch_sdp_blocks(lv, prm, e, st);
+    Counters hc;
+    HIP_TRY(ctx, hipMemcpyAsync(&hc, dCounters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    tock(3);
+    if (hc.overflow) {
+      (void)hipEventDestroy(evA);
+      (void)hipEventDestroy(evB);
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "internal: work-list overflow at level %d", level);
+    }
+    if (getenv("BLASR_HIP_SDP_TRACE"))
+      fprintf(stderr, "[sdp] level %d: tasks %d keys %lld frags %lld -> blocks %llu sw %llu children %llu\n", level,
+              nTasks, (long long)totalKeys, (long long)nFragTotal, hc.pool, hc.sw, hc.child);
+    LevelOut lo;
+    lo.poolKeys = e.poolKeys;
+    lo.poolVals = e.poolVals;
+    lo.poolCount = (int64_t)hc.pool;
+    lo.sw = e.sw;
+    lo.swCount = (int64_t)hc.sw;
+    outs.push_back(lo);
+    dTasks = e.children;
+    nTasks = (int)hc.child;
+    k = k - 4 > 5 ? k - 4 : 5;
+  }
+
+  // ---- gap fills (SWAlign) and assembly ----
+  tick();
+  int64_t poolTotal = 0, swTotal = 0;
+  for (auto &lo : outs) {
+    poolTotal += lo.poolCount;
+    swTotal += lo.swCount;
+  }
+  // q*t < noRecurseUnder bounds the blocks of one fill by min(q,t) <= sqrt(noRecurseUnder)
+  int64_t perFill = 1;
+  while (perFill * perFill < std::max(sp->recurse_over, 1)) perFill++;
+  const int64_t poolCap = poolTotal + swTotal * perFill + 16;
+  uint64_t *poolKeys = arena.get<uint64_t>((size_t)poolCap), *poolVals = arena.get<uint64_t>((size_t)poolCap);
+  uint64_t *poolKeysSorted = arena.get<uint64_t>((size_t)poolCap), *poolValsSorted = arena.get<uint64_t>((size_t)poolCap);
+  ARENA_CHECK();
+  int64_t at = 0;
+  for (auto &lo : outs) {
+    if (lo.poolCount > 0) {
+      HIP_TRY(ctx, hipMemcpyAsync(poolKeys + at, lo.poolKeys, sizeof(uint64_t) * lo.poolCount, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(poolVals + at, lo.poolVals, sizeof(uint64_t) * lo.poolCount, hipMemcpyDeviceToDevice, st));
+      at += lo.poolCount;
+    }
+  }
+  Counters init;
+  memset(&init, 0, sizeof(init));
+  init.pool = (unsigned long long)at;
+  HIP_TRY(ctx, hipMemcpyAsync(dCounters, &init, sizeof(Counters), hipMemcpyHostToDevice, st));
+  if (swTotal > 0) {
+    // scratch per lane: two score rows of (t+1) ints + (q+1)(t+1) arrow bytes, q*t < noRecurseUnder
+    const int64_t nru = std::max(sp->recurse_over, 1);
+    const int64_t scratchPerLane = ((2 * (nru + 1) * 4 + (2 * nru + 2) + 255) / 256) * 256;
+    const int64_t lanes = std::min<int64_t>((swTotal + 255) / 256, 512) * 256;
+    uint8_t *scratch = arena.get<uint8_t>((size_t)(scratchPerLane * lanes));
+    ARENA_CHECK();
+    SdpEmit e;
+    memset(&e, 0, sizeof(e));
+    e.poolKeys = poolKeys;
+    e.poolVals = poolVals;
+    e.poolCount = &dCounters->pool;
+    e.poolCap = poolCap;
+    e.overflow = &dCounters->overflow;
+    for (auto &lo : outs) launch_sw(lo.sw, lo.swCount, b->seq, dMatrix, prm, scratch, scratchPerLane, e, st);
+  }
+  Counters hc;
+  HIP_TRY(ctx, hipMemcpyAsync(&hc, dCounters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  const int64_t nPool = (int64_t)hc.pool;
+  if (getenv("BLASR_HIP_SDP_TRACE"))
+    fprintf(stderr, "[sdp] assembled: chain blocks %lld, sw fills %lld, pool %lld\n", (long long)poolTotal,
+            (long long)swTotal, (long long)nPool);
+  if (hc.overflow || nPool > poolCap) {
+    (void)hipEventDestroy(evA);
+    (void)hipEventDestroy(evB);
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "internal: block pool overflow");
+  }
+  int32_t *countPerTop = arena.get<int32_t>(n);
+  int64_t *counts64 = arena.get<int64_t>(n + 1);
+  int64_t *blkOff = arena.get<int64_t>(n + 1);
+  ARENA_CHECK();
+  HIP_TRY(ctx, hipMemsetAsync(countPerTop, 0, sizeof(int32_t) * n, st));
+  const uint64_t *sortedKeys = poolKeys, *sortedVals = poolVals;
+  if (nPool > 0) {
+    if (nPool >= (1ll << 32)) {
+      (void)hipEventDestroy(evA);
+      (void)hipEventDestroy(evB);
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld blocks", (long long)nPool);
+    }
+    const unsigned endBit = (unsigned)(32 + bits_for((uint64_t)n));
+    size_t sortBytes = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sortBytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
+                                           (size_t)nPool, 0u, endBit, st));
+    void *sortTmp = arena.get<char>(sortBytes);
+    ARENA_CHECK();
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(sortTmp, sortBytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
+                                           (size_t)nPool, 0u, endBit, st));
+    sortedKeys = poolKeysSorted;
+    sortedVals = poolValsSorted;
+    launch_pool_histogram(sortedKeys, nPool, countPerTop, st);
+  }
+  {
+    // blkOff = exclusive scan of the per-candidate block counts
+    size_t scanBytes = 0;
+    auto in = rocprim::make_transform_iterator(countPerTop, [] __device__(int32_t v) { return (int64_t)v; });
+    (void)counts64;
+    HIP_TRY(ctx, hipMemsetAsync(blkOff + n, 0, sizeof(int64_t), st));
+    HIP_TRY(ctx, rocprim::inclusive_scan(nullptr, scanBytes, in, blkOff + 1, (size_t)n, rocprim::plus<int64_t>(), st));
+    void *scanTmp = arena.get<char>(scanBytes);
+    ARENA_CHECK();
+    HIP_TRY(ctx, hipMemsetAsync(blkOff, 0, sizeof(int64_t), st));
+    HIP_TRY(ctx, rocprim::inclusive_scan(scanTmp, scanBytes, in, blkOff + 1, (size_t)n, rocprim::plus<int64_t>(), st));
+  }
+  launch_sdp_finish(n, dTop, b->seq, sortedKeys, sortedVals, blkOff, dMatrix, score->ins, score->del,
+                    score->affine_open, score->affine_extend, reinterpret_cast<SdpResult *>(results), blocks, blocksCap,
+                    st);
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  tock(3);
+  (void)hipEventDestroy(evA);
+  (void)hipEventDestroy(evB);
+  for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
+  ctx->sdpCounters[0] = totalInvocations;
+  ctx->sdpCounters[1] = totalFrags;
+  ctx->sdpCounters[2] = swTotal;
+  if (blocksUsed) *blocksUsed = nPool;
+  if (nPool > blocksCap)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "blocks arena too small: need %lld, have %lld", (long long)nPool,
+                          (long long)blocksCap);
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
+                       const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                       int64_t blocksCap, int64_t *blocksUsed) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !sp || !score || b->n < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
+  if (blocksUsed) *blocksUsed = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int64_t seqBytes = 0;
+  for (int i = 0; i < n; i++) {
+    if (b->q_len[i] < 0 || b->t_len[i] < 0 || b->q_off[i] < 0 || b->t_off[i] < 0)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "negative length or offset in candidate %d", i);
+    seqBytes = std::max<int64_t>(seqBytes, std::max(b->q_off[i] + b->q_len[i], b->t_off[i] + b->t_len[i]));
+  }
+  struct Dev {
+    void *p = nullptr;
+    ~Dev() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  Dev dSeq, dQOff, dQLen, dTOff, dTLen, dRes, dBlocks;
+  auto up = [&](Dev &d, const void *src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(&d.p, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  HIP_TRY(ctx, up(dSeq, b->seq, (size_t)seqBytes));
+  HIP_TRY(ctx, up(dQOff, b->q_off, sizeof(int64_t) * n));
+  HIP_TRY(ctx, up(dQLen, b->q_len, sizeof(int32_t) * n));
+  HIP_TRY(ctx, up(dTOff, b->t_off, sizeof(int64_t) * n));
+  HIP_TRY(ctx, up(dTLen, b->t_len, sizeof(int32_t) * n));
+  HIP_TRY(ctx, hipMalloc(&dRes.p, sizeof(blasr_hip_sdp_result) * n));
+  HIP_TRY(ctx, hipMalloc(&dBlocks.p, std::max<size_t>(sizeof(int32_t) * 3 * (size_t)blocksCap, 16)));
+  blasr_hip_sdp_batch db;
+  db.n = n;
+  db.seq = (const uint8_t *)dSeq.p;
+  db.q_off = (const int64_t *)dQOff.p;
+  db.q_len = (const int32_t *)dQLen.p;
+  db.t_off = (const int64_t *)dTOff.p;
+  db.t_len = (const int32_t *)dTLen.p;
+  int64_t used = 0;
+  int rc = blasr_hip_sdp_device(ctx, &db, sp, score, (blasr_hip_sdp_result *)dRes.p, (int32_t *)dBlocks.p, blocksCap,
+                                &used);
+  if (blocksUsed) *blocksUsed = used;
+  if (rc != BLASR_HIP_OK && rc != BLASR_HIP_ERR_CAPACITY) return rc;
+  HIP_TRY(ctx, hipMemcpy(results, dRes.p, sizeof(blasr_hip_sdp_result) * n, hipMemcpyDeviceToHost));
+  const int64_t copyBlocks = std::min(used, blocksCap);
+  if (copyBlocks > 0)
+    HIP_TRY(ctx, hipMemcpy(blocks, dBlocks.p, sizeof(int32_t) * 3 * (size_t)copyBlocks, hipMemcpyDeviceToHost));
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal interface between the C-ABI host layer (sdp_api.hip) and the gfx950
+// kernels of the SDP stage (sdp_kernels.hip).  Public surface: include/blasr_hip.h.
+#ifndef BLASR_AMD_SDP_KERNELS_H_
+#define BLASR_AMD_SDP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blasr_hip {
+
+// One SDPAlign invocation (SDPAlign.h:95-626): a top-level candidate or a
+// recursive call on a gap rectangle.
+struct SdpTask {
+  int64_t qOff, tOff;  // first base of the query / target rectangle in the sequence pool
+  int32_t qLen, tLen;
+  int32_t k;           // wordSize
+  int32_t type;        // 0 = Local, 1 = Global (AlignmentUtils.h:14-15)
+  int32_t prefix;      // sdpPrefixLength
+  int32_t recurse;     // recursion budget left
+  int32_t maxPerPos;   // maxMatchesPerPosition
+  int32_t top;         // index of the top-level candidate this call belongs to
+  int32_t qOrg, tOrg;  // origin of the rectangle in the top-level candidate's coordinates
+};
+
+// SWAlign(Global) on a gap rectangle with q*t < noRecurseUnder (SDPAlign.h:502-504, :438-441)
+struct SwTask {
+  int64_t qOff, tOff;
+  int32_t qLen, tLen;
+  int32_t top, qOrg, tOrg, pad;
+};
+
+struct Frag {  // sdp/SDPFragment.h:5-17, the fields that are data
+  uint32_t x, y, len, pad;
+};
+
+// Finished blocks, in top-level coordinates, as two parallel arrays (keys sort them):
+//   key = candidate << 32 | q        val = t << 32 | length
+
+struct SdpParams {
+  int sdpIns, sdpDel;
+  float indelRate;
+  int noRecurseUnder;
+  int match;       // scoreMatrix[0][0]
+  int ins, del;    // score function gap costs (SWAlign)
+};
+
+struct SdpLevelArrays {
+  int n;
+  const SdpTask *tasks;
+  const int64_t *keyOff;   // n+1, exclusive scan of tLen
+  uint64_t *keys;          // target k-mer keys, sorted per task
+  int32_t *nRaw;           // 3n: prefix / middle / suffix fragment counts
+  const int64_t *fragOff;  // n+1, exclusive scan of the raw fragment counts
+  Frag *raw;               // prefix | middle | suffix fragments as StoreMatchingPositions emits them
+  Frag *frags;             // sorted by (x,y), duplicates removed (SDPAlign.h:256-269)
+  int32_t *nFrag;          // n
+  uint64_t *yxKeys;        // (y << 32 | x) for StoreAbove
+  uint32_t *yxIdx;
+  int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
+  int32_t *colCol, *colOpt;                               // column set storage, per fragment slot
+  int32_t *chainEnd;                                      // n: last fragment of the reported chain
+  int32_t *scratchA;                                      // per fragment: chain indices
+  int32_t *scratchB;                                      // 3 per fragment: candidate blocks
+};
+
+struct SdpEmit {
+  uint64_t *poolKeys, *poolVals;
+  unsigned long long *poolCount;
+  int64_t poolCap;
+  SwTask *sw;
+  unsigned long long *swCount;
+  int64_t swCap;
+  SdpTask *children;
+  unsigned long long *childCount;
+  int64_t childCap;
+  int32_t *overflow;
+};
+
+void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st);
+void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st);
+void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
+void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
+void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);
+void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st);
+void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);
+void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st);
+void launch_sdp_blocks(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, hipStream_t st);
+void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
+               uint8_t *scratch, int64_t scratchPerLane, const SdpEmit &e, hipStream_t st);
+
+// top-level results
+struct SdpResult {  // layout-identical to blasr_hip_sdp_result
+  int32_t status, score, q_pos, t_pos, n_blocks, stats_score, n_match, n_mismatch, n_ins, n_del;
+  int64_t blk_off;
+};
+void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const uint64_t *poolKeys,
+                       const uint64_t *poolVals, const int64_t *blkOff,
+                       const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
+                       int64_t blocksCap, hipStream_t st);
+void launch_pool_histogram(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop, hipStream_t st);
+// tLen (or the three raw fragment counts summed, or nFrag) of every task as int64, for the offset scans
+void launch_sdp_gather_sizes(const SdpLevelArrays &lv, int what, int64_t *out, hipStream_t st);
+void launch_sdp_segment_ends(const SdpLevelArrays &lv, int64_t *ends, hipStream_t st);
+
+}  // namespace blasr_hip
+#endif

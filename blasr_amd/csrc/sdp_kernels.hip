@@ -1,0 +1,1117 @@
+// sdp_kernels.hip -- gfx950 kernels for BLASR's SDP stage.
+//
+// What the reference does per candidate interval (one CPU thread, one call):
+//   SDPAlign                         SDPAlign.h:95-626
+//     SequenceToTupleList            tuples/DNATuple.h:308-359
+//     TupleList::Sort / FindAll      tuples/TupleList.h:98-126
+//     StoreMatchingPositions         tuples/TupleMatching.h:37-61
+//     std::sort + de-duplication     SDPAlign.h:256-269
+//     SDPLongestCommonSubsequence    sdp/SparseDynamicProgramming.h:70-322
+//     block merge / trim / filter    SDPAlign.h:308-413
+//     SWAlign(Global) gap fills      SWAlign.h:19-389
+//     recursive SDPAlign on big gaps SDPAlign.h:445-456, :509-520
+//
+// How it is laid out here: the recursion becomes successive kernel WAVES (level 0 =
+// the candidates, level 1 = their large gap rectangles, level 2 = theirs); within a
+// level every SDPAlign invocation is one wavefront:
+//   sdp_keys      lane = target position: 2-bit k-mer keys (k-mer << 24 | pos)
+//   sdp_sort_keys one wavefront per task: stable LSD radix sort of the keys by k-mer (LDS histogram)
+//   sdp_match     lane = query position: binary search of the sorted keys, fragment emission in
+//                 StoreMatchingPositions order; prefix/suffix 5-mer fragments by direct comparison
+//   sdp_order     merge of the prefix/middle/suffix lists; when duplicates exist the libstdc++
+//                 introsort schedule is replayed so that the same duplicate survives
+//   sdp_above_predcl  the two STATIC predecessors of every fragment ("above", and the predecessor in
+//                 the sweep set, which depends only on geometry) for all fragments in parallel
+//   sdp_chain     the row sweep proper: sequential over fragments, wave-parallel ordered-set
+//                 operations (64-ary search, lane-parallel shifts) for the column set
+//   sdp_blocks    chain -> blocks -> trim/filter, emits finished blocks, SWAlign jobs and the next
+//                 level's SDPAlign jobs
+//   sw            one lane per SWAlign(Global) gap fill
+//   (device radix sort of all finished blocks by (candidate, query position): gap fills slot in
+//    between their parents' blocks, so sorting by query position IS the in-order assembly)
+//   sdp_finish    Local re-basing, SDPAlign's return score, ComputeAlignmentStats
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdp_kernels.h"
+#include "wave_utils.h"
+
+namespace blasr_hip {
+
+#ifndef DEBUG_DCACHE_INV
+#define DEBUG_DCACHE_INV 0
+#endif
+constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
+
+__device__ __forceinline__ int wave_task_index() {
+  if (DEBUG_DCACHE_INV) __builtin_amdgcn_s_dcache_inv();
+  return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+}
+
+// ---------------------------------------------------------------------------
+// sdp_keys: every k-mer of the target whose k bases are all ACGT (DNATuple.h:308-359),
+// first base in the least-significant bits (FromStringRL :55-83)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const uint8_t *seq) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const SdpTask t = lv.tasks[idx];
+  uint64_t *keys = lv.keys + lv.keyOff[idx];
+  const uint8_t *tSeq = seq + t.tOff;
+  const uint64_t invalid = 1ull << (kPosBits + 2 * t.k);
+  for (int p0 = 0; p0 < t.tLen; p0 += 64) {
+    const int p = p0 + lane;
+    if (p < t.tLen) {
+      uint64_t key = invalid | (uint64_t)p;
+      if (p + t.k <= t.tLen) {
+        uint64_t kmer = 0;
+        bool ok = true;
+        for (int j = 0; j < t.k; j++) {
+          const int c = base_code(tSeq[p + j]);
+          ok = ok && c < 4;
+          kmer |= (uint64_t)(c & 3) << (2 * j);
+        }
+        if (ok) key = (kmer << kPosBits) | (uint64_t)p;
+      }
+      keys[p] = key;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stable LSD radix sort of one task's records by bits [beginBit, endBit) of the key, done by one
+// wavefront (8-bit digits, histogram in LDS, ranks inside a 64-record chunk from ballots).
+// Stability is what makes it usable here: the k-mer keys enter ordered by position and are sorted by
+// k-mer only; the fragments enter ordered by (x,y) and are sorted by y only.
+// ---------------------------------------------------------------------------
+template <bool kHasVals>
+__device__ void wave_radix_sort(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, int n, int beginBit,
+                                int endBit, unsigned *hist /* 256 LDS words of this wave */, bool &resultInB) {
+  const int lane = lane_id();
+  const unsigned long long ltMask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  resultInB = false;
+  for (int shift = beginBit; shift < endBit; shift += 8) {
+    const uint64_t *kin = resultInB ? keysB : keysA;
+    uint64_t *kout = resultInB ? keysA : keysB;
+    const uint32_t *vin = resultInB ? valsB : valsA;
+    uint32_t *vout = resultInB ? valsA : valsB;
+    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < n) atomicAdd(&hist[(unsigned)(kin[i] >> shift) & 255u], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {  // exclusive prefix over the 256 bins: lane owns bins 4*lane .. 4*lane+3
+      unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const unsigned sum = c0 + c1 + c2 + c3;
+      const unsigned excl = wave_prefix_sum(sum) - sum;
+      __builtin_amdgcn_wave_barrier();
+      hist[4 * lane] = excl;
+      hist[4 * lane + 1] = excl + c0;
+      hist[4 * lane + 2] = excl + c0 + c1;
+      hist[4 * lane + 3] = excl + c0 + c1 + c2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool on = i < n;
+      uint64_t key = 0;
+      uint32_t val = 0;
+      if (on) {
+        key = kin[i];
+        if (kHasVals) val = vin[i];
+      }
+      const unsigned d = (unsigned)(key >> shift) & 255u;
+      unsigned long long same = __ballot(on);
+      for (int b = 0; b < 8; b++) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        same &= ((d >> b) & 1u) ? m : ~m;
+      }
+      const unsigned rank = (unsigned)__popcll(same & ltMask);
+      unsigned base = 0;
+      if (on) base = hist[d];
+      __builtin_amdgcn_wave_barrier();
+      if (on) {
+        kout[base + rank] = key;
+        if (kHasVals) vout[base + rank] = val;
+        if (rank == 0) hist[d] = base + (unsigned)__popcll(same);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    resultInB = !resultInB;
+  }
+}
+
+__global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, uint64_t *tmp) {
+  __shared__ unsigned hist[4][256];
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const SdpTask t = lv.tasks[idx];
+  uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
+  bool inB;
+  wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
+  if (inB)
+    for (int i = lane; i < t.tLen; i += 64) a[i] = b[i];
+}
+
+__global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uint64_t *tmpKeys, uint32_t *tmpIdx) {
+  __shared__ unsigned hist[4][256];
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int F = lv.nFrag[idx];
+  const int64_t base = lv.fragOff[idx];
+  bool inB;
+  // keys are y << 32 | x, already ordered by (x,y): a stable sort on the 24 bits of y gives (y,x) order
+  wave_radix_sort<true>(lv.yxKeys + base, tmpKeys + base, lv.yxIdx + base, tmpIdx + base, F, 32, 32 + kPosBits,
+                        hist[threadIdx.x >> 6], inB);
+  if (inB)
+    for (int i = lane; i < F; i += 64) lv.yxIdx[base + i] = tmpIdx[base + i];
+}
+
+// small-word (<= 5) k-mer of s[p .. p+ks), or -1 when it holds a non-ACGT base
+__device__ __forceinline__ int small_kmer(const uint8_t *s, int p, int ks) {
+  int v = 0;
+  for (int j = 0; j < ks; j++) {
+    const int c = base_code(s[p + j]);
+    if (c >= 4) return -1;
+    v |= c << (2 * j);
+  }
+  return v;
+}
+
+__device__ __forceinline__ int lower_bound_u64(const uint64_t *a, int n, uint64_t key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------
+// sdp_match: StoreMatchingPositions for the prefix, the whole sequence and the suffix
+// (SDPAlign.h:148-242).  kWrite = false counts, kWrite = true writes the fragments.
+// ---------------------------------------------------------------------------
+template <bool kWrite>
+__global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const uint8_t *seq) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const SdpTask t = lv.tasks[idx];
+  const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
+  const uint64_t *keys = lv.keys + lv.keyOff[idx];
+  const int k = t.k, ks = k < 5 ? k : 5;
+  // SDPAlign.h:148-182
+  const int prefixLength = min(t.tLen, t.prefix);
+  const int suffixLength = min(t.tLen - prefixLength, t.prefix);
+  const int suffixPos = t.tLen - suffixLength;
+  const int qPrefixLength = min(t.qLen, t.prefix);
+  const int qSuffixLength = min(t.qLen - qPrefixLength, t.prefix);
+  const int qSuffixPos = t.qLen - qSuffixLength;
+  Frag *out = kWrite ? lv.raw + lv.fragOff[idx] : nullptr;
+  int written = 0;  // uniform running count
+
+  // prefix (part 0) and suffix (part 2): short sequences, compared directly
+  auto smallPart = [&](const uint8_t *qs, int qn, const uint8_t *ts, int tn, int xOff, int yOff) {
+    int total = 0;
+    for (int x0 = 0; x0 + ks <= qn; x0 += 64) {
+      const int x = x0 + lane;
+      int cnt = 0, qk = -1;
+      if (x + ks <= qn) {
+        qk = small_kmer(qs, x, ks);
+        if (qk >= 0)
+          for (int y = 0; y + ks <= tn; y++) cnt += small_kmer(ts, y, ks) == qk;
+        if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+      }
+      const unsigned incl = wave_prefix_sum((unsigned)cnt);
+      if (kWrite && cnt > 0) {
+        int w = written + total + (int)incl - cnt;
+        for (int y = 0; y + ks <= tn; y++)
+          if (small_kmer(ts, y, ks) == qk) {
+            Frag f;
+            f.x = (uint32_t)(x + xOff);
+            f.y = (uint32_t)(y + yOff);
+            f.len = (uint32_t)ks;
+            f.pad = 0;
+            out[w++] = f;
+          }
+      }
+      total += __builtin_amdgcn_readlane((int)incl, 63);
+    }
+    return total;
+  };
+  const int nP = (ks >= 1) ? smallPart(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0) : 0;
+  written += nP;
+
+  // middle (part 1): the whole query against the sorted k-mer keys of the whole target
+  int nM = 0;
+  for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
+    const int x = x0 + lane;
+    int lo = 0, cnt = 0;
+    if (x + k <= t.qLen) {
+      uint64_t kmer = 0;
+      bool ok = true;
+      for (int j = 0; j < k; j++) {
+        const int c = base_code(qSeq[x + j]);
+        ok = ok && c < 4;
+        kmer |= (uint64_t)(c & 3) << (2 * j);
+      }
+      if (ok) {
+        lo = lower_bound_u64(keys, t.tLen, kmer << kPosBits);
+        const int hi = lower_bound_u64(keys, t.tLen, (kmer + 1) << kPosBits);
+        cnt = hi - lo;
+        if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+      }
+    }
+    const unsigned incl = wave_prefix_sum((unsigned)cnt);
+    if (kWrite && cnt > 0) {
+      int w = written + nM + (int)incl - cnt;
+      for (int j = 0; j < cnt; j++) {
+        Frag f;
+        f.x = (uint32_t)x;
+        f.y = (uint32_t)(keys[lo + j] & ((1ull << kPosBits) - 1));
+        f.len = (uint32_t)k;
+        f.pad = 0;
+        out[w++] = f;
+      }
+    }
+    nM += __builtin_amdgcn_readlane((int)incl, 63);
+  }
+  written += nM;
+  const int nS = (ks >= 1) ? smallPart(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
+                                       suffixPos)
+                           : 0;
+  if (!kWrite && lane == 0) {
+    lv.nRaw[3 * idx] = nP;
+    lv.nRaw[3 * idx + 1] = nM;
+    lv.nRaw[3 * idx + 2] = nS;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sdp_order: std::sort by (x,y) + keep the first of each (x,y) (SDPAlign.h:256-269)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t frag_key(const Frag &f) { return ((uint64_t)f.x << 32) | f.y; }
+__device__ __forceinline__ bool frag_less(const Frag &a, const Frag &b) { return frag_key(a) < frag_key(b); }
+
+__device__ int lower_bound_frag(const Frag *a, int n, uint64_t key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (frag_key(a[mid]) < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// libstdc++ (GCC 11.4) std::sort schedule, replayed by one lane.  Only reached when the prefix /
+// middle / suffix lists share an (x,y): which duplicate survives depends on this exact schedule.
+__device__ void is_swap(Frag *a, Frag *b) {
+  Frag t = *a;
+  *a = *b;
+  *b = t;
+}
+__device__ void is_adjust_heap(Frag *first, long hole, long len, Frag value) {
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (frag_less(first[child], first[child - 1])) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;
+  while (hole > top && frag_less(first[parent], value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+__device__ void is_heapsort(Frag *first, Frag *last) {
+  const long len = last - first;
+  if (len >= 2) {
+    long parent = (len - 2) / 2;
+    for (;;) {
+      Frag v = first[parent];
+      is_adjust_heap(first, parent, len, v);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    Frag v = *last;
+    *last = *first;
+    is_adjust_heap(first, 0, last - first, v);
+  }
+}
+__device__ void is_unguarded_linear_insert(Frag *last) {
+  Frag val = *last;
+  Frag *next = last - 1;
+  while (frag_less(val, *next)) {
+    *last = *next;
+    last = next;
+    --next;
+  }
+  *last = val;
+}
+__device__ void is_insertion_sort(Frag *first, Frag *last) {
+  if (first == last) return;
+  for (Frag *i = first + 1; i != last; ++i) {
+    if (frag_less(*i, *first)) {
+      Frag val = *i;
+      for (Frag *p = i; p != first; --p) *p = *(p - 1);
+      *first = val;
+    } else
+      is_unguarded_linear_insert(i);
+  }
+}
+__device__ void introsort_frags(Frag *first, long n) {
+  if (n <= 0) return;
+  long lg = 0;
+  for (long m = n; m > 1; m >>= 1) lg++;
+  // explicit stack for the recursion on the right partition
+  Frag *stFirst[64], *stLast[64];
+  long stDepth[64];
+  int sp = 0;
+  stFirst[0] = first;
+  stLast[0] = first + n;
+  stDepth[0] = lg * 2;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    Frag *f = stFirst[sp], *l = stLast[sp];
+    long depth = stDepth[sp];
+    // __introsort_loop(f, l, depth): right parts are pushed and processed first, as the recursion does
+    // (the order of processing disjoint ranges does not change the result)
+    while (l - f > 16) {
+      if (depth == 0) {
+        is_heapsort(f, l);
+        break;
+      }
+      --depth;
+      Frag *mid = f + (l - f) / 2;
+      // __move_median_to_first(f, f+1, mid, l-1)
+      Frag *a = f + 1, *b = mid, *c = l - 1;
+      if (frag_less(*a, *b)) {
+        if (frag_less(*b, *c)) is_swap(f, b);
+        else if (frag_less(*a, *c)) is_swap(f, c);
+        else is_swap(f, a);
+      } else if (frag_less(*a, *c)) is_swap(f, a);
+      else if (frag_less(*b, *c)) is_swap(f, c);
+      else is_swap(f, b);
+      // __unguarded_partition(f+1, l, f)
+      Frag *lo = f + 1, *hi = l;
+      for (;;) {
+        while (frag_less(*lo, *f)) ++lo;
+        --hi;
+        while (frag_less(*f, *hi)) --hi;
+        if (!(lo < hi)) break;
+        is_swap(lo, hi);
+        ++lo;
+      }
+      stFirst[sp] = lo;
+      stLast[sp] = l;
+      stDepth[sp] = depth;
+      sp++;
+      l = lo;
+    }
+  }
+  if (n > 16) {
+    is_insertion_sort(first, first + 16);
+    for (Frag *i = first + 16; i != first + n; ++i) is_unguarded_linear_insert(i);
+  } else
+    is_insertion_sort(first, first + n);
+}
+
+__global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int nP = lv.nRaw[3 * idx], nM = lv.nRaw[3 * idx + 1], nS = lv.nRaw[3 * idx + 2];
+  const Frag *P = lv.raw + lv.fragOff[idx], *M = P + nP, *S = M + nM;
+  Frag *out = lv.frags + lv.fragOff[idx];
+  const int nAll = nP + nM + nS;
+  // duplicates can only occur ACROSS the three lists (each list has unique (x,y))
+  bool tie = false;
+  for (int i = lane; i < nP; i += 64) {
+    const uint64_t key = frag_key(P[i]);
+    int j = lower_bound_frag(M, nM, key);
+    if (j < nM && frag_key(M[j]) == key) tie = true;
+    j = lower_bound_frag(S, nS, key);
+    if (j < nS && frag_key(S[j]) == key) tie = true;
+  }
+  for (int i = lane; i < nS; i += 64) {
+    const uint64_t key = frag_key(S[i]);
+    const int j = lower_bound_frag(M, nM, key);
+    if (j < nM && frag_key(M[j]) == key) tie = true;
+  }
+  if (__ballot(tie) == 0ull) {
+    // all keys distinct: the sorted order is unique, place every fragment at its rank
+    for (int i = lane; i < nP; i += 64) {
+      const uint64_t key = frag_key(P[i]);
+      out[i + lower_bound_frag(M, nM, key) + lower_bound_frag(S, nS, key)] = P[i];
+    }
+    for (int i = lane; i < nM; i += 64) {
+      const uint64_t key = frag_key(M[i]);
+      const int shift = (nP ? lower_bound_frag(P, nP, key) : 0) + (nS ? lower_bound_frag(S, nS, key) : 0);
+      out[i + shift] = M[i];
+    }
+    for (int i = lane; i < nS; i += 64) {
+      const uint64_t key = frag_key(S[i]);
+      out[i + lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key)] = S[i];
+    }
+    if (lane == 0) lv.nFrag[idx] = nAll;
+  } else {
+    for (int i = lane; i < nAll; i += 64) out[i] = P[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+      introsort_frags(out, nAll);
+      int f = 0, cur = 0;
+      while (f + 1 <= nAll) {
+        out[cur] = out[f];
+        while (f < nAll && out[cur].x == out[f].x && out[cur].y == out[f].y) f++;
+        cur++;
+      }
+      lv.nFrag[idx] = cur;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// StoreAbove (SparseDynamicProgramming.h:55-68) and the sweep-set predecessor
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdp_yx_keys_kernel(SdpLevelArrays lv) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int F = lv.nFrag[idx];
+  const int64_t base = lv.fragOff[idx];
+  for (int i = lane; i < F; i += 64) {
+    const Frag f = lv.frags[base + i];
+    lv.yxKeys[base + i] = ((uint64_t)f.y << 32) | f.x;
+    lv.yxIdx[base + i] = (uint32_t)i;
+    lv.above[base + i] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int F = lv.nFrag[idx];
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  const int k = lv.tasks[idx].k;
+  // above: neighbours in (y,x) order (the sorted index list is in yxIdx)
+  for (int j = 1 + lane; j < F; j += 64) {
+    const int a = (int)lv.yxIdx[base + j - 1], b = (int)lv.yxIdx[base + j];
+    const Frag fa = fr[a], fb = fr[b];
+    if (fa.x <= fb.x && fa.x + fa.len > fb.x && fa.y < fb.y) lv.above[base + b] = a;
+  }
+  // sweepSet.Predecessor (SDPSet.h:94-119 with Fragment::operator< = (diag, x), SDPFragment.h:78-91): when
+  // fragment f is scored the set holds exactly the fragments of the k+1 previous rows, so the answer is a
+  // function of the geometry alone: the largest (diag, x) with diag <= f.diag among x in [f.x-k-1, f.x-1].
+  for (int i = lane; i < F; i += 64) {
+    const Frag f = fr[i];
+    const int fdiag = (int)(f.y - f.x);
+    const uint32_t xLow = f.x > (uint32_t)(k + 1) ? f.x - (uint32_t)(k + 1) : 0u;
+    int lo = 0, hi = i;  // first index with x >= xLow
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (fr[mid].x < xLow) lo = mid + 1; else hi = mid;
+    }
+    int best = -1, bestDiag = 0;
+    uint32_t bestX = 0;
+    for (int j = lo; j < i; j++) {
+      const Frag p = fr[j];
+      if (p.x >= f.x) break;
+      const int d = (int)(p.y - p.x);
+      if (d <= fdiag && (best < 0 || d > bestDiag || (d == bestDiag && p.x > bestX))) {
+        best = j;
+        bestDiag = d;
+        bestX = p.x;
+      }
+    }
+    lv.predCl[base + i] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sdp_chain: SDPLongestCommonSubsequence (SparseDynamicProgramming.h:70-322)
+// ---------------------------------------------------------------------------
+struct ColSet {  // SDPSet<SDPColumn>: sorted by column; wave-cooperative operations, uniform results
+  int *col, *opt;
+  int n;
+};
+__device__ int cs_lower_bound(const ColSet &s, int key) {
+  const int lane = lane_id();
+  int lo = 0, hi = s.n;
+  while (hi - lo > 64) {
+    const int stride = (hi - lo + 63) / 64;
+    const int p = lo + lane * stride;
+    const int v = p < hi ? s.col[p] : INT32_MAX;
+    const int c = __popcll(__ballot(p < hi && v < key));
+    const int nlo = c > 0 ? lo + (c - 1) * stride + 1 : lo;
+    const int nhi = min(hi, lo + c * stride);
+    lo = nlo;
+    hi = nhi;
+  }
+  const int p = lo + lane;
+  const int v = p < hi ? s.col[p] : INT32_MAX;
+  return lo + __popcll(__ballot(p < hi && v < key));
+}
+__device__ void cs_insert_at(ColSet &s, int pos, int col, int opt) {
+  const int lane = lane_id();
+  if (s.n > pos) {
+    for (int base = pos + ((s.n - 1 - pos) / 64) * 64; base >= pos; base -= 64) {
+      const int i = base + lane;
+      int c = 0, o = 0;
+      if (i < s.n) {
+        c = s.col[i];
+        o = s.opt[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (i < s.n) {
+        s.col[i + 1] = c;
+        s.opt[i + 1] = o;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  if (lane == 0) {
+    s.col[pos] = col;
+    s.opt[pos] = opt;
+  }
+  s.n++;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ void cs_erase_range(ColSet &s, int first, int count) {  // removes [first, first+count)
+  const int lane = lane_id();
+  for (int base = first + count; base < s.n; base += 64) {
+    const int i = base + lane;
+    int c = 0, o = 0;
+    if (i < s.n) {
+      c = s.col[i];
+      o = s.opt[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i < s.n) {
+      s.col[i - count] = c;
+      s.opt[i - count] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  s.n -= count;
+}
+
+// IndelPenalty (SparseDynamicProgramming.h:27-53)
+__device__ __forceinline__ int indel_penalty(int x1, int y1, int x2, int y2, int insertion, int deletion) {
+  const int drift = (x1 - y1) - (x2 - y2);
+  if (drift > 0) return (int)((1.0 * drift) * insertion);
+  if (drift < 0) return (int)((-1.0 * drift) * deletion);
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int F = lv.nFrag[idx];
+  if (F == 0) {
+    if (lane == 0) lv.chainEnd[idx] = -1;
+    return;
+  }
+  const SdpTask t = lv.tasks[idx];
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
+  const int *predCl = lv.predCl + base, *above = lv.above + base;
+  ColSet cols;
+  cols.col = lv.colCol + base;
+  cols.opt = lv.colOpt + base;
+  cols.n = 0;
+  const int k = t.k;
+  const uint32_t fragmentLength = (uint32_t)k;
+  const uint32_t weight = (uint32_t)k;
+  int fTrail = 0;
+  int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
+  uint32_t maxLen = 0;
+  for (int i = 0; i < F; i++) {
+    const Frag f = fr[i];
+    // rows leaving the window: fragments with x <= f.x - k - 2 have been retired before row f.x is scored (:248-309)
+    while (fTrail < i) {
+      const Frag ft = fr[fTrail];
+      if ((int64_t)ft.x + k + 2 > (int64_t)f.x) break;
+      const int costT = cost[fTrail];
+      int pos = cs_lower_bound(cols, (int)ft.y);
+      const bool member = pos < cols.n && cols.col[pos] == (int)ft.y;
+      bool store = true;
+      if (member) store = cost[cols.opt[pos]] < costT;  // sic (:260-267)
+      if (store) {
+        if (member) {
+          if (lane == 0) cols.opt[pos] = fTrail;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+          cs_insert_at(cols, pos, (int)ft.y, fTrail);
+        }
+        // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
+        int del = 0;
+        while (cols.n - del >= 2 && pos + 1 + del < cols.n && cost[cols.opt[pos + 1 + del]] > costT) del++;
+        if (del) cs_erase_range(cols, pos + 1, del);
+      }
+      fTrail++;
+    }
+    int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
+    bool foundPrev = false;
+    if (cols.n > 0) {
+      int pos = cs_lower_bound(cols, (int)f.y);
+      bool have = false;
+      if (pos < cols.n && cols.col[pos] == (int)f.y) have = true;
+      else if (pos > 0) {
+        pos--;
+        have = true;
+      }
+      if (have) {
+        cpFrag = cols.opt[pos];
+        const Frag p = fr[cpFrag];
+        cp = cost[cpFrag] + (int)sqrt((double)abs((int)(f.x + f.y) - (int)(p.x + p.y))) - (int)f.len;
+        foundPrev = true;
+      }
+    }
+    const int clFrag = predCl[i];
+    if (clFrag >= 0) {
+      const Frag p = fr[clFrag];
+      int ov = (int)(fragmentLength - (f.y - p.y)) * prm.match;
+      if (ov > 0) ov = 0;
+      cl = cost[clFrag] + ov + indel_penalty((int)f.x, (int)f.y, (int)p.x, (int)p.y, prm.sdpIns, prm.sdpDel);
+      foundPrev = true;
+    }
+    const int aboveIdx = above[i];
+    if (aboveIdx >= 0) {
+      const Frag p = fr[aboveIdx];
+      ca = (int)((uint32_t)cost[aboveIdx] + (fragmentLength - (uint32_t)(int)(f.y - p.y)) * (uint32_t)prm.match +
+                 (uint32_t)indel_penalty((int)f.x, (int)f.y, (int)p.x, (int)p.y, prm.sdpIns, prm.sdpDel));
+      foundPrev = true;
+    }
+    int mc = cl < ca ? cl : ca;
+    if (cp < mc) mc = cp;
+    int myCost, myPrev;
+    uint32_t myLen;
+    if (foundPrev && (t.type == 1 || (t.type == 0 && mc < 0))) {
+      myCost = (int)((uint32_t)mc - weight);
+      if (mc == cp) myPrev = cpFrag;
+      else if (mc == cl) myPrev = clFrag;
+      else myPrev = aboveIdx;
+      myLen = (uint32_t)chainLen[myPrev] + 1u;
+    } else {
+      myPrev = -1;
+      myLen = 1;
+      if (t.type == 1) myCost = (int)((f.x + f.y) * (uint32_t)prm.sdpDel + fragmentLength * (uint32_t)prm.match - weight);
+      else myCost = (int)(fragmentLength * (uint32_t)prm.match - weight);
+    }
+    // every lane stores the same value to the same address, so each lane later reads its own store
+    cost[i] = myCost;
+    chainPrev[i] = myPrev;
+    chainLen[i] = (int)myLen;
+    if (minCost > myCost) {
+      minCost = myCost;
+      minIdx = i;
+    }
+    if (myLen > maxLen) {
+      maxLen = myLen;
+      maxLenIdx = i;
+    }
+  }
+  if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
+}
+
+// ---------------------------------------------------------------------------
+// sdp_blocks: chain -> blocks (SDPAlign.h:308-335), trim (:349-357), filter (:372-413), and the
+// work lists of :423-536 (front fill for Global, fills between consecutive blocks)
+// ---------------------------------------------------------------------------
+__device__ void emit_block(const SdpEmit &e, const SdpTask &t, uint32_t q, uint32_t tt, uint32_t len) {
+  const unsigned long long at = atomicAdd(e.poolCount, 1ull);
+  if ((int64_t)at >= e.poolCap) {
+    *e.overflow = 1;
+    return;
+  }
+  e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
+  e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
+}
+__device__ void emit_sw(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft) {
+  const unsigned long long at = atomicAdd(e.swCount, 1ull);
+  if ((int64_t)at >= e.swCap) {
+    *e.overflow = 1;
+    return;
+  }
+  SwTask s;
+  s.qOff = t.qOff + q0;
+  s.tOff = t.tOff + t0;
+  s.qLen = (int)fq;
+  s.tLen = (int)ft;
+  s.top = t.top;
+  s.qOrg = t.qOrg + (int)q0;
+  s.tOrg = t.tOrg + (int)t0;
+  s.pad = 0;
+  e.sw[at] = s;
+}
+__device__ void emit_child(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft,
+                           int prefix, int maxPerPos) {
+  const unsigned long long at = atomicAdd(e.childCount, 1ull);
+  if ((int64_t)at >= e.childCap) {
+    *e.overflow = 1;
+    return;
+  }
+  SdpTask c;
+  c.qOff = t.qOff + q0;
+  c.tOff = t.tOff + t0;
+  c.qLen = (int)fq;
+  c.tLen = (int)ft;
+  c.k = t.k - 4 > 5 ? t.k - 4 : 5;
+  c.type = 1;  // Global
+  c.prefix = prefix;
+  c.recurse = t.recurse - 1;
+  c.maxPerPos = maxPerPos;
+  c.top = t.top;
+  c.qOrg = t.qOrg + (int)q0;
+  c.tOrg = t.tOrg + (int)t0;
+  e.children[at] = c;
+}
+
+__global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpParams prm, SdpEmit e) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  if (lane_id() != 0) return;
+  const int F = lv.nFrag[idx];
+  if (F == 0) return;
+  const SdpTask t = lv.tasks[idx];
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  const int *chainPrev = lv.chainPrev + base;
+  int *chain = lv.scratchA + base;
+  uint32_t *cb = reinterpret_cast<uint32_t *>(lv.scratchB + 3 * base);  // (q,t,len) triplets
+  int nChain = 0;
+  for (int f = lv.chainEnd[idx]; f != -1 && nChain < F; f = chainPrev[f]) chain[nChain++] = f;
+  for (int i = 0; i < nChain / 2; i++) {
+    const int tmp = chain[i];
+    chain[i] = chain[nChain - 1 - i];
+    chain[nChain - 1 - i] = tmp;
+  }
+  int ncb = 0;
+  for (int f = 0; f < nChain; f++) {
+    const int startF = f;
+    while (f < nChain - 1 && fr[chain[f]].x == fr[chain[f + 1]].x - 1 && fr[chain[f]].y == fr[chain[f + 1]].y - 1) f++;
+    cb[3 * ncb] = fr[chain[startF]].x;
+    cb[3 * ncb + 1] = fr[chain[startF]].y;
+    cb[3 * ncb + 2] = fr[chain[f]].x + fr[chain[f]].len - fr[chain[startF]].x;
+    ncb++;
+  }
+  for (int b = 0; b + 1 < ncb; b++) {
+    if (cb[3 * b] + cb[3 * b + 2] > cb[3 * b + 3]) cb[3 * b + 2] = cb[3 * b + 3] - cb[3 * b];
+    if (cb[3 * b + 1] + cb[3 * b + 2] > cb[3 * b + 4]) cb[3 * b + 2] = cb[3 * b + 4] - cb[3 * b + 1];
+  }
+  // bad blocks: zero length, or off-diagonal against both neighbours (float compare as in :405)
+  unsigned char *good = reinterpret_cast<unsigned char *>(chain);  // chain[] is no longer needed
+  for (int b = 0; b < ncb; b++) good[b] = cb[3 * b + 2] != 0;
+  for (int b = 1; b + 1 < ncb; b++) {
+    const int pq = (int)cb[3 * b - 3], pt = (int)cb[3 * b - 2], q = (int)cb[3 * b], tt = (int)cb[3 * b + 1];
+    const int nq = (int)cb[3 * b + 3], nt = (int)cb[3 * b + 4];
+    const int prevDiag = abs((tt - q) - (pt - pq));
+    const int prevDist = (int)min((uint32_t)(tt - pt), (uint32_t)(q - pq));
+    const int nextDiag = abs((nt - nq) - (tt - q));
+    const int nextDist = (int)min((uint32_t)(nt - tt), (uint32_t)(nq - q));
+    if (prevDist * prm.indelRate < prevDiag && nextDist * prm.indelRate < nextDiag) good[b] = 0;
+  }
+  {
+    int w = 0;
+    for (int b = 0; b < ncb; b++)
+      if (good[b]) {
+        cb[3 * w] = cb[3 * b];
+        cb[3 * w + 1] = cb[3 * b + 1];
+        cb[3 * w + 2] = cb[3 * b + 2];
+        w++;
+      }
+    ncb = w;
+  }
+  if (ncb == 0) return;
+  const uint32_t nru = (uint32_t)prm.noRecurseUnder;
+  // :423-474 front fill (Global only; extendFrontByLocalAlignment is false on this path)
+  if (t.type == 1 && cb[0] > 0 && cb[1] > 0) {
+    const uint32_t fq = cb[0], ft = cb[1];
+    if (t.recurse == 0 && fq * ft < nru) emit_sw(e, t, 0, 0, fq, ft);
+    else if (t.recurse != 0) emit_child(e, t, 0, 0, fq, ft, t.prefix, 6 /* EndAnchored lands in this slot, :456 */);
+  }
+  for (int b = 0; b < ncb; b++) {
+    emit_block(e, t, cb[3 * b], cb[3 * b + 1], cb[3 * b + 2]);
+    if (b + 1 < ncb) {
+      const uint32_t q0 = cb[3 * b] + cb[3 * b + 2], t0 = cb[3 * b + 1] + cb[3 * b + 2];
+      const uint32_t fq = cb[3 * b + 3] - q0, ft = cb[3 * b + 4] - t0;
+      if (fq > 0 && ft > 0) {
+        if (fq * ft < nru) emit_sw(e, t, q0, t0, fq, ft);
+        else if (t.recurse != 0) emit_child(e, t, q0, t0, fq, ft, 0, 0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sw: SWAlign, Global (SWAlign.h:19-389); only the Diagonal runs are kept (SDPAlign.h:529-534)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n, const uint8_t *seq,
+                                                 const int32_t *matrix, SdpParams prm, uint8_t *scratch,
+                                                 int64_t scratchPerLane, SdpEmit e) {
+  __shared__ int m[25];
+  if (threadIdx.x < 25) m[threadIdx.x] = matrix[threadIdx.x];
+  __syncthreads();
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  uint8_t *mine = scratch + gid * scratchPerLane;
+  for (int64_t i = gid; i < n; i += stride) {
+    const SwTask t = tasks[i];
+    const uint8_t *q = seq + t.qOff, *tt = seq + t.tOff;
+    const int nCols = t.tLen + 1;
+    int *prev = reinterpret_cast<int *>(mine);
+    int *cur = prev + nCols;
+    uint8_t *arrows = reinterpret_cast<uint8_t *>(cur + nCols);  // (qLen+1) x nCols, 0 Diagonal 1 Up 2 Left
+    for (int c = 0; c < nCols; c++) prev[c] = prm.del * c;
+    for (int r = 0; r < t.qLen; r++) {
+      const int qc = base_code(q[r]);
+      cur[0] = prm.ins * (r + 1);
+      for (int c = 0; c < t.tLen; c++) {
+        const int mt = m[qc * 5 + base_code(tt[c])] + prev[c];
+        const int qGap = prev[c + 1] + prm.ins;
+        const int tGap = cur[c] + prm.del;
+        int mn = mt < qGap ? mt : qGap;
+        if (tGap < mn) mn = tGap;
+        cur[c + 1] = mn;
+        arrows[(r + 1) * nCols + c + 1] = (mn == mt) ? 0 : (mn == qGap) ? 1 : 2;  // Diagonal, Up, Left (:196-207)
+      }
+      int *tmp = prev;
+      prev = cur;
+      cur = tmp;
+    }
+    // traceback (q,t) -> (0,0); boundary arrows: row 0 Left, column 0 Up (:49-64)
+    int r = t.qLen, c = t.tLen, runLen = 0;
+    while (r > 0 || c > 0) {
+      const int a = r == 0 ? 2 : (c == 0 ? 1 : arrows[r * nCols + c]);
+      if (a == 0) {
+        r--;
+        c--;
+        runLen++;
+      } else {
+        if (runLen) {
+          const unsigned long long at = atomicAdd(e.poolCount, 1ull);
+          if ((int64_t)at < e.poolCap) {
+            e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + r);
+            e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + c) << 32) | (uint32_t)runLen;
+          } else
+            *e.overflow = 1;
+          runLen = 0;
+        }
+        if (a == 1) r--; else c--;
+      }
+    }
+    if (runLen) {
+      const unsigned long long at = atomicAdd(e.poolCount, 1ull);
+      if ((int64_t)at < e.poolCap) {
+        e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)t.qOrg;
+        e.poolVals[at] = ((uint64_t)(uint32_t)t.tOrg << 32) | (uint32_t)runLen;
+      } else
+        *e.overflow = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// assembly + statistics of the top-level candidates
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_histogram_kernel(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&countPerTop[(uint32_t)(poolKeys[i] >> 32)], 1);
+}
+
+// sizes of the variable-length per-task arrays, as int64, for the device offset scans
+__global__ __launch_bounds__(256) void sdp_gather_sizes_kernel(SdpLevelArrays lv, int what, int64_t *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv.n) return;
+  int64_t v;
+  if (what == 0) v = lv.tasks[i].tLen;
+  else if (what == 1) v = (int64_t)lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
+  else v = lv.nFrag[i];
+  out[i] = v;
+}
+__global__ __launch_bounds__(256) void sdp_segment_ends_kernel(SdpLevelArrays lv, int64_t *ends) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < lv.n) ends[i] = lv.fragOff[i] + lv.nFrag[i];
+}
+
+// Per top-level candidate (one wavefront): SDPAlign.h:602-624 (Local re-basing, return score) followed by
+// ComputeAlignmentStats on an alignment WITHOUT gap lists (AlignmentUtils.h:408-446, :494-529): the gap
+// between two blocks is spelled as the query surplus, then the target surplus, then the common part as
+// aligned columns.
+__global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *tasks, const uint8_t *seq,
+                                                         const uint64_t *poolKeys, const uint64_t *poolVals,
+                                                         const int64_t *blkOff,
+                                                         const int32_t *matrix, int ins, int del, int open, int ext,
+                                                         SdpResult *results, int32_t *blocks, int64_t blocksCap) {
+  __shared__ int m[25];
+  if (threadIdx.x < 25) m[threadIdx.x] = matrix[threadIdx.x];
+  __syncthreads();
+  const int idx = wave_task_index();
+  if (idx >= n) return;
+  const int lane = lane_id();
+  const SdpTask t = tasks[idx];
+  const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
+  const int64_t b0 = blkOff[idx];
+  const int nb = (int)(blkOff[idx + 1] - b0);
+  SdpResult res;
+  res.status = 0;
+  res.score = res.q_pos = res.t_pos = res.stats_score = res.n_match = res.n_mismatch = res.n_ins = res.n_del = 0;
+  res.n_blocks = nb;
+  res.blk_off = b0;
+  if (nb == 0) {
+    if (lane == 0) results[idx] = res;
+    return;
+  }
+  int qPos = 0, tPos = 0;
+  if (t.type == 0) {
+    qPos = (int)(uint32_t)poolKeys[b0];
+    tPos = (int)(poolVals[b0] >> 32);
+  }
+  const bool fits = b0 + nb <= blocksCap;
+  int blockScore = 0, nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0, gapScore = 0, commonScore = 0;
+  auto columns = [&](int q, int tt, int len, int &scoreAcc) {
+    for (int j = 0; j < len; j++) {
+      const int qc = base_code(qSeq[q + j]), tc = base_code(tSeq[tt + j]);
+      scoreAcc += m[qc * 5 + tc];
+      if (qc == tc) nMatch++; else nMismatch++;
+    }
+  };
+  auto gapRun = [&](int len, bool deletion) {
+    if (len <= 0) return;
+    const int linear = (deletion ? del : ins) * len, affine = len * ext + open;
+    gapScore += linear < affine ? linear : affine;
+    if (deletion) nDel += len; else nIns += len;
+  };
+  for (int b = lane; b < nb; b += 64) {
+    const uint64_t pk = poolKeys[b0 + b], pv = poolVals[b0 + b];
+    const int q = (int)(uint32_t)pk, tt = (int)(pv >> 32), len = (int)(uint32_t)pv;
+    if (fits) {
+      blocks[3 * (b0 + b)] = q - qPos;
+      blocks[3 * (b0 + b) + 1] = tt - tPos;
+      blocks[3 * (b0 + b) + 2] = len;
+    }
+    columns(q, tt, len, blockScore);
+    if (b + 1 < nb) {
+      int qGap = (int)(uint32_t)poolKeys[b0 + b + 1] - (q + len), tGap = (int)(poolVals[b0 + b + 1] >> 32) - (tt + len);
+      if (qGap > 0 || tGap > 0) {
+        int common = qGap;
+        if (qGap > tGap) common = tGap;
+        qGap -= common;
+        tGap -= common;
+        gapRun(qGap, false);
+        gapRun(tGap, true);
+        columns(q + len + qGap, tt + len + tGap, common, commonScore);
+      }
+    }
+    if (b == 0 && (q - qPos > 0 || tt - tPos > 0)) {
+      // leading offset of a Global alignment (:408-446): common part aligned, then target-, then query surplus
+      int qp = q - qPos, tp = tt - tPos;
+      int common = qp;
+      if (common > tp) common = tp;
+      columns(qPos, tPos, common, commonScore);
+      gapRun(tp - common, true);
+      gapRun(qp - common, false);
+    }
+  }
+  int vals[7] = {blockScore, commonScore, gapScore, nMatch, nMismatch, nIns, nDel};
+  for (int v = 0; v < 7; v++)
+    for (int off = 32; off > 0; off >>= 1) vals[v] += __shfl_xor(vals[v], off);
+  if (lane == 0) {
+    res.status = fits ? 0 : 8;
+    res.score = vals[0];
+    res.q_pos = qPos;
+    res.t_pos = tPos;
+    res.stats_score = vals[0] + vals[1] + vals[2];
+    res.n_match = vals[3];
+    res.n_mismatch = vals[4];
+    res.n_ins = vals[5];
+    res.n_del = vals[6];
+    results[idx] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static dim3 wave_grid(int n) { return dim3((unsigned)((n + 3) / 4)); }
+
+void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+}
+void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, tmp);
+}
+void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_yx_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, tmpKeys, tmpIdx);
+}
+void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
+  if (lv.n <= 0) return;
+  if (write) hipLaunchKernelGGL(sdp_match_kernel<true>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  else hipLaunchKernelGGL(sdp_match_kernel<false>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+}
+void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_order_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+}
+void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_yx_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+}
+void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+}
+void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+}
+void launch_sdp_blocks(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_blocks_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, e);
+}
+void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
+               uint8_t *scratch, int64_t scratchPerLane, const SdpEmit &e, hipStream_t st) {
+  if (n <= 0) return;
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+  hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, n, seq, matrix, p, scratch, scratchPerLane, e);
+}
+void launch_pool_histogram(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pool_histogram_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, poolKeys, n,
+                     countPerTop);
+}
+void launch_sdp_gather_sizes(const SdpLevelArrays &lv, int what, int64_t *out, hipStream_t st) {
+  if (lv.n > 0)
+    hipLaunchKernelGGL(sdp_gather_sizes_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, what, out);
+}
+void launch_sdp_segment_ends(const SdpLevelArrays &lv, int64_t *ends, hipStream_t st) {
+  if (lv.n > 0)
+    hipLaunchKernelGGL(sdp_segment_ends_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, ends);
+}
+void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const uint64_t *poolKeys,
+                       const uint64_t *poolVals, const int64_t *blkOff,
+                       const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
+                       int64_t blocksCap, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(sdp_finish_kernel, wave_grid(n), dim3(256), 0, st, n, tasks, seq, poolKeys, poolVals, blkOff,
+                     matrix, ins, del, open, ext, results, blocks, blocksCap);
+}
+
+}  // namespace blasr_hip

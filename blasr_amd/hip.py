@@ -26,7 +26,7 @@ GAP_QUERY, GAP_TARGET = 0, 1  # Gap::GapSeq, AlignmentGapList.h:11
 EXPORTS = [
     "blasr_hip_abi_version", "blasr_hip_create", "blasr_hip_destroy", "blasr_hip_last_error",
     "blasr_hip_set_workspace_limit", "blasr_hip_stream", "blasr_hip_refine_device", "blasr_hip_refine_host",
-    "blasr_hip_refine_last_timing",
+    "blasr_hip_refine_last_timing", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
 ]
 
 # SMRTDistanceMatrix (ScoreMatrices.h:22-28): the matrix Blasr.cpp installs at :807-809
@@ -49,6 +49,44 @@ class _RefineBatch(C.Structure):
     _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
                 ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("blocks", C.c_void_p), ("blk_off", C.c_void_p),
                 ("n_blocks", C.c_void_p)]
+
+
+class _SdpParams(C.Structure):
+    _fields_ = [("word_size", C.c_int32), ("sdp_ins", C.c_int32), ("sdp_del", C.c_int32), ("indel_rate", C.c_float),
+                ("align_type", C.c_int32), ("detailed", C.c_int32), ("extend_front", C.c_int32),
+                ("prefix_length", C.c_int32), ("recurse", C.c_int32), ("recurse_over", C.c_int32),
+                ("max_per_position", C.c_int32)]
+
+
+class _SdpBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_off", C.c_void_p), ("t_len", C.c_void_p)]
+
+
+SDP_RESULT_DTYPE = np.dtype([
+    ("status", "<i4"), ("score", "<i4"), ("q_pos", "<i4"), ("t_pos", "<i4"), ("n_blocks", "<i4"),
+    ("stats_score", "<i4"), ("n_match", "<i4"), ("n_mismatch", "<i4"), ("n_ins", "<i4"), ("n_del", "<i4"),
+    ("blk_off", "<i8")])
+assert SDP_RESULT_DTYPE.itemsize == 48
+
+
+class SdpParams:
+    """What AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722), defaults of
+    MappingParameters.h:192-361."""
+
+    def __init__(self, k=11, sdp_ins=5, sdp_del=10, indel_rate=0.9, align_type=0, detailed=1, extend_front=0,
+                 prefix=50, recurse=2, recurse_over=1000, max_per_pos=0):
+        self.k, self.sdp_ins, self.sdp_del, self.indel_rate = k, sdp_ins, sdp_del, indel_rate
+        self.align_type, self.detailed, self.extend_front = align_type, detailed, extend_front
+        self.prefix, self.recurse, self.recurse_over, self.max_per_pos = prefix, recurse, recurse_over, max_per_pos
+
+    def as_struct(self):
+        s = _SdpParams()
+        s.word_size, s.sdp_ins, s.sdp_del, s.indel_rate = self.k, self.sdp_ins, self.sdp_del, self.indel_rate
+        s.align_type, s.detailed, s.extend_front = self.align_type, self.detailed, self.extend_front
+        s.prefix_length, s.recurse, s.recurse_over = self.prefix, self.recurse, self.recurse_over
+        s.max_per_position = self.max_per_pos
+        return s
 
 
 RESULT_DTYPE = np.dtype([
@@ -95,6 +133,11 @@ def load_library():
         lib.blasr_hip_stream.argtypes = [C.c_void_p]
         lib.blasr_hip_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
         lib.blasr_hip_refine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_sdp_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        for name in ("blasr_hip_sdp_device", "blasr_hip_sdp_host"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_SdpBatch), C.POINTER(_SdpParams),
+                                           C.POINTER(_ScoreParams), C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -259,6 +302,64 @@ class Context:
             o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
             out.append(RefineResult(r, o))
         return out
+
+    def sdp(self, pairs, sdp=None, score=None, blocks_capacity=None):
+        """SDPAlign + ComputeAlignmentStats for a list of (query, target) uint8 arrays (host memory).
+        Returns a list of dicts: score, qPos, tPos, blocks (n,3), stats."""
+        sdp, score = sdp or SdpParams(), score or ScoreParams()
+        n = len(pairs)
+        if n == 0:
+            return []
+        seqs, q_off, q_len, t_off, t_len, at = [], [], [], [], [], 0
+        for q, t in pairs:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            q_off.append(at); q_len.append(len(q)); at += len(q)
+            t_off.append(at); t_len.append(len(t)); at += len(t)
+            seqs += [q, t]
+        seq = np.ascontiguousarray(np.concatenate(seqs)) if at else np.zeros(1, np.uint8)
+        q_off, t_off = np.array(q_off, np.int64), np.array(t_off, np.int64)
+        q_len, t_len = np.array(q_len, np.int32), np.array(t_len, np.int32)
+        sb = _SdpBatch()
+        sb.n = n
+        sb.seq, sb.q_off, sb.q_len = seq.ctypes.data, q_off.ctypes.data, q_len.ctypes.data
+        sb.t_off, sb.t_len = t_off.ctypes.data, t_len.ctypes.data
+        cap = int(np.minimum(q_len, t_len).sum() + n) if blocks_capacity is None else int(blocks_capacity)
+        results = np.zeros(n, dtype=SDP_RESULT_DTYPE)
+        blocks = np.zeros(3 * max(cap, 1), dtype=np.int32)
+        used = C.c_int64(0)
+        sp, sc = sdp.as_struct(), score.as_struct()
+        rc = self.lib.blasr_hip_sdp_host(self.handle, C.byref(sb), C.byref(sp), C.byref(sc), results.ctypes.data,
+                                         blocks.ctypes.data, cap, C.byref(used))
+        self._check(rc)
+        out = []
+        for r in results:
+            b0 = int(r["blk_off"])
+            out.append(dict(status=int(r["status"]), score=int(r["score"]), qPos=int(r["q_pos"]),
+                            tPos=int(r["t_pos"]), blocks=blocks[3 * b0: 3 * (b0 + int(r["n_blocks"]))].reshape(-1, 3).copy(),
+                            stats=dict(score=int(r["stats_score"]), nMatch=int(r["n_match"]),
+                                       nMismatch=int(r["n_mismatch"]), nIns=int(r["n_ins"]), nDel=int(r["n_del"]))))
+        return out
+
+    def sdp_last_timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int64 * 3)()
+        self._check(self.lib.blasr_hip_sdp_last_timing(self.handle, ms, cnt))
+        return dict(keys_ms=ms[0], match_ms=ms[1], chain_ms=ms[2], blocks_ms=ms[3], invocations=cnt[0],
+                    fragments=cnt[1], sw_fills=cnt[2])
+
+    def sdp_device(self, dev_ptrs, n, sdp, score, results_ptr, blocks_ptr, blocks_capacity):
+        """Device-resident variant (raw device addresses); returns the number of block triplets produced."""
+        sb = _SdpBatch()
+        sb.n = n
+        for k in ("seq", "q_off", "q_len", "t_off", "t_len"):
+            setattr(sb, k, int(dev_ptrs[k]))
+        used = C.c_int64(0)
+        sp, sc = sdp.as_struct(), score.as_struct()
+        rc = self.lib.blasr_hip_sdp_device(self.handle, C.byref(sb), C.byref(sp), C.byref(sc), C.c_void_p(results_ptr),
+                                           C.c_void_p(blocks_ptr), int(blocks_capacity), C.byref(used))
+        self._check(rc)
+        return used.value
 
     def refine_device(self, dev_ptrs, n, band, score, results_ptr, ops_ptr, ops_capacity):
         """Device-resident variant: dev_ptrs maps the blasr_hip_refine_batch field names to raw

@@ -156,6 +156,66 @@ int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *batc
  * (DESIGN.md), counters[2] = fill kernel launches. */
 int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
 
+/* ---- SDP: SDPAlign + ComputeAlignmentStats ----------------------------- */
+/* The parameters AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722;
+ * defaults MappingParameters.h:192-361).  Supported on the device: align_type
+ * Local (0) or Global (1), detailed = 1, extend_front = 0, word_size <= 16,
+ * sequences shorter than 2^24 bases (else ERR_UNSUPPORTED). */
+typedef struct blasr_hip_sdp_params {
+  int32_t word_size;        /* sdpTupleSize (11) */
+  int32_t sdp_ins;          /* params.sdpIns (5) */
+  int32_t sdp_del;          /* params.sdpDel (10) */
+  float indel_rate;         /* params.indelRate * 3 (0.9) */
+  int32_t align_type;       /* Local */
+  int32_t detailed;         /* params.detailedSDPAlignment (1) */
+  int32_t extend_front;     /* params.extendFrontAlignment (0) */
+  int32_t prefix_length;    /* params.sdpPrefix (50) */
+  int32_t recurse;          /* params.recurse (2) */
+  int32_t recurse_over;     /* params.recurseOver (1000) */
+  int32_t max_per_position; /* params.sdpMaxAnchorsPerPosition (0) */
+} blasr_hip_sdp_params;
+
+/* Candidate i: query = seq[q_off[i] ..+q_len[i]) (alignment->qAlignedSeq, Blasr.cpp:1332-1336),
+ * target = seq[t_off[i] ..+t_len[i]) (alignment->tAlignedSeq, :1311-1325). */
+typedef struct blasr_hip_sdp_batch {
+  int32_t n;
+  const uint8_t *seq;
+  const int64_t *q_off;
+  const int32_t *q_len;
+  const int64_t *t_off;
+  const int32_t *t_len;
+} blasr_hip_sdp_batch;
+
+/* What AlignIntervals keeps of the SDP alignment: Alignment.qPos/tPos/blocks, the value SDPAlign
+ * returns, and the ComputeAlignmentStats fields (Blasr.cpp:1723-1724) that order and filter the
+ * candidates before refinement (:2547, :2594-2596). */
+typedef struct blasr_hip_sdp_result {
+  int32_t status;      /* 0, or BLASR_HIP_TASK_OPS_OVERFLOW when the blocks arena was too small */
+  int32_t score;       /* return value of SDPAlign (SDPAlign.h:624) */
+  int32_t q_pos;       /* alignment.qPos */
+  int32_t t_pos;       /* alignment.tPos */
+  int32_t n_blocks;
+  int32_t stats_score; /* alignment.score after ComputeAlignmentStats(affine) */
+  int32_t n_match;
+  int32_t n_mismatch;
+  int32_t n_ins;
+  int32_t n_del;
+  int64_t blk_off;     /* first block (triplet index) of this candidate in the blocks arena */
+} blasr_hip_sdp_result;
+
+/* blocks: arena of blocks_capacity (qPos,tPos,length) int32 triplets, relative to (q_pos,t_pos)
+ * like Alignment.blocks; *blocks_used receives the number of triplets produced. */
+int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch, const blasr_hip_sdp_params *sdp,
+                         const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                         int64_t blocks_capacity, int64_t *blocks_used);
+int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch, const blasr_hip_sdp_params *sdp,
+                       const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                       int64_t blocks_capacity, int64_t *blocks_used);
+/* Wall time (ms) of the last SDP call's device phases: [0] k-mer keys + sort, [1] match + order,
+ * [2] chain, [3] blocks + gap fills + assembly; counters: [0] SDPAlign invocations (all levels),
+ * [1] fragments chained, [2] SWAlign gap fills. */
+int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
+
 #ifdef __cplusplus
 }
 #endif
