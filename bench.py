@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X refine stage on BASELINE.json's workload.
+"""bench.py -- throughput of the MI355X refine path on BASELINE.json's workload.
 
-One "step" = one pass of the hot path over one batch of synthetic candidates
-that are already resident in HBM: guide geometry -> banded affine fill
-(AffineGuidedAlign) -> traceback + ComputeAlignmentStats -> op compaction,
-through the C ABI (blasr_hip_refine_device).  Workload at N=1 = BASELINE.json
-configs[1]: 100k synthetic 10 kb PacBio-like reads (ins 11 % / del 4 % / sub
-1 %) against a 4.64 Mb i.i.d. genome (E. coli K12 length; the real FASTA is not
-available offline), band 16, default scores.  With N>1 every rank processes its
-own 100k-read shard (weak scaling, no data-path collective; one RCCL all-reduce
-of the per-rank counters at the end, as SURVEY.md section 8e prescribes).
+One "step" = one pass of the hot path over one batch of synthetic candidates already resident in
+HBM, through the C ABI of include/blasr_hip.h:
+
+  blasr_hip_sdp_device     SDPAlign (k-mer seeding, chaining, SWAlign / recursive gap fills) +
+                           ComputeAlignmentStats                 (alignment/Blasr.cpp:1716-1724)
+  (device glue)            trim query/target to the SDP extent   (alignment/Blasr.cpp:850-859)
+  blasr_hip_refine_device  AffineGuidedAlign + traceback + ComputeAlignmentStats (:862-878)
+
+Workload at N=1 = BASELINE.json configs[1]: 100k synthetic 10 kb PacBio-like reads (ins 11 % /
+del 4 % / sub 1 %) against a 4.64 Mb i.i.d. genome (E. coli K12 length; the real FASTA is not
+available offline), -sdpTupleSize 11, band 16, default scores; one candidate window per read, built
+by the window rule of AlignIntervals.  With N>1 every rank processes its own shard of the same size
+(weak scaling, no data-path collective; one RCCL all-reduce of the run counters at the end).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -25,32 +28,26 @@ sys.path.insert(0, ROOT)
 
 
 def cpu_baseline(w, n_sample, band):
-    """The CPU oracle (a bit-exact port of the reference's AffineGuidedAlign +
-    ComputeAlignmentStats) timed on one host core over the first `n_sample`
-    candidates of the same workload.  Checker code: never on the product path."""
+    """The CPU oracle (bit-exact port of SDPAlign + AffineGuidedAlign + ComputeAlignmentStats) timed on
+    one host core over the first `n_sample` candidates of the same workload.  Checker code: never on the
+    product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from blasr_testlib import load_oracle
 
     oracle = load_oracle()
-    import numpy as np
-
     seq = w["seq"].cpu().numpy()
     q_off, q_len = w["q_off"][:n_sample].cpu().numpy(), w["q_len"][:n_sample].cpu().numpy()
     t_off, t_len = w["t_off"][:n_sample].cpu().numpy(), w["t_len"][:n_sample].cpu().numpy()
-    blk_off, n_blk = w["blk_off"][:n_sample].cpu().numpy(), w["n_blocks"][:n_sample].cpu().numpy()
-    hi = int(blk_off[-1] + n_blk[-1])
-    blocks = w["blocks"][: 3 * hi].cpu().numpy().reshape(-1, 3)
-    tasks = [(seq[q_off[i]: q_off[i] + q_len[i]], seq[t_off[i]: t_off[i] + t_len[i]],
-              blocks[blk_off[i]: blk_off[i] + n_blk[i]]) for i in range(n_sample)]
+    tasks = [(seq[q_off[i]: q_off[i] + q_len[i]], seq[t_off[i]: t_off[i] + t_len[i]]) for i in range(n_sample)]
     cells = 0
     t0 = time.perf_counter()
-    for q, t, bl in tasks:
-        cells += oracle.affine_guided_align(q, t, bl, band=band)["nCells"]
+    for q, t in tasks:
+        cells += oracle.refine_candidate(q, t, band=band)["nCells"]
     dt = time.perf_counter() - t0
     bases = int(q_len.sum())
-    return dict(value=bases / dt, unit="aligned bases/s", cores=1, kind="port",
-                sample="first %d candidates of the same workload (%.1f s, %.1f Mcells/s on one core)"
-                       % (n_sample, dt, cells / dt / 1e6))
+    return dict(value=bases / dt, unit="bases/s", cores=1, kind="port",
+                sample="first %d candidates of the same workload, SDP + refine (%.1f s, %.1f ms/read on one core)"
+                       % (n_sample, dt, dt / n_sample * 1e3))
 
 
 def main():
@@ -71,7 +68,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the refine stage has no CPU path")
+        raise SystemExit("bench.py needs an MI355X: the refine path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -80,21 +77,44 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import blasr_amd
-    from blasr_amd import synth
+    from blasr_amd import shard, synth
 
     ctx = blasr_amd.Context(local_rank)
     ctx.set_workspace_limit(160 << 30)
-    w = synth.make_refine_workload(args.reads, args.read_len, args.seed + rank, dev)
+    w = synth.make_sdp_workload(args.reads, args.read_len, args.seed + rank, dev)
     n = int(w["q_len"].numel())
-    ptrs = {k: w[k].data_ptr() for k in ("seq", "q_off", "q_len", "t_off", "t_len", "blocks", "blk_off", "n_blocks")}
-    results = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
+    sdp_ptrs = {k: w[k].data_ptr() for k in ("seq", "q_off", "q_len", "t_off", "t_len")}
+    sdp_res = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    blk_cap = int(torch.minimum(w["q_len"], w["t_len"]).sum().item() // 4 + n)
+    blocks = torch.zeros(3 * blk_cap, dtype=torch.int32, device=dev)
+    ref_res = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
     ops_cap = int((w["q_len"].sum().item() + w["t_len"].sum().item()) // 2 + 1024)
     ops = torch.zeros(ops_cap, dtype=torch.int32, device=dev)
-    score = blasr_amd.ScoreParams()
+    score, sdp_par = blasr_amd.ScoreParams(), blasr_amd.SdpParams()
     torch.cuda.synchronize()
 
     def step():
-        return ctx.refine_device(ptrs, n, args.band, score, results.data_ptr(), ops.data_ptr(), ops_cap)
+        # a-2..a-5 + a-9: SDPAlign and its statistics
+        ctx.sdp_device(sdp_ptrs, n, sdp_par, score, sdp_res.data_ptr(), blocks.data_ptr(), blk_cap)
+        t_sdp = ctx.sdp_last_timing()
+        # RefineAlignment's trimming (Blasr.cpp:850-859): pure index arithmetic on the result records
+        r = sdp_res.view(torch.int32).view(n, 12)
+        q_pos, t_pos, n_blk = r[:, 2].to(torch.int64), r[:, 3].to(torch.int64), r[:, 4].contiguous()
+        blk_off = sdp_res.view(torch.int64).view(n, 6)[:, 5].contiguous()
+        last = (blk_off + n_blk - 1).clamp_min(0)
+        b3 = blocks.view(-1, 3)
+        has = n_blk > 0
+        q_len2 = torch.where(has, b3[last, 0] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
+        t_len2 = torch.where(has, b3[last, 1] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
+        q_off2 = (w["q_off"] + q_pos).contiguous()
+        t_off2 = (w["t_off"] + t_pos).contiguous()
+        ptrs = dict(seq=w["seq"].data_ptr(), q_off=q_off2.data_ptr(), q_len=q_len2.data_ptr(), t_off=t_off2.data_ptr(),
+                    t_len=t_len2.data_ptr(), blocks=blocks.data_ptr(), blk_off=blk_off.data_ptr(),
+                    n_blocks=n_blk.data_ptr())
+        torch.cuda.synchronize()  # the glue ran on torch's stream, the library uses its own
+        # a-6..a-9: guided banded affine DP, traceback, statistics
+        ctx.refine_device(ptrs, n, args.band, score, ref_res.data_ptr(), ops.data_ptr(), ops_cap)
+        return t_sdp, ctx.last_timing()
 
     def barrier():
         torch.cuda.synchronize()
@@ -105,63 +125,60 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    fill_ms = fill_bytes = cells = launches = 0
-    stage_ms = [0.0, 0.0, 0.0, 0.0]
+    acc = {}
     for _ in range(args.steps):
-        step()
-        tm = ctx.last_timing()  # HIP events recorded on the library's own stream
-        fill_ms += tm["fill_ms"]
-        fill_bytes += tm["fill_bytes"]
-        cells += tm["cells"]
-        launches += tm["fill_launches"]
-        for i, k in enumerate(("geometry_ms", "fill_ms", "traceback_ms", "compact_ms")):
-            stage_ms[i] += tm[k]
+        t_sdp, t_ref = step()
+        for k, v in list(t_sdp.items()) + list(t_ref.items()):
+            acc[k] = acc.get(k, 0) + v
     barrier()
     elapsed = time.perf_counter() - t0
 
-    rec = results.view(torch.int32).view(n, 14)
+    rec = ref_res.view(torch.int32).view(n, 14)
     ok = rec[:, 0] == 0
-    from blasr_amd import shard
-
     # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
     totals = shard.reduce_counters(n, int(ok.sum()), int((w["q_len"].to(torch.int64) * ok).sum()),
                                    int(rec[:, 4].to(torch.int64).sum()), device=dev)
     elapsed = shard.max_over_ranks(elapsed, device=dev)
-    reads_total, aligned_reads = totals["reads"], totals["aligned_reads"]
-    aligned_bases, cells_total = totals["aligned_bases"], totals["dp_cells"]
 
     if rank == 0:
-        value = aligned_bases * args.steps / elapsed
-        achieved = fill_bytes / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
+        K = args.steps
+        value = totals["aligned_bases"] * K / elapsed
+        fill_ms, launches = acc["fill_ms"], max(acc["fill_launches"], 1)
+        achieved = acc["fill_bytes"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
         out = {
-            "metric": "aligned bases/sec (refine stage: guided banded affine DP + traceback + stats)",
+            "metric": "aligned bases/sec (refine path: SDP chaining + guided banded affine DP), GCUPS per GPU",
             "value": value,
             "unit": "bases/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": "synthetic: i.i.d. %d-base genome, %d x %d-base reads per GPU (ins 11%%/del 4%%/sub 1%%), "
-                    "guide blocks = ungapped runs of the simulated alignment" % (synth.ECOLI_K12_LENGTH, args.reads,
-                                                                                  args.read_len),
+            "data": "synthetic: i.i.d. %d-base genome, %d x %d-base reads per GPU (ins 11%%/del 4%%/sub 1%%), one "
+                    "candidate window per read (AlignIntervals window rule)" % (synth.ECOLI_K12_LENGTH, args.reads,
+                                                                                args.read_len),
             "config": {"workload": "configs[1]: 100k synthetic 10 kb reads vs E. coli-K12-length genome, "
-                                   "refine stage, band 16, SMRT matrix, ins=del=5, open=50, ext=0",
+                                   "-sdpTupleSize 11, band 16, SMRT matrix, ins=del=5, open=50, ext=0; SDP + refine",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "band": args.band,
-                       "candidates": reads_total, "aligned_reads": aligned_reads},
-            "gcups_per_gpu": cells_total / world * args.steps / elapsed / 1e9,
-            "stage_ms_per_step": {k: v / args.steps for k, v in zip(("geometry", "fill", "traceback", "compact"),
-                                                                     stage_ms)},
+                       "candidates": totals["reads"], "aligned_reads": totals["aligned_reads"]},
+            "gcups_per_gpu": totals["dp_cells"] / world * K / elapsed / 1e9,
+            "stage_ms_per_step": {
+                "sdp_keys_sort": acc["keys_ms"] / K, "sdp_match_order": acc["match_ms"] / K,
+                "sdp_chain": acc["chain_ms"] / K, "sdp_blocks_fills_assembly": acc["blocks_ms"] / K,
+                "refine_geometry": acc["geometry_ms"] / K, "refine_fill": fill_ms / K,
+                "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
+            "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
+                                      "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
             "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill_kernel<false, true>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "traffic_note": "PMC passes (profiles/r01_pmc_counters_20k_reads.json): FETCH_SIZE x2 + "
                                          "WRITE_SIZE = 1.11 x the algorithmic bytes of the same launch",
-                         "algorithmic_bytes_per_launch": fill_bytes / max(launches, 1),
-                         "launches": launches, "avg_launch_ms": fill_ms / max(launches, 1),
-                         "fill_gcups": cells / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
+                         "algorithmic_bytes_per_launch": acc["fill_bytes"] / launches,
+                         "launches": launches, "avg_launch_ms": fill_ms / launches,
+                         "fill_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_sample, n), args.band)

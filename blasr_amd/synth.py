@@ -217,3 +217,75 @@ def make_refine_workload(n_reads, read_len, seed, device, genome_len=ECOLI_K12_L
                 blocks=torch.cat(blk_parts).reshape(-1).contiguous(),
                 blk_off=(torch.cumsum(nblk, 0) - nblk).to(torch.int64).contiguous(),
                 n_blocks=nblk.to(torch.int32).contiguous())
+
+
+def make_sdp_workload(n_reads, read_len, seed, device, genome_len=ECOLI_K12_LENGTH, ins=0.11, dele=0.04, sub=0.01,
+                      max_unanchored=300, slab=4096):
+    """SDP-stage inputs for `n_reads` synthetic PacBio-like reads: what AlignIntervals hands to SDPAlign
+    (alignment/Blasr.cpp:1311-1336, :1716-1722) for the one true candidate interval of every read.
+
+    query  = the whole read (forward as sequenced);
+    target = the genome window of the read's origin, extended on each side by the 0.3 x (unanchored read
+             end) that the 1.3x stretch of Blasr.cpp:1247-1265 adds beyond the read's own footprint
+             (unanchored ends uniform in 0..max_unanchored), clipped to the genome, reverse-complemented
+             for reverse-strand reads.
+
+    Returns torch tensors laid out as blasr_hip_sdp_batch wants: seq, q_off, q_len, t_off, t_len."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.int64, device=device)
+    genome = torch.randint(0, 4, (genome_len,), generator=gen, device=device, dtype=torch.int64)
+    L = read_len
+    ar = torch.arange(L, device=device)
+    q_parts, t_parts, q_lens, t_lens = [], [], [], []
+    for s0 in range(0, n_reads, slab):
+        n = min(slab, n_reads - s0)
+        pos = torch.randint(0, genome_len - L, (n,), generator=gen, device=device)
+        strand = torch.randint(0, 2, (n,), generator=gen, device=device)
+        idx = pos[:, None] + ar[None, :]
+        idx = torch.where(strand[:, None] == 1, pos[:, None] + (L - 1 - ar)[None, :], idx)
+        tmpl = genome[idx]
+        tmpl = torch.where(strand[:, None] == 1, comp[tmpl], tmpl)
+        u = torch.rand((n, L), generator=gen, device=device)
+        keep = u >= dele
+        do_sub = keep & (u < dele + sub)
+        shift = torch.randint(1, 4, (n, L), generator=gen, device=device)
+        base = torch.where(do_sub, (tmpl + shift) & 3, tmpl)
+        if ins > 0:
+            v = torch.rand((n, L), generator=gen, device=device).clamp_min(1e-12)
+            k = torch.floor(torch.log(v) / np.log(ins)).to(torch.int64)
+        else:
+            k = torch.zeros((n, L), dtype=torch.int64, device=device)
+        emit = keep.to(torch.int64) + k
+        qpos = torch.cumsum(emit, dim=1) - emit
+        rlen = emit.sum(dim=1)
+        roff = torch.cumsum(rlen, 0) - rlen
+        reads = torch.randint(0, 4, (int(rlen.sum()),), generator=gen, device=device)
+        krow, kcol = torch.nonzero(keep, as_tuple=True)
+        reads[roff[krow] + qpos[krow, kcol]] = base[krow, kcol]
+        q_parts.append(acgt[reads])
+        q_lens.append(rlen)
+        # window = footprint extended by 0.3 x unanchored ends, clipped
+        ext0 = (torch.randint(0, max_unanchored + 1, (n,), generator=gen, device=device) * 3) // 10
+        ext1 = (torch.randint(0, max_unanchored + 1, (n,), generator=gen, device=device) * 3) // 10
+        w0 = torch.clamp(pos - ext0, min=0)
+        w1 = torch.clamp(pos + L + ext1, max=genome_len)
+        wl = w1 - w0
+        wo = torch.cumsum(wl, 0) - wl
+        rows = torch.repeat_interleave(torch.arange(n, device=device), wl)
+        off = torch.arange(int(wl.sum()), device=device) - wo[rows]
+        gidx = torch.where(strand[rows] == 1, w1[rows] - 1 - off, w0[rows] + off)
+        win = genome[gidx]
+        win = torch.where(strand[rows] == 1, comp[win], win)
+        t_parts.append(acgt[win])
+        t_lens.append(wl)
+    q_len, t_len = torch.cat(q_lens), torch.cat(t_lens)
+    qpool, tpool = torch.cat(q_parts), torch.cat(t_parts)
+    return dict(seq=torch.cat([qpool, tpool]).contiguous(),
+                q_off=(torch.cumsum(q_len, 0) - q_len).to(torch.int64).contiguous(),
+                q_len=q_len.to(torch.int32).contiguous(),
+                t_off=(torch.cumsum(t_len, 0) - t_len + qpool.numel()).to(torch.int64).contiguous(),
+                t_len=t_len.to(torch.int32).contiguous())

@@ -138,6 +138,30 @@ class Checker:
                     gapCounts=gap_counts[: ngl.value].copy(),
                     gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
 
+    def refine_candidate(self, q, t, sc=None, sp=None, band=16):
+        """SDPAlign(Local) -> stats -> AffineGuidedAlign -> stats for one candidate window (oracle only)."""
+        sc, sp = sc or ScoreParams(), sp or SdpParams()
+        q, t = _u8(q), _u8(t)
+        cap = len(q) + len(t) + 16
+        blocks = np.zeros(3 * cap, dtype=np.int32)
+        gap_counts = np.zeros(cap, dtype=np.int32)
+        gap_items = np.zeros(2 * cap, dtype=np.int32)
+        out = np.zeros(12, dtype=np.int32)
+        pct = C.c_float(0)
+        qpos, tpos, nb, ngl, ngi = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        f = self.fn("refine_candidate")
+        f.restype = C.c_int
+        rc = f(_p(q, C.c_ubyte), len(q), _p(t, C.c_ubyte), len(t), _p(sc.matrix), sc.ins, sc.dele, sc.affine_open,
+               sc.affine_extend, sp.k, sp.sdp_ins, sp.sdp_del, C.c_float(sp.indel_rate), sp.prefix, sp.recurse,
+               sp.recurse_over, band, _p(out), C.byref(pct), C.byref(qpos), C.byref(tpos), _p(blocks), cap,
+               C.byref(nb), _p(gap_counts), cap, C.byref(ngl), _p(gap_items), cap, C.byref(ngi))
+        assert rc == 0, rc
+        return dict(sdpScore=int(out[0]), sdpStatsScore=int(out[1]), sdpQPos=int(out[2]), sdpTPos=int(out[3]),
+                    nSdpBlocks=int(out[4]), dpScore=int(out[5]), nCells=int(out[6]), score=int(out[7]),
+                    nMatch=int(out[8]), nMismatch=int(out[9]), nIns=int(out[10]), nDel=int(out[11]), pct=pct.value,
+                    qPos=qpos.value, tPos=tpos.value, blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
+                    gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
+
     def compute_alignment_stats(self, q, t, qpos, tpos, blocks, gap_counts=None, gap_items=None, sc=None,
                                 affine=1):
         sc = sc or ScoreParams()
