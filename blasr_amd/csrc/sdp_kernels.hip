@@ -740,15 +740,6 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
 // sdp_blocks: chain -> blocks (SDPAlign.h:308-335), trim (:349-357), filter (:372-413), and the
 // work lists of :423-536 (front fill for Global, fills between consecutive blocks)
 // ---------------------------------------------------------------------------
-__device__ void emit_block(const SdpEmit &e, const SdpTask &t, uint32_t q, uint32_t tt, uint32_t len) {
-  const unsigned long long at = atomicAdd(e.poolCount, 1ull);
-  if ((int64_t)at >= e.poolCap) {
-    *e.overflow = 1;
-    return;
-  }
-  e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
-  e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
-}
 __device__ void emit_sw(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft) {
   const unsigned long long at = atomicAdd(e.swCount, 1ull);
   if ((int64_t)at >= e.swCap) {
@@ -789,78 +780,178 @@ __device__ void emit_child(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint
   e.children[at] = c;
 }
 
+// One wavefront per task.  Only the chain back-trace is serial (a linked list); run merging, trimming,
+// filtering, compaction and the emission of blocks / gap-fill jobs are lane-parallel with wave prefix
+// sums, and every 64-block chunk reserves its output slots with ONE atomic per work list.
 __global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpParams prm, SdpEmit e) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
-  if (lane_id() != 0) return;
+  const int lane = lane_id();
   const int F = lv.nFrag[idx];
   if (F == 0) return;
   const SdpTask t = lv.tasks[idx];
   const int64_t base = lv.fragOff[idx];
   const Frag *fr = lv.frags + base;
   const int *chainPrev = lv.chainPrev + base;
-  int *chain = lv.scratchA + base;
-  uint32_t *cb = reinterpret_cast<uint32_t *>(lv.scratchB + 3 * base);  // (q,t,len) triplets
+  int *chainRev = lv.scratchA + base;                                     // chain, last fragment first
+  uint32_t *cb = reinterpret_cast<uint32_t *>(lv.scratchB + 3 * base);   // candidate blocks (q,t,end)
+  uint32_t *fb = reinterpret_cast<uint32_t *>(lv.cost + base);           // final blocks reuse cost/chainLen/predCl
+  uint32_t *fbT = reinterpret_cast<uint32_t *>(lv.chainLen + base);
+  uint32_t *fbL = reinterpret_cast<uint32_t *>(lv.predCl + base);
+  // ---- back-trace (serial) ----
   int nChain = 0;
-  for (int f = lv.chainEnd[idx]; f != -1 && nChain < F; f = chainPrev[f]) chain[nChain++] = f;
-  for (int i = 0; i < nChain / 2; i++) {
-    const int tmp = chain[i];
-    chain[i] = chain[nChain - 1 - i];
-    chain[nChain - 1 - i] = tmp;
-  }
+  if (lane == 0)
+    for (int f = lv.chainEnd[idx]; f != -1 && nChain < F; f = chainPrev[f]) chainRev[nChain++] = f;
+  nChain = __builtin_amdgcn_readfirstlane(nChain);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (nChain == 0) return;
+  // ---- runs of +1/+1 fragments become candidate blocks (:308-335) ----
   int ncb = 0;
-  for (int f = 0; f < nChain; f++) {
-    const int startF = f;
-    while (f < nChain - 1 && fr[chain[f]].x == fr[chain[f + 1]].x - 1 && fr[chain[f]].y == fr[chain[f + 1]].y - 1) f++;
-    cb[3 * ncb] = fr[chain[startF]].x;
-    cb[3 * ncb + 1] = fr[chain[startF]].y;
-    cb[3 * ncb + 2] = fr[chain[f]].x + fr[chain[f]].len - fr[chain[startF]].x;
-    ncb++;
-  }
-  for (int b = 0; b + 1 < ncb; b++) {
-    if (cb[3 * b] + cb[3 * b + 2] > cb[3 * b + 3]) cb[3 * b + 2] = cb[3 * b + 3] - cb[3 * b];
-    if (cb[3 * b + 1] + cb[3 * b + 2] > cb[3 * b + 4]) cb[3 * b + 2] = cb[3 * b + 4] - cb[3 * b + 1];
-  }
-  // bad blocks: zero length, or off-diagonal against both neighbours (float compare as in :405)
-  unsigned char *good = reinterpret_cast<unsigned char *>(chain);  // chain[] is no longer needed
-  for (int b = 0; b < ncb; b++) good[b] = cb[3 * b + 2] != 0;
-  for (int b = 1; b + 1 < ncb; b++) {
-    const int pq = (int)cb[3 * b - 3], pt = (int)cb[3 * b - 2], q = (int)cb[3 * b], tt = (int)cb[3 * b + 1];
-    const int nq = (int)cb[3 * b + 3], nt = (int)cb[3 * b + 4];
-    const int prevDiag = abs((tt - q) - (pt - pq));
-    const int prevDist = (int)min((uint32_t)(tt - pt), (uint32_t)(q - pq));
-    const int nextDiag = abs((nt - nq) - (tt - q));
-    const int nextDist = (int)min((uint32_t)(nt - tt), (uint32_t)(nq - q));
-    if (prevDist * prm.indelRate < prevDiag && nextDist * prm.indelRate < nextDiag) good[b] = 0;
-  }
-  {
-    int w = 0;
-    for (int b = 0; b < ncb; b++)
-      if (good[b]) {
-        cb[3 * w] = cb[3 * b];
-        cb[3 * w + 1] = cb[3 * b + 1];
-        cb[3 * w + 2] = cb[3 * b + 2];
-        w++;
+  for (int i0 = 0; i0 < nChain; i0 += 64) {
+    const int i = i0 + lane;
+    bool start = false, last = false;
+    Frag f;
+    f.x = f.y = f.len = 0;
+    if (i < nChain) {
+      f = fr[chainRev[nChain - 1 - i]];
+      start = true;
+      if (i > 0) {
+        const Frag p = fr[chainRev[nChain - i]];
+        start = !(p.x + 1 == f.x && p.y + 1 == f.y);
       }
-    ncb = w;
+      last = true;
+      if (i + 1 < nChain) {
+        const Frag nx = fr[chainRev[nChain - 2 - i]];
+        last = !(f.x + 1 == nx.x && f.y + 1 == nx.y);
+      }
+    }
+    const unsigned incl = wave_prefix_sum(start ? 1u : 0u);
+    const int b = ncb + (int)incl - 1;  // block this fragment belongs to
+    if (start) {
+      cb[3 * b] = f.x;
+      cb[3 * b + 1] = f.y;
+    }
+    if (last) cb[3 * b + 2] = f.x + f.len;  // block.length = x_last + len_last - x_first (:332)
+    ncb += __builtin_amdgcn_readlane((int)incl, 63);
   }
-  if (ncb == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ---- trim overlaps (:349-357), drop zero-length and off-diagonal blocks (:372-413), compact ----
+  int nfb = 0;
+  for (int b0 = 0; b0 < ncb; b0 += 64) {
+    const int b = b0 + lane;
+    bool good = false;
+    uint32_t q = 0, tt = 0, len = 0;
+    if (b < ncb) {
+      q = cb[3 * b];
+      tt = cb[3 * b + 1];
+      len = cb[3 * b + 2] - q;
+      if (b + 1 < ncb) {
+        const uint32_t nq = cb[3 * b + 3], nt = cb[3 * b + 4];
+        if (q + len > nq) len = nq - q;
+        if (tt + len > nt) len = nt - tt;
+        if (b > 0) {
+          const int pq = (int)cb[3 * b - 3], pt = (int)cb[3 * b - 2];
+          const int prevDiag = abs(((int)tt - (int)q) - (pt - pq));
+          const int prevDist = (int)min(tt - (uint32_t)pt, q - (uint32_t)pq);
+          const int nextDiag = abs(((int)nt - (int)nq) - ((int)tt - (int)q));
+          const int nextDist = (int)min(nt - tt, nq - q);
+          good = !(prevDist * prm.indelRate < prevDiag && nextDist * prm.indelRate < nextDiag);
+        } else
+          good = true;
+      } else
+        good = true;
+      good = good && len != 0;
+    }
+    const unsigned incl = wave_prefix_sum(good ? 1u : 0u);
+    if (good) {
+      const int w = nfb + (int)incl - 1;
+      fb[w] = q;
+      fbT[w] = tt;
+      fbL[w] = len;
+    }
+    nfb += __builtin_amdgcn_readlane((int)incl, 63);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (nfb == 0) return;
   const uint32_t nru = (uint32_t)prm.noRecurseUnder;
-  // :423-474 front fill (Global only; extendFrontByLocalAlignment is false on this path)
-  if (t.type == 1 && cb[0] > 0 && cb[1] > 0) {
-    const uint32_t fq = cb[0], ft = cb[1];
+  // ---- :423-474 front fill (Global only; extendFrontByLocalAlignment is false on this path) ----
+  if (lane == 0 && t.type == 1 && fb[0] > 0 && fbT[0] > 0) {
+    const uint32_t fq = fb[0], ft = fbT[0];
     if (t.recurse == 0 && fq * ft < nru) emit_sw(e, t, 0, 0, fq, ft);
     else if (t.recurse != 0) emit_child(e, t, 0, 0, fq, ft, t.prefix, 6 /* EndAnchored lands in this slot, :456 */);
   }
-  for (int b = 0; b < ncb; b++) {
-    emit_block(e, t, cb[3 * b], cb[3 * b + 1], cb[3 * b + 2]);
-    if (b + 1 < ncb) {
-      const uint32_t q0 = cb[3 * b] + cb[3 * b + 2], t0 = cb[3 * b + 1] + cb[3 * b + 2];
-      const uint32_t fq = cb[3 * b + 3] - q0, ft = cb[3 * b + 4] - t0;
-      if (fq > 0 && ft > 0) {
-        if (fq * ft < nru) emit_sw(e, t, q0, t0, fq, ft);
-        else if (t.recurse != 0) emit_child(e, t, q0, t0, fq, ft, 0, 0);
+  // ---- blocks and the fills between consecutive blocks (:481-536) ----
+  for (int b0 = 0; b0 < nfb; b0 += 64) {
+    const int b = b0 + lane;
+    const bool on = b < nfb;
+    uint32_t q = 0, tt = 0, len = 0, q0 = 0, t0 = 0, fq = 0, ft = 0;
+    int kind = 0;  // 1 = SWAlign fill, 2 = recursive SDPAlign
+    if (on) {
+      q = fb[b];
+      tt = fbT[b];
+      len = fbL[b];
+      if (b + 1 < nfb) {
+        q0 = q + len;
+        t0 = tt + len;
+        fq = fb[b + 1] - q0;
+        ft = fbT[b + 1] - t0;
+        if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
       }
+    }
+    const unsigned long long mOn = __ballot(on), mSw = __ballot(kind == 1), mCh = __ballot(kind == 2);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long basePool = 0, baseSw = 0, baseCh = 0;
+    if (lane == 0) {
+      basePool = atomicAdd(e.poolCount, (unsigned long long)__popcll(mOn));
+      if (mSw) baseSw = atomicAdd(e.swCount, (unsigned long long)__popcll(mSw));
+      if (mCh) baseCh = atomicAdd(e.childCount, (unsigned long long)__popcll(mCh));
+    }
+    basePool = __shfl(basePool, 0);
+    baseSw = __shfl(baseSw, 0);
+    baseCh = __shfl(baseCh, 0);
+    if (on) {
+      const unsigned long long at = basePool + (unsigned long long)__popcll(mOn & lt);
+      if ((int64_t)at < e.poolCap) {
+        e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
+        e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
+      } else
+        *e.overflow = 1;
+    }
+    if (kind == 1) {
+      const unsigned long long at = baseSw + (unsigned long long)__popcll(mSw & lt);
+      if ((int64_t)at < e.swCap) {
+        SwTask sw;
+        sw.qOff = t.qOff + q0;
+        sw.tOff = t.tOff + t0;
+        sw.qLen = (int)fq;
+        sw.tLen = (int)ft;
+        sw.top = t.top;
+        sw.qOrg = t.qOrg + (int)q0;
+        sw.tOrg = t.tOrg + (int)t0;
+        sw.pad = 0;
+        e.sw[at] = sw;
+      } else
+        *e.overflow = 1;
+    }
+    if (kind == 2) {
+      const unsigned long long at = baseCh + (unsigned long long)__popcll(mCh & lt);
+      if ((int64_t)at < e.childCap) {
+        SdpTask c;
+        c.qOff = t.qOff + q0;
+        c.tOff = t.tOff + t0;
+        c.qLen = (int)fq;
+        c.tLen = (int)ft;
+        c.k = t.k - 4 > 5 ? t.k - 4 : 5;
+        c.type = 1;
+        c.prefix = 0;
+        c.recurse = t.recurse - 1;
+        c.maxPerPos = 0;
+        c.top = t.top;
+        c.qOrg = t.qOrg + (int)q0;
+        c.tOrg = t.tOrg + (int)t0;
+        e.children[at] = c;
+      } else
+        *e.overflow = 1;
     }
   }
 }
