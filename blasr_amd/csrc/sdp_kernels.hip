@@ -197,8 +197,11 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t *a, int n, uint64_
 // sdp_match: StoreMatchingPositions for the prefix, the whole sequence and the suffix
 // (SDPAlign.h:148-242).  kWrite = false counts, kWrite = true writes the fragments.
 // ---------------------------------------------------------------------------
+constexpr int kBucketBits = 11;  // LDS bucket index over the leading bits of the k-mer (per wavefront: 8 KB)
+
 template <bool kWrite>
 __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const uint8_t *seq) {
+  __shared__ uint32_t bucketStart[4][(1 << kBucketBits) + 1];
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
@@ -248,7 +251,24 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   const int nP = (ks >= 1) ? smallPart(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0) : 0;
   written += nP;
 
-  // middle (part 1): the whole query against the sorted k-mer keys of the whole target
+  // middle (part 1): the whole query against the sorted k-mer keys of the whole target.
+  // For long targets the binary search is narrowed by a bucket index over the leading k-mer bits that the
+  // wavefront builds in LDS from the sorted keys (one pass), instead of ~2 x log2(tLen) dependent HBM reads.
+  const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
+  const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
+  const bool useBuckets = t.tLen >= 256;
+  uint32_t *bucket = bucketStart[threadIdx.x >> 6];
+  if (useBuckets) {
+    const int nB = 1 << bBits;
+    for (int b = lane; b <= nB; b += 64) bucket[b] = (uint32_t)t.tLen;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < t.tLen; i += 64) {
+      const int cur = (int)min((uint64_t)nB, keys[i] >> bShift);
+      const int prev = i == 0 ? -1 : (int)min((uint64_t)nB, keys[i - 1] >> bShift);
+      for (int b = prev + 1; b <= cur; b++) bucket[b] = (uint32_t)i;  // first key of every bucket in (prev, cur]
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   int nM = 0;
   for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
     const int x = x0 + lane;
@@ -262,8 +282,14 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
         kmer |= (uint64_t)(c & 3) << (2 * j);
       }
       if (ok) {
-        lo = lower_bound_u64(keys, t.tLen, kmer << kPosBits);
-        const int hi = lower_bound_u64(keys, t.tLen, (kmer + 1) << kPosBits);
+        int rLo = 0, rHi = t.tLen;
+        if (useBuckets) {
+          const int b = (int)(kmer >> (2 * k - bBits));
+          rLo = (int)bucket[b];
+          rHi = (int)bucket[b + 1];
+        }
+        lo = rLo + lower_bound_u64(keys + rLo, rHi - rLo, kmer << kPosBits);
+        const int hi = lo + lower_bound_u64(keys + lo, rHi - lo, (kmer + 1) << kPosBits);
         cnt = hi - lo;
         if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
       }
