@@ -291,31 +291,52 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
 
     // ---- blocks, gap-fill jobs, next level ----
     tick();
-    SdpEmit e;
-    e.poolCap = nFragTotal;
-    e.swCap = nFragTotal;
-    e.childCap = nFragTotal;
-    e.poolKeys = arena.get<uint64_t>(nf);
-    e.poolVals = arena.get<uint64_t>(nf);
-    e.sw = arena.get<SwTask>(nf);
-    e.children = arena.get<SdpTask>(nf);
+    // what every task will emit, then exclusive scans -> contention-free slots
+    int32_t *counts = arena.get<int32_t>((size_t)4 * nTasks + 4);
+    int64_t *offPool = arena.get<int64_t>(nTasks + 1), *offSw = arena.get<int64_t>(nTasks + 1),
+            *offChild = arena.get<int64_t>(nTasks + 1);
     ARENA_CHECK();
-    HIP_TRY(ctx, hipMemsetAsync(dCounters, 0, sizeof(Counters), st));
-    e.poolCount = &dCounters->pool;
-    e.swCount = &dCounters->sw;
-    e.childCount = &dCounters->child;
-    e.overflow = &dCounters->overflow;
-    launch_sdp_blocks(lv, prm, e, st);
-    Counters hc;
-    HIP_TRY(ctx, hipMemcpyAsync(&hc, dCounters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemsetAsync(counts + (size_t)4 * nTasks, 0, 4 * sizeof(int32_t), st));
+    launch_sdp_blocks_build(lv, prm, counts, st);
+    {
+      int64_t *offs[3] = {offPool, offSw, offChild};
+      for (int c = 0; c < 3; c++) {
+        auto in = rocprim::make_transform_iterator(
+            rocprim::make_counting_iterator<size_t>(0),
+            [counts, c] __device__(size_t i) { return (int64_t)counts[4 * i + c]; });
+        size_t scanBytes = 0;
+        HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scanBytes, in, offs[c], (int64_t)0, (size_t)nTasks + 1,
+                                             rocprim::plus<int64_t>(), st));
+        void *scanTmp = arena.get<char>(scanBytes);
+        ARENA_CHECK();
+        HIP_TRY(ctx, rocprim::exclusive_scan(scanTmp, scanBytes, in, offs[c], (int64_t)0, (size_t)nTasks + 1,
+                                             rocprim::plus<int64_t>(), st));
+      }
+    }
+    int64_t emitTotals[3] = {0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(&emitTotals[0], offPool + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&emitTotals[1], offSw + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&emitTotals[2], offChild + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    SdpEmit e;
+    memset(&e, 0, sizeof(e));
+    e.poolCap = emitTotals[0];
+    e.swCap = emitTotals[1];
+    e.childCap = emitTotals[2];
+    e.poolKeys = arena.get<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
+    e.poolVals = arena.get<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
+    e.sw = arena.get<SwTask>((size_t)std::max<int64_t>(emitTotals[1], 1));
+    e.children = arena.get<SdpTask>((size_t)std::max<int64_t>(emitTotals[2], 1));
+    ARENA_CHECK();
+    launch_sdp_blocks_emit(lv, prm, e, counts, offPool, offSw, offChild, st);
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
     tock(3);
-    if (hc.overflow) {
-      (void)hipEventDestroy(evA);
-      (void)hipEventDestroy(evB);
-      return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "internal: work-list overflow at level %d", level);
-    }
+    Counters hc;
+    memset(&hc, 0, sizeof(hc));
+    hc.pool = (unsigned long long)emitTotals[0];
+    hc.sw = (unsigned long long)emitTotals[1];
+    hc.child = (unsigned long long)emitTotals[2];
     if (getenv("BLASR_HIP_SDP_TRACE"))
       fprintf(stderr, "[sdp] level %d: tasks %d keys %lld frags %lld -> blocks %llu sw %llu children %llu\n", level,
               nTasks, (long long)totalKeys, (long long)nFragTotal, hc.pool, hc.sw, hc.child);
@@ -360,7 +381,8 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   if (swTotal > 0) {
     // scratch per lane: two score rows of (t+1) ints + (q+1)(t+1) arrow bytes, q*t < noRecurseUnder
     const int64_t nru = std::max(sp->recurse_over, 1);
-    const int64_t scratchPerLane = ((2 * (nru + 1) * 4 + (2 * nru + 2) + 255) / 256) * 256;
+    const int64_t parkOff = ((2 * (nru + 1) * 4 + (2 * nru + 2) + 255) / 256) * 256;
+    const int64_t scratchPerLane = parkOff + ((perFill * 16 + 255) / 256) * 256;  // + parked Diagonal runs
     const int64_t lanes = std::min<int64_t>((swTotal + 255) / 256, 512) * 256;
     uint8_t *scratch = arena.get<uint8_t>((size_t)(scratchPerLane * lanes));
     ARENA_CHECK();
@@ -371,7 +393,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     e.poolCount = &dCounters->pool;
     e.poolCap = poolCap;
     e.overflow = &dCounters->overflow;
-    for (auto &lo : outs) launch_sw(lo.sw, lo.swCount, b->seq, dMatrix, prm, scratch, scratchPerLane, e, st);
+    for (auto &lo : outs) launch_sw(lo.sw, lo.swCount, b->seq, dMatrix, prm, scratch, scratchPerLane, parkOff, e, st);
   }
   Counters hc;
   HIP_TRY(ctx, hipMemcpyAsync(&hc, dCounters, sizeof(Counters), hipMemcpyDeviceToHost, st));

@@ -84,9 +84,12 @@ void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st);
-void launch_sdp_blocks(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, hipStream_t st);
+// counts: 4 ints per task {blocks, SWAlign fills, recursive jobs, 0}
+void launch_sdp_blocks_build(const SdpLevelArrays &lv, const SdpParams &p, int32_t *counts, hipStream_t st);
+void launch_sdp_blocks_emit(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, const int32_t *counts,
+                            const int64_t *offPool, const int64_t *offSw, const int64_t *offChild, hipStream_t st);
 void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
-               uint8_t *scratch, int64_t scratchPerLane, const SdpEmit &e, hipStream_t st);
+               uint8_t *scratch, int64_t scratchPerLane, int64_t parkOff, const SdpEmit &e, hipStream_t st);
 
 // top-level results
 struct SdpResult {  // layout-identical to blasr_hip_sdp_result

@@ -766,54 +766,15 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
 // sdp_blocks: chain -> blocks (SDPAlign.h:308-335), trim (:349-357), filter (:372-413), and the
 // work lists of :423-536 (front fill for Global, fills between consecutive blocks)
 // ---------------------------------------------------------------------------
-__device__ void emit_sw(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft) {
-  const unsigned long long at = atomicAdd(e.swCount, 1ull);
-  if ((int64_t)at >= e.swCap) {
-    *e.overflow = 1;
-    return;
-  }
-  SwTask s;
-  s.qOff = t.qOff + q0;
-  s.tOff = t.tOff + t0;
-  s.qLen = (int)fq;
-  s.tLen = (int)ft;
-  s.top = t.top;
-  s.qOrg = t.qOrg + (int)q0;
-  s.tOrg = t.tOrg + (int)t0;
-  s.pad = 0;
-  e.sw[at] = s;
-}
-__device__ void emit_child(const SdpEmit &e, const SdpTask &t, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft,
-                           int prefix, int maxPerPos) {
-  const unsigned long long at = atomicAdd(e.childCount, 1ull);
-  if ((int64_t)at >= e.childCap) {
-    *e.overflow = 1;
-    return;
-  }
-  SdpTask c;
-  c.qOff = t.qOff + q0;
-  c.tOff = t.tOff + t0;
-  c.qLen = (int)fq;
-  c.tLen = (int)ft;
-  c.k = t.k - 4 > 5 ? t.k - 4 : 5;
-  c.type = 1;  // Global
-  c.prefix = prefix;
-  c.recurse = t.recurse - 1;
-  c.maxPerPos = maxPerPos;
-  c.top = t.top;
-  c.qOrg = t.qOrg + (int)q0;
-  c.tOrg = t.tOrg + (int)t0;
-  e.children[at] = c;
-}
-
 // One wavefront per task.  Only the chain back-trace is serial (a linked list); run merging, trimming,
 // filtering, compaction and the emission of blocks / gap-fill jobs are lane-parallel with wave prefix
 // sums, and every 64-block chunk reserves its output slots with ONE atomic per work list.
-__global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpParams prm, SdpEmit e) {
+__global__ __launch_bounds__(256) void sdp_blocks_build_kernel(SdpLevelArrays lv, SdpParams prm, int32_t *counts) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const int F = lv.nFrag[idx];
+  if (lane == 0) counts[4 * idx] = counts[4 * idx + 1] = counts[4 * idx + 2] = counts[4 * idx + 3] = 0;
   if (F == 0) return;
   const SdpTask t = lv.tasks[idx];
   const int64_t base = lv.fragOff[idx];
@@ -824,11 +785,20 @@ __global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpP
   uint32_t *fb = reinterpret_cast<uint32_t *>(lv.cost + base);           // final blocks reuse cost/chainLen/predCl
   uint32_t *fbT = reinterpret_cast<uint32_t *>(lv.chainLen + base);
   uint32_t *fbL = reinterpret_cast<uint32_t *>(lv.predCl + base);
-  // ---- back-trace (serial) ----
+  // ---- back-trace: a linked list, but chainPrev[i] < i and usually close to i, so the wavefront loads a
+  // window of 64 links ending at the current fragment and hops inside it with v_readlane; a new HBM
+  // round trip is needed only when a hop leaves the window ----
   int nChain = 0;
-  if (lane == 0)
-    for (int f = lv.chainEnd[idx]; f != -1 && nChain < F; f = chainPrev[f]) chainRev[nChain++] = f;
-  nChain = __builtin_amdgcn_readfirstlane(nChain);
+  for (int cur = lv.chainEnd[idx]; cur != -1 && nChain < F;) {
+    const int wBase = cur > 63 ? cur - 63 : 0;
+    const int link = (wBase + lane <= cur) ? chainPrev[wBase + lane] : -1;
+    while (cur >= wBase && nChain < F) {
+      if (lane == 0) chainRev[nChain] = cur;
+      nChain++;
+      cur = __builtin_amdgcn_readlane(link, cur - wBase);
+      if (cur < 0) break;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (nChain == 0) return;
   // ---- runs of +1/+1 fragments become candidate blocks (:308-335) ----
@@ -899,14 +869,90 @@ __global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpP
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (nfb == 0) return;
+  // ---- count what this task will emit: blocks, SWAlign fills, recursive SDPAlign jobs (:423-536) ----
   const uint32_t nru = (uint32_t)prm.noRecurseUnder;
-  // ---- :423-474 front fill (Global only; extendFrontByLocalAlignment is false on this path) ----
-  if (lane == 0 && t.type == 1 && fb[0] > 0 && fbT[0] > 0) {
+  int nSw = 0, nChild = 0;
+  if (t.type == 1 && fb[0] > 0 && fbT[0] > 0) {  // front fill (Global only; extendFront is false on this path)
     const uint32_t fq = fb[0], ft = fbT[0];
-    if (t.recurse == 0 && fq * ft < nru) emit_sw(e, t, 0, 0, fq, ft);
-    else if (t.recurse != 0) emit_child(e, t, 0, 0, fq, ft, t.prefix, 6 /* EndAnchored lands in this slot, :456 */);
+    if (t.recurse == 0 && fq * ft < nru) nSw++;
+    else if (t.recurse != 0) nChild++;
   }
-  // ---- blocks and the fills between consecutive blocks (:481-536) ----
+  for (int b0 = 0; b0 + 1 < nfb; b0 += 64) {
+    const int b = b0 + lane;
+    int kind = 0;
+    if (b + 1 < nfb) {
+      const uint32_t q0 = fb[b] + fbL[b], t0 = fbT[b] + fbL[b];
+      const uint32_t fq = fb[b + 1] - q0, ft = fbT[b + 1] - t0;
+      if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
+    }
+    nSw += __popcll(__ballot(kind == 1));
+    nChild += __popcll(__ballot(kind == 2));
+  }
+  if (lane == 0) {
+    counts[4 * idx] = nfb;
+    counts[4 * idx + 1] = nSw;
+    counts[4 * idx + 2] = nChild;
+  }
+}
+
+// Second half: every task knows where its blocks / fills / recursive jobs go (exclusive scans of the
+// counts), so nothing contends on a global counter.
+__global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv, SdpParams prm, SdpEmit e,
+                                                              const int32_t *counts, const int64_t *offPool,
+                                                              const int64_t *offSw, const int64_t *offChild) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int nfb = counts[4 * idx];
+  if (nfb == 0) return;
+  const SdpTask t = lv.tasks[idx];
+  const int64_t base = lv.fragOff[idx];
+  const uint32_t *fb = reinterpret_cast<const uint32_t *>(lv.cost + base);
+  const uint32_t *fbT = reinterpret_cast<const uint32_t *>(lv.chainLen + base);
+  const uint32_t *fbL = reinterpret_cast<const uint32_t *>(lv.predCl + base);
+  int64_t atPool = offPool[idx], atSw = offSw[idx], atChild = offChild[idx];
+  const uint32_t nru = (uint32_t)prm.noRecurseUnder;
+  auto putSw = [&](int64_t at, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft) {
+    SwTask sw;
+    sw.qOff = t.qOff + q0;
+    sw.tOff = t.tOff + t0;
+    sw.qLen = (int)fq;
+    sw.tLen = (int)ft;
+    sw.top = t.top;
+    sw.qOrg = t.qOrg + (int)q0;
+    sw.tOrg = t.tOrg + (int)t0;
+    sw.pad = 0;
+    e.sw[at] = sw;
+  };
+  auto putChild = [&](int64_t at, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft, int prefix, int maxPerPos) {
+    SdpTask c;
+    c.qOff = t.qOff + q0;
+    c.tOff = t.tOff + t0;
+    c.qLen = (int)fq;
+    c.tLen = (int)ft;
+    c.k = t.k - 4 > 5 ? t.k - 4 : 5;
+    c.type = 1;  // Global
+    c.prefix = prefix;
+    c.recurse = t.recurse - 1;
+    c.maxPerPos = maxPerPos;
+    c.top = t.top;
+    c.qOrg = t.qOrg + (int)q0;
+    c.tOrg = t.tOrg + (int)t0;
+    e.children[at] = c;
+  };
+  // :423-474 front fill
+  if (t.type == 1 && fb[0] > 0 && fbT[0] > 0) {
+    const uint32_t fq = fb[0], ft = fbT[0];
+    if (t.recurse == 0 && fq * ft < nru) {
+      if (lane == 0) putSw(atSw, 0, 0, fq, ft);
+      atSw++;
+    } else if (t.recurse != 0) {
+      if (lane == 0) putChild(atChild, 0, 0, fq, ft, t.prefix, 6 /* EndAnchored lands in this slot, :456 */);
+      atChild++;
+    }
+  }
+  // :481-536 blocks and the fills between consecutive blocks
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int b0 = 0; b0 < nfb; b0 += 64) {
     const int b = b0 + lane;
     const bool on = b < nfb;
@@ -923,62 +969,14 @@ __global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpP
         ft = fbT[b + 1] - t0;
         if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
       }
+      e.poolKeys[atPool + b] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
+      e.poolVals[atPool + b] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
     }
-    const unsigned long long mOn = __ballot(on), mSw = __ballot(kind == 1), mCh = __ballot(kind == 2);
-    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long basePool = 0, baseSw = 0, baseCh = 0;
-    if (lane == 0) {
-      basePool = atomicAdd(e.poolCount, (unsigned long long)__popcll(mOn));
-      if (mSw) baseSw = atomicAdd(e.swCount, (unsigned long long)__popcll(mSw));
-      if (mCh) baseCh = atomicAdd(e.childCount, (unsigned long long)__popcll(mCh));
-    }
-    basePool = __shfl(basePool, 0);
-    baseSw = __shfl(baseSw, 0);
-    baseCh = __shfl(baseCh, 0);
-    if (on) {
-      const unsigned long long at = basePool + (unsigned long long)__popcll(mOn & lt);
-      if ((int64_t)at < e.poolCap) {
-        e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
-        e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
-      } else
-        *e.overflow = 1;
-    }
-    if (kind == 1) {
-      const unsigned long long at = baseSw + (unsigned long long)__popcll(mSw & lt);
-      if ((int64_t)at < e.swCap) {
-        SwTask sw;
-        sw.qOff = t.qOff + q0;
-        sw.tOff = t.tOff + t0;
-        sw.qLen = (int)fq;
-        sw.tLen = (int)ft;
-        sw.top = t.top;
-        sw.qOrg = t.qOrg + (int)q0;
-        sw.tOrg = t.tOrg + (int)t0;
-        sw.pad = 0;
-        e.sw[at] = sw;
-      } else
-        *e.overflow = 1;
-    }
-    if (kind == 2) {
-      const unsigned long long at = baseCh + (unsigned long long)__popcll(mCh & lt);
-      if ((int64_t)at < e.childCap) {
-        SdpTask c;
-        c.qOff = t.qOff + q0;
-        c.tOff = t.tOff + t0;
-        c.qLen = (int)fq;
-        c.tLen = (int)ft;
-        c.k = t.k - 4 > 5 ? t.k - 4 : 5;
-        c.type = 1;
-        c.prefix = 0;
-        c.recurse = t.recurse - 1;
-        c.maxPerPos = 0;
-        c.top = t.top;
-        c.qOrg = t.qOrg + (int)q0;
-        c.tOrg = t.tOrg + (int)t0;
-        e.children[at] = c;
-      } else
-        *e.overflow = 1;
-    }
+    const unsigned long long mSw = __ballot(kind == 1), mCh = __ballot(kind == 2);
+    if (kind == 1) putSw(atSw + __popcll(mSw & lt), q0, t0, fq, ft);
+    if (kind == 2) putChild(atChild + __popcll(mCh & lt), q0, t0, fq, ft, 0, 0);
+    atSw += __popcll(mSw);
+    atChild += __popcll(mCh);
   }
 }
 
@@ -987,15 +985,21 @@ __global__ __launch_bounds__(256) void sdp_blocks_kernel(SdpLevelArrays lv, SdpP
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n, const uint8_t *seq,
                                                  const int32_t *matrix, SdpParams prm, uint8_t *scratch,
-                                                 int64_t scratchPerLane, SdpEmit e) {
+                                                 int64_t scratchPerLane, int64_t parkOff, SdpEmit e) {
   __shared__ int m[25];
   if (threadIdx.x < 25) m[threadIdx.x] = matrix[threadIdx.x];
   __syncthreads();
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   uint8_t *mine = scratch + gid * scratchPerLane;
-  for (int64_t i = gid; i < n; i += stride) {
-    const SwTask t = tasks[i];
+  // all lanes of a wavefront iterate together (the pool reservation below is a wave operation)
+  for (int64_t i0 = gid - (gid & 63); i0 < n; i0 += stride) {
+    const int64_t i = i0 + (gid & 63);
+    const bool live = i < n;
+    SwTask t;
+    t.qOff = t.tOff = 0;
+    t.qLen = t.tLen = t.top = t.qOrg = t.tOrg = t.pad = 0;
+    if (live) t = tasks[i];
     const uint8_t *q = seq + t.qOff, *tt = seq + t.tOff;
     const int nCols = t.tLen + 1;
     int *prev = reinterpret_cast<int *>(mine);
@@ -1018,32 +1022,44 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n,
       prev = cur;
       cur = tmp;
     }
-    // traceback (q,t) -> (0,0); boundary arrows: row 0 Left, column 0 Up (:49-64)
-    int r = t.qLen, c = t.tLen, runLen = 0;
-    while (r > 0 || c > 0) {
-      const int a = r == 0 ? 2 : (c == 0 ? 1 : arrows[r * nCols + c]);
-      if (a == 0) {
-        r--;
-        c--;
-        runLen++;
-      } else {
-        if (runLen) {
-          const unsigned long long at = atomicAdd(e.poolCount, 1ull);
-          if ((int64_t)at < e.poolCap) {
-            e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + r);
-            e.poolVals[at] = ((uint64_t)(uint32_t)(t.tOrg + c) << 32) | (uint32_t)runLen;
-          } else
-            *e.overflow = 1;
-          runLen = 0;
+    // traceback (q,t) -> (0,0); boundary arrows: row 0 Left, column 0 Up (:49-64).  The Diagonal runs are
+    // parked in the lane's scratch ...
+    uint64_t *parkK = reinterpret_cast<uint64_t *>(mine + parkOff);  // <= min(q,t) runs, 16 bytes each
+    int nRuns = 0;
+    if (live) {
+      int r = t.qLen, c = t.tLen, runLen = 0;
+      while (r > 0 || c > 0) {
+        const int a = r == 0 ? 2 : (c == 0 ? 1 : arrows[r * nCols + c]);
+        if (a == 0) {
+          r--;
+          c--;
+          runLen++;
+        } else {
+          if (runLen) {
+            parkK[2 * nRuns] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + r);
+            parkK[2 * nRuns + 1] = ((uint64_t)(uint32_t)(t.tOrg + c) << 32) | (uint32_t)runLen;
+            nRuns++;
+            runLen = 0;
+          }
+          if (a == 1) r--; else c--;
         }
-        if (a == 1) r--; else c--;
+      }
+      if (runLen) {
+        parkK[2 * nRuns] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)t.qOrg;
+        parkK[2 * nRuns + 1] = ((uint64_t)(uint32_t)t.tOrg << 32) | (uint32_t)runLen;
+        nRuns++;
       }
     }
-    if (runLen) {
-      const unsigned long long at = atomicAdd(e.poolCount, 1ull);
-      if ((int64_t)at < e.poolCap) {
-        e.poolKeys[at] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)t.qOrg;
-        e.poolVals[at] = ((uint64_t)(uint32_t)t.tOrg << 32) | (uint32_t)runLen;
+    // ... and the wavefront reserves pool space for all of its lanes with ONE atomic
+    const unsigned incl = wave_prefix_sum((unsigned)nRuns);
+    unsigned long long basePool = 0;
+    if (lane_id() == 63 && incl > 0) basePool = atomicAdd(e.poolCount, (unsigned long long)incl);
+    basePool = __shfl(basePool, 63);
+    const unsigned long long at0 = basePool + incl - (unsigned)nRuns;
+    for (int j = 0; j < nRuns; j++) {
+      if ((int64_t)(at0 + j) < e.poolCap) {
+        e.poolKeys[at0 + j] = parkK[2 * j];
+        e.poolVals[at0 + j] = parkK[2 * j + 1];
       } else
         *e.overflow = 1;
     }
@@ -1200,14 +1216,21 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
 }
-void launch_sdp_blocks(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_blocks_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, e);
+void launch_sdp_blocks_build(const SdpLevelArrays &lv, const SdpParams &p, int32_t *counts, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_blocks_build_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, counts);
+}
+void launch_sdp_blocks_emit(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, const int32_t *counts,
+                            const int64_t *offPool, const int64_t *offSw, const int64_t *offChild, hipStream_t st) {
+  if (lv.n > 0)
+    hipLaunchKernelGGL(sdp_blocks_emit_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, e, counts, offPool, offSw,
+                       offChild);
 }
 void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
-               uint8_t *scratch, int64_t scratchPerLane, const SdpEmit &e, hipStream_t st) {
+               uint8_t *scratch, int64_t scratchPerLane, int64_t parkOff, const SdpEmit &e, hipStream_t st) {
   if (n <= 0) return;
   const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
-  hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, n, seq, matrix, p, scratch, scratchPerLane, e);
+  hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, n, seq, matrix, p, scratch, scratchPerLane,
+                     parkOff, e);
 }
 void launch_pool_histogram(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop, hipStream_t st) {
   if (n <= 0) return;
