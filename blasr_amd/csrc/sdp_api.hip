@@ -224,6 +224,19 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.chainEnd = arena.get<int32_t>(nTasks);
     int64_t *fragOff = arena.get<int64_t>(nTasks + 1);
     ARENA_CHECK();
+    {  // per-query-position search results, written by the count pass and reused by the write pass
+      int64_t *qPosOff = arena.get<int64_t>(nTasks + 1);
+      ARENA_CHECK();
+      launch_sdp_gather_sizes(lv, 3, sizes, st);
+      HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, qPosOff, (int64_t)0, (size_t)nTasks + 1,
+                                           rocprim::plus<int64_t>(), st));
+      int64_t totalQ = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&totalQ, qPosOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      lv.qPosOff = qPosOff;
+      lv.hits = arena.get<uint64_t>((size_t)std::max<int64_t>(totalQ, 1));
+      ARENA_CHECK();
+    }
     launch_sdp_match(lv, b->seq, false, st);
     launch_sdp_gather_sizes(lv, 1, sizes, st);
     HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, fragOff, (int64_t)0, (size_t)nTasks + 1,

@@ -49,6 +49,8 @@ struct SdpLevelArrays {
   const SdpTask *tasks;
   const int64_t *keyOff;   // n+1, exclusive scan of tLen
   uint64_t *keys;          // target k-mer keys, sorted per task
+  const int64_t *qPosOff;  // n+1, exclusive scan of qLen
+  uint64_t *hits;          // per query position: index of the first matching key | match count << 32
   int32_t *nRaw;           // 3n: prefix / middle / suffix fragment counts
   const int64_t *fragOff;  // n+1, exclusive scan of the raw fragment counts
   Frag *raw;               // prefix | middle | suffix fragments as StoreMatchingPositions emits them

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   // wavefront builds in LDS from the sorted keys (one pass), instead of ~2 x log2(tLen) dependent HBM reads.
   const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
   const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
-  const bool useBuckets = t.tLen >= 256;
+  const bool useBuckets = !kWrite && t.tLen >= 256;
   uint32_t *bucket = bucketStart[threadIdx.x >> 6];
   if (useBuckets) {
     const int nB = 1 << bBits;
@@ -270,28 +270,36 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
     __builtin_amdgcn_wave_barrier();
   }
   int nM = 0;
+  uint64_t *hits = lv.hits + lv.qPosOff[idx];  // per query position: first matching key | count << 32
   for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
     const int x = x0 + lane;
     int lo = 0, cnt = 0;
     if (x + k <= t.qLen) {
-      uint64_t kmer = 0;
-      bool ok = true;
-      for (int j = 0; j < k; j++) {
-        const int c = base_code(qSeq[x + j]);
-        ok = ok && c < 4;
-        kmer |= (uint64_t)(c & 3) << (2 * j);
-      }
-      if (ok) {
-        int rLo = 0, rHi = t.tLen;
-        if (useBuckets) {
-          const int b = (int)(kmer >> (2 * k - bBits));
-          rLo = (int)bucket[b];
-          rHi = (int)bucket[b + 1];
+      if (kWrite) {  // the count pass already searched
+        const uint64_t h = hits[x];
+        lo = (int)(uint32_t)h;
+        cnt = (int)(h >> 32);
+      } else {
+        uint64_t kmer = 0;
+        bool ok = true;
+        for (int j = 0; j < k; j++) {
+          const int c = base_code(qSeq[x + j]);
+          ok = ok && c < 4;
+          kmer |= (uint64_t)(c & 3) << (2 * j);
         }
-        lo = rLo + lower_bound_u64(keys + rLo, rHi - rLo, kmer << kPosBits);
-        const int hi = lo + lower_bound_u64(keys + lo, rHi - lo, (kmer + 1) << kPosBits);
-        cnt = hi - lo;
-        if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+        if (ok) {
+          int rLo = 0, rHi = t.tLen;
+          if (useBuckets) {
+            const int b = (int)(kmer >> (2 * k - bBits));
+            rLo = (int)bucket[b];
+            rHi = (int)bucket[b + 1];
+          }
+          lo = rLo + lower_bound_u64(keys + rLo, rHi - rLo, kmer << kPosBits);
+          const int hi = lo + lower_bound_u64(keys + lo, rHi - lo, (kmer + 1) << kPosBits);
+          cnt = hi - lo;
+          if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+        }
+        hits[x] = (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)cnt << 32);
       }
     }
     const unsigned incl = wave_prefix_sum((unsigned)cnt);
@@ -1080,6 +1088,7 @@ __global__ __launch_bounds__(256) void sdp_gather_sizes_kernel(SdpLevelArrays lv
   if (i >= lv.n) return;
   int64_t v;
   if (what == 0) v = lv.tasks[i].tLen;
+  else if (what == 3) v = lv.tasks[i].qLen;
   else if (what == 1) v = (int64_t)lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
   else v = lv.nFrag[i];
   out[i] = v;
