@@ -264,8 +264,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.chainLen = arena.get<int32_t>(nf);
     lv.predCl = arena.get<int32_t>(nf);
     lv.above = arena.get<int32_t>(nf);
-    lv.colCol = arena.get<int32_t>(nf + 64);
-    lv.colOpt = arena.get<int32_t>(nf + 64);
+    lv.colSet = arena.get<int4>(nf + 64);
     lv.scratchA = arena.get<int32_t>(nf);
     lv.scratchB = arena.get<int32_t>(3 * nf);
     ARENA_CHECK();

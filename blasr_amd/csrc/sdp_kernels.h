@@ -59,7 +59,7 @@ struct SdpLevelArrays {
   uint64_t *yxKeys;        // (y << 32 | x) for StoreAbove
   uint32_t *yxIdx;
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
-  int32_t *colCol, *colOpt;                               // column set storage, per fragment slot
+  int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain
   int32_t *scratchA;                                      // per fragment: chain indices
   int32_t *scratchB;                                      // 3 per fragment: candidate blocks

@@ -584,17 +584,23 @@ __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv
 // ---------------------------------------------------------------------------
 // sdp_chain: SDPLongestCommonSubsequence (SparseDynamicProgramming.h:70-322)
 // ---------------------------------------------------------------------------
-struct ColSet {  // SDPSet<SDPColumn>: sorted by column; wave-cooperative operations, uniform results
-  int *col, *opt;
-  int n;
+// The column set (SDPSet<SDPColumn>, sorted by column).  An entry carries what a later query needs
+// from its fragment: {column, fragment index, fragment cost, x + y}.  The spilled part of the set lives in
+// global memory; the wavefront keeps the LAST <= 64 entries in registers (lane j = entry nBase + j),
+// because fragments retire in (x,y) order and the alignment is near-diagonal: almost every insert,
+// replace, erase and predecessor query lands in that tail and needs no memory round trip.
+struct ColSet {
+  int4 *g;        // global storage, entries [0, nBase) are valid there
+  int n, nBase;   // total entries; first entry held in registers
+  int4 tail;      // per-lane register copy of entry nBase + lane (valid while nBase + lane < n)
 };
-__device__ int cs_lower_bound(const ColSet &s, int key) {
+__device__ int cs_global_lower_bound(const int4 *g, int n, int key) {  // wave-cooperative 64-ary search
   const int lane = lane_id();
-  int lo = 0, hi = s.n;
+  int lo = 0, hi = n;
   while (hi - lo > 64) {
     const int stride = (hi - lo + 63) / 64;
     const int p = lo + lane * stride;
-    const int v = p < hi ? s.col[p] : INT32_MAX;
+    const int v = p < hi ? g[p].x : INT32_MAX;
     const int c = __popcll(__ballot(p < hi && v < key));
     const int nlo = c > 0 ? lo + (c - 1) * stride + 1 : lo;
     const int nhi = min(hi, lo + c * stride);
@@ -602,51 +608,100 @@ __device__ int cs_lower_bound(const ColSet &s, int key) {
     hi = nhi;
   }
   const int p = lo + lane;
-  const int v = p < hi ? s.col[p] : INT32_MAX;
+  const int v = p < hi ? g[p].x : INT32_MAX;
   return lo + __popcll(__ballot(p < hi && v < key));
 }
-__device__ void cs_insert_at(ColSet &s, int pos, int col, int opt) {
+__device__ __forceinline__ int4 lane_bcast(const int4 &v, int srcLane) {
+  return make_int4(__builtin_amdgcn_readlane(v.x, srcLane), __builtin_amdgcn_readlane(v.y, srcLane),
+                   __builtin_amdgcn_readlane(v.z, srcLane), __builtin_amdgcn_readlane(v.w, srcLane));
+}
+__device__ __forceinline__ int4 lane_shift_from(const int4 &v, int delta) {  // lane i <- lane i + delta
+  const int src = (lane_id() + delta) * 4;
+  return make_int4(__builtin_amdgcn_ds_bpermute(src, v.x), __builtin_amdgcn_ds_bpermute(src, v.y),
+                   __builtin_amdgcn_ds_bpermute(src, v.z), __builtin_amdgcn_ds_bpermute(src, v.w));
+}
+__device__ void cs_flush(ColSet &s) {  // registers -> global
   const int lane = lane_id();
-  if (s.n > pos) {
-    for (int base = pos + ((s.n - 1 - pos) / 64) * 64; base >= pos; base -= 64) {
-      const int i = base + lane;
-      int c = 0, o = 0;
-      if (i < s.n) {
-        c = s.col[i];
-        o = s.opt[i];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (i < s.n) {
-        s.col[i + 1] = c;
-        s.opt[i + 1] = o;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-  }
-  if (lane == 0) {
-    s.col[pos] = col;
-    s.opt[pos] = opt;
-  }
-  s.n++;
+  if (s.nBase + lane < s.n) s.g[s.nBase + lane] = s.tail;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ void cs_reload(ColSet &s) {  // global -> registers: the last <= 64 entries
+  const int lane = lane_id();
+  s.nBase = s.n > 64 ? s.n - 64 : 0;
+  if (s.nBase + lane < s.n) s.tail = s.g[s.nBase + lane];
+}
+__device__ int cs_lower_bound(const ColSet &s, int key) {
+  if (s.n == 0) return 0;
+  const int lane = lane_id();
+  if (s.nBase == 0 || key > __builtin_amdgcn_readlane(s.tail.x, 0))
+    return s.nBase + __popcll(__ballot(s.nBase + lane < s.n && s.tail.x < key));
+  return cs_global_lower_bound(s.g, s.nBase, key);
+}
+__device__ int4 cs_get(const ColSet &s, int pos) {
+  if (pos >= s.nBase) return lane_bcast(s.tail, pos - s.nBase);
+  return s.g[pos];
+}
+__device__ void cs_set(ColSet &s, int pos, int4 e) {
+  const int lane = lane_id();
+  if (pos >= s.nBase) {
+    if (lane == pos - s.nBase) s.tail = e;
+  } else {
+    if (lane == 0) s.g[pos] = e;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+__device__ void cs_insert_at(ColSet &s, int pos, int4 e) {
+  const int lane = lane_id();
+  if (pos >= s.nBase && s.n - s.nBase == 64) {
+    // tail full: move its lower half to global memory
+    if (lane < 32) s.g[s.nBase + lane] = s.tail;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    s.tail = lane_shift_from(s.tail, 32);
+    s.nBase += 32;
+  }
+  if (pos >= s.nBase) {
+    const int p = pos - s.nBase;
+    const int4 up = make_int4(wave_shr1(s.tail.x, 0), wave_shr1(s.tail.y, 0), wave_shr1(s.tail.z, 0),
+                              wave_shr1(s.tail.w, 0));
+    if (lane > p) s.tail = up;
+    if (lane == p) s.tail = e;
+    s.n++;
+    return;
+  }
+  // rare: the insertion point is in the spilled part -> shift [pos, nBase) up by one in global memory
+  for (int base = pos + ((s.nBase - 1 - pos) / 64) * 64; base >= pos; base -= 64) {
+    const int i = base + lane;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < s.nBase) v = s.g[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i < s.nBase) s.g[i + 1] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (lane == 0) s.g[pos] = e;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  s.nBase++;
+  s.n++;
 }
 __device__ void cs_erase_range(ColSet &s, int first, int count) {  // removes [first, first+count)
   const int lane = lane_id();
+  if (first >= s.nBase) {
+    const int4 down = lane_shift_from(s.tail, count);
+    if (lane >= first - s.nBase) s.tail = down;
+    s.n -= count;
+    return;
+  }
+  // rare: the run starts in the spilled part
+  cs_flush(s);
   for (int base = first + count; base < s.n; base += 64) {
     const int i = base + lane;
-    int c = 0, o = 0;
-    if (i < s.n) {
-      c = s.col[i];
-      o = s.opt[i];
-    }
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < s.n) v = s.g[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (i < s.n) {
-      s.col[i - count] = c;
-      s.opt[i - count] = o;
-    }
+    if (i < s.n) s.g[i - count] = v;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   s.n -= count;
+  cs_reload(s);
 }
 
 // IndelPenalty (SparseDynamicProgramming.h:27-53)
@@ -656,6 +711,22 @@ __device__ __forceinline__ int indel_penalty(int x1, int y1, int x2, int y2, int
   if (drift < 0) return (int)((-1.0 * drift) * deletion);
   return 0;
 }
+// (int)sqrt((double)d) for 0 <= d < 2^31, without the double-precision pipeline
+__device__ __forceinline__ int isqrt_floor(int d) {
+  int s = (int)sqrtf((float)d);
+  while ((long long)s * s > d) s--;
+  while ((long long)(s + 1) * (s + 1) <= d) s++;
+  return s;
+}
+
+// A window of 64 consecutive fragments held one per lane, so that the serial sweep reads the fragment it
+// is scoring, and the recently scored ones it refers to, with v_readlane instead of memory loads.
+struct FragWindow {
+  int x, y, cost, len;  // cost / chain length are filled in as the sweep advances
+};
+struct FragView {
+  int x, y, cost, len;
+};
 
 __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int idx = wave_task_index();
@@ -672,100 +743,152 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
   int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
   const int *predCl = lv.predCl + base, *above = lv.above + base;
   ColSet cols;
-  cols.col = lv.colCol + base;
-  cols.opt = lv.colOpt + base;
-  cols.n = 0;
+  cols.g = lv.colSet + base;
+  cols.n = cols.nBase = 0;
+  cols.tail = make_int4(0, 0, 0, 0);
   const int k = t.k;
   const uint32_t fragmentLength = (uint32_t)k;
   const uint32_t weight = (uint32_t)k;
   int fTrail = 0;
   int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
   uint32_t maxLen = 0;
-  for (int i = 0; i < F; i++) {
-    const Frag f = fr[i];
-    // rows leaving the window: fragments with x <= f.x - k - 2 have been retired before row f.x is scored (:248-309)
-    while (fTrail < i) {
-      const Frag ft = fr[fTrail];
-      if ((int64_t)ft.x + k + 2 > (int64_t)f.x) break;
-      const int costT = cost[fTrail];
-      int pos = cs_lower_bound(cols, (int)ft.y);
-      const bool member = pos < cols.n && cols.col[pos] == (int)ft.y;
-      bool store = true;
-      if (member) store = cost[cols.opt[pos]] < costT;  // sic (:260-267)
-      if (store) {
-        if (member) {
-          if (lane == 0) cols.opt[pos] = fTrail;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        } else {
-          cs_insert_at(cols, pos, (int)ft.y, fTrail);
-        }
-        // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
-        int del = 0;
-        while (cols.n - del >= 2 && pos + 1 + del < cols.n && cost[cols.opt[pos + 1 + del]] > costT) del++;
-        if (del) cs_erase_range(cols, pos + 1, del);
-      }
-      fTrail++;
+  FragWindow cur, prev;
+  cur.x = cur.y = cur.cost = cur.len = 0;
+  prev = cur;
+  for (int w0 = 0; w0 < F; w0 += 64) {
+    prev = cur;
+    int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
+    if (w0 + lane < F) {
+      const Frag f = fr[w0 + lane];
+      fxV = (int)f.x;
+      fyV = (int)f.y;
+      flV = (int)f.len;
+      fpV = predCl[w0 + lane];
+      faV = above[w0 + lane];
     }
-    int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
-    bool foundPrev = false;
-    if (cols.n > 0) {
-      int pos = cs_lower_bound(cols, (int)f.y);
-      bool have = false;
-      if (pos < cols.n && cols.col[pos] == (int)f.y) have = true;
-      else if (pos > 0) {
-        pos--;
-        have = true;
+    cur.x = fxV;
+    cur.y = fyV;
+    // fragment p as seen by the sweep: from the two register windows, else from memory
+    auto view = [&](int p) {
+      FragView v;
+      if (p >= w0) {
+        v.x = __builtin_amdgcn_readlane(cur.x, p - w0);
+        v.y = __builtin_amdgcn_readlane(cur.y, p - w0);
+        v.cost = __builtin_amdgcn_readlane(cur.cost, p - w0);
+        v.len = __builtin_amdgcn_readlane(cur.len, p - w0);
+      } else if (p >= w0 - 64) {
+        v.x = __builtin_amdgcn_readlane(prev.x, p - w0 + 64);
+        v.y = __builtin_amdgcn_readlane(prev.y, p - w0 + 64);
+        v.cost = __builtin_amdgcn_readlane(prev.cost, p - w0 + 64);
+        v.len = __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
+      } else {
+        const Frag f = fr[p];
+        v.x = (int)f.x;
+        v.y = (int)f.y;
+        v.cost = cost[p];
+        v.len = chainLen[p];
       }
-      if (have) {
-        cpFrag = cols.opt[pos];
-        const Frag p = fr[cpFrag];
-        cp = cost[cpFrag] + (int)sqrt((double)abs((int)(f.x + f.y) - (int)(p.x + p.y))) - (int)f.len;
+      return v;
+    };
+    const int nHere = min(64, F - w0);
+    for (int j = 0; j < nHere; j++) {
+      const int i = w0 + j;
+      const int fx = __builtin_amdgcn_readlane(fxV, j), fy = __builtin_amdgcn_readlane(fyV, j);
+      const int fl = __builtin_amdgcn_readlane(flV, j);
+      // rows leaving the window: fragments with x <= f.x - k - 2 are retired before row f.x is scored (:248-309)
+      while (fTrail < i) {
+        const FragView ft = view(fTrail);
+        if ((int64_t)ft.x + k + 2 > (int64_t)fx) break;
+        const int pos = cs_lower_bound(cols, ft.y);
+        int4 at = make_int4(0, 0, 0, 0);
+        bool member = false;
+        if (pos < cols.n) {
+          at = cs_get(cols, pos);
+          member = at.x == ft.y;
+        }
+        bool store = true;
+        if (member) store = at.z < ft.cost;  // sic (:260-267): replaced only when the existing entry is CHEAPER
+        if (store) {
+          const int4 e = make_int4(ft.y, fTrail, ft.cost, ft.x + ft.y);
+          if (member) cs_set(cols, pos, e);
+          else cs_insert_at(cols, pos, e);
+          // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
+          int del = 0;
+          while (cols.n - del >= 2 && pos + 1 + del < cols.n && cs_get(cols, pos + 1 + del).z > ft.cost) del++;
+          if (del) cs_erase_range(cols, pos + 1, del);
+        }
+        fTrail++;
+      }
+      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
+      bool foundPrev = false;
+      if (cols.n > 0) {
+        int pos = cs_lower_bound(cols, fy);
+        bool have = false;
+        int4 at = make_int4(0, 0, 0, 0);
+        if (pos < cols.n) {
+          at = cs_get(cols, pos);
+          have = at.x == fy;
+        }
+        if (!have && pos > 0) {
+          at = cs_get(cols, pos - 1);
+          have = true;
+        }
+        if (have) {
+          cpFrag = at.y;
+          cp = at.z + isqrt_floor(abs((fx + fy) - at.w)) - fl;
+          foundPrev = true;
+        }
+      }
+      const int clFrag = __builtin_amdgcn_readlane(fpV, j);
+      if (clFrag >= 0) {
+        const FragView p = view(clFrag);
+        int ov = (int)(fragmentLength - (uint32_t)(fy - p.y)) * prm.match;
+        if (ov > 0) ov = 0;
+        cl = p.cost + ov + indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel);
         foundPrev = true;
       }
+      const int aboveIdx = __builtin_amdgcn_readlane(faV, j);
+      if (aboveIdx >= 0) {
+        const FragView p = view(aboveIdx);
+        ca = (int)((uint32_t)p.cost + (fragmentLength - (uint32_t)(fy - p.y)) * (uint32_t)prm.match +
+                   (uint32_t)indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel));
+        foundPrev = true;
+      }
+      int mc = cl < ca ? cl : ca;
+      if (cp < mc) mc = cp;
+      int myCost, myPrev;
+      uint32_t myLen;
+      if (foundPrev && (t.type == 1 || (t.type == 0 && mc < 0))) {
+        myCost = (int)((uint32_t)mc - weight);
+        if (mc == cp) myPrev = cpFrag;
+        else if (mc == cl) myPrev = clFrag;
+        else myPrev = aboveIdx;
+        myLen = (uint32_t)view(myPrev).len + 1u;
+      } else {
+        myPrev = -1;
+        myLen = 1;
+        if (t.type == 1)
+          myCost = (int)((uint32_t)(fx + fy) * (uint32_t)prm.sdpDel + fragmentLength * (uint32_t)prm.match - weight);
+        else myCost = (int)(fragmentLength * (uint32_t)prm.match - weight);
+      }
+      if (lane == j) {
+        cur.cost = myCost;
+        cur.len = (int)myLen;
+        // memory copies: chainPrev for the back-trace, cost / chainLen for the rare far look-ups
+        cost[i] = myCost;
+        chainPrev[i] = myPrev;
+        chainLen[i] = (int)myLen;
+      }
+      if (minCost > myCost) {
+        minCost = myCost;
+        minIdx = i;
+      }
+      if (myLen > maxLen) {
+        maxLen = myLen;
+        maxLenIdx = i;
+      }
     }
-    const int clFrag = predCl[i];
-    if (clFrag >= 0) {
-      const Frag p = fr[clFrag];
-      int ov = (int)(fragmentLength - (f.y - p.y)) * prm.match;
-      if (ov > 0) ov = 0;
-      cl = cost[clFrag] + ov + indel_penalty((int)f.x, (int)f.y, (int)p.x, (int)p.y, prm.sdpIns, prm.sdpDel);
-      foundPrev = true;
-    }
-    const int aboveIdx = above[i];
-    if (aboveIdx >= 0) {
-      const Frag p = fr[aboveIdx];
-      ca = (int)((uint32_t)cost[aboveIdx] + (fragmentLength - (uint32_t)(int)(f.y - p.y)) * (uint32_t)prm.match +
-                 (uint32_t)indel_penalty((int)f.x, (int)f.y, (int)p.x, (int)p.y, prm.sdpIns, prm.sdpDel));
-      foundPrev = true;
-    }
-    int mc = cl < ca ? cl : ca;
-    if (cp < mc) mc = cp;
-    int myCost, myPrev;
-    uint32_t myLen;
-    if (foundPrev && (t.type == 1 || (t.type == 0 && mc < 0))) {
-      myCost = (int)((uint32_t)mc - weight);
-      if (mc == cp) myPrev = cpFrag;
-      else if (mc == cl) myPrev = clFrag;
-      else myPrev = aboveIdx;
-      myLen = (uint32_t)chainLen[myPrev] + 1u;
-    } else {
-      myPrev = -1;
-      myLen = 1;
-      if (t.type == 1) myCost = (int)((f.x + f.y) * (uint32_t)prm.sdpDel + fragmentLength * (uint32_t)prm.match - weight);
-      else myCost = (int)(fragmentLength * (uint32_t)prm.match - weight);
-    }
-    // every lane stores the same value to the same address, so each lane later reads its own store
-    cost[i] = myCost;
-    chainPrev[i] = myPrev;
-    chainLen[i] = (int)myLen;
-    if (minCost > myCost) {
-      minCost = myCost;
-      minIdx = i;
-    }
-    if (myLen > maxLen) {
-      maxLen = myLen;
-      maxLenIdx = i;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
 }
