@@ -265,6 +265,8 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.predCl = arena.get<int32_t>(nf);
     lv.above = arena.get<int32_t>(nf);
     lv.colSet = arena.get<int4>(nf + 64);
+    lv.tieList = arena.get<int32_t>(lv.n + 1);
+    lv.tieCount = lv.tieList + lv.n;
     lv.scratchA = arena.get<int32_t>(nf);
     lv.scratchB = arena.get<int32_t>(3 * nf);
     ARENA_CHECK();

@@ -59,6 +59,7 @@ struct SdpLevelArrays {
   uint64_t *yxKeys;        // (y << 32 | x) for StoreAbove
   uint32_t *yxIdx;
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
+  int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain
   int32_t *scratchA;                                      // per fragment: chain indices

@@ -344,17 +344,28 @@ __device__ int lower_bound_frag(const Frag *a, int n, uint64_t key) {
 
 // libstdc++ (GCC 11.4) std::sort schedule, replayed by one lane.  Only reached when the prefix /
 // middle / suffix lists share an (x,y): which duplicate survives depends on this exact schedule.
-__device__ void is_swap(Frag *a, Frag *b) {
-  Frag t = *a;
+// T is either a fragment in global memory or, for the usual sizes, a packed (rank << 16 | index) word
+// in LDS, where the rank orders exactly like (x,y) and equal keys have equal ranks.
+constexpr int kTieLdsSmall = 2560, kTieLdsCap = 12288;  // fragments per task replayed in LDS (two size classes)
+struct FragLess {
+  __device__ __forceinline__ bool operator()(const Frag &a, const Frag &b) const { return frag_less(a, b); }
+};
+struct RankLess {
+  __device__ __forceinline__ bool operator()(uint32_t a, uint32_t b) const { return (a >> 16) < (b >> 16); }
+};
+template <class T>
+__device__ __forceinline__ void is_swap(T *a, T *b) {
+  T t = *a;
   *a = *b;
   *b = t;
 }
-__device__ void is_adjust_heap(Frag *first, long hole, long len, Frag value) {
+template <class T, class Less>
+__device__ __forceinline__ void is_adjust_heap(T *first, long hole, long len, T value, Less less) {
   const long top = hole;
   long child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (frag_less(first[child], first[child - 1])) child--;
+    if (less(first[child], first[child - 1])) child--;
     first[hole] = first[child];
     hole = child;
   }
@@ -364,58 +375,62 @@ __device__ void is_adjust_heap(Frag *first, long hole, long len, Frag value) {
     hole = child - 1;
   }
   long parent = (hole - 1) / 2;
-  while (hole > top && frag_less(first[parent], value)) {
+  while (hole > top && less(first[parent], value)) {
     first[hole] = first[parent];
     hole = parent;
     parent = (hole - 1) / 2;
   }
   first[hole] = value;
 }
-__device__ void is_heapsort(Frag *first, Frag *last) {
+template <class T, class Less>
+__device__ __forceinline__ void is_heapsort(T *first, T *last, Less less) {
   const long len = last - first;
   if (len >= 2) {
     long parent = (len - 2) / 2;
     for (;;) {
-      Frag v = first[parent];
-      is_adjust_heap(first, parent, len, v);
+      T v = first[parent];
+      is_adjust_heap(first, parent, len, v, less);
       if (parent == 0) break;
       parent--;
     }
   }
   while (last - first > 1) {
     --last;
-    Frag v = *last;
+    T v = *last;
     *last = *first;
-    is_adjust_heap(first, 0, last - first, v);
+    is_adjust_heap(first, 0, last - first, v, less);
   }
 }
-__device__ void is_unguarded_linear_insert(Frag *last) {
-  Frag val = *last;
-  Frag *next = last - 1;
-  while (frag_less(val, *next)) {
+template <class T, class Less>
+__device__ __forceinline__ void is_unguarded_linear_insert(T *last, Less less) {
+  T val = *last;
+  T *next = last - 1;
+  while (less(val, *next)) {
     *last = *next;
     last = next;
     --next;
   }
   *last = val;
 }
-__device__ void is_insertion_sort(Frag *first, Frag *last) {
+template <class T, class Less>
+__device__ __forceinline__ void is_insertion_sort(T *first, T *last, Less less) {
   if (first == last) return;
-  for (Frag *i = first + 1; i != last; ++i) {
-    if (frag_less(*i, *first)) {
-      Frag val = *i;
-      for (Frag *p = i; p != first; --p) *p = *(p - 1);
+  for (T *i = first + 1; i != last; ++i) {
+    if (less(*i, *first)) {
+      T val = *i;
+      for (T *p = i; p != first; --p) *p = *(p - 1);
       *first = val;
     } else
-      is_unguarded_linear_insert(i);
+      is_unguarded_linear_insert(i, less);
   }
 }
-__device__ void introsort_frags(Frag *first, long n) {
+template <class T, class Less>
+__device__ __forceinline__ void introsort_replay(T *first, long n, Less less) {
   if (n <= 0) return;
   long lg = 0;
   for (long m = n; m > 1; m >>= 1) lg++;
   // explicit stack for the recursion on the right partition
-  Frag *stFirst[64], *stLast[64];
+  T *stFirst[64], *stLast[64];
   long stDepth[64];
   int sp = 0;
   stFirst[0] = first;
@@ -424,32 +439,32 @@ __device__ void introsort_frags(Frag *first, long n) {
   sp = 1;
   while (sp > 0) {
     --sp;
-    Frag *f = stFirst[sp], *l = stLast[sp];
+    T *f = stFirst[sp], *l = stLast[sp];
     long depth = stDepth[sp];
     // __introsort_loop(f, l, depth): right parts are pushed and processed first, as the recursion does
     // (the order of processing disjoint ranges does not change the result)
     while (l - f > 16) {
       if (depth == 0) {
-        is_heapsort(f, l);
+        is_heapsort(f, l, less);
         break;
       }
       --depth;
-      Frag *mid = f + (l - f) / 2;
+      T *mid = f + (l - f) / 2;
       // __move_median_to_first(f, f+1, mid, l-1)
-      Frag *a = f + 1, *b = mid, *c = l - 1;
-      if (frag_less(*a, *b)) {
-        if (frag_less(*b, *c)) is_swap(f, b);
-        else if (frag_less(*a, *c)) is_swap(f, c);
+      T *a = f + 1, *b = mid, *c = l - 1;
+      if (less(*a, *b)) {
+        if (less(*b, *c)) is_swap(f, b);
+        else if (less(*a, *c)) is_swap(f, c);
         else is_swap(f, a);
-      } else if (frag_less(*a, *c)) is_swap(f, a);
-      else if (frag_less(*b, *c)) is_swap(f, c);
+      } else if (less(*a, *c)) is_swap(f, a);
+      else if (less(*b, *c)) is_swap(f, c);
       else is_swap(f, b);
       // __unguarded_partition(f+1, l, f)
-      Frag *lo = f + 1, *hi = l;
+      T *lo = f + 1, *hi = l;
       for (;;) {
-        while (frag_less(*lo, *f)) ++lo;
+        while (less(*lo, *f)) ++lo;
         --hi;
-        while (frag_less(*f, *hi)) --hi;
+        while (less(*f, *hi)) --hi;
         if (!(lo < hi)) break;
         is_swap(lo, hi);
         ++lo;
@@ -462,10 +477,10 @@ __device__ void introsort_frags(Frag *first, long n) {
     }
   }
   if (n > 16) {
-    is_insertion_sort(first, first + 16);
-    for (Frag *i = first + 16; i != first + n; ++i) is_unguarded_linear_insert(i);
+    is_insertion_sort(first, first + 16, less);
+    for (T *i = first + 16; i != first + n; ++i) is_unguarded_linear_insert(i, less);
   } else
-    is_insertion_sort(first, first + n);
+    is_insertion_sort(first, first + n, less);
 }
 
 __global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
@@ -506,18 +521,144 @@ __global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
       out[i + lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key)] = S[i];
     }
     if (lane == 0) lv.nFrag[idx] = nAll;
-  } else {
-    for (int i = lane; i < nAll; i += 64) out[i] = P[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) {
-      introsort_frags(out, nAll);
-      int f = 0, cur = 0;
-      while (f + 1 <= nAll) {
-        out[cur] = out[f];
-        while (f < nAll && out[cur].x == out[f].x && out[cur].y == out[f].y) f++;
-        cur++;
+  } else if (lane == 0) {
+    lv.tieList[atomicAdd(lv.tieCount, 1)] = idx;  // rare: resolved by sdp_order_ties_kernel
+  }
+}
+
+// The tasks whose lists share an (x,y): replay std::sort's schedule to learn which duplicate comes first.
+// One wavefront per workgroup, the fragments as packed (rank << 16 | index) words in LDS.  The replay is
+// parallel over the recursion tree: std::__introsort_loop's two sub-ranges after a partition are disjoint
+// and never touched from outside again, so every lane replays one range per round; a range of <= 16
+// elements is final for the loop and receives its share of __final_insertion_sort at once (elements
+// left of a cut are <= those right of it, so the linear inserts never cross a cut).
+__device__ __forceinline__ bool rank_less(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+__device__ __forceinline__ void lds_insertion_sort(uint32_t *v, int f, int l) {
+  for (int i = f + 1; i < l; i++) {
+    const uint32_t val = v[i];
+    int j = i;
+    while (j > f && rank_less(val, v[j - 1])) {
+      v[j] = v[j - 1];
+      j--;
+    }
+    v[j] = val;
+  }
+}
+__device__ __forceinline__ int lds_partition(uint32_t *v, int f, int l) {  // returns the cut
+  const int mid = f + (l - f) / 2;
+  // __move_median_to_first(f, f+1, mid, l-1)
+  const uint32_t a = v[f + 1], b = v[mid], c = v[l - 1];
+  int m;
+  if (rank_less(a, b)) m = rank_less(b, c) ? mid : (rank_less(a, c) ? l - 1 : f + 1);
+  else m = rank_less(a, c) ? f + 1 : (rank_less(b, c) ? l - 1 : mid);
+  const uint32_t pivot = v[m];
+  v[m] = v[f];
+  v[f] = pivot;
+  // __unguarded_partition(f+1, l, f)
+  int lo = f + 1, hi = l;
+  for (;;) {
+    uint32_t x = v[lo];
+    while (rank_less(x, pivot)) x = v[++lo];
+    uint32_t y = v[--hi];
+    while (rank_less(pivot, y)) y = v[--hi];
+    if (!(lo < hi)) return lo;
+    v[lo] = y;
+    v[hi] = x;
+    ++lo;
+  }
+}
+template <int kCap>
+__global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, int minAll) {
+  constexpr int kQueue = kCap / 16;
+  __shared__ uint32_t packed[kCap];
+  __shared__ uint2 queue[2][kQueue];  // {f | l << 16, depth limit}
+  const int lane = lane_id();
+  const int nTies = *lv.tieCount;
+  for (int e = blockIdx.x; e < nTies; e += gridDim.x) {
+    const int idx = lv.tieList[e];
+    const int nP = lv.nRaw[3 * idx], nM = lv.nRaw[3 * idx + 1], nS = lv.nRaw[3 * idx + 2];
+    const int nAll = nP + nM + nS;
+    if (nAll < minAll || (nAll > kCap && kCap < kTieLdsCap)) continue;  // another size class takes it
+    const Frag *P = lv.raw + lv.fragOff[idx], *M = P + nP, *S = M + nM;
+    Frag *out = lv.frags + lv.fragOff[idx];
+    if (nAll <= kCap) {
+      // rank = number of fragments with a smaller (x,y): equal keys get equal ranks
+      for (int i = lane; i < nAll; i += 64) {
+        const uint64_t key = frag_key(P[i]);
+        const int rank = lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key) + lower_bound_frag(S, nS, key);
+        packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
       }
-      lv.nFrag[idx] = cur;
+      __syncthreads();
+      int lg = 0;
+      for (int m = nAll; m > 1; m >>= 1) lg++;
+      int nCur = 0, which = 0;
+      if (nAll > 16) {
+        if (lane == 0) queue[0][0] = make_uint2((uint32_t)nAll << 16, (uint32_t)(2 * lg));
+        nCur = 1;
+      } else if (lane == 0)
+        lds_insertion_sort(packed, 0, nAll);
+      __syncthreads();
+      while (nCur > 0) {
+        int nNext = 0;
+        for (int base = 0; base < nCur; base += 64) {
+          const bool has = base + lane < nCur;
+          int cf[2] = {0, 0}, cl[2] = {0, 0};
+          uint32_t depth = 0;
+          if (has) {
+            const uint2 r = queue[which][base + lane];
+            const int f = (int)(r.x & 0xffffu), l = (int)(r.x >> 16);
+            if (r.y == 0) {
+              is_heapsort(packed + f, packed + l, RankLess());
+            } else {
+              depth = r.y - 1;
+              const int cut = lds_partition(packed, f, l);
+              cf[0] = f, cl[0] = cut, cf[1] = cut, cl[1] = l;
+            }
+          }
+          for (int c = 0; c < 2; c++) {
+            const int size = cl[c] - cf[c];
+            const bool push = size > 16;
+            if (has && !push && size > 1) lds_insertion_sort(packed, cf[c], cl[c]);
+            const uint64_t mask = __ballot(push);
+            if (push)
+              queue[which ^ 1][nNext + __popcll(mask & ((1ull << lane) - 1ull))] =
+                  make_uint2((uint32_t)cf[c] | ((uint32_t)cl[c] << 16), depth);
+            nNext += __popcll(mask);
+          }
+        }
+        __syncthreads();
+        which ^= 1;
+        nCur = nNext;
+      }
+      // unique(): the first of every run of equal keys survives
+      int kept = 0;
+      for (int i0 = 0; i0 < nAll; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        uint32_t w = 0;
+        if (i < nAll) {
+          w = packed[i];
+          keep = i == 0 || (packed[i - 1] >> 16) != (w >> 16);
+        }
+        const uint64_t mask = __ballot(keep);
+        if (keep) out[kept + __popcll(mask & ((1ull << lane) - 1ull))] = P[w & 0xffffu];
+        kept += __popcll(mask);
+      }
+      if (lane == 0) lv.nFrag[idx] = kept;
+      __syncthreads();
+    } else {
+      for (int i = lane; i < nAll; i += 64) out[i] = P[i];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane == 0) {
+        introsort_replay(out, (long)nAll, FragLess());
+        int f = 0, cur = 0;
+        while (f + 1 <= nAll) {
+          out[cur] = out[f];
+          while (f < nAll && out[cur].x == out[f].x && out[cur].y == out[f].y) f++;
+          cur++;
+        }
+        lv.nFrag[idx] = cur;
+      }
     }
   }
 }
@@ -1337,7 +1478,12 @@ void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, 
   else hipLaunchKernelGGL(sdp_match_kernel<false>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_order_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+  if (lv.n <= 0) return;
+  (void)hipMemsetAsync(lv.tieCount, 0, sizeof(int32_t), st);
+  hipLaunchKernelGGL(sdp_order_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+  hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsSmall>, dim3((unsigned)std::min(lv.n, 4096)), dim3(64), 0, st, lv, 0);
+  hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsCap>, dim3((unsigned)std::min(lv.n, 1024)), dim3(64), 0, st, lv,
+                     kTieLdsSmall + 1);
 }
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_yx_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
