@@ -397,8 +397,24 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     const int64_t nru = std::max(sp->recurse_over, 1);
     const int64_t parkOff = ((2 * (nru + 1) * 4 + (2 * nru + 2) + 255) / 256) * 256;
     const int64_t scratchPerLane = parkOff + ((perFill * 16 + 255) / 256) * 256;  // + parked Diagonal runs
-    const int64_t lanes = std::min<int64_t>((swTotal + 255) / 256, 512) * 256;
+    int64_t swMax = 0;
+    for (auto &lo : outs) swMax = std::max<int64_t>(swMax, lo.swCount);
+    // fills with both sides <= 63 run with their score row in registers, sorted by shape; the cell keys
+    // carry the arrow in their low bits, so the scores must leave room for that
+    int64_t magnitude = std::max<int64_t>(std::abs((int64_t)score->ins), std::abs((int64_t)score->del));
+    for (int i = 0; i < 25; i++) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)score->matrix[i]));
+    const bool smallOk = magnitude < (1 << 20);
+    const int bigBlocks = 128;
+    const int64_t lanes = (int64_t)bigBlocks * 256;
     uint8_t *scratch = arena.get<uint8_t>((size_t)(scratchPerLane * lanes));
+    uint32_t *smallScratch = arena.get<uint32_t>((size_t)sw_small_scratch_words(sw_small_blocks(swMax)));
+    uint32_t *swKeys = arena.get<uint32_t>((size_t)swMax), *swKeysSorted = arena.get<uint32_t>((size_t)swMax);
+    uint32_t *swIdx = arena.get<uint32_t>((size_t)swMax), *swOrder = arena.get<uint32_t>((size_t)swMax);
+    int32_t *nBig = arena.get<int32_t>(64);
+    size_t swSortBytes = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, swSortBytes, swKeys, swKeysSorted, swIdx, swOrder, (size_t)swMax, 0u,
+                                           13u, st));
+    void *swSortTmp = arena.get<char>(swSortBytes);
     ARENA_CHECK();
     SdpEmit e;
     memset(&e, 0, sizeof(e));
@@ -407,7 +423,49 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     e.poolCount = &dCounters->pool;
     e.poolCap = poolCap;
     e.overflow = &dCounters->overflow;
-    for (auto &lo : outs) launch_sw(lo.sw, lo.swCount, b->seq, dMatrix, prm, scratch, scratchPerLane, parkOff, e, st);
+    if (getenv("BLASR_HIP_SW_HIST")) {
+      // developer aid: size distribution of the SWAlign fills
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      long long hq[12] = {0}, ht[12] = {0}, hcells[12] = {0}, cells = 0, waveMax = 0, nw = 0, waveRect = 0;
+      for (auto &lo : outs) {
+        std::vector<SwTask> h((size_t)lo.swCount);
+        (void)hipMemcpy(h.data(), lo.sw, sizeof(SwTask) * lo.swCount, hipMemcpyDeviceToHost);
+        for (int64_t i = 0; i < lo.swCount; i += 64) {
+          long long mx = 0, mq = 0, mt = 0;
+          for (int64_t j = i; j < std::min(i + 64, lo.swCount); j++) {
+            const long long c = (long long)h[j].qLen * h[j].tLen;
+            cells += c;
+            mx = std::max(mx, c);
+            mq = std::max<long long>(mq, h[j].qLen);
+            mt = std::max<long long>(mt, h[j].tLen);
+            auto bin = [](long long v) { int b = 0; while (v > 1 && b < 11) { v >>= 1; b++; } return b; };
+            hq[bin(h[j].qLen)]++;
+            ht[bin(h[j].tLen)]++;
+            hcells[bin(c)]++;
+          }
+          waveMax += mx;
+          waveRect += mq * mt;
+          nw++;
+        }
+      }
+      fprintf(stderr, "[sw] fills %lld cells %lld  sum(max cells per wave) %lld sum(maxq*maxt per wave) %lld waves %lld\n",
+              (long long)swTotal, cells, waveMax, waveRect, nw);
+      for (int b = 0; b < 12; b++)
+        fprintf(stderr, "[sw] 2^%d: q %lld t %lld cells %lld\n", b, hq[b], ht[b], hcells[b]);
+    }
+    int level = 0;
+    for (auto &lo : outs) {
+      if (lo.swCount <= 0) continue;
+      if (lo.swCount >= (1ll << 32)) return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld fills", (long long)lo.swCount);
+      int32_t *nBigL = nBig + (level++ & 63);
+      HIP_TRY(ctx, hipMemsetAsync(nBigL, 0, sizeof(int32_t), st));
+      launch_sw_sort_keys(lo.sw, lo.swCount, smallOk, swKeys, swIdx, nBigL, st);
+      size_t bytes = swSortBytes;
+      HIP_TRY(ctx, rocprim::radix_sort_pairs(swSortTmp, bytes, swKeys, swKeysSorted, swIdx, swOrder, (size_t)lo.swCount,
+                                             0u, 13u, st));
+      launch_sw_small(lo.sw, swOrder, lo.swCount, nBigL, b->seq, dMatrix, prm, smallScratch, e, st);
+      launch_sw(lo.sw, swOrder, lo.swCount, nBigL, bigBlocks, b->seq, dMatrix, prm, scratch, scratchPerLane, parkOff, e, st);
+    }
   }
   Counters hc;
   HIP_TRY(ctx, hipMemcpyAsync(&hc, dCounters, sizeof(Counters), hipMemcpyDeviceToHost, st));

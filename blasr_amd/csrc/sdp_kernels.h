@@ -91,8 +91,15 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
 void launch_sdp_blocks_build(const SdpLevelArrays &lv, const SdpParams &p, int32_t *counts, hipStream_t st);
 void launch_sdp_blocks_emit(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, const int32_t *counts,
                             const int64_t *offPool, const int64_t *offSw, const int64_t *offChild, hipStream_t st);
-void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
-               uint8_t *scratch, int64_t scratchPerLane, int64_t parkOff, const SdpEmit &e, hipStream_t st);
+void launch_sw_sort_keys(const SwTask *tasks, int64_t n, bool smallOk, uint32_t *keys, uint32_t *vals, int32_t *nBig,
+                         hipStream_t st);
+int64_t sw_small_scratch_words(int blocks);
+int sw_small_blocks(int64_t n);
+void launch_sw_small(const SwTask *tasks, const uint32_t *order, int64_t n, const int32_t *nBig, const uint8_t *seq,
+                     const int32_t *matrix, const SdpParams &p, uint32_t *scratch, const SdpEmit &e, hipStream_t st);
+void launch_sw(const SwTask *tasks, const uint32_t *order, int64_t n, const int32_t *nBig, int blocks,
+               const uint8_t *seq, const int32_t *matrix, const SdpParams &p, uint8_t *scratch, int64_t scratchPerLane,
+               int64_t parkOff, const SdpEmit &e, hipStream_t st);
 
 // top-level results
 struct SdpResult {  // layout-identical to blasr_hip_sdp_result

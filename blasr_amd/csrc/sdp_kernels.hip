@@ -1255,7 +1255,162 @@ __global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv,
 // ---------------------------------------------------------------------------
 // sw: SWAlign, Global (SWAlign.h:19-389); only the Diagonal runs are kept (SDPAlign.h:529-534)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n, const uint8_t *seq,
+// Most fills are a few bases on either side (between consecutive k-mer anchors of the deepest recursion
+// level).  Those with both sides <= 63 are sorted by (target length, query length), so that the 64 fills
+// of a wavefront have the same shape, and run one per lane with the score row in registers
+// (sw_small_kernel).  The others take the general kernel further down.
+constexpr int kSwSmallMax = 63;
+constexpr uint32_t kSwBigKey = 1u << 12;
+constexpr int kSwArrowWords = kSwSmallMax * 4 * 64;        // per wavefront: 63 rows x 4 words x 64 lanes
+constexpr int kSwWaveScratchWords = kSwArrowWords + 64 * 64;  // + 64 parked runs per lane
+
+__global__ __launch_bounds__(256) void sw_sort_keys_kernel(const SwTask *tasks, int64_t n, int smallOk,
+                                                           uint32_t *keys, uint32_t *vals, int32_t *nBig) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool big = false;
+  if (i < n) {
+    const int q = tasks[i].qLen, t = tasks[i].tLen;
+    big = !smallOk || q > kSwSmallMax || t > kSwSmallMax;
+    keys[i] = big ? kSwBigKey : (uint32_t)((t << 6) | q);
+    vals[i] = (uint32_t)i;
+  }
+  const unsigned long long mask = __ballot(big);
+  if (mask != 0ull && lane_id() == 0) atomicAdd(nBig, (int)__popcll(mask));
+}
+
+__global__ __launch_bounds__(256) void sw_small_kernel(const SwTask *tasks, const uint32_t *order, int64_t nAll,
+                                                       const int32_t *nBigPtr, const uint8_t *seq,
+                                                       const int32_t *matrix, SdpParams prm, uint32_t *scratch,
+                                                       SdpEmit e) {
+  __shared__ int m4[25];               // 4 x score: the low two bits of a cell key hold the arrow
+  __shared__ uint8_t qRow[4][64 * 64];  // [wave][row * 64 + lane] = byte offset of the query base's row in m4
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  if (threadIdx.x < 25) m4[threadIdx.x] = matrix[threadIdx.x] * 4;
+  __syncthreads();
+  const int64_t nSmall = nAll - *nBigPtr;
+  const int64_t nChunks = (nSmall + 63) / 64;
+  const int64_t waveId = (int64_t)blockIdx.x * 4 + wv, nWaves = (int64_t)gridDim.x * 4;
+  uint32_t *arr = scratch + waveId * kSwWaveScratchWords + lane;
+  uint32_t *park = arr + kSwArrowWords;
+  const int ins4 = prm.ins * 4, del4 = prm.del * 4;
+  for (int64_t chunk = waveId; chunk < nChunks; chunk += nWaves) {
+    const int64_t pos = chunk * 64 + lane;
+    const bool live = pos < nSmall;
+    SwTask t;
+    t.qOff = t.tOff = 0;
+    t.qLen = t.tLen = t.top = t.qOrg = t.tOrg = t.pad = 0;
+    if (live) t = tasks[order[pos]];
+    const int qMax = wave_max(t.qLen), tMax = wave_max(t.tLen);
+    const int wpr = (tMax + 15) >> 4;
+    const uint8_t *q = seq + t.qOff, *tt = seq + t.tOff;
+    const int qLast = max(t.qLen - 1, 0), tLast = max(t.tLen - 1, 0);
+    // target bases, as byte offsets inside a row of m4, four per register
+    uint32_t tp[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) tp[j] = 0;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      if (g * 4 < tMax) {
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+          tp[g] |= (uint32_t)(base_code(tt[min(g * 4 + cc, tLast)]) * 4) << (8 * cc);
+      }
+    }
+    for (int r = 0; r < qMax; r++) qRow[wv][r * 64 + lane] = (uint8_t)(base_code(q[min(r, qLast)]) * 20);
+    // the lanes of a wavefront all compute qMax x tMax cells; what lies outside a lane's own q x t
+    // never flows into it (dependencies point left and up only) and is ignored by its traceback
+    int row[64];
+#pragma unroll
+    for (int c = 0; c < 64; c++) row[c] = del4 * (c + 1);
+    for (int r = 0; r < qMax; r++) {
+      const int qOff = qRow[wv][r * 64 + lane];
+      int left = ins4 * (r + 1), diag = ins4 * r;
+      uint32_t acc = 0;
+      // columns in groups of four (one register of target offsets): the four score look-ups are issued
+      // together, then the four dependent cells; a group past tMax is skipped by a scalar branch
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        if (g * 4 < tMax) {
+          int sc[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) {
+            const int tOff = (int)((tp[g] >> (8 * cc)) & 0xffu);
+            sc[cc] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(m4) + qOff + tOff);
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) {
+            const int c = g * 4 + cc;
+            const int up = row[c];
+            // Diagonal (0) < Up (1) < Left (2) on equal scores, as the if-chain of SWAlign.h:196-207
+            const int key = min(min(sc[cc] + diag, up + ins4 + 1), left + del4 + 2);
+            diag = up;
+            left = key & ~3;
+            row[c] = left;
+            acc |= (uint32_t)(key & 3) << (2 * (c & 15));
+          }
+          if ((g & 3) == 3) {
+            arr[(r * wpr + (g >> 2)) * 64] = acc;
+            acc = 0;
+          }
+        }
+      }
+      if (((tMax + 3) >> 2) & 3) arr[(r * wpr + (tMax >> 4)) * 64] = acc;
+    }
+    // traceback (q,t) -> (0,0); boundary arrows: row 0 Left, column 0 Up (:49-64)
+    int nRuns = 0;
+    if (live) {
+      int r = t.qLen, c = t.tLen, runLen = 0, cached = -1;
+      uint32_t w = 0;
+      while (r > 0 || c > 0) {
+        int a;
+        if (r == 0) a = 2;
+        else if (c == 0) a = 1;
+        else {
+          const int at = (r - 1) * wpr + ((c - 1) >> 4);
+          if (at != cached) {
+            w = arr[at * 64];
+            cached = at;
+          }
+          a = (int)((w >> (2 * ((c - 1) & 15))) & 3u);
+        }
+        if (a == 0) {
+          r--;
+          c--;
+          runLen++;
+        } else {
+          if (runLen) {
+            park[nRuns * 64] = ((uint32_t)r << 16) | ((uint32_t)c << 8) | (uint32_t)runLen;
+            nRuns++;
+            runLen = 0;
+          }
+          if (a == 1) r--; else c--;
+        }
+      }
+      if (runLen) {
+        park[nRuns * 64] = (uint32_t)runLen;
+        nRuns++;
+      }
+    }
+    // the wavefront reserves pool space for all of its lanes with ONE atomic
+    const unsigned incl = wave_prefix_sum((unsigned)nRuns);
+    unsigned long long basePool = 0;
+    if (lane == 63 && incl > 0) basePool = atomicAdd(e.poolCount, (unsigned long long)incl);
+    basePool = __shfl(basePool, 63);
+    const unsigned long long at0 = basePool + incl - (unsigned)nRuns;
+    for (int j = 0; j < nRuns; j++) {
+      const uint32_t pk = park[j * 64];
+      if ((int64_t)(at0 + j) < e.poolCap) {
+        e.poolKeys[at0 + j] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)(pk >> 16));
+        e.poolVals[at0 + j] = ((uint64_t)(uint32_t)(t.tOrg + (int)((pk >> 8) & 0xffu)) << 32) | (pk & 0xffu);
+      } else
+        *e.overflow = 1;
+    }
+  }
+}
+
+// The general kernel: one lane per fill, rows and arrows in the lane's slice of a scratch buffer.
+__global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, const uint32_t *order, int64_t nAll,
+                                                 const int32_t *nBigPtr, const uint8_t *seq,
                                                  const int32_t *matrix, SdpParams prm, uint8_t *scratch,
                                                  int64_t scratchPerLane, int64_t parkOff, SdpEmit e) {
   __shared__ int m[25];
@@ -1264,6 +1419,9 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n,
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   uint8_t *mine = scratch + gid * scratchPerLane;
+  // the fills that do not fit sw_small_kernel: the last *nBigPtr entries of the sorted order
+  const int64_t n = *nBigPtr;
+  order += nAll - n;
   // all lanes of a wavefront iterate together (the pool reservation below is a wave operation)
   for (int64_t i0 = gid - (gid & 63); i0 < n; i0 += stride) {
     const int64_t i = i0 + (gid & 63);
@@ -1271,7 +1429,7 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, int64_t n,
     SwTask t;
     t.qOff = t.tOff = 0;
     t.qLen = t.tLen = t.top = t.qOrg = t.tOrg = t.pad = 0;
-    if (live) t = tasks[i];
+    if (live) t = tasks[order[i]];
     const uint8_t *q = seq + t.qOff, *tt = seq + t.tOff;
     const int nCols = t.tLen + 1;
     int *prev = reinterpret_cast<int *>(mine);
@@ -1503,12 +1661,26 @@ void launch_sdp_blocks_emit(const SdpLevelArrays &lv, const SdpParams &p, const 
     hipLaunchKernelGGL(sdp_blocks_emit_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, e, counts, offPool, offSw,
                        offChild);
 }
-void launch_sw(const SwTask *tasks, int64_t n, const uint8_t *seq, const int32_t *matrix, const SdpParams &p,
-               uint8_t *scratch, int64_t scratchPerLane, int64_t parkOff, const SdpEmit &e, hipStream_t st) {
+void launch_sw_sort_keys(const SwTask *tasks, int64_t n, bool smallOk, uint32_t *keys, uint32_t *vals, int32_t *nBig,
+                         hipStream_t st) {
   if (n <= 0) return;
-  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
-  hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, n, seq, matrix, p, scratch, scratchPerLane,
-                     parkOff, e);
+  hipLaunchKernelGGL(sw_sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tasks, n,
+                     smallOk ? 1 : 0, keys, vals, nBig);
+}
+int64_t sw_small_scratch_words(int blocks) { return (int64_t)blocks * 4 * kSwWaveScratchWords; }
+int sw_small_blocks(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+void launch_sw_small(const SwTask *tasks, const uint32_t *order, int64_t n, const int32_t *nBig, const uint8_t *seq,
+                     const int32_t *matrix, const SdpParams &p, uint32_t *scratch, const SdpEmit &e, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(sw_small_kernel, dim3(sw_small_blocks(n)), dim3(256), 0, st, tasks, order, n, nBig, seq, matrix, p,
+                     scratch, e);
+}
+void launch_sw(const SwTask *tasks, const uint32_t *order, int64_t n, const int32_t *nBig, int blocks,
+               const uint8_t *seq, const int32_t *matrix, const SdpParams &p, uint8_t *scratch, int64_t scratchPerLane,
+               int64_t parkOff, const SdpEmit &e, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, order, n, nBig, seq, matrix, p, scratch,
+                     scratchPerLane, parkOff, e);
 }
 void launch_pool_histogram(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop, hipStream_t st) {
   if (n <= 0) return;
