@@ -480,11 +480,8 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     (void)hipEventDestroy(evB);
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "internal: block pool overflow");
   }
-  int32_t *countPerTop = arena.get<int32_t>(n);
-  int64_t *counts64 = arena.get<int64_t>(n + 1);
   int64_t *blkOff = arena.get<int64_t>(n + 1);
   ARENA_CHECK();
-  HIP_TRY(ctx, hipMemsetAsync(countPerTop, 0, sizeof(int32_t) * n, st));
   const uint64_t *sortedKeys = poolKeys, *sortedVals = poolVals;
   if (nPool > 0) {
     if (nPool >= (1ll << 32)) {
@@ -502,20 +499,9 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
                                            (size_t)nPool, 0u, endBit, st));
     sortedKeys = poolKeysSorted;
     sortedVals = poolValsSorted;
-    launch_pool_histogram(sortedKeys, nPool, countPerTop, st);
   }
-  {
-    // blkOff = exclusive scan of the per-candidate block counts
-    size_t scanBytes = 0;
-    auto in = rocprim::make_transform_iterator(countPerTop, [] __device__(int32_t v) { return (int64_t)v; });
-    (void)counts64;
-    HIP_TRY(ctx, hipMemsetAsync(blkOff + n, 0, sizeof(int64_t), st));
-    HIP_TRY(ctx, rocprim::inclusive_scan(nullptr, scanBytes, in, blkOff + 1, (size_t)n, rocprim::plus<int64_t>(), st));
-    void *scanTmp = arena.get<char>(scanBytes);
-    ARENA_CHECK();
-    HIP_TRY(ctx, hipMemsetAsync(blkOff, 0, sizeof(int64_t), st));
-    HIP_TRY(ctx, rocprim::inclusive_scan(scanTmp, scanBytes, in, blkOff + 1, (size_t)n, rocprim::plus<int64_t>(), st));
-  }
+  // blkOff[c] = first block of candidate c in the sorted pool (the pool is ordered by candidate)
+  launch_pool_offsets(sortedKeys, nPool, n, blkOff, st);
   launch_sdp_finish(n, dTop, b->seq, sortedKeys, sortedVals, blkOff, dMatrix, score->ins, score->del,
                     score->affine_open, score->affine_extend, reinterpret_cast<SdpResult *>(results), blocks, blocksCap,
                     st);

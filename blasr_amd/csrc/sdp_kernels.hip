@@ -87,58 +87,95 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
 // ---------------------------------------------------------------------------
 template <bool kHasVals>
 __device__ void wave_radix_sort(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, int n, int beginBit,
-                                int endBit, unsigned *hist /* 256 LDS words of this wave */, bool &resultInB) {
+                                int endBit, unsigned *hist /* 512 LDS words of this wave */, bool &resultInB) {
+  constexpr int kAhead = 8;  // 64-record chunks loaded ahead of the serial rank/scatter step
   const int lane = lane_id();
   const unsigned long long ltMask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   resultInB = false;
-  for (int shift = beginBit; shift < endBit; shift += 8) {
+  if (n <= 0 || endBit <= beginBit) return;
+  // histogram of the first digit; the later ones are counted while the previous pass scatters
+  for (int b = lane; b < 256; b += 64) hist[b] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = 0; i0 < n; i0 += 64 * kAhead) {
+    uint64_t k[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const int i = i0 + 64 * j + lane;
+      k[j] = i < n ? keysA[i] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; j++)
+      if (i0 + 64 * j + lane < n) atomicAdd(&hist[(unsigned)(k[j] >> beginBit) & 255u], 1u);
+  }
+  int pass = 0;
+  for (int shift = beginBit; shift < endBit; shift += 8, pass++) {
     const uint64_t *kin = resultInB ? keysB : keysA;
     uint64_t *kout = resultInB ? keysA : keysB;
     const uint32_t *vin = resultInB ? valsB : valsA;
     uint32_t *vout = resultInB ? valsA : valsB;
-    for (int b = lane; b < 256; b += 64) hist[b] = 0;
-    __builtin_amdgcn_wave_barrier();
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      if (i < n) atomicAdd(&hist[(unsigned)(kin[i] >> shift) & 255u], 1u);
-    }
+    unsigned *cur = hist + (pass & 1) * 256, *nxt = hist + ((pass & 1) ^ 1) * 256;
+    const bool more = shift + 8 < endBit;
     __builtin_amdgcn_wave_barrier();
     {  // exclusive prefix over the 256 bins: lane owns bins 4*lane .. 4*lane+3
-      unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      unsigned c0 = cur[4 * lane], c1 = cur[4 * lane + 1], c2 = cur[4 * lane + 2], c3 = cur[4 * lane + 3];
       const unsigned sum = c0 + c1 + c2 + c3;
       const unsigned excl = wave_prefix_sum(sum) - sum;
       __builtin_amdgcn_wave_barrier();
-      hist[4 * lane] = excl;
-      hist[4 * lane + 1] = excl + c0;
-      hist[4 * lane + 2] = excl + c0 + c1;
-      hist[4 * lane + 3] = excl + c0 + c1 + c2;
+      cur[4 * lane] = excl;
+      cur[4 * lane + 1] = excl + c0;
+      cur[4 * lane + 2] = excl + c0 + c1;
+      cur[4 * lane + 3] = excl + c0 + c1 + c2;
+      for (int b = lane; b < 256; b += 64) nxt[b] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      const bool on = i < n;
-      uint64_t key = 0;
-      uint32_t val = 0;
-      if (on) {
-        key = kin[i];
-        if (kHasVals) val = vin[i];
+    uint64_t kn[kAhead];
+    uint32_t vn[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const int i = 64 * j + lane;
+      kn[j] = i < n ? kin[i] : 0;
+      vn[j] = 0;
+      if (kHasVals && i < n) vn[j] = vin[i];
+    }
+    for (int i0 = 0; i0 < n; i0 += 64 * kAhead) {
+      uint64_t k[kAhead];
+      uint32_t v[kAhead];
+#pragma unroll
+      for (int j = 0; j < kAhead; j++) {
+        k[j] = kn[j];
+        v[j] = vn[j];
       }
-      const unsigned d = (unsigned)(key >> shift) & 255u;
-      unsigned long long same = __ballot(on);
-      for (int b = 0; b < 8; b++) {
-        const unsigned long long m = __ballot((d >> b) & 1u);
-        same &= ((d >> b) & 1u) ? m : ~m;
+      if (i0 + 64 * kAhead < n) {
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) {
+          const int i = i0 + 64 * (kAhead + j) + lane;
+          kn[j] = i < n ? kin[i] : 0;
+          if (kHasVals && i < n) vn[j] = vin[i];
+        }
       }
-      const unsigned rank = (unsigned)__popcll(same & ltMask);
-      unsigned base = 0;
-      if (on) base = hist[d];
-      __builtin_amdgcn_wave_barrier();
-      if (on) {
-        kout[base + rank] = key;
-        if (kHasVals) vout[base + rank] = val;
-        if (rank == 0) hist[d] = base + (unsigned)__popcll(same);
+#pragma unroll
+      for (int j = 0; j < kAhead; j++) {
+        if (i0 + 64 * j >= n) break;
+        const bool on = i0 + 64 * j + lane < n;
+        const uint64_t key = k[j];
+        const unsigned d = (unsigned)(key >> shift) & 255u;
+        unsigned long long same = __ballot(on);
+        for (int b = 0; b < 8; b++) {
+          const unsigned long long m = __ballot((d >> b) & 1u);
+          same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const unsigned rank = (unsigned)__popcll(same & ltMask);
+        unsigned base = 0;
+        if (on) base = cur[d];
+        __builtin_amdgcn_wave_barrier();
+        if (on) {
+          kout[base + rank] = key;
+          if (kHasVals) vout[base + rank] = v[j];
+          if (rank == 0) cur[d] = base + (unsigned)__popcll(same);
+          if (more) atomicAdd(&nxt[(unsigned)(key >> (shift + 8)) & 255u], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     resultInB = !resultInB;
@@ -146,7 +183,7 @@ __device__ void wave_radix_sort(uint64_t *keysA, uint64_t *keysB, uint32_t *vals
 }
 
 __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, uint64_t *tmp) {
-  __shared__ unsigned hist[4][256];
+  __shared__ unsigned hist[4][512];
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
@@ -159,7 +196,7 @@ __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, u
 }
 
 __global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uint64_t *tmpKeys, uint32_t *tmpIdx) {
-  __shared__ unsigned hist[4][256];
+  __shared__ unsigned hist[4][512];
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
@@ -167,7 +204,8 @@ __global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uin
   const int64_t base = lv.fragOff[idx];
   bool inB;
   // keys are y << 32 | x, already ordered by (x,y): a stable sort on the 24 bits of y gives (y,x) order
-  wave_radix_sort<true>(lv.yxKeys + base, tmpKeys + base, lv.yxIdx + base, tmpIdx + base, F, 32, 32 + kPosBits,
+  const int yBits = 32 - __builtin_clz((unsigned)max(lv.tasks[idx].tLen, 1));  // y < tLen
+  wave_radix_sort<true>(lv.yxKeys + base, tmpKeys + base, lv.yxIdx + base, tmpIdx + base, F, 32, 32 + yBits,
                         hist[threadIdx.x >> 6], inB);
   if (inB)
     for (int i = lane; i < F; i += 64) lv.yxIdx[base + i] = tmpIdx[base + i];
@@ -1499,9 +1537,13 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwTask *tasks, const uint
 // ---------------------------------------------------------------------------
 // assembly + statistics of the top-level candidates
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_histogram_kernel(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop) {
+// off[c] = index of the first pool entry of candidate c (keys sorted, candidate in the high word), off[n] = nPool
+__global__ __launch_bounds__(256) void pool_offsets_kernel(const uint64_t *poolKeys, int64_t nPool, int n, int64_t *off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&countPerTop[(uint32_t)(poolKeys[i] >> 32)], 1);
+  if (i > nPool) return;
+  const int64_t top = i < nPool ? (int64_t)(poolKeys[i] >> 32) : (int64_t)n;
+  const int64_t prev = i > 0 ? (int64_t)(poolKeys[i - 1] >> 32) : -1;
+  for (int64_t c = prev + 1; c <= top; c++) off[c] = i;
 }
 
 // sizes of the variable-length per-task arrays, as int64, for the device offset scans
@@ -1682,10 +1724,9 @@ void launch_sw(const SwTask *tasks, const uint32_t *order, int64_t n, const int3
   hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(256), 0, st, tasks, order, n, nBig, seq, matrix, p, scratch,
                      scratchPerLane, parkOff, e);
 }
-void launch_pool_histogram(const uint64_t *poolKeys, int64_t n, int32_t *countPerTop, hipStream_t st) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(pool_histogram_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, poolKeys, n,
-                     countPerTop);
+void launch_pool_offsets(const uint64_t *poolKeys, int64_t nPool, int n, int64_t *off, hipStream_t st) {
+  hipLaunchKernelGGL(pool_offsets_kernel, dim3((unsigned)((nPool + 1 + 255) / 256)), dim3(256), 0, st, poolKeys, nPool, n,
+                     off);
 }
 void launch_sdp_gather_sizes(const SdpLevelArrays &lv, int what, int64_t *out, hipStream_t st) {
   if (lv.n > 0)
