@@ -179,6 +179,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   int k = sp->word_size;
   int64_t totalInvocations = 0, totalFrags = 0;
 
+  const int idxMaxT = getenv("BLASR_HIP_NO_INDEX") ? 0 : sdp_match_index_max_target(ctx->device);
   for (int level = 0; nTasks > 0; level++) {
     totalInvocations += nTasks;
     SdpLevelArrays lv;
@@ -187,6 +188,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.tasks = dTasks;
     // ---- k-mer keys of the targets, sorted per task ----
     tick();
+    lv.idxMaxT = idxMaxT;
+    lv.bigList = arena.get<int32_t>(nTasks + 1);
+    lv.bigCount = lv.bigList + nTasks;
+    ARENA_CHECK();
+    launch_sdp_classify(lv, st);
     int64_t *sizes = arena.get<int64_t>(nTasks + 1);
     int64_t *keyOff = arena.get<int64_t>(nTasks + 1);
     ARENA_CHECK();
@@ -238,6 +244,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
       ARENA_CHECK();
     }
     launch_sdp_match(lv, b->seq, false, st);
+    launch_sdp_match_index(lv, b->seq, false, st);
     launch_sdp_gather_sizes(lv, 1, sizes, st);
     HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, fragOff, (int64_t)0, (size_t)nTasks + 1,
                                          rocprim::plus<int64_t>(), st));
@@ -271,6 +278,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.scratchB = arena.get<int32_t>(3 * nf);
     ARENA_CHECK();
     launch_sdp_match(lv, b->seq, true, st);
+    launch_sdp_match_index(lv, b->seq, true, st);
     launch_sdp_order(lv, st);
     launch_sdp_yx_keys(lv, st);
     launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);

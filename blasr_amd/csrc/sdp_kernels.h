@@ -59,6 +59,8 @@ struct SdpLevelArrays {
   uint64_t *yxKeys;        // (y << 32 | x) for StoreAbove
   uint32_t *yxIdx;
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
+  int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
+  int32_t *bigList, *bigCount;  // those tasks
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain
@@ -83,6 +85,9 @@ void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t s
 void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st);
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
+void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st);
+int sdp_match_index_max_target(int device);
+void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);

@@ -43,6 +43,17 @@ namespace blasr_hip {
 #endif
 constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
 
+// long targets are matched by sdp_match_index_kernel (further down) and need no sorted keys
+constexpr int kIdxBuckets = 2048;
+constexpr int kIdxMinT = 1536;   // shorter targets keep the wavefront-per-task kernels
+constexpr int kIdxMaxK = 13;     // 2k bits of k-mer + 2*15 bits of shift must fit a 64-bit window
+constexpr int kIdxCntStride = kIdxBuckets + 1;
+constexpr int kIdxSmallCap = 12288;  // targets up to this size: < 64 KB of LDS per workgroup
+
+__host__ __device__ inline bool task_uses_index(int tLen, int k, int idxMaxT) {
+  return tLen >= kIdxMinT && tLen <= idxMaxT && k <= kIdxMaxK;
+}
+
 __device__ __forceinline__ int wave_task_index() {
   if (DEBUG_DCACHE_INV) __builtin_amdgcn_s_dcache_inv();
   return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -59,6 +70,7 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
   const SdpTask t = lv.tasks[idx];
   uint64_t *keys = lv.keys + lv.keyOff[idx];
   const uint8_t *tSeq = seq + t.tOff;
+  if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // no sorted keys needed
   const uint64_t invalid = 1ull << (kPosBits + 2 * t.k);
   for (int p0 = 0; p0 < t.tLen; p0 += 64) {
     const int p = p0 + lane;
@@ -188,6 +200,7 @@ __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, u
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
+  if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;
   uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
   bool inB;
   wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
@@ -235,6 +248,329 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t *a, int n, uint64_
 // sdp_match: StoreMatchingPositions for the prefix, the whole sequence and the suffix
 // (SDPAlign.h:148-242).  kWrite = false counts, kWrite = true writes the fragments.
 // ---------------------------------------------------------------------------
+// prefix / suffix part of StoreMatchingPositions for one wavefront: every query position's small k-mer
+// against every target position's.  With both parts <= 64 bases (sdpPrefixLength is 50 by default) the
+// target k-mers sit one per lane and are read with v_readlane.
+template <bool kWrite>
+__device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, int xOff, int yOff, int ks,
+                          int maxPerPos, Frag *out, int written) {
+  const int lane = lane_id();
+  if (ks < 1) return 0;
+  if (qn <= 64 && tn <= 64) {
+    const int ny = tn - ks + 1;
+    if (ny <= 0 || qn < ks) return 0;
+    int tk = -2, qk = -1;
+    if (lane < ny) {
+      tk = small_kmer(ts, lane, ks);
+      if (tk < 0) tk = -2;
+    }
+    if (lane + ks <= qn) qk = small_kmer(qs, lane, ks);
+    int cnt = 0;
+    for (int y = 0; y < ny; y++) cnt += __builtin_amdgcn_readlane(tk, y) == qk;
+    if (maxPerPos != 0 && cnt > maxPerPos) cnt = 0;
+    const unsigned incl = wave_prefix_sum((unsigned)cnt);
+    if (kWrite && cnt > 0) {
+      int w = written + (int)incl - cnt;
+      for (int y = 0; y < ny; y++)
+        if (__builtin_amdgcn_readlane(tk, y) == qk) {
+          Frag f;
+          f.x = (uint32_t)(lane + xOff);
+          f.y = (uint32_t)(y + yOff);
+          f.len = (uint32_t)ks;
+          f.pad = 0;
+          out[w++] = f;
+        }
+    }
+    return __builtin_amdgcn_readlane((int)incl, 63);
+  }
+  int total = 0;
+  for (int x0 = 0; x0 + ks <= qn; x0 += 64) {
+    const int x = x0 + lane;
+    int cnt = 0, qk = -1;
+    if (x + ks <= qn) {
+      qk = small_kmer(qs, x, ks);
+      if (qk >= 0)
+        for (int y = 0; y + ks <= tn; y++) cnt += small_kmer(ts, y, ks) == qk;
+      if (maxPerPos != 0 && cnt > maxPerPos) cnt = 0;
+    }
+    const unsigned incl = wave_prefix_sum((unsigned)cnt);
+    if (kWrite && cnt > 0) {
+      int w = written + total + (int)incl - cnt;
+      for (int y = 0; y + ks <= tn; y++)
+        if (small_kmer(ts, y, ks) == qk) {
+          Frag f;
+          f.x = (uint32_t)(x + xOff);
+          f.y = (uint32_t)(y + yOff);
+          f.len = (uint32_t)ks;
+          f.pad = 0;
+          out[w++] = f;
+        }
+    }
+    total += __builtin_amdgcn_readlane((int)incl, 63);
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+// sdp_match_index: the same StoreMatchingPositions for LONG targets, one 256-thread workgroup per task
+// and no k-mer sort at all.  The target's bases are packed into LDS (2 bits + a "not ACGT" bit), its
+// k-mers are bucketed by a hash of the k-mer with a STABLE counting scatter (each wavefront owns a
+// contiguous quarter of the target, so a bucket lists positions in increasing order), and every query
+// k-mer walks its bucket comparing against the packed target.  Matches therefore come out ordered by
+// (query position, target position), as the sorted tuple list of the reference yields them
+// (TupleList.h:98-126, TupleMatching.h:37-61).
+// ---------------------------------------------------------------------------
+struct IdxLds {
+  uint32_t *tCodes, *tBad, *cnt, *qStage, *part;
+  uint8_t *lut;
+  uint16_t *entries;
+};
+__host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
+  int at = 0;
+  offs[0] = at, at += tCap / 16 + 4;          // tCodes
+  offs[1] = at, at += tCap / 32 + 4;          // tBad
+  offs[2] = at, at += 4 * kIdxCntStride;      // cnt: per wavefront and bucket {fill pointer : 16, ticket : 16}
+  offs[3] = at, at += 4 * 104;                // qStage: per wavefront 66 code words + 34 bad words
+  offs[4] = at, at += 16;                     // part
+  offs[5] = at, at += 64;                     // lut
+  offs[6] = at, at += (tCap + 1) / 2 + 2;     // entries
+  return at;
+}
+int64_t idx_lds_bytes(int tCap) {
+  int offs[7];
+  return (int64_t)idx_lds_words(tCap, offs) * 4;
+}
+// 16 consecutive bases starting at p0 -> 16 x 2-bit codes and 16 "not ACGT / outside" bits
+__device__ __forceinline__ void stage16(const uint8_t *s, int len, int p0, const uint8_t *lut, uint32_t &codes,
+                                        uint32_t &bad) {
+  uint32_t w[4] = {0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};  // 'N'
+  if (p0 + 16 <= len) {
+    __builtin_memcpy(w, s + p0, 16);
+  } else {
+    for (int i = 0; i < 16; i++)
+      if (p0 + i < len) w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)s[p0 + i] << (8 * (i & 3)));
+  }
+  codes = 0;
+  bad = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const uint32_t c = lut[(w[i >> 2] >> (8 * (i & 3))) & 0xffu];
+    codes |= (c & 3u) << (2 * i);
+    bad |= (c >> 2) << i;
+  }
+}
+__device__ __forceinline__ uint32_t code_window(const uint32_t *codes, int p, uint32_t kmerMask) {
+  const int w = p >> 4;
+  return __builtin_amdgcn_alignbit(codes[w + 1], codes[w], (uint32_t)(p & 15) * 2u) & kmerMask;
+}
+__device__ __forceinline__ uint32_t bad_window(const uint32_t *bad, int p, uint32_t kMask) {
+  const int w = p >> 5;
+  return __builtin_amdgcn_alignbit(bad[w + 1], bad[w], (uint32_t)(p & 31)) & kMask;
+}
+__device__ __forceinline__ int idx_bucket(uint32_t kmer) { return (int)((kmer ^ (kmer >> 11) ^ (kmer >> 22)) & (kIdxBuckets - 1)); }
+
+__global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool big = false;
+  if (i < lv.n) big = task_uses_index(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT);
+  const unsigned long long mask = __ballot(big);
+  int base = 0;
+  if (mask != 0ull && lane_id() == 0) base = atomicAdd(lv.bigCount, (int)__popcll(mask));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (big) lv.bigList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+}
+
+template <bool kWrite>
+__global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv, const uint8_t *seq, int tCap, int minT) {
+  extern __shared__ uint32_t idxLdsRaw[];
+  IdxLds L;
+  {
+    int offs[7];
+    idx_lds_words(tCap, offs);
+    L.tCodes = idxLdsRaw + offs[0];
+    L.tBad = idxLdsRaw + offs[1];
+    L.cnt = idxLdsRaw + offs[2];
+    L.qStage = idxLdsRaw + offs[3];
+    L.part = idxLdsRaw + offs[4];
+    L.lut = reinterpret_cast<uint8_t *>(idxLdsRaw + offs[5]);
+    L.entries = reinterpret_cast<uint16_t *>(idxLdsRaw + offs[6]);
+  }
+  const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+  L.lut[tid] = (uint8_t)base_code((unsigned)tid);  // 0..3, or 4 = bad bit
+  const int nBig = *lv.bigCount;
+  volatile uint32_t *my = L.cnt + wv * kIdxCntStride;
+  uint32_t *qCodes = L.qStage + wv * 104, *qBad = qCodes + 68;
+  for (int e = blockIdx.x; e < nBig; e += gridDim.x) {
+    const int idx = lv.bigList[e];
+    const SdpTask t = lv.tasks[idx];
+    if (t.tLen > tCap || t.tLen <= minT) continue;  // another size class takes it
+    __syncthreads();
+    const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
+    const int k = t.k, ks = k < 5 ? k : 5;
+    const uint32_t kmerMask = (1u << (2 * k)) - 1u, kMask = (1u << k) - 1u;
+    // ---- the target, packed
+    for (int wi = tid; wi < (t.tLen + 15) / 16 + 2; wi += 256) {
+      uint32_t c, bd;
+      stage16(tSeq, t.tLen, wi * 16, L.lut, c, bd);
+      L.tCodes[wi] = c;
+      reinterpret_cast<uint16_t *>(L.tBad)[wi] = (uint16_t)bd;
+    }
+    for (int i = tid; i < 4 * kIdxCntStride; i += 256) L.cnt[i] = 0;
+    __syncthreads();
+    // ---- bucket sizes per wavefront (each owns a contiguous quarter of the target positions)
+    const int nKmerT = t.tLen - k + 1;
+    const int per = (((nKmerT + 3) / 4) + 63) & ~63;
+    const int lo = min(wv * per, nKmerT), hi = min(nKmerT, lo + per);
+    for (int p = lo + lane; p < hi; p += 64)
+      if (bad_window(L.tBad, p, kMask) == 0u)
+        atomicAdd(const_cast<uint32_t *>(&my[idx_bucket(code_window(L.tCodes, p, kmerMask))]), 1u << 16);
+    __syncthreads();
+    {  // exclusive scan over the buckets; every wavefront's fill pointer starts after the earlier quarters'
+      uint32_t c[4][8], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          c[w][j] = L.cnt[w * kIdxCntStride + 8 * tid + j] >> 16;
+          sum += c[w][j];
+        }
+      }
+      const unsigned incl = wave_prefix_sum(sum);
+      if (lane == 63) L.part[wv] = incl;
+      __syncthreads();
+      uint32_t at = incl - sum;
+      for (int w = 0; w < wv; w++) at += L.part[w];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          L.cnt[w * kIdxCntStride + 8 * tid + j] = (at << 16) | 0xffffu;
+          at += c[w][j];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- stable scatter: in a chunk of 64 positions the lanes that share a bucket take turns, lowest first
+    for (int p0 = lo; p0 < hi; p0 += 64) {
+      const int p = p0 + lane;
+      bool pending = p < hi && bad_window(L.tBad, p, kMask) == 0u;
+      const int d = pending ? idx_bucket(code_window(L.tCodes, p, kmerMask)) : 0;
+      while (__ballot(pending) != 0ull) {
+        if (pending) {
+          const uint32_t word = my[d];
+          atomicMin(const_cast<uint32_t *>(&my[d]), (word & 0xffff0000u) | (uint32_t)lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (pending) {
+          const uint32_t r = my[d];
+          if ((r & 0xffffu) == (uint32_t)lane) {
+            const uint32_t slot = r >> 16;
+            L.entries[slot] = (uint16_t)p;
+            my[d] = ((slot + 1u) << 16) | 0xffffu;
+            pending = false;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    const uint32_t *ends = L.cnt + 3 * kIdxCntStride;  // the last quarter's fill pointers = bucket ends
+    // ---- the query against the index
+    const int nKmerQ = max(t.qLen - k + 1, 0);
+    const int perQ = (((nKmerQ + 3) / 4) + 63) & ~63;
+    const int qlo = min(wv * perQ, nKmerQ), qhi = min(nKmerQ, qlo + perQ);
+    uint32_t *hits = reinterpret_cast<uint32_t *>(lv.hits + lv.qPosOff[idx]);  // match count per query position
+    Frag *out = nullptr;
+    int nP = 0, nMall = 0, wBase = 0;
+    if (kWrite) {
+      out = lv.raw + lv.fragOff[idx];
+      nP = lv.nRaw[3 * idx];
+      nMall = lv.nRaw[3 * idx + 1];
+      int mine = 0;
+      for (int x = qlo + lane; x < qhi; x += 64) mine += (int)hits[x];
+      for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+      if (lane == 0) L.part[8 + wv] = (uint32_t)mine;
+      __syncthreads();
+      wBase = nP;
+      for (int w = 0; w < wv; w++) wBase += (int)L.part[8 + w];
+    }
+    int nM = 0;
+    for (int c0 = qlo; c0 < qhi; c0 += 1024) {
+      __builtin_amdgcn_wave_barrier();
+      for (int wi = lane; wi < 66; wi += 64) {
+        uint32_t c, bd;
+        stage16(qSeq, t.qLen, c0 + wi * 16, L.lut, c, bd);
+        qCodes[wi] = c;
+        reinterpret_cast<uint16_t *>(qBad)[wi] = (uint16_t)bd;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < 16; j++) {
+        const int x0 = c0 + 64 * j;
+        if (x0 >= qhi) break;
+        const int x = x0 + lane;
+        const bool on = x < qhi;
+        const int rel = x - c0;
+        const bool ok = on && bad_window(qBad, rel, kMask) == 0u;
+        const uint32_t km = code_window(qCodes, rel, kmerMask);
+        int cnt = 0, bs = 0, be = 0;
+        if (kWrite) {
+          if (on) cnt = (int)hits[x];
+        }
+        if (ok && (!kWrite || cnt > 0)) {
+          const int b = idx_bucket(km);
+          bs = b ? (int)(ends[b - 1] >> 16) : 0;
+          be = (int)(ends[b] >> 16);
+        }
+        if (!kWrite) {
+          for (int i = bs; i < be; i++) cnt += code_window(L.tCodes, (int)L.entries[i], kmerMask) == km;
+          if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+          if (on) hits[x] = (uint32_t)cnt;
+          nM += cnt;
+        } else {
+          const unsigned incl = wave_prefix_sum((unsigned)cnt);
+          int w = wBase + (int)incl - cnt;
+          for (int i = bs; i < be; i++) {
+            const int pos = (int)L.entries[i];
+            if (code_window(L.tCodes, pos, kmerMask) == km) {
+              Frag f;
+              f.x = (uint32_t)x;
+              f.y = (uint32_t)pos;
+              f.len = (uint32_t)k;
+              f.pad = 0;
+              out[w++] = f;
+            }
+          }
+          wBase += __builtin_amdgcn_readlane((int)incl, 63);
+        }
+      }
+    }
+    // ---- prefix and suffix parts (SDPAlign.h:148-182), wavefront 0 and 1
+    const int prefixLength = min(t.tLen, t.prefix);
+    const int suffixLength = min(t.tLen - prefixLength, t.prefix);
+    const int suffixPos = t.tLen - suffixLength;
+    const int qPrefixLength = min(t.qLen, t.prefix);
+    const int qSuffixLength = min(t.qLen - qPrefixLength, t.prefix);
+    const int qSuffixPos = t.qLen - qSuffixLength;
+    if (!kWrite) {
+      for (int off = 32; off > 0; off >>= 1) nM += __shfl_xor(nM, off);
+      __syncthreads();
+      if (lane == 0) L.part[8 + wv] = (uint32_t)nM;
+      __syncthreads();
+    }
+    if (wv == 0) {
+      const int n0 = small_part<kWrite>(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0, ks, t.maxPerPos, out, 0);
+      if (!kWrite && lane == 0) {
+        lv.nRaw[3 * idx] = n0;
+        lv.nRaw[3 * idx + 1] = (int)(L.part[8] + L.part[9] + L.part[10] + L.part[11]);
+      }
+    } else if (wv == 1) {
+      const int n2 = small_part<kWrite>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
+                                        suffixPos, ks, t.maxPerPos, out, nP + nMall);
+      if (!kWrite && lane == 0) lv.nRaw[3 * idx + 2] = n2;
+    }
+  }
+}
+
 constexpr int kBucketBits = 11;  // LDS bucket index over the leading bits of the k-mer (per wavefront: 8 KB)
 
 template <bool kWrite>
@@ -244,6 +580,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
+  if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // sdp_match_index_kernel's
   const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
   const uint64_t *keys = lv.keys + lv.keyOff[idx];
   const int k = t.k, ks = k < 5 ? k : 5;
@@ -257,36 +594,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   Frag *out = kWrite ? lv.raw + lv.fragOff[idx] : nullptr;
   int written = 0;  // uniform running count
 
-  // prefix (part 0) and suffix (part 2): short sequences, compared directly
-  auto smallPart = [&](const uint8_t *qs, int qn, const uint8_t *ts, int tn, int xOff, int yOff) {
-    int total = 0;
-    for (int x0 = 0; x0 + ks <= qn; x0 += 64) {
-      const int x = x0 + lane;
-      int cnt = 0, qk = -1;
-      if (x + ks <= qn) {
-        qk = small_kmer(qs, x, ks);
-        if (qk >= 0)
-          for (int y = 0; y + ks <= tn; y++) cnt += small_kmer(ts, y, ks) == qk;
-        if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
-      }
-      const unsigned incl = wave_prefix_sum((unsigned)cnt);
-      if (kWrite && cnt > 0) {
-        int w = written + total + (int)incl - cnt;
-        for (int y = 0; y + ks <= tn; y++)
-          if (small_kmer(ts, y, ks) == qk) {
-            Frag f;
-            f.x = (uint32_t)(x + xOff);
-            f.y = (uint32_t)(y + yOff);
-            f.len = (uint32_t)ks;
-            f.pad = 0;
-            out[w++] = f;
-          }
-      }
-      total += __builtin_amdgcn_readlane((int)incl, 63);
-    }
-    return total;
-  };
-  const int nP = (ks >= 1) ? smallPart(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0) : 0;
+  const int nP = small_part<kWrite>(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0, ks, t.maxPerPos, out, written);
   written += nP;
 
   // middle (part 1): the whole query against the sorted k-mer keys of the whole target.
@@ -355,9 +663,8 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
     nM += __builtin_amdgcn_readlane((int)incl, 63);
   }
   written += nM;
-  const int nS = (ks >= 1) ? smallPart(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
-                                       suffixPos)
-                           : 0;
+  const int nS = small_part<kWrite>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
+                                    suffixPos, ks, t.maxPerPos, out, written);
   if (!kWrite && lane == 0) {
     lv.nRaw[3 * idx] = nP;
     lv.nRaw[3 * idx + 1] = nM;
@@ -1551,7 +1858,7 @@ __global__ __launch_bounds__(256) void sdp_gather_sizes_kernel(SdpLevelArrays lv
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv.n) return;
   int64_t v;
-  if (what == 0) v = lv.tasks[i].tLen;
+  if (what == 0) v = task_uses_index(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT) ? 0 : lv.tasks[i].tLen;
   else if (what == 3) v = lv.tasks[i].qLen;
   else if (what == 1) v = (int64_t)lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
   else v = lv.nFrag[i];
@@ -1676,6 +1983,48 @@ void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, 
   if (lv.n <= 0) return;
   if (write) hipLaunchKernelGGL(sdp_match_kernel<true>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
   else hipLaunchKernelGGL(sdp_match_kernel<false>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+}
+void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n <= 0) return;
+  (void)hipMemsetAsync(lv.bigCount, 0, sizeof(int32_t), st);
+  hipLaunchKernelGGL(sdp_classify_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
+}
+int sdp_match_index_max_target(int device) {
+  // the largest target one workgroup can index: bounded by the LDS a workgroup may allocate
+  int maxLds = 0;
+  if (hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) return 0;
+  int optin = 0;
+  if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > maxLds)
+    maxLds = optin;
+  int tCap = 0;
+  for (int c = 4096; c <= 61440; c += 1024)
+    if (idx_lds_bytes(c) <= maxLds) tCap = c;
+  if (tCap > kIdxSmallCap) {
+    const int bytes = (int)idx_lds_bytes(tCap);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sdp_match_index_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&sdp_match_index_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      tCap = kIdxSmallCap;
+    }
+  }
+  return tCap;
+}
+void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
+  if (lv.n <= 0 || lv.idxMaxT <= 0) return;
+  // two size classes, so that the usual targets (<= kIdxSmallCap) get two workgroups per CU
+  const int grid = std::min(lv.n, 1024);
+  const int caps[2] = {std::min(kIdxSmallCap, lv.idxMaxT), lv.idxMaxT};
+  for (int c = 0; c < 2; c++) {
+    if (c == 1 && caps[1] <= caps[0]) break;
+    const int minT = c == 0 ? 0 : caps[0];
+    const size_t bytes = (size_t)idx_lds_bytes(caps[c]);
+    if (write)
+      hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
+    else
+      hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
+  }
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
