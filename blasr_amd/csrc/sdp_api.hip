@@ -191,6 +191,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.idxMaxT = idxMaxT;
     lv.bigList = arena.get<int32_t>(nTasks + 1);
     lv.bigCount = lv.bigList + nTasks;
+    lv.idxFlag = arena.get<int32_t>(nTasks);
     ARENA_CHECK();
     launch_sdp_classify(lv, st);
     int64_t *sizes = arena.get<int64_t>(nTasks + 1);

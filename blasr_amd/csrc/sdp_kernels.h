@@ -61,6 +61,7 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
+  int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain

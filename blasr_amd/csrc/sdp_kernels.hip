@@ -33,6 +33,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "sdp_kernels.h"
 #include "wave_utils.h"
 
@@ -44,7 +49,7 @@ namespace blasr_hip {
 constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
 
 // long targets are matched by sdp_match_index_kernel (further down) and need no sorted keys
-constexpr int kIdxBuckets = 2048;
+constexpr int kIdxBuckets = 1024;
 constexpr int kIdxMinT = 1536;   // shorter targets keep the wavefront-per-task kernels
 constexpr int kIdxMaxK = 13;     // 2k bits of k-mer + 2*15 bits of shift must fit a 64-bit window
 constexpr int kIdxCntStride = kIdxBuckets + 1;
@@ -323,7 +328,7 @@ __device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, 
 struct IdxLds {
   uint32_t *tCodes, *tBad, *cnt, *qStage, *part;
   uint8_t *lut;
-  uint16_t *entries;
+  uint32_t *ent;  // bucket by bucket: {the k-mer bits above the low ten : 16, target position : 16}
 };
 __host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
   int at = 0;
@@ -333,7 +338,8 @@ __host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
   offs[3] = at, at += 4 * 104;                // qStage: per wavefront 66 code words + 34 bad words
   offs[4] = at, at += 16;                     // part
   offs[5] = at, at += 64;                     // lut
-  offs[6] = at, at += (tCap + 1) / 2 + 2;     // entries
+  at = (at + 3) & ~3;
+  offs[6] = at, at += tCap + 8;               // ent (16-byte aligned)
   return at;
 }
 int64_t idx_lds_bytes(int tCap) {
@@ -367,7 +373,12 @@ __device__ __forceinline__ uint32_t bad_window(const uint32_t *bad, int p, uint3
   const int w = p >> 5;
   return __builtin_amdgcn_alignbit(bad[w + 1], bad[w], (uint32_t)(p & 31)) & kMask;
 }
-__device__ __forceinline__ int idx_bucket(uint32_t kmer) { return (int)((kmer ^ (kmer >> 11) ^ (kmer >> 22)) & (kIdxBuckets - 1)); }
+// bucket = low ten bits of the k-mer mixed with the bits above them; (bucket, high bits) <-> k-mer is one to one
+__device__ __forceinline__ uint32_t idx_high(uint32_t kmer) { return kmer >> 10; }  // <= 16 bits for k <= 13
+__device__ __forceinline__ int idx_bucket(uint32_t kmer) {
+  const uint32_t h = kmer >> 10;
+  return (int)((kmer ^ h ^ (h >> 10)) & (kIdxBuckets - 1));
+}
 
 __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,9 +391,13 @@ __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
   if (big) lv.bigList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
 }
 
+// The count pass leaves, per query position, {match count : 16, the first three target positions : 3 x 16} in
+// lv.hits; the write pass turns that into fragments and rebuilds the index only for a task in which some
+// position has more than three matches (lv.idxFlag).
 template <bool kWrite>
 __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv, const uint8_t *seq, int tCap, int minT) {
-  extern __shared__ uint32_t idxLdsRaw[];
+  extern __shared__ uint4 idxLdsRaw4[];  // 16-byte aligned
+  uint32_t *idxLdsRaw = reinterpret_cast<uint32_t *>(idxLdsRaw4);
   IdxLds L;
   {
     int offs[7];
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     L.qStage = idxLdsRaw + offs[3];
     L.part = idxLdsRaw + offs[4];
     L.lut = reinterpret_cast<uint8_t *>(idxLdsRaw + offs[5]);
-    L.entries = reinterpret_cast<uint16_t *>(idxLdsRaw + offs[6]);
+    L.ent = idxLdsRaw + offs[6];
   }
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
   L.lut[tid] = (uint8_t)base_code((unsigned)tid);  // 0..3, or 4 = bad bit
@@ -408,78 +423,82 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
     const int k = t.k, ks = k < 5 ? k : 5;
     const uint32_t kmerMask = (1u << (2 * k)) - 1u, kMask = (1u << k) - 1u;
-    // ---- the target, packed
-    for (int wi = tid; wi < (t.tLen + 15) / 16 + 2; wi += 256) {
-      uint32_t c, bd;
-      stage16(tSeq, t.tLen, wi * 16, L.lut, c, bd);
-      L.tCodes[wi] = c;
-      reinterpret_cast<uint16_t *>(L.tBad)[wi] = (uint16_t)bd;
-    }
-    for (int i = tid; i < 4 * kIdxCntStride; i += 256) L.cnt[i] = 0;
-    __syncthreads();
-    // ---- bucket sizes per wavefront (each owns a contiguous quarter of the target positions)
-    const int nKmerT = t.tLen - k + 1;
-    const int per = (((nKmerT + 3) / 4) + 63) & ~63;
-    const int lo = min(wv * per, nKmerT), hi = min(nKmerT, lo + per);
-    for (int p = lo + lane; p < hi; p += 64)
-      if (bad_window(L.tBad, p, kMask) == 0u)
-        atomicAdd(const_cast<uint32_t *>(&my[idx_bucket(code_window(L.tCodes, p, kmerMask))]), 1u << 16);
-    __syncthreads();
-    {  // exclusive scan over the buckets; every wavefront's fill pointer starts after the earlier quarters'
-      uint32_t c[4][8], sum = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          c[w][j] = L.cnt[w * kIdxCntStride + 8 * tid + j] >> 16;
-          sum += c[w][j];
-        }
+    const bool build = !kWrite || lv.idxFlag[idx] != 0;
+    if (build) {
+      // ---- the target, packed
+      for (int wi = tid; wi < (t.tLen + 15) / 16 + 2; wi += 256) {
+        uint32_t c, bd;
+        stage16(tSeq, t.tLen, wi * 16, L.lut, c, bd);
+        L.tCodes[wi] = c;
+        reinterpret_cast<uint16_t *>(L.tBad)[wi] = (uint16_t)bd;
       }
-      const unsigned incl = wave_prefix_sum(sum);
-      if (lane == 63) L.part[wv] = incl;
+      for (int i = tid; i < 4 * kIdxCntStride; i += 256) L.cnt[i] = 0;
       __syncthreads();
-      uint32_t at = incl - sum;
-      for (int w = 0; w < wv; w++) at += L.part[w];
+      // ---- bucket sizes per wavefront (each owns a contiguous quarter of the target positions)
+      const int nKmerT = t.tLen - k + 1;
+      const int per = (((nKmerT + 3) / 4) + 63) & ~63;
+      const int lo = min(wv * per, nKmerT), hi = min(nKmerT, lo + per);
+      for (int p = lo + lane; p < hi; p += 64)
+        if (bad_window(L.tBad, p, kMask) == 0u)
+          atomicAdd(const_cast<uint32_t *>(&my[idx_bucket(code_window(L.tCodes, p, kmerMask))]), 1u << 16);
+      __syncthreads();
+      {  // exclusive scan over the buckets; every wavefront's fill pointer starts after the earlier quarters'
+        uint32_t c[4][4], sum = 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 4; j++) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-          L.cnt[w * kIdxCntStride + 8 * tid + j] = (at << 16) | 0xffffu;
-          at += c[w][j];
-        }
-      }
-    }
-    __syncthreads();
-    // ---- stable scatter: in a chunk of 64 positions the lanes that share a bucket take turns, lowest first
-    for (int p0 = lo; p0 < hi; p0 += 64) {
-      const int p = p0 + lane;
-      bool pending = p < hi && bad_window(L.tBad, p, kMask) == 0u;
-      const int d = pending ? idx_bucket(code_window(L.tCodes, p, kmerMask)) : 0;
-      while (__ballot(pending) != 0ull) {
-        if (pending) {
-          const uint32_t word = my[d];
-          atomicMin(const_cast<uint32_t *>(&my[d]), (word & 0xffff0000u) | (uint32_t)lane);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (pending) {
-          const uint32_t r = my[d];
-          if ((r & 0xffffu) == (uint32_t)lane) {
-            const uint32_t slot = r >> 16;
-            L.entries[slot] = (uint16_t)p;
-            my[d] = ((slot + 1u) << 16) | 0xffffu;
-            pending = false;
+          for (int w = 0; w < 4; w++) {
+            c[w][j] = L.cnt[w * kIdxCntStride + 4 * tid + j] >> 16;
+            sum += c[w][j];
           }
         }
-        __builtin_amdgcn_wave_barrier();
+        const unsigned incl = wave_prefix_sum(sum);
+        if (lane == 63) L.part[wv] = incl;
+        __syncthreads();
+        uint32_t at = incl - sum;
+        for (int w = 0; w < wv; w++) at += L.part[w];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            L.cnt[w * kIdxCntStride + 4 * tid + j] = (at << 16) | 0xffffu;
+            at += c[w][j];
+          }
+        }
       }
+      __syncthreads();
+      // ---- stable scatter: in a chunk of 64 positions the lanes that share a bucket take turns, lowest first
+      for (int p0 = lo; p0 < hi; p0 += 64) {
+        const int p = p0 + lane;
+        bool pending = p < hi && bad_window(L.tBad, p, kMask) == 0u;
+        const uint32_t tkm = code_window(L.tCodes, p, kmerMask);
+        const int d = pending ? idx_bucket(tkm) : 0;
+        while (__ballot(pending) != 0ull) {
+          if (pending) {
+            const uint32_t word = my[d];
+            atomicMin(const_cast<uint32_t *>(&my[d]), (word & 0xffff0000u) | (uint32_t)lane);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (pending) {
+            const uint32_t r = my[d];
+            if ((r & 0xffffu) == (uint32_t)lane) {
+              const uint32_t slot = r >> 16;
+              L.ent[slot] = (idx_high(tkm) << 16) | (uint32_t)p;
+              my[d] = ((slot + 1u) << 16) | 0xffffu;
+              pending = false;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     const uint32_t *ends = L.cnt + 3 * kIdxCntStride;  // the last quarter's fill pointers = bucket ends
     // ---- the query against the index
     const int nKmerQ = max(t.qLen - k + 1, 0);
     const int perQ = (((nKmerQ + 3) / 4) + 63) & ~63;
     const int qlo = min(wv * perQ, nKmerQ), qhi = min(nKmerQ, qlo + perQ);
-    uint32_t *hits = reinterpret_cast<uint32_t *>(lv.hits + lv.qPosOff[idx]);  // match count per query position
+    uint64_t *hits = lv.hits + lv.qPosOff[idx];
     Frag *out = nullptr;
     int nP = 0, nMall = 0, wBase = 0;
     if (kWrite) {
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       nP = lv.nRaw[3 * idx];
       nMall = lv.nRaw[3 * idx + 1];
       int mine = 0;
-      for (int x = qlo + lane; x < qhi; x += 64) mine += (int)hits[x];
+      for (int x = qlo + lane; x < qhi; x += 64) mine += (int)(hits[x] & 0xffffu);
       for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
       if (lane == 0) L.part[8 + wv] = (uint32_t)mine;
       __syncthreads();
@@ -495,49 +514,81 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       for (int w = 0; w < wv; w++) wBase += (int)L.part[8 + w];
     }
     int nM = 0;
+    bool many = false;  // some position with more than three matches
     for (int c0 = qlo; c0 < qhi; c0 += 1024) {
-      __builtin_amdgcn_wave_barrier();
-      for (int wi = lane; wi < 66; wi += 64) {
-        uint32_t c, bd;
-        stage16(qSeq, t.qLen, c0 + wi * 16, L.lut, c, bd);
-        qCodes[wi] = c;
-        reinterpret_cast<uint16_t *>(qBad)[wi] = (uint16_t)bd;
+      if (build) {
+        __builtin_amdgcn_wave_barrier();
+        for (int wi = lane; wi < 66; wi += 64) {
+          uint32_t c, bd;
+          stage16(qSeq, t.qLen, c0 + wi * 16, L.lut, c, bd);
+          qCodes[wi] = c;
+          reinterpret_cast<uint16_t *>(qBad)[wi] = (uint16_t)bd;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
       for (int j = 0; j < 16; j++) {
         const int x0 = c0 + 64 * j;
         if (x0 >= qhi) break;
         const int x = x0 + lane;
         const bool on = x < qhi;
         const int rel = x - c0;
-        const bool ok = on && bad_window(qBad, rel, kMask) == 0u;
-        const uint32_t km = code_window(qCodes, rel, kmerMask);
+        uint64_t h = 0;
         int cnt = 0, bs = 0, be = 0;
+        uint32_t km = 0;
         if (kWrite) {
-          if (on) cnt = (int)hits[x];
+          if (on) h = hits[x];
+          cnt = (int)(h & 0xffffu);
         }
-        if (ok && (!kWrite || cnt > 0)) {
-          const int b = idx_bucket(km);
-          bs = b ? (int)(ends[b - 1] >> 16) : 0;
-          be = (int)(ends[b] >> 16);
+        if (build) {
+          const bool ok = on && bad_window(qBad, rel, kMask) == 0u;
+          km = code_window(qCodes, rel, kmerMask);
+          if (ok && (!kWrite || cnt > 3)) {
+            const int b = idx_bucket(km);
+            bs = b ? (int)(ends[b - 1] >> 16) : 0;
+            be = (int)(ends[b] >> 16);
+          }
         }
         if (!kWrite) {
-          for (int i = bs; i < be; i++) cnt += code_window(L.tCodes, (int)L.entries[i], kmerMask) == km;
+          // walk the bucket four entries at a time: an entry matches iff its high k-mer bits equal the query's
+          const uint32_t hq = idx_high(km);
+          uint64_t pos3 = 0;
+          for (int g = bs & ~3; g < be; g += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(L.ent + g);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int i = g + u;
+              if ((w4[u] >> 16) == hq && i >= bs && i < be) {
+                if (cnt < 3) pos3 |= (uint64_t)(w4[u] & 0xffffu) << (16 * (cnt + 1));
+                cnt++;
+              }
+            }
+          }
           if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
-          if (on) hits[x] = (uint32_t)cnt;
+          if (cnt > 0xffff) cnt = 0xffff;  // cannot happen: a bucket holds < 65536 entries
+          if (on) hits[x] = cnt ? (pos3 | (uint64_t)cnt) : 0ull;
+          many = many || cnt > 3;
           nM += cnt;
         } else {
           const unsigned incl = wave_prefix_sum((unsigned)cnt);
           int w = wBase + (int)incl - cnt;
-          for (int i = bs; i < be; i++) {
-            const int pos = (int)L.entries[i];
-            if (code_window(L.tCodes, pos, kmerMask) == km) {
-              Frag f;
-              f.x = (uint32_t)x;
-              f.y = (uint32_t)pos;
-              f.len = (uint32_t)k;
-              f.pad = 0;
+          Frag f;
+          f.x = (uint32_t)x;
+          f.len = (uint32_t)k;
+          f.pad = 0;
+          if (cnt > 0 && cnt <= 3) {
+            for (int u = 0; u < cnt; u++) {
+              f.y = (uint32_t)((h >> (16 * (u + 1))) & 0xffffu);
               out[w++] = f;
+            }
+          } else if (cnt > 3) {  // only in a task whose index was rebuilt
+            const uint32_t hq = idx_high(km);
+            for (int i = bs; i < be; i++) {
+              const uint32_t v = L.ent[i];
+              if ((v >> 16) == hq) {
+                f.y = v & 0xffffu;
+                out[w++] = f;
+              }
             }
           }
           wBase += __builtin_amdgcn_readlane((int)incl, 63);
@@ -553,8 +604,12 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     const int qSuffixPos = t.qLen - qSuffixLength;
     if (!kWrite) {
       for (int off = 32; off > 0; off >>= 1) nM += __shfl_xor(nM, off);
+      const bool anyMany = __ballot(many) != 0ull;
       __syncthreads();
-      if (lane == 0) L.part[8 + wv] = (uint32_t)nM;
+      if (lane == 0) {
+        L.part[8 + wv] = (uint32_t)nM;
+        L.part[12 + wv] = anyMany ? 1u : 0u;
+      }
       __syncthreads();
     }
     if (wv == 0) {
@@ -562,6 +617,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       if (!kWrite && lane == 0) {
         lv.nRaw[3 * idx] = n0;
         lv.nRaw[3 * idx + 1] = (int)(L.part[8] + L.part[9] + L.part[10] + L.part[11]);
+        lv.idxFlag[idx] = (int)(L.part[12] | L.part[13] | L.part[14] | L.part[15]);
       }
     } else if (wv == 1) {
       const int n2 = small_part<kWrite>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
@@ -1991,24 +2047,30 @@ void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
 }
 int sdp_match_index_max_target(int device) {
   // the largest target one workgroup can index: bounded by the LDS a workgroup may allocate
-  int maxLds = 0;
-  if (hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) return 0;
-  int optin = 0;
-  if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > maxLds)
-    maxLds = optin;
-  int tCap = 0;
-  for (int c = 4096; c <= 61440; c += 1024)
-    if (idx_lds_bytes(c) <= maxLds) tCap = c;
-  if (tCap > kIdxSmallCap) {
-    const int bytes = (int)idx_lds_bytes(tCap);
+  int plain = 0, optin = 0;
+  if (hipDeviceGetAttribute(&plain, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess) optin = 0;
+  (void)hipGetLastError();
+  auto capFor = [](int bytes) {
+    int tCap = 0;
+    for (int c = 2048; c <= 61440; c += 1024)
+      if (idx_lds_bytes(c) <= bytes) tCap = c;
+    return tCap;
+  };
+  int tCap = capFor(std::min(plain, 65536));
+  const int want = std::max(plain, optin);
+  if (want > 65536) {
+    const int big = capFor(want);
+    const int bytes = (int)idx_lds_bytes(big);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sdp_match_index_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&sdp_match_index_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      tCap = kIdxSmallCap;
-    }
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess)
+      tCap = big;
+    (void)hipGetLastError();
   }
+  if (getenv("BLASR_HIP_SDP_TRACE"))
+    fprintf(stderr, "[sdp] LDS per workgroup %d (opt-in %d) -> indexed targets up to %d bases\n", plain, optin, tCap);
   return tCap;
 }
 void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
