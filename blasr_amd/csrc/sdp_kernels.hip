@@ -58,6 +58,11 @@ constexpr int kIdxSmallCap = 12288;  // targets up to this size: < 64 KB of LDS 
 __host__ __device__ inline bool task_uses_index(int tLen, int k, int idxMaxT) {
   return tLen >= kIdxMinT && tLen <= idxMaxT && k <= kIdxMaxK;
 }
+// ... and so do very short ones: their k-mers sit in registers, two per lane (sdp_match_kernel)
+constexpr int kTinyT = 128;
+__host__ __device__ inline bool task_needs_keys(int tLen, int k, int idxMaxT) {
+  return tLen > kTinyT && !task_uses_index(tLen, k, idxMaxT);
+}
 
 __device__ __forceinline__ int wave_task_index() {
   if (DEBUG_DCACHE_INV) __builtin_amdgcn_s_dcache_inv();
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
   const SdpTask t = lv.tasks[idx];
   uint64_t *keys = lv.keys + lv.keyOff[idx];
   const uint8_t *tSeq = seq + t.tOff;
-  if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // no sorted keys needed
+  if (!task_needs_keys(t.tLen, t.k, lv.idxMaxT)) return;
   const uint64_t invalid = 1ull << (kPosBits + 2 * t.k);
   for (int p0 = 0; p0 < t.tLen; p0 += 64) {
     const int p = p0 + lane;
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, u
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
-  if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;
+  if (!task_needs_keys(t.tLen, t.k, lv.idxMaxT)) return;
   uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
   bool inB;
   wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   // wavefront builds in LDS from the sorted keys (one pass), instead of ~2 x log2(tLen) dependent HBM reads.
   const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
   const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
-  const bool useBuckets = !kWrite && t.tLen >= 256;
+  const bool useBuckets = !kWrite && t.tLen >= 256;  // (t.tLen <= kTinyT takes the register path below)
   uint32_t *bucket = bucketStart[threadIdx.x >> 6];
   if (useBuckets) {
     const int nB = 1 << bBits;
@@ -673,7 +678,60 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   }
   int nM = 0;
   uint64_t *hits = lv.hits + lv.qPosOff[idx];  // per query position: first matching key | count << 32
-  for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
+  const bool tiny = t.tLen <= kTinyT;
+  if (tiny) {
+    // the target's k-mers in registers (positions lane and lane + 64); every query k-mer is compared with
+    // all of them in position order, which is the order of the sorted tuple list
+    auto kmer_at = [&](const uint8_t *sq, int p, int len, bool &ok) {
+      uint32_t v = 0;
+      ok = p + k <= len;
+      if (ok)
+        for (int j = 0; j < k; j++) {
+          const int c = base_code(sq[p + j]);
+          ok = ok && c < 4;
+          v |= (uint32_t)(c & 3) << (2 * j);
+        }
+      return v;
+    };
+    bool ok0, ok1;
+    const uint32_t tk0 = kmer_at(tSeq, lane, t.tLen, ok0), tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
+    const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+    for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
+      const int x = x0 + lane;
+      bool okq;
+      const uint32_t qk = kmer_at(qSeq, x, t.qLen, okq);
+      int cnt = 0;
+      for (unsigned long long m = m0; m != 0ull; m &= m - 1ull)
+        cnt += (uint32_t)__builtin_amdgcn_readlane((int)tk0, __builtin_ctzll(m)) == qk;
+      for (unsigned long long m = m1; m != 0ull; m &= m - 1ull)
+        cnt += (uint32_t)__builtin_amdgcn_readlane((int)tk1, __builtin_ctzll(m)) == qk;
+      if (!okq || (t.maxPerPos != 0 && cnt > t.maxPerPos)) cnt = 0;
+      const unsigned incl = wave_prefix_sum((unsigned)cnt);
+      if (kWrite && cnt > 0) {
+        int w = written + nM + (int)incl - cnt;
+        Frag f;
+        f.x = (uint32_t)x;
+        f.len = (uint32_t)k;
+        f.pad = 0;
+        for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
+          const int y = __builtin_ctzll(m);
+          if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
+            f.y = (uint32_t)y;
+            out[w++] = f;
+          }
+        }
+        for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
+          const int y = __builtin_ctzll(m);
+          if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
+            f.y = (uint32_t)(y + 64);
+            out[w++] = f;
+          }
+        }
+      }
+      nM += __builtin_amdgcn_readlane((int)incl, 63);
+    }
+  }
+  for (int x0 = 0; !tiny && x0 + k <= t.qLen; x0 += 64) {
     const int x = x0 + lane;
     int lo = 0, cnt = 0;
     if (x + k <= t.qLen) {
@@ -1914,7 +1972,7 @@ __global__ __launch_bounds__(256) void sdp_gather_sizes_kernel(SdpLevelArrays lv
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv.n) return;
   int64_t v;
-  if (what == 0) v = task_uses_index(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT) ? 0 : lv.tasks[i].tLen;
+  if (what == 0) v = task_needs_keys(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT) ? lv.tasks[i].tLen : 0;
   else if (what == 3) v = lv.tasks[i].qLen;
   else if (what == 1) v = (int64_t)lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
   else v = lv.nFrag[i];
