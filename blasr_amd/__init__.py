@@ -16,6 +16,13 @@ from .hip import (  # noqa: F401
     ScoreParams,
     SdpParams,
     load_library,
+    remove_low_quality,
+    remove_overlapping,
+    sort_candidates,
+    CANDIDATE_DTYPE,
+    INTERVAL_DTYPE,
+    READ_DTYPE,
+    WINDOW_DTYPE,
 )
 
 __all__ = ["BlasrHipError", "Context", "LIB_PATH", "RefineBatch", "RefineResult", "ScoreParams", "SdpParams", "load_library"]

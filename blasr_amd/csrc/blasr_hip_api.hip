@@ -125,6 +125,8 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   }
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   for (auto &sl : ctx->slabs) (void)hipFree(sl.first);
+  if (ctx->genome) (void)hipFree(ctx->genome);
+  if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
   delete ctx;
   return BLASR_HIP_OK;
 }

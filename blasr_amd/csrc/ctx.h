@@ -21,6 +21,11 @@ struct blasr_hip_ctx {
   int64_t sdpCounters[3] = {0, 0, 0};
   // grow-only slabs for the SDP stage's variable-size intermediates (bump-allocated per call)
   std::vector<std::pair<char *, size_t>> slabs;
+  // the resident genome (ASCII) and its contig table, for the window gather
+  uint8_t *genome = nullptr;
+  int64_t genomeLen = 0;
+  uint32_t *contigStarts = nullptr;
+  int nContigs = 0;
 };
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);

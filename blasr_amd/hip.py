@@ -27,7 +27,28 @@ EXPORTS = [
     "blasr_hip_abi_version", "blasr_hip_create", "blasr_hip_destroy", "blasr_hip_last_error",
     "blasr_hip_set_workspace_limit", "blasr_hip_stream", "blasr_hip_refine_device", "blasr_hip_refine_host",
     "blasr_hip_refine_last_timing", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
+    "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
+    "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
 ]
+
+# include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
+INTERVAL_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"), ("read", "<i4"),
+                           ("strand", "<i4")])
+READ_DTYPE = np.dtype([("off", "<i8"), ("length", "<u4"), ("subread_start", "<u4"), ("subread_end", "<u4"),
+                       ("reserved", "<u4")])
+WINDOW_DTYPE = np.dtype([("t_aligned_seq_pos", "<u4"), ("t_aligned_seq_length", "<u4"), ("t_strand", "<i4"),
+                         ("t_index", "<i4"), ("t_length", "<u4"), ("q_aligned_seq_pos", "<u4"),
+                         ("q_aligned_seq_length", "<u4"), ("q_length", "<u4")])
+CANDIDATE_DTYPE = np.dtype([("score", "<i4"), ("t_pos", "<u4"), ("t_aligned_seq_pos", "<u4"), ("t_end", "<u4"),
+                            ("t_index", "<i4"), ("t_strand", "<i4"), ("pct_similarity", "<f4"), ("n_blocks", "<i4"),
+                            ("blk_off", "<i8")])
+assert INTERVAL_DTYPE.itemsize == 24 and READ_DTYPE.itemsize == 24 and WINDOW_DTYPE.itemsize == 32
+assert CANDIDATE_DTYPE.itemsize == 40
+
+
+class _WindowParams(C.Structure):
+    _fields_ = [("approximate_max_insertion_rate", C.c_float), ("extend_ends", C.c_int32),
+                ("do_global_alignment", C.c_int32), ("reserved", C.c_int32)]
 
 # SMRTDistanceMatrix (ScoreMatrices.h:22-28): the matrix Blasr.cpp installs at :807-809
 SMRT_MATRIX = np.array(
@@ -138,8 +159,57 @@ def load_library():
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_SdpBatch), C.POINTER(_SdpParams),
                                            C.POINTER(_ScoreParams), C.c_void_p, C.c_void_p, C.c_int64,
                                            C.POINTER(C.c_int64)]
+        lib.blasr_hip_upload_genome.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        lib.blasr_hip_windows_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(_WindowParams), C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.blasr_hip_windows_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_int64, C.POINTER(_WindowParams), C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.blasr_hip_sort_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.blasr_hip_remove_low_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                     C.c_int32, C.c_int32]
+        lib.blasr_hip_remove_overlapping.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_float]
         _lib = lib
     return _lib
+
+
+# --- a-10: host-side ordering / pruning of a read's candidates (no device involved) ---------------
+def sort_candidates(cands, order=None):
+    """std::sort(alignmentPtrs, SortAlignmentPointersByScore()) (Blasr.cpp:226-236, :2547, :2178-2180).
+    cands: CANDIDATE_DTYPE array; returns the new order (indices into cands)."""
+    lib = load_library()
+    cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
+    order = np.arange(len(cands), dtype=np.int32) if order is None else np.ascontiguousarray(order, dtype=np.int32).copy()
+    n = lib.blasr_hip_sort_candidates(cands.ctypes.data, len(order), order.ctypes.data)
+    if n < 0:
+        raise BlasrHipError(n, "sort_candidates")
+    return order
+
+
+def remove_low_quality(cands, blocks, order, n_candidates=10, max_gap=0, max_score=-200):
+    """RemoveLowQualityAlignments (Blasr.cpp:2022-2079).  Returns (order, cands): cands[i].score may have been
+    set to max_score by the maxGap rule."""
+    lib = load_library()
+    cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE).copy()
+    order = np.ascontiguousarray(order, dtype=np.int32).copy()
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    n = lib.blasr_hip_remove_low_quality(cands.ctypes.data, blocks.ctypes.data if blocks.size else None, len(order),
+                                         order.ctypes.data, n_candidates, max_gap, max_score)
+    if n < 0:
+        raise BlasrHipError(n, "remove_low_quality")
+    return order[:n], cands
+
+
+def remove_overlapping(cands, order, min_pct_identity=0.0):
+    """RemoveOverlappingAlignments (Blasr.cpp:2081-2161)."""
+    lib = load_library()
+    cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
+    order = np.ascontiguousarray(order, dtype=np.int32).copy()
+    n = lib.blasr_hip_remove_overlapping(cands.ctypes.data, len(order), order.ctypes.data, float(min_pct_identity))
+    if n < 0:
+        raise BlasrHipError(n, "remove_overlapping")
+    return order[:n]
 
 
 class RefineBatch:
@@ -340,6 +410,55 @@ class Context:
                             stats=dict(score=int(r["stats_score"]), nMatch=int(r["n_match"]),
                                        nMismatch=int(r["n_mismatch"]), nIns=int(r["n_ins"]), nDel=int(r["n_del"]))))
         return out
+
+    # --- a-1: candidate windows from the resident genome (AlignIntervals, Blasr.cpp:1208-1336) ---
+    def upload_genome(self, genome, contig_starts=None):
+        genome = np.ascontiguousarray(genome, dtype=np.uint8)
+        self._genome_keepalive = genome
+        cs, nc = None, 0
+        if contig_starts is not None:
+            cs = np.ascontiguousarray(contig_starts, dtype=np.uint32)
+            nc = len(cs) - 1
+        self._check(self.lib.blasr_hip_upload_genome(self.handle, genome.ctypes.data, len(genome),
+                                                     cs.ctypes.data if cs is not None else None, nc))
+
+    @staticmethod
+    def _window_params(rate, extend_ends, do_global):
+        wp = _WindowParams()
+        wp.approximate_max_insertion_rate, wp.extend_ends, wp.do_global_alignment = rate, int(extend_ends), int(do_global)
+        return wp
+
+    def windows(self, intervals, reads, read_pool, rate=1.3, extend_ends=True, do_global=False, seq_capacity=None):
+        """intervals: INTERVAL_DTYPE array, reads: READ_DTYPE array, read_pool: uint8 ASCII.  Returns
+        (seq, q_off, q_len, t_off, t_len, windows) -- the first five are a blasr_hip_sdp_batch."""
+        intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        read_pool = np.ascontiguousarray(read_pool, dtype=np.uint8)
+        n = len(intervals)
+        if seq_capacity is None:
+            seq_capacity = int(sum(int(reads[iv["read"]]["length"]) * 4 + int(iv["end"] - iv["start"]) for iv in intervals)) + 64
+        seq = np.zeros(max(seq_capacity, 1), dtype=np.uint8)
+        q_off, t_off = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+        q_len, t_len = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        win = np.zeros(max(n, 1), dtype=WINDOW_DTYPE)
+        used = C.c_int64(0)
+        wp = self._window_params(rate, extend_ends, do_global)
+        rc = self.lib.blasr_hip_windows_host(self.handle, n, intervals.ctypes.data, len(reads), reads.ctypes.data,
+                                             read_pool.ctypes.data, len(read_pool), C.byref(wp), seq.ctypes.data,
+                                             seq_capacity, q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data,
+                                             t_len.ctypes.data, win.ctypes.data, C.byref(used))
+        self._check(rc)
+        return seq[: used.value], q_off[:n], q_len[:n], t_off[:n], t_len[:n], win[:n]
+
+    def windows_device(self, n, intervals_ptr, reads_ptr, read_pool_ptr, seq_ptr, seq_capacity, q_off_ptr, q_len_ptr,
+                       t_off_ptr, t_len_ptr, windows_ptr, rate=1.3, extend_ends=True, do_global=False):
+        """Raw device pointers (e.g. torch.Tensor.data_ptr()); returns the bytes written to seq."""
+        used = C.c_int64(0)
+        wp = self._window_params(rate, extend_ends, do_global)
+        self._check(self.lib.blasr_hip_windows_device(self.handle, n, intervals_ptr, reads_ptr, read_pool_ptr,
+                                                      C.byref(wp), seq_ptr, seq_capacity, q_off_ptr, q_len_ptr,
+                                                      t_off_ptr, t_len_ptr, windows_ptr, C.byref(used)))
+        return used.value
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()

@@ -216,6 +216,95 @@ int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch, con
  * [1] fragments chained, [2] SWAlign gap fills. */
 int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * a-1: candidate windows -- what AlignIntervals does before it calls SDPAlign
+ * (alignment/Blasr.cpp:1208-1336): stretch the anchor interval by approximateMaxInsertionRate x the
+ * unanchored read ends, clip to the genome / contig, copy the window (reverse-complemented for
+ * Reverse-strand intervals, DNASequence::CopyAsRC) next to the forward read's subread.
+ * The genome stays resident on the device.
+ * ------------------------------------------------------------------------------------------------ */
+/* WeightedInterval (datastructures/anchoring/WeightedInterval.h:12-29): the fields a task needs */
+typedef struct blasr_hip_interval {
+  uint32_t start, end;     /* genome span of the anchor cluster */
+  uint32_t q_start, q_end; /* read span of the anchor cluster, on the strand of the interval */
+  int32_t read;            /* index into the read table */
+  int32_t strand;          /* GetStrandIndex(): 0 Forward, 1 Reverse */
+} blasr_hip_interval;
+
+typedef struct blasr_hip_read {
+  int64_t off;             /* first base in the read pool (forward strand, ASCII) */
+  uint32_t length;
+  uint32_t subread_start;  /* SMRTSequence::subreadStart / subreadEnd */
+  uint32_t subread_end;
+  uint32_t reserved;
+} blasr_hip_read;
+
+typedef struct blasr_hip_window_params {
+  float approximate_max_insertion_rate; /* params.approximateMaxInsertionRate (1.30) */
+  int32_t extend_ends;                  /* params.extendEnds (1) */
+  int32_t do_global_alignment;          /* params.doGlobalAlignment (0) */
+  int32_t reserved;
+} blasr_hip_window_params;
+
+/* the T_AlignmentCandidate fields AlignIntervals sets here (Blasr.cpp:1291-1336) */
+typedef struct blasr_hip_window {
+  uint32_t t_aligned_seq_pos;    /* on the strand of the interval (:1309, :1323) */
+  uint32_t t_aligned_seq_length;
+  int32_t t_strand;
+  int32_t t_index;               /* contig (seqdb index), 0 without a contig table */
+  uint32_t t_length;             /* contig length as the reference computes it (:1291, :1301) */
+  uint32_t q_aligned_seq_pos;    /* read.subreadStart (:1332) */
+  uint32_t q_aligned_seq_length;
+  uint32_t q_length;             /* read.length */
+} blasr_hip_window;
+
+/* Keep `length` ASCII bases resident on the device.  contig_starts: n_contigs + 1 offsets
+ * (SequenceIndexDatabase::seqStartPos) or NULL when the genome is one sequence (useSeqDB = 0). */
+int blasr_hip_upload_genome(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length, const uint32_t *contig_starts,
+                            int32_t n_contigs);
+
+/* Device pointers throughout.  Writes, per interval, the query then the target window into seq_out and
+ * the (q_off, q_len, t_off, t_len) arrays of a blasr_hip_sdp_batch over seq_out.  *seq_used (host)
+ * receives the bytes needed; BLASR_HIP_ERR_CAPACITY when seq_capacity is too small. */
+int blasr_hip_windows_device(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_interval *intervals,
+                             const blasr_hip_read *reads, const uint8_t *read_pool,
+                             const blasr_hip_window_params *params, uint8_t *seq_out, int64_t seq_capacity,
+                             int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len,
+                             blasr_hip_window *windows, int64_t *seq_used);
+/* Same with host pointers (n_reads / read_pool_bytes size the uploads). */
+int blasr_hip_windows_host(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_interval *intervals, int32_t n_reads,
+                           const blasr_hip_read *reads, const uint8_t *read_pool, int64_t read_pool_bytes,
+                           const blasr_hip_window_params *params, uint8_t *seq_out, int64_t seq_capacity,
+                           int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len,
+                           blasr_hip_window *windows, int64_t *seq_used);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-10: ordering and pruning of a read's candidates between the stages (host code in the reference
+ * and here; <= nCandidates records per read): SortAlignmentPointersByScore (Blasr.cpp:226-236),
+ * RemoveLowQualityAlignments (:2022-2079), RemoveOverlappingAlignments (:2081-2161).
+ * `order` lists the live candidates (indices into `cands`), is rewritten in place, and the return
+ * value is the new count (< 0: error).  No device is involved.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_candidate {
+  int32_t score;
+  uint32_t t_pos;
+  uint32_t t_aligned_seq_pos;
+  uint32_t t_end;          /* Alignment::TEnd(): tPos + length of the last block, 0 without blocks */
+  int32_t t_index;
+  int32_t t_strand;
+  float pct_similarity;
+  int32_t n_blocks;
+  int64_t blk_off;         /* first (qPos,tPos,length) triplet of this candidate in `blocks` */
+} blasr_hip_candidate;
+
+int blasr_hip_sort_candidates(const blasr_hip_candidate *cands, int32_t n, int32_t *order);
+/* may overwrite cands[i].score with max_score (the maxGap flagging of :2031-2046) */
+int blasr_hip_remove_low_quality(blasr_hip_candidate *cands, const int32_t *blocks, int32_t n, int32_t *order,
+                                 int32_t n_candidates, int32_t max_gap, int32_t max_score);
+int blasr_hip_remove_overlapping(const blasr_hip_candidate *cands, int32_t n, int32_t *order,
+                                 float min_pct_identity);
+
 #ifdef __cplusplus
 }
 #endif

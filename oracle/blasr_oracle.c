@@ -1550,3 +1550,152 @@ int bo_refine_candidate(const unsigned char *q, int qlen, const unsigned char *t
   aln_free(&sdp);
   return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* a-1: window / strand set-up of AlignIntervals (alignment/Blasr.cpp:1208-1336) */
+/* ------------------------------------------------------------------------- */
+/* out[8]: tAlignedSeqPos (on the strand of the interval), tAlignedSeqLength, tStrand, tIndex,
+ * tLength, qAlignedSeqPos, qAlignedSeqLength, first base of the window on the FORWARD genome */
+void bo_interval_window(unsigned genomeLen, unsigned readLen, unsigned subreadStart, unsigned subreadEnd,
+                        unsigned ivStart, unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand,
+                        const unsigned *contigStarts, int nContigs, float approximateMaxInsertionRate,
+                        int extendEnds, int doGlobalAlignment, int *out) {
+  unsigned matchIntervalStart = ivStart, matchIntervalEnd = ivEnd; /* :1208-1210 */
+  /* :1243-1248 the subread on the strand of the interval */
+  unsigned sStart = subreadStart, sEnd = subreadEnd;
+  if (strand == 1) {
+    sEnd = (readLen - subreadStart - 1) + 1;
+    sStart = readLen - (subreadEnd - 1) - 1;
+  }
+  if (extendEnds) { /* :1250-1266, float arithmetic exactly as written there */
+    unsigned lengthBeforeFirstMatch = (unsigned)((ivQStart - sStart) * approximateMaxInsertionRate);
+    unsigned lengthAfterLastMatch = (unsigned)((sEnd - ivQEnd) * approximateMaxInsertionRate);
+    if (matchIntervalStart < lengthBeforeFirstMatch || doGlobalAlignment) matchIntervalStart = 0;
+    else matchIntervalStart -= lengthBeforeFirstMatch;
+    if (genomeLen < matchIntervalEnd + lengthAfterLastMatch || doGlobalAlignment) matchIntervalEnd = genomeLen;
+    else matchIntervalEnd += lengthAfterLastMatch;
+  }
+  int tIndex = 0;
+  unsigned tLength;
+  if (contigStarts != NULL) { /* :1272-1298 */
+    int nSeqPos = nContigs + 1, idx = 0;
+    if (nSeqPos != 1) { /* SequenceIndexDatabase.h:108-118: upper_bound over seqStartPos[1..] */
+      int lo = 1, hi = nSeqPos;
+      while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (!(ivStart < contigStarts[mid])) lo = mid + 1;
+        else hi = mid;
+      }
+      idx = lo - 1;
+    }
+    unsigned contigStartPos = contigStarts[idx];
+    if (contigStartPos > matchIntervalStart) matchIntervalStart = contigStartPos;
+    unsigned contigEndPos = contigStarts[idx + 1] - 1;
+    if (contigEndPos < matchIntervalEnd) matchIntervalEnd = contigEndPos;
+    tLength = contigEndPos - contigStartPos;
+    tIndex = idx;
+  } else
+    tLength = genomeLen; /* :1300-1304 */
+  unsigned tAlignedSeqPos = matchIntervalStart, tAlignedSeqLength = matchIntervalEnd - matchIntervalStart; /* :1309-1310 */
+  out[7] = (int)tAlignedSeqPos;
+  if (strand == 1) /* :1316-1324: the window is copied as its reverse complement and re-addressed on that strand */
+    tAlignedSeqPos = genomeLen - (tAlignedSeqPos + tAlignedSeqLength - 1) - 1;
+  out[0] = (int)tAlignedSeqPos;
+  out[1] = (int)tAlignedSeqLength;
+  out[2] = strand == 1 ? 1 : 0;
+  out[3] = tIndex;
+  out[4] = (int)tLength;
+  out[5] = (int)subreadStart;          /* :1332 always the forward read */
+  out[6] = (int)(sEnd - sStart);       /* :1333-1334 */
+}
+
+/* DNASequence::Copy / CopyAsRC (DNASequence.h:219-233) with ReverseComplementNuc (NucConversion.h:337-370) */
+static unsigned char bo_rc_nuc(unsigned char c) {
+  if (c < 4) return (unsigned char)(3 - c);
+  switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'N': return 'N';
+    case 'a': return 't';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    case 't': return 'a';
+    case 'n': return 'n';
+    default: return 127;
+  }
+}
+void bo_copy_window(const unsigned char *genome, unsigned fwdStart, unsigned len, int strand, unsigned char *out) {
+  for (unsigned i = 0; i < len; i++)
+    out[i] = strand == 1 ? bo_rc_nuc(genome[fwdStart + len - 1 - i]) : genome[fwdStart + i];
+}
+
+/* ------------------------------------------------------------------------- */
+/* a-10: candidate ordering and pruning (alignment/Blasr.cpp:226-236, 2022-2161)  */
+/* ------------------------------------------------------------------------- */
+/* std::sort(alignmentPtrs, SortAlignmentPointersByScore): (score, tPos + tAlignedSeqPos); order[] in/out */
+void bo_sort_by_score(int n, const int *score, const unsigned *tPos, const unsigned *tAlignedSeqPos, int *order) {
+  frag_t *f = (frag_t *)calloc(n > 0 ? n : 1, sizeof(frag_t));
+  for (int i = 0; i < n; i++) {
+    const int c = order[i];
+    f[i].x = (uint32_t)score[c] ^ 0x80000000u; /* order-preserving image of the signed score */
+    f[i].y = tPos[c] + tAlignedSeqPos[c];
+    f[i].index = c;
+  }
+  introsort_frags(f, n);
+  for (int i = 0; i < n; i++) order[i] = f[i].index;
+  free(f);
+}
+
+/* RemoveLowQualityAlignments (:2022-2079); score[] may be modified (maxGap flagging); returns the new count */
+int bo_remove_low_quality(int n, int *order, int *score, const int *blocks, const int *blkOff, const int *nBlocks,
+                          int nCandidates, int maxGap, int maxScore) {
+  const int lim = nCandidates < n ? nCandidates : n;
+  for (int i = 0; i < lim; i++) {
+    const int c = order[i];
+    if (maxGap > 0) {
+      for (int j = 1; j < nBlocks[c]; j++) {
+        const int *b = blocks + 3 * (blkOff[c] + j), *p = b - 3;
+        const int gq = (int)((unsigned)b[0] - (unsigned)p[0] - (unsigned)b[2]);
+        const int gt = (int)((unsigned)b[1] - (unsigned)p[1] - (unsigned)b[2]);
+        if ((gq >= maxGap && gt < maxGap) || (gt > maxGap && gq < maxGap)) {
+          score[c] = maxScore;
+          break;
+        }
+      }
+    }
+    if (nBlocks[c] == 0 || score[c] > maxScore) return i; /* this and everything after it goes */
+  }
+  return n;
+}
+
+/* RemoveOverlappingAlignments (:2081-2161); tEnd = Alignment::TEnd() of every candidate */
+int bo_remove_overlapping(int n, int *order, const int *score, const unsigned *tPos, const unsigned *tAlignedSeqPos,
+                          const unsigned *tEnd, const int *tIndex, const int *tStrand, const float *pctSimilarity,
+                          float minPctIdentity) {
+  unsigned char *contained = (unsigned char *)calloc(n > 0 ? n : 1, 1);
+  if (n > 0) {
+    for (int i = 0; i < n - 1; i++) {
+      const int a = order[i];
+      if (pctSimilarity[a] < minPctIdentity) continue;
+      const unsigned aB = tAlignedSeqPos[a] + tPos[a], aE = aB + tEnd[a];
+      for (int j = i + 1; j < n; j++) {
+        if (contained[j]) continue;
+        const int b = order[j];
+        if (tIndex[a] != tIndex[b]) continue;
+        const unsigned bB = tAlignedSeqPos[b] + tPos[b], bE = bB + tEnd[b];
+        if (aB <= bB && aE >= bE && tStrand[a] == tStrand[b]) {
+          if (score[a] <= score[b]) contained[j] = 1;
+        } else if (bB <= aB && bE >= aE && tStrand[a] == tStrand[b]) {
+          if (score[b] <= score[a]) contained[i] = 1;
+        }
+      }
+    }
+  }
+  int kept = 0;
+  for (int i = 0; i < n; i++)
+    if (!contained[i]) order[kept++] = order[i];
+  free(contained);
+  return kept;
+}

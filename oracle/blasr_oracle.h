@@ -81,6 +81,25 @@ int bo_refine_candidate(const unsigned char *q, int qlen, const unsigned char *t
                         int *gapCounts, int gapListCap, int *nGapLists, int *gapItems,
                         int gapItemCap, int *nGapItems);
 
+/* a-1: window / strand set-up of AlignIntervals (alignment/Blasr.cpp:1208-1336).  out[8]:
+ * tAlignedSeqPos (on the interval's strand), tAlignedSeqLength, tStrand, tIndex, tLength,
+ * qAlignedSeqPos, qAlignedSeqLength, first base of the window on the forward genome. */
+void bo_interval_window(unsigned genomeLen, unsigned readLen, unsigned subreadStart, unsigned subreadEnd,
+                        unsigned ivStart, unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand,
+                        const unsigned *contigStarts, int nContigs, float approximateMaxInsertionRate,
+                        int extendEnds, int doGlobalAlignment, int *out);
+void bo_copy_window(const unsigned char *genome, unsigned fwdStart, unsigned len, int strand, unsigned char *out);
+
+/* a-10: SortAlignmentPointersByScore, RemoveLowQualityAlignments, RemoveOverlappingAlignments
+ * (alignment/Blasr.cpp:226-236, 2022-2079, 2081-2161) on parallel arrays; order[] lists the live
+ * candidates and is rewritten in place, the return value is the new count. */
+void bo_sort_by_score(int n, const int *score, const unsigned *tPos, const unsigned *tAlignedSeqPos, int *order);
+int bo_remove_low_quality(int n, int *order, int *score, const int *blocks, const int *blkOff, const int *nBlocks,
+                          int nCandidates, int maxGap, int maxScore);
+int bo_remove_overlapping(int n, int *order, const int *score, const unsigned *tPos, const unsigned *tAlignedSeqPos,
+                          const unsigned *tEnd, const int *tIndex, const int *tStrand, const float *pctSimilarity,
+                          float minPctIdentity);
+
 #ifdef __cplusplus
 }
 #endif

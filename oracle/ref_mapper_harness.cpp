@@ -1,0 +1,165 @@
+// oracle/ref_mapper_harness.cpp -- TEST INFRASTRUCTURE, never on the product path.
+//
+// Compiles the reference mapper's own translation unit (alignment/Blasr.cpp, where it lies under
+// $(BLASR_REF); nothing is copied) with its main() renamed, and exposes the two host-side pieces of
+// SURVEY.md section 8 that only exist inside that file behind a C shim:
+//   a-1  the window / strand set-up of AlignIntervals  (Blasr.cpp:1152-1336), followed by the
+//        default SDPAlign + ComputeAlignmentStats call (:1716-1724)
+//   a-10 SortAlignmentPointersByScore (:226-236), RemoveLowQualityAlignments (:2022-2079),
+//        RemoveOverlappingAlignments (:2081-2161)
+// Output: oracle/_ref/libblasr_refmapper.so (git-ignored, travels to the GPU box prebuilt).
+#define main blasr_reference_main
+#include "Blasr.cpp"
+#undef main
+
+#include <cstring>
+
+extern "C" {
+
+// One interval through the reference's AlignIntervals.  contigStarts: nContigs+1 offsets (seqdb
+// seqStartPos) or NULL for a single-contig genome.  out[16]:
+//  0 tAlignedSeqPos 1 tAlignedSeqLength 2 tStrand 3 tIndex 4 tLength 5 qAlignedSeqPos
+//  6 qAlignedSeqLength 7 qPos 8 tPos 9 nBlocks 10 score 11 nMatch 12 nMismatch 13 nIns 14 nDel
+//  15 qLength
+int ref_align_interval(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
+                       unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
+                       unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand, const unsigned *contigStarts,
+                       int nContigs, float approximateMaxInsertionRate, int extendEnds, int sdpTupleSize, int *out,
+                       unsigned char *tSeqOut, int tSeqCap, int *blocksOut, int blocksCap) {
+  MappingParameters params;
+  params.MakeSane();
+  params.approximateMaxInsertionRate = approximateMaxInsertionRate;
+  params.extendEnds = extendEnds != 0;
+  params.sdpTupleSize = sdpTupleSize;
+
+  T_GenomeSequence genome;
+  genome.seq = (Nucleotide *)genomeSeq;
+  genome.length = genomeLen;
+  genome.deleteOnExit = false;
+  genome.title = (char *)"genome";
+  genome.titleLength = 6;
+
+  T_Sequence read, readRC;
+  read.seq = (Nucleotide *)readSeq;
+  read.length = readLen;
+  read.deleteOnExit = false;
+  read.title = (char *)"read";
+  read.titleLength = 4;
+  read.subreadStart = subreadStart;
+  read.subreadEnd = subreadEnd;
+  read.MakeRC(readRC);
+  readRC.subreadStart = read.MakeRCCoordinate(read.subreadEnd - 1);
+  readRC.subreadEnd = read.MakeRCCoordinate(read.subreadStart) + 1;
+
+  SequenceIndexDatabase<FASTASequence> seqdb;
+  if (contigStarts != NULL) {
+    seqdb.seqStartPos = const_cast<DNALength *>(contigStarts);
+    seqdb.nSeqPos = nContigs + 1;
+    seqdb.names = new char *[nContigs];
+    seqdb.nameLengths = new int[nContigs];
+    seqdb.deleteStructures = false;
+    for (int i = 0; i < nContigs; i++) {
+      seqdb.names[i] = (char *)"c";
+      seqdb.nameLengths[i] = 1;
+    }
+  }
+
+  WeightedIntervalSet<ChainedMatchPos> intervals;
+  WeightedInterval<ChainedMatchPos> iv(ivEnd - ivStart, ivStart, ivEnd, strand, 0.0);
+  iv.qStart = ivQStart;
+  iv.qEnd = ivQEnd;
+  iv.qLength = readLen;
+  intervals.insert(iv);
+
+  vector<T_AlignmentCandidate *> alignments(1);
+  alignments[0] = new T_AlignmentCandidate;
+  MappingBuffers buffers;
+  AlignIntervals(genome, read, readRC, intervals, SMRTDistanceMatrix, params.indel, params.indel, params.sdpTupleSize,
+                 contigStarts != NULL, seqdb, alignments, params, params.useScoreCutoff, params.maxScore, buffers, 0);
+  T_AlignmentCandidate &a = *alignments[0];
+  out[0] = (int)a.tAlignedSeqPos;
+  out[1] = (int)a.tAlignedSeqLength;
+  out[2] = a.tStrand;
+  out[3] = a.tIndex;
+  out[4] = (int)a.tLength;
+  out[5] = (int)a.qAlignedSeqPos;
+  out[6] = (int)a.qAlignedSeqLength;
+  out[7] = (int)a.qPos;
+  out[8] = (int)a.tPos;
+  out[9] = (int)a.blocks.size();
+  out[10] = a.score;
+  out[11] = a.nMatch;
+  out[12] = a.nMismatch;
+  out[13] = a.nIns;
+  out[14] = a.nDel;
+  out[15] = (int)a.qLength;
+  int rc = 0;
+  if ((int)a.tAlignedSeq.length > tSeqCap || (int)a.blocks.size() > blocksCap) rc = -1;
+  else {
+    memcpy(tSeqOut, a.tAlignedSeq.seq, a.tAlignedSeq.length);
+    for (size_t b = 0; b < a.blocks.size(); b++) {
+      blocksOut[3 * b] = (int)a.blocks[b].qPos;
+      blocksOut[3 * b + 1] = (int)a.blocks[b].tPos;
+      blocksOut[3 * b + 2] = (int)a.blocks[b].length;
+    }
+  }
+  delete alignments[0];
+  readRC.Free();
+  if (contigStarts != NULL) {
+    delete[] seqdb.names;
+    delete[] seqdb.nameLengths;
+    seqdb.names = NULL;
+    seqdb.nameLengths = NULL;
+    seqdb.seqStartPos = NULL;
+  }
+  return rc;
+}
+
+// The post filters on n candidates given as parallel arrays.  op: 0 = std::sort with
+// SortAlignmentPointersByScore, 1 = RemoveLowQualityAlignments, 2 = RemoveOverlappingAlignments.
+// keptIdx / keptScore receive the surviving candidates in their final order; returns their number.
+int ref_post_filter(int op, int n, const int *score, const unsigned *tPos, const unsigned *tAlignedSeqPos,
+                    const int *tIndex, const int *tStrand, const float *pctSimilarity, const int *blocks,
+                    const int *blkOff, const int *nBlocks, int nCandidates, int maxGap, int maxScore,
+                    float minPctIdentity, int *keptIdx, int *keptScore) {
+  MappingParameters params;
+  params.MakeSane();
+  params.nCandidates = nCandidates;
+  params.maxGap = maxGap;
+  params.maxScore = maxScore;
+  params.minPctIdentity = minPctIdentity;
+  vector<T_AlignmentCandidate *> ptrs(n);
+  for (int i = 0; i < n; i++) {
+    T_AlignmentCandidate *a = new T_AlignmentCandidate;
+    a->score = score[i];
+    a->tPos = tPos[i];
+    a->tAlignedSeqPos = tAlignedSeqPos[i];
+    a->tIndex = tIndex[i];
+    a->tStrand = tStrand[i];
+    a->pctSimilarity = pctSimilarity[i];
+    a->nCells = i;  // carries the candidate's identity through the filters
+    for (int b = 0; b < nBlocks[i]; b++) {
+      Block blk;
+      blk.qPos = blocks[3 * (blkOff[i] + b)];
+      blk.tPos = blocks[3 * (blkOff[i] + b) + 1];
+      blk.length = blocks[3 * (blkOff[i] + b) + 2];
+      a->blocks.push_back(blk);
+    }
+    ptrs[i] = a;
+  }
+  if (op == 0) std::sort(ptrs.begin(), ptrs.end(), SortAlignmentPointersByScore());
+  else if (op == 1) {
+    T_Sequence read;
+    RemoveLowQualityAlignments(read, ptrs, params);
+  } else
+    RemoveOverlappingAlignments(ptrs, params);
+  const int kept = (int)ptrs.size();
+  for (int i = 0; i < kept; i++) {
+    keptIdx[i] = ptrs[i]->nCells;
+    keptScore[i] = ptrs[i]->score;
+    delete ptrs[i];
+  }
+  return kept;
+}
+
+}  // extern "C"

@@ -208,3 +208,173 @@ def ops_from_alignment(res):
             for j in range(starts[b + 1], starts[b + 2]):
                 ops.append((1 if gi[j, 0] == GAP_TARGET else 2, int(gi[j, 1])))
     return ops
+
+
+# ---------------------------------------------------------------------------------------------
+# a-1 / a-10: window set-up of AlignIntervals and the candidate filters.  The oracle restates them
+# (oracle/blasr_oracle.c: bo_interval_window, bo_copy_window, bo_sort_by_score, bo_remove_*); the
+# reference's own code is reached through oracle/_ref/libblasr_refmapper.so (ref_mapper_harness.cpp).
+# ---------------------------------------------------------------------------------------------
+REFMAPPER_SO = os.path.join(ROOT, "oracle", "_ref", "libblasr_refmapper.so")
+WINDOW_FIELDS = ("tAlignedSeqPos", "tAlignedSeqLength", "tStrand", "tIndex", "tLength", "qAlignedSeqPos",
+                 "qAlignedSeqLength")
+
+
+def _pu(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint))
+
+
+class MapperOracle:
+    """bo_interval_window / bo_copy_window / filters of the plain-C oracle."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        self.lib = C.CDLL(ORACLE_SO)
+
+    def window(self, genome, read_len, subread, iv, contigs=None, rate=1.3, extend_ends=1, do_global=0):
+        """iv = (start, end, qStart, qEnd, strand).  Returns (fields dict, target window bytes)."""
+        genome = _u8(genome)
+        cs = None if contigs is None else np.ascontiguousarray(contigs, dtype=np.uint32)
+        out = np.zeros(8, dtype=np.int32)
+        self.lib.bo_interval_window(len(genome), int(read_len), int(subread[0]), int(subread[1]), int(iv[0]), int(iv[1]),
+                                    int(iv[2]), int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
+                                    C.c_float(rate), int(extend_ends), int(do_global), _p(out))
+        t = np.zeros(max(int(out[1]), 1), dtype=np.uint8)
+        self.lib.bo_copy_window(_p(genome, C.c_ubyte), C.c_uint(int(out[7]) & 0xffffffff), int(out[1]), int(out[2]),
+                                _p(t, C.c_ubyte))
+        return dict(zip(WINDOW_FIELDS, (int(v) & 0xffffffff for v in out[:7]))), t[: int(out[1])]
+
+    def sort_by_score(self, score, t_pos, t_aligned_seq_pos, order=None):
+        score = np.ascontiguousarray(score, dtype=np.int32)
+        order = np.arange(len(score), dtype=np.int32) if order is None else np.ascontiguousarray(order, np.int32).copy()
+        self.lib.bo_sort_by_score(len(order), _p(score), _pu(np.ascontiguousarray(t_pos, np.uint32)),
+                                  _pu(np.ascontiguousarray(t_aligned_seq_pos, np.uint32)), _p(order))
+        return order
+
+    def remove_low_quality(self, order, score, blocks, blk_off, n_blocks, n_candidates, max_gap, max_score):
+        order = np.ascontiguousarray(order, np.int32).copy()
+        score = np.ascontiguousarray(score, np.int32).copy()
+        blocks = np.ascontiguousarray(blocks, np.int32).reshape(-1)
+        if blocks.size == 0:
+            blocks = np.zeros(3, np.int32)
+        n = self.lib.bo_remove_low_quality(len(order), _p(order), _p(score), _p(blocks),
+                                           _p(np.ascontiguousarray(blk_off, np.int32)),
+                                           _p(np.ascontiguousarray(n_blocks, np.int32)), n_candidates, max_gap, max_score)
+        return order[:n], score
+
+    def remove_overlapping(self, order, score, t_pos, t_aligned_seq_pos, t_end, t_index, t_strand, pct, min_pct):
+        order = np.ascontiguousarray(order, np.int32).copy()
+        pct = np.ascontiguousarray(pct, np.float32)
+        n = self.lib.bo_remove_overlapping(len(order), _p(order), _p(np.ascontiguousarray(score, np.int32)),
+                                           _pu(np.ascontiguousarray(t_pos, np.uint32)),
+                                           _pu(np.ascontiguousarray(t_aligned_seq_pos, np.uint32)),
+                                           _pu(np.ascontiguousarray(t_end, np.uint32)),
+                                           _p(np.ascontiguousarray(t_index, np.int32)),
+                                           _p(np.ascontiguousarray(t_strand, np.int32)),
+                                           pct.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(min_pct))
+        return order[:n]
+
+
+class MapperRef:
+    """The reference mapper's own AlignIntervals / filters (ref_mapper_harness.cpp)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(REFMAPPER_SO)
+
+    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11):
+        genome, read = _u8(genome), _u8(read)
+        cs = None if contigs is None else np.ascontiguousarray(contigs, dtype=np.uint32)
+        out = np.zeros(16, dtype=np.int32)
+        cap = len(genome) + 16
+        tseq = np.zeros(cap, dtype=np.uint8)
+        blocks = np.zeros(3 * (len(read) + 16), dtype=np.int32)
+        rc = self.lib.ref_align_interval(_p(genome, C.c_ubyte), len(genome), _p(read, C.c_ubyte), len(read),
+                                         int(subread[0]), int(subread[1]), int(iv[0]), int(iv[1]), int(iv[2]),
+                                         int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
+                                         C.c_float(rate), int(extend_ends), int(k), _p(out), _p(tseq, C.c_ubyte), cap,
+                                         _p(blocks), len(read) + 16)
+        assert rc == 0
+        win = dict(zip(WINDOW_FIELDS, (int(v) & 0xffffffff for v in out[:7])))
+        sdp = dict(qPos=int(out[7]), tPos=int(out[8]), blocks=blocks[: 3 * int(out[9])].reshape(-1, 3).copy(),
+                   score=int(out[10]), nMatch=int(out[11]), nMismatch=int(out[12]), nIns=int(out[13]), nDel=int(out[14]))
+        return win, tseq[: int(out[1])].copy(), sdp
+
+    def post_filter(self, op, score, t_pos, t_aligned_seq_pos, t_index, t_strand, pct, blocks, blk_off, n_blocks,
+                    n_candidates=10, max_gap=0, max_score=-200, min_pct=0.0):
+        n = len(score)
+        kept_idx, kept_score = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        blocks = np.ascontiguousarray(blocks, np.int32).reshape(-1)
+        if blocks.size == 0:
+            blocks = np.zeros(3, np.int32)
+        pct = np.ascontiguousarray(pct, np.float32)
+        k = self.lib.ref_post_filter(op, n, _p(np.ascontiguousarray(score, np.int32)),
+                                     _pu(np.ascontiguousarray(t_pos, np.uint32)),
+                                     _pu(np.ascontiguousarray(t_aligned_seq_pos, np.uint32)),
+                                     _p(np.ascontiguousarray(t_index, np.int32)),
+                                     _p(np.ascontiguousarray(t_strand, np.int32)),
+                                     pct.ctypes.data_as(C.POINTER(C.c_float)), _p(blocks),
+                                     _p(np.ascontiguousarray(blk_off, np.int32)),
+                                     _p(np.ascontiguousarray(n_blocks, np.int32)), n_candidates, max_gap, max_score,
+                                     C.c_float(min_pct), _p(kept_idx), _p(kept_score))
+        return kept_idx[:k].copy(), kept_score[:k].copy()
+
+
+def load_refmapper():
+    return MapperRef() if os.path.exists(REFMAPPER_SO) else None
+
+
+def random_interval_case(rng, genome, it):
+    """A read drawn from `genome` and a plausible anchor interval for it (all the corner cases of
+    Blasr.cpp:1243-1298 come up over `it`: both strands, windows clipped at the genome / contig ends)."""
+    from blasr_amd import synth
+    rl = int(rng.integers(300, 3000))
+    pos = int(rng.integers(0, len(genome) - rl))
+    strand = int(rng.integers(0, 2))
+    tmpl = genome[pos:pos + rl]
+    if strand:
+        tmpl = synth.revcomp(tmpl)
+    read = np.ascontiguousarray(synth.mutate(tmpl, rng, 0.11, 0.04, 0.01))
+    L = len(read)
+    ss, se = int(rng.integers(0, 20)), L - int(rng.integers(0, 20))
+    sS, sE = (ss, se) if strand == 0 else (L - se, L - ss)
+    qS, qE = sS + int(rng.integers(0, 100)), sE - int(rng.integers(0, 100))
+    g0, g1 = pos + int(rng.integers(0, 120)), pos + rl - int(rng.integers(0, 120))
+    if it % 7 == 0:
+        g0 = int(rng.integers(0, 50))
+    if it % 11 == 0:
+        g1 = len(genome) - int(rng.integers(0, 50))
+        g0 = min(g0, g1 - 10)
+    contigs = None
+    if it % 3 == 0:
+        cuts = sorted(set([0, len(genome)] + [int(x) for x in rng.integers(1000, len(genome) - 1000, 3)]))
+        contigs = np.array(cuts, dtype=np.uint32)
+    return read, (ss, se), (g0, g1, qS, qE, strand), contigs
+
+
+def random_candidates(rng, n):
+    """n candidates with the collisions the filters care about: equal scores, equal positions,
+    containment on the same / different strand and contig, empty block lists, large gaps."""
+    score = rng.choice([-900, -700, -700, -450, -200, -199, -50], size=n).astype(np.int32)
+    base = rng.choice([1000, 1000, 5000, 9000], size=n).astype(np.uint32)
+    t_aligned_seq_pos = (base + rng.integers(0, 3, size=n)).astype(np.uint32)
+    t_pos = rng.integers(0, 4, size=n).astype(np.uint32)
+    t_index = rng.choice([0, 0, 0, 1], size=n).astype(np.int32)
+    t_strand = rng.choice([0, 0, 1], size=n).astype(np.int32)
+    pct = rng.choice([60.0, 75.0, 88.5], size=n).astype(np.float32)
+    blocks, blk_off, n_blocks, t_end = [], [], [], []
+    for i in range(n):
+        nb = int(rng.choice([0, 1, 3, 6]))
+        blk_off.append(len(blocks))
+        n_blocks.append(nb)
+        q = t = 0
+        for b in range(nb):
+            ln = int(rng.integers(5, 40))
+            blocks.append((q, t, ln))
+            q += ln + int(rng.choice([0, 1, 2, 30]))
+            t += ln + int(rng.choice([0, 1, 2, 30]))
+        t_end.append(blocks[-1][1] + blocks[-1][2] if nb else 0)
+    blocks = np.array(blocks, dtype=np.int32).reshape(-1, 3)
+    return dict(score=score, t_pos=t_pos, t_aligned_seq_pos=t_aligned_seq_pos, t_index=t_index, t_strand=t_strand,
+                pct=pct, blocks=blocks, blk_off=np.array(blk_off, np.int32), n_blocks=np.array(n_blocks, np.int32),
+                t_end=np.array(t_end, np.uint32))
