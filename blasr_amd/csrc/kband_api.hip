@@ -1,0 +1,417 @@
+// kband_api.hip -- a-11: AffineKBandAlign, Global (algorithms/alignment/AffineKBandAlign.h:12-401), the
+// refiner PairwiseLocalAlign runs under -noUseGuidedAlign (alignment/Blasr.cpp:675-746).
+//
+// Fixed band of nCols = 2k+1 columns, column = k + t - q; three matrices: S, affine insertion I, affine
+// homopolymer insertion HP (extension only where q[i] == q[i-1]), linear deletion.
+//   kband_plan_kernel       SetKBoundedLengths (KBandAlign.h:36-56), matrix sizes
+//   kband_fill_kernel       one wavefront per task, a row at a time in 64-column chunks.  I and HP only look
+//                           up; the horizontal (deletion) dependency is linear, so S of a row is one
+//                           prefix-min scan of V[c] - c*del with a carry between chunks.  The rows live in
+//                           LDS and are updated in place; one packed arrow byte per cell goes to HBM.
+//   kband_traceback_kernel  one lane per task: the three-matrix walk of :299-391, run-length encoded into the
+//                           same op arena the guided refiner uses (M / I / D), then the shared compaction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/blasr_hip.h"
+#include "ctx.h"
+#include "refine_kernels.h"
+#include "wave_utils.h"
+
+namespace blasr_hip {
+
+constexpr int kKbMaxCols = 1088;       // widest band held in LDS (k <= 543)
+constexpr int kKbInf = 1 << 28;        // "no such cell": any value above every real score and safe to add to
+// arrow byte: bits 0-1 S arrow (pathMat), bit 2 insPathMat is AffineInsOpen, bit 3 hpInsPathMat is AffineHPInsOpen
+enum { KB_DIAG = 0, KB_LEFT = 1, KB_INS_CLOSE = 2, KB_HP_CLOSE = 3, KB_I_OPEN = 4, KB_H_OPEN = 8 };
+
+struct KbandGeo {
+  int32_t qLen, tLen;  // after SetKBoundedLengths
+  int32_t k, nCols;
+  int32_t status;
+  int32_t pad;
+  int64_t cells;       // (qLen + 1) * nCols
+  int64_t arenaWords;  // worst-case op count
+};
+
+__global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *qLenIn, const int32_t *tLenIn,
+                                                         const int32_t *kIn, KbandGeo *geo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  KbandGeo g;
+  const int64_t qLength = qLenIn[i], tLength = tLenIn[i], k = kIn[i];
+  g.k = (int32_t)k;
+  g.nCols = (int32_t)(2 * k + 1);
+  g.status = 0;
+  g.pad = 0;
+  if (qLength <= 0 || tLength <= 0 || k < 1 || 2 * k + 1 > kKbMaxCols) {
+    g.status = TASK_BAD_GUIDE;
+    g.qLen = g.tLen = 0;
+    g.cells = 0;
+    g.arenaWords = 0;
+  } else {
+    int64_t qLen = qLength, tLen = tLength;  // KBandAlign.h:43-55
+    if (tLength < qLength) qLen = min(qLength, tLength + k);
+    else if (qLength < tLength) tLen = min(tLength, qLength + k);
+    g.qLen = (int32_t)qLen;
+    g.tLen = (int32_t)tLen;
+    g.cells = (qLen + 1) * (2 * k + 1);
+    g.arenaWords = qLen + tLen + 2 * k + 4;
+  }
+  geo[i] = g;
+}
+
+struct KbandArgs {
+  int first, count;
+  int hpInsOpen, hpInsExtend, insOpen, insExtend, del;
+  const int32_t *matrix;
+  const KbandGeo *geo;
+  const uint8_t *seq;
+  const int64_t *qOff, *tOff;
+  uint8_t *arrows;
+  const int64_t *arrowOff;
+  uint32_t *arena;
+  const int64_t *arenaOff;
+  int32_t *opsStart;
+  RefineResult *results;
+};
+
+__global__ __launch_bounds__(256) void kband_fill_kernel(KbandArgs a) {
+  __shared__ int rowS[4][kKbMaxCols + 64], rowI[4][kKbMaxCols + 64], rowH[4][kKbMaxCols + 64];
+  __shared__ int m[25];
+  if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x];
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0) return;
+  int *S = rowS[wv], *I = rowI[wv], *H = rowH[wv];
+  const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
+  uint8_t *arrows = a.arrows + a.arrowOff[task];
+  const int k = g.k, nCols = g.nCols, qLen = g.qLen, tLen = g.tLen;
+  const int del = a.del;
+  // ---- row 0 (:96-150): S = t * del right of the diagonal, I = HP = 0 on it, "infinite" elsewhere
+  for (int c = lane; c < nCols + 64; c += 64) {
+    S[c] = c > k && c < nCols ? (c - k) * del : 0;
+    I[c] = c == k ? 0 : kKbInf;
+    H[c] = c == k ? 0 : kKbInf;
+    if (c < nCols) arrows[c] = (uint8_t)(c > k ? KB_LEFT : (c == k ? (KB_I_OPEN | KB_H_OPEN) : 0));
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int q0 = 1; q0 <= qLen; q0 += 64) {
+    // raw query bytes of these 64 rows (the homopolymer test compares bytes, :183) and of the row before
+    const int qi = q0 - 1 + lane;
+    const int qRawV = qi < qLen ? (int)qSeq[qi] : 0;
+    const int qPrevRaw0 = q0 >= 2 ? (int)qSeq[q0 - 2] : -1;
+    const int nRows = min(64, qLen - q0 + 1);
+    for (int r = 0; r < nRows; r++) {
+      const int q = q0 + r;
+      const int qRaw = __builtin_amdgcn_readlane(qRawV, r);
+      const int qPrevRaw = r > 0 ? __builtin_amdgcn_readlane(qRawV, r - 1) : qPrevRaw0;
+      const bool sameBase = q > 1 && qRaw == qPrevRaw;
+      const int qc = base_code((unsigned)qRaw);
+      uint8_t *arrowRow = arrows + (int64_t)q * nCols;
+      const bool hasB = q <= k;  // the column of t = 0 is inside the band
+      const int cB = k - q;
+      if (hasB && lane == 0) {  // boundary cell of this row (:98-101, :122-125, :135-138)
+        const int v = q * a.insExtend + a.insOpen;
+        S[cB] = v;
+        I[cB] = v;
+        H[cB] = q * a.hpInsExtend + a.hpInsOpen;
+        arrowRow[cB] = (uint8_t)KB_INS_CLOSE;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int cLo = max(0, k - q + 1), cHi = min(2 * k, k + tLen - q);
+      const int cStart = hasB ? cB : cLo;
+      int carry = kKbInf, carryS = kKbInf;  // min of V - c*del left of this chunk; S of the cell left of it
+      for (int cb = cStart; cb <= cHi; cb += 64) {
+        const int c = cb + lane;
+        const bool valid = c >= cLo && c <= cHi;
+        const bool isB = hasB && c == cB;
+        const int sp = S[c];
+        const bool upperOk = c < 2 * k;
+        const int upS = S[c + 1], upI = I[c + 1], upH = H[c + 1];
+        // :169-215 the two insertion matrices look only at the cell above
+        const int hpOpen = upperOk ? upS + a.hpInsOpen : kKbInf;
+        const int hpExt = (sameBase && upperOk) ? upH + a.hpInsExtend : kKbInf;
+        const bool hOpens = hpOpen < hpExt;
+        const int minHp = hOpens ? hpOpen : hpExt;
+        const int insOpen = upperOk ? upS + a.insOpen : kKbInf;
+        const int insExt = upperOk ? upI + a.insExtend : kKbInf;
+        const bool iOpens = insOpen < insExt;
+        const int minIns = iOpens ? insOpen : insExt;
+        int match = kKbInf;
+        if (valid) match = sp + m[qc * 5 + base_code((unsigned)tSeq[c - k + q - 1])];
+        int v = min(match, min(minIns, minHp));
+        v = valid ? v : (isB ? sp : kKbInf);
+        // :219-229 linear deletion: S[c] = min(V[c], S[c-1] + del) = c*del + prefix-min(V[j] - j*del)
+        int x = v - lane * del;
+        x = wave_prefix_min(x);
+        const int e = min(wave_shr1(x, kKbInf), carry);      // cells strictly left of this lane
+        const int s = min(v, e + lane * del);
+        const int left = wave_shr1(s, carryS);                // S of the cell to the left
+        const int delScore = (c == cStart) ? kKbInf : left + del;
+        int arrow = KB_HP_CLOSE;                              // :246-257
+        arrow = (s == minIns) ? KB_INS_CLOSE : arrow;
+        arrow = (s == delScore) ? KB_LEFT : arrow;
+        arrow = (s == match) ? KB_DIAG : arrow;
+        if (valid) {
+          S[c] = s;
+          I[c] = minIns;
+          H[c] = minHp;
+          arrowRow[c] = (uint8_t)(arrow | (iOpens ? KB_I_OPEN : 0) | (hOpens ? KB_H_OPEN : 0));
+        }
+        carry = min(carry, __builtin_amdgcn_readlane(x, 63)) + 64 * del;
+        carryS = __builtin_amdgcn_readlane(s, 63);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  // optScore = scoreMat[qLen][k - (qLen - tLen)] (:301-304, :344)
+  if (lane == 0) {
+    RefineResult res;
+    memset(&res, 0, sizeof(res));
+    res.dp_score = S[k - (qLen - tLen)];
+    res.n_cells = (int32_t)g.cells;
+    a.results[task] = res;
+  }
+}
+
+__global__ __launch_bounds__(64) void kband_traceback_kernel(KbandArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0) {
+    RefineResult res;
+    memset(&res, 0, sizeof(res));
+    res.status = g.status;
+    a.results[task] = res;
+    a.opsStart[task] = 0;
+    return;
+  }
+  const uint8_t *arrows = a.arrows + a.arrowOff[task];
+  uint32_t *arena = a.arena + a.arenaOff[task];
+  const int k = g.k, nCols = g.nCols;
+  int q = g.qLen, t = k - (g.qLen - g.tLen);
+  int pos = (int)g.arenaWords;  // filled from the back, so the ops come out in forward order
+  int curType = -1, curLen = 0, mat = 0, status = 0;
+  auto emit = [&](int type) {
+    if (type == curType) curLen++;
+    else {
+      if (curLen) arena[--pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+      curType = type;
+      curLen = 1;
+    }
+  };
+  int guard = g.qLen + g.tLen + 2 * k + 8;
+  while (q > 0 || (q == 0 && t > k)) {
+    if (--guard < 0 || t < 0 || t >= nCols) {  // cannot happen for a filled matrix
+      status = TASK_BAD_PATH;
+      break;
+    }
+    const int ab = arrows[(int64_t)q * nCols + t];
+    if (mat == 0) {
+      const int ar = ab & 3;
+      if (ar == KB_DIAG) {
+        emit(BLASR_HIP_OP_M);
+        q--;
+      } else if (ar == KB_LEFT) {
+        emit(BLASR_HIP_OP_D);
+        t--;
+      } else
+        mat = ar == KB_INS_CLOSE ? 1 : 2;
+    } else {
+      const bool open = mat == 1 ? (ab & KB_I_OPEN) != 0 : (ab & KB_H_OPEN) != 0;
+      if (open) mat = 0;
+      emit(BLASR_HIP_OP_I);
+      q--;
+      t++;
+    }
+  }
+  if (curLen) arena[--pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+  RefineResult res = a.results[task];
+  res.status = status;
+  res.n_ops = status ? 0 : (int32_t)(g.arenaWords - pos);
+  a.results[task] = res;
+  a.opsStart[task] = pos;
+}
+
+}  // namespace blasr_hip
+
+using namespace blasr_hip;
+
+extern "C" {
+
+int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+                           blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
+                           int64_t *ops_used) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !p || !ops_used || b->n < 0 ||
+      (b->n > 0 && (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !b->k || !results || !ops)))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  *ops_used = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  int64_t magnitude = 0;
+  for (int i = 0; i < 25; i++) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)p->matrix[i]));
+  for (int v : {p->hp_ins_open, p->hp_ins_extend, p->ins_open, p->ins_extend, p->del})
+    magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)v));
+  if (p->del < 0 || magnitude >= (1 << 10))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "kband: deletion penalty must be >= 0, |penalties| < 1024");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  struct Dev {
+    void *p = nullptr;
+    ~Dev() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  Dev dGeo, dMatrix, dArrowOff, dArenaOff, dOpsStart, dTotal;
+  HIP_TRY(ctx, hipMalloc(&dGeo.p, sizeof(KbandGeo) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dMatrix.p, sizeof(int32_t) * 32));
+  HIP_TRY(ctx, hipMalloc(&dArrowOff.p, sizeof(int64_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dArenaOff.p, sizeof(int64_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dOpsStart.p, sizeof(int32_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dTotal.p, sizeof(int64_t)));
+  HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, p->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(dTotal.p, 0, sizeof(int64_t), st));
+  hipLaunchKernelGGL(kband_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, b->q_len, b->t_len, b->k,
+                     static_cast<KbandGeo *>(dGeo.p));
+  std::vector<KbandGeo> geo((size_t)n);
+  HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo.p, sizeof(KbandGeo) * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  // chunks of tasks whose arrow matrices + op arenas fit the workspace
+  const int64_t limit = std::max<int64_t>(ctx->workspaceLimit, 1 << 20);
+  std::vector<int64_t> arrowOff((size_t)n), arenaOff((size_t)n);
+  struct Chunk {
+    int first, count;
+    int64_t arrowBytes, arenaWords;
+  };
+  std::vector<Chunk> chunks;
+  int64_t maxBytes = 0;
+  for (int i = 0; i < n;) {
+    Chunk c{i, 0, 0, 0};
+    while (i < n) {
+      const int64_t ab = (geo[i].cells + 255) & ~(int64_t)255, aw = (geo[i].arenaWords + 63) & ~(int64_t)63;
+      if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw) > limit) break;
+      if (ab + 4 * aw > limit)
+        return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "kband: task %d needs %lld bytes of workspace", i,
+                              (long long)(ab + 4 * aw));
+      arrowOff[i] = c.arrowBytes;
+      arenaOff[i] = c.arenaWords;
+      c.arrowBytes += ab;
+      c.arenaWords += aw;
+      c.count++;
+      i++;
+    }
+    maxBytes = std::max(maxBytes, c.arrowBytes + 4 * c.arenaWords + 1024);
+    chunks.push_back(c);
+  }
+  if (ctx->workspaceBytes < (size_t)maxBytes) {
+    if (ctx->workspace) (void)hipFree(ctx->workspace);
+    ctx->workspace = nullptr;
+    ctx->workspaceBytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->workspace, (size_t)maxBytes));
+    ctx->workspaceBytes = (size_t)maxBytes;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(dArrowOff.p, arrowOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dArenaOff.p, arenaOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
+  for (const Chunk &c : chunks) {
+    KbandArgs a;
+    a.first = c.first;
+    a.count = c.count;
+    a.hpInsOpen = p->hp_ins_open;
+    a.hpInsExtend = p->hp_ins_extend;
+    a.insOpen = p->ins_open;
+    a.insExtend = p->ins_extend;
+    a.del = p->del;
+    a.matrix = static_cast<int32_t *>(dMatrix.p);
+    a.geo = static_cast<KbandGeo *>(dGeo.p);
+    a.seq = b->seq;
+    a.qOff = b->q_off;
+    a.tOff = b->t_off;
+    a.arrows = reinterpret_cast<uint8_t *>(ctx->workspace);
+    a.arrowOff = static_cast<int64_t *>(dArrowOff.p);
+    a.arena = reinterpret_cast<uint32_t *>(ctx->workspace + c.arrowBytes);
+    a.arenaOff = static_cast<int64_t *>(dArenaOff.p);
+    a.opsStart = static_cast<int32_t *>(dOpsStart.p);
+    a.results = dResults;
+    hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
+    launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), st);
+    launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, st);
+  }
+  int64_t total = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&total, dTotal.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  *ops_used = total;
+  if (total > ops_capacity)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "kband: %lld ops produced, arena holds %lld", (long long)total,
+                          (long long)ops_capacity);
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+                         blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !p || !ops_used || b->n < 0 || ops_capacity < 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  *ops_used = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  int64_t seqBytes = 0;
+  for (int i = 0; i < n; i++) {
+    if (b->q_len[i] < 0 || b->t_len[i] < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: negative length");
+    seqBytes = std::max<int64_t>(seqBytes, std::max(b->q_off[i] + b->q_len[i], b->t_off[i] + b->t_len[i]));
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  struct Dev {
+    void *p = nullptr;
+    ~Dev() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  Dev dSeq, dQOff, dTOff, dQLen, dTLen, dK, dRes, dOps;
+  HIP_TRY(ctx, hipMalloc(&dSeq.p, (size_t)std::max<int64_t>(seqBytes, 1)));
+  HIP_TRY(ctx, hipMalloc(&dQOff.p, sizeof(int64_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dTOff.p, sizeof(int64_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dQLen.p, sizeof(int32_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dTLen.p, sizeof(int32_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dK.p, sizeof(int32_t) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dRes.p, sizeof(blasr_hip_refine_result) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc(&dOps.p, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_capacity, 1)));
+  HIP_TRY(ctx, hipMemcpyAsync(dSeq.p, b->seq, (size_t)seqBytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dQOff.p, b->q_off, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dTOff.p, b->t_off, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dQLen.p, b->q_len, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dTLen.p, b->t_len, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dK.p, b->k, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  blasr_hip_kband_batch db;
+  db.n = n;
+  db.seq = static_cast<uint8_t *>(dSeq.p);
+  db.q_off = static_cast<int64_t *>(dQOff.p);
+  db.q_len = static_cast<int32_t *>(dQLen.p);
+  db.t_off = static_cast<int64_t *>(dTOff.p);
+  db.t_len = static_cast<int32_t *>(dTLen.p);
+  db.k = static_cast<int32_t *>(dK.p);
+  const int rc = blasr_hip_kband_device(ctx, &db, p, static_cast<blasr_hip_refine_result *>(dRes.p),
+                                        static_cast<uint32_t *>(dOps.p), ops_capacity, ops_used);
+  if (rc != BLASR_HIP_OK && rc != BLASR_HIP_ERR_CAPACITY) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(results, dRes.p, sizeof(blasr_hip_refine_result) * (size_t)n, hipMemcpyDeviceToHost, st));
+  const int64_t copyOps = std::min(*ops_used, ops_capacity);
+  if (copyOps > 0) HIP_TRY(ctx, hipMemcpyAsync(ops, dOps.p, sizeof(uint32_t) * (size_t)copyOps, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return rc;
+}
+
+}  // extern "C"

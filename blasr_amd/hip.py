@@ -29,6 +29,7 @@ EXPORTS = [
     "blasr_hip_refine_last_timing", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
+    "blasr_hip_kband_device", "blasr_hip_kband_host",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -44,6 +45,51 @@ CANDIDATE_DTYPE = np.dtype([("score", "<i4"), ("t_pos", "<u4"), ("t_aligned_seq_
                             ("blk_off", "<i8")])
 assert INTERVAL_DTYPE.itemsize == 24 and READ_DTYPE.itemsize == 24 and WINDOW_DTYPE.itemsize == 32
 assert CANDIDATE_DTYPE.itemsize == 40
+
+
+class _KbandParams(C.Structure):
+    _fields_ = [("matrix", C.c_int32 * 25), ("hp_ins_open", C.c_int32), ("hp_ins_extend", C.c_int32),
+                ("ins_open", C.c_int32), ("ins_extend", C.c_int32), ("del_", C.c_int32)]
+
+
+class _KbandBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("k", C.c_void_p)]
+
+
+def ops_to_alignment(ops):
+    """Alignment::ArrowPathToAlignment (Alignment.h:190-254) on run-length ops: blocks, and one gap list per
+    slot (list 0 leads); a gap list that runs to the end of the path is emptied.  Returns
+    (blocks (n,3), gapCounts, gapItems (m,2))."""
+    blocks, gap_counts, gap_items = [], [], []
+    q = t = 0
+    ops = np.asarray(ops, dtype=np.uint32)
+    types, lens = (ops & 3).tolist(), (ops >> 2).tolist()
+    i, n = 0, len(types)
+    before_first = True
+    while i < n:
+        if not before_first and types[i] == OP_M:
+            blocks.append((q, t, lens[i]))
+            q += lens[i]
+            t += lens[i]
+            i += 1
+        gap_counts.append(0)
+        first_item = len(gap_items)
+        while i < n and types[i] != OP_M:
+            if types[i] == OP_I:
+                gap_items.append((GAP_TARGET, lens[i]))
+                q += lens[i]
+            else:
+                gap_items.append((GAP_QUERY, lens[i]))
+                t += lens[i]
+            gap_counts[-1] += 1
+            i += 1
+        if i == n:
+            del gap_items[first_item:]
+            gap_counts[-1] = 0
+        before_first = False
+    return (np.array(blocks, np.int32).reshape(-1, 3), np.array(gap_counts, np.int32),
+            np.array(gap_items, np.int32).reshape(-1, 2))
 
 
 class _WindowParams(C.Structure):
@@ -166,6 +212,9 @@ def load_library():
         lib.blasr_hip_windows_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                C.c_int64, C.POINTER(_WindowParams), C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        for name in ("blasr_hip_kband_device", "blasr_hip_kband_host"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_KbandBatch), C.POINTER(_KbandParams), C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         lib.blasr_hip_sort_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.blasr_hip_remove_low_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                                      C.c_int32, C.c_int32]
@@ -459,6 +508,48 @@ class Context:
                                                       C.byref(wp), seq_ptr, seq_capacity, q_off_ptr, q_len_ptr,
                                                       t_off_ptr, t_len_ptr, windows_ptr, C.byref(used)))
         return used.value
+
+    # --- a-11: AffineKBandAlign (the -noUseGuidedAlign refiner, Blasr.cpp:675-746) ---
+    def kband(self, pairs, ks, matrix=None, indel=5, ops_capacity=None):
+        """pairs: list of (query, target) uint8 arrays, ks: band half-widths.  Penalties as PairwiseLocalAlign
+        derives them from params.indel (Blasr.cpp:695-699).  Returns a list of dicts: status, score, nCells, ops,
+        blocks, gapCounts, gapItems."""
+        n = len(pairs)
+        if n == 0:
+            return []
+        seqs, q_off, q_len, t_off, t_len, at = [], [], [], [], [], 0
+        for q, t in pairs:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            q_off.append(at); q_len.append(len(q)); at += len(q)
+            t_off.append(at); t_len.append(len(t)); at += len(t)
+            seqs += [q, t]
+        seq = np.ascontiguousarray(np.concatenate(seqs)) if at else np.zeros(1, np.uint8)
+        q_off, t_off = np.array(q_off, np.int64), np.array(t_off, np.int64)
+        q_len, t_len = np.array(q_len, np.int32), np.array(t_len, np.int32)
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        kb = _KbandBatch()
+        kb.n = n
+        kb.seq, kb.q_off, kb.q_len = seq.ctypes.data, q_off.ctypes.data, q_len.ctypes.data
+        kb.t_off, kb.t_len, kb.k = t_off.ctypes.data, t_len.ctypes.data, ks.ctypes.data
+        kp = _KbandParams()
+        m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
+        for i, v in enumerate(m):
+            kp.matrix[i] = int(v)
+        kp.hp_ins_open, kp.hp_ins_extend, kp.ins_open, kp.ins_extend, kp.del_ = indel + 2, indel - 3, indel + 2, indel - 1, indel
+        cap = int(q_len.sum() + t_len.sum() + 2 * ks.sum() + 8 * n) if ops_capacity is None else int(ops_capacity)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        ops = np.zeros(max(cap, 1), dtype=np.uint32)
+        used = C.c_int64(0)
+        self._check(self.lib.blasr_hip_kband_host(self.handle, C.byref(kb), C.byref(kp), results.ctypes.data,
+                                                  ops.ctypes.data, cap, C.byref(used)))
+        out = []
+        for r in results:
+            o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
+            blocks, gc, gi = ops_to_alignment(o)
+            out.append(dict(status=int(r["status"]), score=int(r["dp_score"]), nCells=int(r["n_cells"]), ops=o,
+                            blocks=blocks, gapCounts=gc, gapItems=gi))
+        return out
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()

@@ -305,6 +305,45 @@ int blasr_hip_remove_low_quality(blasr_hip_candidate *cands, const int32_t *bloc
 int blasr_hip_remove_overlapping(const blasr_hip_candidate *cands, int32_t n, int32_t *order,
                                  float min_pct_identity);
 
+/* ------------------------------------------------------------------------------------------------
+ * a-11: AffineKBandAlign, Global (algorithms/alignment/AffineKBandAlign.h:12-401) -- the refiner
+ * PairwiseLocalAlign runs under -noUseGuidedAlign (alignment/Blasr.cpp:675-746): fixed band of
+ * 2k+1 columns, affine insertion + affine homopolymer insertion + linear deletion.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_kband_params {
+  int32_t matrix[25];     /* SMRTDistanceMatrix (Blasr.cpp:695) */
+  int32_t hp_ins_open;    /* params.indel + 2 */
+  int32_t hp_ins_extend;  /* params.indel - 3 */
+  int32_t ins_open;       /* params.indel + 2 */
+  int32_t ins_extend;     /* params.indel - 1 */
+  int32_t del;            /* params.indel */
+} blasr_hip_kband_params;
+
+/* Candidate i: query / target as for the guided refiner (trimmed to the SDP extent, Blasr.cpp:968-981),
+ * k[i] = the band half-width handed to AffineKBandAlign (k * 1.2 of :699; 2k+1 <= 1088 here, else the
+ * candidate gets BLASR_HIP_TASK_BAD_GUIDE). */
+typedef struct blasr_hip_kband_batch {
+  int32_t n;
+  const uint8_t *seq;
+  const int64_t *q_off;
+  const int32_t *q_len;
+  const int64_t *t_off;
+  const int32_t *t_len;
+  const int32_t *k;
+} blasr_hip_kband_batch;
+
+/* Results reuse blasr_hip_refine_result: dp_score = the function's return value, n_cells = (qLen+1)(2k+1),
+ * q_pos = t_pos = 0, ops as for the guided refiner but WITHOUT RemoveAlignmentPrefixGaps (leading gap
+ * ops form Alignment.gaps[0]; ArrowPathToAlignment drops a trailing gap run, Alignment.h:190-254).
+ * The statistics fields are 0: the reference computes them with an uninitialised score matrix here
+ * (Blasr.cpp:689-690), so they are not defined. */
+int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
+                           const blasr_hip_kband_params *params, blasr_hip_refine_result *results, uint32_t *ops,
+                           int64_t ops_capacity, int64_t *ops_used);
+int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
+                         const blasr_hip_kband_params *params, blasr_hip_refine_result *results, uint32_t *ops,
+                         int64_t ops_capacity, int64_t *ops_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1699,3 +1699,152 @@ int bo_remove_overlapping(int n, int *order, const int *score, const unsigned *t
   free(contained);
   return kept;
 }
+
+/* ------------------------------------------------------------------------- */
+/* a-11: AffineKBandAlign, Global (algorithms/alignment/AffineKBandAlign.h:12-401) */
+/* ------------------------------------------------------------------------- */
+/* S + affine insertion I + affine homopolymer insertion HP, linear deletion, fixed band of 2k+1
+ * columns stored as column = k + t - q.  Cells outside the band / outside the sequences are never read. */
+#define KB_INF (2147483647 - 1000) /* INF_INT - 1000, :30 */
+static int three_bit(unsigned char c) { /* ThreeBit on the supported alphabet (ACGTN, both cases); else N */
+  init_tables();
+  const int v = g_three[c];
+  return v > 4 ? 4 : v;
+}
+enum { KB_DIAG, KB_LEFT, KB_INS_CLOSE, KB_HP_CLOSE, KB_NONE };
+static int affine_kband_align(const unsigned char *qs, uint32_t qLength, const unsigned char *ts, uint32_t tLength,
+                              const int m[5][5], int hpInsOpen, int hpInsExtend, int insOpen, int insExtend,
+                              int del, int k, aln_t *out) {
+  uint32_t tLen, qLen; /* SetKBoundedLengths, KBandAlign.h:36-56 */
+  if (tLength < qLength) {
+    tLen = tLength;
+    qLen = qLength < tLength + (uint32_t)k ? qLength : tLength + (uint32_t)k;
+  } else if (qLength < tLength) {
+    qLen = qLength;
+    tLen = tLength < qLength + (uint32_t)k ? tLength : qLength + (uint32_t)k;
+  } else {
+    qLen = qLength;
+    tLen = tLength;
+  }
+  const size_t nCols = 2 * (size_t)k + 1, total = ((size_t)qLen + 1) * nCols;
+  int *S = (int *)calloc(total, sizeof(int)), *H = (int *)calloc(total, sizeof(int)), *I = (int *)calloc(total, sizeof(int));
+  unsigned char *PS = (unsigned char *)malloc(total), *PH = (unsigned char *)calloc(total, 1), *PI = (unsigned char *)calloc(total, 1);
+  memset(PS, KB_NONE, total);
+#define IX(r, c) ((size_t)(r) * nCols + (size_t)(c))
+  /* boundaries :96-150 (alignType Global); PH / PI: 1 = Open, 0 = Up */
+  I[IX(0, k)] = 0;
+  PI[IX(0, k)] = 1;
+  for (int q = 1; q <= k && q < (int)qLen + 1; q++) I[IX(q, k - q)] = q * insExtend + insOpen;
+  H[IX(0, k)] = 0;
+  PH[IX(0, k)] = 1;
+  for (int q = 1; q <= k && q < (int)qLen + 1; q++) H[IX(q, k - q)] = q * hpInsExtend + hpInsOpen;
+  for (int t = k + 1; t < (int)nCols; t++) {
+    H[IX(0, t)] = KB_INF;
+    I[IX(0, t)] = KB_INF;
+  }
+  for (int q = 1; q <= k && q < (int)qLen + 1; q++) {
+    S[IX(q, k - q)] = I[IX(q, k - q)];
+    PS[IX(q, k - q)] = KB_INS_CLOSE;
+  }
+  for (int t = 1; t <= k; t++) {
+    S[IX(0, t + k)] = t * del;
+    PS[IX(0, t + k)] = KB_LEFT;
+  }
+  /* recurrence :161-279 */
+  for (int q = 1; q <= (int)qLen; q++) {
+    for (int t = q - k; t < q + k + 1; t++) {
+      if (t < 1) continue;
+      if ((uint32_t)t > tLen) break;
+      const size_t upper = IX(q - 1, k + t - q + 1), cur = IX(q, k + t - q);
+      const int hpOpenScore = t < q + k ? S[upper] + hpInsOpen : KB_INF;
+      int hpExtendScore = KB_INF;
+      if (q > 1 && qs[q - 1] == qs[q - 2] && t < q + k) hpExtendScore = H[upper] + hpInsExtend;
+      int minHp;
+      if (hpOpenScore < hpExtendScore) {
+        PH[cur] = 1;
+        minHp = hpOpenScore;
+      } else {
+        PH[cur] = 0;
+        minHp = hpExtendScore;
+      }
+      H[cur] = minHp;
+      int insOpenScore = KB_INF, insExtendScore = KB_INF;
+      if (t < q + k) {
+        insOpenScore = S[upper] + insOpen;
+        insExtendScore = I[upper] + insExtend;
+      }
+      int minIns;
+      if (insOpenScore < insExtendScore) {
+        PI[cur] = 1;
+        minIns = insOpenScore;
+      } else {
+        PI[cur] = 0;
+        minIns = insExtendScore;
+      }
+      I[cur] = minIns;
+      const int delScore = t == q - k ? KB_INF : S[IX(q, k + t - q - 1)] + del;
+      const int matchScore = S[IX(q - 1, k + t - q)] + m[three_bit(qs[q - 1])][three_bit(ts[t - 1])];
+      int minScore = minIns < minHp ? minIns : minHp;
+      if (delScore < minScore) minScore = delScore;
+      if (matchScore < minScore) minScore = matchScore;
+      S[cur] = minScore;
+      PS[cur] = minScore == matchScore ? KB_DIAG : minScore == delScore ? KB_LEFT : minScore == minIns ? KB_INS_CLOSE : KB_HP_CLOSE;
+    }
+  }
+  /* traceback :299-391, Global */
+  int q = (int)qLen, t = k - ((int)qLen - (int)tLen);
+  const int optScore = S[IX(q, t)];
+  unsigned char *path = (unsigned char *)malloc((size_t)qLen + tLen + 2 * (size_t)k + 16);
+  int n = 0, mat = 0; /* 0 Match, 1 AffineIns, 2 AffineHPIns */
+  while (q > 0 || (q == 0 && t > k)) {
+    if (mat == 0) {
+      const int a = PS[IX(q, t)];
+      if (a == KB_DIAG) {
+        path[n++] = A_DIAG;
+        q--;
+      } else if (a == KB_LEFT) {
+        path[n++] = A_LEFT;
+        t--;
+      } else if (a == KB_INS_CLOSE) mat = 1;
+      else if (a == KB_HP_CLOSE) mat = 2;
+      else break; /* NoArrow: the reference would spin forever; cannot happen for a computed cell */
+    } else {
+      const int open = mat == 1 ? PI[IX(q, t)] : PH[IX(q, t)];
+      if (open) mat = 0;
+      path[n++] = A_UP;
+      q--;
+      t++;
+    }
+  }
+  for (int i = 0; i < n / 2; i++) {
+    unsigned char tmp = path[i];
+    path[i] = path[n - 1 - i];
+    path[n - 1 - i] = tmp;
+  }
+  arrow_path_to_alignment(out, path, n);
+#undef IX
+  free(path);
+  free(S);
+  free(H);
+  free(I);
+  free(PS);
+  free(PH);
+  free(PI);
+  return optScore;
+}
+
+int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25,
+                          int hpInsOpen, int hpInsExtend, int insOpen, int insExtend, int del, int k, int *score,
+                          int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
+                          int *gapItems, int gapItemCap, int *nGapItems) {
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  aln_t a;
+  aln_init(&a);
+  *score = affine_kband_align(q, (uint32_t)qlen, t, (uint32_t)tlen, m, hpInsOpen, hpInsExtend, insOpen, insExtend, del,
+                              k, &a);
+  int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+  aln_free(&a);
+  return rc;
+}

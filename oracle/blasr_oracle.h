@@ -100,6 +100,12 @@ int bo_remove_overlapping(int n, int *order, const int *score, const unsigned *t
                           const unsigned *tEnd, const int *tIndex, const int *tStrand, const float *pctSimilarity,
                           float minPctIdentity);
 
+/* a-11: AffineKBandAlign, Global (AffineKBandAlign.h:12-401) as PairwiseLocalAlign calls it (Blasr.cpp:695-703). */
+int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25,
+                          int hpInsOpen, int hpInsExtend, int insOpen, int insExtend, int del, int k, int *score,
+                          int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
+                          int *gapItems, int gapItemCap, int *nGapItems);
+
 #ifdef __cplusplus
 }
 #endif

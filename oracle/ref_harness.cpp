@@ -254,4 +254,27 @@ void ref_compute_alignment_stats(const unsigned char *q, const unsigned char *t,
   *pct = a.pctSimilarity;
 }
 
+// AffineKBandAlign (AffineKBandAlign.h:12-401) as PairwiseLocalAlign calls it (Blasr.cpp:695-703):
+// Global, the caller's six matrices are fresh vectors.  Returns the flattened alignment; *score = the
+// function's return value (S at the end cell).
+int ref_affine_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen,
+                           const int *matrix25, int hpInsOpen, int hpInsExtend, int insOpen, int insExtend,
+                           int del, int k, int *score, int *blocks, int blockCap, int *nBlocks,
+                           int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                           int *nGapItems) {
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  FASTQSequence qs;
+  DNASequence ts;
+  set_seq(qs, q, qlen);
+  set_seq(ts, t, tlen);
+  std::vector<int> scoreMat, hpInsScoreMat, insScoreMat;
+  std::vector<Arrow> pathMat, hpInsPathMat, insPathMat;
+  Alignment a;
+  *score = AffineKBandAlign(qs, ts, m, hpInsOpen, hpInsExtend, insOpen, insExtend, del, k, scoreMat, pathMat,
+                            hpInsScoreMat, hpInsPathMat, insScoreMat, insPathMat, a, Global);
+  return flatten(a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+}
+
 }  // extern "C"

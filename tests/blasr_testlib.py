@@ -378,3 +378,22 @@ def random_candidates(rng, n):
     return dict(score=score, t_pos=t_pos, t_aligned_seq_pos=t_aligned_seq_pos, t_index=t_index, t_strand=t_strand,
                 pct=pct, blocks=blocks, blk_off=np.array(blk_off, np.int32), n_blocks=np.array(n_blocks, np.int32),
                 t_end=np.array(t_end, np.uint32))
+
+
+def affine_kband_align(checker, q, t, k, matrix=None, indel=5):
+    """AffineKBandAlign, Global, with the penalties PairwiseLocalAlign derives from params.indel
+    (Blasr.cpp:695-703).  `checker` = load_oracle() or load_ref().  Returns score, blocks, gap lists."""
+    q, t = _u8(q), _u8(t)
+    m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
+    cap = len(q) + len(t) + 2 * k + 16
+    blocks = np.zeros(3 * cap, dtype=np.int32)
+    gap_counts, gap_items = np.zeros(cap, dtype=np.int32), np.zeros(2 * cap, dtype=np.int32)
+    score, nb, ngl, ngi = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    f = checker.fn("affine_kband_align")
+    f.restype = C.c_int
+    rc = f(_p(q, C.c_ubyte), len(q), _p(t, C.c_ubyte), len(t), _p(m), indel + 2, indel - 3, indel + 2, indel - 1, indel,
+           int(k), C.byref(score), _p(blocks), cap, C.byref(nb), _p(gap_counts), cap, C.byref(ngl), _p(gap_items), cap,
+           C.byref(ngi))
+    assert rc == 0
+    return dict(score=score.value, blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
+                gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())

@@ -1,0 +1,76 @@
+"""a-11 on the device: blasr_hip_kband_* (AffineKBandAlign, Global) against golden vectors produced by the
+reference's own template and against the oracle, bit-exact: score, blocks, gap lists."""
+import os
+
+import numpy as np
+import pytest
+
+import blasr_amd
+from blasr_testlib import affine_kband_align
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = blasr_amd.Context(0)
+    yield c
+    c.close()
+
+
+def same(r, want):
+    return (r["status"] == 0 and r["score"] == want["score"] and np.array_equal(r["blocks"], want["blocks"])
+            and np.array_equal(r["gapCounts"], want["gapCounts"]) and np.array_equal(r["gapItems"], want["gapItems"]))
+
+
+def test_kband_matches_golden(ctx):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kband_golden.npz"))
+    n = int(g["n"])
+    pairs = [(g["c%d_q" % i], g["c%d_t" % i]) for i in range(n)]
+    ks = [int(g["c%d_k" % i]) for i in range(n)]
+    res = ctx.kband(pairs, ks)
+    for i, r in enumerate(res):
+        want = dict(score=int(g["c%d_score" % i]), blocks=g["c%d_blocks" % i], gapCounts=g["c%d_gapCounts" % i],
+                    gapItems=g["c%d_gapItems" % i])
+        assert same(r, want), (i, len(pairs[i][0]), len(pairs[i][1]), ks[i], r["score"], want["score"])
+
+
+def test_kband_matches_oracle_random(ctx, oracle):
+    from blasr_amd import synth
+    rng = np.random.default_rng(12)
+    pairs, ks = [], []
+    for it in range(96):
+        ql = int(rng.choice([3, 17, 64, 65, 200, 900, 2500]))
+        q, t = synth.make_pair(rng, ql, flank=(0, 0))
+        if it % 5 == 0:
+            t = t[: max(1, len(t) - int(rng.integers(0, 40)))]
+        if it % 7 == 0:
+            q = q[: max(1, len(q) - int(rng.integers(0, 40)))]
+        if it % 9 == 0:
+            q = q.copy()
+            q[len(q) // 3: len(q) // 3 + 9] = ord("T")  # a homopolymer run: the HP matrix gets used
+        pairs.append((q, t))
+        ks.append(int(rng.choice([10, 12, 31, 32, 33, 64, 100, 300, 543])))
+    res = ctx.kband(pairs, ks)
+    for (q, t), k, r in zip(pairs, ks, res):
+        assert same(r, affine_kband_align(oracle, q, t, k)), (len(q), len(t), k)
+
+
+def test_kband_chunked_workspace_and_errors(ctx, oracle):
+    from blasr_amd import synth
+    rng = np.random.default_rng(4)
+    pairs = [synth.make_pair(rng, 700, flank=(0, 0)) for _ in range(12)]
+    ks = [40] * 12
+    small = blasr_amd.Context(0)
+    small.set_workspace_limit(1 << 20)  # one or two candidates per chunk
+    res = small.kband(pairs, ks)
+    for (q, t), r in zip(pairs, res):
+        assert same(r, affine_kband_align(oracle, q, t, 40))
+    # band too wide for the LDS rows: per-candidate status, the others still run
+    res = small.kband(pairs[:2], [40, 600])
+    assert res[0]["status"] == 0 and res[1]["status"] == blasr_amd.hip.TASK_BAD_GUIDE
+    with pytest.raises(blasr_amd.BlasrHipError) as e:
+        small.kband(pairs[:1], [40], ops_capacity=1)
+    assert e.value.code == blasr_amd.hip.ERR_CAPACITY
+    small.close()

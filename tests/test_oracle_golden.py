@@ -53,3 +53,16 @@ def test_chain_matches_reference(oracle, golden):
         qlen, k = (int(v) for v in golden["ch%02d_par" % i])
         assert np.array_equal(oracle.sdp_chain(qlen, xyl, k, align_type=LOCAL), golden["ch%02d_local" % i])
         assert np.array_equal(oracle.sdp_chain(qlen, xyl, k, align_type=GLOBAL), golden["ch%02d_global" % i])
+
+
+def test_oracle_affine_kband_matches_golden(oracle):
+    """a-11: the oracle's AffineKBandAlign restatement against the vectors of the reference's template."""
+    import os
+    from blasr_testlib import affine_kband_align
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kband_golden.npz"))
+    for i in range(int(g["n"])):
+        r = affine_kband_align(oracle, g["c%d_q" % i], g["c%d_t" % i], int(g["c%d_k" % i]))
+        assert r["score"] == int(g["c%d_score" % i]), i
+        assert np.array_equal(r["blocks"], g["c%d_blocks" % i]), i
+        assert np.array_equal(r["gapCounts"], g["c%d_gapCounts" % i]), i
+        assert np.array_equal(r["gapItems"], g["c%d_gapItems" % i]), i
