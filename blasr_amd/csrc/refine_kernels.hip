@@ -561,9 +561,14 @@ __device__ __forceinline__ uint64_t load_window(const uint8_t *p) {
   return v;
 }
 
+// Candidates per wavefront.  The walk is latency-bound (a dependent load per row), so the device wants many
+// resident wavefronts rather than full ones: with 64 candidates per wavefront configs[1] yields only 1.5
+// wavefronts per SIMD.
+constexpr int kTbLanes = 32;
+
 __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, TraceArgs args) {
-  const int idx = blockIdx.x * 64 + threadIdx.x;
-  const bool inRange = idx < args.count;
+  const int idx = blockIdx.x * kTbLanes + threadIdx.x;
+  const bool inRange = idx < args.count && threadIdx.x < kTbLanes;
   const int task = args.first + (inRange ? idx : 0);
   const TaskGeometry geo = args.geo[task];
   bool alive = inRange && geo.status == 0;
@@ -859,7 +864,7 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
   if (args.count <= 0) return;
-  hipLaunchKernelGGL(traceback_kernel, dim3((args.count + 63) / 64), dim3(64), 0, stream, batch, args);
+  hipLaunchKernelGGL(traceback_kernel, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
   hipLaunchKernelGGL(stats_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
 }
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,

@@ -192,6 +192,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.bigList = arena.get<int32_t>(nTasks + 1);
     lv.bigCount = lv.bigList + nTasks;
     lv.idxFlag = arena.get<int32_t>(nTasks);
+    lv.fused = arena.get<int32_t>(nTasks);
     ARENA_CHECK();
     launch_sdp_classify(lv, st);
     int64_t *sizes = arena.get<int64_t>(nTasks + 1);
@@ -280,6 +281,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     ARENA_CHECK();
     launch_sdp_match(lv, b->seq, true, st);
     launch_sdp_match_index(lv, b->seq, true, st);
+    launch_sdp_small(lv, prm, st);  // invocations with <= 64 fragments: order .. chain in one kernel
     launch_sdp_order(lv, st);
     launch_sdp_yx_keys(lv, st);
     launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);

@@ -61,6 +61,7 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
+  int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)
   int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
@@ -87,6 +88,7 @@ void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t s
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st);
+void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st);
 int sdp_match_index_max_target(int device);
 void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);

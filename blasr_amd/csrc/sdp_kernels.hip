@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uin
   __shared__ unsigned hist[4][512];
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  if (lv.fused[idx]) return;
   const int lane = lane_id();
   const int F = lv.nFrag[idx];
   const int64_t base = lv.fragOff[idx];
@@ -945,6 +946,7 @@ __device__ __forceinline__ void introsort_replay(T *first, long n, Less less) {
 __global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  if (lv.fused[idx]) return;  // sdp_small_kernel's
   const int lane = lane_id();
   const int nP = lv.nRaw[3 * idx], nM = lv.nRaw[3 * idx + 1], nS = lv.nRaw[3 * idx + 2];
   const Frag *P = lv.raw + lv.fragOff[idx], *M = P + nP, *S = M + nM;
@@ -1128,6 +1130,7 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
 __global__ __launch_bounds__(256) void sdp_yx_keys_kernel(SdpLevelArrays lv) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  if (lv.fused[idx]) return;
   const int lane = lane_id();
   const int F = lv.nFrag[idx];
   const int64_t base = lv.fragOff[idx];
@@ -1142,6 +1145,7 @@ __global__ __launch_bounds__(256) void sdp_yx_keys_kernel(SdpLevelArrays lv) {
 __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  if (lv.fused[idx]) return;
   const int lane = lane_id();
   const int F = lv.nFrag[idx];
   const int64_t base = lv.fragOff[idx];
@@ -1328,16 +1332,16 @@ struct FragView {
   int x, y, cost, len;
 };
 
-__global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
+// The sweep of one invocation.  kPreloaded: the (<= 64) fragments and their static predecessors are handed
+// over in registers (lane = fragment) by sdp_small_kernel instead of being read from memory.
+template <bool kPreloaded>
+__device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpParams &prm, int idx, const SdpTask &t,
+                                            int F, int preX, int preY, int preLen, int prePred, int preAbove) {
   const int lane = lane_id();
-  const int F = lv.nFrag[idx];
   if (F == 0) {
     if (lane == 0) lv.chainEnd[idx] = -1;
     return;
   }
-  const SdpTask t = lv.tasks[idx];
   const int64_t base = lv.fragOff[idx];
   const Frag *fr = lv.frags + base;
   int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
@@ -1358,7 +1362,9 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
   for (int w0 = 0; w0 < F; w0 += 64) {
     prev = cur;
     int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
-    if (w0 + lane < F) {
+    if (kPreloaded) {
+      fxV = preX, fyV = preY, flV = preLen, fpV = prePred, faV = preAbove;
+    } else if (w0 + lane < F) {
       const Frag f = fr[w0 + lane];
       fxV = (int)f.x;
       fyV = (int)f.y;
@@ -1491,6 +1497,123 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
+}
+
+__global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  if (lv.fused[idx]) return;  // sdp_small_kernel's
+  chain_sweep<false>(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], 0, 0, 0, -1, -1);
+}
+
+// ---------------------------------------------------------------------------
+// sdp_small: an invocation with at most 64 raw fragments (nearly all of the recursion levels: 7 and 1.3
+// fragments on average at configs[1]) does everything between the match and the blocks in ONE kernel, with the
+// fragments one per lane: sort + keep-first (SDPAlign.h:256-269), StoreAbove, the sweep-set predecessor and
+// the sweep itself.  All-pairs comparisons through v_readlane replace the sorts.
+// An invocation whose lists tie on an (x,y) AND hold more than 16 fragments needs std::sort's schedule
+// replayed; it is left to the general kernels (lv.fused[idx] = 0).  With <= 16 elements std::sort is a plain
+// insertion sort, i.e. stable, so the first of the duplicates in prefix | middle | suffix order survives.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int idx = wave_task_index();
+  if (idx >= lv.n) return;
+  const int lane = lane_id();
+  const int nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
+  if (nAll > 64) {
+    if (lane == 0) lv.fused[idx] = 0;
+    return;
+  }
+  const int64_t base = lv.fragOff[idx];
+  uint32_t x = 0xffffffffu, y = 0xffffffffu, len = 0;
+  if (lane < nAll) {
+    const Frag f = lv.raw[base + lane];
+    x = f.x;
+    y = f.y;
+    len = f.len;
+  }
+  // ---- rank by (x,y), equal keys in input order
+  int rank = 0;
+  bool dup = false;
+  for (int j = 0; j < nAll; j++) {
+    const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j), yj = (uint32_t)__builtin_amdgcn_readlane((int)y, j);
+    const bool eq = xj == x && yj == y;
+    const bool less = xj < x || (xj == x && yj < y);
+    rank += (less || (eq && j < lane)) ? 1 : 0;
+    dup = dup || (eq && j < lane);
+  }
+  dup = dup && lane < nAll;
+  const unsigned long long dupMask = __ballot(dup);
+  if (dupMask != 0ull && nAll > 16) {
+    if (lane == 0) lv.fused[idx] = 0;
+    return;
+  }
+  if (lane == 0) lv.fused[idx] = 1;
+  // ---- drop the later duplicates, place the survivors at their rank among the survivors
+  int dest = 64;  // lanes without a fragment and dropped duplicates park beyond the survivors
+  const int F = nAll - (int)__popcll(dupMask);
+  if (lane < nAll && !dup) {
+    // rank counts every smaller-or-earlier element, duplicates included: subtract the dropped ones among them
+    int droppedBefore = 0;
+    for (unsigned long long m = dupMask; m != 0ull; m &= m - 1ull) {
+      const int j = __builtin_ctzll(m);
+      const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x, j), yj = (uint32_t)__builtin_amdgcn_readlane((int)y, j);
+      droppedBefore += (xj < x || (xj == x && (yj < y || (yj == y && j < lane)))) ? 1 : 0;
+    }
+    dest = rank - droppedBefore;
+  }
+  // ds_permute pushes a lane's value to lane dest; parked lanes must not collide with survivors
+  const unsigned long long liveMask = __ballot(dest < 64);
+  if (dest >= 64) dest = F + (int)__popcll(~liveMask & ((1ull << lane) - 1ull));
+  const int fx = __builtin_amdgcn_ds_permute(dest * 4, (int)x), fy = __builtin_amdgcn_ds_permute(dest * 4, (int)y);
+  const int fl = __builtin_amdgcn_ds_permute(dest * 4, (int)len);
+  const bool on = lane < F;
+  if (on) {
+    Frag f;
+    f.x = (uint32_t)fx;
+    f.y = (uint32_t)fy;
+    f.len = (uint32_t)fl;
+    f.pad = 0;
+    lv.frags[base + lane] = f;
+  }
+  if (lane == 0) lv.nFrag[idx] = F;
+  const SdpTask t = lv.tasks[idx];
+  // ---- StoreAbove (SparseDynamicProgramming.h:55-68): the neighbour in (y,x) order
+  int r2 = 0;
+  for (int j = 0; j < F; j++) {
+    const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane(fx, j), yj = (uint32_t)__builtin_amdgcn_readlane(fy, j);
+    r2 += (yj < (uint32_t)fy || (yj == (uint32_t)fy && xj < (uint32_t)fx)) ? 1 : 0;
+  }
+  if (!on) r2 = lane;  // keep the permutation a bijection
+  const int byYx = __builtin_amdgcn_ds_permute(r2 * 4, lane);  // lane r: the fragment with (y,x) rank r
+  int above = -1;
+  {
+    const int a = __builtin_amdgcn_ds_bpermute(max(r2 - 1, 0) * 4, byYx);
+    const uint32_t ax = (uint32_t)__builtin_amdgcn_ds_bpermute(a * 4, fx), ay = (uint32_t)__builtin_amdgcn_ds_bpermute(a * 4, fy);
+    const uint32_t al = (uint32_t)__builtin_amdgcn_ds_bpermute(a * 4, fl);
+    if (on && r2 > 0 && ax <= (uint32_t)fx && ax + al > (uint32_t)fx && ay < (uint32_t)fy) above = a;
+  }
+  // ---- sweepSet.Predecessor: the largest (diag, x) with diag <= f.diag among x in [f.x-k-1, f.x-1]
+  int pred = -1;
+  {
+    const int k = t.k;
+    const int fdiag = fy - fx;
+    const uint32_t xLow = (uint32_t)fx > (uint32_t)(k + 1) ? (uint32_t)fx - (uint32_t)(k + 1) : 0u;
+    int bestDiag = 0;
+    uint32_t bestX = 0;
+    for (int j = 0; j < F; j++) {
+      const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane(fx, j);
+      const int d = __builtin_amdgcn_readlane(fy, j) - (int)xj;
+      if (j < lane && xj >= xLow && xj < (uint32_t)fx && d <= fdiag &&
+          (pred < 0 || d > bestDiag || (d == bestDiag && xj > bestX))) {
+        pred = j;
+        bestDiag = d;
+        bestX = xj;
+      }
+    }
+    if (!on) pred = -1;
+  }
+  chain_sweep<true>(lv, prm, idx, t, F, fx, fy, fl, pred, above);
 }
 
 // ---------------------------------------------------------------------------
@@ -2145,6 +2268,9 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
     else
       hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
   }
+}
+void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
