@@ -117,3 +117,60 @@ def test_unsupported_parameters_are_rejected(ctx):
     with pytest.raises(blasr_amd.BlasrHipError) as e:
         ctx.sdp([(q, q)], blasr_amd.SdpParams(extend_front=1))
     assert e.value.code == blasr_amd.hip.ERR_UNSUPPORTED
+
+
+def _repetitive_pair(rng, qlen, unit_len, copies):
+    """A pair whose target holds a tandem repeat (many identical k-mers: long bucket chains, positions with
+    more than three matches, ties between the prefix / middle / suffix lists)."""
+    q, t = synth.make_pair(rng, qlen, flank=(0, 50))
+    unit = synth.random_genome(unit_len, int(rng.integers(1, 1 << 30)))
+    rep = np.tile(unit, copies)
+    at_t, at_q = int(rng.integers(0, max(1, len(t) - len(rep)))), int(rng.integers(0, max(1, len(q) - len(rep))))
+    t, q = t.copy(), q.copy()
+    t[at_t: at_t + len(rep)] = rep[: len(t) - at_t]
+    q[at_q: at_q + len(rep)] = rep[: len(q) - at_q]
+    return q, t
+
+
+def test_match_paths_against_oracle(ctx, oracle):
+    """Every way the device finds k-mer matches -- targets <= 128 bases (registers), mid-size (sorted keys), long
+    (LDS index, both size classes), word sizes below and above the index's limit, repeats with and without a
+    cap on the matches per position -- against the oracle."""
+    from blasr_testlib import ScoreParams as OSc, SdpParams as OSp
+    rng = np.random.default_rng(204)
+    osc = OSc()
+    cases = []
+    for qlen in (40, 100, 128, 200, 700, 1400, 1600, 3000, 9000):
+        for k in (5, 8, 11, 13, 14):
+            if qlen >= 3000 and k in (8, 14) and qlen != 3000:
+                continue
+            q, t = synth.make_pair(rng, qlen, flank=(0, int(rng.integers(0, 120))))
+            cases.append((q, t, OSp(k=k, max_per_pos=int(rng.choice([0, 0, 2])), align_type=int(rng.integers(0, 2)),
+                                    prefix=int(rng.choice([0, 50])))))
+    for qlen, unit, copies, mpp in ((300, 3, 40, 0), (900, 7, 30, 0), (2500, 11, 40, 0), (2500, 2, 150, 5),
+                                    (5000, 31, 20, 0), (5000, 1, 400, 10), (60, 2, 12, 0), (120, 5, 8, 3)):
+        q, t = _repetitive_pair(rng, qlen, unit, copies)
+        cases.append((q, t, OSp(k=int(rng.choice([5, 7, 11])), max_per_pos=mpp)))
+    q, t = synth.make_pair(rng, 14000, flank=(0, 300))  # second LDS size class
+    cases.append((q, t, OSp()))
+    q, t = synth.make_pair(rng, 2000, flank=(0, 0), n_run=30)
+    cases.append((q, t, OSp()))
+    for it, (q, t, osp) in enumerate(cases):
+        got = ctx.sdp([(q, t)], _sdp_params(osp), _score(osc))[0]
+        w = oracle.sdp_align(q, t, osc, osp)
+        st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"], sc=osc)
+        _check(got, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]],
+               (it, len(q), len(t), vars(osp)))
+
+
+def test_batch_of_mixed_sizes_against_oracle(ctx, oracle):
+    """One call, candidates of very different sizes side by side (all size classes of every kernel at once)."""
+    rng = np.random.default_rng(205)
+    pairs = [synth.make_pair(rng, int(n), flank=(0, int(rng.integers(0, 200))))
+             for n in rng.choice([30, 90, 150, 400, 1200, 2000, 4500, 7000], size=40)]
+    pairs += [_repetitive_pair(rng, 1800, 4, 60), _repetitive_pair(rng, 90, 3, 10)]
+    got = ctx.sdp(pairs)
+    for i, ((q, t), g) in enumerate(zip(pairs, got)):
+        w = oracle.sdp_align(q, t)
+        st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])
+        _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (i, len(q), len(t)))
