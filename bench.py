@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
+PMC_FILL_TRAFFIC = {(100000, 10000, 16): 52275489952.0}
+
+
 def cpu_baseline(w, n_sample, band):
     """The CPU oracle (bit-exact port of SDPAlign + AffineGuidedAlign + ComputeAlignmentStats) timed on
     one host core over the first `n_sample` candidates of the same workload.  Checker code: never on the
@@ -173,9 +177,13 @@ def main():
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
             "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill_kernel<false, true>", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "traffic_note": "PMC passes (profiles/r01_pmc_counters_20k_reads.json): FETCH_SIZE x2 + "
-                                         "WRITE_SIZE = 1.11 x the algorithmic bytes of the same launch",
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
+                         # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
+                         "traffic": PMC_FILL_TRAFFIC.get((args.reads, args.read_len, args.band)),
+                         "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                         "profiles/r01_v9_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "= 52.3 GB per launch = 1.09 x the algorithmic bytes",
                          "algorithmic_bytes_per_launch": acc["fill_bytes"] / launches,
                          "launches": launches, "avg_launch_ms": fill_ms / launches,
                          "fill_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},

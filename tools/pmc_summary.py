@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 --pmc counters per kernel.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out1 -o p -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out2 -o p -- python3 bench.py ...
+    python3 tools/pmc_summary.py out.json out1/p_counter_collection.csv out2/p_counter_collection.csv
+
+FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes
+(MI355X_MICROARCH.md, HBM section), so it is doubled in the derived "hbm_bytes"."""
+import collections
+import csv
+import json
+import sys
+
+
+def main():
+    out, files = sys.argv[1], sys.argv[2:]
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(lambda: collections.defaultdict(set))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0]
+            per[name][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[name][r["Counter_Name"]].add(r["Dispatch_Id"])
+    res = {}
+    for name, c in per.items():
+        if "blasr_hip" not in name:
+            continue
+        d = dict(c)
+        d["dispatches"] = max(len(v) for v in calls[name].values())
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            d["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            d["hbm_bytes_per_dispatch"] = d["hbm_bytes"] / d["dispatches"]
+        res[name] = d
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for name in sorted(res, key=lambda n: -res[n].get("hbm_bytes", 0))[:12]:
+        print("%-70s %s" % (name[:70], {k: round(v, 1) for k, v in res[name].items()}))
+
+
+if __name__ == "__main__":
+    main()
