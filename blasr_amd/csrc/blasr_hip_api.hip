@@ -189,6 +189,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   const size_t oMatrix = carve(sizeof(int32_t) * 25), oTotal = carve(sizeof(int64_t));
   const size_t oWideTasks = carve(sizeof(int32_t) * n), oWideOff = carve(sizeof(int64_t) * n),
                oWideSize = carve(sizeof(int32_t) * n);
+  const size_t oList4 = carve(sizeof(int32_t) * n), oList1 = carve(sizeof(int32_t) * n);
   const size_t fixedBytes = off;
   // first make room for the fixed part + a modest variable part; grown below once the geometry is known
   int rc = ensure_workspace(ctx, fixedBytes);
@@ -318,6 +319,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   int32_t *dWideTasks = reinterpret_cast<int32_t *>(ws + oWideTasks);
   int64_t *dWideOff = reinterpret_cast<int64_t *>(ws + oWideOff);
   int32_t *dWideSize = reinterpret_cast<int32_t *>(ws + oWideSize);
+  int32_t *dList4 = reinterpret_cast<int32_t *>(ws + oList4), *dList1 = reinterpret_cast<int32_t *>(ws + oList1);
   HIP_TRY(ctx, hipMemcpyAsync(dArrowOff, plan.arrowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dRowOff, plan.rowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dArenaOff, plan.arenaOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
@@ -364,8 +366,36 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRingOff = dWideOff;
     fa.wideRingSize = dWideSize;
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
+    fa.taskList = nullptr;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
-    launch_fill(view, fa, false, fast, st);
+    if (fast && !getenv("BLASR_HIP_NO_FILL4")) {
+      // candidates whose rows all fit fill4_kernel's two passes run four to a wavefront, longest first so the
+      // four of a wavefront finish together; the others keep one wavefront each
+      std::vector<int32_t> list4, list1;
+      for (int i = c.first; i < c.first + c.count; i++) {
+        if (geo[i].status != 0) continue;
+        if (geo[i].maxWidth <= fill4_max_width()) list4.push_back(i);
+        else list1.push_back(i);
+      }
+      std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
+      if (!list4.empty()) {
+        HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
+        FillArgs f4 = fa;
+        f4.taskList = dList4;
+        f4.count = (int)list4.size();
+        launch_fill4(view, f4, st);
+      }
+      if (!list1.empty()) {
+        HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
+        FillArgs f1 = fa;
+        f1.taskList = dList1;
+        f1.count = (int)list1.size();
+        launch_fill(view, f1, false, fast, st);
+      }
+      HIP_TRY(ctx, hipStreamSynchronize(st));  // the host lists go out of scope
+    } else {
+      launch_fill(view, fa, false, fast, st);
+    }
     if (!c.wideTasks.empty()) {
       const int nw = (int)c.wideTasks.size();
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));

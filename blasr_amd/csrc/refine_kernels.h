@@ -56,6 +56,7 @@ struct FillArgs {
   int2 *rowTab;             // per row: {matrix offset of the row's first cell, first column}
   const int64_t *rowOff;
   int32_t *dpScore;
+  const int32_t *taskList;  // when set: the candidates to process (indices into the batch), `count` of them
   // global-ring variant: candidates whose rows are too wide for LDS
   const int32_t *wideTasks;
   const int64_t *wideRingOff;
@@ -83,6 +84,9 @@ void launch_geometry(const RefineBatchView &batch, int band, int first, int coun
                      hipStream_t stream);
 void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool fast,
                  hipStream_t stream);
+// four candidates per wavefront (tagged-key variant only); args.taskList / args.count name the candidates
+void launch_fill4(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream);
+int fill4_max_width();
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
 // *total holds the op count of all candidates before `first` on entry and including them on exit
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,

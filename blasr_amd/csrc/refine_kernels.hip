@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   const int lane = lane_id();
   const int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   if (idx >= args.count) return;
-  const int task = kGlobalRing ? args.wideTasks[idx] : args.first + idx;
+  const int task = kGlobalRing ? args.wideTasks[idx] : (args.taskList ? args.taskList[idx] : args.first + idx);
   const TaskGeometry geo = args.geo[task];
   if (geo.status != 0) return;
   if (!kGlobalRing && geo.maxWidth > kLdsMaxWidth) return;  // handled by the global-ring launch
@@ -532,6 +532,263 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
   int fs = finalScore;
   for (int off = 32; off > 0; off >>= 1) fs += __shfl_xor(fs, off);
   if (lane == 0) args.dpScore[task] = fs;
+}
+
+// ---------------------------------------------------------------------------
+// fill4_kernel: the same recurrence, FOUR candidates per wavefront.
+//
+// A band row is ~33 cells, so one candidate per wavefront leaves half of the 64 lanes idle while the kernel is
+// bound by VALU issue.  Here each candidate owns one 16-lane DPP row and every lane three consecutive cells
+// (48 columns per pass; wider rows take further passes with carries).  The row above lives in a per-candidate
+// LDS ring indexed by target column -- any band shift is just an address -- and is updated in place.  The
+// horizontal minima are a lane-local prefix over the three cells plus a 16-lane DPP scan (row_shr 1,2,4,8),
+// which never crosses into another candidate's lanes.  Tagged keys as in fill_kernel<.., true>; candidates
+// outside that variant's domain, or with a row wider than kF4MaxWidth, stay with fill_kernel.
+// ---------------------------------------------------------------------------
+constexpr int kF4Ring = 128;       // {S,I} columns per candidate (a row and the row above overlap in it)
+constexpr int kF4RingT = 128;      // packed matrix columns per candidate (a row plus the 16-column staging step)
+constexpr int kF4MaxWidth = 96;    // widest row: two passes (a third would alias the ring)
+
+__device__ __forceinline__ void row16_prefix_min2(int &a, int &b) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b));
+}
+
+__global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillArgs args) {
+  __shared__ int2 ringLds[4][4][kF4Ring];
+  __shared__ uint32_t ringTLds[4][4][kF4RingT];
+  __shared__ int2 rowA[4][4][64];          // per row of the current 64-row batch: {matrix offset, first column}
+  __shared__ unsigned short rowB[4][4][64];  // width | query code << 8
+  __shared__ unsigned char flagScratch[4][64];
+  __shared__ uint32_t packedCol[8];        // per target code: the matrix column for queries A,C,G,T, one byte each
+  if (threadIdx.x < 5) {
+    uint32_t v = 0;
+    for (int qc = 0; qc < 4; qc++) v |= (uint32_t)(args.matrix[qc * 5 + threadIdx.x] & 0xff) << (8 * qc);
+    packedCol[threadIdx.x] = v;
+  }
+  __shared__ int matN[5];  // the query-N row of the matrix
+  if (threadIdx.x < 5) matN[threadIdx.x] = args.matrix[20 + threadIdx.x];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int grp = lane >> 4, l = lane & 15;
+  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * 4;
+  if (slot0 >= args.count) return;
+
+  // ---- the four candidates of this wavefront (uniform values), and each lane's own candidate
+  int taskG[4], qG[4], tEndG[4];
+  GuideCursor cur[4];
+  const uint8_t *qSeqG[4];
+  int2 *rowTabG[4];
+  int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0;
+  const uint8_t *myTSeq = nullptr;
+  uint8_t *myArrows = nullptr;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    taskG[g] = -1;
+    qG[g] = 0;
+    tEndG[g] = 0;
+    qSeqG[g] = nullptr;
+    rowTabG[g] = nullptr;
+    if (slot0 + g < args.count) {
+      const int task = args.taskList[slot0 + g];
+      taskG[g] = task;
+      const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+      const int nBlocks = batch.n_blocks[task];
+      guide_begin(cur[g], blocks, nBlocks, args.band);
+      qG[g] = cur[g].Q;
+      tEndG[g] = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+      qSeqG[g] = batch.seq + batch.q_off[task];
+      rowTabG[g] = args.rowTab + args.rowOff[task];
+      if (grp == g) {
+        myTask = task;
+        myQ = qG[g];
+        myTEnd = tEndG[g];
+        myTLen = batch.t_len[task];
+        myTSeq = batch.seq + batch.t_off[task];
+        myArrows = args.arrows + args.arrowOff[task];
+        myPlo = cur[g].tStart - 1;
+        myPhi = myPlo + guide_row0_tpost(cur[g]);
+      }
+    }
+  }
+  const int maxQ = max(max(qG[0], qG[1]), max(qG[2], qG[3]));
+  int2 *ring = ringLds[wave][grp];
+  uint32_t *ringT = ringTLds[wave][grp];
+
+  const int inf = 1 << 30;
+  const int kIns = args.ins << kShift, kDel = args.del << kShift, kOpen = args.open << kShift, kExt = args.ext << kShift;
+  int pDel[3], pExt[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    pDel[j] = (3 * l + j) * kDel;
+    pExt[j] = (3 * l + j) * kExt;
+  }
+  // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open
+  if (myTask >= 0)
+    for (int c = myPlo + l; c <= myPhi; c += 16) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+  myTLoaded = myPlo < 0 ? 0 : myPlo;
+  __builtin_amdgcn_wave_barrier();
+
+  for (int r0 = 1; r0 <= maxQ; r0 += 64) {
+    // ---- geometry and query codes of the next 64 rows of every candidate
+    bool wideBatch = false;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (taskG[g] >= 0 && r0 <= qG[g]) {
+        int tV, loV, hiV;
+        unsigned rsV;
+        guide_group(cur[g], r0, flagScratch[wave], tV, loV, hiV, rsV);
+        const int nRows = min(64, qG[g] - r0 + 1);
+        if (lane < nRows) {
+          rowTabG[g][r0 + lane] = make_int2((int)rsV, loV);
+          const int qc = base_code(qSeqG[g][cur[g].qStart + r0 - 1 + lane]);
+          const int width = min(hiV, tEndG[g] - 1) - loV + 1;  // cells with t >= tEnd are skipped (:268-269)
+          rowA[wave][g][lane] = make_int2((int)rsV, loV);
+          rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
+          wideBatch = wideBatch || width > 48;
+        }
+      }
+    }
+    const bool anyWide = __ballot(wideBatch) != 0ull;
+    __builtin_amdgcn_wave_barrier();
+    const int nRowsMax = min(64, maxQ - r0 + 1);
+    for (int i = 0; i < nRowsMax; i++) {
+      const int r = r0 + i;
+      const bool rowOn = myTask >= 0 && r <= myQ;
+      const int2 rec = rowA[wave][grp][i];
+      const unsigned wb = rowB[wave][grp][i];
+      const int lo = rec.y, width = (int)(wb & 0xffu), qc = (int)(wb >> 8);
+      const int hiC = lo + width - 1;
+      // ---- stage the packed matrix columns of the target up to this row's last column
+      while (__ballot(rowOn && myTLoaded <= hiC) != 0ull) {
+        if (rowOn && myTLoaded <= hiC) {
+          const int c = myTLoaded + l;
+          const int code = c < myTLen ? base_code(myTSeq[c]) : 4;
+          ringT[c & (kF4RingT - 1)] = packedCol[code];
+          myTLoaded += 16;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      int nPass = 1;
+      if (anyWide) nPass = wave_max(rowOn ? (width + 47) / 48 : 0);
+      int carryA = inf, carryB = inf, carryDiag = inf;
+      uint8_t *arrowRow = myArrows + (unsigned)rec.x;
+      for (int pass = 0; pass < nPass; pass++) {
+        const int cb = lo + 48 * pass, c0 = cb + 3 * l;
+        // ---- the row above, by column
+        int upS[3], upI[3], diagS[3];
+        bool act[3];
+        const int2 dRaw = ring[(c0 - 1) & (kF4Ring - 1)];
+        int d0 = dRaw.x;
+        if (pass > 0) d0 = (l == 0) ? carryDiag : d0;  // column cb-1 was overwritten by the previous pass
+        d0 = (c0 - 1 <= myPhi && c0 - 1 >= myPlo) ? d0 : inf;
+        int lastRaw = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int c = c0 + j;
+          const int2 up = ring[c & (kF4Ring - 1)];
+          if (j == 2) lastRaw = up.x;
+          const bool upValid = c <= myPhi;  // c >= lo >= plo always
+          upS[j] = upValid ? up.x : inf;
+          upI[j] = upValid ? up.y : inf;
+          act[j] = rowOn && c <= hiC;
+        }
+        diagS[0] = d0;
+        diagS[1] = upS[0];
+        diagS[2] = upS[1];
+        carryDiag = dpp<0x121, 0xf>(0, lastRaw);  // row_ror:1: lane 0 of the group receives lane 15's value
+        // ---- substitution scores
+        int m[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const uint32_t te = ringT[(c0 + j) & (kF4RingT - 1)];
+          m[j] = (int)__builtin_amdgcn_sbfe((int)te, (qc & 3) * 8, 8);
+        }
+        if (__ballot(rowOn && qc >= 4) != 0ull) {  // query N (rare): the packed column has no N row
+#pragma unroll
+          for (int j = 0; j < 3; j++)
+            if (qc >= 4 && act[j]) {
+              const int c = c0 + j;
+              const int tcode = (c >= 0 && c < myTLen) ? base_code(myTSeq[c]) : 4;
+              m[j] = matN[tcode];
+            }
+        }
+        // ---- vertical candidates and the two horizontal chains
+        int vKey[3], insEK[3], ia[3], ib[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int matchK = (m[j] << kShift) + diagS[j];
+          const int insSK = upS[j] + (kIns + AR_UP);
+          insEK[j] = upI[j] + (kExt + AR_INS_CLOSE);
+          vKey[j] = min(matchK, min(insSK, insEK[j]));
+          int v = vKey[j] & ~kTagMask;
+          v = act[j] ? v : inf;
+          ia[j] = v - pDel[j];
+          ib[j] = v - pExt[j];
+        }
+        const int a01 = min(ia[0], ia[1]), b01 = min(ib[0], ib[1]);
+        int pa = min(a01, ia[2]), pb = min(b01, ib[2]);  // this lane's three cells
+        row16_prefix_min2(pa, pb);                       // inclusive over the lanes of the candidate
+        int ea = dpp<0x111, 0xf>(inf, pa), eb = dpp<0x111, 0xf>(inf, pb);  // lanes before this one
+        ea = min(ea, carryA);
+        eb = min(eb, carryB);
+        const int eaj[3] = {ea, min(ea, ia[0]), min(ea, a01)};
+        const int ebj[3] = {eb, min(eb, ib[0]), min(eb, b01)};
+        uint32_t arrowPack = 0;
+        int finalS = 0;
+        bool isFinal = false;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int aK = eaj[j] + (pDel[j] + AR_LEFT);                 // S[c-1] + del
+          const int bK = ebj[j] + (pExt[j] + kOpen + AR_DEL_CLOSE);    // D[c-1] + ext
+          const int sKey = min(vKey[j], min(aK, bK));
+          const int sv = sKey & ~kTagMask;
+          const int openKey = sv + (kOpen + AR_I_OPEN);
+          const int iKey = min(openKey, insEK[j] & ~kTagMask);
+          const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
+          const int arrow = (sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN));
+          arrowPack |= (uint32_t)arrow << (8 * j);
+          // cells beyond the row's end are stored as "no cell": the next row may look at them
+          ring[(c0 + j) & (kF4Ring - 1)] = make_int2(act[j] ? sv : inf, act[j] ? (iKey & ~kTagMask) : inf);
+          const bool fin = act[j] && c0 + j == myTEnd - 1;
+          finalS = fin ? sv : finalS;
+          isFinal = isFinal || fin;
+        }
+        if (isFinal && r == myQ) args.dpScore[myTask] = finalS >> kShift;  // S[Q][tEnd-1] (:481-483)
+        // ---- arrows: three consecutive bytes per lane.  Bytes of cells beyond the row's end spill into the
+        // next row's space (or the slack after the last row) and are overwritten when that row is stored.
+        if (act[0]) {
+          uint8_t *ap = arrowRow + (c0 - lo);
+          ap[0] = (uint8_t)arrowPack;
+          ap[1] = (uint8_t)(arrowPack >> 8);
+          ap[2] = (uint8_t)(arrowPack >> 16);
+        }
+        if (nPass > 1) {  // carries into the next 48 columns
+          const int ta = __builtin_amdgcn_ds_bpermute((lane | 15) * 4, pa), tb = __builtin_amdgcn_ds_bpermute((lane | 15) * 4, pb);
+          carryA = min(carryA, ta) + 48 * kDel;
+          carryB = min(carryB, tb) + 48 * kExt;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (rowOn) {
+        myPlo = lo;
+        myPhi = hiC;
+      }
+    }
+  }
 }
 
 template __global__ void fill_kernel<false, true>(RefineBatchView, FillArgs);
@@ -862,6 +1119,11 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
       hipLaunchKernelGGL((fill_kernel<false, false>), grid, block, 0, stream, batch, args);
   }
 }
+void launch_fill4(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {
+  if (args.count <= 0) return;
+  hipLaunchKernelGGL(fill4_kernel, dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+}
+int fill4_max_width() { return kF4MaxWidth; }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
   if (args.count <= 0) return;
   hipLaunchKernelGGL(traceback_kernel, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
