@@ -694,19 +694,54 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
         }
       return v;
     };
-    bool ok0, ok1;
-    const uint32_t tk0 = kmer_at(tSeq, lane, t.tLen, ok0), tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
-    const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+    // count pass: per query position {count : 16, the first three target positions : 3 x 16} go to `hits`, so
+    // the write pass is a copy unless some position has more than three matches
+    bool haveT = false;
+    uint32_t tk0 = 0, tk1 = 0;
+    unsigned long long m0 = 0, m1 = 0;
     for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
       const int x = x0 + lane;
-      bool okq;
-      const uint32_t qk = kmer_at(qSeq, x, t.qLen, okq);
+      const bool inQ = x + k <= t.qLen;
+      uint64_t h = 0;
       int cnt = 0;
-      for (unsigned long long m = m0; m != 0ull; m &= m - 1ull)
-        cnt += (uint32_t)__builtin_amdgcn_readlane((int)tk0, __builtin_ctzll(m)) == qk;
-      for (unsigned long long m = m1; m != 0ull; m &= m - 1ull)
-        cnt += (uint32_t)__builtin_amdgcn_readlane((int)tk1, __builtin_ctzll(m)) == qk;
-      if (!okq || (t.maxPerPos != 0 && cnt > t.maxPerPos)) cnt = 0;
+      bool replay = !kWrite;
+      if (kWrite) {
+        if (inQ) h = hits[x];
+        cnt = (int)(h & 0xffffu);
+        replay = __ballot(cnt > 3) != 0ull;
+      }
+      uint32_t qk = 0;
+      if (replay) {
+        if (!haveT) {
+          bool ok0, ok1;
+          tk0 = kmer_at(tSeq, lane, t.tLen, ok0);
+          tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
+          m0 = __ballot(ok0);
+          m1 = __ballot(ok1);
+          haveT = true;
+        }
+        bool okq;
+        qk = kmer_at(qSeq, x, t.qLen, okq);
+        if (!kWrite) {
+          uint64_t pos3 = 0;
+          for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
+            const int y = __builtin_ctzll(m);
+            if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
+              if (cnt < 3) pos3 |= (uint64_t)y << (16 * (cnt + 1));
+              cnt++;
+            }
+          }
+          for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
+            const int y = __builtin_ctzll(m);
+            if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
+              if (cnt < 3) pos3 |= (uint64_t)(y + 64) << (16 * (cnt + 1));
+              cnt++;
+            }
+          }
+          if (!okq || (t.maxPerPos != 0 && cnt > t.maxPerPos)) cnt = 0;
+          if (inQ) hits[x] = cnt ? (pos3 | (uint64_t)cnt) : 0ull;
+        }
+      }
       const unsigned incl = wave_prefix_sum((unsigned)cnt);
       if (kWrite && cnt > 0) {
         int w = written + nM + (int)incl - cnt;
@@ -714,18 +749,25 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
         f.x = (uint32_t)x;
         f.len = (uint32_t)k;
         f.pad = 0;
-        for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
-          const int y = __builtin_ctzll(m);
-          if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
-            f.y = (uint32_t)y;
+        if (cnt <= 3) {
+          for (int u = 0; u < cnt; u++) {
+            f.y = (uint32_t)((h >> (16 * (u + 1))) & 0xffffu);
             out[w++] = f;
           }
-        }
-        for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
-          const int y = __builtin_ctzll(m);
-          if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
-            f.y = (uint32_t)(y + 64);
-            out[w++] = f;
+        } else {
+          for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
+            const int y = __builtin_ctzll(m);
+            if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
+              f.y = (uint32_t)y;
+              out[w++] = f;
+            }
+          }
+          for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
+            const int y = __builtin_ctzll(m);
+            if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
+              f.y = (uint32_t)(y + 64);
+              out[w++] = f;
+            }
           }
         }
       }
@@ -1028,11 +1070,74 @@ __device__ __forceinline__ int lds_partition(uint32_t *v, int f, int l) {  // re
     ++lo;
   }
 }
+// __unguarded_partition of a LONG range by the whole wavefront.  The serial two-pointer loop swaps the k-th
+// element from the left that is not below the pivot (position L[k]) with the k-th from the right that is not
+// above it (R[k]) for as long as L[k] < R[k]; both pointers only ever look at elements no swap has touched, so L
+// and R can be listed from the original array in parallel, and the loop returns min(L[K], R[K-1]) at the first K
+// with L[K] >= R[K].  `pos` holds the two position lists.
+__device__ int coop_partition(uint32_t *v, int f, int l, unsigned short *pos, int cap) {
+  const int lane = lane_id();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int mid = f + (l - f) / 2;
+  // __move_median_to_first(f, f+1, mid, l-1): every lane evaluates it, lane 0 swaps
+  const uint32_t a = v[f + 1], b = v[mid], c = v[l - 1];
+  int m;
+  if (rank_less(a, b)) m = rank_less(b, c) ? mid : (rank_less(a, c) ? l - 1 : f + 1);
+  else m = rank_less(a, c) ? f + 1 : (rank_less(b, c) ? l - 1 : mid);
+  const uint32_t pivot = v[m];
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    v[m] = v[f];
+    v[f] = pivot;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t p = pivot >> 16;
+  unsigned short *L = pos, *R = pos + cap;
+  int nL = 0, nR = 0;
+  for (int base = f + 1; base < l; base += 64) {
+    const int i = base + lane;
+    const bool flag = i < l && (v[i] >> 16) >= p;
+    const unsigned long long mask = __ballot(flag);
+    if (flag) L[nL + __popcll(mask & lt)] = (unsigned short)i;
+    nL += (int)__popcll(mask);
+  }
+  for (int top = l - 1; top > f; top -= 64) {
+    const int i = top - lane;
+    const bool flag = i > f && (v[i] >> 16) <= p;
+    const unsigned long long mask = __ballot(flag);
+    if (flag) R[nR + __popcll(mask & lt)] = (unsigned short)i;
+    nR += (int)__popcll(mask);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int nMin = min(nL, nR);
+  int K = 0;
+  for (int k0 = 0; k0 < nMin; k0 += 64) {
+    const int k = k0 + lane;
+    const unsigned long long mask = __ballot(k < nMin && L[k] < R[k]);
+    K += (int)__popcll(mask);
+    if (mask != ~0ull) break;  // L ascends and R descends: the condition is a prefix property
+  }
+  for (int k = lane; k < K; k += 64) {
+    const int ia = L[k], ib = R[k];
+    const uint32_t x = v[ia], y = v[ib];
+    v[ia] = y;
+    v[ib] = x;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int cut = INT32_MAX;
+  if (K < nL) cut = L[K];
+  if (K > 0) cut = min(cut, (int)R[K - 1]);
+  return cut;
+}
+
 template <int kCap>
 __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, int minAll) {
   constexpr int kQueue = kCap / 16;
+  constexpr bool kCoop = kCap <= 4096;  // long ranges are partitioned by the whole wavefront (LDS for the lists)
+  constexpr int kCoopMin = 96;
   __shared__ uint32_t packed[kCap];
   __shared__ uint2 queue[2][kQueue];  // {f | l << 16, depth limit}
+  __shared__ unsigned short posLists[kCoop ? 2 * kCap : 2];
   const int lane = lane_id();
   const int nTies = *lv.tieCount;
   for (int e = blockIdx.x; e < nTies; e += gridDim.x) {
@@ -1062,11 +1167,33 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
       while (nCur > 0) {
         int nNext = 0;
         for (int base = 0; base < nCur; base += 64) {
-          const bool has = base + lane < nCur;
+          bool has = base + lane < nCur;
           int cf[2] = {0, 0}, cl[2] = {0, 0};
           uint32_t depth = 0;
+          uint2 r = make_uint2(0, 0);
+          if (has) r = queue[which][base + lane];
+          if (kCoop) {
+            const bool big = has && r.y != 0 && (int)(r.x >> 16) - (int)(r.x & 0xffffu) >= kCoopMin;
+            for (unsigned long long bm = __ballot(big); bm != 0ull; bm &= bm - 1ull) {
+              const int src = __builtin_ctzll(bm);
+              const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)r.x, src);
+              const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.y, src) - 1u;
+              const int f = (int)(rx & 0xffffu), l = (int)(rx >> 16);
+              const int cut = coop_partition(packed, f, l, posLists, kCap);
+              const int bf[2] = {f, cut}, bl[2] = {cut, l};
+              for (int c = 0; c < 2; c++) {
+                const int size = bl[c] - bf[c];
+                if (size > 16) {
+                  if (lane == 0) queue[which ^ 1][nNext] = make_uint2((uint32_t)bf[c] | ((uint32_t)bl[c] << 16), d);
+                  nNext++;
+                } else if (size > 1 && lane == 0)
+                  lds_insertion_sort(packed, bf[c], bl[c]);
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+            has = has && !big;
+          }
           if (has) {
-            const uint2 r = queue[which][base + lane];
             const int f = (int)(r.x & 0xffffu), l = (int)(r.x >> 16);
             if (r.y == 0) {
               is_heapsort(packed + f, packed + l, RankLess());
