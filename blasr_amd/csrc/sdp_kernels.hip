@@ -1138,6 +1138,8 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
   __shared__ uint32_t packed[kCap];
   __shared__ uint2 queue[2][kQueue];  // {f | l << 16, depth limit}
   __shared__ unsigned short posLists[kCoop ? 2 * kCap : 2];
+  constexpr int kPsCap = 512;
+  __shared__ uint64_t psKeys[kPsCap];  // keys of the prefix and suffix lists
   const int lane = lane_id();
   const int nTies = *lv.tieCount;
   for (int e = blockIdx.x; e < nTies; e += gridDim.x) {
@@ -1148,11 +1150,32 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
     const Frag *P = lv.raw + lv.fragOff[idx], *M = P + nP, *S = M + nM;
     Frag *out = lv.frags + lv.fragOff[idx];
     if (nAll <= kCap) {
-      // rank = number of fragments with a smaller (x,y): equal keys get equal ranks
-      for (int i = lane; i < nAll; i += 64) {
-        const uint64_t key = frag_key(P[i]);
-        const int rank = lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key) + lower_bound_frag(S, nS, key);
-        packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
+      // rank = number of fragments with a smaller (x,y): equal keys get equal ranks.  The prefix and suffix
+      // lists are short: with their keys in LDS a middle fragment's rank needs no dependent HBM reads
+      if (nP + nS <= kPsCap) {
+        for (int i = lane; i < nP; i += 64) psKeys[i] = frag_key(P[i]);
+        for (int i = lane; i < nS; i += 64) psKeys[nP + i] = frag_key(S[i]);
+        __syncthreads();
+        auto lb = [&](const uint64_t *a, int n, uint64_t key) {
+          int lo = 0, hi = n;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (a[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          return lo;
+        };
+        for (int i = lane; i < nAll; i += 64) {
+          const bool inM = i >= nP && i < nP + nM;
+          const uint64_t key = inM ? frag_key(P[i]) : psKeys[i < nP ? i : i - nM];
+          const int rank = lb(psKeys, nP, key) + lb(psKeys + nP, nS, key) + (inM ? i - nP : lower_bound_frag(M, nM, key));
+          packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
+        }
+      } else {
+        for (int i = lane; i < nAll; i += 64) {
+          const uint64_t key = frag_key(P[i]);
+          const int rank = lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key) + lower_bound_frag(S, nS, key);
+          packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
+        }
       }
       __syncthreads();
       int lg = 0;
