@@ -94,10 +94,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
   if ((sp->align_type != 0 && sp->align_type != 1) || sp->detailed != 1 || sp->extend_front != 0 ||
-      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0)
+      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
+      sp->sdp_ins >= 64 || sp->sdp_del <= -64 || sp->sdp_del >= 64)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
                           "SDP parameters outside the device domain (align_type Local/Global, detailed=1, "
-                          "extend_front=0, 1 <= word_size <= 16)");
+                          "extend_front=0, 1 <= word_size <= 16, |sdp_ins|, |sdp_del| < 64)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   Arena arena(ctx, st);

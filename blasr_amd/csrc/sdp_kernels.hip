@@ -1395,6 +1395,10 @@ __device__ int4 cs_get(const ColSet &s, int pos) {
   if (pos >= s.nBase) return lane_bcast(s.tail, pos - s.nBase);
   return s.g[pos];
 }
+__device__ int cs_get_cost(const ColSet &s, int pos) {
+  if (pos >= s.nBase) return __builtin_amdgcn_readlane(s.tail.z, pos - s.nBase);
+  return s.g[pos].z;
+}
 __device__ void cs_set(ColSet &s, int pos, int4 e) {
   const int lane = lane_id();
   if (pos >= s.nBase) {
@@ -1459,10 +1463,12 @@ __device__ void cs_erase_range(ColSet &s, int first, int count) {  // removes [f
 }
 
 // IndelPenalty (SparseDynamicProgramming.h:27-53)
+// The reference forms the product in double and truncates; with |drift| < 2^25 (sequences < 2^24, checked on the
+// host) and penalties below 64 the product is an exact integer below 2^31, so integer arithmetic gives the same.
 __device__ __forceinline__ int indel_penalty(int x1, int y1, int x2, int y2, int insertion, int deletion) {
   const int drift = (x1 - y1) - (x2 - y2);
-  if (drift > 0) return (int)((1.0 * drift) * insertion);
-  if (drift < 0) return (int)((-1.0 * drift) * deletion);
+  if (drift > 0) return drift * insertion;
+  if (drift < 0) return -drift * deletion;
   return 0;
 }
 // (int)sqrt((double)d) for 0 <= d < 2^31, without the double-precision pipeline
@@ -1507,6 +1513,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
   int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
   uint32_t maxLen = 0;
   FragWindow cur, prev;
+  int curPrev = -1;
   cur.x = cur.y = cur.cost = cur.len = 0;
   prev = cur;
   for (int w0 = 0; w0 < F; w0 += 64) {
@@ -1525,26 +1532,33 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
     cur.x = fxV;
     cur.y = fyV;
     // fragment p as seen by the sweep: from the two register windows, else from memory
-    auto view = [&](int p) {
+    // kLen = false leaves out the chain length (only the chosen predecessor's is ever needed)
+    auto view = [&](int p, bool wantLen) {
       FragView v;
+      v.len = 0;
       if (p >= w0) {
         v.x = __builtin_amdgcn_readlane(cur.x, p - w0);
         v.y = __builtin_amdgcn_readlane(cur.y, p - w0);
         v.cost = __builtin_amdgcn_readlane(cur.cost, p - w0);
-        v.len = __builtin_amdgcn_readlane(cur.len, p - w0);
+        if (wantLen) v.len = __builtin_amdgcn_readlane(cur.len, p - w0);
       } else if (p >= w0 - 64) {
         v.x = __builtin_amdgcn_readlane(prev.x, p - w0 + 64);
         v.y = __builtin_amdgcn_readlane(prev.y, p - w0 + 64);
         v.cost = __builtin_amdgcn_readlane(prev.cost, p - w0 + 64);
-        v.len = __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
+        if (wantLen) v.len = __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
       } else {
         const Frag f = fr[p];
         v.x = (int)f.x;
         v.y = (int)f.y;
         v.cost = cost[p];
-        v.len = chainLen[p];
+        if (wantLen) v.len = chainLen[p];
       }
       return v;
+    };
+    auto view_len = [&](int p) {
+      if (p >= w0) return __builtin_amdgcn_readlane(cur.len, p - w0);
+      if (p >= w0 - 64) return __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
+      return chainLen[p];
     };
     const int nHere = min(64, F - w0);
     for (int j = 0; j < nHere; j++) {
@@ -1553,7 +1567,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
       const int fl = __builtin_amdgcn_readlane(flV, j);
       // rows leaving the window: fragments with x <= f.x - k - 2 are retired before row f.x is scored (:248-309)
       while (fTrail < i) {
-        const FragView ft = view(fTrail);
+        const FragView ft = view(fTrail, false);
         if ((int64_t)ft.x + k + 2 > (int64_t)fx) break;
         const int pos = cs_lower_bound(cols, ft.y);
         int4 at = make_int4(0, 0, 0, 0);
@@ -1570,7 +1584,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
           else cs_insert_at(cols, pos, e);
           // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
           int del = 0;
-          while (cols.n - del >= 2 && pos + 1 + del < cols.n && cs_get(cols, pos + 1 + del).z > ft.cost) del++;
+          while (cols.n - del >= 2 && pos + 1 + del < cols.n && cs_get_cost(cols, pos + 1 + del) > ft.cost) del++;
           if (del) cs_erase_range(cols, pos + 1, del);
         }
         fTrail++;
@@ -1597,7 +1611,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
       }
       const int clFrag = __builtin_amdgcn_readlane(fpV, j);
       if (clFrag >= 0) {
-        const FragView p = view(clFrag);
+        const FragView p = view(clFrag, false);
         int ov = (int)(fragmentLength - (uint32_t)(fy - p.y)) * prm.match;
         if (ov > 0) ov = 0;
         cl = p.cost + ov + indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel);
@@ -1605,7 +1619,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
       }
       const int aboveIdx = __builtin_amdgcn_readlane(faV, j);
       if (aboveIdx >= 0) {
-        const FragView p = view(aboveIdx);
+        const FragView p = view(aboveIdx, false);
         ca = (int)((uint32_t)p.cost + (fragmentLength - (uint32_t)(fy - p.y)) * (uint32_t)prm.match +
                    (uint32_t)indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel));
         foundPrev = true;
@@ -1619,7 +1633,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
         if (mc == cp) myPrev = cpFrag;
         else if (mc == cl) myPrev = clFrag;
         else myPrev = aboveIdx;
-        myLen = (uint32_t)view(myPrev).len + 1u;
+        myLen = (uint32_t)view_len(myPrev) + 1u;
       } else {
         myPrev = -1;
         myLen = 1;
@@ -1630,10 +1644,7 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
       if (lane == j) {
         cur.cost = myCost;
         cur.len = (int)myLen;
-        // memory copies: chainPrev for the back-trace, cost / chainLen for the rare far look-ups
-        cost[i] = myCost;
-        chainPrev[i] = myPrev;
-        chainLen[i] = (int)myLen;
+        curPrev = myPrev;
       }
       if (minCost > myCost) {
         minCost = myCost;
@@ -1643,6 +1654,13 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
         maxLen = myLen;
         maxLenIdx = i;
       }
+    }
+    // memory copies, one coalesced store per window: chainPrev for the back-trace, cost / chainLen for the rare
+    // look-ups that reach further back than the previous window
+    if (w0 + lane < F) {
+      cost[w0 + lane] = cur.cost;
+      chainPrev[w0 + lane] = curPrev;
+      chainLen[w0 + lane] = cur.len;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }

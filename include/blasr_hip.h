@@ -159,7 +159,7 @@ int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t 
 /* ---- SDP: SDPAlign + ComputeAlignmentStats ----------------------------- */
 /* The parameters AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722;
  * defaults MappingParameters.h:192-361).  Supported on the device: align_type
- * Local (0) or Global (1), detailed = 1, extend_front = 0, word_size <= 16,
+ * Local (0) or Global (1), detailed = 1, extend_front = 0, word_size <= 16, |sdp_ins|, |sdp_del| < 64,
  * sequences shorter than 2^24 bases (else ERR_UNSUPPORTED). */
 typedef struct blasr_hip_sdp_params {
   int32_t word_size;        /* sdpTupleSize (11) */
