@@ -176,7 +176,10 @@ def main():
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
-            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill_kernel<false, true>", "achieved": achieved,
+            # the DP fill = fill4_kernel (four candidates per wavefront) + fill_kernel for the candidates with a
+            # row wider than 96 cells; bytes and time are those of the whole fill launch group
+            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill4_kernel (+ fill_kernel for wide rows)",
+                         "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process

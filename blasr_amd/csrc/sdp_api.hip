@@ -50,11 +50,6 @@ struct Arena {
     }
     char *p = ctx->slabs[slab].first + offset;
     offset += bytes;
-    const int idx = count++;
-    if (const char *poison = getenv("BLASR_HIP_POISON")) {  // developer aid: make reads of unwritten memory visible
-      const char *lo = getenv("BLASR_HIP_POISON_LO"), *hi = getenv("BLASR_HIP_POISON_HI");
-      if ((!lo || idx >= atoi(lo)) && (!hi || idx < atoi(hi))) (void)hipMemsetAsync(p, atoi(poison), bytes, st);
-    }
     return reinterpret_cast<T *>(p);
   }
 };
@@ -293,28 +288,6 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     tick();
     launch_sdp_chain(lv, prm, st);
     tock(2);
-    if (level == 0 && getenv("BLASR_HIP_SDP_DEBUG")) {
-      // developer aid: dump the fragments and chain state of candidate 0 (level 0)
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      int32_t nf0 = 0, end0 = 0;
-      (void)hipMemcpy(&nf0, lv.nFrag, 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&end0, lv.chainEnd, 4, hipMemcpyDeviceToHost);
-      std::vector<Frag> hf(std::max(nf0, 1));
-      std::vector<int32_t> hc(std::max(nf0, 1)), hp(std::max(nf0, 1)), hcl(std::max(nf0, 1)), hab(std::max(nf0, 1));
-      (void)hipMemcpy(hf.data(), lv.frags, sizeof(Frag) * nf0, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hc.data(), lv.cost, 4 * nf0, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hp.data(), lv.chainPrev, 4 * nf0, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hcl.data(), lv.predCl, 4 * nf0, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hab.data(), lv.above, 4 * nf0, hipMemcpyDeviceToHost);
-      FILE *fp = fopen(getenv("BLASR_HIP_SDP_DEBUG"), "w");
-      if (fp) {
-        fprintf(fp, "%d %d\n", nf0, end0);
-        for (int i = 0; i < nf0; i++)
-          fprintf(fp, "%u %u %u %d %d %d %d\n", hf[i].x, hf[i].y, hf[i].len, hc[i], hp[i], hcl[i], hab[i]);
-        fclose(fp);
-      }
-    }
-
     // ---- blocks, gap-fill jobs, next level ----
     tick();
     // what every task will emit, then exclusive scans -> contention-free slots
@@ -435,36 +408,6 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     e.poolCount = &dCounters->pool;
     e.poolCap = poolCap;
     e.overflow = &dCounters->overflow;
-    if (getenv("BLASR_HIP_SW_HIST")) {
-      // developer aid: size distribution of the SWAlign fills
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      long long hq[12] = {0}, ht[12] = {0}, hcells[12] = {0}, cells = 0, waveMax = 0, nw = 0, waveRect = 0;
-      for (auto &lo : outs) {
-        std::vector<SwTask> h((size_t)lo.swCount);
-        (void)hipMemcpy(h.data(), lo.sw, sizeof(SwTask) * lo.swCount, hipMemcpyDeviceToHost);
-        for (int64_t i = 0; i < lo.swCount; i += 64) {
-          long long mx = 0, mq = 0, mt = 0;
-          for (int64_t j = i; j < std::min(i + 64, lo.swCount); j++) {
-            const long long c = (long long)h[j].qLen * h[j].tLen;
-            cells += c;
-            mx = std::max(mx, c);
-            mq = std::max<long long>(mq, h[j].qLen);
-            mt = std::max<long long>(mt, h[j].tLen);
-            auto bin = [](long long v) { int b = 0; while (v > 1 && b < 11) { v >>= 1; b++; } return b; };
-            hq[bin(h[j].qLen)]++;
-            ht[bin(h[j].tLen)]++;
-            hcells[bin(c)]++;
-          }
-          waveMax += mx;
-          waveRect += mq * mt;
-          nw++;
-        }
-      }
-      fprintf(stderr, "[sw] fills %lld cells %lld  sum(max cells per wave) %lld sum(maxq*maxt per wave) %lld waves %lld\n",
-              (long long)swTotal, cells, waveMax, waveRect, nw);
-      for (int b = 0; b < 12; b++)
-        fprintf(stderr, "[sw] 2^%d: q %lld t %lld cells %lld\n", b, hq[b], ht[b], hcells[b]);
-    }
     int level = 0;
     for (auto &lo : outs) {
       if (lo.swCount <= 0) continue;

@@ -43,9 +43,6 @@
 
 namespace blasr_hip {
 
-#ifndef DEBUG_DCACHE_INV
-#define DEBUG_DCACHE_INV 0
-#endif
 constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
 
 // long targets are matched by sdp_match_index_kernel (further down) and need no sorted keys
@@ -65,7 +62,6 @@ __host__ __device__ inline bool task_needs_keys(int tLen, int k, int idxMaxT) {
 }
 
 __device__ __forceinline__ int wave_task_index() {
-  if (DEBUG_DCACHE_INV) __builtin_amdgcn_s_dcache_inv();
   return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 }
 

@@ -158,3 +158,40 @@ def test_unsupported_gap_costs_are_rejected(ctx):
     with pytest.raises(blasr_amd.BlasrHipError) as e:
         ctx.refine(b, ops_capacity=0)
     assert e.value.code == hip.ERR_CAPACITY
+
+
+def test_one_candidate_per_wavefront_kernel_agrees(ctx, golden, monkeypatch):
+    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront) instead of fill4_kernel
+    (four per wavefront): the same goldens must come out of both."""
+    cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
+             and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
+    b = blasr_amd.RefineBatch()
+    for c in cases:
+        b.add(c.qs, c.ts, c.sdp_blocks)
+    monkeypatch.setenv("BLASR_HIP_NO_FILL4", "1")
+    for c, got in zip(cases, ctx.refine(b)):
+        assert first_difference(got.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
+    monkeypatch.delenv("BLASR_HIP_NO_FILL4")
+
+
+def test_many_candidates_of_ragged_lengths(ctx, oracle):
+    """fill4_kernel packs four candidates of different lengths and widths into one wavefront."""
+    rng = np.random.default_rng(77)
+    b = blasr_amd.RefineBatch()
+    want = []
+    for it in range(37):  # not a multiple of four
+        q, t = synth.make_pair(rng, int(rng.integers(60, 1500)), flank=(0, int(rng.integers(0, 80))),
+                               big_indel=(("del", int(rng.integers(20, 90))) if it % 5 == 0 else None))
+        sdp = oracle.sdp_align(q, t)
+        if len(sdp["blocks"]) == 0:
+            continue
+        last = sdp["blocks"][-1]
+        qs = q[sdp["qPos"]: sdp["qPos"] + last[0] + last[2]]
+        ts = t[sdp["tPos"]: sdp["tPos"] + last[1] + last[2]]
+        b.add(qs, ts, sdp["blocks"])
+        want.append(oracle.affine_guided_align(qs, ts, sdp["blocks"]))
+    got = ctx.refine(b)
+    assert len(got) == len(want) >= 30
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.status == 0, i
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i

@@ -174,3 +174,20 @@ def test_batch_of_mixed_sizes_against_oracle(ctx, oracle):
         w = oracle.sdp_align(q, t)
         st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])
         _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (i, len(q), len(t)))
+
+
+def test_alternative_kernels_agree(ctx, oracle, monkeypatch):
+    """The library picks its kernels by size class; the switches BLASR_HIP_NO_INDEX (long targets through the
+    sorted-key kernels instead of the LDS index) force the general path, which must give the same answers."""
+    rng = np.random.default_rng(206)
+    pairs = [synth.make_pair(rng, n, flank=(0, 150)) for n in (1700, 2600, 5200)]
+    want = [oracle.sdp_align(q, t) for q, t in pairs]
+    for env in ({}, {"BLASR_HIP_NO_INDEX": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = ctx.sdp(pairs)
+        for (q, t), g, w in zip(pairs, got, want):
+            st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])
+            _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (env, len(q)))
+        for k in env:
+            monkeypatch.delenv(k)
