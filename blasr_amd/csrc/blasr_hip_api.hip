@@ -264,7 +264,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       size_t a = 0, r = 0, ar = 0, w = 0;
       int ringSize = 0;
       if (geo[i].status == 0) {
-        a = align_up((size_t)geo[i].cells + 8, 64);  // + 8: the traceback reads 8-byte windows
+        a = align_up((size_t)geo[i].cells + 16, 64);  // + 16: the traceback reads 16-byte windows
         r = sizeof(int2) * ((size_t)geo[i].rows + 1);
         ar = sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
         if (geo[i].maxWidth > kLdsMaxWidth) {
@@ -338,7 +338,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     size_t arrowB = 0, rowB = 0, arenaB = 0;
     for (int i = c.first; i < c.first + c.count; i++)
       if (geo[i].status == 0) {
-        arrowB += align_up((size_t)geo[i].cells + 8, 64);
+        arrowB += align_up((size_t)geo[i].cells + 16, 64);
         rowB += sizeof(int2) * ((size_t)geo[i].rows + 1);
         arenaB += sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
       }

@@ -800,22 +800,25 @@ template __global__ void fill_kernel<true, false>(RefineBatchView, FillArgs);
 // traceback_kernel: one lane per candidate (AffineGuidedAlign.h:377-468), fused with
 // ArrowPathToAlignment (RLE, Alignment.h:190-254) and RemoveAlignmentPrefixGaps.
 //
-// The walk is a chain of dependent byte loads, so it is organised around memory
-// latency: the outer loop advances one DP row per iteration (every arrow except
-// Left/AffineDelLeft moves up exactly one row), and the arrow bytes of a row are
-// fetched as an 8-byte window four rows before the path gets there (the path
-// drifts at most one column per row, so a window ending at the current column
-// still covers it), the row records eight rows ahead.  The loop is unrolled by 8
-// so that every window / record lives in a statically named register and the
-// compiler can wait with counted vmcnt instead of draining all loads.
+// The walk is a chain of dependent byte loads, so it is organised around memory latency: rows are taken
+// EIGHT at a time.  At the start of a batch the lane issues, back to back, the 16-byte arrow windows of the
+// eight rows ahead (the path moves at most one column per row unless it runs through a deletion, so the
+// window of the j-th row ends 8 columns right of the column it would reach on a pure diagonal) and the row
+// records of the following batch; the single wait for these loads is the only exposed memory latency per
+// eight rows.  A path that leaves its window (a long deletion) fetches on demand.
 // ---------------------------------------------------------------------------
-constexpr int kTbWin = 8;  // bytes per prefetched arrow window
+constexpr int kTbWin = 16;  // bytes per prefetched arrow window
 
-__device__ __forceinline__ uint64_t load_window(const uint8_t *p) {
-  // unaligned 8-byte load (global memory allows it); p stays inside the candidate's arrow slab
-  uint64_t v;
-  __builtin_memcpy(&v, p, 8);
+__device__ __forceinline__ uint4 load_window(const uint8_t *p) {
+  // unaligned 16-byte load (global memory allows it); p + 16 stays inside the candidate's arrow slab
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
   return v;
+}
+__device__ __forceinline__ unsigned window_byte(const uint4 &w, int i) {  // 0 <= i < 16
+  const uint32_t lo = (i & 4) ? w.y : w.x, hi = (i & 4) ? w.w : w.z;
+  const uint32_t d = (i & 8) ? hi : lo;
+  return (d >> ((i & 3) * 8)) & 0xffu;
 }
 
 // Candidates per wavefront.  The walk is latency-bound (a dependent load per row), so the device wants many
@@ -867,25 +870,28 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
     curLen = 1;
   };
 
-  // slot k of RT holds the record of row Q-k' (k' = k mod 8), slot k of W/CB the window of row Q-k' (k' mod 4)
-  int2 RT[8];
-  uint64_t W[4];
-  int CB[4];
+  // RT[j] = record of the j-th row of the current batch (rows rTop, rTop-1, ...), RTn the same for the next one
+  int2 RT[8], RTn[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) RT[j] = (alive && Q - j >= 1) ? rowTab[Q - j] : make_int2(0, 0);
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    CB[j] = max(c - (kTbWin - 1), RT[j].y);
-    W[j] = (alive && Q - j >= 1) ? load_window(arrows + (unsigned)RT[j].x + (unsigned)(CB[j] - RT[j].y)) : 0ull;
-  }
 
-  for (int k0 = 0; __any(alive); k0 += 8) {
+  for (int rTop = Q; __any(alive); rTop -= 8) {
+    uint4 W[8];
+    int CB[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int r = Q - (k0 + j);
+      CB[j] = max(c - j - (kTbWin / 2 - 1), RT[j].y);
+      W[j] = (alive && rTop - j >= 1) ? load_window(arrows + (unsigned)RT[j].x + (unsigned)(CB[j] - RT[j].y))
+                                      : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) RTn[j] = (alive && rTop - 8 - j >= 1) ? rowTab[rTop - 8 - j] : make_int2(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = rTop - j;
       if (alive && r >= 1) {
-        uint64_t win = W[j & 3];
-        int cb = CB[j & 3];
+        uint4 win = W[j];
+        int cb = CB[j];
         const int2 row = RT[j];  // {matrix offset of the row, first column}
         // all moves inside row r
         int guard = (tEnd - tStart) + 8;
@@ -894,7 +900,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
             cb = max(c - (kTbWin - 1), row.y);
             win = load_window(arrows + (unsigned)row.x + (unsigned)(cb - row.y));
           }
-          const unsigned a = (unsigned)(win >> ((c - cb) * 8)) & 0xffu;
+          const unsigned a = window_byte(win, c - cb);
           if (state == 0) {
             const unsigned s = a & 7u;
             if (s == AR_DIAG) {
@@ -941,14 +947,6 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
             break;
           }
         }
-        // the path is now in row r-1.  Prefetch the window of row r-4 and the record of row r-8
-        // into the slots this row just vacated.
-        if (r - 4 >= 1) {
-          const int2 ahead = RT[(j + 4) & 7];
-          CB[j & 3] = max(c - (kTbWin - 1), ahead.y);
-          W[j & 3] = load_window(arrows + (unsigned)ahead.x + (unsigned)(CB[j & 3] - ahead.y));
-        }
-        if (r - 8 >= 1) RT[j] = rowTab[r - 8];
         if (r == 1 && alive) {
           // row 0 (the deletion row, :178-208): Left arrows down to column tStart-1; the walk ends when
           // q < qStart and t < tStart
@@ -960,6 +958,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++) RT[j] = RTn[j];
   }
   if (inRange && geo.status == 0) {
     emit(-2);  // flush the last run
