@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL_TRAFFIC = {(100000, 10000, 16): 52275489952.0}
+PMC_FILL_TRAFFIC = {(100000, 10000, 16): 62832779552.0}
 
 
 def cpu_baseline(w, n_sample, band):
@@ -185,8 +185,8 @@ def main():
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
                          "traffic": PMC_FILL_TRAFFIC.get((args.reads, args.read_len, args.band)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v9_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
-                                         "= 52.3 GB per launch = 1.09 x the algorithmic bytes",
+                                         "profiles/r01_v10_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "summed over the three fill kernels = 62.8 GB = 1.31 x the algorithmic bytes",
                          "algorithmic_bytes_per_launch": acc["fill_bytes"] / launches,
                          "launches": launches, "avg_launch_ms": fill_ms / launches,
                          "fill_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
