@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
     const int k = t.k, ks = k < 5 ? k : 5;
     const uint32_t kmerMask = (1u << (2 * k)) - 1u, kMask = (1u << k) - 1u;
-    const bool build = !kWrite || lv.idxFlag[idx] != 0;
+    if (kWrite && lv.idxFlag[idx] == 0) continue;  // sdp_match_index_copy_kernel's
+    const bool build = true;
     if (build) {
       // ---- the target, packed
       for (int wi = tid; wi < (t.tLen + 15) / 16 + 2; wi += 256) {
@@ -626,6 +627,64 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
                                         suffixPos, ks, t.maxPerPos, out, nP + nMall);
       if (!kWrite && lane == 0) lv.nRaw[3 * idx + 2] = n2;
     }
+  }
+}
+
+// Write pass for the invocations whose count pass found at most three matches per query position (lv.idxFlag
+// = 0, nearly all of them): every fragment is already spelled out in lv.hits, so this is a copy that needs no
+// index and no LDS -- a separate kernel so that its occupancy is not limited by the index's LDS footprint.
+__global__ __launch_bounds__(256) void sdp_match_index_copy_kernel(SdpLevelArrays lv, const uint8_t *seq) {
+  __shared__ int part[4];
+  const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+  const int nBig = *lv.bigCount;
+  for (int e = blockIdx.x; e < nBig; e += gridDim.x) {
+    const int idx = lv.bigList[e];
+    if (lv.idxFlag[idx] != 0) continue;  // sdp_match_index_kernel<true> rebuilds the index for it
+    const SdpTask t = lv.tasks[idx];
+    const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
+    const int k = t.k, ks = k < 5 ? k : 5;
+    const int nKmerQ = max(t.qLen - k + 1, 0);
+    const int perQ = (((nKmerQ + 3) / 4) + 63) & ~63;
+    const int qlo = min(wv * perQ, nKmerQ), qhi = min(nKmerQ, qlo + perQ);
+    const uint64_t *hits = lv.hits + lv.qPosOff[idx];
+    Frag *out = lv.raw + lv.fragOff[idx];
+    const int nP = lv.nRaw[3 * idx], nMall = lv.nRaw[3 * idx + 1];
+    int mine = 0;
+    for (int x = qlo + lane; x < qhi; x += 64) mine += (int)(hits[x] & 0xffffu);
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    __syncthreads();
+    if (lane == 0) part[wv] = mine;
+    __syncthreads();
+    int wBase = nP;
+    for (int w = 0; w < wv; w++) wBase += part[w];
+    for (int x0 = qlo; x0 < qhi; x0 += 64) {
+      const int x = x0 + lane;
+      uint64_t h = 0;
+      if (x < qhi) h = hits[x];
+      const int cnt = (int)(h & 0xffffu);
+      const unsigned incl = wave_prefix_sum((unsigned)cnt);
+      int w = wBase + (int)incl - cnt;
+      Frag f;
+      f.x = (uint32_t)x;
+      f.len = (uint32_t)k;
+      f.pad = 0;
+      for (int u = 0; u < cnt; u++) {
+        f.y = (uint32_t)((h >> (16 * (u + 1))) & 0xffffu);
+        out[w++] = f;
+      }
+      wBase += __builtin_amdgcn_readlane((int)incl, 63);
+    }
+    // prefix and suffix parts (SDPAlign.h:148-182), wavefront 0 and 1
+    const int prefixLength = min(t.tLen, t.prefix);
+    const int suffixLength = min(t.tLen - prefixLength, t.prefix);
+    const int suffixPos = t.tLen - suffixLength;
+    const int qPrefixLength = min(t.qLen, t.prefix);
+    const int qSuffixLength = min(t.qLen - qPrefixLength, t.prefix);
+    const int qSuffixPos = t.qLen - qSuffixLength;
+    if (wv == 0) small_part<true>(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0, ks, t.maxPerPos, out, 0);
+    else if (wv == 1)
+      small_part<true>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos, suffixPos, ks,
+                       t.maxPerPos, out, nP + nMall);
   }
 }
 
@@ -2423,6 +2482,7 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
   // two size classes, so that the usual targets (<= kIdxSmallCap) get two workgroups per CU
   const int grid = std::min(lv.n, 1024);
   const int caps[2] = {std::min(kIdxSmallCap, lv.idxMaxT), lv.idxMaxT};
+  if (write) hipLaunchKernelGGL(sdp_match_index_copy_kernel, dim3(std::min(lv.n, 8192)), dim3(256), 0, st, lv, seq);
   for (int c = 0; c < 2; c++) {
     if (c == 1 && caps[1] <= caps[0]) break;
     const int minT = c == 0 ? 0 : caps[0];
