@@ -243,27 +243,264 @@ __global__ __launch_bounds__(64) void kband_traceback_kernel(KbandArgs a) {
   a.opsStart[task] = pos;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403): one matrix, linear gaps, alignment
+// types Global / QueryFit / TargetFit / Fit.  The reference fills its matrices with 0 / NoArrow and its loops
+// skip some cells that later ones read (row 0 beyond t < tLen, the TargetFit column); to get exactly those
+// values the kernel keeps a full image of the current and the previous matrix row in LDS, zero-filled before
+// the boundary values and the computed cells go in, and writes an arrow byte for EVERY cell of the matrix.
+// ---------------------------------------------------------------------------------------------
+enum { KL_DIAG = 0, KL_UP = 1, KL_LEFT = 2, KL_NONE = 3 };
+enum { KT_GLOBAL = 1, KT_QUERYFIT = 2, KT_TARGETFIT = 3, KT_FIT = 7 };
+
+struct KbandLinearArgs {
+  int first, count;
+  int ins, del, fnIns, fnDel, alignType;
+  const int32_t *matrix;
+  const KbandGeo *geo;
+  const uint8_t *seq;
+  const int64_t *qOff, *tOff;
+  uint8_t *arrows;
+  const int64_t *arrowOff;
+  int32_t *scores;          // per task: last row image (nCols), S[q][t = tLen] for q = 0..qLen, then S[q][column
+                            // k - (qLen - tLen)] for q = 0..qLen (where the reference starts a TargetFit walk)
+  const int64_t *scoreOff;
+  uint32_t *arena;
+  const int64_t *arenaOff;
+  int32_t *opsStart;
+  RefineResult *results;
+};
+
+__global__ __launch_bounds__(256) void kband_linear_fill_kernel(KbandLinearArgs a) {
+  __shared__ int rowImg[4][2][kKbMaxCols + 64];
+  __shared__ int m[25];
+  if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x];
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0) return;
+  const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
+  uint8_t *arrows = a.arrows + a.arrowOff[task];
+  int32_t *scores = a.scores + a.scoreOff[task];
+  const int k = g.k, nCols = g.nCols, qLen = g.qLen, tLen = g.tLen, fnDel = a.fnDel;
+  const bool fitQ = a.alignType == KT_QUERYFIT || a.alignType == KT_FIT;
+  const bool fitT = a.alignType == KT_TARGETFIT || a.alignType == KT_FIT;
+  int *prev = rowImg[wv][0], *cur = rowImg[wv][1];
+  // ---- row 0 (:113-141)
+  for (int c = lane; c < nCols + 64; c += 64) {
+    int v = 0, ar = KL_NONE;
+    const int t = c - k;
+    if (c < nCols && t >= 1 && t <= k && t < tLen && (a.alignType == KT_GLOBAL || fitQ)) {
+      v = a.alignType == KT_GLOBAL ? t * a.del : 0;
+      ar = KL_LEFT;
+    }
+    if (c == k) ar = KL_DIAG;
+    prev[c] = v;
+    if (c < nCols) arrows[c] = (uint8_t)ar;
+  }
+  const int cEnd = k - (qLen - tLen);  // the Global end column; TargetFit / Fit keep it for whatever row they pick
+  if (lane == 0) {
+    if (tLen <= k) scores[nCols] = prev[k + tLen];  // S[0][t = tLen]
+    scores[nCols + qLen + 1] = prev[cEnd];
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int q = 1; q <= qLen; q++) {
+    const int qc = base_code((unsigned)qSeq[q - 1]);
+    uint8_t *arrowRow = arrows + (int64_t)q * nCols;
+    // the zero-filled row with its boundary cells
+    for (int c = lane; c < nCols + 64; c += 64) {
+      cur[c] = 0;
+      if (c < nCols) arrowRow[c] = (uint8_t)KL_NONE;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (q <= k) {
+        cur[k - q] = q * a.ins;
+        arrowRow[k - q] = (uint8_t)KL_UP;
+      }
+      if (fitT && q <= k && q < qLen) {
+        cur[0] = 0;
+        arrowRow[0] = (uint8_t)KL_UP;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cLo = max(0, k - q + 1), cHi = min(2 * k, k + tLen - q);
+    const int cSeed = cLo - 1;  // the cell left of the first computed one (t = 0 or outside the band)
+    // carry: min of S[j] + (cb - j)*fnDel over the cells left of the chunk, so that adding lane*fnDel gives the
+    // deletion chain's value at the lane; seeded with the cell left of the first computed one
+    int carry = cSeed >= 0 ? cur[cSeed] + fnDel : kKbInf;
+    int carryS = cSeed >= 0 ? cur[cSeed] : kKbInf;
+    for (int cb = cLo; cb <= cHi; cb += 64) {
+      const int c = cb + lane;
+      const bool valid = c <= cHi;
+      int match = kKbInf, insS = kKbInf;
+      if (valid) {
+        match = prev[c] + m[base_code((unsigned)tSeq[c - k + q - 1]) * 5 + qc];  // scoreMatrix[ref][query]
+        if (c < 2 * k) insS = prev[c + 1] + a.fnIns;
+      }
+      const int v = min(match, insS);
+      int x = v - lane * fnDel;
+      x = wave_prefix_min(x);
+      const int e = min(wave_shr1(x, kKbInf), carry);
+      const int s = min(v, e + lane * fnDel);
+      const int left = wave_shr1(s, carryS);
+      const bool hasLeft = c > 0;  // t == q - k has no deletion (:151-153)
+      const int delScore = hasLeft ? left + fnDel : kKbInf;
+      const int arrow = (s == match) ? KL_DIAG : ((s == delScore) ? KL_LEFT : KL_UP);
+      if (valid) {
+        cur[c] = s;
+        arrowRow[c] = (uint8_t)arrow;
+      }
+      carry = min(carry, __builtin_amdgcn_readlane(x, 63)) + 64 * fnDel;
+      carryS = __builtin_amdgcn_readlane(s, 63);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      const int cT = k + tLen - q;  // the cell of t = tLen in this row, if inside the band
+      if (cT >= 0 && cT < nCols) scores[nCols + q] = cur[cT];
+      scores[nCols + qLen + 1 + q] = cur[cEnd];
+    }
+    int *tmp = prev;
+    prev = cur;
+    cur = tmp;
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int c = lane; c < nCols; c += 64) scores[c] = prev[c];  // the last row
+}
+
+__global__ __launch_bounds__(64) void kband_linear_traceback_kernel(KbandLinearArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  RefineResult res;
+  memset(&res, 0, sizeof(res));
+  if (g.status != 0) {
+    res.status = g.status;
+    a.results[task] = res;
+    a.opsStart[task] = 0;
+    return;
+  }
+  const uint8_t *arrows = a.arrows + a.arrowOff[task];
+  const int32_t *scores = a.scores + a.scoreOff[task];
+  uint32_t *arena = a.arena + a.arenaOff[task];
+  const int k = g.k, nCols = g.nCols, qLen = g.qLen, tLen = g.tLen, at = a.alignType;
+  // ---- end cell (:228-296)
+  int q = qLen, t = k - (qLen - tLen);
+  const int globalMin = scores[t];
+  int minLastCol = globalMin, minLastRow = globalMin, minLastColIdx = 0, minLastRowIdx = 0;
+  if (at == KT_QUERYFIT || at == KT_FIT) {
+    bool set = false;
+    for (int t2 = q - k; t2 < qLen + k + 1; t2++) {
+      if (t2 < 1 || t2 > tLen) continue;
+      const int v = scores[k + t2 - q];
+      if (!set || v < minLastRow) {
+        set = true;
+        minLastRow = v;
+        minLastRowIdx = t2;
+      }
+    }
+    if (set) t = k - (q - minLastRowIdx);
+  }
+  if (at == KT_TARGETFIT || at == KT_FIT) {
+    const int t2 = k - (qLen - tLen);
+    bool set = false;
+    for (int q2 = qLen; (uint32_t)q2 >= (uint32_t)tLen - (uint32_t)k && q2 > 0; q2--) {  // unsigned, as :279
+      const int v = scores[nCols + q2];
+      if (!set || v < minLastCol) {
+        minLastCol = v;
+        set = true;
+        minLastColIdx = q2;
+      }
+    }
+    if (at == KT_FIT) {
+      if (minLastCol < minLastRow) {
+        t = t2;
+        q = minLastColIdx;
+      }
+    } else {
+      t = t2;
+      q = minLastColIdx;
+    }
+  }
+  // optScore = scoreMat[q][t]: on the last row, or (TargetFit / Fit) in column k - (qLen - tLen) of row q
+  res.dp_score = q == qLen ? scores[t] : scores[nCols + qLen + 1 + q];
+  // ---- traceback (:317-381)
+  int pos = (int)g.arenaWords, curType = -1, curLen = 0;
+  auto emit = [&](int type) {
+    if (type == curType) curLen++;
+    else {
+      if (curLen) arena[--pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+      curType = type;
+      curLen = 1;
+    }
+  };
+  int guard = qLen + tLen + 2 * k + 8;
+  for (;;) {
+    bool go;
+    if (at == KT_GLOBAL || at == KT_QUERYFIT) go = q > 0 && (t < k ? (k - t != q) : true);
+    else if (at == KT_FIT) go = q > 0 && (t < k ? (k - t != q) : true) && (q <= k ? k - q != t : true);
+    else go = q > 0 && (q < k ? k - q != t : true);
+    if (!go || --guard < 0 || t < 0 || t >= nCols) break;
+    const int ar = arrows[(int64_t)q * nCols + t];
+    if (ar == KL_NONE) break;
+    if (ar == KL_DIAG) {
+      emit(BLASR_HIP_OP_M);
+      q--;
+    } else if (ar == KL_UP) {
+      emit(BLASR_HIP_OP_I);
+      q--;
+      t++;
+    } else {
+      emit(BLASR_HIP_OP_D);
+      t--;
+    }
+  }
+  if (curLen) arena[--pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+  res.q_pos = q;
+  res.t_pos = t < k ? (k - t) - q : (t - k) - q;
+  res.n_cells = (int32_t)g.cells;
+  res.n_ops = (int32_t)(g.arenaWords - pos);
+  a.results[task] = res;
+  a.opsStart[task] = pos;
+}
+
 }  // namespace blasr_hip
 
 using namespace blasr_hip;
 
 extern "C" {
 
-int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
-                           blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
-                           int64_t *ops_used) {
+}  // extern "C"
+
+namespace {
+// p: AffineKBandAlign parameters, or lp: KBandAlign parameters (exactly one is set)
+int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+              const blasr_hip_kband_linear_params *lp, blasr_hip_refine_result *results, uint32_t *ops,
+              int64_t ops_capacity, int64_t *ops_used) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
-  if (!b || !p || !ops_used || b->n < 0 ||
+  if (!b || (!p && !lp) || !ops_used || b->n < 0 ||
       (b->n > 0 && (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !b->k || !results || !ops)))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   *ops_used = 0;
   const int n = b->n;
   if (n == 0) return BLASR_HIP_OK;
+  const int32_t *hostMatrix = p ? p->matrix : lp->matrix;
   int64_t magnitude = 0;
-  for (int i = 0; i < 25; i++) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)p->matrix[i]));
-  for (int v : {p->hp_ins_open, p->hp_ins_extend, p->ins_open, p->ins_extend, p->del})
-    magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)v));
-  if (p->del < 0 || magnitude >= (1 << 10))
+  for (int i = 0; i < 25; i++) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)hostMatrix[i]));
+  if (p) {
+    for (int v : {p->hp_ins_open, p->hp_ins_extend, p->ins_open, p->ins_extend, p->del})
+      magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)v));
+  } else {
+    for (int v : {lp->ins, lp->del, lp->fn_ins, lp->fn_del}) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)v));
+    if (lp->align_type != 1 && lp->align_type != 2 && lp->align_type != 3 && lp->align_type != 7)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "kband: align_type must be Global, QueryFit, TargetFit or Fit");
+  }
+  if ((p ? p->del : lp->fn_del) < 0 || magnitude >= (1 << 10))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "kband: deletion penalty must be >= 0, |penalties| < 1024");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -273,14 +510,15 @@ int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, c
       if (p) (void)hipFree(p);
     }
   };
-  Dev dGeo, dMatrix, dArrowOff, dArenaOff, dOpsStart, dTotal;
+  Dev dGeo, dMatrix, dArrowOff, dArenaOff, dOpsStart, dTotal, dScoreOff;
   HIP_TRY(ctx, hipMalloc(&dGeo.p, sizeof(KbandGeo) * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&dMatrix.p, sizeof(int32_t) * 32));
   HIP_TRY(ctx, hipMalloc(&dArrowOff.p, sizeof(int64_t) * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&dArenaOff.p, sizeof(int64_t) * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&dOpsStart.p, sizeof(int32_t) * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&dTotal.p, sizeof(int64_t)));
-  HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, p->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMalloc(&dScoreOff.p, sizeof(int64_t) * (size_t)n));
+  HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, hostMatrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(dTotal.p, 0, sizeof(int64_t), st));
   hipLaunchKernelGGL(kband_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, b->q_len, b->t_len, b->k,
                      static_cast<KbandGeo *>(dGeo.p));
@@ -289,29 +527,33 @@ int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, c
   HIP_TRY(ctx, hipStreamSynchronize(st));
   // chunks of tasks whose arrow matrices + op arenas fit the workspace
   const int64_t limit = std::max<int64_t>(ctx->workspaceLimit, 1 << 20);
-  std::vector<int64_t> arrowOff((size_t)n), arenaOff((size_t)n);
+  std::vector<int64_t> arrowOff((size_t)n), arenaOff((size_t)n), scoreOff((size_t)n);
   struct Chunk {
     int first, count;
-    int64_t arrowBytes, arenaWords;
+    int64_t arrowBytes, arenaWords, scoreWords;
   };
   std::vector<Chunk> chunks;
   int64_t maxBytes = 0;
   for (int i = 0; i < n;) {
-    Chunk c{i, 0, 0, 0};
+    Chunk c{i, 0, 0, 0, 0};
     while (i < n) {
       const int64_t ab = (geo[i].cells + 255) & ~(int64_t)255, aw = (geo[i].arenaWords + 63) & ~(int64_t)63;
-      if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw) > limit) break;
-      if (ab + 4 * aw > limit)
+      // KBandAlign also keeps the last row and the column of t = tLen for the choice of the end cell
+      const int64_t sw = lp ? (((int64_t)geo[i].nCols + 2 * ((int64_t)geo[i].qLen + 1) + 63) & ~(int64_t)63) : 0;
+      if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw + c.scoreWords + sw) > limit) break;
+      if (ab + 4 * (aw + sw) > limit)
         return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "kband: task %d needs %lld bytes of workspace", i,
-                              (long long)(ab + 4 * aw));
+                              (long long)(ab + 4 * (aw + sw)));
       arrowOff[i] = c.arrowBytes;
       arenaOff[i] = c.arenaWords;
+      scoreOff[i] = c.scoreWords;
       c.arrowBytes += ab;
       c.arenaWords += aw;
+      c.scoreWords += sw;
       c.count++;
       i++;
     }
-    maxBytes = std::max(maxBytes, c.arrowBytes + 4 * c.arenaWords + 1024);
+    maxBytes = std::max(maxBytes, c.arrowBytes + 4 * (c.arenaWords + c.scoreWords) + 1024);
     chunks.push_back(c);
   }
   if (ctx->workspaceBytes < (size_t)maxBytes) {
@@ -323,8 +565,38 @@ int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, c
   }
   HIP_TRY(ctx, hipMemcpyAsync(dArrowOff.p, arrowOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dArenaOff.p, arenaOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dScoreOff.p, scoreOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
   RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
   for (const Chunk &c : chunks) {
+    if (lp) {
+      KbandLinearArgs a;
+      a.first = c.first;
+      a.count = c.count;
+      a.ins = lp->ins;
+      a.del = lp->del;
+      a.fnIns = lp->fn_ins;
+      a.fnDel = lp->fn_del;
+      a.alignType = lp->align_type;
+      a.matrix = static_cast<int32_t *>(dMatrix.p);
+      a.geo = static_cast<KbandGeo *>(dGeo.p);
+      a.seq = b->seq;
+      a.qOff = b->q_off;
+      a.tOff = b->t_off;
+      a.arrows = reinterpret_cast<uint8_t *>(ctx->workspace);
+      a.arrowOff = static_cast<int64_t *>(dArrowOff.p);
+      a.arena = reinterpret_cast<uint32_t *>(ctx->workspace + c.arrowBytes);
+      a.arenaOff = static_cast<int64_t *>(dArenaOff.p);
+      a.scores = reinterpret_cast<int32_t *>(ctx->workspace + c.arrowBytes + 4 * c.arenaWords);
+      a.scoreOff = static_cast<int64_t *>(dScoreOff.p);
+      a.opsStart = static_cast<int32_t *>(dOpsStart.p);
+      a.results = dResults;
+      hipLaunchKernelGGL(kband_linear_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(kband_linear_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
+      launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), st);
+      launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, st);
+      HIP_TRY(ctx, hipStreamSynchronize(st));  // the next chunk reuses the workspace
+      continue;
+    }
     KbandArgs a;
     a.first = c.first;
     a.count = c.count;
@@ -360,10 +632,11 @@ int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, c
   return BLASR_HIP_OK;
 }
 
-int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
-                         blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+int kband_run_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+                   const blasr_hip_kband_linear_params *lp, blasr_hip_refine_result *results, uint32_t *ops,
+                   int64_t ops_capacity, int64_t *ops_used) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
-  if (!b || !p || !ops_used || b->n < 0 || ops_capacity < 0)
+  if (!b || (!p && !lp) || !ops_used || b->n < 0 || ops_capacity < 0)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   *ops_used = 0;
   const int n = b->n;
@@ -404,14 +677,40 @@ int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, con
   db.t_off = static_cast<int64_t *>(dTOff.p);
   db.t_len = static_cast<int32_t *>(dTLen.p);
   db.k = static_cast<int32_t *>(dK.p);
-  const int rc = blasr_hip_kband_device(ctx, &db, p, static_cast<blasr_hip_refine_result *>(dRes.p),
-                                        static_cast<uint32_t *>(dOps.p), ops_capacity, ops_used);
+  const int rc = kband_run(ctx, &db, p, lp, static_cast<blasr_hip_refine_result *>(dRes.p),
+                           static_cast<uint32_t *>(dOps.p), ops_capacity, ops_used);
   if (rc != BLASR_HIP_OK && rc != BLASR_HIP_ERR_CAPACITY) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(results, dRes.p, sizeof(blasr_hip_refine_result) * (size_t)n, hipMemcpyDeviceToHost, st));
   const int64_t copyOps = std::min(*ops_used, ops_capacity);
   if (copyOps > 0) HIP_TRY(ctx, hipMemcpyAsync(ops, dOps.p, sizeof(uint32_t) * (size_t)copyOps, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+                           blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+  if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  return kband_run(ctx, b, p, nullptr, results, ops, ops_capacity, ops_used);
+}
+int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
+                         blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+  if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  return kband_run_host(ctx, b, p, nullptr, results, ops, ops_capacity, ops_used);
+}
+int blasr_hip_kband_linear_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b,
+                                  const blasr_hip_kband_linear_params *p, blasr_hip_refine_result *results,
+                                  uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+  if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  return kband_run(ctx, b, nullptr, p, results, ops, ops_capacity, ops_used);
+}
+int blasr_hip_kband_linear_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b,
+                                const blasr_hip_kband_linear_params *p, blasr_hip_refine_result *results, uint32_t *ops,
+                                int64_t ops_capacity, int64_t *ops_used) {
+  if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
+  return kband_run_host(ctx, b, nullptr, p, results, ops, ops_capacity, ops_used);
 }
 
 }  // extern "C"

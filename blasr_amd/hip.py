@@ -29,7 +29,7 @@ EXPORTS = [
     "blasr_hip_refine_last_timing", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
-    "blasr_hip_kband_device", "blasr_hip_kband_host",
+    "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -50,6 +50,11 @@ assert CANDIDATE_DTYPE.itemsize == 40
 class _KbandParams(C.Structure):
     _fields_ = [("matrix", C.c_int32 * 25), ("hp_ins_open", C.c_int32), ("hp_ins_extend", C.c_int32),
                 ("ins_open", C.c_int32), ("ins_extend", C.c_int32), ("del_", C.c_int32)]
+
+
+class _KbandLinearParams(C.Structure):
+    _fields_ = [("matrix", C.c_int32 * 25), ("ins", C.c_int32), ("del_", C.c_int32), ("fn_ins", C.c_int32),
+                ("fn_del", C.c_int32), ("align_type", C.c_int32)]
 
 
 class _KbandBatch(C.Structure):
@@ -214,6 +219,9 @@ def load_library():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         for name in ("blasr_hip_kband_device", "blasr_hip_kband_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_KbandBatch), C.POINTER(_KbandParams), C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        for name in ("blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_KbandBatch), C.POINTER(_KbandLinearParams), C.c_void_p,
                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         lib.blasr_hip_sort_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.blasr_hip_remove_low_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -510,13 +518,8 @@ class Context:
         return used.value
 
     # --- a-11: AffineKBandAlign (the -noUseGuidedAlign refiner, Blasr.cpp:675-746) ---
-    def kband(self, pairs, ks, matrix=None, indel=5, ops_capacity=None):
-        """pairs: list of (query, target) uint8 arrays, ks: band half-widths.  Penalties as PairwiseLocalAlign
-        derives them from params.indel (Blasr.cpp:695-699).  Returns a list of dicts: status, score, nCells, ops,
-        blocks, gapCounts, gapItems."""
+    def _kband_call(self, fn, pairs, ks, params, ops_capacity):
         n = len(pairs)
-        if n == 0:
-            return []
         seqs, q_off, q_len, t_off, t_len, at = [], [], [], [], [], 0
         for q, t in pairs:
             q = np.ascontiguousarray(q, dtype=np.uint8)
@@ -532,24 +535,44 @@ class Context:
         kb.n = n
         kb.seq, kb.q_off, kb.q_len = seq.ctypes.data, q_off.ctypes.data, q_len.ctypes.data
         kb.t_off, kb.t_len, kb.k = t_off.ctypes.data, t_len.ctypes.data, ks.ctypes.data
+        cap = int(q_len.sum() + t_len.sum() + 2 * ks.sum() + 8 * n) if ops_capacity is None else int(ops_capacity)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        ops = np.zeros(max(cap, 1), dtype=np.uint32)
+        used = C.c_int64(0)
+        self._check(fn(self.handle, C.byref(kb), C.byref(params), results.ctypes.data, ops.ctypes.data, cap,
+                       C.byref(used)))
+        out = []
+        for r in results:
+            o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
+            blocks, gc, gi = ops_to_alignment(o)
+            out.append(dict(status=int(r["status"]), score=int(r["dp_score"]), nCells=int(r["n_cells"]),
+                            qPos=int(r["q_pos"]), tPos=int(r["t_pos"]), ops=o, blocks=blocks, gapCounts=gc, gapItems=gi))
+        return out
+
+    def kband(self, pairs, ks, matrix=None, indel=5, ops_capacity=None):
+        """AffineKBandAlign, Global.  pairs: list of (query, target) uint8 arrays, ks: band half-widths.
+        Penalties as PairwiseLocalAlign derives them from params.indel (Blasr.cpp:695-699).  Returns a list of
+        dicts: status, score, nCells, ops, blocks, gapCounts, gapItems."""
+        if len(pairs) == 0:
+            return []
         kp = _KbandParams()
         m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
         for i, v in enumerate(m):
             kp.matrix[i] = int(v)
         kp.hp_ins_open, kp.hp_ins_extend, kp.ins_open, kp.ins_extend, kp.del_ = indel + 2, indel - 3, indel + 2, indel - 1, indel
-        cap = int(q_len.sum() + t_len.sum() + 2 * ks.sum() + 8 * n) if ops_capacity is None else int(ops_capacity)
-        results = np.zeros(n, dtype=RESULT_DTYPE)
-        ops = np.zeros(max(cap, 1), dtype=np.uint32)
-        used = C.c_int64(0)
-        self._check(self.lib.blasr_hip_kband_host(self.handle, C.byref(kb), C.byref(kp), results.ctypes.data,
-                                                  ops.ctypes.data, cap, C.byref(used)))
-        out = []
-        for r in results:
-            o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
-            blocks, gc, gi = ops_to_alignment(o)
-            out.append(dict(status=int(r["status"]), score=int(r["dp_score"]), nCells=int(r["n_cells"]), ops=o,
-                            blocks=blocks, gapCounts=gc, gapItems=gi))
-        return out
+        return self._kband_call(self.lib.blasr_hip_kband_host, pairs, ks, kp, ops_capacity)
+
+    def kband_linear(self, pairs, ks, align_type=1, matrix=None, ins=5, dele=5, fn_ins=5, fn_del=5, ops_capacity=None):
+        """KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403); align_type Global 1, QueryFit 2,
+        TargetFit 3, Fit 7.  Returns dicts with score, qPos, tPos, nCells, blocks, gap lists."""
+        if len(pairs) == 0:
+            return []
+        kp = _KbandLinearParams()
+        m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
+        for i, v in enumerate(m):
+            kp.matrix[i] = int(v)
+        kp.ins, kp.del_, kp.fn_ins, kp.fn_del, kp.align_type = ins, dele, fn_ins, fn_del, align_type
+        return self._kband_call(self.lib.blasr_hip_kband_linear_host, pairs, ks, kp, ops_capacity)
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()

@@ -344,6 +344,27 @@ int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
                          const blasr_hip_kband_params *params, blasr_hip_refine_result *results, uint32_t *ops,
                          int64_t ops_capacity, int64_t *ops_used);
 
+/* KBandAlign with a DistanceMatrixScoreFunction (algorithms/alignment/KBandAlign.h:74-403): the banded,
+ * linear-gap aligner behind -doGlobalAlignment (alignment/Blasr.cpp:819-823, Global) and behind
+ * PairwiseLocalAlign for reads with quality values (Blasr.cpp:714-730, Fit).  ins / del are the function's
+ * boundary penalties, fn_ins / fn_del what scoreFn.Insertion / Deletion return inside the recurrence;
+ * scoreFn.Match = matrix[ThreeBit[ref]][ThreeBit[query]] (DistanceMatrixScoreFunction.h:43-45). */
+typedef struct blasr_hip_kband_linear_params {
+  int32_t matrix[25];
+  int32_t ins, del;
+  int32_t fn_ins, fn_del;
+  int32_t align_type;  /* AlignmentType (AlignmentUtils.h:12-30): Global 1, QueryFit 2, TargetFit 3, Fit 7 */
+} blasr_hip_kband_linear_params;
+
+/* Results as for blasr_hip_kband_*: q_pos / t_pos = alignment.qPos / tPos (KBandAlign.h:388-398),
+ * n_cells = alignment.nCells, dp_score = the return value. */
+int blasr_hip_kband_linear_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
+                                  const blasr_hip_kband_linear_params *params, blasr_hip_refine_result *results,
+                                  uint32_t *ops, int64_t ops_capacity, int64_t *ops_used);
+int blasr_hip_kband_linear_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
+                                const blasr_hip_kband_linear_params *params, blasr_hip_refine_result *results,
+                                uint32_t *ops, int64_t ops_capacity, int64_t *ops_used);
+
 #ifdef __cplusplus
 }
 #endif

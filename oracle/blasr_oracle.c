@@ -1848,3 +1848,163 @@ int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char 
   aln_free(&a);
   return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* a-11: KBandAlign with a DistanceMatrixScoreFunction (algorithms/alignment/KBandAlign.h:74-403) */
+/* ------------------------------------------------------------------------- */
+/* AlignmentType (AlignmentUtils.h:14-58): Global 1, QueryFit 2, TargetFit 3, ..., Fit 7.
+ * ins/del: boundary penalties; fnIns/fnDel: scoreFn.Insertion / Deletion inside the recurrence;
+ * scoreFn.Match = matrix[ThreeBit[ref]][ThreeBit[query]] (DistanceMatrixScoreFunction.h:43-45).
+ * Cells the loops skip keep the 0 / NoArrow the matrices are filled with, exactly as in the reference. */
+enum { KT_GLOBAL = 1, KT_QUERYFIT = 2, KT_TARGETFIT = 3, KT_FIT = 7 };
+static int kband_align(const unsigned char *qs, uint32_t qLength, const unsigned char *ts, uint32_t tLength,
+                       const int m[5][5], int ins, int del, int fnIns, int fnDel, int k, int alignType, aln_t *out,
+                       int *nCellsOut) {
+  uint32_t tLen, qLen; /* SetKBoundedLengths, :36-56 */
+  if (tLength < qLength) {
+    tLen = tLength;
+    qLen = qLength < tLength + (uint32_t)k ? qLength : tLength + (uint32_t)k;
+  } else if (qLength < tLength) {
+    qLen = qLength;
+    tLen = tLength < qLength + (uint32_t)k ? tLength : qLength + (uint32_t)k;
+  } else {
+    qLen = qLength;
+    tLen = tLength;
+  }
+  const size_t nCols = 2 * (size_t)k + 1, total = ((size_t)qLen + 1) * nCols;
+  *nCellsOut = (int)total;
+  int *S = (int *)calloc(total, sizeof(int));
+  unsigned char *P = (unsigned char *)malloc(total);
+  memset(P, A_NONE, total);
+#define IX(r, c) ((size_t)(r) * nCols + (size_t)(c))
+  int q, t;
+  for (q = 1; q <= k && (uint32_t)q < qLen + 1; q++) { /* :113-116 */
+    S[IX(q, k - q)] = q * ins;
+    P[IX(q, k - q)] = A_UP;
+  }
+  if (alignType == KT_GLOBAL)
+    for (t = 1; t <= k && (uint32_t)t < tLen; t++) { /* :117-122, note t < tLen */
+      S[IX(0, t + k)] = t * del;
+      P[IX(0, t + k)] = A_LEFT;
+    }
+  if (alignType == KT_QUERYFIT || alignType == KT_FIT)
+    for (t = 1; (t <= k) & ((uint32_t)t < tLen); t++) {
+      S[IX(0, t + k)] = 0;
+      P[IX(0, t + k)] = A_LEFT;
+    }
+  if (alignType == KT_TARGETFIT || alignType == KT_FIT)
+    for (q = 1; (q <= k) & ((uint32_t)q < qLen); q++) { /* :129-134: column 0, as written there */
+      S[IX(q, 0)] = 0;
+      P[IX(q, 0)] = A_UP;
+    }
+  S[IX(0, k)] = 0;
+  P[IX(0, k)] = A_DIAG;
+  for (q = 1; (uint32_t)q <= qLen; q++) { /* :144-222, samplePaths = false */
+    for (t = q - k; t < q + k + 1; t++) {
+      if (t < 1) continue;
+      if ((uint32_t)t > tLen) continue;
+      const int delScore = t == q - k ? 2147483647 : S[IX(q, k + t - q - 1)] + fnDel;
+      const int matchScore = S[IX(q - 1, k + t - q)] + m[three_bit(ts[t - 1])][three_bit(qs[q - 1])];
+      const int insScore = t == q + k ? 2147483647 : S[IX(q - 1, k + t - q + 1)] + fnIns;
+      int minScore = insScore < delScore ? insScore : delScore;
+      if (matchScore < minScore) minScore = matchScore;
+      const size_t cur = IX(q, k + t - q);
+      S[cur] = minScore;
+      P[cur] = minScore == matchScore ? A_DIAG : (minScore == delScore ? A_LEFT : A_UP);
+    }
+  }
+  /* end cell :228-296 */
+  q = (int)qLen;
+  t = k - (int)(qLen - tLen);
+  const int globalMinScore = S[IX(q, t)];
+  int minLastColScore = globalMinScore, minLastRowScore = globalMinScore;
+  int minLastColScoreIndex = 0, minLastRowScoreIndex = 0;
+  if (alignType == KT_QUERYFIT || alignType == KT_FIT) {
+    int q2 = (int)qLen, t2, minScoreSet = 0;
+    for (t2 = q - k; t2 < q2 + k + 1; t2++) {
+      if (t2 < 1) continue;
+      if ((uint32_t)t2 > tLen) continue;
+      if (!minScoreSet || S[IX(q2, k + t2 - q)] < minLastRowScore) {
+        minScoreSet = 1;
+        minLastRowScore = S[IX(q2, k + t2 - q)];
+        minLastRowScoreIndex = t2;
+      }
+    }
+    if (minScoreSet) {
+      t2 = k - (q - minLastRowScoreIndex);
+      t = t2;
+      q = q2;
+    }
+  }
+  if (alignType == KT_TARGETFIT || alignType == KT_FIT) {
+    int q2, t2 = k - (int)(qLen - tLen), minScoreSet = 0;
+    for (q2 = (int)qLen; (uint32_t)q2 >= tLen - (uint32_t)k && q2 > 0; q2--) { /* unsigned compare, :279 */
+      const size_t index = IX(q2, k + (int)tLen - q2);
+      if (!minScoreSet || S[index] < minLastColScore) {
+        minLastColScore = S[index];
+        minScoreSet = 1;
+        minLastColScoreIndex = q2;
+      }
+    }
+    if (alignType == KT_FIT) {
+      if (minLastColScore < minLastRowScore) {
+        t = t2;
+        q = minLastColScoreIndex;
+      }
+    } else {
+      t = t2;
+      q = minLastColScoreIndex;
+    }
+  }
+  const int optScore = S[IX(q, t)];
+  /* traceback :317-381 */
+  unsigned char *path = (unsigned char *)malloc((size_t)qLen + tLen + 2 * (size_t)k + 16);
+  int n = 0;
+  for (;;) {
+    int go;
+    if (alignType == KT_GLOBAL || alignType == KT_QUERYFIT) go = q > 0 && (t < k ? (k - t != q) : 1);
+    else if (alignType == KT_FIT) go = q > 0 && (t < k ? (k - t != q) : 1) && (q <= k ? k - q != t : 1);
+    else go = q > 0 && (q < k ? k - q != t : 1);
+    if (!go) break;
+    const int a = P[IX(q, t)];
+    if (a == A_NONE) break;
+    path[n++] = (unsigned char)a;
+    if (a == A_DIAG) q--;
+    else if (a == A_UP) {
+      q--;
+      t++;
+    } else
+      t--;
+  }
+  out->qPos = (uint32_t)q;
+  out->tPos = t < k ? (uint32_t)((k - t) - q) : (uint32_t)((t - k) - q);
+  for (int i = 0; i < n / 2; i++) {
+    unsigned char tmp = path[i];
+    path[i] = path[n - 1 - i];
+    path[n - 1 - i] = tmp;
+  }
+  arrow_path_to_alignment(out, path, n);
+#undef IX
+  free(path);
+  free(S);
+  free(P);
+  return optScore;
+}
+
+int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25, int ins,
+                   int del, int fnIns, int fnDel, int k, int alignType, int *out, int *blocks, int blockCap,
+                   int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                   int *nGapItems) {
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  aln_t a;
+  aln_init(&a);
+  int nCells = 0;
+  out[0] = kband_align(q, (uint32_t)qlen, t, (uint32_t)tlen, m, ins, del, fnIns, fnDel, k, alignType, &a, &nCells);
+  out[1] = (int)a.qPos;
+  out[2] = (int)a.tPos;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+  aln_free(&a);
+  return rc;
+}

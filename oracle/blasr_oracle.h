@@ -106,6 +106,13 @@ int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char 
                           int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
                           int *gapItems, int gapItemCap, int *nGapItems);
 
+/* a-11: KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403); alignType Global 1, QueryFit 2,
+ * TargetFit 3, Fit 7; out[3] = score, qPos, tPos. */
+int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25, int ins,
+                   int del, int fnIns, int fnDel, int k, int alignType, int *out, int *blocks, int blockCap,
+                   int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                   int *nGapItems);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,4 +277,30 @@ int ref_affine_kband_align(const unsigned char *q, int qlen, const unsigned char
   return flatten(a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
 }
 
+// KBandAlign (KBandAlign.h:74-403) with a DistanceMatrixScoreFunction, as RefineAlignment calls it for
+// -doGlobalAlignment (Blasr.cpp:819-823, Global) and PairwiseLocalAlign for reads with quality values
+// (Blasr.cpp:714-730, Fit).  ins/del: the boundary penalties (function arguments); fnIns/fnDel: the penalties
+// of the score function used inside the recurrence.  out[3] = score, qPos, tPos.
+int ref_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25, int ins,
+                    int del, int fnIns, int fnDel, int k, int alignType, int *out, int *blocks, int blockCap,
+                    int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                    int *nGapItems) {
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  ScoreFn fn;
+  make_score_fn(fn, matrix25, fnIns, fnDel, 0, 0);
+  FASTQSequence qs;
+  DNASequence ts;
+  set_seq(qs, q, qlen);
+  set_seq(ts, t, tlen);
+  std::vector<int> scoreMat;
+  std::vector<Arrow> pathMat;
+  Alignment a;
+  out[0] = KBandAlign(qs, ts, m, ins, del, k, scoreMat, pathMat, a, (AlignmentType)alignType, fn, false);
+  out[1] = (int)a.qPos;
+  out[2] = (int)a.tPos;
+  return flatten(a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+}
+
 }  // extern "C"

@@ -397,3 +397,26 @@ def affine_kband_align(checker, q, t, k, matrix=None, indel=5):
     assert rc == 0
     return dict(score=score.value, blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
                 gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
+
+
+KBAND_GLOBAL, KBAND_QUERYFIT, KBAND_TARGETFIT, KBAND_FIT = 1, 2, 3, 7  # AlignmentType, AlignmentUtils.h:12-30
+
+
+def kband_align(checker, q, t, k, align_type=KBAND_GLOBAL, matrix=None, ins=5, dele=5, fn_ins=5, fn_del=5):
+    """KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403).  ins/dele: boundary penalties,
+    fn_ins/fn_del: the score function's.  Returns score, qPos, tPos, blocks, gap lists."""
+    q, t = _u8(q), _u8(t)
+    m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
+    cap = len(q) + len(t) + 2 * k + 16
+    blocks = np.zeros(3 * cap, dtype=np.int32)
+    gap_counts, gap_items = np.zeros(cap, dtype=np.int32), np.zeros(2 * cap, dtype=np.int32)
+    out = np.zeros(3, dtype=np.int32)
+    nb, ngl, ngi = C.c_int(0), C.c_int(0), C.c_int(0)
+    f = checker.fn("kband_align")
+    f.restype = C.c_int
+    rc = f(_p(q, C.c_ubyte), len(q), _p(t, C.c_ubyte), len(t), _p(m), int(ins), int(dele), int(fn_ins), int(fn_del),
+           int(k), int(align_type), _p(out), _p(blocks), cap, C.byref(nb), _p(gap_counts), cap, C.byref(ngl),
+           _p(gap_items), cap, C.byref(ngi))
+    assert rc == 0
+    return dict(score=int(out[0]), qPos=int(out[1]), tPos=int(out[2]), blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
+                gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())

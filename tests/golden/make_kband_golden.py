@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from blasr_testlib import affine_kband_align, load_ref  # noqa: E402
+from blasr_testlib import affine_kband_align, kband_align, load_ref  # noqa: E402
 from blasr_amd import synth  # noqa: E402
 
 
@@ -47,6 +47,23 @@ def main():
         out["c%d_q" % i], out["c%d_t" % i], out["c%d_k" % i] = np.ascontiguousarray(q), np.ascontiguousarray(t), np.int64(k)
         out["c%d_score" % i] = np.int64(r["score"])
         out["c%d_blocks" % i], out["c%d_gapCounts" % i], out["c%d_gapItems" % i] = r["blocks"], r["gapCounts"], r["gapItems"]
+    # KBandAlign (one matrix, linear gaps) in its four alignment types
+    lin = []
+    for i, (ql, k) in enumerate([(15, 10), (80, 12), (300, 12), (1200, 20), (1200, 60), (2500, 30)]):
+        for at in (1, 2, 3, 7):
+            q, t = synth.make_pair(rng, ql, flank=(0, int(rng.choice([0, 12]))))
+            if (i + at) % 3 == 0:
+                t = t[: max(12, len(t) - 9)]
+            if (i + at) % 4 == 0:
+                q = q[: max(12, len(q) - 11)]
+            lin.append((q, t, k, at, int(rng.choice([5, 7])), int(rng.choice([5, 7])), 5, int(rng.choice([4, 5, 6]))))
+    out["n_linear"] = np.int64(len(lin))
+    for i, (q, t, k, at, ins, dele, fi, fd) in enumerate(lin):
+        r = kband_align(ref, q, t, k, at, ins=ins, dele=dele, fn_ins=fi, fn_del=fd)
+        out["l%d_q" % i], out["l%d_t" % i] = np.ascontiguousarray(q), np.ascontiguousarray(t)
+        out["l%d_par" % i] = np.array([k, at, ins, dele, fi, fd], dtype=np.int64)
+        out["l%d_res" % i] = np.array([r["score"], r["qPos"], r["tPos"]], dtype=np.int64)
+        out["l%d_blocks" % i], out["l%d_gapCounts" % i], out["l%d_gapItems" % i] = r["blocks"], r["gapCounts"], r["gapItems"]
     path = os.path.join(HERE, "kband_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

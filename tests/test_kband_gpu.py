@@ -74,3 +74,40 @@ def test_kband_chunked_workspace_and_errors(ctx, oracle):
         small.kband(pairs[:1], [40], ops_capacity=1)
     assert e.value.code == blasr_amd.hip.ERR_CAPACITY
     small.close()
+
+
+def same_linear(r, want):
+    return (r["status"] == 0 and (r["score"], r["qPos"], r["tPos"]) == (want["score"], want["qPos"], want["tPos"])
+            and np.array_equal(r["blocks"], want["blocks"]) and np.array_equal(r["gapCounts"], want["gapCounts"])
+            and np.array_equal(r["gapItems"], want["gapItems"]))
+
+
+def test_kband_linear_matches_golden(ctx):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kband_golden.npz"))
+    for i in range(int(g["n_linear"])):
+        k, at, ins, dele, fi, fd = (int(v) for v in g["l%d_par" % i])
+        r = ctx.kband_linear([(g["l%d_q" % i], g["l%d_t" % i])], [k], at, ins=ins, dele=dele, fn_ins=fi, fn_del=fd)[0]
+        res = g["l%d_res" % i]
+        want = dict(score=int(res[0]), qPos=int(res[1]), tPos=int(res[2]), blocks=g["l%d_blocks" % i],
+                    gapCounts=g["l%d_gapCounts" % i], gapItems=g["l%d_gapItems" % i])
+        assert same_linear(r, want), (i, k, at, r["score"], want["score"], r["qPos"], want["qPos"], r["tPos"], want["tPos"])
+
+
+def test_kband_linear_matches_oracle_random(ctx, oracle):
+    from blasr_amd import synth
+    from blasr_testlib import kband_align
+    rng = np.random.default_rng(13)
+    for at in (1, 2, 3, 7):
+        pairs, ks = [], []
+        for it in range(40):
+            ql = int(rng.choice([12, 40, 65, 200, 900, 2500]))
+            q, t = synth.make_pair(rng, ql, flank=(0, int(rng.choice([0, 0, 20]))))
+            if it % 5 == 0:
+                t = t[: max(12, len(t) - int(rng.integers(0, 30)))]
+            if it % 7 == 0:
+                q = q[: max(12, len(q) - int(rng.integers(0, 30)))]
+            pairs.append((q, t))
+            ks.append(int(rng.choice([10, 12, 31, 32, 33, 64, 150, 400])))
+        res = ctx.kband_linear(pairs, ks, at, ins=7, dele=6, fn_ins=5, fn_del=4)
+        for (q, t), k, r in zip(pairs, ks, res):
+            assert same_linear(r, kband_align(oracle, q, t, k, at, ins=7, dele=6, fn_ins=5, fn_del=4)), (at, len(q), len(t), k)

@@ -66,3 +66,21 @@ def test_oracle_affine_kband_matches_golden(oracle):
         assert np.array_equal(r["blocks"], g["c%d_blocks" % i]), i
         assert np.array_equal(r["gapCounts"], g["c%d_gapCounts" % i]), i
         assert np.array_equal(r["gapItems"], g["c%d_gapItems" % i]), i
+
+
+def test_oracle_kband_linear_matches_golden(oracle):
+    """a-11: the oracle's KBandAlign restatement (Global / QueryFit / TargetFit / Fit) against the vectors of the
+    reference's template."""
+    import os
+    from blasr_testlib import kband_align
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kband_golden.npz"))
+    types = set()
+    for i in range(int(g["n_linear"])):
+        k, at, ins, dele, fi, fd = (int(v) for v in g["l%d_par" % i])
+        r = kband_align(oracle, g["l%d_q" % i], g["l%d_t" % i], k, at, ins=ins, dele=dele, fn_ins=fi, fn_del=fd)
+        assert [r["score"], r["qPos"], r["tPos"]] == [int(v) for v in g["l%d_res" % i]], i
+        assert np.array_equal(r["blocks"], g["l%d_blocks" % i]), i
+        assert np.array_equal(r["gapCounts"], g["l%d_gapCounts" % i]), i
+        assert np.array_equal(r["gapItems"], g["l%d_gapItems" % i]), i
+        types.add(at)
+    assert types == {1, 2, 3, 7}
