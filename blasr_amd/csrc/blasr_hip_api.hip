@@ -108,7 +108,8 @@ int blasr_hip_create(int device, blasr_hip_ctx **out) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BLASR_HIP_ERR_NO_DEVICE;  // kernels are gfx950-only
   blasr_hip_ctx *ctx = new blasr_hip_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return BLASR_HIP_ERR_HIP;
   }
@@ -122,6 +123,10 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
+  }
+  if (ctx->sideStream) {
+    (void)hipStreamSynchronize(ctx->sideStream);
+    (void)hipStreamDestroy(ctx->sideStream);
   }
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   for (auto &sl : ctx->slabs) (void)hipFree(sl.first);
@@ -368,6 +373,22 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     fa.taskList = nullptr;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes first and on
+    // the side stream, underneath the main fill launches.
+    bool wideLaunched = false;
+    if (!c.wideTasks.empty()) {
+      const int nw = (int)c.wideTasks.size();
+      HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipEventRecord(ev[7], st));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));  // the uploads and everything before them
+      FillArgs fw = fa;
+      fw.count = nw;
+      launch_fill(view, fw, true, fast, ctx->sideStream);
+      HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
+      wideLaunched = true;
+    }
     if (fast && !getenv("BLASR_HIP_NO_FILL4")) {
       // candidates whose rows all fit fill4_kernel's two passes run four to a wavefront, longest first so the
       // four of a wavefront finish together; the others keep one wavefront each
@@ -396,15 +417,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     } else {
       launch_fill(view, fa, false, fast, st);
     }
-    if (!c.wideTasks.empty()) {
-      const int nw = (int)c.wideTasks.size();
-      HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
-      FillArgs fw = fa;
-      fw.count = nw;
-      launch_fill(view, fw, true, fast, st);
-    }
+    if (wideLaunched) HIP_TRY(ctx, hipStreamWaitEvent(st, ev[6], 0));  // join the side stream
     HIP_TRY(ctx, hipEventRecord(ev[3], st));
 
     TraceArgs ta;

@@ -11,6 +11,7 @@
 struct blasr_hip_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t sideStream = nullptr;  // long thin kernels that can run underneath the main ones
   char *workspace = nullptr;
   size_t workspaceBytes = 0;
   int64_t workspaceLimit = 48ll << 30;
