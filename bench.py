@@ -31,10 +31,11 @@ sys.path.insert(0, ROOT)
 PMC_FILL_TRAFFIC = {(100000, 10000, 16): 62832779552.0}
 
 
-def cpu_baseline(w, n_sample, band):
+def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
     """The CPU oracle (bit-exact port of SDPAlign + AffineGuidedAlign + ComputeAlignmentStats) timed on
     one host core over the first `n_sample` candidates of the same workload.  Checker code: never on the
-    product path."""
+    product path.  Since the oracle's answers are at hand, the device's result records of the same candidates
+    (from the last timed step) are compared with them field by field."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from blasr_testlib import load_oracle
 
@@ -43,15 +44,25 @@ def cpu_baseline(w, n_sample, band):
     q_off, q_len = w["q_off"][:n_sample].cpu().numpy(), w["q_len"][:n_sample].cpu().numpy()
     t_off, t_len = w["t_off"][:n_sample].cpu().numpy(), w["t_len"][:n_sample].cpu().numpy()
     tasks = [(seq[q_off[i]: q_off[i] + q_len[i]], seq[t_off[i]: t_off[i] + t_len[i]]) for i in range(n_sample)]
-    cells = 0
+    res = []
     t0 = time.perf_counter()
     for q, t in tasks:
-        cells += oracle.refine_candidate(q, t, band=band)["nCells"]
+        res.append(oracle.refine_candidate(q, t, band=band))
     dt = time.perf_counter() - t0
     bases = int(q_len.sum())
+    mismatches = 0
+    for i, o in enumerate(res):
+        s, r = sdp_rec[i], ref_rec[i]
+        dev = (int(s[1]), int(s[5]), int(s[2]), int(s[3]), int(s[4]),           # SDP: score, stats score, qPos, tPos, blocks
+               int(r[3]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[9]),  # refine: DP score .. nDel
+               int(s[2]) + int(r[1]), int(s[3]) + int(r[2]))                   # window-relative qPos, tPos
+        cpu = (o["sdpScore"], o["sdpStatsScore"], o["sdpQPos"], o["sdpTPos"], o["nSdpBlocks"], o["dpScore"],
+               o["nCells"], o["score"], o["nMatch"], o["nMismatch"], o["nIns"], o["nDel"], o["qPos"], o["tPos"])
+        mismatches += dev != cpu or int(s[0]) != 0 or int(r[0]) != 0
     return dict(value=bases / dt, unit="bases/s", cores=1, kind="port",
                 sample="first %d candidates of the same workload, SDP + refine (%.1f s, %.1f ms/read on one core)"
-                       % (n_sample, dt, dt / n_sample * 1e3))
+                       % (n_sample, dt, dt / n_sample * 1e3),
+                parity_checked=len(res), parity_mismatches=mismatches)
 
 
 def main():
@@ -192,7 +203,10 @@ def main():
                          "fill_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_sample, n), args.band)
+            ns = min(args.cpu_sample, n)
+            out["cpu_baseline"] = cpu_baseline(w, ns, args.band,
+                                               sdp_res.view(torch.int32).view(n, 12)[:ns].cpu().numpy(),
+                                               rec[:ns].cpu().numpy())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
