@@ -690,14 +690,17 @@ __global__ __launch_bounds__(256) void sdp_match_index_copy_kernel(SdpLevelArray
 
 constexpr int kBucketBits = 11;  // LDS bucket index over the leading bits of the k-mer (per wavefront: 8 KB)
 
-template <bool kWrite>
+// kBuckets: the count pass of targets >= 256 bases narrows its binary searches with a bucket index in LDS (32 KB
+// per workgroup); everything else runs in the instantiation without it, at full occupancy.
+template <bool kWrite, bool kBuckets>
 __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const uint8_t *seq) {
-  __shared__ uint32_t bucketStart[4][(1 << kBucketBits) + 1];
+  __shared__ uint32_t bucketStart[kBuckets ? 4 : 1][kBuckets ? (1 << kBucketBits) + 1 : 1];
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
   if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // sdp_match_index_kernel's
+  if ((!kWrite && t.tLen >= 256) != kBuckets) return;    // the other instantiation's
   const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
   const uint64_t *keys = lv.keys + lv.keyOff[idx];
   const int k = t.k, ks = k < 5 ? k : 5;
@@ -719,8 +722,8 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   // wavefront builds in LDS from the sorted keys (one pass), instead of ~2 x log2(tLen) dependent HBM reads.
   const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
   const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
-  const bool useBuckets = !kWrite && t.tLen >= 256;  // (t.tLen <= kTinyT takes the register path below)
-  uint32_t *bucket = bucketStart[threadIdx.x >> 6];
+  const bool useBuckets = kBuckets;  // (t.tLen <= kTinyT takes the register path below)
+  uint32_t *bucket = bucketStart[kBuckets ? threadIdx.x >> 6 : 0];
   if (useBuckets) {
     const int nB = 1 << bBits;
     for (int b = lane; b <= nB; b += 64) bucket[b] = (uint32_t)t.tLen;
@@ -2441,8 +2444,11 @@ void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *t
 }
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
   if (lv.n <= 0) return;
-  if (write) hipLaunchKernelGGL(sdp_match_kernel<true>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
-  else hipLaunchKernelGGL(sdp_match_kernel<false>, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  if (write) hipLaunchKernelGGL((sdp_match_kernel<true, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  else {
+    hipLaunchKernelGGL((sdp_match_kernel<false, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+    hipLaunchKernelGGL((sdp_match_kernel<false, true>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  }
 }
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
