@@ -399,21 +399,29 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         else list1.push_back(i);
       }
       std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
-      if (!list4.empty()) {
+      // both lists are uploaded first; the one-candidate-per-wavefront kernel then runs on the side stream, so
+      // that each kernel's last, partly filled round of wavefronts is covered by the other
+      if (!list4.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
+      if (!list1.empty()) {
+        HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipEventRecord(ev[7], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));
+        FillArgs f1 = fa;
+        f1.taskList = dList1;
+        f1.count = (int)list1.size();
+        launch_fill(view, f1, false, fast, ctx->sideStream);
+        HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
+        wideLaunched = true;
+      }
+      if (!list4.empty()) {
         FillArgs f4 = fa;
         f4.taskList = dList4;
         f4.count = (int)list4.size();
         launch_fill4(view, f4, st);
       }
-      if (!list1.empty()) {
-        HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
-        FillArgs f1 = fa;
-        f1.taskList = dList1;
-        f1.count = (int)list1.size();
-        launch_fill(view, f1, false, fast, st);
-      }
       HIP_TRY(ctx, hipStreamSynchronize(st));  // the host lists go out of scope
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->sideStream));
     } else {
       launch_fill(view, fa, false, fast, st);
     }
