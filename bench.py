@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL_TRAFFIC = {(100000, 10000, 16): 62832779552.0}
+PMC_FILL4_TRAFFIC = {(100000, 10000, 16): 50102588352.0}
 
 
 def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
@@ -129,7 +129,10 @@ def main():
         torch.cuda.synchronize()  # the glue ran on torch's stream, the library uses its own
         # a-6..a-9: guided banded affine DP, traceback, statistics
         ctx.refine_device(ptrs, n, args.band, score, ref_res.data_ptr(), ops.data_ptr(), ops_cap)
-        return t_sdp, ctx.last_timing()
+        t_ref = ctx.last_timing()
+        f4 = ctx.last_fill4()
+        t_ref.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"], fill4_cells=f4["cells"])
+        return t_sdp, t_ref
 
     def barrier():
         torch.cuda.synchronize()
@@ -158,8 +161,12 @@ def main():
     if rank == 0:
         K = args.steps
         value = totals["aligned_bases"] * K / elapsed
-        fill_ms, launches = acc["fill_ms"], max(acc["fill_launches"], 1)
-        achieved = acc["fill_bytes"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
+        fill_ms = acc["fill_ms"]
+        # the dominant kernel: fill4_kernel (four candidates per wavefront), timed on its own with HIP events on
+        # the library's stream; its algorithmic bytes = 1 B per band cell + the bases + 8 B per row record of
+        # the candidates it processed
+        f4_ms, f4_launches = acc["fill4_ms"], max(acc["fill4_launches"], 1)
+        achieved = acc["fill4_bytes"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0
         out = {
             "metric": "aligned bases/sec (refine path: SDP chaining + guided banded affine DP), GCUPS per GPU",
             "value": value,
@@ -187,20 +194,20 @@ def main():
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
-            # the DP fill = fill4_kernel (four candidates per wavefront) + fill_kernel for the candidates with a
-            # row wider than 96 cells; bytes and time are those of the whole fill launch group
-            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill4_kernel (+ fill_kernel for wide rows)",
-                         "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fill4_kernel", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
-                         "traffic": PMC_FILL_TRAFFIC.get((args.reads, args.read_len, args.band)),
+                         "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v10_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
-                                         "summed over the three fill kernels = 62.8 GB = 1.31 x the algorithmic bytes",
-                         "algorithmic_bytes_per_launch": acc["fill_bytes"] / launches,
-                         "launches": launches, "avg_launch_ms": fill_ms / launches,
-                         "fill_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
+                                         "profiles/r01_v11_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "of the fill4_kernel launch",
+                         "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
+                         "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
+                         "kernel_gcups": acc["fill4_cells"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0,
+                         "candidates_note": "candidates whose rows all fit 96 cells (76 % here); the others take "
+                                            "fill_kernel, one per wavefront",
+                         "fill_stage_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }
         if world == 1 and args.cpu_sample > 0:
             ns = min(args.cpu_sample, n)

@@ -146,6 +146,16 @@ int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes) {
 
 void *blasr_hip_stream(blasr_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *launches, int64_t *algorithmic_bytes,
+                                int64_t *cells) {
+  if (!ctx || !ms || !launches || !algorithmic_bytes || !cells) return BLASR_HIP_ERR_INVALID;
+  *ms = ctx->fill4Ms;
+  *launches = ctx->fill4Launches;
+  *algorithmic_bytes = ctx->fill4Bytes;
+  *cells = ctx->fill4Cells;
+  return BLASR_HIP_OK;
+}
+
 int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) ms[i] = ctx->ms[i];
@@ -200,11 +210,17 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   int rc = ensure_workspace(ctx, fixedBytes);
   if (rc) return rc;
 
-  hipEvent_t ev[8];
+  hipEvent_t ev[8], evF4[2];
   for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+  for (auto &e : evF4) HIP_TRY(ctx, hipEventCreate(&e));
   auto destroyEvents = [&]() {
     for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : evF4) (void)hipEventDestroy(e);
   };
+  int64_t fill4Bytes = 0, fill4Cells = 0;
+  ctx->fill4Ms = 0;
+  ctx->fill4Launches = 0;
+  ctx->fill4Bytes = ctx->fill4Cells = 0;
 
   // ---- geometry -------------------------------------------------------------
   TaskGeometry *dGeo = reinterpret_cast<TaskGeometry *>(ctx->workspace + oGeo);
@@ -375,7 +391,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
     // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes first and on
     // the side stream, underneath the main fill launches.
-    bool wideLaunched = false;
+    bool wideLaunched = false, timedFill4 = false;
     if (!c.wideTasks.empty()) {
       const int nw = (int)c.wideTasks.size();
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
@@ -399,29 +415,36 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         else list1.push_back(i);
       }
       std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
-      // both lists are uploaded first; the one-candidate-per-wavefront kernel then runs on the side stream, so
-      // that each kernel's last, partly filled round of wavefronts is covered by the other
       if (!list4.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
-      if (!list1.empty()) {
+      if (!list1.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipEventRecord(ev[7], st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));
-        FillArgs f1 = fa;
-        f1.taskList = dList1;
-        f1.count = (int)list1.size();
-        launch_fill(view, f1, false, fast, ctx->sideStream);
-        HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
-        wideLaunched = true;
-      }
       if (!list4.empty()) {
         FillArgs f4 = fa;
         f4.taskList = dList4;
         f4.count = (int)list4.size();
+        HIP_TRY(ctx, hipEventRecord(evF4[0], st));
         launch_fill4(view, f4, st);
+        HIP_TRY(ctx, hipEventRecord(evF4[1], st));
+        timedFill4 = true;
+        for (int32_t i : list4) {
+          fill4Bytes += geo[i].cells + (int64_t)geo[i].rows + geo[i].tSpan + 8 * (int64_t)geo[i].rows;
+          fill4Cells += geo[i].cells;
+        }
+        ctx->fill4Launches += 1;
+      }
+      if (!list1.empty()) {
+        FillArgs f1 = fa;
+        f1.taskList = dList1;
+        f1.count = (int)list1.size();
+        launch_fill(view, f1, false, fast, st);
       }
       HIP_TRY(ctx, hipStreamSynchronize(st));  // the host lists go out of scope
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->sideStream));
+      if (timedFill4) {
+        float t4 = 0;
+        (void)hipEventElapsedTime(&t4, evF4[0], evF4[1]);
+        ctx->fill4Ms += t4;
+      }
     } else {
       launch_fill(view, fa, false, fast, st);
     }
@@ -474,6 +497,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   // algorithmic bytes of the fill: 1 B/cell arrows out, bases in, 8 B/row record out
   int64_t seqBytes = totalRows + totalSpan;
   ctx->counters[1] = totalCells + seqBytes + 8 * totalRows;
+  ctx->fill4Bytes = fill4Bytes;
+  ctx->fill4Cells = fill4Cells;
   if (opsUsed) *opsUsed = total;
   if (total > opsCapacity)
     return fail(ctx, BLASR_HIP_ERR_CAPACITY, "ops arena too small: need %lld, have %lld", (long long)total,

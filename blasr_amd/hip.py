@@ -26,7 +26,7 @@ GAP_QUERY, GAP_TARGET = 0, 1  # Gap::GapSeq, AlignmentGapList.h:11
 EXPORTS = [
     "blasr_hip_abi_version", "blasr_hip_create", "blasr_hip_destroy", "blasr_hip_last_error",
     "blasr_hip_set_workspace_limit", "blasr_hip_stream", "blasr_hip_refine_device", "blasr_hip_refine_host",
-    "blasr_hip_refine_last_timing", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
+    "blasr_hip_refine_last_timing", "blasr_hip_refine_last_fill4", "blasr_hip_sdp_device", "blasr_hip_sdp_host", "blasr_hip_sdp_last_timing",
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
@@ -206,6 +206,8 @@ def load_library():
         lib.blasr_hip_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
         lib.blasr_hip_refine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         lib.blasr_hip_sdp_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_refine_last_fill4.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64),
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         for name in ("blasr_hip_sdp_device", "blasr_hip_sdp_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_SdpBatch), C.POINTER(_SdpParams),
                                            C.POINTER(_ScoreParams), C.c_void_p, C.c_void_p, C.c_int64,
@@ -573,6 +575,12 @@ class Context:
             kp.matrix[i] = int(v)
         kp.ins, kp.del_, kp.fn_ins, kp.fn_del, kp.align_type = ins, dele, fn_ins, fn_del, align_type
         return self._kband_call(self.lib.blasr_hip_kband_linear_host, pairs, ks, kp, ops_capacity)
+
+    def last_fill4(self):
+        """fill4_kernel launches of the last refine call: ms (HIP events), launches, algorithmic bytes, cells."""
+        ms, n, b, c = C.c_float(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.blasr_hip_refine_last_fill4(self.handle, C.byref(ms), C.byref(n), C.byref(b), C.byref(c)))
+        return dict(ms=ms.value, launches=n.value, bytes=b.value, cells=c.value)
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()
