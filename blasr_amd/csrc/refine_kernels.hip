@@ -12,16 +12,16 @@
 //                    derived 64 at a time with lane = row (block lookup by
 //                    ballot + mbcnt, band start by a wave prefix-max, matrix
 //                    offsets by a wave prefix-sum); emits nCells / widest row.
-//   fill_kernel      one wavefront per candidate, lane = band column.  A row is
+//   fill4_kernel     FOUR candidates per wavefront (one 16-lane DPP row each, three cells per lane) for the
+//                    candidates whose rows all fit 96 cells; the row above in a per-candidate LDS ring.
+//   fill_kernel      one wavefront per candidate, lane = band column, for the others.  In both a row is
 //                    one pass: the vertical/diagonal candidates are elementwise,
 //                    the horizontal (deletion) dependency is closed with two
 //                    DPP prefix-min scans, so a whole row costs O(1) wave
-//                    instructions instead of a serial sweep.  Score rows
-//                    (S and affine-insert I) live in an LDS ring indexed by
-//                    target column; only the 1-byte packed arrows (3 bits S,
+//                    instructions instead of a serial sweep.  Only the 1-byte packed arrows (3 bits S,
 //                    1 bit I, 1 bit D) and an 8-byte row record go to HBM.
-//   traceback_kernel one lane per candidate: walks the packed arrows backwards with the
-//                    arrow bytes prefetched four rows ahead, run-length encodes the path.
+//   traceback_kernel one lane per candidate: walks the packed arrows backwards, eight rows per batch of
+//                    prefetched 16-byte windows, run-length encodes the path.
 //   stats_kernel     one wavefront per candidate, lane = op: ComputeAlignmentStats.
 //   scan / compact   exclusive scan of op counts and a coalesced copy of the
 //                    per-candidate op runs into the caller's arena.

@@ -11,25 +11,29 @@
 //     SWAlign(Global) gap fills      SWAlign.h:19-389
 //     recursive SDPAlign on big gaps SDPAlign.h:445-456, :509-520
 //
-// How it is laid out here: the recursion becomes successive kernel WAVES (level 0 =
-// the candidates, level 1 = their large gap rectangles, level 2 = theirs); within a
-// level every SDPAlign invocation is one wavefront:
-//   sdp_keys      lane = target position: 2-bit k-mer keys (k-mer << 24 | pos)
-//   sdp_sort_keys one wavefront per task: stable LSD radix sort of the keys by k-mer (LDS histogram)
-//   sdp_match     lane = query position: binary search of the sorted keys, fragment emission in
-//                 StoreMatchingPositions order; prefix/suffix 5-mer fragments by direct comparison
-//   sdp_order     merge of the prefix/middle/suffix lists; when duplicates exist the libstdc++
-//                 introsort schedule is replayed so that the same duplicate survives
-//   sdp_above_predcl  the two STATIC predecessors of every fragment ("above", and the predecessor in
-//                 the sweep set, which depends only on geometry) for all fragments in parallel
-//   sdp_chain     the row sweep proper: sequential over fragments, wave-parallel ordered-set
-//                 operations (64-ary search, lane-parallel shifts) for the column set
-//   sdp_blocks    chain -> blocks -> trim/filter, emits finished blocks, SWAlign jobs and the next
-//                 level's SDPAlign jobs
-//   sw            one lane per SWAlign(Global) gap fill
+// How it is laid out here: the recursion becomes successive kernel WAVES (level 0 = the candidates, level 1 =
+// their large gap rectangles, level 2 = theirs); within a level every SDPAlign invocation runs through
+//   sdp_classify       long targets (>= 1536 bases) are listed for the LDS-index matcher
+//   sdp_match_index    long targets: one workgroup per invocation, the target's k-mers in an LDS hash index built
+//                      with a stable counting scatter; count pass + copy pass (index rebuilt only if needed)
+//   sdp_keys / sdp_sort_keys / sdp_match   mid-size targets: 2-bit k-mer keys, a wave-level stable LSD radix sort,
+//                      binary search; targets <= 128 bases: k-mers in registers, all-pairs by v_readlane;
+//                      prefix/suffix 5-mer fragments by direct comparison
+//   sdp_small          invocations with <= 64 fragments: sort + keep-first, StoreAbove, sweep-set predecessor and
+//                      the sweep itself in one kernel, fragments one per lane
+//   sdp_order (+ sdp_order_ties)   merge of the prefix/middle/suffix lists; when duplicates exist the libstdc++
+//                      introsort schedule is replayed in LDS so that the same duplicate survives
+//   sdp_yx_keys / sdp_sort_yx / sdp_above_predcl   the two STATIC predecessors of every fragment ("above", and the
+//                      predecessor in the sweep set, which depends only on geometry), all fragments in parallel
+//   sdp_chain          the row sweep proper: sequential over fragments, the fragment window and the tail of the
+//                      column set in registers
+//   sdp_blocks_build / sdp_blocks_emit   chain -> blocks -> trim/filter; finished blocks, SWAlign jobs and the next
+//                      level's SDPAlign jobs through count -> scan -> emit
+//   sw_sort_keys / sw_small / sw   SWAlign(Global) gap fills, sorted by shape, one per lane
 //   (device radix sort of all finished blocks by (candidate, query position): gap fills slot in
 //    between their parents' blocks, so sorting by query position IS the in-order assembly)
-//   sdp_finish    Local re-basing, SDPAlign's return score, ComputeAlignmentStats
+//   pool_offsets / sdp_finish   per-candidate block ranges, Local re-basing, SDPAlign's return score,
+//                      ComputeAlignmentStats
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
