@@ -734,8 +734,9 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
           const int insSK = upS[j] + (kIns + AR_UP);
           insEK[j] = upI[j] + (kExt + AR_INS_CLOSE);
           vKey[j] = min(matchK, min(insSK, insEK[j]));
-          int v = vKey[j] & ~kTagMask;
-          v = act[j] ? v : inf;
+          // cells beyond the row's end are NOT masked here: they lie right of every real cell and the horizontal
+          // minima only flow left to right (their ring entries are stored as "no cell" below)
+          const int v = vKey[j] & ~kTagMask;
           ia[j] = v - pDel[j];
           ib[j] = v - pExt[j];
         }
