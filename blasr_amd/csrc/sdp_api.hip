@@ -189,6 +189,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     lv.bigCount = lv.bigList + nTasks;
     lv.idxFlag = arena.get<int32_t>(nTasks);
     lv.fused = arena.get<int32_t>(nTasks);
+    lv.chainList = nullptr;
+    if (!getenv("BLASR_HIP_NO_CHAIN4")) {
+      lv.chainList = arena.get<int32_t>(nTasks + 1);
+      lv.chainCount = lv.chainList + nTasks;
+    }
     ARENA_CHECK();
     launch_sdp_classify(lv, st);
     int64_t *sizes = arena.get<int64_t>(nTasks + 1);
@@ -288,6 +293,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     tick();
     launch_sdp_chain(lv, prm, st);
     tock(2);
+
     // ---- blocks, gap-fill jobs, next level ----
     tick();
     // what every task will emit, then exclusive scans -> contention-free slots

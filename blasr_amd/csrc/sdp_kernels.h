@@ -61,6 +61,7 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
+  int32_t *chainList, *chainCount;  // invocations for sdp_chain4_kernel (not fused, >= 1 fragment); null: use sdp_chain_kernel
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)
   int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel

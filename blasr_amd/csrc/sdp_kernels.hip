@@ -1729,6 +1729,339 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
   if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
 }
 
+// ---------------------------------------------------------------------------
+// sdp_chain4: the same sweep, FOUR invocations per wavefront.
+//
+// The sweep scores one fragment at a time, so with one invocation per wavefront 63 lanes wait on one.  Here
+// every invocation owns a 16-lane group: a window of 16 fragments (and the previous 16) one per lane, and the
+// last 16 entries of its column set, shifted with row DPP operations that never leave the group.  What was a
+// v_readlane becomes a ds_bpermute inside the group, what was a scalar becomes a per-group vector value, and the
+// four groups step through their fragments in lockstep.  An operation whose position lies below a group's 16
+// register entries (a fragment far off the diagonal, about four per 10 kb read) is "deep": it is carried out on
+// the array in memory by all 64 lanes for that one group (gcs_* above), then the group reloads its tail.
+// ---------------------------------------------------------------------------
+// Column-set operations on an array that lies entirely in memory, performed by all 64 lanes for ONE invocation
+// (sdp_chain4_kernel's rare "deep" operations: the position lies below the 16 entries a group keeps in registers).
+__device__ void gcs_insert(int4 *g, int n, int pos, int4 e) {  // n entries before the insert
+  const int lane = lane_id();
+  for (int top = n; top > pos; top -= 64) {  // move [pos, n) up by one, highest chunk first
+    const int i = top - 1 - lane;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i >= pos) v = g[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i >= pos) g[i + 1] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (lane == 0) g[pos] = e;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ void gcs_erase(int4 *g, int n, int first, int count) {  // removes [first, first + count)
+  const int lane = lane_id();
+  for (int b = first + count; b < n; b += 64) {
+    const int i = b + lane;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < n) v = g[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i < n) g[i - count] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+__device__ __forceinline__ int4 *uniform_ptr(int4 *p, int srcLane) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, srcLane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srcLane);
+  return reinterpret_cast<int4 *>(((uint64_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool take = false;
+  if (i < lv.n && !lv.fused[i]) {
+    if (lv.nFrag[i] == 0) lv.chainEnd[i] = -1;
+    else take = true;
+  }
+  const unsigned long long mask = __ballot(take);
+  int base = 0;
+  if (mask != 0ull && lane_id() == 0) base = atomicAdd(lv.chainCount, (int)__popcll(mask));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (take) lv.chainList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+}
+
+__global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int lane = lane_id(), l = lane & 15, gb = lane & 48;
+  const int nList = *lv.chainCount;
+  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
+  if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
+  const bool on = slot < nList;
+  const int idx = on ? lv.chainList[slot] : 0;
+  const int F = on ? lv.nFrag[idx] : 0;
+  const SdpTask t = lv.tasks[idx];
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
+  const int *predCl = lv.predCl + base, *above = lv.above + base;
+  int4 *colG = lv.colSet + base;
+  const int k = t.k, type = t.type;
+  auto gbp = [&](int v, int i) { return __builtin_amdgcn_ds_bpermute((gb + (i & 15)) << 2, v); };
+  auto gcount = [&](bool flag) {
+    const unsigned long long m = __ballot(flag);
+    return (int)__popc((unsigned)((m >> gb) & 0xffffull));
+  };
+  int curX = 0, curY = 0, curCost = 0, curLen = 0, curPrev = -1, prvX = 0, prvY = 0, prvCost = 0, prvLen = 0;
+  int4 tail = make_int4(0, 0, 0, 0);
+  int n = 0, nBase = 0, fTrail = 0;
+  int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
+  uint32_t maxLen = 0;
+  int maxF = F;
+  for (int off = 32; off > 0; off >>= 1) maxF = max(maxF, __shfl_xor(maxF, off));
+  for (int w0 = 0; w0 < maxF; w0 += 16) {
+    prvX = curX, prvY = curY, prvCost = curCost, prvLen = curLen;
+    int flV = 0, fpV = -1, faV = -1;
+    curX = curY = 0;
+    if (on && w0 + l < F) {
+      const Frag f = fr[w0 + l];
+      curX = (int)f.x;
+      curY = (int)f.y;
+      flV = (int)f.len;
+      fpV = predCl[w0 + l];
+      faV = above[w0 + l];
+    }
+    // fragment p of this group: from the two register windows, else from memory
+    auto view3 = [&](int p, bool need, int &vx, int &vy, int &vc) {
+      const int rel = p - w0;
+      const int xa = gbp(curX, rel), ya = gbp(curY, rel), ca = gbp(curCost, rel);
+      const int xb = gbp(prvX, rel + 16), yb = gbp(prvY, rel + 16), cb = gbp(prvCost, rel + 16);
+      vx = rel >= 0 ? xa : xb;
+      vy = rel >= 0 ? ya : yb;
+      vc = rel >= 0 ? ca : cb;
+      if (__ballot(need && rel < -16) != 0ull) {
+        if (need && rel < -16) {
+          const Frag f = fr[p];
+          vx = (int)f.x;
+          vy = (int)f.y;
+          vc = cost[p];
+        }
+      }
+    };
+    for (int j = 0; j < 16; j++) {
+      const int i = w0 + j;
+      const bool act = on && i < F;
+      if (__ballot(act) == 0ull) break;
+      const int fx = gbp(curX, j), fy = gbp(curY, j), fl = gbp(flV, j);
+      // ---- rows leaving the window: fragments with x <= f.x - k - 2 are retired first (:248-309)
+      for (;;) {
+        bool need = act && fTrail < i;
+        int ftx, fty, ftc;
+        view3(need ? fTrail : i, need, ftx, fty, ftc);
+        need = need && (int64_t)ftx + k + 2 <= (int64_t)fx;
+        if (__ballot(need) == 0ull) break;
+        const bool validLane = nBase + l < n;
+        const int tail0 = gbp(tail.x, 0);
+        const int pos = nBase + gcount(validLane && tail.x < fty);
+        // "deep": the position lies below the entries held in registers, or the insert would have to go into the
+        // half of the tail that is about to be spilled -> the whole retirement is done in memory, see below
+        const int atx = gbp(tail.x, pos - nBase), atz = gbp(tail.z, pos - nBase);
+        const bool memberT = pos < n && atx == fty;
+        const bool deep = need && ((nBase != 0 && !(fty > tail0)) ||
+                                   (!memberT && n - nBase == 16 && pos < nBase + 8));
+        const bool fast = need && !deep;
+        const bool member = fast && memberT;
+        const bool store = fast && (!member || atz < ftc);  // sic (:260-267)
+        const int4 e = make_int4(fty, fTrail, ftc, ftx + fty);
+        if (store && member && l == pos - nBase) tail = e;
+        const bool doIns = store && !member;
+        const bool full = doIns && n - nBase == 16;
+        if (__ballot(full) != 0ull) {  // spill the lower half of the tail
+          if (full && l < 8) colG[nBase + l] = tail;
+          const int sx = gbp(tail.x, l + 8), sy = gbp(tail.y, l + 8), sz = gbp(tail.z, l + 8), sw = gbp(tail.w, l + 8);
+          if (full) {
+            tail = make_int4(sx, sy, sz, sw);
+            nBase += 8;
+          }
+        }
+        {
+          const int p = pos - nBase;
+          const int ux = dpp<0x111, 0xf>(0, tail.x), uy = dpp<0x111, 0xf>(0, tail.y);
+          const int uz = dpp<0x111, 0xf>(0, tail.z), uw = dpp<0x111, 0xf>(0, tail.w);
+          if (doIns && l > p) tail = make_int4(ux, uy, uz, uw);
+          if (doIns && l == p) tail = e;
+          n += doIns ? 1 : 0;
+        }
+        // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
+        int del = 0;
+        for (;;) {
+          const int sc = gbp(tail.z, pos + 1 + del - nBase);
+          const bool more = store && n - del >= 2 && pos + 1 + del < n && sc > ftc;
+          if (__ballot(more) == 0ull) break;
+          del += more ? 1 : 0;
+        }
+        if (__ballot(del > 0) != 0ull) {
+          const int ex = gbp(tail.x, l + del), ey = gbp(tail.y, l + del), ez = gbp(tail.z, l + del), ew = gbp(tail.w, l + del);
+          if (del > 0 && l >= pos + 1 - nBase) tail = make_int4(ex, ey, ez, ew);
+          n -= del;
+        }
+        // ---- deep retirements, one group at a time, with all 64 lanes on the array in memory
+        for (unsigned long long dm = __ballot(deep); dm != 0ull;) {
+          const int g0 = __builtin_ctzll(dm) & 48;  // first lane of the group
+          dm &= ~(0xffffull << g0);
+          if (gb == g0 && nBase + l < n) colG[nBase + l] = tail;  // the registers' share joins the array
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          int4 *gp = uniform_ptr(colG, g0);
+          int N = __builtin_amdgcn_readlane(n, g0);
+          const int key = __builtin_amdgcn_readlane(fty, g0), kc = __builtin_amdgcn_readlane(ftc, g0);
+          const int4 ge = make_int4(key, __builtin_amdgcn_readlane(fTrail, g0), kc,
+                                    __builtin_amdgcn_readlane(ftx, g0) + key);
+          const int gpos = cs_global_lower_bound(gp, N, key);
+          bool gmember = false;
+          int4 at = make_int4(0, 0, 0, 0);
+          if (gpos < N) {
+            at = gp[gpos];
+            gmember = at.x == key;
+          }
+          if (!gmember || at.z < kc) {
+            if (gmember) {
+              if (lane == 0) gp[gpos] = ge;
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else {
+              gcs_insert(gp, N, gpos, ge);
+              N++;
+            }
+            int gdel = 0;
+            while (N - gdel >= 2 && gpos + 1 + gdel < N && gp[gpos + 1 + gdel].z > kc) gdel++;
+            if (gdel) {
+              gcs_erase(gp, N, gpos + 1, gdel);
+              N -= gdel;
+            }
+          }
+          if (gb == g0) {  // back into registers: the last 16 entries
+            n = N;
+            nBase = N > 16 ? N - 16 : 0;
+            if (nBase + l < n) tail = colG[nBase + l];
+          }
+        }
+        fTrail += need ? 1 : 0;
+      }
+      // ---- the three predecessors
+      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
+      bool foundPrev = false;
+      {
+        const bool q = act && n > 0;
+        const bool validLane = nBase + l < n;
+        const int tail0 = gbp(tail.x, 0);
+        const int pos = nBase + gcount(validLane && tail.x < fy);
+        const bool deep = q && nBase != 0 && !(fy > tail0);  // the predecessor lies below the registers' share
+        const bool qf = q && !deep;
+        const int atx = gbp(tail.x, pos - nBase);
+        const bool exact = qf && pos < n && atx == fy;
+        bool have = qf && (exact || pos > 0);
+        const int sel = (exact ? pos : pos - 1) - nBase;
+        int aty = gbp(tail.y, sel), atz = gbp(tail.z, sel), atw = gbp(tail.w, sel);
+        for (unsigned long long dm = __ballot(deep); dm != 0ull;) {
+          const int g0 = __builtin_ctzll(dm) & 48;
+          dm &= ~(0xffffull << g0);
+          int4 *gp = uniform_ptr(colG, g0);
+          const int NB = __builtin_amdgcn_readlane(nBase, g0), key = __builtin_amdgcn_readlane(fy, g0);
+          // entries [0, NB) are in memory; entry NB is the group's first register entry (its column is >= key)
+          const int gpos = cs_global_lower_bound(gp, NB, key);
+          bool gexact = false;
+          int4 at = make_int4(0, 0, 0, 0);
+          if (gpos < NB) {
+            at = gp[gpos];
+            gexact = at.x == key;
+          } else if (__builtin_amdgcn_readlane(tail.x, g0) == key) {
+            at = make_int4(key, __builtin_amdgcn_readlane(tail.y, g0), __builtin_amdgcn_readlane(tail.z, g0),
+                           __builtin_amdgcn_readlane(tail.w, g0));
+            gexact = true;
+          }
+          bool ghave = gexact;
+          if (!gexact && gpos > 0) {
+            at = gp[gpos - 1];
+            ghave = true;
+          }
+          if (gb == g0) {
+            have = ghave;
+            aty = at.y;
+            atz = at.z;
+            atw = at.w;
+          }
+        }
+        if (have) {
+          const int d = abs((fx + fy) - atw);
+          int s = (int)sqrtf((float)d);
+          s -= ((unsigned)s * (unsigned)s > (unsigned)d) ? 1 : 0;
+          s += ((unsigned)(s + 1) * (unsigned)(s + 1) <= (unsigned)d) ? 1 : 0;
+          cpFrag = aty;
+          cp = atz + s - fl;
+          foundPrev = true;
+        }
+      }
+      const int clFrag = gbp(fpV, j), aboveIdx = gbp(faV, j);
+      {
+        int px, py, pc;
+        const bool needCl = act && clFrag >= 0;
+        view3(needCl ? clFrag : i, needCl, px, py, pc);
+        if (needCl) {
+          int ov = (int)((uint32_t)k - (uint32_t)(fy - py)) * prm.match;
+          if (ov > 0) ov = 0;
+          cl = pc + ov + indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel);
+          foundPrev = true;
+        }
+        const bool needCa = act && aboveIdx >= 0;
+        view3(needCa ? aboveIdx : i, needCa, px, py, pc);
+        if (needCa) {
+          ca = (int)((uint32_t)pc + ((uint32_t)k - (uint32_t)(fy - py)) * (uint32_t)prm.match +
+                     (uint32_t)indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel));
+          foundPrev = true;
+        }
+      }
+      int mc = cl < ca ? cl : ca;
+      if (cp < mc) mc = cp;
+      int myCost, myPrev;
+      uint32_t myLen;
+      const bool linked = foundPrev && (type == 1 || (type == 0 && mc < 0));
+      {
+        myPrev = -1;
+        if (linked) myPrev = (mc == cp) ? cpFrag : ((mc == cl) ? clFrag : aboveIdx);
+        // the chosen predecessor's chain length
+        const int p = linked && act ? myPrev : i;
+        const int rel = p - w0;
+        const int la = gbp(curLen, rel), lb = gbp(prvLen, rel + 16);
+        int pl = rel >= 0 ? la : lb;
+        if (__ballot(linked && act && rel < -16) != 0ull)
+          if (linked && act && rel < -16) pl = chainLen[p];
+        if (linked) {
+          myCost = (int)((uint32_t)mc - (uint32_t)k);
+          myLen = (uint32_t)pl + 1u;
+        } else {
+          myLen = 1;
+          if (type == 1) myCost = (int)((uint32_t)(fx + fy) * (uint32_t)prm.sdpDel + (uint32_t)k * (uint32_t)prm.match - (uint32_t)k);
+          else myCost = (int)((uint32_t)k * (uint32_t)prm.match - (uint32_t)k);
+        }
+      }
+      if (act && l == j) {
+        curCost = myCost;
+        curLen = (int)myLen;
+        curPrev = myPrev;
+      }
+      if (act && minCost > myCost) {
+        minCost = myCost;
+        minIdx = i;
+      }
+      if (act && myLen > maxLen) {
+        maxLen = myLen;
+        maxLenIdx = i;
+      }
+    }
+    if (on && w0 + l < F) {
+      cost[w0 + l] = curCost;
+      chainPrev[w0 + l] = curPrev;
+      chainLen[w0 + l] = curLen;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (on && l == 0) lv.chainEnd[idx] = type == 0 ? minIdx : maxLenIdx;
+}
+
 __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
@@ -2521,7 +2854,14 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
 }
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+  if (lv.n <= 0) return;
+  if (lv.chainList != nullptr) {  // four invocations per wavefront
+    (void)hipMemsetAsync(lv.chainCount, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+  } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
+    hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+  }
 }
 void launch_sdp_blocks_build(const SdpLevelArrays &lv, const SdpParams &p, int32_t *counts, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_blocks_build_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, counts);
