@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv) 
   if (take) lv.chainList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
 }
 
-__global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
+__global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int lane = lane_id(), l = lane & 15, gb = lane & 48;
   const int nList = *lv.chainCount;
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
@@ -1797,9 +1797,12 @@ __global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpP
   const int F = on ? lv.nFrag[idx] : 0;
   const SdpTask t = lv.tasks[idx];
   const int64_t base = lv.fragOff[idx];
-  const Frag *fr = lv.frags + base;
-  int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
-  const int *predCl = lv.predCl + base, *above = lv.above + base;
+  // per-group arrays are addressed as (uniform array base) + base + index: one 64-bit offset per lane instead of
+  // seven pointers
+#define C4_FR(i) lv.frags[base + (i)]
+#define C4_COST(i) lv.cost[base + (i)]
+#define C4_PREV(i) lv.chainPrev[base + (i)]
+#define C4_LEN(i) lv.chainLen[base + (i)]
   int4 *colG = lv.colSet + base;
   const int k = t.k, type = t.type;
   auto gbp = [&](int v, int i) { return __builtin_amdgcn_ds_bpermute((gb + (i & 15)) << 2, v); };
@@ -1819,12 +1822,12 @@ __global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpP
     int flV = 0, fpV = -1, faV = -1;
     curX = curY = 0;
     if (on && w0 + l < F) {
-      const Frag f = fr[w0 + l];
+      const Frag f = C4_FR(w0 + l);
       curX = (int)f.x;
       curY = (int)f.y;
       flV = (int)f.len;
-      fpV = predCl[w0 + l];
-      faV = above[w0 + l];
+      fpV = lv.predCl[base + w0 + l];
+      faV = lv.above[base + w0 + l];
     }
     // fragment p of this group: from the two register windows, else from memory
     auto view3 = [&](int p, bool need, int &vx, int &vy, int &vc) {
@@ -1836,10 +1839,10 @@ __global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpP
       vc = rel >= 0 ? ca : cb;
       if (__ballot(need && rel < -16) != 0ull) {
         if (need && rel < -16) {
-          const Frag f = fr[p];
+          const Frag f = C4_FR(p);
           vx = (int)f.x;
           vy = (int)f.y;
-          vc = cost[p];
+          vc = C4_COST(p);
         }
       }
     };
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpP
         const int la = gbp(curLen, rel), lb = gbp(prvLen, rel + 16);
         int pl = rel >= 0 ? la : lb;
         if (__ballot(linked && act && rel < -16) != 0ull)
-          if (linked && act && rel < -16) pl = chainLen[p];
+          if (linked && act && rel < -16) pl = C4_LEN(p);
         if (linked) {
           myCost = (int)((uint32_t)mc - (uint32_t)k);
           myLen = (uint32_t)pl + 1u;
@@ -2053,13 +2056,17 @@ __global__ __launch_bounds__(256) void sdp_chain4_kernel(SdpLevelArrays lv, SdpP
       }
     }
     if (on && w0 + l < F) {
-      cost[w0 + l] = curCost;
-      chainPrev[w0 + l] = curPrev;
-      chainLen[w0 + l] = curLen;
+      C4_COST(w0 + l) = curCost;
+      C4_PREV(w0 + l) = curPrev;
+      C4_LEN(w0 + l) = curLen;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (on && l == 0) lv.chainEnd[idx] = type == 0 ? minIdx : maxLenIdx;
+#undef C4_FR
+#undef C4_COST
+#undef C4_PREV
+#undef C4_LEN
 }
 
 __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
