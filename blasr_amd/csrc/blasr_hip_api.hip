@@ -406,7 +406,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       wideLaunched = true;
     }
     if (fast && !getenv("BLASR_HIP_NO_FILL4")) {
-      // candidates whose rows all fit fill4_kernel's two passes run four to a wavefront, longest first so the
+      // candidates whose rows all fit fillp_kernel's passes run four to a wavefront, longest first so the
       // four of a wavefront finish together; the others keep one wavefront each
       std::vector<int32_t> list4, list1;
       for (int i = c.first; i < c.first + c.count; i++) {
@@ -415,6 +415,16 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         else list1.push_back(i);
       }
       std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
+      if (getenv("BLASR_HIP_GEO_HIST")) {
+        int h[8] = {0};
+        for (int i = c.first; i < c.first + c.count; i++) {
+          if (geo[i].status != 0) continue;
+          const int w = geo[i].maxWidth;
+          h[w <= 40 ? 0 : w <= 47 ? 1 : w <= 56 ? 2 : w <= 64 ? 3 : w <= 80 ? 4 : w <= 96 ? 5 : w <= 128 ? 6 : 7]++;
+        }
+        fprintf(stderr, "maxWidth hist <=40:%d <=47:%d <=56:%d <=64:%d <=80:%d <=96:%d <=128:%d more:%d\n", h[0], h[1], h[2],
+                h[3], h[4], h[5], h[6], h[7]);
+      }
       if (!list4.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
       if (!list1.empty())
@@ -424,7 +434,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         f4.taskList = dList4;
         f4.count = (int)list4.size();
         HIP_TRY(ctx, hipEventRecord(evF4[0], st));
-        launch_fill4(view, f4, st);
+        launch_fill4(view, f4, getenv("BLASR_HIP_FILL_LANES8") ? 8 : 16, st);
         HIP_TRY(ctx, hipEventRecord(evF4[1], st));
         timedFill4 = true;
         for (int32_t i : list4) {

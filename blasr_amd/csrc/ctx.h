@@ -18,7 +18,7 @@ struct blasr_hip_ctx {
   std::string lastError;
   float ms[4] = {0, 0, 0, 0};
   int64_t counters[3] = {0, 0, 0};
-  // the dominant kernel of the refine stage on its own: fill4_kernel launches of the last call
+  // the dominant kernel of the refine stage on its own: fillp_kernel launches of the last call
   float fill4Ms = 0;
   int64_t fill4Launches = 0, fill4Bytes = 0, fill4Cells = 0;
   float sdpMs[4] = {0, 0, 0, 0};

@@ -12,8 +12,8 @@
 //                    derived 64 at a time with lane = row (block lookup by
 //                    ballot + mbcnt, band start by a wave prefix-max, matrix
 //                    offsets by a wave prefix-sum); emits nCells / widest row.
-//   fill4_kernel     FOUR candidates per wavefront (one 16-lane DPP row each, three cells per lane) for the
-//                    candidates whose rows all fit 96 cells; the row above in a per-candidate LDS ring.
+//   fillp_kernel     FOUR candidates per wavefront (one 16-lane DPP row each, three cells per lane) for the
+//                    candidates whose rows all fit 112 cells; the row above in a per-candidate LDS ring.
 //   fill_kernel      one wavefront per candidate, lane = band column, for the others.  In both a row is
 //                    one pass: the vertical/diagonal candidates are elementwise,
 //                    the horizontal (deletion) dependency is closed with two
@@ -535,21 +535,26 @@ __global__ __launch_bounds__(256) void fill_kernel(RefineBatchView batch, FillAr
 }
 
 // ---------------------------------------------------------------------------
-// fill4_kernel: the same recurrence, FOUR candidates per wavefront.
+// fillp_kernel<kL>: the same recurrence, 64/kL candidates per wavefront.
 //
 // A band row is ~33 cells, so one candidate per wavefront leaves half of the 64 lanes idle while the kernel is
-// bound by VALU issue.  Here each candidate owns one 16-lane DPP row and every lane three consecutive cells
-// (48 columns per pass; wider rows take further passes with carries).  The row above lives in a per-candidate
-// LDS ring indexed by target column -- any band shift is just an address -- and is updated in place.  The
-// horizontal minima are a lane-local prefix over the three cells plus a 16-lane DPP scan (row_shr 1,2,4,8),
-// which never crosses into another candidate's lanes.  Tagged keys as in fill_kernel<.., true>; candidates
+// bound by VALU issue.  Here each candidate owns kL lanes (16: one DPP row, 8: half of one) and every lane 48/kL
+// consecutive cells (48 columns per pass; wider rows take further passes with carries).  The row above lives in
+// a per-candidate LDS ring indexed by target column -- any band shift is just an address -- and is updated in
+// place.  The horizontal minima are a lane-local prefix over the lane's cells plus a DPP scan over the kL lanes
+// that never crosses into another candidate's lanes.  Tagged keys as in fill_kernel<.., true>; candidates
 // outside that variant's domain, or with a row wider than kF4MaxWidth, stay with fill_kernel.
+// The fewer lanes per candidate, the more of the per-row bookkeeping (row records, staging, scan, loop) is shared.
 // ---------------------------------------------------------------------------
 constexpr int kF4Ring = 128;       // {S,I} columns per candidate (a row and the row above overlap in it)
-constexpr int kF4RingT = 128;      // packed matrix columns per candidate (a row plus the 16-column staging step)
-constexpr int kF4MaxWidth = 96;    // widest row: two passes (a third would alias the ring)
+constexpr int kF4RingT = 128;      // packed matrix columns per candidate (a row plus the staging step)
+constexpr int kF4MaxWidth = 112;   // widest row: with the staging step it fills the packed-column ring
+constexpr int kF4Pass = 48;        // columns per pass
 
-__device__ __forceinline__ void row16_prefix_min2(int &a, int &b) {
+template <int kL>
+__device__ __forceinline__ void group_prefix_min2(int &a, int &b);
+template <>
+__device__ __forceinline__ void group_prefix_min2<16>(int &a, int &b) {
   asm volatile(
       "s_nop 1\n\t"
       "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -566,12 +571,39 @@ __device__ __forceinline__ void row16_prefix_min2(int &a, int &b) {
       "s_nop 1"
       : "+v"(a), "+v"(b));
 }
+// eight lanes: two quad steps (a lane that has no left neighbour reads itself, and min is idempotent), then the
+// total of the lower quad reaches the upper one (banks 1 and 3 of each DPP row only)
+template <>
+__device__ __forceinline__ void group_prefix_min2<8>(int &a, int &b) {
+  int ta, tb;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %1, %1, %1 quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_mov_b32_dpp %2, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %3, %1 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_min_i32_dpp %0, %2, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_min_i32_dpp %1, %3, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b), "=&v"(ta), "=&v"(tb));
+}
 
-__global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillArgs args) {
-  __shared__ int2 ringLds[4][4][kF4Ring];
-  __shared__ uint32_t ringTLds[4][4][kF4RingT];
-  __shared__ int2 rowA[4][4][64];          // per row of the current 64-row batch: {matrix offset, first column}
-  __shared__ unsigned short rowB[4][4][64];  // width | query code << 8
+typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
+typedef uint16_t __attribute__((aligned(1))) unaligned_u16;
+
+template <int kL>
+__global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillArgs args) {
+  constexpr int kT = 64 / kL;      // candidates per wavefront
+  constexpr int kC = kF4Pass / kL;  // cells per lane and pass
+  __shared__ int2 ringLds[4][kT][kF4Ring];
+  __shared__ uint32_t ringTLds[4][kT][kF4RingT];
+  __shared__ int2 rowA[4][kT][64];          // per row of the current 64-row batch: {matrix offset, first column}
+  __shared__ unsigned short rowB[4][kT][64];  // width | query code << 8
   __shared__ unsigned char flagScratch[4][64];
   __shared__ uint32_t packedCol[8];        // per target code: the matrix column for queries A,C,G,T, one byte each
   if (threadIdx.x < 5) {
@@ -583,20 +615,20 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
   if (threadIdx.x < 5) matN[threadIdx.x] = args.matrix[20 + threadIdx.x];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int grp = lane >> 4, l = lane & 15;
-  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * 4;
+  const int grp = lane / kL, l = lane % kL;
+  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * kT;
   if (slot0 >= args.count) return;
 
-  // ---- the four candidates of this wavefront (uniform values), and each lane's own candidate
-  int taskG[4], qG[4], tEndG[4];
-  GuideCursor cur[4];
-  const uint8_t *qSeqG[4];
-  int2 *rowTabG[4];
+  // ---- the candidates of this wavefront (uniform values), and each lane's own candidate
+  int taskG[kT], qG[kT], tEndG[kT];
+  GuideCursor cur[kT];
+  const uint8_t *qSeqG[kT];
+  int2 *rowTabG[kT];
   int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0;
   const uint8_t *myTSeq = nullptr;
   uint8_t *myArrows = nullptr;
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
+  for (int g = 0; g < kT; g++) {
     taskG[g] = -1;
     qG[g] = 0;
     tEndG[g] = 0;
@@ -624,21 +656,23 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
       }
     }
   }
-  const int maxQ = max(max(qG[0], qG[1]), max(qG[2], qG[3]));
+  int maxQ = 0;
+#pragma unroll
+  for (int g = 0; g < kT; g++) maxQ = max(maxQ, qG[g]);
   int2 *ring = ringLds[wave][grp];
   uint32_t *ringT = ringTLds[wave][grp];
 
   const int inf = 1 << 30;
   const int kIns = args.ins << kShift, kDel = args.del << kShift, kOpen = args.open << kShift, kExt = args.ext << kShift;
-  int pDel[3], pExt[3];
+  int pDel[kC], pExt[kC];
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    pDel[j] = (3 * l + j) * kDel;
-    pExt[j] = (3 * l + j) * kExt;
+  for (int j = 0; j < kC; j++) {
+    pDel[j] = (kC * l + j) * kDel;
+    pExt[j] = (kC * l + j) * kExt;
   }
   // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open
   if (myTask >= 0)
-    for (int c = myPlo + l; c <= myPhi; c += 16) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+    for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
   myTLoaded = myPlo < 0 ? 0 : myPlo;
   __builtin_amdgcn_wave_barrier();
 
@@ -646,7 +680,7 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
     // ---- geometry and query codes of the next 64 rows of every candidate
     bool wideBatch = false;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
+    for (int g = 0; g < kT; g++) {
       if (taskG[g] >= 0 && r0 <= qG[g]) {
         int tV, loV, hiV;
         unsigned rsV;
@@ -658,7 +692,7 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
           const int width = min(hiV, tEndG[g] - 1) - loV + 1;  // cells with t >= tEnd are skipped (:268-269)
           rowA[wave][g][lane] = make_int2((int)rsV, loV);
           rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
-          wideBatch = wideBatch || width > 48;
+          wideBatch = wideBatch || width > kF4Pass;
         }
       }
     }
@@ -678,109 +712,115 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
           const int c = myTLoaded + l;
           const int code = c < myTLen ? base_code(myTSeq[c]) : 4;
           ringT[c & (kF4RingT - 1)] = packedCol[code];
-          myTLoaded += 16;
+          myTLoaded += kL;
         }
       }
       __builtin_amdgcn_wave_barrier();
       int nPass = 1;
-      if (anyWide) nPass = wave_max(rowOn ? (width + 47) / 48 : 0);
+      if (anyWide) nPass = wave_max(rowOn ? (width + kF4Pass - 1) / kF4Pass : 0);
       int carryA = inf, carryB = inf, carryDiag = inf;
       uint8_t *arrowRow = myArrows + (unsigned)rec.x;
       for (int pass = 0; pass < nPass; pass++) {
-        const int cb = lo + 48 * pass, c0 = cb + 3 * l;
-        // ---- the row above, by column
-        int upS[3], upI[3], diagS[3];
-        bool act[3];
+        const int cb = lo + kF4Pass * pass, c0 = cb + kC * l;
+        // ---- the row above, by column.  Ring entries right of the previous row's last cell are stale.
+        int upS[kC], upI[kC], diagS[kC];
         const int2 dRaw = ring[(c0 - 1) & (kF4Ring - 1)];
         int d0 = dRaw.x;
         if (pass > 0) d0 = (l == 0) ? carryDiag : d0;  // column cb-1 was overwritten by the previous pass
         d0 = (c0 - 1 <= myPhi && c0 - 1 >= myPlo) ? d0 : inf;
         int lastRaw = 0;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < kC; j++) {
           const int c = c0 + j;
           const int2 up = ring[c & (kF4Ring - 1)];
-          if (j == 2) lastRaw = up.x;
+          if (j == kC - 1) lastRaw = up.x;
           const bool upValid = c <= myPhi;  // c >= lo >= plo always
           upS[j] = upValid ? up.x : inf;
           upI[j] = upValid ? up.y : inf;
-          act[j] = rowOn && c <= hiC;
         }
         diagS[0] = d0;
-        diagS[1] = upS[0];
-        diagS[2] = upS[1];
-        carryDiag = dpp<0x121, 0xf>(0, lastRaw);  // row_ror:1: lane 0 of the group receives lane 15's value
-        // ---- substitution scores
-        int m[3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 1; j < kC; j++) diagS[j] = upS[j - 1];
+        // ---- substitution scores
+        int m[kC];
+#pragma unroll
+        for (int j = 0; j < kC; j++) {
           const uint32_t te = ringT[(c0 + j) & (kF4RingT - 1)];
           m[j] = (int)__builtin_amdgcn_sbfe((int)te, (qc & 3) * 8, 8);
         }
         if (__ballot(rowOn && qc >= 4) != 0ull) {  // query N (rare): the packed column has no N row
 #pragma unroll
-          for (int j = 0; j < 3; j++)
-            if (qc >= 4 && act[j]) {
+          for (int j = 0; j < kC; j++)
+            if (rowOn && qc >= 4) {
               const int c = c0 + j;
               const int tcode = (c >= 0 && c < myTLen) ? base_code(myTSeq[c]) : 4;
               m[j] = matN[tcode];
             }
         }
-        // ---- vertical candidates and the two horizontal chains
-        int vKey[3], insEK[3], ia[3], ib[3];
+        // ---- vertical candidates and the two horizontal chains.  Cells beyond the row's end are not masked:
+        // they lie right of every real cell, the horizontal minima only flow left to right, and what they leave
+        // in the ring is never read as a cell (the next row's validity test above).
+        int vKey[kC], insEK[kC], ia[kC], ib[kC], preA[kC], preB[kC];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < kC; j++) {
           const int matchK = (m[j] << kShift) + diagS[j];
           const int insSK = upS[j] + (kIns + AR_UP);
           insEK[j] = upI[j] + (kExt + AR_INS_CLOSE);
           vKey[j] = min(matchK, min(insSK, insEK[j]));
-          // cells beyond the row's end are NOT masked here: they lie right of every real cell and the horizontal
-          // minima only flow left to right (their ring entries are stored as "no cell" below)
           const int v = vKey[j] & ~kTagMask;
           ia[j] = v - pDel[j];
           ib[j] = v - pExt[j];
+          preA[j] = j == 0 ? ia[0] : min(preA[j - 1], ia[j]);  // inclusive over this lane's cells
+          preB[j] = j == 0 ? ib[0] : min(preB[j - 1], ib[j]);
         }
-        const int a01 = min(ia[0], ia[1]), b01 = min(ib[0], ib[1]);
-        int pa = min(a01, ia[2]), pb = min(b01, ib[2]);  // this lane's three cells
-        row16_prefix_min2(pa, pb);                       // inclusive over the lanes of the candidate
+        int pa = preA[kC - 1], pb = preB[kC - 1];
+        group_prefix_min2<kL>(pa, pb);  // inclusive over the lanes of the candidate
         int ea = dpp<0x111, 0xf>(inf, pa), eb = dpp<0x111, 0xf>(inf, pb);  // lanes before this one
+        if (kL < 16) {
+          ea = l == 0 ? inf : ea;
+          eb = l == 0 ? inf : eb;
+        }
         ea = min(ea, carryA);
         eb = min(eb, carryB);
-        const int eaj[3] = {ea, min(ea, ia[0]), min(ea, a01)};
-        const int ebj[3] = {eb, min(eb, ib[0]), min(eb, b01)};
-        uint32_t arrowPack = 0;
-        int finalS = 0;
-        bool isFinal = false;
+        uint32_t arrowLo = 0, arrowHi = 0;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const int aK = eaj[j] + (pDel[j] + AR_LEFT);                 // S[c-1] + del
-          const int bK = ebj[j] + (pExt[j] + kOpen + AR_DEL_CLOSE);    // D[c-1] + ext
+        for (int j = 0; j < kC; j++) {
+          const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
+          const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
+          const int aK = eaj + (pDel[j] + AR_LEFT);                 // S[c-1] + del
+          const int bK = ebj + (pExt[j] + kOpen + AR_DEL_CLOSE);    // D[c-1] + ext
           const int sKey = min(vKey[j], min(aK, bK));
           const int sv = sKey & ~kTagMask;
           const int openKey = sv + (kOpen + AR_I_OPEN);
           const int iKey = min(openKey, insEK[j] & ~kTagMask);
           const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
-          const int arrow = (sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN));
-          arrowPack |= (uint32_t)arrow << (8 * j);
-          // cells beyond the row's end are stored as "no cell": the next row may look at them
-          ring[(c0 + j) & (kF4Ring - 1)] = make_int2(act[j] ? sv : inf, act[j] ? (iKey & ~kTagMask) : inf);
-          const bool fin = act[j] && c0 + j == myTEnd - 1;
-          finalS = fin ? sv : finalS;
-          isFinal = isFinal || fin;
+          const uint32_t arrow = (uint32_t)((sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN)));
+          if (j < 4)
+            arrowLo |= arrow << (8 * j);
+          else
+            arrowHi |= arrow << (8 * (j - 4));
+          // (a third pass must not write beyond the row's end: those slots hold the row's first columns)
+          if (rowOn && (pass < 2 || c0 + j <= hiC)) ring[(c0 + j) & (kF4Ring - 1)] = make_int2(sv, iKey & ~kTagMask);
         }
-        if (isFinal && r == myQ) args.dpScore[myTask] = finalS >> kShift;  // S[Q][tEnd-1] (:481-483)
-        // ---- arrows: three consecutive bytes per lane.  Bytes of cells beyond the row's end spill into the
+        // ---- arrows: kC consecutive bytes per lane.  Bytes of cells beyond the row's end spill into the
         // next row's space (or the slack after the last row) and are overwritten when that row is stored.
-        if (act[0]) {
+        if (rowOn && c0 <= hiC) {
           uint8_t *ap = arrowRow + (c0 - lo);
-          ap[0] = (uint8_t)arrowPack;
-          ap[1] = (uint8_t)(arrowPack >> 8);
-          ap[2] = (uint8_t)(arrowPack >> 16);
+          if (kC == 3) {
+            ap[0] = (uint8_t)arrowLo;
+            ap[1] = (uint8_t)(arrowLo >> 8);
+            ap[2] = (uint8_t)(arrowLo >> 16);
+          } else {
+            *(unaligned_u32 *)ap = arrowLo;
+            *(unaligned_u16 *)(ap + 4) = (uint16_t)arrowHi;
+          }
         }
         if (nPass > 1) {  // carries into the next 48 columns
-          const int ta = __builtin_amdgcn_ds_bpermute((lane | 15) * 4, pa), tb = __builtin_amdgcn_ds_bpermute((lane | 15) * 4, pb);
-          carryA = min(carryA, ta) + 48 * kDel;
-          carryB = min(carryB, tb) + 48 * kExt;
+          const int last = (lane | (kL - 1)) * 4;
+          const int ta = __builtin_amdgcn_ds_bpermute(last, pa), tb = __builtin_amdgcn_ds_bpermute(last, pb);
+          carryA = min(carryA, ta) + kF4Pass * kDel;
+          carryB = min(carryB, tb) + kF4Pass * kExt;
+          carryDiag = __builtin_amdgcn_ds_bpermute(last, lastRaw);  // the raw S of column cb+47, for lane 0
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -790,7 +830,12 @@ __global__ __launch_bounds__(256) void fill4_kernel(RefineBatchView batch, FillA
       }
     }
   }
+  // ---- S[Q][tEnd-1] (:481-483): a candidate's ring is not written after its last row
+  if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
+    args.dpScore[myTask] = ring[(myTEnd - 1) & (kF4Ring - 1)].x >> kShift;
 }
+template __global__ void fillp_kernel<16>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<8>(RefineBatchView, FillArgs);
 
 template __global__ void fill_kernel<false, true>(RefineBatchView, FillArgs);
 template __global__ void fill_kernel<false, false>(RefineBatchView, FillArgs);
@@ -1120,9 +1165,12 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
       hipLaunchKernelGGL((fill_kernel<false, false>), grid, block, 0, stream, batch, args);
   }
 }
-void launch_fill4(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {
+void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream) {
   if (args.count <= 0) return;
-  hipLaunchKernelGGL(fill4_kernel, dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+  if (lanes == 16)
+    hipLaunchKernelGGL(fillp_kernel<16>, dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+  else
+    hipLaunchKernelGGL(fillp_kernel<8>, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
 }
 int fill4_max_width() { return kF4MaxWidth; }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {

@@ -577,7 +577,7 @@ class Context:
         return self._kband_call(self.lib.blasr_hip_kband_linear_host, pairs, ks, kp, ops_capacity)
 
     def last_fill4(self):
-        """fill4_kernel launches of the last refine call: ms (HIP events), launches, algorithmic bytes, cells."""
+        """fillp_kernel launches of the last refine call: ms (HIP events), launches, algorithmic bytes, cells."""
         ms, n, b, c = C.c_float(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._check(self.lib.blasr_hip_refine_last_fill4(self.handle, C.byref(ms), C.byref(n), C.byref(b), C.byref(c)))
         return dict(ms=ms.value, launches=n.value, bytes=b.value, cells=c.value)

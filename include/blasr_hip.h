@@ -155,7 +155,7 @@ int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *batc
  * counters[0] = band cells filled, counters[1] = algorithmic bytes of the fill
  * (DESIGN.md), counters[2] = fill kernel launches. */
 int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
-/* The dominant kernel on its own: the fill4_kernel launches (four candidates per wavefront) of the last refine
+/* The dominant kernel on its own: the fillp_kernel launches (four candidates per wavefront) of the last refine
  * call -- HIP-event time on the library's stream, number of launches, algorithmic bytes (1 B per band cell +
  * the bases read + 8 B per row record) and band cells of the candidates those launches processed. */
 int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *launches, int64_t *algorithmic_bytes,

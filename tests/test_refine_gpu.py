@@ -160,22 +160,28 @@ def test_unsupported_gap_costs_are_rejected(ctx):
     assert e.value.code == hip.ERR_CAPACITY
 
 
-def test_one_candidate_per_wavefront_kernel_agrees(ctx, golden, monkeypatch):
-    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront) instead of fill4_kernel
-    (four per wavefront): the same goldens must come out of both."""
+@pytest.mark.parametrize("switch", ["BLASR_HIP_NO_FILL4", "BLASR_HIP_FILL_LANES8"])
+def test_alternative_fill_kernels_agree(ctx, golden, monkeypatch, switch):
+    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront) instead of fillp_kernel<16>
+    (four per wavefront); BLASR_HIP_FILL_LANES8 selects fillp_kernel<8> (eight per wavefront).  The same goldens
+    must come out of all of them."""
     cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
              and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
     b = blasr_amd.RefineBatch()
     for c in cases:
         b.add(c.qs, c.ts, c.sdp_blocks)
-    monkeypatch.setenv("BLASR_HIP_NO_FILL4", "1")
+    monkeypatch.setenv(switch, "1")
     for c, got in zip(cases, ctx.refine(b)):
         assert first_difference(got.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
-    monkeypatch.delenv("BLASR_HIP_NO_FILL4")
+    monkeypatch.delenv(switch)
 
 
-def test_many_candidates_of_ragged_lengths(ctx, oracle):
-    """fill4_kernel packs four candidates of different lengths and widths into one wavefront."""
+@pytest.mark.parametrize("lanes8", [False, True])
+def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
+    """fillp_kernel packs four (or eight) candidates of different lengths and widths into one wavefront; rows of
+    up to 112 cells take up to three passes."""
+    if lanes8:
+        monkeypatch.setenv("BLASR_HIP_FILL_LANES8", "1")
     rng = np.random.default_rng(77)
     b = blasr_amd.RefineBatch()
     want = []
