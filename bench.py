@@ -12,8 +12,14 @@ HBM, through the C ABI of include/blasr_hip.h:
 Workload at N=1 = BASELINE.json configs[1]: 100k synthetic 10 kb PacBio-like reads (ins 11 % /
 del 4 % / sub 1 %) against a 4.64 Mb i.i.d. genome (E. coli K12 length; the real FASTA is not
 available offline), -sdpTupleSize 11, band 16, default scores; one candidate window per read, built
-by the window rule of AlignIntervals.  With N>1 every rank processes its own shard of the same size
-(weak scaling, no data-path collective; one RCCL all-reduce of the run counters at the end).
+by the window rule of AlignIntervals.  With N>1 every rank processes its own shard of the same size (weak
+scaling, no data-path collective; one RCCL all-reduce of the run counters at the end).
+
+--contexts C maps the batch with C host threads at once, each through its own context (the C ABI's "one context
+per host thread", the reference's -nproc).  Kernels of two independent streams fill the tails and the
+latency-bound phases of each other's: 269 ms per pass with two threads against 300 ms with one.
+The default is ONE, so that every kernel has the GPU to itself and the roofline block means what it says; with
+two the same launches take 36-58 ms depending on what they happen to share the GPU with.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL4_TRAFFIC = {(100000, 10000, 16): 50121824448.0}
+PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55380430112.0}
 
 
 def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
@@ -73,6 +79,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--band", type=int, default=16)
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="host threads (each with its own context) that map the batch at the same time")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="candidates timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
     args = ap.parse_args()
@@ -91,70 +99,108 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    import threading
+
     import blasr_amd
     from blasr_amd import shard, synth
 
-    ctx = blasr_amd.Context(local_rank)
-    ctx.set_workspace_limit(160 << 30)
-    w = synth.make_sdp_workload(args.reads, args.read_len, args.seed + rank, dev)
-    n = int(w["q_len"].numel())
-    sdp_ptrs = {k: w[k].data_ptr() for k in ("seq", "q_off", "q_len", "t_off", "t_len")}
-    sdp_res = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
-    blk_cap = int(torch.minimum(w["q_len"], w["t_len"]).sum().item() // 4 + n)
-    blocks = torch.zeros(3 * blk_cap, dtype=torch.int32, device=dev)
-    ref_res = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
-    ops_cap = int((w["q_len"].sum().item() + w["t_len"].sum().item()) // 2 + 1024)
-    ops = torch.zeros(ops_cap, dtype=torch.int32, device=dev)
+    class Mapper:
+        """One host thread's share of the batch: its own context (own HIP streams and workspace), as the
+        reference's -nproc threads each own their MappingBuffers (Blasr.cpp:318-369, :4811-4842)."""
+
+        def __init__(self, reads, seed):
+            self.ctx = blasr_amd.Context(local_rank)
+            self.ctx.set_workspace_limit((160 << 30) // args.contexts)
+            self.w = w = synth.make_sdp_workload(reads, args.read_len, seed, dev)
+            self.n = n = int(w["q_len"].numel())
+            self.sdp_ptrs = {k: w[k].data_ptr() for k in ("seq", "q_off", "q_len", "t_off", "t_len")}
+            self.sdp_res = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+            self.blk_cap = int(torch.minimum(w["q_len"], w["t_len"]).sum().item() // 4 + n)
+            self.blocks = torch.zeros(3 * self.blk_cap, dtype=torch.int32, device=dev)
+            self.ref_res = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
+            self.ops_cap = int((w["q_len"].sum().item() + w["t_len"].sum().item()) // 2 + 1024)
+            self.ops = torch.zeros(self.ops_cap, dtype=torch.int32, device=dev)
+            self.glue = torch.cuda.Stream(device=dev)
+            self.acc = {}
+
+        def step(self):
+            n, w = self.n, self.w
+            # a-2..a-5 + a-9: SDPAlign and its statistics
+            self.ctx.sdp_device(self.sdp_ptrs, n, sdp_par, score, self.sdp_res.data_ptr(), self.blocks.data_ptr(),
+                                self.blk_cap)
+            t_sdp = self.ctx.sdp_last_timing()
+            with torch.cuda.stream(self.glue):
+                # RefineAlignment's trimming (Blasr.cpp:850-859): pure index arithmetic on the result records
+                r = self.sdp_res.view(torch.int32).view(n, 12)
+                q_pos, t_pos, n_blk = r[:, 2].to(torch.int64), r[:, 3].to(torch.int64), r[:, 4].contiguous()
+                blk_off = self.sdp_res.view(torch.int64).view(n, 6)[:, 5].contiguous()
+                last = (blk_off + n_blk - 1).clamp_min(0)
+                b3 = self.blocks.view(-1, 3)
+                has = n_blk > 0
+                q_len2 = torch.where(has, b3[last, 0] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
+                t_len2 = torch.where(has, b3[last, 1] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
+                q_off2 = (w["q_off"] + q_pos).contiguous()
+                t_off2 = (w["t_off"] + t_pos).contiguous()
+                ptrs = dict(seq=w["seq"].data_ptr(), q_off=q_off2.data_ptr(), q_len=q_len2.data_ptr(),
+                            t_off=t_off2.data_ptr(), t_len=t_len2.data_ptr(), blocks=self.blocks.data_ptr(),
+                            blk_off=blk_off.data_ptr(), n_blocks=n_blk.data_ptr())
+                self.glue.synchronize()  # the glue ran on a torch stream, the library uses its own
+            # a-6..a-9: guided banded affine DP, traceback, statistics
+            self.ctx.refine_device(ptrs, n, args.band, score, self.ref_res.data_ptr(), self.ops.data_ptr(),
+                                   self.ops_cap)
+            t_ref = self.ctx.last_timing()
+            f4 = self.ctx.last_fill4()
+            t_ref.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"],
+                         fill4_cells=f4["cells"])
+            for k, v in list(t_sdp.items()) + list(t_ref.items()):
+                self.acc[k] = self.acc.get(k, 0) + v
+
     score, sdp_par = blasr_amd.ScoreParams(), blasr_amd.SdpParams()
+    C = max(1, args.contexts)
+    share = [args.reads * (i + 1) // C - args.reads * i // C for i in range(C)]
+    mappers = [Mapper(share[i], args.seed + rank * C + i) for i in range(C)]
     torch.cuda.synchronize()
 
-    def step():
-        # a-2..a-5 + a-9: SDPAlign and its statistics
-        ctx.sdp_device(sdp_ptrs, n, sdp_par, score, sdp_res.data_ptr(), blocks.data_ptr(), blk_cap)
-        t_sdp = ctx.sdp_last_timing()
-        # RefineAlignment's trimming (Blasr.cpp:850-859): pure index arithmetic on the result records
-        r = sdp_res.view(torch.int32).view(n, 12)
-        q_pos, t_pos, n_blk = r[:, 2].to(torch.int64), r[:, 3].to(torch.int64), r[:, 4].contiguous()
-        blk_off = sdp_res.view(torch.int64).view(n, 6)[:, 5].contiguous()
-        last = (blk_off + n_blk - 1).clamp_min(0)
-        b3 = blocks.view(-1, 3)
-        has = n_blk > 0
-        q_len2 = torch.where(has, b3[last, 0] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
-        t_len2 = torch.where(has, b3[last, 1] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
-        q_off2 = (w["q_off"] + q_pos).contiguous()
-        t_off2 = (w["t_off"] + t_pos).contiguous()
-        ptrs = dict(seq=w["seq"].data_ptr(), q_off=q_off2.data_ptr(), q_len=q_len2.data_ptr(), t_off=t_off2.data_ptr(),
-                    t_len=t_len2.data_ptr(), blocks=blocks.data_ptr(), blk_off=blk_off.data_ptr(),
-                    n_blocks=n_blk.data_ptr())
-        torch.cuda.synchronize()  # the glue ran on torch's stream, the library uses its own
-        # a-6..a-9: guided banded affine DP, traceback, statistics
-        ctx.refine_device(ptrs, n, args.band, score, ref_res.data_ptr(), ops.data_ptr(), ops_cap)
-        t_ref = ctx.last_timing()
-        f4 = ctx.last_fill4()
-        t_ref.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"], fill4_cells=f4["cells"])
-        return t_sdp, t_ref
+    def run_steps(k):
+        # the batch is mapped by C host threads at once, each through its own context: kernels of independent
+        # streams fill the tails and the latency-bound phases of each other's
+        def body(m):
+            for _ in range(k):
+                m.step()
+        if C == 1:
+            body(mappers[0])
+            return
+        ths = [threading.Thread(target=body, args=(m,)) for m in mappers]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
+    for m in mappers:
+        m.acc = {}
     barrier()
     t0 = time.perf_counter()
-    acc = {}
-    for _ in range(args.steps):
-        t_sdp, t_ref = step()
-        for k, v in list(t_sdp.items()) + list(t_ref.items()):
-            acc[k] = acc.get(k, 0) + v
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    acc = {}
+    for m in mappers:
+        for k, v in m.acc.items():
+            acc[k] = acc.get(k, 0) + v
 
+    n = sum(m.n for m in mappers)
+    ref_res = torch.cat([m.ref_res for m in mappers])
+    q_len_all = torch.cat([m.w["q_len"] for m in mappers])
     rec = ref_res.view(torch.int32).view(n, 14)
     ok = rec[:, 0] == 0
     # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
-    totals = shard.reduce_counters(n, int(ok.sum()), int((w["q_len"].to(torch.int64) * ok).sum()),
+    totals = shard.reduce_counters(n, int(ok.sum()), int((q_len_all.to(torch.int64) * ok).sum()),
                                    int(rec[:, 4].to(torch.int64).sum()), device=dev)
     elapsed = shard.max_over_ranks(elapsed, device=dev)
 
@@ -185,8 +231,10 @@ def main():
             "config": {"workload": "configs[1]: 100k synthetic 10 kb reads vs E. coli-K12-length genome, "
                                    "-sdpTupleSize 11, band 16, SMRT matrix, ins=del=5, open=50, ext=0; SDP + refine",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "band": args.band,
+                       "host_threads_per_gpu": C,
                        "candidates": totals["reads"], "aligned_reads": totals["aligned_reads"]},
             "gcups_per_gpu": totals["dp_cells"] / world * K / elapsed / 1e9,
+            # HIP-event times of the stages summed over the contexts; with more than one they overlap in time
             "stage_ms_per_step": {
                 "sdp_keys_sort": acc["keys_ms"] / K, "sdp_match_order": acc["match_ms"] / K,
                 "sdp_chain": acc["chain_ms"] / K, "sdp_blocks_fills_assembly": acc["blocks_ms"] / K,
@@ -198,9 +246,9 @@ def main():
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
-                         "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band)),
+                         "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v13_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "profiles/r01_v14_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
                                          "of the fillp_kernel<16> launch",
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
                          "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
@@ -210,9 +258,10 @@ def main():
                          "fill_stage_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }
         if world == 1 and args.cpu_sample > 0:
-            ns = min(args.cpu_sample, n)
-            out["cpu_baseline"] = cpu_baseline(w, ns, args.band,
-                                               sdp_res.view(torch.int32).view(n, 12)[:ns].cpu().numpy(),
+            m0 = mappers[0]
+            ns = min(args.cpu_sample, m0.n)
+            out["cpu_baseline"] = cpu_baseline(m0.w, ns, args.band,
+                                               m0.sdp_res.view(torch.int32).view(m0.n, 12)[:ns].cpu().numpy(),
                                                rec[:ns].cpu().numpy())
         print(json.dumps(out))
     if dist is not None:
