@@ -75,3 +75,54 @@ def test_windows_sdp_filters_refine_against_oracle(oracle):
         assert g.status == 0, i
         assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
     ctx.close()
+
+
+def test_two_host_threads_with_their_own_contexts(oracle):
+    """The C ABI's threading rule (include/blasr_hip.h): one context per host thread, any number of threads at
+    once -- the reference's -nproc.  Two threads run SDP + refine on different pairs at the same time, several
+    rounds each; every result must be what the oracle says, i.e. nothing is shared between contexts."""
+    import threading
+
+    rng = np.random.default_rng(515)
+    sets = []
+    for t in range(2):
+        pairs = [synth.make_pair(rng, int(rng.integers(300, 5000)), flank=(0, int(rng.integers(0, 120))))
+                 for _ in range(24)]
+        sets.append(pairs)
+    out, errors = [None, None], []
+
+    def work(t):
+        try:
+            ctx = blasr_amd.Context(0)
+            for _ in range(3):
+                sdp = ctx.sdp(sets[t])
+                b = blasr_amd.RefineBatch()
+                keep = []
+                for (q, tt), s in zip(sets[t], sdp):
+                    if len(s["blocks"]) == 0:
+                        continue
+                    last = s["blocks"][-1]
+                    qs = q[s["qPos"]: s["qPos"] + last[0] + last[2]]
+                    ts = tt[s["tPos"]: s["tPos"] + last[1] + last[2]]
+                    b.add(qs, ts, s["blocks"])
+                    keep.append((qs, ts, s["blocks"]))
+                out[t] = (sdp, keep, ctx.refine(b))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for t in range(2):
+        sdp, keep, refined = out[t]
+        for i, ((q, tt), s) in enumerate(zip(sets[t], sdp)):
+            o = oracle.sdp_align(q, tt)
+            assert (s["status"], s["score"], s["qPos"], s["tPos"]) == (0, o["score"], o["qPos"], o["tPos"]), (t, i)
+            assert np.array_equal(s["blocks"], o["blocks"]), (t, i)
+        assert len(refined) == len(keep) > 0
+        for i, ((qs, ts, blocks), g) in enumerate(zip(keep, refined)):
+            w = oracle.affine_guided_align(qs, ts, blocks)
+            assert g.status == 0 and first_difference(g.as_dict(), w, REFINE_KEYS) is None, (t, i)
