@@ -2209,6 +2209,113 @@ __global__ __launch_bounds__(256) void sdp_blocks_build_kernel(SdpLevelArrays lv
   uint32_t *fb = reinterpret_cast<uint32_t *>(lv.cost + base);           // final blocks reuse cost/chainLen/predCl
   uint32_t *fbT = reinterpret_cast<uint32_t *>(lv.chainLen + base);
   uint32_t *fbL = reinterpret_cast<uint32_t *>(lv.predCl + base);
+  if (F <= 64) {
+    // ---- the usual invocation of the recursion levels: all of it with lane = fragment, nothing parked in HBM
+    // between the steps (the general path below makes five dependent round trips)
+    __shared__ int stage[4][3][64];
+    int(*sc)[64] = stage[threadIdx.x >> 6];
+    const int link = lane < F ? chainPrev[lane] : -1;
+    Frag f;
+    f.x = f.y = f.len = 0;
+    if (lane < F) f = fr[lane];
+    int revSrc = 0, nChain = 0;  // lane h: the fragment h hops before the chain's end
+    for (int cur = lv.chainEnd[idx]; cur >= 0 && nChain < F;) {
+      if (lane == nChain) revSrc = cur;
+      nChain++;
+      cur = __builtin_amdgcn_readlane(link, cur);
+    }
+    if (nChain == 0) return;
+    const bool on = lane < nChain;
+    const int src = __builtin_amdgcn_ds_bpermute((nChain - 1 - lane) << 2, revSrc);  // chain order: lane i = i-th
+    const int fx = __builtin_amdgcn_ds_bpermute(src << 2, (int)f.x), fy = __builtin_amdgcn_ds_bpermute(src << 2, (int)f.y);
+    const int fl = __builtin_amdgcn_ds_bpermute(src << 2, (int)f.len);
+    auto next_lane = [](int v) { return dpp<0x130, 0xf>(0, v); };  // wave_shl:1, lane i <- lane i+1
+    // runs of +1/+1 fragments become candidate blocks (:308-335)
+    const int px = wave_shr1(fx, 0), py = wave_shr1(fy, 0), nx = next_lane(fx), ny = next_lane(fy);
+    const bool start = on && (lane == 0 || !(px + 1 == fx && py + 1 == fy));
+    const bool last = on && (lane + 1 >= nChain || !(fx + 1 == nx && fy + 1 == ny));
+    const unsigned incl = wave_prefix_sum(start ? 1u : 0u);
+    const int ncb = __builtin_amdgcn_readlane((int)incl, 63);
+    if (start) {
+      sc[0][incl - 1] = fx;
+      sc[1][incl - 1] = fy;
+    }
+    if (last) sc[2][incl - 1] = fx + fl;  // block.length = x_last + len_last - x_first (:332)
+    __builtin_amdgcn_wave_barrier();
+    uint32_t q = 0, tt = 0, len = 0;
+    if (lane < ncb) {
+      q = (uint32_t)sc[0][lane];
+      tt = (uint32_t)sc[1][lane];
+      len = (uint32_t)sc[2][lane] - q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // trim overlaps (:349-357), drop zero-length and off-diagonal blocks (:372-413), compact
+    bool good = false;
+    {
+      const uint32_t nq = (uint32_t)next_lane((int)q), nt = (uint32_t)next_lane((int)tt);
+      const int pq = wave_shr1((int)q, 0), pt = wave_shr1((int)tt, 0);
+      if (lane < ncb) {
+        if (lane + 1 < ncb) {
+          if (q + len > nq) len = nq - q;
+          if (tt + len > nt) len = nt - tt;
+          if (lane > 0) {
+            const int prevDiag = abs(((int)tt - (int)q) - (pt - pq));
+            const int prevDist = (int)min(tt - (uint32_t)pt, q - (uint32_t)pq);
+            const int nextDiag = abs(((int)nt - (int)nq) - ((int)tt - (int)q));
+            const int nextDist = (int)min(nt - tt, nq - q);
+            good = !(prevDist * prm.indelRate < prevDiag && nextDist * prm.indelRate < nextDiag);
+          } else
+            good = true;
+        } else
+          good = true;
+        good = good && len != 0;
+      }
+    }
+    const unsigned incl2 = wave_prefix_sum(good ? 1u : 0u);
+    const int nfb = __builtin_amdgcn_readlane((int)incl2, 63);
+    if (nfb == 0) return;
+    if (good) {
+      const int w = (int)incl2 - 1;
+      fb[w] = q;
+      fbT[w] = tt;
+      fbL[w] = len;
+      sc[0][w] = (int)q;
+      sc[1][w] = (int)tt;
+      sc[2][w] = (int)len;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t bq = 0, bt = 0, bl = 0;
+    if (lane < nfb) {
+      bq = (uint32_t)sc[0][lane];
+      bt = (uint32_t)sc[1][lane];
+      bl = (uint32_t)sc[2][lane];
+    }
+    // count what this task will emit: blocks, SWAlign fills, recursive SDPAlign jobs (:423-536)
+    const uint32_t nru = (uint32_t)prm.noRecurseUnder;
+    int nSw = 0, nChild = 0;
+    const uint32_t q00 = (uint32_t)__builtin_amdgcn_readlane((int)bq, 0), t00 = (uint32_t)__builtin_amdgcn_readlane((int)bt, 0);
+    if (t.type == 1 && q00 > 0 && t00 > 0) {  // front fill (Global only; extendFront is false on this path)
+      if (t.recurse == 0 && q00 * t00 < nru) nSw++;
+      else if (t.recurse != 0) nChild++;
+    }
+    {
+      const uint32_t nq = (uint32_t)next_lane((int)bq), nt = (uint32_t)next_lane((int)bt);
+      int kind = 0;
+      if (lane + 1 < nfb) {
+        const uint32_t q0 = bq + bl, t0 = bt + bl;
+        const uint32_t fq = nq - q0, ft = nt - t0;
+        if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
+      }
+      nSw += __popcll(__ballot(kind == 1));
+      nChild += __popcll(__ballot(kind == 2));
+    }
+    if (lane == 0) {
+      counts[4 * idx] = nfb;
+      counts[4 * idx + 1] = nSw;
+      counts[4 * idx + 2] = nChild;
+    }
+    return;
+  }
   // ---- back-trace: a linked list, but chainPrev[i] < i and usually close to i, so the wavefront loads a
   // window of 64 links ending at the current fragment and hops inside it with v_readlane; a new HBM
   // round trip is needed only when a hop leaves the window ----
