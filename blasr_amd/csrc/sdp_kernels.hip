@@ -1787,14 +1787,16 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv) 
   if (take) lv.chainList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
 }
 
-__global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
+// The sweep of up to four invocations, one per 16-lane group: `on` says whether this lane's group has one, `idx`
+// which (uniform within the group).  Fragments, predCl and above are read from the level's arrays, unless the
+// caller holds the whole invocation (at most 16 fragments, lane = fragment) in registers: kPre.
+template <bool kPre>
+__device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpParams &prm, const bool on,
+                                            const int idx, const int preF = 0, const int preX = 0,
+                                            const int preY = 0, const int preLen = 0, const int prePred = -1,
+                                            const int preAbove = -1) {
   const int lane = lane_id(), l = lane & 15, gb = lane & 48;
-  const int nList = *lv.chainCount;
-  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
-  if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
-  const bool on = slot < nList;
-  const int idx = on ? lv.chainList[slot] : 0;
-  const int F = on ? lv.nFrag[idx] : 0;
+  const int F = on ? (kPre ? preF : lv.nFrag[idx]) : 0;
   const SdpTask t = lv.tasks[idx];
   const int64_t base = lv.fragOff[idx];
   // per-group arrays are addressed as (uniform array base) + base + index: one 64-bit offset per lane instead of
@@ -1821,7 +1823,15 @@ __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, S
     prvX = curX, prvY = curY, prvCost = curCost, prvLen = curLen;
     int flV = 0, fpV = -1, faV = -1;
     curX = curY = 0;
-    if (on && w0 + l < F) {
+    if (kPre) {
+      if (on && l < F) {
+        curX = preX;
+        curY = preY;
+        flV = preLen;
+        fpV = prePred;
+        faV = preAbove;
+      }
+    } else if (on && w0 + l < F) {
       const Frag f = C4_FR(w0 + l);
       curX = (int)f.x;
       curY = (int)f.y;
@@ -2069,6 +2079,123 @@ __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, S
 #undef C4_LEN
 }
 
+__global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int lane = lane_id();
+  const int nList = *lv.chainCount;
+  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
+  if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
+  const bool on = slot < nList;
+  chain4_body<false>(lv, prm, on, on ? lv.chainList[slot] : 0);
+}
+
+// sdp_small4_kernel: what sdp_small_kernel does, for invocations of at most kSmall4Max raw fragments (most of
+// the recursion levels' millions) and FOUR of them per wavefront, one per 16-lane group: ranks by all-pairs
+// comparison inside the group, duplicates dropped, StoreAbove and the sweep set's predecessor the same way; the
+// sweep itself is chain4_body's.
+constexpr int kSmall4Max = 16;
+__global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int lane = lane_id(), l = lane & 15, gb = lane & 48;
+  const int idx0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4;
+  if (idx0 >= lv.n) return;
+  const int idx = idx0 + (lane >> 4);
+  int nAll = 0;
+  if (idx < lv.n) nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
+  const bool mine = idx < lv.n && nAll <= kSmall4Max;
+  if (__ballot(mine) == 0ull) return;
+  const int64_t base = mine ? lv.fragOff[idx] : 0;
+  auto gbp = [&](int v, int i) { return __builtin_amdgcn_ds_bpermute((gb + (i & 15)) << 2, v); };
+  auto gmask = [&](bool flag) { return (unsigned)((__ballot(flag) >> gb) & 0xffffull); };
+  uint32_t x = 0xffffffffu, y = 0xffffffffu, len = 0;
+  const bool raw = mine && l < nAll;
+  if (raw) {
+    const Frag f = lv.raw[base + l];
+    x = f.x;
+    y = f.y;
+    len = f.len;
+  }
+  // ---- rank by (x,y), equal keys in input order
+  int rank = 0;
+  bool dup = false;
+#pragma unroll 4
+  for (int j = 0; j < 16; j++) {
+    const uint32_t xj = (uint32_t)gbp((int)x, j), yj = (uint32_t)gbp((int)y, j);
+    const bool eq = xj == x && yj == y;
+    const bool less = xj < x || (xj == x && yj < y);
+    rank += (less || (eq && j < l)) ? 1 : 0;
+    dup = dup || (eq && j < l);
+  }
+  dup = dup && raw;
+  const unsigned dupMask = gmask(dup);
+  const int F = mine ? nAll - (int)__popc(dupMask) : 0;  // (a group without an invocation must permute onto itself)
+  // ---- drop the later duplicates, place the survivors at their rank among the survivors
+  int dest = 16;  // lanes without a fragment and dropped duplicates park beyond the survivors
+  {
+    int droppedBefore = 0;
+    if (__ballot(dup) != 0ull) {
+      for (int j = 0; j < 16; j++) {
+        const uint32_t xj = (uint32_t)gbp((int)x, j), yj = (uint32_t)gbp((int)y, j);
+        const bool dj = ((dupMask >> j) & 1u) != 0u;
+        droppedBefore += (dj && (xj < x || (xj == x && (yj < y || (yj == y && j < l))))) ? 1 : 0;
+      }
+    }
+    if (raw && !dup) dest = rank - droppedBefore;
+  }
+  const unsigned liveMask = gmask(dest < 16);
+  if (dest >= 16) dest = F + (int)__popc(~liveMask & ((1u << l) - 1u) & 0xffffu);
+  const int fx = __builtin_amdgcn_ds_permute((gb + dest) * 4, (int)x), fy = __builtin_amdgcn_ds_permute((gb + dest) * 4, (int)y);
+  const int fl = __builtin_amdgcn_ds_permute((gb + dest) * 4, (int)len);
+  const bool on = mine && l < F;
+  if (on) {
+    Frag f;
+    f.x = (uint32_t)fx;
+    f.y = (uint32_t)fy;
+    f.len = (uint32_t)fl;
+    f.pad = 0;
+    lv.frags[base + l] = f;
+  }
+  if (mine && l == 0) {
+    lv.nFrag[idx] = F;
+    lv.fused[idx] = 1;
+  }
+  const int k = lv.tasks[mine ? idx : idx0].k;
+  // ---- StoreAbove (SparseDynamicProgramming.h:55-68): the neighbour in (y,x) order
+  int r2 = 0;
+#pragma unroll 4
+  for (int j = 0; j < 16; j++) {
+    const uint32_t xj = (uint32_t)gbp(fx, j), yj = (uint32_t)gbp(fy, j);
+    r2 += (j < F && (yj < (uint32_t)fy || (yj == (uint32_t)fy && xj < (uint32_t)fx))) ? 1 : 0;
+  }
+  if (!on) r2 = l;  // keep the permutation a bijection
+  const int byYx = __builtin_amdgcn_ds_permute((gb + r2) * 4, l);  // lane r: the fragment with (y,x) rank r
+  int above = -1;
+  {
+    const int a = gbp(byYx, max(r2 - 1, 0));
+    const uint32_t ax = (uint32_t)gbp(fx, a), ay = (uint32_t)gbp(fy, a), al = (uint32_t)gbp(fl, a);
+    if (on && r2 > 0 && ax <= (uint32_t)fx && ax + al > (uint32_t)fx && ay < (uint32_t)fy) above = a;
+  }
+  // ---- sweepSet.Predecessor: the largest (diag, x) with diag <= f.diag among x in [f.x-k-1, f.x-1]
+  int pred = -1;
+  {
+    const int fdiag = fy - fx;
+    const uint32_t xLow = (uint32_t)fx > (uint32_t)(k + 1) ? (uint32_t)fx - (uint32_t)(k + 1) : 0u;
+    int bestDiag = 0;
+    uint32_t bestX = 0;
+#pragma unroll 4
+    for (int j = 0; j < 16; j++) {
+      const uint32_t xj = (uint32_t)gbp(fx, j);
+      const int d = gbp(fy, j) - (int)xj;
+      if (j < l && xj >= xLow && xj < (uint32_t)fx && d <= fdiag &&
+          (pred < 0 || d > bestDiag || (d == bestDiag && xj > bestX))) {
+        pred = j;
+        bestDiag = d;
+        bestX = xj;
+      }
+    }
+    if (!on) pred = -1;
+  }
+  chain4_body<true>(lv, prm, mine, mine ? idx : 0, F, fx, fy, fl, pred, above);
+}
+
 __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
@@ -2085,11 +2212,12 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
 // replayed; it is left to the general kernels (lv.fused[idx] = 0).  With <= 16 elements std::sort is a plain
 // insertion sort, i.e. stable, so the first of the duplicates in prefix | middle | suffix order survives.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpParams prm) {
+__global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpParams prm, int minAll) {
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
   const int nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
+  if (nAll < minAll) return;  // sdp_small4_kernel's
   if (nAll > 64) {
     if (lane == 0) lv.fused[idx] = 0;
     return;
@@ -2951,7 +3079,10 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
   }
 }
 void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+  if (lv.n <= 0) return;
+  const bool small4 = getenv("BLASR_HIP_NO_SMALL4") == nullptr;
+  if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+  hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, small4 ? kSmall4Max + 1 : 0);
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;

@@ -178,12 +178,13 @@ def test_batch_of_mixed_sizes_against_oracle(ctx, oracle):
 
 def test_alternative_kernels_agree(ctx, oracle, monkeypatch):
     """The library picks its kernels by size class; the switches BLASR_HIP_NO_INDEX (long targets through the
-    sorted-key kernels instead of the LDS index) and BLASR_HIP_NO_CHAIN4 (the sweep with one invocation per
-    wavefront instead of four) force the general paths, which must give the same answers."""
+    sorted-key kernels instead of the LDS index), BLASR_HIP_NO_CHAIN4 (the sweep with one invocation per
+    wavefront instead of four) and BLASR_HIP_NO_SMALL4 (invocations of at most 16 fragments one per wavefront
+    instead of four) force the general paths, which must give the same answers."""
     rng = np.random.default_rng(206)
     pairs = [synth.make_pair(rng, n, flank=(0, 150)) for n in (1700, 2600, 5200)]
     want = [oracle.sdp_align(q, t) for q, t in pairs]
-    for env in ({}, {"BLASR_HIP_NO_INDEX": "1"}, {"BLASR_HIP_NO_CHAIN4": "1"}):
+    for env in ({}, {"BLASR_HIP_NO_INDEX": "1"}, {"BLASR_HIP_NO_CHAIN4": "1"}, {"BLASR_HIP_NO_SMALL4": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = ctx.sdp(pairs)
