@@ -2107,6 +2107,9 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
   auto gmask = [&](bool flag) { return (unsigned)((__ballot(flag) >> gb) & 0xffffull); };
   uint32_t x = 0xffffffffu, y = 0xffffffffu, len = 0;
   const bool raw = mine && l < nAll;
+  int maxN = mine ? nAll : 0;  // the loops below stop at the largest invocation of the wavefront
+  for (int off = 32; off >= 16; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+  maxN = __builtin_amdgcn_readfirstlane(maxN);
   if (raw) {
     const Frag f = lv.raw[base + l];
     x = f.x;
@@ -2116,8 +2119,7 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
   // ---- rank by (x,y), equal keys in input order
   int rank = 0;
   bool dup = false;
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
+  for (int j = 0; j < maxN; j++) {
     const uint32_t xj = (uint32_t)gbp((int)x, j), yj = (uint32_t)gbp((int)y, j);
     const bool eq = xj == x && yj == y;
     const bool less = xj < x || (xj == x && yj < y);
@@ -2132,7 +2134,7 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
   {
     int droppedBefore = 0;
     if (__ballot(dup) != 0ull) {
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < maxN; j++) {
         const uint32_t xj = (uint32_t)gbp((int)x, j), yj = (uint32_t)gbp((int)y, j);
         const bool dj = ((dupMask >> j) & 1u) != 0u;
         droppedBefore += (dj && (xj < x || (xj == x && (yj < y || (yj == y && j < l))))) ? 1 : 0;
@@ -2160,8 +2162,7 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
   const int k = lv.tasks[mine ? idx : idx0].k;
   // ---- StoreAbove (SparseDynamicProgramming.h:55-68): the neighbour in (y,x) order
   int r2 = 0;
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
+  for (int j = 0; j < maxN; j++) {
     const uint32_t xj = (uint32_t)gbp(fx, j), yj = (uint32_t)gbp(fy, j);
     r2 += (j < F && (yj < (uint32_t)fy || (yj == (uint32_t)fy && xj < (uint32_t)fx))) ? 1 : 0;
   }
@@ -2180,8 +2181,7 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
     const uint32_t xLow = (uint32_t)fx > (uint32_t)(k + 1) ? (uint32_t)fx - (uint32_t)(k + 1) : 0u;
     int bestDiag = 0;
     uint32_t bestX = 0;
-#pragma unroll 4
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < maxN; j++) {
       const uint32_t xj = (uint32_t)gbp(fx, j);
       const int d = gbp(fy, j) - (int)xj;
       if (j < l && xj >= xLow && xj < (uint32_t)fx && d <= fdiag &&
