@@ -867,10 +867,35 @@ __device__ __forceinline__ unsigned window_byte(const uint4 &w, int i) {  // 0 <
   return (d >> ((i & 3) * 8)) & 0xffu;
 }
 
-// Candidates per wavefront.  The walk is latency-bound (a dependent load per row), so the device wants many
-// resident wavefronts rather than full ones: with 64 candidates per wavefront configs[1] yields only 1.5
-// wavefronts per SIMD.
+// Candidates per wavefront.  The walk is a chain of dependent steps, so the device wants many resident wavefronts
+// rather than full ones: with 64 candidates per wavefront configs[1] yields only 1.5 wavefronts per SIMD.
 constexpr int kTbLanes = 32;
+
+// One step of the walk, without a branch: what the arrow at (row, column) makes of the state.
+//   index   state 0 (match matrix): the S arrow, 0..7;  state 1 (affine insertion): 8 + its "open" bit;
+//           state 2 (affine deletion): 10 + its "open" bit
+//   entry   bits 0-1 the op the step emits (3 = none), bit 2 column step, bit 3 the step leaves the row,
+//           bits 4-5 next state, bit 6 impossible arrow
+#define TB_E(op, dc, leave, st, bad) ((uint32_t)((op) | ((dc) << 2) | ((leave) << 3) | ((st) << 4) | ((bad) << 6)))
+__device__ __forceinline__ unsigned tb_entry(int idx) {
+  constexpr uint32_t kS03 = TB_E(OP_M, 1, 1, 0, 0) | TB_E(OP_D, 1, 0, 0, 0) << 8 |     // Diagonal, Left
+                            TB_E(OP_I, 0, 1, 0, 0) << 16 | TB_E(OP_I, 0, 1, 1, 0) << 24;  // Up, AffineInsClose
+  constexpr uint32_t kS47 = TB_E(OP_D, 1, 0, 2, 0) | TB_E(3, 0, 1, 0, 1) << 8 |        // AffineDelClose, -
+                            TB_E(3, 0, 1, 0, 1) << 16 | TB_E(3, 0, 1, 0, 1) << 24;
+  constexpr uint32_t kID = TB_E(OP_I, 0, 1, 1, 0) | TB_E(3, 0, 0, 0, 0) << 8 |         // I: up / open
+                           TB_E(OP_D, 1, 0, 2, 0) << 16 | TB_E(3, 0, 0, 0, 0) << 24;   // D: left / open
+  const uint32_t d = idx < 4 ? kS03 : (idx < 8 ? kS47 : kID);
+  return (d >> ((idx & 3) * 8)) & 0xffu;
+}
+#undef TB_E
+static_assert(AR_DIAG == 0 && AR_LEFT == 1 && AR_UP == 2 && AR_INS_CLOSE == 3 && AR_DEL_CLOSE == 4, "tb_entry order");
+
+// Where a candidate's op codes go: two bits per op in walk order, sixteen to a dword, dword k at codesEnd - 4 (k+1)
+// -- the tail of the candidate's own arrow slab.  The walk has consumed those arrows before the codes get there:
+// every op crosses at least one cell (one byte of arrows) and costs a quarter of a byte.
+__device__ __forceinline__ uint32_t *tb_codes_end(uint8_t *arrows, int64_t cells) {
+  return reinterpret_cast<uint32_t *>(arrows + ((cells + 16) & ~(int64_t)3));
+}
 
 __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, TraceArgs args) {
   const int idx = blockIdx.x * kTbLanes + threadIdx.x;
@@ -878,42 +903,27 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   const int task = args.first + (inRange ? idx : 0);
   const TaskGeometry geo = args.geo[task];
   bool alive = inRange && geo.status == 0;
-  if (inRange && geo.status != 0) {
-    RefineResult res;
-    res.status = geo.status;
-    res.q_pos = res.t_pos = res.dp_score = res.n_cells = res.score = 0;
-    res.n_match = res.n_mismatch = res.n_ins = res.n_del = res.n_ops = 0;
-    res.reserved = 0;
-    res.ops_off = 0;
-    args.results[task] = res;
-    args.opsStart[task] = 0;
-  }
   const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
   const int nBlocks = alive ? batch.n_blocks[task] : 1;
-  const int qStart = alive ? blocks[0] : 0, tStart = alive ? blocks[1] : 0;
+  const int tStart = alive ? blocks[1] : 0;
   const int Q = alive ? geo.rows : 0;
   const int tEnd = alive ? blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2] : 0;
-  const uint8_t *arrows = args.arrows + args.arrowOff[task];
+  uint8_t *arrows = const_cast<uint8_t *>(args.arrows) + args.arrowOff[task];
   const int2 *rowTab = args.rowTab + args.rowOff[task];
-  uint32_t *arena = args.arena + args.arenaOff[task];
-  const int cap = Q + (tEnd - tStart) + 2;
+  uint32_t *codes = tb_codes_end(arrows, alive ? geo.cells : 0);  // grows downwards
 
-  int w = cap;  // ops are written backwards: arena[w .. cap) is the forward op list
-  int curType = -1, curLen = 0;
-  bool seenM = false;
+  uint64_t acc = 0;  // ops not yet stored, oldest in the low bits
+  int fill = 0, nOps = 0;
   int c = tEnd - 1, state = 0;  // 0 = match matrix, 1 = affine ins, 2 = affine del
   int status = 0;
-  auto emit = [&](int type) {
-    if (type == curType) {
-      curLen++;
-      return;
+  auto flush16 = [&]() {  // lanes holding sixteen ops or more store a dword
+    if (__ballot(fill >= 16) != 0ull) {
+      if (fill >= 16) {
+        *--codes = (uint32_t)acc;
+        acc >>= 32;
+        fill -= 16;
+      }
     }
-    if (curLen > 0) {
-      if (curType == OP_M) seenM = true;
-      if (seenM) arena[--w] = ((uint32_t)curLen << 2) | (uint32_t)curType;  // gaps behind the last block are dropped
-    }
-    curType = type;
-    curLen = 1;
   };
 
   // RT[j] = record of the j-th row of the current batch (rows rTop, rTop-1, ...), RTn the same for the next one
@@ -935,96 +945,165 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int r = rTop - j;
-      if (alive && r >= 1) {
-        uint4 win = W[j];
-        int cb = CB[j];
-        const int2 row = RT[j];  // {matrix offset of the row, first column}
-        // all moves inside row r
-        int guard = (tEnd - tStart) + 8;
-        for (;;) {
+      bool inRow = alive && r >= 1;
+      uint4 win = W[j];
+      int cb = CB[j];
+      const int2 row = RT[j];  // {matrix offset of the row, first column}
+      int guard = (tEnd - tStart) + 8;
+      // all moves inside row r, every lane in step
+      while (__ballot(inRow) != 0ull) {
+        if (inRow) {
           if (c < cb || c >= cb + kTbWin) {  // the path left the prefetched window (long deletion): fetch on demand
             cb = max(c - (kTbWin - 1), row.y);
             win = load_window(arrows + (unsigned)row.x + (unsigned)(cb - row.y));
           }
           const unsigned a = window_byte(win, c - cb);
-          if (state == 0) {
-            const unsigned s = a & 7u;
-            if (s == AR_DIAG) {
-              emit(OP_M);
-              c--;
-              break;
-            } else if (s == AR_UP) {
-              emit(OP_I);
-              break;
-            } else if (s == AR_INS_CLOSE) {
-              emit(OP_I);
-              state = 1;
-              break;
-            } else if (s == AR_LEFT) {
-              emit(OP_D);
-              c--;
-            } else if (s == AR_DEL_CLOSE) {
-              emit(OP_D);
-              c--;
-              state = 2;
-            } else {
-              status = TASK_BAD_PATH;
-              alive = false;
-              break;
-            }
-          } else if (state == 1) {
-            if (a & AR_I_OPEN) {
-              state = 0;
-            } else {
-              emit(OP_I);
-              break;
-            }
-          } else {
-            if (a & AR_D_OPEN) {
-              state = 0;
-            } else {
-              emit(OP_D);
-              c--;
-            }
+          const int at = state == 0 ? (int)(a & 7u) : (state == 1 ? 8 + (int)((a >> 3) & 1u) : 10 + (int)((a >> 4) & 1u));
+          const unsigned e = tb_entry(at);
+          const unsigned op = e & 3u;
+          if (op != 3u) {
+            acc |= (uint64_t)op << (2 * fill);
+            fill++;
+            nOps++;
           }
-          if (--guard < 0) {
+          c -= (int)((e >> 2) & 1u);
+          state = (int)((e >> 4) & 3u);
+          const bool bad = (e >> 6) != 0u || --guard < 0;
+          if (bad) {
             status = TASK_BAD_PATH;
             alive = false;
-            break;
           }
+          inRow = !bad && ((e >> 3) & 1u) == 0u;
         }
-        if (r == 1 && alive) {
-          // row 0 (the deletion row, :178-208): Left arrows down to column tStart-1; the walk ends when
-          // q < qStart and t < tStart
-          while (c >= tStart) {
-            emit(OP_D);
-            c--;
-          }
-          alive = false;
-        }
+        if (__ballot(fill == 32) != 0ull) flush16();  // a long deletion run inside one row
       }
+      if (r == 1 && alive) {
+        // row 0 (the deletion row, :178-208): Left arrows down to column tStart-1; the walk ends when
+        // q < qStart and t < tStart
+        while (c >= tStart) {
+          acc |= (uint64_t)OP_D << (2 * fill);
+          fill++;
+          nOps++;
+          c--;
+          if (fill == 32) {
+            *--codes = (uint32_t)acc;
+            acc >>= 32;
+            fill -= 16;
+          }
+        }
+        alive = false;
+      }
+      flush16();
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) RT[j] = RTn[j];
   }
-  if (inRange && geo.status == 0) {
-    emit(-2);  // flush the last run
-    // RemoveAlignmentPrefixGaps (AlignmentUtils.h:620-644): leading gap runs fold into qPos / tPos
-    int leadI = 0, leadD = 0;
-    while (w < cap && (arena[w] & 3u) != OP_M) {
-      if ((arena[w] & 3u) == OP_I) leadI += (int)(arena[w] >> 2); else leadD += (int)(arena[w] >> 2);
-      w++;
+  if (inRange) {
+    if (geo.status == 0) {
+      while (fill > 0) {  // the last, partly filled dwords
+        *--codes = (uint32_t)acc;
+        acc >>= 32;
+        fill -= 16;
+      }
     }
-    RefineResult res;
-    res.status = status;
-    res.q_pos = qStart + (w < cap ? leadI : 0);
-    res.t_pos = tStart + (w < cap ? leadD : 0);
+    args.opsStart[task] = nOps;                                       // runs_kernel turns both into
+    args.results[task].status = geo.status != 0 ? geo.status : status;  // the candidate's record
+  }
+}
+
+// ---------------------------------------------------------------------------
+// runs_kernel: the op codes of the walk (alignment end first) become the run-length encoded op list, one
+// wavefront per candidate (ArrowPathToAlignment, Alignment.h:190-254): lane = sixteen ops, a run is written
+// when its end is seen, run k of the walk at arena[cap-1-k], so that the list reads forwards.  Gap runs behind
+// the last block are dropped (:251-253 clears the trailing gap list) and leading ones fold into qPos / tPos
+// (RemoveAlignmentPrefixGaps, AlignmentUtils.h:620-644).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void runs_kernel(RefineBatchView batch, TraceArgs args) {
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (idx >= args.count) return;
+  const int task = args.first + idx;
+  const TaskGeometry geo = args.geo[task];
+  const int status = args.results[task].status;
+  RefineResult res;
+  res.status = status;
+  res.q_pos = res.t_pos = res.dp_score = res.n_cells = res.score = 0;
+  res.n_match = res.n_mismatch = res.n_ins = res.n_del = res.n_ops = 0;
+  res.reserved = 0;
+  res.ops_off = 0;
+  if (geo.status != 0) {
+    if (lane == 0) {
+      args.results[task] = res;
+      args.opsStart[task] = 0;
+    }
+    return;
+  }
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const int nBlocks = batch.n_blocks[task];
+  const int qStart = blocks[0], tStart = blocks[1];
+  const int tEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+  const int cap = geo.rows + (tEnd - tStart) + 2;
+  uint32_t *arena = args.arena + args.arenaOff[task];
+  const uint32_t *codes = tb_codes_end(const_cast<uint8_t *>(args.arrows) + args.arrowOff[task], geo.cells);
+  const int n = args.opsStart[task];  // ops of the walk
+
+  int nRuns = 0, firstM = INT32_MAX;  // boundaries seen so far (= runs begun), first run that is a block
+  int lastStart = 0;                  // where the run in progress began
+  uint32_t carryWord = 0;             // the dword before this iteration's first
+  for (int d0 = 0; 16 * d0 < n; d0 += 64) {
+    const int d = d0 + lane;
+    const bool have = 16 * d < n;
+    const uint32_t word = have ? codes[-1 - d] : 0u;
+    const uint32_t before = (uint32_t)wave_shr1((int)word, (int)carryWord);
+    carryWord = (uint32_t)__builtin_amdgcn_readlane((int)word, 63);
+    // op i starts a run when it differs from op i-1 (op 0 always does)
+    const uint32_t shifted = (word << 2) | (before >> 30);
+    uint32_t diff = word ^ shifted;
+    diff = (diff | (diff >> 1)) & 0x55555555u;
+    if (d == 0) diff |= 1u;
+    const int valid = have ? min(16, n - 16 * d) : 0;
+    if (valid < 16) diff &= (1u << (2 * valid)) - 1u;
+    const int nb = __popc(diff);
+    const unsigned inclNb = wave_prefix_sum((unsigned)nb);
+    int lastB = nb ? 16 * d + ((31 - __clz(diff)) >> 1) : -1;
+    const int inclLast = wave_prefix_max(lastB);
+    int prevStart = max(wave_shr1(inclLast, -1), lastStart);  // start of the run in progress at this lane's first op
+    int k = nRuns + (int)(inclNb - (unsigned)nb);              // index of this lane's first boundary
+    for (uint32_t m = diff; m != 0u; m &= m - 1u) {
+      const int i = __builtin_ctz(m) >> 1, p = 16 * d + i;
+      if (k >= 1) {  // the run that ends here
+        const uint32_t ty = i > 0 ? (word >> (2 * (i - 1))) & 3u : before >> 30;
+        arena[cap - k] = ((uint32_t)(p - prevStart) << 2) | ty;
+        if (ty == OP_M) firstM = min(firstM, k - 1);
+      }
+      prevStart = p;
+      k++;
+    }
+    nRuns += __builtin_amdgcn_readlane((int)inclNb, 63);
+    lastStart = max(lastStart, __builtin_amdgcn_readlane(inclLast, 63));
+  }
+  if (n > 0 && lane == 0) {  // the last run of the walk
+    const uint32_t ty = (codes[-1 - ((n - 1) >> 4)] >> (2 * ((n - 1) & 15))) & 3u;
+    arena[cap - nRuns] = ((uint32_t)(n - lastStart) << 2) | ty;
+    if (ty == OP_M) firstM = min(firstM, nRuns - 1);
+  }
+  firstM = -wave_max(-firstM);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    int w = cap, end = cap, leadI = 0, leadD = 0;
+    if (firstM != INT32_MAX) {  // without a block nothing is kept
+      w = cap - nRuns;
+      end = cap - firstM;
+      while (w < end && (arena[w] & 3u) != OP_M) {
+        if ((arena[w] & 3u) == OP_I) leadI += (int)(arena[w] >> 2); else leadD += (int)(arena[w] >> 2);
+        w++;
+      }
+    }
+    res.q_pos = qStart + leadI;
+    res.t_pos = tStart + leadD;
     res.dp_score = args.dpScore[task];
     res.n_cells = (int32_t)geo.cells;
-    res.score = res.n_match = res.n_mismatch = res.n_ins = res.n_del = 0;  // stats_kernel
-    res.n_ops = cap - w;
-    res.reserved = 0;
-    res.ops_off = 0;
+    res.n_ops = end - w;
     args.results[task] = res;
     args.opsStart[task] = w;
   }
@@ -1176,6 +1255,7 @@ int fill4_max_width() { return kF4MaxWidth; }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
   if (args.count <= 0) return;
   hipLaunchKernelGGL(traceback_kernel, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
+  hipLaunchKernelGGL(runs_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
   hipLaunchKernelGGL(stats_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
 }
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,
