@@ -415,6 +415,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         else list1.push_back(i);
       }
       std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
+      std::stable_sort(list1.begin(), list1.end(), [&](int32_t a, int32_t b) { return geo[a].cells > geo[b].cells; });
       if (getenv("BLASR_HIP_GEO_HIST")) {
         int h[8] = {0};
         for (int i = c.first; i < c.first + c.count; i++) {
