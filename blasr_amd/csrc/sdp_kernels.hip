@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
   constexpr int kCoopMin = 96;
   __shared__ uint32_t packed[kCap];
   __shared__ uint2 queue[2][kQueue];  // {f | l << 16, depth limit}
-  __shared__ unsigned short posLists[kCoop ? 2 * kCap : 2];
+  __shared__ __attribute__((aligned(4))) unsigned short posLists[kCoop ? 2 * kCap : 2];
   constexpr int kPsCap = 512;
   __shared__ uint64_t psKeys[kPsCap];  // keys of the prefix and suffix lists
   const int lane = lane_id();
@@ -1229,14 +1229,20 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
         for (int i = lane; i < nAll; i += 64) {
           const bool inM = i >= nP && i < nP + nM;
           const uint64_t key = inM ? frag_key(P[i]) : psKeys[i < nP ? i : i - nM];
-          const int rank = lb(psKeys, nP, key) + lb(psKeys + nP, nS, key) + (inM ? i - nP : lower_bound_frag(M, nM, key));
-          packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
+          const int rp = lb(psKeys, nP, key), rs = lb(psKeys + nP, nS, key);
+          const int rm = inM ? i - nP : lower_bound_frag(M, nM, key);
+          // bit 15: the key occurs in more than one of the three lists, i.e. this element is part of a tie
+          const int lists = (rp < nP && psKeys[rp] == key) + (rs < nS && psKeys[nP + rs] == key) +
+                            (inM || (rm < nM && frag_key(M[rm]) == key));
+          packed[i] = ((uint32_t)(rp + rs + rm) << 16) | (lists >= 2 ? 0x8000u : 0u) | (uint32_t)i;
         }
       } else {
         for (int i = lane; i < nAll; i += 64) {
           const uint64_t key = frag_key(P[i]);
-          const int rank = lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key) + lower_bound_frag(S, nS, key);
-          packed[i] = ((uint32_t)rank << 16) | (uint32_t)i;
+          const int rp = lower_bound_frag(P, nP, key), rm = lower_bound_frag(M, nM, key), rs = lower_bound_frag(S, nS, key);
+          const int lists = (rp < nP && frag_key(P[rp]) == key) + (rm < nM && frag_key(M[rm]) == key) +
+                            (rs < nS && frag_key(S[rs]) == key);
+          packed[i] = ((uint32_t)(rp + rs + rm) << 16) | (lists >= 2 ? 0x8000u : 0u) | (uint32_t)i;
         }
       }
       __syncthreads();
@@ -1268,6 +1274,33 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
               const int bf[2] = {f, cut}, bl[2] = {cut, l};
               for (int c = 0; c < 2; c++) {
                 const int size = bl[c] - bf[c];
+                // A range without two elements of a tie has distinct keys: whatever introsort does with it, it
+                // ends up sorted.  With consecutive ranks (the rule) that is a scatter, no replay.
+                if (size >= kCoopMin) {
+                  int nTie = 0, rMin = INT32_MAX, rMax = -1;
+                  for (int i0 = bf[c]; i0 < bl[c]; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t w = i < bl[c] ? packed[i] : 0u;
+                    nTie += (int)__popcll(__ballot(i < bl[c] && (w & 0x8000u) != 0u));
+                    if (i < bl[c]) {
+                      rMin = min(rMin, (int)(w >> 16));
+                      rMax = max(rMax, (int)(w >> 16));
+                    }
+                  }
+                  rMax = wave_max(rMax);
+                  rMin = -wave_max(-rMin);
+                  if (nTie <= 1 && rMax - rMin + 1 == size) {
+                    uint32_t *tmp = reinterpret_cast<uint32_t *>(posLists);
+                    for (int i = bf[c] + lane; i < bl[c]; i += 64) tmp[i - bf[c]] = packed[i];
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < size; i += 64) {
+                      const uint32_t w = tmp[i];
+                      packed[bf[c] + (int)(w >> 16) - rMin] = w;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                  }
+                }
                 if (size > 16) {
                   if (lane == 0) queue[which ^ 1][nNext] = make_uint2((uint32_t)bf[c] | ((uint32_t)bl[c] << 16), d);
                   nNext++;
@@ -1314,7 +1347,7 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
           keep = i == 0 || (packed[i - 1] >> 16) != (w >> 16);
         }
         const uint64_t mask = __ballot(keep);
-        if (keep) out[kept + __popcll(mask & ((1ull << lane) - 1ull))] = P[w & 0xffffu];
+        if (keep) out[kept + __popcll(mask & ((1ull << lane) - 1ull))] = P[w & 0x7fffu];
         kept += __popcll(mask);
       }
       if (lane == 0) lv.nFrag[idx] = kept;
