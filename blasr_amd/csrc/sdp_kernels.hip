@@ -1196,7 +1196,7 @@ template <int kCap>
 __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, int minAll) {
   constexpr int kQueue = kCap / 16;
   constexpr bool kCoop = kCap <= 4096;  // long ranges are partitioned by the whole wavefront (LDS for the lists)
-  constexpr int kCoopMin = 96;
+  constexpr int kCoopMin = 32;
   __shared__ uint32_t packed[kCap];
   __shared__ uint2 queue[2][kQueue];  // {f | l << 16, depth limit}
   __shared__ __attribute__((aligned(4))) unsigned short posLists[kCoop ? 2 * kCap : 2];
