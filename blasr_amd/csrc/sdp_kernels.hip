@@ -1409,16 +1409,14 @@ __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv
     const Frag f = fr[i];
     const int fdiag = (int)(f.y - f.x);
     const uint32_t xLow = f.x > (uint32_t)(k + 1) ? f.x - (uint32_t)(k + 1) : 0u;
-    int lo = 0, hi = i;  // first index with x >= xLow
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (fr[mid].x < xLow) lo = mid + 1; else hi = mid;
-    }
+    // the candidates are the few fragments just before i (sorted by x): walk back until x < xLow.  (diag, x)
+    // pairs are unique, so the order in which they are looked at does not matter
     int best = -1, bestDiag = 0;
     uint32_t bestX = 0;
-    for (int j = lo; j < i; j++) {
+    for (int j = i - 1; j >= 0; j--) {
       const Frag p = fr[j];
-      if (p.x >= f.x) break;
+      if (p.x < xLow) break;
+      if (p.x >= f.x) continue;  // the same row
       const int d = (int)(p.y - p.x);
       if (d <= fdiag && (best < 0 || d > bestDiag || (d == bestDiag && p.x > bestX))) {
         best = j;
