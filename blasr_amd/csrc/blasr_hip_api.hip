@@ -38,11 +38,25 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// What this context's workspace may grow to: the caller's limit, and what the device can give it -- its own
+// allocation plus what is free, less a fixed reserve (so that the answer does not creep from call to call).
+int64_t workspace_reach(const blasr_hip_ctx *ctx) {
+  int64_t limit = ctx->workspaceLimit;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+    const int64_t reserve = std::max<int64_t>((int64_t)2 << 30, (int64_t)(totalB / 32));
+    limit = std::min<int64_t>(limit, std::max<int64_t>((int64_t)ctx->workspaceBytes + (int64_t)freeB - reserve, 1 << 20));
+  } else {
+    (void)hipGetLastError();
+  }
+  return limit;
+}
+
 int ensure_workspace(blasr_hip_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->workspaceBytes) return BLASR_HIP_OK;
-  if ((int64_t)bytes > ctx->workspaceLimit)
-    return fail(ctx, BLASR_HIP_ERR_NOMEM, "workspace of %zu bytes exceeds the limit of %lld", bytes,
-                (long long)ctx->workspaceLimit);
+  const int64_t reach = workspace_reach(ctx);
+  if ((int64_t)bytes > reach)
+    return fail(ctx, BLASR_HIP_ERR_NOMEM, "workspace of %zu bytes exceeds the limit of %lld", bytes, (long long)reach);
   if (ctx->workspace) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(ctx->workspace));
@@ -50,7 +64,7 @@ int ensure_workspace(blasr_hip_ctx *ctx, size_t bytes) {
     ctx->workspaceBytes = 0;
   }
   // grow with head-room so that steady-state batches do not reallocate
-  size_t want = std::min<size_t>((size_t)ctx->workspaceLimit, bytes + bytes / 8);
+  size_t want = std::min<size_t>((size_t)reach, bytes + bytes / 8);
   if (hipMalloc((void **)&ctx->workspace, want) != hipSuccess) {
     (void)hipGetLastError();
     want = bytes;
@@ -261,8 +275,10 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   plan.arrowOff.resize(n);
   plan.rowOff.resize(n);
   plan.arenaOff.resize(n);
-  const size_t budget = (size_t)ctx->workspaceLimit > fixedBytes + (1u << 20) ? (size_t)ctx->workspaceLimit - fixedBytes
-                                                                               : (1u << 20);
+  // the chunks must fit the caller's limit AND what the device can still give this context (the SDP stage's
+  // slabs, other contexts and the caller's own buffers share the HBM)
+  const int64_t limit = workspace_reach(ctx);
+  const size_t budget = (size_t)limit > fixedBytes + (1u << 20) ? (size_t)limit - fixedBytes : (1u << 20);
   {
     Plan::Chunk cur;
     cur.first = 0;
