@@ -432,16 +432,6 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       }
       std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
       std::stable_sort(list1.begin(), list1.end(), [&](int32_t a, int32_t b) { return geo[a].cells > geo[b].cells; });
-      if (getenv("BLASR_HIP_GEO_HIST")) {
-        int h[8] = {0};
-        for (int i = c.first; i < c.first + c.count; i++) {
-          if (geo[i].status != 0) continue;
-          const int w = geo[i].maxWidth;
-          h[w <= 40 ? 0 : w <= 47 ? 1 : w <= 56 ? 2 : w <= 64 ? 3 : w <= 80 ? 4 : w <= 96 ? 5 : w <= 128 ? 6 : 7]++;
-        }
-        fprintf(stderr, "maxWidth hist <=40:%d <=47:%d <=56:%d <=64:%d <=80:%d <=96:%d <=128:%d more:%d\n", h[0], h[1], h[2],
-                h[3], h[4], h[5], h[6], h[7]);
-      }
       if (!list4.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
       if (!list1.empty())
