@@ -19,6 +19,9 @@ from .hip import (  # noqa: F401
     remove_low_quality,
     remove_overlapping,
     sort_candidates,
+    cigar,
+    m4_line,
+    ref_contig_location,
     CANDIDATE_DTYPE,
     INTERVAL_DTYPE,
     READ_DTYPE,

@@ -30,6 +30,7 @@ EXPORTS = [
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
+    "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -231,6 +232,75 @@ def load_library():
         lib.blasr_hip_remove_overlapping.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_float]
         _lib = lib
     return _lib
+
+
+# --- next-2: first pieces of the output epilogue (host code, no device involved) --------------------
+CLIP_HARD, CLIP_SOFT, CLIP_SUBREAD, CLIP_NONE = 0, 1, 2, 3  # SAMOutput::Clipping (printers/SAMPrinter.h:26)
+
+
+class _CigarParams(C.Structure):
+    _fields_ = [("clipping", C.c_int32), ("t_strand", C.c_int32), ("read_length", C.c_uint32),
+                ("low_quality_prefix", C.c_uint32), ("low_quality_suffix", C.c_uint32), ("subread_start", C.c_uint32),
+                ("subread_end", C.c_uint32), ("q_align_start", C.c_uint32), ("q_align_end", C.c_uint32)]
+
+
+class _M4Fields(C.Structure):
+    _fields_ = [("q_name", C.c_char_p), ("t_name", C.c_char_p), ("score", C.c_int32), ("pct_similarity", C.c_float),
+                ("q_strand", C.c_int32), ("q_align_start", C.c_uint32), ("q_align_end", C.c_uint32),
+                ("q_length", C.c_uint32), ("t_strand", C.c_int32), ("t_align_start", C.c_uint32),
+                ("t_align_end", C.c_uint32), ("t_length", C.c_uint32), ("map_qv", C.c_int32)]
+
+
+def ref_contig_location(t_aligned_seq_pos, t_aligned_seq_length, t_strand, seq_start_pos, genome_length):
+    """AssignRefContigLocation (Blasr.cpp:2183-2220): (contig index, position of the window inside the contig)."""
+    lib = load_library()
+    sp = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
+    contig, pos = C.c_int32(0), C.c_uint32(0)
+    rc = lib.blasr_hip_ref_contig_location(C.c_uint32(t_aligned_seq_pos), C.c_uint32(t_aligned_seq_length), int(t_strand),
+                                           sp.ctypes.data_as(C.c_void_p), len(sp), C.c_uint32(genome_length),
+                                           C.byref(contig), C.byref(pos))
+    if rc < 0:
+        raise BlasrHipError(rc, "ref_contig_location")
+    return contig.value, pos.value
+
+
+def cigar(q_aligned_seq, t_aligned_seq, q_pos, t_pos, ops=None, blocks=None, clipping=CLIP_NONE, t_strand=0,
+          read_length=0, low_quality_prefix=0, low_quality_suffix=0, subread_start=0, subread_end=0, q_align_start=0,
+          q_align_end=0):
+    """CreateCIGARString (printers/SAMPrinter.h:346-416) from the refine stage's op list (packed words or
+    ops_to_alignment's input) or from blocks.  Returns (cigar string, (prefixSoft, suffixSoft, prefixHard, suffixHard))."""
+    lib = load_library()
+    q = np.ascontiguousarray(np.frombuffer(q_aligned_seq, dtype=np.uint8) if isinstance(q_aligned_seq, bytes) else q_aligned_seq, dtype=np.uint8)
+    t = np.ascontiguousarray(np.frombuffer(t_aligned_seq, dtype=np.uint8) if isinstance(t_aligned_seq, bytes) else t_aligned_seq, dtype=np.uint8)
+    o = None if ops is None else np.ascontiguousarray(ops, dtype=np.uint32)
+    b = None if blocks is None else np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1)
+    p = _CigarParams(clipping, t_strand, read_length, low_quality_prefix, low_quality_suffix, subread_start, subread_end,
+                     q_align_start, q_align_end)
+    cap = 16 * (len(q) + len(t) + 8)
+    out = C.create_string_buffer(cap)
+    n = C.c_int64(0)
+    clips = (C.c_uint32 * 4)()
+    rc = lib.blasr_hip_cigar(q.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), int(q_pos), int(t_pos),
+                             None if o is None else o.ctypes.data_as(C.c_void_p), C.c_int64(0 if o is None else len(o)),
+                             None if b is None else b.ctypes.data_as(C.c_void_p), C.c_int64(0 if b is None else len(b) // 3),
+                             C.byref(p), out, C.c_int64(cap), C.byref(n), clips)
+    if rc < 0:
+        raise BlasrHipError(rc, "cigar")
+    return out.value.decode(), tuple(int(v) for v in clips)
+
+
+def m4_line(q_name, t_name, score, pct_similarity, q_strand, q_align_start, q_align_end, q_length, t_strand,
+            t_align_start, t_align_end, t_length, map_qv):
+    """IntervalAlignmentPrinter::Print (printers/IntervalAlignmentPrinter.h:9-38): one -m 4 line."""
+    lib = load_library()
+    f = _M4Fields(q_name.encode(), t_name.encode(), score, pct_similarity, q_strand, q_align_start, q_align_end, q_length,
+                  t_strand, t_align_start, t_align_end, t_length, map_qv)
+    out = C.create_string_buffer(len(q_name) + len(t_name) + 256)
+    n = C.c_int64(0)
+    rc = lib.blasr_hip_m4_line(C.byref(f), out, C.c_int64(len(out)), C.byref(n))
+    if rc < 0:
+        raise BlasrHipError(rc, "m4_line")
+    return out.value.decode()
 
 
 # --- a-10: host-side ordering / pruning of a read's candidates (no device involved) ---------------

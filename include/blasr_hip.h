@@ -370,6 +370,52 @@ int blasr_hip_kband_linear_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch 
                                 const blasr_hip_kband_linear_params *params, blasr_hip_refine_result *results,
                                 uint32_t *ops, int64_t ops_capacity, int64_t *ops_used);
 
+/* ------------------------------------------------------------------------------------------------
+ * Output epilogue, first pieces: host functions, no GPU work.
+ * ------------------------------------------------------------------------------------------------ */
+/* AssignRefContigLocation (alignment/Blasr.cpp:2183-2220): the contig of an alignment whose target window starts
+ * at t_aligned_seq_pos of the concatenated genome (of its reverse complement when t_strand = 1), and the window's
+ * position inside that contig.  seq_start_pos: SequenceIndexDatabase::seqStartPos, n_seq_pos entries (contigs + 1;
+ * SearchForIndex, SequenceIndexDatabase.h:108-118). */
+int blasr_hip_ref_contig_location(uint32_t t_aligned_seq_pos, uint32_t t_aligned_seq_length, int32_t t_strand,
+                                  const uint32_t *seq_start_pos, int32_t n_seq_pos, uint32_t genome_length,
+                                  int32_t *contig, uint32_t *contig_pos);
+
+/* SAMPrinter::Clipping (printers/SAMPrinter.h:26) */
+enum { BLASR_HIP_CLIP_HARD = 0, BLASR_HIP_CLIP_SOFT = 1, BLASR_HIP_CLIP_SUBREAD = 2, BLASR_HIP_CLIP_NONE = 3 };
+typedef struct blasr_hip_cigar_params {
+  int32_t clipping;   /* BLASR_HIP_CLIP_* */
+  int32_t t_strand;   /* 1: the op list is reversed at the end (:408-411) */
+  uint32_t read_length, low_quality_prefix, low_quality_suffix, subread_start, subread_end; /* SMRTSequence fields */
+  uint32_t q_align_start, q_align_end; /* AlignmentCandidate::QAlignStart() / QAlignEnd() (AlignmentCandidate.h:150-156) */
+} blasr_hip_cigar_params;
+/* CreateCIGARString (printers/SAMPrinter.h:346-416) with CreateNoClippingCigarOps (:206-298), AddGaps (:122-136),
+ * AddUngappedOperations / AddUnmatchedOperations (:138-201), SetSoftClip / SetHardClip (:300-335).
+ * The alignment is given EITHER as the refine stage's op list (ops, n_ops: (length << 2) | M 0 / I 1 / D 2 -- an
+ * alignment with gap lists) OR as blocks (q, t, length triplets relative to q_pos / t_pos -- an alignment without
+ * gap lists, e.g. straight from SDPAlign); q_pos / t_pos = alignment.qPos / tPos inside the aligned sequences.
+ * Matches are split into = and X by comparing the raw characters.  clips (may be NULL) receives
+ * {prefixSoftClip, suffixSoftClip, prefixHardClip, suffixHardClip}; *cigar_len the length without the NUL. */
+int blasr_hip_cigar(const uint8_t *q_aligned_seq, const uint8_t *t_aligned_seq, int32_t q_pos, int32_t t_pos,
+                    const uint32_t *ops, int64_t n_ops, const int32_t *blocks, int64_t n_blocks,
+                    const blasr_hip_cigar_params *params, char *cigar, int64_t cigar_capacity, int64_t *cigar_len,
+                    uint32_t clips[4]);
+
+/* IntervalAlignmentPrinter::Print (printers/IntervalAlignmentPrinter.h:9-38): the 13 columns of -m 4.
+ * q_align_start / q_align_end = QAlignStart() / QAlignEnd(); t_align_start = TAlignStart(); t_align_end =
+ * tAlignedSeqPos + tPos + last block's tPos + length (:27-30). */
+typedef struct blasr_hip_m4_fields {
+  const char *q_name, *t_name;
+  int32_t score;
+  float pct_similarity;
+  int32_t q_strand;
+  uint32_t q_align_start, q_align_end, q_length;
+  int32_t t_strand;
+  uint32_t t_align_start, t_align_end, t_length;
+  int32_t map_qv;
+} blasr_hip_m4_fields;
+int blasr_hip_m4_line(const blasr_hip_m4_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
+
 #ifdef __cplusplus
 }
 #endif

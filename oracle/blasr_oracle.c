@@ -13,6 +13,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -2007,4 +2008,173 @@ int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int
   int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
   aln_free(&a);
   return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * next-2: first pieces of the output epilogue
+ * --------------------------------------------------------------------------------------------------------- */
+/* SequenceIndexDatabase::SearchForIndex (SequenceIndexDatabase.h:108-118): upper_bound over seqStartPos[1..] */
+static int search_for_index(const unsigned *seqStartPos, int nSeqPos, unsigned pos) {
+  int lo = 1, hi = nSeqPos;
+  if (nSeqPos == 1) return 0;
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    if (seqStartPos[mid] <= pos) lo = mid + 1; else hi = mid;
+  }
+  return lo - 1;
+}
+
+/* AssignRefContigLocation (Blasr.cpp:2183-2220); out2 = {contig index, tAlignedSeqPos inside the contig} */
+void bo_ref_contig_location(unsigned tAlignedSeqPos, unsigned tAlignedSeqLength, int tStrand, const unsigned *seqStartPos,
+                            int nSeqPos, unsigned genomeLength, unsigned *out2) {
+  if (tStrand == 0) {
+    int idx = search_for_index(seqStartPos, nSeqPos, tAlignedSeqPos);
+    out2[0] = (unsigned)idx;
+    out2[1] = tAlignedSeqPos - seqStartPos[idx];
+  } else {
+    /* MakeRCCoordinate(p) = length - p - 1 (DNASequence.h:215-217) */
+    unsigned forwardTPos = genomeLength - (tAlignedSeqPos + tAlignedSeqLength - 1) - 1;
+    int idx = search_for_index(seqStartPos, nSeqPos, forwardTPos);
+    unsigned reverseTOffset = genomeLength - (seqStartPos[idx + 1] - 2) - 1;
+    out2[0] = (unsigned)idx;
+    out2[1] = tAlignedSeqPos - reverseTOffset;
+  }
+}
+
+typedef struct {
+  int *size;
+  char *op;
+  long n, cap;
+} cigar_ops;
+static void cigar_push(cigar_ops *c, int size, char op) {
+  if (c->n == c->cap) {
+    c->cap = c->cap ? 2 * c->cap : 64;
+    c->size = (int *)realloc(c->size, sizeof(int) * (size_t)c->cap);
+    c->op = (char *)realloc(c->op, (size_t)c->cap);
+  }
+  c->size[c->n] = size;
+  c->op[c->n] = op;
+  c->n++;
+}
+/* AddUngappedOperations / AddUnmatchedOperations (SAMPrinter.h:138-201) */
+static void cigar_match_runs(cigar_ops *c, const unsigned char *q, const unsigned char *t, int len) {
+  int i = 0;
+  while (i < len) {
+    int start = i;
+    while (i < len && q[i] != t[i]) i++;
+    if (i > start) cigar_push(c, i - start, 'X');
+    start = i;
+    while (i < len && q[i] == t[i]) i++;
+    if (i > start) cigar_push(c, i - start, '=');
+  }
+}
+
+/* CreateCIGARString (SAMPrinter.h:346-416); returns the string's length, -1 if outCap is too small */
+int bo_cigar(const unsigned char *q, const unsigned char *t, int qPos, int tPos, const unsigned *ops, long nOps,
+             const int *blocks, long nBlocks, int clipping, int tStrand, unsigned readLength, unsigned lowQualityPrefix,
+             unsigned lowQualitySuffix, unsigned subreadStart, unsigned subreadEnd, unsigned qAlignStart,
+             unsigned qAlignEnd, char *out, int outCap, unsigned *clips4) {
+  unsigned prefixSoft = 0, suffixSoft = 0, prefixHard = 0, suffixHard = 0;
+  cigar_ops c = {NULL, NULL, 0, 0};
+  long i, b;
+  int at = 0, qp, tp;
+  if (clipping == 0) { /* hard: SetHardClip :320-335 */
+    prefixHard = qAlignStart;
+    suffixHard = readLength - qAlignEnd;
+    if (tStrand == 1) {
+      unsigned sw = prefixHard;
+      prefixHard = suffixHard;
+      suffixHard = sw;
+    }
+  }
+  if (clipping == 1 || clipping == 2) { /* soft, subread :366-382 */
+    if (clipping == 1) {
+      prefixHard = lowQualityPrefix;
+      suffixHard = lowQualitySuffix;
+    } else {
+      prefixHard = subreadStart > lowQualityPrefix ? subreadStart : lowQualityPrefix;
+      suffixHard = readLength - subreadEnd > lowQualitySuffix ? readLength - subreadEnd : lowQualitySuffix;
+    }
+    /* SetSoftClip :300-313 */
+    prefixSoft = qAlignStart + (ops ? 0u : (unsigned)blocks[0]) - prefixHard;
+    suffixSoft = readLength - suffixHard - qAlignEnd;
+  }
+  if (prefixHard > 0) cigar_push(&c, (int)prefixHard, 'H');
+  if (prefixSoft > 0) cigar_push(&c, (int)prefixSoft, 'S');
+  /* :388-389: qPos + blocks[0].qPos */
+  qp = qPos + (ops ? 0 : blocks[0]);
+  tp = tPos + (ops ? 0 : blocks[1]);
+  if (ops) { /* CreateNoClippingCigarOps with gap lists: AddGaps(0) is empty, then block, AddGaps(b+1) */
+    for (i = 0; i < nOps; i++) {
+      int len = (int)(ops[i] >> 2), ty = (int)(ops[i] & 3u);
+      if (ty == 0) {
+        cigar_match_runs(&c, q + qp, t + tp, len);
+        qp += len;
+        tp += len;
+      } else if (ty == 2) { /* Gap::Query -> D (:125-129) */
+        cigar_push(&c, len, 'D');
+        tp += len;
+      } else { /* Gap::Target -> I */
+        cigar_push(&c, len, 'I');
+        qp += len;
+      }
+    }
+  } else { /* nGaps == 0 (:228-287) */
+    for (b = 0; b < nBlocks; b++) {
+      int len = blocks[3 * b + 2], qGap = 0, tGap = 0, unmatched = 0;
+      if (b + 1 < nBlocks) {
+        qGap = blocks[3 * (b + 1)] - blocks[3 * b] - len;
+        tGap = blocks[3 * (b + 1) + 1] - blocks[3 * b + 1] - len;
+      }
+      cigar_match_runs(&c, q + qp, t + tp, len);
+      qp += len;
+      tp += len;
+      if (qGap > 0 && tGap > 0) {
+        int common = qGap < tGap ? qGap : tGap;
+        qGap -= common;
+        tGap -= common;
+        unmatched = common;
+      }
+      if (qGap > 0) {
+        cigar_push(&c, qGap, 'I');
+        qp += qGap;
+      }
+      if (tGap > 0) {
+        cigar_push(&c, tGap, 'D');
+        tp += tGap;
+      }
+      cigar_match_runs(&c, q + qp, t + tp, unmatched);
+      qp += unmatched;
+      tp += unmatched;
+    }
+  }
+  if (suffixSoft > 0) cigar_push(&c, (int)suffixSoft, 'S');
+  if (suffixHard > 0) cigar_push(&c, (int)suffixHard, 'H');
+  clips4[0] = prefixSoft;
+  clips4[1] = suffixSoft;
+  clips4[2] = prefixHard;
+  clips4[3] = suffixHard;
+  for (i = 0; i < c.n; i++) {
+    long k = tStrand == 1 ? c.n - 1 - i : i; /* :408-411 */
+    int w = snprintf(out + at, at < outCap ? (size_t)(outCap - at) : 0, "%d%c", c.size[k], c.op[k]);
+    at += w;
+    if (at >= outCap) {
+      at = -1;
+      break;
+    }
+  }
+  free(c.size);
+  free(c.op);
+  if (at == 0 && outCap > 0) out[0] = 0;
+  return at;
+}
+
+/* IntervalAlignmentPrinter::Print (:9-38); ostream << float = %g with six significant digits */
+int bo_m4_line(const char *qName, const char *tName, int score, float pctSimilarity, int qStrand, unsigned qAlignStart,
+               unsigned qAlignEnd, unsigned qLength, int tStrand, unsigned tAlignStart, unsigned tAlignEnd,
+               unsigned tLength, int mapQV, char *out, int outCap) {
+  int w = snprintf(out, (size_t)outCap, "%s %s %d %g %d %u %u %u %d %u %u %u %d\n", qName, tName, score,
+                   (double)pctSimilarity, qStrand, qAlignStart, qAlignEnd, qLength, tStrand, tAlignStart, tAlignEnd,
+                   tLength, mapQV);
+  return w < outCap ? w : -1;
 }

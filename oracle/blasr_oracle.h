@@ -113,6 +113,19 @@ int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int
                    int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
                    int *nGapItems);
 
+/* next-2 (first pieces of the output epilogue): AssignRefContigLocation (alignment/Blasr.cpp:2183-2220),
+ * CreateCIGARString (printers/SAMPrinter.h:122-416; clipping: hard 0, soft 1, subread 2, none 3),
+ * IntervalAlignmentPrinter::Print (printers/IntervalAlignmentPrinter.h:9-38). */
+void bo_ref_contig_location(unsigned tAlignedSeqPos, unsigned tAlignedSeqLength, int tStrand, const unsigned *seqStartPos,
+                            int nSeqPos, unsigned genomeLength, unsigned *out2);
+int bo_cigar(const unsigned char *q, const unsigned char *t, int qPos, int tPos, const unsigned *ops, long nOps,
+             const int *blocks, long nBlocks, int clipping, int tStrand, unsigned readLength, unsigned lowQualityPrefix,
+             unsigned lowQualitySuffix, unsigned subreadStart, unsigned subreadEnd, unsigned qAlignStart,
+             unsigned qAlignEnd, char *out, int outCap, unsigned *clips4);
+int bo_m4_line(const char *qName, const char *tName, int score, float pctSimilarity, int qStrand, unsigned qAlignStart,
+               unsigned qAlignEnd, unsigned qLength, int tStrand, unsigned tAlignStart, unsigned tAlignEnd,
+               unsigned tLength, int mapQV, char *out, int outCap);
+
 #ifdef __cplusplus
 }
 #endif

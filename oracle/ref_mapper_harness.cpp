@@ -163,3 +163,127 @@ int ref_post_filter(int op, int n, const int *score, const unsigned *tPos, const
 }
 
 }  // extern "C"
+
+// ---- output epilogue -------------------------------------------------------
+// An alignment for the printers from the refine stage's op list ((len << 2) | M 0 / I 1 / D 2) or from blocks.
+static void fill_alignment(T_AlignmentCandidate &a, const unsigned char *q, const unsigned char *t, int qPos, int tPos,
+                           const unsigned *ops, long nOps, const int *blocks, long nBlocks) {
+  a.qAlignedSeq.seq = (Nucleotide *)q;
+  a.tAlignedSeq.seq = (Nucleotide *)t;
+  a.qAlignedSeq.deleteOnExit = a.tAlignedSeq.deleteOnExit = false;
+  a.qPos = qPos;
+  a.tPos = tPos;
+  if (ops != NULL) {
+    int qq = 0, tt = 0;
+    a.gaps.push_back(GapList());
+    for (long i = 0; i < nOps; i++) {
+      const int len = (int)(ops[i] >> 2), ty = (int)(ops[i] & 3u);
+      if (ty == 0) {
+        Block b;
+        b.qPos = qq;
+        b.tPos = tt;
+        b.length = len;
+        a.blocks.push_back(b);
+        a.gaps.push_back(GapList());
+        qq += len;
+        tt += len;
+      } else if (ty == 2) {
+        a.gaps.back().push_back(Gap(Gap::Query, len));
+        tt += len;
+      } else {
+        a.gaps.back().push_back(Gap(Gap::Target, len));
+        qq += len;
+      }
+    }
+  } else {
+    for (long b = 0; b < nBlocks; b++) {
+      Block blk;
+      blk.qPos = blocks[3 * b];
+      blk.tPos = blocks[3 * b + 1];
+      blk.length = blocks[3 * b + 2];
+      a.blocks.push_back(blk);
+    }
+  }
+}
+
+extern "C" {
+
+// AssignRefContigLocation on an alignment with the given window; out = {contig, tAlignedSeqPos afterwards}
+int ref_contig_location(unsigned tAlignedSeqPos, unsigned tAlignedSeqLength, int tStrand, const unsigned *seqStartPos,
+                        int nSeqPos, unsigned genomeLength, unsigned *out) {
+  SequenceIndexDatabase<FASTQSequence> seqdb;
+  seqdb.seqStartPos = const_cast<DNALength *>(seqStartPos);
+  seqdb.nSeqPos = nSeqPos;
+  seqdb.deleteStructures = false;
+  DNASequence genome;
+  genome.length = genomeLength;
+  T_AlignmentCandidate a;
+  a.tAlignedSeqPos = tAlignedSeqPos;
+  a.tAlignedSeqLength = tAlignedSeqLength;
+  a.tStrand = tStrand;
+  out[0] = (unsigned)seqdb.SearchForIndex(tStrand == 0 ? tAlignedSeqPos
+                                                        : genome.MakeRCCoordinate(tAlignedSeqPos + tAlignedSeqLength - 1));
+  AssignRefContigLocation(a, seqdb, genome);
+  out[1] = a.tAlignedSeqPos;
+  seqdb.seqStartPos = NULL;
+  return 0;
+}
+
+// SAMOutput::CreateCIGARString; clips = {prefixSoft, suffixSoft, prefixHard, suffixHard}; returns the length
+int ref_cigar(const unsigned char *q, const unsigned char *t, int qPos, int tPos, const unsigned *ops, long nOps,
+              const int *blocks, long nBlocks, int clipping, int tStrand, unsigned readLength, unsigned lowQualityPrefix,
+              unsigned lowQualitySuffix, unsigned subreadStart, unsigned subreadEnd, unsigned qAlignStart, char *out,
+              int outCap, unsigned *clips) {
+  T_AlignmentCandidate a;
+  fill_alignment(a, q, t, qPos, tPos, ops, nOps, blocks, nBlocks);
+  a.tStrand = tStrand;
+  a.qAlignedSeqPos = qAlignStart - (unsigned)qPos;  // QAlignStart() = qPos + qAlignedSeqPos
+  SMRTSequence read;
+  read.length = readLength;
+  read.lowQualityPrefix = lowQualityPrefix;
+  read.lowQualitySuffix = lowQualitySuffix;
+  read.subreadStart = subreadStart;
+  read.subreadEnd = subreadEnd;
+  string cigar;
+  DNALength ps, ss, ph, sh;
+  SAMOutput::CreateCIGARString(a, read, cigar, (SAMOutput::Clipping)clipping, ps, ss, ph, sh);
+  clips[0] = ps;
+  clips[1] = ss;
+  clips[2] = ph;
+  clips[3] = sh;
+  clips[4] = a.QAlignEnd();
+  if ((int)cigar.size() + 1 > outCap) return -1;
+  memcpy(out, cigar.c_str(), cigar.size() + 1);
+  return (int)cigar.size();
+}
+
+// IntervalAlignmentPrinter::Print
+int ref_m4_line(const char *qName, const char *tName, int score, float pctSimilarity, int qStrand, unsigned qAlignedSeqPos,
+                unsigned qPos, unsigned qLength, int tStrand, unsigned tAlignedSeqPos, unsigned tPos, unsigned tLength,
+                int mapQV, const int *blocks, long nBlocks, char *out, int outCap, unsigned *derived) {
+  T_AlignmentCandidate a;
+  static unsigned char dummy[1] = {0};
+  fill_alignment(a, dummy, dummy, (int)qPos, (int)tPos, NULL, 0, blocks, nBlocks);
+  a.qName = qName;
+  a.tName = tName;
+  a.score = score;
+  a.pctSimilarity = pctSimilarity;
+  a.qStrand = qStrand;
+  a.tStrand = tStrand;
+  a.qAlignedSeqPos = qAlignedSeqPos;
+  a.tAlignedSeqPos = tAlignedSeqPos;
+  a.qLength = qLength;
+  a.tLength = tLength;
+  a.mapQV = mapQV;
+  stringstream strm;
+  IntervalAlignmentPrinter::Print(a, strm);
+  const string s = strm.str();
+  derived[0] = a.QAlignStart();
+  derived[1] = a.QAlignEnd();
+  derived[2] = a.TAlignStart();
+  if ((int)s.size() + 1 > outCap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+}  // extern "C"

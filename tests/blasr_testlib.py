@@ -420,3 +420,131 @@ def kband_align(checker, q, t, k, align_type=KBAND_GLOBAL, matrix=None, ins=5, d
     assert rc == 0
     return dict(score=int(out[0]), qPos=int(out[1]), tPos=int(out[2]), blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
                 gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
+
+
+# --- next-2: the epilogue pieces, oracle (plain C) and reference (ref_mapper_harness.cpp) --------------------
+class EpilogueChecker:
+    """bo_* of the oracle (kind="oracle") or ref_* of the reference harness (kind="ref"), same Python surface."""
+
+    def __init__(self, kind):
+        self.kind = kind
+        if kind == "oracle":
+            if not os.path.exists(ORACLE_SO):
+                build_oracle()
+            self.lib = C.CDLL(ORACLE_SO)
+        else:
+            self.lib = C.CDLL(REFMAPPER_SO)
+
+    def ref_contig_location(self, pos, length, strand, seq_start_pos, genome_length):
+        sp = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
+        out = np.zeros(2, dtype=np.uint32)
+        fn = self.lib.bo_ref_contig_location if self.kind == "oracle" else self.lib.ref_contig_location
+        fn(C.c_uint(pos), C.c_uint(length), int(strand), _pu(sp), len(sp), C.c_uint(genome_length), _pu(out))
+        return int(out[0]), int(out[1])
+
+    def cigar(self, q, t, q_pos, t_pos, ops=None, blocks=None, clipping=3, t_strand=0, read_length=0, lqp=0, lqs=0,
+              subread_start=0, subread_end=0, q_align_start=0, q_align_end=0):
+        q, t = _u8(q), _u8(t)
+        o = None if ops is None else np.ascontiguousarray(ops, dtype=np.uint32)
+        b = None if blocks is None else np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1)
+        cap = 16 * (len(q) + len(t) + 8)
+        out = C.create_string_buffer(cap)
+        clips = np.zeros(5, dtype=np.uint32)
+        args = [_p(q, C.c_ubyte), _p(t, C.c_ubyte), int(q_pos), int(t_pos), _pu(o), C.c_long(0 if o is None else len(o)),
+                None if b is None else _p(b), C.c_long(0 if b is None else len(b) // 3), int(clipping), int(t_strand),
+                C.c_uint(read_length), C.c_uint(lqp), C.c_uint(lqs), C.c_uint(subread_start), C.c_uint(subread_end),
+                C.c_uint(q_align_start)]
+        if self.kind == "oracle":
+            n = self.lib.bo_cigar(*args, C.c_uint(q_align_end), out, cap, _pu(clips))
+        else:
+            n = self.lib.ref_cigar(*args, out, cap, _pu(clips))
+            assert int(clips[4]) == q_align_end, (int(clips[4]), q_align_end)  # the harness derives QAlignEnd() itself
+        assert n >= 0
+        return out.value.decode(), tuple(int(v) for v in clips[:4])
+
+    def m4_line(self, q_name, t_name, score, pct, q_strand, q_aligned_seq_pos, q_pos, q_length, t_strand,
+                t_aligned_seq_pos, t_pos, t_length, map_qv, blocks):
+        """blocks: (n,3) relative to q_pos / t_pos.  Returns (line, (QAlignStart, QAlignEnd, TAlignStart, tEnd))."""
+        b = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+        q_start, t_start = q_pos + q_aligned_seq_pos, t_pos + t_aligned_seq_pos
+        q_end = int(b[-1, 0] + b[-1, 2]) + q_start
+        t_end = t_aligned_seq_pos + t_pos + int(b[-1, 1] + b[-1, 2])
+        out = C.create_string_buffer(len(q_name) + len(t_name) + 256)
+        if self.kind == "oracle":
+            n = self.lib.bo_m4_line(q_name.encode(), t_name.encode(), int(score), C.c_float(pct), int(q_strand),
+                                    C.c_uint(q_start), C.c_uint(q_end), C.c_uint(q_length), int(t_strand),
+                                    C.c_uint(t_start), C.c_uint(t_end), C.c_uint(t_length), int(map_qv), out, len(out))
+        else:
+            derived = np.zeros(3, dtype=np.uint32)
+            n = self.lib.ref_m4_line(q_name.encode(), t_name.encode(), int(score), C.c_float(pct), int(q_strand),
+                                     C.c_uint(q_aligned_seq_pos), C.c_uint(q_pos), C.c_uint(q_length), int(t_strand),
+                                     C.c_uint(t_aligned_seq_pos), C.c_uint(t_pos), C.c_uint(t_length), int(map_qv),
+                                     _p(b.reshape(-1)), C.c_long(len(b)), out, len(out), _pu(derived))
+            assert (int(derived[0]), int(derived[1]), int(derived[2])) == (q_start, q_end, t_start)
+        assert n >= 0
+        return out.value.decode(), (q_start, q_end, t_start, t_end)
+
+
+def random_epilogue_cases(rng, n):
+    """Alignments for the printers: op lists as the refine stage emits them (block first and last), sequences with
+    mixed case and N so that the = / X split is exercised, every clipping mode and both strands."""
+    cases = []
+    letters = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    for it in range(n):
+        n_runs = int(rng.integers(1, 12)) * 2 - 1
+        ops, qlen, tlen = [], 0, 0
+        for r in range(n_runs):
+            if r % 2 == 0:
+                ln = int(rng.integers(1, 40))
+                ops.append((ln << 2) | 0)
+                qlen += ln
+                tlen += ln
+            else:
+                for g in range(int(rng.integers(1, 4))):  # several gaps in one slot, alternating kinds
+                    ty = int(rng.integers(1, 3)) if g == 0 else 3 - (ops[-1] & 3)
+                    ln = int(rng.integers(1, 12))
+                    ops.append((ln << 2) | ty)
+                    if ty == 1:
+                        qlen += ln
+                    else:
+                        tlen += ln
+        q_pos, t_pos = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        t = letters[rng.integers(0, len(letters), t_pos + tlen + 5)].copy()
+        q = letters[rng.integers(0, len(letters), q_pos + qlen + 5)].copy()
+        # make most aligned columns agree
+        qi, ti = q_pos, t_pos
+        for w in ops:
+            ln, ty = w >> 2, w & 3
+            if ty == 0:
+                keep = rng.random(ln) < 0.85
+                q[qi:qi + ln] = np.where(keep, t[ti:ti + ln], q[qi:qi + ln])
+                qi += ln
+                ti += ln
+            elif ty == 1:
+                qi += ln
+            else:
+                ti += ln
+        q_aligned_seq_pos = int(rng.integers(0, 50))
+        q_align_start = q_pos + q_aligned_seq_pos
+        q_align_end = q_align_start + qlen
+        lqp, lqs = int(rng.integers(0, q_align_start + 1)), int(rng.integers(0, 20))
+        read_length = q_align_end + lqs + int(rng.integers(0, 40))
+        sub_start = int(rng.integers(0, q_align_start + 1))
+        sub_end = int(rng.integers(q_align_end, read_length + 1))
+        # blocks of the same alignment (for the no-gap-list form of the printer)
+        blocks, qq, tt = [], 0, 0
+        for w in ops:
+            ln, ty = w >> 2, w & 3
+            if ty == 0:
+                blocks.append((qq, tt, ln))
+                qq += ln
+                tt += ln
+            elif ty == 1:
+                qq += ln
+            else:
+                tt += ln
+        cases.append(dict(q=q, t=t, q_pos=q_pos, t_pos=t_pos, ops=np.array(ops, dtype=np.uint32),
+                          blocks=np.array(blocks, dtype=np.int32), clipping=it % 4, t_strand=(it // 4) % 2,
+                          read_length=read_length, lqp=lqp, lqs=lqs, subread_start=sub_start, subread_end=sub_end,
+                          q_align_start=q_align_start, q_align_end=q_align_end))
+    return cases

@@ -1,0 +1,116 @@
+"""First pieces of the output epilogue -- AssignRefContigLocation, CreateCIGARString,
+IntervalAlignmentPrinter::Print.  Host code on both sides, so no GPU is needed: the library's functions and the
+oracle's restatement against golden vectors made with the reference's own code
+(tests/golden/make_epilogue_golden.py), and against each other on fresh random cases."""
+import os
+
+import numpy as np
+import pytest
+
+import blasr_amd
+import blasr_testlib as T
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "epilogue_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return T.EpilogueChecker("oracle")
+
+
+def _s(a):
+    return bytes(a).decode()
+
+
+def test_ref_contig_location_golden(golden, orc):
+    for i in range(int(golden["contig_n"])):
+        pos, wl, strand, glen = (int(v) for v in golden["contig%d_in" % i])
+        starts = golden["contig%d_starts" % i]
+        want = tuple(int(v) for v in golden["contig%d_out" % i])
+        assert orc.ref_contig_location(pos, wl, strand, starts, glen) == want, i
+        assert blasr_amd.ref_contig_location(pos, wl, strand, starts, glen) == want, i
+
+
+def test_cigar_golden(golden, orc):
+    for i in range(int(golden["cigar_n"])):
+        q, t = golden["cigar%d_q" % i], golden["cigar%d_t" % i]
+        (q_pos, t_pos, clipping, t_strand, read_length, lqp, lqs, sub_start, sub_end, q_start,
+         q_end) = (int(v) for v in golden["cigar%d_par" % i])
+        clips = tuple(int(v) for v in golden["cigar%d_clips" % i])
+        for form, key, want_clips in (("ops", "cigar%d_from_ops" % i, clips[:4]), ("blocks", "cigar%d_from_blocks" % i, clips[4:])):
+            arg = {form: golden["cigar%d_%s" % (i, form)]}
+            want = _s(golden[key])
+            got = orc.cigar(q, t, q_pos, t_pos, clipping=clipping, t_strand=t_strand, read_length=read_length, lqp=lqp,
+                            lqs=lqs, subread_start=sub_start, subread_end=sub_end, q_align_start=q_start,
+                            q_align_end=q_end, **arg)
+            assert got == (want, want_clips), (i, form)
+            got = blasr_amd.cigar(q, t, q_pos, t_pos, clipping=clipping, t_strand=t_strand, read_length=read_length,
+                                  low_quality_prefix=lqp, low_quality_suffix=lqs, subread_start=sub_start,
+                                  subread_end=sub_end, q_align_start=q_start, q_align_end=q_end, **arg)
+            assert got == (want, want_clips), (i, form)
+
+
+def test_m4_line_golden(golden, orc):
+    for i in range(int(golden["m4_n"])):
+        q_name, t_name = _s(golden["m4_%d_names" % i]).split("\n")
+        score, q_strand, qasp, q_pos, q_length, t_strand, tasp, t_pos, t_length, map_qv = (int(v) for v in golden["m4_%d_num" % i])
+        pct = float(golden["m4_%d_pct" % i][0])
+        blocks = golden["m4_%d_blocks" % i]
+        want = _s(golden["m4_%d_line" % i])
+        q_start, q_end, t_start, t_end = (int(v) for v in golden["m4_%d_derived" % i])
+        line, derived = orc.m4_line(q_name, t_name, score, pct, q_strand, qasp, q_pos, q_length, t_strand, tasp, t_pos,
+                                    t_length, map_qv, blocks)
+        assert line == want and derived == (q_start, q_end, t_start, t_end), i
+        assert blasr_amd.m4_line(q_name, t_name, score, pct, q_strand, q_start, q_end, q_length, t_strand, t_start, t_end,
+                                 t_length, map_qv) == want, i
+        assert len(want.split()) == 13
+
+
+def test_cigar_library_against_oracle_on_random_cases(orc):
+    rng = np.random.default_rng(99)
+    for i, c in enumerate(T.random_epilogue_cases(rng, 300)):
+        kw = dict(clipping=c["clipping"], t_strand=c["t_strand"], read_length=c["read_length"],
+                  subread_start=c["subread_start"], subread_end=c["subread_end"], q_align_start=c["q_align_start"],
+                  q_align_end=c["q_align_end"])
+        for form in ("ops", "blocks"):
+            arg = {form: c[form]}
+            want = orc.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], lqp=c["lqp"], lqs=c["lqs"], **kw, **arg)
+            got = blasr_amd.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], low_quality_prefix=c["lqp"],
+                                  low_quality_suffix=c["lqs"], **kw, **arg)
+            assert got == want, (i, form)
+            # what a CIGAR must satisfy whatever the path: the query-consuming ops add up to the read
+            n_q = sum(int(n) for n, op in _ops(got[0]) if op in "=XISH")
+            assert n_q == c["read_length"] or c["clipping"] == blasr_amd.hip.CLIP_NONE, (i, form)
+
+
+def _ops(cigar):
+    out, num = [], ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((num, ch))
+            num = ""
+    return out
+
+
+def test_capacity_and_argument_errors():
+    q = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lib = blasr_amd.load_library()
+    import ctypes as C
+    ops = np.array([(4 << 2) | 0], dtype=np.uint32)
+    p = blasr_amd.hip._CigarParams(blasr_amd.hip.CLIP_NONE, 0, 4, 0, 0, 0, 4, 0, 4)
+    n = C.c_int64(0)
+    buf = C.create_string_buffer(2)
+    rc = lib.blasr_hip_cigar(q.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), 0, 0,
+                             ops.ctypes.data_as(C.c_void_p), C.c_int64(1), None, C.c_int64(0), C.byref(p), buf,
+                             C.c_int64(2), C.byref(n), None)
+    assert rc == blasr_amd.hip.ERR_CAPACITY and n.value == 2  # "4=" needs three bytes
+    rc = lib.blasr_hip_cigar(q.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), 0, 0, None, C.c_int64(0), None,
+                             C.c_int64(0), C.byref(p), buf, C.c_int64(2), C.byref(n), None)
+    assert rc == blasr_amd.hip.ERR_INVALID

@@ -1,6 +1,7 @@
 """Randomised sweep: oracle/blasr_oracle.c against the reference build
 (oracle/_ref/libblasr_ref.so).  Skipped where the reference build is absent."""
 import numpy as np
+import pytest
 
 from blasr_amd import synth
 from blasr_testlib import SMRT_MATRIX, ScoreParams, SdpParams
@@ -82,3 +83,37 @@ def test_introsort_clone_matches_std_sort_on_ties(oracle, ref):
                                dele=0.0, sub=0.0, flank=(0, 0))
         a, b = oracle.sdp_align(q, t), ref.sdp_align(q, t)
         assert first_difference(a, b, ["score", "qPos", "tPos", "blocks"]) is None, it
+
+
+def test_epilogue_pieces_against_the_reference_printers():
+    """next-2: the oracle's restatement of AssignRefContigLocation / CreateCIGARString / IntervalAlignmentPrinter
+    against the reference's own code on fresh random cases (the committed goldens cover a fixed set)."""
+    import os
+
+    import blasr_testlib as T
+    if not os.path.exists(T.REFMAPPER_SO):
+        pytest.skip("reference mapper harness not built (oracle/_ref)")
+    orc, rf = T.EpilogueChecker("oracle"), T.EpilogueChecker("ref")
+    rng = np.random.default_rng(424242)
+    for i, c in enumerate(T.random_epilogue_cases(rng, 400)):
+        kw = dict(clipping=c["clipping"], t_strand=c["t_strand"], read_length=c["read_length"], lqp=c["lqp"],
+                  lqs=c["lqs"], subread_start=c["subread_start"], subread_end=c["subread_end"],
+                  q_align_start=c["q_align_start"], q_align_end=c["q_align_end"])
+        assert orc.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], ops=c["ops"], **kw) == \
+            rf.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], ops=c["ops"], **kw), i
+        assert orc.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], blocks=c["blocks"], **kw) == \
+            rf.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], blocks=c["blocks"], **kw), i
+    for it in range(300):
+        ncontig = int(rng.integers(1, 7))
+        lens = rng.integers(100, 3000, ncontig)
+        starts = np.concatenate([[0], np.cumsum(lens + 1)]).astype(np.uint32)
+        glen, strand, ci = int(starts[-1]), int(rng.integers(0, 2)), int(rng.integers(0, ncontig))
+        wl = int(rng.integers(1, lens[ci]))
+        fstart = int(starts[ci]) + int(rng.integers(0, lens[ci] - wl + 1))
+        pos = fstart if strand == 0 else glen - (fstart + wl - 1) - 1
+        assert orc.ref_contig_location(pos, wl, strand, starts, glen) == rf.ref_contig_location(pos, wl, strand, starts, glen)
+        blocks = [(0, 0, int(rng.integers(1, 900)))]
+        args = ("m/%d" % it, "ref%d" % ci, int(rng.integers(-90000, 10)), float(np.float32(rng.random() * 100)), it % 2,
+                int(rng.integers(0, 500)), int(rng.integers(0, 50)), int(rng.integers(1000, 40000)), strand,
+                pos, int(rng.integers(0, 50)), glen, int(rng.integers(0, 255)))
+        assert orc.m4_line(*args, blocks) == rf.m4_line(*args, blocks), it
