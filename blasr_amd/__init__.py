@@ -21,6 +21,7 @@ from .hip import (  # noqa: F401
     sort_candidates,
     cigar,
     m4_line,
+    map_qvs,
     ref_contig_location,
     CANDIDATE_DTYPE,
     INTERVAL_DTYPE,

@@ -4,10 +4,13 @@
 //   blasr_hip_ref_contig_location   AssignRefContigLocation             alignment/Blasr.cpp:2183-2220
 //   blasr_hip_cigar                 CreateCIGARString and its helpers   printers/SAMPrinter.h:122-416
 //   blasr_hip_m4_line               IntervalAlignmentPrinter::Print     printers/IntervalAlignmentPrinter.h:9-38
+//   blasr_hip_map_qvs               StoreMapQVs and its helpers         alignment/Blasr.cpp:2647-2950
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -190,3 +193,174 @@ int blasr_hip_m4_line(const blasr_hip_m4_fields *f, char *line, int64_t line_cap
 }
 
 }  // extern "C"
+
+namespace {
+
+int three_bit(uint8_t c) {  // ThreeBit (NucConversion.h): A C G T in either case, everything else 4
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+
+// LogSumOfTwo (utils/LogUtils.h:11-41), float intermediates and all
+double log_sum_of_two(double value1, double value2) {
+  const double kLog10 = 2.3025850929;
+  double minValue = value1, maxValue = value2;
+  if (maxValue < minValue) {
+    minValue = value2;
+    maxValue = value1;
+  }
+  minValue *= kLog10;
+  maxValue *= kLog10;
+  const double difference = minValue - maxValue;
+  if (difference < -30) return maxValue / kLog10;
+  if (difference < -8) return (maxValue + exp(difference)) / kLog10;
+  const float expv = exp(difference);
+  const float log1pv = log1p(expv);
+  return (maxValue + log1pv) / kLog10;
+}
+
+struct QInterval {
+  int start, end;
+};
+// AlignmentCandidate::GetQInterval (AlignmentCandidate.h:162-174)
+QInterval q_interval(const blasr_hip_mapqv_alignment &a, bool forwardStrand) {
+  QInterval r;
+  r.start = (int)a.q_align_start;
+  r.end = (int)a.q_align_end;
+  if (forwardStrand && a.q_strand == 1) {
+    const int fs = (int)a.q_length - r.end, fe = (int)a.q_length - r.start;
+    r.start = fs;
+    r.end = fe;
+  }
+  return r;
+}
+
+// AlignmentsOverlap (Blasr.cpp:2679-2722)
+bool alignments_overlap(const blasr_hip_mapqv_alignment &a, const blasr_hip_mapqv_alignment &b, float minPercentOverlap) {
+  const QInterval A = q_interval(a, true), B = q_interval(b, true);
+  int ovp = 0;
+  if (A.start <= B.start && A.end >= B.end) return true;
+  if (B.start <= A.start && B.end >= A.end) return true;
+  if (A.end >= B.start && A.end <= B.end) ovp = A.end - B.start;
+  else if (A.start >= B.start && A.start <= B.end) ovp = B.end - A.start;
+  float ovpPercent;
+  if (A.end - A.start > 0 && B.end - B.start > 0)
+    ovpPercent = std::max(float(ovp) / float(A.end - A.start), float(ovp) / float(B.end - B.start));
+  else
+    ovpPercent = 0;
+  return ovpPercent > minPercentOverlap;
+}
+
+}  // namespace
+
+extern "C" int blasr_hip_map_qvs(const blasr_hip_mapqv_alignment *alns, int32_t n, const blasr_hip_mapqv_params *p,
+                                 const uint8_t *substitution_qv, int32_t *map_qv, float *prob_score_out) {
+  if (n < 0 || (n > 0 && (!alns || !map_qv)) || !p) return BLASR_HIP_ERR_INVALID;
+  const int kMaxPhred = 254, kWiggle = 5;  // MAX_PHRED_SCORE, MAPQV_END_ALIGN_WIGGLE (Blasr.cpp:79-80)
+  std::vector<float> probScore((size_t)n);
+  // ---- rescoring with the log-probability matrix (:2777-2785, ComputeAlignmentScore AlignmentUtils.h:127-170)
+  for (int a = 0; a < n; a++) {
+    const blasr_hip_mapqv_alignment &al = alns[a];
+    if (!al.q_aligned_seq || !al.t_aligned_seq || !al.ops || al.n_ops <= 0) return BLASR_HIP_ERR_INVALID;
+    int score = 0, q = al.q_pos, t = al.t_pos;
+    for (int64_t i = 0; i < al.n_ops; i++) {
+      const int len = (int)(al.ops[i] >> 2), ty = (int)(al.ops[i] & 3u);
+      if (ty == 0) {
+        for (int l = 0; l < len; l++) score += p->matrix[three_bit(al.t_aligned_seq[t + l]) * 5 + three_bit(al.q_aligned_seq[q + l])];
+        q += len;
+        t += len;
+      } else {
+        const int unit = ty == 1 ? p->ins : p->del;
+        if (p->affine_align && p->affine_open + len * p->affine_extend < len * unit) score += p->affine_open + len * p->affine_extend;
+        else score += len * unit;
+        if (ty == 1) q += len; else t += len;
+      }
+    }
+    probScore[a] = -score / 10.0;
+  }
+  // ---- PartitionOverlappingAlignments (:2726-2759)
+  std::vector<std::set<int> > partitions;
+  for (int i = 0; i < n; i++) {
+    bool found = false;
+    for (size_t pi = 0; pi < partitions.size() && !found; pi++)
+      for (std::set<int>::iterator it = partitions[pi].begin(); it != partitions[pi].end() && !found; ++it)
+        if (alignments_overlap(alns[i], alns[*it], p->min_fraction_overlapping) ||
+            (alns[i].q_align_start <= alns[*it].q_align_start && alns[i].q_align_end > alns[*it].q_align_end)) {
+          partitions[pi].insert(i);
+          found = true;
+        }
+    if (!found) {
+      partitions.push_back(std::set<int>());
+      partitions.back().insert(i);
+    }
+  }
+  // ---- the widest alignment of every partition (:2797-2826)
+  std::vector<int> begin(partitions.size(), -1), end(partitions.size(), -1), pscore(partitions.size(), 0);
+  for (size_t pi = 0; pi < partitions.size(); pi++) {
+    std::set<int>::iterator it = partitions[pi].begin();
+    QInterval iv = q_interval(alns[*it], false);
+    begin[pi] = iv.start;
+    end[pi] = iv.end;
+    pscore[pi] = alns[*it].n_match;
+    for (++it; it != partitions[pi].end(); ++it) {
+      iv = q_interval(alns[*it], false);
+      if (iv.end - iv.start > end[pi] - begin[pi] && alns[*it].n_match * 1.20 >= pscore[pi]) {
+        begin[pi] = iv.start;
+        end[pi] = iv.end;
+        pscore[pi] = alns[*it].n_match;
+      }
+    }
+  }
+  // ---- what an alignment would lose if it were extended to the partition's ends (:2851-2873, SumMismatches :2647-2671)
+  for (size_t pi = 0; pi < partitions.size(); pi++)
+    for (std::set<int>::iterator it = partitions[pi].begin(); it != partitions[pi].end(); ++it) {
+      const QInterval iv = q_interval(alns[*it], true);
+      int mismatchSum = 0;
+      if (iv.start - begin[pi] > kWiggle || end[pi] - iv.end > kWiggle) {
+        if (substitution_qv) {
+          for (int x = begin[pi]; x < iv.start; x++) mismatchSum += substitution_qv[x];
+          for (int x = iv.end; x < end[pi]; x++) mismatchSum += substitution_qv[x];
+        } else {
+          mismatchSum += 15 * ((iv.start - begin[pi]) + (end[pi] - iv.end));
+        }
+      }
+      probScore[*it] += -(mismatchSum) * 0.5;
+    }
+  // ---- mapQV from the scores of a partition (:2878-2944)
+  for (size_t pi = 0; pi < partitions.size(); pi++) {
+    std::set<int>::iterator it = partitions[pi].begin();
+    float denominator = probScore[*it];
+    int maxNMatch = alns[*it].n_match;
+    for (++it; it != partitions[pi].end(); ++it) {
+      if (alns[*it].n_match > maxNMatch) maxNMatch = alns[*it].n_match;
+      if (alns[*it].n_match * 1.2 >= maxNMatch) denominator = log_sum_of_two(denominator, probScore[*it]);
+    }
+    for (it = partitions[pi].begin(); it != partitions[pi].end(); ++it) {
+      if (partitions[pi].size() == 1) {
+        map_qv[*it] = kMaxPhred;
+      } else if (probScore[*it] - denominator < -20) {
+        map_qv[*it] = 0;
+      } else {
+        const double log10v = log(10);
+        const double sub = probScore[*it] - denominator;
+        const double expo = exp(log10v * sub);
+        const double diff = 1.0 - expo;
+        int phred;
+        if (expo == 0) phred = 0;
+        else if (diff == 0) phred = kMaxPhred;
+        else phred = -10 * log10(diff);  // Phred (utils/PhredUtils.h:10-13), truncated
+        if (phred > kMaxPhred) phred = kMaxPhred;
+        if (phred < 0) phred = 0;
+        map_qv[*it] = phred;
+      }
+    }
+  }
+  if (prob_score_out)
+    for (int a = 0; a < n; a++) prob_score_out[a] = probScore[a];
+  return BLASR_HIP_OK;
+}

@@ -30,7 +30,7 @@ EXPORTS = [
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
-    "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line",
+    "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -301,6 +301,48 @@ def m4_line(q_name, t_name, score, pct_similarity, q_strand, q_align_start, q_al
     if rc < 0:
         raise BlasrHipError(rc, "m4_line")
     return out.value.decode()
+
+
+class _MapQvAlignment(C.Structure):
+    _fields_ = [("q_aligned_seq", C.c_void_p), ("t_aligned_seq", C.c_void_p), ("ops", C.c_void_p), ("n_ops", C.c_int64),
+                ("q_pos", C.c_int32), ("t_pos", C.c_int32), ("q_align_start", C.c_uint32), ("q_align_end", C.c_uint32),
+                ("q_strand", C.c_int32), ("q_length", C.c_uint32), ("n_match", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _MapQvParams(C.Structure):
+    _fields_ = [("matrix", C.c_int32 * 25), ("ins", C.c_int32), ("del_", C.c_int32), ("affine_open", C.c_int32),
+                ("affine_extend", C.c_int32), ("affine_align", C.c_int32), ("min_fraction_overlapping", C.c_float)]
+
+
+SMRT_LOG_PROB_MATRIX = [0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0]
+
+
+def map_qvs(alignments, substitution_qv=None, matrix=None, ins=5, dele=5, affine_open=50, affine_extend=0, affine_align=True,
+            min_fraction_overlapping=0.75):
+    """StoreMapQVs (Blasr.cpp:2761-2950) for the alignments of one read: a list of dicts with q, t (aligned
+    sequences), ops, q_pos, t_pos, q_align_start, q_align_end, q_strand, q_length, n_match.
+    Returns (mapQV list, probScore list)."""
+    lib = load_library()
+    n = len(alignments)
+    arr = (_MapQvAlignment * max(n, 1))()
+    keep = []
+    for i, a in enumerate(alignments):
+        q = np.ascontiguousarray(a["q"], dtype=np.uint8)
+        t = np.ascontiguousarray(a["t"], dtype=np.uint8)
+        o = np.ascontiguousarray(a["ops"], dtype=np.uint32)
+        keep.append((q, t, o))
+        arr[i] = _MapQvAlignment(q.ctypes.data, t.ctypes.data, o.ctypes.data, len(o), a["q_pos"], a["t_pos"],
+                                 a["q_align_start"], a["q_align_end"], a["q_strand"], a["q_length"], a["n_match"], 0)
+    p = _MapQvParams((C.c_int32 * 25)(*(SMRT_LOG_PROB_MATRIX if matrix is None else [int(v) for v in np.asarray(matrix).reshape(-1)])),
+                     ins, dele, affine_open, affine_extend, 1 if affine_align else 0, min_fraction_overlapping)
+    qv = None if substitution_qv is None else np.ascontiguousarray(substitution_qv, dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    prob = np.zeros(max(n, 1), dtype=np.float32)
+    rc = lib.blasr_hip_map_qvs(arr, n, C.byref(p), None if qv is None else qv.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), prob.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise BlasrHipError(rc, "map_qvs")
+    return [int(v) for v in out[:n]], [float(v) for v in prob[:n]]
 
 
 # --- a-10: host-side ordering / pruning of a read's candidates (no device involved) ---------------

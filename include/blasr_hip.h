@@ -416,6 +416,32 @@ typedef struct blasr_hip_m4_fields {
 } blasr_hip_m4_fields;
 int blasr_hip_m4_line(const blasr_hip_m4_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
 
+/* StoreMapQVs (alignment/Blasr.cpp:2761-2950) with ComputeAlignmentScore on gap lists (AlignmentUtils.h:127-170),
+ * PartitionOverlappingAlignments / AlignmentsOverlap (:2679-2759), SumMismatches (:2647-2671), LogSumOfTwo
+ * (utils/LogUtils.h:11-41), Phred (utils/PhredUtils.h:10-13): the mapping quality of every alignment of one read,
+ * from the alignments that overlap it on the read.  Alignments in the order of alignmentPtrs. */
+typedef struct blasr_hip_mapqv_alignment {
+  const uint8_t *q_aligned_seq, *t_aligned_seq; /* alignment.qAlignedSeq / tAlignedSeq */
+  const uint32_t *ops;                          /* the refine stage's op list = blocks + gap lists */
+  int64_t n_ops;
+  int32_t q_pos, t_pos;                         /* alignment.qPos / tPos */
+  uint32_t q_align_start, q_align_end;          /* QAlignStart() / QAlignEnd() */
+  int32_t q_strand;
+  uint32_t q_length;
+  int32_t n_match;
+  int32_t reserved;
+} blasr_hip_mapqv_alignment;
+typedef struct blasr_hip_mapqv_params {
+  int32_t matrix[25];              /* SMRTLogProbMatrix (ScoreMatrices.h:28-34), [target][query] as Match() indexes it */
+  int32_t ins, del, affine_open, affine_extend; /* MappingParameters::InitializeScoreFunction (:587-592) */
+  int32_t affine_align;            /* params.affineAlign */
+  float min_fraction_overlapping;  /* params.minFractionToBeConsideredOverlapping (0.75) */
+} blasr_hip_mapqv_params;
+/* substitution_qv: read.substitutionQV (one byte per read base) or NULL; prob_score (may be NULL) receives the
+ * alignments' probScore after the adjustment of :2851-2873. */
+int blasr_hip_map_qvs(const blasr_hip_mapqv_alignment *alignments, int32_t n, const blasr_hip_mapqv_params *params,
+                      const uint8_t *substitution_qv, int32_t *map_qv, float *prob_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2178,3 +2178,164 @@ int bo_m4_line(const char *qName, const char *tName, int score, float pctSimilar
                    tLength, mapQV);
   return w < outCap ? w : -1;
 }
+
+/* ---- StoreMapQVs ------------------------------------------------------------------------------------------- */
+/* LogSumOfTwo (utils/LogUtils.h:11-41); LOG10 there is the literal 2.3025850929 */
+static double mq_log_sum_of_two(double value1, double value2) {
+  double minValue = value1, maxValue = value2, difference;
+  if (maxValue < minValue) {
+    minValue = value2;
+    maxValue = value1;
+  }
+  minValue *= 2.3025850929;
+  maxValue *= 2.3025850929;
+  difference = minValue - maxValue;
+  if (difference < -30) return maxValue / 2.3025850929;
+  if (difference < -8) return (maxValue + exp(difference)) / 2.3025850929;
+  {
+    float expv = exp(difference);
+    float log1pv = log1p(expv);
+    return (maxValue + log1pv) / 2.3025850929;
+  }
+}
+/* AlignmentCandidate::GetQInterval (AlignmentCandidate.h:162-174) */
+static void mq_interval(unsigned start, unsigned end, int qStrand, unsigned qLength, int forward, int *s, int *e) {
+  *s = (int)start;
+  *e = (int)end;
+  if (forward && qStrand == 1) {
+    int fs = (int)qLength - *e, fe = (int)qLength - *s;
+    *s = fs;
+    *e = fe;
+  }
+}
+/* AlignmentsOverlap (Blasr.cpp:2679-2722) on forward-strand intervals */
+static int mq_overlap(int aS, int aE, int bS, int bE, float minPercentOverlap) {
+  int ovp = 0;
+  float pct;
+  if (aS <= bS && aE >= bE) return 1;
+  if (bS <= aS && bE >= aE) return 1;
+  if (aE >= bS && aE <= bE) ovp = aE - bS;
+  else if (aS >= bS && aS <= bE) ovp = bE - aS;
+  if (aE - aS > 0 && bE - bS > 0) {
+    float x = (float)ovp / (float)(aE - aS), y = (float)ovp / (float)(bE - bS);
+    pct = x > y ? x : y;
+  } else {
+    pct = 0;
+  }
+  return pct > minPercentOverlap;
+}
+
+void bo_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned char *const *tSeqs, const int *qPos,
+                      const int *tPos, const unsigned *ops, const long *opOff, const unsigned *qAlignStart,
+                      const unsigned *qAlignEnd, const int *qStrand, const unsigned *qLength, const int *nMatch,
+                      const unsigned char *qvs, const int *matrix25, int ins, int del, int affineOpen, int affineExtend,
+                      int affineAlign, float minFraction, int *mapQV, float *probScore) {
+  /* partitions as arrays: part[i] = partition of alignment i; members are visited in increasing index, which is
+   * the iteration order of the reference's set<int> */
+  int *part = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int nPart = 0, a, p, i;
+  int *pBegin, *pEnd, *pScore;
+  for (a = 0; a < n; a++) { /* :2777-2785 with ComputeAlignmentScore (AlignmentUtils.h:127-170) */
+    int score = 0, q = qPos[a], t = tPos[a];
+    long k;
+    for (k = opOff[a]; k < opOff[a + 1]; k++) {
+      int len = (int)(ops[k] >> 2), ty = (int)(ops[k] & 3u), l;
+      if (ty == 0) {
+        for (l = 0; l < len; l++) score += matrix25[three_bit(tSeqs[a][t + l]) * 5 + three_bit(qSeqs[a][q + l])];
+        q += len;
+        t += len;
+      } else {
+        int unit = ty == 1 ? ins : del;
+        if (affineAlign && affineOpen + len * affineExtend < len * unit) score += affineOpen + len * affineExtend;
+        else score += len * unit;
+        if (ty == 1) q += len; else t += len;
+      }
+    }
+    probScore[a] = -score / 10.0;
+  }
+  for (i = 0; i < n; i++) { /* PartitionOverlappingAlignments :2726-2759 */
+    int found = -1, iS, iE;
+    mq_interval(qAlignStart[i], qAlignEnd[i], qStrand[i], qLength[i], 1, &iS, &iE);
+    for (p = 0; p < nPart && found < 0; p++) {
+      int j;
+      for (j = 0; j < i && found < 0; j++) {
+        int jS, jE;
+        if (part[j] != p) continue;
+        mq_interval(qAlignStart[j], qAlignEnd[j], qStrand[j], qLength[j], 1, &jS, &jE);
+        if (mq_overlap(iS, iE, jS, jE, minFraction) ||
+            (qAlignStart[i] <= qAlignStart[j] && qAlignEnd[i] > qAlignEnd[j]))
+          found = p;
+      }
+    }
+    part[i] = found >= 0 ? found : nPart++;
+  }
+  pBegin = (int *)malloc(sizeof(int) * (size_t)(nPart > 0 ? nPart : 1));
+  pEnd = (int *)malloc(sizeof(int) * (size_t)(nPart > 0 ? nPart : 1));
+  pScore = (int *)malloc(sizeof(int) * (size_t)(nPart > 0 ? nPart : 1));
+  for (p = 0; p < nPart; p++) { /* :2797-2826 */
+    int first = 1;
+    for (i = 0; i < n; i++) {
+      int s, e;
+      if (part[i] != p) continue;
+      mq_interval(qAlignStart[i], qAlignEnd[i], qStrand[i], qLength[i], 0, &s, &e);
+      if (first || (e - s > pEnd[p] - pBegin[p] && nMatch[i] * 1.20 >= pScore[p])) {
+        pBegin[p] = s;
+        pEnd[p] = e;
+        pScore[p] = nMatch[i];
+      }
+      first = 0;
+    }
+  }
+  for (i = 0; i < n; i++) { /* :2851-2873, SumMismatches :2647-2671 */
+    int s, e, mismatchSum = 0, x;
+    p = part[i];
+    mq_interval(qAlignStart[i], qAlignEnd[i], qStrand[i], qLength[i], 1, &s, &e);
+    if (s - pBegin[p] > 5 || pEnd[p] - e > 5) {
+      if (qvs != NULL) {
+        for (x = pBegin[p]; x < s; x++) mismatchSum += qvs[x];
+        for (x = e; x < pEnd[p]; x++) mismatchSum += qvs[x];
+      } else {
+        mismatchSum += 15 * ((s - pBegin[p]) + (pEnd[p] - e));
+      }
+    }
+    probScore[i] += -(mismatchSum) * 0.5;
+  }
+  for (p = 0; p < nPart; p++) { /* :2878-2944 */
+    float denominator = 0;
+    int maxNMatch = 0, first = 1, size = 0;
+    for (i = 0; i < n; i++) {
+      if (part[i] != p) continue;
+      size++;
+      if (first) {
+        denominator = probScore[i];
+        maxNMatch = nMatch[i];
+        first = 0;
+      } else {
+        if (nMatch[i] > maxNMatch) maxNMatch = nMatch[i];
+        if (nMatch[i] * 1.2 >= maxNMatch) denominator = mq_log_sum_of_two(denominator, probScore[i]);
+      }
+    }
+    for (i = 0; i < n; i++) {
+      if (part[i] != p) continue;
+      if (size == 1) {
+        mapQV[i] = 254;
+      } else if (probScore[i] - denominator < -20) {
+        mapQV[i] = 0;
+      } else {
+        double log10v = log(10), sub = probScore[i] - denominator;
+        double expo = exp(log10v * sub), diff = 1.0 - expo;
+        int phred;
+        if (expo == 0) phred = 0;
+        else if (diff == 0) phred = 254;
+        else phred = -10 * log10(diff);
+        if (phred > 254) phred = 254;
+        if (phred < 0) phred = 0;
+        mapQV[i] = phred;
+      }
+    }
+  }
+  free(part);
+  free(pBegin);
+  free(pEnd);
+  free(pScore);
+}

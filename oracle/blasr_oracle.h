@@ -126,6 +126,15 @@ int bo_m4_line(const char *qName, const char *tName, int score, float pctSimilar
                unsigned qAlignEnd, unsigned qLength, int tStrand, unsigned tAlignStart, unsigned tAlignEnd,
                unsigned tLength, int mapQV, char *out, int outCap);
 
+/* next-2: StoreMapQVs (alignment/Blasr.cpp:2647-2950) on n alignments of one read given as parallel arrays; the op
+ * lists ((len << 2) | M 0 / I 1 / D 2) are concatenated, opOff has n+1 entries; matrix25 is indexed
+ * [target][query] as DistanceMatrixScoreFunction::Match does; qvs = read.substitutionQV or NULL. */
+void bo_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned char *const *tSeqs, const int *qPos,
+                      const int *tPos, const unsigned *ops, const long *opOff, const unsigned *qAlignStart,
+                      const unsigned *qAlignEnd, const int *qStrand, const unsigned *qLength, const int *nMatch,
+                      const unsigned char *qvs, const int *matrix25, int ins, int del, int affineOpen, int affineExtend,
+                      int affineAlign, float minFraction, int *mapQV, float *probScore);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,3 +287,48 @@ int ref_m4_line(const char *qName, const char *tName, int score, float pctSimila
 }
 
 }  // extern "C"
+
+extern "C" {
+
+// StoreMapQVs on n alignments of one read given as parallel arrays (op lists concatenated, opOff[n+1]).
+// qvs: read.substitutionQV or NULL.  mapQV / probScore receive the results.
+int ref_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned char *const *tSeqs, const int *qPos,
+                      const int *tPos, const unsigned *ops, const long *opOff, const unsigned *qAlignStart,
+                      const int *qStrand, const unsigned *qLength, const int *nMatch, unsigned readLength,
+                      const unsigned char *qvs, int ins, int del, int affineOpen, int affineExtend, int affineAlign,
+                      float minFraction, int *mapQV, float *probScore) {
+  MappingParameters params;
+  params.MakeSane();
+  params.insertion = ins;
+  params.deletion = del;
+  params.affineOpen = affineOpen;
+  params.affineExtend = affineExtend;
+  params.affineAlign = affineAlign != 0;
+  params.minFractionToBeConsideredOverlapping = minFraction;
+  vector<T_AlignmentCandidate *> ptrs(n);
+  for (int i = 0; i < n; i++) {
+    T_AlignmentCandidate *a = new T_AlignmentCandidate;
+    fill_alignment(*a, qSeqs[i], tSeqs[i], qPos[i], tPos[i], ops + opOff[i], opOff[i + 1] - opOff[i], NULL, 0);
+    a->qAlignedSeqPos = qAlignStart[i] - (unsigned)qPos[i];
+    a->qStrand = qStrand[i];
+    a->qLength = qLength[i];
+    a->nMatch = nMatch[i];
+    ptrs[i] = a;
+  }
+  SMRTSequence read;
+  read.length = readLength;
+  if (qvs != NULL) {
+    read.substitutionQV.data = const_cast<unsigned char *>(qvs);
+  }
+  MappingBuffers buffers;
+  StoreMapQVs(read, ptrs, params, buffers);
+  read.substitutionQV.data = NULL;
+  for (int i = 0; i < n; i++) {
+    mapQV[i] = ptrs[i]->mapQV;
+    probScore[i] = ptrs[i]->probScore;
+    delete ptrs[i];
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -548,3 +548,119 @@ def random_epilogue_cases(rng, n):
                           read_length=read_length, lqp=lqp, lqs=lqs, subread_start=sub_start, subread_end=sub_end,
                           q_align_start=q_align_start, q_align_end=q_align_end))
     return cases
+
+
+def _store_map_qvs(checker, alignments, substitution_qv=None, ins=5, dele=5, affine_open=50, affine_extend=0,
+                   affine_align=1, min_fraction=0.75):
+    """StoreMapQVs through the oracle (bo_store_map_qvs) or the reference harness (ref_store_map_qvs)."""
+    n = len(alignments)
+    qs = [_u8(a["q"]) for a in alignments]
+    ts = [_u8(a["t"]) for a in alignments]
+    qptr = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_p(x, C.c_ubyte) for x in qs])
+    tptr = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_p(x, C.c_ubyte) for x in ts])
+    ops = np.concatenate([np.asarray(a["ops"], dtype=np.uint32) for a in alignments]) if n else np.zeros(1, np.uint32)
+    op_off = np.zeros(n + 1, dtype=np.int64)
+    for i, a in enumerate(alignments):
+        op_off[i + 1] = op_off[i] + len(a["ops"])
+    ia = lambda k: np.array([a[k] for a in alignments] or [0], dtype=np.int32)  # noqa: E731
+    ua = lambda k: np.array([a[k] for a in alignments] or [0], dtype=np.uint32)  # noqa: E731
+    q_pos, t_pos, q_strand, n_match = ia("q_pos"), ia("t_pos"), ia("q_strand"), ia("n_match")
+    q_start, q_end, q_length = ua("q_align_start"), ua("q_align_end"), ua("q_length")
+    qv = None if substitution_qv is None else _u8(substitution_qv)
+    map_qv, prob = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+    if checker.kind == "oracle":
+        from blasr_amd.hip import SMRT_LOG_PROB_MATRIX
+        m = np.array(SMRT_LOG_PROB_MATRIX, dtype=np.int32)
+        checker.lib.bo_store_map_qvs(n, qptr, tptr, _p(q_pos), _p(t_pos), _pu(ops), _p(op_off, C.c_long), _pu(q_start),
+                                     _pu(q_end), _p(q_strand), _pu(q_length), _p(n_match),
+                                     None if qv is None else _p(qv, C.c_ubyte), _p(m), ins, dele, affine_open,
+                                     affine_extend, affine_align, C.c_float(min_fraction), _p(map_qv), _p(prob, C.c_float))
+    else:
+        read_length = int(max([a["q_length"] for a in alignments] or [0]))
+        checker.lib.ref_store_map_qvs(n, qptr, tptr, _p(q_pos), _p(t_pos), _pu(ops), _p(op_off, C.c_long), _pu(q_start),
+                                      _p(q_strand), _pu(q_length), _p(n_match), C.c_uint(read_length),
+                                      None if qv is None else _p(qv, C.c_ubyte), ins, dele, affine_open, affine_extend,
+                                      affine_align, C.c_float(min_fraction), _p(map_qv), _p(prob, C.c_float))
+    return [int(v) for v in map_qv[:n]], [float(v) for v in prob[:n]]
+
+
+EpilogueChecker.store_map_qvs = _store_map_qvs
+
+
+def random_mapqv_case(rng, it):
+    """The alignments of one read for StoreMapQVs: one to six, mostly overlapping on the read (the competing
+    candidates of a repeat), sometimes disjoint (a chimeric read), both strands, with and without substitution QVs."""
+    read_length = int(rng.integers(400, 3000))
+    n = int(rng.integers(1, 7))
+    letters = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    alns = []
+    base_start = int(rng.integers(0, read_length // 4))
+    base_end = int(rng.integers(3 * read_length // 4, read_length + 1))
+    for a in range(n):
+        if rng.random() < 0.75:  # a competitor over (nearly) the same part of the read
+            s = max(0, base_start + int(rng.integers(-40, 60)))
+            e = min(read_length, base_end + int(rng.integers(-60, 40)))
+        else:  # somewhere else on the read
+            s = int(rng.integers(0, read_length - 50))
+            e = int(rng.integers(s + 30, read_length + 1))
+        span = e - s
+        ops, qlen, tlen = [], 0, 0
+        while qlen < span:
+            ln = min(int(rng.integers(1, 60)), span - qlen)
+            ops.append((ln << 2) | 0)
+            qlen += ln
+            tlen += ln
+            if qlen < span and rng.random() < 0.8:
+                ty = int(rng.integers(1, 3))
+                gl = int(rng.integers(1, 60 if rng.random() < 0.1 else 6))
+                if ty == 1:
+                    gl = min(gl, span - qlen - 1)
+                    if gl <= 0:
+                        continue
+                    qlen += gl
+                else:
+                    tlen += gl
+                ops.append((gl << 2) | ty)
+        if (ops[-1] & 3) != 0:  # the list ends with a block
+            ops.append((1 << 2) | 0)
+            qlen += 1
+            tlen += 1
+            e = s + qlen
+            if e > read_length:
+                read_length = e
+        q_pos, t_pos = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+        t = letters[rng.integers(0, 9, t_pos + tlen + 4)].copy()
+        q = letters[rng.integers(0, 9, q_pos + qlen + 4)].copy()
+        ident = 0.70 + 0.29 * rng.random()
+        qi, ti, n_match = q_pos, t_pos, 0
+        for w in ops:
+            ln, ty = w >> 2, w & 3
+            if ty == 0:
+                keep = rng.random(ln) < ident
+                q[qi:qi + ln] = np.where(keep, t[ti:ti + ln], q[qi:qi + ln])
+                n_match += int(keep.sum())
+                qi += ln
+                ti += ln
+            elif ty == 1:
+                qi += ln
+            else:
+                ti += ln
+        q_strand = int(rng.integers(0, 2))
+        alns.append(dict(q=q, t=t, ops=np.array(ops, dtype=np.uint32), q_pos=q_pos, t_pos=t_pos, q_align_start=s,
+                         q_align_end=s + qlen, q_strand=q_strand, q_length=0, n_match=n_match))
+    # near-ties: copies of the first alignment with a few bases changed, so that the Phred branch sees scores a
+    # fraction of a unit apart (a repeat with a handful of differences)
+    for c in range(int(rng.integers(0, 4))):
+        a = dict(alns[0])
+        q = a["q"].copy()
+        span = a["q_align_end"] - a["q_align_start"]
+        for k in range(int(rng.integers(0, 7))):
+            q[a["q_pos"] + int(rng.integers(0, span))] = letters[int(rng.integers(0, 9))]
+        a["q"] = q
+        a["n_match"] = max(0, a["n_match"] - int(rng.integers(0, 7)))
+        a["q_strand"] = int(rng.integers(0, 2)) if rng.random() < 0.2 else a["q_strand"]
+        alns.insert(int(rng.integers(0, len(alns) + 1)), a)
+    for a in alns:
+        a["q_length"] = read_length
+    qv = rng.integers(0, 60, read_length).astype(np.uint8) if it % 3 == 0 else None
+    return alns, qv

@@ -2,7 +2,7 @@
 """Golden vectors for the first pieces of the output epilogue, generated HERE with
 the reference's own code (oracle/_ref/libblasr_refmapper.so = alignment/Blasr.cpp compiled where it lies):
 AssignRefContigLocation, SAMOutput::CreateCIGARString (op-list and block form, all four clipping modes, both
-strands), IntervalAlignmentPrinter::Print.  Run from the repo root:  python tests/golden/make_epilogue_golden.py"""
+strands), IntervalAlignmentPrinter::Print, StoreMapQVs.  Run from the repo root:  python tests/golden/make_epilogue_golden.py"""
 import os
 import sys
 
@@ -86,8 +86,25 @@ def main():
         g["m4_%d_blocks" % i] = c[13]
         g["m4_%d_derived" % i] = np.array(derived, dtype=np.int64)
         g["m4_%d_line" % i] = np.frombuffer(line.encode(), dtype=np.uint8)
+    # StoreMapQVs: the alignments of 80 reads
+    n_reads = 80
+    g["mapqv_n"] = np.array(n_reads)
+    for i in range(n_reads):
+        alns, qv = T.random_mapqv_case(rng, i)
+        par = dict(affine_align=i % 2, affine_open=[50, 30, 10][i % 3], affine_extend=[0, 1][i % 2], ins=[5, 4, 8][i % 3],
+                   dele=[5, 5, 8][i % 3])
+        map_qv, prob = ref.store_map_qvs(alns, qv, **par)
+        g["mapqv%d_par" % i] = np.array([par["ins"], par["dele"], par["affine_open"], par["affine_extend"],
+                                         par["affine_align"], len(alns)], dtype=np.int64)
+        g["mapqv%d_qv" % i] = qv if qv is not None else np.zeros(0, dtype=np.uint8)
+        for j, a in enumerate(alns):
+            g["mapqv%d_%d_q" % (i, j)], g["mapqv%d_%d_t" % (i, j)], g["mapqv%d_%d_ops" % (i, j)] = a["q"], a["t"], a["ops"]
+            g["mapqv%d_%d_num" % (i, j)] = np.array([a["q_pos"], a["t_pos"], a["q_align_start"], a["q_align_end"],
+                                                     a["q_strand"], a["q_length"], a["n_match"]], dtype=np.int64)
+        g["mapqv%d_out" % i] = np.array(map_qv, dtype=np.int64)
+        g["mapqv%d_prob" % i] = np.array(prob, dtype=np.float32)
     np.savez_compressed(os.path.join(HERE, "epilogue_golden.npz"), **g)
-    print("wrote epilogue_golden.npz:", len(cc), "contig,", len(cg), "cigar,", len(mc), "m4 cases")
+    print("wrote epilogue_golden.npz:", len(cc), "contig,", len(cg), "cigar,", len(mc), "m4 cases,", n_reads, "reads for mapQV")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """First pieces of the output epilogue -- AssignRefContigLocation, CreateCIGARString,
-IntervalAlignmentPrinter::Print.  Host code on both sides, so no GPU is needed: the library's functions and the
+IntervalAlignmentPrinter::Print, StoreMapQVs.  Host code on both sides, so no GPU is needed: the library's functions and the
 oracle's restatement against golden vectors made with the reference's own code
 (tests/golden/make_epilogue_golden.py), and against each other on fresh random cases."""
 import os
@@ -69,6 +69,46 @@ def test_m4_line_golden(golden, orc):
         assert blasr_amd.m4_line(q_name, t_name, score, pct, q_strand, q_start, q_end, q_length, t_strand, t_start, t_end,
                                  t_length, map_qv) == want, i
         assert len(want.split()) == 13
+
+
+def _golden_read(golden, i):
+    ins, dele, affine_open, affine_extend, affine_align, n = (int(v) for v in golden["mapqv%d_par" % i])
+    qv = golden["mapqv%d_qv" % i]
+    alns = []
+    for j in range(n):
+        q_pos, t_pos, q_start, q_end, q_strand, q_length, n_match = (int(v) for v in golden["mapqv%d_%d_num" % (i, j)])
+        alns.append(dict(q=golden["mapqv%d_%d_q" % (i, j)], t=golden["mapqv%d_%d_t" % (i, j)],
+                         ops=golden["mapqv%d_%d_ops" % (i, j)], q_pos=q_pos, t_pos=t_pos, q_align_start=q_start,
+                         q_align_end=q_end, q_strand=q_strand, q_length=q_length, n_match=n_match))
+    par = dict(ins=ins, dele=dele, affine_open=affine_open, affine_extend=affine_extend, affine_align=affine_align)
+    return alns, (qv if len(qv) else None), par
+
+
+def test_map_qvs_golden(golden, orc):
+    seen = set()
+    for i in range(int(golden["mapqv_n"])):
+        alns, qv, par = _golden_read(golden, i)
+        want = [int(v) for v in golden["mapqv%d_out" % i]]
+        want_prob = [float(v) for v in golden["mapqv%d_prob" % i]]
+        assert orc.store_map_qvs(alns, qv, **par) == (want, want_prob), i
+        got = blasr_amd.map_qvs(alns, qv, ins=par["ins"], dele=par["dele"], affine_open=par["affine_open"],
+                                affine_extend=par["affine_extend"], affine_align=bool(par["affine_align"]))
+        assert got == (want, want_prob), i
+        seen.update(want)
+    assert 254 in seen and 0 in seen and len(seen) > 5  # lone alignments, losers and the Phred branch in between
+
+
+def test_map_qvs_library_against_oracle_on_random_reads(orc):
+    rng = np.random.default_rng(4711)
+    for it in range(400):
+        alns, qv = T.random_mapqv_case(rng, it)
+        par = dict(ins=[5, 4, 8][it % 3], dele=[5, 5, 8][it % 3], affine_open=[50, 30, 10][it % 3],
+                   affine_extend=[0, 1][it % 2], affine_align=it % 2)
+        want = orc.store_map_qvs(alns, qv, **par)
+        got = blasr_amd.map_qvs(alns, qv, ins=par["ins"], dele=par["dele"], affine_open=par["affine_open"],
+                                affine_extend=par["affine_extend"], affine_align=bool(par["affine_align"]))
+        assert got == want, it
+    assert blasr_amd.map_qvs([]) == ([], [])
 
 
 def test_cigar_library_against_oracle_on_random_cases(orc):

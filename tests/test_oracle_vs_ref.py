@@ -117,3 +117,8 @@ def test_epilogue_pieces_against_the_reference_printers():
                 int(rng.integers(0, 500)), int(rng.integers(0, 50)), int(rng.integers(1000, 40000)), strand,
                 pos, int(rng.integers(0, 50)), glen, int(rng.integers(0, 255)))
         assert orc.m4_line(*args, blocks) == rf.m4_line(*args, blocks), it
+    for it in range(400):
+        alns, qv = T.random_mapqv_case(rng, it)
+        par = dict(ins=[5, 4, 8][it % 3], dele=[5, 5, 8][it % 3], affine_open=[50, 30, 10][it % 3],
+                   affine_extend=[0, 1][it % 2], affine_align=it % 2)
+        assert orc.store_map_qvs(alns, qv, **par) == rf.store_map_qvs(alns, qv, **par), it
