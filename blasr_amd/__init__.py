@@ -22,6 +22,7 @@ from .hip import (  # noqa: F401
     cigar,
     m4_line,
     map_qvs,
+    sam_line,
     ref_contig_location,
     CANDIDATE_DTYPE,
     INTERVAL_DTYPE,

@@ -5,6 +5,7 @@
 //   blasr_hip_cigar                 CreateCIGARString and its helpers   printers/SAMPrinter.h:122-416
 //   blasr_hip_m4_line               IntervalAlignmentPrinter::Print     printers/IntervalAlignmentPrinter.h:9-38
 //   blasr_hip_map_qvs               StoreMapQVs and its helpers         alignment/Blasr.cpp:2647-2950
+//   blasr_hip_sam_line              SAMOutput::PrintAlignment           printers/SAMPrinter.h:29-105, 418-548
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -362,5 +363,101 @@ extern "C" int blasr_hip_map_qvs(const blasr_hip_mapqv_alignment *alns, int32_t 
   }
   if (prob_score_out)
     for (int a = 0; a < n; a++) prob_score_out[a] = probScore[a];
+  return BLASR_HIP_OK;
+}
+
+namespace {
+uint8_t rc_nuc_host(uint8_t c) {  // ReverseComplementNuc (NucConversion.h:337-370)
+  switch (c) {
+    case 0: return 3;
+    case 1: return 2;
+    case 2: return 1;
+    case 3: return 0;
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'N': return 'N';
+    case 'a': return 't';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    case 't': return 'a';
+    case 'n': return 'n';
+    default: return 127;
+  }
+}
+}  // namespace
+
+extern "C" int blasr_hip_sam_line(const blasr_hip_sam_fields *f, char *line, int64_t line_cap, int64_t *line_len) {
+  if (!f || !f->q_name || !f->t_name || !f->read_group_id || !f->cigar || !f->read_seq || !line_len)
+    return BLASR_HIP_ERR_INVALID;
+  // SetAlignedSequence (:58-105): which part of the read is printed
+  uint32_t start = 0, length = 0;
+  if (f->clipping == BLASR_HIP_CLIP_NONE || f->clipping == BLASR_HIP_CLIP_HARD) {
+    start = f->q_align_start;
+    length = f->q_align_end - f->q_align_start;
+  } else if (f->clipping == BLASR_HIP_CLIP_SOFT) {
+    length = f->read_length - f->low_quality_prefix - f->low_quality_suffix;
+    start = f->low_quality_prefix;
+  } else if (f->clipping == BLASR_HIP_CLIP_SUBREAD) {
+    length = f->subread_end - f->subread_start;
+    start = f->subread_start;
+  } else {
+    return BLASR_HIP_ERR_INVALID;
+  }
+  if ((uint64_t)start + length > f->read_length) return BLASR_HIP_ERR_INVALID;
+  std::string seq((size_t)length, ' '), qual;
+  if (f->t_strand == 0) {
+    for (uint32_t i = 0; i < length; i++) seq[i] = (char)f->read_seq[start + i];
+  } else {  // MakeRC: reverse complement, qualities reversed
+    for (uint32_t i = 0; i < length; i++) seq[i] = (char)rc_nuc_host(f->read_seq[start + length - 1 - i]);
+  }
+  if (f->read_qual) {
+    qual.resize(length);
+    for (uint32_t i = 0; i < length; i++)
+      qual[i] = (char)(f->read_qual[f->t_strand == 0 ? start + i : start + length - 1 - i] + 33);  // charToQuality
+  } else {
+    qual = "*";
+  }
+  unsigned flag = 0;  // BuildFlag (:29-50)
+  if (f->t_strand != f->q_strand) flag |= 0x10;  // SEQ_REVERSED
+  if (!f->is_primary) flag |= 0x100;             // SECONDARY_ALIGNMENT
+  const uint32_t pos = f->t_strand == 0 ? f->t_align_start + 1 : f->t_length - (f->t_align_start + f->t_end) + 1;
+  char buf[256];
+  std::string s = std::string(f->q_name) + "\t";
+  snprintf(buf, sizeof buf, "%u\t", flag);
+  s += buf;
+  s += std::string(f->t_name) + "\t";
+  snprintf(buf, sizeof buf, "%u\t%d\t", pos, f->map_qv);
+  s += buf;
+  s += std::string(f->cigar) + "\t*\t0\t";
+  snprintf(buf, sizeof buf, "%u\t", f->t_end);  // TLEN = GenomicTEnd() - GenomicTBegin()
+  s += buf;
+  s += seq + "\t" + qual + "\t";
+  s += "RG:Z:" + std::string(f->read_group_id) + "\t";
+  snprintf(buf, sizeof buf, "AS:i:%d\t", f->score);
+  s += buf;
+  if (f->clipping == BLASR_HIP_CLIP_NONE) {
+    snprintf(buf, sizeof buf, "XS:i:%u\tXE:i:%u\t", f->q_align_start + 1, f->q_align_end + 1);
+    s += buf;
+  } else {
+    uint32_t xs = f->clips[2], xe = f->read_length - f->clips[3];
+    if (f->t_strand == 1) {
+      xs = f->clips[3];
+      xe = f->read_length - f->clips[2];
+    }
+    snprintf(buf, sizeof buf, "XS:i:%u\tXE:i:%u\tqs:i:%d\tqe:i:%d\t", xs + 1, xe + 1, f->qs, f->qe);
+    s += buf;
+  }
+  snprintf(buf, sizeof buf, "zm:i:%d\tXL:i:%u\tXT:i:1\tNM:i:%d\tFI:i:%u\tXQ:i:%u\t", f->hole_number, f->q_aligned_seq_length,
+           f->edit_dist, f->q_aligned_seq_pos + 1, f->q_length);
+  s += buf;
+  // samFile.precision(4) from here on
+  snprintf(buf, sizeof buf, "rq:f:%.4g\tnp:i:%d\tcx:i:%d\tsn:B:f,%.4g,%.4g,%.4g,%.4g\n", (double)f->read_quality, f->num_passes,
+           f->subread_context, (double)f->snr[0], (double)f->snr[1], (double)f->snr[2], (double)f->snr[3]);
+  s += buf;
+  *line_len = (int64_t)s.size();
+  if (!line || (int64_t)s.size() + 1 > line_cap) return BLASR_HIP_ERR_CAPACITY;
+  memcpy(line, s.c_str(), s.size() + 1);
   return BLASR_HIP_OK;
 }

@@ -31,6 +31,7 @@ EXPORTS = [
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
+    "blasr_hip_sam_line",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -300,6 +301,42 @@ def m4_line(q_name, t_name, score, pct_similarity, q_strand, q_align_start, q_al
     rc = lib.blasr_hip_m4_line(C.byref(f), out, C.c_int64(len(out)), C.byref(n))
     if rc < 0:
         raise BlasrHipError(rc, "m4_line")
+    return out.value.decode()
+
+
+class _SamFields(C.Structure):
+    _fields_ = [("q_name", C.c_char_p), ("t_name", C.c_char_p), ("read_group_id", C.c_char_p), ("cigar", C.c_char_p),
+                ("read_seq", C.c_void_p), ("read_qual", C.c_void_p), ("clips", C.c_uint32 * 4), ("clipping", C.c_int32),
+                ("q_strand", C.c_int32), ("t_strand", C.c_int32), ("is_primary", C.c_int32), ("read_length", C.c_uint32),
+                ("low_quality_prefix", C.c_uint32), ("low_quality_suffix", C.c_uint32), ("subread_start", C.c_uint32),
+                ("subread_end", C.c_uint32), ("q_align_start", C.c_uint32), ("q_align_end", C.c_uint32),
+                ("t_align_start", C.c_uint32), ("t_end", C.c_uint32), ("t_length", C.c_uint32), ("q_length", C.c_uint32),
+                ("q_aligned_seq_pos", C.c_uint32), ("q_aligned_seq_length", C.c_uint32), ("map_qv", C.c_int32),
+                ("score", C.c_int32), ("edit_dist", C.c_int32), ("hole_number", C.c_int32), ("qs", C.c_int32),
+                ("qe", C.c_int32), ("num_passes", C.c_int32), ("subread_context", C.c_int32),
+                ("read_quality", C.c_float), ("snr", C.c_float * 4)]
+
+
+def sam_line(q_name, t_name, read_group_id, cigar_string, clips, read_seq, read_qual=None, **kw):
+    """SAMOutput::PrintAlignment (printers/SAMPrinter.h:418-548): one SAM record.  kw: the remaining fields of
+    blasr_hip_sam_fields (include/blasr_hip.h) by name; snr is a sequence of four."""
+    lib = load_library()
+    seq = np.ascontiguousarray(read_seq, dtype=np.uint8)
+    qual = None if read_qual is None else np.ascontiguousarray(read_qual, dtype=np.uint8)
+    f = _SamFields()
+    f.q_name, f.t_name, f.read_group_id, f.cigar = q_name.encode(), t_name.encode(), read_group_id.encode(), cigar_string.encode()
+    f.read_seq = seq.ctypes.data
+    f.read_qual = None if qual is None else qual.ctypes.data
+    f.clips = (C.c_uint32 * 4)(*[int(v) for v in clips])
+    f.snr = (C.c_float * 4)(*[float(v) for v in kw.pop("snr", (0, 0, 0, 0))])
+    for k, v in kw.items():
+        setattr(f, k, v)
+    cap = 2 * len(seq) + len(cigar_string) + len(q_name) + len(t_name) + len(read_group_id) + 512
+    out = C.create_string_buffer(cap)
+    n = C.c_int64(0)
+    rc = lib.blasr_hip_sam_line(C.byref(f), out, C.c_int64(cap), C.byref(n))
+    if rc < 0:
+        raise BlasrHipError(rc, "sam_line")
     return out.value.decode()
 
 

@@ -442,6 +442,28 @@ typedef struct blasr_hip_mapqv_params {
 int blasr_hip_map_qvs(const blasr_hip_mapqv_alignment *alignments, int32_t n, const blasr_hip_mapqv_params *params,
                       const uint8_t *substitution_qv, int32_t *map_qv, float *prob_score);
 
+/* SAMOutput::PrintAlignment (printers/SAMPrinter.h:418-548, passthrough = false, no supplemental QVs) with
+ * BuildFlag (:29-50) and SetAlignedSequence (:58-105): one SAM record, newline included.  cigar / clips are what
+ * blasr_hip_cigar returned for the same alignment and clipping. */
+typedef struct blasr_hip_sam_fields {
+  const char *q_name, *t_name, *read_group_id, *cigar;
+  const uint8_t *read_seq;   /* the read, forward strand, read_length bases */
+  const uint8_t *read_qual;  /* read.qual.data or NULL */
+  uint32_t clips[4];         /* {prefixSoftClip, suffixSoftClip, prefixHardClip, suffixHardClip} */
+  int32_t clipping;          /* BLASR_HIP_CLIP_* */
+  int32_t q_strand, t_strand, is_primary;
+  uint32_t read_length, low_quality_prefix, low_quality_suffix, subread_start, subread_end;
+  uint32_t q_align_start, q_align_end; /* QAlignStart() / QAlignEnd() */
+  uint32_t t_align_start;    /* TAlignStart() + blocks[0].tPos (:437) */
+  uint32_t t_end;            /* TEnd(): last block's tPos + length */
+  uint32_t t_length, q_length;
+  uint32_t q_aligned_seq_pos, q_aligned_seq_length; /* FI and XL */
+  int32_t map_qv, score, edit_dist; /* edit_dist = AlignmentContext::editDist */
+  int32_t hole_number, qs, qe, num_passes, subread_context; /* SMRTSequence fields */
+  float read_quality, snr[4];
+} blasr_hip_sam_fields;
+int blasr_hip_sam_line(const blasr_hip_sam_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2339,3 +2339,67 @@ void bo_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned c
   free(pEnd);
   free(pScore);
 }
+
+/* ---- SAMOutput::PrintAlignment ----------------------------------------------------------------------------- */
+static unsigned char sam_rc(unsigned char c) { /* ReverseComplementNuc (NucConversion.h:337-370) */
+  switch (c) {
+    case 0: return 3; case 1: return 2; case 2: return 1; case 3: return 0;
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; case 'n': return 'n';
+    default: return 127;
+  }
+}
+int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, const unsigned char *readSeq,
+                const unsigned char *readQual, const char *cigar, const unsigned *clips4, const int *iv, const float *fv,
+                char *out, int outCap) {
+  const int clipping = iv[2], qStrand = iv[3], tStrand = iv[4], isPrimary = iv[5];
+  const unsigned readLength = (unsigned)iv[6], lqp = (unsigned)iv[7], lqs = (unsigned)iv[8];
+  const unsigned subreadStart = (unsigned)iv[9], subreadEnd = (unsigned)iv[10];
+  const unsigned qAlignStart = (unsigned)iv[24], qAlignEnd = (unsigned)iv[25], tAlignStart = (unsigned)iv[26];
+  const unsigned tEnd = (unsigned)iv[27], tLength = (unsigned)iv[14];
+  unsigned start = 0, length = 0, flag = 0, pos, i;
+  int at = 0;
+#define SAM_PUT(...) do { int w_ = snprintf(out + at, at < outCap ? (size_t)(outCap - at) : 0, __VA_ARGS__); at += w_; \
+                          if (at >= outCap) return -1; } while (0)
+  /* SetAlignedSequence :58-105 */
+  if (clipping == 3 || clipping == 0) {
+    start = qAlignStart;
+    length = qAlignEnd - qAlignStart;
+  } else if (clipping == 1) {
+    length = readLength - lqp - lqs;
+    start = lqp;
+  } else {
+    length = subreadEnd - subreadStart;
+    start = subreadStart;
+  }
+  if (tStrand != qStrand) flag |= 0x10; /* BuildFlag :29-50 */
+  if (!isPrimary) flag |= 0x100;
+  pos = tStrand == 0 ? tAlignStart + 1 : tLength - (tAlignStart + tEnd) + 1; /* :437-446 */
+  SAM_PUT("%s\t%u\t%s\t%u\t%d\t%s\t*\t0\t%u\t", qName, flag, tName, pos, iv[16], cigar, tEnd);
+  if (at + (int)length + 2 >= outCap) return -1;
+  for (i = 0; i < length; i++) out[at++] = (char)(tStrand == 0 ? readSeq[start + i] : sam_rc(readSeq[start + length - 1 - i]));
+  out[at++] = '\t';
+  if (readQual != NULL) {
+    if (at + (int)length + 2 >= outCap) return -1;
+    for (i = 0; i < length; i++) out[at++] = (char)(readQual[tStrand == 0 ? start + i : start + length - 1 - i] + 33);
+  } else {
+    out[at++] = '*';
+  }
+  SAM_PUT("\tRG:Z:%s\tAS:i:%d\t", readGroupId, iv[17]);
+  if (clipping == 3) {
+    SAM_PUT("XS:i:%u\tXE:i:%u\t", qAlignStart + 1, qAlignEnd + 1);
+  } else {
+    unsigned xs = clips4[2], xe = readLength - clips4[3];
+    if (tStrand == 1) {
+      xs = clips4[3];
+      xe = readLength - clips4[2];
+    }
+    SAM_PUT("XS:i:%u\tXE:i:%u\tqs:i:%d\tqe:i:%d\t", xs + 1, xe + 1, iv[20], iv[21]);
+  }
+  SAM_PUT("zm:i:%d\tXL:i:%u\tXT:i:1\tNM:i:%d\tFI:i:%u\tXQ:i:%u\t", iv[19], (unsigned)iv[12], iv[18], (unsigned)iv[11] + 1,
+          (unsigned)iv[15]);
+  SAM_PUT("rq:f:%.4g\tnp:i:%d\tcx:i:%d\tsn:B:f,%.4g,%.4g,%.4g,%.4g\n", (double)fv[0], iv[22], iv[23], (double)fv[1],
+          (double)fv[2], (double)fv[3], (double)fv[4]);
+#undef SAM_PUT
+  return at;
+}

@@ -135,6 +135,13 @@ void bo_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned c
                       const unsigned char *qvs, const int *matrix25, int ins, int del, int affineOpen, int affineExtend,
                       int affineAlign, float minFraction, int *mapQV, float *probScore);
 
+/* next-2: SAMOutput::PrintAlignment (printers/SAMPrinter.h:418-548; BuildFlag :29-50, SetAlignedSequence :58-105),
+ * no passthrough, no supplemental QVs.  iv / fv as in oracle/ref_mapper_harness.cpp ref_sam_line, with
+ * iv[24..27] = QAlignStart, QAlignEnd, TAlignStart + blocks[0].tPos, TEnd and clips4 from bo_cigar. */
+int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, const unsigned char *readSeq,
+                const unsigned char *readQual, const char *cigar, const unsigned *clips4, const int *iv, const float *fv,
+                char *out, int outCap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -332,3 +332,69 @@ int ref_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned c
 }
 
 }  // extern "C"
+
+extern "C" {
+
+// SAMOutput::PrintAlignment.  iv: 0 qPos 1 tPos 2 clipping 3 qStrand 4 tStrand 5 isPrimary 6 readLength
+// 7 lowQualityPrefix 8 lowQualitySuffix 9 subreadStart 10 subreadEnd 11 qAlignedSeqPos 12 qAlignedSeqLength
+// 13 tAlignedSeqPos 14 tLength 15 qLength 16 mapQV 17 score 18 editDist 19 holeNumber 20 qs 21 qe 22 numPasses
+// 23 subreadContext.  fv: readQuality, snr[4].  derived: QAlignStart, QAlignEnd, TAlignStart + blocks[0].tPos, TEnd.
+int ref_sam_line(const char *qName, const char *tName, const char *readGroupId, const unsigned char *readSeq,
+                 const unsigned char *readQual, const unsigned *ops, long nOps, const int *blocks, long nBlocks,
+                 const int *iv, const float *fv, char *out, int outCap, unsigned *derived) {
+  T_AlignmentCandidate a;
+  static unsigned char dummy[1] = {0};
+  fill_alignment(a, dummy, dummy, iv[0], iv[1], ops, nOps, blocks, nBlocks);
+  // the CIGAR compares the aligned sequences: give it the read itself and the same bases as target (all '=')
+  a.qName = qName;
+  a.tName = tName;
+  a.qStrand = iv[3];
+  a.tStrand = iv[4];
+  a.qAlignedSeqPos = iv[11];
+  a.qAlignedSeq.length = iv[12];
+  a.tAlignedSeqPos = iv[13];
+  a.tLength = iv[14];
+  a.qLength = iv[15];
+  a.mapQV = iv[16];
+  a.score = iv[17];
+  SMRTSequence read;
+  read.seq = const_cast<unsigned char *>(readSeq);
+  read.length = iv[6];
+  read.deleteOnExit = false;
+  if (readQual != NULL) read.qual.data = const_cast<unsigned char *>(readQual);
+  read.lowQualityPrefix = iv[7];
+  read.lowQualitySuffix = iv[8];
+  read.subreadStart = iv[9];
+  read.subreadEnd = iv[10];
+  read.holeNumber = iv[19];
+  read.qs = iv[20];
+  read.qe = iv[21];
+  read.numPasses = iv[22];
+  read.subreadContext = iv[23];
+  read.readQuality = fv[0];
+  for (int i = 0; i < 4; i++) read.snr[i] = fv[1 + i];
+  // aligned sequences for the = / X split: the bases at the alignment's own coordinates
+  vector<unsigned char> qa((size_t)iv[0] + a.QEnd() + 1, 'A'), ta((size_t)iv[1] + a.TEnd() + 1, 'A');
+  a.qAlignedSeq.seq = &qa[0];
+  a.tAlignedSeq.seq = &ta[0];
+  AlignmentContext context;
+  context.isPrimary = iv[5] != 0;
+  context.readGroupId = readGroupId;
+  context.editDist = iv[18];
+  SupplementalQVList qvlist;
+  stringstream strm;
+  SAMOutput::PrintAlignment(a, read, strm, context, qvlist, (SAMOutput::Clipping)iv[2]);
+  derived[0] = a.QAlignStart();
+  derived[1] = a.QAlignEnd();
+  derived[2] = a.TAlignStart() + a.blocks[0].tPos;
+  derived[3] = a.TEnd();
+  read.seq = NULL;
+  read.qual.data = NULL;
+  a.qAlignedSeq.seq = a.tAlignedSeq.seq = NULL;
+  const string s = strm.str();
+  if ((int)s.size() + 1 > outCap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+}  // extern "C"

@@ -664,3 +664,77 @@ def random_mapqv_case(rng, it):
         a["q_length"] = read_length
     qv = rng.integers(0, 60, read_length).astype(np.uint8) if it % 3 == 0 else None
     return alns, qv
+
+
+SAM_INT_FIELDS = ("q_pos", "t_pos", "clipping", "q_strand", "t_strand", "is_primary", "read_length", "low_quality_prefix",
+                  "low_quality_suffix", "subread_start", "subread_end", "q_aligned_seq_pos", "q_aligned_seq_length",
+                  "t_aligned_seq_pos", "t_length", "q_length", "map_qv", "score", "edit_dist", "hole_number", "qs", "qe",
+                  "num_passes", "subread_context")
+
+
+def _sam_line(checker, c, cigar=None, clips=None, derived=None):
+    """SAMOutput::PrintAlignment through the reference harness (returns (line, derived)) or the oracle (needs the
+    CIGAR, the clips and the derived positions)."""
+    iv = np.array([c[k] for k in SAM_INT_FIELDS] + ([0] * 4 if derived is None else list(derived)), dtype=np.int32)
+    fv = np.array([c["read_quality"]] + list(c["snr"]), dtype=np.float32)
+    seq = _u8(c["read_seq"])
+    qual = None if c["read_qual"] is None else _u8(c["read_qual"])
+    cap = 2 * len(seq) + 4096
+    out = C.create_string_buffer(cap)
+    if checker.kind == "ref":
+        b = np.ascontiguousarray(c["blocks"], dtype=np.int32).reshape(-1)
+        der = np.zeros(4, dtype=np.uint32)
+        n = checker.lib.ref_sam_line(c["q_name"].encode(), c["t_name"].encode(), c["read_group_id"].encode(),
+                                     _p(seq, C.c_ubyte), None if qual is None else _p(qual, C.c_ubyte), None, C.c_long(0),
+                                     _p(b), C.c_long(len(b) // 3), _p(iv), _p(fv, C.c_float), out, cap, _pu(der))
+        assert n >= 0
+        return out.value.decode(), tuple(int(v) for v in der)
+    k4 = np.array(clips, dtype=np.uint32)
+    n = checker.lib.bo_sam_line(c["q_name"].encode(), c["t_name"].encode(), c["read_group_id"].encode(),
+                                _p(seq, C.c_ubyte), None if qual is None else _p(qual, C.c_ubyte), cigar.encode(), _pu(k4),
+                                _p(iv), _p(fv, C.c_float), out, cap)
+    assert n >= 0
+    return out.value.decode()
+
+
+EpilogueChecker.sam_line = _sam_line
+
+
+def random_sam_case(rng, it):
+    """One alignment and its read for the SAM printer.  The asserts of PrintAlignment (:508, :512) hold: the hard
+    clips plus the printed sequence make up the read."""
+    letters = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    nb = int(rng.integers(1, 6))
+    blocks, q, t = [], 0, 0
+    for b in range(nb):
+        ln = int(rng.integers(1, 60))
+        blocks.append((q, t, ln))
+        q += ln + int(rng.integers(0, 5))
+        t += ln + int(rng.integers(0, 5))
+    q_end_rel = blocks[-1][0] + blocks[-1][2]
+    q_pos, t_pos = int(rng.integers(0, 10)), int(rng.integers(0, 10))
+    q_aligned_seq_pos = int(rng.integers(0, 60))
+    q_align_start = q_pos + q_aligned_seq_pos
+    q_align_end = q_align_start + q_end_rel
+    clipping = it % 4
+    lqp = int(rng.integers(0, q_align_start + 1))
+    lqs = int(rng.integers(0, 15))
+    read_length = q_align_end + lqs + int(rng.integers(0, 30))
+    sub_start = int(rng.integers(lqp, q_align_start + 1))         # subread clipping: lqp <= subreadStart
+    sub_end = int(rng.integers(q_align_end, read_length - lqs + 1))  # and lqs <= length - subreadEnd
+    t_aligned_seq_pos = int(rng.integers(0, 5000))
+    t_end_rel = blocks[-1][1] + blocks[-1][2]
+    t_length = t_aligned_seq_pos + t_pos + t_end_rel + int(rng.integers(0, 3000))
+    return dict(q_name="m%d/%d/0_%d" % (it, it * 3, read_length), t_name="ctg%d" % (it % 4), read_group_id="rg%x" % (it * 2654435761 % 2**32),
+                read_seq=letters[rng.integers(0, 9, read_length)].copy(),
+                read_qual=None if it % 3 == 0 else rng.integers(0, 60, read_length).astype(np.uint8),
+                blocks=np.array(blocks, dtype=np.int32), q_pos=q_pos, t_pos=t_pos, clipping=clipping,
+                q_strand=int(rng.integers(0, 2)), t_strand=int(rng.integers(0, 2)), is_primary=int(rng.integers(0, 2)),
+                read_length=read_length, low_quality_prefix=lqp, low_quality_suffix=lqs, subread_start=sub_start,
+                subread_end=sub_end, q_aligned_seq_pos=q_aligned_seq_pos, q_aligned_seq_length=int(rng.integers(q_end_rel, q_end_rel + 50)),
+                t_aligned_seq_pos=t_aligned_seq_pos, t_length=t_length, q_length=read_length,
+                map_qv=int(rng.integers(0, 255)), score=int(rng.integers(-50000, 10)), edit_dist=int(rng.integers(0, 900)),
+                hole_number=int(rng.integers(-1, 160000)), qs=int(rng.integers(0, 500)), qe=int(rng.integers(500, 40000)),
+                num_passes=int(rng.integers(0, 9)), subread_context=int(rng.integers(0, 4)),
+                read_quality=float(np.float32([0.0, 0.8, 0.85331, 1.0, 0.123456][it % 5])),
+                snr=[float(np.float32(v)) for v in rng.random(4) * [12, 9, 7, 100]])

@@ -2,7 +2,7 @@
 """Golden vectors for the first pieces of the output epilogue, generated HERE with
 the reference's own code (oracle/_ref/libblasr_refmapper.so = alignment/Blasr.cpp compiled where it lies):
 AssignRefContigLocation, SAMOutput::CreateCIGARString (op-list and block form, all four clipping modes, both
-strands), IntervalAlignmentPrinter::Print, StoreMapQVs.  Run from the repo root:  python tests/golden/make_epilogue_golden.py"""
+strands), IntervalAlignmentPrinter::Print, StoreMapQVs, SAMOutput::PrintAlignment.  Run from the repo root:  python tests/golden/make_epilogue_golden.py"""
 import os
 import sys
 
@@ -103,8 +103,23 @@ def main():
                                                      a["q_strand"], a["q_length"], a["n_match"]], dtype=np.int64)
         g["mapqv%d_out" % i] = np.array(map_qv, dtype=np.int64)
         g["mapqv%d_prob" % i] = np.array(prob, dtype=np.float32)
+    # SAMOutput::PrintAlignment
+    n_sam = 64
+    g["sam_n"] = np.array(n_sam)
+    for i in range(n_sam):
+        c = T.random_sam_case(rng, i)
+        line, derived = ref.sam_line(c)
+        g["sam%d_names" % i] = np.frombuffer("\n".join((c["q_name"], c["t_name"], c["read_group_id"])).encode(), dtype=np.uint8)
+        g["sam%d_seq" % i] = c["read_seq"]
+        g["sam%d_qual" % i] = c["read_qual"] if c["read_qual"] is not None else np.zeros(0, dtype=np.uint8)
+        g["sam%d_blocks" % i] = c["blocks"]
+        g["sam%d_int" % i] = np.array([c[k] for k in T.SAM_INT_FIELDS], dtype=np.int64)
+        g["sam%d_float" % i] = np.array([c["read_quality"]] + list(c["snr"]), dtype=np.float32)
+        g["sam%d_derived" % i] = np.array(derived, dtype=np.int64)
+        g["sam%d_line" % i] = np.frombuffer(line.encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "epilogue_golden.npz"), **g)
-    print("wrote epilogue_golden.npz:", len(cc), "contig,", len(cg), "cigar,", len(mc), "m4 cases,", n_reads, "reads for mapQV")
+    print("wrote epilogue_golden.npz:", len(cc), "contig,", len(cg), "cigar,", len(mc), "m4 cases,", n_reads,
+          "reads for mapQV,", n_sam, "SAM records")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """First pieces of the output epilogue -- AssignRefContigLocation, CreateCIGARString,
-IntervalAlignmentPrinter::Print, StoreMapQVs.  Host code on both sides, so no GPU is needed: the library's functions and the
+IntervalAlignmentPrinter::Print, StoreMapQVs, SAMOutput::PrintAlignment.  Host code on both sides, so no GPU is needed: the library's functions and the
 oracle's restatement against golden vectors made with the reference's own code
 (tests/golden/make_epilogue_golden.py), and against each other on fresh random cases."""
 import os
@@ -109,6 +109,42 @@ def test_map_qvs_library_against_oracle_on_random_reads(orc):
                                 affine_extend=par["affine_extend"], affine_align=bool(par["affine_align"]))
         assert got == want, it
     assert blasr_amd.map_qvs([]) == ([], [])
+
+
+def _sam_through(orc, c, derived):
+    """(oracle line, library line) for a SAM case; the CIGAR is made on all-A aligned sequences, which is what the
+    reference harness gives PrintAlignment."""
+    n = max(c["q_pos"], c["t_pos"]) + int(sum(c["blocks"][-1])) + 8
+    a = np.full(n, ord("A"), dtype=np.uint8)
+    cig, clips = blasr_amd.cigar(a, a, c["q_pos"], c["t_pos"], blocks=c["blocks"], clipping=c["clipping"],
+                                 t_strand=c["t_strand"], read_length=c["read_length"],
+                                 low_quality_prefix=c["low_quality_prefix"], low_quality_suffix=c["low_quality_suffix"],
+                                 subread_start=c["subread_start"], subread_end=c["subread_end"],
+                                 q_align_start=derived[0], q_align_end=derived[1])
+    kw = {k: c[k] for k in ("clipping", "q_strand", "t_strand", "is_primary", "read_length", "low_quality_prefix",
+                            "low_quality_suffix", "subread_start", "subread_end", "t_length", "q_length",
+                            "q_aligned_seq_pos", "q_aligned_seq_length", "map_qv", "score", "edit_dist", "hole_number",
+                            "qs", "qe", "num_passes", "subread_context", "read_quality", "snr")}
+    lib_line = blasr_amd.sam_line(c["q_name"], c["t_name"], c["read_group_id"], cig, clips, c["read_seq"], c["read_qual"],
+                                  q_align_start=derived[0], q_align_end=derived[1], t_align_start=derived[2],
+                                  t_end=derived[3], **kw)
+    return orc.sam_line(c, cig, clips, derived), lib_line
+
+
+def test_sam_line_golden(golden, orc):
+    for i in range(int(golden["sam_n"])):
+        q_name, t_name, rg = _s(golden["sam%d_names" % i]).split("\n")
+        c = dict(zip(T.SAM_INT_FIELDS, (int(v) for v in golden["sam%d_int" % i])))
+        fv = [float(v) for v in golden["sam%d_float" % i]]
+        qual = golden["sam%d_qual" % i]
+        c.update(q_name=q_name, t_name=t_name, read_group_id=rg, read_seq=golden["sam%d_seq" % i],
+                 read_qual=qual if len(qual) else None, blocks=golden["sam%d_blocks" % i], read_quality=fv[0], snr=fv[1:])
+        derived = tuple(int(v) for v in golden["sam%d_derived" % i])
+        want = _s(golden["sam%d_line" % i])
+        got_oracle, got_lib = _sam_through(orc, c, derived)
+        assert got_oracle == want, i
+        assert got_lib == want, i
+        assert want.endswith("\n") and len(want.split("\t")) >= 12
 
 
 def test_cigar_library_against_oracle_on_random_cases(orc):

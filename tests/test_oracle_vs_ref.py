@@ -122,3 +122,13 @@ def test_epilogue_pieces_against_the_reference_printers():
         par = dict(ins=[5, 4, 8][it % 3], dele=[5, 5, 8][it % 3], affine_open=[50, 30, 10][it % 3],
                    affine_extend=[0, 1][it % 2], affine_align=it % 2)
         assert orc.store_map_qvs(alns, qv, **par) == rf.store_map_qvs(alns, qv, **par), it
+    for it in range(300):  # the SAM record: the reference harness against the oracle (CIGAR from the library)
+        c = T.random_sam_case(rng, it)
+        line, derived = rf.sam_line(c)
+        n = max(c["q_pos"], c["t_pos"]) + int(sum(c["blocks"][-1])) + 8
+        a = np.full(n, ord("A"), dtype=np.uint8)
+        cig, clips = orc.cigar(a, a, c["q_pos"], c["t_pos"], blocks=c["blocks"], clipping=c["clipping"],
+                               t_strand=c["t_strand"], read_length=c["read_length"], lqp=c["low_quality_prefix"],
+                               lqs=c["low_quality_suffix"], subread_start=c["subread_start"],
+                               subread_end=c["subread_end"], q_align_start=derived[0], q_align_end=derived[1])
+        assert orc.sam_line(c, cig, clips, derived) == line, it
