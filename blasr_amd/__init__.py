@@ -22,6 +22,7 @@ from .hip import (  # noqa: F401
     cigar,
     m4_line,
     map_qvs,
+    order_gaps_by_type,
     sam_line,
     ref_contig_location,
     CANDIDATE_DTYPE,

@@ -6,6 +6,7 @@
 //   blasr_hip_m4_line               IntervalAlignmentPrinter::Print     printers/IntervalAlignmentPrinter.h:9-38
 //   blasr_hip_map_qvs               StoreMapQVs and its helpers         alignment/Blasr.cpp:2647-2950
 //   blasr_hip_sam_line              SAMOutput::PrintAlignment           printers/SAMPrinter.h:29-105, 418-548
+//   blasr_hip_order_gaps_by_type    Alignment::OrderGapsByType          datastructures/alignment/Alignment.h:255-317
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -459,5 +460,50 @@ extern "C" int blasr_hip_sam_line(const blasr_hip_sam_fields *f, char *line, int
   *line_len = (int64_t)s.size();
   if (!line || (int64_t)s.size() + 1 > line_cap) return BLASR_HIP_ERR_CAPACITY;
   memcpy(line, s.c_str(), s.size() + 1);
+  return BLASR_HIP_OK;
+}
+
+// -forPicard (Blasr.cpp:2621-2626): samtools / picard reject insertion-deletion-insertion patterns, so the gaps
+// between two blocks are condensed to ONE gap of the longer kind, shortened by the other kind's bases, which become
+// aligned columns of the block before (Alignment.h:255-317).  The blocks stay separate blocks.
+extern "C" int blasr_hip_order_gaps_by_type(const uint32_t *ops, int64_t n_ops, uint32_t *out, int64_t out_cap,
+                                            int64_t *n_out) {
+  if (!ops || n_ops <= 0 || !n_out) return BLASR_HIP_ERR_INVALID;
+  std::vector<uint32_t> r;
+  int64_t i = 0;
+  while (i < n_ops) {
+    if ((ops[i] & 3u) == 0u) {
+      r.push_back(ops[i]);
+      i++;
+      continue;
+    }
+    int64_t j = i;
+    uint32_t target = 0, query = 0;  // Gap::Target = insertion (op 1), Gap::Query = deletion (op 2)
+    while (j < n_ops && (ops[j] & 3u) != 0u) {
+      if ((ops[j] & 3u) == 1u) target += ops[j] >> 2; else query += ops[j] >> 2;
+      j++;
+    }
+    if (j - i <= 1 || r.empty()) {  // a single gap stays as it is
+      for (int64_t k = i; k < j; k++) r.push_back(ops[k]);
+    } else {
+      uint32_t matchExtend;
+      uint32_t gap = 0;
+      if (target > query) {
+        gap = ((target - query) << 2) | 1u;
+        matchExtend = query;
+      } else if (query > target) {
+        gap = ((query - target) << 2) | 2u;
+        matchExtend = target;
+      } else {
+        matchExtend = target;
+      }
+      r.back() += matchExtend << 2;  // blocks[g-1].length += matchExtend
+      if (gap) r.push_back(gap);
+    }
+    i = j;
+  }
+  *n_out = (int64_t)r.size();
+  if (!out || (int64_t)r.size() > out_cap) return BLASR_HIP_ERR_CAPACITY;
+  memcpy(out, r.data(), sizeof(uint32_t) * r.size());
   return BLASR_HIP_OK;
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
-    "blasr_hip_sam_line",
+    "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -302,6 +302,19 @@ def m4_line(q_name, t_name, score, pct_similarity, q_strand, q_align_start, q_al
     if rc < 0:
         raise BlasrHipError(rc, "m4_line")
     return out.value.decode()
+
+
+def order_gaps_by_type(ops):
+    """Alignment::OrderGapsByType (Alignment.h:255-317, -forPicard) on an op list."""
+    lib = load_library()
+    o = np.ascontiguousarray(ops, dtype=np.uint32)
+    out = np.zeros(max(len(o), 1), dtype=np.uint32)
+    n = C.c_int64(0)
+    rc = lib.blasr_hip_order_gaps_by_type(o.ctypes.data_as(C.c_void_p), C.c_int64(len(o)), out.ctypes.data_as(C.c_void_p),
+                                          C.c_int64(len(out)), C.byref(n))
+    if rc < 0:
+        raise BlasrHipError(rc, "order_gaps_by_type")
+    return out[: n.value].copy()
 
 
 class _SamFields(C.Structure):

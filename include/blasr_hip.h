@@ -464,6 +464,13 @@ typedef struct blasr_hip_sam_fields {
 } blasr_hip_sam_fields;
 int blasr_hip_sam_line(const blasr_hip_sam_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
 
+/* Alignment::OrderGapsByType (datastructures/alignment/Alignment.h:255-317), which MapRead applies under -forPicard
+ * (alignment/Blasr.cpp:2621-2626), on an op list: where two blocks are separated by more than one gap, the gaps
+ * are condensed to one of the longer kind, shortened by the bases of the other kind, which extend the block
+ * before.  out may alias nothing; *n_out receives the new length (<= n_ops). */
+int blasr_hip_order_gaps_by_type(const uint32_t *ops, int64_t n_ops, uint32_t *out, int64_t out_capacity,
+                                 int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2403,3 +2403,34 @@ int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, c
 #undef SAM_PUT
   return at;
 }
+
+/* Alignment::OrderGapsByType (Alignment.h:255-317): gap list g sits between block g-1 and block g; lists with more
+ * than one gap are replaced by the net gap, and the bases that cancel lengthen block g-1. */
+long bo_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out) {
+  long i = 0, n = 0;
+  while (i < nOps) {
+    long j = i, k;
+    unsigned targetLen = 0, queryLen = 0;
+    if ((ops[i] & 3u) == 0) {
+      out[n++] = ops[i++];
+      continue;
+    }
+    while (j < nOps && (ops[j] & 3u) != 0) {
+      if ((ops[j] & 3u) == 1) targetLen += ops[j] >> 2; else queryLen += ops[j] >> 2;
+      j++;
+    }
+    if (j - i <= 1 || n == 0) {
+      for (k = i; k < j; k++) out[n++] = ops[k];
+    } else if (targetLen > queryLen) {
+      out[n - 1] += queryLen << 2;
+      out[n++] = ((targetLen - queryLen) << 2) | 1u;
+    } else if (queryLen > targetLen) {
+      out[n - 1] += targetLen << 2;
+      out[n++] = ((queryLen - targetLen) << 2) | 2u;
+    } else {
+      out[n - 1] += targetLen << 2;
+    }
+    i = j;
+  }
+  return n;
+}

@@ -142,6 +142,9 @@ int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, c
                 const unsigned char *readQual, const char *cigar, const unsigned *clips4, const int *iv, const float *fv,
                 char *out, int outCap);
 
+/* next-2: Alignment::OrderGapsByType (Alignment.h:255-317) on an op list; returns the new number of ops */
+long bo_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,3 +398,24 @@ int ref_sam_line(const char *qName, const char *tName, const char *readGroupId, 
 }
 
 }  // extern "C"
+
+extern "C" {
+
+// Alignment::OrderGapsByType on the alignment of an op list, turned back into an op list; returns its length
+long ref_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out) {
+  T_AlignmentCandidate a;
+  static unsigned char dummy[1] = {0};
+  fill_alignment(a, dummy, dummy, 0, 0, ops, nOps, NULL, 0);
+  a.qAlignedSeq.seq = a.tAlignedSeq.seq = NULL;
+  a.OrderGapsByType();
+  long n = 0;
+  for (size_t b = 0; b < a.blocks.size(); b++) {
+    out[n++] = ((unsigned)a.blocks[b].length << 2) | 0u;
+    if (b + 1 < a.gaps.size())
+      for (size_t g = 0; g < a.gaps[b + 1].size(); g++)
+        out[n++] = ((unsigned)a.gaps[b + 1][g].length << 2) | (a.gaps[b + 1][g].seq == Gap::Target ? 1u : 2u);
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -738,3 +738,15 @@ def random_sam_case(rng, it):
                 num_passes=int(rng.integers(0, 9)), subread_context=int(rng.integers(0, 4)),
                 read_quality=float(np.float32([0.0, 0.8, 0.85331, 1.0, 0.123456][it % 5])),
                 snr=[float(np.float32(v)) for v in rng.random(4) * [12, 9, 7, 100]])
+
+
+def _order_gaps_by_type(checker, ops):
+    o = np.ascontiguousarray(ops, dtype=np.uint32)
+    out = np.zeros(len(o) + 1, dtype=np.uint32)
+    fn = checker.lib.bo_order_gaps_by_type if checker.kind == "oracle" else checker.lib.ref_order_gaps_by_type
+    fn.restype = C.c_long
+    n = fn(_pu(o), C.c_long(len(o)), _pu(out))
+    return out[:n].copy()
+
+
+EpilogueChecker.order_gaps_by_type = _order_gaps_by_type

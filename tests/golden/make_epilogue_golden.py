@@ -103,6 +103,9 @@ def main():
                                                      a["q_strand"], a["q_length"], a["n_match"]], dtype=np.int64)
         g["mapqv%d_out" % i] = np.array(map_qv, dtype=np.int64)
         g["mapqv%d_prob" % i] = np.array(prob, dtype=np.float32)
+    # Alignment::OrderGapsByType on the op lists of the CIGAR cases
+    for i, c in enumerate(cg):
+        g["cigar%d_ordered" % i] = ref.order_gaps_by_type(c["ops"])
     # SAMOutput::PrintAlignment
     n_sam = 64
     g["sam_n"] = np.array(n_sam)

@@ -111,6 +111,20 @@ def test_map_qvs_library_against_oracle_on_random_reads(orc):
     assert blasr_amd.map_qvs([]) == ([], [])
 
 
+def test_order_gaps_by_type_golden(golden, orc):
+    changed = 0
+    for i in range(int(golden["cigar_n"])):
+        ops, want = golden["cigar%d_ops" % i], golden["cigar%d_ordered" % i]
+        assert np.array_equal(orc.order_gaps_by_type(ops), want), i
+        got = blasr_amd.order_gaps_by_type(ops)
+        assert np.array_equal(got, want), i
+        # the transformation keeps the extent of the alignment on both sequences
+        ext = lambda o: (sum(int(w >> 2) for w in o if w & 3 != 2), sum(int(w >> 2) for w in o if w & 3 != 1))  # noqa: E731
+        assert ext(got) == ext(ops), i
+        changed += len(want) != len(ops)
+    assert changed > 10
+
+
 def _sam_through(orc, c, derived):
     """(oracle line, library line) for a SAM case; the CIGAR is made on all-A aligned sequences, which is what the
     reference harness gives PrintAlignment."""

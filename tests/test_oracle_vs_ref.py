@@ -103,6 +103,7 @@ def test_epilogue_pieces_against_the_reference_printers():
             rf.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], ops=c["ops"], **kw), i
         assert orc.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], blocks=c["blocks"], **kw) == \
             rf.cigar(c["q"], c["t"], c["q_pos"], c["t_pos"], blocks=c["blocks"], **kw), i
+        assert np.array_equal(orc.order_gaps_by_type(c["ops"]), rf.order_gaps_by_type(c["ops"])), i
     for it in range(300):
         ncontig = int(rng.integers(1, 7))
         lens = rng.integers(100, 3000, ncontig)
