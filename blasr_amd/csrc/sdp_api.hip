@@ -76,25 +76,16 @@ int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t cou
   return BLASR_HIP_OK;
 }
 
-int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
-                         const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
-                         int64_t blocksCap, int64_t *blocksUsed) {
-  if (!ctx) return BLASR_HIP_ERR_INVALID;
-  if (!b || !sp || !score || b->n < 0 || blocksCap < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
-  if (blocksUsed) *blocksUsed = 0;
-  for (int i = 0; i < 4; i++) ctx->sdpMs[i] = 0;
-  for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = 0;
+}  // extern "C"
+
+namespace {
+
+// One chunk of a batch: arguments validated by blasr_hip_sdp_device; blk_off of the results counts from blkBase
+// (the blocks of the chunks before), `blocks` / `blocksCap` are what is left of the caller's arena.
+int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
+                     const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                     int64_t blocksCap, int64_t *blocksUsed, int64_t blkBase) {
   const int n = b->n;
-  if (n == 0) return BLASR_HIP_OK;
-  if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
-    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
-  if ((sp->align_type != 0 && sp->align_type != 1) || sp->detailed != 1 || sp->extend_front != 0 ||
-      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
-      sp->sdp_ins >= 64 || sp->sdp_del <= -64 || sp->sdp_del >= 64)
-    return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
-                          "SDP parameters outside the device domain (align_type Local/Global, detailed=1, "
-                          "extend_front=0, 1 <= word_size <= 16, |sdp_ins|, |sdp_del| < 64)");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   Arena arena(ctx, st);
   hipEvent_t evA, evB;
@@ -465,7 +456,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   launch_pool_offsets(sortedKeys, nPool, n, blkOff, st);
   launch_sdp_finish(n, dTop, b->seq, sortedKeys, sortedVals, blkOff, dMatrix, score->ins, score->del,
                     score->affine_open, score->affine_extend, reinterpret_cast<SdpResult *>(results), blocks, blocksCap,
-                    st);
+                    blkBase, st);
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   tock(3);
@@ -477,7 +468,93 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   ctx->sdpCounters[2] = swTotal;
   if (blocksUsed) *blocksUsed = nPool;
   if (nPool > blocksCap)
-    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "blocks arena too small: need %lld, have %lld", (long long)nPool,
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "blocks arena too small: need %lld more, have %lld",
+                          (long long)nPool, (long long)blocksCap);
+  return BLASR_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
+                         const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
+                         int64_t blocksCap, int64_t *blocksUsed) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !sp || !score || b->n < 0 || blocksCap < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
+  if (blocksUsed) *blocksUsed = 0;
+  for (int i = 0; i < 4; i++) ctx->sdpMs[i] = 0;
+  for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = 0;
+  const int n = b->n;
+  if (n == 0) return BLASR_HIP_OK;
+  if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
+  if ((sp->align_type != 0 && sp->align_type != 1) || sp->detailed != 1 || sp->extend_front != 0 ||
+      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
+      sp->sdp_ins >= 64 || sp->sdp_del <= -64 || sp->sdp_del >= 64)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
+                          "SDP parameters outside the device domain (align_type Local/Global, detailed=1, "
+                          "extend_front=0, 1 <= word_size <= 16, |sdp_ins|, |sdp_del| < 64)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // ---- chunks.  The level arrays take ~35 bytes per base of query + target (fragments, keys, the sweep's arrays,
+  // the block pool); a batch that would not fit what the device can give this context is taken in pieces.  Tasks
+  // are independent, so the pieces only share the caller's block arena.
+  std::vector<int32_t> qLen((size_t)n), tLen((size_t)n);
+  HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), b->q_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), b->t_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t budgetBases = INT64_MAX;
+  {
+    size_t freeB = 0, totalB = 0, held = 0;
+    for (auto &sl : ctx->slabs) held += sl.second;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+      const int64_t reserve = std::max<int64_t>((int64_t)2 << 30, (int64_t)(totalB / 32));
+      const int64_t reach = (int64_t)held + (int64_t)freeB - reserve;
+      budgetBases = std::max<int64_t>(reach / 48, 1 << 20);
+    } else {
+      (void)hipGetLastError();
+    }
+    if (const char *e = getenv("BLASR_HIP_SDP_CHUNK_BASES")) budgetBases = std::max<int64_t>(atoll(e), 1);
+  }
+  std::vector<int> cut(1, 0);
+  {
+    int64_t acc = 0;
+    for (int i = 0; i < n; i++) {
+      const int64_t bases = (int64_t)std::max(qLen[i], 0) + std::max(tLen[i], 0);
+      if (i > cut.back() && acc + bases > budgetBases) {
+        cut.push_back(i);
+        acc = 0;
+      }
+      acc += bases;
+    }
+    cut.push_back(n);
+  }
+  float ms[4] = {0, 0, 0, 0};
+  int64_t counters[3] = {0, 0, 0}, used = 0;
+  bool overflow = false;
+  for (size_t c = 0; c + 1 < cut.size(); c++) {
+    const int first = cut[c], cnt = cut[c + 1] - cut[c];
+    blasr_hip_sdp_batch sub = *b;
+    sub.n = cnt;
+    sub.q_off = b->q_off + first;
+    sub.q_len = b->q_len + first;
+    sub.t_off = b->t_off + first;
+    sub.t_len = b->t_len + first;
+    const int64_t left = std::max<int64_t>(blocksCap - used, 0);
+    int64_t usedHere = 0;
+    const int rc = sdp_device_chunk(ctx, &sub, sp, score, results + first, blocks ? blocks + 3 * std::min(used, blocksCap) : nullptr,
+                                    left, &usedHere, used);
+    if (rc == BLASR_HIP_ERR_CAPACITY) overflow = true;
+    else if (rc != BLASR_HIP_OK) return rc;
+    used += usedHere;
+    for (int i = 0; i < 4; i++) ms[i] += ctx->sdpMs[i];
+    for (int i = 0; i < 3; i++) counters[i] += ctx->sdpCounters[i];
+  }
+  for (int i = 0; i < 4; i++) ctx->sdpMs[i] = ms[i];
+  for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = counters[i];
+  if (blocksUsed) *blocksUsed = used;
+  if (overflow)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "blocks arena too small: need %lld, have %lld", (long long)used,
                           (long long)blocksCap);
   return BLASR_HIP_OK;
 }

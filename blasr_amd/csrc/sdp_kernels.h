@@ -118,7 +118,7 @@ struct SdpResult {  // layout-identical to blasr_hip_sdp_result
 void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const uint64_t *poolKeys,
                        const uint64_t *poolVals, const int64_t *blkOff,
                        const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
-                       int64_t blocksCap, hipStream_t st);
+                       int64_t blocksCap, int64_t blkBase, hipStream_t st);
 void launch_pool_offsets(const uint64_t *poolKeys, int64_t nPool, int n, int64_t *off, hipStream_t st);
 // tLen (or the three raw fragment counts summed, or nFrag) of every task as int64, for the offset scans
 void launch_sdp_gather_sizes(const SdpLevelArrays &lv, int what, int64_t *out, hipStream_t st);

@@ -2950,7 +2950,8 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
                                                          const uint64_t *poolKeys, const uint64_t *poolVals,
                                                          const int64_t *blkOff,
                                                          const int32_t *matrix, int ins, int del, int open, int ext,
-                                                         SdpResult *results, int32_t *blocks, int64_t blocksCap) {
+                                                         SdpResult *results, int32_t *blocks, int64_t blocksCap,
+                                                         int64_t blkBase) {
   __shared__ int m[25];
   if (threadIdx.x < 25) m[threadIdx.x] = matrix[threadIdx.x];
   __syncthreads();
@@ -2965,7 +2966,7 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
   res.status = 0;
   res.score = res.q_pos = res.t_pos = res.stats_score = res.n_match = res.n_mismatch = res.n_ins = res.n_del = 0;
   res.n_blocks = nb;
-  res.blk_off = b0;
+  res.blk_off = b0 + blkBase;  // blkBase: the blocks of the chunks before this one (the arena pointer is already past them)
   if (nb == 0) {
     if (lane == 0) results[idx] = res;
     return;
@@ -3184,10 +3185,10 @@ void launch_sdp_segment_ends(const SdpLevelArrays &lv, int64_t *ends, hipStream_
 void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const uint64_t *poolKeys,
                        const uint64_t *poolVals, const int64_t *blkOff,
                        const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
-                       int64_t blocksCap, hipStream_t st) {
+                       int64_t blocksCap, int64_t blkBase, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(sdp_finish_kernel, wave_grid(n), dim3(256), 0, st, n, tasks, seq, poolKeys, poolVals, blkOff,
-                     matrix, ins, del, open, ext, results, blocks, blocksCap);
+                     matrix, ins, del, open, ext, results, blocks, blocksCap, blkBase);
 }
 
 }  // namespace blasr_hip

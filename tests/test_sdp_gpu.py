@@ -193,3 +193,19 @@ def test_alternative_kernels_agree(ctx, oracle, monkeypatch):
             _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (env, len(q)))
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_batch_taken_in_chunks(ctx, monkeypatch):
+    """A batch too large for the memory the device can give the context is taken in pieces
+    (BLASR_HIP_SDP_CHUNK_BASES forces small ones here): same records, block offsets counted through the pieces."""
+    rng = np.random.default_rng(808)
+    pairs = [synth.make_pair(rng, int(rng.integers(200, 3000)), flank=(0, int(rng.integers(0, 100)))) for _ in range(40)]
+    whole = ctx.sdp(pairs)
+    monkeypatch.setenv("BLASR_HIP_SDP_CHUNK_BASES", "9000")  # a handful of pairs per piece
+    pieces = ctx.sdp(pairs)
+    monkeypatch.delenv("BLASR_HIP_SDP_CHUNK_BASES")
+    assert len(whole) == len(pieces) == len(pairs)
+    for i, (a, b) in enumerate(zip(whole, pieces)):
+        assert (a["status"], a["score"], a["qPos"], a["tPos"]) == (b["status"], b["score"], b["qPos"], b["tPos"]), i
+        assert np.array_equal(a["blocks"], b["blocks"]), i
+        assert a["stats"] == b["stats"], i
