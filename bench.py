@@ -120,7 +120,9 @@ def main():
             self.ref_res = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
             self.ops_cap = int((w["q_len"].sum().item() + w["t_len"].sum().item()) // 2 + 1024)
             self.ops = torch.zeros(self.ops_cap, dtype=torch.int32, device=dev)
-            self.glue = torch.cuda.Stream(device=dev)
+            # the glue between the two calls runs on torch's stream: its own one per thread when several threads map
+            # at once (the default stream would serialise them)
+            self.glue = torch.cuda.Stream(device=dev) if args.contexts > 1 else torch.cuda.current_stream()
             self.acc = {}
 
         def step(self):
