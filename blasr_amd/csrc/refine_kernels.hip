@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
 
   for (int r0 = 1; r0 <= maxQ; r0 += 64) {
     // ---- geometry and query codes of the next 64 rows of every candidate
-    bool wideBatch = false;
+    int passesV = 1;  // lane i: the passes row r0+i takes, i.e. what its widest candidate needs
 #pragma unroll
     for (int g = 0; g < kT; g++) {
       if (taskG[g] >= 0 && r0 <= qG[g]) {
@@ -692,11 +692,10 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           const int width = min(hiV, tEndG[g] - 1) - loV + 1;  // cells with t >= tEnd are skipped (:268-269)
           rowA[wave][g][lane] = make_int2((int)rsV, loV);
           rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
-          wideBatch = wideBatch || width > kF4Pass;
+          passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
         }
       }
     }
-    const bool anyWide = __ballot(wideBatch) != 0ull;
     __builtin_amdgcn_wave_barrier();
     const int nRowsMax = min(64, maxQ - r0 + 1);
     for (int i = 0; i < nRowsMax; i++) {
@@ -716,8 +715,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         }
       }
       __builtin_amdgcn_wave_barrier();
-      int nPass = 1;
-      if (anyWide) nPass = wave_max(rowOn ? (width + kF4Pass - 1) / kF4Pass : 0);
+      const int nPass = __builtin_amdgcn_readlane(passesV, i);
       int carryA = inf, carryB = inf, carryDiag = inf;
       uint8_t *arrowRow = myArrows + (unsigned)rec.x;
       for (int pass = 0; pass < nPass; pass++) {
