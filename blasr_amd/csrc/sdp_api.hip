@@ -282,6 +282,18 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
 
     // ---- chain ----
     tick();
+    if (lv.chainList != nullptr) {
+      // longest invocations first, the four of a wavefront of about the same size
+      uint32_t *ck = arena.get<uint32_t>(nTasks), *ckOut = arena.get<uint32_t>(nTasks);
+      int32_t *cv = arena.get<int32_t>(nTasks);
+      ARENA_CHECK();
+      launch_sdp_chain_list(lv, ck, cv, st);
+      size_t sortBytes = 0;
+      HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(nullptr, sortBytes, ck, ckOut, cv, lv.chainList, (size_t)nTasks, 0u, 32u, st));
+      void *sortTmp = arena.get<char>(sortBytes);
+      ARENA_CHECK();
+      HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, ck, ckOut, cv, lv.chainList, (size_t)nTasks, 0u, 32u, st));
+    }
     launch_sdp_chain(lv, prm, st);
     tock(2);
 

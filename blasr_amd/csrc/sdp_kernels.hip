@@ -1804,18 +1804,22 @@ __device__ __forceinline__ int4 *uniform_ptr(int4 *p, int srcLane) {
   return reinterpret_cast<int4 *>(((uint64_t)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv) {
+// The invocations sdp_chain4_kernel takes, as (fragment count, index) pairs for a descending sort: the four of a
+// wavefront then have about the same number of fragments (the wavefront runs as long as its longest) and the long
+// ones start first.  Entries that are not taken get the key 0 and end up behind the list.
+__global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, uint32_t *keys, int32_t *vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool take = false;
   if (i < lv.n && !lv.fused[i]) {
     if (lv.nFrag[i] == 0) lv.chainEnd[i] = -1;
     else take = true;
   }
+  if (i < lv.n) {
+    keys[i] = take ? (uint32_t)lv.nFrag[i] : 0u;
+    vals[i] = i;
+  }
   const unsigned long long mask = __ballot(take);
-  int base = 0;
-  if (mask != 0ull && lane_id() == 0) base = atomicAdd(lv.chainCount, (int)__popcll(mask));
-  base = __builtin_amdgcn_readfirstlane(base);
-  if (take) lv.chainList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+  if (mask != 0ull && lane_id() == 0) atomicAdd(lv.chainCount, (int)__popcll(mask));
 }
 
 // The sweep of up to four invocations, one per 16-lane group: `on` says whether this lane's group has one, `idx`
@@ -3130,11 +3134,14 @@ void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st) {
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
 }
+void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
+  if (lv.n <= 0) return;
+  (void)hipMemsetAsync(lv.chainCount, 0, sizeof(int32_t), st);
+  hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
+}
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
   if (lv.n <= 0) return;
-  if (lv.chainList != nullptr) {  // four invocations per wavefront
-    (void)hipMemsetAsync(lv.chainCount, 0, sizeof(int32_t), st);
-    hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
+  if (lv.chainList != nullptr) {  // four invocations per wavefront; the list is sorted (launch_sdp_chain_list + sort)
     hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
     hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
