@@ -273,7 +273,22 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     ARENA_CHECK();
     launch_sdp_match(lv, b->seq, true, st);
     launch_sdp_match_index(lv, b->seq, true, st);
-    launch_sdp_small(lv, prm, st);  // invocations with <= 64 fragments: order .. chain in one kernel
+    {  // invocations with <= 64 fragments: order .. chain in one kernel; those with <= 16 four per wavefront, by size
+      int32_t *smallOrder = nullptr;
+      if (!getenv("BLASR_HIP_NO_SMALL4")) {
+        uint32_t *sk = arena.get<uint32_t>(nTasks), *skOut = arena.get<uint32_t>(nTasks);
+        int32_t *sv = arena.get<int32_t>(nTasks);
+        smallOrder = arena.get<int32_t>(nTasks);
+        ARENA_CHECK();
+        launch_sdp_small4_keys(lv, sk, sv, st);
+        size_t sortBytes = 0;
+        HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(nullptr, sortBytes, sk, skOut, sv, smallOrder, (size_t)nTasks, 0u, 5u, st));
+        void *sortTmp = arena.get<char>(sortBytes);
+        ARENA_CHECK();
+        HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, sk, skOut, sv, smallOrder, (size_t)nTasks, 0u, 5u, st));
+      }
+      launch_sdp_small(lv, prm, smallOrder, st);
+    }
     launch_sdp_order(lv, st);
     launch_sdp_yx_keys(lv, st);
     launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);

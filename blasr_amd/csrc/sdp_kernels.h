@@ -89,7 +89,9 @@ void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t s
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st);
-void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st);
+// order: the level's invocations sorted by launch_sdp_small4_keys' keys, descending (nullptr: no sdp_small4_kernel)
+void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st);
+void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_t *order, hipStream_t st);
 int sdp_match_index_max_target(int device);
 void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);

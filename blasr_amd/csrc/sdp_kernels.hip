@@ -2128,14 +2128,26 @@ __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, S
 // comparison inside the group, duplicates dropped, StoreAbove and the sweep set's predecessor the same way; the
 // sweep itself is chain4_body's.
 constexpr int kSmall4Max = 16;
-__global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, SdpParams prm) {
+// order[] lists the level's invocations by their number of raw fragments, descending (those with more than
+// kSmall4Max first): the four of a wavefront are of a size -- its loops run to the largest -- and the big ones go
+// first.  sdp_small4_keys_kernel writes the sort keys.
+__global__ __launch_bounds__(256) void sdp_small4_keys_kernel(SdpLevelArrays lv, uint32_t *keys, int32_t *vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv.n) return;
+  const int nAll = lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
+  keys[i] = (uint32_t)min(nAll, kSmall4Max + 1);
+  vals[i] = i;
+}
+__global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, SdpParams prm, const int32_t *order) {
   const int lane = lane_id(), l = lane & 15, gb = lane & 48;
-  const int idx0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4;
-  if (idx0 >= lv.n) return;
-  const int idx = idx0 + (lane >> 4);
+  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4;
+  if (slot0 >= lv.n) return;
+  const int slot = slot0 + (lane >> 4);
+  const int idx0 = order[slot0];  // any valid invocation, for the lanes without one
+  const int idx = slot < lv.n ? order[slot] : idx0;
   int nAll = 0;
-  if (idx < lv.n) nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
-  const bool mine = idx < lv.n && nAll <= kSmall4Max;
+  if (slot < lv.n) nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
+  const bool mine = slot < lv.n && nAll <= kSmall4Max;
   if (__ballot(mine) == 0ull) return;
   const int64_t base = mine ? lv.fragOff[idx] : 0;
   auto gbp = [&](int v, int i) { return __builtin_amdgcn_ds_bpermute((gb + (i & 15)) << 2, v); };
@@ -2194,7 +2206,7 @@ __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, S
     lv.nFrag[idx] = F;
     lv.fused[idx] = 1;
   }
-  const int k = lv.tasks[mine ? idx : idx0].k;
+  const int k = lv.tasks[idx].k;
   // ---- StoreAbove (SparseDynamicProgramming.h:55-68): the neighbour in (y,x) order
   int r2 = 0;
   for (int j = 0; j < maxN; j++) {
@@ -3114,10 +3126,13 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
       hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
   }
 }
-void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
+void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_small4_keys_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
+}
+void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_t *order, hipStream_t st) {
   if (lv.n <= 0) return;
-  const bool small4 = getenv("BLASR_HIP_NO_SMALL4") == nullptr;
-  if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+  const bool small4 = order != nullptr;
+  if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p, order);
   hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, small4 ? kSmall4Max + 1 : 0);
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
