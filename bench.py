@@ -17,7 +17,7 @@ scaling, no data-path collective; one RCCL all-reduce of the run counters at the
 
 --contexts C maps the batch with C host threads at once, each through its own context (the C ABI's "one context
 per host thread", the reference's -nproc).  Kernels of two independent streams fill the tails and the
-latency-bound phases of each other's: 248 ms per pass with two threads against 274 ms with one.
+latency-bound phases of each other's: 247 ms per pass with two threads against 271 ms with one.
 The default is ONE, so that every kernel has the GPU to itself and the roofline block means what it says; with
 two the same launches take 36-58 ms depending on what they happen to share the GPU with.
 
@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55460159904.0}
+PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55459493568.0}
 
 
 def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
@@ -250,7 +250,7 @@ def main():
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
                          "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v17_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "profiles/r01_v18_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
                                          "of the fillp_kernel<16> launch",
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
                          "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
