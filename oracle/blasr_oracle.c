@@ -1141,6 +1141,17 @@ static int cell_index(const guide_row *g, int nRows, int row, int col) {
   return -1;
 }
 
+/* A probe for the design of a 16-bit fill: over all rows filled since the last reset, the
+ * largest spread of S within a row (max - min over its cells), the number of rows, and how many had a spread of
+ * 512 / 1024 or more.  Test infrastructure like the rest of this file. */
+static long g_probe[4];
+static int g_probe_on;
+void bo_probe_row_spread(int enable, long *out4) {
+  if (out4 != NULL) memcpy(out4, g_probe, sizeof g_probe);
+  g_probe_on = enable;
+  memset(g_probe, 0, sizeof g_probe);
+}
+
 static int affine_guided_align(const unsigned char *qSeq, const unsigned char *tSeq,
                                const block_t *guideBlocks, int nGuideBlocks, const score_fn *fn,
                                int bandSize, aln_t *alignment) {
@@ -1181,7 +1192,18 @@ static int affine_guided_align(const unsigned char *qSeq, const unsigned char *t
    * values computed from the same predecessors, so it is not restated. */
   for (int q = qStart; q < qEnd; q++) {
     int qi = q - qStart + 1;
-    for (int t = g[qi].t - g[qi].tPre; t < g[qi].t + g[qi].tPost + 1; t++) {
+    int rowMin = INF_INT, rowMax = -INF_INT;
+    for (int t = g[qi].t - g[qi].tPre; t <= g[qi].t + g[qi].tPost + 1; t++) {
+      if (t == g[qi].t + g[qi].tPost + 1) { /* the row is done */
+        if (g_probe_on && rowMin != INF_INT) {
+          long spread = (long)rowMax - rowMin;
+          if (spread > g_probe[0]) g_probe[0] = spread;
+          g_probe[1]++;
+          if (spread >= 512) g_probe[2]++;
+          if (spread >= 1024) g_probe[3]++;
+        }
+        break;
+      }
       if (t < -1) continue;
       if (t >= tEnd) continue;
       int mi = cell_index(g, nRows, qi - 1, t - 1), ii = cell_index(g, nRows, qi - 1, t),
@@ -1202,6 +1224,10 @@ static int affine_guided_align(const unsigned char *qSeq, const unsigned char *t
       if (insExt < mn) mn = insExt;
       if (delExt < mn) mn = delExt;
       S[cur] = mn;
+      if (mn != INF_INT) {
+        if (mn < rowMin) rowMin = mn;
+        if (mn > rowMax) rowMax = mn;
+      }
       if (mn == INF_INT)
         PS[cur] = A_NONE;
       else if (mn == matchScore)

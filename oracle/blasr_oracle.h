@@ -145,6 +145,10 @@ int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, c
 /* next-2: Alignment::OrderGapsByType (Alignment.h:255-317) on an op list; returns the new number of ops */
 long bo_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out);
 
+/* design probe: {largest row spread of S, rows, rows with spread >= 512, >= 1024} of the
+ * AffineGuidedAlign fills since the last call; enable != 0 keeps counting */
+void bo_probe_row_spread(int enable, long *out4);
+
 #ifdef __cplusplus
 }
 #endif
