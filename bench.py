@@ -37,15 +37,38 @@ sys.path.insert(0, ROOT)
 PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55459493568.0}
 
 
-def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
-    """The CPU oracle (bit-exact port of SDPAlign + AffineGuidedAlign + ComputeAlignmentStats) timed on
-    one host core over the first `n_sample` candidates of the same workload.  Checker code: never on the
-    product path.  Since the oracle's answers are at hand, the device's result records of the same candidates
-    (from the last timed step) are compared with them field by field."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from blasr_testlib import load_oracle
+def reference_candidate(ref, q, t, band):
+    """One candidate through the REFERENCE's own functions (oracle/_ref/libblasr_ref.so: SDPAlign,
+    ComputeAlignmentStats, AffineGuidedAlign compiled from the reference sources), in the order of
+    AlignIntervals (Blasr.cpp:1716-1724) and RefineAlignment (:850-914); the same fields as the oracle's
+    refine_candidate."""
+    sdp = ref.sdp_align(q, t)
+    blocks = sdp["blocks"]
+    st = ref.compute_alignment_stats(q, t, sdp["qPos"], sdp["tPos"], blocks)
+    out = dict(sdpScore=sdp["score"], sdpStatsScore=st["score"], sdpQPos=sdp["qPos"], sdpTPos=sdp["tPos"],
+               nSdpBlocks=len(blocks), dpScore=0, nCells=0, score=0, nMatch=0, nMismatch=0, nIns=0, nDel=0,
+               qPos=sdp["qPos"], tPos=sdp["tPos"])
+    if len(blocks):
+        last = blocks[-1]
+        qs = q[sdp["qPos"]: sdp["qPos"] + int(last[0] + last[2])]
+        ts = t[sdp["tPos"]: sdp["tPos"] + int(last[1] + last[2])]
+        r = ref.affine_guided_align(qs, ts, blocks, band=band)
+        out.update({k: r[k] for k in ("dpScore", "nCells", "score", "nMatch", "nMismatch", "nIns", "nDel")})
+        out["qPos"], out["tPos"] = sdp["qPos"] + r["qPos"], sdp["tPos"] + r["tPos"]
+    return out
 
-    oracle = load_oracle()
+
+def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
+    """The path on one host core over the first `n_sample` candidates of the same workload: through the
+    reference's own code where its build is at hand (oracle/_ref/libblasr_ref.so, kind "reference"), else through
+    the oracle (its bit-exact restatement, kind "port").  Checker code: never on the product path.  Since the CPU
+    answers are at hand, the device's result records of the same candidates (from the last timed step) are
+    compared with them field by field."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from blasr_testlib import load_oracle, load_ref
+
+    ref = load_ref()
+    oracle = None if ref is not None else load_oracle()
     seq = w["seq"].cpu().numpy()
     q_off, q_len = w["q_off"][:n_sample].cpu().numpy(), w["q_len"][:n_sample].cpu().numpy()
     t_off, t_len = w["t_off"][:n_sample].cpu().numpy(), w["t_len"][:n_sample].cpu().numpy()
@@ -53,7 +76,7 @@ def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
     res = []
     t0 = time.perf_counter()
     for q, t in tasks:
-        res.append(oracle.refine_candidate(q, t, band=band))
+        res.append(reference_candidate(ref, q, t, band) if ref is not None else oracle.refine_candidate(q, t, band=band))
     dt = time.perf_counter() - t0
     bases = int(q_len.sum())
     mismatches = 0
@@ -65,9 +88,11 @@ def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
         cpu = (o["sdpScore"], o["sdpStatsScore"], o["sdpQPos"], o["sdpTPos"], o["nSdpBlocks"], o["dpScore"],
                o["nCells"], o["score"], o["nMatch"], o["nMismatch"], o["nIns"], o["nDel"], o["qPos"], o["tPos"])
         mismatches += dev != cpu or int(s[0]) != 0 or int(r[0]) != 0
-    return dict(value=bases / dt, unit="bases/s", cores=1, kind="port",
-                sample="first %d candidates of the same workload, SDP + refine (%.1f s, %.1f ms/read on one core)"
-                       % (n_sample, dt, dt / n_sample * 1e3),
+    what = ("the reference's own SDPAlign + AffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
+            if ref is not None else "the oracle's restatement of SDP + refine")
+    return dict(value=bases / dt, unit="bases/s", cores=1, kind="reference" if ref is not None else "port",
+                sample="first %d candidates of the same workload through %s (%.1f s, %.1f ms/read on one core)"
+                       % (n_sample, what, dt, dt / n_sample * 1e3),
                 parity_checked=len(res), parity_mismatches=mismatches)
 
 
