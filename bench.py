@@ -58,7 +58,7 @@ def reference_candidate(ref, q, t, band):
     return out
 
 
-def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
+def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec, cores=1):
     """The path on one host core over the first `n_sample` candidates of the same workload: through the
     reference's own code where its build is at hand (oracle/_ref/libblasr_ref.so, kind "reference"), else through
     the oracle (its bit-exact restatement, kind "port").  Checker code: never on the product path.  Since the CPU
@@ -73,10 +73,17 @@ def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
     q_off, q_len = w["q_off"][:n_sample].cpu().numpy(), w["q_len"][:n_sample].cpu().numpy()
     t_off, t_len = w["t_off"][:n_sample].cpu().numpy(), w["t_len"][:n_sample].cpu().numpy()
     tasks = [(seq[q_off[i]: q_off[i] + q_len[i]], seq[t_off[i]: t_off[i] + t_len[i]]) for i in range(n_sample)]
-    res = []
+    one = (lambda qt: reference_candidate(ref, qt[0], qt[1], band)) if ref is not None else \
+          (lambda qt: oracle.refine_candidate(qt[0], qt[1], band=band))
     t0 = time.perf_counter()
-    for q, t in tasks:
-        res.append(reference_candidate(ref, q, t, band) if ref is not None else oracle.refine_candidate(q, t, band=band))
+    if cores <= 1:
+        res = [one(qt) for qt in tasks]
+    else:
+        # the reference's -nproc: its functions are re-entrant (one MappingBuffers per call here), and ctypes
+        # releases the interpreter lock for the duration of a call, so host threads do run side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=cores) as pool:
+            res = list(pool.map(one, tasks, chunksize=8))
     dt = time.perf_counter() - t0
     bases = int(q_len.sum())
     mismatches = 0
@@ -90,9 +97,9 @@ def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec):
         mismatches += dev != cpu or int(s[0]) != 0 or int(r[0]) != 0
     what = ("the reference's own SDPAlign + AffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
             if ref is not None else "the oracle's restatement of SDP + refine")
-    return dict(value=bases / dt, unit="bases/s", cores=1, kind="reference" if ref is not None else "port",
-                sample="first %d candidates of the same workload through %s (%.1f s, %.1f ms/read on one core)"
-                       % (n_sample, what, dt, dt / n_sample * 1e3),
+    return dict(value=bases / dt, unit="bases/s", cores=max(cores, 1), kind="reference" if ref is not None else "port",
+                sample="first %d candidates of the same workload through %s (%.1f s on %d host thread%s, %.1f ms/read per thread)"
+                       % (n_sample, what, dt, max(cores, 1), "" if cores <= 1 else "s", dt * max(cores, 1) / n_sample * 1e3),
                 parity_checked=len(res), parity_mismatches=mismatches)
 
 
@@ -106,7 +113,8 @@ def main():
     ap.add_argument("--band", type=int, default=16)
     ap.add_argument("--contexts", type=int, default=1,
                     help="host threads (each with its own context) that map the batch at the same time")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="candidates timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4800, help="candidates timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (0 = min(8, cores))")
     ap.add_argument("--seed", type=int, default=3)
     args = ap.parse_args()
 
@@ -287,9 +295,10 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             m0 = mappers[0]
             ns = min(args.cpu_sample, m0.n)
+            cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(m0.w, ns, args.band,
                                                m0.sdp_res.view(torch.int32).view(m0.n, 12)[:ns].cpu().numpy(),
-                                               rec[:ns].cpu().numpy())
+                                               rec[:ns].cpu().numpy(), cores)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
