@@ -126,3 +126,56 @@ def test_two_host_threads_with_their_own_contexts(oracle):
         for i, ((qs, ts, blocks), g) in enumerate(zip(keep, refined)):
             w = oracle.affine_guided_align(qs, ts, blocks)
             assert g.status == 0 and first_difference(g.as_dict(), w, REFINE_KEYS) is None, (t, i)
+
+
+def test_device_results_through_the_output_epilogue(oracle):
+    """The refine stage's op lists go straight into the epilogue functions (include/blasr_hip.h: map_qvs, cigar,
+    sam_line, m4_line): the printed records made from the DEVICE's results must equal the records the oracle's
+    epilogue makes from the ORACLE's alignments of the same read -- three competing candidates of one read here
+    (the read against its own locus and against two mutated copies of it, a repeat)."""
+    from blasr_testlib import EpilogueChecker, ops_from_alignment
+    rng = np.random.default_rng(31337)
+    orc = EpilogueChecker("oracle")
+    ctx = blasr_amd.Context(0)
+    for trial in range(4):
+        q, t0 = synth.make_pair(rng, int(rng.integers(1500, 5000)), flank=(0, 200))
+        targets = [t0, synth.mutate(t0, rng, 0.004, 0.004, 0.01), synth.mutate(t0, rng, 0.01, 0.01, 0.03)]
+        pairs = [(q, np.ascontiguousarray(t)) for t in targets]
+        sdp = ctx.sdp(pairs)
+        batch, keep = blasr_amd.RefineBatch(), []
+        for (qq, tt), s in zip(pairs, sdp):
+            last = s["blocks"][-1]
+            qs = qq[s["qPos"]: s["qPos"] + last[0] + last[2]]
+            ts = tt[s["tPos"]: s["tPos"] + last[1] + last[2]]
+            batch.add(qs, ts, s["blocks"])
+            keep.append((qs, ts, s))
+        refined = ctx.refine(batch)
+        dev_alns, orc_alns = [], []
+        for (qs, ts, s), r in zip(keep, refined):
+            o = oracle.affine_guided_align(qs, ts, s["blocks"])
+            o_ops = np.array([(ln << 2) | ty for ty, ln in ops_from_alignment(o)], dtype=np.uint32)
+            q_span = lambda ops: int(sum(int(w >> 2) for w in ops if w & 3 != 2))  # noqa: E731
+            dev_alns.append(dict(q=qs, t=ts, ops=r.ops, q_pos=r.qPos, t_pos=r.tPos, q_align_start=s["qPos"] + r.qPos,
+                                 q_align_end=s["qPos"] + r.qPos + q_span(r.ops), q_strand=0, q_length=len(q),
+                                 n_match=r.nMatch))
+            orc_alns.append(dict(q=qs, t=ts, ops=o_ops, q_pos=o["qPos"], t_pos=o["tPos"],
+                                 q_align_start=s["qPos"] + o["qPos"], q_align_end=s["qPos"] + o["qPos"] + q_span(o_ops),
+                                 q_strand=0, q_length=len(q), n_match=o["nMatch"]))
+        got_qv, _ = blasr_amd.map_qvs(dev_alns)
+        want_qv, _ = orc.store_map_qvs(orc_alns)
+        assert got_qv == want_qv, trial
+        for i, (d, o, r) in enumerate(zip(dev_alns, orc_alns, refined)):
+            kw = dict(clipping=blasr_amd.hip.CLIP_SOFT, read_length=len(q), q_align_start=d["q_align_start"],
+                      q_align_end=d["q_align_end"])
+            cig, clips = blasr_amd.cigar(d["q"], d["t"], d["q_pos"], d["t_pos"], ops=d["ops"], **kw)
+            want_cig, want_clips = orc.cigar(o["q"], o["t"], o["q_pos"], o["t_pos"], ops=o["ops"], clipping=1,
+                                             read_length=len(q), q_align_start=o["q_align_start"],
+                                             q_align_end=o["q_align_end"])
+            assert (cig, clips) == (want_cig, want_clips), (trial, i)
+            t_span = int(sum(int(w >> 2) for w in d["ops"] if w & 3 != 1))
+            line = blasr_amd.m4_line("read/%d" % trial, "ref", r.score, float(r.pctSimilarity), 0, d["q_align_start"],
+                                     d["q_align_end"], len(q), 0, d["t_pos"], d["t_pos"] + t_span, len(d["t"]), got_qv[i])
+            want_line, _ = orc.m4_line("read/%d" % trial, "ref", r.score, float(r.pctSimilarity), 0, 0, d["q_align_start"],
+                                       len(q), 0, 0, d["t_pos"], len(d["t"]), want_qv[i],
+                                       [(0, 0, 1), (d["q_align_end"] - d["q_align_start"] - 1, t_span - 1, 1)])
+            assert line == want_line, (trial, i)
