@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end golden on NOISY reads: PacBio-like 1.5-4 kb reads against a two-contig genome with planted repeats,
-mapped by the REFERENCE BINARY (oracle/_ref/blasrmc -m 4 -bestn 1 -nproc 1 -V 1).  Besides the -m 4 lines the
+mapped by the REFERENCE BINARY (oracle/_ref/blasrmc -m 4 -bestn 1 -nproc 1 -V 1, and once more with -sam).  Besides the -m 4 lines and the SAM records the
 fixture keeps the candidate intervals the reference derived from its anchors (the ` intv:` lines of -V 1,
 Blasr.cpp:2508-2517) -- the one thing the device path does not compute itself (anchoring, SURVEY next-1).
 Run from the repo root:  python tests/golden/make_m4_noisy_golden.py"""
@@ -57,6 +57,14 @@ def main():
                             os.path.join(tmp, "genome.fasta"), "-m", "4", "-bestn", "1", "-nproc", "1", "-V", "1",
                             "-out", out], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         lines = open(out).read()
+        sam_out = os.path.join(tmp, "out.sam")
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "blasrmc"), os.path.join(tmp, "reads.fasta"),
+                        os.path.join(tmp, "genome.fasta"), "-sam", "-bestn", "1", "-nproc", "1", "-out", sam_out],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sam = open(sam_out).read()
+    sam_header = "".join(x + "\n" for x in sam.splitlines() if x.startswith("@") and not x.startswith("@PG"))
+    sam_lines = "".join(x + "\n" for x in sam.splitlines() if not x.startswith("@"))
+    assert len(sam_lines.splitlines()) == n_reads
     # the intervals, read by read (one ` intv: index ...` header per read)
     intervals, owner = [], []
     r = -1
@@ -73,7 +81,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "m4_noisy_golden.npz"), contig0=contigs[0], contig1=contigs[1],
                         reads=np.concatenate(reads), read_lens=np.array([len(x) for x in reads], dtype=np.int32),
                         intervals=np.array(intervals, dtype=np.int64), owner=np.array(owner, dtype=np.int32),
-                        lines=np.frombuffer(lines.encode(), dtype=np.uint8))
+                        lines=np.frombuffer(lines.encode(), dtype=np.uint8),
+                        sam_header=np.frombuffer(sam_header.encode(), dtype=np.uint8),
+                        sam_lines=np.frombuffer(sam_lines.encode(), dtype=np.uint8))
     print(lines.splitlines()[0])
 
 

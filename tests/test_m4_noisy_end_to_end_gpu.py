@@ -5,7 +5,8 @@ kept, besides the -m 4 lines, the candidate intervals it derived from its anchor
 order (Blasr.cpp:2530-2644, 3509-3516, 3086): windows -> SDPAlign + statistics per interval -> sort by score ->
 RemoveLowQualityAlignments -> AffineGuidedAlign + statistics -> sort -> RemoveLowQualityAlignments ->
 RemoveOverlappingAlignments -> AssignRefContigLocation -> StoreMapQVs -> the -m 4 line of the best one.
-The lines must equal the reference's byte for byte."""
+The lines must equal the reference's byte for byte, and so must the SAM records of the same alignments (-sam:
+CreateCIGARString + SAMOutput::PrintAlignment)."""
 import os
 
 import numpy as np
@@ -23,6 +24,8 @@ def test_m4_lines_of_noisy_reads_with_the_reference_intervals():
     g = np.load(GOLDEN)
     contigs = [g["contig0"], g["contig1"]]
     want = bytes(g["lines"]).decode().splitlines()
+    want_sam = bytes(g["sam_lines"]).decode().splitlines()
+    read_group = [x for x in bytes(g["sam_header"]).decode().splitlines() if x.startswith("@RG")][0].split("ID:")[1].split("\t")[0]
     read_lens, pool, intervals, owner = g["read_lens"], g["reads"], g["intervals"], g["owner"]
     genome = np.concatenate([contigs[0], [ord("N")], contigs[1], [ord("N")]]).astype(np.uint8)
     starts = np.array([0, len(contigs[0]) + 1, len(contigs[0]) + 1 + len(contigs[1]) + 1], dtype=np.uint32)
@@ -52,7 +55,7 @@ def test_m4_lines_of_noisy_reads_with_the_reference_intervals():
         slot[k] = len(slot)
         batch.add(q[s["qPos"]: s["qPos"] + last[0] + last[2]], t[s["tPos"]: s["tPos"] + last[1] + last[2]], s["blocks"])
     refined = ctx.refine(batch)
-    got = []
+    got, got_sam = [], []
     for r in range(n_reads):
         ks = [k for k in range(n_iv) if owner[k] == r]
         L = int(read_lens[r])
@@ -123,5 +126,27 @@ def test_m4_lines_of_noisy_reads_with_the_reference_intervals():
                                  int(win[k]["t_strand"]), contig_pos + rr.tPos, contig_pos + rr.tPos + t_span,
                                  int(win[k]["t_length"]), map_qv)
         got.append(line.rstrip("\n"))
+        # ---- the SAM record of the same alignment (-sam, clipping none): CIGAR + PrintAlignment
+        a0, strand = alns[0], int(win[k]["t_strand"])
+        # -sam switches forPicard on (MappingParameters.h:488-491), so MapRead has run OrderGapsByType over the
+        # alignment (Blasr.cpp:2621-2626) before it is printed
+        sam_ops = blasr_amd.order_gaps_by_type(rr.ops)
+        if cands[j0]["score"] < MAX_SCORE:  # StoreMapQVs comes after it and scores the re-ordered gap lists
+            map_qv = blasr_amd.map_qvs([dict(x, ops=blasr_amd.order_gaps_by_type(x["ops"])) for x in alns])[0][0]
+        cig, clips = blasr_amd.cigar(a0["q"], a0["t"], rr.qPos, rr.tPos, ops=sam_ops, clipping=blasr_amd.hip.CLIP_NONE,
+                                     t_strand=strand, read_length=L, q_align_start=a0["q_align_start"],
+                                     q_align_end=a0["q_align_end"])
+        read_seq = pool[int(reads[r]["off"]): int(reads[r]["off"]) + L]
+        sam = blasr_amd.sam_line("read%d/%d/0_%d/0_%d" % (r, r, L, L), "contig%d" % contig, read_group, cig, clips,
+                                 read_seq, None, clipping=blasr_amd.hip.CLIP_NONE, q_strand=0, t_strand=strand,
+                                 is_primary=1, read_length=L, subread_start=0, subread_end=L,
+                                 q_align_start=a0["q_align_start"], q_align_end=a0["q_align_end"],
+                                 t_align_start=contig_pos + rr.tPos, t_end=t_span, t_length=int(win[k]["t_length"]),
+                                 q_length=L, q_aligned_seq_pos=int(win[k]["q_aligned_seq_pos"]) + s["qPos"],
+                                 q_aligned_seq_length=len(a0["q"]), map_qv=map_qv, score=rr.score, edit_dist=0,
+                                 hole_number=-1)
+        got_sam.append(sam.rstrip("\n"))
     bad = [(a, b) for a, b in zip(got, want) if a != b]
     assert len(got) == len(want) and not bad, (len(got), len(want), bad[:3])
+    bad = [(a[:300], b[:300]) for a, b in zip(got_sam, want_sam) if a != b]
+    assert len(got_sam) == len(want_sam) and not bad, (len(bad), bad[:2])
