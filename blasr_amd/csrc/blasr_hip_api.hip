@@ -405,10 +405,11 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     fa.taskList = nullptr;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
-    // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes first and on
-    // the side stream, underneath the main fill launches.
+    // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes on the side
+    // stream, underneath fill_kernel's launch (after fillp_kernel when that runs, so its launch is timed alone).
     bool wideLaunched = false, timedFill4 = false;
-    if (!c.wideTasks.empty()) {
+    auto launch_wide = [&]() -> int {
+      if (c.wideTasks.empty()) return 0;
       const int nw = (int)c.wideTasks.size();
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
@@ -420,22 +421,37 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       launch_fill(view, fw, true, fast, ctx->sideStream);
       HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
       wideLaunched = true;
+      return 0;
+    };
+    const bool packed = fast && !getenv("BLASR_HIP_NO_FILL4");
+    if (!packed) {
+      rc = launch_wide();
+      if (rc) return rc;
     }
-    if (fast && !getenv("BLASR_HIP_NO_FILL4")) {
+    if (packed) {
       // candidates whose rows all fit fillp_kernel's passes run four to a wavefront, longest first so the
       // four of a wavefront finish together; the others keep one wavefront each
+      // (the device waits for list4: a counting sort over the row counts, stable in the candidate index; list1 is
+      // sorted while fillp_kernel runs)
       std::vector<int32_t> list4, list1;
-      for (int i = c.first; i < c.first + c.count; i++) {
-        if (geo[i].status != 0) continue;
-        if (geo[i].maxWidth <= fill4_max_width()) list4.push_back(i);
-        else list1.push_back(i);
+      {
+        const int w4 = fill4_max_width();
+        int32_t maxRows = 0;
+        for (int i = c.first; i < c.first + c.count; i++)
+          if (geo[i].status == 0 && geo[i].maxWidth <= w4) maxRows = std::max(maxRows, geo[i].rows);
+        std::vector<int32_t> at((size_t)maxRows + 2, 0);
+        for (int i = c.first; i < c.first + c.count; i++) {
+          if (geo[i].status != 0) continue;
+          if (geo[i].maxWidth <= w4) at[maxRows - geo[i].rows + 1]++;  // slot 0 = the longest
+          else list1.push_back(i);
+        }
+        for (int32_t r = 0; r <= maxRows; r++) at[r + 1] += at[r];
+        list4.resize((size_t)at[maxRows + 1]);
+        for (int i = c.first; i < c.first + c.count; i++)
+          if (geo[i].status == 0 && geo[i].maxWidth <= w4) list4[at[maxRows - geo[i].rows]++] = i;
       }
-      std::stable_sort(list4.begin(), list4.end(), [&](int32_t a, int32_t b) { return geo[a].rows > geo[b].rows; });
-      std::stable_sort(list1.begin(), list1.end(), [&](int32_t a, int32_t b) { return geo[a].cells > geo[b].cells; });
       if (!list4.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dList4, list4.data(), sizeof(int32_t) * list4.size(), hipMemcpyHostToDevice, st));
-      if (!list1.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
       if (!list4.empty()) {
         FillArgs f4 = fa;
         f4.taskList = dList4;
@@ -450,7 +466,14 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         }
         ctx->fill4Launches += 1;
       }
+      rc = launch_wide();
+      if (rc) return rc;
       if (!list1.empty()) {
+        std::vector<std::pair<int64_t, int32_t>> key1(list1.size());
+        for (size_t u = 0; u < list1.size(); u++) key1[u] = {-geo[list1[u]].cells, list1[u]};
+        std::sort(key1.begin(), key1.end());  // = a stable sort by cells, largest first
+        for (size_t u = 0; u < list1.size(); u++) list1[u] = key1[u].second;
+        HIP_TRY(ctx, hipMemcpyAsync(dList1, list1.data(), sizeof(int32_t) * list1.size(), hipMemcpyHostToDevice, st));
         FillArgs f1 = fa;
         f1.taskList = dList1;
         f1.count = (int)list1.size();
