@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55459493568.0}
+PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55454561152.0}
 
 
 def reference_candidate(ref, q, t, band):
@@ -283,7 +283,7 @@ def main():
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
                          "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v18_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "profiles/r01_v19_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
                                          "of the fillp_kernel<16> launch",
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
                          "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
