@@ -94,6 +94,40 @@ def test_windows_match_oracle_random_and_chain_into_sdp(ctx, oracle):
         assert np.array_equal(r["blocks"], o["blocks"])
 
 
+def test_windows_on_a_genome_beyond_two_gigabases():
+    """Coordinates are DNALength = 32-bit unsigned in the reference (Types.h); a human-sized genome puts most of
+    them above 2^31.  3.2 G bases (a random block of prime length, repeated, so that an offset wrong by a power of
+    two lands on different bases), windows all over it, with and without a contig table, both strands."""
+    from blasr_amd import synth
+    mo = MapperOracle()
+    rng = np.random.default_rng(2024)
+    block = synth.random_genome(67108859, 7)
+    genome = np.tile(block, 48)
+    assert 2 ** 31 < len(genome) < 2 ** 32
+    big = blasr_amd.Context(0)
+    cuts = np.array([0, 900_000_011, 2_147_483_000, 2_147_484_500, 3_000_000_019, len(genome)], dtype=np.uint32)
+    try:
+        for contigs in (None, cuts):
+            big.upload_genome(genome, contigs)
+            cases, want = [], []
+            # (its that are multiples of 3 / 7 / 11 make contig tables or genome-long intervals: not here)
+            for it, kind in enumerate([i for i in range(1, 200) if i % 3 and i % 7 and i % 11][:40]):
+                read, subread, iv, _ = random_interval_case(rng, genome, kind)
+                if it % 5 == 0:  # straddle 2^31 (and, with the table, a contig end next to it)
+                    shift = 2 ** 31 - (iv[0] + iv[1]) // 2
+                    iv = (iv[0] + shift, iv[1] + shift, iv[2], iv[3], iv[4])
+                elif it % 5 == 1:  # the top of the coordinate range
+                    shift = 3_150_000_000 + 1000 * it - iv[0]
+                    iv = (iv[0] + shift, iv[1] + shift, iv[2], iv[3], iv[4])
+                cases.append((read, subread, iv))
+                want.append(mo.window(genome, len(read), subread, iv, contigs))
+            assert sum(1 for _, _, iv in cases if iv[0] > 2 ** 31) >= 10 and sum(1 for _, _, iv in cases if iv[0] < 2 ** 31 < iv[1]) >= 8
+            ivs, reads, pool = pack(cases)
+            check(big.windows(ivs, reads, pool), cases, want)
+    finally:
+        big.close()
+
+
 def test_windows_errors(ctx):
     from blasr_amd import synth
     rng = np.random.default_rng(5)
