@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
 PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 55454561152.0}
+# wavefront VALU instructions of the same launch (SQ_INSTS_VALU, same profile)
+PMC_FILL4_VALU_INSTS = {(100000, 10000, 16, 1): 38053789679.0}
 
 
 def reference_candidate(ref, q, t, band):
@@ -292,6 +294,15 @@ def main():
                                             "fill_kernel, one per wavefront",
                          "fill_stage_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
         }
+        valu = PMC_FILL4_VALU_INSTS.get((args.reads, args.read_len, args.band, C))
+        if valu and f4_ms > 0:
+            # what actually bounds the kernel (integer DP: no MFMA, far from the HBM roof): VALU issue slots.
+            # A wave64 VALU instruction holds its SIMD for 4 cycles (tools/valu_rate.hip); 256 CUs x 4 SIMDs.
+            out["roofline"]["valu_issue"] = {
+                "wave_insts_per_launch": valu, "cycles_per_wave_inst": 4, "simds": 1024, "clock_ghz_max": 2.4,
+                "frac_of_issue_slots_at_max_clock": valu * 4 / (1024 * 2.4e9 * (f4_ms / f4_launches) / 1e3),
+                "note": "SQ_INSTS_VALU of the launch (profiles/r01_v19_pmc_counters_100k_reads.json) x 4 cycles over "
+                        "the SIMD cycles of the measured launch time at the 2.4 GHz maximum clock"}
         if world == 1 and args.cpu_sample > 0:
             m0 = mappers[0]
             ns = min(args.cpu_sample, m0.n)
