@@ -792,11 +792,18 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           const int openKey = sv + (kOpen + AR_I_OPEN);
           const int iKey = min(openKey, insEK[j] & ~kTagMask);
           const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
-          const uint32_t arrow = (uint32_t)((sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN)));
-          if (j < 4)
-            arrowLo |= arrow << (8 * j);
-          else
-            arrowHi |= arrow << (8 * (j - 4));
+          // the arrow byte = the tags of the three keys: S tags live in bits 0-2, the open flags in bits 3-4, and
+          // nothing else is set below kShift -- so it is the OR of the keys, masked once (after packing, kC == 3)
+          const uint32_t arrow = (uint32_t)(sKey | iKey | dKey);
+          if (kC == 3) {
+            if (j == 1) arrowLo = __builtin_amdgcn_perm(arrow, arrowLo, 0x0c0c0400u) & 0x1f1fu;  // {cell 0, cell 1}
+            else if (j == 0) arrowLo = arrow;
+            else arrowHi = arrow & kTagMask;                                                     // cell 2
+          } else if (j < 4) {
+            arrowLo |= (arrow & kTagMask) << (8 * j);
+          } else {
+            arrowHi |= (arrow & kTagMask) << (8 * (j - 4));
+          }
           // (a third pass must not write beyond the row's end: those slots hold the row's first columns)
           if (rowOn && (pass < 2 || c0 + j <= hiC)) ring[(c0 + j) & (kF4Ring - 1)] = make_int2(sv, iKey & ~kTagMask);
         }
@@ -805,9 +812,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         if (rowOn && c0 <= hiC) {
           uint8_t *ap = arrowRow + (c0 - lo);
           if (kC == 3) {
-            ap[0] = (uint8_t)arrowLo;
-            ap[1] = (uint8_t)(arrowLo >> 8);
-            ap[2] = (uint8_t)(arrowLo >> 16);
+            *(unaligned_u16 *)ap = (uint16_t)arrowLo;
+            ap[2] = (uint8_t)arrowHi;
           } else {
             *(unaligned_u32 *)ap = arrowLo;
             *(unaligned_u16 *)(ap + 4) = (uint16_t)arrowHi;
