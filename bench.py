@@ -245,7 +245,7 @@ def main():
         K = args.steps
         value = totals["aligned_bases"] * K / elapsed
         fill_ms = acc["fill_ms"]
-        # the dominant kernel: fillp_kernel<16> (four candidates per wavefront), timed on its own with HIP events on
+        # the dominant kernel: fillp_kernel<16, true> (four candidates per wavefront), timed on its own with HIP events on
         # the library's stream; its algorithmic bytes = 1 B per band cell + the bases + 8 B per row record of
         # the candidates it processed
         f4_ms, f4_launches = acc["fill4_ms"], max(acc["fill4_launches"], 1)
@@ -279,14 +279,14 @@ def main():
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
-            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fillp_kernel<16>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fillp_kernel<16, true>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
                          "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
                                          "profiles/r01_v20_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
-                                         "of the fillp_kernel<16> launch",
+                                         "of the fillp_kernel<16, true> launch",
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
                          "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
                          "kernel_gcups": acc["fill4_cells"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0,

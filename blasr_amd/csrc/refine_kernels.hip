@@ -596,7 +596,9 @@ __device__ __forceinline__ void group_prefix_min2<8>(int &a, int &b) {
 typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
 typedef uint16_t __attribute__((aligned(1))) unaligned_u16;
 
-template <int kL>
+// kExt0: the affine extension penalty is 0 (the reference's default): the D chain has no per-column term and the
+// extension of I is the value above itself -- six instructions less per row.
+template <int kL, bool kExt0>
 __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillArgs args) {
   constexpr int kT = 64 / kL;      // candidates per wavefront
   constexpr int kC = kF4Pass / kL;  // cells per lane and pass
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           vKey[j] = min(matchK, min(insSK, insEK[j]));
           const int v = vKey[j] & ~kTagMask;
           ia[j] = v - pDel[j];
-          ib[j] = v - pExt[j];
+          ib[j] = kExt0 ? v : v - pExt[j];
           preA[j] = j == 0 ? ia[0] : min(preA[j - 1], ia[j]);  // inclusive over this lane's cells
           preB[j] = j == 0 ? ib[0] : min(preB[j - 1], ib[j]);
         }
@@ -786,11 +788,11 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
           const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
           const int aK = eaj + (pDel[j] + AR_LEFT);                 // S[c-1] + del
-          const int bK = ebj + (pExt[j] + kOpen + AR_DEL_CLOSE);    // D[c-1] + ext
+          const int bK = ebj + ((kExt0 ? 0 : pExt[j]) + kOpen + AR_DEL_CLOSE);    // D[c-1] + ext
           const int sKey = min(vKey[j], min(aK, bK));
           const int sv = sKey & ~kTagMask;
           const int openKey = sv + (kOpen + AR_I_OPEN);
-          const int iKey = min(openKey, insEK[j] & ~kTagMask);
+          const int iKey = min(openKey, kExt0 ? upI[j] : insEK[j] & ~kTagMask);  // (ring entries carry no tag)
           const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
           // the arrow byte = the tags of the three keys: S tags live in bits 0-2, the open flags in bits 3-4, and
           // nothing else is set below kShift -- so it is the OR of the keys, masked once (after packing, kC == 3)
@@ -838,8 +840,9 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
     args.dpScore[myTask] = ring[(myTEnd - 1) & (kF4Ring - 1)].x >> kShift;
 }
-template __global__ void fillp_kernel<16>(RefineBatchView, FillArgs);
-template __global__ void fillp_kernel<8>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, true>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, false>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<8, false>(RefineBatchView, FillArgs);
 
 template __global__ void fill_kernel<false, true>(RefineBatchView, FillArgs);
 template __global__ void fill_kernel<false, false>(RefineBatchView, FillArgs);
@@ -1250,10 +1253,12 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 }
 void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream) {
   if (args.count <= 0) return;
-  if (lanes == 16)
-    hipLaunchKernelGGL(fillp_kernel<16>, dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+  if (lanes == 16 && args.ext == 0)
+    hipLaunchKernelGGL((fillp_kernel<16, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+  else if (lanes == 16)
+    hipLaunchKernelGGL((fillp_kernel<16, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else
-    hipLaunchKernelGGL(fillp_kernel<8>, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+    hipLaunchKernelGGL((fillp_kernel<8, false>), dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
 }
 int fill4_max_width() { return kF4MaxWidth; }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
