@@ -283,8 +283,11 @@ __device__ __forceinline__ void row_chunk(const RowConsts<kFast> &k, ChunkCarry 
     // I = (S + open < I_up + ext) ? open : extend -- ties extend, so "open" carries the larger tag
     const int openKey = s + (k.open + AR_I_OPEN);
     const int iKey = min(openKey, insEK & ~kTagMask);
-    const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
-    arrowOut = (sKey & 7) | ((iKey | dKey) & (AR_I_OPEN | AR_D_OPEN));
+    // D = (S + open < D_left + ext) ? open : extend, of which only the flag is kept: with the tags in place
+    // (open 8 against close 4 on multiples of 32) the strict comparison of the untagged values is openKey < bK.
+    // S tags live in bits 0-2, the open flags in bits 3-4, nothing else below kShift: the byte is the OR, masked
+    const int dFlag = openKey < bK ? AR_D_OPEN : 0;
+    arrowOut = (sKey | iKey | dFlag) & kTagMask;
     sOut = active ? s : k.inf;
     iOut = active ? (iKey & ~kTagMask) : k.inf;
     if (!kOnlyChunk) {
@@ -793,10 +796,10 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           const int sv = sKey & ~kTagMask;
           const int openKey = sv + (kOpen + AR_I_OPEN);
           const int iKey = min(openKey, kExt0 ? upI[j] : insEK[j] & ~kTagMask);  // (ring entries carry no tag)
-          const int dKey = min(openKey + (AR_D_OPEN - AR_I_OPEN), bK & ~kTagMask);
+          const int dFlag = openKey < bK ? AR_D_OPEN : 0;  // = the tag of min(S + open, D + ext), see row_chunk
           // the arrow byte = the tags of the three keys: S tags live in bits 0-2, the open flags in bits 3-4, and
           // nothing else is set below kShift -- so it is the OR of the keys, masked once (after packing, kC == 3)
-          const uint32_t arrow = (uint32_t)(sKey | iKey | dKey);
+          const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag);
           if (kC == 3) {
             if (j == 1) arrowLo = __builtin_amdgcn_perm(arrow, arrowLo, 0x0c0c0400u) & 0x1f1fu;  // {cell 0, cell 1}
             else if (j == 0) arrowLo = arrow;
