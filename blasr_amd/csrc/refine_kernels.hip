@@ -783,8 +783,10 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           ea = l == 0 ? inf : ea;
           eb = l == 0 ? inf : eb;
         }
-        ea = min(ea, carryA);
-        eb = min(eb, carryB);
+        if (pass > 0) {  // (no cap at "inf" otherwise: what exceeds it loses every comparison against a real cell)
+          ea = min(ea, carryA);
+          eb = min(eb, carryB);
+        }
         uint32_t arrowLo = 0, arrowHi = 0;
 #pragma unroll
         for (int j = 0; j < kC; j++) {
