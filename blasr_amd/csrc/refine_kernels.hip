@@ -681,6 +681,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   myTLoaded = myPlo < 0 ? 0 : myPlo;
   __builtin_amdgcn_wave_barrier();
 
+  int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
   for (int r0 = 1; r0 <= maxQ; r0 += 64) {
     // ---- geometry and query codes of the next 64 rows of every candidate
     int passesV = 1;  // lane i: the passes row r0+i takes, i.e. what its widest candidate needs
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
       }
       __builtin_amdgcn_wave_barrier();
       const int nPass = __builtin_amdgcn_readlane(passesV, i);
-      int carryA = inf, carryB = inf, carryDiag = inf;
+      // (carryA/B/Diag, declared before the row loops, are only read in passes after a row's first)
       uint8_t *arrowRow = myArrows + (unsigned)rec.x;
       for (int pass = 0; pass < nPass; pass++) {
         const int cb = lo + kF4Pass * pass, c0 = cb + kC * l;
@@ -778,7 +779,11 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         }
         int pa = preA[kC - 1], pb = preB[kC - 1];
         group_prefix_min2<kL>(pa, pb);  // inclusive over the lanes of the candidate
-        int ea = dpp<0x111, 0xf>(inf, pa), eb = dpp<0x111, 0xf>(inf, pb);  // lanes before this one
+        // lanes before this one; lane 0 of a DPP row has no source and keeps the old value of the destination,
+        // which therefore stays the "inf" it was given before the loops
+        eaKeep = dpp<0x111, 0xf>(eaKeep, pa);
+        ebKeep = dpp<0x111, 0xf>(ebKeep, pb);
+        int ea = eaKeep, eb = ebKeep;
         if (kL < 16) {
           ea = l == 0 ? inf : ea;
           eb = l == 0 ? inf : eb;
@@ -829,8 +834,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         if (nPass > 1) {  // carries into the next 48 columns
           const int last = (lane | (kL - 1)) * 4;
           const int ta = __builtin_amdgcn_ds_bpermute(last, pa), tb = __builtin_amdgcn_ds_bpermute(last, pb);
-          carryA = min(carryA, ta) + kF4Pass * kDel;
-          carryB = min(carryB, tb) + kF4Pass * kExt;
+          carryA = (pass > 0 ? min(carryA, ta) : ta) + kF4Pass * kDel;
+          carryB = (pass > 0 ? min(carryB, tb) : tb) + kF4Pass * kExt;
           carryDiag = __builtin_amdgcn_ds_bpermute(last, lastRaw);  // the raw S of column cb+47, for lane 0
         }
         __builtin_amdgcn_wave_barrier();
