@@ -685,6 +685,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   for (int r0 = 1; r0 <= maxQ; r0 += 64) {
     // ---- geometry and query codes of the next 64 rows of every candidate
     int passesV = 1;  // lane i: the passes row r0+i takes, i.e. what its widest candidate needs
+    bool spanBad = false;  // some candidate's 64 rows span more target columns than its packed-column ring holds
+    int myHmax = 0;        // the last column my candidate touches in these rows
 #pragma unroll
     for (int g = 0; g < kT; g++) {
       if (taskG[g] >= 0 && r0 <= qG[g]) {
@@ -692,6 +694,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         unsigned rsV;
         guide_group(cur[g], r0, flagScratch[wave], tV, loV, hiV, rsV);
         const int nRows = min(64, qG[g] - r0 + 1);
+        int lastV = INT32_MIN;
         if (lane < nRows) {
           rowTabG[g][r0 + lane] = make_int2((int)rsV, loV);
           const int qc = base_code(qSeqG[g][cur[g].qStart + r0 - 1 + lane]);
@@ -699,10 +702,28 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           rowA[wave][g][lane] = make_int2((int)rsV, loV);
           rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
           passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
+          lastV = loV + max(width, 0) - 1;
         }
+        const int hMax = wave_max(lastV);
+        spanBad = spanBad || hMax + kL - __builtin_amdgcn_readlane(loV, 0) > kF4RingT;
+        if (grp == g) myHmax = hMax;
       }
     }
     __builtin_amdgcn_wave_barrier();
+    // ---- the packed matrix columns of the target for all 64 rows at once when they fit the ring next to the
+    // first row's columns (nearly always); otherwise row by row below
+    const bool ahead = !spanBad;
+    if (ahead) {
+      const bool on = myTask >= 0 && r0 <= myQ;
+      while (__ballot(on && myTLoaded <= myHmax) != 0ull) {
+        if (on && myTLoaded <= myHmax) {
+          const int c = myTLoaded + l;
+          const int code = c < myTLen ? base_code(myTSeq[c]) : 4;
+          ringT[c & (kF4RingT - 1)] = packedCol[code];
+          myTLoaded += kL;
+        }
+      }
+    }
     const int nRowsMax = min(64, maxQ - r0 + 1);
     for (int i = 0; i < nRowsMax; i++) {
       const int r = r0 + i;
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
       const int lo = rec.y, width = (int)(wb & 0xffu), qc = (int)(wb >> 8);
       const int hiC = lo + width - 1;
       // ---- stage the packed matrix columns of the target up to this row's last column
-      while (__ballot(rowOn && myTLoaded <= hiC) != 0ull) {
+      while (!ahead && __ballot(rowOn && myTLoaded <= hiC) != 0ull) {
         if (rowOn && myTLoaded <= hiC) {
           const int c = myTLoaded + l;
           const int code = c < myTLen ? base_code(myTSeq[c]) : 4;
