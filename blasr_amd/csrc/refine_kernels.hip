@@ -687,6 +687,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
     int passesV = 1;  // lane i: the passes row r0+i takes, i.e. what its widest candidate needs
     bool spanBad = false;  // some candidate's 64 rows span more target columns than its packed-column ring holds
     int myHmax = 0;        // the last column my candidate touches in these rows
+    bool nV = false;       // some query base of these rows is not ACGT
 #pragma unroll
     for (int g = 0; g < kT; g++) {
       if (taskG[g] >= 0 && r0 <= qG[g]) {
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
           passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
           lastV = loV + max(width, 0) - 1;
+          nV = nV || qc >= 4;
         }
         const int hMax = wave_max(lastV);
         spanBad = spanBad || hMax + kL - __builtin_amdgcn_readlane(loV, 0) > kF4RingT;
@@ -713,6 +715,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
     // ---- the packed matrix columns of the target for all 64 rows at once when they fit the ring next to the
     // first row's columns (nearly always); otherwise row by row below
     const bool ahead = !spanBad;
+    const bool batchHasN = __ballot(nV) != 0ull;
     if (ahead) {
       const bool on = myTask >= 0 && r0 <= myQ;
       while (__ballot(on && myTLoaded <= myHmax) != 0ull) {
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           const uint32_t te = ringT[(c0 + j) & (kF4RingT - 1)];
           m[j] = (int)__builtin_amdgcn_sbfe((int)te, (qc & 3) * 8, 8);
         }
-        if (__ballot(rowOn && qc >= 4) != 0ull) {  // query N (rare): the packed column has no N row
+        if (batchHasN && __ballot(rowOn && qc >= 4) != 0ull) {  // query N (rare): the packed column has no N row
 #pragma unroll
           for (int j = 0; j < kC; j++)
             if (rowOn && qc >= 4) {
