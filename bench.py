@@ -34,9 +34,9 @@ sys.path.insert(0, ROOT)
 
 
 # bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 56428472960.0}
+PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 56375466304.0}
 # wavefront VALU instructions of the same launch (SQ_INSTS_VALU, same profile)
-PMC_FILL4_VALU_INSTS = {(100000, 10000, 16, 1): 31486127690.0}
+PMC_FILL4_VALU_INSTS = {(100000, 10000, 16, 1): 31494305558.0}
 
 
 def reference_candidate(ref, q, t, band):
@@ -285,7 +285,7 @@ def main():
                          # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
                          "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
                          "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v23_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
+                                         "profiles/r01_v24_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
                                          "of the fillp_kernel<16, true> launch",
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
                          "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
@@ -301,7 +301,7 @@ def main():
             out["roofline"]["valu_issue"] = {
                 "wave_insts_per_launch": valu, "cycles_per_wave_inst": 4, "simds": 1024, "clock_ghz_max": 2.4,
                 "frac_of_issue_slots_at_max_clock": valu * 4 / (1024 * 2.4e9 * (f4_ms / f4_launches) / 1e3),
-                "note": "SQ_INSTS_VALU of the launch (profiles/r01_v23_pmc_counters_100k_reads.json) x 4 cycles over "
+                "note": "SQ_INSTS_VALU of the launch (profiles/r01_v24_pmc_counters_100k_reads.json) x 4 cycles over "
                         "the SIMD cycles of the measured launch time at the 2.4 GHz maximum clock"}
         if world == 1 and args.cpu_sample > 0:
             m0 = mappers[0]
