@@ -26,6 +26,7 @@ from .hip import (  # noqa: F401
     sam_line,
     ref_contig_location,
     CANDIDATE_DTYPE,
+    HIT_DTYPE,
     INTERVAL_DTYPE,
     READ_DTYPE,
     WINDOW_DTYPE,

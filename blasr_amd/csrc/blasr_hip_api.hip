@@ -23,6 +23,25 @@ static_assert(offsetof(RefineResult, ops_off) == offsetof(blasr_hip_refine_resul
 namespace {
 }  // namespace
 
+int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (bytes <= b.bytes) return BLASR_HIP_OK;
+  if (b.p) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  const size_t want = bytes + bytes / 8 + 256;  // head-room: steady-state batches do not reallocate
+  if (hipMalloc((void **)&b.p, want) == hipSuccess) {
+    b.bytes = want;
+    return BLASR_HIP_OK;
+  }
+  (void)hipGetLastError();
+  HIP_TRY(ctx, hipMalloc((void **)&b.p, bytes));
+  b.bytes = bytes;
+  return BLASR_HIP_OK;
+}
+
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -144,8 +163,10 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   }
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   for (auto &sl : ctx->slabs) (void)hipFree(sl.first);
-  if (ctx->genome) (void)hipFree(ctx->genome);
+  if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
+  for (auto &b : ctx->mapBuf)
+    if (b.p) (void)hipFree(b.p);
   delete ctx;
   return BLASR_HIP_OK;
 }

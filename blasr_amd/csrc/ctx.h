@@ -8,6 +8,12 @@
 #include <utility>
 #include <vector>
 
+// A grow-only device buffer owned by the context (freed in blasr_hip_destroy).
+struct DevBuf {
+  char *p = nullptr;
+  size_t bytes = 0;
+};
+
 struct blasr_hip_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -27,10 +33,20 @@ struct blasr_hip_ctx {
   std::vector<std::pair<char *, size_t>> slabs;
   // the resident genome (ASCII) and its contig table, for the window gather
   uint8_t *genome = nullptr;
+  bool genomeOwned = true;  // false: adopted from the caller (blasr_hip_adopt_genome_device)
   int64_t genomeLen = 0;
   uint32_t *contigStarts = nullptr;
   int nContigs = 0;
+  // the mapper's device-side state between its stages (blasr_hip_map_reads_*): window pool, SDP batch arrays,
+  // result records, block and op arenas, the trimmed refine batch
+  enum { kMapBufs = 20 };
+  DevBuf mapBuf[kMapBufs];
+  float mapMs[6] = {0, 0, 0, 0, 0, 0};
+  int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
 };
+
+// grows (never shrinks) a context buffer; the old contents are NOT kept
+int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes);
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
 

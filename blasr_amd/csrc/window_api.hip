@@ -141,20 +141,46 @@ __global__ __launch_bounds__(256) void window_gather_kernel(int n, const blasr_h
 
 using namespace blasr_hip;
 
+namespace {
+void drop_genome(blasr_hip_ctx *ctx) {
+  if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
+  if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
+  ctx->genome = nullptr;
+  ctx->genomeOwned = true;
+  ctx->contigStarts = nullptr;
+  ctx->genomeLen = 0;
+  ctx->nContigs = 0;
+}
+}  // namespace
+
 extern "C" {
+
+int blasr_hip_adopt_genome_device(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length,
+                                  const uint32_t *contig_starts_host, int32_t n_contigs) {
+  if (!ctx || !ascii || length <= 0 || length >= (1ll << 32) || n_contigs < 0 || (contig_starts_host && n_contigs < 1))
+    return ctx ? blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "adopt_genome: bad arguments") : BLASR_HIP_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  drop_genome(ctx);
+  if (contig_starts_host) {
+    HIP_TRY(ctx, hipMalloc(&ctx->contigStarts, sizeof(uint32_t) * (size_t)(n_contigs + 1)));
+    HIP_TRY(ctx, hipMemcpy(ctx->contigStarts, contig_starts_host, sizeof(uint32_t) * (size_t)(n_contigs + 1),
+                           hipMemcpyHostToDevice));
+    ctx->nContigs = n_contigs;
+  }
+  ctx->genome = const_cast<uint8_t *>(ascii);
+  ctx->genomeOwned = false;
+  ctx->genomeLen = length;
+  return BLASR_HIP_OK;
+}
 
 int blasr_hip_upload_genome(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length, const uint32_t *contig_starts,
                             int32_t n_contigs) {
   if (!ctx || !ascii || length <= 0 || length >= (1ll << 32) || n_contigs < 0 || (contig_starts && n_contigs < 1))
     return ctx ? blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "upload_genome: bad arguments") : BLASR_HIP_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->genome) (void)hipFree(ctx->genome);
-  if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
-  ctx->genome = nullptr;
-  ctx->contigStarts = nullptr;
-  ctx->genomeLen = 0;
-  ctx->nContigs = 0;
+  drop_genome(ctx);
   HIP_TRY(ctx, hipMalloc(&ctx->genome, (size_t)length));
+  ctx->genomeOwned = true;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->genome, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream));
   if (contig_starts) {
     HIP_TRY(ctx, hipMalloc(&ctx->contigStarts, sizeof(uint32_t) * (size_t)(n_contigs + 1)));

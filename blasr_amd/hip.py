@@ -32,6 +32,9 @@ EXPORTS = [
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
+    "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
+    "blasr_hip_map_default_params", "blasr_hip_map_last_timing", "blasr_hip_map_device_arenas",
+    "blasr_hip_adopt_genome_device",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -45,8 +48,15 @@ WINDOW_DTYPE = np.dtype([("t_aligned_seq_pos", "<u4"), ("t_aligned_seq_length", 
 CANDIDATE_DTYPE = np.dtype([("score", "<i4"), ("t_pos", "<u4"), ("t_aligned_seq_pos", "<u4"), ("t_end", "<u4"),
                             ("t_index", "<i4"), ("t_strand", "<i4"), ("pct_similarity", "<f4"), ("n_blocks", "<i4"),
                             ("blk_off", "<i8")])
+# blasr_hip_hit: one alignment MapRead keeps (blasr_hip_map_reads_*)
+HIT_DTYPE = np.dtype([("read", "<i4"), ("interval", "<i4"), ("t_strand", "<i4"), ("t_index", "<i4"),
+                      ("t_aligned_seq_pos", "<u4"), ("t_aligned_seq_length", "<u4"), ("t_length", "<u4"),
+                      ("q_aligned_seq_pos", "<u4"), ("q_aligned_seq_length", "<u4"), ("q_length", "<u4"),
+                      ("q_pos", "<i4"), ("t_pos", "<i4"), ("score", "<i4"), ("n_match", "<i4"), ("n_mismatch", "<i4"),
+                      ("n_ins", "<i4"), ("n_del", "<i4"), ("n_cells", "<i4"), ("pct_similarity", "<f4"),
+                      ("n_ops", "<i4"), ("ops_off", "<i8"), ("q_off", "<i8"), ("t_off", "<i8")])
 assert INTERVAL_DTYPE.itemsize == 24 and READ_DTYPE.itemsize == 24 and WINDOW_DTYPE.itemsize == 32
-assert CANDIDATE_DTYPE.itemsize == 40
+assert CANDIDATE_DTYPE.itemsize == 40 and HIT_DTYPE.itemsize == 104
 
 
 class _KbandParams(C.Structure):
@@ -144,12 +154,27 @@ SDP_RESULT_DTYPE = np.dtype([
 assert SDP_RESULT_DTYPE.itemsize == 48
 
 
+class _MapParams(C.Structure):
+    _fields_ = [("window", _WindowParams), ("sdp", _SdpParams), ("score", _ScoreParams), ("band", C.c_int32),
+                ("n_candidates", C.c_int32), ("max_gap", C.c_int32), ("max_score", C.c_int32),
+                ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32)]
+
+
+class _MapFetch(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("seq_capacity", C.c_int64), ("seq_used", C.c_int64), ("ops", C.c_void_p),
+                ("ops_capacity", C.c_int64), ("ops_used", C.c_int64)]
+
+
+# params.indelRate * 3 as the reference computes it (float x int in single precision, Blasr.cpp:1717)
+DEFAULT_INDEL_RATE = float(np.float32(0.3) * np.float32(3))
+
+
 class SdpParams:
     """What AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722), defaults of
     MappingParameters.h:192-361."""
 
-    def __init__(self, k=11, sdp_ins=5, sdp_del=10, indel_rate=0.9, align_type=0, detailed=1, extend_front=0,
-                 prefix=50, recurse=2, recurse_over=1000, max_per_pos=0):
+    def __init__(self, k=11, sdp_ins=5, sdp_del=10, indel_rate=DEFAULT_INDEL_RATE, align_type=0, detailed=1,
+                 extend_front=0, prefix=50, recurse=2, recurse_over=1000, max_per_pos=0):
         self.k, self.sdp_ins, self.sdp_del, self.indel_rate = k, sdp_ins, sdp_del, indel_rate
         self.align_type, self.detailed, self.extend_front = align_type, detailed, extend_front
         self.prefix, self.recurse, self.recurse_over, self.max_per_pos = prefix, recurse, recurse_over, max_per_pos
@@ -231,6 +256,19 @@ def load_library():
         lib.blasr_hip_remove_low_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                                      C.c_int32, C.c_int32]
         lib.blasr_hip_remove_overlapping.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_float]
+        lib.blasr_hip_refine_from_sdp_device.argtypes = [C.c_void_p, C.POINTER(_SdpBatch), C.c_void_p, C.c_void_p,
+                                                         C.c_int32, C.c_void_p, C.c_int32, C.POINTER(_ScoreParams),
+                                                         C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.blasr_hip_map_reads_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                   C.POINTER(_MapParams), C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                                                   C.c_void_p, C.POINTER(_MapFetch)]
+        lib.blasr_hip_map_reads_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                                 C.c_void_p, C.POINTER(_MapParams), C.c_void_p, C.c_int64,
+                                                 C.POINTER(C.c_int64), C.c_void_p, C.POINTER(_MapFetch)]
+        lib.blasr_hip_map_default_params.argtypes = [C.POINTER(_MapParams)]
+        lib.blasr_hip_map_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_map_device_arenas.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        lib.blasr_hip_adopt_genome_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
         _lib = lib
     return _lib
 
@@ -679,6 +717,101 @@ class Context:
         self._check(self.lib.blasr_hip_windows_device(self.handle, n, intervals_ptr, reads_ptr, read_pool_ptr,
                                                       C.byref(wp), seq_ptr, seq_capacity, q_off_ptr, q_len_ptr,
                                                       t_off_ptr, t_len_ptr, windows_ptr, C.byref(used)))
+        return used.value
+
+    def adopt_genome_device(self, genome_ptr, length, contig_starts=None):
+        """The genome already sits in device memory (raw address) and stays the caller's."""
+        cs, nc = None, 0
+        if contig_starts is not None:
+            cs = np.ascontiguousarray(contig_starts, dtype=np.uint32)
+            nc = len(cs) - 1
+        self._check(self.lib.blasr_hip_adopt_genome_device(self.handle, C.c_void_p(genome_ptr), int(length),
+                                                           cs.ctypes.data if cs is not None else None, nc))
+
+    # --- MapRead from the intervals on (Blasr.cpp:2530-2644), C++ driver inside the library ---
+    def map_params(self, **kw):
+        """blasr_hip_map_params with the defaults of MappingParameters.h; keyword overrides: band, n_candidates,
+        max_gap, max_score, min_pct_identity, sort_refined, sdp=SdpParams, score=ScoreParams, rate, extend_ends,
+        do_global."""
+        p = _MapParams()
+        self.lib.blasr_hip_map_default_params(C.byref(p))
+        if "sdp" in kw:
+            p.sdp = kw.pop("sdp").as_struct()
+        if "score" in kw:
+            p.score = kw.pop("score").as_struct()
+        if "rate" in kw:
+            p.window.approximate_max_insertion_rate = kw.pop("rate")
+        if "extend_ends" in kw:
+            p.window.extend_ends = int(kw.pop("extend_ends"))
+        if "do_global" in kw:
+            p.window.do_global_alignment = int(kw.pop("do_global"))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def map_last_timing(self):
+        ms = (C.c_float * 6)()
+        cnt = (C.c_int64 * 6)()
+        self._check(self.lib.blasr_hip_map_last_timing(self.handle, ms, cnt))
+        return dict(windows_ms=ms[0], sdp_ms=ms[1], filter1_ms=ms[2], refine_ms=ms[3], filter2_ms=ms[4], fetch_ms=ms[5],
+                    intervals=cnt[0], refined=cnt[1], aligned_reads=cnt[2], aligned_bases=cnt[3], dp_cells=cnt[4],
+                    hits=cnt[5])
+
+    def map_reads(self, reads, read_pool, intervals, params=None, fetch=True):
+        """blasr_hip_map_reads_host: reads READ_DTYPE, read_pool uint8, intervals INTERVAL_DTYPE (host arrays).
+        Returns (hits HIT_DTYPE array, read_hit_off, seq arena, ops arena); with fetch the hits' q_off / t_off /
+        ops_off index the two arenas."""
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        read_pool = np.ascontiguousarray(read_pool, dtype=np.uint8)
+        intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
+        params = params or self.map_params()
+        n_reads, n_iv = len(reads), len(intervals)
+        cap = max(n_iv, 1)
+        hits = np.zeros(cap, dtype=HIT_DTYPE)
+        off = np.zeros(n_reads + 1, dtype=np.int64)
+        n_hits = C.c_int64(0)
+        f, seq, ops = None, np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+        if fetch:
+            owner = np.clip(intervals["read"].astype(np.int64), 0, max(n_reads - 1, 0))
+            longest = reads["length"].astype(np.int64)[owner] if n_reads and n_iv else np.zeros(0, np.int64)
+            seq_cap = int((longest * 3 + (intervals["end"].astype(np.int64) - intervals["start"])).clip(0).sum()) + 64
+            seq, ops = np.zeros(seq_cap, np.uint8), np.zeros(seq_cap, np.uint32)
+            f = _MapFetch(seq.ctypes.data, seq_cap, 0, ops.ctypes.data, seq_cap, 0)
+        rc = self.lib.blasr_hip_map_reads_host(self.handle, n_reads, reads.ctypes.data, read_pool.ctypes.data,
+                                               len(read_pool), n_iv, intervals.ctypes.data, C.byref(params),
+                                               hits.ctypes.data, cap, C.byref(n_hits), off.ctypes.data,
+                                               C.byref(f) if f is not None else None)
+        self._check(rc)
+        if f is not None:
+            seq, ops = seq[: f.seq_used], ops[: f.ops_used]
+        return hits[: n_hits.value], off, seq, ops
+
+    def map_reads_device(self, n_reads, reads_ptr, read_pool_ptr, n_intervals, intervals_ptr, params, hits, read_hit_off=None):
+        """Device-resident reads / pool / intervals (raw addresses); hits: a HIT_DTYPE host array to fill.
+        Returns the number of hits; their offsets index the context's device arenas."""
+        n_hits = C.c_int64(0)
+        rc = self.lib.blasr_hip_map_reads_device(self.handle, n_reads, C.c_void_p(reads_ptr), C.c_void_p(read_pool_ptr),
+                                                 n_intervals, C.c_void_p(intervals_ptr), C.byref(params),
+                                                 hits.ctypes.data, len(hits), C.byref(n_hits),
+                                                 read_hit_off.ctypes.data if read_hit_off is not None else None, None)
+        self._check(rc)
+        return n_hits.value
+
+    def refine_from_sdp_device(self, dev_ptrs, sdp_results_ptr, blocks_ptr, n_sel, sel_ptr, band, score, results_ptr,
+                               ops_ptr, ops_capacity):
+        """RefineAlignment's trimming + refine on the SDP stage's own device records (raw addresses)."""
+        sb = _SdpBatch()
+        sb.n = int(dev_ptrs["n"])
+        for k in ("seq", "q_off", "q_len", "t_off", "t_len"):
+            setattr(sb, k, int(dev_ptrs[k]))
+        used = C.c_int64(0)
+        sc = score.as_struct()
+        rc = self.lib.blasr_hip_refine_from_sdp_device(self.handle, C.byref(sb), C.c_void_p(sdp_results_ptr),
+                                                       C.c_void_p(blocks_ptr), int(n_sel),
+                                                       C.c_void_p(sel_ptr) if sel_ptr else None, band, C.byref(sc),
+                                                       C.c_void_p(results_ptr), C.c_void_p(ops_ptr), int(ops_capacity),
+                                                       C.byref(used))
+        self._check(rc)
         return used.value
 
     # --- a-11: AffineKBandAlign (the -noUseGuidedAlign refiner, Blasr.cpp:675-746) ---

@@ -311,6 +311,103 @@ int blasr_hip_remove_overlapping(const blasr_hip_candidate *cands, int32_t n, in
                                  float min_pct_identity);
 
 /* ------------------------------------------------------------------------------------------------
+ * RefineAlignment's trimming (alignment/Blasr.cpp:850-859) inside the library: the SDP stage's own batch,
+ * result records and block arena go straight into the refine stage.  Candidate i of the call is candidate
+ * sel[i] of the SDP batch (sel = NULL: all n_sel = batch->n of them, in order); its query / target are the SDP
+ * window cut to [q_pos, q_pos + last block's qPos + length) / [t_pos, ...), its guide the SDP blocks.
+ * A candidate without blocks comes back with BLASR_HIP_TASK_EMPTY_GUIDE.  Device pointers throughout.
+ * ------------------------------------------------------------------------------------------------ */
+int blasr_hip_refine_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch,
+                                     const blasr_hip_sdp_result *sdp_results, const int32_t *blocks, int32_t n_sel,
+                                     const int32_t *sel, int32_t band, const blasr_hip_score_params *score,
+                                     blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
+                                     int64_t *ops_used);
+
+/* ------------------------------------------------------------------------------------------------
+ * MapRead from the candidate intervals on (alignment/Blasr.cpp:2530-2644), for a whole block of reads at once:
+ *   AlignIntervals: windows (:1208-1336) -> SDPAlign + ComputeAlignmentStats per interval (:1716-1724)
+ *   sort by score (:2547), RemoveLowQualityAlignments (:2594-2596)
+ *   RefineAlignments on the survivors (:2607, :2164-2181, copy-back :888-914), sort
+ *   RemoveLowQualityAlignments, RemoveOverlappingAlignments (:2615-2616)
+ * The per-interval stages run as device batches over all reads, the per-read ordering and pruning on the host
+ * in the reference's order (C++, as there).  What comes back per read is the list of alignments MapRead leaves in
+ * alignmentPtrs, best first: the input of AssignRefContigLocation / StoreMapQVs / the printers
+ * (blasr_hip_ref_contig_location, blasr_hip_map_qvs, blasr_hip_m4_line, blasr_hip_cigar, blasr_hip_sam_line).
+ * Anchoring -- where the intervals come from -- is the caller's (SURVEY next-1).
+ * The genome must be resident (blasr_hip_upload_genome / blasr_hip_adopt_genome_device).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_map_params {
+  blasr_hip_window_params window;
+  blasr_hip_sdp_params sdp;      /* as AlignIntervals passes them (:1716-1722) */
+  blasr_hip_score_params score;  /* SMRTDistanceMatrix + InitializeScoreFunction (:807-809) */
+  int32_t band;                  /* params.bandSize (16) */
+  int32_t n_candidates;          /* params.nCandidates (10) */
+  int32_t max_gap;               /* params.maxGap (0) */
+  int32_t max_score;             /* params.maxScore (-200) */
+  float min_pct_identity;        /* params.minPctIdentity (0) */
+  int32_t sort_refined;          /* params.sortRefinedAlignments (1) */
+} blasr_hip_map_params;
+
+/* One alignment MapRead keeps: the T_AlignmentCandidate fields after RefineAlignment's copy-back. */
+typedef struct blasr_hip_hit {
+  int32_t read;                  /* index into the read table */
+  int32_t interval;              /* index of the candidate interval it came from */
+  int32_t t_strand, t_index;
+  uint32_t t_aligned_seq_pos;    /* on the strand of the interval, after += tPos of the SDP alignment (:909) */
+  uint32_t t_aligned_seq_length; /* tSeq.length (:915) */
+  uint32_t t_length;             /* contig length as AlignIntervals computed it */
+  uint32_t q_aligned_seq_pos;    /* after += qPos of the SDP alignment (:910) */
+  uint32_t q_aligned_seq_length;
+  uint32_t q_length;             /* read.length */
+  int32_t q_pos, t_pos;          /* refinedAlignment.qPos / tPos */
+  int32_t score;                 /* ComputeAlignmentStats score of the refined alignment */
+  int32_t n_match, n_mismatch, n_ins, n_del;
+  int32_t n_cells;
+  float pct_similarity;
+  int32_t n_ops;
+  int64_t ops_off;               /* first op in the ops arena (device arena, or the host one when fetched) */
+  int64_t q_off, t_off;          /* qAlignedSeq / tAlignedSeq in the sequence arena (ditto) */
+} blasr_hip_hit;
+
+/* Optional host arenas: the aligned sequences and op lists of the hits only, gathered on the device and
+ * downloaded in one copy each -- what the epilogue needs.  On return seq_used / ops_used hold what was needed;
+ * BLASR_HIP_ERR_CAPACITY when a capacity was too small (the hits themselves are valid). */
+typedef struct blasr_hip_map_fetch {
+  uint8_t *seq;
+  int64_t seq_capacity, seq_used;
+  uint32_t *ops;
+  int64_t ops_capacity, ops_used;
+} blasr_hip_map_fetch;
+
+/* reads / read_pool / intervals: device pointers; everything else host.  hits: at most hits_capacity records,
+ * *n_hits receives the number needed; read_hit_off (n_reads + 1 entries, may be NULL): the hits of read r are
+ * hits[read_hit_off[r] .. read_hit_off[r+1]).  Intervals may come in any order; the candidates of a read keep the
+ * order of their intervals (the order of the reference's interval set). */
+int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                               const uint8_t *read_pool, int32_t n_intervals, const blasr_hip_interval *intervals,
+                               const blasr_hip_map_params *params, blasr_hip_hit *hits, int64_t hits_capacity,
+                               int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch);
+/* Same with host pointers (read_pool_bytes sizes the upload). */
+int blasr_hip_map_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                             const uint8_t *read_pool, int64_t read_pool_bytes, int32_t n_intervals,
+                             const blasr_hip_interval *intervals, const blasr_hip_map_params *params,
+                             blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
+                             blasr_hip_map_fetch *fetch);
+/* Defaults of MappingParameters.h (the values every field comment above names). */
+int blasr_hip_map_default_params(blasr_hip_map_params *params);
+/* Wall time (ms) of the stages of the last map call: [0] windows, [1] SDP, [2] sort + first filter (host),
+ * [3] refine, [4] sort + the two filters (host), [5] fetch; counters: [0] candidate intervals, [1] candidates
+ * refined, [2] reads with an alignment, [3] bases of those reads, [4] band cells of the refined candidates,
+ * [5] hits. */
+int blasr_hip_map_last_timing(const blasr_hip_ctx *ctx, float ms[6], int64_t counters[6]);
+/* Without fetch arenas a hit's q_off / t_off / ops_off index the context's own device arenas: these
+ * (valid until the next map call on the context). */
+int blasr_hip_map_device_arenas(blasr_hip_ctx *ctx, const uint8_t **seq, const uint32_t **ops);
+/* The genome is already in device memory and stays the caller's (not copied, not freed). */
+int blasr_hip_adopt_genome_device(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length,
+                                  const uint32_t *contig_starts_host, int32_t n_contigs);
+
+/* ------------------------------------------------------------------------------------------------
  * a-11: AffineKBandAlign, Global (algorithms/alignment/AffineKBandAlign.h:12-401) -- the refiner
  * PairwiseLocalAlign runs under -noUseGuidedAlign (alignment/Blasr.cpp:675-746): fixed band of
  * 2k+1 columns, affine insertion + affine homopolymer insertion + linear deletion.

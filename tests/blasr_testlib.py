@@ -750,3 +750,184 @@ def _order_gaps_by_type(checker, ops):
 
 
 EpilogueChecker.order_gaps_by_type = _order_gaps_by_type
+
+
+# ---------------------------------------------------------------------------------------------
+# MapRead from the intervals on, composed from the oracle's pieces in the reference's order
+# (Blasr.cpp:2530-2644): the checker for blasr_hip_map_reads_* (blasr_amd/csrc/mapread_api.hip).
+# ---------------------------------------------------------------------------------------------
+def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=16, n_candidates=10, max_gap=0,
+                     max_score=-200, min_pct=0.0, sp=None, sc=None):
+    """reads / intervals: the product's READ_DTYPE / INTERVAL_DTYPE arrays.  Returns, per read, the alignments
+    MapRead keeps (best first) as dicts: interval, the hit record's fields, q / t (aligned sequences), ops."""
+    sp, sc = sp or SdpParams(), sc or ScoreParams()
+    by_read = [[] for _ in range(len(reads))]
+    for k, iv in enumerate(intervals):
+        by_read[int(iv["read"])].append(k)
+    out = []
+    for r, ks in enumerate(by_read):
+        rd = reads[r]
+        read = pool[int(rd["off"]): int(rd["off"]) + int(rd["length"])]
+        c = []
+        for k in ks:
+            iv = intervals[k]
+            w, tseq = mo.window(genome, len(read), (int(rd["subread_start"]), int(rd["subread_end"])),
+                                (int(iv["start"]), int(iv["end"]), int(iv["q_start"]), int(iv["q_end"]), int(iv["strand"])),
+                                contigs)
+            q = read[w["qAlignedSeqPos"]: w["qAlignedSeqPos"] + w["qAlignedSeqLength"]]
+            s = oracle.sdp_align(q, tseq, sc, sp)
+            st = oracle.compute_alignment_stats(q, tseq, s["qPos"], s["tPos"], s["blocks"], sc=sc)
+            c.append(dict(interval=k, win=w, q=q, t=tseq, sdp=s, score=st["score"], pct=np.float32(st["pct"]),
+                          t_pos=s["tPos"], t_aligned_seq_pos=w["tAlignedSeqPos"], t_end=0, blocks=s["blocks"],
+                          refined=None))
+
+        def filters(order, low_quality_only):
+            score = np.array([x["score"] for x in c], np.int32)
+            blocks = [np.asarray(x["blocks"], np.int32).reshape(-1, 3) for x in c]
+            n_blocks = np.array([len(b) for b in blocks], np.int32)
+            blk_off = np.concatenate([[0], np.cumsum(n_blocks)])[:-1].astype(np.int32)
+            flat = np.concatenate(blocks).reshape(-1) if n_blocks.sum() else np.zeros(0, np.int32)
+            t_pos = np.array([x["t_pos"] for x in c], np.uint32)
+            tasp = np.array([x["t_aligned_seq_pos"] for x in c], np.uint32)
+            order = mo.sort_by_score(score, t_pos, tasp, order)
+            order, score = mo.remove_low_quality(order, score, flat, blk_off, n_blocks, n_candidates, max_gap, max_score)
+            for j, x in enumerate(c):
+                x["score"] = int(score[j])
+            if not low_quality_only:
+                order = mo.remove_overlapping(order, score, t_pos, tasp, np.array([x["t_end"] for x in c], np.uint32),
+                                              np.array([x["win"]["tIndex"] for x in c], np.int32),
+                                              np.array([x["win"]["tStrand"] for x in c], np.int32),
+                                              np.array([x["pct"] for x in c], np.float32), min_pct)
+            return order
+
+        res = []
+        out.append(res)
+        if not c:
+            continue
+        order = filters(np.arange(len(c), dtype=np.int32), True)                       # :2547, :2594-2596
+        for j in order:                                                                # RefineAlignments :2164-2181
+            x = c[int(j)]
+            bl = x["sdp"]["blocks"]
+            if len(bl) == 0:
+                continue
+            qs = x["q"][x["sdp"]["qPos"]: x["sdp"]["qPos"] + bl[-1, 0] + bl[-1, 2]]
+            ts = x["t"][x["sdp"]["tPos"]: x["sdp"]["tPos"] + bl[-1, 1] + bl[-1, 2]]
+            rr = oracle.affine_guided_align(qs, ts, bl, sc, band)
+            x.update(refined=rr, qs=qs, ts=ts, score=rr["score"], pct=np.float32(rr["pct"]), t_pos=rr["tPos"],
+                     t_aligned_seq_pos=x["win"]["tAlignedSeqPos"] + x["sdp"]["tPos"], blocks=rr["blocks"],
+                     t_end=(int(rr["blocks"][-1, 1] + rr["blocks"][-1, 2]) if len(rr["blocks"]) else 0))
+        order = filters(order, False)                                                  # :2178-2180, :2615-2616
+        for j in order:
+            x = c[int(j)]
+            rr = x["refined"]
+            if rr is None:
+                continue
+            res.append(dict(interval=x["interval"], t_strand=x["win"]["tStrand"], t_index=x["win"]["tIndex"],
+                            t_aligned_seq_pos=x["t_aligned_seq_pos"] & 0xffffffff, t_aligned_seq_length=len(x["ts"]),
+                            t_length=x["win"]["tLength"],
+                            q_aligned_seq_pos=x["win"]["qAlignedSeqPos"] + x["sdp"]["qPos"],
+                            q_aligned_seq_length=len(x["qs"]), q_length=len(read), q_pos=rr["qPos"], t_pos=rr["tPos"],
+                            score=rr["score"], n_match=rr["nMatch"], n_mismatch=rr["nMismatch"], n_ins=rr["nIns"],
+                            n_del=rr["nDel"], n_cells=rr["nCells"], pct_similarity=np.float32(rr["pct"]),
+                            q=x["qs"], t=x["ts"], ops=[(l << 2) | ty for ty, l in ops_from_alignment(rr)]))
+    return out
+
+
+HIT_FIELDS = ("interval", "t_strand", "t_index", "t_aligned_seq_pos", "t_aligned_seq_length", "t_length",
+              "q_aligned_seq_pos", "q_aligned_seq_length", "q_length", "q_pos", "t_pos", "score", "n_match",
+              "n_mismatch", "n_ins", "n_del", "n_cells", "pct_similarity")
+
+
+def repeat_genome_case(rng, n_reads, genome_len=300000, read_len=(800, 3000), copies=(2, 5), divergence=(0.01, 0.06)):
+    """A genome with planted repeat families and reads drawn half from the repeats: every read gets its true
+    locus and the loci of the other copies of its family as candidate intervals (what anchoring reports on a
+    repeat-bearing genome: 1..copies competing candidates), on either strand.  Returns genome, pool, reads,
+    intervals (product dtypes)."""
+    import blasr_amd
+    from blasr_amd import synth
+    genome = synth.random_genome(genome_len, int(rng.integers(1, 1 << 30)))
+    fams = []
+    for f in range(4):
+        unit = int(rng.integers(3000, 6000))
+        src = int(rng.integers(0, genome_len - unit))
+        k = int(rng.integers(copies[0], copies[1] + 1))
+        locs = [(src, 0)]
+        for _ in range(k - 1):
+            d = float(rng.uniform(*divergence))
+            piece = np.ascontiguousarray(synth.mutate(genome[src:src + unit], rng, d / 3, d / 3, d / 3))
+            strand = int(rng.integers(0, 2))
+            if strand:
+                piece = synth.revcomp(piece)
+            at = int(rng.integers(0, genome_len - len(piece)))
+            genome[at:at + len(piece)] = piece
+            locs.append((at, strand))
+        fams.append((unit, locs))
+    reads = np.zeros(n_reads, dtype=blasr_amd.READ_DTYPE)
+    ivs, pool, off = [], [], 0
+    for r in range(n_reads):
+        rl = int(rng.integers(*read_len))
+        strand = int(rng.integers(0, 2))
+        if r % 2 == 0:
+            unit, locs = fams[(r // 2) % len(fams)]
+            rl = min(rl, unit - 200)
+            inner = int(rng.integers(0, unit - rl))
+            pos = locs[0][0] + inner
+            others = [(a + inner, s) for a, s in locs[1:]]
+        else:
+            pos, others = int(rng.integers(0, genome_len - rl)), []
+        tmpl = genome[pos:pos + rl]
+        if strand:
+            tmpl = synth.revcomp(tmpl)
+        read = np.ascontiguousarray(synth.mutate(tmpl, rng, 0.11, 0.04, 0.01))
+        L = len(read)
+        reads[r] = (off, L, 0, L, 0)
+        pool.append(read)
+        off += L
+        cands = [(pos, strand)] + [(min(max(a, 0), genome_len - rl), strand ^ s) for a, s in others]
+        order = rng.permutation(len(cands))
+        for ci in order:
+            a, s = cands[int(ci)]
+            ua0, ua1 = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+            g0 = a + int(rng.integers(0, 60))
+            g1 = a + rl - int(rng.integers(0, 60))
+            ivs.append((g0, g1, ua0, L - ua1, r, s))
+    return genome, np.concatenate(pool), reads, np.array(ivs, dtype=blasr_amd.INTERVAL_DTYPE)
+
+
+# ---------------------------------------------------------------------------------------------
+# Raw device buffers for the *_device entry points, through the HIP runtime the library itself is linked
+# against (torch bundles another copy of the runtime, which cannot take the device after this one has).
+# ---------------------------------------------------------------------------------------------
+class DeviceMemory:
+    def __init__(self):
+        self.rt = C.CDLL("libamdhip64.so.7")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.held = []
+
+    def zeros(self, nbytes):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), max(int(nbytes), 16)) == 0
+        assert self.rt.hipMemset(p, 0, max(int(nbytes), 16)) == 0
+        self.held.append(p)
+        return p.value
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        p = self.zeros(a.nbytes)
+        if a.nbytes:
+            assert self.rt.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        return p
+
+    def download(self, ptr, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        if out.nbytes:
+            assert self.rt.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        for p in self.held:
+            self.rt.hipFree(p)
+        self.held = []

@@ -38,6 +38,21 @@ def test_result_record_layout_matches_header():
     assert sum(int(f[0]) // 8 for f in fields) == hip.RESULT_DTYPE.itemsize
 
 
+def test_hit_record_layout_matches_header():
+    text = open(os.path.join(ROOT, "include", "blasr_hip.h")).read()
+    body = text[text.index("typedef struct blasr_hip_hit {"):text.index("} blasr_hip_hit;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for ty, names in re.findall(r"\b(u?int32_t|int64_t|float)\s+([a-z_, ]+);", body):
+        fields += [(ty, n.strip()) for n in names.split(",")]
+    assert [f[1] for f in fields] == list(hip.HIT_DTYPE.names)
+    assert sum(8 if f[0] == "int64_t" else 4 for f in fields) == hip.HIT_DTYPE.itemsize
+    p = hip._MapParams()
+    assert blasr_amd.load_library().blasr_hip_map_default_params(C.byref(p)) == 0
+    assert (p.band, p.n_candidates, p.max_gap, p.max_score, p.sdp.word_size, p.score.affine_open) == (16, 10, 0, -200, 11, 50)
+    assert p.sdp.indel_rate == np.float32(0.3) * np.float32(3)  # params.indelRate * 3 in single precision
+
+
 def test_no_device_is_a_loud_failure():
     import torch
     if torch.cuda.is_available():

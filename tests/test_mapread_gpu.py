@@ -1,0 +1,127 @@
+"""The C++ MapRead driver of the library (blasr_hip_map_reads_*, blasr_amd/csrc/mapread_api.hip) and the in-library
+trimming (blasr_hip_refine_from_sdp_device) against MapRead composed from the ORACLE's pieces in the reference's
+order (tests/blasr_testlib.py:oracle_map_reads): windows -> SDP + statistics -> sort -> RemoveLowQualityAlignments
+-> refine the survivors -> sort -> RemoveLowQualityAlignments -> RemoveOverlappingAlignments, on reads with
+competing candidates (a genome with planted repeat families), every field of every surviving alignment, its aligned
+sequences and its op list."""
+import numpy as np
+import pytest
+
+import blasr_amd
+from blasr_amd import hip
+from blasr_testlib import HIT_FIELDS, MapperOracle, oracle_map_reads, repeat_genome_case
+
+pytestmark = pytest.mark.gpu
+
+
+def check_hits(hits, off, seq, ops, want):
+    assert len(off) == len(want) + 1
+    n_multi = 0
+    for r, w in enumerate(want):
+        mine = hits[int(off[r]): int(off[r + 1])]
+        assert len(mine) == len(w), (r, len(mine), len(w))
+        n_multi += len(w) > 1
+        for h, x in zip(mine, w):
+            assert int(h["read"]) == r
+            for f in HIT_FIELDS:
+                assert h[f] == x[f], (r, f, h[f], x[f])
+            q = seq[int(h["q_off"]): int(h["q_off"]) + int(h["q_aligned_seq_length"])]
+            t = seq[int(h["t_off"]): int(h["t_off"]) + int(h["t_aligned_seq_length"])]
+            assert np.array_equal(q, x["q"]) and np.array_equal(t, x["t"]), r
+            assert ops[int(h["ops_off"]): int(h["ops_off"]) + int(h["n_ops"])].tolist() == x["ops"], r
+    return n_multi
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_gap=40), dict(n_candidates=2), dict(max_score=-2000, min_pct_identity=80.0)])
+def test_map_reads_against_oracle_composition(oracle, kw):
+    rng = np.random.default_rng(77)
+    genome, pool, reads, ivs = repeat_genome_case(rng, 48)
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome)
+    params = ctx.map_params(**kw)
+    hits, off, seq, ops = ctx.map_reads(reads, pool, ivs, params=params)
+    want = oracle_map_reads(oracle, MapperOracle(), genome, None, pool, reads, ivs, n_candidates=params.n_candidates,
+                            max_gap=params.max_gap, max_score=params.max_score, min_pct=params.min_pct_identity)
+    n_multi = check_hits(hits, off, seq, ops, want)
+    t = ctx.map_last_timing()
+    assert t["intervals"] == len(ivs) and t["hits"] == len(hits)
+    assert t["aligned_reads"] == sum(1 for w in want if w)
+    assert t["aligned_bases"] == sum(int(reads[r]["length"]) for r, w in enumerate(want) if w)
+    if not kw:
+        assert n_multi >= 3  # reads that keep several alignments do occur
+        assert t["refined"] < len(ivs) or all(len(w) for w in want)
+    ctx.close()
+
+
+def test_map_reads_with_contigs_and_empty_inputs(oracle):
+    rng = np.random.default_rng(78)
+    genome, pool, reads, ivs = repeat_genome_case(rng, 20, genome_len=120000)
+    contigs = np.array([0, 30000, 75000, len(genome)], dtype=np.uint32)
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, contigs)
+    hits, off, seq, ops = ctx.map_reads(reads, pool, ivs)
+    want = oracle_map_reads(oracle, MapperOracle(), genome, contigs, pool, reads, ivs)
+    check_hits(hits, off, seq, ops, want)
+    # a read without intervals keeps an empty slice; no intervals at all is not an error
+    some = ivs[ivs["read"] != 3]
+    hits2, off2, _, _ = ctx.map_reads(reads, pool, some)
+    assert off2[3] == off2[4] and len(hits2) == len(hits) - (off[4] - off[3])
+    hits3, off3, _, _ = ctx.map_reads(reads, pool, ivs[:0])
+    assert len(hits3) == 0 and off3.tolist() == [0] * (len(reads) + 1)
+    # an interval naming a read that does not exist is refused
+    bad = ivs.copy()
+    bad[0]["read"] = len(reads)
+    with pytest.raises(blasr_amd.BlasrHipError) as e:
+        ctx.map_reads(reads, pool, bad)
+    assert e.value.code == hip.ERR_INVALID
+    ctx.close()
+
+
+def test_refine_from_sdp_equals_host_trimming(oracle):
+    """blasr_hip_refine_from_sdp_device on the SDP stage's device records = trimming on the host + blasr_hip_refine_host,
+    for all candidates and for a selection (out of order, with a candidate that has no blocks)."""
+    rng = np.random.default_rng(79)
+    from blasr_amd import synth
+    from blasr_testlib import DeviceMemory
+    pairs = [synth.make_pair(rng, int(rng.integers(300, 2500))) for _ in range(12)]
+    pairs.append((np.frombuffer(b"ACGTACGTAC" * 8, np.uint8), np.frombuffer(b"TTTTTTTTTT" * 9, np.uint8)))  # no blocks
+    ctx = blasr_amd.Context(0)
+    mem = DeviceMemory()
+    seqs, q_off, q_len, t_off, t_len, at = [], [], [], [], [], 0
+    for q, t in pairs:
+        q_off.append(at); q_len.append(len(q)); at += len(q)
+        t_off.append(at); t_len.append(len(t)); at += len(t)
+        seqs += [q, t]
+    n = len(pairs)
+    ptrs = dict(seq=mem.upload(np.concatenate(seqs)), q_off=mem.upload(np.array(q_off, np.int64)),
+                q_len=mem.upload(np.array(q_len, np.int32)), t_off=mem.upload(np.array(t_off, np.int64)),
+                t_len=mem.upload(np.array(t_len, np.int32)))
+    sdp_res, blocks = mem.zeros(n * 48), mem.zeros(12 * at)
+    ctx.sdp_device(ptrs, n, blasr_amd.SdpParams(), blasr_amd.ScoreParams(), sdp_res, blocks, at)
+    host_sdp = ctx.sdp(pairs)
+    batch = blasr_amd.RefineBatch()
+    for (q, t), s in zip(pairs, host_sdp):
+        bl = s["blocks"]
+        if len(bl):
+            batch.add(q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]], t[s["tPos"]: s["tPos"] + bl[-1, 1] + bl[-1, 2]], bl)
+        else:
+            batch.add(q[:0], t[:0], bl)
+    want = ctx.refine(batch)
+    assert want[-1].status == hip.TASK_EMPTY_GUIDE
+    ptrs["n"] = n
+    for sel in (None, [5, 0, 12, 7, 7, 3]):
+        m = n if sel is None else len(sel)
+        sel_p = 0 if sel is None else mem.upload(np.array(sel, np.int32))
+        res, ops = mem.zeros(m * 56), mem.zeros(8 * at)
+        ctx.refine_from_sdp_device(ptrs, sdp_res, blocks, m, sel_p, 16, blasr_amd.ScoreParams(), res, ops, 2 * at)
+        rec = mem.download(res, hip.RESULT_DTYPE, m)
+        ops_h = mem.download(ops, np.uint32, 2 * at)
+        for i in range(m):
+            w = want[i if sel is None else sel[i]]
+            g = blasr_amd.RefineResult(rec[i], ops_h[int(rec[i]["ops_off"]): int(rec[i]["ops_off"]) + int(rec[i]["n_ops"])])
+            assert g.status == w.status
+            assert (g.qPos, g.tPos, g.dpScore, g.nCells, g.score, g.nMatch, g.nMismatch, g.nIns, g.nDel) == \
+                   (w.qPos, w.tPos, w.dpScore, w.nCells, w.score, w.nMatch, w.nMismatch, w.nIns, w.nDel), i
+            assert g.ops.tolist() == w.ops.tolist(), i
+    mem.free()
+    ctx.close()
