@@ -20,28 +20,6 @@ using namespace blasr_hip;
 static_assert(sizeof(RefineResult) == sizeof(blasr_hip_refine_result), "result record layout");
 static_assert(offsetof(RefineResult, ops_off) == offsetof(blasr_hip_refine_result, ops_off), "result record layout");
 
-namespace {
-}  // namespace
-
-int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes) {
-  if (bytes <= b.bytes) return BLASR_HIP_OK;
-  if (b.p) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipFree(b.p));
-    b.p = nullptr;
-    b.bytes = 0;
-  }
-  const size_t want = bytes + bytes / 8 + 256;  // head-room: steady-state batches do not reallocate
-  if (hipMalloc((void **)&b.p, want) == hipSuccess) {
-    b.bytes = want;
-    return BLASR_HIP_OK;
-  }
-  (void)hipGetLastError();
-  HIP_TRY(ctx, hipMalloc((void **)&b.p, bytes));
-  b.bytes = bytes;
-  return BLASR_HIP_OK;
-}
-
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -124,6 +102,28 @@ struct Plan {
 
 }  // namespace
 
+int64_t blasr_hip_workspace_reach(const blasr_hip_ctx *ctx) { return workspace_reach(ctx); }
+int blasr_hip_grow_workspace(blasr_hip_ctx *ctx, size_t bytes) { return ensure_workspace(ctx, bytes); }
+
+int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (bytes <= b.bytes) return BLASR_HIP_OK;
+  if (b.p) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  const size_t want = bytes + bytes / 8 + 256;  // head-room: steady-state batches do not reallocate
+  if (hipMalloc((void **)&b.p, want) == hipSuccess) {
+    b.bytes = want;
+    return BLASR_HIP_OK;
+  }
+  (void)hipGetLastError();
+  HIP_TRY(ctx, hipMalloc((void **)&b.p, bytes));
+  b.bytes = bytes;
+  return BLASR_HIP_OK;
+}
+
 extern "C" {
 
 int blasr_hip_abi_version(void) { return BLASR_HIP_ABI_VERSION; }
@@ -162,7 +162,6 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     (void)hipStreamDestroy(ctx->sideStream);
   }
   if (ctx->workspace) (void)hipFree(ctx->workspace);
-  for (auto &sl : ctx->slabs) (void)hipFree(sl.first);
   if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
   for (auto &b : ctx->mapBuf)
@@ -177,6 +176,14 @@ int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes) {
   if (!ctx || bytes < (1 << 20)) return BLASR_HIP_ERR_INVALID;
   ctx->workspaceLimit = bytes;
   return BLASR_HIP_OK;
+}
+
+int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
+  if (!ctx) return 0;
+  int64_t total = (int64_t)ctx->workspaceBytes;
+  for (const auto &b : ctx->mapBuf) total += (int64_t)b.bytes;
+  if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
+  return total;
 }
 
 void *blasr_hip_stream(blasr_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

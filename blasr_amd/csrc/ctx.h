@@ -29,8 +29,6 @@ struct blasr_hip_ctx {
   int64_t fill4Launches = 0, fill4Bytes = 0, fill4Cells = 0;
   float sdpMs[4] = {0, 0, 0, 0};
   int64_t sdpCounters[3] = {0, 0, 0};
-  // grow-only slabs for the SDP stage's variable-size intermediates (bump-allocated per call)
-  std::vector<std::pair<char *, size_t>> slabs;
   // the resident genome (ASCII) and its contig table, for the window gather
   uint8_t *genome = nullptr;
   bool genomeOwned = true;  // false: adopted from the caller (blasr_hip_adopt_genome_device)
@@ -45,6 +43,11 @@ struct blasr_hip_ctx {
   int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
 };
 
+// what the workspace may grow to: the caller's limit, and the context's own allocation plus the free device memory
+// less a reserve
+int64_t blasr_hip_workspace_reach(const blasr_hip_ctx *ctx);
+// grows (never shrinks) the workspace; the old contents are NOT kept.  BLASR_HIP_ERR_NOMEM beyond the reach.
+int blasr_hip_grow_workspace(blasr_hip_ctx *ctx, size_t bytes);
 // grows (never shrinks) a context buffer; the old contents are NOT kept
 int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes);
 

@@ -21,36 +21,54 @@ static_assert(sizeof(SdpResult) == sizeof(blasr_hip_sdp_result), "result record 
 
 namespace {
 
-// Bump allocator over the context's grow-only device slabs (hipMalloc'd once, reused by every call:
-// the analogue of MappingBuffers' "grow to the high-water mark and keep", Blasr.cpp:313-369).
+// Bump allocator over the context's ONE grow-only workspace (the region the refine stage uses after this stage is
+// done with it: the analogue of MappingBuffers' "grow to the high-water mark and keep", Blasr.cpp:313-369).
+// A request that does not fit what is left of the workspace gets an allocation of its own for the rest of the
+// call; when the call ends those are freed and the workspace grown to the call's high-water mark, so that the
+// next call of that size is served from the one region again.  Nothing is ever left fragmented or unaccounted:
+// what the context holds is the workspace, bounded by blasr_hip_set_workspace_limit.
 struct Arena {
   blasr_hip_ctx *ctx;
   hipStream_t st;
-  size_t slab = 0, offset = 0;
+  size_t offset = 0, high = 0;
+  std::vector<void *> overflow;
   hipError_t err = hipSuccess;
-  int count = 0;
   Arena(blasr_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {}
+  Arena(const Arena &) = delete;
+  Arena &operator=(const Arena &) = delete;
   template <typename T>
   T *get(size_t n) {
     const size_t bytes = (std::max<size_t>(n * sizeof(T), 256) + 255) / 256 * 256;
-    while (slab < ctx->slabs.size() && offset + bytes > ctx->slabs[slab].second) {
-      slab++;
-      offset = 0;
+    high += bytes;
+    if (offset + bytes <= ctx->workspaceBytes) {
+      char *p = ctx->workspace + offset;
+      offset += bytes;
+      return reinterpret_cast<T *>(p);
     }
-    if (slab == ctx->slabs.size()) {
-      const size_t want = std::max<size_t>(bytes, (size_t)256 << 20);
-      char *p = nullptr;
-      hipError_t e = hipMalloc((void **)&p, want);
-      if (e != hipSuccess) {
-        err = e;
-        return nullptr;
-      }
-      ctx->slabs.push_back(std::make_pair(p, want));
-      offset = 0;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      err = e;
+      return nullptr;
     }
-    char *p = ctx->slabs[slab].first + offset;
-    offset += bytes;
+    overflow.push_back(p);
     return reinterpret_cast<T *>(p);
+  }
+  // end of the call (every path): the stream must be idle before memory it may still use goes away
+  ~Arena() {
+    if (overflow.empty()) return;
+    (void)hipStreamSynchronize(st);
+    for (void *p : overflow) (void)hipFree(p);
+    (void)blasr_hip_grow_workspace(ctx, high + high / 8);  // best effort: failing to grow is not an error
+  }
+};
+
+struct Events {
+  hipEvent_t a = nullptr, b = nullptr;
+  ~Events() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
   }
 };
 
@@ -88,9 +106,10 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   const int n = b->n;
   hipStream_t st = ctx->stream;
   Arena arena(ctx, st);
-  hipEvent_t evA, evB;
-  HIP_TRY(ctx, hipEventCreate(&evA));
-  HIP_TRY(ctx, hipEventCreate(&evB));
+  Events ev;
+  HIP_TRY(ctx, hipEventCreate(&ev.a));
+  HIP_TRY(ctx, hipEventCreate(&ev.b));
+  hipEvent_t evA = ev.a, evB = ev.b;
   float phaseMs[4] = {0, 0, 0, 0};
   auto tick = [&]() { (void)hipEventRecord(evA, st); };
   auto tock = [&](int phase) {
@@ -102,11 +121,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   };
 #define ARENA_CHECK()                                                                                        \
   do {                                                                                                       \
-    if (arena.err != hipSuccess) {                                                                           \
-      (void)hipEventDestroy(evA);                                                                            \
-      (void)hipEventDestroy(evB);                                                                            \
+    if (arena.err != hipSuccess)                                                                             \
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "device allocation failed: %s", hipGetErrorString(arena.err)); \
-    }                                                                                                        \
   } while (0)
 
   // ---- level 0 tasks from the batch (lengths are needed on the host to plan) ----
@@ -120,8 +136,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   std::vector<SdpTask> top(n);
   for (int i = 0; i < n; i++) {
     if (qLen[i] < 0 || tLen[i] < 0 || qLen[i] >= (1 << 24) || tLen[i] >= (1 << 24)) {
-      (void)hipEventDestroy(evA);
-      (void)hipEventDestroy(evB);
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "candidate %d: sequence length outside [0, 2^24)", i);
     }
     SdpTask &t = top[i];
@@ -203,8 +217,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     HIP_TRY(ctx, hipMemcpyAsync(&totalKeys, keyOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (totalKeys >= (1ll << 32)) {
-      (void)hipEventDestroy(evA);
-      (void)hipEventDestroy(evB);
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld target bases in one level",
                             (long long)totalKeys);
     }
@@ -246,8 +258,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     HIP_TRY(ctx, hipMemcpyAsync(&nFragTotal, fragOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (nFragTotal >= (1ll << 31)) {
-      (void)hipEventDestroy(evA);
-      (void)hipEventDestroy(evB);
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld fragments in one level",
                             (long long)nFragTotal);
     }
@@ -455,8 +465,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     fprintf(stderr, "[sdp] assembled: chain blocks %lld, sw fills %lld, pool %lld\n", (long long)poolTotal,
             (long long)swTotal, (long long)nPool);
   if (hc.overflow || nPool > poolCap) {
-    (void)hipEventDestroy(evA);
-    (void)hipEventDestroy(evB);
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "internal: block pool overflow");
   }
   int64_t *blkOff = arena.get<int64_t>(n + 1);
@@ -464,8 +472,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   const uint64_t *sortedKeys = poolKeys, *sortedVals = poolVals;
   if (nPool > 0) {
     if (nPool >= (1ll << 32)) {
-      (void)hipEventDestroy(evA);
-      (void)hipEventDestroy(evB);
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld blocks", (long long)nPool);
     }
     const unsigned endBit = (unsigned)(32 + bits_for((uint64_t)n));
@@ -487,8 +493,6 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   tock(3);
-  (void)hipEventDestroy(evA);
-  (void)hipEventDestroy(evB);
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
   ctx->sdpCounters[0] = totalInvocations;
   ctx->sdpCounters[1] = totalFrags;
@@ -530,19 +534,9 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), b->q_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), b->t_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  int64_t budgetBases = INT64_MAX;
-  {
-    size_t freeB = 0, totalB = 0, held = 0;
-    for (auto &sl : ctx->slabs) held += sl.second;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-      const int64_t reserve = std::max<int64_t>((int64_t)2 << 30, (int64_t)(totalB / 32));
-      const int64_t reach = (int64_t)held + (int64_t)freeB - reserve;
-      budgetBases = std::max<int64_t>(reach / 48, 1 << 20);
-    } else {
-      (void)hipGetLastError();
-    }
-    if (const char *e = getenv("BLASR_HIP_SDP_CHUNK_BASES")) budgetBases = std::max<int64_t>(atoll(e), 1);
-  }
+  // what the workspace may grow to: the caller's limit and what the device can still give this context
+  int64_t budgetBases = std::max<int64_t>(blasr_hip_workspace_reach(ctx) / 48, 1 << 16);
+  if (const char *e = getenv("BLASR_HIP_SDP_CHUNK_BASES")) budgetBases = std::max<int64_t>(atoll(e), 1);
   std::vector<int> cut(1, 0);
   {
     int64_t acc = 0;

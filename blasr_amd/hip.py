@@ -34,7 +34,7 @@ EXPORTS = [
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
     "blasr_hip_map_default_params", "blasr_hip_map_last_timing", "blasr_hip_map_device_arenas",
-    "blasr_hip_adopt_genome_device",
+    "blasr_hip_adopt_genome_device", "blasr_hip_held_bytes",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -223,6 +223,8 @@ def load_library():
         lib = C.CDLL(LIB_PATH)
         lib.blasr_hip_last_error.restype = C.c_char_p
         lib.blasr_hip_stream.restype = C.c_void_p
+        lib.blasr_hip_held_bytes.restype = C.c_int64
+        lib.blasr_hip_held_bytes.argtypes = [C.c_void_p]
         for name in ("blasr_hip_refine_device", "blasr_hip_refine_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_RefineBatch), C.c_int32, C.POINTER(_ScoreParams),
                                            C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
@@ -595,6 +597,9 @@ class Context:
     @property
     def stream(self):
         return self.lib.blasr_hip_stream(self.handle)
+
+    def held_bytes(self):
+        return int(self.lib.blasr_hip_held_bytes(self.handle))
 
     def set_workspace_limit(self, nbytes):
         self._check(self.lib.blasr_hip_set_workspace_limit(self.handle, int(nbytes)))

@@ -289,3 +289,253 @@ def make_sdp_workload(n_reads, read_len, seed, device, genome_len=ECOLI_K12_LENG
                 q_len=q_len.to(torch.int32).contiguous(),
                 t_off=(torch.cumsum(t_len, 0) - t_len + qpool.numel()).to(torch.int64).contiguous(),
                 t_len=t_len.to(torch.int32).contiguous())
+
+
+# ---------------------------------------------------------------------------
+# configs[2]: reads against an hg19-sized genome with planted repeat families, 1-10 candidate intervals per
+# read (bench.py).  Everything is generated on the device; nothing here aligns anything.
+# ---------------------------------------------------------------------------
+# chr1..22, X, Y of hg19 (GRCh37); the contigs sit in one concatenated genome, each followed by one N, as the
+# reference lays a multi-FASTA out (SequenceIndexDatabase::seqStartPos)
+HG19_CHROM_LENGTHS = (249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022,
+                      141213431, 135534747, 135006516, 133851895, 115169878, 107349540, 102531392, 90354753,
+                      81195210, 78077248, 59128983, 63025520, 48129895, 51304566, 155270560, 59373566)
+
+
+def contig_table(lengths):
+    """seqStartPos of contigs of the given lengths, one separator base after each."""
+    starts = [0]
+    for n in lengths:
+        starts.append(starts[-1] + int(n) + 1)
+    return np.array(starts, dtype=np.int64)
+
+
+def make_repeat_genome(contig_lengths, seed, device, families=2000, unit=(6000, 20000), copies=(2, 10),
+                       divergence=(0.01, 0.06)):
+    """An i.i.d. ACGT genome (uint8 ASCII, one N after every contig) with `families` repeat families planted: every
+    family is one random unit of `unit` bases that occurs `copies` times, each copy diverged from the unit by
+    substitutions at a rate drawn from `divergence`, on either strand, in its own slot of the genome (copies never
+    overlap).  Returns (genome tensor, seqStartPos int64 array, copy table): the copy table is a dict of int64
+    tensors sorted by position -- start, family, strand, and per family its unit length."""
+    import torch
+
+    starts = contig_table(contig_lengths)
+    total = int(starts[-1])
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    genome = torch.empty(total, dtype=torch.uint8, device=device)
+    step = 1 << 27
+    for a in range(0, total, step):
+        b = min(total, a + step)
+        genome[a:b] = lut[torch.randint(0, 4, (b - a,), generator=gen, device=device)]
+    genome[torch.as_tensor(starts[1:] - 1, device=device)] = ord("N")
+    # ---- repeat families
+    cpu = np.random.default_rng(seed)
+    n_copies = cpu.integers(copies[0], copies[1] + 1, size=families)
+    units = cpu.integers(unit[0], unit[1] + 1, size=families)
+    fam_of = np.repeat(np.arange(families), n_copies)
+    cpu.shuffle(fam_of)
+    n_total = len(fam_of)
+    slot = total // max(n_total, 1)
+    assert slot > 2 * unit[1], "genome too small for the repeat families"
+    pos = (np.arange(n_total, dtype=np.int64) * slot + cpu.integers(0, slot - unit[1] - 1, size=n_total)).astype(np.int64)
+    strand = cpu.integers(0, 2, size=n_total)
+    div = cpu.uniform(divergence[0], divergence[1], size=n_total)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    comp[:] = ord("N")
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    unit_seq = {}
+    for c in range(n_total):
+        f = int(fam_of[c])
+        U = int(units[f])
+        if f not in unit_seq:
+            unit_seq[f] = lut[torch.randint(0, 4, (U,), generator=gen, device=device)]
+        s = unit_seq[f].clone()
+        hit = torch.rand(U, generator=gen, device=device) < float(div[c])
+        sub = lut[torch.randint(0, 4, (U,), generator=gen, device=device)]
+        s = torch.where(hit, sub, s)
+        if strand[c]:
+            s = comp[s.long()].flip(0)
+        genome[int(pos[c]): int(pos[c]) + U] = s
+    table = dict(start=torch.as_tensor(pos, device=device), family=torch.as_tensor(fam_of.astype(np.int64), device=device),
+                 strand=torch.as_tensor(strand.astype(np.int64), device=device),
+                 unit=torch.as_tensor(units.astype(np.int64), device=device))
+    return genome, starts, table
+
+
+def make_map_workload(genome, copies, n_reads, read_len, seed, device, ins=0.11, dele=0.04, sub=0.01,
+                      max_unanchored=300, min_overlap=1000, spurious=2.0, max_candidates=10, slab=4096):
+    """`n_reads` PacBio-like reads drawn uniformly from `genome` (either strand, the error channel of `mutate`) and
+    what anchoring would hand MapRead for each: its true locus, the matching stretch of every other copy of a
+    repeat family the read overlaps by >= min_overlap bases, and Poisson(spurious) chance clusters elsewhere in the
+    genome (a short anchored stretch of the read against unrelated sequence) -- at most `max_candidates` intervals
+    per read (params.nCandidates), in random order.  Interval coordinates follow WeightedInterval
+    (datastructures/anchoring/WeightedInterval.h:12-29): genome span on the forward genome, read span on the strand
+    of the interval.
+
+    Returns dict: pool (uint8 tensor), reads (READ_DTYPE numpy), intervals (INTERVAL_DTYPE numpy), origin
+    (pos, strand int64 tensors), kind (numpy int8 per interval: 0 true, 1 repeat copy, 2 spurious)."""
+    import torch
+
+    from .hip import INTERVAL_DTYPE, READ_DTYPE
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    G = int(genome.numel())
+    L = read_len
+    ar = torch.arange(L, device=device)
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for i, x in enumerate(b"ACGT"):
+        code[x] = i
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    q_parts, q_lens, pos_all, strand_all = [], [], [], []
+    for s0 in range(0, n_reads, slab):
+        n = min(slab, n_reads - s0)
+        pos = torch.randint(0, G - L, (n,), generator=gen, device=device)
+        strand = torch.randint(0, 2, (n,), generator=gen, device=device)
+        idx = torch.where(strand[:, None] == 1, pos[:, None] + (L - 1 - ar)[None, :], pos[:, None] + ar[None, :])
+        raw = genome[idx]
+        tmpl = code[raw.long()]
+        tmpl = torch.where(strand[:, None] == 1, 3 - tmpl, tmpl)
+        u = torch.rand((n, L), generator=gen, device=device)
+        keep = u >= dele
+        do_sub = keep & (u < dele + sub)
+        shift = torch.randint(1, 4, (n, L), generator=gen, device=device)
+        base = torch.where(do_sub, (tmpl + shift) & 3, tmpl)
+        v = torch.rand((n, L), generator=gen, device=device).clamp_min(1e-12)
+        k = torch.floor(torch.log(v) / np.log(ins)).to(torch.int64) if ins > 0 else torch.zeros((n, L), dtype=torch.int64, device=device)
+        emit = keep.to(torch.int64) + k
+        qpos = torch.cumsum(emit, dim=1) - emit
+        rlen = emit.sum(dim=1)
+        roff = torch.cumsum(rlen, 0) - rlen
+        rd = torch.randint(0, 4, (int(rlen.sum()),), generator=gen, device=device)
+        krow, kcol = torch.nonzero(keep, as_tuple=True)
+        rd[roff[krow] + qpos[krow, kcol]] = base[krow, kcol]
+        rd = acgt[rd]
+        # a template base that is N (a contig separator) stays N in the read
+        nrow, ncol = torch.nonzero((raw == ord("N")) & keep, as_tuple=True)
+        rd[roff[nrow] + qpos[nrow, ncol]] = ord("N")
+        q_parts.append(rd)
+        q_lens.append(rlen)
+        pos_all.append(pos)
+        strand_all.append(strand)
+    q_len = torch.cat(q_lens)
+    pool = torch.cat(q_parts)
+    pos, strand = torch.cat(pos_all), torch.cat(strand_all)
+    n = n_reads
+    rid = torch.arange(n, device=device)
+
+    def rnd(hi, m):
+        return torch.randint(0, hi, (m,), generator=gen, device=device)
+
+    # ---- (1) the true locus, less the unanchored read ends
+    scale = L / q_len.to(torch.float64)
+    ua0, ua1 = rnd(max_unanchored + 1, n), rnd(max_unanchored + 1, n)
+    iv_start = [pos + (ua0 * scale).to(torch.int64)]
+    iv_end = [pos + L - (ua1 * scale).to(torch.int64)]
+    iv_qs, iv_qe = [ua0], [q_len - ua1]
+    iv_read, iv_strand, iv_kind = [rid], [strand], [torch.zeros(n, dtype=torch.int64, device=device)]
+    # ---- (2) the other copies of the repeat family the read overlaps most
+    if copies is not None and copies["start"].numel() > 0:
+        cs, cf, cstr = copies["start"], copies["family"], copies["strand"]
+        cu = copies["unit"][cf]
+        # candidates: the copy starting at or before the read's start, and the next one
+        j = torch.searchsorted(cs, pos, right=True) - 1
+        best_ov = torch.zeros(n, dtype=torch.int64, device=device)
+        best_c = torch.full((n,), -1, dtype=torch.int64, device=device)
+        for cand in (j, j + 1):
+            ok = (cand >= 0) & (cand < cs.numel())
+            cc = cand.clamp(0, cs.numel() - 1)
+            ov = (torch.minimum(pos + L, cs[cc] + cu[cc]) - torch.maximum(pos, cs[cc])).clamp_min(0)
+            ov = torch.where(ok, ov, torch.zeros_like(ov))
+            better = ov > best_ov
+            best_ov = torch.where(better, ov, best_ov)
+            best_c = torch.where(better, cc, best_c)
+        has = best_ov >= min_overlap
+        r_sel = rid[has]
+        c_sel = best_c[has]
+        # all copies of the same family: a (family -> copies) table, padded to the largest family
+        order = torch.argsort(cf, stable=True)
+        fam_sorted = cf[order]
+        n_fam = int(copies["unit"].numel())
+        fam_first = torch.searchsorted(fam_sorted, torch.arange(n_fam, device=device))
+        fam_count = torch.bincount(cf, minlength=n_fam)
+        kmax = int(fam_count.max())
+        f_sel = cf[c_sel]
+        for slot_i in range(kmax):
+            m = (slot_i < fam_count[f_sel])
+            d = order[(fam_first[f_sel] + slot_i).clamp_max(order.numel() - 1)]
+            m = m & (d != c_sel)
+            rr, c, dd = r_sel[m], c_sel[m], d[m]
+            if rr.numel() == 0:
+                continue
+            U = cu[c]
+            g0 = torch.maximum(pos[rr], cs[c])
+            g1 = torch.minimum(pos[rr] + L, cs[c] + U)           # overlapped stretch [g0, g1) of the true locus
+            # unit coordinates of the stretch (a copy on strand 1 holds the unit reverse-complemented)
+            a = torch.where(cstr[c] == 0, g0 - cs[c], cs[c] + U - g1)
+            b = torch.where(cstr[c] == 0, g1 - cs[c], cs[c] + U - g0)
+            # the same stretch in copy dd
+            h0 = torch.where(cstr[dd] == 0, cs[dd] + a, cs[dd] + U - b)
+            h1 = torch.where(cstr[dd] == 0, cs[dd] + b, cs[dd] + U - a)
+            rel = cstr[c] ^ cstr[dd]
+            # read span of the stretch, in the orientation of the true locus (= the strand of the true interval)
+            inv = q_len[rr].to(torch.float64) / L
+            qa = ((g0 - pos[rr]) * inv).to(torch.int64)
+            qb = ((g1 - pos[rr]) * inv).to(torch.int64).clamp_max(q_len[rr])
+            t0, t1 = rnd(100, rr.numel()), rnd(100, rr.numel())
+            qa2, qb2 = qa + t0, (qb - t1)
+            keepm = qb2 - qa2 >= 200
+            qs = torch.where(rel == 0, qa2, q_len[rr] - qb2)
+            qe = torch.where(rel == 0, qb2, q_len[rr] - qa2)
+            iv_start.append((h0 + torch.where(rel == 0, t0, t1))[keepm])
+            iv_end.append((h1 - torch.where(rel == 0, t1, t0))[keepm])
+            iv_qs.append(qs[keepm])
+            iv_qe.append(qe[keepm])
+            iv_read.append(rr[keepm])
+            iv_strand.append((strand[rr] ^ rel)[keepm])
+            iv_kind.append(torch.ones(int(keepm.sum()), dtype=torch.int64, device=device))
+    # ---- (3) chance clusters: a short stretch of the read against unrelated sequence
+    if spurious > 0:
+        cnt = torch.poisson(torch.full((n,), float(spurious), device=device), generator=gen).to(torch.int64)
+        rr = torch.repeat_interleave(rid, cnt)
+        m = rr.numel()
+        span = 300 + rnd(1200, m)
+        qs = (torch.rand(m, generator=gen, device=device) * (q_len[rr] - span).clamp_min(1)).to(torch.int64)
+        gs = torch.randint(0, G - 2 * L, (m,), generator=gen, device=device) + L
+        iv_start.append(gs)
+        iv_end.append(gs + span)
+        iv_qs.append(qs)
+        iv_qe.append(torch.minimum(qs + span, q_len[rr]))
+        iv_read.append(rr)
+        iv_strand.append(rnd(2, m))
+        iv_kind.append(torch.full((m,), 2, dtype=torch.int64, device=device))
+    start, end = torch.cat(iv_start), torch.cat(iv_end)
+    qs, qe = torch.cat(iv_qs), torch.cat(iv_qe)
+    owner, st, kind = torch.cat(iv_read), torch.cat(iv_strand), torch.cat(iv_kind)
+    # ---- at most max_candidates per read, the true locus and the repeat copies first; then a random order per read
+    key = owner * 4 + kind
+    o1 = torch.argsort(key, stable=True)
+    owner_s = owner[o1]
+    first = torch.searchsorted(owner_s, rid)
+    rank = torch.arange(owner_s.numel(), device=device) - first[owner_s]
+    o1 = o1[rank < max_candidates]
+    shuffle = torch.rand(o1.numel(), generator=gen, device=device)
+    o2 = torch.argsort(owner[o1].to(torch.float64) + shuffle.to(torch.float64) * 0.5, stable=True)
+    sel = o1[o2]
+    iv = np.zeros(int(sel.numel()), dtype=INTERVAL_DTYPE)
+    iv["start"] = start[sel].clamp(0, G).cpu().numpy().astype(np.uint32)
+    iv["end"] = end[sel].clamp(0, G).cpu().numpy().astype(np.uint32)
+    iv["q_start"] = qs[sel].cpu().numpy().astype(np.uint32)
+    iv["q_end"] = qe[sel].cpu().numpy().astype(np.uint32)
+    iv["read"] = owner[sel].cpu().numpy().astype(np.int32)
+    iv["strand"] = st[sel].cpu().numpy().astype(np.int32)
+    reads = np.zeros(n, dtype=READ_DTYPE)
+    ql = q_len.cpu().numpy()
+    reads["off"] = np.cumsum(ql) - ql
+    reads["length"] = ql
+    reads["subread_start"] = 0
+    reads["subread_end"] = ql
+    return dict(pool=pool.contiguous(), reads=reads, intervals=iv, origin=(pos, strand), kind=kind[sel].cpu().numpy().astype(np.int8))

@@ -130,6 +130,9 @@ const char *blasr_hip_last_error(const blasr_hip_ctx *ctx);
 /* Upper bound for the grow-only device workspace, bytes (default 48 GiB);
  * larger batches are processed in several waves of kernels. */
 int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes);
+/* Device memory the context holds right now, bytes: the workspace (shared by the SDP and the refine stage), the
+ * mapper's arenas and a genome it owns.  Everything a call needs beyond it is released before the call returns. */
+int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx);
 /* The context's stream as a hipStream_t (void* to keep HIP out of this header). */
 void *blasr_hip_stream(blasr_hip_ctx *ctx);
 

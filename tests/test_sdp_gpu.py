@@ -195,9 +195,10 @@ def test_alternative_kernels_agree(ctx, oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_batch_taken_in_chunks(ctx, monkeypatch):
+def test_batch_taken_in_chunks(ctx, oracle, monkeypatch):
     """A batch too large for the memory the device can give the context is taken in pieces
-    (BLASR_HIP_SDP_CHUNK_BASES forces small ones here): same records, block offsets counted through the pieces."""
+    (BLASR_HIP_SDP_CHUNK_BASES forces small ones here): same records, block offsets counted through the pieces,
+    and both equal the oracle's."""
     rng = np.random.default_rng(808)
     pairs = [synth.make_pair(rng, int(rng.integers(200, 3000)), flank=(0, int(rng.integers(0, 100)))) for _ in range(40)]
     whole = ctx.sdp(pairs)
@@ -209,3 +210,33 @@ def test_batch_taken_in_chunks(ctx, monkeypatch):
         assert (a["status"], a["score"], a["qPos"], a["tPos"]) == (b["status"], b["score"], b["qPos"], b["tPos"]), i
         assert np.array_equal(a["blocks"], b["blocks"]), i
         assert a["stats"] == b["stats"], i
+        w = oracle.sdp_align(*pairs[i])
+        assert (b["score"], b["qPos"], b["tPos"]) == (w["score"], w["qPos"], w["tPos"]), i
+        assert np.array_equal(b["blocks"], w["blocks"]), i
+
+
+def test_workspace_stays_bounded_over_growing_batches():
+    """Batches of growing size (what real reads are): the device memory the context holds follows the largest
+    call instead of piling up an allocation per size (one region, grown to the call's high-water mark), and a
+    repeated call allocates nothing."""
+    rng = np.random.default_rng(31)
+    ctx = blasr_amd.Context(0)
+    held, bases = [], []
+    for n in (4, 9, 17, 30, 30, 12):
+        pairs = [synth.make_pair(rng, 3000) for _ in range(n)]
+        ctx.sdp(pairs)
+        held.append(ctx.held_bytes())
+        bases.append(sum(len(q) + len(t) for q, t in pairs))
+    assert held[4] == held[3] and held[5] == held[4]        # the same size again, and a smaller one: no growth
+    assert all(b >= a for a, b in zip(held, held[1:]))
+    assert held[3] < 2 * held[2] * bases[3] / bases[2] + (64 << 20)  # grows with the batch, not with the history
+    # the refine stage shares the region
+    before = ctx.held_bytes()
+    q, t = synth.make_pair(rng, 2000)
+    s = ctx.sdp([(q, t)])[0]
+    batch = blasr_amd.RefineBatch()
+    bl = s["blocks"]
+    batch.add(q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]], t[s["tPos"]: s["tPos"] + bl[-1, 1] + bl[-1, 2]], bl)
+    assert ctx.refine(batch)[0].status == 0
+    assert ctx.held_bytes() == before
+    ctx.close()
