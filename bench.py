@@ -1,130 +1,268 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X refine path on BASELINE.json's workload.
 
-One "step" = one pass of the hot path over one batch of synthetic candidates already resident in
-HBM, through the C ABI of include/blasr_hip.h:
+One "step" = one pass of the WHOLE hot path over one block of synthetic reads whose inputs (genome, reads,
+candidate intervals) are resident in HBM: ONE call of the library's C++ MapRead driver through the C ABI of
+include/blasr_hip.h (blasr_hip_map_reads_device, blasr_amd/csrc/mapread_api.hip), in the reference's order:
 
-  blasr_hip_sdp_device     SDPAlign (k-mer seeding, chaining, SWAlign / recursive gap fills) +
-                           ComputeAlignmentStats                 (alignment/Blasr.cpp:1716-1724)
-  (device glue)            trim query/target to the SDP extent   (alignment/Blasr.cpp:850-859)
-  blasr_hip_refine_device  AffineGuidedAlign + traceback + ComputeAlignmentStats (:862-878)
+  a-1   windows of AlignIntervals from the resident genome           alignment/Blasr.cpp:1208-1336
+  a-2.. SDPAlign + ComputeAlignmentStats of every candidate interval  :1716-1724
+  a-10  sort by score, RemoveLowQualityAlignments (host, C++)         :2547, :2594-2596
+  trim  RefineAlignment's trimming, as a kernel                       :850-859
+  a-6.. AffineGuidedAlign + traceback + ComputeAlignmentStats of the survivors  :862-878
+  a-10  sort, RemoveLowQualityAlignments, RemoveOverlappingAlignments (host, C++)  :2178-2180, :2615-2616
 
-Workload at N=1 = BASELINE.json configs[1]: 100k synthetic 10 kb PacBio-like reads (ins 11 % /
-del 4 % / sub 1 %) against a 4.64 Mb i.i.d. genome (E. coli K12 length; the real FASTA is not
-available offline), -sdpTupleSize 11, band 16, default scores; one candidate window per read, built
-by the window rule of AlignIntervals.  With N>1 every rank processes its own shard of the same size (weak
-scaling, no data-path collective; one RCCL all-reduce of the run counters at the end).
+No torch kernel runs inside a step (torch only generated the inputs and carries the counters' all-reduce).
 
---contexts C maps the batch with C host threads at once, each through its own context (the C ABI's "one context
-per host thread", the reference's -nproc).  Kernels of two independent streams fill the tails and the
-latency-bound phases of each other's: 247 ms per pass with two threads against 271 ms with one.
-The default is ONE, so that every kernel has the GPU to itself and the roofline block means what it says; with
-two the same launches take 36-58 ms depending on what they happen to share the GPU with.
+Workloads (--config, BASELINE.json configs[]):
+  2 (default)  N reads of 10 kb (ins 11 % / del 4 % / sub 1 %) against an hg19-SIZED synthetic genome (24 contigs of
+               the hg19 chromosome lengths, 3.1 Gbases resident; the real FASTA is not available offline) with planted
+               repeat families; per read 1-10 candidate intervals: its true locus, the matching stretch of every
+               other copy of a repeat family it overlaps, and chance clusters against unrelated sequence.
+  1            the same reads against a 4.64 Mb genome (E. coli K12 length), one candidate per read.
+  4            30 kb reads, ins 10 % / del 5 % / sub 1 %, LOOSE intervals (target windows up to ~1.7 x the read:
+               the heavy-tailed SDP regime of BASELINE.md).
+With N>1 every rank maps its own shard of the same size against its own replica of the genome (weak scaling, no
+data-path collective; one RCCL all-reduce of the run counters at the end).  `python bench.py --gpus N` started
+without a launcher starts its N ranks itself (fresh child processes, before anything touches a GPU).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-
-# bytes per fill launch measured with rocprofv3 --pmc for (reads per GPU, read length, band): see profiles/
-PMC_FILL4_TRAFFIC = {(100000, 10000, 16, 1): 56375466304.0}
-# wavefront VALU instructions of the same launch (SQ_INSTS_VALU, same profile)
-PMC_FILL4_VALU_INSTS = {(100000, 10000, 16, 1): 31494305558.0}
-
-
-def reference_candidate(ref, q, t, band):
-    """One candidate through the REFERENCE's own functions (oracle/_ref/libblasr_ref.so: SDPAlign,
-    ComputeAlignmentStats, AffineGuidedAlign compiled from the reference sources), in the order of
-    AlignIntervals (Blasr.cpp:1716-1724) and RefineAlignment (:850-914); the same fields as the oracle's
-    refine_candidate."""
-    sdp = ref.sdp_align(q, t)
-    blocks = sdp["blocks"]
-    st = ref.compute_alignment_stats(q, t, sdp["qPos"], sdp["tPos"], blocks)
-    out = dict(sdpScore=sdp["score"], sdpStatsScore=st["score"], sdpQPos=sdp["qPos"], sdpTPos=sdp["tPos"],
-               nSdpBlocks=len(blocks), dpScore=0, nCells=0, score=0, nMatch=0, nMismatch=0, nIns=0, nDel=0,
-               qPos=sdp["qPos"], tPos=sdp["tPos"])
-    if len(blocks):
-        last = blocks[-1]
-        qs = q[sdp["qPos"]: sdp["qPos"] + int(last[0] + last[2])]
-        ts = t[sdp["tPos"]: sdp["tPos"] + int(last[1] + last[2])]
-        r = ref.affine_guided_align(qs, ts, blocks, band=band)
-        out.update({k: r[k] for k in ("dpScore", "nCells", "score", "nMatch", "nMismatch", "nIns", "nDel")})
-        out["qPos"], out["tPos"] = sdp["qPos"] + r["qPos"], sdp["tPos"] + r["tPos"]
-    return out
+# PMC figures of the dominant kernel, measured with separate rocprofv3 --pmc passes (profiles/): keyed by the
+# workload they were taken on and tagged with the library build they belong to; reported only when both match.
+PMC = {
+    # (config, reads, read_len, band): {...}   -- filled in from profiles/r02_* 
+}
 
 
-def cpu_baseline(w, n_sample, band, sdp_rec, ref_rec, cores=1):
-    """The path on one host core over the first `n_sample` candidates of the same workload: through the
-    reference's own code where its build is at hand (oracle/_ref/libblasr_ref.so, kind "reference"), else through
-    the oracle (its bit-exact restatement, kind "port").  Checker code: never on the product path.  Since the CPU
-    answers are at hand, the device's result records of the same candidates (from the last timed step) are
-    compared with them field by field."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from blasr_testlib import load_oracle, load_ref
-
-    ref = load_ref()
-    oracle = None if ref is not None else load_oracle()
-    seq = w["seq"].cpu().numpy()
-    q_off, q_len = w["q_off"][:n_sample].cpu().numpy(), w["q_len"][:n_sample].cpu().numpy()
-    t_off, t_len = w["t_off"][:n_sample].cpu().numpy(), w["t_len"][:n_sample].cpu().numpy()
-    tasks = [(seq[q_off[i]: q_off[i] + q_len[i]], seq[t_off[i]: t_off[i] + t_len[i]]) for i in range(n_sample)]
-    one = (lambda qt: reference_candidate(ref, qt[0], qt[1], band)) if ref is not None else \
-          (lambda qt: oracle.refine_candidate(qt[0], qt[1], band=band))
-    t0 = time.perf_counter()
-    if cores <= 1:
-        res = [one(qt) for qt in tasks]
-    else:
-        # the reference's -nproc: its functions are re-entrant (one MappingBuffers per call here), and ctypes
-        # releases the interpreter lock for the duration of a call, so host threads do run side by side
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=cores) as pool:
-            res = list(pool.map(one, tasks, chunksize=8))
-    dt = time.perf_counter() - t0
-    bases = int(q_len.sum())
-    mismatches = 0
-    for i, o in enumerate(res):
-        s, r = sdp_rec[i], ref_rec[i]
-        dev = (int(s[1]), int(s[5]), int(s[2]), int(s[3]), int(s[4]),           # SDP: score, stats score, qPos, tPos, blocks
-               int(r[3]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[9]),  # refine: DP score .. nDel
-               int(s[2]) + int(r[1]), int(s[3]) + int(r[2]))                   # window-relative qPos, tPos
-        cpu = (o["sdpScore"], o["sdpStatsScore"], o["sdpQPos"], o["sdpTPos"], o["nSdpBlocks"], o["dpScore"],
-               o["nCells"], o["score"], o["nMatch"], o["nMismatch"], o["nIns"], o["nDel"], o["qPos"], o["tPos"])
-        mismatches += dev != cpu or int(s[0]) != 0 or int(r[0]) != 0
-    what = ("the reference's own SDPAlign + AffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
-            if ref is not None else "the oracle's restatement of SDP + refine")
-    return dict(value=bases / dt, unit="bases/s", cores=max(cores, 1), kind="reference" if ref is not None else "port",
-                sample="first %d candidates of the same workload through %s (%.1f s on %d host thread%s, %.1f ms/read per thread)"
-                       % (n_sample, what, dt, max(cores, 1), "" if cores <= 1 else "s", dt * max(cores, 1) / n_sample * 1e3),
-                parity_checked=len(res), parity_mismatches=mismatches)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 4), help="BASELINE.json configs[] index")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the config's: 100000; 6250 for config 4)")
+    ap.add_argument("--read-len", type=int, default=0, help="template bases per read (0 = the config's)")
     ap.add_argument("--band", type=int, default=16)
-    ap.add_argument("--contexts", type=int, default=1,
-                    help="host threads (each with its own context) that map the batch at the same time")
-    ap.add_argument("--cpu-sample", type=int, default=4800, help="candidates timed on the host cores (0 = skip)")
+    ap.add_argument("--families", type=int, default=-1, help="repeat families planted in the genome (-1 = the config's)")
+    ap.add_argument("--spurious", type=float, default=-1.0, help="mean chance clusters per read (-1 = the config's)")
+    ap.add_argument("--genome-len", type=int, default=0, help="override the genome length (single contig)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the host cores (0 = skip, -1 = auto)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (0 = min(8, cores))")
+    ap.add_argument("--blasrmc-reads", type=int, default=-1,
+                    help="reads mapped by the reference binary (oracle/_ref/blasrmc) as a second baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
-    args = ap.parse_args()
+    ap.add_argument("--stub-device", action="store_true",
+                    help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
+    return ap.parse_args(argv)
 
+
+def config_defaults(args):
+    """The workload of a BASELINE.json config as concrete numbers."""
+    c = args.config
+    d = dict(reads=100000, read_len=10000, ins=0.11, dele=0.04, sub=0.01, families=0, spurious=0.0, loose=0.0,
+             max_unanchored=300, hg=False)
+    if c == 2:
+        d.update(families=4000, spurious=2.0, hg=True)
+    if c == 4:
+        d.update(reads=6250, read_len=30000, ins=0.10, dele=0.05, sub=0.01, families=0, spurious=0.0, loose=0.35,
+                 max_unanchored=2000, hg=False)
+    if args.reads > 0:
+        d["reads"] = args.reads
+    if args.read_len > 0:
+        d["read_len"] = args.read_len
+    if args.families >= 0:
+        d["families"] = args.families
+    if args.spurious >= 0:
+        d["spurious"] = args.spurious
+    return d
+
+
+def workload_label(args, d, genome_len, n_contigs):
+    """config.workload, built from what actually ran."""
+    names = {1: "configs[1]", 2: "configs[2]", 4: "configs[4] (per-GPU share)"}
+    return ("%s: %d synthetic %.0f kb reads per GPU (ins %.0f%%/del %.0f%%/sub %.0f%%) vs a %d-base synthetic genome "
+            "(%d contig%s%s), %d planted repeat families, %.1f chance clusters per read%s, -sdpTupleSize 11, band %d, "
+            "SMRT matrix, ins=del=5, open=50, ext=0, nCandidates 10; timed step = windows + SDP + sort/filter + refine "
+            "+ sort/filters" % (
+                names[args.config], d["reads"], d["read_len"] / 1e3, d["ins"] * 100, d["dele"] * 100, d["sub"] * 100,
+                genome_len, n_contigs, "" if n_contigs == 1 else "s",
+                ", hg19 chromosome lengths" if d["hg"] and not args.genome_len else "", d["families"], d["spurious"],
+                ", intervals loosened by up to %.0f%% of the read per side" % (d["loose"] * 100) if d["loose"] else "",
+                args.band))
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks as fresh children (the contract's own command
+    line) before this process has touched a GPU, and leave with their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (checker code: never on the product path)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores):
+    """The path for the first `n_reads` reads of the same workload on the host cores: every candidate interval
+    through the reference's OWN SDPAlign + ComputeAlignmentStats, the survivors through its AffineGuidedAlign +
+    ComputeAlignmentStats (oracle/_ref/libblasr_ref.so, built from the reference's sources where they lie: kind
+    "reference"; the oracle's bit-exact restatement where that build is absent: kind "port"), windows and the per-read
+    sort / filters through the oracle's restatement of AlignIntervals' window rule and the post filters.  Since the
+    CPU answers are at hand, the device's hits of the same reads (last timed step) are compared with them."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from blasr_testlib import HIT_FIELDS, MapperOracle, load_oracle, load_ref, oracle_map_reads
+
+    ref = load_ref()
+    engine = ref if ref is not None else load_oracle()
+    mo = MapperOracle()
+    reads, iv = wl["reads"][:n_reads], wl["intervals"]
+    iv = iv[iv["read"] < n_reads]
+    pool = wl["pool"][: int(reads["off"][-1] + reads["length"][-1])].cpu().numpy()
+    genome = genome_t.cpu().numpy()  # (3 GB for configs[2]: the checker's window rule reads it by address)
+    contigs = None if len(starts) <= 2 else starts.astype(np.uint32)
+
+    def one(r):
+        mine = iv[iv["read"] == r].copy()
+        mine["read"] = 0
+        rd = reads[r: r + 1].copy()
+        p = pool[int(rd["off"][0]): int(rd["off"][0]) + int(rd["length"][0])]
+        rd["off"] = 0
+        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band)[0]
+
+    t0 = time.perf_counter()
+    if cores <= 1:
+        res = [one(r) for r in range(n_reads)]
+    else:
+        # the reference's -nproc: its functions are re-entrant, and ctypes releases the interpreter lock for the
+        # duration of a call, so host threads do run side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=cores) as pool_ex:
+            res = list(pool_ex.map(one, range(n_reads), chunksize=4))
+    dt = time.perf_counter() - t0
+    aligned = sum(int(reads["length"][r]) for r in range(n_reads) if res[r])
+    mismatches = 0
+    for r in range(n_reads):
+        mine = hits[int(hit_off[r]): int(hit_off[r + 1])]
+        local = np.nonzero(iv["read"] == r)[0]  # the checker numbered the read's intervals 0..
+        glob = np.nonzero(wl["intervals"]["read"] == r)[0]
+        ok = len(mine) == len(res[r])
+        for h, x in zip(mine, res[r]):
+            for f in HIT_FIELDS:
+                want = x[f] if f != "interval" else int(glob[x[f]])
+                ok = ok and h[f] == want
+        mismatches += not ok
+    what = ("the reference's own SDPAlign + AffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
+            if ref is not None else "the oracle's restatement of SDP + refine")
+    return dict(value=aligned / dt, unit="bases/s", cores=max(cores, 1), kind="reference" if ref is not None else "port",
+                sample="first %d reads of the same workload (%d candidate intervals) through %s, windows / sort / filters "
+                       "through the oracle (%.1f s on %d host thread%s, %.1f ms/read per thread)"
+                       % (n_reads, len(iv), what, dt, max(cores, 1), "" if cores <= 1 else "s",
+                          dt * max(cores, 1) / max(n_reads, 1) * 1e3),
+                parity_checked=n_reads, parity_mismatches=int(mismatches))
+
+
+def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores):
+    """The reference BINARY (oracle/_ref/blasrmc -nproc N -m 4 -bestn 1) on a FASTA dump of the first `n_reads`
+    reads against a FASTA of their own loci (+- 5 kb, one contig each: the 3-Gbase genome has no suffix array the
+    binary could load, and building one is out of a benchmark's reach), wall time less a zero-read run: whole BLASR
+    -- anchoring, intervals, the path, mapQV, printing -- per read."""
+    import tempfile
+
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "blasrmc")
+    if not os.path.exists(exe) or n_reads <= 0:
+        return None
+    pos, strand = wl["origin"]
+    pos = pos[:n_reads].cpu().numpy()
+    G = int(genome_t.numel())
+    reads = wl["reads"][:n_reads]
+    pool = wl["pool"][: int(reads["off"][-1] + reads["length"][-1])].cpu().numpy()
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "genome.fasta"), "w") as f:
+            for r in range(n_reads):
+                a, b = max(0, int(pos[r]) - 5000), min(G, int(pos[r]) + read_len + 5000)
+                f.write(">locus%d\n%s\n" % (r, bytes(genome_t[a:b].cpu().numpy()).decode()))
+        with open(os.path.join(tmp, "reads.fasta"), "w") as f:
+            for r in range(n_reads):
+                s = pool[int(reads["off"][r]): int(reads["off"][r]) + int(reads["length"][r])]
+                f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(s), bytes(s).decode()))
+        open(os.path.join(tmp, "none.fasta"), "w").write(">none/0/0_4\nACGT\n")
+        wall = {}
+        for tag, fa in (("none", "none.fasta"), ("reads", "reads.fasta")):
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, os.path.join(tmp, fa), os.path.join(tmp, "genome.fasta"), "-m", "4", "-bestn", "1",
+                                "-nproc", str(cores), "-out", os.path.join(tmp, tag + ".m4")],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+            wall[tag] = time.perf_counter() - t0
+            if p.returncode != 0:
+                return dict(error="blasrmc exit %d" % p.returncode)
+        lines = open(os.path.join(tmp, "reads.m4")).read().splitlines()
+    dt = max(wall["reads"] - wall["none"], 1e-9)
+    names = set(x.split()[0] for x in lines)
+    aligned = sum(int(reads["length"][r]) for r in range(n_reads) if any(n.startswith("read%d/" % r) for n in names))
+    return dict(value=aligned / dt, unit="bases/s", cores=cores, kind="reference binary",
+                sample="oracle/_ref/blasrmc -nproc %d -m 4 -bestn 1 on the first %d reads against a FASTA of their own "
+                       "loci (+-5 kb): %.1f s wall less %.1f s of a zero-read run (suffix array built in-process), "
+                       "%d reads reported; whole BLASR incl. anchoring, not only the path"
+                       % (cores, n_reads, wall["reads"], wall["none"], len(names)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))  # nothing below has run: no GPU call in this process
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs"
+                         % (args.gpus, world, world, args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    d = config_defaults(args)
+
+    import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from blasr_amd import shard
+
+    if args.stub_device:
+        # dry run of everything around the device step: launch, rendezvous, shard seeds, counters, reduce, report
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        n = d["reads"]
+        t0 = time.perf_counter()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0 + 1e-3)
+        totals = shard.reduce_counters(n, n, n * d["read_len"], 0)
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "scaling": "weak", "config": {"workload": workload_label(args, d, 0, 1),
+                                                            "reads": totals["reads"], "aligned_reads": totals["aligned_reads"]},
+                              "value": totals["aligned_bases"] * args.steps / elapsed, "stub": True,
+                              "seeds": [args.seed + r for r in range(world)]}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the refine path has no CPU implementation")
     torch.cuda.set_device(local_rank)
@@ -134,124 +272,79 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    import threading
-
     import blasr_amd
-    from blasr_amd import shard, synth
+    from blasr_amd import hip, synth
 
-    class Mapper:
-        """One host thread's share of the batch: its own context (own HIP streams and workspace), as the
-        reference's -nproc threads each own their MappingBuffers (Blasr.cpp:318-369, :4811-4842)."""
-
-        def __init__(self, reads, seed):
-            self.ctx = blasr_amd.Context(local_rank)
-            self.ctx.set_workspace_limit((160 << 30) // args.contexts)
-            self.w = w = synth.make_sdp_workload(reads, args.read_len, seed, dev)
-            self.n = n = int(w["q_len"].numel())
-            self.sdp_ptrs = {k: w[k].data_ptr() for k in ("seq", "q_off", "q_len", "t_off", "t_len")}
-            self.sdp_res = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
-            self.blk_cap = int(torch.minimum(w["q_len"], w["t_len"]).sum().item() // 4 + n)
-            self.blocks = torch.zeros(3 * self.blk_cap, dtype=torch.int32, device=dev)
-            self.ref_res = torch.zeros(n * 56, dtype=torch.uint8, device=dev)
-            self.ops_cap = int((w["q_len"].sum().item() + w["t_len"].sum().item()) // 2 + 1024)
-            self.ops = torch.zeros(self.ops_cap, dtype=torch.int32, device=dev)
-            # the glue between the two calls runs on torch's stream: its own one per thread when several threads map
-            # at once (the default stream would serialise them)
-            self.glue = torch.cuda.Stream(device=dev) if args.contexts > 1 else torch.cuda.current_stream()
-            self.acc = {}
-
-        def step(self):
-            n, w = self.n, self.w
-            # a-2..a-5 + a-9: SDPAlign and its statistics
-            self.ctx.sdp_device(self.sdp_ptrs, n, sdp_par, score, self.sdp_res.data_ptr(), self.blocks.data_ptr(),
-                                self.blk_cap)
-            t_sdp = self.ctx.sdp_last_timing()
-            with torch.cuda.stream(self.glue):
-                # RefineAlignment's trimming (Blasr.cpp:850-859): pure index arithmetic on the result records
-                r = self.sdp_res.view(torch.int32).view(n, 12)
-                q_pos, t_pos, n_blk = r[:, 2].to(torch.int64), r[:, 3].to(torch.int64), r[:, 4].contiguous()
-                blk_off = self.sdp_res.view(torch.int64).view(n, 6)[:, 5].contiguous()
-                last = (blk_off + n_blk - 1).clamp_min(0)
-                b3 = self.blocks.view(-1, 3)
-                has = n_blk > 0
-                q_len2 = torch.where(has, b3[last, 0] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
-                t_len2 = torch.where(has, b3[last, 1] + b3[last, 2], torch.zeros_like(n_blk)).contiguous()
-                q_off2 = (w["q_off"] + q_pos).contiguous()
-                t_off2 = (w["t_off"] + t_pos).contiguous()
-                ptrs = dict(seq=w["seq"].data_ptr(), q_off=q_off2.data_ptr(), q_len=q_len2.data_ptr(),
-                            t_off=t_off2.data_ptr(), t_len=t_len2.data_ptr(), blocks=self.blocks.data_ptr(),
-                            blk_off=blk_off.data_ptr(), n_blocks=n_blk.data_ptr())
-                self.glue.synchronize()  # the glue ran on a torch stream, the library uses its own
-            # a-6..a-9: guided banded affine DP, traceback, statistics
-            self.ctx.refine_device(ptrs, n, args.band, score, self.ref_res.data_ptr(), self.ops.data_ptr(),
-                                   self.ops_cap)
-            t_ref = self.ctx.last_timing()
-            f4 = self.ctx.last_fill4()
-            t_ref.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"],
-                         fill4_cells=f4["cells"])
-            for k, v in list(t_sdp.items()) + list(t_ref.items()):
-                self.acc[k] = self.acc.get(k, 0) + v
-
-    score, sdp_par = blasr_amd.ScoreParams(), blasr_amd.SdpParams()
-    C = max(1, args.contexts)
-    share = [args.reads * (i + 1) // C - args.reads * i // C for i in range(C)]
-    mappers = [Mapper(share[i], args.seed + rank * C + i) for i in range(C)]
+    # ---- inputs, generated on the device ------------------------------------------------------------------------
+    t_gen = time.perf_counter()
+    if args.genome_len > 0:
+        contig_lengths = [args.genome_len]
+    elif d["hg"]:
+        contig_lengths = list(synth.HG19_CHROM_LENGTHS)
+    else:
+        contig_lengths = [synth.ECOLI_K12_LENGTH]
+    genome, starts, copies = synth.make_repeat_genome(contig_lengths, 1, dev, families=d["families"])
+    wl = synth.make_map_workload(genome, copies if d["families"] > 0 else None, d["reads"], d["read_len"],
+                                 args.seed + rank, dev, ins=d["ins"], dele=d["dele"], sub=d["sub"],
+                                 max_unanchored=d["max_unanchored"], spurious=d["spurious"], loose=d["loose"])
+    G = int(genome.numel())
+    n_reads, n_iv = len(wl["reads"]), len(wl["intervals"])
+    reads_t = torch.from_numpy(wl["reads"].view(np.uint8)).to(dev)
+    iv_t = torch.from_numpy(wl["intervals"].view(np.uint8)).to(dev)
     torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
 
-    def run_steps(k):
-        # the batch is mapped by C host threads at once, each through its own context: kernels of independent
-        # streams fill the tails and the latency-bound phases of each other's
-        def body(m):
-            for _ in range(k):
-                m.step()
-        if C == 1:
-            body(mappers[0])
-            return
-        ths = [threading.Thread(target=body, args=(m,)) for m in mappers]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+    ctx = blasr_amd.Context(local_rank)
+    ctx.set_workspace_limit(200 << 30)
+    ctx.adopt_genome_device(genome.data_ptr(), G, starts.astype(np.uint32) if len(starts) > 2 else None)
+    params = ctx.map_params(band=args.band)
+    hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
+    hit_off = np.zeros(n_reads + 1, dtype=np.int64)
+    acc = {}
+
+    def step():
+        ctx.map_reads_device(n_reads, reads_t.data_ptr(), wl["pool"].data_ptr(), n_iv, iv_t.data_ptr(), params, hits, hit_off)
+        t = dict(ctx.map_last_timing())
+        t.update(ctx.sdp_last_timing())
+        t.update(ctx.last_timing())
+        f4 = ctx.last_fill4()
+        t.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"], fill4_cells=f4["cells"])
+        for k, v in t.items():
+            acc[k] = acc.get(k, 0) + v
+        return t
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    run_steps(args.warmup)
-    for m in mappers:
-        m.acc = {}
+    for _ in range(args.warmup):
+        step()
+    acc.clear()
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    last = None
+    for _ in range(args.steps):
+        last = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    acc = {}
-    for m in mappers:
-        for k, v in m.acc.items():
-            acc[k] = acc.get(k, 0) + v
 
-    n = sum(m.n for m in mappers)
-    ref_res = torch.cat([m.ref_res for m in mappers])
-    q_len_all = torch.cat([m.w["q_len"] for m in mappers])
-    rec = ref_res.view(torch.int32).view(n, 14)
-    ok = rec[:, 0] == 0
     # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
-    totals = shard.reduce_counters(n, int(ok.sum()), int((q_len_all.to(torch.int64) * ok).sum()),
-                                   int(rec[:, 4].to(torch.int64).sum()), device=dev)
+    totals = shard.reduce_counters(n_reads, last["aligned_reads"], last["aligned_bases"], last["dp_cells"], device=dev)
     elapsed = shard.max_over_ranks(elapsed, device=dev)
 
     if rank == 0:
         K = args.steps
         value = totals["aligned_bases"] * K / elapsed
-        fill_ms = acc["fill_ms"]
-        # the dominant kernel: fillp_kernel<16, true> (four candidates per wavefront), timed on its own with HIP events on
-        # the library's stream; its algorithmic bytes = 1 B per band cell + the bases + 8 B per row record of
-        # the candidates it processed (DESIGN.md 2.3)
         f4_ms, f4_launches = acc["fill4_ms"], max(acc["fill4_launches"], 1)
         achieved = acc["fill4_bytes"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0
+
+        def gbps(nbytes, ms):
+            return nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+
+        kinds = np.bincount(wl["kind"], minlength=3)
         out = {
-            "metric": "aligned bases/sec (refine path: SDP chaining + guided banded affine DP), GCUPS per GPU",
+            "metric": "aligned bases/sec (refine path: windows + SDP chaining + guided banded affine DP + filters), GCUPS per GPU",
             "value": value,
             "unit": "bases/s",
             "n_gpus": world,
@@ -262,57 +355,66 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": "synthetic: i.i.d. %d-base genome, %d x %d-base reads per GPU (ins 11%%/del 4%%/sub 1%%), one "
-                    "candidate window per read (AlignIntervals window rule)" % (synth.ECOLI_K12_LENGTH, args.reads,
-                                                                                args.read_len),
-            "config": {"workload": "configs[1]: 100k synthetic 10 kb reads vs E. coli-K12-length genome, "
-                                   "-sdpTupleSize 11, band 16, SMRT matrix, ins=del=5, open=50, ext=0; SDP + refine",
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "band": args.band,
-                       "host_threads_per_gpu": C,
-                       "candidates": totals["reads"], "aligned_reads": totals["aligned_reads"]},
+            "data": "synthetic, generated on the device in %.0f s: %d-base i.i.d. genome with %d planted repeat families "
+                    "(%d copies), %d reads, %d candidate intervals (%d true loci, %d repeat copies, %d chance clusters)"
+                    % (t_gen, G, d["families"], 0 if copies is None else int(copies["start"].numel()), n_reads, n_iv,
+                       kinds[0], kinds[1], kinds[2]),
+            "config": {"workload": workload_label(args, d, G, len(starts) - 1),
+                       "reads_per_gpu": n_reads, "read_len": d["read_len"], "band": args.band,
+                       "candidate_intervals_per_gpu": n_iv, "candidates_refined_per_gpu": int(last["refined"]),
+                       "reads": totals["reads"], "aligned_reads": totals["aligned_reads"], "hits_per_gpu": int(last["hits"])},
             "gcups_per_gpu": totals["dp_cells"] / world * K / elapsed / 1e9,
-            # HIP-event times of the stages summed over the contexts; with more than one they overlap in time
+            # wall time of the mapper's stages (host clock around each stage of the C++ driver) ...
             "stage_ms_per_step": {
+                "windows": acc["windows_ms"] / K, "sdp": acc["sdp_ms"] / K, "filters_after_sdp": acc["filter1_ms"] / K,
+                "refine": acc["refine_ms"] / K, "filters": acc["filter2_ms"] / K,
+                # ... and HIP-event times of the device phases inside the two big ones
                 "sdp_keys_sort": acc["keys_ms"] / K, "sdp_match_order": acc["match_ms"] / K,
                 "sdp_chain": acc["chain_ms"] / K, "sdp_blocks_fills_assembly": acc["blocks_ms"] / K,
-                "refine_geometry": acc["geometry_ms"] / K, "refine_fill": fill_ms / K,
+                "refine_geometry": acc["geometry_ms"] / K, "refine_fill": acc["fill_ms"] / K,
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
+            # the dominant kernel: fillp_kernel<16, true> (four candidates per wavefront), timed on its own with HIP
+            # events on the library's stream; its algorithmic bytes = 1 B per band cell + the bases + 8 B per row
+            # record of the candidates it processed.  The kernel is bound by VALU issue, not by HBM
+            # (profiles/r02_valu_rate.txt): the HBM fraction is what the contract asks for.
             "roofline": {"bound": "hbm", "kernel": "blasr_hip::fillp_kernel<16, true>", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         # HBM bytes of one launch from the PMC passes of this same workload (separate rocprofv3
-                         # --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); not measurable in-process
-                         "traffic": PMC_FILL4_TRAFFIC.get((args.reads, args.read_len, args.band, C)),
-                         "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                         "profiles/r01_v24_pmc_counters_100k_reads.json: 2 x FETCH_SIZE + WRITE_SIZE "
-                                         "of the fillp_kernel<16, true> launch",
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
-                         "launches": f4_launches, "avg_launch_ms": f4_ms / f4_launches,
+                         "launches_per_step": f4_launches / K, "avg_launch_ms": f4_ms / f4_launches,
                          "kernel_gcups": acc["fill4_cells"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0,
-                         "candidates_note": "candidates whose rows all fit 112 cells (82 % here); the others take "
-                                            "fill_kernel, one per wavefront",
-                         "fill_stage_gcups": acc["cells"] / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0},
+                         "limiter": "VALU issue (integer min / compare / DPP issue at 4 cycles per wave64 instruction)",
+                         "fill_stage_gcups": acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0},
+            # the SDP phases against the same roof: algorithmic bytes by SURVEY.md 8(d)'s model over HIP-event time
+            "sdp_rooflines": {
+                name: {"bound": "hbm", "achieved": gbps(acc[b], acc[m]), "peak": 8000.0, "unit": "GB/s",
+                       "frac": gbps(acc[b], acc[m]) / 8000.0, "algorithmic_bytes_per_step": acc[b] / K,
+                       "ms_per_step": acc[m] / K}
+                for name, b, m in (("keys_sort", "keys_bytes", "keys_ms"), ("match_order", "match_bytes", "match_ms"),
+                                   ("chain", "chain_bytes", "chain_ms"), ("blocks_fills_assembly", "blocks_bytes", "blocks_ms"))},
+            "device_memory_held_gb": ctx.held_bytes() / 2**30,
         }
-        valu = PMC_FILL4_VALU_INSTS.get((args.reads, args.read_len, args.band, C))
-        if valu and f4_ms > 0:
-            # what actually bounds the kernel (integer DP: no MFMA, far from the HBM roof): VALU issue slots.
-            # A wave64 VALU instruction holds its SIMD for 4 cycles (tools/valu_rate.hip); 256 CUs x 4 SIMDs.
-            out["roofline"]["valu_issue"] = {
-                "wave_insts_per_launch": valu, "cycles_per_wave_inst": 4, "simds": 1024, "clock_ghz_max": 2.4,
-                "frac_of_issue_slots_at_max_clock": valu * 4 / (1024 * 2.4e9 * (f4_ms / f4_launches) / 1e3),
-                "note": "SQ_INSTS_VALU of the launch (profiles/r01_v24_pmc_counters_100k_reads.json) x 4 cycles over "
-                        "the SIMD cycles of the measured launch time at the 2.4 GHz maximum clock"}
-        if world == 1 and args.cpu_sample > 0:
-            m0 = mappers[0]
-            ns = min(args.cpu_sample, m0.n)
+        pmc = PMC.get((args.config, n_reads, d["read_len"], args.band))
+        if pmc:
+            out["roofline"]["traffic"] = pmc["traffic"]
+            out["roofline"]["traffic_note"] = pmc["note"]
+        if world == 1:
             cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(m0.w, ns, args.band,
-                                               m0.sdp_res.view(torch.int32).view(m0.n, 12)[:ns].cpu().numpy(),
-                                               rec[:ns].cpu().numpy(), cores)
+            ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, int(2400 * 10000 / d["read_len"]) // max(1, round(n_iv / n_reads)))
+            ns = min(ns, n_reads)
+            if ns > 0:
+                out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores)
+            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 2000000 // d["read_len"]))
+            if nb > 0:
+                ncores = os.cpu_count() or 1
+                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores))
+                if b is not None:
+                    out["cpu_baseline_whole_blasr"] = b
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

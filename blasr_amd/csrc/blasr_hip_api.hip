@@ -146,6 +146,11 @@ int blasr_hip_create(int device, blasr_hip_ctx **out) {
     delete ctx;
     return BLASR_HIP_ERR_HIP;
   }
+  for (auto &e : ctx->events)
+    if (hipEventCreate(&e) != hipSuccess) {
+      blasr_hip_destroy(ctx);
+      return BLASR_HIP_ERR_HIP;
+    }
   *out = ctx;
   return BLASR_HIP_OK;
 }
@@ -161,6 +166,8 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->sideStream);
     (void)hipStreamDestroy(ctx->sideStream);
   }
+  for (auto &e : ctx->events)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
@@ -252,13 +259,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   int rc = ensure_workspace(ctx, fixedBytes);
   if (rc) return rc;
 
-  hipEvent_t ev[8], evF4[2];
-  for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-  for (auto &e : evF4) HIP_TRY(ctx, hipEventCreate(&e));
-  auto destroyEvents = [&]() {
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    for (auto &e : evF4) (void)hipEventDestroy(e);
-  };
+  hipEvent_t *ev = ctx->events, *evF4 = ctx->events + 8;  // the context's own: nothing to release on an error path
+  auto destroyEvents = [&]() {};
   int64_t fill4Bytes = 0, fill4Cells = 0;
   ctx->fill4Ms = 0;
   ctx->fill4Launches = 0;

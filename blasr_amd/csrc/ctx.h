@@ -18,6 +18,7 @@ struct blasr_hip_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;  // long thin kernels that can run underneath the main ones
+  hipEvent_t events[12] = {};        // timing / cross-stream events of the refine call, created with the context
   char *workspace = nullptr;
   size_t workspaceBytes = 0;
   int64_t workspaceLimit = 48ll << 30;
@@ -29,6 +30,7 @@ struct blasr_hip_ctx {
   int64_t fill4Launches = 0, fill4Bytes = 0, fill4Cells = 0;
   float sdpMs[4] = {0, 0, 0, 0};
   int64_t sdpCounters[3] = {0, 0, 0};
+  int64_t sdpBytes[4] = {0, 0, 0, 0};
   // the resident genome (ASCII) and its contig table, for the window gather
   uint8_t *genome = nullptr;
   bool genomeOwned = true;  // false: adopted from the caller (blasr_hip_adopt_genome_device)

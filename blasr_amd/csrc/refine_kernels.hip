@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, in
   bool bad = false;
   for (int b = lane; b < nBlocks; b += 64) {
     int q = blocks[3 * b], t = blocks[3 * b + 1], l = blocks[3 * b + 2];
-    if (q < 0 || t < 0 || l <= 0 || q + l > qLen || t + l > tLen) bad = true;
+    if (q < 0 || t < 0 || l <= 0 || (int64_t)q + l > qLen || (int64_t)t + l > tLen) bad = true;
     if (b + 1 < nBlocks) {
       int nq = blocks[3 * b + 3], nt = blocks[3 * b + 4];
-      if (nq < q + l || nt < t + l) bad = true;
+      if (nq < (int64_t)q + l || nt < (int64_t)t + l) bad = true;
     }
   }
   if (__ballot(bad) != 0ull) {
@@ -185,12 +185,23 @@ __global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, in
   GuideCursor g;
   guide_begin(g, blocks, nBlocks, band);
   int widest = guide_row0_tpost(g) + 1;
+  // the kernels address a candidate's cells with 32 bits (GuideCursor::cellCarry, the row records): count in 64
+  // here and refuse a candidate whose band would wrap them (a megabase read with a band of thousands)
+  int64_t cells64 = (int64_t)g.cellCarry;
   for (int r0 = 1; r0 <= g.Q; r0 += 64) {
     int t, lo, hi;
     unsigned rs;
+    const unsigned before = g.cellCarry;
     guide_group(g, r0, flagScratch[wave], t, lo, hi, rs);
+    cells64 += (int64_t)(unsigned)(g.cellCarry - before);
     int w = (r0 + lane <= g.Q) ? hi - lo + 1 : 0;
     widest = max(widest, wave_max(w));
+    if (w < 0 || w >= (1 << 24)) cells64 = INT64_MAX / 2;  // (uniform after the ballot below)
+  }
+  if (__ballot(cells64 >= ((int64_t)1 << 31) - 64) != 0ull) {
+    out.status = TASK_BAD_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
   }
   out.rows = g.Q;
   out.cells = (int64_t)g.cellCarry;

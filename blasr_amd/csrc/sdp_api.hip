@@ -94,6 +94,12 @@ int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t cou
   return BLASR_HIP_OK;
 }
 
+int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]) {
+  if (!ctx || !bytes) return BLASR_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; i++) bytes[i] = ctx->sdpBytes[i];
+  return BLASR_HIP_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -111,6 +117,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipEventCreate(&ev.b));
   hipEvent_t evA = ev.a, evB = ev.b;
   float phaseMs[4] = {0, 0, 0, 0};
+  int64_t phaseBytes[4] = {0, 0, 0, 0};  // algorithmic bytes by SURVEY 8(d)'s model, see blasr_hip_sdp_last_bytes
   auto tick = [&]() { (void)hipEventRecord(evA, st); };
   auto tock = [&](int phase) {
     (void)hipEventRecord(evB, st);
@@ -196,8 +203,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.fused = arena.get<int32_t>(nTasks);
     lv.chainList = nullptr;
     if (!getenv("BLASR_HIP_NO_CHAIN4")) {
-      lv.chainList = arena.get<int32_t>(nTasks + 1);
+      lv.chainList = arena.get<int32_t>(nTasks + 2);
       lv.chainCount = lv.chainList + nTasks;
+      lv.scatterCount = lv.chainCount + 1;
     }
     ARENA_CHECK();
     launch_sdp_classify(lv, st);
@@ -220,6 +228,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld target bases in one level",
                             (long long)totalKeys);
     }
+    phaseBytes[0] += totalKeys * 8 * (1 + 2 * ((2 * k + 7) / 8));  // key + position records, P radix passes read + write
     uint64_t *keysIn = arena.get<uint64_t>((size_t)totalKeys);
     uint64_t *keysOut = arena.get<uint64_t>((size_t)totalKeys);
     ARENA_CHECK();
@@ -245,6 +254,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       int64_t totalQ = 0;
       HIP_TRY(ctx, hipMemcpyAsync(&totalQ, qPosOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(ctx, hipStreamSynchronize(st));
+      phaseBytes[1] += totalQ * 8;
       lv.qPosOff = qPosOff;
       lv.hits = arena.get<uint64_t>((size_t)std::max<int64_t>(totalQ, 1));
       ARENA_CHECK();
@@ -254,14 +264,31 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     launch_sdp_gather_sizes(lv, 1, sizes, st);
     HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, fragOff, (int64_t)0, (size_t)nTasks + 1,
                                          rocprim::plus<int64_t>(), st));
-    int64_t nFragTotal = 0;
+    int64_t nFragTotal = 0, nColTotal = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&nFragTotal, fragOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    // column slots of the invocations whose fragments may scatter (sdp_chain_bits_kernel): one per target base
+    int64_t *colOff = nullptr;
+    if (lv.chainList != nullptr && !getenv("BLASR_HIP_NO_CHAIN_BITS")) {
+      colOff = arena.get<int64_t>(nTasks + 1);
+      ARENA_CHECK();
+      launch_sdp_gather_sizes(lv, 4, sizes, st);
+      HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, colOff, (int64_t)0, (size_t)nTasks + 1,
+                                           rocprim::plus<int64_t>(), st));
+      HIP_TRY(ctx, hipMemcpyAsync(&nColTotal, colOff + nTasks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (nColTotal > 0) {
+      lv.colOff = colOff;
+      lv.colEnt = arena.get<int4>((size_t)nColTotal);
+      ARENA_CHECK();
+    }
     if (nFragTotal >= (1ll << 31)) {
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld fragments in one level",
                             (long long)nFragTotal);
     }
     totalFrags += nFragTotal;
+    phaseBytes[1] += nFragTotal * 16;  // fragments written
+    phaseBytes[2] += nFragTotal * 16;  // and read by the sweep
     const size_t nf = (size_t)std::max<int64_t>(nFragTotal, 1);
     lv.fragOff = fragOff;
     lv.raw = arena.get<Frag>(nf);
@@ -493,7 +520,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   tock(3);
+  phaseBytes[3] += nPool * 12;
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
+  for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = phaseBytes[i];
   ctx->sdpCounters[0] = totalInvocations;
   ctx->sdpCounters[1] = totalFrags;
   ctx->sdpCounters[2] = swTotal;
@@ -516,6 +545,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   if (blocksUsed) *blocksUsed = 0;
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = 0;
   for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = 0;
+  for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = 0;
   const int n = b->n;
   if (n == 0) return BLASR_HIP_OK;
   if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
@@ -551,7 +581,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     cut.push_back(n);
   }
   float ms[4] = {0, 0, 0, 0};
-  int64_t counters[3] = {0, 0, 0}, used = 0;
+  int64_t counters[3] = {0, 0, 0}, used = 0, bytes[4] = {0, 0, 0, 0};
   bool overflow = false;
   for (size_t c = 0; c + 1 < cut.size(); c++) {
     const int first = cut[c], cnt = cut[c + 1] - cut[c];
@@ -570,7 +600,9 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     used += usedHere;
     for (int i = 0; i < 4; i++) ms[i] += ctx->sdpMs[i];
     for (int i = 0; i < 3; i++) counters[i] += ctx->sdpCounters[i];
+    for (int i = 0; i < 4; i++) bytes[i] += ctx->sdpBytes[i];
   }
+  for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = bytes[i];
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = ms[i];
   for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = counters[i];
   if (blocksUsed) *blocksUsed = used;

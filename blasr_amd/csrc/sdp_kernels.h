@@ -62,6 +62,11 @@ struct SdpLevelArrays {
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
   int32_t *chainList, *chainCount;  // invocations for sdp_chain4_kernel (not fused, >= 1 fragment); null: use sdp_chain_kernel
+  // invocations whose fragments scatter over the rectangle (the recursion's Global calls: unrelated sequence gives
+  // chance matches anywhere) take sdp_chain_bits_kernel: they come first in chainList, scatterCount of them
+  int32_t *scatterCount;
+  const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)
+  int4 *colEnt;                 // per target column: {column, fragment, cost, x+y} of the column set's entry there
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)
   int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
@@ -125,7 +130,10 @@ void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const ui
                        const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
                        int64_t blocksCap, int64_t blkBase, hipStream_t st);
 void launch_pool_offsets(const uint64_t *poolKeys, int64_t nPool, int n, int64_t *off, hipStream_t st);
-// tLen (or the three raw fragment counts summed, or nFrag) of every task as int64, for the offset scans
+// widest target sdp_chain_bits_kernel takes (its bitmap lives in LDS)
+int sdp_chain_bits_max_target();
+// tLen (or the three raw fragment counts summed, or nFrag; 4: the column slots of lv.colEnt) of every task as int64,
+// for the offset scans
 void launch_sdp_gather_sizes(const SdpLevelArrays &lv, int what, int64_t *out, hipStream_t st);
 void launch_sdp_segment_ends(const SdpLevelArrays &lv, int64_t *ends, hipStream_t st);
 

@@ -61,6 +61,13 @@ __host__ __device__ inline bool task_uses_index(int tLen, int k, int idxMaxT) {
 }
 // ... and so do very short ones: their k-mers sit in registers, two per lane (sdp_match_kernel)
 constexpr int kTinyT = 128;
+// An invocation that may take sdp_chain_bits_kernel (and so gets a column slot per target base): a Global call --
+// the recursion's; a top-level Local alignment is near-diagonal -- that the small kernels cannot have (they take at
+// most 64 raw fragments, and only without ties above 16), on a target the LDS bitmap spans.
+constexpr int kBitsMaxTarget = 65536;
+__host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragments) {
+  return t.type == 1 && rawFragments > 16 && t.tLen <= kBitsMaxTarget;
+}
 __host__ __device__ inline bool task_needs_keys(int tLen, int k, int idxMaxT) {
   return tLen > kTinyT && !task_uses_index(tLen, k, idxMaxT);
 }
@@ -1809,17 +1816,20 @@ __device__ __forceinline__ int4 *uniform_ptr(int4 *p, int srcLane) {
 // ones start first.  Entries that are not taken get the key 0 and end up behind the list.
 __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, uint32_t *keys, int32_t *vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool take = false;
+  bool take = false, scatter = false;
   if (i < lv.n && !lv.fused[i]) {
     if (lv.nFrag[i] == 0) lv.chainEnd[i] = -1;
     else take = true;
+    // (a task that is not fused has more than 16 raw fragments, so it was given its column slots)
+    scatter = take && lv.colEnt != nullptr && lv.colOff[i + 1] > lv.colOff[i];
   }
   if (i < lv.n) {
-    keys[i] = take ? (uint32_t)lv.nFrag[i] : 0u;
+    keys[i] = take ? ((uint32_t)lv.nFrag[i] | (scatter ? 0x80000000u : 0u)) : 0u;  // the scattered ones sort first
     vals[i] = i;
   }
-  const unsigned long long mask = __ballot(take);
+  const unsigned long long mask = __ballot(take && !scatter), smask = __ballot(scatter);
   if (mask != 0ull && lane_id() == 0) atomicAdd(lv.chainCount, (int)__popcll(mask));
+  if (smask != 0ull && lane_id() == 0) atomicAdd(lv.scatterCount, (int)__popcll(smask));
 }
 
 // The sweep of up to four invocations, one per 16-lane group: `on` says whether this lane's group has one, `idx`
@@ -2116,11 +2126,252 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
 
 __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int lane = lane_id();
-  const int nList = *lv.chainCount;
+  const int nList = *lv.chainCount, nScatter = *lv.scatterCount;  // the list starts with sdp_chain_bits_kernel's
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
   const bool on = slot < nList;
-  chain4_body<false>(lv, prm, on, on ? lv.chainList[slot] : 0);
+  chain4_body<false>(lv, prm, on, on ? lv.chainList[nScatter + slot] : 0);
+}
+
+// ---------------------------------------------------------------------------
+// sdp_chain_bits: the same sweep for invocations whose fragments SCATTER over the rectangle.
+//
+// chain4's column set keeps its top in registers because an alignment is near-diagonal: fragments retire in (x,y)
+// order, so the set is touched at its high end.  The recursion's calls on the gaps of a chance chain (a candidate
+// interval on unrelated sequence: a few random k-mer hits chained, then SDPAlign on the rectangles between them
+// with a shorter word) see the opposite: hits anywhere, costs that rise along the chain (the square-root term of
+// the column predecessor outweighs a fragment's weight), a set of hundreds of entries and 40 % of the operations
+// far below its top -- each a shifted array in memory there.  Here the set is a BITMAP over the target's columns
+// in LDS (one wavefront per invocation, 2048 words = 65536 columns) with a one-word-per-lane summary in a register,
+// and the entries sit in memory at their column: membership, predecessor, successor, insert and erase are a
+// constant number of LDS reads and ballots whatever the size of the set and wherever they land.
+// ---------------------------------------------------------------------------
+constexpr int kBitsWords = kBitsMaxTarget / 32;
+struct BitCols {
+  uint32_t *bits;    // LDS: bit c of the map = column c is in the set
+  int4 *ent;         // memory: the entry of a member column {column, fragment, cost, x + y}
+  uint32_t summary;  // lane i, bit b: word 32 i + b of the map is not empty
+  int n;
+};
+__device__ __forceinline__ uint32_t bc_word(const BitCols &s, int w) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)s.bits[w]);
+}
+// the largest member <= y, or -1
+__device__ __forceinline__ int bc_pred_le(const BitCols &s, int y) {
+  const int w = y >> 5, b = y & 31;
+  const uint32_t word = bc_word(s, w) & (b == 31 ? 0xffffffffu : ((2u << b) - 1u));
+  if (word) return (w << 5) + 31 - __clz((int)word);
+  const int lane = lane_id(), li = w >> 5, bi = w & 31;
+  uint32_t m = s.summary;
+  if (lane == li) m &= (1u << bi) - 1u;
+  if (lane > li) m = 0;
+  const unsigned long long ball = __ballot(m != 0u);
+  if (ball == 0ull) return -1;
+  const int hl = 63 - __clzll((long long)ball);
+  const uint32_t hm = (uint32_t)__builtin_amdgcn_readlane((int)m, hl);
+  const int w2 = (hl << 5) + 31 - __clz((int)hm);
+  return (w2 << 5) + 31 - __clz((int)bc_word(s, w2));
+}
+// the smallest member > y, or -1
+__device__ __forceinline__ int bc_succ_gt(const BitCols &s, int y) {
+  const int w = y >> 5, b = y & 31;
+  const uint32_t word = bc_word(s, w) & (b == 31 ? 0u : ~((2u << b) - 1u));
+  if (word) return (w << 5) + __ffs((int)word) - 1;
+  const int lane = lane_id(), li = w >> 5, bi = w & 31;
+  uint32_t m = s.summary;
+  if (lane == li) m &= bi == 31 ? 0u : ~((2u << bi) - 1u);
+  if (lane < li) m = 0;
+  const unsigned long long ball = __ballot(m != 0u);
+  if (ball == 0ull) return -1;
+  const int ll = __builtin_ctzll(ball);
+  const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)m, ll);
+  const int w2 = (ll << 5) + __ffs((int)lm) - 1;
+  return (w2 << 5) + __ffs((int)bc_word(s, w2)) - 1;
+}
+__device__ __forceinline__ void bc_set(BitCols &s, int y) {
+  const int w = y >> 5;
+  const uint32_t v = bc_word(s, w) | (1u << (y & 31));
+  if (lane_id() == 0) s.bits[w] = v;
+  __builtin_amdgcn_wave_barrier();
+  if (lane_id() == (w >> 5)) s.summary |= 1u << (w & 31);
+}
+__device__ __forceinline__ void bc_clear(BitCols &s, int y) {
+  const int w = y >> 5;
+  const uint32_t v = bc_word(s, w) & ~(1u << (y & 31));
+  if (lane_id() == 0) s.bits[w] = v;
+  __builtin_amdgcn_wave_barrier();
+  if (v == 0u && lane_id() == (w >> 5)) s.summary &= ~(1u << (w & 31));
+}
+// one entry, the same address in every lane (a broadcast load; the scalar cache would not see the wave's own stores)
+__device__ __forceinline__ int4 bc_entry(const BitCols &s, int col) {
+  const int4 e = s.ent[col];
+  return make_int4(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y),
+                   __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
+}
+
+__device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const SdpParams &prm, int idx, const SdpTask &t,
+                                                 int F, uint32_t *ldsBits) {
+  const int lane = lane_id();
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
+  const int *predCl = lv.predCl + base, *above = lv.above + base;
+  BitCols cols;
+  cols.bits = ldsBits;
+  cols.ent = lv.colEnt + lv.colOff[idx];
+  cols.summary = 0;
+  cols.n = 0;
+  for (int w = lane; w < ((t.tLen + 31) >> 5); w += 64) ldsBits[w] = 0;
+  __builtin_amdgcn_wave_barrier();
+  const int k = t.k;
+  const uint32_t fragmentLength = (uint32_t)k, weight = (uint32_t)k;
+  int fTrail = 0;
+  int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
+  uint32_t maxLen = 0;
+  FragWindow cur, prev;
+  int curPrev = -1;
+  cur.x = cur.y = cur.cost = cur.len = 0;
+  prev = cur;
+  for (int w0 = 0; w0 < F; w0 += 64) {
+    prev = cur;
+    int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
+    if (w0 + lane < F) {
+      const Frag f = fr[w0 + lane];
+      fxV = (int)f.x;
+      fyV = (int)f.y;
+      flV = (int)f.len;
+      fpV = predCl[w0 + lane];
+      faV = above[w0 + lane];
+    }
+    cur.x = fxV;
+    cur.y = fyV;
+    auto view = [&](int p) {
+      FragView v;
+      v.len = 0;
+      if (p >= w0) {
+        v.x = __builtin_amdgcn_readlane(cur.x, p - w0);
+        v.y = __builtin_amdgcn_readlane(cur.y, p - w0);
+        v.cost = __builtin_amdgcn_readlane(cur.cost, p - w0);
+      } else if (p >= w0 - 64) {
+        v.x = __builtin_amdgcn_readlane(prev.x, p - w0 + 64);
+        v.y = __builtin_amdgcn_readlane(prev.y, p - w0 + 64);
+        v.cost = __builtin_amdgcn_readlane(prev.cost, p - w0 + 64);
+      } else {
+        const Frag f = fr[p];
+        v.x = __builtin_amdgcn_readfirstlane((int)f.x);
+        v.y = __builtin_amdgcn_readfirstlane((int)f.y);
+        v.cost = __builtin_amdgcn_readfirstlane(cost[p]);
+      }
+      return v;
+    };
+    auto view_len = [&](int p) {
+      if (p >= w0) return __builtin_amdgcn_readlane(cur.len, p - w0);
+      if (p >= w0 - 64) return __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
+      return __builtin_amdgcn_readfirstlane(chainLen[p]);
+    };
+    const int nHere = min(64, F - w0);
+    for (int j = 0; j < nHere; j++) {
+      const int i = w0 + j;
+      const int fx = __builtin_amdgcn_readlane(fxV, j), fy = __builtin_amdgcn_readlane(fyV, j);
+      const int fl = __builtin_amdgcn_readlane(flV, j);
+      // rows leaving the window: fragments with x <= f.x - k - 2 are retired before row f.x is scored (:248-309)
+      while (fTrail < i) {
+        const FragView ft = view(fTrail);
+        if ((int64_t)ft.x + k + 2 > (int64_t)fx) break;
+        const bool member = ((bc_word(cols, ft.y >> 5) >> (ft.y & 31)) & 1u) != 0u;
+        bool store = true;
+        if (member) store = bc_entry(cols, ft.y).z < ft.cost;  // sic (:260-267): replaced only when the existing entry is CHEAPER
+        if (store) {
+          if (lane == 0) cols.ent[ft.y] = make_int4(ft.y, fTrail, ft.cost, ft.x + ft.y);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (!member) {
+            bc_set(cols, ft.y);
+            cols.n++;
+          }
+          // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
+          while (cols.n >= 2) {
+            const int sc = bc_succ_gt(cols, ft.y);
+            if (sc < 0 || !(bc_entry(cols, sc).z > ft.cost)) break;
+            bc_clear(cols, sc);
+            cols.n--;
+          }
+        }
+        fTrail++;
+      }
+      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
+      bool foundPrev = false;
+      if (cols.n > 0) {
+        const int pc = bc_pred_le(cols, fy);
+        if (pc >= 0) {
+          const int4 at = bc_entry(cols, pc);
+          cpFrag = at.y;
+          cp = at.z + isqrt_floor(abs((fx + fy) - at.w)) - fl;
+          foundPrev = true;
+        }
+      }
+      const int clFrag = __builtin_amdgcn_readlane(fpV, j);
+      if (clFrag >= 0) {
+        const FragView p = view(clFrag);
+        int ov = (int)(fragmentLength - (uint32_t)(fy - p.y)) * prm.match;
+        if (ov > 0) ov = 0;
+        cl = p.cost + ov + indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel);
+        foundPrev = true;
+      }
+      const int aboveIdx = __builtin_amdgcn_readlane(faV, j);
+      if (aboveIdx >= 0) {
+        const FragView p = view(aboveIdx);
+        ca = (int)((uint32_t)p.cost + (fragmentLength - (uint32_t)(fy - p.y)) * (uint32_t)prm.match +
+                   (uint32_t)indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel));
+        foundPrev = true;
+      }
+      int mc = cl < ca ? cl : ca;
+      if (cp < mc) mc = cp;
+      int myCost, myPrev;
+      uint32_t myLen;
+      if (foundPrev && (t.type == 1 || (t.type == 0 && mc < 0))) {
+        myCost = (int)((uint32_t)mc - weight);
+        if (mc == cp) myPrev = cpFrag;
+        else if (mc == cl) myPrev = clFrag;
+        else myPrev = aboveIdx;
+        myLen = (uint32_t)view_len(myPrev) + 1u;
+      } else {
+        myPrev = -1;
+        myLen = 1;
+        if (t.type == 1)
+          myCost = (int)((uint32_t)(fx + fy) * (uint32_t)prm.sdpDel + fragmentLength * (uint32_t)prm.match - weight);
+        else myCost = (int)(fragmentLength * (uint32_t)prm.match - weight);
+      }
+      if (lane == j) {
+        cur.cost = myCost;
+        cur.len = (int)myLen;
+        curPrev = myPrev;
+      }
+      if (minCost > myCost) {
+        minCost = myCost;
+        minIdx = i;
+      }
+      if (myLen > maxLen) {
+        maxLen = myLen;
+        maxLenIdx = i;
+      }
+    }
+    if (w0 + lane < F) {
+      cost[w0 + lane] = cur.cost;
+      chainPrev[w0 + lane] = curPrev;
+      chainLen[w0 + lane] = cur.len;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
+}
+
+__global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, SdpParams prm) {
+  __shared__ uint32_t bits[4][kBitsWords];
+  const int wave = threadIdx.x >> 6;
+  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+  if (slot >= *lv.scatterCount) return;
+  const int idx = lv.chainList[slot];
+  chain_sweep_bits(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], bits[wave]);
 }
 
 // sdp_small4_kernel: what sdp_small_kernel does, for invocations of at most kSmall4Max raw fragments (most of
@@ -2950,6 +3201,7 @@ __global__ __launch_bounds__(256) void sdp_gather_sizes_kernel(SdpLevelArrays lv
   if (what == 0) v = task_needs_keys(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT) ? lv.tasks[i].tLen : 0;
   else if (what == 3) v = lv.tasks[i].qLen;
   else if (what == 1) v = (int64_t)lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
+  else if (what == 4) v = task_may_scatter(lv.tasks[i], lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2]) ? lv.tasks[i].tLen : 0;
   else v = lv.nFrag[i];
   out[i] = v;
 }
@@ -3149,14 +3401,18 @@ void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st) {
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
 }
+int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.chainCount, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(lv.scatterCount, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
   if (lv.n <= 0) return;
   if (lv.chainList != nullptr) {  // four invocations per wavefront; the list is sorted (launch_sdp_chain_list + sort)
+    if (lv.colEnt != nullptr)   // the scattered ones, one per wavefront (the device knows how many: the grid is an upper bound)
+      hipLaunchKernelGGL(sdp_chain_bits_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
     hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
     hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);

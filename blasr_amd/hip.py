@@ -34,7 +34,7 @@ EXPORTS = [
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
     "blasr_hip_map_default_params", "blasr_hip_map_last_timing", "blasr_hip_map_device_arenas",
-    "blasr_hip_adopt_genome_device", "blasr_hip_held_bytes",
+    "blasr_hip_adopt_genome_device", "blasr_hip_held_bytes", "blasr_hip_sdp_last_bytes",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -235,6 +235,7 @@ def load_library():
         lib.blasr_hip_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
         lib.blasr_hip_refine_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         lib.blasr_hip_sdp_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_sdp_last_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.blasr_hip_refine_last_fill4.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64),
                                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         for name in ("blasr_hip_sdp_device", "blasr_hip_sdp_host"):
@@ -886,8 +887,11 @@ class Context:
         ms = (C.c_float * 4)()
         cnt = (C.c_int64 * 3)()
         self._check(self.lib.blasr_hip_sdp_last_timing(self.handle, ms, cnt))
+        by = (C.c_int64 * 4)()
+        self._check(self.lib.blasr_hip_sdp_last_bytes(self.handle, by))
         return dict(keys_ms=ms[0], match_ms=ms[1], chain_ms=ms[2], blocks_ms=ms[3], invocations=cnt[0],
-                    fragments=cnt[1], sw_fills=cnt[2])
+                    fragments=cnt[1], sw_fills=cnt[2], keys_bytes=by[0], match_bytes=by[1], chain_bytes=by[2],
+                    blocks_bytes=by[3])
 
     def sdp_device(self, dev_ptrs, n, sdp, score, results_ptr, blocks_ptr, blocks_capacity):
         """Device-resident variant (raw device addresses); returns the number of block triplets produced."""

@@ -366,12 +366,14 @@ def make_repeat_genome(contig_lengths, seed, device, families=2000, unit=(6000, 
 
 
 def make_map_workload(genome, copies, n_reads, read_len, seed, device, ins=0.11, dele=0.04, sub=0.01,
-                      max_unanchored=300, min_overlap=1000, spurious=2.0, max_candidates=10, slab=4096):
+                      max_unanchored=300, min_overlap=1000, spurious=2.0, max_candidates=10, loose=0.0, slab=4096):
     """`n_reads` PacBio-like reads drawn uniformly from `genome` (either strand, the error channel of `mutate`) and
     what anchoring would hand MapRead for each: its true locus, the matching stretch of every other copy of a
     repeat family the read overlaps by >= min_overlap bases, and Poisson(spurious) chance clusters elsewhere in the
     genome (a short anchored stretch of the read against unrelated sequence) -- at most `max_candidates` intervals
-    per read (params.nCandidates), in random order.  Interval coordinates follow WeightedInterval
+    per read (params.nCandidates), in random order.  loose > 0 widens the true locus' interval by up to loose x the
+    read length on either side (anchor clusters that reach beyond the read: target windows much longer than the
+    query).  Interval coordinates follow WeightedInterval
     (datastructures/anchoring/WeightedInterval.h:12-29): genome span on the forward genome, read span on the strand
     of the interval.
 
@@ -433,8 +435,10 @@ def make_map_workload(genome, copies, n_reads, read_len, seed, device, ins=0.11,
     # ---- (1) the true locus, less the unanchored read ends
     scale = L / q_len.to(torch.float64)
     ua0, ua1 = rnd(max_unanchored + 1, n), rnd(max_unanchored + 1, n)
-    iv_start = [pos + (ua0 * scale).to(torch.int64)]
-    iv_end = [pos + L - (ua1 * scale).to(torch.int64)]
+    lo_extra = rnd(int(loose * L) + 1, n) if loose > 0 else torch.zeros(n, dtype=torch.int64, device=device)
+    hi_extra = rnd(int(loose * L) + 1, n) if loose > 0 else torch.zeros(n, dtype=torch.int64, device=device)
+    iv_start = [(pos + (ua0 * scale).to(torch.int64) - lo_extra).clamp_min(0)]
+    iv_end = [(pos + L - (ua1 * scale).to(torch.int64) + hi_extra).clamp_max(G)]
     iv_qs, iv_qe = [ua0], [q_len - ua1]
     iv_read, iv_strand, iv_kind = [rid], [strand], [torch.zeros(n, dtype=torch.int64, device=device)]
     # ---- (2) the other copies of the repeat family the read overlaps most

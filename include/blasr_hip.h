@@ -223,6 +223,11 @@ int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch, con
  * [2] chain, [3] blocks + gap fills + assembly; counters: [0] SDPAlign invocations (all levels),
  * [1] fragments chained, [2] SWAlign gap fills. */
 int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]);
+/* Algorithmic bytes of the same four phases of the last SDP call, by the model of SURVEY.md 8(d) summed over all
+ * SDPAlign invocations (recursion levels included): [0] (tLen-k+1) x 8 B x (1 + 2P) key records through P = ceil(2k/8)
+ * radix passes, [1] (qLen-k+1) x 8 B of query k-mers + 16 B per fragment written, [2] 16 B per fragment read by the
+ * sweep, [3] 12 B per block. */
+int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]);
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -605,10 +605,31 @@ static int cset_lower_bound(const cset_t *s, int col) {
   return lo;
 }
 
+/* probe (diagnostics for the device kernels' design, not part of any result): how large the column set of a sweep
+ * gets and how far from its top the operations land.  out: [0] sweeps, [1] fragments, [2] largest set, [3] set
+ * operations, [4] operations more than 16 entries below the top, [5..9] fragments in sweeps whose largest set was
+ * <= 16, <= 64, <= 256, <= 1024, larger */
+static int g_cs_probe = 0;
+static long g_cs_stat[10];
+void bo_probe_colset(int enable, long *out10) {
+  if (out10) memcpy(out10, g_cs_stat, sizeof(g_cs_stat));
+  g_cs_probe = enable;
+  memset(g_cs_stat, 0, sizeof(g_cs_stat));
+}
+#define CS_PROBE_OP(pos, n)                              \
+  do {                                                   \
+    if (g_cs_probe) {                                    \
+      g_cs_stat[3]++;                                    \
+      if ((pos) < (n) - 16) g_cs_stat[4]++;              \
+      if ((n) > csMax) csMax = (n);                      \
+    }                                                    \
+  } while (0)
+
 static int sdp_lcs(uint32_t queryLength, frag_t *F, int nF, uint32_t fragmentLength, int insertion,
                    int deletion, int match, int alignType, int **chainOut) {
   *chainOut = NULL;
   if (nF < 1) return 0;
+  int csMax = 0;
   qsort(F, nF, sizeof(frag_t), cmp_frag_xy); /* :78 (keys unique -> order unique) */
   for (int i = 0; i < nF; i++) F[i].index = i;
   /* StoreAbove :55-68 */
@@ -633,6 +654,7 @@ static int sdp_lcs(uint32_t queryLength, frag_t *F, int nF, uint32_t fragmentLen
       /* colSet.Predecessor: largest column <= f.y (SDPSet.h:94-119) */
       if (cols.n > 0) {
         int pos = cset_lower_bound(&cols, (int)f->y);
+        CS_PROBE_OP(pos, cols.n);
         int have = 0;
         if (pos < cols.n && cols.col[pos] == (int)f->y)
           have = 1;
@@ -706,6 +728,7 @@ static int sdp_lcs(uint32_t queryLength, frag_t *F, int nF, uint32_t fragmentLen
       while (fTrail < nF && F[fTrail].x == trailRow) {
         frag_t *f = &F[fTrail];
         int pos = cset_lower_bound(&cols, (int)f->y);
+        CS_PROBE_OP(pos, cols.n);
         int member = (pos < cols.n && cols.col[pos] == (int)f->y);
         int store = 0;
         if (member) {
@@ -742,6 +765,12 @@ static int sdp_lcs(uint32_t queryLength, frag_t *F, int nF, uint32_t fragmentLen
         ++fTrail;
       }
     }
+  }
+  if (g_cs_probe) {
+    g_cs_stat[0]++;
+    g_cs_stat[1] += nF;
+    if (csMax > g_cs_stat[2]) g_cs_stat[2] = csMax;
+    g_cs_stat[csMax <= 16 ? 5 : csMax <= 64 ? 6 : csMax <= 256 ? 7 : csMax <= 1024 ? 8 : 9] += nF;
   }
   if (alignType == BO_LOCAL) maxChainFragment = minFragmentIndex;
   int n = 0, cap = 64;

@@ -240,3 +240,39 @@ def test_workspace_stays_bounded_over_growing_batches():
     assert ctx.refine(batch)[0].status == 0
     assert ctx.held_bytes() == before
     ctx.close()
+
+
+def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
+    """Candidate intervals on unrelated sequence (chance anchor clusters): a few random k-mer hits are chained and the
+    recursion runs SDPAlign(Global) with shorter words on the large rectangles between them -- fragments scattered all
+    over the rectangle, a column set of hundreds of entries touched anywhere (sdp_chain_bits_kernel: bitmap column
+    set).  Local top level as AlignIntervals calls it, and Global calls on random rectangles directly; both chain
+    kernels (BLASR_HIP_NO_CHAIN_BITS: the register-tail sweep) against the oracle."""
+    rng = np.random.default_rng(4242)
+    pairs = [(np.ascontiguousarray(synth.mutate(synth.random_genome(int(rng.integers(3000, 9000)), 500 + i), rng)),
+              synth.random_genome(int(rng.integers(4000, 12000)), 600 + i)) for i in range(10)]
+    want = [oracle.sdp_align(q, t) for q, t in pairs]
+    def as_list(st):
+        return [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]]
+
+    stats = [as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])) for (q, t), w in zip(pairs, want)]
+    for env in (None, "BLASR_HIP_NO_CHAIN_BITS"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        got = ctx.sdp(pairs)
+        if env:
+            monkeypatch.delenv(env)
+        for i, (g, w, st) in enumerate(zip(got, want, stats)):
+            _check(g, w, st, "unrelated %d %s" % (i, env))
+    # Global calls with short words on random rectangles, as the recursion issues them
+    from blasr_testlib import SdpParams as OSdp
+    for k in (7, 5):
+        rect = [(synth.random_genome(int(rng.integers(400, 2500)), 700 + 10 * k + i),
+                 synth.random_genome(int(rng.integers(400, 3500)), 800 + 10 * k + i)) for i in range(8)]
+        osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
+        sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
+        got = ctx.sdp(rect, sdp=sp)
+        for i, ((q, t), g) in enumerate(zip(rect, got)):
+            w = oracle.sdp_align(q, t, None, osp)
+            st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
+            _check(g, w, st, "rectangle k=%d %d" % (k, i))
