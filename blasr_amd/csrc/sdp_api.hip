@@ -203,9 +203,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.fused = arena.get<int32_t>(nTasks);
     lv.chainList = nullptr;
     if (!getenv("BLASR_HIP_NO_CHAIN4")) {
-      lv.chainList = arena.get<int32_t>(nTasks + 2);
+      lv.chainList = arena.get<int32_t>(nTasks + 4);
       lv.chainCount = lv.chainList + nTasks;
-      lv.scatterCount = lv.chainCount + 1;
+      if (const char *e = getenv("BLASR_HIP_CHAIN_SCATTER")) lv.scatterMode = atoi(e);
     }
     ARENA_CHECK();
     launch_sdp_classify(lv, st);

@@ -61,10 +61,13 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
-  int32_t *chainList, *chainCount;  // invocations for sdp_chain4_kernel (not fused, >= 1 fragment); null: use sdp_chain_kernel
-  // invocations whose fragments scatter over the rectangle (the recursion's Global calls: unrelated sequence gives
-  // chance matches anywhere) take sdp_chain_bits_kernel: they come first in chainList, scatterCount of them
-  int32_t *scatterCount;
+  // The sweep's invocations (not fused, >= 1 fragment), sorted by category and fragment count, and the four category
+  // counts: chainCount[0] sdp_chain4_kernel's; [1..3] the invocations whose fragments scatter over the rectangle (the
+  // recursion's Global calls: unrelated sequence gives chance matches anywhere), which come FIRST in the list:
+  // [3] sdp_chain_bits_kernel with a large target, [2] with a small one, [1] sdp_chain_wide_kernel.
+  // chainList null: everything through sdp_chain_kernel.
+  int32_t *chainList, *chainCount;
+  int scatterMode;              // 1: the scattered invocations take sdp_chain_wide_kernel instead (tests)
   const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)
   int4 *colEnt;                 // per target column: {column, fragment, cost, x+y} of the column set's entry there
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)

@@ -65,6 +65,8 @@ constexpr int kTinyT = 128;
 // the recursion's; a top-level Local alignment is near-diagonal -- that the small kernels cannot have (they take at
 // most 64 raw fragments, and only without ties above 16), on a target the LDS bitmap spans.
 constexpr int kBitsMaxTarget = 65536;
+constexpr int kBitsSmallTarget = 16384;  // sdp_chain_bits_kernel's small instantiation (2 KB of LDS per wavefront)
+constexpr int kWideSets = 8;         // register sets of 64 column-set entries in sdp_chain_wide_kernel
 __host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragments) {
   return t.type == 1 && rawFragments > 16 && t.tLen <= kBitsMaxTarget;
 }
@@ -1443,11 +1445,17 @@ __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv
 // global memory; the wavefront keeps the LAST <= 64 entries in registers (lane j = entry nBase + j),
 // because fragments retire in (x,y) order and the alignment is near-diagonal: almost every insert,
 // replace, erase and predecessor query lands in that tail and needs no memory round trip.
-struct ColSet {
+// kS: register sets of 64 entries.  One is enough for an alignment (near-diagonal); sdp_chain_wide_kernel keeps four
+// -- 256 entries -- for invocations whose fragments scatter: there the set has a few hundred entries and is touched
+// anywhere, and with the whole set in registers an insert in its middle is a handful of DPP moves instead of a shifted
+// array in memory.
+template <int kS>
+struct ColSetT {
   int4 *g;        // global storage, entries [0, nBase) are valid there
   int n, nBase;   // total entries; first entry held in registers
-  int4 tail;      // per-lane register copy of entry nBase + lane (valid while nBase + lane < n)
+  int4 r[kS];     // r[j], lane l = entry nBase + 64 j + l (valid while that index < n)
 };
+typedef ColSetT<1> ColSet;
 __device__ int cs_global_lower_bound(const int4 *g, int n, int key) {  // wave-cooperative 64-ary search
   const int lane = lane_id();
   int lo = 0, hi = n;
@@ -1474,55 +1482,105 @@ __device__ __forceinline__ int4 lane_shift_from(const int4 &v, int delta) {  // 
   return make_int4(__builtin_amdgcn_ds_bpermute(src, v.x), __builtin_amdgcn_ds_bpermute(src, v.y),
                    __builtin_amdgcn_ds_bpermute(src, v.z), __builtin_amdgcn_ds_bpermute(src, v.w));
 }
-__device__ void cs_flush(ColSet &s) {  // registers -> global
+__device__ __forceinline__ int4 lane_shr1(const int4 &v, const int4 &edge) {  // lane i <- lane i - 1, lane 0 <- edge
+  return make_int4(wave_shr1(v.x, edge.x), wave_shr1(v.y, edge.y), wave_shr1(v.z, edge.z), wave_shr1(v.w, edge.w));
+}
+template <int kS>
+__device__ void cs_flush(ColSetT<kS> &s) {  // registers -> global
   const int lane = lane_id();
-  if (s.nBase + lane < s.n) s.g[s.nBase + lane] = s.tail;
+#pragma unroll
+  for (int j = 0; j < kS; j++)
+    if (s.nBase + 64 * j + lane < s.n) s.g[s.nBase + 64 * j + lane] = s.r[j];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-__device__ void cs_reload(ColSet &s) {  // global -> registers: the last <= 64 entries
+template <int kS>
+__device__ void cs_reload(ColSetT<kS> &s) {  // global -> registers: the last <= 64 kS entries
   const int lane = lane_id();
-  s.nBase = s.n > 64 ? s.n - 64 : 0;
-  if (s.nBase + lane < s.n) s.tail = s.g[s.nBase + lane];
+  s.nBase = s.n > 64 * kS ? s.n - 64 * kS : 0;
+#pragma unroll
+  for (int j = 0; j < kS; j++)
+    if (s.nBase + 64 * j + lane < s.n) s.r[j] = s.g[s.nBase + 64 * j + lane];
 }
-__device__ int cs_lower_bound(const ColSet &s, int key) {
+template <int kS>
+__device__ int cs_lower_bound(const ColSetT<kS> &s, int key) {
   if (s.n == 0) return 0;
   const int lane = lane_id();
-  if (s.nBase == 0 || key > __builtin_amdgcn_readlane(s.tail.x, 0))
-    return s.nBase + __popcll(__ballot(s.nBase + lane < s.n && s.tail.x < key));
+  if (s.nBase == 0 || key > __builtin_amdgcn_readlane(s.r[0].x, 0)) {
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kS; j++) cnt += __popcll(__ballot(s.nBase + 64 * j + lane < s.n && s.r[j].x < key));
+    return s.nBase + cnt;
+  }
   return cs_global_lower_bound(s.g, s.nBase, key);
 }
-__device__ int4 cs_get(const ColSet &s, int pos) {
-  if (pos >= s.nBase) return lane_bcast(s.tail, pos - s.nBase);
+template <int kS>
+__device__ int4 cs_get(const ColSetT<kS> &s, int pos) {
+  if (pos >= s.nBase) {
+    const int rel = pos - s.nBase;
+    int4 v = lane_bcast(s.r[0], rel & 63);
+#pragma unroll
+    for (int j = 1; j < kS; j++)
+      if ((rel >> 6) == j) v = lane_bcast(s.r[j], rel & 63);
+    return v;
+  }
   return s.g[pos];
 }
-__device__ int cs_get_cost(const ColSet &s, int pos) {
-  if (pos >= s.nBase) return __builtin_amdgcn_readlane(s.tail.z, pos - s.nBase);
+template <int kS>
+__device__ int cs_get_cost(const ColSetT<kS> &s, int pos) {
+  if (pos >= s.nBase) {
+    const int rel = pos - s.nBase;
+    int v = __builtin_amdgcn_readlane(s.r[0].z, rel & 63);
+#pragma unroll
+    for (int j = 1; j < kS; j++)
+      if ((rel >> 6) == j) v = __builtin_amdgcn_readlane(s.r[j].z, rel & 63);
+    return v;
+  }
   return s.g[pos].z;
 }
-__device__ void cs_set(ColSet &s, int pos, int4 e) {
+template <int kS>
+__device__ void cs_set(ColSetT<kS> &s, int pos, int4 e) {
   const int lane = lane_id();
   if (pos >= s.nBase) {
-    if (lane == pos - s.nBase) s.tail = e;
+    const int rel = pos - s.nBase;
+#pragma unroll
+    for (int j = 0; j < kS; j++)
+      if ((rel >> 6) == j && lane == (rel & 63)) s.r[j] = e;
   } else {
     if (lane == 0) s.g[pos] = e;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
-__device__ void cs_insert_at(ColSet &s, int pos, int4 e) {
+template <int kS>
+__device__ void cs_insert_at(ColSetT<kS> &s, int pos, int4 e) {
   const int lane = lane_id();
-  if (pos >= s.nBase && s.n - s.nBase == 64) {
-    // tail full: move its lower half to global memory
-    if (lane < 32) s.g[s.nBase + lane] = s.tail;
+  if (pos >= s.nBase && s.n - s.nBase == 64 * kS) {
+    // registers full: their lowest entries move to global memory (half a set when there is only one)
+    constexpr int kSpill = kS == 1 ? 32 : 64;
+    if (lane < kSpill) s.g[s.nBase + lane] = s.r[0];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    s.tail = lane_shift_from(s.tail, 32);
-    s.nBase += 32;
+    if (kS == 1) {
+      s.r[0] = lane_shift_from(s.r[0], 32);
+    } else {
+#pragma unroll
+      for (int j = 0; j + 1 < kS; j++) s.r[j] = s.r[j + 1];
+    }
+    s.nBase += kSpill;
   }
   if (pos >= s.nBase) {
-    const int p = pos - s.nBase;
-    const int4 up = make_int4(wave_shr1(s.tail.x, 0), wave_shr1(s.tail.y, 0), wave_shr1(s.tail.z, 0),
-                              wave_shr1(s.tail.w, 0));
-    if (lane > p) s.tail = up;
-    if (lane == p) s.tail = e;
+    const int rel = pos - s.nBase, jp = rel >> 6, lp = rel & 63;
+    const int4 zero = make_int4(0, 0, 0, 0);
+    // every entry at or above the position moves up by one; from the top set down, so that a set still holds its
+    // old last entry when the set above takes it over
+#pragma unroll
+    for (int j = kS - 1; j >= 0; j--) {
+      if (j > jp) {
+        s.r[j] = lane_shr1(s.r[j], lane_bcast(s.r[j > 0 ? j - 1 : 0], 63));
+      } else if (j == jp) {
+        const int4 up = lane_shr1(s.r[j], zero);
+        if (lane > lp) s.r[j] = up;
+        if (lane == lp) s.r[j] = e;
+      }
+    }
     s.n++;
     return;
   }
@@ -1540,11 +1598,33 @@ __device__ void cs_insert_at(ColSet &s, int pos, int4 e) {
   s.nBase++;
   s.n++;
 }
-__device__ void cs_erase_range(ColSet &s, int first, int count) {  // removes [first, first+count)
+template <int kS>
+__device__ void cs_erase_range(ColSetT<kS> &s, int first, int count) {  // removes [first, first+count)
   const int lane = lane_id();
   if (first >= s.nBase) {
-    const int4 down = lane_shift_from(s.tail, count);
-    if (lane >= first - s.nBase) s.tail = down;
+    if (kS == 1) {
+      const int4 down = lane_shift_from(s.r[0], count);
+      if (lane >= first - s.nBase) s.r[0] = down;
+    } else {
+      // register index i (>= first - nBase) takes the entry of index i + count: a whole number of sets plus a lane shift
+      const int f = first - s.nBase, q = count >> 6, sh = count & 63;
+      const int src = lane + sh;
+      int4 nw[kS];
+#pragma unroll
+      for (int j = 0; j < kS; j++) {
+        int4 a = make_int4(0, 0, 0, 0), b = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int jq = 0; jq < kS; jq++) {
+          if (j + q == jq) a = s.r[jq];
+          if (j + q + 1 == jq) b = s.r[jq];
+        }
+        const int4 va = lane_shift_from(a, sh), vb = lane_shift_from(b, sh - 64);
+        nw[j] = src < 64 ? va : vb;
+      }
+#pragma unroll
+      for (int j = 0; j < kS; j++)
+        if (64 * j + lane >= f) s.r[j] = nw[j];
+    }
     s.n -= count;
     return;
   }
@@ -1590,7 +1670,7 @@ struct FragView {
 
 // The sweep of one invocation.  kPreloaded: the (<= 64) fragments and their static predecessors are handed
 // over in registers (lane = fragment) by sdp_small_kernel instead of being read from memory.
-template <bool kPreloaded>
+template <bool kPreloaded, int kS = 1>
 __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpParams &prm, int idx, const SdpTask &t,
                                             int F, int preX, int preY, int preLen, int prePred, int preAbove) {
   const int lane = lane_id();
@@ -1602,10 +1682,11 @@ __device__ __forceinline__ void chain_sweep(const SdpLevelArrays &lv, const SdpP
   const Frag *fr = lv.frags + base;
   int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
   const int *predCl = lv.predCl + base, *above = lv.above + base;
-  ColSet cols;
+  ColSetT<kS> cols;
   cols.g = lv.colSet + base;
   cols.n = cols.nBase = 0;
-  cols.tail = make_int4(0, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < kS; j++) cols.r[j] = make_int4(0, 0, 0, 0);
   const int k = t.k;
   const uint32_t fragmentLength = (uint32_t)k;
   const uint32_t weight = (uint32_t)k;
@@ -1823,13 +1904,19 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     // (a task that is not fused has more than 16 raw fragments, so it was given its column slots)
     scatter = take && lv.colEnt != nullptr && lv.colOff[i + 1] > lv.colOff[i];
   }
+  // categories, in the order of the sorted list: 3 bitmap sweep, target beyond kBitsSmallTarget columns; 2 bitmap
+  // sweep, smaller target (a quarter of the LDS: more wavefronts in flight); 1 the 512-register sweep (tests only:
+  // BLASR_HIP_CHAIN_SCATTER=1); 0 sdp_chain4_kernel
+  int cat = 0;
+  if (scatter) cat = lv.scatterMode == 1 ? 1 : (lv.tasks[i].tLen > kBitsSmallTarget ? 3 : 2);
   if (i < lv.n) {
-    keys[i] = take ? ((uint32_t)lv.nFrag[i] | (scatter ? 0x80000000u : 0u)) : 0u;  // the scattered ones sort first
+    keys[i] = take ? (((uint32_t)cat << 30) | (uint32_t)min(lv.nFrag[i], (1 << 30) - 1)) : 0u;
     vals[i] = i;
   }
-  const unsigned long long mask = __ballot(take && !scatter), smask = __ballot(scatter);
-  if (mask != 0ull && lane_id() == 0) atomicAdd(lv.chainCount, (int)__popcll(mask));
-  if (smask != 0ull && lane_id() == 0) atomicAdd(lv.scatterCount, (int)__popcll(smask));
+  for (int c = 0; c < 4; c++) {
+    const unsigned long long m = __ballot(take && cat == c);
+    if (m != 0ull && lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
+  }
 }
 
 // The sweep of up to four invocations, one per 16-lane group: `on` says whether this lane's group has one, `idx`
@@ -2126,7 +2213,7 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
 
 __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int lane = lane_id();
-  const int nList = *lv.chainCount, nScatter = *lv.scatterCount;  // the list starts with sdp_chain_bits_kernel's
+  const int nList = lv.chainCount[0], nScatter = lv.chainCount[1] + lv.chainCount[2] + lv.chainCount[3];  // the list starts with the scattered ones
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
   const bool on = slot < nList;
@@ -2149,7 +2236,7 @@ __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, S
 constexpr int kBitsWords = kBitsMaxTarget / 32;
 struct BitCols {
   uint32_t *bits;    // LDS: bit c of the map = column c is in the set
-  int4 *ent;         // memory: the entry of a member column {column, fragment, cost, x + y}
+  int4 *ent;         // memory: the entry of a member column {chain length, fragment, cost, x + y} of its fragment
   uint32_t summary;  // lane i, bit b: word 32 i + b of the map is not empty
   int n;
 };
@@ -2282,7 +2369,7 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
         bool store = true;
         if (member) store = bc_entry(cols, ft.y).z < ft.cost;  // sic (:260-267): replaced only when the existing entry is CHEAPER
         if (store) {
-          if (lane == 0) cols.ent[ft.y] = make_int4(ft.y, fTrail, ft.cost, ft.x + ft.y);
+          if (lane == 0) cols.ent[ft.y] = make_int4(view_len(fTrail), fTrail, ft.cost, ft.x + ft.y);
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           if (!member) {
             bc_set(cols, ft.y);
@@ -2298,13 +2385,14 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
         }
         fTrail++;
       }
-      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1;
+      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1, cpLen = 0;
       bool foundPrev = false;
       if (cols.n > 0) {
         const int pc = bc_pred_le(cols, fy);
         if (pc >= 0) {
           const int4 at = bc_entry(cols, pc);
           cpFrag = at.y;
+          cpLen = at.x;  // the chain length comes with the entry: no second round trip for a far predecessor
           cp = at.z + isqrt_floor(abs((fx + fy) - at.w)) - fl;
           foundPrev = true;
         }
@@ -2333,7 +2421,7 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
         if (mc == cp) myPrev = cpFrag;
         else if (mc == cl) myPrev = clFrag;
         else myPrev = aboveIdx;
-        myLen = (uint32_t)view_len(myPrev) + 1u;
+        myLen = (uint32_t)(mc == cp ? cpLen : view_len(myPrev)) + 1u;
       } else {
         myPrev = -1;
         myLen = 1;
@@ -2365,13 +2453,24 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
   if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
 }
 
+template <int kWords>
 __global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, SdpParams prm) {
-  __shared__ uint32_t bits[4][kBitsWords];
+  __shared__ uint32_t bits[4][kWords];
   const int wave = threadIdx.x >> 6;
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
-  if (slot >= *lv.scatterCount) return;
-  const int idx = lv.chainList[slot];
+  const bool large = kWords == kBitsWords;  // the list: [large targets | small targets | ...]
+  if (slot >= lv.chainCount[large ? 3 : 2]) return;
+  const int idx = lv.chainList[(large ? 0 : lv.chainCount[3]) + slot];
   chain_sweep_bits(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], bits[wave]);
+}
+
+// sdp_chain_wide: one scattered invocation per wavefront, the sweep of sdp_chain_kernel with 256 entries of the column
+// set in registers (ColSetT<4>)
+__global__ __launch_bounds__(256) void sdp_chain_wide_kernel(SdpLevelArrays lv, SdpParams prm) {
+  const int slot = wave_task_index();
+  if (slot >= lv.chainCount[1]) return;
+  const int idx = lv.chainList[lv.chainCount[3] + lv.chainCount[2] + slot];
+  chain_sweep<false, kWideSets>(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], 0, 0, 0, -1, -1);
 }
 
 // sdp_small4_kernel: what sdp_small_kernel does, for invocations of at most kSmall4Max raw fragments (most of
@@ -3404,15 +3503,17 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
 int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;
-  (void)hipMemsetAsync(lv.chainCount, 0, sizeof(int32_t), st);
-  (void)hipMemsetAsync(lv.scatterCount, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(lv.chainCount, 0, 4 * sizeof(int32_t), st);  // one count per category
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
   if (lv.n <= 0) return;
   if (lv.chainList != nullptr) {  // four invocations per wavefront; the list is sorted (launch_sdp_chain_list + sort)
-    if (lv.colEnt != nullptr)   // the scattered ones, one per wavefront (the device knows how many: the grid is an upper bound)
-      hipLaunchKernelGGL(sdp_chain_bits_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+    if (lv.colEnt != nullptr) {  // the scattered ones, one per wavefront (the device knows how many: the grid is an upper bound)
+      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+      if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+    }
     hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
     hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);

@@ -256,9 +256,11 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
         return [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]]
 
     stats = [as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])) for (q, t), w in zip(pairs, want)]
-    for env in (None, "BLASR_HIP_NO_CHAIN_BITS"):
+    # the scattered invocations through the bitmap sweep (default), the 512-register sweep (1), and without either
+    # (the register-tail sweep of chain4)
+    for env, val in ((None, None), ("BLASR_HIP_CHAIN_SCATTER", "1"), ("BLASR_HIP_NO_CHAIN_BITS", "1")):
         if env:
-            monkeypatch.setenv(env, "1")
+            monkeypatch.setenv(env, val)
         got = ctx.sdp(pairs)
         if env:
             monkeypatch.delenv(env)
@@ -269,10 +271,15 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
     for k in (7, 5):
         rect = [(synth.random_genome(int(rng.integers(400, 2500)), 700 + 10 * k + i),
                  synth.random_genome(int(rng.integers(400, 3500)), 800 + 10 * k + i)) for i in range(8)]
+        # one rectangle large enough for a column set beyond the 256 register entries (spill path of the wide sweep)
+        rect.append((synth.random_genome(9000, 900 + k), synth.random_genome(12000, 950 + k)))
         osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
         sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
-        got = ctx.sdp(rect, sdp=sp)
-        for i, ((q, t), g) in enumerate(zip(rect, got)):
-            w = oracle.sdp_align(q, t, None, osp)
-            st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
-            _check(g, w, st, "rectangle k=%d %d" % (k, i))
+        want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]
+        for mode in ("0", "1"):
+            monkeypatch.setenv("BLASR_HIP_CHAIN_SCATTER", mode)
+            got = ctx.sdp(rect, sdp=sp)
+            monkeypatch.delenv("BLASR_HIP_CHAIN_SCATTER")
+            for i, ((q, t), g, w) in enumerate(zip(rect, got, want)):
+                st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
+                _check(g, w, st, "rectangle k=%d %d mode %s" % (k, i, mode))
