@@ -203,7 +203,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.fused = arena.get<int32_t>(nTasks);
     lv.chainList = nullptr;
     if (!getenv("BLASR_HIP_NO_CHAIN4")) {
-      lv.chainList = arena.get<int32_t>(nTasks + 4);
+      lv.chainList = arena.get<int32_t>(nTasks + 5);
       lv.chainCount = lv.chainList + nTasks;
       if (const char *e = getenv("BLASR_HIP_CHAIN_SCATTER")) lv.scatterMode = atoi(e);
     }
@@ -348,6 +348,23 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     }
     launch_sdp_chain(lv, prm, st);
     tock(2);
+    if (getenv("BLASR_HIP_SDP_TRACE") && lv.chainList != nullptr) {  // the sweep's categories and its largest invocations
+      int32_t cnt[5] = {0, 0, 0, 0, 0};
+      HIP_TRY(ctx, hipMemcpy(cnt, lv.chainCount, sizeof(cnt), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[sdp] level %d sweep: chain4 %d, wide %d, bits4 %d, bits %d, bits-large %d;", level, cnt[0], cnt[1],
+              cnt[2], cnt[3], cnt[4]);
+      int at = 0;
+      for (int c = 4; c >= 0; c--) {
+        if (cnt[c] > 0) {
+          int32_t first = 0, nf = 0;
+          HIP_TRY(ctx, hipMemcpy(&first, lv.chainList + at, sizeof(int32_t), hipMemcpyDeviceToHost));
+          HIP_TRY(ctx, hipMemcpy(&nf, lv.nFrag + first, sizeof(int32_t), hipMemcpyDeviceToHost));
+          fprintf(stderr, " largest of category %d: %d fragments;", c, nf);
+        }
+        at += cnt[c];
+      }
+      fprintf(stderr, "\n");
+    }
 
     // ---- blocks, gap-fill jobs, next level ----
     tick();

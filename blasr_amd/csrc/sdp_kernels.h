@@ -61,13 +61,13 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
-  // The sweep's invocations (not fused, >= 1 fragment), sorted by category and fragment count, and the four category
-  // counts: chainCount[0] sdp_chain4_kernel's; [1..3] the invocations whose fragments scatter over the rectangle (the
+  // The sweep's invocations (not fused, >= 1 fragment), sorted by category and fragment count, and the five category
+  // counts: chainCount[0] sdp_chain4_kernel's; [1..4] the invocations whose fragments scatter over the rectangle (the
   // recursion's Global calls: unrelated sequence gives chance matches anywhere), which come FIRST in the list:
-  // [3] sdp_chain_bits_kernel with a large target, [2] with a small one, [1] sdp_chain_wide_kernel.
-  // chainList null: everything through sdp_chain_kernel.
+  // [4] sdp_chain_bits_kernel with a large target, [3] with a small one, [2] sdp_chain_bits4_kernel, [1]
+  // sdp_chain_wide_kernel.  chainList null: everything through sdp_chain_kernel.
   int32_t *chainList, *chainCount;
-  int scatterMode;              // 1: the scattered invocations take sdp_chain_wide_kernel instead (tests)
+  int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront
   const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)
   int4 *colEnt;                 // per target column: {column, fragment, cost, x+y} of the column set's entry there
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)

@@ -66,6 +66,8 @@ constexpr int kTinyT = 128;
 // most 64 raw fragments, and only without ties above 16), on a target the LDS bitmap spans.
 constexpr int kBitsMaxTarget = 65536;
 constexpr int kBitsSmallTarget = 16384;  // sdp_chain_bits_kernel's small instantiation (2 KB of LDS per wavefront)
+constexpr int kBits4Target = 4096;   // sdp_chain_bits4_kernel: columns (128 words of LDS per invocation) ...
+constexpr int kBits4MaxFrags = 1024; // ... and fragments of the invocations it takes
 constexpr int kWideSets = 8;         // register sets of 64 column-set entries in sdp_chain_wide_kernel
 __host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragments) {
   return t.type == 1 && rawFragments > 16 && t.tLen <= kBitsMaxTarget;
@@ -1904,16 +1906,19 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     // (a task that is not fused has more than 16 raw fragments, so it was given its column slots)
     scatter = take && lv.colEnt != nullptr && lv.colOff[i + 1] > lv.colOff[i];
   }
-  // categories, in the order of the sorted list: 3 bitmap sweep, target beyond kBitsSmallTarget columns; 2 bitmap
-  // sweep, smaller target (a quarter of the LDS: more wavefronts in flight); 1 the 512-register sweep (tests only:
-  // BLASR_HIP_CHAIN_SCATTER=1); 0 sdp_chain4_kernel
+  // categories, in the order of the sorted list: 4 bitmap sweep, a wavefront each, target beyond kBitsSmallTarget
+  // columns; 3 the same with a smaller target (a quarter of the LDS); 2 bitmap sweep four per wavefront (small target,
+  // few fragments: the bulk); 1 the 512-register sweep (tests only: BLASR_HIP_CHAIN_SCATTER=1); 0 sdp_chain4_kernel
   int cat = 0;
-  if (scatter) cat = lv.scatterMode == 1 ? 1 : (lv.tasks[i].tLen > kBitsSmallTarget ? 3 : 2);
+  if (scatter) {
+    const int tl = lv.tasks[i].tLen;
+    cat = lv.scatterMode == 1 ? 1 : (tl > kBitsSmallTarget ? 4 : ((tl > kBits4Target || lv.nFrag[i] > kBits4MaxFrags || lv.scatterMode == 2) ? 3 : 2));
+  }
   if (i < lv.n) {
-    keys[i] = take ? (((uint32_t)cat << 30) | (uint32_t)min(lv.nFrag[i], (1 << 30) - 1)) : 0u;
+    keys[i] = take ? (((uint32_t)cat << 29) | (uint32_t)min(lv.nFrag[i], (1 << 29) - 1)) : 0u;
     vals[i] = i;
   }
-  for (int c = 0; c < 4; c++) {
+  for (int c = 0; c < 5; c++) {
     const unsigned long long m = __ballot(take && cat == c);
     if (m != 0ull && lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
   }
@@ -2213,7 +2218,8 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
 
 __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int lane = lane_id();
-  const int nList = lv.chainCount[0], nScatter = lv.chainCount[1] + lv.chainCount[2] + lv.chainCount[3];  // the list starts with the scattered ones
+  const int nList = lv.chainCount[0];  // the list starts with the scattered ones
+  const int nScatter = lv.chainCount[1] + lv.chainCount[2] + lv.chainCount[3] + lv.chainCount[4];
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
   const bool on = slot < nList;
@@ -2296,6 +2302,35 @@ __device__ __forceinline__ int4 bc_entry(const BitCols &s, int col) {
                    __builtin_amdgcn_readfirstlane(e.z), __builtin_amdgcn_readfirstlane(e.w));
 }
 
+// per-lane variant of bc_pred_le: every lane asks for its own column (the window's speculative queries)
+__device__ __forceinline__ int bc_pred_le_lanes(const BitCols &s, int y, bool ok) {
+  const int w = ok ? y >> 5 : 0, b = y & 31;
+  const uint32_t word = s.bits[w] & (b == 31 ? 0xffffffffu : ((2u << b) - 1u));
+  const int li = w >> 5, bi = w & 31;
+  const unsigned long long top = __ballot(s.summary != 0u);  // lanes whose 32 words are not all empty
+  const uint32_t own = (uint32_t)__builtin_amdgcn_ds_bpermute(li << 2, (int)s.summary) & ((1u << bi) - 1u);
+  const unsigned long long below = top & ((1ull << li) - 1ull);
+  const int hl = below ? 63 - __clzll((long long)below) : 0;
+  const uint32_t far = (uint32_t)__builtin_amdgcn_ds_bpermute(hl << 2, (int)s.summary);
+  int w2 = -1;
+  if (below) w2 = (hl << 5) + 31 - __clz((int)far);
+  if (own) w2 = (li << 5) + 31 - __clz((int)own);
+  const uint32_t word2 = s.bits[w2 < 0 ? 0 : w2];
+  int r = -1;
+  if (w2 >= 0) r = (w2 << 5) + 31 - __clz((int)(word2 | 1u));
+  if (word) r = (w << 5) + 31 - __clz((int)word);
+  return ok ? r : -1;
+}
+
+// The sweep is a chain of dependent steps, and an invocation with thousands of scattered fragments is as long as
+// its chain: the kernel's time is its longest invocation's.  What is kept off that chain here:
+//  * the column predecessors of a whole window of 64 fragments are looked up at once, lane = fragment (bitmap in LDS,
+//    then ONE round of 64 entry loads), and a lane's answer stays good until a retirement touches the columns between
+//    its predecessor and its own (`dirty`, one vector comparison per change of the set) -- only then is the query
+//    repeated when the fragment's turn comes;
+//  * a retirement looks for its first successor BEFORE it stores its entry (the bit of a greater column does not
+//    depend on it), so that the successor's cost and the store are one round trip, not two;
+//  * a store is waited for only when the next load of an entry is due.
 __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const SdpParams &prm, int idx, const SdpTask &t,
                                                  int F, uint32_t *ldsBits) {
   const int lane = lane_id();
@@ -2319,6 +2354,11 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
   int curPrev = -1;
   cur.x = cur.y = cur.cost = cur.len = 0;
   prev = cur;
+  bool pendingStore = false;  // an entry was stored and not yet waited for
+  auto settle = [&]() {
+    if (pendingStore) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    pendingStore = false;
+  };
   for (int w0 = 0; w0 < F; w0 += 64) {
     prev = cur;
     int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
@@ -2332,6 +2372,18 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
     }
     cur.x = fxV;
     cur.y = fyV;
+    // ---- the window's column predecessors, speculatively, against the set as it stands now
+    settle();
+    const bool inWin = w0 + lane < F;
+    const int specPred = bc_pred_le_lanes(cols, fyV, inWin && cols.n > 0);
+    int4 specEnt = make_int4(0, 0, 0, 0);
+    if (specPred >= 0) specEnt = cols.ent[specPred];
+    // (waited for here, one round trip per window: a retirement below may store to one of these addresses)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    bool dirty = false;
+    auto touched = [&](int col, bool inserted) {  // the set changed at `col`: whose speculative answer is stale?
+      dirty = dirty || col == specPred || (inserted && col > specPred && col <= fyV);
+    };
     auto view = [&](int p) {
       FragView v;
       v.len = 0;
@@ -2366,21 +2418,28 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
         const FragView ft = view(fTrail);
         if ((int64_t)ft.x + k + 2 > (int64_t)fx) break;
         const bool member = ((bc_word(cols, ft.y >> 5) >> (ft.y & 31)) & 1u) != 0u;
+        // Successor() needs at least two elements (SDPSet.h:72-87): the set's size after this fragment went in
+        int sc = (cols.n + (member ? 0 : 1) >= 2) ? bc_succ_gt(cols, ft.y) : -1;
         bool store = true;
+        int scCost = 0;
+        if (member || sc >= 0) settle();
+        if (sc >= 0) scCost = cols.ent[sc].z;  // (issued before the store below: one round trip for both)
         if (member) store = bc_entry(cols, ft.y).z < ft.cost;  // sic (:260-267): replaced only when the existing entry is CHEAPER
         if (store) {
           if (lane == 0) cols.ent[ft.y] = make_int4(view_len(fTrail), fTrail, ft.cost, ft.x + ft.y);
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          pendingStore = true;
+          touched(ft.y, true);
           if (!member) {
             bc_set(cols, ft.y);
             cols.n++;
           }
-          // delete the costlier successors; Successor() needs at least two elements (SDPSet.h:72-87)
-          while (cols.n >= 2) {
-            const int sc = bc_succ_gt(cols, ft.y);
-            if (sc < 0 || !(bc_entry(cols, sc).z > ft.cost)) break;
+          // delete the costlier successors
+          while (sc >= 0 && __builtin_amdgcn_readfirstlane(scCost) > ft.cost) {
             bc_clear(cols, sc);
             cols.n--;
+            touched(sc, false);
+            sc = cols.n >= 2 ? bc_succ_gt(cols, ft.y) : -1;
+            if (sc >= 0) scCost = cols.ent[sc].z;  // (never the entry just stored: sc > ft.y)
           }
         }
         fTrail++;
@@ -2388,9 +2447,19 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
       int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1, cpLen = 0;
       bool foundPrev = false;
       if (cols.n > 0) {
-        const int pc = bc_pred_le(cols, fy);
+        int4 at = make_int4(0, 0, 0, 0);
+        int pc;
+        if (__builtin_amdgcn_readlane((int)dirty, j) == 0) {
+          pc = __builtin_amdgcn_readlane(specPred, j);
+          at = lane_bcast(specEnt, j);
+        } else {
+          pc = bc_pred_le(cols, fy);
+          if (pc >= 0) {
+            settle();
+            at = bc_entry(cols, pc);
+          }
+        }
         if (pc >= 0) {
-          const int4 at = bc_entry(cols, pc);
           cpFrag = at.y;
           cpLen = at.x;  // the chain length comes with the entry: no second round trip for a far predecessor
           cp = at.z + isqrt_floor(abs((fx + fy) - at.w)) - fl;
@@ -2449,6 +2518,7 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
       chainLen[w0 + lane] = cur.len;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    pendingStore = false;
   }
   if (lane == 0) lv.chainEnd[idx] = t.type == 0 ? minIdx : maxLenIdx;
 }
@@ -2459,9 +2529,242 @@ __global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, 
   const int wave = threadIdx.x >> 6;
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
   const bool large = kWords == kBitsWords;  // the list: [large targets | small targets | ...]
-  if (slot >= lv.chainCount[large ? 3 : 2]) return;
-  const int idx = lv.chainList[(large ? 0 : lv.chainCount[3]) + slot];
+  if (slot >= lv.chainCount[large ? 4 : 3]) return;
+  const int idx = lv.chainList[(large ? 0 : lv.chainCount[4]) + slot];
   chain_sweep_bits(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], bits[wave]);
+}
+
+// ---------------------------------------------------------------------------
+// sdp_chain_bits4: the bitmap sweep, FOUR invocations per wavefront (one per 16-lane group, as sdp_chain4_kernel).
+// One invocation per wavefront is a scalar program (two thirds of its instructions run on the CU's one scalar unit)
+// and is bound by that unit; four per wavefront do the same work as vector instructions, a fourth of them per
+// fragment.  Per group: kWords words of bitmap in LDS, the summary one word per lane (16 lanes x 32 bits = 512 words
+// at most), the windows of 16 + 16 fragments of chain4_body.  The four step in lockstep, so this kernel takes the
+// many SHORT scattered invocations (sorted by size, four of a kind per wavefront); the long ones -- a wavefront is as
+// slow as its longest -- keep a wavefront each (sdp_chain_bits_kernel).
+// ---------------------------------------------------------------------------
+template <int kWords>
+__device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const SdpParams &prm, const bool on,
+                                                 const int idx, uint32_t *bits /* this group's words */) {
+  const int lane = lane_id(), l = lane & 15, gb = lane & 48;
+  const int F = on ? lv.nFrag[idx] : 0;
+  const SdpTask t = lv.tasks[idx];
+  const int64_t base = lv.fragOff[idx];
+  int4 *ent = lv.colEnt + (on ? lv.colOff[idx] : 0);
+  const int k = t.k, type = t.type;
+  auto gbp = [&](int v, int i) { return __builtin_amdgcn_ds_bpermute((gb + (i & 15)) << 2, v); };
+  auto gballot = [&](bool flag) { return (uint32_t)((__ballot(flag) >> gb) & 0xffffull); };
+  for (int w = l; w < kWords; w += 16) bits[w] = 0;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t summary = 0;  // lane l, bit b: word 32 l + b of the group's map is not empty
+  int n = 0, fTrail = 0;
+  int curX = 0, curY = 0, curCost = 0, curLen = 0, curPrev = -1, prvX = 0, prvY = 0, prvCost = 0, prvLen = 0;
+  int minCost = INT32_MAX, minIdx = -1, maxLenIdx = -1;
+  uint32_t maxLen = 0;
+  int maxF = F;
+  for (int off = 32; off > 0; off >>= 1) maxF = max(maxF, __shfl_xor(maxF, off));
+  // the largest member <= y (-1: none) / the smallest member > y (-1: none); `ok` lanes only, the others read word 0
+  auto pred_le = [&](int y, bool ok) {
+    const int w = ok ? y >> 5 : 0, b = y & 31;
+    const uint32_t word = bits[w] & (b == 31 ? 0xffffffffu : ((2u << b) - 1u));
+    const int li = w >> 5, bi = w & 31;
+    uint32_t m = summary;
+    m = l == li ? (m & ((1u << bi) - 1u)) : (l > li ? 0u : m);
+    const uint32_t gm = gballot(m != 0u);
+    const int hl = 31 - __clz((int)(gm | 1u));
+    const uint32_t hm = (uint32_t)gbp((int)m, hl);
+    const int w2 = gm ? (hl << 5) + 31 - __clz((int)(hm | 1u)) : 0;
+    const uint32_t word2 = bits[w2];
+    int r = -1;
+    if (gm) r = (w2 << 5) + 31 - __clz((int)(word2 | 1u));
+    if (word) r = (w << 5) + 31 - __clz((int)word);
+    return ok ? r : -1;
+  };
+  auto succ_gt = [&](int y, bool ok) {
+    const int w = ok ? y >> 5 : 0, b = y & 31;
+    const uint32_t word = bits[w] & (b == 31 ? 0u : ~((2u << b) - 1u));
+    const int li = w >> 5, bi = w & 31;
+    uint32_t m = summary;
+    m = l == li ? (bi == 31 ? 0u : (m & ~((2u << bi) - 1u))) : (l < li ? 0u : m);
+    const uint32_t gm = gballot(m != 0u);
+    const int ll = gm ? __ffs((int)gm) - 1 : 0;
+    const uint32_t lm = (uint32_t)gbp((int)m, ll);
+    const int w2 = gm ? (ll << 5) + __ffs((int)lm) - 1 : 0;
+    const uint32_t word2 = bits[w2];
+    int r = -1;
+    if (gm && word2) r = (w2 << 5) + __ffs((int)word2) - 1;
+    if (word) r = (w << 5) + __ffs((int)word) - 1;
+    return ok ? r : -1;
+  };
+  for (int w0 = 0; w0 < maxF; w0 += 16) {
+    prvX = curX, prvY = curY, prvCost = curCost, prvLen = curLen;
+    int flV = 0, fpV = -1, faV = -1;
+    curX = curY = 0;
+    if (on && w0 + l < F) {
+      const Frag f = lv.frags[base + w0 + l];
+      curX = (int)f.x;
+      curY = (int)f.y;
+      flV = (int)f.len;
+      fpV = lv.predCl[base + w0 + l];
+      faV = lv.above[base + w0 + l];
+    }
+    // fragment p of this group: x, y, cost and chain length, from the two register windows, else from memory
+    auto view4 = [&](int p, bool need, int &vx, int &vy, int &vc, int &vl) {
+      const int rel = p - w0;
+      const int xa = gbp(curX, rel), ya = gbp(curY, rel), ca = gbp(curCost, rel), la = gbp(curLen, rel);
+      const int xb = gbp(prvX, rel + 16), yb = gbp(prvY, rel + 16), cb = gbp(prvCost, rel + 16), lb = gbp(prvLen, rel + 16);
+      vx = rel >= 0 ? xa : xb;
+      vy = rel >= 0 ? ya : yb;
+      vc = rel >= 0 ? ca : cb;
+      vl = rel >= 0 ? la : lb;
+      if (__ballot(need && rel < -16) != 0ull) {
+        if (need && rel < -16) {
+          const Frag f = lv.frags[base + p];
+          vx = (int)f.x;
+          vy = (int)f.y;
+          vc = lv.cost[base + p];
+          vl = lv.chainLen[base + p];
+        }
+      }
+    };
+    for (int j = 0; j < 16; j++) {
+      const int i = w0 + j;
+      const bool act = on && i < F;
+      if (__ballot(act) == 0ull) break;
+      const int fx = gbp(curX, j), fy = gbp(curY, j), fl = gbp(flV, j);
+      // ---- rows leaving the window: fragments with x <= f.x - k - 2 are retired first (:248-309)
+      for (;;) {
+        bool need = act && fTrail < i;
+        int ftx, fty, ftc, ftl;
+        view4(need ? fTrail : i, need, ftx, fty, ftc, ftl);
+        need = need && (int64_t)ftx + k + 2 <= (int64_t)fx;
+        if (__ballot(need) == 0ull) break;
+        const int w = need ? fty >> 5 : 0;
+        const uint32_t word = bits[w], bit = 1u << (fty & 31);
+        const bool member = need && (word & bit) != 0u;
+        // the first successor, before the entry goes in (the bit of a greater column does not depend on it): its
+        // cost and the store below are one round trip.  Successor() needs at least two elements (SDPSet.h:72-87)
+        int sc = succ_gt(fty, need && n + (member ? 0 : 1) >= 2);
+        int atCost = 0, scCost = 0;
+        if (__ballot(member || sc >= 0) != 0ull) {
+          if (member) atCost = ent[fty].z;
+          if (sc >= 0) scCost = ent[sc].z;
+        }
+        bool store = need && (!member || atCost < ftc);  // sic (:260-267): replaced only when the existing entry is CHEAPER
+        if (store && l == 0) ent[fty] = make_int4(ftl, fTrail, ftc, ftx + fty);
+        const bool ins = store && !member;
+        if (ins && l == 0) bits[w] = word | bit;
+        if (ins && l == (w >> 5)) summary |= 1u << (w & 31);
+        n += ins ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+        // delete the costlier successors
+        for (;;) {
+          const bool del = store && sc >= 0 && scCost > ftc;
+          if (__ballot(del) == 0ull) break;
+          const int ws = del ? sc >> 5 : 0;
+          const uint32_t wv = bits[ws] & ~(1u << (sc & 31));
+          if (del && l == 0) bits[ws] = wv;
+          if (del && wv == 0u && l == (ws >> 5)) summary &= ~(1u << (ws & 31));
+          n -= del ? 1 : 0;
+          __builtin_amdgcn_wave_barrier();
+          store = del;  // a group goes on only while it deletes
+          sc = succ_gt(fty, del && n >= 2);
+          if (__ballot(sc >= 0) != 0ull)
+            if (sc >= 0) scCost = ent[sc].z;  // (never the entry just stored: sc > fty)
+        }
+        // the entry must have landed before a later step loads it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        fTrail += need ? 1 : 0;
+      }
+      // ---- the three predecessors
+      int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX, cpFrag = -1, cpLen = 0;
+      bool foundPrev = false;
+      {
+        const bool q = act && n > 0;
+        const int pc = pred_le(fy, q);
+        const bool have = q && pc >= 0;
+        int4 at = make_int4(0, 0, 0, 0);
+        if (__ballot(have) != 0ull)
+          if (have) at = ent[pc];
+        if (have) {
+          const int d = abs((fx + fy) - at.w);
+          int sq = (int)sqrtf((float)d);
+          sq -= ((unsigned)sq * (unsigned)sq > (unsigned)d) ? 1 : 0;
+          sq += ((unsigned)(sq + 1) * (unsigned)(sq + 1) <= (unsigned)d) ? 1 : 0;
+          cpFrag = at.y;
+          cpLen = at.x;
+          cp = at.z + sq - fl;
+          foundPrev = true;
+        }
+      }
+      const int clFrag = gbp(fpV, j), aboveIdx = gbp(faV, j);
+      int clLen = 0, caLen = 0;
+      {
+        int px, py, pc;
+        const bool needCl = act && clFrag >= 0;
+        view4(needCl ? clFrag : i, needCl, px, py, pc, clLen);
+        if (needCl) {
+          int ov = (int)((uint32_t)k - (uint32_t)(fy - py)) * prm.match;
+          if (ov > 0) ov = 0;
+          cl = pc + ov + indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel);
+          foundPrev = true;
+        }
+        const bool needCa = act && aboveIdx >= 0;
+        view4(needCa ? aboveIdx : i, needCa, px, py, pc, caLen);
+        if (needCa) {
+          ca = (int)((uint32_t)pc + ((uint32_t)k - (uint32_t)(fy - py)) * (uint32_t)prm.match +
+                     (uint32_t)indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel));
+          foundPrev = true;
+        }
+      }
+      int mc = cl < ca ? cl : ca;
+      if (cp < mc) mc = cp;
+      int myCost, myPrev = -1;
+      uint32_t myLen = 1;
+      const bool linked = foundPrev && (type == 1 || (type == 0 && mc < 0));
+      if (linked) {
+        myPrev = (mc == cp) ? cpFrag : ((mc == cl) ? clFrag : aboveIdx);
+        myLen = (uint32_t)((mc == cp) ? cpLen : ((mc == cl) ? clLen : caLen)) + 1u;
+        myCost = (int)((uint32_t)mc - (uint32_t)k);
+      } else if (type == 1) {
+        myCost = (int)((uint32_t)(fx + fy) * (uint32_t)prm.sdpDel + (uint32_t)k * (uint32_t)prm.match - (uint32_t)k);
+      } else {
+        myCost = (int)((uint32_t)k * (uint32_t)prm.match - (uint32_t)k);
+      }
+      if (act && l == j) {
+        curCost = myCost;
+        curLen = (int)myLen;
+        curPrev = myPrev;
+      }
+      if (act && minCost > myCost) {
+        minCost = myCost;
+        minIdx = i;
+      }
+      if (act && myLen > maxLen) {
+        maxLen = myLen;
+        maxLenIdx = i;
+      }
+    }
+    if (on && w0 + l < F) {
+      lv.cost[base + w0 + l] = curCost;
+      lv.chainPrev[base + w0 + l] = curPrev;
+      lv.chainLen[base + w0 + l] = curLen;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (on && l == 0) lv.chainEnd[idx] = type == 0 ? minIdx : maxLenIdx;
+}
+
+// category 2 of the chain list (small targets, few fragments), four per wavefront
+__global__ __launch_bounds__(256, 8) void sdp_chain_bits4_kernel(SdpLevelArrays lv, SdpParams prm) {
+  __shared__ uint32_t bits[4][4][kBits4Target / 32];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int nList = lv.chainCount[2];
+  const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * 4 + (lane >> 4);
+  if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;
+  const bool on = slot < nList;
+  chain_bits4_body<kBits4Target / 32>(lv, prm, on, on ? lv.chainList[lv.chainCount[4] + lv.chainCount[3] + slot] : 0,
+                                      bits[wave][lane >> 4]);
 }
 
 // sdp_chain_wide: one scattered invocation per wavefront, the sweep of sdp_chain_kernel with 256 entries of the column
@@ -2469,7 +2772,7 @@ __global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, 
 __global__ __launch_bounds__(256) void sdp_chain_wide_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int slot = wave_task_index();
   if (slot >= lv.chainCount[1]) return;
-  const int idx = lv.chainList[lv.chainCount[3] + lv.chainCount[2] + slot];
+  const int idx = lv.chainList[lv.chainCount[4] + lv.chainCount[3] + lv.chainCount[2] + slot];
   chain_sweep<false, kWideSets>(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], 0, 0, 0, -1, -1);
 }
 
@@ -3503,15 +3806,16 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
 int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;
-  (void)hipMemsetAsync(lv.chainCount, 0, 4 * sizeof(int32_t), st);  // one count per category
+  (void)hipMemsetAsync(lv.chainCount, 0, 5 * sizeof(int32_t), st);  // one count per category
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
   if (lv.n <= 0) return;
-  if (lv.chainList != nullptr) {  // four invocations per wavefront; the list is sorted (launch_sdp_chain_list + sort)
-    if (lv.colEnt != nullptr) {  // the scattered ones, one per wavefront (the device knows how many: the grid is an upper bound)
+  if (lv.chainList != nullptr) {  // the list is sorted by category and size (launch_sdp_chain_list + sort)
+    if (lv.colEnt != nullptr) {  // the scattered ones (the device knows how many of each kind: the grids are upper bounds)
       hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
       hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+      hipLaunchKernelGGL(sdp_chain_bits4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
       if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
     }
     hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);

@@ -256,9 +256,10 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
         return [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]]
 
     stats = [as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])) for (q, t), w in zip(pairs, want)]
-    # the scattered invocations through the bitmap sweep (default), the 512-register sweep (1), and without either
-    # (the register-tail sweep of chain4)
-    for env, val in ((None, None), ("BLASR_HIP_CHAIN_SCATTER", "1"), ("BLASR_HIP_NO_CHAIN_BITS", "1")):
+    # the scattered invocations through the bitmap sweep four per wavefront (default) and one per wavefront (2), the
+    # 512-register sweep (1), and without any of them (the register-tail sweep of chain4)
+    for env, val in ((None, None), ("BLASR_HIP_CHAIN_SCATTER", "1"), ("BLASR_HIP_CHAIN_SCATTER", "2"),
+                     ("BLASR_HIP_NO_CHAIN_BITS", "1")):
         if env:
             monkeypatch.setenv(env, val)
         got = ctx.sdp(pairs)
@@ -276,7 +277,7 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
         osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
         sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
         want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]
-        for mode in ("0", "1"):
+        for mode in ("0", "1", "2"):
             monkeypatch.setenv("BLASR_HIP_CHAIN_SCATTER", mode)
             got = ctx.sdp(rect, sdp=sp)
             monkeypatch.delenv("BLASR_HIP_CHAIN_SCATTER")
