@@ -317,8 +317,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     cur.wideBytes = 0;
     size_t arrowB = 0, rowB = 0, arenaB = 0;
     auto flush = [&](int nextFirst) {
-      // arrows | rowTab | arena | wide rings, each section 256-aligned
-      cur.bytes = align_up(arrowB, 256) + align_up(rowB, 256) + align_up(arenaB, 256) + cur.wideBytes;
+      // arrows | rowTab | rowMeta (2 bytes where rowTab has 8) | arena | wide rings, each section 256-aligned
+      cur.bytes = align_up(arrowB, 256) + align_up(rowB, 256) + align_up(rowB / 4, 256) + align_up(arenaB, 256) +
+                  cur.wideBytes;
       plan.chunks.push_back(cur);
       cur = Plan::Chunk();
       cur.first = nextFirst;
@@ -340,8 +341,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
           w = align_up((size_t)ringSize * 12, 256);
         }
       }
-      const size_t need = a + r + ar + w + 1024;
-      if (cur.count > 0 && arrowB + rowB + arenaB + cur.wideBytes + need > budget) flush(i);
+      const size_t need = a + r + r / 4 + ar + w + 1280;
+      if (cur.count > 0 && arrowB + rowB + rowB / 4 + arenaB + cur.wideBytes + need > budget) flush(i);
       if (need > budget) {
         destroyEvents();
         return fail(ctx, BLASR_HIP_ERR_NOMEM, "candidate %d alone needs %zu bytes of workspace", i, need);
@@ -411,7 +412,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       }
     char *pArrows = ws + oVar;
     char *pRows = pArrows + align_up(arrowB, 256);
-    char *pArena = pRows + align_up(rowB, 256);
+    char *pMeta = pRows + align_up(rowB, 256);
+    char *pArena = pMeta + align_up(rowB / 4, 256);
     char *pWide = pArena + align_up(arenaB, 256);
 
     FillArgs fa;
@@ -428,6 +430,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.arrowOff = dArrowOff;
     fa.rowTab = reinterpret_cast<int2 *>(pRows);
     fa.rowOff = dRowOff;
+    fa.rowMeta = reinterpret_cast<const unsigned short *>(pMeta);
     fa.dpScore = dDp;
     fa.wideTasks = dWideTasks;
     fa.wideRingOff = dWideOff;
@@ -435,6 +438,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     fa.taskList = nullptr;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    // the row records of the chunk's candidates, now that they have their place in the workspace
+    launch_geometry_rows(view, band, c.first, c.count, dGeo, fa.rowTab, dRowOff, reinterpret_cast<unsigned short *>(pMeta), st);
     // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes on the side
     // stream, underneath fill_kernel's launch (after fillp_kernel when that runs, so its launch is timed alone).
     bool wideLaunched = false, timedFill4 = false;

@@ -55,6 +55,7 @@ struct FillArgs {
   const int64_t *arrowOff;  // per candidate
   int2 *rowTab;             // per row: {matrix offset of the row's first cell, first column}
   const int64_t *rowOff;
+  const unsigned short *rowMeta;  // per row (indexed like rowTab): cells | query code << 12 (geometry_rows_kernel)
   int32_t *dpScore;
   const int32_t *taskList;  // when set: the candidates to process (indices into the batch), `count` of them
   // global-ring variant: candidates whose rows are too wide for LDS
@@ -82,6 +83,9 @@ struct TraceArgs {
 
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
                      hipStream_t stream);
+// the row records of candidates [first, first+count): rowTab / rowMeta at rowOff[candidate] + row
+void launch_geometry_rows(const RefineBatchView &batch, int band, int first, int count, const TaskGeometry *geo,
+                          int2 *rowTab, const int64_t *rowOff, unsigned short *rowMeta, hipStream_t stream);
 void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool fast,
                  hipStream_t stream);
 // four candidates per wavefront (tagged-key variant only); args.taskList / args.count name the candidates

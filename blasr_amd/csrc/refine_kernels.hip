@@ -211,6 +211,43 @@ __global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, in
 }
 
 // ---------------------------------------------------------------------------
+// geometry_rows_kernel: the second walk over the guide, once the chunk plan has given every candidate its place in
+// the workspace: the row records {matrix offset of the row's first cell, first column} and, per row, its number of
+// cells (those with t >= tEnd left out, AffineGuidedAlign.h:268-269) and the query base's code.  The fill kernels
+// read them back 64 rows at a time, coalesced, instead of deriving the geometry again for every batch of rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geometry_rows_kernel(RefineBatchView batch, int band, int first, int count,
+                                                              const TaskGeometry *geo, int2 *rowTab,
+                                                              const int64_t *rowOff, unsigned short *rowMeta) {
+  __shared__ unsigned char flagScratch[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (idx >= count) return;
+  const int task = first + idx;
+  if (geo[task].status != 0) return;
+  const int nBlocks = batch.n_blocks[task];
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const uint8_t *qSeq = batch.seq + batch.q_off[task];
+  int2 *rows = rowTab + rowOff[task];
+  unsigned short *meta = rowMeta + rowOff[task];
+  GuideCursor g;
+  guide_begin(g, blocks, nBlocks, band);
+  const int tEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+  for (int r0 = 1; r0 <= g.Q; r0 += 64) {
+    int t, lo, hi;
+    unsigned rs;
+    guide_group(g, r0, flagScratch[wave], t, lo, hi, rs);
+    if (r0 + lane <= g.Q) {
+      const int width = min(hi, tEnd - 1) - lo + 1;
+      const int qc = base_code(qSeq[g.qStart + r0 - 1 + lane]);
+      rows[r0 + lane] = make_int2((int)rs, lo);
+      meta[r0 + lane] = (unsigned short)(min(max(width, 0), 0xfff) | (qc << 12));  // (a width beyond 4095 saturates: wide rows
+    }                                                                             //  are not fillp_kernel's)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // fill_kernel
 // ---------------------------------------------------------------------------
 // Packed arrow byte written per band cell:
@@ -620,7 +657,6 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   __shared__ uint32_t ringTLds[4][kT][kF4RingT];
   __shared__ int2 rowA[4][kT][64];          // per row of the current 64-row batch: {matrix offset, first column}
   __shared__ unsigned short rowB[4][kT][64];  // width | query code << 8
-  __shared__ unsigned char flagScratch[4][64];
   __shared__ uint32_t packedCol[8];        // per target code: the matrix column for queries A,C,G,T, one byte each
   if (threadIdx.x < 5) {
     uint32_t v = 0;
@@ -636,10 +672,9 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   if (slot0 >= args.count) return;
 
   // ---- the candidates of this wavefront (uniform values), and each lane's own candidate
-  int taskG[kT], qG[kT], tEndG[kT];
-  GuideCursor cur[kT];
-  const uint8_t *qSeqG[kT];
-  int2 *rowTabG[kT];
+  int taskG[kT], qG[kT];
+  const int2 *rowTabG[kT];
+  const unsigned short *rowMetaG[kT];
   int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0;
   const uint8_t *myTSeq = nullptr;
   uint8_t *myArrows = nullptr;
@@ -647,28 +682,27 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   for (int g = 0; g < kT; g++) {
     taskG[g] = -1;
     qG[g] = 0;
-    tEndG[g] = 0;
-    qSeqG[g] = nullptr;
     rowTabG[g] = nullptr;
+    rowMetaG[g] = nullptr;
     if (slot0 + g < args.count) {
       const int task = args.taskList[slot0 + g];
       taskG[g] = task;
       const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
       const int nBlocks = batch.n_blocks[task];
-      guide_begin(cur[g], blocks, nBlocks, args.band);
-      qG[g] = cur[g].Q;
-      tEndG[g] = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
-      qSeqG[g] = batch.seq + batch.q_off[task];
+      GuideCursor cur;
+      guide_begin(cur, blocks, nBlocks, args.band);
+      qG[g] = cur.Q;
       rowTabG[g] = args.rowTab + args.rowOff[task];
+      rowMetaG[g] = args.rowMeta + args.rowOff[task];
       if (grp == g) {
         myTask = task;
-        myQ = qG[g];
-        myTEnd = tEndG[g];
+        myQ = cur.Q;
+        myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
         myTLen = batch.t_len[task];
         myTSeq = batch.seq + batch.t_off[task];
         myArrows = args.arrows + args.arrowOff[task];
-        myPlo = cur[g].tStart - 1;
-        myPhi = myPlo + guide_row0_tpost(cur[g]);
+        myPlo = cur.tStart - 1;
+        myPhi = myPlo + guide_row0_tpost(cur);
       }
     }
   }
@@ -694,7 +728,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
 
   int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
   for (int r0 = 1; r0 <= maxQ; r0 += 64) {
-    // ---- geometry and query codes of the next 64 rows of every candidate
+    // ---- the row records and query codes of the next 64 rows of every candidate (geometry_rows_kernel wrote them)
     int passesV = 1;  // lane i: the passes row r0+i takes, i.e. what its widest candidate needs
     bool spanBad = false;  // some candidate's 64 rows span more target columns than its packed-column ring holds
     int myHmax = 0;        // the last column my candidate touches in these rows
@@ -702,19 +736,17 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
 #pragma unroll
     for (int g = 0; g < kT; g++) {
       if (taskG[g] >= 0 && r0 <= qG[g]) {
-        int tV, loV, hiV;
-        unsigned rsV;
-        guide_group(cur[g], r0, flagScratch[wave], tV, loV, hiV, rsV);
         const int nRows = min(64, qG[g] - r0 + 1);
-        int lastV = INT32_MIN;
+        int lastV = INT32_MIN, loV = 0;
         if (lane < nRows) {
-          rowTabG[g][r0 + lane] = make_int2((int)rsV, loV);
-          const int qc = base_code(qSeqG[g][cur[g].qStart + r0 - 1 + lane]);
-          const int width = min(hiV, tEndG[g] - 1) - loV + 1;  // cells with t >= tEnd are skipped (:268-269)
-          rowA[wave][g][lane] = make_int2((int)rsV, loV);
-          rowB[wave][g][lane] = (unsigned short)(max(width, 0) | (qc << 8));
+          const int2 rec = rowTabG[g][r0 + lane];
+          const unsigned m = rowMetaG[g][r0 + lane];
+          const int width = (int)(m & 0xfffu), qc = (int)(m >> 12);
+          loV = rec.y;
+          rowA[wave][g][lane] = rec;
+          rowB[wave][g][lane] = (unsigned short)(width | (qc << 8));
           passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
-          lastV = loV + max(width, 0) - 1;
+          lastV = loV + width - 1;
           nV = nV || qc >= 4;
         }
         const int hMax = wave_max(lastV);
@@ -1279,6 +1311,12 @@ void launch_geometry(const RefineBatchView &batch, int band, int first, int coun
                      hipStream_t stream) {
   if (count <= 0) return;
   hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
+}
+void launch_geometry_rows(const RefineBatchView &batch, int band, int first, int count, const TaskGeometry *geo,
+                          int2 *rowTab, const int64_t *rowOff, unsigned short *rowMeta, hipStream_t stream) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(geometry_rows_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo,
+                     rowTab, rowOff, rowMeta);
 }
 void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool globalRing, bool fast,
                  hipStream_t stream) {
