@@ -31,6 +31,7 @@ struct blasr_hip_ctx {
   float sdpMs[4] = {0, 0, 0, 0};
   int64_t sdpCounters[3] = {0, 0, 0};
   int64_t sdpBytes[4] = {0, 0, 0, 0};
+  double sdpBytesPerBase = 48.0;  // level arrays per base of query + target, as the last pieces needed them
   // the resident genome (ASCII) and its contig table, for the window gather
   uint8_t *genome = nullptr;
   bool genomeOwned = true;  // false: adopted from the caller (blasr_hip_adopt_genome_device)

@@ -33,6 +33,7 @@ struct Arena {
   size_t offset = 0, high = 0;
   std::vector<void *> overflow;
   hipError_t err = hipSuccess;
+  int64_t *highOut = nullptr;  // receives the bytes the call asked for in all
   Arena(blasr_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {}
   Arena(const Arena &) = delete;
   Arena &operator=(const Arena &) = delete;
@@ -57,10 +58,13 @@ struct Arena {
   }
   // end of the call (every path): the stream must be idle before memory it may still use goes away
   ~Arena() {
+    if (highOut) *highOut = (int64_t)high;
     if (overflow.empty()) return;
     (void)hipStreamSynchronize(st);
     for (void *p : overflow) (void)hipFree(p);
-    (void)blasr_hip_grow_workspace(ctx, high + high / 8);  // best effort: failing to grow is not an error
+    const std::string keep = ctx->lastError;  // best effort: failing to grow is not an error, and not the call's message
+    (void)blasr_hip_grow_workspace(ctx, high + high / 8);
+    ctx->lastError = keep;
   }
 };
 
@@ -108,10 +112,11 @@ namespace {
 // (the blocks of the chunks before), `blocks` / `blocksCap` are what is left of the caller's arena.
 int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
                      const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
-                     int64_t blocksCap, int64_t *blocksUsed, int64_t blkBase) {
+                     int64_t blocksCap, int64_t *blocksUsed, int64_t blkBase, int64_t *arenaHigh) {
   const int n = b->n;
   hipStream_t st = ctx->stream;
   Arena arena(ctx, st);
+  arena.highOut = arenaHigh;
   Events ev;
   HIP_TRY(ctx, hipEventCreate(&ev.a));
   HIP_TRY(ctx, hipEventCreate(&ev.b));
@@ -581,27 +586,27 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), b->q_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), b->t_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  // what the workspace may grow to: the caller's limit and what the device can still give this context
-  int64_t budgetBases = std::max<int64_t>(blasr_hip_workspace_reach(ctx) / 48, 1 << 16);
-  if (const char *e = getenv("BLASR_HIP_SDP_CHUNK_BASES")) budgetBases = std::max<int64_t>(atoll(e), 1);
-  std::vector<int> cut(1, 0);
-  {
-    int64_t acc = 0;
-    for (int i = 0; i < n; i++) {
-      const int64_t bases = (int64_t)std::max(qLen[i], 0) + std::max(tLen[i], 0);
-      if (i > cut.back() && acc + bases > budgetBases) {
-        cut.push_back(i);
-        acc = 0;
-      }
-      acc += bases;
-    }
-    cut.push_back(n);
-  }
+  // Pieces: as many candidates as the memory the context may use (the caller's limit, what the device can still
+  // give) holds at the bytes per base the level arrays took so far -- ~48 for alignments, ten times that where
+  // chance clusters make the recursion flood (configs[4]); the figure follows what the pieces actually used.  A piece
+  // that does not fit after all (the device refuses an allocation) is taken again as two halves.
+  const char *forced = getenv("BLASR_HIP_SDP_CHUNK_BASES");
   float ms[4] = {0, 0, 0, 0};
   int64_t counters[3] = {0, 0, 0}, used = 0, bytes[4] = {0, 0, 0, 0};
   bool overflow = false;
-  for (size_t c = 0; c + 1 < cut.size(); c++) {
-    const int first = cut[c], cnt = cut[c + 1] - cut[c];
+  int first = 0;
+  int limitCount = n;  // a piece that failed caps the next attempt at half its candidates
+  while (first < n) {
+    int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 48.0)), 1 << 16);
+    if (forced) budgetBases = std::max<int64_t>(atoll(forced), 1);
+    int cnt = 0;
+    int64_t acc = 0;
+    while (first + cnt < n && cnt < limitCount) {
+      const int64_t bases = (int64_t)std::max(qLen[first + cnt], 0) + std::max(tLen[first + cnt], 0);
+      if (cnt > 0 && acc + bases > budgetBases) break;
+      acc += bases;
+      cnt++;
+    }
     blasr_hip_sdp_batch sub = *b;
     sub.n = cnt;
     sub.q_off = b->q_off + first;
@@ -609,11 +614,22 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     sub.t_off = b->t_off + first;
     sub.t_len = b->t_len + first;
     const int64_t left = std::max<int64_t>(blocksCap - used, 0);
-    int64_t usedHere = 0;
+    int64_t usedHere = 0, arenaHigh = 0;
     const int rc = sdp_device_chunk(ctx, &sub, sp, score, results + first, blocks ? blocks + 3 * std::min(used, blocksCap) : nullptr,
-                                    left, &usedHere, used);
+                                    left, &usedHere, used, &arenaHigh);
+    if (acc > 0 && arenaHigh > 0 && !forced)  // (an aborted piece reports what it had asked for so far: a lower bound)
+      ctx->sdpBytesPerBase = std::max(ctx->sdpBytesPerBase * (rc == BLASR_HIP_OK ? 0.5 : 1.0), 1.25 * (double)arenaHigh / (double)acc);
+    if (rc == BLASR_HIP_ERR_NOMEM && cnt > 1) {
+      limitCount = cnt / 2;
+      ctx->sdpBytesPerBase *= 1.5;
+      if (getenv("BLASR_HIP_SDP_TRACE"))
+        fprintf(stderr, "[sdp] a piece of %d candidates did not fit the device memory: again in halves\n", cnt);
+      continue;
+    }
     if (rc == BLASR_HIP_ERR_CAPACITY) overflow = true;
     else if (rc != BLASR_HIP_OK) return rc;
+    limitCount = n;
+    first += cnt;
     used += usedHere;
     for (int i = 0; i < 4; i++) ms[i] += ctx->sdpMs[i];
     for (int i = 0; i < 3; i++) counters[i] += ctx->sdpCounters[i];

@@ -64,7 +64,7 @@ constexpr int kTinyT = 128;
 // An invocation that may take sdp_chain_bits_kernel (and so gets a column slot per target base): a Global call --
 // the recursion's; a top-level Local alignment is near-diagonal -- that the small kernels cannot have (they take at
 // most 64 raw fragments, and only without ties above 16), on a target the LDS bitmap spans.
-constexpr int kBitsMaxTarget = 65536;
+constexpr int kBitsMaxTarget = 131072;
 constexpr int kBitsSmallTarget = 16384;  // sdp_chain_bits_kernel's small instantiation (2 KB of LDS per wavefront)
 constexpr int kBits4Target = 4096;   // sdp_chain_bits4_kernel: columns (128 words of LDS per invocation) ...
 constexpr int kBits4MaxFrags = 1024; // ... and fragments of the invocations it takes
@@ -2243,26 +2243,32 @@ constexpr int kBitsWords = kBitsMaxTarget / 32;
 struct BitCols {
   uint32_t *bits;    // LDS: bit c of the map = column c is in the set
   int4 *ent;         // memory: the entry of a member column {chain length, fragment, cost, x + y} of its fragment
-  uint32_t summary;  // lane i, bit b: word 32 i + b of the map is not empty
+  uint64_t summary;  // lane i, bit b: word 64 i + b of the map is not empty (64 lanes x 64 words x 32 columns)
   int n;
 };
 __device__ __forceinline__ uint32_t bc_word(const BitCols &s, int w) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)s.bits[w]);
+}
+__device__ __forceinline__ uint64_t bc_summary_of(const BitCols &s, int srcLane) {  // uniform lane
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s.summary, srcLane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s.summary >> 32), srcLane);
+  return ((uint64_t)hi << 32) | lo;
 }
 // the largest member <= y, or -1
 __device__ __forceinline__ int bc_pred_le(const BitCols &s, int y) {
   const int w = y >> 5, b = y & 31;
   const uint32_t word = bc_word(s, w) & (b == 31 ? 0xffffffffu : ((2u << b) - 1u));
   if (word) return (w << 5) + 31 - __clz((int)word);
-  const int lane = lane_id(), li = w >> 5, bi = w & 31;
-  uint32_t m = s.summary;
-  if (lane == li) m &= (1u << bi) - 1u;
+  const int lane = lane_id(), li = w >> 6, bi = w & 63;
+  uint64_t m = s.summary;
+  if (lane == li) m &= (1ull << bi) - 1ull;
   if (lane > li) m = 0;
-  const unsigned long long ball = __ballot(m != 0u);
+  const unsigned long long ball = __ballot(m != 0ull);
   if (ball == 0ull) return -1;
   const int hl = 63 - __clzll((long long)ball);
-  const uint32_t hm = (uint32_t)__builtin_amdgcn_readlane((int)m, hl);
-  const int w2 = (hl << 5) + 31 - __clz((int)hm);
+  uint64_t hm = bc_summary_of(s, hl);
+  if (hl == li) hm &= (1ull << bi) - 1ull;
+  const int w2 = (hl << 6) + 63 - __clzll((long long)hm);
   return (w2 << 5) + 31 - __clz((int)bc_word(s, w2));
 }
 // the smallest member > y, or -1
@@ -2270,15 +2276,17 @@ __device__ __forceinline__ int bc_succ_gt(const BitCols &s, int y) {
   const int w = y >> 5, b = y & 31;
   const uint32_t word = bc_word(s, w) & (b == 31 ? 0u : ~((2u << b) - 1u));
   if (word) return (w << 5) + __ffs((int)word) - 1;
-  const int lane = lane_id(), li = w >> 5, bi = w & 31;
-  uint32_t m = s.summary;
-  if (lane == li) m &= bi == 31 ? 0u : ~((2u << bi) - 1u);
+  const int lane = lane_id(), li = w >> 6, bi = w & 63;
+  uint64_t m = s.summary;
+  const uint64_t above = bi == 63 ? 0ull : ~((2ull << bi) - 1ull);
+  if (lane == li) m &= above;
   if (lane < li) m = 0;
-  const unsigned long long ball = __ballot(m != 0u);
+  const unsigned long long ball = __ballot(m != 0ull);
   if (ball == 0ull) return -1;
   const int ll = __builtin_ctzll(ball);
-  const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)m, ll);
-  const int w2 = (ll << 5) + __ffs((int)lm) - 1;
+  uint64_t lm = bc_summary_of(s, ll);
+  if (ll == li) lm &= above;
+  const int w2 = (ll << 6) + __builtin_ctzll(lm);
   return (w2 << 5) + __ffs((int)bc_word(s, w2)) - 1;
 }
 __device__ __forceinline__ void bc_set(BitCols &s, int y) {
@@ -2286,14 +2294,14 @@ __device__ __forceinline__ void bc_set(BitCols &s, int y) {
   const uint32_t v = bc_word(s, w) | (1u << (y & 31));
   if (lane_id() == 0) s.bits[w] = v;
   __builtin_amdgcn_wave_barrier();
-  if (lane_id() == (w >> 5)) s.summary |= 1u << (w & 31);
+  if (lane_id() == (w >> 6)) s.summary |= 1ull << (w & 63);
 }
 __device__ __forceinline__ void bc_clear(BitCols &s, int y) {
   const int w = y >> 5;
   const uint32_t v = bc_word(s, w) & ~(1u << (y & 31));
   if (lane_id() == 0) s.bits[w] = v;
   __builtin_amdgcn_wave_barrier();
-  if (v == 0u && lane_id() == (w >> 5)) s.summary &= ~(1u << (w & 31));
+  if (v == 0u && lane_id() == (w >> 6)) s.summary &= ~(1ull << (w & 63));
 }
 // one entry, the same address in every lane (a broadcast load; the scalar cache would not see the wave's own stores)
 __device__ __forceinline__ int4 bc_entry(const BitCols &s, int col) {
@@ -2303,18 +2311,23 @@ __device__ __forceinline__ int4 bc_entry(const BitCols &s, int col) {
 }
 
 // per-lane variant of bc_pred_le: every lane asks for its own column (the window's speculative queries)
+__device__ __forceinline__ uint64_t bperm64(uint64_t v, int srcLane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ int bc_pred_le_lanes(const BitCols &s, int y, bool ok) {
   const int w = ok ? y >> 5 : 0, b = y & 31;
   const uint32_t word = s.bits[w] & (b == 31 ? 0xffffffffu : ((2u << b) - 1u));
-  const int li = w >> 5, bi = w & 31;
-  const unsigned long long top = __ballot(s.summary != 0u);  // lanes whose 32 words are not all empty
-  const uint32_t own = (uint32_t)__builtin_amdgcn_ds_bpermute(li << 2, (int)s.summary) & ((1u << bi) - 1u);
+  const int li = w >> 6, bi = w & 63;
+  const unsigned long long top = __ballot(s.summary != 0ull);  // lanes whose 64 words are not all empty
+  const uint64_t own = bperm64(s.summary, li) & ((1ull << bi) - 1ull);
   const unsigned long long below = top & ((1ull << li) - 1ull);
   const int hl = below ? 63 - __clzll((long long)below) : 0;
-  const uint32_t far = (uint32_t)__builtin_amdgcn_ds_bpermute(hl << 2, (int)s.summary);
+  const uint64_t far = bperm64(s.summary, hl);
   int w2 = -1;
-  if (below) w2 = (hl << 5) + 31 - __clz((int)far);
-  if (own) w2 = (li << 5) + 31 - __clz((int)own);
+  if (below) w2 = (hl << 6) + 63 - __clzll((long long)far);
+  if (own) w2 = (li << 6) + 63 - __clzll((long long)own);
   const uint32_t word2 = s.bits[w2 < 0 ? 0 : w2];
   int r = -1;
   if (w2 >= 0) r = (w2 << 5) + 31 - __clz((int)(word2 | 1u));

@@ -366,14 +366,19 @@ def make_repeat_genome(contig_lengths, seed, device, families=2000, unit=(6000, 
 
 
 def make_map_workload(genome, copies, n_reads, read_len, seed, device, ins=0.11, dele=0.04, sub=0.01,
-                      max_unanchored=300, min_overlap=1000, spurious=2.0, max_candidates=10, loose=0.0, slab=4096):
+                      max_unanchored=300, min_overlap=1000, spurious=2.0, max_candidates=10, loose=0.0,
+                      spurious_span=None, slab=4096):
     """`n_reads` PacBio-like reads drawn uniformly from `genome` (either strand, the error channel of `mutate`) and
     what anchoring would hand MapRead for each: its true locus, the matching stretch of every other copy of a
     repeat family the read overlaps by >= min_overlap bases, and Poisson(spurious) chance clusters elsewhere in the
     genome (a short anchored stretch of the read against unrelated sequence) -- at most `max_candidates` intervals
     per read (params.nCandidates), in random order.  loose > 0 widens the true locus' interval by up to loose x the
     read length on either side (anchor clusters that reach beyond the read: target windows much longer than the
-    query).  Interval coordinates follow WeightedInterval
+    query).  spurious_span = (q_lo, q_hi, g_lo, g_hi), fractions of the read length, makes the chance clusters LONG
+    (read span uniform in [q_lo, q_hi], genome span in [g_lo, g_hi]): what the reference's anchoring reports for 30 kb
+    reads at 15 % indels -- eight or nine such intervals per read next to the true one (blasrmc -V 1; they are what
+    costs the reference 455 ms of SDPAlign per read); None: a short stretch of 300-1500 bases.
+    Interval coordinates follow WeightedInterval
     (datastructures/anchoring/WeightedInterval.h:12-29): genome span on the forward genome, read span on the strand
     of the interval.
 
@@ -506,11 +511,19 @@ def make_map_workload(genome, copies, n_reads, read_len, seed, device, ins=0.11,
         cnt = torch.poisson(torch.full((n,), float(spurious), device=device), generator=gen).to(torch.int64)
         rr = torch.repeat_interleave(rid, cnt)
         m = rr.numel()
-        span = 300 + rnd(1200, m)
+        if spurious_span is None:
+            span = 300 + rnd(1200, m)
+            gspan = span
+        else:
+            q_lo, q_hi, g_lo, g_hi = spurious_span
+            u = torch.rand(m, generator=gen, device=device)
+            span = ((q_lo + (q_hi - q_lo) * u) * q_len[rr]).to(torch.int64).clamp_min(50)
+            u = torch.rand(m, generator=gen, device=device)
+            gspan = ((g_lo + (g_hi - g_lo) * u) * q_len[rr]).to(torch.int64).clamp_min(50)
         qs = (torch.rand(m, generator=gen, device=device) * (q_len[rr] - span).clamp_min(1)).to(torch.int64)
-        gs = torch.randint(0, G - 2 * L, (m,), generator=gen, device=device) + L
+        gs = torch.randint(0, G - 4 * L, (m,), generator=gen, device=device) + L
         iv_start.append(gs)
-        iv_end.append(gs + span)
+        iv_end.append(gs + gspan)
         iv_qs.append(qs)
         iv_qe.append(torch.minimum(qs + span, q_len[rr]))
         iv_read.append(rr)

@@ -274,6 +274,9 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
                  synth.random_genome(int(rng.integers(400, 3500)), 800 + 10 * k + i)) for i in range(8)]
         # one rectangle large enough for a column set beyond the 256 register entries (spill path of the wide sweep)
         rect.append((synth.random_genome(9000, 900 + k), synth.random_genome(12000, 950 + k)))
+        if k == 7:  # and targets beyond 16384 and 65536 columns (the larger bitmap classes)
+            rect.append((synth.random_genome(2500, 990), synth.random_genome(30000, 991)))
+            rect.append((synth.random_genome(2000, 992), synth.random_genome(80000, 993)))
         osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
         sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
         want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]

@@ -104,9 +104,9 @@ def test_bench_workload_label_follows_the_arguments():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for argv, must in ((["--config", "4"], ["configs[4]", "6250 synthetic 30 kb", "ins 10%/del 5%", "loosened"]),
+    for argv, must in ((["--config", "4"], ["configs[4]", "6250 synthetic 30 kb", "ins 10%/del 5%", "8.00 chance clusters", "long:"]),
                        (["--config", "1", "--reads", "777", "--band", "30"], ["configs[1]", "777 synthetic 10 kb", "band 30", "0 planted"]),
-                       ([], ["configs[2]", "100000 synthetic 10 kb", "4000 planted repeat families", "2.0 chance clusters"])):
+                       ([], ["configs[2]", "100000 synthetic 10 kb", "4000 planted repeat families", "0.25 chance clusters"])):
         args = bench.parse_args(argv)
         d = bench.config_defaults(args)
         label = bench.workload_label(args, d, 1234, 1)
