@@ -413,7 +413,7 @@ def main():
             ns = min(ns, n_reads)
             if ns > 0:
                 out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores)
-            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 2000000 // d["read_len"]))
+            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 10000000 // d["read_len"]))
             if nb > 0:
                 ncores = os.cpu_count() or 1
                 b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores))

@@ -2335,14 +2335,36 @@ __device__ __forceinline__ int bc_pred_le_lanes(const BitCols &s, int y, bool ok
   return ok ? r : -1;
 }
 
+// per-lane variant of bc_succ_gt
+__device__ __forceinline__ int bc_succ_gt_lanes(const BitCols &s, int y, bool ok) {
+  const int w = ok ? y >> 5 : 0, b = y & 31;
+  const uint32_t word = s.bits[w] & (b == 31 ? 0u : ~((2u << b) - 1u));
+  const int li = w >> 6, bi = w & 63;
+  const unsigned long long top = __ballot(s.summary != 0ull);
+  const uint64_t own = bperm64(s.summary, li) & (bi == 63 ? 0ull : ~((2ull << bi) - 1ull));
+  const unsigned long long above = li == 63 ? 0ull : top & ~((2ull << li) - 1ull);
+  const int ll = above ? __builtin_ctzll(above) : 0;
+  const uint64_t far = bperm64(s.summary, ll);
+  int w2 = -1;
+  if (above) w2 = (ll << 6) + __builtin_ctzll(far | (1ull << 63));
+  if (own) w2 = (li << 6) + __builtin_ctzll(own);
+  const uint32_t word2 = s.bits[w2 < 0 ? 0 : w2];
+  int r = -1;
+  if (w2 >= 0 && word2) r = (w2 << 5) + __ffs((int)word2) - 1;
+  if (word) r = (w << 5) + __ffs((int)word) - 1;
+  return ok ? r : -1;
+}
+
 // The sweep is a chain of dependent steps, and an invocation with thousands of scattered fragments is as long as
 // its chain: the kernel's time is its longest invocation's.  What is kept off that chain here:
 //  * the column predecessors of a whole window of 64 fragments are looked up at once, lane = fragment (bitmap in LDS,
 //    then ONE round of 64 entry loads), and a lane's answer stays good until a retirement touches the columns between
 //    its predecessor and its own (`dirty`, one vector comparison per change of the set) -- only then is the query
 //    repeated when the fragment's turn comes;
-//  * a retirement looks for its first successor BEFORE it stores its entry (the bit of a greater column does not
-//    depend on it), so that the successor's cost and the store are one round trip, not two;
+//  * the same for the retirements: the first successor of each of the next 64 fragments to retire, and its cost, are
+//    fetched at once (lane = fragment) and stay good until the set changes between a fragment's column and its
+//    successor; a retirement that finds its answer stale looks for its successor BEFORE it stores its entry (the bit
+//    of a greater column does not depend on it), so that the successor's cost and the store are one round trip;
 //  * a store is waited for only when the next load of an entry is due.
 __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const SdpParams &prm, int idx, const SdpTask &t,
                                                  int F, uint32_t *ldsBits) {
@@ -2372,6 +2394,20 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
     if (pendingStore) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     pendingStore = false;
   };
+  // the retirements' speculation: lane = fragment rw0 + lane, its column, first successor (-1: none) and that one's cost
+  int rw0 = -64, rY = 0, rSucc = -1, rSuccCost = 0;  // (the first retirement fetches the first batch)
+  bool rDirty = true;
+  auto refresh_retirements = [&](int from) {
+    rw0 = from;
+    const bool ok = from + lane < F && cols.n > 0;
+    rY = from + lane < F ? (int)fr[from + lane].y : 0;
+    settle();
+    rSucc = bc_succ_gt_lanes(cols, rY, ok);
+    rSuccCost = 0;
+    if (rSucc >= 0) rSuccCost = cols.ent[rSucc].z;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    rDirty = !ok;  // (an empty set has no answers to keep)
+  };
   for (int w0 = 0; w0 < F; w0 += 64) {
     prev = cur;
     int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
@@ -2396,6 +2432,7 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
     bool dirty = false;
     auto touched = [&](int col, bool inserted) {  // the set changed at `col`: whose speculative answer is stale?
       dirty = dirty || col == specPred || (inserted && col > specPred && col <= fyV);
+      rDirty = rDirty || col == rSucc || (inserted && col > rY && (rSucc < 0 || col < rSucc));
     };
     auto view = [&](int p) {
       FragView v;
@@ -2431,12 +2468,24 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
         const FragView ft = view(fTrail);
         if ((int64_t)ft.x + k + 2 > (int64_t)fx) break;
         const bool member = ((bc_word(cols, ft.y >> 5) >> (ft.y & 31)) & 1u) != 0u;
+        if (fTrail >= rw0 + 64) refresh_retirements(fTrail);
         // Successor() needs at least two elements (SDPSet.h:72-87): the set's size after this fragment went in
-        int sc = (cols.n + (member ? 0 : 1) >= 2) ? bc_succ_gt(cols, ft.y) : -1;
+        const bool wantSucc = cols.n + (member ? 0 : 1) >= 2;
+        int sc = -1, scCost = 0;
+        const int rl = fTrail - rw0;
+        const bool specOk = rl >= 0 && __builtin_amdgcn_readlane((int)rDirty, rl < 0 ? 0 : rl) == 0;
+        if (wantSucc && specOk) {
+          sc = __builtin_amdgcn_readlane(rSucc, rl);
+          scCost = __builtin_amdgcn_readlane(rSuccCost, rl);
+        } else if (wantSucc) {
+          sc = bc_succ_gt(cols, ft.y);
+          if (sc >= 0) {
+            settle();
+            scCost = cols.ent[sc].z;  // (issued before the store below: one round trip for both)
+          }
+        }
         bool store = true;
-        int scCost = 0;
-        if (member || sc >= 0) settle();
-        if (sc >= 0) scCost = cols.ent[sc].z;  // (issued before the store below: one round trip for both)
+        if (member) settle();
         if (member) store = bc_entry(cols, ft.y).z < ft.cost;  // sic (:260-267): replaced only when the existing entry is CHEAPER
         if (store) {
           if (lane == 0) cols.ent[ft.y] = make_int4(view_len(fTrail), fTrail, ft.cost, ft.x + ft.y);

@@ -4,22 +4,23 @@
 #   stats_bench.json   the JSON line bench.py printed under that profiler run
 #   pmc.json           per-kernel FETCH_SIZE / WRITE_SIZE / SQ counters (separate --pmc passes, one step each)
 #   bench_100k.json    the JSON line of an unprofiled default run (with the CPU baseline)
-# usage (from the repo root):  gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh gpurun_out/final'
+# usage (from the repo root):  gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh gpurun_out/final [bench.py arguments]'
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/${1:-gpurun_out/final}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o k -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-sample 0 \
+ARGS="${@:2}"   # extra bench.py arguments (e.g. --config 4)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o k -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-sample 0 --blasrmc-reads 0 $ARGS \
     > "$OUT/stats_bench.json" 2> "$OUT/kt.err"
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
   i=$((i + 1))
-  rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc$i" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --cpu-sample 0 \
+  rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc$i" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --cpu-sample 0 --blasrmc-reads 0 $ARGS \
       > /dev/null 2> "$OUT/pmc$i.err"
 done
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc.json" $(find "$OUT"/pmc* -name '*counter_collection.csv') > "$OUT/pmc_top.txt"
 rm -rf "$OUT"/kt "$OUT"/pmc[0-9]
-cd "$ROOT" && python3 bench.py > "$OUT/bench_100k.json" 2> "$OUT/bench.err"
-tail -c 600 "$OUT/bench_100k.json"
+cd "$ROOT" && python3 bench.py $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -c 600 "$OUT/bench.json"
