@@ -125,3 +125,51 @@ def test_refine_from_sdp_equals_host_trimming(oracle):
             assert g.ops.tolist() == w.ops.tolist(), i
     mem.free()
     ctx.close()
+
+
+def test_two_mapping_threads_give_the_single_thread_results(oracle):
+    """The C ABI is one context per host thread (the reference's -nproc): two threads map the two halves of a block of
+    reads at the same time, each through its own context and streams, over several rounds -- every hit record, aligned
+    sequence and op list must equal what one thread produces for the same reads (those results are checked against
+    the oracle by the tests above).  A missing stream / event dependency inside the library would show up here."""
+    import threading
+    rng = np.random.default_rng(80)
+    genome, pool, reads, ivs = repeat_genome_case(rng, 160, genome_len=400000, read_len=(1500, 6000))
+    half = len(reads) // 2
+
+    def subset(lo, hi):
+        m = (ivs["read"] >= lo) & (ivs["read"] < hi)
+        s = ivs[m].copy()
+        s["read"] -= lo
+        r = reads[lo:hi].copy()
+        base = int(r["off"][0])
+        r["off"] -= base
+        return r, pool[base: base + int(r["off"][-1] + r["length"][-1])], s
+
+    parts = [subset(0, half), subset(half, len(reads))]
+    one = blasr_amd.Context(0)
+    one.upload_genome(genome)
+    want = [one.map_reads(r, p, s) for r, p, s in parts]
+    one.close()
+    ctxs = [blasr_amd.Context(0) for _ in parts]
+    for c in ctxs:
+        c.upload_genome(genome)
+    n_candidates = 0
+    for rnd in range(6):
+        got = [None, None]
+
+        def work(i):
+            got[i] = ctxs[i].map_reads(*parts[i])
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for i in range(2):
+            for a, b in zip(got[i], want[i]):
+                assert np.array_equal(a, b), (rnd, i)
+        n_candidates += len(ivs)
+    assert n_candidates >= 2000
+    for c in ctxs:
+        c.close()

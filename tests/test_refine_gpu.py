@@ -201,3 +201,41 @@ def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.status == 0, i
         assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
+
+
+@pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_FILL4"])
+def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch):
+    """Guides whose consecutive blocks drift by hundreds to thousands of columns (what SDPAlign(Local) makes of a repeat
+    copy the read overlaps only in part: it chains on through chance fragments): rows of band + |drift| cells, on
+    both sides of what the LDS ring holds (192 cells; the global-memory ring beyond), against the oracle."""
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    rng = np.random.default_rng(909)
+    b, want = blasr_amd.RefineBatch(), []
+    for drift in (150, 400, 900, 1500, 3000, 4500, 6000):
+        # two homologous stretches, the target carrying `drift` extra bases between them (deletion-like) or the read
+        # (insertion-like): the guide's second block starts `drift` columns off the first one's diagonal
+        for kind in ("del", "ins"):
+            n1, n2 = int(rng.integers(300, 900)), int(rng.integers(300, 900))
+            core = synth.random_genome(n1 + n2, int(rng.integers(1, 1 << 30)))
+            extra = synth.random_genome(drift, int(rng.integers(1, 1 << 30)))
+            read = np.ascontiguousarray(synth.mutate(core, rng, 0.08, 0.03, 0.01))
+            cut = int(n1 * len(read) / len(core))
+            if kind == "del":
+                q, t = read, np.concatenate([core[:n1], extra, core[n1:]])
+            else:
+                q, t = np.concatenate([read[:cut], extra, read[cut:]]), core
+            # the guide: a short block in each stretch (as SDP would leave them), the second `drift` off the first
+            q2 = cut + (drift if kind == "ins" else 0) + 40
+            t2 = n1 + (drift if kind == "del" else 0) + 40
+            bl = np.array([[20, 20, 12], [q2, t2, 12], [q2 + 100, t2 + 100, 12]], dtype=np.int32)
+            qs, ts = np.ascontiguousarray(q[: q2 + 112]), np.ascontiguousarray(t[: t2 + 112])
+            b.add(qs, ts, bl)
+            want.append(oracle.affine_guided_align(qs, ts, bl))
+    got = ctx.refine(b)
+    widest = 0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.status == 0, i
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
+    if switch:
+        monkeypatch.delenv(switch)
