@@ -163,6 +163,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     t.top = i;
     t.qOrg = 0;
     t.tOrg = 0;
+    t.flags = (sp->extend_front ? kSdpExtendFront : 0) | (sp->detailed ? kSdpDetailed : 0);
+    t.pad = 0;
   }
   SdpTask *dTop = arena.get<SdpTask>(n);
   int32_t *dMatrix = arena.get<int32_t>(32);
@@ -572,12 +574,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   if (n == 0) return BLASR_HIP_OK;
   if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
-  if ((sp->align_type != 0 && sp->align_type != 1) || sp->detailed != 1 || sp->extend_front != 0 ||
-      sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
+  if ((sp->align_type != 0 && sp->align_type != 1) || sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
       sp->sdp_ins >= 64 || sp->sdp_del <= -64 || sp->sdp_del >= 64)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
-                          "SDP parameters outside the device domain (align_type Local/Global, detailed=1, "
-                          "extend_front=0, 1 <= word_size <= 16, |sdp_ins|, |sdp_del| < 64)");
+                          "SDP parameters outside the device domain (align_type Local/Global, 1 <= word_size <= 16, "
+                          "|sdp_ins|, |sdp_del| < 64)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // ---- chunks.  The level arrays take ~35 bytes per base of query + target (fragments, keys, the sweep's arrays,
   // the block pool); a batch that would not fit what the device can give this context is taken in pieces.  Tasks

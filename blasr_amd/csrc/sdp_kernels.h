@@ -20,7 +20,10 @@ struct SdpTask {
   int32_t maxPerPos;   // maxMatchesPerPosition
   int32_t top;         // index of the top-level candidate this call belongs to
   int32_t qOrg, tOrg;  // origin of the rectangle in the top-level candidate's coordinates
+  int32_t flags;       // kSdpExtendFront: extendFrontByLocalAlignment; kSdpDetailed: detailedAlignment
+  int32_t pad;
 };
+enum { kSdpExtendFront = 1, kSdpDetailed = 2 };
 
 // SWAlign(Global) on a gap rectangle with q*t < noRecurseUnder (SDPAlign.h:502-504, :438-441)
 struct SwTask {

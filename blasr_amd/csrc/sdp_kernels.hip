@@ -3184,20 +3184,30 @@ __global__ __launch_bounds__(256) void sdp_blocks_build_kernel(SdpLevelArrays lv
     const uint32_t nru = (uint32_t)prm.noRecurseUnder;
     int nSw = 0, nChild = 0;
     const uint32_t q00 = (uint32_t)__builtin_amdgcn_readlane((int)bq, 0), t00 = (uint32_t)__builtin_amdgcn_readlane((int)bt, 0);
-    if (t.type == 1 && q00 > 0 && t00 > 0) {  // front fill (Global only; extendFront is false on this path)
+    const bool ends = t.type == 1 || (t.flags & kSdpExtendFront);  // :437, :546
+    if (ends && q00 > 0 && t00 > 0) {  // front fill
       if (t.recurse == 0 && q00 * t00 < nru) nSw++;
       else if (t.recurse != 0) nChild++;
     }
     {
       const uint32_t nq = (uint32_t)next_lane((int)bq), nt = (uint32_t)next_lane((int)bt);
       int kind = 0;
-      if (lane + 1 < nfb) {
+      if (lane + 1 < nfb && (t.flags & kSdpDetailed)) {
         const uint32_t q0 = bq + bl, t0 = bt + bl;
         const uint32_t fq = nq - q0, ft = nt - t0;
         if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
       }
       nSw += __popcll(__ballot(kind == 1));
       nChild += __popcll(__ballot(kind == 2));
+    }
+    if (t.flags & kSdpExtendFront) {  // tail fill (:546-598: only under extendFrontByLocalAlignment)
+      const uint32_t qe = (uint32_t)__builtin_amdgcn_readlane((int)(bq + bl), nfb - 1);
+      const uint32_t te = (uint32_t)__builtin_amdgcn_readlane((int)(bt + bl), nfb - 1);
+      const uint32_t fq = (uint32_t)t.qLen - qe, ft = (uint32_t)t.tLen - te;
+      if (fq > 0 && ft > 0) {
+        if (t.recurse == 0 && fq * ft < nru) nSw++;
+        else if (t.recurse != 0) nChild++;
+      }
     }
     if (lane == 0) {
       counts[4 * idx] = nfb;
@@ -3293,15 +3303,23 @@ __global__ __launch_bounds__(256) void sdp_blocks_build_kernel(SdpLevelArrays lv
   // ---- count what this task will emit: blocks, SWAlign fills, recursive SDPAlign jobs (:423-536) ----
   const uint32_t nru = (uint32_t)prm.noRecurseUnder;
   int nSw = 0, nChild = 0;
-  if (t.type == 1 && fb[0] > 0 && fbT[0] > 0) {  // front fill (Global only; extendFront is false on this path)
+  const bool ends = t.type == 1 || (t.flags & kSdpExtendFront);  // :437, :546
+  if (ends && fb[0] > 0 && fbT[0] > 0) {  // front fill
     const uint32_t fq = fb[0], ft = fbT[0];
     if (t.recurse == 0 && fq * ft < nru) nSw++;
     else if (t.recurse != 0) nChild++;
   }
+  if (t.flags & kSdpExtendFront) {  // tail fill (:546-598: only under extendFrontByLocalAlignment)
+    const uint32_t fq = (uint32_t)t.qLen - (fb[nfb - 1] + fbL[nfb - 1]), ft = (uint32_t)t.tLen - (fbT[nfb - 1] + fbL[nfb - 1]);
+    if (fq > 0 && ft > 0) {
+      if (t.recurse == 0 && fq * ft < nru) nSw++;
+      else if (t.recurse != 0) nChild++;
+    }
+  }
   for (int b0 = 0; b0 + 1 < nfb; b0 += 64) {
     const int b = b0 + lane;
     int kind = 0;
-    if (b + 1 < nfb) {
+    if (b + 1 < nfb && (t.flags & kSdpDetailed)) {
       const uint32_t q0 = fb[b] + fbL[b], t0 = fbT[b] + fbL[b];
       const uint32_t fq = fb[b + 1] - q0, ft = fbT[b + 1] - t0;
       if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
@@ -3345,13 +3363,14 @@ __global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv,
     sw.pad = 0;
     e.sw[at] = sw;
   };
-  auto putChild = [&](int64_t at, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft, int prefix, int maxPerPos) {
+  auto putChild = [&](int64_t at, uint32_t q0, uint32_t t0, uint32_t fq, uint32_t ft, int k, int prefix, int maxPerPos,
+                      int flags) {
     SdpTask c;
     c.qOff = t.qOff + q0;
     c.tOff = t.tOff + t0;
     c.qLen = (int)fq;
     c.tLen = (int)ft;
-    c.k = t.k - 4 > 5 ? t.k - 4 : 5;
+    c.k = k;
     c.type = 1;  // Global
     c.prefix = prefix;
     c.recurse = t.recurse - 1;
@@ -3359,17 +3378,35 @@ __global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv,
     c.top = t.top;
     c.qOrg = t.qOrg + (int)q0;
     c.tOrg = t.tOrg + (int)t0;
+    c.flags = flags;
+    c.pad = 0;
     e.children[at] = c;
   };
+  const int kMinus4 = t.k - 4 > 5 ? t.k - 4 : 5;
+  const bool ends = t.type == 1 || (t.flags & kSdpExtendFront);
   // :423-474 front fill
-  if (t.type == 1 && fb[0] > 0 && fbT[0] > 0) {
+  if (ends && fb[0] > 0 && fbT[0] > 0) {
     const uint32_t fq = fb[0], ft = fbT[0];
     if (t.recurse == 0 && fq * ft < nru) {
       if (lane == 0) putSw(atSw, 0, 0, fq, ft);
       atSw++;
     } else if (t.recurse != 0) {
-      if (lane == 0) putChild(atChild, 0, 0, fq, ft, t.prefix, 6 /* EndAnchored lands in this slot, :456 */);
+      if (lane == 0) putChild(atChild, 0, 0, fq, ft, kMinus4, t.prefix, 6 /* EndAnchored lands in this slot, :456 */, t.flags);
       atChild++;
+    }
+  }
+  // :546-598 tail fill, only under extendFrontByLocalAlignment: word size k / 2 (sic), the call's own maxMatchesPerPosition
+  if (t.flags & kSdpExtendFront) {
+    const uint32_t q0 = fb[nfb - 1] + fbL[nfb - 1], t0 = fbT[nfb - 1] + fbL[nfb - 1];
+    const uint32_t fq = (uint32_t)t.qLen - q0, ft = (uint32_t)t.tLen - t0;
+    if (fq > 0 && ft > 0) {
+      if (t.recurse == 0 && fq * ft < nru) {
+        if (lane == 0) putSw(atSw, q0, t0, fq, ft);
+        atSw++;
+      } else if (t.recurse != 0) {
+        if (lane == 0) putChild(atChild, q0, t0, fq, ft, t.k / 2 > 5 ? t.k / 2 : 5, t.prefix, t.maxPerPos, t.flags);
+        atChild++;
+      }
     }
   }
   // :481-536 blocks and the fills between consecutive blocks
@@ -3388,14 +3425,14 @@ __global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv,
         t0 = tt + len;
         fq = fb[b + 1] - q0;
         ft = fbT[b + 1] - t0;
-        if (fq > 0 && ft > 0) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
+        if (fq > 0 && ft > 0 && (t.flags & kSdpDetailed)) kind = (fq * ft < nru) ? 1 : (t.recurse != 0 ? 2 : 0);
       }
       e.poolKeys[atPool + b] = ((uint64_t)(uint32_t)t.top << 32) | (uint32_t)(t.qOrg + (int)q);
       e.poolVals[atPool + b] = ((uint64_t)(uint32_t)(t.tOrg + (int)tt) << 32) | len;
     }
     const unsigned long long mSw = __ballot(kind == 1), mCh = __ballot(kind == 2);
     if (kind == 1) putSw(atSw + __popcll(mSw & lt), q0, t0, fq, ft);
-    if (kind == 2) putChild(atChild + __popcll(mCh & lt), q0, t0, fq, ft, 0, 0);
+    if (kind == 2) putChild(atChild + __popcll(mCh & lt), q0, t0, fq, ft, kMinus4, 0, 0, t.flags & kSdpDetailed);
     atSw += __popcll(mSw);
     atChild += __popcll(mCh);
   }

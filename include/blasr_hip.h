@@ -167,8 +167,9 @@ int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *la
 /* ---- SDP: SDPAlign + ComputeAlignmentStats ----------------------------- */
 /* The parameters AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722;
  * defaults MappingParameters.h:192-361).  Supported on the device: align_type
- * Local (0) or Global (1), detailed = 1, extend_front = 0, word_size <= 16, |sdp_ins|, |sdp_del| < 64,
- * sequences shorter than 2^24 bases (else ERR_UNSUPPORTED). */
+ * Local (0) or Global (1), word_size <= 16, |sdp_ins|, |sdp_del| < 64, sequences shorter than 2^24 bases (else
+ * ERR_UNSUPPORTED); detailed = 0 (no fills between blocks, SDPAlign.h:497-499) and extend_front = 1 (front fill of
+ * a Local call :437-474, tail fill with word size k / 2 :546-598) included. */
 typedef struct blasr_hip_sdp_params {
   int32_t word_size;        /* sdpTupleSize (11) */
   int32_t sdp_ins;          /* params.sdpIns (5) */

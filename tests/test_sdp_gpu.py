@@ -83,7 +83,7 @@ def test_random_tasks_against_oracle(ctx, oracle):
 def test_parameter_variety_against_oracle(ctx, oracle):
     from blasr_testlib import ScoreParams as OSc, SdpParams as OSp
     rng = np.random.default_rng(202)
-    for it in range(60):
+    for it in range(120):
         q, t = synth.make_pair(rng, int(rng.integers(20, 1500)), flank=(0, int(rng.integers(0, 100))),
                                ins=float(rng.uniform(0, 0.15)), dele=float(rng.uniform(0, 0.1)),
                                sub=float(rng.uniform(0, 0.05)))
@@ -93,8 +93,11 @@ def test_parameter_variety_against_oracle(ctx, oracle):
             m[np.arange(4), np.arange(4)] = -rng.integers(1, 8, size=4)
         osc = OSc(m, int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(0, 60)), int(rng.integers(0, 3)))
         osp = OSp(k=int(rng.integers(4, 14)), sdp_ins=int(rng.integers(1, 12)), sdp_del=int(rng.integers(1, 12)),
-                  indel_rate=float(rng.uniform(0.1, 1.0)), align_type=int(rng.integers(0, 2)), detailed=1,
-                  extend_front=0, prefix=int(rng.choice([0, 20, 50])), recurse=int(rng.integers(0, 4)),
+                  indel_rate=float(rng.uniform(0.1, 1.0)), align_type=int(rng.integers(0, 2)),
+                  # the second half of the sweep: the two non-default branches of SDPAlign (:437-474 / :546-598 front
+                  # and tail fill under extendFrontByLocalAlignment, :497-499 no fills without detailedAlignment)
+                  detailed=1 if it < 60 else int(rng.integers(0, 2)), extend_front=0 if it < 60 else int(rng.integers(0, 2)),
+                  prefix=int(rng.choice([0, 20, 50])), recurse=int(rng.integers(0, 4)),
                   recurse_over=int(rng.choice([100, 1000, 10000])), max_per_pos=int(rng.choice([0, 0, 3])))
         got = ctx.sdp([(q, t)], _sdp_params(osp), _score(osc))[0]
         w = oracle.sdp_align(q, t, osc, osp)
@@ -112,10 +115,25 @@ def test_long_noisy_reads_against_oracle(ctx, oracle):
         _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], len(q))
 
 
+def test_extend_front_and_coarse_alignment_on_noisy_reads(ctx, oracle):
+    """-extendFrontAlignment (front and tail fills of the Local top-level call, the tail with word size k / 2) and
+    detailedSDPAlignment = 0 (no fills between blocks) on PacBio-like reads with unaligned flanks."""
+    from blasr_testlib import SdpParams as OSp
+    rng = np.random.default_rng(204)
+    pairs = [synth.make_pair(rng, int(rng.integers(1500, 9000)), flank=(50, 600)) for _ in range(8)]
+    for ef, det in ((1, 1), (0, 0), (1, 0)):
+        osp = OSp(extend_front=ef, detailed=det)
+        got = ctx.sdp(pairs, _sdp_params(osp))
+        for i, ((q, t), g) in enumerate(zip(pairs, got)):
+            w = oracle.sdp_align(q, t, None, osp)
+            st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])
+            _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (ef, det, i))
+
+
 def test_unsupported_parameters_are_rejected(ctx):
     q = np.frombuffer(b"ACGTACGTACGTACGTACGT", np.uint8)
     with pytest.raises(blasr_amd.BlasrHipError) as e:
-        ctx.sdp([(q, q)], blasr_amd.SdpParams(extend_front=1))
+        ctx.sdp([(q, q)], blasr_amd.SdpParams(k=17))
     assert e.value.code == blasr_amd.hip.ERR_UNSUPPORTED
 
 
