@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--blasrmc-reads", type=int, default=-1,
                     help="reads mapped by the reference binary (oracle/_ref/blasrmc) as a second baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="let the ranks share the GPUs that exist (rank r on device r mod devices, gloo for the counters): "
+                         "runs the N-rank path with the real device step on a box with fewer GPUs; the line says so")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -272,12 +275,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the refine path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.share_gpus:
+        raise SystemExit("bench.py: %d ranks but %d GPUs (--share-gpus runs them on the GPUs there are)" % (world, n_dev))
+    shared = args.share_gpus and world > n_dev
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:  # RCCL refuses two ranks on one device: the four counters go over gloo instead
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    red_dev = "cpu" if shared else dev
 
     import blasr_amd
     from blasr_amd import hip, synth
@@ -302,8 +314,8 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    ctx = blasr_amd.Context(local_rank)
-    ctx.set_workspace_limit(200 << 30)
+    ctx = blasr_amd.Context(device_index)
+    ctx.set_workspace_limit((200 << 30) // (1 if not shared else -(-world // n_dev)))
     ctx.adopt_genome_device(genome.data_ptr(), G, starts.astype(np.uint32) if len(starts) > 2 else None)
     params = ctx.map_params(band=args.band)
     hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
@@ -338,8 +350,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
-    totals = shard.reduce_counters(n_reads, last["aligned_reads"], last["aligned_bases"], last["dp_cells"], device=dev)
-    elapsed = shard.max_over_ranks(elapsed, device=dev)
+    totals = shard.reduce_counters(n_reads, last["aligned_reads"], last["aligned_bases"], last["dp_cells"], device=red_dev)
+    elapsed = shard.max_over_ranks(elapsed, device=red_dev)
 
     if rank == 0:
         K = args.steps
@@ -403,6 +415,10 @@ def main():
                                    ("chain", "chain_bytes", "chain_ms"), ("blocks_fills_assembly", "blocks_bytes", "blocks_ms"))},
             "device_memory_held_gb": ctx.held_bytes() / 2**30,
         }
+        if shared:
+            out["physical_gpus"] = n_dev
+            out["note"] = ("%d ranks SHARE %d GPU%s (--share-gpus, counters over gloo): a run of the multi-rank path, "
+                           "not a scaling measurement" % (world, n_dev, "" if n_dev == 1 else "s"))
         pmc = PMC.get((args.config, n_reads, d["read_len"], args.band))
         if pmc:
             out["roofline"]["traffic"] = pmc["traffic"]

@@ -173,3 +173,28 @@ def test_two_mapping_threads_give_the_single_thread_results(oracle):
     assert n_candidates >= 2000
     for c in ctxs:
         c.close()
+
+
+def test_bench_with_two_ranks_on_the_devices_there_are():
+    """The N > 1 path of bench.py with the REAL device step: `bench.py --gpus 2 --share-gpus` starts its two ranks itself;
+    on a one-GPU box both map their own shard on that GPU (each through its own context) and the four counters are
+    reduced across the ranks.  The line must say n_gpus = 2, carry both shards' counters, and say that the GPUs were
+    shared (it is a run of the path, not a scaling figure)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpus", "--config", "1", "--reads", "600",
+                        "--read-len", "3000", "--genome-len", "400000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0",
+                        "--blasrmc-reads", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [json.loads(x) for x in p.stdout.decode().splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["reads"] == 1200 and d["config"]["aligned_reads"] == 1200
+    assert d["scaling"] == "weak" and d["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["physical_gpus"] == torch.cuda.device_count() and "SHARE" in d["note"]
