@@ -1,0 +1,227 @@
+// formats_api.hip -- next-4: the reference's on-disk inputs, read by the library's host
+// side so that a C++ caller needs nothing of the reference to feed the path.  Host code only (no device involved).
+//
+//   blasr_hip_fasta_read        FASTAReader::GetNext / ReadAllSequences (FASTAReader.h:166-216, 255-271): a record is a
+//                               title line (everything after '>', spaces included) and the whitespace-separated
+//                               words of the following lines up to the next line that starts with '>'
+//   blasr_hip_fasta_concatenate FASTAReader::ReadAllSequencesIntoOne (:113-146) + the seqdb it fills
+//                               (SequenceIndexDatabase: seqStartPos, names) + genome.ToUpper() (Blasr.cpp:4354): the
+//                               contigs back to back, one 'N' after each
+//   blasr_hip_sa_read           SuffixArray::Read (datastructures/suffixarray/SuffixArray.h:608-630; layout written by
+//                               Write :505-532): magic 0xacac0001, the component list, the index array, the lookup table
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/blasr_hip.h"
+
+struct blasr_hip_fasta {
+  std::vector<std::string> titles;
+  std::vector<std::vector<uint8_t>> seqs;
+  std::string error;
+};
+
+struct blasr_hip_sa {
+  std::vector<uint32_t> index, startPos, endPos;
+  uint32_t lookupTableLength = 0, lookupPrefixLength = 0;
+  int hasArray = 0, hasLookup = 0;
+};
+
+namespace {
+
+bool read_file(const char *path, std::vector<char> &buf) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  buf.resize(n > 0 ? (size_t)n : 0);
+  const size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == buf.size();
+}
+
+// Records of a FASTA text as the reference's reader sees them (delim '>').  Lines end at '\n' (getline); words are
+// separated by the whitespace `operator>>` skips (space, \t, \r, \v, \f); characters before the first line that
+// starts with the delimiter are skipped (AdvanceToTitleStart), and the title of a record is the rest of its first
+// line after the delimiter, a trailing '\r' and inner spaces included.
+void parse_fasta(const char *p, size_t n, blasr_hip_fasta &out) {
+  size_t at = 0;
+  while (true) {
+    while (at < n && p[at] != '>') at++;  // AdvanceToTitleStart looks at every character, not only line starts
+    if (at >= n) break;
+    size_t e = at;
+    while (e < n && p[e] != '\n') e++;
+    out.titles.push_back(std::string(p + at + 1, e - at - 1));
+    out.seqs.push_back(std::vector<uint8_t>());
+    std::vector<uint8_t> &s = out.seqs.back();
+    at = e < n ? e + 1 : n;
+    while (at < n && p[at] != '>') {  // a line that starts with the delimiter ends the record (file.peek())
+      size_t le = at;
+      while (le < n && p[le] != '\n') le++;
+      for (size_t i = at; i < le; i++) {
+        const char c = p[i];
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f') continue;
+        s.push_back((uint8_t)c);
+      }
+      at = le < n ? le + 1 : n;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out) {
+  if (!path || !out) return BLASR_HIP_ERR_INVALID;
+  *out = nullptr;
+  std::vector<char> buf;
+  if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_fasta *f = new blasr_hip_fasta();
+  parse_fasta(buf.data(), buf.size(), *f);
+  *out = f;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_fasta_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+  if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_fasta *f = new blasr_hip_fasta();
+  parse_fasta(text, (size_t)length, *f);
+  *out = f;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_fasta_free(blasr_hip_fasta *f) {
+  delete f;
+  return BLASR_HIP_OK;
+}
+
+int64_t blasr_hip_fasta_count(const blasr_hip_fasta *f) { return f ? (int64_t)f->seqs.size() : 0; }
+
+int blasr_hip_fasta_record(const blasr_hip_fasta *f, int64_t i, const char **title, int64_t *title_length,
+                           const uint8_t **seq, int64_t *seq_length) {
+  if (!f || i < 0 || i >= (int64_t)f->seqs.size()) return BLASR_HIP_ERR_INVALID;
+  if (title) *title = f->titles[(size_t)i].c_str();
+  if (title_length) *title_length = (int64_t)f->titles[(size_t)i].size();
+  if (seq) *seq = f->seqs[(size_t)i].data();
+  if (seq_length) *seq_length = (int64_t)f->seqs[(size_t)i].size();
+  return BLASR_HIP_OK;
+}
+
+int64_t blasr_hip_fasta_name(const blasr_hip_fasta *f, int64_t i, char *name, int64_t capacity) {
+  // FASTASequence::GetName (FASTASequence.h:36-52): the title up to its first blank
+  if (!f || i < 0 || i >= (int64_t)f->titles.size()) return BLASR_HIP_ERR_INVALID;
+  const std::string &t = f->titles[(size_t)i];
+  size_t n = 0;
+  while (n < t.size() && t[n] != ' ' && t[n] != '\t' && t[n] != '\n' && t[n] != '\r') n++;
+  if (name && capacity > 0) {
+    const size_t c = std::min(n, (size_t)capacity - 1);
+    memcpy(name, t.data(), c);
+    name[c] = 0;
+  }
+  return (int64_t)n;
+}
+
+int64_t blasr_hip_fasta_concatenate(const blasr_hip_fasta *f, int to_upper, uint8_t *genome, int64_t capacity,
+                                    uint32_t *seq_start_pos) {
+  if (!f) return BLASR_HIP_ERR_INVALID;
+  int64_t total = 0;
+  for (auto &s : f->seqs) total += (int64_t)s.size() + 1;
+  if (total >= (1ll << 32)) return BLASR_HIP_ERR_UNSUPPORTED;  // "Reading fasta files greater than 4Gbytes is not supported."
+  if (seq_start_pos) {
+    uint32_t at = 0;
+    seq_start_pos[0] = 0;
+    for (size_t i = 0; i < f->seqs.size(); i++) {
+      at += (uint32_t)f->seqs[i].size() + 1;
+      seq_start_pos[i + 1] = at;
+    }
+  }
+  if (!genome) return total;
+  if (capacity < total) return BLASR_HIP_ERR_CAPACITY;
+  int64_t at = 0;
+  for (auto &s : f->seqs) {
+    for (size_t i = 0; i < s.size(); i++) {
+      uint8_t c = s[i];
+      if (to_upper) {  // DNASequence::ToUpper through the AllToUpper table (NucConversion.h:230-263): codes 0-3 and
+        uint8_t u = 'N';  // ACGT in either case become the letter, EVERYTHING else (IUPAC codes too) becomes N
+        if (c == 0 || c == 'A' || c == 'a') u = 'A';
+        if (c == 1 || c == 'C' || c == 'c') u = 'C';
+        if (c == 2 || c == 'G' || c == 'g') u = 'G';
+        if (c == 3 || c == 'T' || c == 't') u = 'T';
+        c = u;
+      }
+      genome[at + (int64_t)i] = c;
+    }
+    at += (int64_t)s.size();
+    genome[at++] = 'N';
+  }
+  return total;
+}
+
+int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) {
+  if (!path || !out) return BLASR_HIP_ERR_INVALID;
+  *out = nullptr;
+  std::vector<char> buf;
+  if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  size_t at = 0;
+  auto take = [&](void *dst, size_t bytes) {
+    if (at + bytes > buf.size()) return false;
+    memcpy(dst, buf.data() + at, bytes);
+    at += bytes;
+    return true;
+  };
+  uint32_t magic = 0;
+  int32_t comp[2] = {0, 0};
+  if (!take(&magic, 4) || magic != 0xacac0001u) return BLASR_HIP_ERR_UNSUPPORTED;  // (files without the magic number: not read)
+  if (!take(comp, 8)) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_sa *sa = new blasr_hip_sa();
+  sa->hasArray = comp[0];
+  sa->hasLookup = comp[1];
+  bool ok = true;
+  if (comp[0]) {
+    uint32_t len = 0;
+    ok = take(&len, 4);
+    if (ok) {
+      sa->index.resize(len);
+      ok = take(sa->index.data(), 4ull * len);
+    }
+  }
+  if (ok && comp[1]) {
+    ok = take(&sa->lookupTableLength, 4) && take(&sa->lookupPrefixLength, 4);
+    if (ok) {
+      sa->startPos.resize(sa->lookupTableLength);
+      sa->endPos.resize(sa->lookupTableLength);
+      ok = take(sa->startPos.data(), 4ull * sa->lookupTableLength) && take(sa->endPos.data(), 4ull * sa->lookupTableLength);
+    }
+  }
+  if (!ok) {
+    delete sa;
+    return BLASR_HIP_ERR_INVALID;
+  }
+  *out = sa;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_sa_free(blasr_hip_sa *sa) {
+  delete sa;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t *length, const uint32_t **start_pos_table,
+                        const uint32_t **end_pos_table, int64_t *lookup_table_length, int32_t *lookup_prefix_length) {
+  if (!sa) return BLASR_HIP_ERR_INVALID;
+  if (index) *index = sa->index.data();
+  if (length) *length = (int64_t)sa->index.size();
+  if (start_pos_table) *start_pos_table = sa->startPos.data();
+  if (end_pos_table) *end_pos_table = sa->endPos.data();
+  if (lookup_table_length) *lookup_table_length = sa->lookupTableLength;
+  if (lookup_prefix_length) *lookup_prefix_length = (int32_t)sa->lookupPrefixLength;
+  return BLASR_HIP_OK;
+}
+
+}  // extern "C"

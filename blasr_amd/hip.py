@@ -35,6 +35,9 @@ EXPORTS = [
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
     "blasr_hip_map_default_params", "blasr_hip_map_last_timing", "blasr_hip_map_device_arenas",
     "blasr_hip_adopt_genome_device", "blasr_hip_held_bytes", "blasr_hip_sdp_last_bytes",
+    "blasr_hip_fasta_read", "blasr_hip_fasta_parse", "blasr_hip_fasta_free", "blasr_hip_fasta_count",
+    "blasr_hip_fasta_record", "blasr_hip_fasta_name", "blasr_hip_fasta_concatenate",
+    "blasr_hip_sa_read", "blasr_hip_sa_free", "blasr_hip_sa_arrays",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -919,3 +922,70 @@ class Context:
                                               C.c_void_p(ops_ptr), int(ops_capacity), C.byref(used))
         self._check(rc)
         return used.value
+
+
+# --- next-4: the reference's on-disk inputs (host code, no device involved) -----------------------------
+def read_fasta(path=None, text=None):
+    """FASTAReader::ReadAllSequences: [(title, sequence uint8 array)] of a FASTA file (or of `text`, bytes)."""
+    lib = load_library()
+    h = C.c_void_p()
+    if path is not None:
+        rc = lib.blasr_hip_fasta_read(path.encode(), C.byref(h))
+    else:
+        rc = lib.blasr_hip_fasta_parse(text, C.c_int64(len(text)), C.byref(h))
+    if rc != OK:
+        raise BlasrHipError(rc, "fasta_read %s" % path)
+    lib.blasr_hip_fasta_count.restype = C.c_int64
+    out = []
+    for i in range(lib.blasr_hip_fasta_count(h)):
+        t, tl, s, sl = C.c_char_p(), C.c_int64(0), C.c_void_p(), C.c_int64(0)
+        lib.blasr_hip_fasta_record(h, C.c_int64(i), C.byref(t), C.byref(tl), C.byref(s), C.byref(sl))
+        title = C.string_at(t, tl.value)
+        seq = np.frombuffer(C.string_at(s, sl.value), dtype=np.uint8).copy() if sl.value else np.zeros(0, np.uint8)
+        out.append((title, seq))
+    lib.blasr_hip_fasta_free(h)
+    return out
+
+
+def read_genome(path):
+    """A genome FASTA as Blasr.cpp holds it: (genome uint8 array: contigs back to back, an N after each, upper case;
+    seqStartPos uint32 array; names)."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.blasr_hip_fasta_read(path.encode(), C.byref(h))
+    if rc != OK:
+        raise BlasrHipError(rc, "fasta_read %s" % path)
+    lib.blasr_hip_fasta_count.restype = C.c_int64
+    lib.blasr_hip_fasta_concatenate.restype = C.c_int64
+    lib.blasr_hip_fasta_name.restype = C.c_int64
+    n = lib.blasr_hip_fasta_count(h)
+    starts = np.zeros(n + 1, dtype=np.uint32)
+    total = lib.blasr_hip_fasta_concatenate(h, 1, None, C.c_int64(0), starts.ctypes.data_as(C.c_void_p))
+    genome = np.zeros(max(total, 1), dtype=np.uint8)
+    got = lib.blasr_hip_fasta_concatenate(h, 1, genome.ctypes.data_as(C.c_void_p), C.c_int64(total), None)
+    names = []
+    for i in range(n):
+        buf = C.create_string_buffer(4096)
+        lib.blasr_hip_fasta_name(h, C.c_int64(i), buf, C.c_int64(4096))
+        names.append(buf.value.decode())
+    lib.blasr_hip_fasta_free(h)
+    if got < 0:
+        raise BlasrHipError(int(got), "fasta_concatenate")
+    return genome[:total], starts, names
+
+
+def read_suffix_array(path):
+    """SuffixArray::Read: dict(index, start_pos_table, end_pos_table, lookup_prefix_length) of a .sa file."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.blasr_hip_sa_read(path.encode(), C.byref(h))
+    if rc != OK:
+        raise BlasrHipError(rc, "sa_read %s" % path)
+    idx, sp, ep = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n, ltl, lpl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    lib.blasr_hip_sa_arrays(h, C.byref(idx), C.byref(n), C.byref(sp), C.byref(ep), C.byref(ltl), C.byref(lpl))
+    take = lambda p, k: np.frombuffer(C.string_at(p, 4 * k), dtype=np.uint32).copy() if k else np.zeros(0, np.uint32)
+    out = dict(index=take(idx, n.value), start_pos_table=take(sp, ltl.value), end_pos_table=take(ep, ltl.value),
+               lookup_prefix_length=lpl.value)
+    lib.blasr_hip_sa_free(h)
+    return out

@@ -1,0 +1,154 @@
+// examples/map_fasta.cpp -- a C++ host over the C ABI of include/blasr_hip.h, nothing else: FASTA in, `-m 4` lines out.
+//
+//   map_fasta reads.fasta genome.fasta intervals.txt [bestn]
+//
+// What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
+//   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
+//   reads       blasr_hip_fasta_read                                   (ReaderAgglomerate, FASTA)
+//   intervals   one per line: read start end qStart qEnd strand        (the candidate intervals anchoring reports: the
+//               one stage that is not built, SURVEY next-1; `blasrmc -V 1` prints them)
+//   MapRead     blasr_hip_map_reads_host                               (:2530-2644, C++ inside the library)
+//   epilogue    blasr_hip_ref_contig_location, blasr_hip_map_qvs, blasr_hip_m4_line   (:3509-3516, :3086)
+// Build: g++ -O2 -std=c++11 -I include examples/map_fasta.cpp -L blasr_amd -lblasr_hip -Wl,-rpath,'$ORIGIN/../blasr_amd'
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "blasr_hip.h"
+
+static void die(const char *what, blasr_hip_ctx *ctx) {
+  fprintf(stderr, "map_fasta: %s%s%s\n", what, ctx ? ": " : "", ctx ? blasr_hip_last_error(ctx) : "");
+  exit(1);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta intervals.txt [bestn]", NULL);
+  const int bestn = argc > 4 ? atoi(argv[4]) : 1;
+  // ---- genome: contigs back to back, an N after each, upper case; the contig table; names up to the first blank
+  blasr_hip_fasta *gf = NULL, *rf = NULL;
+  if (blasr_hip_fasta_read(argv[2], &gf) != BLASR_HIP_OK) die("cannot read the genome", NULL);
+  const int64_t nContigs = blasr_hip_fasta_count(gf);
+  std::vector<uint32_t> starts((size_t)nContigs + 1);
+  const int64_t genomeLen = blasr_hip_fasta_concatenate(gf, 1, NULL, 0, starts.data());
+  if (genomeLen <= 0) die("empty genome", NULL);
+  std::vector<uint8_t> genome((size_t)genomeLen);
+  blasr_hip_fasta_concatenate(gf, 1, genome.data(), genomeLen, NULL);
+  std::vector<std::string> contigNames;
+  for (int64_t i = 0; i < nContigs; i++) {
+    char buf[1024];
+    blasr_hip_fasta_name(gf, i, buf, sizeof(buf));
+    contigNames.push_back(buf);
+  }
+  // ---- reads
+  if (blasr_hip_fasta_read(argv[1], &rf) != BLASR_HIP_OK) die("cannot read the reads", NULL);
+  const int nReads = (int)blasr_hip_fasta_count(rf);
+  std::vector<blasr_hip_read> reads((size_t)nReads);
+  std::vector<uint8_t> pool;
+  std::vector<std::string> readNames;
+  for (int r = 0; r < nReads; r++) {
+    const uint8_t *s;
+    int64_t n;
+    char buf[1024];
+    blasr_hip_fasta_record(rf, r, NULL, NULL, &s, &n);
+    blasr_hip_fasta_name(rf, r, buf, sizeof(buf));
+    reads[r].off = (int64_t)pool.size();
+    reads[r].length = (uint32_t)n;
+    reads[r].subread_start = 0;
+    reads[r].subread_end = (uint32_t)n;
+    reads[r].reserved = 0;
+    pool.insert(pool.end(), s, s + n);
+    // the reference appends the subread's coordinates to the name it prints (SMRTSequence title handling)
+    readNames.push_back(std::string(buf) + "/0_" + std::to_string((long long)n));
+  }
+  // ---- candidate intervals
+  std::vector<blasr_hip_interval> ivs;
+  FILE *f = fopen(argv[3], "r");
+  if (!f) die("cannot read the intervals", NULL);
+  long long rd, st, en, qs, qe, sd;
+  while (fscanf(f, "%lld %lld %lld %lld %lld %lld", &rd, &st, &en, &qs, &qe, &sd) == 6) {
+    blasr_hip_interval iv = {(uint32_t)st, (uint32_t)en, (uint32_t)qs, (uint32_t)qe, (int32_t)rd, (int32_t)sd};
+    ivs.push_back(iv);
+  }
+  fclose(f);
+  // ---- MapRead for the whole block
+  blasr_hip_ctx *ctx = NULL;
+  if (blasr_hip_create(0, &ctx) != BLASR_HIP_OK) die("no gfx950 device", NULL);
+  if (blasr_hip_upload_genome(ctx, genome.data(), genomeLen, nContigs > 1 ? starts.data() : NULL, nContigs > 1 ? (int32_t)nContigs : 0))
+    die("upload_genome", ctx);
+  blasr_hip_map_params prm;
+  blasr_hip_map_default_params(&prm);
+  std::vector<blasr_hip_hit> hits(ivs.size() + 1);
+  std::vector<int64_t> hitOff((size_t)nReads + 1);
+  int64_t seqCap = 64, nHits = 0;
+  for (size_t k = 0; k < ivs.size(); k++) seqCap += 3ll * reads[ivs[k].read].length + (ivs[k].end - ivs[k].start);
+  std::vector<uint8_t> seqArena((size_t)seqCap);
+  std::vector<uint32_t> opsArena((size_t)seqCap);
+  blasr_hip_map_fetch fetch = {seqArena.data(), seqCap, 0, opsArena.data(), seqCap, 0};
+  if (blasr_hip_map_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), (int32_t)ivs.size(), ivs.data(), &prm,
+                               hits.data(), (int64_t)hits.size(), &nHits, hitOff.data(), &fetch) != BLASR_HIP_OK)
+    die("map_reads", ctx);
+  // ---- per read: StoreMapQVs over its alignments, then the line(s) of the best
+  blasr_hip_mapqv_params qp;
+  static const int32_t logProb[25] = {0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0};
+  memcpy(qp.matrix, logProb, sizeof(logProb));  // SMRTLogProbMatrix (ScoreMatrices.h:28-34)
+  qp.ins = 5, qp.del = 5, qp.affine_open = 50, qp.affine_extend = 0;  // InitializeScoreFunction (MappingParameters.h:587-592)
+  qp.affine_align = 1;
+  qp.min_fraction_overlapping = 0.75f;
+  for (int r = 0; r < nReads; r++) {
+    const int64_t a = hitOff[r], b = hitOff[r + 1];
+    if (a == b) continue;
+    std::vector<blasr_hip_mapqv_alignment> alns;
+    for (int64_t i = a; i < b; i++) {
+      const blasr_hip_hit &h = hits[i];
+      blasr_hip_mapqv_alignment m;
+      m.q_aligned_seq = seqArena.data() + h.q_off;
+      m.t_aligned_seq = seqArena.data() + h.t_off;
+      m.ops = opsArena.data() + h.ops_off;
+      m.n_ops = h.n_ops;
+      m.q_pos = h.q_pos;
+      m.t_pos = h.t_pos;
+      m.q_align_start = h.q_aligned_seq_pos + (uint32_t)h.q_pos;
+      m.q_align_end = m.q_align_start + (uint32_t)(h.n_match + h.n_mismatch + h.n_ins);
+      m.q_strand = 0;
+      m.q_length = h.q_length;
+      m.n_match = h.n_match;
+      m.reserved = 0;
+      alns.push_back(m);
+    }
+    std::vector<int32_t> qv(alns.size());
+    if (blasr_hip_map_qvs(alns.data(), (int32_t)alns.size(), &qp, NULL, qv.data(), NULL) < 0) die("map_qvs", NULL);
+    for (int64_t i = a; i < b && i - a < bestn; i++) {
+      const blasr_hip_hit &h = hits[i];
+      int32_t contig = 0;
+      uint32_t contigPos = 0;
+      blasr_hip_ref_contig_location(h.t_aligned_seq_pos, h.t_aligned_seq_length, h.t_strand, starts.data(), (int32_t)nContigs + 1,
+                                    (uint32_t)genomeLen, &contig, &contigPos);
+      blasr_hip_m4_fields m4;
+      m4.q_name = readNames[r].c_str();
+      m4.t_name = contigNames[(size_t)contig].c_str();
+      m4.score = h.score;
+      m4.pct_similarity = h.pct_similarity;
+      m4.q_strand = 0;
+      m4.q_align_start = alns[(size_t)(i - a)].q_align_start;
+      m4.q_align_end = alns[(size_t)(i - a)].q_align_end;
+      m4.q_length = h.q_length;
+      m4.t_strand = h.t_strand;
+      m4.t_align_start = contigPos + (uint32_t)h.t_pos;
+      m4.t_align_end = m4.t_align_start + (uint32_t)(h.n_match + h.n_mismatch + h.n_del);
+      m4.t_length = h.t_length;
+      m4.map_qv = h.score < prm.max_score ? qv[(size_t)(i - a)] : 50;
+      char line[4096];
+      int64_t len = 0;
+      if (blasr_hip_m4_line(&m4, line, sizeof(line), &len) < 0) die("m4_line", NULL);
+      fwrite(line, 1, (size_t)len, stdout);
+    }
+  }
+  blasr_hip_destroy(ctx);
+  blasr_hip_fasta_free(gf);
+  blasr_hip_fasta_free(rf);
+  return 0;
+}

@@ -577,6 +577,36 @@ int blasr_hip_sam_line(const blasr_hip_sam_fields *fields, char *line, int64_t l
 int blasr_hip_order_gaps_by_type(const uint32_t *ops, int64_t n_ops, uint32_t *out, int64_t out_capacity,
                                  int64_t *n_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * next-4: the reference's on-disk inputs.  Host functions, no GPU work.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_fasta blasr_hip_fasta;
+/* FASTAReader::ReadAllSequences (FASTAReader.h:166-216, :255-271): every record of a FASTA file / text -- the title
+ * (the whole line after '>') and the sequence (the whitespace-separated words of the lines up to the next '>'). */
+int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out);
+int blasr_hip_fasta_parse(const char *text, int64_t length, blasr_hip_fasta **out);
+int blasr_hip_fasta_free(blasr_hip_fasta *fasta);
+int64_t blasr_hip_fasta_count(const blasr_hip_fasta *fasta);
+/* Record i; the pointers stay valid until blasr_hip_fasta_free.  Any output may be NULL. */
+int blasr_hip_fasta_record(const blasr_hip_fasta *fasta, int64_t i, const char **title, int64_t *title_length,
+                           const uint8_t **seq, int64_t *seq_length);
+/* FASTASequence::GetName (FASTASequence.h:36-52): the title up to its first blank; returns its length. */
+int64_t blasr_hip_fasta_name(const blasr_hip_fasta *fasta, int64_t i, char *name, int64_t capacity);
+/* FASTAReader::ReadAllSequencesIntoOne (:113-146) as Blasr.cpp reads a genome (:4329, :4354): the records back to
+ * back, one 'N' after each, upper-cased when to_upper is set; seq_start_pos (count + 1 entries, may be NULL) receives
+ * SequenceIndexDatabase::seqStartPos.  Returns the length (with genome == NULL: only the length and the table), < 0 on
+ * error. */
+int64_t blasr_hip_fasta_concatenate(const blasr_hip_fasta *fasta, int to_upper, uint8_t *genome, int64_t capacity,
+                                    uint32_t *seq_start_pos);
+
+typedef struct blasr_hip_sa blasr_hip_sa;
+/* SuffixArray::Read (datastructures/suffixarray/SuffixArray.h:608-630): a .sa file as sawriter writes it (:505-532):
+ * magic 0xacac0001, the component list, the index array, the lookup table (start / end of every prefix's range). */
+int blasr_hip_sa_read(const char *path, blasr_hip_sa **out);
+int blasr_hip_sa_free(blasr_hip_sa *sa);
+int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t *length, const uint32_t **start_pos_table,
+                        const uint32_t **end_pos_table, int64_t *lookup_table_length, int32_t *lookup_prefix_length);
+
 #ifdef __cplusplus
 }
 #endif

@@ -419,3 +419,70 @@ long ref_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out) {
 }
 
 }  // extern "C"
+
+// ---- next-4: the reference's own readers (FASTAReader, SuffixArray::Read), for the parity of
+// blasr_amd/csrc/formats_api.hip ----
+extern "C" {
+
+// FASTAReader::ReadAllSequencesIntoOne + genome.ToUpper() as Blasr.cpp reads a genome (:4329, :4354).
+// Returns the length (or -1 when the buffers are too small); starts: nSeq + 1 entries; titles: the records' titles
+// joined by '\n'.
+long ref_read_genome(const char *path, unsigned char *seqOut, long seqCap, unsigned *starts, int startsCap, char *titles,
+                     long titlesCap, int *nSeqOut) {
+  string name(path);
+  FASTAReader reader;
+  reader.Initialize(name);
+  FASTASequence genome;
+  SequenceIndexDatabase<FASTASequence> seqdb;
+  reader.ReadAllSequencesIntoOne(genome, &seqdb);
+  genome.ToUpper();
+  const int nSeq = seqdb.nSeqPos - 1;
+  *nSeqOut = nSeq;
+  if ((long)genome.length > seqCap || nSeq + 1 > startsCap) return -1;
+  memcpy(seqOut, genome.seq, genome.length);
+  string all;
+  for (int i = 0; i <= nSeq; i++) starts[i] = seqdb.seqStartPos[i];
+  for (int i = 0; i < nSeq; i++) {
+    all += string(seqdb.names[i]);
+    all += "\n";
+  }
+  if ((long)all.size() + 1 > titlesCap) return -1;
+  memcpy(titles, all.c_str(), all.size() + 1);
+  return genome.length;
+}
+
+// FASTAReader::GetNext over a file: sequence lengths and bytes back to back; returns the number of records
+int ref_read_fasta_records(const char *path, unsigned char *seqOut, long seqCap, long *lengths, int maxRecords) {
+  string name(path);
+  FASTAReader reader;
+  reader.Initialize(name);
+  FASTASequence seq;
+  int n = 0;
+  long at = 0;
+  while (reader.GetNext(seq)) {
+    if (n >= maxRecords || at + (long)seq.length > seqCap) return -1;
+    memcpy(seqOut + at, seq.seq, seq.length);
+    at += seq.length;
+    lengths[n++] = seq.length;
+  }
+  return n;
+}
+
+// SuffixArray::Read: the index array and the lookup table of a .sa file.  out[0] = length, out[1] = lookupTableLength,
+// out[2] = lookupPrefixLength
+int ref_read_sa(const char *path, unsigned *index, long indexCap, unsigned *startPos, unsigned *endPos, long tableCap,
+                long *out) {
+  DNASuffixArray sa;
+  string name(path);
+  if (!sa.Read(name)) return -1;
+  out[0] = sa.length;
+  out[1] = sa.lookupTableLength;
+  out[2] = sa.lookupPrefixLength;
+  if ((long)sa.length > indexCap || (long)sa.lookupTableLength > tableCap) return -2;
+  memcpy(index, sa.index, sizeof(unsigned) * sa.length);
+  memcpy(startPos, sa.startPosTable, sizeof(unsigned) * sa.lookupTableLength);
+  memcpy(endPos, sa.endPosTable, sizeof(unsigned) * sa.lookupTableLength);
+  return 0;
+}
+
+}  // extern "C"

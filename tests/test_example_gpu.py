@@ -1,0 +1,33 @@
+"""examples/map_fasta: a C++ program over the C ABI alone -- the library's FASTA readers (next-4), MapRead for the whole
+block (blasr_hip_map_reads_host), contig location, mapQV, the -m 4 printer -- run as a binary on the noisy
+multi-candidate fixture: FASTA files and the reference's candidate intervals in, the reference binary's -m 4 lines
+out, byte for byte."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_dropin_gpu import write_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "map_fasta")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "m4_noisy_golden.npz")
+
+
+@pytest.mark.gpu
+def test_cpp_example_prints_the_reference_lines(tmp_path):
+    if not os.path.exists(EXE):
+        pytest.skip("examples/map_fasta not built (python -c 'import __graft_entry__ as g; g.build()')")
+    want = write_inputs(str(tmp_path))
+    g = np.load(GOLDEN)
+    with open(os.path.join(str(tmp_path), "intervals.txt"), "w") as f:
+        for (s, e, qs, qe, strand), r in zip(g["intervals"], g["owner"]):
+            f.write("%d %d %d %d %d %d\n" % (r, s, e, qs, qe, strand))
+    p = subprocess.run([EXE, os.path.join(str(tmp_path), "reads.fasta"), os.path.join(str(tmp_path), "genome.fasta"),
+                        os.path.join(str(tmp_path), "intervals.txt"), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = sorted(p.stdout.decode().splitlines())
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]

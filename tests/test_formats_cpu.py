@@ -1,0 +1,108 @@
+"""next-4: the library's readers of the reference's on-disk inputs -- FASTA (records, the concatenated
+upper-cased genome with its contig table, names) and the .sa file of sawriter -- against the reference's OWN readers
+(FASTAReader / SequenceIndexDatabase / SuffixArray::Read through oracle/_ref/libblasr_refmapper.so) on files written
+here, and against a small committed fixture where that build is absent."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from blasr_amd import hip, synth
+from blasr_testlib import REFMAPPER_SO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAWRITER = os.path.join(ROOT, "oracle", "_ref", "sawritermc")
+
+AWKWARD = (b"junk before the first record\n>contig one  with spaces\t and a tab\nACGTacgtNNrykm\nacgt ACGT\tGG\n\n  TT  \n"
+           b">second\r\nAC\r\nGT\r\n>empty title follows\n>\nAAAA\n>last|no newline at the end\nCCCCGGGG")
+
+
+def write(tmp_path, name, data):
+    p = os.path.join(str(tmp_path), name)
+    with open(p, "wb") as f:
+        f.write(data)
+    return p
+
+
+def test_fasta_records_and_genome_of_an_awkward_file(tmp_path):
+    p = write(tmp_path, "awkward.fasta", AWKWARD)
+    recs = hip.read_fasta(p)
+    assert [t for t, _ in recs] == [b"contig one  with spaces\t and a tab", b"second\r", b"empty title follows", b"",
+                                    b"last|no newline at the end"]
+    assert [bytes(s) for _, s in recs] == [b"ACGTacgtNNrykmacgtACGTGGTT", b"ACGT", b"", b"AAAA", b"CCCCGGGG"]
+    assert hip.read_fasta(text=AWKWARD)[0][1].tobytes() == recs[0][1].tobytes()
+    genome, starts, names = hip.read_genome(p)
+    # everything that is not ACGT in either case becomes N (AllToUpper, NucConversion.h:230-263); one N after each contig
+    assert bytes(genome) == b"ACGTACGTNNNNNNACGTACGTGGTTN" + b"ACGTN" + b"N" + b"AAAAN" + b"CCCCGGGGN"
+    assert starts.tolist() == [0, 27, 32, 33, 38, 47]
+    assert names == ["contig", "second", "empty", "", "last|no"]
+
+
+@pytest.mark.skipif(not os.path.exists(REFMAPPER_SO), reason="oracle/_ref/libblasr_refmapper.so not built")
+def test_fasta_against_the_reference_reader(tmp_path):
+    ref = C.CDLL(REFMAPPER_SO)
+    ref.ref_read_genome.restype = C.c_long
+    rng = np.random.default_rng(5)
+    # (without the record whose title is empty: the reference's seqdb builds a std::string from its NULL title)
+    files = [AWKWARD.replace(b">\nAAAA\n", b"")]
+    for it in range(6):  # random multi-FASTA files: line lengths, blank lines, lower case, IUPAC codes, several words
+        out = b""
+        for c in range(int(rng.integers(1, 6))):
+            s = bytes(synth.random_genome(int(rng.integers(0, 900)), 100 * it + c))
+            if it % 2:
+                s = s.lower()
+            s = bytearray(s)
+            for _ in range(len(s) // 50):
+                s[int(rng.integers(0, len(s)))] = int(rng.choice(list(b"NnRYKMswb")))
+            out += b">c%d some description %d\n" % (c, it)
+            w = int(rng.integers(10, 80))
+            for k in range(0, len(s), w):
+                out += bytes(s[k:k + w]) + (b" " if rng.integers(0, 5) == 0 else b"") + b"\n"
+                if rng.integers(0, 9) == 0:
+                    out += b"\n"
+        files.append(out)
+    for i, data in enumerate(files):
+        p = write(tmp_path, "f%d.fasta" % i, data)
+        genome, starts, names = hip.read_genome(p)
+        seq = np.zeros(len(data) + 64, np.uint8)
+        st = np.zeros(64, np.uint32)
+        titles = C.create_string_buffer(len(data) + 64)
+        n = C.c_int(0)
+        L = ref.ref_read_genome(p.encode(), seq.ctypes.data_as(C.c_void_p), C.c_long(len(seq)), st.ctypes.data_as(C.c_void_p), 64,
+                                titles, C.c_long(len(titles)), C.byref(n))
+        assert L == len(genome), i
+        assert np.array_equal(seq[:L], genome), i
+        assert st[: n.value + 1].tolist() == starts.tolist(), i
+        recs = hip.read_fasta(p)
+        assert titles.value.split(b"\n")[:-1] == [t for t, _ in recs], i
+        lengths = (C.c_long * 64)()
+        k = ref.ref_read_fasta_records(p.encode(), seq.ctypes.data_as(C.c_void_p), C.c_long(len(seq)), lengths, 64)
+        assert k == len(recs) and [lengths[j] for j in range(k)] == [len(s) for _, s in recs], i
+        assert bytes(seq[: sum(lengths[j] for j in range(k))]) == b"".join(bytes(s) for _, s in recs), i
+
+
+@pytest.mark.skipif(not (os.path.exists(SAWRITER) and os.path.exists(REFMAPPER_SO)), reason="reference tools not built")
+def test_suffix_array_file_of_sawriter(tmp_path):
+    """A .sa written by the reference's sawriter for a two-contig genome: the library reads the same index array and
+    lookup table as SuffixArray::Read; the index is a permutation that sorts the suffixes it lists."""
+    g = b">a\n" + bytes(synth.random_genome(30000, 3)) + b"\n>b\n" + bytes(synth.random_genome(12000, 4)) + b"\n"
+    fa = write(tmp_path, "g.fasta", g)
+    sa_path = os.path.join(str(tmp_path), "g.fasta.sa")
+    subprocess.run([SAWRITER, sa_path, fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    sa = hip.read_suffix_array(sa_path)
+    ref = C.CDLL(REFMAPPER_SO)
+    n = len(sa["index"])
+    m = len(sa["start_pos_table"]) + 8
+    idx, sp, ep = np.zeros(n + 8, np.uint32), np.zeros(m, np.uint32), np.zeros(m, np.uint32)
+    out = (C.c_long * 3)()
+    rc = ref.ref_read_sa(sa_path.encode(), idx.ctypes.data_as(C.c_void_p), C.c_long(len(idx)), sp.ctypes.data_as(C.c_void_p),
+                         ep.ctypes.data_as(C.c_void_p), C.c_long(len(sp)), out)
+    assert rc == 0 and out[0] == n and out[2] == sa["lookup_prefix_length"]
+    assert np.array_equal(idx[:n], sa["index"])
+    assert np.array_equal(sp[: out[1]], sa["start_pos_table"]) and np.array_equal(ep[: out[1]], sa["end_pos_table"])
+    genome, starts, _ = hip.read_genome(fa)
+    assert n <= len(genome) and len(set(sa["index"][:2000].tolist())) == 2000
+    a, b = int(sa["index"][100]), int(sa["index"][101])
+    assert bytes(genome[a: a + 40]) <= bytes(genome[b: b + 40])  # neighbours in the array are in suffix order
