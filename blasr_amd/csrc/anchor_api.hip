@@ -1,0 +1,742 @@
+// next-1, device half: anchoring reads in the suffix array of the genome.
+//
+// Replaces MapReadToGenome (common/algorithms/anchoring/MapBySuffixArray.h:217-311) for both strands of every read
+// of a batch, and SortMatchPosList (datastructures/anchoring/MatchPos.h:166-168) on the lists:
+//   anchor_search_kernel   one lane per read position p of one strand: StoreLCPBounds (SuffixArray.h:928-1070) --
+//                          the lookup table's range for the first bases, then one SearchLeftBound / SearchRightBound
+//                          pair (:733-816) per further base -- and the heuristics of LocateAnchorBoundsInSuffixArray
+//                          (MapBySuffixArray.h:93-204): extend a unique match along the genome, back a dead-end
+//                          unique match up by one base, back a repeated one up by `expand`.  The last few ranges
+//                          are kept in registers (the only ones those heuristics revisit).  Output: the range
+//                          [low, low + count) of the index array and the match length, per position.
+//   anchor_advance_kernel  advanceExactMatches: the positions the reference's loop skips, one lane per strand
+//   (rocprim scan)         exclusive scan of the counts -> where every position's anchors go
+//   anchor_emit_kernel     one wavefront per 64 positions, one lane per anchor: (index[low + i], p, length)
+//   (rocprim segmented radix sort on (t, q)) + anchor_pack_kernel   SortMatchPosList
+// The genome (ASCII), the index array and the lookup table stay resident: 4 bytes of index per genome base, sized for
+// a whole human genome in HBM.  The work is latency / random-sector bound: every probe of a binary search is a load of
+// index[m] followed by a dependent load of genome[index[m] + offset].
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/blasr_hip.h"
+#include "ctx.h"
+#include "wave_utils.h"
+
+namespace {
+using namespace blasr_hip;
+
+// ThreeBit (NucConversion.h:48-84), rebuilt from its defining property: codes 0..4 map to themselves, '$' to 5,
+// ACGT in both cases to 0..3, the IUPAC ambiguity letters the table lists to 4, everything else 255.
+struct NucTable {
+  uint8_t v[256];
+};
+constexpr NucTable make_three_bit() {
+  NucTable t{};
+  for (int i = 0; i < 256; i++) t.v[i] = 255;
+  for (int i = 0; i < 5; i++) t.v[i] = (uint8_t)i;
+  t.v['$'] = 5;
+  const char acgt[4] = {'A', 'C', 'G', 'T'};
+  for (int i = 0; i < 4; i++) {
+    t.v[(int)acgt[i]] = (uint8_t)i;
+    t.v[(int)acgt[i] + 32] = (uint8_t)i;
+  }
+  const char upper[] = "BDHKMNRSUVWY_";
+  for (int i = 0; upper[i]; i++) t.v[(int)upper[i]] = 4;
+  const char lower[] = "bdhkmnrsuvwxy";
+  for (int i = 0; lower[i]; i++) t.v[(int)lower[i]] = 4;
+  return t;
+}
+__constant__ NucTable kThreeBit = make_three_bit();
+
+// ReverseComplementNuc (NucConversion.h:337-370): codes 0..3, ACGTN in both cases, everything else 127
+__device__ __forceinline__ uint8_t rc_nuc(uint8_t c) {
+  uint8_t r = 127;
+  r = c < 4 ? (uint8_t)(3 - c) : r;
+  r = c == 'A' ? 'T' : r;
+  r = c == 'C' ? 'G' : r;
+  r = c == 'G' ? 'C' : r;
+  r = c == 'T' ? 'A' : r;
+  r = c == 'N' ? 'N' : r;
+  r = c == 'a' ? 't' : r;
+  r = c == 'c' ? 'g' : r;
+  r = c == 'g' ? 'c' : r;
+  r = c == 't' ? 'a' : r;
+  r = c == 'n' ? 'n' : r;
+  return r;
+}
+
+struct AnchorSeg {     // one strand of one read
+  int64_t off;         // first base of the forward read in the pool
+  uint32_t len;        // read.length
+  uint32_t start;      // subreadStart on this strand (Blasr.cpp:3449-3450 for the reverse one)
+  uint32_t matchEnd;   // subreadEnd - minPrefixMatchLength + 1 (MapBySuffixArray.h:46)
+  uint32_t strand;
+};
+
+struct AnchorArgs {
+  const uint8_t *genome;
+  uint32_t tlen;
+  const uint32_t *index, *startPos, *endPos;
+  int prefixLen;
+  const uint8_t *pool;
+  const AnchorSeg *seg;
+  const int64_t *posOff;  // nSeg + 1: first position of every segment in this piece
+  int nSeg;
+  int64_t nPos;
+  uint32_t minMatch, minPrefix;
+  int expand, maxAnchors, advance, maxLcp, useLookup, stopUnique;
+  uint32_t *lo, *cnt, *len;
+  uint32_t *lcp;                // per position: lcpLength as the advance step sees it (only when advance != 0)
+  unsigned long long *probes;   // optional: probes of the index array
+};
+
+__device__ __forceinline__ uint8_t strand_base(const uint8_t *pool, const AnchorSeg &s, uint32_t at) {
+  return s.strand ? rc_nuc(pool[s.off + (int64_t)(s.len - 1 - at)]) : pool[s.off + (int64_t)at];
+}
+
+// the segment a position of the piece belongs to: the last s with posOff[s] <= g
+__device__ __forceinline__ int segment_of(const int64_t *posOff, int nSeg, int64_t g) {
+  int lo = 0, hi = nSeg;  // posOff[lo] <= g < posOff[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (posOff[mid] <= g)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// SearchLeftBound (SuffixArray.h:733-775)
+__device__ __forceinline__ uint32_t left_bound(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq,
+                                               uint32_t l, uint32_t r, unsigned &probes) {
+  uint32_t ll = l, lr = r;
+  while (ll < lr) {
+    const uint32_t m = ll + ((lr - ll) >> 1);
+    const uint32_t im = a.index[m];
+    probes++;
+    const uint32_t sufLen = a.tlen - im;
+    if (sufLen == offset) {
+      ll = m + 1;
+      continue;
+    }
+    int comp = -1;
+    if (sufLen > offset) comp = (int)three[a.genome[(uint64_t)im + offset]] - tq;
+    if (comp < 0)
+      ll = m + 1;
+    else
+      lr = m;
+  }
+  return ll;
+}
+
+// SearchRightBound (SuffixArray.h:777-816), with its early stop at a suffix that ends exactly at `offset`
+__device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq,
+                                                uint32_t l, uint32_t r, unsigned &probes) {
+  uint32_t rl = l, rr = r;
+  while (rl < rr) {
+    const uint32_t m = rl + ((rr - rl) >> 1);
+    const uint32_t im = a.index[m];
+    probes++;
+    const uint32_t sufLen = a.tlen - im;
+    if (sufLen == offset) {
+      rr = m;
+      break;
+    }
+    if (sufLen < offset) {
+      rr = m;
+    } else {
+      const int comp = (int)three[a.genome[(uint64_t)im + offset]] - tq;
+      if (comp <= 0)
+        rl = m + 1;
+      else
+        rr = m;
+    }
+  }
+  return rr;
+}
+
+// kHist: how many of the latest (low, high) pairs stay in registers = max(expand, 1) + 1
+template <int kHist>
+__global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
+  __shared__ uint8_t three[256];
+  three[threadIdx.x] = kThreeBit.v[threadIdx.x];
+  __syncthreads();
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.nPos) return;
+  const int si = segment_of(a.posOff, a.nSeg, g);
+  const AnchorSeg s = a.seg[si];
+  const uint32_t p = s.start + (uint32_t)(g - a.posOff[si]);
+  const uint32_t queryLength = s.matchEnd - p;  // MapBySuffixArray.h:66
+
+  uint32_t hl[kHist], hr[kHist];  // [0] = the latest pair
+#pragma unroll
+  for (int i = 0; i < kHist; i++) hl[i] = hr[i] = 0;
+  uint32_t n = 0;  // pairs stored (lowMatchBound.size())
+  uint32_t l = 0, r = a.tlen, lcp = 0;
+  unsigned probes = 0;
+  bool searching = true;
+  if (a.useLookup) {  // SuffixArray.h:954-990; DNATuple::FromStringLR (tuples/DNATuple.h:24-52)
+    uint64_t tuple = 0;
+    bool ok = true;
+    for (int i = 0; i < a.prefixLen; i++) {
+      const int c = three[strand_base(a.pool, s, p + (uint32_t)i)];
+      ok = ok && c < 4;
+      tuple = (tuple << 2) + (uint64_t)(c & 3);
+    }
+    if (ok) {
+      l = a.startPos[tuple];
+      r = a.endPos[tuple];
+      lcp = (uint32_t)a.prefixLen;
+    }
+    if (ok && l < r) {
+      hl[0] = l;
+      hr[0] = r;
+      n = 1;
+    } else {
+      lcp = 0;
+      searching = false;
+    }
+  }
+  while (searching && l < r && lcp < queryLength) {  // SuffixArray.h:996-1067
+    if (a.stopUnique && l == r - 1) break;
+    if (a.maxLcp && lcp >= (uint32_t)a.maxLcp) break;
+    {
+      const uint64_t at = (uint64_t)a.index[l] + lcp;
+      probes++;
+      if (at >= a.tlen || three[a.genome[at]] >= 4) break;  // a genome as Blasr holds it ends in 'N': at < tlen
+    }
+    const int tq = three[strand_base(a.pool, s, p + lcp)];
+    l = left_bound(a, three, lcp, tq, l, r, probes);
+    r = right_bound(a, three, lcp, tq, l, r, probes);
+    if (l == r) break;
+    const uint64_t at = (uint64_t)a.index[l] + lcp;
+    probes++;
+    if (at >= a.tlen || tq >= 4 || (int)three[a.genome[at]] != tq) break;
+#pragma unroll
+    for (int i = kHist - 1; i > 0; i--) {
+      hl[i] = hl[i - 1];
+      hr[i] = hr[i - 1];
+    }
+    hl[0] = l;
+    hr[0] = r;
+    n++;
+    lcp++;
+  }
+
+  // LocateAnchorBoundsInSuffixArray's heuristics (MapBySuffixArray.h:93-204).  (Its loop at :104-109 never runs: a
+  // pair is only stored with low < high.)
+  uint32_t ml = 0, mh = 0, mlen = 0;
+  if (n > 0) {
+    ml = hl[0];
+    mh = hr[0];
+    mlen = a.minPrefix + n - 1;
+    if (ml + 1 == mh) {  // unique: follow the genome as far as it agrees with the read
+      uint32_t ext = mlen;
+      int64_t refPos = (int64_t)a.index[ml] + ext - 1;
+      int64_t queryPos = (int64_t)p + ext - 1;
+      bool extended = false;
+      while (refPos + 1 < (int64_t)a.tlen && queryPos + 1 < (int64_t)s.len) {
+        const uint8_t gc = a.genome[refPos + 1];
+        if (gc == 'N' || gc != strand_base(a.pool, s, (uint32_t)(queryPos + 1))) break;
+        if (!(a.maxLcp == 0 || ext < (uint32_t)a.maxLcp)) break;
+        refPos++;
+        queryPos++;
+        ext++;
+        extended = true;
+      }
+      lcp = ext;
+      if (extended) {
+        mlen = ext;
+      } else if (n > 1) {  // a unique match that ends in an error: one base back
+        ml = hl[1];
+        mh = hr[1];
+        mlen = a.minPrefix + n - 2;
+      }
+    } else {  // repeated: `expand` bases back, at most to the first pair
+      const uint32_t back = n > (uint32_t)a.expand ? (uint32_t)a.expand : n - 1;
+#pragma unroll
+      for (int i = 1; i < kHist; i++)
+        if (back == (uint32_t)i) {
+          ml = hl[i];
+          mh = hr[i];
+        }
+      mlen = a.minPrefix + (n - back) - 1;
+    }
+  }
+  // MapReadToGenome's emission test (:284-300); the trimming of a match that runs past the read is applied in place
+  // there, so later anchors of the position see the trimmed length
+  uint32_t count = 0;
+  if (mh - ml <= (uint32_t)a.maxAnchors && mlen >= a.minMatch) {
+    count = mh - ml;
+    if (count > 0 && mlen + p > s.len) {
+      mlen = s.len - p;
+      if (mlen < a.minMatch) count = 1;
+    }
+  }
+  a.lo[g] = ml;
+  a.cnt[g] = count;
+  a.len[g] = mlen;
+  if (a.lcp) a.lcp[g] = lcp;
+  if (a.probes) atomicAdd(a.probes, (unsigned long long)probes);
+}
+
+// advanceExactMatches (MapBySuffixArray.h:206-212): the loop over p skips max(1, lcpLength - advance) further
+// positions after each one it looks at; the skipped ones report no match.
+__global__ __launch_bounds__(64) void anchor_advance_kernel(AnchorArgs a) {
+  const int si = blockIdx.x * 64 + threadIdx.x;
+  if (si >= a.nSeg) return;
+  const int64_t begin = a.posOff[si], end = a.posOff[si + 1];
+  int64_t g = begin;
+  while (g < end) {
+    const int step = (int)(a.lcp[g] - (uint32_t)a.advance);
+    const int64_t next = g + (step > 1 ? step : 1) + 1;
+    for (int64_t k = g + 1; k < next && k < end; k++) a.cnt[k] = 0;
+    g = next;
+  }
+}
+
+// first anchor of every segment of the piece (exclusive scan value at the segment's first position)
+__global__ __launch_bounds__(256) void anchor_seg_offsets_kernel(int nSeg, const int64_t *posOff,
+                                                                 const int64_t *anchorOff, int64_t *segAnchor,
+                                                                 uint32_t *segAnchor32) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s > nSeg) return;
+  const int64_t v = anchorOff[posOff[s]];
+  segAnchor[s] = v;
+  segAnchor32[s] = (uint32_t)v;
+}
+
+// One wavefront per 64 consecutive positions, one lane per anchor.  sorted: (t << 32 | q) keys and length values for
+// the sort; else the records themselves.
+__global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const int64_t *anchorOff, uint64_t *keys,
+                                                          uint32_t *vals, blasr_hip_anchor *out, int *error) {
+  __shared__ uint32_t sIncl[4][64], sLo[4][64], sLen[4][64], sQ[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g0 = ((int64_t)blockIdx.x * 4 + w) * 64;
+  if (g0 >= a.nPos) return;
+  const int64_t g = g0 + lane;
+  const uint32_t c = g < a.nPos ? a.cnt[g] : 0;
+  const uint32_t incl = wave_prefix_sum(c);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (total == 0) return;
+  uint32_t q = 0;
+  if (c) {
+    const int si = segment_of(a.posOff, a.nSeg, g);
+    q = a.seg[si].start + (uint32_t)(g - a.posOff[si]);
+  }
+  sIncl[w][lane] = incl;
+  sLo[w][lane] = g < a.nPos ? a.lo[g] : 0;
+  sLen[w][lane] = g < a.nPos ? a.len[g] : 0;
+  sQ[w][lane] = q;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int64_t base = anchorOff[g0];
+  for (uint32_t j = lane; j < total; j += 64) {
+    int lo = 0, hi = 63;  // the first k with sIncl[k] > j
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sIncl[w][mid] > j)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    const uint32_t excl = lo ? sIncl[w][lo - 1] : 0;
+    const uint32_t t = a.index[sLo[w][lo] + (j - excl)];
+    const uint32_t len = sLen[w][lo];
+    // the reference's asserts (MapBySuffixArray.h:301-302)
+    if ((uint64_t)t + len > a.tlen || len == 0 || a.genome[(uint64_t)t + len - 1] == 'N') atomicOr(error, 1);
+    if (keys) {
+      keys[base + j] = ((uint64_t)t << 32) | sQ[w][lo];
+      vals[base + j] = len;
+    } else {
+      blasr_hip_anchor rec;
+      rec.t = t;
+      rec.q = sQ[w][lo];
+      rec.l = len;
+      out[base + j] = rec;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint64_t *keys, const uint32_t *vals,
+                                                          blasr_hip_anchor *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  blasr_hip_anchor rec;
+  rec.t = (uint32_t)(k >> 32);
+  rec.q = (uint32_t)k;
+  rec.l = vals[i];
+  out[i] = rec;
+}
+
+struct Events {
+  hipEvent_t e[8] = {};
+  ~Events() {
+    for (auto &x : e)
+      if (x) (void)hipEventDestroy(x);
+  }
+};
+
+void launch_search(const AnchorArgs &a, hipStream_t st) {
+  const unsigned blocks = (unsigned)((a.nPos + 255) / 256);
+  const int hist = std::max(a.expand, 1) + 1;
+  if (hist <= 2)
+    hipLaunchKernelGGL(anchor_search_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+  else if (hist <= 4)
+    hipLaunchKernelGGL(anchor_search_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(anchor_search_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
+}
+
+constexpr int64_t kPiecePositions = 48ll << 20;  // read positions searched per piece (20 bytes of arrays each)
+constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort call (rocprim counts in 32 bits)
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) {
+  if (!p) return BLASR_HIP_ERR_INVALID;
+  p->min_match_length = 12;
+  p->min_prefix_match_length = 8;
+  p->expand = 0;
+  p->max_anchors_per_position = 1000;
+  p->advance_exact_matches = 0;
+  p->max_lcp_length = 0;
+  p->use_lookup_table = 1;
+  p->stop_mapping_once_unique = 1;
+  p->forward_only = 0;
+  p->sorted = 1;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int64_t length,
+                                  const uint32_t *start_pos_table, const uint32_t *end_pos_table,
+                                  int64_t lookup_table_length, int32_t lookup_prefix_length) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!index || length <= 0 || length >= (1ll << 32) || lookup_table_length < 0 || lookup_prefix_length < 0 ||
+      lookup_prefix_length > 16 ||
+      (lookup_table_length > 0 &&
+       (!start_pos_table || !end_pos_table || lookup_table_length != (1ll << (2 * lookup_prefix_length)))))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "upload_suffix_array: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->saIndex) (void)hipFree(ctx->saIndex);
+  if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
+  if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
+  ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
+  ctx->saLen = ctx->saTableLen = 0;
+  ctx->saPrefixLen = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->saIndex, sizeof(uint32_t) * (size_t)length));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->saIndex, index, sizeof(uint32_t) * (size_t)length, hipMemcpyHostToDevice,
+                              ctx->stream));
+  if (lookup_table_length > 0) {
+    HIP_TRY(ctx, hipMalloc(&ctx->saStartPos, sizeof(uint32_t) * (size_t)lookup_table_length));
+    HIP_TRY(ctx, hipMalloc(&ctx->saEndPos, sizeof(uint32_t) * (size_t)lookup_table_length));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->saStartPos, start_pos_table, sizeof(uint32_t) * (size_t)lookup_table_length,
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->saEndPos, end_pos_table, sizeof(uint32_t) * (size_t)lookup_table_length,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->saLen = length;
+  ctx->saTableLen = lookup_table_length;
+  ctx->saPrefixLen = lookup_prefix_length;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_anchor_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[4]) {
+  if (!ctx || !ms || !counters) return BLASR_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; i++) {
+    ms[i] = ctx->anchorMs[i];
+    counters[i] = ctx->anchorCounters[i];
+  }
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                                  const uint8_t *read_pool, const blasr_hip_anchor_params *params,
+                                  blasr_hip_anchor *anchors, int64_t capacity, int64_t *n_anchors,
+                                  int64_t *list_off) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (n_reads < 0 || !params || !n_anchors || !list_off || capacity < 0 || (capacity > 0 && !anchors) ||
+      (n_reads > 0 && (!reads || !read_pool)))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: bad arguments");
+  if (!ctx->genome || !ctx->saIndex)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: no genome / suffix array uploaded");
+  if (ctx->saLen != ctx->genomeLen)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: the suffix array lists %lld suffixes, the genome has %lld bases",
+                          (long long)ctx->saLen, (long long)ctx->genomeLen);
+  const blasr_hip_anchor_params &P = *params;
+  const bool useLookup = P.use_lookup_table != 0 && ctx->saTableLen > 0;
+  const uint32_t trim = std::max(P.min_match_length + 1, (uint32_t)ctx->saPrefixLen + 1);  // MapBySuffixArray.h:270
+  if (P.expand < 0 || P.expand > 7 || P.max_anchors_per_position < 0 || P.advance_exact_matches < 0 ||
+      P.max_lcp_length < 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: expand outside 0..7, or a negative parameter");
+  // positions past the searched ones would be read by the emission loop (the reference's assert at :283)
+  if (P.min_prefix_match_length > trim + 1)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: min_prefix_match_length %u beyond the mapped part of a read",
+                          P.min_prefix_match_length);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < 4; i++) {
+    ctx->anchorMs[i] = 0;
+    ctx->anchorCounters[i] = 0;
+  }
+  const int strands = P.forward_only ? 1 : 2;
+  const int64_t nLists = 2 * (int64_t)n_reads;
+  for (int64_t i = 0; i <= nLists; i++) list_off[i] = 0;
+  *n_anchors = 0;
+  if (n_reads == 0) return BLASR_HIP_OK;
+
+  // every list's searched positions: [subreadStart, min(matchEnd, endOfMapping)) -- the emission loop (:276) never
+  // looks at a later one, and a later one never changes an earlier one
+  std::vector<AnchorSeg> segs((size_t)nLists);
+  std::vector<int64_t> segPos((size_t)nLists, 0);
+  for (int32_t r = 0; r < n_reads; r++) {
+    const blasr_hip_read &rd = reads[r];
+    if (rd.subread_start > rd.subread_end || rd.subread_end > rd.length || rd.off < 0)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: read %d has a bad subread", r);
+    for (int sd = 0; sd < 2; sd++) {
+      AnchorSeg s;
+      s.off = rd.off;
+      s.len = rd.length;
+      s.strand = (uint32_t)sd;
+      const uint32_t s0 = sd ? rd.length - rd.subread_end : rd.subread_start;
+      const uint32_t s1 = sd ? rd.length - rd.subread_start : rd.subread_end;
+      s.start = s0;
+      s.matchEnd = s1 + 1 - P.min_prefix_match_length;
+      int64_t np = 0;
+      const uint32_t span = s1 - s0;
+      if (sd < strands && span >= P.min_match_length &&
+          !(P.min_prefix_match_length > 0 && span < P.min_prefix_match_length)) {
+        const int64_t endOfMapping = s1 < trim ? 0 : (int64_t)s1 - trim;
+        const int64_t matchEnd = (int64_t)s1 - P.min_prefix_match_length + 1;
+        np = std::max<int64_t>(0, std::min(matchEnd, endOfMapping) - (int64_t)s0);
+      }
+      segs[(size_t)(2 * r + sd)] = s;
+      segPos[(size_t)(2 * r + sd)] = np;
+    }
+  }
+
+  Events ev;
+  for (auto &e : ev.e) HIP_TRY(ctx, hipEventCreate(&e));
+  const bool countProbes = getenv("BLASR_HIP_ANCHOR_COUNT_PROBES") != nullptr;
+  const bool sorted = P.sorted != 0;
+  bool overflow = false;
+  int64_t emitted = 0;  // anchors of the pieces so far
+  int64_t first = 0;    // first list of the piece
+  int64_t pieceLimit = kPiecePositions;
+  if (const char *e = getenv("BLASR_HIP_ANCHOR_PIECE")) pieceLimit = std::max<int64_t>(1, atoll(e));
+  std::vector<int64_t> posOff, segAnchor;
+  while (first < nLists) {
+    int64_t last = first, nPos = 0;
+    while (last < nLists && (last == first || nPos + segPos[(size_t)last] <= pieceLimit)) nPos += segPos[(size_t)last++];
+    const int nSeg = (int)(last - first);
+    posOff.assign((size_t)nSeg + 1, 0);
+    for (int i = 0; i < nSeg; i++) posOff[(size_t)i + 1] = posOff[(size_t)i] + segPos[(size_t)(first + i)];
+    if (nPos == 0) {
+      for (int64_t i = first; i < last; i++) list_off[i] = emitted;
+      first = last;
+      continue;
+    }
+    // workspace: segments, position offsets, per-position arrays, scan output, scan scratch, counters
+    size_t scanBytes = 0;
+    {
+      uint32_t *nullU32 = nullptr;
+      int64_t *nullI64 = nullptr;
+      HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, scanBytes, nullU32, nullI64, (int64_t)0, (size_t)nPos + 1,
+                                           rocprim::plus<int64_t>(), st));
+    }
+    const size_t need = sizeof(AnchorSeg) * (size_t)nSeg + (sizeof(int64_t) * 2 + 4) * ((size_t)nSeg + 1) +
+                        (size_t)(nPos + 1) * (4 * 4 + 8) + scanBytes + 4096;
+    if (ctx->workspaceBytes < need) {
+      const int rc = blasr_hip_grow_workspace(ctx, need);
+      if (rc != BLASR_HIP_OK) return rc;
+    }
+    char *w = ctx->workspace;
+    auto take = [&](size_t bytes) {
+      char *p = w;
+      w += (bytes + 255) & ~(size_t)255;
+      return p;
+    };
+    // (the 256-byte rounding of each of the ten arrays is inside the 4096 spare bytes)
+    AnchorSeg *dSeg = (AnchorSeg *)take(sizeof(AnchorSeg) * (size_t)nSeg);
+    int64_t *dPosOff = (int64_t *)take(sizeof(int64_t) * ((size_t)nSeg + 1));
+    int64_t *dSegAnchor = (int64_t *)take(sizeof(int64_t) * ((size_t)nSeg + 1));
+    uint32_t *dSegAnchor32 = (uint32_t *)take(4 * ((size_t)nSeg + 1));
+    uint32_t *dLo = (uint32_t *)take(4 * (size_t)(nPos + 1));
+    uint32_t *dCnt = (uint32_t *)take(4 * (size_t)(nPos + 1));
+    uint32_t *dLen = (uint32_t *)take(4 * (size_t)(nPos + 1));
+    uint32_t *dLcp = (uint32_t *)take(4 * (size_t)(nPos + 1));
+    int64_t *dAnchorOff = (int64_t *)take(8 * (size_t)(nPos + 1));
+    void *scanTmp = take(scanBytes);
+    unsigned long long *dProbes = (unsigned long long *)take(16);
+    int *dError = (int *)(dProbes + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(dSeg, segs.data() + first, sizeof(AnchorSeg) * (size_t)nSeg, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dPosOff, posOff.data(), sizeof(int64_t) * ((size_t)nSeg + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(dProbes, 0, 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(dCnt + nPos, 0, 4, st));  // the scan's extra element
+
+    AnchorArgs a;
+    a.genome = ctx->genome;
+    a.tlen = (uint32_t)ctx->genomeLen;
+    a.index = ctx->saIndex;
+    a.startPos = ctx->saStartPos;
+    a.endPos = ctx->saEndPos;
+    a.prefixLen = ctx->saPrefixLen;
+    a.pool = read_pool;
+    a.seg = dSeg;
+    a.posOff = dPosOff;
+    a.nSeg = nSeg;
+    a.nPos = nPos;
+    a.minMatch = P.min_match_length;
+    a.minPrefix = P.min_prefix_match_length;
+    a.expand = P.expand;
+    a.maxAnchors = P.max_anchors_per_position;
+    a.advance = P.advance_exact_matches;
+    a.maxLcp = P.max_lcp_length;
+    a.useLookup = useLookup ? 1 : 0;
+    a.stopUnique = P.stop_mapping_once_unique != 0;
+    a.lo = dLo;
+    a.cnt = dCnt;
+    a.len = dLen;
+    a.lcp = P.advance_exact_matches ? dLcp : nullptr;
+    a.probes = countProbes ? dProbes : nullptr;
+
+    HIP_TRY(ctx, hipEventRecord(ev.e[0], st));
+    launch_search(a, st);
+    if (P.advance_exact_matches)
+      hipLaunchKernelGGL(anchor_advance_kernel, dim3((unsigned)((nSeg + 63) / 64)), dim3(64), 0, st, a);
+    HIP_TRY(ctx, hipEventRecord(ev.e[1], st));
+    HIP_TRY(ctx, rocprim::exclusive_scan(scanTmp, scanBytes, dCnt, dAnchorOff, (int64_t)0, (size_t)nPos + 1,
+                                         rocprim::plus<int64_t>(), st));
+    hipLaunchKernelGGL(anchor_seg_offsets_kernel, dim3((unsigned)((nSeg + 256) / 256)), dim3(256), 0, st, nSeg, dPosOff,
+                       dAnchorOff, dSegAnchor, dSegAnchor32);
+    segAnchor.assign((size_t)nSeg + 1, 0);
+    HIP_TRY(ctx, hipMemcpyAsync(segAnchor.data(), dSegAnchor, sizeof(int64_t) * ((size_t)nSeg + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int64_t pieceAnchors = segAnchor[(size_t)nSeg];
+    for (int i = 0; i < nSeg; i++) list_off[first + i] = emitted + segAnchor[(size_t)i];
+    ctx->anchorCounters[0] += nPos;
+    ctx->anchorCounters[2] += 1;
+    if (emitted + pieceAnchors > capacity) overflow = true;
+    if (!overflow && pieceAnchors > 0) {
+      blasr_hip_anchor *out = anchors + emitted;
+      uint64_t *keys = nullptr, *keysAlt = nullptr;
+      uint32_t *vals = nullptr, *valsAlt = nullptr;
+      if (sorted) {
+        if (pieceAnchors > kSortLimit)
+          return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: %lld anchors in one piece of %d lists; lower BLASR_HIP_ANCHOR_PIECE",
+                                (long long)pieceAnchors, nSeg);
+        for (int b = 0; b < 4; b++) {
+          const int rc = blasr_hip_ensure(ctx, ctx->anchorBuf[b], (size_t)pieceAnchors * (b < 2 ? 8 : 4));
+          if (rc != BLASR_HIP_OK) return rc;
+        }
+        keys = (uint64_t *)ctx->anchorBuf[0].p;
+        keysAlt = (uint64_t *)ctx->anchorBuf[1].p;
+        vals = (uint32_t *)ctx->anchorBuf[2].p;
+        valsAlt = (uint32_t *)ctx->anchorBuf[3].p;
+      }
+      hipLaunchKernelGGL(anchor_emit_kernel, dim3((unsigned)((nPos + 255) / 256)), dim3(256), 0, st, a, dAnchorOff, keys,
+                         vals, out, dError);
+      HIP_TRY(ctx, hipEventRecord(ev.e[2], st));
+      if (sorted) {
+        rocprim::double_buffer<uint64_t> kb(keys, keysAlt);
+        rocprim::double_buffer<uint32_t> vb(vals, valsAlt);
+        size_t sortBytes = 0;
+        HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
+                                                         dSegAnchor32, dSegAnchor32 + 1, 0, 64, st));
+        // the position arrays are dead once the anchors are out: the sort's scratch goes over them
+        void *sortTmp = dLo;
+        if ((size_t)((char *)ctx->workspace + ctx->workspaceBytes - (char *)dLo) < sortBytes)
+          return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: sort scratch of %zu bytes", sortBytes);
+        HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(sortTmp, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
+                                                         dSegAnchor32, dSegAnchor32 + 1, 0, 64, st));
+        hipLaunchKernelGGL(anchor_pack_kernel, dim3((unsigned)((pieceAnchors + 255) / 256)), dim3(256), 0, st, pieceAnchors,
+                           kb.current(), vb.current(), out);
+      }
+      HIP_TRY(ctx, hipEventRecord(ev.e[3], st));
+      int hostError = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&hostError, dError, sizeof(int), hipMemcpyDeviceToHost, st));
+      unsigned long long hostProbes = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(&hostProbes, dProbes, sizeof(hostProbes), hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      if (hostError)
+        return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: an anchor runs past the genome or ends on an N (the reference asserts, MapBySuffixArray.h:301-302)");
+      ctx->anchorCounters[3] += (int64_t)hostProbes;
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+      ctx->anchorMs[0] += ms;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[1], ev.e[2]));
+      ctx->anchorMs[1] += ms;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
+      ctx->anchorMs[2] += ms;
+    } else {
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+      ctx->anchorMs[0] += ms;
+      if (countProbes) {
+        unsigned long long hostProbes = 0;
+        HIP_TRY(ctx, hipMemcpy(&hostProbes, dProbes, sizeof(hostProbes), hipMemcpyDeviceToHost));
+        ctx->anchorCounters[3] += (int64_t)hostProbes;
+      }
+    }
+    emitted += pieceAnchors;
+    first = last;
+  }
+  list_off[nLists] = emitted;
+  *n_anchors = emitted;
+  ctx->anchorCounters[1] = emitted;
+  ctx->anchorMs[3] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  if (overflow)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "anchor_reads: %lld anchors, capacity %lld", (long long)emitted,
+                          (long long)capacity);
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_anchor_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                                const uint8_t *read_pool, int64_t read_pool_bytes,
+                                const blasr_hip_anchor_params *params, blasr_hip_anchor *anchors, int64_t capacity,
+                                int64_t *n_anchors, int64_t *list_off) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (read_pool_bytes < 0 || (read_pool_bytes > 0 && !read_pool) || capacity < 0 || (capacity > 0 && !anchors))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads_host: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t *dPool = nullptr;
+  blasr_hip_anchor *dAnchors = nullptr;
+  struct Free {
+    void *&p;
+    ~Free() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  void *p0 = nullptr, *p1 = nullptr;
+  Free f0{p0}, f1{p1};
+  HIP_TRY(ctx, hipMalloc(&p0, (size_t)std::max<int64_t>(read_pool_bytes, 1)));
+  HIP_TRY(ctx, hipMalloc(&p1, sizeof(blasr_hip_anchor) * (size_t)std::max<int64_t>(capacity, 1)));
+  dPool = (uint8_t *)p0;
+  dAnchors = (blasr_hip_anchor *)p1;
+  if (read_pool_bytes > 0) HIP_TRY(ctx, hipMemcpy(dPool, read_pool, (size_t)read_pool_bytes, hipMemcpyHostToDevice));
+  for (int32_t r = 0; r < n_reads && reads; r++)
+    if (reads[r].off < 0 || reads[r].off + (int64_t)reads[r].length > read_pool_bytes)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads_host: read %d outside the pool", r);
+  const int rc = blasr_hip_anchor_reads_device(ctx, n_reads, reads, dPool, params, dAnchors, capacity, n_anchors, list_off);
+  if (rc != BLASR_HIP_OK) return rc;
+  if (*n_anchors > 0)
+    HIP_TRY(ctx, hipMemcpy(anchors, dAnchors, sizeof(blasr_hip_anchor) * (size_t)*n_anchors, hipMemcpyDeviceToHost));
+  return BLASR_HIP_OK;
+}
+
+}  // extern "C"

@@ -173,6 +173,11 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
   for (auto &b : ctx->mapBuf)
     if (b.p) (void)hipFree(b.p);
+  for (auto &b : ctx->anchorBuf)
+    if (b.p) (void)hipFree(b.p);
+  if (ctx->saIndex) (void)hipFree(ctx->saIndex);
+  if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
+  if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   delete ctx;
   return BLASR_HIP_OK;
 }
@@ -190,6 +195,8 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
   int64_t total = (int64_t)ctx->workspaceBytes;
   for (const auto &b : ctx->mapBuf) total += (int64_t)b.bytes;
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
+  for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
+  total += 4 * ctx->saLen + 8 * ctx->saTableLen;
   return total;
 }
 

@@ -44,6 +44,14 @@ struct blasr_hip_ctx {
   DevBuf mapBuf[kMapBufs];
   float mapMs[6] = {0, 0, 0, 0, 0, 0};
   int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
+  // the resident suffix array of the genome (blasr_hip_upload_suffix_array): index, the lookup table's ranges
+  uint32_t *saIndex = nullptr, *saStartPos = nullptr, *saEndPos = nullptr;
+  int64_t saLen = 0, saTableLen = 0;
+  int saPrefixLen = 0;
+  enum { kAnchorBufs = 4 };
+  DevBuf anchorBuf[kAnchorBufs];  // sort keys / values of the anchor stage (double-buffered)
+  float anchorMs[4] = {0, 0, 0, 0};
+  int64_t anchorCounters[4] = {0, 0, 0, 0};
 };
 
 // what the workspace may grow to: the caller's limit, and the context's own allocation plus the free device memory

@@ -38,6 +38,8 @@ EXPORTS = [
     "blasr_hip_fasta_read", "blasr_hip_fasta_parse", "blasr_hip_fasta_free", "blasr_hip_fasta_count",
     "blasr_hip_fasta_record", "blasr_hip_fasta_name", "blasr_hip_fasta_concatenate",
     "blasr_hip_sa_read", "blasr_hip_sa_free", "blasr_hip_sa_arrays",
+    "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
+    "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -163,6 +165,17 @@ class _MapParams(C.Structure):
                 ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32)]
 
 
+class _AnchorParams(C.Structure):
+    _fields_ = [("min_match_length", C.c_uint32), ("min_prefix_match_length", C.c_uint32), ("expand", C.c_int32),
+                ("max_anchors_per_position", C.c_int32), ("advance_exact_matches", C.c_int32),
+                ("max_lcp_length", C.c_int32), ("use_lookup_table", C.c_int32), ("stop_mapping_once_unique", C.c_int32),
+                ("forward_only", C.c_int32), ("sorted", C.c_int32)]
+
+
+# blasr_hip_anchor: MatchPos t, q, l
+ANCHOR_DTYPE = np.dtype([("t", "<u4"), ("q", "<u4"), ("l", "<u4")])
+
+
 class _MapFetch(C.Structure):
     _fields_ = [("seq", C.c_void_p), ("seq_capacity", C.c_int64), ("seq_used", C.c_int64), ("ops", C.c_void_p),
                 ("ops_capacity", C.c_int64), ("ops_used", C.c_int64)]
@@ -275,6 +288,16 @@ def load_library():
         lib.blasr_hip_map_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         lib.blasr_hip_map_device_arenas.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         lib.blasr_hip_adopt_genome_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        lib.blasr_hip_anchor_default_params.argtypes = [C.POINTER(_AnchorParams)]
+        lib.blasr_hip_upload_suffix_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                      C.c_int64, C.c_int32]
+        lib.blasr_hip_anchor_reads_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                      C.POINTER(_AnchorParams), C.c_void_p, C.c_int64,
+                                                      C.POINTER(C.c_int64), C.c_void_p]
+        lib.blasr_hip_anchor_reads_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                                    C.POINTER(_AnchorParams), C.c_void_p, C.c_int64,
+                                                    C.POINTER(C.c_int64), C.c_void_p]
+        lib.blasr_hip_anchor_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -822,6 +845,68 @@ class Context:
                                                        C.byref(used))
         self._check(rc)
         return used.value
+
+    # --- next-1, device half: MapReadToGenome over the suffix array (MapBySuffixArray.h:217-311) ---
+    def upload_suffix_array(self, sa):
+        """sa: what read_suffix_array returns (index, start_pos_table, end_pos_table, lookup_prefix_length)."""
+        idx = np.ascontiguousarray(sa["index"], dtype=np.uint32)
+        sp = np.ascontiguousarray(sa["start_pos_table"], dtype=np.uint32)
+        ep = np.ascontiguousarray(sa["end_pos_table"], dtype=np.uint32)
+        self._check(self.lib.blasr_hip_upload_suffix_array(self.handle, idx.ctypes.data, C.c_int64(len(idx)),
+                                                           sp.ctypes.data if len(sp) else None,
+                                                           ep.ctypes.data if len(ep) else None, C.c_int64(len(sp)),
+                                                           int(sa["lookup_prefix_length"])))
+
+    def anchor_params(self, **kw):
+        """blasr_hip_anchor_params with the reference's defaults; keyword overrides by field name."""
+        p = _AnchorParams()
+        self.lib.blasr_hip_anchor_default_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, int(v))
+        return p
+
+    def anchor_reads(self, reads, read_pool, params=None, capacity=None):
+        """blasr_hip_anchor_reads_host: (anchors ANCHOR_DTYPE array, list_off); list 2r = read r forward, 2r+1 = its
+        reverse complement.  The capacity grows once when the first guess was short."""
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        read_pool = np.ascontiguousarray(read_pool, dtype=np.uint8)
+        params = params or self.anchor_params()
+        n = len(reads)
+        cap = int(capacity) if capacity is not None else 4 * int(reads["length"].astype(np.int64).sum()) + 1024
+        off = np.zeros(2 * n + 1, dtype=np.int64)
+        need = C.c_int64(0)
+        for _ in range(2):
+            out = np.zeros(max(cap, 1), dtype=ANCHOR_DTYPE)
+            rc = self.lib.blasr_hip_anchor_reads_host(self.handle, n, reads.ctypes.data, read_pool.ctypes.data,
+                                                      C.c_int64(len(read_pool)), C.byref(params), out.ctypes.data,
+                                                      C.c_int64(cap), C.byref(need), off.ctypes.data)
+            if rc == ERR_CAPACITY and capacity is None and need.value > cap:
+                cap = need.value
+                continue
+            break
+        self._check(rc)
+        return out[: need.value], off
+
+    def anchor_reads_device(self, reads, read_pool_ptr, params, anchors_ptr, capacity):
+        """Device-resident read pool and anchor array (raw addresses); reads: host READ_DTYPE array.  Returns
+        (number of anchors, list_off)."""
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        off = np.zeros(2 * len(reads) + 1, dtype=np.int64)
+        need = C.c_int64(0)
+        self._check(self.lib.blasr_hip_anchor_reads_device(self.handle, len(reads), reads.ctypes.data,
+                                                           C.c_void_p(read_pool_ptr), C.byref(params),
+                                                           C.c_void_p(anchors_ptr), C.c_int64(capacity), C.byref(need),
+                                                           off.ctypes.data))
+        return need.value, off
+
+    def anchor_last_timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int64 * 4)()
+        self._check(self.lib.blasr_hip_anchor_last_timing(self.handle, ms, cnt))
+        return dict(search_ms=ms[0], emit_ms=ms[1], sort_ms=ms[2], wall_ms=ms[3], positions=cnt[0], anchors=cnt[1],
+                    pieces=cnt[2], probes=cnt[3])
 
     # --- a-11: AffineKBandAlign (the -noUseGuidedAlign refiner, Blasr.cpp:675-746) ---
     def _kband_call(self, fn, pairs, ks, params, ops_capacity):

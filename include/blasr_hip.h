@@ -607,6 +607,64 @@ int blasr_hip_sa_free(blasr_hip_sa *sa);
 int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t *length, const uint32_t **start_pos_table,
                         const uint32_t **end_pos_table, int64_t *lookup_table_length, int32_t *lookup_prefix_length);
 
+/* ------------------------------------------------------------------------------------------------
+ * next-1, device half: anchoring a read in the suffix array of the genome.
+ * Replaces MapReadToGenome (common/algorithms/anchoring/MapBySuffixArray.h:217-311), with
+ * LocateAnchorBoundsInSuffixArray (:24-215) and SuffixArray::StoreLCPBounds / SearchLeftBound /
+ * SearchRightBound (common/datastructures/suffixarray/SuffixArray.h:928-1070, :733-816) underneath, as
+ * MapRead calls it for both strands of a read (alignment/Blasr.cpp:2279-2297), and SortMatchPosList
+ * (:2339-2340; datastructures/anchoring/MatchPos.h:120-131,166-168) on the two lists.  One lane per read
+ * position walks the suffix array; the genome, the index and the lookup table stay resident on the device.
+ * FindMaxIncreasingInterval (the host half of next-1) consumes the sorted lists.
+ * ------------------------------------------------------------------------------------------------ */
+/* AnchorParameters (datastructures/anchoring/AnchorParameters.h:9-42) as Blasr.cpp fills it (:398, :2273), and
+ * the arguments of the two calls. */
+typedef struct blasr_hip_anchor_params {
+  uint32_t min_match_length;         /* anchorParameters.minMatchLength = params.minMatchLength (12) */
+  uint32_t min_prefix_match_length;  /* MapReadToGenome's minPrefixMatchLength = params.lookupTableLength (8); match
+                                        lengths are counted from it even when the table's prefix differs */
+  int32_t expand;                    /* anchorParameters.expand, 0..7: the MapRead iteration (:2273) */
+  int32_t max_anchors_per_position;  /* 1000 */
+  int32_t advance_exact_matches;     /* 0 */
+  int32_t max_lcp_length;            /* 0: no limit */
+  int32_t use_lookup_table;          /* 1 */
+  int32_t stop_mapping_once_unique;  /* 1 (MappingParameters.h:309) */
+  int32_t forward_only;              /* params.forwardOnly (0): no reverse-complement list */
+  int32_t sorted;                    /* 1: SortMatchPosList applied (t, then q); 0: the order MapReadToGenome emits */
+} blasr_hip_anchor_params;
+/* removeEncompassedMatches is not offered: the reference indexes its per-position arrays with read.length there
+ * (MapBySuffixArray.h:252-256), past their end. */
+
+/* MatchPos (datastructures/anchoring/MatchPos.h:11-40): t genome position, q read position on the strand of the
+ * list, l match length */
+typedef struct blasr_hip_anchor {
+  uint32_t t, q, l;
+} blasr_hip_anchor;
+
+int blasr_hip_anchor_default_params(blasr_hip_anchor_params *params);
+/* The suffix array of the uploaded genome (host arrays as blasr_hip_sa_arrays returns them; length must equal the
+ * genome's).  Replaces the arrays SuffixArray::Read leaves in memory. */
+int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int64_t length,
+                                  const uint32_t *start_pos_table, const uint32_t *end_pos_table,
+                                  int64_t lookup_table_length, int32_t lookup_prefix_length);
+/* reads: HOST table; read_pool: device (forward strands, ASCII); anchors: device, at most capacity records;
+ * *n_anchors receives the number needed (BLASR_HIP_ERR_CAPACITY when it exceeds capacity; nothing is valid then).
+ * list_off (host, 2 * n_reads + 1 entries): list 2r is read r's matchPosList, list 2r+1 its rcMatchPosList (q on the
+ * reverse-complemented read, as the reference holds it).  BLASR_HIP_ERR_INVALID also where the reference's own
+ * asserts (MapBySuffixArray.h:283, :301-302) would fire. */
+int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                                  const uint8_t *read_pool, const blasr_hip_anchor_params *params,
+                                  blasr_hip_anchor *anchors, int64_t capacity, int64_t *n_anchors, int64_t *list_off);
+/* Same with a host read pool and a host anchor array. */
+int blasr_hip_anchor_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                                const uint8_t *read_pool, int64_t read_pool_bytes,
+                                const blasr_hip_anchor_params *params, blasr_hip_anchor *anchors, int64_t capacity,
+                                int64_t *n_anchors, int64_t *list_off);
+/* Device time (ms) of the last anchor call: [0] suffix-array search, [1] count scan + emission, [2] sort, [3] whole
+ * call (wall); counters: [0] read positions searched, [1] anchors, [2] pieces, [3] probes of the index array made by
+ * the search (when counted: BLASR_HIP_ANCHOR_COUNT_PROBES=1, else 0). */
+int blasr_hip_anchor_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[4]);
+
 #ifdef __cplusplus
 }
 #endif

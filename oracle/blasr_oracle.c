@@ -2489,3 +2489,234 @@ long bo_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out) {
   }
   return n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* next-1, device half: MapReadToGenome over the suffix array                 */
+/* ------------------------------------------------------------------------- */
+/* SearchLeftBound (datastructures/suffixarray/SuffixArray.h:733-775): first suffix in [l, r) whose character
+ * `offset` bases in is >= queryChar; suffixes that end at or before `offset` sort low. */
+static long sa_left_bound(const unsigned char *target, long targetLength, const unsigned *index, unsigned offset,
+                          unsigned char queryChar, long l, long r) {
+  long ll = l, lr = r;
+  while (ll < lr) {
+    const long m = (ll + lr) / 2;
+    const long sufLen = targetLength - (long)index[m];
+    if (sufLen == (long)offset) {
+      ll = m + 1;
+      continue;
+    }
+    int comp;
+    if (sufLen < (long)offset)
+      comp = -1;
+    else
+      comp = g_three[target[index[m] + offset]] - g_three[queryChar]; /* DefaultCompareStrings, CompareStrings.h:8-10 */
+    if (comp < 0)
+      ll = m + 1;
+    else
+      lr = m;
+  }
+  return ll;
+}
+
+/* SearchRightBound (SuffixArray.h:777-816): first suffix in [l, r) whose character is > queryChar; a suffix that ends
+ * exactly at `offset` stops the search where it stands (the reference's early break, kept). */
+static long sa_right_bound(const unsigned char *target, long targetLength, const unsigned *index, unsigned offset,
+                           unsigned char queryChar, long l, long r) {
+  long rl = l, rr = r;
+  while (rl < rr) {
+    const long m = (rl + rr) / 2;
+    const long sufLen = targetLength - (long)index[m];
+    if (sufLen == (long)offset) {
+      rr = m;
+      break;
+    }
+    if (sufLen < (long)offset) {
+      rr = m;
+    } else {
+      const int comp = g_three[target[index[m] + offset]] - g_three[queryChar];
+      if (comp <= 0)
+        rl = m + 1;
+      else
+        rr = m;
+    }
+  }
+  return rr;
+}
+
+/* StoreLCPBounds (SuffixArray.h:928-1070).  lows/highs receive one pair per matched length; returns lcpLength and
+ * stores the number of pairs in *nBounds.  The pairs are kept in a growing array owned by the caller. */
+typedef struct {
+  long *low, *high;
+  long n, cap;
+} sa_bounds;
+static void sa_bounds_push(sa_bounds *b, long l, long r) {
+  if (b->n == b->cap) {
+    b->cap = b->cap ? 2 * b->cap : 64;
+    b->low = (long *)realloc(b->low, sizeof(long) * (size_t)b->cap);
+    b->high = (long *)realloc(b->high, sizeof(long) * (size_t)b->cap);
+  }
+  b->low[b->n] = l;
+  b->high[b->n] = r;
+  b->n++;
+}
+static unsigned sa_store_lcp_bounds(const unsigned char *target, long targetLength, const unsigned *index,
+                                    const unsigned *startPosTable, const unsigned *endPosTable,
+                                    int lookupPrefixLength, const unsigned char *query, unsigned queryLength,
+                                    int useLookupTable, int maxMatchLength, int stopOnceUnique, sa_bounds *b) {
+  long l = 0, r = targetLength;
+  unsigned lcpLength = 0;
+  if (useLookupTable && startPosTable != NULL) {
+    /* DNATuple::FromStringLR (tuples/DNATuple.h:24-52) */
+    unsigned long tuple = 0;
+    for (int i = 0; i < lookupPrefixLength; i++) {
+      if (!g_isactg[query[i]]) return 0;
+      tuple = (tuple << 2) + (unsigned long)g_two[query[i]];
+    }
+    l = startPosTable[tuple];
+    r = endPosTable[tuple];
+    lcpLength = (unsigned)lookupPrefixLength;
+    if (l < r)
+      sa_bounds_push(b, l, r);
+    else
+      return 0;
+  }
+  while (l < r && lcpLength < queryLength) {
+    if (stopOnceUnique && l == r - 1) break;
+    if (maxMatchLength && lcpLength >= (unsigned)maxMatchLength) break;
+    if (g_three[target[index[l] + lcpLength]] >= 4) break;
+    l = sa_left_bound(target, targetLength, index, lcpLength, query[lcpLength], l, r);
+    r = sa_right_bound(target, targetLength, index, lcpLength, query[lcpLength], l, r);
+    if (l == r || (long)index[l] + lcpLength >= targetLength || g_three[query[lcpLength]] >= 4 ||
+        g_three[target[index[l] + lcpLength]] - g_three[query[lcpLength]] != 0)
+      break;
+    sa_bounds_push(b, l, r);
+    lcpLength++;
+  }
+  return lcpLength;
+}
+
+/* LocateAnchorBoundsInSuffixArray (algorithms/anchoring/MapBySuffixArray.h:24-215) followed by MapReadToGenome's
+ * emission loop (:217-311).  ap[7] = minMatchLength, expand, useLookupTable, maxAnchorsPerPosition,
+ * advanceExactMatches, maxLCPLength, stopMappingOnceUnique (AnchorParameters.h:9-42; removeEncompassedMatches reads
+ * past its arrays in the reference and is not restated).  The read is one strand, already reverse-complemented by
+ * the caller for the other.  out: (t, q, l) triples in emission order.  Returns the count; -3 / -4 where the
+ * reference's asserts (:283, :301-302) would fire. */
+long bo_map_read_to_genome(const unsigned char *genome, unsigned genomeLength, const unsigned *saIndex,
+                           const unsigned *startPosTable, const unsigned *endPosTable, int lookupPrefixLength,
+                           const unsigned char *read, unsigned readLength, unsigned subreadStart, unsigned subreadEnd,
+                           unsigned minPrefixMatchLength, const int *ap, unsigned *out, long cap) {
+  init_tables();
+  const unsigned minMatchLength = (unsigned)ap[0];
+  const int expand = ap[1], useLookupTable = ap[2], maxAnchorsPerPosition = ap[3], advanceExactMatches = ap[4],
+            maxLCPLength = ap[5], stopMappingOnceUnique = ap[6];
+  if (subreadEnd - subreadStart < minMatchLength) return 0; /* :227-230 */
+  unsigned *matchLow = NULL, *matchHigh = NULL, *matchLength = NULL;
+  unsigned numSearched = 0;
+  sa_bounds b = {NULL, NULL, 0, 0};
+  if (!(minPrefixMatchLength > 0 && subreadEnd - subreadStart < minPrefixMatchLength)) { /* :39-42 */
+    const unsigned matchEnd = subreadEnd - minPrefixMatchLength + 1;
+    numSearched = matchEnd - subreadStart;
+    matchLow = (unsigned *)calloc(numSearched ? numSearched : 1, sizeof(unsigned));
+    matchHigh = (unsigned *)calloc(numSearched ? numSearched : 1, sizeof(unsigned));
+    matchLength = (unsigned *)calloc(numSearched ? numSearched : 1, sizeof(unsigned));
+    unsigned p, m;
+    for (m = 0, p = subreadStart; p < matchEnd; p++, m++) {
+      b.n = 0;
+      unsigned lcpLength =
+          sa_store_lcp_bounds(genome, (long)genomeLength, saIndex, startPosTable, endPosTable, lookupPrefixLength,
+                              read + p, matchEnd - p, useLookupTable, maxLCPLength, stopMappingOnceUnique, &b);
+      matchLow[m] = matchHigh[m] = matchLength[m] = 0;
+      if (b.n > 0) {
+        long lcpSearchLength = b.n;
+        while (lcpSearchLength > 0 && b.low[lcpSearchLength - 1] == b.high[lcpSearchLength - 1]) { /* :104-109 */
+          lcpSearchLength--;
+          lcpLength--;
+        }
+        matchLow[m] = (unsigned)b.low[lcpSearchLength - 1];
+        matchHigh[m] = (unsigned)b.high[lcpSearchLength - 1];
+        matchLength[m] = minPrefixMatchLength + (unsigned)lcpSearchLength - 1;
+        if (matchLow[m] + 1 == matchHigh[m]) { /* unique: extend along the genome, :134-174 */
+          lcpLength = minPrefixMatchLength + (unsigned)lcpSearchLength - 1;
+          long refPos = (long)saIndex[matchLow[m]] + lcpLength - 1;
+          long queryPos = (long)p + lcpLength - 1;
+          int extended = 0;
+          while (refPos + 1 < (long)genomeLength && queryPos + 1 < (long)readLength && genome[refPos + 1] != 'N' &&
+                 genome[refPos + 1] == read[queryPos + 1] &&
+                 (maxLCPLength == 0 || lcpLength < (unsigned)maxLCPLength)) {
+            refPos++;
+            queryPos++;
+            lcpLength++;
+            extended = 1;
+          }
+          if (extended) {
+            matchLength[m] = lcpLength;
+          } else {
+            if (lcpSearchLength > 1) lcpSearchLength--;
+            matchLow[m] = (unsigned)b.low[lcpSearchLength - 1];
+            matchHigh[m] = (unsigned)b.high[lcpSearchLength - 1];
+            matchLength[m] = minPrefixMatchLength + (unsigned)lcpSearchLength - 1;
+          }
+        } else { /* not unique: back off by expand, :176-193 */
+          if (lcpSearchLength > expand)
+            lcpSearchLength -= expand;
+          else
+            lcpSearchLength = 1;
+          matchLow[m] = (unsigned)b.low[lcpSearchLength - 1];
+          matchHigh[m] = (unsigned)b.high[lcpSearchLength - 1];
+          matchLength[m] = minPrefixMatchLength + (unsigned)lcpSearchLength - 1;
+        }
+      }
+      if (advanceExactMatches) { /* :206-212 */
+        const int adv = (int)(lcpLength - (unsigned)advanceExactMatches);
+        p += (unsigned)(adv > 1 ? adv : 1);
+        m += (unsigned)(adv > 1 ? adv : 1);
+      }
+    }
+  }
+  free(b.low);
+  free(b.high);
+  /* MapReadToGenome's emission, :268-306 */
+  unsigned trim = minMatchLength + 1;
+  if ((unsigned)lookupPrefixLength + 1 > trim) trim = (unsigned)lookupPrefixLength + 1;
+  const unsigned endOfMapping = subreadEnd < trim ? 0 : subreadEnd - trim;
+  long n = 0;
+  for (unsigned pos = subreadStart; pos < endOfMapping; pos++) {
+    const unsigned mi = pos - subreadStart;
+    if (mi >= numSearched) {
+      n = -3;
+      break;
+    }
+    if (matchHigh[mi] - matchLow[mi] <= (unsigned)maxAnchorsPerPosition) {
+      for (unsigned mp = matchLow[mi]; mp < matchHigh[mi]; mp++) {
+        if (matchLength[mi] < minMatchLength) continue;
+        if (matchLength[mi] + pos > readLength) matchLength[mi] = readLength - pos;
+        if ((unsigned long)saIndex[mp] + matchLength[mi] > genomeLength ||
+            genome[saIndex[mp] + matchLength[mi] - 1] == 'N') {
+          n = -4;
+          break;
+        }
+        if (n < cap) {
+          out[3 * n] = saIndex[mp];
+          out[3 * n + 1] = pos;
+          out[3 * n + 2] = matchLength[mi];
+        }
+        n++;
+      }
+      if (n < 0) break;
+    }
+  }
+  free(matchLow);
+  free(matchHigh);
+  free(matchLength);
+  return n;
+}
+
+/* SortMatchPosList (datastructures/anchoring/MatchPos.h:120-131,166-168): ascending t, then q.  (t, q) pairs are
+ * distinct within one list, so the order is total. */
+static int cmp_match_pos(const void *a, const void *b) {
+  const unsigned *x = (const unsigned *)a, *y = (const unsigned *)b;
+  if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+  if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+  return 0;
+}
+void bo_sort_match_pos(unsigned *triples, long n) { qsort(triples, (size_t)n, 3 * sizeof(unsigned), cmp_match_pos); }

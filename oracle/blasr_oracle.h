@@ -145,6 +145,18 @@ int bo_sam_line(const char *qName, const char *tName, const char *readGroupId, c
 /* next-2: Alignment::OrderGapsByType (Alignment.h:255-317) on an op list; returns the new number of ops */
 long bo_order_gaps_by_type(const unsigned *ops, long nOps, unsigned *out);
 
+/* next-1, device half: MapReadToGenome over the suffix array (algorithms/anchoring/MapBySuffixArray.h:24-311,
+ * SuffixArray::StoreLCPBounds datastructures/suffixarray/SuffixArray.h:928-1070, SearchLeftBound / SearchRightBound
+ * :733-816) on one strand (the caller reverse-complements for the other).  ap[7] = minMatchLength, expand,
+ * useLookupTable, maxAnchorsPerPosition, advanceExactMatches, maxLCPLength, stopMappingOnceUnique.  out = (t, q, l)
+ * triples in emission order; returns the count, or -3 / -4 where the reference's asserts would fire. */
+long bo_map_read_to_genome(const unsigned char *genome, unsigned genomeLength, const unsigned *saIndex,
+                           const unsigned *startPosTable, const unsigned *endPosTable, int lookupPrefixLength,
+                           const unsigned char *read, unsigned readLength, unsigned subreadStart, unsigned subreadEnd,
+                           unsigned minPrefixMatchLength, const int *ap, unsigned *out, long cap);
+/* SortMatchPosList (datastructures/anchoring/MatchPos.h:120-131,166-168) on (t, q, l) triples */
+void bo_sort_match_pos(unsigned *triples, long n);
+
 /* design probe: {largest row spread of S, rows, rows with spread >= 512, >= 1024} of the
  * AffineGuidedAlign fills since the last call; enable != 0 keeps counting */
 void bo_probe_row_spread(int enable, long *out4);

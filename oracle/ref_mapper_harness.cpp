@@ -485,4 +485,57 @@ int ref_read_sa(const char *path, unsigned *index, long indexCap, unsigned *star
   return 0;
 }
 
+// next-1 (device half): the reference's MapReadToGenome (algorithms/anchoring/MapBySuffixArray.h:217-311) on one
+// strand of one read, against a suffix array read by SuffixArray::Read.  ref_sa_open keeps the array for later calls.
+void *ref_sa_open(const char *path) {
+  DNASuffixArray *sa = new DNASuffixArray;
+  string name(path);
+  if (!sa->Read(name)) {
+    delete sa;
+    return NULL;
+  }
+  return sa;
+}
+void ref_sa_close(void *h) { delete (DNASuffixArray *)h; }
+
+// ap[7] = minMatchLength, expand, useLookupTable, maxAnchorsPerPosition, advanceExactMatches, maxLCPLength,
+// stopMappingOnceUnique.  strand 1 maps the reverse complement with Blasr.cpp:3449-3450's subread coordinates.
+// out: (t, q, l) triples in emission order; sorted != 0 applies SortMatchPosList.  Returns the count (the first cap
+// triples are stored).
+long ref_map_read_to_genome(void *h, const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
+                            unsigned readLen, unsigned subreadStart, unsigned subreadEnd, int strand,
+                            unsigned minPrefixMatchLength, const int *ap, int sorted, unsigned *out, long cap) {
+  DNASuffixArray &sa = *(DNASuffixArray *)h;
+  T_GenomeSequence genome;
+  genome.seq = (Nucleotide *)genomeSeq;
+  genome.length = genomeLen;
+  genome.deleteOnExit = false;
+  T_Sequence read, readRC;
+  read.seq = (Nucleotide *)readSeq;
+  read.length = readLen;
+  read.deleteOnExit = false;
+  read.subreadStart = subreadStart;
+  read.subreadEnd = subreadEnd;
+  read.MakeRC(readRC);
+  readRC.subreadStart = readLen - subreadEnd;
+  readRC.subreadEnd = readLen - subreadStart;
+  AnchorParameters anchor;
+  anchor.minMatchLength = ap[0];
+  anchor.expand = ap[1];
+  anchor.useLookupTable = ap[2] != 0;
+  anchor.maxAnchorsPerPosition = ap[3];
+  anchor.advanceExactMatches = ap[4];
+  anchor.maxLCPLength = ap[5];
+  anchor.stopMappingOnceUnique = ap[6] != 0;
+  vector<ChainedMatchPos> matches;
+  MapReadToGenome(genome, sa, strand ? readRC : read, minPrefixMatchLength, matches, anchor);
+  if (sorted) SortMatchPosList(matches);
+  for (long i = 0; i < (long)matches.size() && i < cap; i++) {
+    out[3 * i] = matches[i].t;
+    out[3 * i + 1] = matches[i].q;
+    out[3 * i + 2] = matches[i].l;
+  }
+  return (long)matches.size();
+}
+
 }  // extern "C"

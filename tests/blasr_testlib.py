@@ -931,3 +931,102 @@ class DeviceMemory:
         for p in self.held:
             self.rt.hipFree(p)
         self.held = []
+
+
+# ---------------------------------------------------------------------------------------------
+# next-1, device half: anchoring in the suffix array (MapReadToGenome)
+# ---------------------------------------------------------------------------------------------
+SAWRITER = os.path.join(ROOT, "oracle", "_ref", "sawritermc")
+
+# (minMatchLength, expand, useLookupTable, maxAnchorsPerPosition, advanceExactMatches, maxLCPLength,
+#  stopMappingOnceUnique): the defaults of Blasr.cpp, then every switch away from them
+ANCHOR_PARAM_SETS = [
+    (12, 0, 1, 1000, 0, 0, 1), (12, 1, 1, 1000, 0, 0, 1), (14, 2, 1, 1000, 0, 0, 0), (10, 0, 1, 3, 0, 0, 1),
+    (12, 1, 1, 1000, 2, 0, 1), (12, 0, 1, 1000, 0, 20, 0), (8, 3, 1, 50, 0, 15, 1), (12, 0, 0, 1000, 0, 0, 1),
+    (12, 1, 1, 1000, 5, 0, 0), (9, 5, 1, 1000, 0, 0, 0), (13, 7, 1, 8, 30, 0, 1),
+]
+
+
+def anchor_genome_case(rng, n_reads, genome_len=120000, read_len=(300, 1500)):
+    """A two-contig genome with planted repeat families, a run of N and a tandem repeat, and reads drawn from it
+    (half from the repeats), some with N inside and some with a subread shorter than the read.  Returns the FASTA
+    text, reads (READ_DTYPE), pool."""
+    genome, pool, reads, _ = repeat_genome_case(rng, n_reads, genome_len=genome_len, read_len=read_len)
+    g = bytearray(bytes(genome))
+    g[5000:5040] = b"N" * 40
+    g[genome_len // 2:genome_len // 2 + 600] = (b"ACGGTCA" * 100)[:600]
+    cut = (2 * genome_len) // 3
+    fasta = b">a\n" + bytes(g[:cut]) + b"\n>b\n" + bytes(g[cut:]) + b"\n"
+    pool = np.ascontiguousarray(pool).copy()
+    reads = reads.copy()
+    for r in range(len(reads)):
+        off, L = int(reads[r]["off"]), int(reads[r]["length"])
+        if r % 5 == 0:
+            pool[off + L // 3: off + L // 3 + 3] = ord("N")
+        if r % 3 == 0:
+            reads[r]["subread_start"], reads[r]["subread_end"] = L // 10, L - L // 7
+    return fasta, reads, pool
+
+
+def write_suffix_array(tmp_dir, fasta, blt=None):
+    """FASTA text -> (genome, contig starts, suffix array dict, .sa path) through the reference's sawriter."""
+    import subprocess
+    from blasr_amd import hip
+    fa = os.path.join(str(tmp_dir), "g%s.fasta" % (blt or ""))
+    with open(fa, "wb") as f:
+        f.write(fasta)
+    cmd = [SAWRITER, fa + ".sa", fa] + (["-blt", str(blt)] if blt else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+    genome, starts, _ = hip.read_genome(fa)
+    return genome, starts, hip.read_suffix_array(fa + ".sa"), fa + ".sa"
+
+
+def strand_view(read, s0, s1, strand):
+    """The sequence and subread MapRead hands MapReadToGenome for a strand (Blasr.cpp:3449-3450)."""
+    from blasr_amd import synth
+    L = len(read)
+    if strand:
+        return np.ascontiguousarray(synth.revcomp(read)), L - s1, L - s0
+    return np.ascontiguousarray(read), s0, s1
+
+
+def oracle_anchors(oracle, genome, sa, read, s0, s1, strand, min_prefix, ap, sort=False):
+    """bo_map_read_to_genome (+ bo_sort_match_pos) on one strand -> (n, 3) uint32 array of (t, q, l); None where the
+    reference would assert."""
+    oracle = getattr(oracle, "lib", oracle)  # a Checker or the library itself
+    oracle.bo_map_read_to_genome.restype = C.c_long
+    q, a0, a1 = strand_view(read, s0, s1, strand)
+    ap = np.asarray(ap, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    cap = 1 << 16
+    while True:
+        out = np.zeros(3 * cap, np.uint32)
+        n = oracle.bo_map_read_to_genome(vp(genome), len(genome), vp(sa["index"]), vp(sa["start_pos_table"]),
+                                         vp(sa["end_pos_table"]), int(sa["lookup_prefix_length"]), vp(q), len(q), a0, a1,
+                                         int(min_prefix), vp(ap), vp(out), C.c_long(cap))
+        if n <= cap:
+            break
+        cap = n
+    if n < 0:  # the reference's asserts (MapBySuffixArray.h:283, :301-302) would end the process
+        return None
+    out = out[: 3 * n].reshape(n, 3)
+    if sort and n:
+        oracle.bo_sort_match_pos(vp(out), C.c_long(n))
+    return out
+
+
+def ref_anchors(ref, handle, genome, read, s0, s1, strand, min_prefix, ap, sort=False):
+    """The reference's MapReadToGenome (+ SortMatchPosList) through oracle/_ref/libblasr_refmapper.so."""
+    ref.ref_map_read_to_genome.restype = C.c_long
+    ap = np.asarray(ap, dtype=np.int32)
+    read = np.ascontiguousarray(read)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    cap = 1 << 16
+    while True:
+        out = np.zeros(3 * cap, np.uint32)
+        n = ref.ref_map_read_to_genome(C.c_void_p(handle), vp(genome), len(genome), vp(read), len(read), s0, s1, strand,
+                                       int(min_prefix), vp(ap), int(sort), vp(out), C.c_long(cap))
+        if n <= cap:
+            break
+        cap = n
+    return out[: 3 * n].reshape(n, 3)

@@ -53,6 +53,21 @@ def test_hit_record_layout_matches_header():
     assert p.sdp.indel_rate == np.float32(0.3) * np.float32(3)  # params.indelRate * 3 in single precision
 
 
+def test_anchor_records_match_header():
+    text = open(os.path.join(ROOT, "include", "blasr_hip.h")).read()
+    body = text[text.index("typedef struct blasr_hip_anchor_params {"):text.index("} blasr_hip_anchor_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for _, n in re.findall(r"\b(u?int32_t)\s+([a-z_]+);", body)]
+    assert names == [f[0] for f in hip._AnchorParams._fields_] and C.sizeof(hip._AnchorParams) == 4 * len(names)
+    assert hip.ANCHOR_DTYPE.itemsize == 12 and hip.ANCHOR_DTYPE.names == ("t", "q", "l")
+    p = hip._AnchorParams()
+    assert blasr_amd.load_library().blasr_hip_anchor_default_params(C.byref(p)) == 0
+    # MappingParameters.h:243 (lookupTableLength 8), :309 (stopMappingOnceUnique), AnchorParameters.h:34-37
+    assert (p.min_match_length, p.min_prefix_match_length, p.expand, p.max_anchors_per_position, p.advance_exact_matches,
+            p.max_lcp_length, p.use_lookup_table, p.stop_mapping_once_unique, p.forward_only, p.sorted) == (
+        12, 8, 0, 1000, 0, 0, 1, 1, 0, 1)
+
+
 def test_no_device_is_a_loud_failure():
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""next-1, device half, measured: blasr_hip_anchor_reads_device on reads sampled from a synthetic genome whose suffix
+array the reference's own sawriter builds on the spot (oracle/_ref/sawritermc travels to the GPU box prebuilt), with the
+reference's MapReadToGenome (oracle/_ref/libblasr_refmapper.so, one host thread) timed beside it on a bounded sample of
+the same reads and every anchor of that sample compared.  One JSON line.
+
+    python tools/anchor_bench.py [--genome-mb 50] [--reads 2000] [--read-len 10000] [--steps 3]
+
+The parameters are what Blasr.cpp ends up with for a default sawriter index: lookup prefix 13, so -minMatch is raised
+to 13 (Blasr.cpp:4433-4436), minPrefixMatchLength = params.lookupTableLength = 8, stopMappingOnceUnique,
+maxAnchorsPerPosition 1000, expand 0."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-mb", type=float, default=50.0)
+    ap.add_argument("--reads", type=int, default=2000)
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--cpu-reads", type=int, default=40)
+    ap.add_argument("--blt", type=int, default=0)
+    ap.add_argument("--families", type=int, default=200)
+    args = ap.parse_args()
+    import blasr_amd
+    from blasr_amd import hip, synth
+    import blasr_testlib as T
+
+    rng = np.random.default_rng(5)
+    glen = int(args.genome_mb * 1e6)
+    genome = synth.random_genome(glen, 17)
+    for f in range(args.families):  # repeat families: 2..6 copies of a 3-8 kb unit at 1-6 % divergence
+        unit = int(rng.integers(3000, 8000))
+        src = int(rng.integers(0, glen - unit))
+        for _ in range(int(rng.integers(1, 6))):
+            d = float(rng.uniform(0.01, 0.06))
+            piece = np.ascontiguousarray(synth.mutate(genome[src:src + unit], rng, d / 3, d / 3, d / 3))
+            at = int(rng.integers(0, glen - len(piece)))
+            genome[at:at + len(piece)] = piece
+    reads = np.zeros(args.reads, dtype=hip.READ_DTYPE)
+    pool, off = [], 0
+    for r in range(args.reads):
+        pos = int(rng.integers(0, glen - args.read_len))
+        tmpl = genome[pos:pos + args.read_len]
+        if r % 2:
+            tmpl = synth.revcomp(tmpl)
+        rd = np.ascontiguousarray(synth.mutate(tmpl, rng, 0.11, 0.04, 0.01))
+        reads[r] = (off, len(rd), 0, len(rd), 0)
+        pool.append(rd)
+        off += len(rd)
+    pool = np.concatenate(pool)
+    tmp = tempfile.mkdtemp(prefix="anchor_bench_")
+    t0 = time.time()
+    fasta = b">g\n" + bytes(genome) + b"\n"
+    G, starts, sa, sa_path = T.write_suffix_array(tmp, fasta, args.blt or None)
+    t_sa = time.time() - t0
+    prefix = int(sa["lookup_prefix_length"])
+    min_match = max(12, prefix)
+
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(G)
+    ctx.upload_suffix_array(sa)
+    p = ctx.anchor_params(min_match_length=min_match, min_prefix_match_length=8)
+    mem = T.DeviceMemory()
+    d_pool = mem.upload(pool)
+    cap = 8 * int(reads["length"].astype(np.int64).sum())
+    d_out = mem.zeros(cap * hip.ANCHOR_DTYPE.itemsize)
+    os.environ["BLASR_HIP_ANCHOR_COUNT_PROBES"] = "1"
+    n, loff = ctx.anchor_reads_device(reads, d_pool, p, d_out, cap)  # warm-up, and the probe count
+    probes = ctx.anchor_last_timing()["probes"]
+    del os.environ["BLASR_HIP_ANCHOR_COUNT_PROBES"]
+    ms = []
+    for _ in range(args.steps):
+        t0 = time.time()
+        n, loff = ctx.anchor_reads_device(reads, d_pool, p, d_out, cap)
+        wall = (time.time() - t0) * 1e3
+        t = ctx.anchor_last_timing()
+        ms.append((wall, t["search_ms"], t["emit_ms"], t["sort_ms"]))
+    best = min(ms)
+    anchors = mem.download(d_out, hip.ANCHOR_DTYPE, n)
+
+    # the reference itself on the first reads, one thread
+    cpu = None
+    if os.path.exists(T.REFMAPPER_SO):
+        ref = C.CDLL(T.REFMAPPER_SO)
+        ref.ref_sa_open.restype = C.c_void_p
+        h = ref.ref_sa_open(sa_path.encode())
+        aps = (min_match, 0, 1, 1000, 0, 0, 1)
+        k = min(args.cpu_reads, args.reads)
+        differ, t_cpu, n_cpu = 0, 0.0, 0
+        for r in range(k):
+            o, L = int(reads[r]["off"]), int(reads[r]["length"])
+            rd = np.ascontiguousarray(pool[o:o + L])
+            for strand in (0, 1):
+                t0 = time.time()
+                w = T.ref_anchors(ref, h, G, rd, 0, L, strand, 8, aps, True)
+                t_cpu += time.time() - t0
+                mine = anchors[int(loff[2 * r + strand]): int(loff[2 * r + strand + 1])]
+                got = np.stack([mine["t"], mine["q"], mine["l"]], axis=1) if len(mine) else np.zeros((0, 3), np.uint32)
+                differ += not np.array_equal(got, w)
+                n_cpu += len(w)
+        ref.ref_sa_close(C.c_void_p(h))
+        bases = int(reads["length"][:k].astype(np.int64).sum())
+        cpu = dict(kind="reference", cores=1, sample="%d reads, both strands, MapReadToGenome + SortMatchPosList" % k,
+                   seconds=round(t_cpu, 3), bases_per_s=round(bases / t_cpu), anchors=n_cpu, lists_that_differ=differ)
+    t = ctx.anchor_last_timing()
+    total_bases = int(reads["length"].astype(np.int64).sum())
+    # algorithmic bytes of the search: every probe reads one index entry (4 B) and one genome byte, in separate sectors
+    out = dict(stage="anchor (MapReadToGenome x 2 strands + SortMatchPosList)", genome_bases=len(G), lookup_prefix=prefix,
+               min_match=min_match, reads=args.reads, read_len=args.read_len, positions=t["positions"], anchors=int(n),
+               pieces=t["pieces"], probes=int(probes), probes_per_position=round(probes / max(t["positions"], 1), 1),
+               wall_ms=round(best[0], 2), search_ms=round(best[1], 2), emit_ms=round(best[2], 2), sort_ms=round(best[3], 2),
+               bases_per_s=round(total_bases / (best[0] / 1e3)),
+               probes_per_s=round(probes / (best[1] / 1e3)) if best[1] > 0 else None,
+               sector_GBps=round(probes * 64 / (best[1] / 1e3) / 1e9, 1) if best[1] > 0 else None,
+               sa_build_s=round(t_sa, 1), cpu_baseline=cpu)
+    if cpu:
+        out["vs_cpu_thread"] = round(out["bases_per_s"] / cpu["bases_per_s"], 1)
+    print(json.dumps(out))
+    mem.free()
+    ctx.close()
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+
+
+if __name__ == "__main__":
+    main()
