@@ -408,7 +408,7 @@ extern "C" {
 
 int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) {
   if (!p) return BLASR_HIP_ERR_INVALID;
-  p->min_match_length = 12;
+  p->min_match_length = 14;
   p->min_prefix_match_length = 8;
   p->expand = 0;
   p->max_anchors_per_position = 1000;

@@ -370,6 +370,22 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     }
     if (cur.count > 0) flush(n);
   }
+  if (getenv("BLASR_HIP_REFINE_TRACE")) {  // where the cells are: by the widest row of the candidate
+    const int edges[] = {64, 112, 192, 256, 384, 512, 1024, 2048, 4096, 1 << 30};
+    int64_t cnt[10] = {}, rows[10] = {}, cells[10] = {};
+    for (int i = 0; i < n; i++) {
+      if (geo[i].status != 0) continue;
+      int b = 0;
+      while (geo[i].maxWidth > edges[b]) b++;
+      cnt[b]++;
+      rows[b] += geo[i].rows;
+      cells[b] += geo[i].cells;
+    }
+    for (int b = 0; b < 10; b++)
+      if (cnt[b])
+        fprintf(stderr, "[refine] widest row <= %d: %lld candidates, %lld rows, %lld cells (%.1f per row)\n", edges[b],
+                (long long)cnt[b], (long long)rows[b], (long long)cells[b], (double)cells[b] / (double)rows[b]);
+  }
   size_t maxChunk = 0;
   for (auto &c : plan.chunks) maxChunk = std::max(maxChunk, c.bytes);
   const size_t oVar = fixedBytes;

@@ -40,6 +40,7 @@ EXPORTS = [
     "blasr_hip_sa_read", "blasr_hip_sa_free", "blasr_hip_sa_arrays",
     "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
+    "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -172,6 +173,11 @@ class _AnchorParams(C.Structure):
                 ("forward_only", C.c_int32), ("sorted", C.c_int32)]
 
 
+class _IntervalParams(C.Structure):
+    _fields_ = [("n_candidates", C.c_int32), ("min_interval", C.c_int32), ("indel_rate", C.c_float),
+                ("max_p_value", C.c_float), ("remove_contained_intervals", C.c_int32), ("threads", C.c_int32)]
+
+
 # blasr_hip_anchor: MatchPos t, q, l
 ANCHOR_DTYPE = np.dtype([("t", "<u4"), ("q", "<u4"), ("l", "<u4")])
 
@@ -298,6 +304,12 @@ def load_library():
                                                     C.POINTER(_AnchorParams), C.c_void_p, C.c_int64,
                                                     C.POINTER(C.c_int64), C.c_void_p]
         lib.blasr_hip_anchor_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_interval_default_params.argtypes = [C.POINTER(_IntervalParams)]
+        lib.blasr_hip_count_tuples.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        lib.blasr_hip_find_intervals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(_IntervalParams), C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.POINTER(C.c_int64), C.c_void_p]
         _lib = lib
     return _lib
 
@@ -1010,6 +1022,55 @@ class Context:
 
 
 # --- next-4: the reference's on-disk inputs (host code, no device involved) -----------------------------
+# --- next-1, host half: anchors -> candidate intervals (host code of the library) -------------------
+def interval_params(**kw):
+    """blasr_hip_interval_params with the reference's defaults; keyword overrides by field name."""
+    p = _IntervalParams()
+    load_library().blasr_hip_interval_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def count_tuples(genome, tuple_size=8):
+    """TupleCountTable of the genome (Blasr.cpp:4479-4482): int32 array of 4^tuple_size counts."""
+    genome = np.ascontiguousarray(genome, dtype=np.uint8)
+    table = np.zeros(1 << (2 * tuple_size), dtype=np.int32)
+    rc = load_library().blasr_hip_count_tuples(genome.ctypes.data, len(genome), tuple_size, table.ctypes.data)
+    if rc != OK:
+        raise BlasrHipError(rc, "count_tuples")
+    return table
+
+
+def find_intervals(genome, seq_start_pos, count_table, reads, anchors, list_off, params=None, stale=None):
+    """blasr_hip_find_intervals: (intervals INTERVAL_DTYPE, read_interval_off, p_values)."""
+    lib = load_library()
+    genome = np.ascontiguousarray(genome, dtype=np.uint8)
+    starts = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
+    table = np.ascontiguousarray(count_table, dtype=np.int32)
+    k = (len(table).bit_length() - 1) // 2
+    reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+    anchors = np.ascontiguousarray(anchors, dtype=ANCHOR_DTYPE)
+    list_off = np.ascontiguousarray(list_off, dtype=np.int64)
+    params = params or interval_params()
+    st = np.ascontiguousarray(stale, dtype=ANCHOR_DTYPE) if stale is not None else None
+    n = len(reads)
+    cap = max(n * max(int(params.n_candidates), 1), 1)
+    out = np.zeros(cap, dtype=INTERVAL_DTYPE)
+    pv = np.zeros(cap, dtype=np.float32)
+    off = np.zeros(n + 1, dtype=np.int64)
+    need = C.c_int64(0)
+    rc = lib.blasr_hip_find_intervals(genome.ctypes.data, len(genome), starts.ctypes.data, len(starts), table.ctypes.data,
+                                      k, n, reads.ctypes.data, anchors.ctypes.data if len(anchors) else None,
+                                      list_off.ctypes.data, st.ctypes.data if st is not None else None, C.byref(params),
+                                      out.ctypes.data, pv.ctypes.data, cap, C.byref(need), off.ctypes.data)
+    if rc != OK:
+        raise BlasrHipError(rc, "find_intervals")
+    return out[: need.value], off, pv[: need.value]
+
+
 def read_fasta(path=None, text=None):
     """FASTAReader::ReadAllSequences: [(title, sequence uint8 array)] of a FASTA file (or of `text`, bytes)."""
     lib = load_library()

@@ -620,7 +620,7 @@ int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t 
 /* AnchorParameters (datastructures/anchoring/AnchorParameters.h:9-42) as Blasr.cpp fills it (:398, :2273), and
  * the arguments of the two calls. */
 typedef struct blasr_hip_anchor_params {
-  uint32_t min_match_length;         /* anchorParameters.minMatchLength = params.minMatchLength (12) */
+  uint32_t min_match_length;         /* anchorParameters.minMatchLength = params.minMatchLength (14, MappingParameters.h:244) */
   uint32_t min_prefix_match_length;  /* MapReadToGenome's minPrefixMatchLength = params.lookupTableLength (8); match
                                         lengths are counted from it even when the table's prefix differs */
   int32_t expand;                    /* anchorParameters.expand, 0..7: the MapRead iteration (:2273) */
@@ -664,6 +664,45 @@ int blasr_hip_anchor_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr
  * call (wall); counters: [0] read positions searched, [1] anchors, [2] pieces, [3] probes of the index array made by
  * the search (when counted: BLASR_HIP_ANCHOR_COUNT_PROBES=1, else 0). */
 int blasr_hip_anchor_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[4]);
+
+/* ------------------------------------------------------------------------------------------------
+ * next-1, host half: from the sorted anchor lists to the candidate intervals of a read.  Host code, no
+ * GPU work (1 % of the anchoring time).  Replaces, per read, MapRead between SortMatchPosList and
+ * AlignIntervals (alignment/Blasr.cpp:2342-2500) with the reference's default switches (pValueType 0,
+ * globalChainType 0, no overlap / noSelf / maxAnchorGap / limsAlign / piecewiseMatch):
+ * RemoveOverlappingAnchors on both lists (algorithms/anchoring/FindMaxInterval.h:282-315), then
+ * FindMaxIncreasingInterval(Forward, ...) and (Reverse, ...) (:661-843: StoreLargestIntervals :394-640,
+ * GlobalChain algorithms/anchoring/GlobalChain.h:101-207, the p-value of LISPValue.h:84-172, the size
+ * weight) into ONE WeightedIntervalSet of nCandidates (datastructures/anchoring/WeightedInterval.h:189-268),
+ * optionally RemoveContained (:133-181).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_interval_params {
+  int32_t n_candidates;               /* params.nCandidates (10): the interval set's maxSize */
+  int32_t min_interval;               /* params.minInterval (100) */
+  float indel_rate;                   /* params.indelRate (0.30): intervalLength = subread * (1 + indelRate), at most +50000 */
+  float max_p_value;                  /* log(0.5), set in MapRead (Blasr.cpp:2371) */
+  int32_t remove_contained_intervals; /* params.removeContainedIntervals (0) */
+  int32_t threads;                    /* host threads over the reads; 0 = up to 16 */
+} blasr_hip_interval_params;
+int blasr_hip_interval_default_params(blasr_hip_interval_params *params);
+/* TupleCountTable::AddSequenceTupleCountsLR (datastructures/tuplelists/TupleCountTable.h:63-73) as Blasr.cpp:4479-4482
+ * builds it when no .ctab is given (tuple_size = params.lookupTableLength, 8): count_table has 4^tuple_size entries. */
+int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t tuple_size, int32_t *count_table);
+/* anchors / list_off: what blasr_hip_anchor_reads_* returned with sorted = 1 (host arrays).  seq_start_pos:
+ * SequenceIndexDatabase::seqStartPos (n_seq_pos = contigs + 1 entries).  intervals (at most capacity; *n_intervals
+ * receives the number needed, BLASR_HIP_ERR_CAPACITY beyond): read r's are intervals[read_interval_off[r] ..
+ * read_interval_off[r+1]) in the order AlignIntervals walks the set (p-value, then start); p_values (may be NULL)
+ * receives their p-values.
+ * stale (2 * n_reads anchors, may be NULL = zeros): StoreLargestIntervals reads the element one past the end of its
+ * list (FindMaxInterval.h:493, :581, :617).  After RemoveOverlappingAnchors removed anything that element is the
+ * list's own old entry at that index -- modelled here; when nothing was removed the reference sees whatever its
+ * reused buffer held, and `stale` is that element (list 2r, 2r+1 of read r). */
+int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                             int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
+                             const blasr_hip_read *reads, const blasr_hip_anchor *anchors, const int64_t *list_off,
+                             const blasr_hip_anchor *stale, const blasr_hip_interval_params *params,
+                             blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
+                             int64_t *read_interval_off);
 
 #ifdef __cplusplus
 }

@@ -538,4 +538,102 @@ long ref_map_read_to_genome(void *h, const unsigned char *genomeSeq, unsigned ge
   return (long)matches.size();
 }
 
+// next-1, host half: the reference's own RemoveOverlappingAnchors + FindMaxIncreasingInterval (Forward, then Reverse)
+// into one WeightedIntervalSet, as MapRead runs them with its default switches (Blasr.cpp:2342-2500).
+// ref_ct_open builds the tuple count table as Blasr.cpp:4479-4482 does when no .ctab is given.
+struct RefCountTable {
+  TupleCountTable<T_GenomeSequence, DNATuple> ct;
+};
+void *ref_ct_open(const unsigned char *genomeSeq, unsigned genomeLen, int tupleSize) {
+  RefCountTable *h = new RefCountTable;
+  T_GenomeSequence genome;
+  genome.seq = (Nucleotide *)genomeSeq;
+  genome.length = genomeLen;
+  genome.deleteOnExit = false;
+  TupleMetrics tm;
+  tm.Initialize(tupleSize);
+  h->ct.InitCountTable(tm);
+  h->ct.AddSequenceTupleCountsLR(genome);
+  return h;
+}
+void ref_ct_close(void *h) { delete (RefCountTable *)h; }
+long ref_ct_table(void *h, int *out, long cap) {
+  RefCountTable *c = (RefCountTable *)h;
+  for (long i = 0; i < c->ct.countTableLength && i < cap; i++) out[i] = c->ct.countTable[i];
+  return c->ct.countTableLength;
+}
+
+// fwd / rc: (t, q, l) triples sorted as SortMatchPosList leaves them; stale: 2 triples = the element the reference
+// finds one past the end of each list's buffer (the vector is built one longer and shrunk, so that element is defined).
+// iv[5] = nCandidates, minInterval, removeContainedIntervals, -, -; fv[2] = indelRate, maxPValue.
+// out: (start, end, qStart, qEnd, strand) per interval in the set's order; pv: their p-values.  Returns the count.
+long ref_find_intervals(void *ctHandle, const unsigned char *genomeSeq, unsigned genomeLen, const unsigned *seqStartPos,
+                        int nSeqPos, unsigned readLen, unsigned subreadStart, unsigned subreadEnd, const unsigned *fwd,
+                        long nFwd, const unsigned *rc, long nRc, const unsigned *stale, const int *iv, const float *fv,
+                        unsigned *out, float *pv, long cap) {
+  RefCountTable *c = (RefCountTable *)ctHandle;
+  T_GenomeSequence genome;
+  genome.seq = (Nucleotide *)genomeSeq;
+  genome.length = genomeLen;
+  genome.deleteOnExit = false;
+  SequenceIndexDatabase<FASTASequence> seqdb;
+  seqdb.seqStartPos = const_cast<DNALength *>(seqStartPos);
+  seqdb.nSeqPos = nSeqPos;
+  seqdb.deleteStructures = false;
+  SeqBoundaryFtr<FASTASequence> seqBoundary(&seqdb);
+  T_Sequence read;
+  read.seq = NULL;
+  read.length = readLen;
+  read.deleteOnExit = false;
+  read.subreadStart = subreadStart;
+  read.subreadEnd = subreadEnd;
+
+  vector<ChainedMatchPos> lists[2];
+  const unsigned *src[2] = {fwd, rc};
+  const long n[2] = {nFwd, nRc};
+  for (int s = 0; s < 2; s++) {
+    lists[s].reserve(n[s] + 1);
+    for (long i = 0; i < n[s]; i++) lists[s].push_back(ChainedMatchPos(src[s][3 * i], src[s][3 * i + 1], src[s][3 * i + 2]));
+    lists[s].push_back(ChainedMatchPos(stale[3 * s], stale[3 * s + 1], stale[3 * s + 2]));
+    lists[s].resize(n[s]);  // the stale element stays in the buffer, as a longer earlier list would leave it
+  }
+  MappingParameters params;
+  params.MakeSane();
+  params.nCandidates = iv[0];
+  params.minInterval = iv[1];
+  params.removeContainedIntervals = iv[2] != 0;
+  params.indelRate = fv[0];
+  PValueWeightor lisPValue(read, genome, c->ct.tm, &c->ct);
+  LISSizeWeightor<vector<ChainedMatchPos> > lisWeightFn;
+  IntervalSearchParameters intervalSearchParameters;
+  params.InitializeIntervalSearchParameters(intervalSearchParameters);
+  intervalSearchParameters.maxPValue = fv[1];
+  WeightedIntervalSet<ChainedMatchPos> topIntervals(params.nCandidates);
+  MappingBuffers buffers;
+  RemoveOverlappingAnchors(lists[0]);
+  RemoveOverlappingAnchors(lists[1]);
+  DNALength maxGapLength = 50000;  // Blasr.cpp:2402-2406
+  DNALength intervalLength = (read.subreadEnd - read.subreadStart) * (1 + params.indelRate);
+  if (intervalLength - (read.subreadEnd - read.subreadStart) > maxGapLength)
+    intervalLength = (read.subreadEnd - read.subreadStart) + maxGapLength;
+  FindMaxIncreasingInterval(Forward, lists[0], intervalLength, params.nCandidates, seqBoundary, lisPValue, lisWeightFn,
+                            topIntervals, genome, read, intervalSearchParameters, &buffers.globalChainEndpointBuffer,
+                            &buffers.sdpFragmentSet, (const char *)NULL);
+  FindMaxIncreasingInterval(Reverse, lists[1], intervalLength, params.nCandidates, seqBoundary, lisPValue, lisWeightFn,
+                            topIntervals, genome, read, intervalSearchParameters, &buffers.globalChainEndpointBuffer,
+                            &buffers.sdpFragmentSet, (const char *)NULL);
+  if (params.removeContainedIntervals) topIntervals.RemoveContained();
+  long k = 0;
+  for (WeightedIntervalSet<ChainedMatchPos>::iterator it = topIntervals.begin(); it != topIntervals.end(); ++it, ++k) {
+    if (k >= cap) continue;
+    out[5 * k] = it->start;
+    out[5 * k + 1] = it->end;
+    out[5 * k + 2] = it->qStart;
+    out[5 * k + 3] = it->qEnd;
+    out[5 * k + 4] = it->GetStrandIndex();
+    pv[k] = it->pValue;
+  }
+  return k;
+}
+
 }  // extern "C"

@@ -1030,3 +1030,25 @@ def ref_anchors(ref, handle, genome, read, s0, s1, strand, min_prefix, ap, sort=
             break
         cap = n
     return out[: 3 * n].reshape(n, 3)
+
+
+def ref_find_intervals(ref, ct_handle, genome, starts, read_len, s0, s1, fwd, rc, stale, n_candidates=10, min_interval=100,
+                       remove_contained=0, indel_rate=0.3, max_p_value=None):
+    """The reference's RemoveOverlappingAnchors + FindMaxIncreasingInterval x 2 (+ RemoveContained) through
+    oracle/_ref/libblasr_refmapper.so.  fwd / rc / stale: (n, 3) uint32 (t, q, l).  Returns ((k, 5) uint32 array of
+    start, end, qStart, qEnd, strand; float32 p-values)."""
+    import math
+    ref.ref_find_intervals.restype = C.c_long
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    fwd, rc, stale = (np.ascontiguousarray(x, dtype=np.uint32) for x in (fwd, rc, stale))
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    iv = np.array([n_candidates, min_interval, remove_contained, 0, 0], np.int32)
+    fv = np.array([indel_rate, math.log(0.5) if max_p_value is None else max_p_value], np.float32)
+    cap = max(n_candidates, 1) + 4
+    out = np.zeros(5 * cap, np.uint32)
+    pv = np.zeros(cap, np.float32)
+    k = ref.ref_find_intervals(C.c_void_p(ct_handle), vp(genome), len(genome), vp(starts), len(starts), read_len, s0, s1,
+                               vp(fwd), C.c_long(len(fwd)), vp(rc), C.c_long(len(rc)), vp(stale), vp(iv), vp(fv), vp(out),
+                               vp(pv), C.c_long(cap))
+    assert k <= cap
+    return out[: 5 * k].reshape(k, 5), pv[:k]

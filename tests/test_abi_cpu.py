@@ -62,10 +62,10 @@ def test_anchor_records_match_header():
     assert hip.ANCHOR_DTYPE.itemsize == 12 and hip.ANCHOR_DTYPE.names == ("t", "q", "l")
     p = hip._AnchorParams()
     assert blasr_amd.load_library().blasr_hip_anchor_default_params(C.byref(p)) == 0
-    # MappingParameters.h:243 (lookupTableLength 8), :309 (stopMappingOnceUnique), AnchorParameters.h:34-37
+    # MappingParameters.h:244 (minMatchLength 14), :243 (lookupTableLength 8), :309 (stopMappingOnceUnique), AnchorParameters.h:34-37
     assert (p.min_match_length, p.min_prefix_match_length, p.expand, p.max_anchors_per_position, p.advance_exact_matches,
             p.max_lcp_length, p.use_lookup_table, p.stop_mapping_once_unique, p.forward_only, p.sorted) == (
-        12, 8, 0, 1000, 0, 0, 1, 1, 0, 1)
+        14, 8, 0, 1000, 0, 0, 1, 1, 0, 1)
 
 
 def test_no_device_is_a_loud_failure():

@@ -6,8 +6,8 @@ the same reads and every anchor of that sample compared.  One JSON line.
 
     python tools/anchor_bench.py [--genome-mb 50] [--reads 2000] [--read-len 10000] [--steps 3]
 
-The parameters are what Blasr.cpp ends up with for a default sawriter index: lookup prefix 13, so -minMatch is raised
-to 13 (Blasr.cpp:4433-4436), minPrefixMatchLength = params.lookupTableLength = 8, stopMappingOnceUnique,
+The parameters are what Blasr.cpp ends up with for a default sawriter index: lookup prefix 13, -minMatch 14
+(MappingParameters.h:244), minPrefixMatchLength = params.lookupTableLength = 8, stopMappingOnceUnique,
 maxAnchorsPerPosition 1000, expand 0."""
 import argparse
 import ctypes as C
@@ -67,7 +67,7 @@ def main():
     G, starts, sa, sa_path = T.write_suffix_array(tmp, fasta, args.blt or None)
     t_sa = time.time() - t0
     prefix = int(sa["lookup_prefix_length"])
-    min_match = max(12, prefix)
+    min_match = max(14, prefix)
 
     ctx = blasr_amd.Context(0)
     ctx.upload_genome(G)
