@@ -32,6 +32,6 @@ from .hip import (  # noqa: F401
     WINDOW_DTYPE,
 )
 
-from .mapread import Hit, m4_record, map_reads, sam_record  # noqa: F401,E402
+from .mapread import Hit, candidate_intervals, m4_record, map_reads, sam_record  # noqa: F401,E402
 
 __all__ = ["BlasrHipError", "Context", "LIB_PATH", "RefineBatch", "RefineResult", "ScoreParams", "SdpParams", "load_library"]

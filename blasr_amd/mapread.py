@@ -28,6 +28,15 @@ class Hit(dict):
     q_aligned_seq_pos, n_match, read_length."""
 
 
+def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, anchor_params=None, interval_params=None):
+    """MapRead up to AlignIntervals (Blasr.cpp:2279-2500): MapReadToGenome for both strands + SortMatchPosList on the
+    device (the context holds the genome and its suffix array), then RemoveOverlappingAnchors /
+    FindMaxIncreasingInterval / the interval set on the host.  Returns (intervals INTERVAL_DTYPE in the order
+    AlignIntervals walks them read by read, read_interval_off, p_values)."""
+    anchors, list_off = ctx.anchor_reads(reads, pool, anchor_params)
+    return hip.find_intervals(genome, contig_starts, count_table, reads, anchors, list_off, interval_params)
+
+
 def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard=False, bestn=None, params=None):
     """reads: READ_DTYPE array over `pool`; intervals: INTERVAL_DTYPE array (any order, each naming its read).
     The context must hold the genome.  Returns, per read, the list of Hits the reference would keep, best first.

@@ -1,12 +1,15 @@
 // examples/map_fasta.cpp -- a C++ host over the C ABI of include/blasr_hip.h, nothing else: FASTA in, `-m 4` lines out.
 //
-//   map_fasta reads.fasta genome.fasta intervals.txt [bestn]
+//   map_fasta reads.fasta genome.fasta genome.fasta.sa [bestn]     the whole mapper: anchoring included
+//   map_fasta reads.fasta genome.fasta intervals.txt   [bestn]     candidate intervals given (e.g. blasrmc -V 1's)
 //
 // What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
 //   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
 //   reads       blasr_hip_fasta_read                                   (ReaderAgglomerate, FASTA)
-//   intervals   one per line: read start end qStart qEnd strand        (the candidate intervals anchoring reports: the
-//               one stage that is not built, SURVEY next-1; `blasrmc -V 1` prints them)
+//   anchoring   blasr_hip_sa_read + blasr_hip_upload_suffix_array + blasr_hip_anchor_reads_host (MapReadToGenome x 2 +
+//               SortMatchPosList on the device, :2279-2340), blasr_hip_count_tuples (:4479-4482) +
+//               blasr_hip_find_intervals (RemoveOverlappingAnchors, FindMaxIncreasingInterval, :2380-2500)
+//               -- or, with a text file: one interval per line: read start end qStart qEnd strand
 //   MapRead     blasr_hip_map_reads_host                               (:2530-2644, C++ inside the library)
 //   epilogue    blasr_hip_ref_contig_location, blasr_hip_map_qvs, blasr_hip_m4_line   (:3509-3516, :3086)
 // Build: g++ -O2 -std=c++11 -I include examples/map_fasta.cpp -L blasr_amd -lblasr_hip -Wl,-rpath,'$ORIGIN/../blasr_amd'
@@ -26,7 +29,7 @@ static void die(const char *what, blasr_hip_ctx *ctx) {
 }
 
 int main(int argc, char **argv) {
-  if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta intervals.txt [bestn]", NULL);
+  if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta (genome.fasta.sa | intervals.txt) [bestn]", NULL);
   const int bestn = argc > 4 ? atoi(argv[4]) : 1;
   // ---- genome: contigs back to back, an N after each, upper case; the contig table; names up to the first blank
   blasr_hip_fasta *gf = NULL, *rf = NULL;
@@ -64,21 +67,60 @@ int main(int argc, char **argv) {
     // the reference appends the subread's coordinates to the name it prints (SMRTSequence title handling)
     readNames.push_back(std::string(buf) + "/0_" + std::to_string((long long)n));
   }
-  // ---- candidate intervals
-  std::vector<blasr_hip_interval> ivs;
-  FILE *f = fopen(argv[3], "r");
-  if (!f) die("cannot read the intervals", NULL);
-  long long rd, st, en, qs, qe, sd;
-  while (fscanf(f, "%lld %lld %lld %lld %lld %lld", &rd, &st, &en, &qs, &qe, &sd) == 6) {
-    blasr_hip_interval iv = {(uint32_t)st, (uint32_t)en, (uint32_t)qs, (uint32_t)qe, (int32_t)rd, (int32_t)sd};
-    ivs.push_back(iv);
-  }
-  fclose(f);
-  // ---- MapRead for the whole block
   blasr_hip_ctx *ctx = NULL;
   if (blasr_hip_create(0, &ctx) != BLASR_HIP_OK) die("no gfx950 device", NULL);
   if (blasr_hip_upload_genome(ctx, genome.data(), genomeLen, nContigs > 1 ? starts.data() : NULL, nContigs > 1 ? (int32_t)nContigs : 0))
     die("upload_genome", ctx);
+  // ---- candidate intervals: from the reads (a .sa file given) or from a text file
+  std::vector<blasr_hip_interval> ivs;
+  const size_t nameLen = strlen(argv[3]);
+  if (nameLen > 3 && strcmp(argv[3] + nameLen - 3, ".sa") == 0) {
+    blasr_hip_sa *sa = NULL;
+    if (blasr_hip_sa_read(argv[3], &sa) != BLASR_HIP_OK) die("cannot read the suffix array", NULL);
+    const uint32_t *index, *startPos, *endPos;
+    int64_t saLen, tableLen;
+    int32_t prefixLen;
+    blasr_hip_sa_arrays(sa, &index, &saLen, &startPos, &endPos, &tableLen, &prefixLen);
+    if (blasr_hip_upload_suffix_array(ctx, index, saLen, startPos, endPos, tableLen, prefixLen)) die("upload_suffix_array", ctx);
+    blasr_hip_sa_free(sa);
+    blasr_hip_anchor_params ap;
+    blasr_hip_anchor_default_params(&ap);
+    if (ap.min_match_length < (uint32_t)prefixLen) ap.min_match_length = (uint32_t)prefixLen;  // Blasr.cpp:4433-4436
+    std::vector<int64_t> listOff(2 * (size_t)nReads + 1);
+    std::vector<blasr_hip_anchor> anchors(4 * pool.size() + 1024);
+    int64_t nAnchors = 0;
+    int rc = blasr_hip_anchor_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), &ap, anchors.data(),
+                                         (int64_t)anchors.size(), &nAnchors, listOff.data());
+    if (rc == BLASR_HIP_ERR_CAPACITY) {
+      anchors.resize((size_t)nAnchors);
+      rc = blasr_hip_anchor_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), &ap, anchors.data(),
+                                       (int64_t)anchors.size(), &nAnchors, listOff.data());
+    }
+    if (rc != BLASR_HIP_OK) die("anchor_reads", ctx);
+    std::vector<int32_t> countTable((size_t)1 << 16);  // tuples of params.lookupTableLength = 8 bases
+    blasr_hip_count_tuples(genome.data(), genomeLen, 8, countTable.data());
+    blasr_hip_interval_params ip;
+    blasr_hip_interval_default_params(&ip);
+    // the contig table as the reference's seqdb holds it; a single contig still has its two boundaries
+    ivs.resize((size_t)nReads * (size_t)ip.n_candidates + 1);
+    std::vector<int64_t> ivOff((size_t)nReads + 1);
+    int64_t nIvs = 0;
+    if (blasr_hip_find_intervals(genome.data(), genomeLen, starts.data(), (int32_t)nContigs + 1, countTable.data(), 8, nReads,
+                                 reads.data(), anchors.data(), listOff.data(), NULL, &ip, ivs.data(), NULL, (int64_t)ivs.size(),
+                                 &nIvs, ivOff.data()) != BLASR_HIP_OK)
+      die("find_intervals", NULL);
+    ivs.resize((size_t)nIvs);
+  } else {
+    FILE *f = fopen(argv[3], "r");
+    if (!f) die("cannot read the intervals", NULL);
+    long long rd, st, en, qs, qe, sd;
+    while (fscanf(f, "%lld %lld %lld %lld %lld %lld", &rd, &st, &en, &qs, &qe, &sd) == 6) {
+      blasr_hip_interval iv = {(uint32_t)st, (uint32_t)en, (uint32_t)qs, (uint32_t)qe, (int32_t)rd, (int32_t)sd};
+      ivs.push_back(iv);
+    }
+    fclose(f);
+  }
+  // ---- MapRead for the whole block
   blasr_hip_map_params prm;
   blasr_hip_map_default_params(&prm);
   std::vector<blasr_hip_hit> hits(ivs.size() + 1);

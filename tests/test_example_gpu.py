@@ -31,3 +31,22 @@ def test_cpp_example_prints_the_reference_lines(tmp_path):
     assert len(got) == len(want) == 80
     bad = [(a, b) for a, b in zip(got, want) if a != b]
     assert not bad, bad[:3]
+
+
+@pytest.mark.gpu
+def test_cpp_example_maps_from_fasta_and_suffix_array_alone(tmp_path):
+    """The same binary as a whole mapper: reads.fasta + genome.fasta + the .sa file of the reference's sawriter in, the
+    reference binary's -m 4 lines out (anchoring on the device, interval finding on the host, then MapRead)."""
+    sawriter = os.path.join(ROOT, "oracle", "_ref", "sawritermc")
+    if not os.path.exists(EXE) or not os.path.exists(sawriter):
+        pytest.skip("examples/map_fasta or oracle/_ref/sawritermc not built")
+    want = write_inputs(str(tmp_path))
+    fa = os.path.join(str(tmp_path), "genome.fasta")
+    subprocess.run([sawriter, fa + ".sa", fa, "-blt", "8"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run([EXE, os.path.join(str(tmp_path), "reads.fasta"), fa, fa + ".sa", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = sorted(p.stdout.decode().splitlines())
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]

@@ -9,18 +9,33 @@ RemoveOverlappingAlignments -> AssignRefContigLocation -> StoreMapQVs -> the -m 
 The lines must equal the reference's byte for byte, and so must the SAM records of the same alignments (-sam:
 CreateCIGARString + SAMOutput::PrintAlignment)."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
 
 import blasr_amd
+from blasr_amd import hip
 
 pytestmark = pytest.mark.gpu
+
+SAWRITER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "sawritermc")
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m4_noisy_golden.npz")
 
 
 def test_m4_lines_of_noisy_reads_with_the_reference_intervals():
+    run_end_to_end(own_intervals=False)
+
+
+@pytest.mark.skipif(not os.path.exists(SAWRITER), reason="oracle/_ref/sawritermc not built (the suffix array's writer)")
+def test_m4_lines_of_noisy_reads_from_the_reads_alone(tmp_path):
+    """No reference intervals: the library anchors the reads itself (suffix-array search on the device, interval finding
+    on the host) and must arrive at the reference binary's 125 intervals, -m 4 lines and SAM records."""
+    run_end_to_end(own_intervals=True, tmp_path=tmp_path)
+
+
+def run_end_to_end(own_intervals, tmp_path=None):
     g = np.load(GOLDEN)
     contigs = [g["contig0"], g["contig1"]]
     want = bytes(g["lines"]).decode().splitlines()
@@ -41,6 +56,16 @@ def test_m4_lines_of_noisy_reads_with_the_reference_intervals():
     for k in range(n_iv):
         s, e, qs, qe, strand = (int(v) for v in intervals[k])
         ivs[k] = (s, e, qs, qe, int(owner[k]), strand)
+    if own_intervals:
+        # the suffix array blasrmc builds on the fly (Blasr.cpp:4407-4420: lookup prefix 8) = sawriter -blt 8
+        fa = os.path.join(str(tmp_path), "genome.fasta")
+        with open(fa, "wb") as f:
+            f.write(b">contig0\n" + bytes(contigs[0]) + b"\n>contig1\n" + bytes(contigs[1]) + b"\n")
+        subprocess.run([SAWRITER, fa + ".sa", fa, "-blt", "8"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ctx.upload_suffix_array(hip.read_suffix_array(fa + ".sa"))
+        mine, _, _ = blasr_amd.candidate_intervals(ctx, genome, starts, hip.count_tuples(genome, 8), pool, reads)
+        assert np.array_equal(mine, ivs)
+        ivs = mine
     # -m 4: bestn 1, gap lists as the aligner left them
     got = []
     for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, reads, ivs, bestn=1)):
