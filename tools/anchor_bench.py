@@ -111,10 +111,42 @@ def main():
                 got = np.stack([mine["t"], mine["q"], mine["l"]], axis=1) if len(mine) else np.zeros((0, 3), np.uint32)
                 differ += not np.array_equal(got, w)
                 n_cpu += len(w)
-        ref.ref_sa_close(C.c_void_p(h))
         bases = int(reads["length"][:k].astype(np.int64).sum())
         cpu = dict(kind="reference", cores=1, sample="%d reads, both strands, MapReadToGenome + SortMatchPosList" % k,
                    seconds=round(t_cpu, 3), bases_per_s=round(bases / t_cpu), anchors=n_cpu, lists_that_differ=differ)
+    # the host half: anchors -> candidate intervals (RemoveOverlappingAnchors, FindMaxIncreasingInterval, interval set)
+    starts = np.asarray(starts, dtype=np.uint32)
+    t0 = time.time()
+    count_table = hip.count_tuples(G, 8)
+    t_ct = time.time() - t0
+    ip = hip.interval_params()
+    t0 = time.time()
+    ivs, ioff, pvs = hip.find_intervals(G, starts, count_table, reads, anchors, loff, ip)
+    t_iv = time.time() - t0
+    host = dict(intervals=int(len(ivs)), find_intervals_ms=round(t_iv * 1e3, 1), threads="up to 16",
+                count_table_s=round(t_ct, 2), reads_per_s=round(args.reads / t_iv))
+    if cpu is not None:
+        ref.ref_ct_open.restype = C.c_void_p
+        hct = ref.ref_ct_open(G.ctypes.data_as(C.c_void_p), len(G), 8)
+        k = min(args.cpu_reads, args.reads)
+        t_ref, differ = 0.0, 0
+        zero = np.zeros((2, 3), np.uint32)
+        for r in range(k):
+            L = int(reads[r]["length"])
+            lists = []
+            for strand in (0, 1):
+                mine = anchors[int(loff[2 * r + strand]): int(loff[2 * r + strand + 1])]
+                lists.append(np.stack([mine["t"], mine["q"], mine["l"]], axis=1) if len(mine) else np.zeros((0, 3), np.uint32))
+            t0 = time.time()
+            want, wpv = T.ref_find_intervals(ref, hct, G, starts, L, 0, L, lists[0], lists[1], zero)
+            t_ref += time.time() - t0
+            m = ivs[int(ioff[r]): int(ioff[r + 1])]
+            got = (np.stack([m["start"], m["end"], m["q_start"], m["q_end"], m["strand"].astype(np.uint32)], axis=1)
+                   if len(m) else np.zeros((0, 5), np.uint32))
+            differ += not (np.array_equal(got, want) and np.array_equal(pvs[int(ioff[r]): int(ioff[r + 1])], wpv))
+        ref.ref_ct_close(C.c_void_p(hct))
+        host["reference"] = dict(kind="reference", cores=1, sample="%d reads" % k, seconds=round(t_ref, 3),
+                                 reads_per_s=round(k / t_ref), reads_that_differ=differ)
     t = ctx.anchor_last_timing()
     total_bases = int(reads["length"].astype(np.int64).sum())
     # algorithmic bytes of the search: every probe reads one index entry (4 B) and one genome byte, in separate sectors
@@ -125,10 +157,12 @@ def main():
                bases_per_s=round(total_bases / (best[0] / 1e3)),
                probes_per_s=round(probes / (best[1] / 1e3)) if best[1] > 0 else None,
                sector_GBps=round(probes * 64 / (best[1] / 1e3) / 1e9, 1) if best[1] > 0 else None,
-               sa_build_s=round(t_sa, 1), cpu_baseline=cpu)
+               sa_build_s=round(t_sa, 1), cpu_baseline=cpu, host_half=host)
     if cpu:
         out["vs_cpu_thread"] = round(out["bases_per_s"] / cpu["bases_per_s"], 1)
     print(json.dumps(out))
+    if cpu is not None:
+        ref.ref_sa_close(C.c_void_p(h))
     mem.free()
     ctx.close()
     for f in os.listdir(tmp):
