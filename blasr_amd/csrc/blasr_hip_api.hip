@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -258,8 +259,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
                oArenaOff = carve(sizeof(int64_t) * n);
   const size_t oOpsStart = carve(sizeof(int32_t) * n), oDp = carve(sizeof(int32_t) * n);
   const size_t oMatrix = carve(sizeof(int32_t) * 25), oTotal = carve(sizeof(int64_t));
-  const size_t oWideTasks = carve(sizeof(int32_t) * n), oWideOff = carve(sizeof(int64_t) * n),
-               oWideSize = carve(sizeof(int32_t) * n);
+  // (+ 4: the hybrid kernel's list is padded to whole wavefronts)
+  const size_t oWideTasks = carve(sizeof(int32_t) * ((size_t)n + 4)), oWideOff = carve(sizeof(int64_t) * ((size_t)n + 4)),
+               oWideSize = carve(sizeof(int32_t) * ((size_t)n + 4));
   const size_t oList4 = carve(sizeof(int32_t) * n), oList1 = carve(sizeof(int32_t) * n);
   const size_t fixedBytes = off;
   // first make room for the fixed part + a modest variable part; grown below once the geometry is known
@@ -307,6 +309,16 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     return rc;
   }
 
+  // The tagged-key fill variant needs byte-sized matrix entries, ext < del and |score| < 2^24;
+  // anything else runs the compare-based variant (same results, more instructions per cell).
+  bool fast = score->affine_extend < score->del && scoreMagnitude * (longest + 66) < (1ll << 24);
+  for (int i = 0; i < 25; i++) fast = fast && score->matrix[i] >= -128 && score->matrix[i] <= 127;
+  const bool packed = fast && !getenv("BLASR_HIP_NO_FILL4");
+  // candidates with a row too wide for fillp_kernel: its hybrid variant (narrow rows several candidates to a
+  // wavefront, wide rows by the whole wavefront through a global ring) unless switched off
+  const bool hybrid = packed && !getenv("BLASR_HIP_NO_HYBRID");
+  const int wideOver = hybrid ? fill4_max_width() : kLdsMaxWidth;
+
   // ---- plan: contiguous chunks of candidates that fit the workspace ----------
   Plan plan;
   plan.arrowOff.resize(n);
@@ -342,8 +354,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         a = align_up((size_t)geo[i].cells + 16, 64);  // + 16: the traceback reads 16-byte windows
         r = sizeof(int2) * ((size_t)geo[i].rows + 1);
         ar = sizeof(uint32_t) * ((size_t)geo[i].rows + geo[i].tSpan + 2);
-        if (geo[i].maxWidth > kLdsMaxWidth) {
-          ringSize = 2048;
+        if (geo[i].maxWidth > wideOver) {
+          ringSize = hybrid ? 512 : 2048;
           while (ringSize < 2 * geo[i].maxWidth + 128) ringSize *= 2;
           w = align_up((size_t)ringSize * 12, 256);
         }
@@ -380,6 +392,17 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       cnt[b]++;
       rows[b] += geo[i].rows;
       cells[b] += geo[i].cells;
+    }
+    {
+      std::vector<int64_t> top;
+      for (int i = 0; i < n; i++)
+        if (geo[i].status == 0) top.push_back(geo[i].cells);
+      std::sort(top.begin(), top.end(), std::greater<int64_t>());
+      fprintf(stderr, "[refine] heaviest candidates (cells):");
+      for (size_t u = 0; u < top.size() && u < 8; u++) fprintf(stderr, " %lld", (long long)top[u]);
+      for (size_t u : {(size_t)100, (size_t)1000, (size_t)10000})
+        if (u < top.size()) fprintf(stderr, "  #%zu: %lld", u, (long long)top[u]);
+      fprintf(stderr, "\n");
     }
     for (int b = 0; b < 10; b++)
       if (cnt[b])
@@ -418,10 +441,6 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   HIP_TRY(ctx, hipMemsetAsync(dTotal, 0, sizeof(int64_t), st));
   HIP_TRY(ctx, hipMemsetAsync(dDp, 0, sizeof(int32_t) * n, st));
 
-  // The tagged-key fill variant needs byte-sized matrix entries, ext < del and |score| < 2^24;
-  // anything else runs the compare-based variant (same results, more instructions per cell).
-  bool fast = score->affine_extend < score->del && scoreMagnitude * (longest + 66) < (1ll << 24);
-  for (int i = 0; i < 25; i++) fast = fast && score->matrix[i] >= -128 && score->matrix[i] <= 127;
   RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
   float msFill = 0, msTrace = 0, msCompact = 0;
   for (auto &c : plan.chunks) {
@@ -468,20 +487,53 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     bool wideLaunched = false, timedFill4 = false;
     auto launch_wide = [&]() -> int {
       if (c.wideTasks.empty()) return 0;
-      const int nw = (int)c.wideTasks.size();
+      int nw = (int)c.wideTasks.size();
+      if (hybrid) {
+        // A wavefront takes the wide rows of its four candidates one after the other, so the heavy candidates (by
+        // cells) must not share one: sorted by cells, candidate p of the order goes to wavefront p mod W, so every
+        // wavefront holds one of the W heaviest, one of the next W, ...; empty slots are -1.
+        std::vector<int32_t> order((size_t)nw);
+        for (int u = 0; u < nw; u++) order[(size_t)u] = u;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+          return geo[c.wideTasks[(size_t)a]].cells > geo[c.wideTasks[(size_t)b]].cells;
+        });
+        const int W = (nw + 3) / 4;
+        std::vector<int32_t> t2((size_t)W * 4, -1), s2((size_t)W * 4, 512);
+        std::vector<int64_t> o2((size_t)W * 4, 0);
+        for (int p = 0; p < nw; p++) {
+          const size_t slot = (size_t)(p % W) * 4 + (size_t)(p / W);
+          t2[slot] = c.wideTasks[(size_t)order[(size_t)p]];
+          o2[slot] = c.wideRingOff[(size_t)order[(size_t)p]];
+          s2[slot] = c.wideRingSize[(size_t)order[(size_t)p]];
+        }
+        c.wideTasks.swap(t2);
+        c.wideRingOff.swap(o2);
+        c.wideRingSize.swap(s2);
+        nw = W * 4;
+      }
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipEventRecord(ev[7], st));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));  // the uploads and everything before them
       FillArgs fw = fa;
       fw.count = nw;
-      launch_fill(view, fw, true, fast, ctx->sideStream);
+      if (hybrid) fw.taskList = dWideTasks;
+      if (getenv("BLASR_HIP_FILL_SERIAL")) {  // measurement: every fill kernel alone on the main stream
+        if (hybrid)
+          launch_fill_hybrid(view, fw, st);
+        else
+          launch_fill(view, fw, true, fast, st);
+        return 0;
+      }
+      HIP_TRY(ctx, hipEventRecord(ev[7], st));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));  // the uploads and everything before them
+      if (hybrid)
+        launch_fill_hybrid(view, fw, ctx->sideStream);
+      else
+        launch_fill(view, fw, true, fast, ctx->sideStream);
       HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
       wideLaunched = true;
       return 0;
     };
-    const bool packed = fast && !getenv("BLASR_HIP_NO_FILL4");
     if (!packed) {
       rc = launch_wide();
       if (rc) return rc;
@@ -501,7 +553,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         for (int i = c.first; i < c.first + c.count; i++) {
           if (geo[i].status != 0) continue;
           if (geo[i].maxWidth <= w4) at[maxRows - geo[i].rows + 1]++;  // slot 0 = the longest
-          else list1.push_back(i);
+          else if (!hybrid) list1.push_back(i);
         }
         for (int32_t r = 0; r <= maxRows; r++) at[r + 1] += at[r];
         list4.resize((size_t)at[maxRows + 1]);

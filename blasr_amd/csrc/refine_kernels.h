@@ -91,6 +91,7 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 // four candidates per wavefront (tagged-key variant only); args.taskList / args.count name the candidates
 void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream);
 int fill4_max_width();
+void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream);
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
 // *total holds the op count of all candidates before `first` on entry and including them on exit
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,

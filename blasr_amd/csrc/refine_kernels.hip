@@ -30,6 +30,8 @@
 #include <stdint.h>
 
 #include "refine_kernels.h"
+#include <type_traits>
+
 #include "wave_utils.h"
 
 namespace blasr_hip {
@@ -649,14 +651,22 @@ typedef uint16_t __attribute__((aligned(1))) unaligned_u16;
 
 // kExt0: the affine extension penalty is 0 (the reference's default): the D chain has no per-column term and the
 // extension of I is the value above itself -- six instructions less per row.
-template <int kL, bool kExt0>
+// kHybrid: the candidates with a row wider than kF4MaxWidth.  Their narrow rows (most of them: a wide row is what a
+// large gap of the guide leaves behind) run as above, several candidates to a wavefront; a wide row is taken by the
+// WHOLE wavefront, 64 columns per step (fill_kernel's ring path), through a per-candidate ring in global memory, while
+// the other candidates of the wavefront wait.  The row above moves between the LDS ring and the global ring when the
+// width class changes (at most kF4MaxWidth + 2 columns either way).
+template <int kL, bool kExt0, bool kHybrid>
 __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillArgs args) {
   constexpr int kT = 64 / kL;      // candidates per wavefront
   constexpr int kC = kF4Pass / kL;  // cells per lane and pass
+  typedef typename std::conditional<kHybrid, uint32_t, unsigned short>::type RowB;
+  constexpr int kQcShift = kHybrid ? 24 : 8;
+  constexpr unsigned kWidthMask = kHybrid ? 0xffffffu : 0xffu;
   __shared__ int2 ringLds[4][kT][kF4Ring];
   __shared__ uint32_t ringTLds[4][kT][kF4RingT];
   __shared__ int2 rowA[4][kT][64];          // per row of the current 64-row batch: {matrix offset, first column}
-  __shared__ unsigned short rowB[4][kT][64];  // width | query code << 8
+  __shared__ RowB rowB[4][kT][64];          // width | query code << 8 (<< 24 in the hybrid variant)
   __shared__ uint32_t packedCol[8];        // per target code: the matrix column for queries A,C,G,T, one byte each
   if (threadIdx.x < 5) {
     uint32_t v = 0;
@@ -675,7 +685,15 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   int taskG[kT], qG[kT];
   const int2 *rowTabG[kT];
   const unsigned short *rowMetaG[kT];
-  int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0;
+  // hybrid variant: what the wavefront needs of a candidate when it takes one of its wide rows
+  int tEndG[kT], tLenG[kT], gMaskG[kT];
+  unsigned cellsG[kT];
+  const uint8_t *tSeqG[kT];
+  uint8_t *arrowsG[kT];
+  int2 *gRingG[kT];
+  int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0, myGMask = 0;
+  bool myPrevGlobal = false;  // the row above lives in the global ring (the last row was a wide one)
+  int2 *myGRing = nullptr;
   const uint8_t *myTSeq = nullptr;
   uint8_t *myArrows = nullptr;
 #pragma unroll
@@ -684,9 +702,29 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
     qG[g] = 0;
     rowTabG[g] = nullptr;
     rowMetaG[g] = nullptr;
-    if (slot0 + g < args.count) {
+    tEndG[g] = tLenG[g] = gMaskG[g] = 0;
+    cellsG[g] = 0;
+    tSeqG[g] = nullptr;
+    arrowsG[g] = nullptr;
+    gRingG[g] = nullptr;
+    if (slot0 + g < args.count && args.taskList[slot0 + g] >= 0) {  // (the hybrid list has empty slots: -1)
       const int task = args.taskList[slot0 + g];
       taskG[g] = task;
+      if (kHybrid) {
+        const int32_t *blk = batch.blocks + 3 * batch.blk_off[task];
+        const int nb = batch.n_blocks[task];
+        tEndG[g] = blk[3 * (nb - 1) + 1] + blk[3 * (nb - 1) + 2];
+        tLenG[g] = batch.t_len[task];
+        cellsG[g] = (unsigned)args.geo[task].cells;
+        tSeqG[g] = batch.seq + batch.t_off[task];
+        arrowsG[g] = args.arrows + args.arrowOff[task];
+        gMaskG[g] = args.wideRingSize[slot0 + g] - 1;
+        gRingG[g] = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot0 + g]);
+        if (grp == g) {
+          myGMask = gMaskG[g];
+          myGRing = gRingG[g];
+        }
+      }
       const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
       const int nBlocks = batch.n_blocks[task];
       GuideCursor cur;
@@ -721,10 +759,23 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
     pExt[j] = (kC * l + j) * kExt;
   }
   // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open
-  if (myTask >= 0)
+  if (kHybrid && myTask >= 0 && myPhi - myPlo + 1 > kF4MaxWidth) {  // a wide row 0 goes straight to the global ring
+    for (int c = myPlo + l; c <= myPhi; c += kL) myGRing[c & myGMask] = make_int2((c - myPlo) * kDel, kOpen);
+    myPrevGlobal = true;
+  } else if (myTask >= 0) {
     for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+  }
   myTLoaded = myPlo < 0 ? 0 : myPlo;
+  if (kHybrid) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  RowConsts<true> kc;  // the wide rows' constants (row_chunk)
+  kc.inf = inf;
+  kc.ins = kIns;
+  kc.del = kDel;
+  kc.open = kOpen;
+  kc.ext = kExt;
+  kc.laneDel = lane * kDel;
+  kc.laneExt = lane * kExt;
 
   int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
   for (int r0 = 1; r0 <= maxQ; r0 += 64) {
@@ -741,17 +792,29 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
         if (lane < nRows) {
           const int2 rec = rowTabG[g][r0 + lane];
           const unsigned m = rowMetaG[g][r0 + lane];
-          const int width = (int)(m & 0xfffu), qc = (int)(m >> 12);
+          int width = (int)(m & 0xfffu);
+          const int qc = (int)(m >> 12);
           loV = rec.y;
+          if (kHybrid && width == 0xfff) {  // saturated: the row's cells are what lies before the next row's first one
+            const unsigned next = r0 + lane < qG[g] ? (unsigned)rowTabG[g][r0 + lane + 1].x : cellsG[g];
+            const int hi = loV + (int)(next - (unsigned)rec.x) - 1;
+            width = min(hi, tEndG[g] - 1) - loV + 1;
+          }
           rowA[wave][g][lane] = rec;
-          rowB[wave][g][lane] = (unsigned short)(width | (qc << 8));
-          passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
-          lastV = loV + width - 1;
+          rowB[wave][g][lane] = (RowB)((unsigned)width | ((unsigned)qc << kQcShift));
+          if (!kHybrid || width <= kF4MaxWidth) {
+            passesV = max(passesV, (width + kF4Pass - 1) / kF4Pass);
+            lastV = loV + width - 1;
+          }
           nV = nV || qc >= 4;
         }
         const int hMax = wave_max(lastV);
         spanBad = spanBad || hMax + kL - __builtin_amdgcn_readlane(loV, 0) > kF4RingT;
-        if (grp == g) myHmax = hMax;
+        if (grp == g) {
+          myHmax = hMax;
+          // columns left of the batch's first row are never read again (the rows' first columns only grow)
+          if (kHybrid) myTLoaded = max(myTLoaded, __builtin_amdgcn_readlane(loV, 0));
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -773,11 +836,114 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
     const int nRowsMax = min(64, maxQ - r0 + 1);
     for (int i = 0; i < nRowsMax; i++) {
       const int r = r0 + i;
-      const bool rowOn = myTask >= 0 && r <= myQ;
       const int2 rec = rowA[wave][grp][i];
       const unsigned wb = rowB[wave][grp][i];
-      const int lo = rec.y, width = (int)(wb & 0xffu), qc = (int)(wb >> 8);
+      const int lo = rec.y, width = (int)(wb & kWidthMask), qc = (int)(wb >> kQcShift);
       const int hiC = lo + width - 1;
+      const bool isWide = kHybrid && width > kF4MaxWidth;
+      const bool rowAll = myTask >= 0 && r <= myQ;
+      if (kHybrid) {
+        const unsigned long long wideMask = __ballot(rowAll && isWide);
+        if (wideMask != 0ull) {
+#pragma unroll
+          for (int g = 0; g < kT; g++) {
+            if (((wideMask >> (g * kL)) & 1ull) == 0ull) continue;
+            // ---- one wide row of candidate g, the whole wavefront on it (fill_kernel's ring path)
+            const int src = g * kL;
+            const int wLo = __builtin_amdgcn_readlane(lo, src), wHi = __builtin_amdgcn_readlane(hiC, src);
+            const int wPlo = __builtin_amdgcn_readlane(myPlo, src), wPhi = __builtin_amdgcn_readlane(myPhi, src);
+            const int wQc = __builtin_amdgcn_readlane(qc, src);
+            const unsigned wRow = (unsigned)__builtin_amdgcn_readlane(rec.x, src);
+            const bool wGlobal = __builtin_amdgcn_readlane((int)myPrevGlobal, src) != 0;
+            int2 *gring = gRingG[g];
+            const int gmask = gMaskG[g];
+            if (!wGlobal) {  // the row above is a narrow one: from the LDS ring into the global ring
+              for (int c = wPlo + lane; c <= wPhi; c += 64) gring[c & gmask] = ringLds[wave][g][c & (kF4Ring - 1)];
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            // Which of this row's {S, I} the next row can read: when that row is a narrow one of the same batch, only
+            // its own columns (and one to their left); the candidate's last row only feeds the final score.  The
+            // others are not stored -- most of a wide row, which nothing below it ever looks at.
+            int keepLo = INT32_MIN, keepHi = INT32_MAX;
+            if (r == qG[g]) {
+              keepLo = keepHi = tEndG[g] - 1;
+            } else if (i + 1 < 64) {
+              const int nLo = rowA[wave][g][i + 1].y;
+              const int nWidth = (int)((unsigned)rowB[wave][g][i + 1] & kWidthMask);
+              if (nWidth <= kF4MaxWidth) {
+                keepLo = nLo - 1;
+                keepHi = nLo + nWidth - 1;
+              }
+            }
+            uint8_t *wArrows = arrowsG[g] + wRow;
+            const uint8_t *wT = tSeqG[g];
+            const int wTLen = tLenG[g];
+            ChunkCarry carry;
+            carry.a = carry.b = carry.s = inf;
+            int cDiag = 0;
+            // the target bases and the row above run one step ahead of their use (nothing a step stores is read
+            // by a later step of the same row, bar column cb-1, which travels in cDiag)
+            int tNext = (wLo + lane >= 0 && wLo + lane < wTLen) ? (int)wT[wLo + lane] : 'N';
+            int2 upNext = make_int2(inf, inf);
+            int sdNext = inf;
+            if (wLo <= wPhi + 1) {
+              upNext = gring[(wLo + lane) & gmask];
+              sdNext = gring[(wLo + lane - 1) & gmask].x;
+            }
+            for (int cb = wLo; cb <= wHi; cb += 64) {
+              const int c = cb + lane;
+              const bool active = c <= wHi;
+              const int tCur = tNext;
+              int2 up = upNext;
+              int sd = sdNext;
+              if (cb + 64 <= wHi) {
+                tNext = (c + 64 >= 0 && c + 64 < wTLen) ? (int)wT[c + 64] : 'N';
+                if (cb + 64 <= wPhi + 1) {  // beyond the row above there is nothing to read
+                  upNext = gring[(c + 64) & gmask];
+                  sdNext = gring[(c + 63) & gmask].x;
+                } else {
+                  upNext = make_int2(inf, inf);
+                  sdNext = inf;
+                }
+              }
+              if (cb <= wPhi + 1) {
+                if (cb > wLo) sd = (lane == 0) ? cDiag : sd;  // column cb-1 is overwritten by the previous step
+                cDiag = __builtin_amdgcn_readlane(up.x, 63);
+                const bool upValid = c <= wPhi, diagValid = (c - 1 <= wPhi) && (c > wPlo);
+                up.x = upValid ? up.x : inf;
+                up.y = upValid ? up.y : inf;
+                sd = diagValid ? sd : inf;
+              }
+              const int tcode = base_code((unsigned)tCur);
+              const int mm = wQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedCol[tcode], (wQc & 3) * 8, 8) : matN[tcode];
+              int sv, iv, arrow;
+              row_chunk<true, false>(kc, carry, active, up.x, up.y, sd, mm, sv, iv, arrow);
+              if (active) {
+                if (c >= keepLo && c <= keepHi) gring[c & gmask] = make_int2(sv, iv);
+                wArrows[c - wLo] = (uint8_t)arrow;
+              }
+            }
+            // (this row's stores are read by the next row only: one wait for all of them)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (grp == g) {
+              myPlo = wLo;
+              myPhi = wHi;
+              myPrevGlobal = true;
+            }
+          }
+        }
+        // ---- back to narrow rows: the columns this row reads of the wide row above, into the LDS ring
+        if (__ballot(rowAll && !isWide && myPrevGlobal) != 0ull) {
+          if (rowAll && !isWide && myPrevGlobal) {
+            for (int c = lo - 1 + l; c <= min(hiC, myPhi); c += kL)
+              if (c >= myPlo) ring[c & (kF4Ring - 1)] = myGRing[c & myGMask];
+            myPrevGlobal = false;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      const bool rowOn = rowAll && !isWide;
+      if (kHybrid && rowOn) myTLoaded = max(myTLoaded, lo);
       // ---- stage the packed matrix columns of the target up to this row's last column
       while (!ahead && __ballot(rowOn && myTLoaded <= hiC) != 0ull) {
         if (rowOn && myTLoaded <= hiC) {
@@ -915,11 +1081,14 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   }
   // ---- S[Q][tEnd-1] (:481-483): a candidate's ring is not written after its last row
   if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
-    args.dpScore[myTask] = ring[(myTEnd - 1) & (kF4Ring - 1)].x >> kShift;
+    args.dpScore[myTask] =
+        (kHybrid && myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
 }
-template __global__ void fillp_kernel<16, true>(RefineBatchView, FillArgs);
-template __global__ void fillp_kernel<16, false>(RefineBatchView, FillArgs);
-template __global__ void fillp_kernel<8, false>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, true, false>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, false, false>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<8, false, false>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, true, true>(RefineBatchView, FillArgs);
+template __global__ void fillp_kernel<16, false, true>(RefineBatchView, FillArgs);
 
 template __global__ void fill_kernel<false, true>(RefineBatchView, FillArgs);
 template __global__ void fill_kernel<false, false>(RefineBatchView, FillArgs);
@@ -1337,11 +1506,19 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream) {
   if (args.count <= 0) return;
   if (lanes == 16 && args.ext == 0)
-    hipLaunchKernelGGL((fillp_kernel<16, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+    hipLaunchKernelGGL((fillp_kernel<16, true, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else if (lanes == 16)
-    hipLaunchKernelGGL((fillp_kernel<16, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+    hipLaunchKernelGGL((fillp_kernel<16, false, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else
-    hipLaunchKernelGGL((fillp_kernel<8, false>), dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+    hipLaunchKernelGGL((fillp_kernel<8, false, false>), dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+}
+// the candidates with wide rows: args.taskList = the list, args.wideRingOff / wideRingSize indexed like it
+void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {
+  if (args.count <= 0) return;
+  if (args.ext == 0)
+    hipLaunchKernelGGL((fillp_kernel<16, true, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
+  else
+    hipLaunchKernelGGL((fillp_kernel<16, false, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
 }
 int fill4_max_width() { return kF4MaxWidth; }
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {

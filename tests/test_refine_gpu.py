@@ -203,7 +203,7 @@ def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
         assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
 
 
-@pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_FILL4"])
+@pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4"])
 def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch):
     """Guides whose consecutive blocks drift by hundreds to thousands of columns (what SDPAlign(Local) makes of a repeat
     copy the read overlaps only in part: it chains on through chance fragments): rows of band + |drift| cells, on
@@ -237,5 +237,45 @@ def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.status == 0, i
         assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
+    if switch:
+        monkeypatch.delenv(switch)
+
+
+@pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID"])
+def test_guides_with_several_gaps_share_wavefronts(ctx, oracle, monkeypatch, switch):
+    """What the hybrid fill kernel is for (candidates whose rows are narrow except where the guide jumps): guides of
+    3-7 short blocks with gaps of tens to thousands of columns and rows between them, in either direction and back to
+    back, unequal lengths, so that the four candidates of a wavefront meet their wide rows at different times, some in
+    consecutive rows, some in the first rows; also a batch of fewer candidates than a wavefront holds."""
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    rng = np.random.default_rng(4242)
+    for n_cand in (3, 41):
+        b, want = blasr_amd.RefineBatch(), []
+        for it in range(n_cand):
+            nb = int(rng.integers(3, 8))
+            q = t = int(rng.integers(0, 30))
+            blocks = []
+            for k in range(nb):
+                length = int(rng.integers(8, 40))
+                blocks.append([q, t, length])
+                step = int(rng.integers(20, 400))
+                gap = int(rng.choice([0, 30, 120, 200, 700, 2500, 5000])) if k + 1 < nb else 0
+                if it % 7 == 0 and k == 0:
+                    gap = 1800  # a jump right after the first block: the first rows are the wide ones
+                kind = int(rng.integers(0, 3))
+                q += length + step + (gap if kind == 1 else 0)
+                t += length + step + (gap if kind == 0 else 0) + (gap // 3 if kind == 2 else 0)
+            qs = synth.random_genome(q + 30, int(rng.integers(1, 1 << 30)))
+            ts = synth.random_genome(t + 30, int(rng.integers(1, 1 << 30)))
+            for (bq, bt, bl) in blocks:  # the blocks are exact matches, as SDP's are
+                ts[bt: bt + bl] = qs[bq: bq + bl]
+            bl = np.array(blocks, dtype=np.int32)
+            b.add(qs, ts, bl)
+            want.append(oracle.affine_guided_align(qs, ts, bl))
+        got = ctx.refine(b)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.status == 0, (n_cand, i)
+            assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, (n_cand, i)
     if switch:
         monkeypatch.delenv(switch)
