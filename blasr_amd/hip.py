@@ -41,6 +41,7 @@ EXPORTS = [
     "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
+    "blasr_hip_build_suffix_array", "blasr_hip_sa_write",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -304,6 +305,8 @@ def load_library():
                                                     C.POINTER(_AnchorParams), C.c_void_p, C.c_int64,
                                                     C.POINTER(C.c_int64), C.c_void_p]
         lib.blasr_hip_anchor_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        lib.blasr_hip_build_suffix_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.blasr_hip_sa_write.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         lib.blasr_hip_interval_default_params.argtypes = [C.POINTER(_IntervalParams)]
         lib.blasr_hip_count_tuples.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.blasr_hip_find_intervals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -718,6 +721,7 @@ class Context:
     def upload_genome(self, genome, contig_starts=None):
         genome = np.ascontiguousarray(genome, dtype=np.uint8)
         self._genome_keepalive = genome
+        self.genome_length = len(genome)
         cs, nc = None, 0
         if contig_starts is not None:
             cs = np.ascontiguousarray(contig_starts, dtype=np.uint32)
@@ -771,6 +775,7 @@ class Context:
             nc = len(cs) - 1
         self._check(self.lib.blasr_hip_adopt_genome_device(self.handle, C.c_void_p(genome_ptr), int(length),
                                                            cs.ctypes.data if cs is not None else None, nc))
+        self.genome_length = int(length)
 
     # --- MapRead from the intervals on (Blasr.cpp:2530-2644), C++ driver inside the library ---
     def map_params(self, **kw):
@@ -868,6 +873,21 @@ class Context:
                                                            sp.ctypes.data if len(sp) else None,
                                                            ep.ctypes.data if len(ep) else None, C.c_int64(len(sp)),
                                                            int(sa["lookup_prefix_length"])))
+
+    def build_suffix_array(self, lookup_prefix_length=8, download=True):
+        """The suffix array of the uploaded genome and its lookup table, built on the device (what the reference's
+        sawriter computes); it stays resident for anchor_reads.  With download: the dict read_suffix_array returns."""
+        n = self.genome_length
+        tl = (1 << (2 * lookup_prefix_length)) if lookup_prefix_length else 0
+        idx = np.zeros(n if download else 0, np.uint32)
+        sp, ep = np.zeros(tl if download else 0, np.uint32), np.zeros(tl if download else 0, np.uint32)
+        self._check(self.lib.blasr_hip_build_suffix_array(self.handle, lookup_prefix_length,
+                                                          idx.ctypes.data if download else None,
+                                                          sp.ctypes.data if download and tl else None,
+                                                          ep.ctypes.data if download and tl else None))
+        if download:
+            return dict(index=idx, start_pos_table=sp, end_pos_table=ep, lookup_prefix_length=lookup_prefix_length)
+        return None
 
     def anchor_params(self, **kw):
         """blasr_hip_anchor_params with the reference's defaults; keyword overrides by field name."""
@@ -1118,6 +1138,17 @@ def read_genome(path):
     if got < 0:
         raise BlasrHipError(int(got), "fasta_concatenate")
     return genome[:total], starts, names
+
+
+def write_suffix_array(path, sa):
+    """SuffixArray::Write as sawriter calls it: the index array and the lookup table of `sa` (a read_suffix_array dict)."""
+    idx = np.ascontiguousarray(sa["index"], dtype=np.uint32)
+    sp = np.ascontiguousarray(sa["start_pos_table"], dtype=np.uint32)
+    ep = np.ascontiguousarray(sa["end_pos_table"], dtype=np.uint32)
+    rc = load_library().blasr_hip_sa_write(path.encode(), idx.ctypes.data, len(idx), sp.ctypes.data if len(sp) else None,
+                                           ep.ctypes.data if len(ep) else None, len(sp), int(sa["lookup_prefix_length"]))
+    if rc != OK:
+        raise BlasrHipError(rc, "sa_write %s" % path)
 
 
 def read_suffix_array(path):

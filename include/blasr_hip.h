@@ -704,6 +704,20 @@ int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const
                              blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
                              int64_t *read_interval_off);
 
+/* ------------------------------------------------------------------------------------------------
+ * next-4: the suffix array and its lookup table built on the device, and sawriter's file written.  Replaces
+ * LarssonBuildSuffixArray + BuildLookupTable (common/datastructures/suffixarray/SuffixArray.h:256-269, :193-249) as
+ * Blasr.cpp runs them when no .sa is given (alignment/Blasr.cpp:4407-4421) and as sawriter does
+ * (alignment/SAWriter.cpp:187-232), and SuffixArray::Write (:505-532).  The array of the uploaded genome stays
+ * resident for blasr_hip_anchor_reads_*; the host copies are optional (index_out: genome length entries,
+ * start_pos_out / end_pos_out: 4^lookup_prefix_length entries; lookup_prefix_length 0..14, 0 = no table).
+ * Working memory on the device: 32 bytes per genome base.
+ * ------------------------------------------------------------------------------------------------ */
+int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_length, uint32_t *index_out,
+                                 uint32_t *start_pos_out, uint32_t *end_pos_out);
+int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, const uint32_t *start_pos_table,
+                       const uint32_t *end_pos_table, int64_t lookup_table_length, int32_t lookup_prefix_length);
+
 #ifdef __cplusplus
 }
 #endif
