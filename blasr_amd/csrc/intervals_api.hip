@@ -592,7 +592,7 @@ int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t
   for (int64_t i = 0; i < genome_length; i++) {
     if (is_actg(genome[i])) {
       tuple = ((tuple << 2) + (uint64_t)two_bit(genome[i])) & mask;
-      valid++;
+      if (valid < tuple_size) valid++;  // (saturating: a run of ACGT can be longer than an int counts)
     } else {
       valid = 0;
       tuple = 0;

@@ -497,6 +497,21 @@ void *ref_sa_open(const char *path) {
   return sa;
 }
 void ref_sa_close(void *h) { delete (DNASuffixArray *)h; }
+// The same object over arrays that are already in memory (the caller keeps them alive): what SuffixArray::Read leaves
+// behind, without the file (:577-583 for the tuple metrics).
+void *ref_sa_adopt(unsigned *index, unsigned length, unsigned *startPosTable, unsigned *endPosTable,
+                   unsigned lookupTableLength, unsigned lookupPrefixLength) {
+  DNASuffixArray *sa = new DNASuffixArray;
+  sa->deleteStructures = false;
+  sa->index = index;
+  sa->length = length;
+  sa->startPosTable = startPosTable;
+  sa->endPosTable = endPosTable;
+  sa->lookupTableLength = lookupTableLength;
+  sa->lookupPrefixLength = lookupPrefixLength;
+  sa->tm.Initialize(lookupPrefixLength);
+  return sa;
+}
 
 // ap[7] = minMatchLength, expand, useLookupTable, maxAnchorsPerPosition, advanceExactMatches, maxLCPLength,
 // stopMappingOnceUnique.  strand 1 maps the reverse complement with Blasr.cpp:3449-3450's subread coordinates.

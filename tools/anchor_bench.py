@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""next-1, device half, measured: blasr_hip_anchor_reads_device on reads sampled from a synthetic genome whose suffix
-array the reference's own sawriter builds on the spot (oracle/_ref/sawritermc travels to the GPU box prebuilt), with the
+"""next-1 measured: blasr_hip_anchor_reads_device on reads sampled from a synthetic genome whose suffix array
+blasr_hip_build_suffix_array builds on the device (--sa sawriter: the reference's own tool instead), with the
 reference's MapReadToGenome (oracle/_ref/libblasr_refmapper.so, one host thread) timed beside it on a bounded sample of
 the same reads and every anchor of that sample compared.  One JSON line.
 
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=40)
     ap.add_argument("--blt", type=int, default=0)
     ap.add_argument("--families", type=int, default=200)
+    ap.add_argument("--sa", choices=("device", "sawriter"), default="device")
     args = ap.parse_args()
     import blasr_amd
     from blasr_amd import hip, synth
@@ -62,16 +63,25 @@ def main():
         off += len(rd)
     pool = np.concatenate(pool)
     tmp = tempfile.mkdtemp(prefix="anchor_bench_")
-    t0 = time.time()
-    fasta = b">g\n" + bytes(genome) + b"\n"
-    G, starts, sa, sa_path = T.write_suffix_array(tmp, fasta, args.blt or None)
-    t_sa = time.time() - t0
+    ctx = blasr_amd.Context(0)
+    if args.sa == "sawriter":
+        t0 = time.time()
+        fasta = b">g\n" + bytes(genome) + b"\n"
+        G, starts, sa, sa_path = T.write_suffix_array(tmp, fasta, args.blt or None)
+        t_sa = time.time() - t0
+        ctx.upload_genome(G)
+        ctx.upload_suffix_array(sa)
+    else:
+        G = np.concatenate([genome, np.array([ord("N")], np.uint8)])  # one contig and the N after it
+        starts = np.array([0, len(G)], np.uint32)
+        ctx.upload_genome(G)
+        t0 = time.time()
+        sa = ctx.build_suffix_array(args.blt or 13)  # sawriter's default prefix
+        t_sa = time.time() - t0
+    del genome
     prefix = int(sa["lookup_prefix_length"])
     min_match = max(14, prefix)
 
-    ctx = blasr_amd.Context(0)
-    ctx.upload_genome(G)
-    ctx.upload_suffix_array(sa)
     p = ctx.anchor_params(min_match_length=min_match, min_prefix_match_length=8)
     mem = T.DeviceMemory()
     d_pool = mem.upload(pool)
@@ -95,8 +105,10 @@ def main():
     cpu = None
     if os.path.exists(T.REFMAPPER_SO):
         ref = C.CDLL(T.REFMAPPER_SO)
-        ref.ref_sa_open.restype = C.c_void_p
-        h = ref.ref_sa_open(sa_path.encode())
+        ref.ref_sa_adopt.restype = C.c_void_p
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        h = ref.ref_sa_adopt(vp(sa["index"]), len(sa["index"]), vp(sa["start_pos_table"]), vp(sa["end_pos_table"]),
+                             len(sa["start_pos_table"]), prefix)
         aps = (min_match, 0, 1, 1000, 0, 0, 1)
         k = min(args.cpu_reads, args.reads)
         differ, t_cpu, n_cpu = 0, 0.0, 0
@@ -157,7 +169,7 @@ def main():
                bases_per_s=round(total_bases / (best[0] / 1e3)),
                probes_per_s=round(probes / (best[1] / 1e3)) if best[1] > 0 else None,
                sector_GBps=round(probes * 64 / (best[1] / 1e3) / 1e9, 1) if best[1] > 0 else None,
-               sa_build_s=round(t_sa, 1), cpu_baseline=cpu, host_half=host)
+               sa_build=args.sa, sa_build_s=round(t_sa, 1), cpu_baseline=cpu, host_half=host)
     if cpu:
         out["vs_cpu_thread"] = round(out["bases_per_s"] / cpu["bases_per_s"], 1)
     print(json.dumps(out))
