@@ -85,6 +85,7 @@ struct AnchorArgs {
   const uint8_t *genome;
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
+  const uint32_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
   int prefixLen;
   const uint8_t *pool;
   const AnchorSeg *seg;
@@ -115,21 +116,65 @@ __device__ __forceinline__ int segment_of(const int64_t *posOff, int nSeg, int64
   return lo;
 }
 
+// The companion of the index array: for the suffix at array position m, the kExtBases bases that follow its first
+// `prefixLen` ones -- bits 2k, 2k+1 = base k, bits 26-29 = how many of them are ACGT before the first that is not,
+// bit 31 = that first one is the end of the genome (not an N).  Inside a search range every suffix shares the bases
+// matched so far with the read, so the symbol at the next offset is always among those: ONE load per probe, from an
+// array the binary search walks with locality, instead of index[m] and then genome[index[m] + offset].
+constexpr int kExtBases = 13;
+
+__global__ __launch_bounds__(256) void anchor_ext_kernel(const uint8_t *genome, uint32_t tlen, const uint32_t *index,
+                                                         int64_t n, int prefixLen, uint32_t *ext) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= n) return;
+  const uint64_t base = (uint64_t)index[m] + (uint64_t)prefixLen;
+  uint32_t bits = 0, vl = 0, end = 0;
+  for (int k = 0; k < kExtBases; k++) {
+    if (base + k >= tlen) {
+      end = 1;
+      break;
+    }
+    const int c = kThreeBit.v[genome[base + k]];
+    if (c >= 4) break;
+    bits |= (uint32_t)c << (2 * k);
+    vl++;
+  }
+  ext[m] = bits | (vl << 26) | (end << 31);
+}
+
+// What the suffix at array position m holds `offset` bases in: 0..3 that base, 4 a base that is not ACGT, 5 nothing
+// (the suffix ends exactly there), 6 the suffix is shorter still.
+__device__ __forceinline__ int suffix_symbol(const AnchorArgs &a, const uint8_t *three, uint32_t m, uint32_t offset,
+                                             unsigned &probes) {
+  probes++;
+  const uint32_t k = offset - (uint32_t)a.prefixLen;  // (wraps to a large number below the prefix)
+  if (a.ext && k < (uint32_t)kExtBases) {
+    const uint32_t w = a.ext[m];
+    const uint32_t vl = (w >> 26) & 15u;
+    if (k < vl) return (int)((w >> (2 * k)) & 3u);
+    if (k == vl) return (w >> 31) ? 5 : 4;
+    // (k > vl: not for a suffix of the current range; the general path answers)
+  }
+  const uint32_t im = a.index[m];
+  const uint32_t sufLen = a.tlen - im;
+  if (sufLen == offset) return 5;
+  if (sufLen < offset) return 6;
+  const int t = three[a.genome[(uint64_t)im + offset]];
+  return t < 4 ? t : 4;
+}
+
 // SearchLeftBound (SuffixArray.h:733-775)
 __device__ __forceinline__ uint32_t left_bound(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq,
                                                uint32_t l, uint32_t r, unsigned &probes) {
   uint32_t ll = l, lr = r;
   while (ll < lr) {
     const uint32_t m = ll + ((lr - ll) >> 1);
-    const uint32_t im = a.index[m];
-    probes++;
-    const uint32_t sufLen = a.tlen - im;
-    if (sufLen == offset) {
+    const int sym = suffix_symbol(a, three, m, offset, probes);
+    if (sym == 5) {
       ll = m + 1;
       continue;
     }
-    int comp = -1;
-    if (sufLen > offset) comp = (int)three[a.genome[(uint64_t)im + offset]] - tq;
+    const int comp = sym == 6 ? -1 : sym - tq;
     if (comp < 0)
       ll = m + 1;
     else
@@ -144,21 +189,17 @@ __device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8
   uint32_t rl = l, rr = r;
   while (rl < rr) {
     const uint32_t m = rl + ((rr - rl) >> 1);
-    const uint32_t im = a.index[m];
-    probes++;
-    const uint32_t sufLen = a.tlen - im;
-    if (sufLen == offset) {
+    const int sym = suffix_symbol(a, three, m, offset, probes);
+    if (sym == 5) {
       rr = m;
       break;
     }
-    if (sufLen < offset) {
+    if (sym == 6) {
       rr = m;
+    } else if (sym - tq <= 0) {
+      rl = m + 1;
     } else {
-      const int comp = (int)three[a.genome[(uint64_t)im + offset]] - tq;
-      if (comp <= 0)
-        rl = m + 1;
-      else
-        rr = m;
+      rr = m;
     }
   }
   return rr;
@@ -209,18 +250,13 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   while (searching && l < r && lcp < queryLength) {  // SuffixArray.h:996-1067
     if (a.stopUnique && l == r - 1) break;
     if (a.maxLcp && lcp >= (uint32_t)a.maxLcp) break;
-    {
-      const uint64_t at = (uint64_t)a.index[l] + lcp;
-      probes++;
-      if (at >= a.tlen || three[a.genome[at]] >= 4) break;  // a genome as Blasr holds it ends in 'N': at < tlen
-    }
+    // the next genome base is an N (a genome as Blasr holds it ends in one, so the array never runs past it)
+    if (suffix_symbol(a, three, l, lcp, probes) >= 4) break;
     const int tq = three[strand_base(a.pool, s, p + lcp)];
     l = left_bound(a, three, lcp, tq, l, r, probes);
     r = right_bound(a, three, lcp, tq, l, r, probes);
     if (l == r) break;
-    const uint64_t at = (uint64_t)a.index[l] + lcp;
-    probes++;
-    if (at >= a.tlen || tq >= 4 || (int)three[a.genome[at]] != tq) break;
+    if (tq >= 4 || suffix_symbol(a, three, l, lcp, probes) != tq) break;
 #pragma unroll
     for (int i = kHist - 1; i > 0; i--) {
       hl[i] = hl[i - 1];
@@ -435,6 +471,7 @@ int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int
   if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
+  ctx->saExtIndex = nullptr;  // (the companion array of the old index is stale)
   ctx->saLen = ctx->saTableLen = 0;
   ctx->saPrefixLen = 0;
   HIP_TRY(ctx, hipMalloc(&ctx->saIndex, sizeof(uint32_t) * (size_t)length));
@@ -530,6 +567,17 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     }
   }
 
+  // the companion array of the index, made once per (genome, index) pair
+  const bool useExt = !getenv("BLASR_HIP_ANCHOR_NO_EXT");
+  if (useExt && (!ctx->saExt || ctx->saExtGenome != ctx->genome || ctx->saExtIndex != ctx->saIndex)) {
+    if (ctx->saExt) (void)hipFree(ctx->saExt);
+    ctx->saExt = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint32_t) * (size_t)ctx->saLen));
+    hipLaunchKernelGGL(anchor_ext_kernel, dim3((unsigned)((ctx->saLen + 255) / 256)), dim3(256), 0, st, ctx->genome,
+                       (uint32_t)ctx->genomeLen, ctx->saIndex, ctx->saLen, ctx->saPrefixLen, ctx->saExt);
+    ctx->saExtGenome = ctx->genome;
+    ctx->saExtIndex = ctx->saIndex;
+  }
   Events ev;
   for (auto &e : ev.e) HIP_TRY(ctx, hipEventCreate(&e));
   const bool countProbes = getenv("BLASR_HIP_ANCHOR_COUNT_PROBES") != nullptr;
@@ -595,6 +643,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.index = ctx->saIndex;
     a.startPos = ctx->saStartPos;
     a.endPos = ctx->saEndPos;
+    a.ext = useExt ? ctx->saExt : nullptr;
     a.prefixLen = ctx->saPrefixLen;
     a.pool = read_pool;
     a.seg = dSeg;

@@ -177,6 +177,7 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   for (auto &b : ctx->anchorBuf)
     if (b.p) (void)hipFree(b.p);
   if (ctx->saIndex) (void)hipFree(ctx->saIndex);
+  if (ctx->saExt) (void)hipFree(ctx->saExt);
   if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   delete ctx;
@@ -197,7 +198,7 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
   for (const auto &b : ctx->mapBuf) total += (int64_t)b.bytes;
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
   for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
-  total += 4 * ctx->saLen + 8 * ctx->saTableLen;
+  total += (ctx->saExt ? 8 : 4) * ctx->saLen + 8 * ctx->saTableLen;
   return total;
 }
 

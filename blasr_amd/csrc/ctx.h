@@ -48,6 +48,10 @@ struct blasr_hip_ctx {
   uint32_t *saIndex = nullptr, *saStartPos = nullptr, *saEndPos = nullptr;
   int64_t saLen = 0, saTableLen = 0;
   int saPrefixLen = 0;
+  // per array position, the bases that follow the lookup prefix (anchor_api.hip: the search reads them instead of
+  // index[] + genome[]); built at the first anchor call for the (genome, index) pair it was made from
+  uint32_t *saExt = nullptr;
+  const void *saExtGenome = nullptr, *saExtIndex = nullptr;
   enum { kAnchorBufs = 4 };
   DevBuf anchorBuf[kAnchorBufs];  // sort keys / values of the anchor stage (double-buffered)
   float anchorMs[4] = {0, 0, 0, 0};

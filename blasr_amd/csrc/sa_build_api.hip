@@ -172,6 +172,7 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
+  ctx->saExtIndex = nullptr;  // (the companion array of the old index is stale)
   ctx->saLen = ctx->saTableLen = 0;
   ctx->saPrefixLen = 0;
   HIP_TRY(ctx, hipMalloc(&ctx->saIndex, 4 * (size_t)n));

@@ -146,6 +146,7 @@ void drop_genome(blasr_hip_ctx *ctx) {
   if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
   ctx->genome = nullptr;
+  ctx->saExtGenome = nullptr;  // (anchor_api.hip's companion array was made from this genome)
   ctx->genomeOwned = true;
   ctx->contigStarts = nullptr;
   ctx->genomeLen = 0;

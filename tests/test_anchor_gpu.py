@@ -155,6 +155,12 @@ def test_anchor_pieces_forward_only_capacity_and_device_entry(oracle, monkeypatc
     ctx.close()
 
 
+def test_anchors_without_the_companion_array(monkeypatch):
+    """BLASR_HIP_ANCHOR_NO_EXT: every probe through index[] and genome[] (the reference's own access pattern)."""
+    monkeypatch.setenv("BLASR_HIP_ANCHOR_NO_EXT", "1")
+    test_anchors_against_the_golden_lists_of_the_reference()
+
+
 def test_anchor_edges():
     z, sa = golden_case()
     genome, reads, pool = z["genome"], z["reads"], z["pool"]
