@@ -66,6 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpus", action="store_true",
                     help="let the ranks share the GPUs that exist (rank r on device r mod devices, gloo for the counters): "
                          "runs the N-rank path with the real device step on a box with fewer GPUs; the line says so")
+    ap.add_argument("--from-reads", type=int, default=0, metavar="STEPS",
+                    help="after the timed steps, also run STEPS passes of the WHOLE mapper from the reads alone (index "
+                         "built on the device, suffix-array anchoring, interval finding on the host, then the path) and "
+                         "report them as `end_to_end` (N=1 only; needs ~130 GB of HBM for an hg19-size genome)")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -235,6 +239,118 @@ def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole mapper from the reads alone (SURVEY next-1 + next-4 in front of the path): opt-in, reported beside the metric
+# ---------------------------------------------------------------------------------------------------------------
+def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
+    import numpy as np
+    import torch
+    from blasr_amd import hip
+    out = {"index_build_s": wl["index_build_s"]}
+    t0 = time.perf_counter()
+    genome_h = genome_t.cpu().numpy()  # the interval finder's p-values read the genome and its 8-mer counts on the host
+    seq_starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    count_table = hip.count_tuples(genome_h, 8)
+    out["host_genome_copy_and_count_table_s"] = round(time.perf_counter() - t0, 2)
+    reads, pool_ptr = wl["reads"], wl["pool"].data_ptr()
+    n_reads = len(reads)
+    ap = ctx.anchor_params(min_match_length=14, min_prefix_match_length=8)  # Blasr's values for a sawriter index
+    ip = hip.interval_params(threads=min(64, os.cpu_count() or 1))
+    cap = 20000 * n_reads
+    d_anchors = torch.empty(cap * 12, dtype=torch.uint8, device=dev)
+    h_anchors = torch.empty(cap * 12, dtype=torch.uint8).pin_memory()
+    # The reads go through the anchoring in blocks: while the device searches block b + 1, the host threads turn the
+    # anchors of block b into intervals (the reference does both per read on every mapping thread).  The path then
+    # runs on all intervals at once.
+    from concurrent.futures import ThreadPoolExecutor
+    n_blocks = max(1, min(16, n_reads // 5000))
+    cuts = [n_reads * b // n_blocks for b in range(n_blocks + 1)]
+    stages = {"anchor_device": 0.0, "anchors_to_host (issue only: the copy runs under the next block)": 0.0,
+              "find_intervals_host (overlapped with the two above)": 0.0,
+              "wait_for_last_intervals": 0.0, "map_reads_device": 0.0}
+    last = {}
+    anchor_ms = {}
+    host_pool = ThreadPoolExecutor(max_workers=1)
+
+    copy_stream = torch.cuda.Stream(device=dev)
+
+    def host_job(lo, hi, a_lo, n, list_off, copied):
+        copied.synchronize()
+        t0 = time.perf_counter()
+        rd = reads[lo:hi]
+        anchors = h_anchors.numpy()[a_lo * 12: (a_lo + n) * 12].view(hip.ANCHOR_DTYPE)
+        ivs, iv_off, _ = hip.find_intervals(genome_h, seq_starts, count_table, rd, anchors, list_off, ip)
+        ivs["read"] += lo
+        return ivs, iv_off, time.perf_counter() - t0
+
+    t_all = time.perf_counter()
+    for _ in range(steps):
+        jobs, used, n_total = [], 0, 0
+        for b in range(n_blocks):
+            lo, hi = cuts[b], cuts[b + 1]
+            t0 = time.perf_counter()
+            n, list_off = ctx.anchor_reads_device(reads[lo:hi], pool_ptr, ap, d_anchors.data_ptr() + used * 12, cap - used)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            # the anchors cross PCIe on a side stream, underneath the search of the next block
+            with torch.cuda.stream(copy_stream):
+                h_anchors[used * 12: (used + n) * 12].copy_(d_anchors[used * 12: (used + n) * 12], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+            t2 = time.perf_counter()
+            jobs.append(host_pool.submit(host_job, lo, hi, used, n, list_off, copied))
+            for k, v in ctx.anchor_last_timing().items():
+                if k.endswith("_ms"):
+                    anchor_ms[k] = anchor_ms.get(k, 0.0) + v
+            used += n
+            n_total += n
+            stages["anchor_device"] += t1 - t0
+            stages["anchors_to_host (issue only: the copy runs under the next block)"] += t2 - t1
+        t3 = time.perf_counter()
+        parts = [j.result() for j in jobs]
+        t4 = time.perf_counter()
+        ivs = np.concatenate([p[0] for p in parts])
+        iv_off = np.concatenate([[0]] + [p[1][1:] + sum(len(q[0]) for q in parts[:k]) for k, p in enumerate(parts)])
+        stages["find_intervals_host (overlapped with the two above)"] += sum(p[2] for p in parts)
+        stages["wait_for_last_intervals"] += t4 - t3
+        iv_t = torch.from_numpy(ivs.view(np.uint8)).to(dev)
+        hits = np.zeros(max(len(ivs), 1), dtype=hip.HIT_DTYPE)
+        hit_off = np.zeros(n_reads + 1, dtype=np.int64)
+        ctx.map_reads_device(n_reads, wl["reads_t"].data_ptr(), pool_ptr, len(ivs), iv_t.data_ptr(), params, hits, hit_off)
+        torch.cuda.synchronize()
+        stages["map_reads_device"] += time.perf_counter() - t4
+        last = dict(anchors=int(n_total), intervals=int(len(ivs)), timing=ctx.map_last_timing(), anchor=ctx.anchor_last_timing(),
+                    hit_off=hit_off, ivs=ivs, iv_off=iv_off)
+    host_pool.shutdown()
+    wall = (time.perf_counter() - t_all) / steps
+    # how many reads have their true locus among the candidate intervals (the synthetic set-up knows it)
+    true_iv = wl["intervals"][wl["kind"] == 0]
+    found = 0
+    ivs, iv_off = last["ivs"], last["iv_off"]
+    for k in range(0, len(true_iv), max(1, len(true_iv) // 2000)):
+        tv = true_iv[k]
+        mine = ivs[int(iv_off[tv["read"]]): int(iv_off[tv["read"] + 1])]
+        mid = (int(tv["start"]) + int(tv["end"])) // 2
+        found += bool(((mine["start"] <= mid) & (mine["end"] >= mid) & (mine["strand"] == tv["strand"])).any())
+    sampled = len(range(0, len(true_iv), max(1, len(true_iv) // 2000)))
+    tm = last["timing"]
+    out.update({
+        "what": "reads -> hits: MapReadToGenome x 2 strands + SortMatchPosList on the device, anchors to the host, "
+                "RemoveOverlappingAnchors / FindMaxIncreasingInterval / interval set on %d host threads (block b on the "
+                "host while the device anchors block b + 1), then the timed path of the metric on the intervals found "
+                "(instead of the synthetic ones)" % ip.threads,
+        "steps": steps, "ms_per_step": wall * 1e3, "reads_per_s": n_reads / wall,
+        "aligned_bases_per_s": tm["aligned_bases"] / wall,
+        "stage_ms_per_step": {k: v / steps * 1e3 for k, v in stages.items()},
+        "anchors_per_step": last["anchors"], "candidate_intervals": last["intervals"], "hits": int(tm["hits"]),
+        "aligned_reads": int(tm["aligned_reads"]),
+        "anchor_blocks": n_blocks, "anchor_device_ms_per_step": {k: v / steps for k, v in anchor_ms.items()},
+        "true_locus_among_intervals": "%d of %d sampled reads" % (found, sampled),
+    })
+    return out
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -310,6 +426,7 @@ def main():
     G = int(genome.numel())
     n_reads, n_iv = len(wl["reads"]), len(wl["intervals"])
     reads_t = torch.from_numpy(wl["reads"].view(np.uint8)).to(dev)
+    wl["reads_t"] = reads_t
     iv_t = torch.from_numpy(wl["intervals"].view(np.uint8)).to(dev)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
@@ -317,6 +434,13 @@ def main():
     ctx = blasr_amd.Context(device_index)
     ctx.set_workspace_limit((200 << 30) // (1 if not shared else -(-world // n_dev)))
     ctx.adopt_genome_device(genome.data_ptr(), G, starts.astype(np.uint32) if len(starts) > 2 else None)
+    if args.from_reads > 0 and world == 1:
+        # the index of the genome, built on the device while the 32 B per base it takes to build are still free
+        # (sawriter's default lookup prefix; the array stays resident for the end-to-end leg)
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        ctx.build_suffix_array(13, download=False)
+        wl["index_build_s"] = round(time.perf_counter() - t0, 2)
     params = ctx.map_params(band=args.band)
     hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
@@ -435,6 +559,12 @@ def main():
                 b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores))
                 if b is not None:
                     out["cpu_baseline_whole_blasr"] = b
+            if args.from_reads > 0:
+                torch.cuda.empty_cache()
+                out["end_to_end"] = end_to_end(ctx, genome, starts, wl, params, args.from_reads, dev)
+                if "cpu_baseline_whole_blasr" in out and out["cpu_baseline_whole_blasr"].get("reads_per_s"):
+                    out["end_to_end"]["vs_whole_blasr"] = (out["end_to_end"]["reads_per_s"] /
+                                                           out["cpu_baseline_whole_blasr"]["reads_per_s"])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -435,7 +435,7 @@ void launch_search(const AnchorArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(anchor_search_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
 }
 
-constexpr int64_t kPiecePositions = 48ll << 20;  // read positions searched per piece (20 bytes of arrays each)
+constexpr int64_t kPiecePositions = 48ll << 20;  // read positions searched per piece (24 bytes of arrays each)
 constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort call (rocprim counts in 32 bits)
 
 }  // namespace
@@ -578,8 +578,33 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     ctx->saExtGenome = ctx->genome;
     ctx->saExtIndex = ctx->saIndex;
   }
-  Events ev;
-  for (auto &e : ev.e) HIP_TRY(ctx, hipEventCreate(&e));
+  {  // pinned results: one int64 per list boundary of the largest piece (never more than all lists)
+    const size_t want = sizeof(int64_t) * ((size_t)nLists + 2);
+    if (ctx->anchorPinnedBytes < want) {
+      if (ctx->anchorPinned) (void)hipHostFree(ctx->anchorPinned);
+      ctx->anchorPinned = nullptr;
+      ctx->anchorPinnedBytes = 0;
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->anchorPinned, want, hipHostMallocDefault));
+      ctx->anchorPinnedBytes = want;
+    }
+    if (!ctx->anchorFlags) HIP_TRY(ctx, hipMalloc((void **)&ctx->anchorFlags, 16));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->anchorFlags, 0, 16, st));
+  }
+  unsigned long long *dProbes = ctx->anchorFlags;
+  int *dError = (int *)(ctx->anchorFlags + 1);
+  struct PieceEvents {
+    hipEvent_t e[4];
+    bool emitted;
+  };
+  std::vector<PieceEvents> pieceEvents;
+  struct EventGuard {
+    std::vector<PieceEvents> &v;
+    ~EventGuard() {
+      for (auto &p : v)
+        for (auto &x : p.e)
+          if (x) (void)hipEventDestroy(x);
+    }
+  } eventGuard{pieceEvents};
   const bool countProbes = getenv("BLASR_HIP_ANCHOR_COUNT_PROBES") != nullptr;
   const bool sorted = P.sorted != 0;
   bool overflow = false;
@@ -587,7 +612,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
   int64_t first = 0;    // first list of the piece
   int64_t pieceLimit = kPiecePositions;
   if (const char *e = getenv("BLASR_HIP_ANCHOR_PIECE")) pieceLimit = std::max<int64_t>(1, atoll(e));
-  std::vector<int64_t> posOff, segAnchor;
+  std::vector<int64_t> posOff;
   while (first < nLists) {
     int64_t last = first, nPos = 0;
     while (last < nLists && (last == first || nPos + segPos[(size_t)last] <= pieceLimit)) nPos += segPos[(size_t)last++];
@@ -630,11 +655,8 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     uint32_t *dLcp = (uint32_t *)take(4 * (size_t)(nPos + 1));
     int64_t *dAnchorOff = (int64_t *)take(8 * (size_t)(nPos + 1));
     void *scanTmp = take(scanBytes);
-    unsigned long long *dProbes = (unsigned long long *)take(16);
-    int *dError = (int *)(dProbes + 1);
     HIP_TRY(ctx, hipMemcpyAsync(dSeg, segs.data() + first, sizeof(AnchorSeg) * (size_t)nSeg, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dPosOff, posOff.data(), sizeof(int64_t) * ((size_t)nSeg + 1), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(dProbes, 0, 16, st));
     HIP_TRY(ctx, hipMemsetAsync(dCnt + nPos, 0, 4, st));  // the scan's extra element
 
     AnchorArgs a;
@@ -664,6 +686,9 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.lcp = P.advance_exact_matches ? dLcp : nullptr;
     a.probes = countProbes ? dProbes : nullptr;
 
+    pieceEvents.push_back(PieceEvents{{nullptr, nullptr, nullptr, nullptr}, false});
+    PieceEvents &ev = pieceEvents.back();
+    for (auto &e : ev.e) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventRecord(ev.e[0], st));
     launch_search(a, st);
     if (P.advance_exact_matches)
@@ -671,11 +696,11 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     HIP_TRY(ctx, hipEventRecord(ev.e[1], st));
     HIP_TRY(ctx, rocprim::exclusive_scan(scanTmp, scanBytes, dCnt, dAnchorOff, (int64_t)0, (size_t)nPos + 1,
                                          rocprim::plus<int64_t>(), st));
+    (void)dSegAnchor;
     hipLaunchKernelGGL(anchor_seg_offsets_kernel, dim3((unsigned)((nSeg + 256) / 256)), dim3(256), 0, st, nSeg, dPosOff,
-                       dAnchorOff, dSegAnchor, dSegAnchor32);
-    segAnchor.assign((size_t)nSeg + 1, 0);
-    HIP_TRY(ctx, hipMemcpyAsync(segAnchor.data(), dSegAnchor, sizeof(int64_t) * ((size_t)nSeg + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+                       dAnchorOff, ctx->anchorPinned, dSegAnchor32);
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // the one wait of the piece: how many anchors it has
+    const int64_t *segAnchor = ctx->anchorPinned;
     const int64_t pieceAnchors = segAnchor[(size_t)nSeg];
     for (int i = 0; i < nSeg; i++) list_off[first + i] = emitted + segAnchor[(size_t)i];
     ctx->anchorCounters[0] += nPos;
@@ -717,33 +742,30 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
                            kb.current(), vb.current(), out);
       }
       HIP_TRY(ctx, hipEventRecord(ev.e[3], st));
-      int hostError = 0;
-      HIP_TRY(ctx, hipMemcpyAsync(&hostError, dError, sizeof(int), hipMemcpyDeviceToHost, st));
-      unsigned long long hostProbes = 0;
-      HIP_TRY(ctx, hipMemcpyAsync(&hostProbes, dProbes, sizeof(hostProbes), hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      if (hostError)
-        return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: an anchor runs past the genome or ends on an N (the reference asserts, MapBySuffixArray.h:301-302)");
-      ctx->anchorCounters[3] += (int64_t)hostProbes;
-      float ms = 0;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
-      ctx->anchorMs[0] += ms;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[1], ev.e[2]));
-      ctx->anchorMs[1] += ms;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
-      ctx->anchorMs[2] += ms;
-    } else {
-      float ms = 0;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
-      ctx->anchorMs[0] += ms;
-      if (countProbes) {
-        unsigned long long hostProbes = 0;
-        HIP_TRY(ctx, hipMemcpy(&hostProbes, dProbes, sizeof(hostProbes), hipMemcpyDeviceToHost));
-        ctx->anchorCounters[3] += (int64_t)hostProbes;
-      }
+      ev.emitted = true;
     }
     emitted += pieceAnchors;
     first = last;
+  }
+  // ---- once per call: the assert flag, the probe count, the device times of the pieces
+  {
+    unsigned long long flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->anchorFlags, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (auto &pe : pieceEvents) {
+      float ms = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
+      ctx->anchorMs[0] += ms;
+      if (pe.emitted) {
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pe.e[1], pe.e[2]));
+        ctx->anchorMs[1] += ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pe.e[2], pe.e[3]));
+        ctx->anchorMs[2] += ms;
+      }
+    }
+    ctx->anchorCounters[3] = (int64_t)flags[0];
+    if ((int)(flags[1] & 0xffffffffu))
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: an anchor runs past the genome or ends on an N (the reference asserts, MapBySuffixArray.h:301-302)");
   }
   list_off[nLists] = emitted;
   *n_anchors = emitted;

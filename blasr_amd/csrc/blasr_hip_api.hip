@@ -178,6 +178,8 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   if (ctx->saIndex) (void)hipFree(ctx->saIndex);
   if (ctx->saExt) (void)hipFree(ctx->saExt);
+  if (ctx->anchorPinned) (void)hipHostFree(ctx->anchorPinned);
+  if (ctx->anchorFlags) (void)hipFree(ctx->anchorFlags);
   if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   delete ctx;

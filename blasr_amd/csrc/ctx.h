@@ -52,6 +52,12 @@ struct blasr_hip_ctx {
   // index[] + genome[]); built at the first anchor call for the (genome, index) pair it was made from
   uint32_t *saExt = nullptr;
   const void *saExtGenome = nullptr, *saExtIndex = nullptr;
+  // anchor stage: what the host needs back after each piece (the lists' first anchors) is written by the device
+  // straight into pinned host memory -- no copy queued behind other transfers; the probe count and the assert flag
+  // stay on the device until the call ends
+  int64_t *anchorPinned = nullptr;
+  size_t anchorPinnedBytes = 0;
+  unsigned long long *anchorFlags = nullptr;  // device: {probes, error}
   enum { kAnchorBufs = 4 };
   DevBuf anchorBuf[kAnchorBufs];  // sort keys / values of the anchor stage (double-buffered)
   float anchorMs[4] = {0, 0, 0, 0};
