@@ -224,4 +224,36 @@ int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t 
   return BLASR_HIP_OK;
 }
 
+// TupleCountTable::Write / Read (datastructures/tuplelists/TupleCountTable.h:75-90): the .ctab file Blasr looks for
+// next to the genome (Blasr.cpp:4463-4477) -- countTableLength, nTuples, tupleSize, the counts (all int32).
+int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t tuple_size) {
+  if (!path || !count_table || tuple_size < 1 || tuple_size > 15) return BLASR_HIP_ERR_INVALID;
+  FILE *f = fopen(path, "wb");
+  if (!f) return BLASR_HIP_ERR_INVALID;
+  const int32_t len = (int32_t)(1ll << (2 * tuple_size));
+  int32_t nTuples = 0;  // the reference counts in an int as well: wraps beyond 2^31 tuples
+  for (int64_t i = 0; i < (int64_t)len; i++) nTuples = (int32_t)((uint32_t)nTuples + (uint32_t)count_table[i]);
+  bool ok = fwrite(&len, 4, 1, f) == 1 && fwrite(&nTuples, 4, 1, f) == 1 && fwrite(&tuple_size, 4, 1, f) == 1 &&
+            fwrite(count_table, 4, (size_t)len, f) == (size_t)len;
+  ok = fclose(f) == 0 && ok;
+  return ok ? BLASR_HIP_OK : BLASR_HIP_ERR_INVALID;
+}
+
+// Returns the number of counts the file holds (with count_table == NULL or too small a capacity nothing is copied).
+int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capacity, int32_t *tuple_size) {
+  if (!path) return BLASR_HIP_ERR_INVALID;
+  FILE *f = fopen(path, "rb");
+  if (!f) return BLASR_HIP_ERR_INVALID;
+  int32_t head[3] = {0, 0, 0};
+  int64_t out = BLASR_HIP_ERR_INVALID;
+  if (fread(head, 4, 3, f) == 3 && head[0] > 0 && head[2] >= 1 && head[2] <= 15 && head[0] == (int32_t)(1ll << (2 * head[2]))) {
+    out = head[0];
+    if (tuple_size) *tuple_size = head[2];
+    if (count_table && capacity >= head[0] && fread(count_table, 4, (size_t)head[0], f) != (size_t)head[0])
+      out = BLASR_HIP_ERR_INVALID;
+  }
+  fclose(f);
+  return out;
+}
+
 }  // extern "C"

@@ -41,7 +41,7 @@ EXPORTS = [
     "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
-    "blasr_hip_build_suffix_array", "blasr_hip_sa_write",
+    "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -1062,6 +1062,31 @@ def count_tuples(genome, tuple_size=8):
     if rc != OK:
         raise BlasrHipError(rc, "count_tuples")
     return table
+
+
+def write_count_table(path, count_table):
+    """TupleCountTable::Write: the .ctab file of a count table (count_tuples' output)."""
+    table = np.ascontiguousarray(count_table, dtype=np.int32)
+    k = (len(table).bit_length() - 1) // 2
+    lib = load_library()
+    lib.blasr_hip_ctab_write.argtypes = [C.c_char_p, C.c_void_p, C.c_int32]
+    if lib.blasr_hip_ctab_write(path.encode(), table.ctypes.data, k) != OK:
+        raise BlasrHipError(ERR_INVALID, "ctab_write %s" % path)
+
+
+def read_count_table(path):
+    """TupleCountTable::Read: (counts int32 array, tuple size) of a .ctab file."""
+    lib = load_library()
+    lib.blasr_hip_ctab_read.restype = C.c_int64
+    lib.blasr_hip_ctab_read.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+    k = C.c_int32(0)
+    n = lib.blasr_hip_ctab_read(path.encode(), None, 0, C.byref(k))
+    if n < 0:
+        raise BlasrHipError(int(n), "ctab_read %s" % path)
+    table = np.zeros(n, dtype=np.int32)
+    if lib.blasr_hip_ctab_read(path.encode(), table.ctypes.data, n, C.byref(k)) != n:
+        raise BlasrHipError(ERR_INVALID, "ctab_read %s" % path)
+    return table, k.value
 
 
 def find_intervals(genome, seq_start_pos, count_table, reads, anchors, list_off, params=None, stale=None):

@@ -718,6 +718,12 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
 int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, const uint32_t *start_pos_table,
                        const uint32_t *end_pos_table, int64_t lookup_table_length, int32_t lookup_prefix_length);
 
+/* The .ctab file of a tuple count table (TupleCountTable::Write / Read, datastructures/tuplelists/TupleCountTable.h:75-90;
+ * Blasr.cpp:4463-4477 picks up <genome>.ctab): blasr_hip_ctab_read returns the number of counts in the file (< 0 on
+ * error) and copies them when count_table has room. */
+int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t tuple_size);
+int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capacity, int32_t *tuple_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -572,6 +572,20 @@ void *ref_ct_open(const unsigned char *genomeSeq, unsigned genomeLen, int tupleS
   return h;
 }
 void ref_ct_close(void *h) { delete (RefCountTable *)h; }
+// TupleCountTable::Write / Read on a file (the .ctab format)
+int ref_ct_write(void *h, const char *path) {
+  ofstream out(path, std::ios::out | std::ios::binary);
+  if (!out.good()) return -1;
+  ((RefCountTable *)h)->ct.Write(out);
+  return 0;
+}
+void *ref_ct_read(const char *path) {
+  ifstream in(path, std::ios::in | std::ios::binary);
+  if (!in.good()) return NULL;
+  RefCountTable *h = new RefCountTable;
+  h->ct.Read(in);
+  return h;
+}
 long ref_ct_table(void *h, int *out, long cap) {
   RefCountTable *c = (RefCountTable *)h;
   for (long i = 0; i < c->ct.countTableLength && i < cap; i++) out[i] = c->ct.countTable[i];

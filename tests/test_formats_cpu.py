@@ -106,3 +106,32 @@ def test_suffix_array_file_of_sawriter(tmp_path):
     assert n <= len(genome) and len(set(sa["index"][:2000].tolist())) == 2000
     a, b = int(sa["index"][100]), int(sa["index"][101])
     assert bytes(genome[a: a + 40]) <= bytes(genome[b: b + 40])  # neighbours in the array are in suffix order
+
+
+@pytest.mark.skipif(not os.path.exists(REFMAPPER_SO), reason="oracle/_ref/libblasr_refmapper.so not built")
+def test_count_table_file_against_the_reference(tmp_path):
+    """.ctab: the library's count table of a genome written by the library is what the reference's TupleCountTable
+    reads, and what the reference writes the library reads; the two files are byte for byte the same."""
+    ref = C.CDLL(REFMAPPER_SO)
+    ref.ref_ct_open.restype = C.c_void_p
+    ref.ref_ct_read.restype = C.c_void_p
+    ref.ref_ct_table.restype = C.c_long
+    g = np.concatenate([synth.random_genome(40000, 8), np.frombuffer(b"NNNN", np.uint8), synth.random_genome(9000, 9),
+                        np.frombuffer(b"N", np.uint8)])
+    for k in (5, 8):
+        mine = hip.count_tuples(g, k)
+        p_mine, p_ref = os.path.join(str(tmp_path), "mine%d.ctab" % k), os.path.join(str(tmp_path), "ref%d.ctab" % k)
+        hip.write_count_table(p_mine, mine)
+        h = ref.ref_ct_open(g.ctypes.data_as(C.c_void_p), len(g), k)
+        assert ref.ref_ct_write(C.c_void_p(h), p_ref.encode()) == 0
+        assert open(p_mine, "rb").read() == open(p_ref, "rb").read()
+        back, kk = hip.read_count_table(p_ref)
+        assert kk == k and np.array_equal(back, mine)
+        h2 = ref.ref_ct_read(p_mine.encode())
+        tab = np.zeros(len(mine), np.int32)
+        assert ref.ref_ct_table(C.c_void_p(h2), tab.ctypes.data_as(C.c_void_p), C.c_long(len(tab))) == len(mine)
+        assert np.array_equal(tab, mine)
+        ref.ref_ct_close(C.c_void_p(h))
+        ref.ref_ct_close(C.c_void_p(h2))
+    with pytest.raises(hip.BlasrHipError):
+        hip.read_count_table(os.path.join(str(tmp_path), "missing.ctab"))
