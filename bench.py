@@ -42,7 +42,12 @@ sys.path.insert(0, ROOT)
 # PMC figures of the dominant kernel, measured with separate rocprofv3 --pmc passes (profiles/): keyed by the
 # workload they were taken on and tagged with the library build they belong to; reported only when both match.
 PMC = {
-    # (config, reads, read_len, band): {...}   -- filled in from profiles/r02_* 
+    # (config, reads, read_len, band): HBM bytes per launch of the roofline kernel = (FETCH_SIZE + WRITE_SIZE) x the
+    # unit and gfx950 corrections of tools/pmc_summary.py, separate rocprofv3 --pmc passes (tools/pmc_config1.sh).
+    # configs[2]'s set-up cannot be profiled with --pmc on this image, so only configs[1] is here.
+    (1, 100000, 10000, 16): {"traffic": 42178089536.0,
+                             "note": "profiles/r02_v3_pmc_counters_configs1_100k_reads.json, fillp_kernel<16, true, false>, "
+                                     "one launch of the same workload and build: 1.13 x the algorithmic bytes"},
 }
 
 
