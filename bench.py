@@ -256,7 +256,7 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     t0 = time.perf_counter()
     genome_h = genome_t.cpu().numpy()  # the interval finder's p-values read the genome and its 8-mer counts on the host
     seq_starts = np.ascontiguousarray(starts, dtype=np.uint32)
-    count_table = hip.count_tuples(genome_h, 8)
+    count_table = ctx.count_tuples(8)  # on the device
     out["host_genome_copy_and_count_table_s"] = round(time.perf_counter() - t0, 2)
     reads, pool_ptr = wl["reads"], wl["pool"].data_ptr()
     n_reads = len(reads)

@@ -108,6 +108,21 @@ __global__ __launch_bounds__(256) void sa_lookup_info_kernel(const uint8_t *geno
   info[j] = (ok && cls != 3 ? word : 0u) | (cls << 28);
 }
 
+// TupleCountTable::AddSequenceTupleCountsLR (datastructures/tuplelists/TupleCountTable.h:63-73) over the resident genome:
+// every position whose `k` bases are all ACGT counts its word.  Words are spread over 4^k counters, so the atomics of a
+// wavefront rarely meet.
+__global__ __launch_bounds__(256) void count_tuples_kernel(const uint8_t *genome, int64_t n, int k, int32_t *table) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i + k > n) return;
+  uint32_t word = 0;
+  for (int j = 0; j < k; j++) {
+    const unsigned s = sym_rank(genome[i + j]);
+    if (s < 1 || s > 4) return;
+    word = (word << 2) | (s - 1);
+  }
+  atomicAdd(&table[word], 1);
+}
+
 struct Dev {
   void *p = nullptr;
   ~Dev() {
@@ -224,6 +239,22 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   ctx->saPrefixLen = p;
   if (start_pos_out) memcpy(start_pos_out, startPos.data(), 4 * (size_t)tableLen);
   if (end_pos_out) memcpy(end_pos_out, endPos.data(), 4 * (size_t)tableLen);
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_count_tuples_device(blasr_hip_ctx *ctx, int32_t tuple_size, int32_t *count_table) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!ctx->genome || tuple_size < 1 || tuple_size > 14 || !count_table)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "count_tuples_device: no genome, or bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t entries = 1ll << (2 * tuple_size);
+  Dev table;
+  HIP_TRY(ctx, hipMalloc(&table.p, 4 * (size_t)entries));
+  HIP_TRY(ctx, hipMemsetAsync(table.p, 0, 4 * (size_t)entries, ctx->stream));
+  hipLaunchKernelGGL(count_tuples_kernel, dim3((unsigned)((ctx->genomeLen + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->genome, ctx->genomeLen, tuple_size, (int32_t *)table.p);
+  HIP_TRY(ctx, hipMemcpyAsync(count_table, table.p, 4 * (size_t)entries, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BLASR_HIP_OK;
 }
 

@@ -42,6 +42,7 @@ EXPORTS = [
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
+    "blasr_hip_count_tuples_device",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -888,6 +889,13 @@ class Context:
         if download:
             return dict(index=idx, start_pos_table=sp, end_pos_table=ep, lookup_prefix_length=lookup_prefix_length)
         return None
+
+    def count_tuples(self, tuple_size=8):
+        """The tuple count table of the uploaded genome, counted on the device (= hip.count_tuples of the same genome)."""
+        table = np.zeros(1 << (2 * tuple_size), dtype=np.int32)
+        self.lib.blasr_hip_count_tuples_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        self._check(self.lib.blasr_hip_count_tuples_device(self.handle, tuple_size, table.ctypes.data))
+        return table
 
     def anchor_params(self, **kw):
         """blasr_hip_anchor_params with the reference's defaults; keyword overrides by field name."""

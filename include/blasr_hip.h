@@ -688,6 +688,8 @@ int blasr_hip_interval_default_params(blasr_hip_interval_params *params);
 /* TupleCountTable::AddSequenceTupleCountsLR (datastructures/tuplelists/TupleCountTable.h:63-73) as Blasr.cpp:4479-4482
  * builds it when no .ctab is given (tuple_size = params.lookupTableLength, 8): count_table has 4^tuple_size entries. */
 int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t tuple_size, int32_t *count_table);
+/* The same table counted on the device from the uploaded genome (count_table: host, 4^tuple_size entries). */
+int blasr_hip_count_tuples_device(blasr_hip_ctx *ctx, int32_t tuple_size, int32_t *count_table);
 /* anchors / list_off: what blasr_hip_anchor_reads_* returned with sorted = 1 (host arrays).  seq_start_pos:
  * SequenceIndexDatabase::seqStartPos (n_seq_pos = contigs + 1 entries).  intervals (at most capacity; *n_intervals
  * receives the number needed, BLASR_HIP_ERR_CAPACITY beyond): read r's are intervals[read_interval_off[r] ..

@@ -71,4 +71,6 @@ def test_anchors_from_the_device_built_index_equal_the_golden_lists():
     assert np.array_equal(A.as_triples(anchors[int(off[2 * r + strand]): int(off[2 * r + strand + 1])]), z["anchors"][:n])
     with pytest.raises(hip.BlasrHipError):
         ctx.build_suffix_array(15)
+    for k in (3, 8):  # the count table of the same genome, on the device and on the host
+        assert np.array_equal(ctx.count_tuples(k), hip.count_tuples(z["genome"], k))
     ctx.close()
