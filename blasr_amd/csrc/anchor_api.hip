@@ -205,6 +205,64 @@ __device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8
   return rr;
 }
 
+// SearchLeftBound followed by SearchRightBound on its result are the lower and the upper bound of `tq` among the
+// symbols of [l, r), which the array's order keeps sorted: one descent finds a suffix that holds `tq`, then the two
+// bounds are looked for on either side of it -- the same two numbers with about a third fewer probes.  A suffix that
+// ends at or before `offset` (symbols 5, 6: only possible without the lookup table, at the first bases) is where the
+// two searches of the reference differ from a plain ordering, so the pair is then computed as the reference does.
+// Returns true when the pair came from the plain descent (then, if l < r, the suffix at l holds tq at `offset`).
+__device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq, uint32_t &l,
+                                            uint32_t &r, unsigned &probes) {
+  uint32_t lo = l, hi = r;
+  bool plain = true;
+  while (lo < hi && plain) {
+    const uint32_t m = lo + ((hi - lo) >> 1);
+    const int s = suffix_symbol(a, three, m, offset, probes);
+    if (s >= 5) {
+      plain = false;
+    } else if (s < tq) {
+      lo = m + 1;
+    } else if (s > tq) {
+      hi = m;
+    } else {
+      uint32_t x = lo, y = m;  // the first suffix that holds tq
+      while (x < y && plain) {
+        const uint32_t mm = x + ((y - x) >> 1);
+        const int s2 = suffix_symbol(a, three, mm, offset, probes);
+        if (s2 >= 5)
+          plain = false;
+        else if (s2 < tq)
+          x = mm + 1;
+        else
+          y = mm;
+      }
+      uint32_t u = m + 1, v = hi;  // the first suffix beyond them
+      while (u < v && plain) {
+        const uint32_t mm = u + ((v - u) >> 1);
+        const int s2 = suffix_symbol(a, three, mm, offset, probes);
+        if (s2 >= 5)
+          plain = false;
+        else if (s2 <= tq)
+          u = mm + 1;
+        else
+          v = mm;
+      }
+      if (plain) {
+        l = x;
+        r = u;
+        return true;
+      }
+    }
+  }
+  if (plain) {  // nothing holds tq: both bounds fall on the first larger symbol
+    l = r = lo;
+    return true;
+  }
+  l = left_bound(a, three, offset, tq, l, r, probes);
+  r = right_bound(a, three, offset, tq, l, r, probes);
+  return false;
+}
+
 // kHist: how many of the latest (low, high) pairs stay in registers = max(expand, 1) + 1
 template <int kHist>
 __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
@@ -253,10 +311,10 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
     // the next genome base is an N (a genome as Blasr holds it ends in one, so the array never runs past it)
     if (suffix_symbol(a, three, l, lcp, probes) >= 4) break;
     const int tq = three[strand_base(a.pool, s, p + lcp)];
-    l = left_bound(a, three, lcp, tq, l, r, probes);
-    r = right_bound(a, three, lcp, tq, l, r, probes);
+    const bool plain = equal_range(a, three, lcp, tq, l, r, probes);
     if (l == r) break;
-    if (tq >= 4 || suffix_symbol(a, three, l, lcp, probes) != tq) break;
+    // (:1044-1051: the suffix at l must hold the read's base; after the plain descent it does by construction)
+    if (tq >= 4 || (!plain && suffix_symbol(a, three, l, lcp, probes) != tq)) break;
 #pragma unroll
     for (int i = kHist - 1; i > 0; i--) {
       hl[i] = hl[i - 1];
