@@ -260,75 +260,29 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     out["host_genome_copy_and_count_table_s"] = round(time.perf_counter() - t0, 2)
     reads, pool_ptr = wl["reads"], wl["pool"].data_ptr()
     n_reads = len(reads)
+    # ONE C++ call per pass (blasr_hip_map_from_reads_device, blasr_amd/csrc/pipeline_api.hip): the anchoring in sub-blocks
+    # of reads, each sub-block's anchors copied to pinned host memory on a side stream and turned into intervals by host
+    # threads while the device searches the next sub-block, then the path on all the intervals found
     ap = ctx.anchor_params(min_match_length=14, min_prefix_match_length=8)  # Blasr's values for a sawriter index
     ip = hip.interval_params(threads=min(64, os.cpu_count() or 1))
-    cap = 20000 * n_reads
-    d_anchors = torch.empty(cap * 12, dtype=torch.uint8, device=dev)
-    h_anchors = torch.empty(cap * 12, dtype=torch.uint8).pin_memory()
-    # The reads go through the anchoring in blocks: while the device searches block b + 1, the host threads turn the
-    # anchors of block b into intervals (the reference does both per read on every mapping thread).  The path then
-    # runs on all intervals at once.
-    from concurrent.futures import ThreadPoolExecutor
-    n_blocks = max(1, min(16, n_reads // 5000))
-    cuts = [n_reads * b // n_blocks for b in range(n_blocks + 1)]
-    stages = {"anchor_device": 0.0, "anchors_to_host (issue only: the copy runs under the next block)": 0.0,
-              "find_intervals_host (overlapped with the two above)": 0.0,
-              "wait_for_last_intervals": 0.0, "map_reads_device": 0.0}
+    pp = ctx.pipeline_params(reads_per_block=6250, anchor=ap, interval=ip, map=params)
+    hits = np.zeros(10 * n_reads, dtype=hip.HIT_DTYPE)
+    hit_off = np.zeros(n_reads + 1, dtype=np.int64)
+    stages = {}
     last = {}
-    anchor_ms = {}
-    host_pool = ThreadPoolExecutor(max_workers=1)
-
-    copy_stream = torch.cuda.Stream(device=dev)
-
-    def host_job(lo, hi, a_lo, n, list_off, copied):
-        copied.synchronize()
-        t0 = time.perf_counter()
-        rd = reads[lo:hi]
-        anchors = h_anchors.numpy()[a_lo * 12: (a_lo + n) * 12].view(hip.ANCHOR_DTYPE)
-        ivs, iv_off, _ = hip.find_intervals(genome_h, seq_starts, count_table, rd, anchors, list_off, ip)
-        ivs["read"] += lo
-        return ivs, iv_off, time.perf_counter() - t0
-
+    # one untimed pass first: the device and pinned anchor buffers are allocated on it (14 GB each at configs[2])
+    ctx.map_from_reads_device(genome_h, seq_starts, count_table, reads, wl["reads_t"].data_ptr(), pool_ptr, pp, hits, hit_off)
     t_all = time.perf_counter()
     for _ in range(steps):
-        jobs, used, n_total = [], 0, 0
-        for b in range(n_blocks):
-            lo, hi = cuts[b], cuts[b + 1]
-            t0 = time.perf_counter()
-            n, list_off = ctx.anchor_reads_device(reads[lo:hi], pool_ptr, ap, d_anchors.data_ptr() + used * 12, cap - used)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            # the anchors cross PCIe on a side stream, underneath the search of the next block
-            with torch.cuda.stream(copy_stream):
-                h_anchors[used * 12: (used + n) * 12].copy_(d_anchors[used * 12: (used + n) * 12], non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(copy_stream)
-            t2 = time.perf_counter()
-            jobs.append(host_pool.submit(host_job, lo, hi, used, n, list_off, copied))
-            for k, v in ctx.anchor_last_timing().items():
-                if k.endswith("_ms"):
-                    anchor_ms[k] = anchor_ms.get(k, 0.0) + v
-            used += n
-            n_total += n
-            stages["anchor_device"] += t1 - t0
-            stages["anchors_to_host (issue only: the copy runs under the next block)"] += t2 - t1
-        t3 = time.perf_counter()
-        parts = [j.result() for j in jobs]
-        t4 = time.perf_counter()
-        ivs = np.concatenate([p[0] for p in parts])
-        iv_off = np.concatenate([[0]] + [p[1][1:] + sum(len(q[0]) for q in parts[:k]) for k, p in enumerate(parts)])
-        stages["find_intervals_host (overlapped with the two above)"] += sum(p[2] for p in parts)
-        stages["wait_for_last_intervals"] += t4 - t3
-        iv_t = torch.from_numpy(ivs.view(np.uint8)).to(dev)
-        hits = np.zeros(max(len(ivs), 1), dtype=hip.HIT_DTYPE)
-        hit_off = np.zeros(n_reads + 1, dtype=np.int64)
-        ctx.map_reads_device(n_reads, wl["reads_t"].data_ptr(), pool_ptr, len(ivs), iv_t.data_ptr(), params, hits, hit_off)
-        torch.cuda.synchronize()
-        stages["map_reads_device"] += time.perf_counter() - t4
-        last = dict(anchors=int(n_total), intervals=int(len(ivs)), timing=ctx.map_last_timing(), anchor=ctx.anchor_last_timing(),
-                    hit_off=hit_off, ivs=ivs, iv_off=iv_off)
-    host_pool.shutdown()
+        n_hits, ivs = ctx.map_from_reads_device(genome_h, seq_starts, count_table, reads, wl["reads_t"].data_ptr(), pool_ptr,
+                                                pp, hits, hit_off, intervals_capacity=10 * n_reads)
+        pt = ctx.pipeline_last_timing()
+        for k in ("anchoring_ms", "wait_for_intervals_ms", "path_ms", "host_intervals_ms"):
+            stages[k] = stages.get(k, 0.0) + pt[k] / 1e3
+        iv_off = np.concatenate([[0], np.cumsum(np.bincount(ivs["read"], minlength=n_reads))])
+        last = dict(anchors=int(pt["anchors"]), intervals=int(len(ivs)), timing=ctx.map_last_timing(), ivs=ivs, iv_off=iv_off)
     wall = (time.perf_counter() - t_all) / steps
+    n_blocks = -(-n_reads // 6250)
     # how many reads have their true locus among the candidate intervals (the synthetic set-up knows it)
     true_iv = wl["intervals"][wl["kind"] == 0]
     found = 0
@@ -341,16 +295,17 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     sampled = len(range(0, len(true_iv), max(1, len(true_iv) // 2000)))
     tm = last["timing"]
     out.update({
-        "what": "reads -> hits: MapReadToGenome x 2 strands + SortMatchPosList on the device, anchors to the host, "
-                "RemoveOverlappingAnchors / FindMaxIncreasingInterval / interval set on %d host threads (block b on the "
-                "host while the device anchors block b + 1), then the timed path of the metric on the intervals found "
-                "(instead of the synthetic ones)" % ip.threads,
+        "what": "reads -> hits in one C++ call (blasr_hip_map_from_reads_device): MapReadToGenome x 2 strands + "
+                "SortMatchPosList on the device, anchors to pinned host memory, RemoveOverlappingAnchors / "
+                "FindMaxIncreasingInterval / interval set on %d host threads (sub-block b on the host while the device "
+                "anchors sub-block b + 1), then the timed path of the metric on the intervals found (instead of the "
+                "synthetic ones)" % ip.threads,
         "steps": steps, "ms_per_step": wall * 1e3, "reads_per_s": n_reads / wall,
         "aligned_bases_per_s": tm["aligned_bases"] / wall,
         "stage_ms_per_step": {k: v / steps * 1e3 for k, v in stages.items()},
         "anchors_per_step": last["anchors"], "candidate_intervals": last["intervals"], "hits": int(tm["hits"]),
         "aligned_reads": int(tm["aligned_reads"]),
-        "anchor_blocks": n_blocks, "anchor_device_ms_per_step": {k: v / steps for k, v in anchor_ms.items()},
+        "anchor_blocks": n_blocks,
         "true_locus_among_intervals": "%d of %d sampled reads" % (found, sampled),
     })
     return out

@@ -179,6 +179,9 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   if (ctx->saIndex) (void)hipFree(ctx->saIndex);
   if (ctx->saExt) (void)hipFree(ctx->saExt);
   if (ctx->anchorPinned) (void)hipHostFree(ctx->anchorPinned);
+  if (ctx->pipePinned) (void)hipHostFree(ctx->pipePinned);
+  if (ctx->pipeAnchors.p) (void)hipFree(ctx->pipeAnchors.p);
+  if (ctx->pipeIntervals.p) (void)hipFree(ctx->pipeIntervals.p);
   if (ctx->anchorFlags) (void)hipFree(ctx->anchorFlags);
   if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
@@ -200,6 +203,7 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
   for (const auto &b : ctx->mapBuf) total += (int64_t)b.bytes;
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
   for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
+  total += (int64_t)ctx->pipeAnchors.bytes + (int64_t)ctx->pipeIntervals.bytes;
   total += (ctx->saExt ? 8 : 4) * ctx->saLen + 8 * ctx->saTableLen;
   return total;
 }

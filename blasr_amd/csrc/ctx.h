@@ -58,6 +58,13 @@ struct blasr_hip_ctx {
   int64_t *anchorPinned = nullptr;
   size_t anchorPinnedBytes = 0;
   unsigned long long *anchorFlags = nullptr;  // device: {probes, error}
+  // the whole-mapper driver (pipeline_api.hip): all anchors of a block on the device and mirrored in pinned host
+  // memory, the intervals found
+  DevBuf pipeAnchors, pipeIntervals;
+  void *pipePinned = nullptr;
+  size_t pipePinnedBytes = 0;
+  float pipeMs[4] = {0, 0, 0, 0};
+  int64_t pipeCounters[2] = {0, 0};
   enum { kAnchorBufs = 4 };
   DevBuf anchorBuf[kAnchorBufs];  // sort keys / values of the anchor stage (double-buffered)
   float anchorMs[4] = {0, 0, 0, 0};

@@ -1,0 +1,243 @@
+// The whole of MapRead for a block of reads, from the reads alone (alignment/Blasr.cpp:2247-2644): the anchoring
+// (anchor_api.hip), the interval finding (intervals_api.hip) and the path (mapread_api.hip) strung together in C++.
+//
+// The reads go through the anchoring in sub-blocks.  While the device searches sub-block b + 1, the anchors of
+// sub-block b cross PCIe on the side stream into pinned memory and a host thread (which fans out over the reads) turns
+// them into candidate intervals -- the reference does both per read on every mapping thread; here the device stage and
+// the host stage of consecutive sub-blocks overlap.  The path then runs once on all the intervals found.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/blasr_hip.h"
+#include "ctx.h"
+
+namespace {
+
+struct Job {
+  int32_t first, count;     // reads [first, first + count)
+  int64_t anchorOff;        // first anchor of the sub-block in the pinned buffer
+  std::vector<int64_t> listOff;
+  hipEvent_t copied;
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) {
+  if (!p) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_anchor_default_params(&p->anchor);
+  blasr_hip_interval_default_params(&p->interval);
+  blasr_hip_map_default_params(&p->map);
+  p->reads_per_block = 6250;
+  p->reserved = 0;
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_pipeline_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[2]) {
+  if (!ctx || !ms || !counters) return BLASR_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; i++) ms[i] = ctx->pipeMs[i];
+  counters[0] = ctx->pipeCounters[0];
+  counters[1] = ctx->pipeCounters[1];
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
+                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                    int32_t n_reads, const blasr_hip_read *reads_host, const blasr_hip_read *reads_device,
+                                    const uint8_t *read_pool_device, const blasr_hip_pipeline_params *params,
+                                    blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
+                                    blasr_hip_map_fetch *fetch, blasr_hip_interval *intervals_out,
+                                    int64_t intervals_capacity, int64_t *n_intervals) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!genome_host || !seq_start_pos || n_seq_pos < 1 || !count_table || n_reads < 0 || !params || !n_hits ||
+      (n_reads > 0 && (!reads_host || !reads_device || !read_pool_device)) || (hits_capacity > 0 && !hits) ||
+      (intervals_capacity > 0 && !intervals_out))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_from_reads: bad arguments");
+  if (!ctx->genome || !ctx->saIndex)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_from_reads: no genome / suffix array on the device");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  blasr_hip_anchor_params ap = params->anchor;
+  ap.sorted = 1;
+  ap.forward_only = 0;
+  const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 6250;
+  const double t0 = now_ms();
+
+  // ---- the host stage: one thread takes the sub-blocks in order
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Job *> queue;
+  bool done = false;
+  int hostError = BLASR_HIP_OK;
+  std::vector<std::vector<blasr_hip_interval>> blockIvs;
+  std::vector<std::vector<int64_t>> blockIvOff;
+  double hostMs = 0;
+  const blasr_hip_anchor *pinned = nullptr;  // set before the first job is queued
+  std::thread worker([&]() {
+    for (;;) {
+      Job *job = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&]() { return !queue.empty() || done; });
+        if (queue.empty()) return;
+        job = queue.front();
+        queue.pop_front();
+      }
+      (void)hipSetDevice(ctx->device);
+      (void)hipEventSynchronize(job->copied);
+      const double h0 = now_ms();
+      std::vector<blasr_hip_interval> ivs((size_t)job->count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
+      std::vector<int64_t> off((size_t)job->count + 1);
+      int64_t n = 0;
+      const int rc = blasr_hip_find_intervals(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
+                                              count_tuple_size, job->count, reads_host + job->first,
+                                              pinned + job->anchorOff, job->listOff.data(), nullptr, &params->interval,
+                                              ivs.data(), nullptr, (int64_t)ivs.size(), &n, off.data());
+      ivs.resize((size_t)std::max<int64_t>(n, 0));
+      for (auto &iv : ivs) iv.read += job->first;
+      hostMs += now_ms() - h0;
+      std::lock_guard<std::mutex> lock(mu);
+      if (rc != BLASR_HIP_OK && hostError == BLASR_HIP_OK) hostError = rc;
+      blockIvs.push_back(std::move(ivs));
+      blockIvOff.push_back(std::move(off));
+    }
+  });
+  auto finish_worker = [&]() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      done = true;
+    }
+    cv.notify_all();
+    if (worker.joinable()) worker.join();
+  };
+
+  // ---- the device stage
+  std::vector<Job> jobs((size_t)((n_reads + perBlock - 1) / perBlock));
+  for (auto &j : jobs) j.copied = nullptr;
+  struct Cleanup {
+    std::vector<Job> &jobs;
+    ~Cleanup() {
+      for (auto &j : jobs)
+        if (j.copied) (void)hipEventDestroy(j.copied);
+    }
+  } cleanup{jobs};
+  int64_t used = 0;
+  int rc = BLASR_HIP_OK;
+  for (size_t b = 0; b < jobs.size() && rc == BLASR_HIP_OK; b++) {
+    Job &j = jobs[b];
+    j.first = (int32_t)(b * (size_t)perBlock);
+    j.count = std::min(perBlock, n_reads - j.first);
+    j.listOff.assign(2 * (size_t)j.count + 1, 0);
+    int64_t blockBases = 0;
+    for (int32_t r = j.first; r < j.first + j.count; r++) blockBases += reads_host[r].length;
+    int64_t expect = 2 * blockBases + 4096;  // anchors of this sub-block: a guess, corrected by the count a short call returns
+    for (int attempt = 0; attempt < 2 && rc == BLASR_HIP_OK; attempt++) {
+      // ---- room on the device (grow-only; what earlier sub-blocks wrote moves along)
+      const size_t wantDev = sizeof(blasr_hip_anchor) * (size_t)(used + expect);
+      if (wantDev > ctx->pipeAnchors.bytes) {
+        DevBuf bigger;
+        if ((rc = blasr_hip_ensure(ctx, bigger, wantDev + wantDev / 4)) != BLASR_HIP_OK) break;
+        (void)hipStreamSynchronize(ctx->sideStream);  // copies out of the old buffer
+        if (used > 0)
+          (void)hipMemcpy(bigger.p, ctx->pipeAnchors.p, sizeof(blasr_hip_anchor) * (size_t)used, hipMemcpyDeviceToDevice);
+        if (ctx->pipeAnchors.p) (void)hipFree(ctx->pipeAnchors.p);
+        ctx->pipeAnchors = bigger;
+      }
+      const int64_t cap = (int64_t)(ctx->pipeAnchors.bytes / sizeof(blasr_hip_anchor)) - used;
+      int64_t n = 0;
+      rc = blasr_hip_anchor_reads_device(ctx, j.count, reads_host + j.first, read_pool_device, &ap,
+                                         (blasr_hip_anchor *)ctx->pipeAnchors.p + used, cap, &n, j.listOff.data());
+      if (rc == BLASR_HIP_ERR_CAPACITY && attempt == 0) {
+        expect = n + 1;
+        rc = BLASR_HIP_OK;
+        continue;
+      }
+      if (rc != BLASR_HIP_OK) break;
+      // ---- the pinned host mirror, same offsets.  Growing it: the host stage must have finished with the old one
+      // (what it has already turned into intervals is not needed again)
+      const size_t wantPinned = sizeof(blasr_hip_anchor) * (size_t)(used + n + 1);
+      if (wantPinned > ctx->pipePinnedBytes) {
+        for (;;) {
+          {
+            std::lock_guard<std::mutex> lock(mu);
+            if (queue.empty() && blockIvs.size() == b) break;
+          }
+          std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        (void)hipStreamSynchronize(ctx->sideStream);
+        if (ctx->pipePinned) (void)hipHostFree(ctx->pipePinned);
+        ctx->pipePinned = nullptr;
+        ctx->pipePinnedBytes = 0;
+        const int64_t blocksLeft = (int64_t)(jobs.size() - b);
+        const size_t bytes = sizeof(blasr_hip_anchor) * (size_t)(used + (n + n / 8) * blocksLeft + 1024);
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+          rc = blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "map_from_reads: %zu bytes of pinned host memory", bytes);
+          break;
+        }
+        ctx->pipePinned = p;
+        ctx->pipePinnedBytes = bytes;
+      }
+      pinned = (const blasr_hip_anchor *)ctx->pipePinned;
+      j.anchorOff = used;
+      if (hipEventCreateWithFlags(&j.copied, hipEventDisableTiming) != hipSuccess) {
+        rc = blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_from_reads: event");
+        break;
+      }
+      // the anchor call has synchronised the main stream: the copy can start at once, under the next sub-block
+      (void)hipMemcpyAsync((blasr_hip_anchor *)ctx->pipePinned + used, (blasr_hip_anchor *)ctx->pipeAnchors.p + used,
+                           sizeof(blasr_hip_anchor) * (size_t)n, hipMemcpyDeviceToHost, ctx->sideStream);
+      (void)hipEventRecord(j.copied, ctx->sideStream);
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        queue.push_back(&j);
+      }
+      cv.notify_all();
+      used += n;
+      break;
+    }
+  }
+  const double t1 = now_ms();
+  finish_worker();
+  const double t2 = now_ms();
+  if (rc == BLASR_HIP_OK && hostError != BLASR_HIP_OK) rc = blasr_hip_fail(ctx, hostError, "map_from_reads: find_intervals failed");
+  if (rc != BLASR_HIP_OK) return rc;
+
+  // ---- all intervals, in read order; then the path
+  int64_t total = 0;
+  for (auto &v : blockIvs) total += (int64_t)v.size();
+  std::vector<blasr_hip_interval> ivs;
+  ivs.reserve((size_t)total);
+  for (auto &v : blockIvs) ivs.insert(ivs.end(), v.begin(), v.end());
+  if (n_intervals) *n_intervals = total;
+  if (intervals_out) memcpy(intervals_out, ivs.data(), sizeof(blasr_hip_interval) * (size_t)std::min(total, intervals_capacity));
+  if ((rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(total + 1))) != BLASR_HIP_OK) return rc;
+  HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, ivs.data(), sizeof(blasr_hip_interval) * (size_t)total, hipMemcpyHostToDevice));
+  rc = blasr_hip_map_reads_device(ctx, n_reads, reads_device, read_pool_device, (int32_t)total,
+                                  (const blasr_hip_interval *)ctx->pipeIntervals.p, &params->map, hits, hits_capacity, n_hits,
+                                  read_hit_off, fetch);
+  const double t3 = now_ms();
+  ctx->pipeMs[0] = (float)(t1 - t0);  // anchoring of all sub-blocks (the host stage runs underneath)
+  ctx->pipeMs[1] = (float)(t2 - t1);  // waiting for the host stage's last sub-block
+  ctx->pipeMs[2] = (float)(t3 - t2);  // the path
+  ctx->pipeMs[3] = (float)hostMs;     // host time spent finding intervals (hidden under [0] except [1])
+  ctx->pipeCounters[0] = used;
+  ctx->pipeCounters[1] = total;
+  if (rc == BLASR_HIP_OK && intervals_out && total > intervals_capacity)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: %lld intervals, capacity %lld", (long long)total,
+                          (long long)intervals_capacity);
+  return rc;
+}
+
+}  // extern "C"

@@ -42,7 +42,8 @@ EXPORTS = [
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
-    "blasr_hip_count_tuples_device",
+    "blasr_hip_count_tuples_device", "blasr_hip_pipeline_default_params", "blasr_hip_map_from_reads_device",
+    "blasr_hip_pipeline_last_timing",
 ]
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
@@ -178,6 +179,11 @@ class _AnchorParams(C.Structure):
 class _IntervalParams(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("min_interval", C.c_int32), ("indel_rate", C.c_float),
                 ("max_p_value", C.c_float), ("remove_contained_intervals", C.c_int32), ("threads", C.c_int32)]
+
+
+class _PipelineParams(C.Structure):
+    _fields_ = [("anchor", _AnchorParams), ("interval", _IntervalParams), ("map", _MapParams),
+                ("reads_per_block", C.c_int32), ("reserved", C.c_int32)]
 
 
 # blasr_hip_anchor: MatchPos t, q, l
@@ -896,6 +902,51 @@ class Context:
         self.lib.blasr_hip_count_tuples_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         self._check(self.lib.blasr_hip_count_tuples_device(self.handle, tuple_size, table.ctypes.data))
         return table
+
+    def pipeline_params(self, reads_per_block=None, anchor=None, interval=None, map=None):
+        p = _PipelineParams()
+        self.lib.blasr_hip_pipeline_default_params.argtypes = [C.POINTER(_PipelineParams)]
+        self.lib.blasr_hip_pipeline_default_params(C.byref(p))
+        if anchor is not None:
+            p.anchor = anchor
+        if interval is not None:
+            p.interval = interval
+        if map is not None:
+            p.map = map
+        if reads_per_block:
+            p.reads_per_block = int(reads_per_block)
+        return p
+
+    def map_from_reads_device(self, genome_host, seq_start_pos, count_table, reads, reads_ptr, read_pool_ptr, params, hits,
+                              read_hit_off=None, intervals_capacity=0):
+        """blasr_hip_map_from_reads_device: anchoring in sub-blocks overlapped with the host's interval finding, then the
+        path.  genome_host / seq_start_pos / count_table: host arrays (the interval finder's); reads: host READ_DTYPE
+        array, reads_ptr / read_pool_ptr: the same table and the pool on the device; hits: HIT_DTYPE host array to fill.
+        Returns (number of hits, intervals INTERVAL_DTYPE array or None)."""
+        genome_host = np.ascontiguousarray(genome_host, dtype=np.uint8)
+        starts = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
+        table = np.ascontiguousarray(count_table, dtype=np.int32)
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        k = (len(table).bit_length() - 1) // 2
+        ivs = np.zeros(intervals_capacity, dtype=INTERVAL_DTYPE) if intervals_capacity else None
+        n_hits, n_iv = C.c_int64(0), C.c_int64(0)
+        f = self.lib.blasr_hip_map_from_reads_device
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.POINTER(_PipelineParams), C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        self._check(f(self.handle, genome_host.ctypes.data, starts.ctypes.data, len(starts), table.ctypes.data, k, len(reads),
+                      reads.ctypes.data, C.c_void_p(reads_ptr), C.c_void_p(read_pool_ptr), C.byref(params), hits.ctypes.data,
+                      len(hits), C.byref(n_hits), read_hit_off.ctypes.data if read_hit_off is not None else None, None,
+                      ivs.ctypes.data if ivs is not None else None, intervals_capacity, C.byref(n_iv)))
+        return n_hits.value, (ivs[: n_iv.value] if ivs is not None else None)
+
+    def pipeline_last_timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int64 * 2)()
+        self.lib.blasr_hip_pipeline_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        self._check(self.lib.blasr_hip_pipeline_last_timing(self.handle, ms, cnt))
+        return dict(anchoring_ms=ms[0], wait_for_intervals_ms=ms[1], path_ms=ms[2], host_intervals_ms=ms[3], anchors=cnt[0],
+                    intervals=cnt[1])
 
     def anchor_params(self, **kw):
         """blasr_hip_anchor_params with the reference's defaults; keyword overrides by field name."""

@@ -726,6 +726,35 @@ int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, 
 int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t tuple_size);
 int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capacity, int32_t *tuple_size);
 
+/* ------------------------------------------------------------------------------------------------
+ * MapRead for a block of reads from the reads alone (alignment/Blasr.cpp:2247-2644): anchoring on the device
+ * (blasr_hip_anchor_reads_device, in sub-blocks of reads_per_block reads), the anchors of a sub-block to pinned host
+ * memory and into blasr_hip_find_intervals on host threads while the device searches the next sub-block, then
+ * blasr_hip_map_reads_device on all the intervals found.  Needs the genome and its suffix array on the device
+ * (blasr_hip_upload_genome / _adopt_, blasr_hip_upload_suffix_array / blasr_hip_build_suffix_array) and, for the
+ * p-values of the interval finder, the genome, its contig table and its tuple count table on the host.
+ * reads_host / reads_device: the same read table in both places; read_pool_device: device.
+ * intervals_out (may be NULL): the candidate intervals found, read by read.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_pipeline_params {
+  blasr_hip_anchor_params anchor;      /* sorted / forward_only are forced to 1 / 0 */
+  blasr_hip_interval_params interval;
+  blasr_hip_map_params map;
+  int32_t reads_per_block;             /* 6250 */
+  int32_t reserved;
+} blasr_hip_pipeline_params;
+int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *params);
+int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
+                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                    int32_t n_reads, const blasr_hip_read *reads_host, const blasr_hip_read *reads_device,
+                                    const uint8_t *read_pool_device, const blasr_hip_pipeline_params *params,
+                                    blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
+                                    blasr_hip_map_fetch *fetch, blasr_hip_interval *intervals_out,
+                                    int64_t intervals_capacity, int64_t *n_intervals);
+/* Wall time (ms) of the last call: [0] anchoring of all sub-blocks (host stage underneath), [1] waiting for the host
+ * stage's last sub-block, [2] the path, [3] host time spent finding intervals; counters: anchors, intervals. */
+int blasr_hip_pipeline_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,3 +82,44 @@ def run_end_to_end(own_intervals, tmp_path=None):
     assert len(got) == len(want) and not bad, (len(got), len(want), bad[:3])
     bad = [(a[:300], b[:300]) for a, b in zip(got_sam, want_sam) if a != b]
     assert len(got_sam) == len(want_sam) and not bad, (len(bad), bad[:2])
+
+
+@pytest.mark.skipif(not os.path.exists(SAWRITER), reason="oracle/_ref/sawritermc not built (the suffix array's writer)")
+@pytest.mark.parametrize("reads_per_block", [7, 1000])
+def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_per_block):
+    """blasr_hip_map_from_reads_device (anchoring in sub-blocks overlapped with the host's interval finding, then the
+    path, in C++): the reference binary's 125 candidate intervals and the hits of the step-by-step route, for sub-blocks
+    of 7 reads (12 of them in flight) and for one sub-block."""
+    from blasr_testlib import DeviceMemory
+    g = np.load(GOLDEN)
+    contigs = [g["contig0"], g["contig1"]]
+    genome = np.concatenate([contigs[0], [ord("N")], contigs[1], [ord("N")]]).astype(np.uint8)
+    starts = np.array([0, len(contigs[0]) + 1, len(genome)], dtype=np.uint32)
+    read_lens, pool = g["read_lens"], np.ascontiguousarray(g["reads"])
+    reads = np.zeros(len(read_lens), dtype=blasr_amd.READ_DTYPE)
+    off = 0
+    for i in range(len(read_lens)):
+        reads[i] = (off, int(read_lens[i]), 0, int(read_lens[i]), 0)
+        off += int(read_lens[i])
+    want_iv = np.zeros(len(g["intervals"]), dtype=blasr_amd.INTERVAL_DTYPE)
+    for k, (s, e, qs, qe, strand) in enumerate(g["intervals"]):
+        want_iv[k] = (int(s), int(e), int(qs), int(qe), int(g["owner"][k]), int(strand))
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, starts)
+    ctx.build_suffix_array(8, download=False)  # what blasrmc builds on the fly (lookup prefix 8)
+    mem = DeviceMemory()
+    d_reads, d_pool = mem.upload(reads.view(np.uint8)), mem.upload(pool)
+    hits = np.zeros(len(want_iv) + 8, dtype=hip.HIT_DTYPE)
+    hit_off = np.zeros(len(reads) + 1, dtype=np.int64)
+    p = ctx.pipeline_params(reads_per_block=reads_per_block)
+    n, ivs = ctx.map_from_reads_device(genome, starts, ctx.count_tuples(8), reads, d_reads, d_pool, p, hits, hit_off,
+                                       intervals_capacity=len(want_iv) + 8)
+    assert np.array_equal(ivs, want_iv)
+    t = ctx.pipeline_last_timing()
+    assert t["intervals"] == len(want_iv) and t["anchors"] > 10000
+    want_hits, want_off, _, _ = ctx.map_reads(reads, pool, want_iv, fetch=False)
+    assert n == len(want_hits) and np.array_equal(hit_off, want_off)
+    for f in ("read", "interval", "t_strand", "t_aligned_seq_pos", "q_pos", "t_pos", "score", "n_match", "n_ops"):
+        assert np.array_equal(hits[:n][f], want_hits[f]), f
+    mem.free()
+    ctx.close()
