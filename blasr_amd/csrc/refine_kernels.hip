@@ -676,6 +676,12 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   __shared__ int matN[5];  // the query-N row of the matrix
   if (threadIdx.x < 5) matN[threadIdx.x] = args.matrix[20 + threadIdx.x];
   __syncthreads();
+  // hybrid variant: the packed column by target CHARACTER (one LDS read per cell of a wide row instead of the decode)
+  __shared__ uint32_t packedByChar[kHybrid ? 256 : 1];
+  if (kHybrid) {
+    packedByChar[threadIdx.x] = packedCol[base_code((unsigned)threadIdx.x)];
+    __syncthreads();
+  }
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int grp = lane / kL, l = lane % kL;
   const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * kT;
@@ -914,8 +920,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
                 up.y = upValid ? up.y : inf;
                 sd = diagValid ? sd : inf;
               }
-              const int tcode = base_code((unsigned)tCur);
-              const int mm = wQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedCol[tcode], (wQc & 3) * 8, 8) : matN[tcode];
+              const int mm = wQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur & 255], (wQc & 3) * 8, 8)
+                                     : matN[base_code((unsigned)tCur)];
               int sv, iv, arrow;
               row_chunk<true, false>(kc, carry, active, up.x, up.y, sd, mm, sv, iv, arrow);
               if (active) {
