@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void sa_first_keys_kernel(const uint8_t *genom
   sa[i] = (uint32_t)i;
 }
 
+constexpr int kGroupCounters = 4096;
+
 // heads[j] = j where a new key starts, else 0; counts the groups
 __global__ __launch_bounds__(256) void sa_heads_kernel(const uint64_t *keys, int64_t n, uint32_t *heads,
                                                        unsigned long long *groups) {
@@ -63,8 +65,9 @@ __global__ __launch_bounds__(256) void sa_heads_kernel(const uint64_t *keys, int
     head = j == 0 || keys[j] != keys[j - 1];
     heads[j] = head ? (uint32_t)j : 0u;
   }
+  // (one counter would take 48 M atomics on one address for an hg19-size genome: kGroupCounters of them, by block)
   const unsigned long long m = __ballot(head);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(groups, (unsigned long long)__popcll(m));
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&groups[blockIdx.x & (kGroupCounters - 1)], (unsigned long long)__popcll(m));
 }
 
 __global__ __launch_bounds__(256) void sa_rank_kernel(const uint32_t *sa, const uint32_t *groupStart, int64_t n,
@@ -151,7 +154,7 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   HIP_TRY(ctx, hipMalloc(&saB.p, 4 * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&rank.p, 4 * (size_t)n));
   HIP_TRY(ctx, hipMalloc(&heads.p, 4 * (size_t)n));
-  HIP_TRY(ctx, hipMalloc(&counter.p, 8));
+  HIP_TRY(ctx, hipMalloc(&counter.p, 8 * kGroupCounters));
   rocprim::double_buffer<uint64_t> keys((uint64_t *)keysA.p, (uint64_t *)keysB.p);
   rocprim::double_buffer<uint32_t> sa((uint32_t *)saA.p, (uint32_t *)saB.p);
   size_t sortBytes = 0, scanBytes = 0;
@@ -165,12 +168,14 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   int rounds = 0;
   while (true) {
     HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp.p, sortBytes, keys, sa, (size_t)n, 0, rounds == 0 ? 3 * kFirst : 64, st));
-    HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8, st));
+    HIP_TRY(ctx, hipMemsetAsync(counter.p, 0, 8 * kGroupCounters, st));
     hipLaunchKernelGGL(sa_heads_kernel, dim3(blocks), dim3(256), 0, st, keys.current(), n, (uint32_t *)heads.p,
                        (unsigned long long *)counter.p);
-    unsigned long long groups = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&groups, counter.p, 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> partial(kGroupCounters);
+    HIP_TRY(ctx, hipMemcpyAsync(partial.data(), counter.p, 8 * kGroupCounters, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    unsigned long long groups = 0;
+    for (unsigned long long v : partial) groups += v;
     if ((int64_t)groups == n) break;
     if (++rounds > 40) return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "build_suffix_array: ranks did not separate");
     HIP_TRY(ctx, rocprim::inclusive_scan(tmp.p, scanBytes, (uint32_t *)heads.p, (uint32_t *)heads.p, (size_t)n,

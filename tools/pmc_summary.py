@@ -19,12 +19,12 @@ def main():
     calls = collections.defaultdict(lambda: collections.defaultdict(set))
     for f in files:
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             per[name][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[name][r["Counter_Name"]].add(r["Dispatch_Id"])
     res = {}
     for name, c in per.items():
-        if "blasr_hip" not in name:
+        if not any(tag in name for tag in ("blasr_hip", "anchor_", "sa_", "count_tuples")):
             continue
         d = dict(c)
         d["dispatches"] = max(len(v) for v in calls[name].values())
