@@ -85,7 +85,7 @@ struct AnchorArgs {
   const uint8_t *genome;
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
-  const uint32_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
+  const uint16_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
   int prefixLen;
   const uint8_t *pool;
   const AnchorSeg *seg;
@@ -117,14 +117,16 @@ __device__ __forceinline__ int segment_of(const int64_t *posOff, int nSeg, int64
 }
 
 // The companion of the index array: for the suffix at array position m, the kExtBases bases that follow its first
-// `prefixLen` ones -- bits 2k, 2k+1 = base k, bits 26-29 = how many of them are ACGT before the first that is not,
-// bit 31 = that first one is the end of the genome (not an N).  Inside a search range every suffix shares the bases
-// matched so far with the read, so the symbol at the next offset is always among those: ONE load per probe, from an
-// array the binary search walks with locality, instead of index[m] and then genome[index[m] + offset].
-constexpr int kExtBases = 13;
+// `prefixLen` ones, in 16 bits -- bits 2k, 2k+1 = base k, bits 12-14 = how many of them are ACGT before the first
+// that is not, bit 15 = that first one is the end of the genome (not an N).  Inside a search range every suffix shares
+// the bases matched so far with the read, so the symbol at the next offset is always among those: ONE load per probe,
+// and 32 suffixes to a 64-byte sector -- the range a 13-base prefix leaves on a human-size genome (~46 suffixes) is two
+// sectors, and the steps after the first stay inside what the first one fetched.  The kernel is bound by HBM sectors
+// (DESIGN.md 2.8), so the entry is kept this small; searches deeper than prefix + kExtBases read index[] + genome[].
+constexpr int kExtBases = 6;
 
 __global__ __launch_bounds__(256) void anchor_ext_kernel(const uint8_t *genome, uint32_t tlen, const uint32_t *index,
-                                                         int64_t n, int prefixLen, uint32_t *ext) {
+                                                         int64_t n, int prefixLen, uint16_t *ext) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= n) return;
   const uint64_t base = (uint64_t)index[m] + (uint64_t)prefixLen;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void anchor_ext_kernel(const uint8_t *genome, 
     bits |= (uint32_t)c << (2 * k);
     vl++;
   }
-  ext[m] = bits | (vl << 26) | (end << 31);
+  ext[m] = (uint16_t)(bits | (vl << 12) | (end << 15));
 }
 
 // What the suffix at array position m holds `offset` bases in: 0..3 that base, 4 a base that is not ACGT, 5 nothing
@@ -150,9 +152,9 @@ __device__ __forceinline__ int suffix_symbol(const AnchorArgs &a, const uint8_t 
   const uint32_t k = offset - (uint32_t)a.prefixLen;  // (wraps to a large number below the prefix)
   if (a.ext && k < (uint32_t)kExtBases) {
     const uint32_t w = a.ext[m];
-    const uint32_t vl = (w >> 26) & 15u;
+    const uint32_t vl = (w >> 12) & 7u;
     if (k < vl) return (int)((w >> (2 * k)) & 3u);
-    if (k == vl) return (w >> 31) ? 5 : 4;
+    if (k == vl) return (w >> 15) ? 5 : 4;
     // (k > vl: not for a suffix of the current range; the general path answers)
   }
   const uint32_t im = a.index[m];
@@ -630,7 +632,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
   if (useExt && (!ctx->saExt || ctx->saExtGenome != ctx->genome || ctx->saExtIndex != ctx->saIndex)) {
     if (ctx->saExt) (void)hipFree(ctx->saExt);
     ctx->saExt = nullptr;
-    HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint32_t) * (size_t)ctx->saLen));
+    HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint16_t) * (size_t)ctx->saLen));
     hipLaunchKernelGGL(anchor_ext_kernel, dim3((unsigned)((ctx->saLen + 255) / 256)), dim3(256), 0, st, ctx->genome,
                        (uint32_t)ctx->genomeLen, ctx->saIndex, ctx->saLen, ctx->saPrefixLen, ctx->saExt);
     ctx->saExtGenome = ctx->genome;

@@ -204,7 +204,7 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
   for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
   total += (int64_t)ctx->pipeAnchors.bytes + (int64_t)ctx->pipeIntervals.bytes;
-  total += (ctx->saExt ? 8 : 4) * ctx->saLen + 8 * ctx->saTableLen;
+  total += (ctx->saExt ? 6 : 4) * ctx->saLen + 8 * ctx->saTableLen;
   return total;
 }
 

@@ -50,7 +50,7 @@ struct blasr_hip_ctx {
   int saPrefixLen = 0;
   // per array position, the bases that follow the lookup prefix (anchor_api.hip: the search reads them instead of
   // index[] + genome[]); built at the first anchor call for the (genome, index) pair it was made from
-  uint32_t *saExt = nullptr;
+  uint16_t *saExt = nullptr;
   const void *saExtGenome = nullptr, *saExtIndex = nullptr;
   // anchor stage: what the host needs back after each piece (the lists' first anchors) is written by the device
   // straight into pinned host memory -- no copy queued behind other transfers; the probe count and the assert flag
