@@ -196,8 +196,13 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
         break;
       }
       // the anchor call has synchronised the main stream: the copy can start at once, under the next sub-block
-      (void)hipMemcpyAsync((blasr_hip_anchor *)ctx->pipePinned + used, (blasr_hip_anchor *)ctx->pipeAnchors.p + used,
-                           sizeof(blasr_hip_anchor) * (size_t)n, hipMemcpyDeviceToHost, ctx->sideStream);
+      // (in 64 MB pieces: what the next sub-block's pieces report through pinned memory then waits behind 2 ms of
+      //  transfer, not behind the whole sub-block's 30)
+      for (int64_t at = 0; at < n; at += (64ll << 20) / (int64_t)sizeof(blasr_hip_anchor)) {
+        const int64_t m = std::min<int64_t>(n - at, (64ll << 20) / (int64_t)sizeof(blasr_hip_anchor));
+        (void)hipMemcpyAsync((blasr_hip_anchor *)ctx->pipePinned + used + at, (blasr_hip_anchor *)ctx->pipeAnchors.p + used + at,
+                             sizeof(blasr_hip_anchor) * (size_t)m, hipMemcpyDeviceToHost, ctx->sideStream);
+      }
       (void)hipEventRecord(j.copied, ctx->sideStream);
       {
         std::lock_guard<std::mutex> lock(mu);
