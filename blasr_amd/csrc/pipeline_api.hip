@@ -245,4 +245,33 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   return rc;
 }
 
+int blasr_hip_map_from_reads_host(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
+                                  int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
+                                  const blasr_hip_read *reads, const uint8_t *read_pool, int64_t read_pool_bytes,
+                                  const blasr_hip_pipeline_params *params, blasr_hip_hit *hits, int64_t hits_capacity,
+                                  int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch,
+                                  blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (n_reads < 0 || read_pool_bytes < 0 || (n_reads > 0 && (!reads || !read_pool)))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_from_reads_host: bad arguments");
+  for (int32_t r = 0; r < n_reads; r++)
+    if (reads[r].off < 0 || reads[r].off + (int64_t)reads[r].length > read_pool_bytes)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_from_reads_host: read %d outside the pool", r);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  struct Free {
+    void *p = nullptr;
+    ~Free() {
+      if (p) (void)hipFree(p);
+    }
+  } dReads, dPool;
+  HIP_TRY(ctx, hipMalloc(&dReads.p, sizeof(blasr_hip_read) * (size_t)std::max(n_reads, 1)));
+  HIP_TRY(ctx, hipMalloc(&dPool.p, (size_t)std::max<int64_t>(read_pool_bytes, 1)));
+  if (n_reads > 0) HIP_TRY(ctx, hipMemcpy(dReads.p, reads, sizeof(blasr_hip_read) * (size_t)n_reads, hipMemcpyHostToDevice));
+  if (read_pool_bytes > 0) HIP_TRY(ctx, hipMemcpy(dPool.p, read_pool, (size_t)read_pool_bytes, hipMemcpyHostToDevice));
+  return blasr_hip_map_from_reads_device(ctx, genome_host, seq_start_pos, n_seq_pos, count_table, count_tuple_size, n_reads,
+                                         reads, (const blasr_hip_read *)dReads.p, (const uint8_t *)dPool.p, params, hits,
+                                         hits_capacity, n_hits, read_hit_off, fetch, intervals_out, intervals_capacity,
+                                         n_intervals);
+}
+
 }  // extern "C"

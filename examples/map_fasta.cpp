@@ -6,10 +6,10 @@
 // What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
 //   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
 //   reads       blasr_hip_fasta_read                                   (ReaderAgglomerate, FASTA)
-//   anchoring   blasr_hip_sa_read + blasr_hip_upload_suffix_array + blasr_hip_anchor_reads_host (MapReadToGenome x 2 +
-//               SortMatchPosList on the device, :2279-2340), blasr_hip_count_tuples (:4479-4482) +
-//               blasr_hip_find_intervals (RemoveOverlappingAnchors, FindMaxIncreasingInterval, :2380-2500)
-//               -- or, with a text file: one interval per line: read start end qStart qEnd strand
+//   with a .sa  blasr_hip_sa_read + blasr_hip_upload_suffix_array, blasr_hip_count_tuples_device (:4479-4482), then ALL of
+//               MapRead in one call, blasr_hip_map_from_reads_host: MapReadToGenome x 2 + SortMatchPosList on the device
+//               (:2279-2340), RemoveOverlappingAnchors / FindMaxIncreasingInterval on host threads (:2380-2500), the path
+//   with a text file   one interval per line: read start end qStart qEnd strand
 //   MapRead     blasr_hip_map_reads_host                               (:2530-2644, C++ inside the library)
 //   epilogue    blasr_hip_ref_contig_location, blasr_hip_map_qvs, blasr_hip_m4_line   (:3509-3516, :3086)
 // Build: g++ -O2 -std=c++11 -I include examples/map_fasta.cpp -L blasr_amd -lblasr_hip -Wl,-rpath,'$ORIGIN/../blasr_amd'
@@ -73,6 +73,12 @@ int main(int argc, char **argv) {
     die("upload_genome", ctx);
   // ---- candidate intervals: from the reads (a .sa file given) or from a text file
   std::vector<blasr_hip_interval> ivs;
+  bool oneCall = false;
+  std::vector<blasr_hip_hit> hitsOne;
+  std::vector<int64_t> hitOffOne;
+  std::vector<uint8_t> seqArenaOne;
+  std::vector<uint32_t> opsArenaOne;
+  int64_t seqCapOne = 0, nHitsOne = 0;
   const size_t nameLen = strlen(argv[3]);
   if (nameLen > 3 && strcmp(argv[3] + nameLen - 3, ".sa") == 0) {
     blasr_hip_sa *sa = NULL;
@@ -83,32 +89,27 @@ int main(int argc, char **argv) {
     blasr_hip_sa_arrays(sa, &index, &saLen, &startPos, &endPos, &tableLen, &prefixLen);
     if (blasr_hip_upload_suffix_array(ctx, index, saLen, startPos, endPos, tableLen, prefixLen)) die("upload_suffix_array", ctx);
     blasr_hip_sa_free(sa);
-    blasr_hip_anchor_params ap;
-    blasr_hip_anchor_default_params(&ap);
-    if (ap.min_match_length < (uint32_t)prefixLen) ap.min_match_length = (uint32_t)prefixLen;  // Blasr.cpp:4433-4436
-    std::vector<int64_t> listOff(2 * (size_t)nReads + 1);
-    std::vector<blasr_hip_anchor> anchors(4 * pool.size() + 1024);
-    int64_t nAnchors = 0;
-    int rc = blasr_hip_anchor_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), &ap, anchors.data(),
-                                         (int64_t)anchors.size(), &nAnchors, listOff.data());
-    if (rc == BLASR_HIP_ERR_CAPACITY) {
-      anchors.resize((size_t)nAnchors);
-      rc = blasr_hip_anchor_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), &ap, anchors.data(),
-                                       (int64_t)anchors.size(), &nAnchors, listOff.data());
-    }
-    if (rc != BLASR_HIP_OK) die("anchor_reads", ctx);
-    std::vector<int32_t> countTable((size_t)1 << 16);  // tuples of params.lookupTableLength = 8 bases
-    blasr_hip_count_tuples(genome.data(), genomeLen, 8, countTable.data());
-    blasr_hip_interval_params ip;
-    blasr_hip_interval_default_params(&ip);
-    // the contig table as the reference's seqdb holds it; a single contig still has its two boundaries
-    ivs.resize((size_t)nReads * (size_t)ip.n_candidates + 1);
-    std::vector<int64_t> ivOff((size_t)nReads + 1);
+    // the whole of MapRead in one call: anchoring in sub-blocks on the device, interval finding on host threads
+    // underneath, then the path (blasr_hip_map_from_reads_host)
+    blasr_hip_pipeline_params pp;
+    blasr_hip_pipeline_default_params(&pp);
+    if (pp.anchor.min_match_length < (uint32_t)prefixLen) pp.anchor.min_match_length = (uint32_t)prefixLen;  // Blasr.cpp:4433-4436
+    std::vector<int32_t> countTable((size_t)1 << 16);  // tuples of params.lookupTableLength = 8 bases (Blasr.cpp:4479-4482)
+    if (blasr_hip_count_tuples_device(ctx, 8, countTable.data())) die("count_tuples", ctx);
+    oneCall = true;
+    ivs.resize((size_t)nReads * (size_t)pp.interval.n_candidates + 1);
+    hitsOne.resize(ivs.size() + 1);
+    hitOffOne.resize((size_t)nReads + 1);
+    seqCapOne = 64;
+    for (int r = 0; r < nReads; r++) seqCapOne += (int64_t)pp.interval.n_candidates * (5ll * reads[r].length + 4096);
+    seqArenaOne.resize((size_t)seqCapOne);
+    opsArenaOne.resize((size_t)seqCapOne);
+    blasr_hip_map_fetch fetchOne = {seqArenaOne.data(), seqCapOne, 0, opsArenaOne.data(), seqCapOne, 0};
     int64_t nIvs = 0;
-    if (blasr_hip_find_intervals(genome.data(), genomeLen, starts.data(), (int32_t)nContigs + 1, countTable.data(), 8, nReads,
-                                 reads.data(), anchors.data(), listOff.data(), NULL, &ip, ivs.data(), NULL, (int64_t)ivs.size(),
-                                 &nIvs, ivOff.data()) != BLASR_HIP_OK)
-      die("find_intervals", NULL);
+    if (blasr_hip_map_from_reads_host(ctx, genome.data(), starts.data(), (int32_t)nContigs + 1, countTable.data(), 8, nReads,
+                                      reads.data(), pool.data(), (int64_t)pool.size(), &pp, hitsOne.data(), (int64_t)hitsOne.size(),
+                                      &nHitsOne, hitOffOne.data(), &fetchOne, ivs.data(), (int64_t)ivs.size(), &nIvs) != BLASR_HIP_OK)
+      die("map_from_reads", ctx);
     ivs.resize((size_t)nIvs);
   } else {
     FILE *f = fopen(argv[3], "r");
@@ -121,18 +122,31 @@ int main(int argc, char **argv) {
     fclose(f);
   }
   // ---- MapRead for the whole block
-  blasr_hip_map_params prm;
+  std::vector<blasr_hip_hit> hits;
+  std::vector<int64_t> hitOff;
+  std::vector<uint8_t> seqArena;
+  std::vector<uint32_t> opsArena;
+  int64_t nHits = 0;
+  blasr_hip_map_params prm;  // (the one-call route used the same defaults)
   blasr_hip_map_default_params(&prm);
-  std::vector<blasr_hip_hit> hits(ivs.size() + 1);
-  std::vector<int64_t> hitOff((size_t)nReads + 1);
-  int64_t seqCap = 64, nHits = 0;
-  for (size_t k = 0; k < ivs.size(); k++) seqCap += 3ll * reads[ivs[k].read].length + (ivs[k].end - ivs[k].start);
-  std::vector<uint8_t> seqArena((size_t)seqCap);
-  std::vector<uint32_t> opsArena((size_t)seqCap);
-  blasr_hip_map_fetch fetch = {seqArena.data(), seqCap, 0, opsArena.data(), seqCap, 0};
-  if (blasr_hip_map_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), (int32_t)ivs.size(), ivs.data(), &prm,
-                               hits.data(), (int64_t)hits.size(), &nHits, hitOff.data(), &fetch) != BLASR_HIP_OK)
-    die("map_reads", ctx);
+  if (oneCall) {  // (already mapped above)
+    hits.swap(hitsOne);
+    hitOff.swap(hitOffOne);
+    seqArena.swap(seqArenaOne);
+    opsArena.swap(opsArenaOne);
+    nHits = nHitsOne;
+  } else {
+    hits.resize(ivs.size() + 1);
+    hitOff.resize((size_t)nReads + 1);
+    int64_t seqCap = 64;
+    for (size_t k = 0; k < ivs.size(); k++) seqCap += 3ll * reads[ivs[k].read].length + (ivs[k].end - ivs[k].start);
+    seqArena.resize((size_t)seqCap);
+    opsArena.resize((size_t)seqCap);
+    blasr_hip_map_fetch fetch = {seqArena.data(), seqCap, 0, opsArena.data(), seqCap, 0};
+    if (blasr_hip_map_reads_host(ctx, nReads, reads.data(), pool.data(), (int64_t)pool.size(), (int32_t)ivs.size(), ivs.data(), &prm,
+                                 hits.data(), (int64_t)hits.size(), &nHits, hitOff.data(), &fetch) != BLASR_HIP_OK)
+      die("map_reads", ctx);
+  }
   // ---- per read: StoreMapQVs over its alignments, then the line(s) of the best
   blasr_hip_mapqv_params qp;
   static const int32_t logProb[25] = {0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0, 15, 15, 15, 15, 15, 0};

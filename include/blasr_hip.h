@@ -751,6 +751,13 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
                                     blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
                                     blasr_hip_map_fetch *fetch, blasr_hip_interval *intervals_out,
                                     int64_t intervals_capacity, int64_t *n_intervals);
+/* Same with a host read table and pool (uploaded for the call). */
+int blasr_hip_map_from_reads_host(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
+                                  int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
+                                  const blasr_hip_read *reads, const uint8_t *read_pool, int64_t read_pool_bytes,
+                                  const blasr_hip_pipeline_params *params, blasr_hip_hit *hits, int64_t hits_capacity,
+                                  int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch,
+                                  blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals);
 /* Wall time (ms) of the last call: [0] anchoring of all sub-blocks (host stage underneath), [1] waiting for the host
  * stage's last sub-block, [2] the path, [3] host time spent finding intervals; counters: anchors, intervals. */
 int blasr_hip_pipeline_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[2]);
