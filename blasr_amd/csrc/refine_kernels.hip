@@ -861,10 +861,16 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
             const int wQc = __builtin_amdgcn_readlane(qc, src);
             const unsigned wRow = (unsigned)__builtin_amdgcn_readlane(rec.x, src);
             const bool wGlobal = __builtin_amdgcn_readlane((int)myPrevGlobal, src) != 0;
-            int2 *gring = gRingG[g];
+            // (explicitly global: as generic pointers these become FLAT accesses, whose lgkmcnt the LDS reads of the
+            //  step then wait on -- which would serialise the prefetch of the next step behind this one)
+            typedef unsigned long long __attribute__((address_space(1))) GPair;  // {S, I} of a ring entry
+            typedef uint8_t __attribute__((address_space(1))) GByte;
+            GPair *gring = (GPair *)gRingG[g];
+            auto pair_of = [](int2 v) { return (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32); };
+            auto int2_of = [](unsigned long long p) { return make_int2((int)(uint32_t)p, (int)(uint32_t)(p >> 32)); };
             const int gmask = gMaskG[g];
             if (!wGlobal) {  // the row above is a narrow one: from the LDS ring into the global ring
-              for (int c = wPlo + lane; c <= wPhi; c += 64) gring[c & gmask] = ringLds[wave][g][c & (kF4Ring - 1)];
+              for (int c = wPlo + lane; c <= wPhi; c += 64) gring[c & gmask] = pair_of(ringLds[wave][g][c & (kF4Ring - 1)]);
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             // Which of this row's {S, I} the next row can read: when that row is a narrow one of the same batch, only
@@ -881,8 +887,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
                 keepHi = nLo + nWidth - 1;
               }
             }
-            uint8_t *wArrows = arrowsG[g] + wRow;
-            const uint8_t *wT = tSeqG[g];
+            GByte *wArrows = (GByte *)(arrowsG[g] + wRow);
+            const GByte *wT = (const GByte *)tSeqG[g];
             const int wTLen = tLenG[g];
             ChunkCarry carry;
             carry.a = carry.b = carry.s = inf;
@@ -893,8 +899,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
             int2 upNext = make_int2(inf, inf);
             int sdNext = inf;
             if (wLo <= wPhi + 1) {
-              upNext = gring[(wLo + lane) & gmask];
-              sdNext = gring[(wLo + lane - 1) & gmask].x;
+              upNext = int2_of(gring[(wLo + lane) & gmask]);
+              sdNext = (int)(uint32_t)gring[(wLo + lane - 1) & gmask];
             }
             for (int cb = wLo; cb <= wHi; cb += 64) {
               const int c = cb + lane;
@@ -905,8 +911,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
               if (cb + 64 <= wHi) {
                 tNext = (c + 64 >= 0 && c + 64 < wTLen) ? (int)wT[c + 64] : 'N';
                 if (cb + 64 <= wPhi + 1) {  // beyond the row above there is nothing to read
-                  upNext = gring[(c + 64) & gmask];
-                  sdNext = gring[(c + 63) & gmask].x;
+                  upNext = int2_of(gring[(c + 64) & gmask]);
+                  sdNext = (int)(uint32_t)gring[(c + 63) & gmask];
                 } else {
                   upNext = make_int2(inf, inf);
                   sdNext = inf;
@@ -925,7 +931,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
               int sv, iv, arrow;
               row_chunk<true, false>(kc, carry, active, up.x, up.y, sd, mm, sv, iv, arrow);
               if (active) {
-                if (c >= keepLo && c <= keepHi) gring[c & gmask] = make_int2(sv, iv);
+                if (c >= keepLo && c <= keepHi) gring[c & gmask] = pair_of(make_int2(sv, iv));
                 wArrows[c - wLo] = (uint8_t)arrow;
               }
             }
