@@ -180,4 +180,53 @@ static void RefineAlignmentsGPU(T_Sequence &query, std::vector<T_AlignmentCandid
   if (params.sortRefinedAlignments)  // Blasr.cpp:2178-2180
     std::sort(alignmentPtrs.begin(), alignmentPtrs.end(), SortAlignmentPointersByScore());
 }
+// Replaces the two MapReadToGenome calls of MapRead (Blasr.cpp:2279-2297) for one read: both strands anchored on the
+// device in the suffix array the mapper holds (uploaded once per mapping thread's context).  The lists come back in
+// MapReadToGenome's own order; MapRead sorts them itself right after (:2339-2340).
+static __thread bool tlsHipIndexUploaded = false;
+
+template <typename T_GenomeSeq, typename T_SuffixArrayT, typename T_Sequence>
+static void MapReadToGenomeGPU(T_GenomeSeq &genome, T_SuffixArrayT &sarray, T_Sequence &read, MappingParameters &params,
+                               std::vector<ChainedMatchPos> &matchPosList, std::vector<ChainedMatchPos> &rcMatchPosList,
+                               int &numKeysMatched, int &rcNumKeysMatched) {
+  if (!tlsHipIndexUploaded) {
+    if (blasr_hip_upload_genome(tlsHipCtx, (const uint8_t *)genome.seq, genome.length, NULL, 0) != BLASR_HIP_OK ||
+        blasr_hip_upload_suffix_array(tlsHipCtx, sarray.index, sarray.length, sarray.startPosTable, sarray.endPosTable,
+                                      sarray.lookupTableLength, sarray.lookupPrefixLength) != BLASR_HIP_OK) {
+      cout << "ERROR, GPU index upload failed: " << blasr_hip_last_error(tlsHipCtx) << endl;
+      exit(1);
+    }
+    tlsHipIndexUploaded = true;
+  }
+  blasr_hip_anchor_params ap;
+  blasr_hip_anchor_default_params(&ap);
+  ap.min_match_length = params.anchorParameters.minMatchLength;
+  ap.min_prefix_match_length = params.lookupTableLength;
+  ap.expand = params.anchorParameters.expand;
+  ap.max_anchors_per_position = params.anchorParameters.maxAnchorsPerPosition;
+  ap.advance_exact_matches = params.anchorParameters.advanceExactMatches;
+  ap.max_lcp_length = params.anchorParameters.maxLCPLength;
+  ap.use_lookup_table = params.anchorParameters.useLookupTable;
+  ap.stop_mapping_once_unique = params.anchorParameters.stopMappingOnceUnique;
+  ap.forward_only = params.forwardOnly;
+  ap.sorted = 0;
+  blasr_hip_read rd = {0, read.length, read.subreadStart, read.subreadEnd, 0};
+  std::vector<blasr_hip_anchor> anchors(4 * (size_t)read.length + 1024);
+  int64_t listOff[3] = {0, 0, 0}, n = 0;
+  int rc = blasr_hip_anchor_reads_host(tlsHipCtx, 1, &rd, (const uint8_t *)read.seq, read.length, &ap, anchors.data(),
+                                       (int64_t)anchors.size(), &n, listOff);
+  if (rc == BLASR_HIP_ERR_CAPACITY) {
+    anchors.resize((size_t)n + 1);
+    rc = blasr_hip_anchor_reads_host(tlsHipCtx, 1, &rd, (const uint8_t *)read.seq, read.length, &ap, anchors.data(),
+                                     (int64_t)anchors.size(), &n, listOff);
+  }
+  if (rc != BLASR_HIP_OK) {
+    cout << "ERROR, GPU anchoring failed: " << blasr_hip_last_error(tlsHipCtx) << endl;
+    exit(1);
+  }
+  for (int64_t i = listOff[0]; i < listOff[1]; i++) matchPosList.push_back(ChainedMatchPos(anchors[i].t, anchors[i].q, anchors[i].l));
+  for (int64_t i = listOff[1]; i < listOff[2]; i++) rcMatchPosList.push_back(ChainedMatchPos(anchors[i].t, anchors[i].q, anchors[i].l));
+  numKeysMatched = (int)matchPosList.size();
+  rcNumKeysMatched = (int)rcMatchPosList.size();
+}
 #endif

@@ -8,6 +8,7 @@ committed: oracle/_ref is git-ignored), adds oracle/dropin/blasr_hip_dropin.h (t
   Blasr.cpp             #include of the helper before AlignIntervals
                         AlignIntervals (:1716-1724)   SDPAlign + ComputeAlignmentStats -> SDPAlignCandidateGPU under -useGPU
                         RefineAlignments (:2164-2181) the per-candidate loop -> RefineAlignmentsGPU under -useGPU
+                        MapRead (:2279-2297)          the two MapReadToGenome calls -> MapReadToGenomeGPU under -useGPU
                         MapReads (:3238)              one blasr_hip context per mapping thread, next to MappingBuffers
                         main (:4023)                  -useGPU / -gpuDevice registered with the command-line parser
 Usage: python oracle/make_dropin.py [reference checkout]   (default /root/reference)"""
@@ -59,6 +60,11 @@ def main():
                     "  if (params.useGPU) {\n    RefineAlignmentsGPU(*bothQueryStrands[0], alignmentPtrs, params);\n    return;\n  }\n"
                     "  UInt i;\n  for (i = 0; i < alignmentPtrs.size(); i++ ) {\n    RefineAlignment(*bothQueryStrands[0], genome, "
                     "*alignmentPtrs[i], params, mappingBuffers);\n  }\n", "RefineAlignments")
+    bl = patch_once(bl, "    if (params.useSuffixArray) {\n      params.anchorParameters.lcpBoundsOutPtr = mapData->lcpBoundsOutPtr;\n",
+                    "    if (params.useGPU and params.useSuffixArray) {\n      MapReadToGenomeGPU(genome, sarray, read, params, "
+                    "mappingBuffers.matchPosList, mappingBuffers.rcMatchPosList, numKeysMatched, rcNumKeysMatched);\n    }\n"
+                    "    else if (params.useSuffixArray) {\n      params.anchorParameters.lcpBoundsOutPtr = mapData->lcpBoundsOutPtr;\n",
+                    "MapRead's anchoring")
     bl = patch_once(bl, "  MappingBuffers mappingBuffers;\n  while (true) {\n",
                     "  MappingBuffers mappingBuffers;\n  BlasrHipThreadContext hipThreadContext(params.useGPU, params.gpuDevice);\n"
                     "  while (true) {\n", "MapReads")

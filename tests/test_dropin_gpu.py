@@ -1,8 +1,10 @@
 """The drop-in, compiled for real: oracle/_ref/blasrmc_gpu is the REFERENCE's own alignment/Blasr.cpp with
 INTEGRATION.md's patch applied (oracle/make_dropin.py: a scratch copy at build time; oracle/dropin/blasr_hip_dropin.h
 holds the new code) and linked against libblasr_hip.so -- a C++ caller of the C ABI inside the reference's MapRead,
-one context per mapping thread.  With -useGPU -nproc 2 it must print the -m 4 lines the unpatched binary printed for
-the noisy reads with competing candidates (tests/golden/m4_noisy_golden.npz), anchoring and all."""
+one context per mapping thread.  With -useGPU -nproc 2 -- MapReadToGenome (both strands, on the device), SDPAlign +
+ComputeAlignmentStats and the refine loop through the library, everything else the reference's own code -- it must
+print the -m 4 lines the unpatched binary printed for the noisy reads with competing candidates
+(tests/golden/m4_noisy_golden.npz)."""
 import os
 import subprocess
 
