@@ -30,6 +30,7 @@ EXPORTS = [
     "blasr_hip_upload_genome", "blasr_hip_windows_device", "blasr_hip_windows_host",
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
+    "blasr_hip_extend_default_params", "blasr_hip_extend_device", "blasr_hip_extend_host",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
@@ -81,6 +82,17 @@ class _KbandLinearParams(C.Structure):
 class _KbandBatch(C.Structure):
     _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
                 ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("k", C.c_void_p)]
+
+
+class _ExtendParams(C.Structure):
+    _fields_ = [("matrix", C.c_int32 * 25), ("ins", C.c_int32), ("del_", C.c_int32), ("band", C.c_int32),
+                ("min_extend_n_bases", C.c_int32), ("max_n_drops", C.c_int32)]
+
+
+class _ExtendBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("q_pos", C.c_void_p), ("t_pos", C.c_void_p),
+                ("reverse", C.c_void_p)]
 
 
 def ops_to_alignment(ops):
@@ -284,6 +296,10 @@ def load_library():
                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         for name in ("blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_KbandBatch), C.POINTER(_KbandLinearParams), C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.blasr_hip_extend_default_params.argtypes = [C.POINTER(_ExtendParams)]
+        for name in ("blasr_hip_extend_device", "blasr_hip_extend_host"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_ExtendBatch), C.POINTER(_ExtendParams), C.c_void_p,
                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         lib.blasr_hip_sort_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.blasr_hip_remove_low_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -1055,6 +1071,52 @@ class Context:
             kp.matrix[i] = int(v)
         kp.ins, kp.del_, kp.fn_ins, kp.fn_del, kp.align_type = ins, dele, fn_ins, fn_del, align_type
         return self._kband_call(self.lib.blasr_hip_kband_linear_host, pairs, ks, kp, ops_capacity)
+
+    def extend(self, tasks, band=10, max_n_drops=10, matrix=None, ins=5, dele=5, min_extend_n_bases=1,
+               ops_capacity=None):
+        """ExtendAlignmentForward / ExtendAlignmentReverse (ExtendAlign.h:365-445), the -extend step of AlignIntervals
+        (Blasr.cpp:1749-1940).  tasks: list of (query, query_pos, target, ref_pos, reverse).  Returns dicts with
+        status, score (the function's return value), qPos, tPos, nCells, ops, blocks, gap lists."""
+        n = len(tasks)
+        if n == 0:
+            return []
+        ep = _ExtendParams()
+        self._check(self.lib.blasr_hip_extend_default_params(C.byref(ep)))
+        if matrix is not None:
+            for i, v in enumerate(np.ascontiguousarray(matrix, dtype=np.int32).reshape(-1)):
+                ep.matrix[i] = int(v)
+        ep.ins, ep.del_, ep.band, ep.min_extend_n_bases, ep.max_n_drops = ins, dele, band, min_extend_n_bases, max_n_drops
+        seqs, q_off, q_len, t_off, t_len, at = [], [], [], [], [], 0
+        for q, _, t, _, _ in tasks:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            q_off.append(at); q_len.append(len(q)); at += len(q)
+            t_off.append(at); t_len.append(len(t)); at += len(t)
+            seqs += [q, t]
+        seq = np.ascontiguousarray(np.concatenate(seqs)) if at else np.zeros(1, np.uint8)
+        q_off, t_off = np.array(q_off, np.int64), np.array(t_off, np.int64)
+        q_len, t_len = np.array(q_len, np.int32), np.array(t_len, np.int32)
+        q_pos = np.array([x[1] for x in tasks], np.int32)
+        t_pos = np.array([x[3] for x in tasks], np.int32)
+        rev = np.array([1 if x[4] else 0 for x in tasks], np.uint8)
+        eb = _ExtendBatch()
+        eb.n = n
+        eb.seq, eb.q_off, eb.q_len = seq.ctypes.data, q_off.ctypes.data, q_len.ctypes.data
+        eb.t_off, eb.t_len = t_off.ctypes.data, t_len.ctypes.data
+        eb.q_pos, eb.t_pos, eb.reverse = q_pos.ctypes.data, t_pos.ctypes.data, rev.ctypes.data
+        cap = int(q_len.sum() + t_len.sum() + 8 * n) if ops_capacity is None else int(ops_capacity)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        ops = np.zeros(max(cap, 1), dtype=np.uint32)
+        used = C.c_int64(0)
+        self._check(self.lib.blasr_hip_extend_host(self.handle, C.byref(eb), C.byref(ep), results.ctypes.data,
+                                                   ops.ctypes.data, cap, C.byref(used)))
+        out = []
+        for r in results:
+            o = ops[int(r["ops_off"]): int(r["ops_off"]) + int(r["n_ops"])].copy()
+            blocks, gc, gi = ops_to_alignment(o)
+            out.append(dict(status=int(r["status"]), score=int(r["dp_score"]), nCells=int(r["n_cells"]),
+                            qPos=int(r["q_pos"]), tPos=int(r["t_pos"]), ops=o, blocks=blocks, gapCounts=gc, gapItems=gi))
+        return out
 
     def last_fill4(self):
         """fillp_kernel launches of the last refine call: ms (HIP events), launches, algorithmic bytes, cells."""

@@ -477,6 +477,50 @@ int blasr_hip_kband_linear_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch 
                                 uint32_t *ops, int64_t ops_capacity, int64_t *ops_used);
 
 /* ------------------------------------------------------------------------------------------------
+ * next-3, first piece: ExtendAlignmentForward / ExtendAlignmentReverse (algorithms/alignment/ExtendAlign.h:115-445),
+ * the -extend step AlignIntervals runs on both ends of every SDP alignment (alignment/Blasr.cpp:1749-1940): band of
+ * 2k+1 diagonals, linear gaps, rows added until max_n_drops rows have raised the row minimum; the alignment ends at
+ * the first cell holding the global minimum.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_extend_params {
+  int32_t matrix[25];          /* distScoreFn.scoreMatrix, [target][query] (DistanceMatrixScoreFunction.h:43-45) */
+  int32_t ins, del;            /* distScoreFn.ins / del = params.insertion / deletion (Blasr.cpp:3666-3667) */
+  int32_t band;                /* k = params.extendBandSize (10); 0..31 here */
+  int32_t min_extend_n_bases;  /* 1 (Blasr.cpp:1833) */
+  int32_t max_n_drops;         /* params.maxExtendDropoff (10) */
+} blasr_hip_extend_params;
+int blasr_hip_extend_default_params(blasr_hip_extend_params *params);
+
+/* Task i mirrors one call: querySeq = seq[q_off[i] .. +q_len[i]), refSeq = seq[t_off[i] .. +t_len[i]),
+ * queryPos = q_pos[i], refPos = t_pos[i].  reverse[i] == 0: ExtendAlignmentForward aligns query[queryPos..) to
+ * target[refPos..); != 0: ExtendAlignmentReverse aligns the bases BEFORE queryPos / refPos, walking left (the
+ * reference reads them as query[queryPos - q], so q_pos <= q_len and t_pos <= t_len are required; otherwise the
+ * task gets BLASR_HIP_TASK_BAD_GUIDE).  Device pointers for _device, host pointers for _host. */
+typedef struct blasr_hip_extend_batch {
+  int32_t n;
+  const uint8_t *seq;
+  const int64_t *q_off;
+  const int32_t *q_len;
+  const int64_t *t_off;
+  const int32_t *t_len;
+  const int32_t *q_pos;
+  const int32_t *t_pos;
+  const uint8_t *reverse;
+} blasr_hip_extend_batch;
+
+/* Results reuse blasr_hip_refine_result: dp_score = the function's return value (0 when a sequence is shorter
+ * than min_extend_n_bases, INT_MAX when no row was scored), q_pos / t_pos = alignment.qPos / tPos (Forward: queryPos /
+ * refPos, ExtendAlign.h:401-402; Reverse: the leftmost aligned base, :97-103), n_cells = cells scored, ops = the
+ * ordered arrow path run-length encoded (Alignment::ArrowPathToAlignment rebuilds blocks / gaps from it and drops
+ * a trailing gap run, Alignment.h:190-254).  The statistics fields are 0. */
+int blasr_hip_extend_device(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *batch,
+                            const blasr_hip_extend_params *params, blasr_hip_refine_result *results, uint32_t *ops,
+                            int64_t ops_capacity, int64_t *ops_used);
+int blasr_hip_extend_host(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *batch,
+                          const blasr_hip_extend_params *params, blasr_hip_refine_result *results, uint32_t *ops,
+                          int64_t ops_capacity, int64_t *ops_used);
+
+/* ------------------------------------------------------------------------------------------------
  * Output epilogue, first pieces: host functions, no GPU work.
  * ------------------------------------------------------------------------------------------------ */
 /* AssignRefContigLocation (alignment/Blasr.cpp:2183-2220): the contig of an alignment whose target window starts

@@ -2066,6 +2066,140 @@ int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int
 }
 
 /* ---------------------------------------------------------------------------------------------------------
+ * next-3 (first piece): ExtendAlignment (algorithms/alignment/ExtendAlign.h:115-363) behind its two entry points
+ * ExtendAlignmentForward (:365-405) and ExtendAlignmentReverse (:407-445), the -extend step of AlignIntervals
+ * (alignment/Blasr.cpp:1749-1940).  Band of 2k+1 diagonals around the main one, linear gaps, rows added until
+ * maxNDrops rows have raised the row minimum; the alignment ends at the first cell holding the global minimum.
+ * --------------------------------------------------------------------------------------------------------- */
+/* idxQ / idxT: T_Index::queryPos / refPos; QuerySeqPos(q) = idxQ + q (ForwardIndex :63-69) or idxQ - q
+ * (ReverseIndex :89-95).  Returns the function's value; *endQ / *endT = globalMinScoreQPos / TPos. */
+static int extend_alignment(const unsigned char *qs, const unsigned char *ts, int idxQ, int idxT, int qAlignLen,
+                            int tAlignLen, int reverse, const int m[5][5], int ins, int del, int k,
+                            int minExtendNBases, int maxNDrops, aln_t *out, int *endQ, int *endT) {
+  const int nCols = 2 * k + 2, middleCol = k + 1; /* :140-148 */
+  *endQ = *endT = 0;
+  if (qAlignLen < minExtendNBases || tAlignLen < minExtendNBases) return 0; /* :150-157 */
+  const int maxRows = qAlignLen + 2;
+  const size_t total = (size_t)maxRows * (size_t)nCols;
+  int *S = (int *)calloc(total, sizeof(int));
+  unsigned char *P = (unsigned char *)malloc(total);
+  memset(P, A_NONE, total);
+  /* RCToIndex (:13-41) with qStart = tStart = 0 */
+#define EX_IN(r, c) ((r) >= 0 && (c) >= 0 && abs((r) - (c)) <= k && middleCol - ((r) - (c)) < nCols)
+#define EX_IX(r, c) ((size_t)(r) * (size_t)nCols + (size_t)(middleCol - ((r) - (c))))
+  for (int q = 1; q <= k && q - 1 != qAlignLen; q++) { /* :186-195 */
+    S[EX_IX(q, 0)] = S[EX_IX(q - 1, 0)] + ins;
+    P[EX_IX(q, 0)] = A_UP;
+  }
+  for (int t = 1; t <= k && t - 1 != tAlignLen; t++) { /* :201-212 */
+    S[EX_IX(0, t)] = S[EX_IX(0, t - 1)] + del;
+    P[EX_IX(0, t)] = A_LEFT;
+  }
+  int nDrops = 0, prevRowMin = INT_MAX, globalMin = INT_MAX, gq = 0, gt = 0;
+  const int maxAlignLength = (qAlignLen < tAlignLen ? qAlignLen : tAlignLen) + maxNDrops; /* :228 */
+  for (int q = 1; q - 1 != qAlignLen && nDrops < maxNDrops && q < maxAlignLength; q++) { /* :230-233 */
+    int curRowMin = INT_MAX;
+    const int tStart = q - k > 1 ? q - k : 1;
+    int tEnd = q + k + 1 < tAlignLen + 1 ? q + k + 1 : tAlignLen + 1;
+    if (maxAlignLength < tEnd) tEnd = maxAlignLength;
+    for (int t = tStart; t < tEnd; t++) { /* :252-330 */
+      const int qPos = reverse ? idxQ - (q - 1) : idxQ + (q - 1), tPos = reverse ? idxT - (t - 1) : idxT + (t - 1);
+      int insScore = INT_MAX, delScore = INT_MAX, matchScore = INT_MAX;
+      if (EX_IN(q - 1, t)) insScore = S[EX_IX(q - 1, t)] + ins;
+      if (EX_IN(q, t - 1)) delScore = S[EX_IX(q, t - 1)] + del;
+      if (EX_IN(q - 1, t - 1)) matchScore = S[EX_IX(q - 1, t - 1)] + m[three_bit(ts[tPos])][three_bit(qs[qPos])];
+      int minScore = matchScore < delScore ? matchScore : delScore;
+      if (insScore < minScore) minScore = insScore;
+      S[EX_IX(q, t)] = minScore;
+      if (minScore != INT_MAX) { /* :306-310: the last test that holds wins */
+        if (minScore == insScore) P[EX_IX(q, t)] = A_UP;
+        if (minScore == delScore) P[EX_IX(q, t)] = A_LEFT;
+        if (minScore == matchScore) P[EX_IX(q, t)] = A_DIAG;
+      } else {
+        P[EX_IX(q, t)] = A_NONE;
+      }
+      if (minScore < curRowMin) curRowMin = minScore;
+      if (minScore < globalMin) {
+        globalMin = minScore;
+        gq = q;
+        gt = t;
+      }
+    }
+    if (curRowMin > prevRowMin) nDrops++; /* :333-336 */
+    prevRowMin = curRowMin;
+  }
+  /* traceback from the global minimum (:339-374) */
+  int q = gq, t = gt, n = 0;
+  unsigned char *path = (unsigned char *)malloc((size_t)gq + (size_t)gt + 1);
+  if (P[EX_IX(q, t)] != A_NONE) {
+    while (q > 0 || t > 0) {
+      const unsigned char arrow = P[EX_IX(q, t)];
+      path[n++] = arrow;
+      if (arrow == A_DIAG) {
+        q--;
+        t--;
+      } else if (arrow == A_LEFT) {
+        t--;
+      } else if (arrow == A_UP) {
+        q--;
+      } else {
+        break; /* the reference asserts here; not reachable from a scored cell */
+      }
+    }
+  }
+  if (!reverse) /* ForwardIndex::OrderArrowVector :79-81; ReverseIndex keeps the order :105-106 */
+    for (int i = 0; i < n / 2; i++) {
+      const unsigned char sw = path[i];
+      path[i] = path[n - 1 - i];
+      path[n - 1 - i] = sw;
+    }
+  arrow_path_to_alignment(out, path, n);
+  if (reverse) { /* :376-377 with ReverseIndex::GetQueryStartPos :97-103 */
+    out->qPos = (uint32_t)(idxQ - (gq - 1));
+    out->tPos = (uint32_t)(idxT - (gt - 1));
+  }
+  *endQ = gq;
+  *endT = gt;
+  free(path);
+  free(S);
+  free(P);
+#undef EX_IN
+#undef EX_IX
+  return globalMin;
+}
+
+/* reverse 0: ExtendAlignmentForward (aligns query[queryPos..) to target[refPos..), qPos/tPos = queryPos/refPos),
+ * reverse 1: ExtendAlignmentReverse (aligns the bases before queryPos / refPos, walking left).
+ * out[5] = return value, qPos, tPos, globalMinScoreQPos, globalMinScoreTPos. */
+int bo_extend_align(const unsigned char *q, int qlen, int queryPos, const unsigned char *t, int tlen, int refPos,
+                    const int *matrix25, int ins, int del, int k, int minExtendNBases, int maxNDrops, int reverse,
+                    int *out, int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
+                    int *gapItems, int gapItemCap, int *nGapItems) {
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  aln_t a;
+  aln_init(&a);
+  int endQ = 0, endT = 0;
+  if (reverse) {
+    out[0] = extend_alignment(q, t, queryPos - 1, refPos - 1, queryPos, refPos, 1, m, ins, del, k, minExtendNBases,
+                              maxNDrops, &a, &endQ, &endT);
+  } else {
+    out[0] = extend_alignment(q, t, queryPos, refPos, qlen - queryPos, tlen - refPos, 0, m, ins, del, k,
+                              minExtendNBases, maxNDrops, &a, &endQ, &endT);
+    a.qPos = (uint32_t)queryPos; /* :401-402 */
+    a.tPos = (uint32_t)refPos;
+  }
+  out[1] = (int)a.qPos;
+  out[2] = (int)a.tPos;
+  out[3] = endQ;
+  out[4] = endT;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+  aln_free(&a);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
  * next-2: first pieces of the output epilogue
  * --------------------------------------------------------------------------------------------------------- */
 /* SequenceIndexDatabase::SearchForIndex (SequenceIndexDatabase.h:108-118): upper_bound over seqStartPos[1..] */

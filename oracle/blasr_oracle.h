@@ -113,6 +113,13 @@ int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int
                    int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
                    int *nGapItems);
 
+/* next-3 (first piece): ExtendAlignmentForward / Reverse (ExtendAlign.h:115-445), the -extend step of AlignIntervals
+ * (Blasr.cpp:1749-1940).  out[5] = return value, qPos, tPos, globalMinScoreQPos, globalMinScoreTPos. */
+int bo_extend_align(const unsigned char *q, int qlen, int queryPos, const unsigned char *t, int tlen, int refPos,
+                    const int *matrix25, int ins, int del, int k, int minExtendNBases, int maxNDrops, int reverse,
+                    int *out, int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
+                    int *gapItems, int gapItemCap, int *nGapItems);
+
 /* next-2 (first pieces of the output epilogue): AssignRefContigLocation (alignment/Blasr.cpp:2183-2220),
  * CreateCIGARString (printers/SAMPrinter.h:122-416; clipping: hard 0, soft 1, subread 2, none 3),
  * IntervalAlignmentPrinter::Print (printers/IntervalAlignmentPrinter.h:9-38). */

@@ -23,6 +23,7 @@
 #include "algorithms/alignment/AffineKBandAlign.h"
 #include "algorithms/alignment/GuidedAlign.h"
 #include "algorithms/alignment/AffineGuidedAlign.h"
+#include "algorithms/alignment/ExtendAlign.h"
 #include "algorithms/alignment/AlignmentUtils.h"
 #include "algorithms/alignment/DistanceMatrixScoreFunction.h"
 
@@ -302,5 +303,32 @@ int ref_kband_align(const unsigned char *q, int qlen, const unsigned char *t, in
   out[2] = (int)a.tPos;
   return flatten(a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
 }
+
+// ExtendAlignmentForward / ExtendAlignmentReverse (ExtendAlign.h:365-445) with the types and the score function
+// AlignIntervals hands them (Blasr.cpp:1826-1838, 1885-1897).  The two matrices are the mapper's reusable buffers:
+// they arrive here large and full of leftovers, which must not show in the result.  out[3] = score, qPos, tPos.
+int ref_extend_align(const unsigned char *q, int qlen, int queryPos, const unsigned char *t, int tlen, int refPos,
+                     const int *matrix25, int ins, int del, int k, int minExtendNBases, int maxNDrops, int reverse,
+                     int *out, int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
+                     int *gapItems, int gapItemCap, int *nGapItems) {
+  ScoreFn fn;
+  make_score_fn(fn, matrix25, ins, del, 0, 0);
+  FASTQSequence qs;
+  DNASequence ts;
+  set_seq(qs, q, qlen);
+  set_seq(ts, t, tlen);
+  std::vector<int> scoreMat((size_t)(qlen + 2) * (2 * k + 2) + 977, -123456);
+  std::vector<Arrow> pathMat(scoreMat.size(), Left);
+  Alignment a;
+  if (reverse)
+    out[0] = ExtendAlignmentReverse(qs, queryPos, ts, refPos, k, scoreMat, pathMat, a, fn, minExtendNBases, maxNDrops);
+  else
+    out[0] = ExtendAlignmentForward(qs, queryPos, ts, refPos, k, scoreMat, pathMat, a, fn, minExtendNBases, maxNDrops);
+  out[1] = (int)a.qPos;
+  out[2] = (int)a.tPos;
+  out[3] = out[4] = -1;
+  return flatten(a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+}
+
 
 }  // extern "C"

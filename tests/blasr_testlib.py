@@ -422,6 +422,62 @@ def kband_align(checker, q, t, k, align_type=KBAND_GLOBAL, matrix=None, ins=5, d
                 gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
 
 
+def extend_align(checker, q, query_pos, t, ref_pos, k=10, max_n_drops=10, reverse=False, matrix=None, ins=5, dele=5,
+                 min_extend_n_bases=1):
+    """ExtendAlignmentForward / ExtendAlignmentReverse (ExtendAlign.h:365-445) with a DistanceMatrixScoreFunction,
+    as AlignIntervals calls them under -extend (Blasr.cpp:1826-1838, 1885-1897).  `checker` = load_oracle() or
+    load_ref().  Returns score (the return value), qPos, tPos, blocks, gap lists."""
+    q, t = _u8(q), _u8(t)
+    m = np.ascontiguousarray(SMRT_MATRIX if matrix is None else matrix, dtype=np.int32).reshape(-1)
+    cap = len(q) + len(t) + 16
+    blocks = np.zeros(3 * cap, dtype=np.int32)
+    gap_counts, gap_items = np.zeros(cap, dtype=np.int32), np.zeros(2 * cap, dtype=np.int32)
+    out = np.zeros(5, dtype=np.int32)
+    nb, ngl, ngi = C.c_int(0), C.c_int(0), C.c_int(0)
+    f = checker.fn("extend_align")
+    f.restype = C.c_int
+    rc = f(_p(q, C.c_ubyte), len(q), int(query_pos), _p(t, C.c_ubyte), len(t), int(ref_pos), _p(m), int(ins), int(dele),
+           int(k), int(min_extend_n_bases), int(max_n_drops), int(bool(reverse)), _p(out), _p(blocks), cap, C.byref(nb),
+           _p(gap_counts), cap, C.byref(ngl), _p(gap_items), cap, C.byref(ngi))
+    assert rc == 0
+    return dict(score=int(out[0]), qPos=int(out[1]), tPos=int(out[2]), blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(),
+                gapCounts=gap_counts[: ngl.value].copy(), gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
+
+
+def random_extend_case(rng, it):
+    """One ExtendAlignment input: a read end and the genome next to it, related by PacBio-like noise for a stretch
+    and unrelated after it (so that the drop-off rule ends the extension), plus the degenerate shapes."""
+    from blasr_amd import synth
+    ql = int(rng.choice([1, 2, 5, 11, 40, 120, 500, 650]))
+    q, t = synth.make_pair(rng, ql, flank=(0, 0))
+    if len(q) == 0 or len(t) == 0:
+        q, t = np.frombuffer(b"A", np.uint8).copy(), np.frombuffer(b"AC", np.uint8).copy()
+    junk = int(rng.choice([0, 0, 30, 200]))
+    if junk:
+        q = np.concatenate([q, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, junk)]])
+        t = np.concatenate([t, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, junk)]])
+    if it % 5 == 0:
+        t = t[: max(1, len(t) - int(rng.integers(0, 60)))]
+    if it % 7 == 0:
+        q = q[: max(1, len(q) - int(rng.integers(0, 60)))]
+    if it % 11 == 0:
+        q = q.copy()
+        q[int(rng.integers(0, len(q)))] = ord("N")
+    if it % 13 == 0:
+        t = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, len(t))]  # nothing to extend into
+    reverse = bool(it % 2)
+    if reverse:
+        q, t = q[::-1].copy(), t[::-1].copy()
+        qp, tp = len(q) - int(rng.choice([0, 0, 1, 3])), len(t) - int(rng.choice([0, 0, 1, 2]))
+        qp, tp = max(qp, 0), max(tp, 0)
+    else:
+        qp, tp = int(rng.choice([0, 0, 1, 4])), int(rng.choice([0, 0, 2]))
+        qp, tp = min(qp, len(q)), min(tp, len(t))
+    k = int(rng.choice([0, 1, 3, 10, 10, 15, 16, 31]))
+    drops = int(rng.choice([0, 1, 2, 10, 10, 25]))
+    return q, qp, t, tp, k, drops, reverse
+
+
 # --- next-2: the epilogue pieces, oracle (plain C) and reference (ref_mapper_harness.cpp) --------------------
 class EpilogueChecker:
     """bo_* of the oracle (kind="oracle") or ref_* of the reference harness (kind="ref"), same Python surface."""

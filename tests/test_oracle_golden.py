@@ -84,3 +84,21 @@ def test_oracle_kband_linear_matches_golden(oracle):
         assert np.array_equal(r["gapItems"], g["l%d_gapItems" % i]), i
         types.add(at)
     assert types == {1, 2, 3, 7}
+
+
+def test_oracle_extend_matches_golden(oracle):
+    """next-3: the oracle's ExtendAlignment restatement (Forward and Reverse) against the vectors of the reference's
+    templates."""
+    import os
+    from blasr_testlib import extend_align
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extend_golden.npz"))
+    seen = set()
+    for i in range(int(g["n"])):
+        qp, tp, k, drops, rev = (int(v) for v in g["e%d_par" % i])
+        r = extend_align(oracle, g["e%d_q" % i], qp, g["e%d_t" % i], tp, k, drops, bool(rev))
+        assert [r["score"], r["qPos"], r["tPos"]] == [int(v) for v in g["e%d_res" % i]], i
+        assert np.array_equal(r["blocks"], g["e%d_blocks" % i]), i
+        assert np.array_equal(r["gapCounts"], g["e%d_gapCounts" % i]), i
+        assert np.array_equal(r["gapItems"], g["e%d_gapItems" % i]), i
+        seen.add((rev, len(r["blocks"]) > 0))
+    assert seen == {(0, False), (0, True), (1, False), (1, True)}

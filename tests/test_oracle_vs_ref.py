@@ -85,6 +85,23 @@ def test_introsort_clone_matches_std_sort_on_ties(oracle, ref):
         assert first_difference(a, b, ["score", "qPos", "tPos", "blocks"]) is None, it
 
 
+def test_extend_alignment_sweep(oracle, ref):
+    """next-3: ExtendAlignmentForward / Reverse, the oracle against the reference's templates over the random shapes
+    (bands 0..31, drop limits 0..25, sequences that end early, N, unrelated sequence).  The harness hands the
+    reference dirty, oversized matrices, as the mapper's reused buffers are."""
+    from blasr_testlib import extend_align, random_extend_case
+    rng = np.random.default_rng(77)
+    extended = 0
+    for it in range(1500):
+        q, qp, t, tp, k, drops, rev = random_extend_case(rng, it)
+        a, b = extend_align(oracle, q, qp, t, tp, k, drops, rev), extend_align(ref, q, qp, t, tp, k, drops, rev)
+        assert (a["score"], a["qPos"], a["tPos"]) == (b["score"], b["qPos"], b["tPos"]), (it, len(q), qp, len(t), tp, k, drops, rev)
+        for key in ("blocks", "gapCounts", "gapItems"):
+            assert np.array_equal(a[key], b[key]), (it, key)
+        extended += len(a["blocks"]) > 0
+    assert extended > 800
+
+
 def test_epilogue_pieces_against_the_reference_printers():
     """next-2: the oracle's restatement of AssignRefContigLocation / CreateCIGARString / IntervalAlignmentPrinter
     against the reference's own code on fresh random cases (the committed goldens cover a fixed set)."""
