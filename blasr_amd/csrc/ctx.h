@@ -8,6 +8,8 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/blasr_hip.h"
+
 // A grow-only device buffer owned by the context (freed in blasr_hip_destroy).
 struct DevBuf {
   char *p = nullptr;
@@ -40,7 +42,7 @@ struct blasr_hip_ctx {
   int nContigs = 0;
   // the mapper's device-side state between its stages (blasr_hip_map_reads_*): window pool, SDP batch arrays,
   // result records, block and op arenas, the trimmed refine batch
-  enum { kMapBufs = 20 };
+  enum { kMapBufs = 24 };
   DevBuf mapBuf[kMapBufs];
   float mapMs[6] = {0, 0, 0, 0, 0, 0};
   int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
@@ -78,6 +80,15 @@ int64_t blasr_hip_workspace_reach(const blasr_hip_ctx *ctx);
 int blasr_hip_grow_workspace(blasr_hip_ctx *ctx, size_t bytes);
 // grows (never shrinks) a context buffer; the old contents are NOT kept
 int blasr_hip_ensure(blasr_hip_ctx *ctx, DevBuf &b, size_t bytes);
+
+// the -extend step of AlignIntervals on the SDP stage's device records (extend_api.hip)
+int blasr_hip_extend_candidates(blasr_hip_ctx *ctx, int n, const blasr_hip_interval *intervals,
+                                const blasr_hip_read *reads, const uint8_t *read_pool,
+                                const blasr_hip_extend_params *ep, const blasr_hip_score_params *score,
+                                const uint8_t *seq, int64_t *qOff, int32_t *qLen, int64_t *tOff, int32_t *tLen,
+                                blasr_hip_window *win, blasr_hip_sdp_result *res, const int32_t *blocks,
+                                DevBuf &newSeq, DevBuf &newBlocks, DevBuf &scratch, DevBuf &opsBuf,
+                                int64_t *blocks_used);
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
 

@@ -29,9 +29,9 @@ namespace {
 // slots of blasr_hip_ctx::mapBuf
 enum {
   MB_SEQ = 0, MB_QOFF, MB_QLEN, MB_TOFF, MB_TLEN, MB_WIN, MB_SDPRES, MB_BLOCKS, MB_SEL, MB_REFRES, MB_OPS, MB_TRIM,
-  MB_FETCH_LIST, MB_FETCH_SEQ, MB_FETCH_OPS, MB_H_READS, MB_H_POOL, MB_H_IVS
+  MB_FETCH_LIST, MB_FETCH_SEQ, MB_FETCH_OPS, MB_H_READS, MB_H_POOL, MB_H_IVS, MB_X_SEQ, MB_X_BLOCKS, MB_X_TMP, MB_X_OPS
 };
-static_assert(MB_H_IVS < blasr_hip_ctx::kMapBufs, "mapBuf slots");
+static_assert(MB_X_OPS < blasr_hip_ctx::kMapBufs, "mapBuf slots");
 
 // Candidate i of the refine call = candidate sel[i] of the SDP batch, trimmed to its SDP extent
 // (tSeq.Copy(tAlignedSeq, tPos, last.tPos + last.length), qSeq.ReferenceSubstring(query, qAlignedSeqPos + qPos,
@@ -167,6 +167,9 @@ int blasr_hip_map_default_params(blasr_hip_map_params *p) {
   p->score.affine_open = 50;
   p->score.affine_extend = 0;
   p->band = 16;
+  p->extend_alignments = 0;    // MappingParameters.h:269
+  p->extend_band_size = 10;    // :312
+  p->max_extend_dropoff = 10;  // :270
   p->n_candidates = 10;
   p->max_gap = 0;
   p->max_score = -200;
@@ -274,6 +277,29 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
     blkCap = blkUsed + 64;  // rare: the blocks of the batch did not fit -- once more with what it takes
   }
   if (rc) return rc;
+  if (prm->extend_alignments) {  // -extend (:1749-1940): both ends of every SDP alignment, then its statistics again
+    blasr_hip_extend_params ep;
+    blasr_hip_extend_default_params(&ep);
+    memcpy(ep.matrix, prm->score.matrix, sizeof(ep.matrix));
+    ep.ins = prm->score.ins;
+    ep.del = prm->score.del;
+    ep.band = prm->extend_band_size;
+    ep.max_n_drops = prm->max_extend_dropoff;
+    rc = blasr_hip_extend_candidates(ctx, n_iv, intervals, reads, read_pool, &ep, &prm->score, (const uint8_t *)mb[MB_SEQ].p,
+                                     (int64_t *)mb[MB_QOFF].p, (int32_t *)mb[MB_QLEN].p, (int64_t *)mb[MB_TOFF].p,
+                                     (int32_t *)mb[MB_TLEN].p, (blasr_hip_window *)mb[MB_WIN].p,
+                                     (blasr_hip_sdp_result *)mb[MB_SDPRES].p, (const int32_t *)mb[MB_BLOCKS].p,
+                                     mb[MB_X_SEQ], mb[MB_X_BLOCKS], mb[MB_X_TMP], mb[MB_X_OPS], &blkUsed);
+    if (rc) return rc;
+    std::swap(mb[MB_SEQ], mb[MB_X_SEQ]);  // the candidates' sequences and blocks now live in the new arenas
+    std::swap(mb[MB_BLOCKS], mb[MB_X_BLOCKS]);
+    sb.seq = (const uint8_t *)mb[MB_SEQ].p;
+    HIP_TRY(ctx, hipMemcpyAsync(win.data(), mb[MB_WIN].p, sizeof(blasr_hip_window) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), mb[MB_QLEN].p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), mb[MB_TLEN].p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(qOff.data(), mb[MB_QOFF].p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(tOff.data(), mb[MB_TOFF].p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+  }
   std::vector<blasr_hip_sdp_result> sdp(n);
   HIP_TRY(ctx, hipMemcpyAsync(sdp.data(), mb[MB_SDPRES].p, sizeof(blasr_hip_sdp_result) * n, hipMemcpyDeviceToHost, st));
   std::vector<int32_t> hostBlocks;  // the maxGap rule of RemoveLowQualityAlignments reads the blocks

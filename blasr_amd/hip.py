@@ -178,7 +178,8 @@ assert SDP_RESULT_DTYPE.itemsize == 48
 class _MapParams(C.Structure):
     _fields_ = [("window", _WindowParams), ("sdp", _SdpParams), ("score", _ScoreParams), ("band", C.c_int32),
                 ("n_candidates", C.c_int32), ("max_gap", C.c_int32), ("max_score", C.c_int32),
-                ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32)]
+                ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32), ("extend_alignments", C.c_int32),
+                ("extend_band_size", C.c_int32), ("max_extend_dropoff", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _AnchorParams(C.Structure):
@@ -803,8 +804,8 @@ class Context:
     # --- MapRead from the intervals on (Blasr.cpp:2530-2644), C++ driver inside the library ---
     def map_params(self, **kw):
         """blasr_hip_map_params with the defaults of MappingParameters.h; keyword overrides: band, n_candidates,
-        max_gap, max_score, min_pct_identity, sort_refined, sdp=SdpParams, score=ScoreParams, rate, extend_ends,
-        do_global."""
+        max_gap, max_score, min_pct_identity, sort_refined, extend_alignments (-extend), extend_band_size,
+        max_extend_dropoff, sdp=SdpParams, score=ScoreParams, rate, extend_ends, do_global."""
         p = _MapParams()
         self.lib.blasr_hip_map_default_params(C.byref(p))
         if "sdp" in kw:

@@ -355,6 +355,11 @@ typedef struct blasr_hip_map_params {
   int32_t max_score;             /* params.maxScore (-200) */
   float min_pct_identity;        /* params.minPctIdentity (0) */
   int32_t sort_refined;          /* params.sortRefinedAlignments (1) */
+  int32_t extend_alignments;     /* params.extendAlignments (0), -extend: both ends of every SDP alignment are
+                                    extended before the first filter (:1749-1940, blasr_hip_extend_* below) */
+  int32_t extend_band_size;      /* params.extendBandSize (10) */
+  int32_t max_extend_dropoff;    /* params.maxExtendDropoff (10) */
+  int32_t reserved;
 } blasr_hip_map_params;
 
 /* One alignment MapRead keeps: the T_AlignmentCandidate fields after RefineAlignment's copy-back. */

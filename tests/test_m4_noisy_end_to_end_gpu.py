@@ -35,6 +35,39 @@ def test_m4_lines_of_noisy_reads_from_the_reads_alone(tmp_path):
     run_end_to_end(own_intervals=True, tmp_path=tmp_path)
 
 
+def test_m4_lines_of_noisy_reads_under_extend():
+    """-extend (Blasr.cpp:1749-1940): ExtendAlignmentForward / Reverse on both ends of every SDP alignment before the
+    filters and the refinement, inside blasr_hip_map_reads (extend_alignments = 1).  The reference binary's lines under
+    -extend (tests/golden/make_m4_noisy_extend_golden.py; 54 of the 80 differ from the default run's), byte for byte."""
+    g = np.load(GOLDEN)
+    want = bytes(np.load(os.path.join(os.path.dirname(GOLDEN), "m4_noisy_extend_golden.npz"))["lines"]).decode().splitlines()
+    plain = bytes(g["lines"]).decode().splitlines()
+    contigs = [g["contig0"], g["contig1"]]
+    read_lens, pool, intervals, owner = g["read_lens"], g["reads"], g["intervals"], g["owner"]
+    genome = np.concatenate([contigs[0], [ord("N")], contigs[1], [ord("N")]]).astype(np.uint8)
+    starts = np.array([0, len(contigs[0]) + 1, len(contigs[0]) + 1 + len(contigs[1]) + 1], dtype=np.uint32)
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, starts)
+    reads = np.zeros(len(read_lens), dtype=blasr_amd.READ_DTYPE)
+    off = 0
+    for i in range(len(read_lens)):
+        reads[i] = (off, int(read_lens[i]), 0, int(read_lens[i]), 0)
+        off += int(read_lens[i])
+    ivs = np.zeros(len(intervals), dtype=blasr_amd.INTERVAL_DTYPE)
+    for k in range(len(intervals)):
+        s, e, qs, qe, strand = (int(v) for v in intervals[k])
+        ivs[k] = (s, e, qs, qe, int(owner[k]), strand)
+    got = []
+    params = ctx.map_params(extend_alignments=1)
+    for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, reads, ivs, bestn=1, params=params)):
+        name = "read%d/%d/0_%d/0_%d" % (r, r, int(read_lens[r]), int(read_lens[r]))
+        got += [blasr_amd.m4_record(h, name, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert len(got) == len(want) and not bad, (len(got), len(want), len(bad), bad[:3])
+    assert sum(a != b for a, b in zip(got, plain)) > 40  # and the extension did change the alignments
+    ctx.close()
+
+
 def run_end_to_end(own_intervals, tmp_path=None):
     g = np.load(GOLDEN)
     contigs = [g["contig0"], g["contig1"]]
