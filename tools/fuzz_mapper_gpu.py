@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Whole-mapper fuzz against the REFERENCE BINARY, on the GPU box: random multi-contig genomes with planted repeats,
+random reads (both strands, several error mixes, some hanging over a contig end), mapped (a) by oracle/_ref/blasrmc
+-m 4 -bestn 1, with and without -extend, and (b) by the library from the reads alone (index built on the device,
+anchoring, interval finding, windows -> SDP -> [extension] -> filters -> refinement -> filters, epilogue).  The -m 4
+lines are compared as sorted sets, byte for byte.  One JSON line.
+
+    python tools/fuzz_mapper_gpu.py [--iters 6] [--reads 120] [--seed 1] [--nproc 16]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--reads", type=int, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--nproc", type=int, default=16)
+    args = ap.parse_args()
+    import blasr_amd
+    from blasr_amd import hip, synth
+    blasr = os.path.join(ROOT, "oracle", "_ref", "blasrmc")
+    rng = np.random.default_rng(args.seed)
+    totals = dict(iters=0, reads=0, lines_plain=0, lines_extend=0, bad_plain=0, bad_extend=0, changed_by_extend=0)
+    examples = []
+    t0 = time.time()
+    for it in range(args.iters):
+        n_contigs = int(rng.integers(1, 4))
+        contigs = [synth.random_genome(int(rng.integers(60000, 160000)), int(rng.integers(1, 1 << 30))) for _ in range(n_contigs)]
+        for _ in range(int(rng.integers(0, 4))):  # planted repeats, some reverse-complemented
+            a, b = int(rng.integers(0, n_contigs)), int(rng.integers(0, n_contigs))
+            ln = int(rng.integers(2000, 7000))
+            src = int(rng.integers(0, len(contigs[a]) - ln))
+            d = float(rng.uniform(0.0, 0.05))
+            piece = np.ascontiguousarray(synth.mutate(contigs[a][src:src + ln], rng, d / 3, d / 3, d / 3))
+            if rng.integers(0, 2):
+                piece = synth.revcomp(piece)
+            at = int(rng.integers(0, len(contigs[b]) - len(piece)))
+            contigs[b] = np.concatenate([contigs[b][:at], piece, contigs[b][at + len(piece):]])
+        reads = []
+        for r in range(args.reads):
+            ci = int(rng.integers(0, n_contigs))
+            rl = int(rng.choice([300, 700, 1500, 3000, 6000]))
+            rl = min(rl, len(contigs[ci]) - 10)
+            mode = int(rng.integers(0, 5))
+            if mode == 0:      # starts at the very beginning of the contig
+                pos = 0
+            elif mode == 1:    # ends at the very end
+                pos = len(contigs[ci]) - rl
+            else:
+                pos = int(rng.integers(0, len(contigs[ci]) - rl))
+            s = contigs[ci][pos:pos + rl]
+            if rng.integers(0, 2):
+                s = synth.revcomp(s)
+            ins, dele, sub = [(0.11, 0.04, 0.01), (0.02, 0.01, 0.01), (0.15, 0.08, 0.03), (0.0, 0.0, 0.0)][int(rng.integers(0, 4))]
+            rd = np.ascontiguousarray(synth.mutate(s, rng, ins, dele, sub))
+            if rng.integers(0, 4) == 0:  # an unrelated tail the extension must not swallow
+                rd = np.concatenate([rd, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(5, 200)))]])
+            if len(rd) < 50:
+                continue
+            reads.append(rd)
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "genome.fasta"), "w") as f:
+                for i, c in enumerate(contigs):
+                    s = bytes(c).decode()
+                    f.write(">contig%d\n" % i)
+                    for k in range(0, len(s), 60):
+                        f.write(s[k:k + 60] + "\n")
+            with open(os.path.join(tmp, "reads.fasta"), "w") as f:
+                for r, rd in enumerate(reads):
+                    f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(rd), bytes(rd).decode()))
+            ref = {}
+            for name, extra in (("plain", []), ("extend", ["-extend"])):
+                path = os.path.join(tmp, name + ".m4")
+                p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta"), "-m", "4",
+                                    "-bestn", "1", "-nproc", str(args.nproc), "-out", path] + extra,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if p.returncode != 0:
+                    ref[name] = None  # the reference asserted / crashed on this input
+                    continue
+                ref[name] = sorted(open(path).read().splitlines())
+        # the library, from the reads alone
+        parts, starts = [], [0]
+        for c in contigs:
+            parts += [c, np.array([ord("N")], np.uint8)]
+            starts.append(starts[-1] + len(c) + 1)
+        genome = np.concatenate(parts).astype(np.uint8)
+        starts = np.array(starts, dtype=np.uint32)
+        ctx = blasr_amd.Context(0)
+        ctx.upload_genome(genome, starts)
+        ctx.build_suffix_array(8, download=False)  # what blasrmc builds on the fly (Blasr.cpp:4407-4420)
+        rt = np.zeros(len(reads), dtype=blasr_amd.READ_DTYPE)
+        off = 0
+        for i, rd in enumerate(reads):
+            rt[i] = (off, len(rd), 0, len(rd), 0)
+            off += len(rd)
+        pool = np.concatenate(reads)
+        ivs, _, _ = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt)
+        mine = {}
+        for name, prm in (("plain", ctx.map_params()), ("extend", ctx.map_params(extend_alignments=1))):
+            got = []
+            for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=1, params=prm)):
+                nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
+                got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+            mine[name] = sorted(got)
+        ctx.close()
+        totals["iters"] += 1
+        totals["reads"] += len(reads)
+        for name in ("plain", "extend"):
+            if ref[name] is None:
+                totals.setdefault("reference_failed_" + name, 0)
+                totals["reference_failed_" + name] += 1
+                continue
+            totals["lines_" + name] += len(ref[name])
+            a, b = set(ref[name]), set(mine[name])
+            diff = len(a ^ b)
+            totals["bad_" + name] += diff
+            if diff and len(examples) < 6:
+                examples.append(dict(it=it, mode=name, only_reference=sorted(a - b)[:2], only_library=sorted(b - a)[:2]))
+        if ref["plain"] is not None and ref["extend"] is not None:
+            totals["changed_by_extend"] += len(set(ref["plain"]) ^ set(ref["extend"])) // 2
+    totals["seconds"] = round(time.time() - t0, 1)
+    totals["seed"] = args.seed
+    totals["examples"] = examples
+    print(json.dumps(totals))
+
+
+if __name__ == "__main__":
+    main()
