@@ -75,6 +75,10 @@ def parse_args(argv=None):
                     help="after the timed steps, also run STEPS passes of the WHOLE mapper from the reads alone (index "
                          "built on the device, suffix-array anchoring, interval finding on the host, then the path) and "
                          "report them as `end_to_end` (N=1 only; needs ~130 GB of HBM for an hg19-size genome)")
+    ap.add_argument("--extend", action="store_true",
+                    help="the reference's -extend (Blasr.cpp:1749-1940): both ends of every SDP alignment extended before "
+                         "the first filter.  NOT the headline configuration; the parity leg against the reference's "
+                         "functions is skipped (tools/fuzz_mapper_gpu.py pins -extend against the reference binary)")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -118,7 +122,8 @@ def workload_label(args, d, genome_len, n_contigs):
                 " (long: %.0f-%.0f%% of the read against %.0f-%.0f%% of its length of unrelated genome)"
                 % tuple(100 * x for x in d["spurious_span"]) if d["spurious_span"] else "",
                 ", intervals loosened by up to %.0f%% of the read per side" % (d["loose"] * 100) if d["loose"] else "",
-                args.band))
+                args.band)) + (" (run with -extend: ExtendAlignmentForward / Reverse before the first filter)"
+                               if args.extend else "")
 
 
 def launch_ranks(args):
@@ -197,7 +202,7 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores):
                 parity_checked=n_reads, parity_mismatches=int(mismatches))
 
 
-def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores):
+def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False):
     """The reference BINARY (oracle/_ref/blasrmc -nproc N -m 4 -bestn 1) on a FASTA dump of the first `n_reads`
     reads against a FASTA of their own loci (+- 5 kb, one contig each: the 3-Gbase genome has no suffix array the
     binary could load, and building one is out of a benchmark's reach), wall time less a zero-read run: whole BLASR
@@ -227,7 +232,7 @@ def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores):
         for tag, fa in (("none", "none.fasta"), ("reads", "reads.fasta")):
             t0 = time.perf_counter()
             p = subprocess.run([exe, os.path.join(tmp, fa), os.path.join(tmp, "genome.fasta"), "-m", "4", "-bestn", "1",
-                                "-nproc", str(cores), "-out", os.path.join(tmp, tag + ".m4")],
+                                "-nproc", str(cores), "-out", os.path.join(tmp, tag + ".m4")] + (["-extend"] if extend else []),
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
             wall[tag] = time.perf_counter() - t0
             if p.returncode != 0:
@@ -401,7 +406,7 @@ def main():
         t0 = time.perf_counter()
         ctx.build_suffix_array(13, download=False)
         wl["index_build_s"] = round(time.perf_counter() - t0, 2)
-    params = ctx.map_params(band=args.band)
+    params = ctx.map_params(band=args.band, extend_alignments=1 if args.extend else 0)
     hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     acc = {}
@@ -511,12 +516,12 @@ def main():
             cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
             ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, int(2400 * 10000 / d["read_len"]) // max(1, round(n_iv / n_reads)))
             ns = min(ns, n_reads)
-            if ns > 0:
+            if ns > 0 and not args.extend:
                 out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores)
             nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 10000000 // d["read_len"]))
             if nb > 0:
                 ncores = os.cpu_count() or 1
-                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores))
+                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores), args.extend)
                 if b is not None:
                     out["cpu_baseline_whole_blasr"] = b
             if args.from_reads > 0:
