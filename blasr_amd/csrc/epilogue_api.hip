@@ -179,6 +179,16 @@ int blasr_hip_cigar(const uint8_t *q_aligned_seq, const uint8_t *t_aligned_seq, 
   return BLASR_HIP_OK;
 }
 
+int blasr_hip_alignment_is_printed(int32_t score, float pct_similarity, uint32_t t_aligned_seq_length, int32_t map_qv,
+                                   const blasr_hip_print_params *p) {
+  if (!p) return BLASR_HIP_ERR_INVALID;
+  if (score > p->max_score) return 0;                                // :2958
+  if (pct_similarity < p->min_pct_identity) return 0;                // :2964 (float against float)
+  if (t_aligned_seq_length < (uint32_t)p->min_align_length) return 0;  // :2970 (DNALength against int: unsigned)
+  if (map_qv < p->min_map_qv) return 0;                              // :2976
+  return 1;
+}
+
 int blasr_hip_m4_line(const blasr_hip_m4_fields *f, char *line, int64_t line_cap, int64_t *line_len) {
   if (!f || !f->q_name || !f->t_name || !line_len) return BLASR_HIP_ERR_INVALID;
   // ostream << float prints like %g with six significant digits

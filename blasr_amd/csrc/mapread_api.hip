@@ -477,7 +477,7 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
         h.q_length = win[k].q_length;
         h.q_pos = rr.q_pos;
         h.t_pos = rr.t_pos;
-        h.score = rr.score;
+        h.score = c.score;  // the refined score, or maxScore where the maxGap rule flagged it (:2041)
         h.n_match = rr.n_match;
         h.n_mismatch = rr.n_mismatch;
         h.n_ins = rr.n_ins;

@@ -31,6 +31,7 @@ EXPORTS = [
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
     "blasr_hip_extend_default_params", "blasr_hip_extend_device", "blasr_hip_extend_host",
+    "blasr_hip_alignment_is_printed",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
@@ -82,6 +83,11 @@ class _KbandLinearParams(C.Structure):
 class _KbandBatch(C.Structure):
     _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
                 ("t_off", C.c_void_p), ("t_len", C.c_void_p), ("k", C.c_void_p)]
+
+
+class _PrintParams(C.Structure):
+    _fields_ = [("max_score", C.c_int32), ("min_pct_identity", C.c_float), ("min_align_length", C.c_int32),
+                ("min_map_qv", C.c_int32)]
 
 
 class _ExtendParams(C.Structure):
@@ -298,6 +304,7 @@ def load_library():
         for name in ("blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_KbandBatch), C.POINTER(_KbandLinearParams), C.c_void_p,
                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.blasr_hip_alignment_is_printed.argtypes = [C.c_int32, C.c_float, C.c_uint32, C.c_int32, C.POINTER(_PrintParams)]
         lib.blasr_hip_extend_default_params.argtypes = [C.POINTER(_ExtendParams)]
         for name in ("blasr_hip_extend_device", "blasr_hip_extend_host"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_ExtendBatch), C.POINTER(_ExtendParams), C.c_void_p,
@@ -1165,6 +1172,14 @@ class Context:
 
 # --- next-4: the reference's on-disk inputs (host code, no device involved) -----------------------------
 # --- next-1, host half: anchors -> candidate intervals (host code of the library) -------------------
+def alignment_is_printed(score, pct_similarity, t_aligned_seq_length, map_qv, max_score=-200, min_pct_identity=0.0,
+                         min_align_length=0, min_map_qv=0):
+    """The gates of PrintAlignment (Blasr.cpp:2957-2978)."""
+    p = _PrintParams(int(max_score), float(min_pct_identity), int(min_align_length), int(min_map_qv))
+    return bool(load_library().blasr_hip_alignment_is_printed(int(score), float(pct_similarity), int(t_aligned_seq_length),
+                                                              int(map_qv), C.byref(p)))
+
+
 def interval_params(**kw):
     """blasr_hip_interval_params with the reference's defaults; keyword overrides by field name."""
     p = _IntervalParams()

@@ -19,7 +19,6 @@ import numpy as np
 
 from . import hip
 
-MAX_SCORE = -200  # MappingParameters::maxScore (MappingParameters.h)
 
 
 class Hit(dict):
@@ -37,7 +36,8 @@ def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, an
     return hip.find_intervals(genome, contig_starts, count_table, reads, anchors, list_off, interval_params)
 
 
-def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard=False, bestn=None, params=None):
+def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard=False, bestn=None, params=None,
+              min_align_length=0, min_map_qv=0):
     """reads: READ_DTYPE array over `pool`; intervals: INTERVAL_DTYPE array (any order, each naming its read).
     The context must hold the genome.  Returns, per read, the list of Hits the reference would keep, best first.
 
@@ -45,6 +45,8 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
     library's C++ driver (blasr_hip_map_reads_host, blasr_amd/csrc/mapread_api.hip); what follows here is the
     epilogue of MapReads (:3509-3516, :3086) through the library's host entry points."""
     n_reads = len(reads)
+    params = params or ctx.map_params()
+    max_score = int(params.max_score)
     hits, off, seq, ops = ctx.map_reads(reads, pool, intervals, params=params, fetch=True)
     out = []
     for r in range(n_reads):
@@ -65,8 +67,14 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
             alns.append(dict(q=qs, t=ts, ops=o, q_pos=int(h["q_pos"]), t_pos=int(h["t_pos"]), q_align_start=q_start,
                              q_align_end=q_start + q_span, q_strand=0, q_length=int(h["q_length"]),
                              n_match=int(h["n_match"])))
-        qvs = hip.map_qvs(alns)[0]
+        # the mapQVs are stored only when the best alignment beats maxScore (:3511-3516); else they stay 50
+        qvs = hip.map_qvs(alns)[0] if int(mine[0]["score"]) < max_score else [50] * len(mine)
         for rank, h in enumerate(mine[: bestn if bestn else len(mine)]):
+            # PrintAlignment's gates (:2957-2978): an alignment held back is not replaced by the next one
+            if not hip.alignment_is_printed(int(h["score"]), float(h["pct_similarity"]), int(h["t_aligned_seq_length"]),
+                                            int(qvs[rank]), max_score, float(params.min_pct_identity), min_align_length,
+                                            min_map_qv):
+                continue
             a = alns[rank]
             strand = int(h["t_strand"])
             contig, contig_pos = hip.ref_contig_location(int(h["t_aligned_seq_pos"]), len(a["t"]), strand,
@@ -77,7 +85,7 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
                            q_align_start=a["q_align_start"], q_align_end=a["q_align_end"],
                            t_start=contig_pos + int(h["t_pos"]), t_end=contig_pos + int(h["t_pos"]) + t_span,
                            t_span=t_span, t_length=int(h["t_length"]),
-                           map_qv=int(qvs[rank]) if int(h["score"]) < MAX_SCORE else 50, ops=a["ops"], q=a["q"],
+                           map_qv=int(qvs[rank]), ops=a["ops"], q=a["q"],
                            t=a["t"], q_pos=int(h["q_pos"]), t_pos=int(h["t_pos"]),
                            q_aligned_seq_pos=int(h["q_aligned_seq_pos"]), n_match=int(h["n_match"]),
                            read_length=int(h["q_length"])))

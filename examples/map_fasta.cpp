@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "blasr_hip.h"
@@ -176,9 +177,17 @@ int main(int argc, char **argv) {
       alns.push_back(m);
     }
     std::vector<int32_t> qv(alns.size());
-    if (blasr_hip_map_qvs(alns.data(), (int32_t)alns.size(), &qp, NULL, qv.data(), NULL) < 0) die("map_qvs", NULL);
+    // the mapQVs are stored only when the best alignment beats maxScore (:3511-3516); they are 50 until then
+    if (hits[a].score < prm.max_score) {
+      if (blasr_hip_map_qvs(alns.data(), (int32_t)alns.size(), &qp, NULL, qv.data(), NULL) < 0) die("map_qvs", NULL);
+    } else {
+      std::fill(qv.begin(), qv.end(), 50);
+    }
+    blasr_hip_print_params gates = {prm.max_score, prm.min_pct_identity, 0, 0};  // PrintAlignment (:2957-2978)
     for (int64_t i = a; i < b && i - a < bestn; i++) {
       const blasr_hip_hit &h = hits[i];
+      if (blasr_hip_alignment_is_printed(h.score, h.pct_similarity, h.t_aligned_seq_length, qv[(size_t)(i - a)], &gates) != 1)
+        continue;
       int32_t contig = 0;
       uint32_t contigPos = 0;
       blasr_hip_ref_contig_location(h.t_aligned_seq_pos, h.t_aligned_seq_length, h.t_strand, starts.data(), (int32_t)nContigs + 1,
@@ -196,7 +205,7 @@ int main(int argc, char **argv) {
       m4.t_align_start = contigPos + (uint32_t)h.t_pos;
       m4.t_align_end = m4.t_align_start + (uint32_t)(h.n_match + h.n_mismatch + h.n_del);
       m4.t_length = h.t_length;
-      m4.map_qv = h.score < prm.max_score ? qv[(size_t)(i - a)] : 50;
+      m4.map_qv = qv[(size_t)(i - a)];
       char line[4096];
       int64_t len = 0;
       if (blasr_hip_m4_line(&m4, line, sizeof(line), &len) < 0) die("m4_line", NULL);

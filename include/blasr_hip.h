@@ -571,6 +571,19 @@ typedef struct blasr_hip_m4_fields {
 } blasr_hip_m4_fields;
 int blasr_hip_m4_line(const blasr_hip_m4_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
 
+/* The gates of PrintAlignment (alignment/Blasr.cpp:2957-2978) an alignment passes before any printer sees it: score
+ * <= maxScore, pctSimilarity >= minPctIdentity, tAlignedSeq.length >= minAlignLength, mapQV >= minMapQV.  PrintAlignments
+ * (:3085-3110) offers it the first nBest alignments of a read; one that is held back is not replaced.  Returns 1
+ * (printed) or 0. */
+typedef struct blasr_hip_print_params {
+  int32_t max_score;        /* params.maxScore (-200) */
+  float min_pct_identity;   /* params.minPctIdentity (0) */
+  int32_t min_align_length; /* params.minAlignLength (0) */
+  int32_t min_map_qv;       /* params.minMapQV (0) */
+} blasr_hip_print_params;
+int blasr_hip_alignment_is_printed(int32_t score, float pct_similarity, uint32_t t_aligned_seq_length, int32_t map_qv,
+                                   const blasr_hip_print_params *params);
+
 /* StoreMapQVs (alignment/Blasr.cpp:2761-2950) with ComputeAlignmentScore on gap lists (AlignmentUtils.h:127-170),
  * PartitionOverlappingAlignments / AlignmentsOverlap (:2679-2759), SumMismatches (:2647-2671), LogSumOfTwo
  * (utils/LogUtils.h:11-41), Phred (utils/PhredUtils.h:10-13): the mapping quality of every alignment of one read,

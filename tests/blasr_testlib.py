@@ -883,7 +883,8 @@ def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=1
                             t_length=x["win"]["tLength"],
                             q_aligned_seq_pos=x["win"]["qAlignedSeqPos"] + x["sdp"]["qPos"],
                             q_aligned_seq_length=len(x["qs"]), q_length=len(read), q_pos=rr["qPos"], t_pos=rr["tPos"],
-                            score=rr["score"], n_match=rr["nMatch"], n_mismatch=rr["nMismatch"], n_ins=rr["nIns"],
+                            score=x["score"],  # the refined score, or maxScore where the maxGap rule flagged it (:2041)
+                            n_match=rr["nMatch"], n_mismatch=rr["nMismatch"], n_ins=rr["nIns"],
                             n_del=rr["nDel"], n_cells=rr["nCells"], pct_similarity=np.float32(rr["pct"]),
                             q=x["qs"], t=x["ts"], ops=[(l << 2) | ty for ty, l in ops_from_alignment(rr)]))
     return out

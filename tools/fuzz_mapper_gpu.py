@@ -27,12 +27,33 @@ def main():
     ap.add_argument("--reads", type=int, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--nproc", type=int, default=16)
+    ap.add_argument("--variants", action="store_true", help="cycle through non-default switches (see the table in main)")
     args = ap.parse_args()
     import blasr_amd
     from blasr_amd import hip, synth
     blasr = os.path.join(ROOT, "oracle", "_ref", "blasrmc")
     rng = np.random.default_rng(args.seed)
     totals = dict(iters=0, reads=0, lines_plain=0, lines_extend=0, bad_plain=0, bad_extend=0, changed_by_extend=0)
+    # non-default switches of the reference and the library parameters they become (MappingParameters.h:367-545,
+    # Blasr.cpp:3999-4135); --variants cycles through them, one per iteration
+    variants = [
+        dict(cli=[], name="default"),
+        dict(cli=["-bestn", "3"], bestn=3, name="bestn3"),
+        dict(cli=["-sdpTupleSize", "8"], sdp=dict(k=8), name="sdpTupleSize8"),
+        dict(cli=["-bandSize", "30"], map=dict(band=30), name="bandSize30"),
+        dict(cli=["-maxScore", "-1500"], map=dict(max_score=-1500), name="maxScore-1500"),
+        dict(cli=["-minPctIdentity", "84"], map=dict(min_pct_identity=84.0), name="minPctIdentity84"),
+        dict(cli=["-nCandidates", "2"], map=dict(n_candidates=2), interval=dict(n_candidates=2), name="nCandidates2"),
+        dict(cli=["-minMatch", "12"], anchor=dict(min_match_length=12), name="minMatch12"),
+        dict(cli=["-extendBandSize", "5", "-maxExtendDropoff", "3"], map=dict(extend_band_size=5, max_extend_dropoff=3),
+             name="extendBand5Drop3"),
+        dict(cli=["-indelRate", "0.2"], sdp=dict(indel_rate=float(np.float32(0.2) * np.float32(3))), interval=dict(indel_rate=0.2),
+             name="indelRate0.2"),
+        dict(cli=["-maxAnchorsPerPosition", "3"], anchor=dict(max_anchors_per_position=3), name="maxAnchorsPerPosition3"),
+        dict(cli=["-sdpIns", "3", "-sdpDel", "7"], sdp=dict(sdp_ins=3, sdp_del=7), name="sdpIns3Del7"),
+        dict(cli=["-maxGap", "40"], map=dict(max_gap=40), name="maxGap40"),
+    ]
+    by_variant = {}
     examples = []
     t0 = time.time()
     for it in range(args.iters):
@@ -80,8 +101,9 @@ def main():
             with open(os.path.join(tmp, "reads.fasta"), "w") as f:
                 for r, rd in enumerate(reads):
                     f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(rd), bytes(rd).decode()))
+            var = variants[it % len(variants)] if args.variants else variants[0]
             ref = {}
-            for name, extra in (("plain", []), ("extend", ["-extend"])):
+            for name, extra in (("plain", var["cli"]), ("extend", var["cli"] + ["-extend"])):
                 path = os.path.join(tmp, name + ".m4")
                 p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta"), "-m", "4",
                                     "-bestn", "1", "-nproc", str(args.nproc), "-out", path] + extra,
@@ -106,11 +128,17 @@ def main():
             rt[i] = (off, len(rd), 0, len(rd), 0)
             off += len(rd)
         pool = np.concatenate(reads)
-        ivs, _, _ = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt)
+        ivs, _, _ = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt,
+                                                  anchor_params=ctx.anchor_params(**var.get("anchor", {})),
+                                                  interval_params=hip.interval_params(**var.get("interval", {})))
         mine = {}
-        for name, prm in (("plain", ctx.map_params()), ("extend", ctx.map_params(extend_alignments=1))):
+        mkw = dict(var.get("map", {}))
+        if "sdp" in var:
+            mkw["sdp"] = hip.SdpParams(**var["sdp"])
+        for name, prm in (("plain", ctx.map_params(**mkw)), ("extend", ctx.map_params(extend_alignments=1, **mkw))):
             got = []
-            for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=1, params=prm)):
+            for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
+                                                         params=prm)):
                 nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
                 got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
             mine[name] = sorted(got)
@@ -126,12 +154,16 @@ def main():
             a, b = set(ref[name]), set(mine[name])
             diff = len(a ^ b)
             totals["bad_" + name] += diff
+            v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
+            v["lines"] += len(ref[name])
+            v["bad"] += diff
             if diff and len(examples) < 6:
-                examples.append(dict(it=it, mode=name, only_reference=sorted(a - b)[:2], only_library=sorted(b - a)[:2]))
+                examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=sorted(a - b)[:2], only_library=sorted(b - a)[:2]))
         if ref["plain"] is not None and ref["extend"] is not None:
             totals["changed_by_extend"] += len(set(ref["plain"]) ^ set(ref["extend"])) // 2
     totals["seconds"] = round(time.time() - t0, 1)
     totals["seed"] = args.seed
+    totals["by_variant"] = by_variant
     totals["examples"] = examples
     print(json.dumps(totals))
 
