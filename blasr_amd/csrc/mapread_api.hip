@@ -208,6 +208,9 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
   for (int i = 0; i < 6; i++) ctx->mapMs[i] = 0, ctx->mapCounters[i] = 0;
   if (read_hit_off)
     for (int r = 0; r <= n_reads; r++) read_hit_off[r] = 0;
+  if (prm->window.do_global_alignment)  // -global replaces the refiner by KBandAlign over the whole window (:811-831)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "map_reads: doGlobalAlignment is not built into the driver "
+                          "(blasr_hip_windows_* and blasr_hip_kband_linear_* cover its pieces)");
   if (n_iv == 0) return BLASR_HIP_OK;
   if (!ctx->genome) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_reads: no genome resident");
   HIP_TRY(ctx, hipSetDevice(ctx->device));

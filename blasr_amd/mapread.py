@@ -68,7 +68,9 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
                              q_align_end=q_start + q_span, q_strand=0, q_length=int(h["q_length"]),
                              n_match=int(h["n_match"])))
         # the mapQVs are stored only when the best alignment beats maxScore (:3511-3516); else they stay 50
-        qvs = hip.map_qvs(alns)[0] if int(mine[0]["score"]) < max_score else [50] * len(mine)
+        qvs = (hip.map_qvs(alns, ins=int(params.score.ins), dele=int(params.score.del_),
+                           affine_open=int(params.score.affine_open), affine_extend=int(params.score.affine_extend))[0]
+               if int(mine[0]["score"]) < max_score else [50] * len(mine))
         for rank, h in enumerate(mine[: bestn if bestn else len(mine)]):
             # PrintAlignment's gates (:2957-2978): an alignment held back is not replaced by the next one
             if not hip.alignment_is_printed(int(h["score"]), float(h["pct_similarity"]), int(h["t_aligned_seq_length"]),

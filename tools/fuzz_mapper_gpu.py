@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--reads", type=int, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--nproc", type=int, default=16)
+    ap.add_argument("--dump", type=int, default=-1, metavar="IT",
+                    help="write the FASTA files of iteration IT to ./fuzz_mapper_dump/ and stop (no GPU needed)")
     ap.add_argument("--variants", action="store_true", help="cycle through non-default switches (see the table in main)")
     args = ap.parse_args()
     import blasr_amd
@@ -52,6 +54,25 @@ def main():
         dict(cli=["-maxAnchorsPerPosition", "3"], anchor=dict(max_anchors_per_position=3), name="maxAnchorsPerPosition3"),
         dict(cli=["-sdpIns", "3", "-sdpDel", "7"], sdp=dict(sdp_ins=3, sdp_del=7), name="sdpIns3Del7"),
         dict(cli=["-maxGap", "40"], map=dict(max_gap=40), name="maxGap40"),
+        dict(cli=["-insertion", "4", "-deletion", "7"], score=dict(ins=4, dele=7), name="insertion4deletion7"),
+        dict(cli=["-affineOpen", "12", "-affineExtend", "2"], score=dict(affine_open=12, affine_extend=2), name="affine12+2"),
+        dict(cli=["-minAlignLength", "1000"], min_align_length=1000, name="minAlignLength1000"),
+        dict(cli=["-minMapQV", "30"], min_map_qv=30, name="minMapQV30"),
+        dict(cli=["-minInterval", "400"], interval=dict(min_interval=400), name="minInterval400"),
+        dict(cli=["-removeContained"], interval=dict(remove_contained_intervals=1), name="removeContained"),
+        dict(cli=["-forwardOnly"], anchor=dict(forward_only=1), name="forwardOnly"),
+        # not here: -advanceExactMatches.  With it the anchors of a list no longer overlap, RemoveOverlappingAnchors
+        # removes nothing, and StoreLargestIntervals' read one past the end of the list (FindMaxInterval.h) lands in
+        # what an EARLIER read left in the buffer: the reference binary's own lines then depend on the order of the
+        # reads (200 reads forwards / backwards under -nproc 1: 11 lines differ; none do by default).  The anchoring
+        # function under that switch is pinned at function level (tests/test_anchor_*.py, tools/fuzz_anchoring_gpu.py).
+        # not here either: -global (KBandAlign over the whole window instead of the guided refiner; the reference prints
+        # nothing for these reads, the library's driver refuses the switch).
+        dict(cli=["-maxLCPLength", "16"], anchor=dict(max_lcp_length=16), name="maxLCPLength16"),
+        dict(cli=["-sdpMaxAnchorsPerPosition", "2"], sdp=dict(max_per_pos=2), name="sdpMaxAnchorsPerPosition2"),
+        dict(cli=["-sdpPrefix", "20"], sdp=dict(prefix=20), name="sdpPrefix20"),
+        dict(cli=["-bestn", "4", "-nCandidates", "4", "-minPctIdentity", "70"], bestn=4,
+             map=dict(n_candidates=4, min_pct_identity=70.0), interval=dict(n_candidates=4), name="bestn4nCandidates4pct70"),
     ]
     by_variant = {}
     examples = []
@@ -91,7 +112,12 @@ def main():
             if len(rd) < 50:
                 continue
             reads.append(rd)
+        if args.dump >= 0 and it < args.dump:
+            continue
         with tempfile.TemporaryDirectory() as tmp:
+            if args.dump >= 0:
+                tmp = os.path.join(os.getcwd(), "fuzz_mapper_dump")
+                os.makedirs(tmp, exist_ok=True)
             with open(os.path.join(tmp, "genome.fasta"), "w") as f:
                 for i, c in enumerate(contigs):
                     s = bytes(c).decode()
@@ -102,16 +128,24 @@ def main():
                 for r, rd in enumerate(reads):
                     f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(rd), bytes(rd).decode()))
             var = variants[it % len(variants)] if args.variants else variants[0]
-            ref = {}
-            for name, extra in (("plain", var["cli"]), ("extend", var["cli"] + ["-extend"])):
-                path = os.path.join(tmp, name + ".m4")
+            if args.dump >= 0:
+                print("iteration %d: variant %s, switches %s, files in %s" % (it, var["name"], var["cli"], tmp))
+                return
+            def run_reference(extra, nproc):
+                path = os.path.join(tmp, "out.m4")
                 p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta"), "-m", "4",
-                                    "-bestn", "1", "-nproc", str(args.nproc), "-out", path] + extra,
+                                    "-bestn", "1", "-nproc", str(nproc), "-out", path] + extra,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 if p.returncode != 0:
-                    ref[name] = None  # the reference asserted / crashed on this input
-                    continue
-                ref[name] = sorted(open(path).read().splitlines())
+                    return None  # the reference asserted / crashed on this input
+                return sorted(open(path).read().splitlines())
+
+            switches = {"plain": var["cli"], "extend": var["cli"] + ["-extend"]}
+            ref = {name: run_reference(extra, args.nproc) for name, extra in switches.items()}
+            # the same once more on ONE thread, for the (rare) input on which the binary's own lines change from run to
+            # run under -nproc > 1 (its interval finder reads one element past the end of a match list, i.e. whatever the
+            # thread's previous read left there): a difference only counts when the one-thread run shows it too
+            ref1 = {name: run_reference(extra, 1) for name, extra in switches.items()} if args.nproc > 1 else ref
         # the library, from the reads alone
         parts, starts = [], [0]
         for c in contigs:
@@ -135,10 +169,13 @@ def main():
         mkw = dict(var.get("map", {}))
         if "sdp" in var:
             mkw["sdp"] = hip.SdpParams(**var["sdp"])
+        if "score" in var:
+            mkw["score"] = hip.ScoreParams(**var["score"])
         for name, prm in (("plain", ctx.map_params(**mkw)), ("extend", ctx.map_params(extend_alignments=1, **mkw))):
             got = []
             for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
-                                                         params=prm)):
+                                                         params=prm, min_align_length=var.get("min_align_length", 0),
+                                                         min_map_qv=var.get("min_map_qv", 0))):
                 nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
                 got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
             mine[name] = sorted(got)
@@ -153,6 +190,9 @@ def main():
             totals["lines_" + name] += len(ref[name])
             a, b = set(ref[name]), set(mine[name])
             diff = len(a ^ b)
+            if diff and ref1[name] is not None and not (set(ref1[name]) ^ b):
+                totals["reference_unstable_under_nproc"] = totals.get("reference_unstable_under_nproc", 0) + 1
+                diff = 0
             totals["bad_" + name] += diff
             v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
             v["lines"] += len(ref[name])
