@@ -473,6 +473,40 @@ extern "C" int blasr_hip_sam_line(const blasr_hip_sam_fields *f, char *line, int
   return BLASR_HIP_OK;
 }
 
+// SAMOutput::PrintUnalignedRead (printers/SAMPrinter.h:578-664): the record -sam prints for a (sub)read without an
+// alignment (Blasr.cpp:3848-3866).  Uses q_name, read_group_id, read_seq, read_length, subread_start / subread_end,
+// clipping, qs, qe, hole_number, read_quality, num_passes, subread_context, snr of the fields; *line_len = 0 where the
+// reference prints nothing (subread out of bounds or empty, :591-600).
+extern "C" int blasr_hip_sam_unaligned_line(const blasr_hip_sam_fields *f, char *line, int64_t line_cap, int64_t *line_len) {
+  if (!f || !f->q_name || !f->read_group_id || !f->read_seq || !line_len) return BLASR_HIP_ERR_INVALID;
+  *line_len = 0;
+  uint32_t length = f->subread_end - f->subread_start;
+  const uint32_t start = f->subread_start;
+  if (start <= f->read_length && length == 0) length = f->read_length - start;  // ReferenceSubstring(read, pos, 0): to the end
+  if (!(start <= f->read_length && length <= f->read_length) || length == 0) {
+    if (line && line_cap > 0) line[0] = 0;
+    return BLASR_HIP_OK;
+  }
+  if ((uint64_t)start + length > f->read_length) return BLASR_HIP_ERR_INVALID;  // the reference would read past the read
+  char buf[256];
+  std::string s = std::string(f->q_name) + "\t4\t*\t0\t0\t*\t*\t0\t0\t";  // SEGMENT_UNMAPPED, fixed defaults (:603)
+  s.append((const char *)f->read_seq + start, length);
+  s += "\t*\tRG:Z:" + std::string(f->read_group_id) + "\t";
+  if (f->clipping == BLASR_HIP_CLIP_SUBREAD)
+    snprintf(buf, sizeof buf, "XS:i:%u\tXE:i:%u\tqs:i:%d\tqe:i:%d\t", f->subread_start + 1, f->subread_end + 1, f->qs, f->qe);
+  else
+    snprintf(buf, sizeof buf, "XS:i:1\tXE:i:%u\tqs:i:1\tqe:i:%u\t", length, length);
+  s += buf;
+  snprintf(buf, sizeof buf, "zm:i:%d\tXL:i:0\trq:f:%.4g\tnp:i:%d\tcx:i:%d\tsn:B:f,%.4g,%.4g,%.4g,%.4g\tXT:i:1\tXQ:i:%u\n",
+           f->hole_number, (double)f->read_quality, f->num_passes, f->subread_context, (double)f->snr[0], (double)f->snr[1],
+           (double)f->snr[2], (double)f->snr[3], length);
+  s += buf;
+  *line_len = (int64_t)s.size();
+  if (!line || (int64_t)s.size() + 1 > line_cap) return BLASR_HIP_ERR_CAPACITY;
+  memcpy(line, s.c_str(), s.size() + 1);
+  return BLASR_HIP_OK;
+}
+
 // -forPicard (Blasr.cpp:2621-2626): samtools / picard reject insertion-deletion-insertion patterns, so the gaps
 // between two blocks are condensed to ONE gap of the longer kind, shortened by the other kind's bases, which become
 // aligned columns of the block before (Alignment.h:255-317).  The blocks stay separate blocks.

@@ -31,7 +31,7 @@ EXPORTS = [
     "blasr_hip_sort_candidates", "blasr_hip_remove_low_quality", "blasr_hip_remove_overlapping",
     "blasr_hip_kband_device", "blasr_hip_kband_host", "blasr_hip_kband_linear_device", "blasr_hip_kband_linear_host",
     "blasr_hip_extend_default_params", "blasr_hip_extend_device", "blasr_hip_extend_host",
-    "blasr_hip_alignment_is_printed",
+    "blasr_hip_alignment_is_printed", "blasr_hip_sam_unaligned_line",
     "blasr_hip_ref_contig_location", "blasr_hip_cigar", "blasr_hip_m4_line", "blasr_hip_map_qvs",
     "blasr_hip_sam_line", "blasr_hip_order_gaps_by_type",
     "blasr_hip_refine_from_sdp_device", "blasr_hip_map_reads_device", "blasr_hip_map_reads_host",
@@ -463,6 +463,29 @@ def sam_line(q_name, t_name, read_group_id, cigar_string, clips, read_seq, read_
     rc = lib.blasr_hip_sam_line(C.byref(f), out, C.c_int64(cap), C.byref(n))
     if rc < 0:
         raise BlasrHipError(rc, "sam_line")
+    return out.value.decode()
+
+
+def sam_unaligned_line(q_name, read_group_id, read_seq, subread_start=0, subread_end=None, clipping=CLIP_NONE, **kw):
+    """SAMOutput::PrintUnalignedRead (printers/SAMPrinter.h:578-664): the record of a (sub)read without an alignment."""
+    lib = load_library()
+    seq = np.ascontiguousarray(read_seq, dtype=np.uint8)
+    f = _SamFields()
+    f.q_name, f.read_group_id = q_name.encode(), read_group_id.encode()
+    f.read_seq = seq.ctypes.data
+    f.read_length = len(seq)
+    f.subread_start, f.subread_end = int(subread_start), len(seq) if subread_end is None else int(subread_end)
+    f.clipping = int(clipping)
+    f.hole_number = int(kw.pop("hole_number", -1))
+    f.snr = (C.c_float * 4)(*[float(v) for v in kw.pop("snr", (0, 0, 0, 0))])
+    for k, v in kw.items():
+        setattr(f, k, v)
+    cap = len(seq) + len(q_name) + len(read_group_id) + 512
+    out = C.create_string_buffer(cap)
+    n = C.c_int64(0)
+    rc = lib.blasr_hip_sam_unaligned_line(C.byref(f), out, C.c_int64(cap), C.byref(n))
+    if rc < 0:
+        raise BlasrHipError(rc, "sam_unaligned_line")
     return out.value.decode()
 
 

@@ -24,7 +24,7 @@ from . import hip
 class Hit(dict):
     """One surviving alignment of a read, in print order.  Keys: read, interval, strand, contig, contig_pos, score,
     pct_similarity, q_align_start, q_align_end, t_start, t_end, t_length, map_qv, ops, q, t, q_pos, t_pos,
-    q_aligned_seq_pos, n_match, read_length."""
+    q_aligned_seq_pos, n_match, read_length, rank (its index among the read's alignments: 0 is the primary one)."""
 
 
 def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, anchor_params=None, interval_params=None):
@@ -37,9 +37,10 @@ def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, an
 
 
 def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard=False, bestn=None, params=None,
-              min_align_length=0, min_map_qv=0):
+              min_align_length=0, min_map_qv=0, unaligned=None):
     """reads: READ_DTYPE array over `pool`; intervals: INTERVAL_DTYPE array (any order, each naming its read).
-    The context must hold the genome.  Returns, per read, the list of Hits the reference would keep, best first.
+    The context must hold the genome.  Returns, per read, the list of Hits the reference would print, best first
+    (`unaligned`, a list, receives the reads MapRead left without any alignment).
 
     MapRead itself -- the device stages and the per-read ordering / pruning between them -- is ONE call into the
     library's C++ driver (blasr_hip_map_reads_host, blasr_amd/csrc/mapread_api.hip); what follows here is the
@@ -54,6 +55,8 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
         res = []
         out.append(res)
         if len(mine) == 0:
+            if unaligned is not None:  # -sam prints a record for these (hip.sam_unaligned_line; Blasr.cpp:3848-3866)
+                unaligned.append(r)
             continue
         # StoreMapQVs over what is left (:3509-3516); -sam has re-ordered the gap lists before it (:2621-2626)
         alns = []
@@ -90,7 +93,7 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
                            map_qv=int(qvs[rank]), ops=a["ops"], q=a["q"],
                            t=a["t"], q_pos=int(h["q_pos"]), t_pos=int(h["t_pos"]),
                            q_aligned_seq_pos=int(h["q_aligned_seq_pos"]), n_match=int(h["n_match"]),
-                           read_length=int(h["q_length"])))
+                           read_length=int(h["q_length"]), rank=rank))
     return out
 
 
@@ -101,10 +104,13 @@ def m4_record(hit, read_name, contig_name):
                        hit["t_length"], hit["map_qv"])
 
 
-def sam_record(hit, read_name, contig_name, read_group, read_seq, quality=None, clipping=hip.CLIP_NONE, is_primary=1,
+def sam_record(hit, read_name, contig_name, read_group, read_seq, quality=None, clipping=hip.CLIP_NONE, is_primary=None,
                subread_start=0, subread_end=None, hole_number=-1):
-    """CreateCIGARString + SAMOutput::PrintAlignment of one Hit (map the reads with for_picard=True for -sam)."""
+    """CreateCIGARString + SAMOutput::PrintAlignment of one Hit (map the reads with for_picard=True for -sam).
+    is_primary: by default what PrintAlignments sets (Blasr.cpp:3109-3114): the first alignment of the read."""
     L = hit["read_length"]
+    if is_primary is None:
+        is_primary = 1 if hit.get("rank", 0) == 0 else 0
     cig, clips = hip.cigar(hit["q"], hit["t"], hit["q_pos"], hit["t_pos"], ops=hit["ops"], clipping=clipping,
                            t_strand=hit["strand"], read_length=L, q_align_start=hit["q_align_start"],
                            q_align_end=hit["q_align_end"])

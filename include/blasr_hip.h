@@ -631,6 +631,12 @@ typedef struct blasr_hip_sam_fields {
   float read_quality, snr[4];
 } blasr_hip_sam_fields;
 int blasr_hip_sam_line(const blasr_hip_sam_fields *fields, char *line, int64_t line_capacity, int64_t *line_len);
+/* SAMOutput::PrintUnalignedRead (printers/SAMPrinter.h:578-664): the record -sam prints for a (sub)read that has no
+ * alignment (alignment/Blasr.cpp:3848-3866): flag 4, the subread's bases, the same tag block.  Reads q_name,
+ * read_group_id, read_seq, read_length, subread_start / subread_end, clipping, qs, qe, hole_number, read_quality,
+ * num_passes, subread_context, snr; *line_len = 0 where the reference prints nothing (empty subread). */
+int blasr_hip_sam_unaligned_line(const blasr_hip_sam_fields *fields, char *line, int64_t line_capacity,
+                                 int64_t *line_len);
 
 /* Alignment::OrderGapsByType (datastructures/alignment/Alignment.h:255-317), which MapRead applies under -forPicard
  * (alignment/Blasr.cpp:2621-2626), on an op list: where two blocks are separated by more than one gap, the gaps

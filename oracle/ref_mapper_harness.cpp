@@ -397,6 +397,36 @@ int ref_sam_line(const char *qName, const char *tName, const char *readGroupId, 
   return (int)s.size();
 }
 
+// SAMOutput::PrintUnalignedRead (printers/SAMPrinter.h:578-664).  iv: 0 readLength 1 subreadStart 2 subreadEnd 3 clipping
+// 4 holeNumber 5 qs 6 qe 7 numPasses 8 subreadContext; fv: readQuality, snr[4].
+int ref_sam_unaligned_line(const char *title, const char *readGroupId, const unsigned char *readSeq, const int *iv,
+                           const float *fv, char *out, int outCap) {
+  SMRTSequence read;
+  read.seq = const_cast<unsigned char *>(readSeq);
+  read.length = iv[0];
+  read.deleteOnExit = false;
+  read.subreadStart = iv[1];
+  read.subreadEnd = iv[2];
+  read.holeNumber = iv[4];
+  read.qs = iv[5];
+  read.qe = iv[6];
+  read.numPasses = iv[7];
+  read.subreadContext = iv[8];
+  read.readQuality = fv[0];
+  for (int i = 0; i < 4; i++) read.snr[i] = fv[1 + i];
+  read.CopyTitle(string(title));
+  AlignmentContext context;
+  context.readGroupId = readGroupId;
+  SupplementalQVList qvlist;
+  stringstream strm;
+  SAMOutput::PrintUnalignedRead(read, strm, context, qvlist, (SAMOutput::Clipping)iv[3]);
+  read.seq = NULL;
+  const string s = strm.str();
+  if ((int)s.size() + 1 > outCap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
 }  // extern "C"
 
 extern "C" {

@@ -2,6 +2,7 @@
 IntervalAlignmentPrinter::Print, StoreMapQVs, SAMOutput::PrintAlignment.  Host code on both sides, so no GPU is needed: the library's functions and the
 oracle's restatement against golden vectors made with the reference's own code
 (tests/golden/make_epilogue_golden.py), and against each other on fresh random cases."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -159,6 +160,41 @@ def test_sam_line_golden(golden, orc):
         assert got_oracle == want, i
         assert got_lib == want, i
         assert want.endswith("\n") and len(want.split("\t")) >= 12
+
+
+def test_sam_unaligned_record():
+    """SAMOutput::PrintUnalignedRead (SAMPrinter.h:578-664): the record -sam prints for a read without an alignment.
+    A line of the reference BINARY (oracle/_ref/blasrmc -sam, a read of a fuzz run) is the fixed vector; where the
+    reference build is present its own function is called beside the library's on random subreads / clippings."""
+    from blasr_amd import hip
+    seq = np.frombuffer(b"TTAGTGTAATGCGCCACGAACATGATACAGCATCTCC", np.uint8)
+    want = ("read106/106/0_37/0_37\t4\t*\t0\t0\t*\t*\t0\t0\tTTAGTGTAATGCGCCACGAACATGATACAGCATCTCC\t*\tRG:Z:5661199fa0\t"
+            "XS:i:1\tXE:i:37\tqs:i:1\tqe:i:37\tzm:i:-1\tXL:i:0\trq:f:0\tnp:i:0\tcx:i:0\tsn:B:f,0,0,0,0\tXT:i:1\tXQ:i:37\n")
+    assert hip.sam_unaligned_line("read106/106/0_37/0_37", "5661199fa0", seq) == want
+    # an empty subread is "the read from there on" (DNASequence::ReferenceSubstring with length 0), nothing at its end
+    assert "\tAATGCG" in hip.sam_unaligned_line("x", "rg", seq, subread_start=7, subread_end=7)
+    assert hip.sam_unaligned_line("x", "rg", seq, subread_start=len(seq), subread_end=len(seq)) == ""
+    ref = T.EpilogueChecker("ref") if os.path.exists(T.REFMAPPER_SO) else None
+    if ref is None:
+        return
+    rng = np.random.default_rng(3)
+    for it in range(60):
+        n = int(rng.integers(1, 200))
+        rd = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, n)]
+        s0 = int(rng.integers(0, n))
+        s1 = int(rng.integers(s0, n + 1))
+        clip = int(rng.integers(0, 4))
+        iv = np.array([n, s0, s1, clip, int(rng.integers(-1, 99)), int(rng.integers(0, 50)), int(rng.integers(50, 99)),
+                       int(rng.integers(0, 9)), int(rng.integers(0, 4))], np.int32)
+        fv = np.array([rng.choice([0.0, 0.8512345, 0.9]), 4.123456, 0.0, 11.5, 7.25], np.float32)
+        out = C.create_string_buffer(n + 600)
+        k = ref.lib.ref_sam_unaligned_line(b"movie/7/0_9", b"abc123", rd.ctypes.data_as(C.c_void_p), iv.ctypes.data_as(C.c_void_p),
+                                           fv.ctypes.data_as(C.c_void_p), out, n + 600)
+        assert k >= 0
+        got = hip.sam_unaligned_line("movie/7/0_9", "abc123", rd, subread_start=s0, subread_end=s1, clipping=clip,
+                                     hole_number=int(iv[4]), qs=int(iv[5]), qe=int(iv[6]), num_passes=int(iv[7]),
+                                     subread_context=int(iv[8]), read_quality=float(fv[0]), snr=[float(v) for v in fv[1:]])
+        assert got == out.value.decode(), (it, got, out.value.decode())
 
 
 def test_cigar_library_against_oracle_on_random_cases(orc):

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--nproc", type=int, default=16)
     ap.add_argument("--dump", type=int, default=-1, metavar="IT",
                     help="write the FASTA files of iteration IT to ./fuzz_mapper_dump/ and stop (no GPU needed)")
+    ap.add_argument("--sam", action="store_true", help="compare SAM records (-sam: CIGAR, flags, tags) instead of -m 4 lines")
     ap.add_argument("--variants", action="store_true", help="cycle through non-default switches (see the table in main)")
     args = ap.parse_args()
     import blasr_amd
@@ -131,14 +132,21 @@ def main():
             if args.dump >= 0:
                 print("iteration %d: variant %s, switches %s, files in %s" % (it, var["name"], var["cli"], tmp))
                 return
+            read_group = [""]
+
             def run_reference(extra, nproc):
                 path = os.path.join(tmp, "out.m4")
-                p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta"), "-m", "4",
-                                    "-bestn", "1", "-nproc", str(nproc), "-out", path] + extra,
+                p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta")] +
+                                   (["-sam"] if args.sam else ["-m", "4"]) +
+                                   ["-bestn", "1", "-nproc", str(nproc), "-out", path] + extra,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 if p.returncode != 0:
                     return None  # the reference asserted / crashed on this input
-                return sorted(open(path).read().splitlines())
+                lines = open(path).read().splitlines()
+                for x in lines:
+                    if x.startswith("@RG"):
+                        read_group[0] = x.split("ID:")[1].split("\t")[0]
+                return sorted(x for x in lines if not x.startswith("@"))
 
             switches = {"plain": var["cli"], "extend": var["cli"] + ["-extend"]}
             ref = {name: run_reference(extra, args.nproc) for name, extra in switches.items()}
@@ -172,12 +180,20 @@ def main():
         if "score" in var:
             mkw["score"] = hip.ScoreParams(**var["score"])
         for name, prm in (("plain", ctx.map_params(**mkw)), ("extend", ctx.map_params(extend_alignments=1, **mkw))):
-            got = []
+            got, unaligned = [], []
             for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
                                                          params=prm, min_align_length=var.get("min_align_length", 0),
-                                                         min_map_qv=var.get("min_map_qv", 0))):
+                                                         min_map_qv=var.get("min_map_qv", 0), for_picard=args.sam,
+                                                         unaligned=unaligned)):
                 nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
-                got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+                if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
+                    got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r]).rstrip("\n")
+                            for h in hits]
+                else:
+                    got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+            if args.sam:  # PrintUnalignedRead for the reads MapRead left without an alignment
+                got += [hip.sam_unaligned_line("read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r])), read_group[0],
+                                               reads[r]).rstrip("\n") for r in unaligned]
             mine[name] = sorted(got)
         ctx.close()
         totals["iters"] += 1
@@ -198,11 +214,12 @@ def main():
             v["lines"] += len(ref[name])
             v["bad"] += diff
             if diff and len(examples) < 6:
-                examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=sorted(a - b)[:2], only_library=sorted(b - a)[:2]))
+                examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=[x[:500] for x in sorted(a - b)[:2]], only_library=[x[:500] for x in sorted(b - a)[:2]]))
         if ref["plain"] is not None and ref["extend"] is not None:
             totals["changed_by_extend"] += len(set(ref["plain"]) ^ set(ref["extend"])) // 2
     totals["seconds"] = round(time.time() - t0, 1)
     totals["seed"] = args.seed
+    totals["format"] = "sam" if args.sam else "m4"
     totals["by_variant"] = by_variant
     totals["examples"] = examples
     print(json.dumps(totals))
