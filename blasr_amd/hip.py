@@ -478,6 +478,7 @@ def sam_unaligned_line(q_name, read_group_id, read_seq, subread_start=0, subread
     f.clipping = int(clipping)
     f.hole_number = int(kw.pop("hole_number", -1))
     f.snr = (C.c_float * 4)(*[float(v) for v in kw.pop("snr", (0, 0, 0, 0))])
+    f.qs, f.qe = f.subread_start + 1, f.subread_end + 1  # the subread's own (SMRTSequence.h:102-103) unless given
     for k, v in kw.items():
         setattr(f, k, v)
     cap = len(seq) + len(q_name) + len(read_group_id) + 512

@@ -113,11 +113,14 @@ def sam_record(hit, read_name, contig_name, read_group, read_seq, quality=None, 
         is_primary = 1 if hit.get("rank", 0) == 0 else 0
     cig, clips = hip.cigar(hit["q"], hit["t"], hit["q_pos"], hit["t_pos"], ops=hit["ops"], clipping=clipping,
                            t_strand=hit["strand"], read_length=L, q_align_start=hit["q_align_start"],
-                           q_align_end=hit["q_align_end"])
+                           q_align_end=hit["q_align_end"], subread_start=subread_start,
+                           subread_end=L if subread_end is None else subread_end)
     return hip.sam_line(read_name, contig_name, read_group, cig, clips, read_seq, quality, clipping=clipping,
                         q_strand=0, t_strand=hit["strand"], is_primary=is_primary, read_length=L,
                         subread_start=subread_start, subread_end=L if subread_end is None else subread_end,
                         q_align_start=hit["q_align_start"], q_align_end=hit["q_align_end"],
                         t_align_start=hit["t_start"], t_end=hit["t_span"], t_length=hit["t_length"], q_length=L,
                         q_aligned_seq_pos=hit["q_aligned_seq_pos"], q_aligned_seq_length=len(hit["q"]),
-                        map_qv=hit["map_qv"], score=hit["score"], edit_dist=0, hole_number=hole_number)
+                        map_qv=hit["map_qv"], score=hit["score"], edit_dist=0, hole_number=hole_number,
+                        # the mapped subread's qs / qe (SMRTSequence.h:102-103), printed under -clipping soft / hard / subread
+                        qs=subread_start + 1, qe=(L if subread_end is None else subread_end) + 1)

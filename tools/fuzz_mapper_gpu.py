@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--nproc", type=int, default=16)
     ap.add_argument("--dump", type=int, default=-1, metavar="IT",
                     help="write the FASTA files of iteration IT to ./fuzz_mapper_dump/ and stop (no GPU needed)")
+    ap.add_argument("--dropin", action="store_true",
+                    help="also run the reference binary patched to call the library (oracle/_ref/blasrmc_gpu -useGPU -nproc 2: "
+                         "anchoring, SDPAlign and the refine loop through the C ABI, the rest its own code) and compare its lines")
     ap.add_argument("--sam", action="store_true", help="compare SAM records (-sam: CIGAR, flags, tags) instead of -m 4 lines")
     ap.add_argument("--variants", action="store_true", help="cycle through non-default switches (see the table in main)")
     args = ap.parse_args()
@@ -72,6 +75,9 @@ def main():
         dict(cli=["-maxLCPLength", "16"], anchor=dict(max_lcp_length=16), name="maxLCPLength16"),
         dict(cli=["-sdpMaxAnchorsPerPosition", "2"], sdp=dict(max_per_pos=2), name="sdpMaxAnchorsPerPosition2"),
         dict(cli=["-sdpPrefix", "20"], sdp=dict(prefix=20), name="sdpPrefix20"),
+        dict(cli=["-clipping", "soft"], clipping=hip.CLIP_SOFT, name="clippingSoft"),
+        dict(cli=["-clipping", "hard"], clipping=hip.CLIP_HARD, name="clippingHard"),
+        dict(cli=["-clipping", "subread"], clipping=hip.CLIP_SUBREAD, name="clippingSubread"),
         dict(cli=["-bestn", "4", "-nCandidates", "4", "-minPctIdentity", "70"], bestn=4,
              map=dict(n_candidates=4, min_pct_identity=70.0), interval=dict(n_candidates=4), name="bestn4nCandidates4pct70"),
     ]
@@ -91,6 +97,11 @@ def main():
                 piece = synth.revcomp(piece)
             at = int(rng.integers(0, len(contigs[b]) - len(piece)))
             contigs[b] = np.concatenate([contigs[b][:at], piece, contigs[b][at + len(piece):]])
+        if it % 3 == 1:  # a run of N inside a contig (the FASTA reader keeps it; anchors and windows meet it)
+            c = int(rng.integers(0, n_contigs))
+            at = int(rng.integers(1000, len(contigs[c]) - 1000))
+            contigs[c] = contigs[c].copy()
+            contigs[c][at:at + int(rng.integers(1, 80))] = ord("N")
         reads = []
         for r in range(args.reads):
             ci = int(rng.integers(0, n_contigs))
@@ -110,6 +121,9 @@ def main():
             rd = np.ascontiguousarray(synth.mutate(s, rng, ins, dele, sub))
             if rng.integers(0, 4) == 0:  # an unrelated tail the extension must not swallow
                 rd = np.concatenate([rd, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(5, 200)))]])
+            if rng.integers(0, 12) == 0:  # a few N in the read
+                rd = rd.copy()
+                rd[rng.integers(0, len(rd), int(rng.integers(1, 4)))] = ord("N")
             if len(rd) < 50:
                 continue
             reads.append(rd)
@@ -134,9 +148,9 @@ def main():
                 return
             read_group = [""]
 
-            def run_reference(extra, nproc):
+            def run_reference(extra, nproc, exe=None):
                 path = os.path.join(tmp, "out.m4")
-                p = subprocess.run([blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta")] +
+                p = subprocess.run([exe or blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta")] +
                                    (["-sam"] if args.sam else ["-m", "4"]) +
                                    ["-bestn", "1", "-nproc", str(nproc), "-out", path] + extra,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -154,6 +168,21 @@ def main():
             # run under -nproc > 1 (its interval finder reads one element past the end of a match list, i.e. whatever the
             # thread's previous read left there): a difference only counts when the one-thread run shows it too
             ref1 = {name: run_reference(extra, 1) for name, extra in switches.items()} if args.nproc > 1 else ref
+            if args.dropin:
+                for name, extra in switches.items():
+                    got = run_reference(extra + ["-useGPU"], 2, os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu"))
+                    if got is None or ref[name] is None:
+                        totals["dropin_failed"] = totals.get("dropin_failed", 0) + (got is None)
+                        continue
+                    totals["dropin_lines"] = totals.get("dropin_lines", 0) + len(got)
+                    d = len(set(got) ^ set(ref[name]))
+                    if d and ref1[name] is not None and not (set(got) ^ set(ref1[name])):
+                        d = 0
+                    totals["dropin_bad"] = totals.get("dropin_bad", 0) + d
+                    if d and len(examples) < 6:
+                        examples.append(dict(it=it, mode=name, variant=var["name"], leg="dropin",
+                                             only_reference=[x[:300] for x in sorted(set(ref[name]) - set(got))[:2]],
+                                             only_dropin=[x[:300] for x in sorted(set(got) - set(ref[name]))[:2]]))
         # the library, from the reads alone
         parts, starts = [], [0]
         for c in contigs:
@@ -187,13 +216,14 @@ def main():
                                                          unaligned=unaligned)):
                 nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
                 if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
-                    got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r]).rstrip("\n")
-                            for h in hits]
+                    got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r],
+                                                 clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n") for h in hits]
                 else:
                     got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
             if args.sam:  # PrintUnalignedRead for the reads MapRead left without an alignment
                 got += [hip.sam_unaligned_line("read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r])), read_group[0],
-                                               reads[r]).rstrip("\n") for r in unaligned]
+                                               reads[r], clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n")
+                        for r in unaligned]
             mine[name] = sorted(got)
         ctx.close()
         totals["iters"] += 1
@@ -213,6 +243,14 @@ def main():
             v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
             v["lines"] += len(ref[name])
             v["bad"] += diff
+            if diff and args.sam and len(examples) < 6:  # which fields of a record differ
+                byname = {x.split("\t")[0]: x for x in b - a}
+                for x in sorted(a - b)[:2]:
+                    y = byname.get(x.split("\t")[0])
+                    if y is not None:
+                        fx, fy = x.split("\t"), y.split("\t")
+                        examples.append(dict(it=it, mode=name, variant=var["name"], fields=[
+                            (i, u[:60], v[:60]) for i, (u, v) in enumerate(zip(fx, fy)) if u != v], n=(len(fx), len(fy))))
             if diff and len(examples) < 6:
                 examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=[x[:500] for x in sorted(a - b)[:2]], only_library=[x[:500] for x in sorted(b - a)[:2]]))
         if ref["plain"] is not None and ref["extend"] is not None:
