@@ -1,7 +1,8 @@
 // examples/map_fasta.cpp -- a C++ host over the C ABI of include/blasr_hip.h, nothing else: FASTA in, `-m 4` lines out.
 //
-//   map_fasta reads.fasta genome.fasta genome.fasta.sa [bestn]     the whole mapper: anchoring included
-//   map_fasta reads.fasta genome.fasta intervals.txt   [bestn]     candidate intervals given (e.g. blasrmc -V 1's)
+//   map_fasta reads.fasta genome.fasta genome.fasta.sa [bestn] [-extend]   the whole mapper: anchoring included
+//   map_fasta reads.fasta genome.fasta intervals.txt   [bestn] [-extend]   candidate intervals given (e.g. blasrmc -V 1's)
+// -extend: the reference's switch of that name (both ends of every SDP alignment extended before the filters)
 //
 // What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
 //   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
@@ -31,7 +32,11 @@ static void die(const char *what, blasr_hip_ctx *ctx) {
 
 int main(int argc, char **argv) {
   if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta (genome.fasta.sa | intervals.txt) [bestn]", NULL);
-  const int bestn = argc > 4 ? atoi(argv[4]) : 1;
+  int bestn = 1, extend = 0;
+  for (int i = 4; i < argc; i++) {
+    if (strcmp(argv[i], "-extend") == 0) extend = 1;
+    else bestn = atoi(argv[i]);
+  }
   // ---- genome: contigs back to back, an N after each, upper case; the contig table; names up to the first blank
   blasr_hip_fasta *gf = NULL, *rf = NULL;
   if (blasr_hip_fasta_read(argv[2], &gf) != BLASR_HIP_OK) die("cannot read the genome", NULL);
@@ -95,6 +100,7 @@ int main(int argc, char **argv) {
     blasr_hip_pipeline_params pp;
     blasr_hip_pipeline_default_params(&pp);
     if (pp.anchor.min_match_length < (uint32_t)prefixLen) pp.anchor.min_match_length = (uint32_t)prefixLen;  // Blasr.cpp:4433-4436
+    pp.map.extend_alignments = extend;
     std::vector<int32_t> countTable((size_t)1 << 16);  // tuples of params.lookupTableLength = 8 bases (Blasr.cpp:4479-4482)
     if (blasr_hip_count_tuples_device(ctx, 8, countTable.data())) die("count_tuples", ctx);
     oneCall = true;
@@ -130,6 +136,7 @@ int main(int argc, char **argv) {
   int64_t nHits = 0;
   blasr_hip_map_params prm;  // (the one-call route used the same defaults)
   blasr_hip_map_default_params(&prm);
+  prm.extend_alignments = extend;
   if (oneCall) {  // (already mapped above)
     hits.swap(hitsOne);
     hitOff.swap(hitOffOne);

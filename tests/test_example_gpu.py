@@ -34,17 +34,21 @@ def test_cpp_example_prints_the_reference_lines(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_example_maps_from_fasta_and_suffix_array_alone(tmp_path):
+@pytest.mark.parametrize("extend", [False, True])
+def test_cpp_example_maps_from_fasta_and_suffix_array_alone(tmp_path, extend):
     """The same binary as a whole mapper: reads.fasta + genome.fasta + the .sa file of the reference's sawriter in, the
-    reference binary's -m 4 lines out (anchoring on the device, interval finding on the host, then MapRead)."""
+    reference binary's -m 4 lines out (anchoring on the device, interval finding on the host, then MapRead); with
+    -extend, the lines the reference binary prints under -extend (tests/golden/m4_noisy_extend_golden.npz)."""
     sawriter = os.path.join(ROOT, "oracle", "_ref", "sawritermc")
     if not os.path.exists(EXE) or not os.path.exists(sawriter):
         pytest.skip("examples/map_fasta or oracle/_ref/sawritermc not built")
     want = write_inputs(str(tmp_path))
+    if extend:
+        want = sorted(bytes(np.load(os.path.join(ROOT, "tests", "golden", "m4_noisy_extend_golden.npz"))["lines"]).decode().splitlines())
     fa = os.path.join(str(tmp_path), "genome.fasta")
     subprocess.run([sawriter, fa + ".sa", fa, "-blt", "8"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    p = subprocess.run([EXE, os.path.join(str(tmp_path), "reads.fasta"), fa, fa + ".sa", "1"], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run([EXE, os.path.join(str(tmp_path), "reads.fasta"), fa, fa + ".sa", "1"] + (["-extend"] if extend else []),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     got = sorted(p.stdout.decode().splitlines())
     assert len(got) == len(want) == 80

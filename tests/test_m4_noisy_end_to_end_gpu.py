@@ -118,8 +118,8 @@ def run_end_to_end(own_intervals, tmp_path=None):
 
 
 @pytest.mark.skipif(not os.path.exists(SAWRITER), reason="oracle/_ref/sawritermc not built (the suffix array's writer)")
-@pytest.mark.parametrize("reads_per_block", [7, 1000])
-def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_per_block):
+@pytest.mark.parametrize("reads_per_block,extend", [(7, 0), (1000, 0), (13, 1)])
+def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_per_block, extend):
     """blasr_hip_map_from_reads_device (anchoring in sub-blocks overlapped with the host's interval finding, then the
     path, in C++): the reference binary's 125 candidate intervals and the hits of the step-by-step route, for sub-blocks
     of 7 reads (12 of them in flight) and for one sub-block."""
@@ -145,12 +145,13 @@ def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_p
     hits = np.zeros(len(want_iv) + 8, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(len(reads) + 1, dtype=np.int64)
     p = ctx.pipeline_params(reads_per_block=reads_per_block)
+    p.map.extend_alignments = extend  # -extend travels with the path's parameters
     n, ivs = ctx.map_from_reads_device(genome, starts, ctx.count_tuples(8), reads, d_reads, d_pool, p, hits, hit_off,
                                        intervals_capacity=len(want_iv) + 8)
     assert np.array_equal(ivs, want_iv)
     t = ctx.pipeline_last_timing()
     assert t["intervals"] == len(want_iv) and t["anchors"] > 10000
-    want_hits, want_off, _, _ = ctx.map_reads(reads, pool, want_iv, fetch=False)
+    want_hits, want_off, _, _ = ctx.map_reads(reads, pool, want_iv, params=ctx.map_params(extend_alignments=extend), fetch=False)
     assert n == len(want_hits) and np.array_equal(hit_off, want_off)
     for f in ("read", "interval", "t_strand", "t_aligned_seq_pos", "q_pos", "t_pos", "score", "n_match", "n_ops"):
         assert np.array_equal(hits[:n][f], want_hits[f]), f

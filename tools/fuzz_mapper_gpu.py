@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--nproc", type=int, default=16)
     ap.add_argument("--dump", type=int, default=-1, metavar="IT",
                     help="write the FASTA files of iteration IT to ./fuzz_mapper_dump/ and stop (no GPU needed)")
+    ap.add_argument("--contig-len", type=int, nargs=2, default=[60000, 160000], metavar=("LO", "HI"))
+    ap.add_argument("--read-lens", type=int, nargs="+", default=[300, 700, 1500, 3000, 6000])
     ap.add_argument("--dropin", action="store_true",
                     help="also run the reference binary patched to call the library (oracle/_ref/blasrmc_gpu -useGPU -nproc 2: "
                          "anchoring, SDPAlign and the refine loop through the C ABI, the rest its own code) and compare its lines")
@@ -86,7 +88,8 @@ def main():
     t0 = time.time()
     for it in range(args.iters):
         n_contigs = int(rng.integers(1, 4))
-        contigs = [synth.random_genome(int(rng.integers(60000, 160000)), int(rng.integers(1, 1 << 30))) for _ in range(n_contigs)]
+        contigs = [synth.random_genome(int(rng.integers(args.contig_len[0], args.contig_len[1])), int(rng.integers(1, 1 << 30)))
+                   for _ in range(n_contigs)]
         for _ in range(int(rng.integers(0, 4))):  # planted repeats, some reverse-complemented
             a, b = int(rng.integers(0, n_contigs)), int(rng.integers(0, n_contigs))
             ln = int(rng.integers(2000, 7000))
@@ -105,7 +108,7 @@ def main():
         reads = []
         for r in range(args.reads):
             ci = int(rng.integers(0, n_contigs))
-            rl = int(rng.choice([300, 700, 1500, 3000, 6000]))
+            rl = int(rng.choice(args.read_lens))
             rl = min(rl, len(contigs[ci]) - 10)
             mode = int(rng.integers(0, 5))
             if mode == 0:      # starts at the very beginning of the contig
