@@ -44,7 +44,11 @@ sys.path.insert(0, ROOT)
 PMC = {
     # (config, reads, read_len, band): HBM bytes per launch of the roofline kernel = (FETCH_SIZE + WRITE_SIZE) x the
     # unit and gfx950 corrections of tools/pmc_summary.py, separate rocprofv3 --pmc passes (tools/pmc_config1.sh).
-    # configs[2]'s set-up cannot be profiled with --pmc on this image, so only configs[1] is here.
+    # configs[2]: rocprofv3 --pmc dies inside torch's generator on this image, so tools/pmc_config2.sh profiles a run that
+    # LOADS the inputs an unprofiled run wrote (--save-workload / --load-workload): same workload, same build.
+    (2, 100000, 10000, 16): {"traffic": 54889864352.0,
+                             "note": "profiles/r02_v4_pmc_counters_configs2_100k_reads.json, fillp_kernel<16, true, false>, "
+                                     "one launch of the same workload and build: 1.13 x the algorithmic bytes"},
     (1, 100000, 10000, 16): {"traffic": 42178089536.0,
                              "note": "profiles/r02_v3_pmc_counters_configs1_100k_reads.json, fillp_kernel<16, true, false>, "
                                      "one launch of the same workload and build: 1.13 x the algorithmic bytes"},
@@ -79,6 +83,11 @@ def parse_args(argv=None):
                     help="the reference's -extend (Blasr.cpp:1749-1940): both ends of every SDP alignment extended before "
                          "the first filter.  NOT the headline configuration; the parity leg against the reference's "
                          "functions is skipped (tools/fuzz_mapper_gpu.py pins -extend against the reference binary)")
+    ap.add_argument("--save-workload", default="", metavar="PATH",
+                    help="write the generated inputs (genome, reads, intervals) to PATH and go on")
+    ap.add_argument("--load-workload", default="", metavar="PATH",
+                    help="read the inputs a --save-workload run wrote instead of generating them (rocprofv3 --pmc dies "
+                         "inside torch's generator on this image: tools/pmc_config2.sh profiles a loaded workload)")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -383,11 +392,25 @@ def main():
         contig_lengths = list(synth.HG19_CHROM_LENGTHS)
     else:
         contig_lengths = [synth.ECOLI_K12_LENGTH]
-    genome, starts, copies = synth.make_repeat_genome(contig_lengths, 1, dev, families=d["families"])
-    wl = synth.make_map_workload(genome, copies if d["families"] > 0 else None, d["reads"], d["read_len"],
-                                 args.seed + rank, dev, ins=d["ins"], dele=d["dele"], sub=d["sub"],
-                                 max_unanchored=d["max_unanchored"], spurious=d["spurious"], loose=d["loose"],
-                                 spurious_span=d["spurious_span"])
+    if args.load_workload:
+        blob = torch.load(args.load_workload, weights_only=False)
+        genome, starts, n_copies = blob["genome"].to(dev), blob["starts"], blob["n_copies"]
+        wl = dict(blob["wl"])
+        wl["pool"] = wl["pool"].to(dev)
+        wl["origin"] = tuple(t.to(dev) for t in wl["origin"])
+    else:
+        genome, starts, copies = synth.make_repeat_genome(contig_lengths, 1, dev, families=d["families"])
+        n_copies = 0 if copies is None else int(copies["start"].numel())
+        wl = synth.make_map_workload(genome, copies if d["families"] > 0 else None, d["reads"], d["read_len"],
+                                     args.seed + rank, dev, ins=d["ins"], dele=d["dele"], sub=d["sub"],
+                                     max_unanchored=d["max_unanchored"], spurious=d["spurious"], loose=d["loose"],
+                                     spurious_span=d["spurious_span"])
+        del copies
+    if args.save_workload:
+        host = dict(wl)
+        host["pool"] = wl["pool"].cpu()
+        host["origin"] = tuple(t.cpu() for t in wl["origin"])
+        torch.save(dict(genome=genome.cpu(), starts=starts, n_copies=n_copies, wl=host), args.save_workload)
     G = int(genome.numel())
     n_reads, n_iv = len(wl["reads"]), len(wl["intervals"])
     reads_t = torch.from_numpy(wl["reads"].view(np.uint8)).to(dev)
@@ -466,7 +489,7 @@ def main():
             "dtype": "int32",
             "data": "synthetic, generated on the device in %.0f s: %d-base i.i.d. genome with %d planted repeat families "
                     "(%d copies), %d reads, %d candidate intervals (%d true loci, %d repeat copies, %d chance clusters)"
-                    % (t_gen, G, d["families"], 0 if copies is None else int(copies["start"].numel()), n_reads, n_iv,
+                    % (t_gen, G, d["families"], n_copies, n_reads, n_iv,
                        kinds[0], kinds[1], kinds[2]),
             "config": {"workload": workload_label(args, d, G, len(starts) - 1),
                        "reads_per_gpu": n_reads, "read_len": d["read_len"], "band": args.band,
