@@ -162,6 +162,20 @@ def test_sam_line_golden(golden, orc):
         assert want.endswith("\n") and len(want.split("\t")) >= 12
 
 
+def test_print_gates():
+    """PrintAlignment's gates (Blasr.cpp:2957-2978): strict comparisons, the aligned length against minAlignLength as
+    unsigned, each gate on its own."""
+    from blasr_amd import hip
+    ok = hip.alignment_is_printed
+    assert ok(-200, 0.0, 0, 0)                                   # the defaults let a score of exactly maxScore through
+    assert not ok(-199, 90.0, 500, 254)                          # score > maxScore
+    assert ok(-1500, 84.0, 500, 254, max_score=-1500, min_pct_identity=84.0)
+    assert not ok(-1500, 83.99, 500, 254, max_score=-1500, min_pct_identity=84.0)
+    assert ok(-900, 90.0, 1000, 30, min_align_length=1000, min_map_qv=30)
+    assert not ok(-900, 90.0, 999, 30, min_align_length=1000)
+    assert not ok(-900, 90.0, 1000, 29, min_map_qv=30)
+
+
 def test_sam_unaligned_record():
     """SAMOutput::PrintUnalignedRead (SAMPrinter.h:578-664): the record -sam prints for a read without an alignment.
     A line of the reference BINARY (oracle/_ref/blasrmc -sam, a read of a fuzz run) is the fixed vector; where the
