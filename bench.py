@@ -81,8 +81,8 @@ def parse_args(argv=None):
                          "report them as `end_to_end` (N=1 only; needs ~130 GB of HBM for an hg19-size genome)")
     ap.add_argument("--extend", action="store_true",
                     help="the reference's -extend (Blasr.cpp:1749-1940): both ends of every SDP alignment extended before "
-                         "the first filter.  NOT the headline configuration; the parity leg against the reference's "
-                         "functions is skipped (tools/fuzz_mapper_gpu.py pins -extend against the reference binary)")
+                         "the first filter.  NOT the headline configuration; the CPU leg then runs the reference's "
+                         "ExtendAlignment too (tools/fuzz_mapper_gpu.py pins -extend against the reference binary)")
     ap.add_argument("--save-workload", default="", metavar="PATH",
                     help="write the generated inputs (genome, reads, intervals) to PATH and go on")
     ap.add_argument("--load-workload", default="", metavar="PATH",
@@ -151,7 +151,7 @@ def launch_ranks(args):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baselines (checker code: never on the product path)
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores):
+def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, extend=False):
     """The path for the first `n_reads` reads of the same workload on the host cores: every candidate interval
     through the reference's OWN SDPAlign + ComputeAlignmentStats, the survivors through its AffineGuidedAlign +
     ComputeAlignmentStats (oracle/_ref/libblasr_ref.so, built from the reference's sources where they lie: kind
@@ -177,7 +177,7 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores):
         rd = reads[r: r + 1].copy()
         p = pool[int(rd["off"][0]): int(rd["off"][0]) + int(rd["length"][0])]
         rd["off"] = 0
-        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band)[0]
+        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band, extend=extend)[0]
 
     t0 = time.perf_counter()
     if cores <= 1:
@@ -201,8 +201,9 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores):
                 want = x[f] if f != "interval" else int(glob[x[f]])
                 ok = ok and h[f] == want
         mismatches += not ok
-    what = ("the reference's own SDPAlign + AffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
-            if ref is not None else "the oracle's restatement of SDP + refine")
+    what = ("the reference's own SDPAlign + %sAffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
+            % ("ExtendAlignmentForward / Reverse + " if extend else "")
+            if ref is not None else "the oracle's restatement of SDP + %srefine" % ("extension + " if extend else ""))
     return dict(value=aligned / dt, unit="bases/s", cores=max(cores, 1), kind="reference" if ref is not None else "port",
                 sample="first %d reads of the same workload (%d candidate intervals) through %s, windows / sort / filters "
                        "through the oracle (%.1f s on %d host thread%s, %.1f ms/read per thread)"
@@ -539,8 +540,8 @@ def main():
             cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
             ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, int(2400 * 10000 / d["read_len"]) // max(1, round(n_iv / n_reads)))
             ns = min(ns, n_reads)
-            if ns > 0 and not args.extend:
-                out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores)
+            if ns > 0:
+                out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores, args.extend)
             nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 10000000 // d["read_len"]))
             if nb > 0:
                 ncores = os.cpu_count() or 1

@@ -812,8 +812,75 @@ EpilogueChecker.order_gaps_by_type = _order_gaps_by_type
 # MapRead from the intervals on, composed from the oracle's pieces in the reference's order
 # (Blasr.cpp:2530-2644): the checker for blasr_hip_map_reads_* (blasr_amd/csrc/mapread_api.hip).
 # ---------------------------------------------------------------------------------------------
+_RC = np.full(256, 127, dtype=np.uint8)  # ReverseComplementNuc (NucConversion.h:337-370)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _RC[_a] = _b
+
+
+def oracle_extend_candidate(oracle, genome, contigs, read, w, q, tseq, s, sc, band=10, drops=10, max_len=500):
+    """The -extend step of AlignIntervals (Blasr.cpp:1749-1940) on one candidate, composed from the oracle's
+    ExtendAlignment and plain index arithmetic (DNALength = 32-bit unsigned, kept with & M): the candidate cut to its SDP
+    extent, up to 500 read / genome bases after it (Forward) and before it (Reverse: called one base early, and on the
+    reverse strand against MakeRC of a FORWARD position, :1876, :1885), AppendAlignment without gap lists.  Returns the
+    new (window fields, query string, target string, sdp record)."""
+    M = 0xffffffff
+    blocks = np.asarray(s["blocks"], np.int64).reshape(-1, 3)
+    if len(blocks) == 0:
+        return w, q, tseq, s
+    L = len(genome)
+    q_end, t_end = int(blocks[-1, 0] + blocks[-1, 2]), int(blocks[-1, 1] + blocks[-1, 2])
+    q_asp, t_asp = (w["qAlignedSeqPos"] + s["qPos"]) & M, (w["tAlignedSeqPos"] + s["tPos"]) & M
+    tw = np.asarray(tseq)[s["tPos"]: s["tPos"] + t_end]
+    cs, ce = (0, L) if contigs is None else (int(contigs[w["tIndex"]]), int(contigs[w["tIndex"] + 1]) - 1)
+    rev_strand = w["tStrand"] == 1
+    c_start, c_end = ((L - ce) & M, (L - cs) & M) if rev_strand else (cs, ce)
+    last_q, last_t = (q_end + q_asp) & M, (t_end + t_asp) & M
+    rsl, gsl = min((len(read) - last_q) & M, max_len), min((c_end - last_t) & M, max_len)
+    rpl, gpl = min(q_asp, max_len), min((t_asp - c_start) & M, max_len)
+
+    def strand_piece(pos, n):  # CopyAsRC: n bases of the strand of the alignment from `pos` on it
+        return genome[pos: pos + n] if not rev_strand else _RC[genome[L - pos - n: L - pos][::-1]]
+
+    m = sc.matrix.reshape(-1)
+    new_blocks = [tuple(int(v) for v in b) for b in blocks]
+    q_len = q_end
+    fwd_t = np.zeros(0, np.uint8)
+    if rsl > 0 and gsl > 0:
+        g_suffix = strand_piece(last_t, gsl)
+        f = extend_align(oracle, read[last_q: last_q + rsl], 0, g_suffix, 0, band, drops, False, matrix=m, ins=sc.ins, dele=sc.dele)
+        if f["score"] < 0:  # :1840-1855
+            fb = f["blocks"]
+            fq, ft = int(fb[-1, 0] + fb[-1, 2]), int(fb[-1, 1] + fb[-1, 2])
+            new_blocks += [(int(b[0]) + q_end, int(b[1]) + t_end, int(b[2])) for b in fb]
+            q_len += fq
+            fwd_t = g_suffix[:ft]
+    q_pos = t_pos = 0
+    pre_t = np.zeros(0, np.uint8)
+    if rpl > 0 and gpl > 0:
+        r_prefix = read[q_asp - rpl: q_asp]
+        if not rev_strand:
+            g_prefix = genome[t_asp - gpl: t_asp]
+        else:  # MakeRC of the forward stretch at the reverse-strand position (:1876)
+            g_prefix = _RC[genome[t_asp - gpl: t_asp][::-1]]
+        v = extend_align(oracle, r_prefix, rpl - 1, g_prefix, gpl - 1, band, drops, True, matrix=m, ins=sc.ins, dele=sc.dele)
+        if v["score"] < 0:  # :1899-1935
+            q_pos, t_pos = v["qPos"], v["tPos"]
+            qs, ts = rpl - q_pos, gpl - t_pos
+            new_blocks = [tuple(int(x) for x in b) for b in v["blocks"]] + [(b[0] + qs, b[1] + ts, b[2]) for b in new_blocks]
+            q_asp, t_asp = (q_asp - rpl) & M, (t_asp - gpl) & M
+            q_len += rpl
+            pre_t = g_prefix
+    new_t = np.concatenate([pre_t, tw, fwd_t]).astype(np.uint8)
+    new_q = np.asarray(read[q_asp: q_asp + q_len], np.uint8)
+    w2 = dict(w)
+    w2.update(qAlignedSeqPos=q_asp, qAlignedSeqLength=len(new_q), tAlignedSeqPos=t_asp, tAlignedSeqLength=len(new_t))
+    s2 = dict(s)
+    s2.update(qPos=int(q_pos), tPos=int(t_pos), blocks=np.array(new_blocks, np.int32).reshape(-1, 3))
+    return w2, new_q, new_t, s2
+
+
 def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=16, n_candidates=10, max_gap=0,
-                     max_score=-200, min_pct=0.0, sp=None, sc=None):
+                     max_score=-200, min_pct=0.0, sp=None, sc=None, extend=False, extend_band=10, extend_drops=10):
     """reads / intervals: the product's READ_DTYPE / INTERVAL_DTYPE arrays.  Returns, per read, the alignments
     MapRead keeps (best first) as dicts: interval, the hit record's fields, q / t (aligned sequences), ops."""
     sp, sc = sp or SdpParams(), sc or ScoreParams()
@@ -832,6 +899,9 @@ def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=1
                                 contigs)
             q = read[w["qAlignedSeqPos"]: w["qAlignedSeqPos"] + w["qAlignedSeqLength"]]
             s = oracle.sdp_align(q, tseq, sc, sp)
+            if extend:
+                w, q, tseq, s = oracle_extend_candidate(oracle, np.asarray(genome), contigs, read, w, q, tseq, s, sc,
+                                                        extend_band, extend_drops)
             st = oracle.compute_alignment_stats(q, tseq, s["qPos"], s["tPos"], s["blocks"], sc=sc)
             c.append(dict(interval=k, win=w, q=q, t=tseq, sdp=s, score=st["score"], pct=np.float32(st["pct"]),
                           t_pos=s["tPos"], t_aligned_seq_pos=w["tAlignedSeqPos"], t_end=0, blocks=s["blocks"],

@@ -32,7 +32,8 @@ def check_hits(hits, off, seq, ops, want):
     return n_multi
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(max_gap=40), dict(n_candidates=2), dict(max_score=-2000, min_pct_identity=80.0)])
+@pytest.mark.parametrize("kw", [dict(), dict(max_gap=40), dict(n_candidates=2), dict(max_score=-2000, min_pct_identity=80.0),
+                                dict(extend_alignments=1), dict(extend_alignments=1, extend_band_size=4, max_extend_dropoff=3)])
 def test_map_reads_against_oracle_composition(oracle, kw):
     rng = np.random.default_rng(77)
     genome, pool, reads, ivs = repeat_genome_case(rng, 48)
@@ -41,7 +42,9 @@ def test_map_reads_against_oracle_composition(oracle, kw):
     params = ctx.map_params(**kw)
     hits, off, seq, ops = ctx.map_reads(reads, pool, ivs, params=params)
     want = oracle_map_reads(oracle, MapperOracle(), genome, None, pool, reads, ivs, n_candidates=params.n_candidates,
-                            max_gap=params.max_gap, max_score=params.max_score, min_pct=params.min_pct_identity)
+                            max_gap=params.max_gap, max_score=params.max_score, min_pct=params.min_pct_identity,
+                            extend=bool(params.extend_alignments), extend_band=params.extend_band_size,
+                            extend_drops=params.max_extend_dropoff)
     n_multi = check_hits(hits, off, seq, ops, want)
     t = ctx.map_last_timing()
     assert t["intervals"] == len(ivs) and t["hits"] == len(hits)
@@ -62,6 +65,8 @@ def test_map_reads_with_contigs_and_empty_inputs(oracle):
     hits, off, seq, ops = ctx.map_reads(reads, pool, ivs)
     want = oracle_map_reads(oracle, MapperOracle(), genome, contigs, pool, reads, ivs)
     check_hits(hits, off, seq, ops, want)
+    hits_x, off_x, seq_x, ops_x = ctx.map_reads(reads, pool, ivs, params=ctx.map_params(extend_alignments=1))
+    check_hits(hits_x, off_x, seq_x, ops_x, oracle_map_reads(oracle, MapperOracle(), genome, contigs, pool, reads, ivs, extend=True))
     # a read without intervals keeps an empty slice; no intervals at all is not an error
     some = ivs[ivs["read"] != 3]
     hits2, off2, _, _ = ctx.map_reads(reads, pool, some)
