@@ -180,6 +180,44 @@ static void RefineAlignmentsGPU(T_Sequence &query, std::vector<T_AlignmentCandid
   if (params.sortRefinedAlignments)  // Blasr.cpp:2178-2180
     std::sort(alignmentPtrs.begin(), alignmentPtrs.end(), SortAlignmentPointersByScore());
 }
+// Replaces ExtendAlignmentForward / ExtendAlignmentReverse under -extend (Blasr.cpp:1826-1838, 1885-1897): one call, one
+// task.  The arrow path comes back as ops; the alignment is rebuilt with the reference's own ArrowPathToAlignment.
+template <typename T_Query, typename T_Ref>
+static int ExtendAlignmentGPU(T_Query &querySeq, int queryPos, T_Ref &refSeq, int refPos, T_AlignmentCandidate &alignment,
+                              MappingParameters &params, bool reverse) {
+  std::vector<uint8_t> seq;
+  seq.insert(seq.end(), querySeq.seq, querySeq.seq + querySeq.length);
+  seq.insert(seq.end(), refSeq.seq, refSeq.seq + refSeq.length);
+  int64_t qOff = 0, tOff = querySeq.length;
+  int32_t qLen = querySeq.length, tLen = refSeq.length, qPos = queryPos, tPos = refPos;
+  uint8_t rev = reverse ? 1 : 0;
+  blasr_hip_extend_batch batch = {1, seq.data(), &qOff, &qLen, &tOff, &tLen, &qPos, &tPos, &rev};
+  blasr_hip_extend_params ep;
+  blasr_hip_extend_default_params(&ep);
+  ep.ins = params.insertion;  // distScoreFn (Blasr.cpp:3666-3668)
+  ep.del = params.deletion;
+  ep.band = params.extendBandSize;
+  ep.max_n_drops = params.maxExtendDropoff;
+  blasr_hip_refine_result res;
+  std::vector<uint32_t> ops((size_t)qLen + tLen + 16);
+  int64_t used = 0;
+  int rc = blasr_hip_extend_host(tlsHipCtx, &batch, &ep, &res, ops.data(), (int64_t)ops.size(), &used);
+  if (rc != BLASR_HIP_OK || res.status != 0) {
+    cout << "ERROR, GPU extension failed: " << blasr_hip_last_error(tlsHipCtx) << endl;
+    exit(1);
+  }
+  std::vector<Arrow> path;
+  for (int o = 0; o < res.n_ops; o++) {
+    uint32_t op = ops[res.ops_off + o];
+    Arrow a = BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_M ? Diagonal : BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_I ? Up : Left;
+    path.insert(path.end(), BLASR_HIP_OP_LEN(op), a);
+  }
+  alignment.ArrowPathToAlignment(path);  // ExtendAlign.h:374-377
+  alignment.qPos = res.q_pos;
+  alignment.tPos = res.t_pos;
+  return res.dp_score;
+}
+
 // Replaces the two MapReadToGenome calls of MapRead (Blasr.cpp:2279-2297) for one read: both strands anchored on the
 // device in the suffix array the mapper holds (uploaded once per mapping thread's context).  The lists come back in
 // MapReadToGenome's own order; MapRead sorts them itself right after (:2339-2340).

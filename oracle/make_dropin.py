@@ -7,6 +7,7 @@ committed: oracle/_ref is git-ignored), adds oracle/dropin/blasr_hip_dropin.h (t
   MappingParameters.h   two fields: bool useGPU (false), int gpuDevice (0)
   Blasr.cpp             #include of the helper before AlignIntervals
                         AlignIntervals (:1716-1724)   SDPAlign + ComputeAlignmentStats -> SDPAlignCandidateGPU under -useGPU
+                        AlignIntervals (:1826, :1885) ExtendAlignmentForward / Reverse (-extend) -> ExtendAlignmentGPU under -useGPU
                         RefineAlignments (:2164-2181) the per-candidate loop -> RefineAlignmentsGPU under -useGPU
                         MapRead (:2279-2297)          the two MapReadToGenome calls -> MapReadToGenomeGPU under -useGPU
                         MapReads (:3238)              one blasr_hip context per mapping thread, next to MappingBuffers
@@ -65,6 +66,14 @@ def main():
                     "mappingBuffers.matchPosList, mappingBuffers.rcMatchPosList, numKeysMatched, rcNumKeysMatched);\n    }\n"
                     "    else if (params.useSuffixArray) {\n      params.anchorParameters.lcpBoundsOutPtr = mapData->lcpBoundsOutPtr;\n",
                     "MapRead's anchoring")
+    bl = patch_once(bl, "          forwardScore = ExtendAlignmentForward(readSuffix, 0,\n",
+                    "          forwardScore = params.useGPU ? ExtendAlignmentGPU(readSuffix, 0, genomeSuffix, 0, "
+                    "extendedAlignmentForward, params, false) :\n                         ExtendAlignmentForward(readSuffix, 0,\n",
+                    "the forward extension")
+    bl = patch_once(bl, "          reverseScore = ExtendAlignmentReverse(readPrefix, readPrefix.length-1,\n",
+                    "          reverseScore = params.useGPU ? ExtendAlignmentGPU(readPrefix, readPrefix.length-1, genomePrefix, "
+                    "genomePrefixLength - 1, extendedAlignmentReverse, params, true) :\n"
+                    "                         ExtendAlignmentReverse(readPrefix, readPrefix.length-1,\n", "the reverse extension")
     bl = patch_once(bl, "  MappingBuffers mappingBuffers;\n  while (true) {\n",
                     "  MappingBuffers mappingBuffers;\n  BlasrHipThreadContext hipThreadContext(params.useGPU, params.gpuDevice);\n"
                     "  while (true) {\n", "MapReads")

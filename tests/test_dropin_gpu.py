@@ -2,7 +2,8 @@
 INTEGRATION.md's patch applied (oracle/make_dropin.py: a scratch copy at build time; oracle/dropin/blasr_hip_dropin.h
 holds the new code) and linked against libblasr_hip.so -- a C++ caller of the C ABI inside the reference's MapRead,
 one context per mapping thread.  With -useGPU -nproc 2 -- MapReadToGenome (both strands, on the device), SDPAlign +
-ComputeAlignmentStats and the refine loop through the library, everything else the reference's own code -- it must
+ComputeAlignmentStats, the two ExtendAlignment calls of -extend and the refine loop through the library, everything else
+the reference's own code -- it must
 print the -m 4 lines the unpatched binary printed for the noisy reads with competing candidates
 (tests/golden/m4_noisy_golden.npz)."""
 import os
@@ -45,6 +46,22 @@ def test_patched_reference_binary_on_the_gpu(tmp_path):
         pytest.skip("oracle/_ref/blasrmc_gpu not built (needs /root/reference at build time)")
     want = write_inputs(str(tmp_path))
     p, got = run(str(tmp_path), ["-useGPU", "-nproc", "2"])
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]
+
+
+@pytest.mark.gpu
+def test_patched_reference_binary_under_extend(tmp_path):
+    """-extend -useGPU: the two ExtendAlignment calls of AlignIntervals (Blasr.cpp:1826, :1885) go through
+    blasr_hip_extend_host as well, the glue around them stays the reference's own; the lines are the unpatched binary's
+    under -extend (tests/golden/m4_noisy_extend_golden.npz)."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/blasrmc_gpu not built (needs /root/reference at build time)")
+    write_inputs(str(tmp_path))
+    want = sorted(bytes(np.load(os.path.join(ROOT, "tests", "golden", "m4_noisy_extend_golden.npz"))["lines"]).decode().splitlines())
+    p, got = run(str(tmp_path), ["-useGPU", "-nproc", "2", "-extend"])
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     assert len(got) == len(want) == 80
     bad = [(a, b) for a, b in zip(got, want) if a != b]
