@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define BLASR_HIP_ABI_VERSION 1
+/* 2: blasr_hip_map_params grew the -extend fields (and blasr_hip_pipeline_params with it); a caller built against
+ * version 1 must be recompiled (compare blasr_hip_abi_version() with the header's value at start-up). */
+#define BLASR_HIP_ABI_VERSION 2
 
 typedef struct blasr_hip_ctx blasr_hip_ctx;
 
