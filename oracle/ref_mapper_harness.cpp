@@ -21,16 +21,23 @@ extern "C" {
 //  0 tAlignedSeqPos 1 tAlignedSeqLength 2 tStrand 3 tIndex 4 tLength 5 qAlignedSeqPos
 //  6 qAlignedSeqLength 7 qPos 8 tPos 9 nBlocks 10 score 11 nMatch 12 nMismatch 13 nIns 14 nDel
 //  15 qLength
-int ref_align_interval(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
-                       unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
-                       unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand, const unsigned *contigStarts,
-                       int nContigs, float approximateMaxInsertionRate, int extendEnds, int sdpTupleSize, int *out,
-                       unsigned char *tSeqOut, int tSeqCap, int *blocksOut, int blocksCap) {
+// extendSwitches: NULL, or {extendAlignments, extendBandSize, maxExtendDropoff} (-extend, Blasr.cpp:1749-1940)
+int ref_align_interval_ex(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
+                          unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
+                          unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand, const unsigned *contigStarts,
+                          int nContigs, float approximateMaxInsertionRate, int extendEnds, int sdpTupleSize,
+                          const int *extendSwitches, int *out, unsigned char *tSeqOut, int tSeqCap, int *blocksOut,
+                          int blocksCap) {
   MappingParameters params;
   params.MakeSane();
   params.approximateMaxInsertionRate = approximateMaxInsertionRate;
   params.extendEnds = extendEnds != 0;
   params.sdpTupleSize = sdpTupleSize;
+  if (extendSwitches != NULL) {
+    params.extendAlignments = extendSwitches[0] != 0;
+    params.extendBandSize = extendSwitches[1];
+    params.maxExtendDropoff = extendSwitches[2];
+  }
 
   T_GenomeSequence genome;
   genome.seq = (Nucleotide *)genomeSeq;
@@ -78,7 +85,9 @@ int ref_align_interval(const unsigned char *genomeSeq, unsigned genomeLen, const
                  contigStarts != NULL, seqdb, alignments, params, params.useScoreCutoff, params.maxScore, buffers, 0);
   T_AlignmentCandidate &a = *alignments[0];
   out[0] = (int)a.tAlignedSeqPos;
-  out[1] = (int)a.tAlignedSeqLength;
+  // (under -extend the field is left at the SDP extent unless the reverse extension was taken, :1770 / :1937: report
+  //  the length of the string itself there)
+  out[1] = extendSwitches != NULL ? (int)a.tAlignedSeq.length : (int)a.tAlignedSeqLength;
   out[2] = a.tStrand;
   out[3] = a.tIndex;
   out[4] = (int)a.tLength;
@@ -113,6 +122,16 @@ int ref_align_interval(const unsigned char *genomeSeq, unsigned genomeLen, const
     seqdb.seqStartPos = NULL;
   }
   return rc;
+}
+
+int ref_align_interval(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
+                       unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
+                       unsigned ivEnd, unsigned ivQStart, unsigned ivQEnd, int strand, const unsigned *contigStarts,
+                       int nContigs, float approximateMaxInsertionRate, int extendEnds, int sdpTupleSize, int *out,
+                       unsigned char *tSeqOut, int tSeqCap, int *blocksOut, int blocksCap) {
+  return ref_align_interval_ex(genomeSeq, genomeLen, readSeq, readLen, subreadStart, subreadEnd, ivStart, ivEnd, ivQStart,
+                               ivQEnd, strand, contigStarts, nContigs, approximateMaxInsertionRate, extendEnds, sdpTupleSize,
+                               NULL, out, tSeqOut, tSeqCap, blocksOut, blocksCap);
 }
 
 // The post filters on n candidates given as parallel arrays.  op: 0 = std::sort with

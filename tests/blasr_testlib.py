@@ -282,18 +282,20 @@ class MapperRef:
     def __init__(self):
         self.lib = C.CDLL(REFMAPPER_SO)
 
-    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11):
+    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11, extend=None):
+        """extend: None, or (extendBandSize, maxExtendDropoff) to run the reference's -extend step as well."""
         genome, read = _u8(genome), _u8(read)
         cs = None if contigs is None else np.ascontiguousarray(contigs, dtype=np.uint32)
         out = np.zeros(16, dtype=np.int32)
         cap = len(genome) + 16
         tseq = np.zeros(cap, dtype=np.uint8)
         blocks = np.zeros(3 * (len(read) + 16), dtype=np.int32)
-        rc = self.lib.ref_align_interval(_p(genome, C.c_ubyte), len(genome), _p(read, C.c_ubyte), len(read),
-                                         int(subread[0]), int(subread[1]), int(iv[0]), int(iv[1]), int(iv[2]),
-                                         int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
-                                         C.c_float(rate), int(extend_ends), int(k), _p(out), _p(tseq, C.c_ubyte), cap,
-                                         _p(blocks), len(read) + 16)
+        sw = None if extend is None else np.array([1, int(extend[0]), int(extend[1])], np.int32)
+        rc = self.lib.ref_align_interval_ex(_p(genome, C.c_ubyte), len(genome), _p(read, C.c_ubyte), len(read),
+                                            int(subread[0]), int(subread[1]), int(iv[0]), int(iv[1]), int(iv[2]),
+                                            int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
+                                            C.c_float(rate), int(extend_ends), int(k), None if sw is None else _p(sw),
+                                            _p(out), _p(tseq, C.c_ubyte), cap, _p(blocks), len(read) + 16)
         assert rc == 0
         win = dict(zip(WINDOW_FIELDS, (int(v) & 0xffffffff for v in out[:7])))
         sdp = dict(qPos=int(out[7]), tPos=int(out[8]), blocks=blocks[: 3 * int(out[9])].reshape(-1, 3).copy(),

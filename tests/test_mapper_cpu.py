@@ -157,3 +157,40 @@ def test_oracle_vs_reference_mapper_live(mo):
                                           p["n_candidates"], p["max_gap"], p["max_score"], p["min_pct"])
             order, oscore = run_oracle_filter(mo, op, c, p)
             assert np.array_equal(order, kept) and np.array_equal(oscore, score), (it, op)
+
+
+def test_extend_step_composition_against_the_reference_align_intervals(mo):
+    """-extend: the checker's composition of the step (blasr_testlib.oracle_extend_candidate: the oracle's ExtendAlignment
+    + index arithmetic) against the reference's OWN AlignIntervals with params.extendAlignments set, one interval at a
+    time: window position and strings, qPos / tPos, every block, the statistics.  Both strands, contigs, windows at the
+    genome / contig ends, several band / drop-off settings."""
+    ref = load_refmapper()
+    if ref is None:
+        pytest.skip("oracle/_ref/libblasr_refmapper.so not built (needs /root/reference)")
+    from blasr_amd import synth
+    from blasr_testlib import ScoreParams, load_oracle, oracle_extend_candidate
+    oracle = load_oracle()
+    rng = np.random.default_rng(91)
+    genome = synth.random_genome(40000, rng)
+    sc = ScoreParams()
+    changed = strands = 0
+    for it in range(60):
+        read, subread, iv, contigs = random_interval_case(rng, genome, it)
+        band, drops = [(10, 10), (4, 3), (15, 25)][it % 3]
+        rwin, rt, rs = ref.align_interval(genome, read, subread, iv, contigs, extend=(band, drops))
+        w, tseq = mo.window(genome, len(read), subread, iv, contigs)
+        q = read[w["qAlignedSeqPos"]: w["qAlignedSeqPos"] + w["qAlignedSeqLength"]]
+        s0 = oracle.sdp_align(q, tseq, sc)
+        w2, q2, t2, s2 = oracle_extend_candidate(oracle, np.asarray(genome), contigs, np.asarray(read), w, q, tseq, s0, sc, band, drops)
+        st = oracle.compute_alignment_stats(q2, t2, s2["qPos"], s2["tPos"], s2["blocks"], sc=sc)
+        for key in ("tAlignedSeqPos", "tStrand", "tIndex", "tLength", "qAlignedSeqPos"):
+            assert w2[key] == rwin[key], (it, key, w2[key], rwin[key])
+        assert (s2["qPos"], s2["tPos"]) == (rs["qPos"], rs["tPos"]), it
+        assert np.array_equal(np.asarray(s2["blocks"]).reshape(-1, 3), rs["blocks"]), it
+        if len(rs["blocks"]):
+            assert np.array_equal(t2, rt), it  # the aligned target string, prefix and suffix pieces included
+            assert (st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]) == (
+                rs["score"], rs["nMatch"], rs["nMismatch"], rs["nIns"], rs["nDel"]), it
+        changed += len(s2["blocks"]) != len(s0["blocks"])
+        strands += int(iv[4])
+    assert changed > 20 and 10 < strands < 50
