@@ -152,6 +152,16 @@ int blasr_hip_create(int device, blasr_hip_ctx **out) {
       blasr_hip_destroy(ctx);
       return BLASR_HIP_ERR_HIP;
     }
+  for (auto &s : ctx->auxStream)
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      blasr_hip_destroy(ctx);
+      return BLASR_HIP_ERR_HIP;
+    }
+  for (auto &e : ctx->auxEvent)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      blasr_hip_destroy(ctx);
+      return BLASR_HIP_ERR_HIP;
+    }
   *out = ctx;
   return BLASR_HIP_OK;
 }
@@ -168,6 +178,13 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     (void)hipStreamDestroy(ctx->sideStream);
   }
   for (auto &e : ctx->events)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &s : ctx->auxStream)
+    if (s) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  for (auto &e : ctx->auxEvent)
     if (e) (void)hipEventDestroy(e);
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);

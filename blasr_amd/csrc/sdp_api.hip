@@ -353,7 +353,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       ARENA_CHECK();
       HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, ck, ckOut, cv, lv.chainList, (size_t)nTasks, 0u, 32u, st));
     }
-    launch_sdp_chain(lv, prm, st);
+    if (getenv("BLASR_HIP_CHAIN_SERIAL")) launch_sdp_chain(lv, prm, st);
+    else launch_sdp_chain(lv, prm, st, ctx->auxStream, ctx->auxEvent);
     tock(2);
     if (getenv("BLASR_HIP_SDP_TRACE") && lv.chainList != nullptr) {  // the sweep's categories and its largest invocations
       int32_t cnt[5] = {0, 0, 0, 0, 0};

@@ -3908,14 +3908,30 @@ void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *va
   (void)hipMemsetAsync(lv.chainCount, 0, 5 * sizeof(int32_t), st);  // one count per category
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
-void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st) {
+void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st, hipStream_t *aux, hipEvent_t *ev) {
   if (lv.n <= 0) return;
   if (lv.chainList != nullptr) {  // the list is sorted by category and size (launch_sdp_chain_list + sort)
     if (lv.colEnt != nullptr) {  // the scattered ones (the device knows how many of each kind: the grids are upper bounds)
-      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
-      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, wave_grid(lv.n), dim3(256), 0, st, lv, p);
-      hipLaunchKernelGGL(sdp_chain_bits4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
-      if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
+      // The categories are disjoint sets of invocations and the long ones are serial chains whose kernels end in a
+      // tail of a few wavefronts: side by side the throughput-bound kernels (chain4, bits4) fill the device under it.
+      const bool fork = aux != nullptr && ev != nullptr;
+      hipStream_t s0 = st, s1 = st, s2 = st;
+      if (fork) {
+        (void)hipEventRecord(ev[0], st);
+        for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+        s0 = aux[0], s1 = aux[1], s2 = aux[2];
+      }
+      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, wave_grid(lv.n), dim3(256), 0, s0, lv, p);
+      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, wave_grid(lv.n), dim3(256), 0, s1, lv, p);
+      hipLaunchKernelGGL(sdp_chain_bits4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, s2, lv, p);
+      if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, wave_grid(lv.n), dim3(256), 0, s2, lv, p);
+      hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+      if (fork)
+        for (int i = 0; i < 3; i++) {
+          (void)hipEventRecord(ev[1 + i], aux[i]);
+          (void)hipStreamWaitEvent(st, ev[1 + i], 0);
+        }
+      return;
     }
     hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
