@@ -21,6 +21,17 @@ extern "C" {
 //  0 tAlignedSeqPos 1 tAlignedSeqLength 2 tStrand 3 tIndex 4 tLength 5 qAlignedSeqPos
 //  6 qAlignedSeqLength 7 qPos 8 tPos 9 nBlocks 10 score 11 nMatch 12 nMismatch 13 nIns 14 nDel
 //  15 qLength
+// The interval's chained anchors for the entry point below (WeightedInterval::matches, what -rbao and -sdpbypass read):
+// n triplets (t, q, l) in the coordinates FindMaxIncreasingInterval leaves them in, or none.  Thread-local: set, call, clear.
+static __thread const unsigned *g_matches = NULL;
+static __thread int g_nMatches = 0;
+static __thread int g_refineBetweenAnchorsOnly = 0;
+void ref_set_interval_matches(const unsigned *tql, int n, int refineBetweenAnchorsOnly) {
+  g_matches = tql;
+  g_nMatches = n;
+  g_refineBetweenAnchorsOnly = refineBetweenAnchorsOnly;
+}
+
 // extendSwitches: NULL, or {extendAlignments, extendBandSize, maxExtendDropoff} (-extend, Blasr.cpp:1749-1940)
 int ref_align_interval_ex(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
                           unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
@@ -76,6 +87,9 @@ int ref_align_interval_ex(const unsigned char *genomeSeq, unsigned genomeLen, co
   iv.qStart = ivQStart;
   iv.qEnd = ivQEnd;
   iv.qLength = readLen;
+  for (int m = 0; m < g_nMatches; m++)
+    iv.matches.push_back(ChainedMatchPos(g_matches[3 * m], g_matches[3 * m + 1], g_matches[3 * m + 2]));
+  if (g_refineBetweenAnchorsOnly) params.refineBetweenAnchorsOnly = true;  // -rbao (Blasr.cpp:1354-1712)
   intervals.insert(iv);
 
   vector<T_AlignmentCandidate *> alignments(1);
