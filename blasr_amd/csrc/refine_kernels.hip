@@ -897,29 +897,30 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
             // by a later step of the same row, bar column cb-1, which travels in cDiag)
             int tNext = (wLo + lane >= 0 && wLo + lane < wTLen) ? (int)wT[wLo + lane] : 'N';
             int2 upNext = make_int2(inf, inf);
-            int sdNext = inf;
             if (wLo <= wPhi + 1) {
               upNext = int2_of(gring[(wLo + lane) & gmask]);
-              sdNext = (int)(uint32_t)gring[(wLo + lane - 1) & gmask];
+              // S of column wLo - 1, the one diagonal neighbour that is nobody's "up": lane 0 carries it into the row
+              if (lane == 0) cDiag = (int)(uint32_t)gring[(wLo - 1) & gmask];
             }
             for (int cb = wLo; cb <= wHi; cb += 64) {
               const int c = cb + lane;
               const bool active = c <= wHi;
               const int tCur = tNext;
               int2 up = upNext;
-              int sd = sdNext;
+              int sd = inf;
               if (cb + 64 <= wHi) {
                 tNext = (c + 64 >= 0 && c + 64 < wTLen) ? (int)wT[c + 64] : 'N';
                 if (cb + 64 <= wPhi + 1) {  // beyond the row above there is nothing to read
                   upNext = int2_of(gring[(c + 64) & gmask]);
-                  sdNext = (int)(uint32_t)gring[(c + 63) & gmask];
                 } else {
                   upNext = make_int2(inf, inf);
-                  sdNext = inf;
                 }
               }
               if (cb <= wPhi + 1) {
-                if (cb > wLo) sd = (lane == 0) ? cDiag : sd;  // column cb-1 is overwritten by the previous step
+                // S of the row above one column to the left = the left neighbour's "up" (column cb - 1: what the
+                // previous step -- or the load above -- left in cDiag; the ring entry itself is overwritten by then)
+                sd = wave_shr1(up.x, inf);
+                sd = (lane == 0) ? __builtin_amdgcn_readfirstlane(cDiag) : sd;
                 cDiag = __builtin_amdgcn_readlane(up.x, 63);
                 const bool upValid = c <= wPhi, diagValid = (c - 1 <= wPhi) && (c > wPlo);
                 up.x = upValid ? up.x : inf;
