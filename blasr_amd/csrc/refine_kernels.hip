@@ -894,28 +894,24 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
             carry.a = carry.b = carry.s = inf;
             int cDiag = 0;
             // the target bases and the row above run one step ahead of their use (nothing a step stores is read
-            // by a later step of the same row, bar column cb-1, which travels in cDiag)
-            int tNext = (wLo + lane >= 0 && wLo + lane < wTLen) ? (int)wT[wLo + lane] : 'N';
-            int2 upNext = make_int2(inf, inf);
-            if (wLo <= wPhi + 1) {
-              upNext = int2_of(gring[(wLo + lane) & gmask]);
-              // S of column wLo - 1, the one diagonal neighbour that is nobody's "up": lane 0 carries it into the row
-              if (lane == 0) cDiag = (int)(uint32_t)gring[(wLo - 1) & gmask];
-            }
-            for (int cb = wLo; cb <= wHi; cb += 64) {
+            // by a later step of the same row, bar column cb-1, which travels in cDiag).  Two steps per trip with two
+            // sets of registers taking turns: with ONE set the copy "current = next" at the end of a step made the
+            // compiler wait there for the loads the step had just issued (s_waitcnt vmcnt(0) in every step).
+            // The loads of the step after are issued UNCONDITIONALLY (clamped target index, any ring slot is memory of
+            // the ring) and what they returned is judged when it is used: with loads behind branches the compiler cannot
+            // count what is in flight and waits for everything (vmcnt(0)) right after issuing the prefetch.
+            const int tLast = max(wTLen - 1, 0);
+            int tA = (int)wT[min(max(wLo + lane, 0), tLast)], tB = 'N';
+            int2 upA = int2_of(gring[(wLo + lane) & gmask]), upB = make_int2(inf, inf);
+            // S of column wLo - 1, the one diagonal neighbour that is nobody's "up": lane 0 carries it into the row
+            if (wLo <= wPhi + 1 && lane == 0) cDiag = (int)(uint32_t)gring[(wLo - 1) & gmask];
+            auto wideStep = [&](const int cb, const int tRaw, int2 up, int &tNext, int2 &upNext) {
               const int c = cb + lane;
               const bool active = c <= wHi;
-              const int tCur = tNext;
-              int2 up = upNext;
               int sd = inf;
-              if (cb + 64 <= wHi) {
-                tNext = (c + 64 >= 0 && c + 64 < wTLen) ? (int)wT[c + 64] : 'N';
-                if (cb + 64 <= wPhi + 1) {  // beyond the row above there is nothing to read
-                  upNext = int2_of(gring[(c + 64) & gmask]);
-                } else {
-                  upNext = make_int2(inf, inf);
-                }
-              }
+              tNext = (int)wT[min(max(c + 64, 0), tLast)];
+              upNext = int2_of(gring[(c + 64) & gmask]);
+              const int tCur = (c >= 0 && c < wTLen) ? tRaw : 'N';
               if (cb <= wPhi + 1) {
                 // S of the row above one column to the left = the left neighbour's "up" (column cb - 1: what the
                 // previous step -- or the load above -- left in cDiag; the ring entry itself is overwritten by then)
@@ -926,6 +922,8 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
                 up.x = upValid ? up.x : inf;
                 up.y = upValid ? up.y : inf;
                 sd = diagValid ? sd : inf;
+              } else {  // beyond the row above there is nothing: whatever the ring slot held is not it
+                up = make_int2(inf, inf);
               }
               const int mm = wQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur & 255], (wQc & 3) * 8, 8)
                                      : matN[base_code((unsigned)tCur)];
@@ -935,6 +933,10 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
                 if (c >= keepLo && c <= keepHi) gring[c & gmask] = pair_of(make_int2(sv, iv));
                 wArrows[c - wLo] = (uint8_t)arrow;
               }
+            };
+            for (int cb = wLo; cb <= wHi; cb += 128) {
+              wideStep(cb, tA, upA, tB, upB);
+              if (cb + 64 <= wHi) wideStep(cb + 64, tB, upB, tA, upA);
             }
             // (this row's stores are read by the next row only: one wait for all of them)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
