@@ -1208,8 +1208,14 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
       W[j] = (alive && rTop - j >= 1) ? load_window(arrows + (unsigned)RT[j].x + (unsigned)(CB[j] - RT[j].y))
                                       : make_uint4(0, 0, 0, 0);
     }
+    // (the choice is made on the ADDRESS, the load itself is unconditional: "cond ? load : 0" put each of the eight
+    //  loads behind a branch with a wait for everything in flight at its end -- eight round trips in a row per batch,
+    //  where these records are not needed before the next batch.  A record of a row that does not exist is not used.)
 #pragma unroll
-    for (int j = 0; j < 8; j++) RTn[j] = (alive && rTop - 8 - j >= 1) ? rowTab[rTop - 8 - j] : make_int2(0, 0);
+    for (int j = 0; j < 8; j++) {
+      const int2 *rec = (alive && rTop - 8 - j >= 1) ? rowTab + (rTop - 8 - j) : reinterpret_cast<const int2 *>(args.geo);
+      RTn[j] = *rec;
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int r = rTop - j;
