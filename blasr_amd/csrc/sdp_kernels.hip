@@ -369,9 +369,16 @@ __device__ __forceinline__ void stage16(const uint8_t *s, int len, int p0, const
   uint32_t w[4] = {0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};  // 'N'
   if (p0 + 16 <= len) {
     __builtin_memcpy(w, s + p0, 16);
-  } else {
+  } else if (p0 < len) {
+    // the last, partial chunk: sixteen UNCONDITIONAL byte loads (index clamped to the last base) and one wait -- as
+    // "if (p0 + i < len) load" every load sat behind a branch and the compiler waited for each in turn, sixteen round
+    // trips with the rest of the workgroup at the barrier behind it, once per packed sequence
+    uint32_t b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) b[i] = (uint32_t)s[min(p0 + i, len - 1)];
+#pragma unroll
     for (int i = 0; i < 16; i++)
-      if (p0 + i < len) w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)s[p0 + i] << (8 * (i & 3)));
+      if (p0 + i < len) w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (b[i] << (8 * (i & 3)));
   }
   codes = 0;
   bad = 0;
