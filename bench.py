@@ -39,20 +39,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# PMC figures of the dominant kernel, measured with separate rocprofv3 --pmc passes (profiles/): keyed by the
-# workload they were taken on and tagged with the library build they belong to; reported only when both match.
-PMC = {
-    # (config, reads, read_len, band): HBM bytes per launch of the roofline kernel = (FETCH_SIZE + WRITE_SIZE) x the
-    # unit and gfx950 corrections of tools/pmc_summary.py, separate rocprofv3 --pmc passes (tools/pmc_config1.sh).
-    # configs[2]: rocprofv3 --pmc dies inside torch's generator on this image, so tools/pmc_config2.sh profiles a run that
-    # LOADS the inputs an unprofiled run wrote (--save-workload / --load-workload): same workload, same build.
-    (2, 100000, 10000, 16): {"traffic": 54889864352.0,
-                             "note": "profiles/r02_v4_pmc_counters_configs2_100k_reads.json, fillp_kernel<16, true, false>, "
-                                     "one launch of the same workload and build: 1.13 x the algorithmic bytes"},
-    (1, 100000, 10000, 16): {"traffic": 42178089536.0,
-                             "note": "profiles/r02_v3_pmc_counters_configs1_100k_reads.json, fillp_kernel<16, true, false>, "
-                                     "one launch of the same workload and build: 1.13 x the algorithmic bytes"},
-}
+# PMC figures (HBM bytes, VALU instructions per launch) come from rocprofv3 --pmc passes kept under profiles/
+# (tools/pmc_config.sh -> tools/pmc_summary.py): a file is used only when it was taken on the SAME workload and with the
+# SAME build of the library (blasr_hip_build_id(): a hash over the library's sources), else `traffic` is null.
+def pmc_for(config, reads, read_len, band, build):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except ValueError:
+            continue
+        w = d.get("workload") or {}
+        if d.get("build_id") == build and (w.get("config"), w.get("reads"), w.get("read_len"), w.get("band")) == (
+                config, reads, read_len, band):
+            return os.path.relpath(path, ROOT), d.get("kernels", {})
+    return None, {}
+
+
+# Issue cost of one wave64 VALU instruction on the MI355X (tools/valu_rate.hip, profiles/r02_valu_rate.txt, 8 waves per
+# SIMD): 4.1-4.4 cycles for min / max / min3 / compare / cndmask / shift / DPP forms, 2.3-2.9 for add / sub / and / or /
+# xor / mov.  The fill kernels' hot loops are ~60 % of the first kind (ISA of fillp_kernel: 80 of 135 per 4-row step).
+VALU_CYCLES = {"slow": 4.15, "fast": 2.4, "slow_share": 0.6}
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def parse_args(argv=None):
@@ -71,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (0 = min(8, cores))")
     ap.add_argument("--blasrmc-reads", type=int, default=-1,
                     help="reads mapped by the reference binary (oracle/_ref/blasrmc) as a second baseline (0 = skip)")
+    ap.add_argument("--workspace-gb", type=float, default=200.0,
+                    help="limit of the context's grow-only device workspace (blasr_hip_set_workspace_limit)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--share-gpus", action="store_true",
                     help="let the ranks share the GPUs that exist (rank r on device r mod devices, gloo for the counters): "
@@ -87,7 +97,7 @@ def parse_args(argv=None):
                     help="write the generated inputs (genome, reads, intervals) to PATH and go on")
     ap.add_argument("--load-workload", default="", metavar="PATH",
                     help="read the inputs a --save-workload run wrote instead of generating them (rocprofv3 --pmc dies "
-                         "inside torch's generator on this image: tools/pmc_config2.sh profiles a loaded workload)")
+                         "inside torch's generator on this image: tools/pmc_config.sh profiles a loaded workload)")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -212,27 +222,41 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, exte
                 parity_checked=n_reads, parity_mismatches=int(mismatches))
 
 
-def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False):
-    """The reference BINARY (oracle/_ref/blasrmc -nproc N -m 4 -bestn 1) on a FASTA dump of the first `n_reads`
-    reads against a FASTA of their own loci (+- 5 kb, one contig each: the 3-Gbase genome has no suffix array the
-    binary could load, and building one is out of a benchmark's reach), wall time less a zero-read run: whole BLASR
-    -- anchoring, intervals, the path, mapQV, printing -- per read."""
+def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False, device_index=0):
+    """The reference BINARY (oracle/_ref/blasrmc -nproc N -m 4 -bestn 1 -sa ...) on a FASTA dump of the first `n_reads`
+    reads against a FASTA of their own loci (+- 5 kb, one contig each: the 3-Gbase genome's index is 12.4 GB on disk and
+    the binary needs minutes to load it), wall time less a zero-read run: whole BLASR -- anchoring, intervals, the path,
+    mapQV, printing -- per read.  The loci genome's suffix array is written beforehand (this library's device builder,
+    byte-identical to sawriter's file: tests/test_sa_build_gpu.py) so that neither run builds it in-process."""
     import tempfile
 
     import numpy as np
     exe = os.path.join(ROOT, "oracle", "_ref", "blasrmc")
     if not os.path.exists(exe) or n_reads <= 0:
         return None
+    import blasr_amd
+    from blasr_amd import hip
     pos, strand = wl["origin"]
     pos = pos[:n_reads].cpu().numpy()
     G = int(genome_t.numel())
     reads = wl["reads"][:n_reads]
     pool = wl["pool"][: int(reads["off"][-1] + reads["length"][-1])].cpu().numpy()
     with tempfile.TemporaryDirectory() as tmp:
+        parts, starts = [], [0]
         with open(os.path.join(tmp, "genome.fasta"), "w") as f:
             for r in range(n_reads):
                 a, b = max(0, int(pos[r]) - 5000), min(G, int(pos[r]) + read_len + 5000)
-                f.write(">locus%d\n%s\n" % (r, bytes(genome_t[a:b].cpu().numpy()).decode()))
+                locus = genome_t[a:b].cpu().numpy()
+                f.write(">locus%d\n%s\n" % (r, bytes(locus).decode()))
+                parts += [locus, np.array([ord("N")], np.uint8)]
+                starts.append(starts[-1] + len(locus) + 1)
+        t0 = time.perf_counter()
+        c2 = blasr_amd.Context(device_index)  # a context of its own: the bench's holds the big genome
+        c2.upload_genome(np.concatenate(parts), np.array(starts, dtype=np.uint32))
+        hip.write_suffix_array(os.path.join(tmp, "genome.fasta.sa"), c2.build_suffix_array(13))
+        c2.close()
+        t_index = time.perf_counter() - t0
+        del parts
         with open(os.path.join(tmp, "reads.fasta"), "w") as f:
             for r in range(n_reads):
                 s = pool[int(reads["off"][r]): int(reads["off"][r]) + int(reads["length"][r])]
@@ -241,7 +265,8 @@ def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False):
         wall = {}
         for tag, fa in (("none", "none.fasta"), ("reads", "reads.fasta")):
             t0 = time.perf_counter()
-            p = subprocess.run([exe, os.path.join(tmp, fa), os.path.join(tmp, "genome.fasta"), "-m", "4", "-bestn", "1",
+            p = subprocess.run([exe, os.path.join(tmp, fa), os.path.join(tmp, "genome.fasta"), "-sa",
+                                os.path.join(tmp, "genome.fasta.sa"), "-m", "4", "-bestn", "1",
                                 "-nproc", str(cores), "-out", os.path.join(tmp, tag + ".m4")] + (["-extend"] if extend else []),
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
             wall[tag] = time.perf_counter() - t0
@@ -249,13 +274,14 @@ def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False):
                 return dict(error="blasrmc exit %d" % p.returncode)
         lines = open(os.path.join(tmp, "reads.m4")).read().splitlines()
     dt = max(wall["reads"] - wall["none"], 1e-9)
-    names = set(x.split()[0] for x in lines)
-    aligned = sum(int(reads["length"][r]) for r in range(n_reads) if any(n.startswith("read%d/" % r) for n in names))
-    return dict(value=aligned / dt, unit="bases/s", cores=cores, kind="reference binary",
-                sample="oracle/_ref/blasrmc -nproc %d -m 4 -bestn 1 on the first %d reads against a FASTA of their own "
-                       "loci (+-5 kb): %.1f s wall less %.1f s of a zero-read run (suffix array built in-process), "
-                       "%d reads reported; whole BLASR incl. anchoring, not only the path"
-                       % (cores, n_reads, wall["reads"], wall["none"], len(names)))
+    names = set(int(x.split("/", 1)[0][4:]) for x in lines)
+    aligned = sum(int(reads["length"][r]) for r in names)
+    return dict(value=aligned / dt, unit="bases/s", cores=cores, kind="reference binary", reads_per_s=n_reads / dt,
+                signal_s=dt,
+                sample="oracle/_ref/blasrmc -nproc %d -m 4 -bestn 1 -sa on the first %d reads against a FASTA of their own "
+                       "loci (+-5 kb; %d bases, its suffix array written beforehand in %.1f s): %.1f s wall less %.1f s of "
+                       "a zero-read run (index load), %d reads reported; whole BLASR incl. anchoring, not only the path"
+                       % (cores, n_reads, starts[-1], t_index, wall["reads"], wall["none"], len(names)))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -421,7 +447,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     ctx = blasr_amd.Context(device_index)
-    ctx.set_workspace_limit((200 << 30) // (1 if not shared else -(-world // n_dev)))
+    ctx.set_workspace_limit(int(args.workspace_gb * (1 << 30)) // (1 if not shared else -(-world // n_dev)))
     ctx.adopt_genome_device(genome.data_ptr(), G, starts.astype(np.uint32) if len(starts) > 2 else None)
     if args.from_reads > 0 and world == 1:
         # the index of the genome, built on the device while the 32 B per base it takes to build are still free
@@ -434,6 +460,7 @@ def main():
     hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     acc = {}
+    kacc = {}  # the refine stage's heavy kernels, each on its own (blasr_hip_refine_last_kernels), summed over the steps
 
     def step():
         ctx.map_reads_device(n_reads, reads_t.data_ptr(), wl["pool"].data_ptr(), n_iv, iv_t.data_ptr(), params, hits, hit_off)
@@ -444,6 +471,10 @@ def main():
         t.update(fill4_ms=f4["ms"], fill4_launches=f4["launches"], fill4_bytes=f4["bytes"], fill4_cells=f4["cells"])
         for k, v in t.items():
             acc[k] = acc.get(k, 0) + v
+        for kr in ctx.last_kernels():
+            a = kacc.setdefault(kr["name"], dict(ms=0.0, launches=0, bytes=0, cells=0, candidates=0))
+            for f in a:
+                a[f] += kr[f]
         return t
 
     def barrier():
@@ -454,6 +485,7 @@ def main():
     for _ in range(args.warmup):
         step()
     acc.clear()
+    kacc.clear()
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -469,8 +501,6 @@ def main():
     if rank == 0:
         K = args.steps
         value = totals["aligned_bases"] * K / elapsed
-        f4_ms, f4_launches = acc["fill4_ms"], max(acc["fill4_launches"], 1)
-        achieved = acc["fill4_bytes"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0
 
         def gbps(nbytes, ms):
             return nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
@@ -508,17 +538,10 @@ def main():
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
-            # the dominant kernel: fillp_kernel<16, true> (four candidates per wavefront), timed on its own with HIP
-            # events on the library's stream; its algorithmic bytes = 1 B per band cell + the bases + 8 B per row
-            # record of the candidates it processed.  The kernel is bound by VALU issue, not by HBM
-            # (profiles/r02_valu_rate.txt): the HBM fraction is what the contract asks for.
-            "roofline": {"bound": "hbm", "kernel": "blasr_hip::fillp_kernel<16, true>", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "algorithmic_bytes_per_launch": acc["fill4_bytes"] / f4_launches,
-                         "launches_per_step": f4_launches / K, "avg_launch_ms": f4_ms / f4_launches,
-                         "kernel_gcups": acc["fill4_cells"] / (f4_ms / 1e3) / 1e9 if f4_ms > 0 else 0.0,
-                         "limiter": "VALU issue (integer min / compare / DPP issue at 4 cycles per wave64 instruction)",
-                         "fill_stage_gcups": acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0},
+            # the dominant kernel of the step = the refine kernel with the largest HIP-event time (filled in below from
+            # blasr_hip_refine_last_kernels: every heavy refine kernel timed on its own, on the stream it ran on, with the
+            # algorithmic bytes of exactly the candidates it processed); the others follow in refine_rooflines
+            "roofline": None, "refine_rooflines": None,
             # the SDP phases against the same roof: algorithmic bytes by SURVEY.md 8(d)'s model over HIP-event time
             "sdp_rooflines": {
                 name: {"bound": "hbm", "achieved": gbps(acc[b], acc[m]), "peak": 8000.0, "unit": "GB/s",
@@ -532,20 +555,55 @@ def main():
             out["physical_gpus"] = n_dev
             out["note"] = ("%d ranks SHARE %d GPU%s (--share-gpus, counters over gloo): a run of the multi-rank path, "
                            "not a scaling measurement" % (world, n_dev, "" if n_dev == 1 else "s"))
-        pmc = PMC.get((args.config, n_reads, d["read_len"], args.band))
-        if pmc:
-            out["roofline"]["traffic"] = pmc["traffic"]
-            out["roofline"]["traffic_note"] = pmc["note"]
+        build = hip.build_id()
+        out["build_id"] = build
+        pmc_path, pmc = pmc_for(args.config, n_reads, d["read_len"], args.band, build)
+        cyc = VALU_CYCLES["slow"] * VALU_CYCLES["slow_share"] + VALU_CYCLES["fast"] * (1 - VALU_CYCLES["slow_share"])
+        lines = []
+        for name, a in kacc.items():
+            if a["ms"] <= 0 or a["launches"] <= 0:
+                continue
+            per_launch_ms = a["ms"] / a["launches"]
+            ach = gbps(a["bytes"], a["ms"])
+            rl = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                  "traffic": None, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                  "launches_per_step": a["launches"] / K, "avg_launch_ms": per_launch_ms,
+                  "candidates_per_launch": a["candidates"] / a["launches"],
+                  "kernel_gcups": a["cells"] / (a["ms"] / 1e3) / 1e9}
+            p = pmc.get(name)
+            if p:  # same workload, same build: HBM bytes and VALU instructions per launch from the counters
+                if p.get("hbm_bytes_per_dispatch") is not None:
+                    rl["traffic"] = p["hbm_bytes_per_dispatch"]
+                    rl["traffic_over_algorithmic"] = p["hbm_bytes_per_dispatch"] / max(rl["algorithmic_bytes_per_launch"], 1)
+                if p.get("SQ_INSTS_VALU"):
+                    insts = p["SQ_INSTS_VALU"] / max(p.get("dispatches", 1), 1)
+                    # the roof that binds the fills: wave64 VALU instructions x their measured issue cost over the SIMD
+                    # cycles of the launch (1024 SIMDs x 2.4 GHz x the HIP-event time of this run)
+                    rl["valu_issue_frac"] = insts * cyc / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3)
+                    rl["valu_issue_frac_range"] = [insts * VALU_CYCLES["fast"] / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3),
+                                                   insts * VALU_CYCLES["slow"] / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3)]
+                    rl["valu_wave_instructions_per_launch"] = insts
+                rl["pmc_profile"] = pmc_path
+            lines.append(rl)
+        lines.sort(key=lambda r: -r["avg_launch_ms"] * r["launches_per_step"])
+        if lines:
+            out["roofline"] = dict(lines[0])
+            out["roofline"]["limiter"] = ("VALU issue (integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
+                                          "instruction, profiles/r02_valu_rate.txt): valu_issue_frac is the roof that binds, "
+                                          "the HBM fraction is what the contract asks for")
+            out["roofline"]["fill_stage_gcups"] = acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0
+            out["refine_rooflines"] = lines[1:]
         if world == 1:
             cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
             ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, int(2400 * 10000 / d["read_len"]) // max(1, round(n_iv / n_reads)))
             ns = min(ns, n_reads)
             if ns > 0:
                 out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores, args.extend)
-            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 10000000 // d["read_len"]))
+            # >= 10 s of signal: 32 threads of the reference binary map ~7 M bases/s of these reads
+            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 80000000 // d["read_len"]))
             if nb > 0:
                 ncores = os.cpu_count() or 1
-                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores), args.extend)
+                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores), args.extend, device_index)
                 if b is not None:
                     out["cpu_baseline_whole_blasr"] = b
             if args.from_reads > 0:

@@ -237,6 +237,36 @@ int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *la
   return BLASR_HIP_OK;
 }
 
+int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_record *out, int capacity) {
+  if (!ctx || (!out && capacity > 0) || capacity < 0) return BLASR_HIP_ERR_INVALID;
+  int n = 0;
+  for (int k = 0; k < BLASR_HIP_KERNEL_KINDS; k++) {
+    if (ctx->kernelRec[k].launches <= 0) continue;
+    if (n < capacity) out[n] = ctx->kernelRec[k];
+    n++;
+  }
+  return n;
+}
+
+const char *blasr_hip_kernel_name(int kind, int ext0) {
+  switch (kind) {
+    case BLASR_HIP_KERNEL_FILL_NARROW:
+      return ext0 ? "blasr_hip::fillp_kernel<16, true, false>" : "blasr_hip::fillp_kernel<16, false, false>";
+    case BLASR_HIP_KERNEL_FILL_HYBRID:
+      return ext0 ? "blasr_hip::fillp_kernel<16, true, true>" : "blasr_hip::fillp_kernel<16, false, true>";
+    case BLASR_HIP_KERNEL_FILL_WAVE:
+      return "blasr_hip::fill_kernel";
+    case BLASR_HIP_KERNEL_TRACEBACK:
+      return "blasr_hip::traceback_kernel";
+  }
+  return "";
+}
+
+#ifndef BLASR_HIP_BUILD_ID
+#define BLASR_HIP_BUILD_ID "unknown"
+#endif
+const char *blasr_hip_build_id(void) { return BLASR_HIP_BUILD_ID; }
+
 int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) ms[i] = ctx->ms[i];
@@ -293,6 +323,19 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   if (rc) return rc;
 
   hipEvent_t *ev = ctx->events, *evF4 = ctx->events + 8;  // the context's own: nothing to release on an error path
+  hipEvent_t *evHy = ctx->events + 10, *evTb = ctx->events + 12, *evF1 = ctx->events + 14;
+  for (int k = 0; k < BLASR_HIP_KERNEL_KINDS; k++) {
+    ctx->kernelRec[k] = blasr_hip_kernel_record();
+    ctx->kernelRec[k].kind = k;
+    ctx->kernelRec[k].ext0 = score->affine_extend == 0;
+  }
+  // what a kernel's launch accounts for: the candidates it processed (algorithmic bytes as DESIGN.md 2.3 / 2.4 count them)
+  auto count_fill = [&](int kind, const TaskGeometry &g) {
+    blasr_hip_kernel_record &r = ctx->kernelRec[kind];
+    r.algorithmic_bytes += g.cells + (int64_t)g.rows + g.tSpan + 8 * (int64_t)g.rows;
+    r.cells += g.cells;
+    r.candidates += 1;
+  };
   auto destroyEvents = [&]() {};
   int64_t fill4Bytes = 0, fill4Cells = 0;
   ctx->fill4Ms = 0;
@@ -508,7 +551,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     launch_geometry_rows(view, band, c.first, c.count, dGeo, fa.rowTab, dRowOff, reinterpret_cast<unsigned short *>(pMeta), st);
     // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes on the side
     // stream, underneath fill_kernel's launch (after fillp_kernel when that runs, so its launch is timed alone).
-    bool wideLaunched = false, timedFill4 = false;
+    bool wideLaunched = false, timedFill4 = false, timedWide = false, timedFill1 = false;
     auto launch_wide = [&]() -> int {
       if (c.wideTasks.empty()) return 0;
       int nw = (int)c.wideTasks.size();
@@ -541,21 +584,45 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       FillArgs fw = fa;
       fw.count = nw;
       if (hybrid) fw.taskList = dWideTasks;
+      if (hybrid && getenv("BLASR_HIP_REFINE_TRACE")) {  // where the hybrid kernel's cells are, by row width
+        unsigned long long *dHist = nullptr, hHist[40];
+        HIP_TRY(ctx, hipMalloc((void **)&dHist, sizeof(hHist)));
+        HIP_TRY(ctx, hipMemsetAsync(dHist, 0, sizeof(hHist), st));
+        launch_row_hist(view, fw, dHist, st);
+        HIP_TRY(ctx, hipMemcpyAsync(hHist, dHist, sizeof(hHist), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        (void)hipFree(dHist);
+        const int edges[] = {48, 96, 112, 192, 384, 576, 1024, 2048, 4096, 1 << 30};
+        for (int b = 0; b < 10; b++)
+          if (hHist[4 * b])
+            fprintf(stderr, "[refine] hybrid list, rows of <= %d cells: %llu rows, %llu cells, %llu below a wide row, %llu steps of 192\n",
+                    edges[b], hHist[4 * b], hHist[4 * b + 1], hHist[4 * b + 2], hHist[4 * b + 3]);
+      }
+      const int wideKind = hybrid ? BLASR_HIP_KERNEL_FILL_HYBRID : BLASR_HIP_KERNEL_FILL_WAVE;
+      for (int32_t t : c.wideTasks)
+        if (t >= 0) count_fill(wideKind, geo[t]);
+      ctx->kernelRec[wideKind].launches += 1;
       if (getenv("BLASR_HIP_FILL_SERIAL")) {  // measurement: every fill kernel alone on the main stream
+        HIP_TRY(ctx, hipEventRecord(evHy[0], st));
         if (hybrid)
           launch_fill_hybrid(view, fw, st);
         else
           launch_fill(view, fw, true, fast, st);
+        HIP_TRY(ctx, hipEventRecord(evHy[1], st));
+        timedWide = true;
         return 0;
       }
       HIP_TRY(ctx, hipEventRecord(ev[7], st));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));  // the uploads and everything before them
+      HIP_TRY(ctx, hipEventRecord(evHy[0], ctx->sideStream));
       if (hybrid)
         launch_fill_hybrid(view, fw, ctx->sideStream);
       else
         launch_fill(view, fw, true, fast, ctx->sideStream);
+      HIP_TRY(ctx, hipEventRecord(evHy[1], ctx->sideStream));
       HIP_TRY(ctx, hipEventRecord(ev[6], ctx->sideStream));
       wideLaunched = true;
+      timedWide = true;
       return 0;
     };
     if (!packed) {
@@ -597,8 +664,10 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         for (int32_t i : list4) {
           fill4Bytes += geo[i].cells + (int64_t)geo[i].rows + geo[i].tSpan + 8 * (int64_t)geo[i].rows;
           fill4Cells += geo[i].cells;
+          count_fill(BLASR_HIP_KERNEL_FILL_NARROW, geo[i]);
         }
         ctx->fill4Launches += 1;
+        ctx->kernelRec[BLASR_HIP_KERNEL_FILL_NARROW].launches += 1;
       }
       rc = launch_wide();
       if (rc) return rc;
@@ -611,16 +680,28 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         FillArgs f1 = fa;
         f1.taskList = dList1;
         f1.count = (int)list1.size();
+        HIP_TRY(ctx, hipEventRecord(evF1[0], st));
         launch_fill(view, f1, false, fast, st);
+        HIP_TRY(ctx, hipEventRecord(evF1[1], st));
+        timedFill1 = true;
+        for (int32_t i : list1) count_fill(BLASR_HIP_KERNEL_FILL_WAVE, geo[i]);
+        ctx->kernelRec[BLASR_HIP_KERNEL_FILL_WAVE].launches += 1;
       }
       HIP_TRY(ctx, hipStreamSynchronize(st));  // the host lists go out of scope
       if (timedFill4) {
         float t4 = 0;
         (void)hipEventElapsedTime(&t4, evF4[0], evF4[1]);
         ctx->fill4Ms += t4;
+        ctx->kernelRec[BLASR_HIP_KERNEL_FILL_NARROW].ms += t4;
       }
     } else {
+      HIP_TRY(ctx, hipEventRecord(evF1[0], st));
       launch_fill(view, fa, false, fast, st);
+      HIP_TRY(ctx, hipEventRecord(evF1[1], st));
+      timedFill1 = true;
+      for (int i = c.first; i < c.first + c.count; i++)
+        if (geo[i].status == 0 && geo[i].maxWidth <= kLdsMaxWidth) count_fill(BLASR_HIP_KERNEL_FILL_WAVE, geo[i]);
+      ctx->kernelRec[BLASR_HIP_KERNEL_FILL_WAVE].launches += 1;
     }
     if (wideLaunched) HIP_TRY(ctx, hipStreamWaitEvent(st, ev[6], 0));  // join the side stream
     HIP_TRY(ctx, hipEventRecord(ev[3], st));
@@ -643,8 +724,17 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     ta.arenaOff = dArenaOff;
     ta.opsStart = dOpsStart;
     ta.results = dResults;
-    launch_traceback(view, ta, st);
+    HIP_TRY(ctx, hipEventRecord(evTb[0], st));
+    launch_traceback(view, ta, st, evTb[1]);
     HIP_TRY(ctx, hipEventRecord(ev[4], st));
+    for (int i = c.first; i < c.first + c.count; i++)
+      if (geo[i].status == 0) {
+        blasr_hip_kernel_record &r = ctx->kernelRec[BLASR_HIP_KERNEL_TRACEBACK];
+        r.algorithmic_bytes += 24 * (int64_t)geo[i].rows;
+        r.cells += geo[i].cells;
+        r.candidates += 1;
+      }
+    ctx->kernelRec[BLASR_HIP_KERNEL_TRACEBACK].launches += 1;
     launch_scan_ops(dResults, c.first, c.count, opsCapacity, dTotal, st);
     launch_compact_ops(dResults, c.first, c.count, ta.arena, dArenaOff, dOpsStart, ops, st);
     HIP_TRY(ctx, hipEventRecord(ev[5], st));
@@ -658,6 +748,16 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     msTrace += t;
     (void)hipEventElapsedTime(&t, ev[4], ev[5]);
     msCompact += t;
+    (void)hipEventElapsedTime(&t, evTb[0], evTb[1]);
+    ctx->kernelRec[BLASR_HIP_KERNEL_TRACEBACK].ms += t;
+    if (timedWide) {
+      (void)hipEventElapsedTime(&t, evHy[0], evHy[1]);
+      ctx->kernelRec[hybrid ? BLASR_HIP_KERNEL_FILL_HYBRID : BLASR_HIP_KERNEL_FILL_WAVE].ms += t;
+    }
+    if (timedFill1) {
+      (void)hipEventElapsedTime(&t, evF1[0], evF1[1]);
+      ctx->kernelRec[BLASR_HIP_KERNEL_FILL_WAVE].ms += t;
+    }
     ctx->counters[2] += 1;
   }
   int64_t total = 0;

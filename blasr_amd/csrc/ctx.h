@@ -24,7 +24,7 @@ struct blasr_hip_ctx {
   enum { kAuxStreams = 3 };
   hipStream_t auxStream[kAuxStreams] = {nullptr, nullptr, nullptr};
   hipEvent_t auxEvent[kAuxStreams + 1] = {nullptr, nullptr, nullptr, nullptr};  // [0] fork, [1..] joins
-  hipEvent_t events[12] = {};        // timing / cross-stream events of the refine call, created with the context
+  hipEvent_t events[16] = {};        // timing / cross-stream events of the refine call, created with the context
   char *workspace = nullptr;
   size_t workspaceBytes = 0;
   int64_t workspaceLimit = 48ll << 30;
@@ -34,6 +34,8 @@ struct blasr_hip_ctx {
   // the dominant kernel of the refine stage on its own: fillp_kernel launches of the last call
   float fill4Ms = 0;
   int64_t fill4Launches = 0, fill4Bytes = 0, fill4Cells = 0;
+  // every heavy kernel of the refine stage on its own (blasr_hip_refine_last_kernels), indexed by BLASR_HIP_KERNEL_*
+  blasr_hip_kernel_record kernelRec[BLASR_HIP_KERNEL_KINDS] = {};
   float sdpMs[4] = {0, 0, 0, 0};
   int64_t sdpCounters[3] = {0, 0, 0};
   int64_t sdpBytes[4] = {0, 0, 0, 0};

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
@@ -167,7 +168,11 @@ int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   std::vector<char> buf;
-  if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  try {
+    if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  } catch (const std::bad_alloc &) {
+    return BLASR_HIP_ERR_NOMEM;
+  }
   size_t at = 0;
   auto take = [&](void *dst, size_t bytes) {
     if (at + bytes > buf.size()) return false;
@@ -179,25 +184,36 @@ int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) {
   int32_t comp[2] = {0, 0};
   if (!take(&magic, 4) || magic != 0xacac0001u) return BLASR_HIP_ERR_UNSUPPORTED;  // (files without the magic number: not read)
   if (!take(comp, 8)) return BLASR_HIP_ERR_INVALID;
-  blasr_hip_sa *sa = new blasr_hip_sa();
-  sa->hasArray = comp[0];
-  sa->hasLookup = comp[1];
+  // sizes come from the header: check them against what the file holds BEFORE anything is allocated (a truncated or
+  // corrupt file would otherwise ask for up to 16 GB), and keep std::bad_alloc inside the C boundary
+  blasr_hip_sa *sa = nullptr;
   bool ok = true;
-  if (comp[0]) {
-    uint32_t len = 0;
-    ok = take(&len, 4);
-    if (ok) {
-      sa->index.resize(len);
-      ok = take(sa->index.data(), 4ull * len);
+  try {
+    sa = new blasr_hip_sa();
+    sa->hasArray = comp[0];
+    sa->hasLookup = comp[1];
+    if (comp[0]) {
+      uint32_t len = 0;
+      ok = take(&len, 4) && at + 4ull * len <= buf.size();
+      if (ok) {
+        sa->index.resize(len);
+        ok = take(sa->index.data(), 4ull * len);
+      }
     }
-  }
-  if (ok && comp[1]) {
-    ok = take(&sa->lookupTableLength, 4) && take(&sa->lookupPrefixLength, 4);
-    if (ok) {
-      sa->startPos.resize(sa->lookupTableLength);
-      sa->endPos.resize(sa->lookupTableLength);
-      ok = take(sa->startPos.data(), 4ull * sa->lookupTableLength) && take(sa->endPos.data(), 4ull * sa->lookupTableLength);
+    if (ok && comp[1]) {
+      ok = take(&sa->lookupTableLength, 4) && take(&sa->lookupPrefixLength, 4);
+      // the table has one range per word of lookupPrefixLength bases (SuffixArray.h:215-222)
+      ok = ok && sa->lookupPrefixLength <= 15 && (uint64_t)sa->lookupTableLength == (1ull << (2 * sa->lookupPrefixLength)) &&
+           at + 8ull * sa->lookupTableLength <= buf.size();
+      if (ok) {
+        sa->startPos.resize(sa->lookupTableLength);
+        sa->endPos.resize(sa->lookupTableLength);
+        ok = take(sa->startPos.data(), 4ull * sa->lookupTableLength) && take(sa->endPos.data(), 4ull * sa->lookupTableLength);
+      }
     }
+  } catch (const std::bad_alloc &) {
+    delete sa;
+    return BLASR_HIP_ERR_NOMEM;
   }
   if (!ok) {
     delete sa;

@@ -92,7 +92,10 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream);
 int fill4_max_width();
 void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream);
-void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream);
+// trace only: row-width histogram of the candidates of args.taskList (10 classes x 4 counters)
+void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigned long long *hist, hipStream_t stream);
+// afterWalk (may be null): recorded behind traceback_kernel, before runs_kernel / stats_kernel
+void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream, hipEvent_t afterWalk = nullptr);
 // *total holds the op count of all candidates before `first` on entry and including them on exit
 void launch_scan_ops(RefineResult *results, int first, int count, int64_t capacity, int64_t *total,
                      hipStream_t stream);

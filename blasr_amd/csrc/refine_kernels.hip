@@ -1495,8 +1495,44 @@ __global__ __launch_bounds__(256) void compact_ops_kernel(const RefineResult *re
 }
 
 // ---------------------------------------------------------------------------
+// row_hist_kernel (BLASR_HIP_REFINE_TRACE only): where the cells of the candidates of a task list are, by row width --
+// hist[b] = {rows, cells, rows whose row above is a wide one too, 192-column steps} for the width classes of kHistEdges
+// ---------------------------------------------------------------------------
+__constant__ int kHistEdges[10] = {48, 96, 112, 192, 384, 576, 1024, 2048, 4096, 1 << 30};
+__global__ __launch_bounds__(256) void row_hist_kernel(RefineBatchView batch, FillArgs args, unsigned long long *hist) {
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (idx >= args.count) return;
+  const int task = args.taskList[idx];
+  if (task < 0) return;
+  const TaskGeometry geo = args.geo[task];
+  const int2 *rowTab = args.rowTab + args.rowOff[task];
+  const int32_t *blk = batch.blocks + 3 * batch.blk_off[task];
+  const int nb = batch.n_blocks[task];
+  const int tEnd = blk[3 * (nb - 1) + 1] + blk[3 * (nb - 1) + 2];
+  auto widthOf = [&](int r) {
+    const unsigned next = r < geo.rows ? (unsigned)rowTab[r + 1].x : (unsigned)geo.cells;
+    const int lo = rowTab[r].y, hi = lo + (int)(next - (unsigned)rowTab[r].x) - 1;
+    return min(hi, tEnd - 1) - lo + 1;
+  };
+  for (int r = 1 + lane; r <= geo.rows; r += 64) {
+    const int w = widthOf(r), pw = r > 1 ? widthOf(r - 1) : 0;
+    int b = 0;
+    while (w > kHistEdges[b]) b++;
+    atomicAdd(&hist[4 * b + 0], 1ull);
+    atomicAdd(&hist[4 * b + 1], (unsigned long long)max(w, 0));
+    if (pw > kF4MaxWidth) atomicAdd(&hist[4 * b + 2], 1ull);
+    atomicAdd(&hist[4 * b + 3], (unsigned long long)((max(w, 0) + 191) / 192));
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
+void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigned long long *hist, hipStream_t stream) {
+  if (args.count <= 0) return;
+  hipLaunchKernelGGL(row_hist_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args, hist);
+}
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
                      hipStream_t stream) {
   if (count <= 0) return;
@@ -1542,9 +1578,13 @@ void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipS
     hipLaunchKernelGGL((fillp_kernel<16, false, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
 }
 int fill4_max_width() { return kF4MaxWidth; }
-void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream) {
-  if (args.count <= 0) return;
+void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream, hipEvent_t afterWalk) {
+  if (args.count <= 0) {
+    if (afterWalk) (void)hipEventRecord(afterWalk, stream);
+    return;
+  }
   hipLaunchKernelGGL(traceback_kernel, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
+  if (afterWalk) (void)hipEventRecord(afterWalk, stream);
   hipLaunchKernelGGL(runs_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
   hipLaunchKernelGGL(stats_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
 }

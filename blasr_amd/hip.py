@@ -45,8 +45,20 @@ EXPORTS = [
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
     "blasr_hip_count_tuples_device", "blasr_hip_pipeline_default_params", "blasr_hip_map_from_reads_device", "blasr_hip_map_from_reads_host",
-    "blasr_hip_pipeline_last_timing",
+    "blasr_hip_pipeline_last_timing", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
 ]
+
+# include/blasr_hip.h: blasr_hip_kernel_record
+KERNEL_RECORD_DTYPE = np.dtype([("kind", "<i4"), ("launches", "<i4"), ("ms", "<f4"), ("ext0", "<i4"),
+                                ("algorithmic_bytes", "<i8"), ("cells", "<i8"), ("candidates", "<i8")])
+
+
+def build_id():
+    """The loaded library's build id (a hash over its sources, blasr_hip_build_id)."""
+    lib = load_library()
+    lib.blasr_hip_build_id.restype = C.c_char_p
+    return lib.blasr_hip_build_id().decode()
+
 
 # include/blasr_hip.h: blasr_hip_interval, blasr_hip_read, blasr_hip_window, blasr_hip_candidate
 INTERVAL_DTYPE = np.dtype([("start", "<u4"), ("end", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"), ("read", "<i4"),
@@ -1155,6 +1167,20 @@ class Context:
         ms, n, b, c = C.c_float(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._check(self.lib.blasr_hip_refine_last_fill4(self.handle, C.byref(ms), C.byref(n), C.byref(b), C.byref(c)))
         return dict(ms=ms.value, launches=n.value, bytes=b.value, cells=c.value)
+
+    def last_kernels(self):
+        """Every heavy kernel of the last refine call on its own (blasr_hip_refine_last_kernels): name as rocprofv3
+        prints it, HIP-event ms, launches, algorithmic bytes, band cells and candidates of exactly those launches."""
+        rec = np.zeros(8, dtype=KERNEL_RECORD_DTYPE)
+        self.lib.blasr_hip_refine_last_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.blasr_hip_kernel_name.argtypes = [C.c_int, C.c_int]
+        self.lib.blasr_hip_kernel_name.restype = C.c_char_p
+        n = self.lib.blasr_hip_refine_last_kernels(self.handle, rec.ctypes.data, len(rec))
+        if n < 0:
+            self._check(n)
+        return [dict(name=self.lib.blasr_hip_kernel_name(int(r["kind"]), int(r["ext0"])).decode(), kind=int(r["kind"]),
+                     ms=float(r["ms"]), launches=int(r["launches"]), bytes=int(r["algorithmic_bytes"]),
+                     cells=int(r["cells"]), candidates=int(r["candidates"])) for r in rec[:n]]
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()

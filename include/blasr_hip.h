@@ -165,6 +165,31 @@ int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t 
  * the bases read + 8 B per row record) and band cells of the candidates those launches processed. */
 int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *launches, int64_t *algorithmic_bytes,
                                 int64_t *cells);
+/* Every heavy kernel of the refine stage on its own (last refine call on this context): HIP-event time of its
+ * launches on the stream they ran on, and the algorithmic bytes / band cells of exactly the candidates those launches
+ * processed.  Fill kernels: 1 B per band cell (arrows out) + the bases read + 8 B per row record;
+ * traceback: one 16-byte arrow window + one 8-byte row record per row walked.  `kind` names the kernel:
+ * blasr_hip_kernel_name(kind) is its full instantiation as rocprofv3 prints it. */
+enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four candidates per wavefront */
+       BLASR_HIP_KERNEL_FILL_HYBRID = 1, /* fillp_kernel<16, ext0, true>: candidates with wide rows */
+       BLASR_HIP_KERNEL_FILL_WAVE = 2,   /* fill_kernel: one candidate per wavefront (compare-based variant) */
+       BLASR_HIP_KERNEL_TRACEBACK = 3,   /* traceback_kernel */
+       BLASR_HIP_KERNEL_KINDS = 4 };
+typedef struct blasr_hip_kernel_record {
+  int32_t kind;
+  int32_t launches;
+  float ms;
+  int32_t ext0;               /* 1: the affine_extend == 0 instantiation ran */
+  int64_t algorithmic_bytes;
+  int64_t cells;
+  int64_t candidates;
+} blasr_hip_kernel_record;
+/* Fills out[0..min(n, capacity)) with the kinds that ran; returns their number n (or a negative error code). */
+int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_record *out, int capacity);
+const char *blasr_hip_kernel_name(int kind, int ext0);
+/* Identifies the BUILD of the library: a hash over its sources taken by the Makefile.  Profiles collected with
+ * rocprofv3 carry it, and bench.py reports PMC traffic only from a profile whose id equals the loaded library's. */
+const char *blasr_hip_build_id(void);
 
 /* ---- SDP: SDPAlign + ComputeAlignmentStats ----------------------------- */
 /* The parameters AlignIntervals passes to SDPAlign (alignment/Blasr.cpp:1716-1722;

@@ -1,0 +1,56 @@
+"""BASELINE.json's configs as the bench generates them (blasr_amd/synth.py: make_repeat_genome / make_map_workload),
+under the driver's GPU tests: a reduced number of reads of configs[2] (hg19-size genome with planted repeat families,
+competing repeat copies, chance clusters) and of configs[4] (30 kb reads at 15 % indels with eight long chance clusters
+per read -- the scattered-sweep regime of the SDP stage), every hit of every read compared with the reference's own
+SDPAlign / AffineGuidedAlign / ComputeAlignmentStats (oracle/_ref/libblasr_ref.so; the oracle's restatement where that
+build is absent) composed into MapRead by the checker.  The same run pins the shape of the bench line: `roofline` names
+the refine kernel with the largest measured time, the others follow in `refine_rooflines`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--blasrmc-reads", "0"]
+                       + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [json.loads(x) for x in p.stdout.decode().splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    return lines[0]
+
+
+def check_line(d, n_reads):
+    cb = d["cpu_baseline"]
+    assert cb["parity_checked"] == n_reads and cb["parity_mismatches"] == 0, cb
+    assert d["config"]["aligned_reads"] == n_reads
+    # the line names the refine kernel that took the longest, with the bytes of exactly its candidates
+    lines = [d["roofline"]] + d["refine_rooflines"]
+    cost = [r["avg_launch_ms"] * r["launches_per_step"] for r in lines]
+    assert cost[0] == max(cost) and all(r["achieved"] > 0 and r["algorithmic_bytes_per_launch"] > 0 for r in lines)
+    names = [r["kernel"] for r in lines]
+    assert "blasr_hip::traceback_kernel" in names and any("fillp_kernel<16, true, false>" in n for n in names)
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-12
+    # traffic only from a PMC profile of this very build and workload
+    assert d["roofline"]["traffic"] is None or d["roofline"]["pmc_profile"].startswith("profiles/")
+    assert len(d["build_id"]) == 12
+
+
+def test_configs2_generator_against_the_reference_functions():
+    d = run_bench("--config", "2", "--reads", "1500", "--cpu-sample", "1500")
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["candidate_intervals_per_gpu"] > 1500
+    check_line(d, 1500)
+    assert any("fillp_kernel<16, true, true>" in r["kernel"] for r in [d["roofline"]] + d["refine_rooflines"])
+
+
+def test_configs4_generator_against_the_reference_functions():
+    d = run_bench("--config", "4", "--reads", "60", "--cpu-sample", "60")
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["candidate_intervals_per_gpu"] >= 60 * 8
+    check_line(d, 60)

@@ -108,6 +108,31 @@ def test_suffix_array_file_of_sawriter(tmp_path):
     assert bytes(genome[a: a + 40]) <= bytes(genome[b: b + 40])  # neighbours in the array are in suffix order
 
 
+def test_truncated_or_corrupt_suffix_array_files_are_refused(tmp_path):
+    """Header fields are checked against what the file holds before anything is sized from them: a truncated file, an
+    index length beyond the file and a lookup table that is not 4^prefix entries come back ERR_INVALID (no allocation
+    of what the header claims, no exception across the C boundary)."""
+    import struct
+    idx = np.arange(100, dtype=np.uint32)
+    table = np.zeros(16, dtype=np.uint32)
+    good = struct.pack("<Iii", 0xacac0001, 1, 1) + struct.pack("<I", 100) + idx.tobytes() + struct.pack("<II", 16, 2) + \
+        table.tobytes() + table.tobytes()
+    cases = {"good": good, "cut_in_index": good[:200], "cut_in_table": good[:-20],
+             "huge_index": good[:12] + struct.pack("<I", 0xfffffff0) + good[16:],
+             "huge_table": good[:416] + struct.pack("<II", 0xfffffff0, 2) + good[424:],
+             "table_not_4_to_prefix": good[:416] + struct.pack("<II", 16, 3) + good[424:]}
+    for name, blob in cases.items():
+        path = os.path.join(str(tmp_path), name + ".sa")
+        open(path, "wb").write(blob)
+        if name == "good":
+            sa = hip.read_suffix_array(path)
+            assert np.array_equal(sa["index"], idx) and sa["lookup_prefix_length"] == 2
+        else:
+            with pytest.raises(hip.BlasrHipError) as e:
+                hip.read_suffix_array(path)
+            assert e.value.code == hip.ERR_INVALID, name
+
+
 @pytest.mark.skipif(not os.path.exists(REFMAPPER_SO), reason="oracle/_ref/libblasr_refmapper.so not built")
 def test_count_table_file_against_the_reference(tmp_path):
     """.ctab: the library's count table of a genome written by the library is what the reference's TupleCountTable
