@@ -546,6 +546,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRingSize = dWideSize;
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     fa.taskList = nullptr;
+    fa.exp = getenv("BLASR_HIP_EXP") ? atoi(getenv("BLASR_HIP_EXP")) : 0;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
     // the row records of the chunk's candidates, now that they have their place in the workspace
     launch_geometry_rows(view, band, c.first, c.count, dGeo, fa.rowTab, dRowOff, reinterpret_cast<unsigned short *>(pMeta), st);
@@ -559,19 +560,39 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         // A wavefront takes the wide rows of its four candidates one after the other, so the heavy candidates (by
         // cells) must not share one: sorted by cells, candidate p of the order goes to wavefront p mod W, so every
         // wavefront holds one of the W heaviest, one of the next W, ...; empty slots are -1.
+        // (BLASR_HIP_HYBRID_ORDER=rows: sorted by rows like the narrow kernel's list, and inside bins of 64 neighbours
+        //  the candidates with the largest excess of cells over a plain band go to different wavefronts.  Measured at
+        //  configs[2], round 3: the narrow rows gain 6 ms, the wide rows lose 40 -- their waits pile up in a few
+        //  wavefronts; kept for experiments.)
         std::vector<int32_t> order((size_t)nw);
         for (int u = 0; u < nw; u++) order[(size_t)u] = u;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-          return geo[c.wideTasks[(size_t)a]].cells > geo[c.wideTasks[(size_t)b]].cells;
-        });
         const int W = (nw + 3) / 4;
         std::vector<int32_t> t2((size_t)W * 4, -1), s2((size_t)W * 4, 512);
         std::vector<int64_t> o2((size_t)W * 4, 0);
-        for (int p = 0; p < nw; p++) {
-          const size_t slot = (size_t)(p % W) * 4 + (size_t)(p / W);
-          t2[slot] = c.wideTasks[(size_t)order[(size_t)p]];
-          o2[slot] = c.wideRingOff[(size_t)order[(size_t)p]];
-          s2[slot] = c.wideRingSize[(size_t)order[(size_t)p]];
+        auto place = [&](size_t slot, int32_t u) {
+          t2[slot] = c.wideTasks[(size_t)u];
+          o2[slot] = c.wideRingOff[(size_t)u];
+          s2[slot] = c.wideRingSize[(size_t)u];
+        };
+        const char *orderEnv = getenv("BLASR_HIP_HYBRID_ORDER");
+        if (!orderEnv || strcmp(orderEnv, "rows")) {
+          std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return geo[c.wideTasks[(size_t)a]].cells > geo[c.wideTasks[(size_t)b]].cells;
+          });
+          for (int p = 0; p < nw; p++) place((size_t)(p % W) * 4 + (size_t)(p / W), order[(size_t)p]);
+        } else {
+          std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return geo[c.wideTasks[(size_t)a]].rows > geo[c.wideTasks[(size_t)b]].rows;
+          });
+          auto excess = [&](int32_t u) {
+            const TaskGeometry &g = geo[c.wideTasks[(size_t)u]];
+            return g.cells - 35 * (int64_t)g.rows;
+          };
+          for (int b0 = 0; b0 < nw; b0 += 64) {
+            const int nb = std::min(64, nw - b0), waves = (nb + 3) / 4;
+            std::stable_sort(order.begin() + b0, order.begin() + b0 + nb, [&](int32_t a, int32_t b) { return excess(a) > excess(b); });
+            for (int m = 0; m < nb; m++) place((size_t)(b0 / 4 + m % waves) * 4 + (size_t)(m / waves), order[(size_t)(b0 + m)]);
+          }
         }
         c.wideTasks.swap(t2);
         c.wideRingOff.swap(o2);

