@@ -21,31 +21,32 @@ static_assert(sizeof(SdpResult) == sizeof(blasr_hip_sdp_result), "result record 
 
 namespace {
 
-// Bump allocator over the context's ONE grow-only workspace (the region the refine stage uses after this stage is
-// done with it: the analogue of MappingBuffers' "grow to the high-water mark and keep", Blasr.cpp:313-369).
-// A request that does not fit what is left of the workspace gets an allocation of its own for the rest of the
-// call; when the call ends those are freed and the workspace grown to the call's high-water mark, so that the
-// next call of that size is served from the one region again.  Nothing is ever left fragmented or unaccounted:
+// Two-ended bump allocator over the context's ONE grow-only workspace (the region the refine stage uses after this
+// stage is done with it: the analogue of MappingBuffers' "grow to the high-water mark and keep", Blasr.cpp:313-369).
+// get() takes from the bottom: the arrays of ONE recursion level (keys, fragments, the sweep's arrays, counts, sort
+// temporaries), given back as a whole by release_level() once the level's kernels are done; keep() takes from the
+// top: what outlives its level (the block pool entries and SWAlign jobs a level emitted, the next level's tasks) --
+// so the stage's footprint is the largest level plus what the levels handed on, not the sum of all levels.
+// A request that does not fit what is left between the two ends gets an allocation of its own (a level's are freed
+// with the level, the others when the call ends); the workspace is then grown to the call's high-water mark, so that
+// the next call of that size is served from the one region again.  Nothing is ever left fragmented or unaccounted:
 // what the context holds is the workspace, bounded by blasr_hip_set_workspace_limit.
 struct Arena {
   blasr_hip_ctx *ctx;
   hipStream_t st;
-  size_t offset = 0, high = 0;
-  std::vector<void *> overflow;
+  size_t bottom = 0, top = 0;            // bytes taken from either end of the workspace
+  size_t ownLevel = 0, ownKept = 0;      // bytes in allocations of their own
+  size_t high = 0;                       // the most that was in use at once
+  std::vector<void *> overflowLevel, overflowKept;
   hipError_t err = hipSuccess;
-  int64_t *highOut = nullptr;  // receives the bytes the call asked for in all
+  int64_t *highOut = nullptr;  // receives the high-water mark
   Arena(blasr_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {}
   Arena(const Arena &) = delete;
   Arena &operator=(const Arena &) = delete;
-  template <typename T>
-  T *get(size_t n) {
-    const size_t bytes = (std::max<size_t>(n * sizeof(T), 256) + 255) / 256 * 256;
-    high += bytes;
-    if (offset + bytes <= ctx->workspaceBytes) {
-      char *p = ctx->workspace + offset;
-      offset += bytes;
-      return reinterpret_cast<T *>(p);
-    }
+  size_t capacity() const { return ctx->workspaceBytes / 256 * 256; }
+  static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 256) + 255) / 256 * 256; }
+  void note() { high = std::max(high, bottom + top + ownLevel + ownKept); }
+  void *own(size_t bytes, std::vector<void *> &list, size_t &counter) {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
@@ -53,18 +54,49 @@ struct Arena {
       err = e;
       return nullptr;
     }
-    overflow.push_back(p);
-    return reinterpret_cast<T *>(p);
+    list.push_back(p);
+    counter += bytes;
+    note();
+    return p;
+  }
+  template <typename T>
+  T *get(size_t n) {  // lives until release_level()
+    const size_t bytes = rounded(n * sizeof(T));
+    if (bottom + bytes + top <= capacity()) {
+      char *p = ctx->workspace + bottom;
+      bottom += bytes;
+      note();
+      return reinterpret_cast<T *>(p);
+    }
+    return reinterpret_cast<T *>(own(bytes, overflowLevel, ownLevel));
+  }
+  template <typename T>
+  T *keep(size_t n) {  // lives until the call ends
+    const size_t bytes = rounded(n * sizeof(T));
+    if (bottom + bytes + top <= capacity()) {
+      top += bytes;
+      note();
+      return reinterpret_cast<T *>(ctx->workspace + capacity() - top);
+    }
+    return reinterpret_cast<T *>(own(bytes, overflowKept, ownKept));
+  }
+  // the level's kernels are done (the caller has synchronised the stream): its arrays go back
+  void release_level(size_t mark) {
+    bottom = mark;
+    for (void *p : overflowLevel) (void)hipFree(p);
+    overflowLevel.clear();
+    ownLevel = 0;
   }
   // end of the call (every path): the stream must be idle before memory it may still use goes away
   ~Arena() {
     if (highOut) *highOut = (int64_t)high;
-    if (overflow.empty()) return;
+    if (overflowLevel.empty() && overflowKept.empty()) return;
     (void)hipStreamSynchronize(st);
-    for (void *p : overflow) (void)hipFree(p);
-    const std::string keep = ctx->lastError;  // best effort: failing to grow is not an error, and not the call's message
+    for (void *p : overflowLevel) (void)hipFree(p);
+    for (void *p : overflowKept) (void)hipFree(p);
+    const std::string keepMsg = ctx->lastError;  // best effort: failing to grow is not an error, and not the call's message
     (void)blasr_hip_grow_workspace(ctx, high + high / 8);
-    ctx->lastError = keep;
+    ctx->lastError = keepMsg;
   }
 };
 
@@ -166,9 +198,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     t.flags = (sp->extend_front ? kSdpExtendFront : 0) | (sp->detailed ? kSdpDetailed : 0);
     t.pad = 0;
   }
-  SdpTask *dTop = arena.get<SdpTask>(n);
-  int32_t *dMatrix = arena.get<int32_t>(32);
-  Counters *dCounters = arena.get<Counters>(1);
+  SdpTask *dTop = arena.keep<SdpTask>(n);  // (needed until the call ends, like everything the levels hand on)
+  int32_t *dMatrix = arena.keep<int32_t>(32);
+  Counters *dCounters = arena.keep<Counters>(1);
   ARENA_CHECK();
   HIP_TRY(ctx, hipMemcpyAsync(dTop, top.data(), sizeof(SdpTask) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dMatrix, score->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
@@ -195,6 +227,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   int64_t totalInvocations = 0, totalFrags = 0;
 
   const int idxMaxT = getenv("BLASR_HIP_NO_INDEX") ? 0 : sdp_match_index_max_target(ctx->device);
+  const size_t levelMark = arena.bottom;  // (what was taken so far lives for the whole call)
   for (int level = 0; nTasks > 0; level++) {
     totalInvocations += nTasks;
     SdpLevelArrays lv;
@@ -408,10 +441,11 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     e.poolCap = emitTotals[0];
     e.swCap = emitTotals[1];
     e.childCap = emitTotals[2];
-    e.poolKeys = arena.get<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
-    e.poolVals = arena.get<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
-    e.sw = arena.get<SwTask>((size_t)std::max<int64_t>(emitTotals[1], 1));
-    e.children = arena.get<SdpTask>((size_t)std::max<int64_t>(emitTotals[2], 1));
+    // (what the level hands on outlives its arrays)
+    e.poolKeys = arena.keep<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
+    e.poolVals = arena.keep<uint64_t>((size_t)std::max<int64_t>(emitTotals[0], 1));
+    e.sw = arena.keep<SwTask>((size_t)std::max<int64_t>(emitTotals[1], 1));
+    e.children = arena.keep<SdpTask>((size_t)std::max<int64_t>(emitTotals[2], 1));
     ARENA_CHECK();
     launch_sdp_blocks_emit(lv, prm, e, counts, offPool, offSw, offChild, st);
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -435,6 +469,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     dTasks = e.children;
     nTasks = (int)hc.child;
     k = k - 4 > 5 ? k - 4 : 5;
+    arena.release_level(levelMark);  // (the stream was synchronised above: nothing of the level is in flight)
   }
 
   // ---- gap fills (SWAlign) and assembly ----
@@ -598,8 +633,10 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   bool overflow = false;
   int first = 0;
   int limitCount = n;  // a piece that failed caps the next attempt at half its candidates
+  int64_t largestAcc = 0;
+  double largestPerBase = 0;
   while (first < n) {
-    int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 48.0)), 1 << 16);
+    int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 16.0)), 1 << 16);
     if (forced) budgetBases = std::max<int64_t>(atoll(forced), 1);
     int cnt = 0;
     int64_t acc = 0;
@@ -619,8 +656,15 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     int64_t usedHere = 0, arenaHigh = 0;
     const int rc = sdp_device_chunk(ctx, &sub, sp, score, results + first, blocks ? blocks + 3 * std::min(used, blocksCap) : nullptr,
                                     left, &usedHere, used, &arenaHigh);
-    if (acc > 0 && arenaHigh > 0 && !forced)  // (an aborted piece reports what it had asked for so far: a lower bound)
+    if (acc > 0 && arenaHigh > 0 && !forced) {  // (an aborted piece reports what it had asked for so far: a lower bound)
       ctx->sdpBytesPerBase = std::max(ctx->sdpBytesPerBase * (rc == BLASR_HIP_OK ? 0.5 : 1.0), 1.25 * (double)arenaHigh / (double)acc);
+      // what the NEXT call plans with is the figure of this call's largest piece: a small last piece carries the
+      // stage's fixed costs on few bases and would make the next call cut a batch in two that fits in one
+      if (rc == BLASR_HIP_OK && acc >= largestAcc) {
+        largestAcc = acc;
+        largestPerBase = ctx->sdpBytesPerBase;
+      }
+    }
     if (rc == BLASR_HIP_ERR_NOMEM && cnt > 1) {
       limitCount = cnt / 2;
       ctx->sdpBytesPerBase *= 1.5;
@@ -637,6 +681,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     for (int i = 0; i < 3; i++) counters[i] += ctx->sdpCounters[i];
     for (int i = 0; i < 4; i++) bytes[i] += ctx->sdpBytes[i];
   }
+  if (largestPerBase > 0) ctx->sdpBytesPerBase = largestPerBase;
   for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = bytes[i];
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = ms[i];
   for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = counters[i];
