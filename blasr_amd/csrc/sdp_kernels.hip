@@ -50,11 +50,11 @@ namespace blasr_hip {
 constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
 
 // long targets are matched by sdp_match_index_kernel (further down) and need no sorted keys
-constexpr int kIdxBuckets = 1024;
+constexpr int kIdxBuckets = 4096;
 constexpr int kIdxMinT = 1536;   // shorter targets keep the wavefront-per-task kernels
 constexpr int kIdxMaxK = 13;     // 2k bits of k-mer + 2*15 bits of shift must fit a 64-bit window
-constexpr int kIdxCntStride = kIdxBuckets + 1;
-constexpr int kIdxSmallCap = 12288;  // targets up to this size: < 64 KB of LDS per workgroup
+constexpr int kIdxSmallCap = 12288;  // targets up to this size: < 40 KB of LDS per workgroup, four workgroups per CU
+constexpr int kIdxMidCap = 20480;    // ... and up to this: three
 
 __host__ __device__ inline bool task_uses_index(int tLen, int k, int idxMaxT) {
   return tLen >= kIdxMinT && tLen <= idxMaxT && k <= kIdxMaxK;
@@ -335,28 +335,30 @@ __device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, 
 
 // ---------------------------------------------------------------------------
 // sdp_match_index: the same StoreMatchingPositions for LONG targets, one 256-thread workgroup per task
-// and no k-mer sort at all.  The target's bases are packed into LDS (2 bits + a "not ACGT" bit), its
-// k-mers are bucketed by a hash of the k-mer with a STABLE counting scatter (each wavefront owns a
-// contiguous quarter of the target, so a bucket lists positions in increasing order), and every query
-// k-mer walks its bucket comparing against the packed target.  Matches therefore come out ordered by
-// (query position, target position), as the sorted tuple list of the reference yields them
-// (TupleList.h:98-126, TupleMatching.h:37-61).
+// and no k-mer sort at all.  The target's bases are packed into LDS (2 bits + a "not ACGT" bit) and the
+// positions of its k-mers bucketed by a hash of the k-mer: 4096 buckets, a position is two bytes, the
+// bucket bounds two bytes each -- 39 KB of LDS for a 12 kb target, four workgroups per CU.  A bucket is filled in
+// whatever order the atomics fall (no ticket loop, one set of counters); every query k-mer walks its
+// bucket -- three entries on average -- and compares the k-mer AT each position in the packed target with its own.
+// Matches must come out ordered by (query position, target position), as the sorted tuple list of the
+// reference yields them (TupleList.h:98-126, TupleMatching.h:37-61): up to three hits of a position are
+// ordered in registers, the rare longer lists are sorted where they are written.
 // ---------------------------------------------------------------------------
 struct IdxLds {
   uint32_t *tCodes, *tBad, *cnt, *qStage, *part;
   uint8_t *lut;
-  uint32_t *ent;  // bucket by bucket: {the k-mer bits above the low ten : 16, target position : 16}
+  uint16_t *ent;  // bucket by bucket: target positions
 };
 __host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
   int at = 0;
   offs[0] = at, at += tCap / 16 + 4;          // tCodes
   offs[1] = at, at += tCap / 32 + 4;          // tBad
-  offs[2] = at, at += 4 * kIdxCntStride;      // cnt: per wavefront and bucket {fill pointer : 16, ticket : 16}
+  offs[2] = at, at += kIdxBuckets / 2 + 4;    // cnt: two buckets per word {count / fill pointer / end : 16} x 2
   offs[3] = at, at += 4 * 104;                // qStage: per wavefront 66 code words + 34 bad words
   offs[4] = at, at += 16;                     // part
   offs[5] = at, at += 64;                     // lut
   at = (at + 3) & ~3;
-  offs[6] = at, at += tCap + 8;               // ent (16-byte aligned)
+  offs[6] = at, at += tCap / 2 + 8;           // ent (16-byte aligned)
   return at;
 }
 int64_t idx_lds_bytes(int tCap) {
@@ -397,12 +399,13 @@ __device__ __forceinline__ uint32_t bad_window(const uint32_t *bad, int p, uint3
   const int w = p >> 5;
   return __builtin_amdgcn_alignbit(bad[w + 1], bad[w], (uint32_t)(p & 31)) & kMask;
 }
-// bucket = low ten bits of the k-mer mixed with the bits above them; (bucket, high bits) <-> k-mer is one to one
-__device__ __forceinline__ uint32_t idx_high(uint32_t kmer) { return kmer >> 10; }  // <= 16 bits for k <= 13
+// bucket = low twelve bits of the k-mer mixed with the bits above them
 __device__ __forceinline__ int idx_bucket(uint32_t kmer) {
-  const uint32_t h = kmer >> 10;
-  return (int)((kmer ^ h ^ (h >> 10)) & (kIdxBuckets - 1));
+  const uint32_t h = kmer >> 12;
+  return (int)((kmer ^ h ^ (h >> 12)) & (kIdxBuckets - 1));
 }
+// the bounds of bucket b once the index is filled: cnt holds every bucket's END (two per word)
+__device__ __forceinline__ int idx_end(const uint32_t *cnt, int b) { return (int)((cnt[b >> 1] >> ((b & 1) * 16)) & 0xffffu); }
 
 __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,12 +435,11 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     L.qStage = idxLdsRaw + offs[3];
     L.part = idxLdsRaw + offs[4];
     L.lut = reinterpret_cast<uint8_t *>(idxLdsRaw + offs[5]);
-    L.ent = idxLdsRaw + offs[6];
+    L.ent = reinterpret_cast<uint16_t *>(idxLdsRaw + offs[6]);
   }
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
   L.lut[tid] = (uint8_t)base_code((unsigned)tid);  // 0..3, or 4 = bad bit
   const int nBig = *lv.bigCount;
-  volatile uint32_t *my = L.cnt + wv * kIdxCntStride;
   uint32_t *qCodes = L.qStage + wv * 104, *qBad = qCodes + 68;
   for (int e = blockIdx.x; e < nBig; e += gridDim.x) {
     const int idx = lv.bigList[e];
@@ -457,68 +459,46 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         L.tCodes[wi] = c;
         reinterpret_cast<uint16_t *>(L.tBad)[wi] = (uint16_t)bd;
       }
-      for (int i = tid; i < 4 * kIdxCntStride; i += 256) L.cnt[i] = 0;
+      for (int i = tid; i < kIdxBuckets / 2 + 4; i += 256) L.cnt[i] = 0;
       __syncthreads();
-      // ---- bucket sizes per wavefront (each owns a contiguous quarter of the target positions)
+      // ---- bucket sizes (two sixteen-bit counters to a word: a target has < 65536 positions, nothing carries over)
       const int nKmerT = t.tLen - k + 1;
-      const int per = (((nKmerT + 3) / 4) + 63) & ~63;
-      const int lo = min(wv * per, nKmerT), hi = min(nKmerT, lo + per);
-      for (int p = lo + lane; p < hi; p += 64)
-        if (bad_window(L.tBad, p, kMask) == 0u)
-          atomicAdd(const_cast<uint32_t *>(&my[idx_bucket(code_window(L.tCodes, p, kmerMask))]), 1u << 16);
+      for (int p = tid; p < nKmerT; p += 256)
+        if (bad_window(L.tBad, p, kMask) == 0u) {
+          const int d = idx_bucket(code_window(L.tCodes, p, kmerMask));
+          atomicAdd(&L.cnt[d >> 1], 1u << ((d & 1) * 16));
+        }
       __syncthreads();
-      {  // exclusive scan over the buckets; every wavefront's fill pointer starts after the earlier quarters'
-        uint32_t c[4][4], sum = 0;
+      {  // exclusive scan over the buckets, sixteen per thread: every bucket's counter becomes its first slot
+        uint32_t w[8], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-          for (int w = 0; w < 4; w++) {
-            c[w][j] = L.cnt[w * kIdxCntStride + 4 * tid + j] >> 16;
-            sum += c[w][j];
-          }
+        for (int j = 0; j < 8; j++) {
+          w[j] = L.cnt[8 * tid + j];
+          sum += (w[j] & 0xffffu) + (w[j] >> 16);
         }
         const unsigned incl = wave_prefix_sum(sum);
         if (lane == 63) L.part[wv] = incl;
         __syncthreads();
         uint32_t at = incl - sum;
-        for (int w = 0; w < wv; w++) at += L.part[w];
+        for (int w0 = 0; w0 < wv; w0++) at += L.part[w0];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-          for (int w = 0; w < 4; w++) {
-            L.cnt[w * kIdxCntStride + 4 * tid + j] = (at << 16) | 0xffffu;
-            at += c[w][j];
-          }
+        for (int j = 0; j < 8; j++) {
+          const uint32_t lo = w[j] & 0xffffu, hi = w[j] >> 16;
+          L.cnt[8 * tid + j] = at | ((at + lo) << 16);
+          at += lo + hi;
         }
       }
       __syncthreads();
-      // ---- stable scatter: in a chunk of 64 positions the lanes that share a bucket take turns, lowest first
-      for (int p0 = lo; p0 < hi; p0 += 64) {
-        const int p = p0 + lane;
-        bool pending = p < hi && bad_window(L.tBad, p, kMask) == 0u;
-        const uint32_t tkm = code_window(L.tCodes, p, kmerMask);
-        const int d = pending ? idx_bucket(tkm) : 0;
-        while (__ballot(pending) != 0ull) {
-          if (pending) {
-            const uint32_t word = my[d];
-            atomicMin(const_cast<uint32_t *>(&my[d]), (word & 0xffff0000u) | (uint32_t)lane);
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (pending) {
-            const uint32_t r = my[d];
-            if ((r & 0xffffu) == (uint32_t)lane) {
-              const uint32_t slot = r >> 16;
-              L.ent[slot] = (idx_high(tkm) << 16) | (uint32_t)p;
-              my[d] = ((slot + 1u) << 16) | 0xffffu;
-              pending = false;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
+      // ---- scatter: a position takes the next slot of its bucket, whichever lane comes first
+      for (int p = tid; p < nKmerT; p += 256)
+        if (bad_window(L.tBad, p, kMask) == 0u) {
+          const int d = idx_bucket(code_window(L.tCodes, p, kmerMask));
+          const uint32_t old = atomicAdd(&L.cnt[d >> 1], 1u << ((d & 1) * 16));
+          L.ent[(old >> ((d & 1) * 16)) & 0xffffu] = (uint16_t)p;
         }
-      }
       __syncthreads();
     }
-    const uint32_t *ends = L.cnt + 3 * kIdxCntStride;  // the last quarter's fill pointers = bucket ends
+    const uint32_t *ends = L.cnt;  // the fill pointers have run to their buckets' ends
     // ---- the query against the index
     const int nKmerQ = max(t.qLen - k + 1, 0);
     const int perQ = (((nKmerQ + 3) / 4) + 63) & ~63;
@@ -569,26 +549,35 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
           km = code_window(qCodes, rel, kmerMask);
           if (ok && (!kWrite || cnt > 3)) {
             const int b = idx_bucket(km);
-            bs = b ? (int)(ends[b - 1] >> 16) : 0;
-            be = (int)(ends[b] >> 16);
+            bs = b ? idx_end(ends, b - 1) : 0;
+            be = idx_end(ends, b);
           }
         }
         if (!kWrite) {
-          // walk the bucket four entries at a time: an entry matches iff its high k-mer bits equal the query's
-          const uint32_t hq = idx_high(km);
-          uint64_t pos3 = 0;
+          // walk the bucket four positions at a time: a position matches iff the k-mer there is the query's.  The
+          // first three matches are kept in increasing order (the bucket is not).
+          uint32_t p0 = 0, p1 = 0, p2 = 0;
           for (int g = bs & ~3; g < be; g += 4) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(L.ent + g);
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            const uint2 v = *reinterpret_cast<const uint2 *>(L.ent + g);
+            const uint32_t pos4[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               const int i = g + u;
-              if ((w4[u] >> 16) == hq && i >= bs && i < be) {
-                if (cnt < 3) pos3 |= (uint64_t)(w4[u] & 0xffffu) << (16 * (cnt + 1));
+              const bool in = i >= bs && i < be;
+              const uint32_t tp = in ? pos4[u] : 0u;
+              if (in && code_window(L.tCodes, (int)tp, kmerMask) == km) {
+                // (sorted insert into p0 <= p1 <= p2; beyond three only the count matters)
+                if (cnt == 0) p0 = tp;
+                else if (cnt == 1) { p1 = max(p0, tp); p0 = min(p0, tp); }
+                else if (cnt == 2) {
+                  const uint32_t lo = min(p0, tp), mid = min(max(p0, tp), p1), hi = max(p1, tp);
+                  p0 = lo, p1 = mid, p2 = hi;
+                }
                 cnt++;
               }
             }
           }
+          const uint64_t pos3 = ((uint64_t)p0 << 16) | ((uint64_t)p1 << 32) | ((uint64_t)p2 << 48);
           if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
           if (cnt > 0xffff) cnt = 0xffff;  // cannot happen: a bucket holds < 65536 entries
           if (on) hits[x] = cnt ? (pos3 | (uint64_t)cnt) : 0ull;
@@ -607,12 +596,18 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
               out[w++] = f;
             }
           } else if (cnt > 3) {  // only in a task whose index was rebuilt
-            const uint32_t hq = idx_high(km);
+            const int w0 = w;
             for (int i = bs; i < be; i++) {
-              const uint32_t v = L.ent[i];
-              if ((v >> 16) == hq) {
-                f.y = v & 0xffffu;
-                out[w++] = f;
+              const uint32_t tp = L.ent[i];
+              if (code_window(L.tCodes, (int)tp, kmerMask) == km) {
+                // insertion into the part already written: the fragments of a position go out by target position
+                int at = w++;
+                while (at > w0 && out[at - 1].y > tp) {
+                  out[at] = out[at - 1];
+                  at--;
+                }
+                f.y = tp;
+                out[at] = f;
               }
             }
           }
@@ -3872,13 +3867,13 @@ int sdp_match_index_max_target(int device) {
 }
 void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
   if (lv.n <= 0 || lv.idxMaxT <= 0) return;
-  // two size classes, so that the usual targets (<= kIdxSmallCap) get two workgroups per CU
+  // three size classes, so that the usual targets (<= kIdxSmallCap) get four workgroups per CU
   const int grid = std::min(lv.n, 1024);
-  const int caps[2] = {std::min(kIdxSmallCap, lv.idxMaxT), lv.idxMaxT};
+  const int caps[3] = {std::min(kIdxSmallCap, lv.idxMaxT), std::min(kIdxMidCap, lv.idxMaxT), lv.idxMaxT};
   if (write) hipLaunchKernelGGL(sdp_match_index_copy_kernel, dim3(std::min(lv.n, 8192)), dim3(256), 0, st, lv, seq);
-  for (int c = 0; c < 2; c++) {
-    if (c == 1 && caps[1] <= caps[0]) break;
-    const int minT = c == 0 ? 0 : caps[0];
+  for (int c = 0; c < 3; c++) {
+    if (c > 0 && caps[c] <= caps[c - 1]) break;
+    const int minT = c == 0 ? 0 : caps[c - 1];
     const size_t bytes = (size_t)idx_lds_bytes(caps[c]);
     if (write)
       hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
