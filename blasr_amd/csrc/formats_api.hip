@@ -7,6 +7,7 @@
 //   blasr_hip_fasta_concatenate FASTAReader::ReadAllSequencesIntoOne (:113-146) + the seqdb it fills
 //                               (SequenceIndexDatabase: seqStartPos, names) + genome.ToUpper() (Blasr.cpp:4354): the
 //                               contigs back to back, one 'N' after each
+//   blasr_hip_fastq_read        FASTQReader::GetNext(FASTQSequence&) (FASTQReader.h:27-66) AS THIS FORK HAS IT, see parse_fastq
 //   blasr_hip_sa_read           SuffixArray::Read (datastructures/suffixarray/SuffixArray.h:608-630; layout written by
 //                               Write :505-532): magic 0xacac0001, the component list, the index array, the lookup table
 #include <stdint.h>
@@ -23,6 +24,7 @@
 struct blasr_hip_fasta {
   std::vector<std::string> titles;
   std::vector<std::vector<uint8_t>> seqs;
+  std::vector<std::vector<uint8_t>> quals;  // FASTQ only: one quality character per base (empty for a FASTA file)
   std::string error;
 };
 
@@ -74,9 +76,131 @@ void parse_fasta(const char *p, size_t n, blasr_hip_fasta &out) {
   }
 }
 
+// FASTQReader::GetNext(FASTQSequence&) of this fork (FASTQReader.h:27-66), character for character.  It is NOT a
+// FASTQ parser: after reading a title line ('@' ...) it calls FASTAReader::GetNext(seq, '@') (:41), which looks for the
+// NEXT '@' from where it stands -- through the record's own bases, its '+' line and its qualities -- reads THAT line as
+// the title and the lines after it, up to one that starts with '+', as the bases (:166-216 with delim '@' and
+// endOfReadDelim '+').  Then one line that must start with '+' (:49-53, else the reference prints an error and
+// exit(0)s), then as many quality characters as there are bases (:54-60: ifstream::get(buf, length + 1) stops at a
+// newline; one more get() swallows it).  On a plain four-line file whose quality strings hold no '@' every SECOND record
+// comes out (titles, bases and qualities of records 2, 4, 6, ...); an '@' among the qualities starts a "title" in the
+// middle of that line.  The binary's behaviour on FASTQ input is this, so this is what is restated.  Where the
+// reference leaves defined ground the restatement stops with an error instead: a missing '+' line (the reference
+// exits), fewer quality characters than bases (it copies uninitialised stack), an empty quality line (its stream
+// fails and the next call never returns).
+// The stream is an in-memory std::ifstream: eof is set by a peek() or get() at the end, or by a getline() that runs
+// into the end before a newline.
+struct TextStream {
+  const char *p;
+  size_t n, at = 0;
+  bool eof = false;
+  int peek() {
+    if (at >= n) {
+      eof = true;
+      return -1;
+    }
+    return (unsigned char)p[at];
+  }
+  int get() {
+    if (at >= n) {
+      eof = true;
+      return -1;
+    }
+    return (unsigned char)p[at++];
+  }
+  std::string getline() {  // (at the end already: eof + fail, an empty line)
+    std::string line;
+    if (at >= n) {
+      eof = true;
+      return line;
+    }
+    size_t e = at;
+    while (e < n && p[e] != '\n') e++;
+    line.assign(p + at, e - at);
+    if (e < n) at = e + 1;
+    else {
+      at = n;
+      eof = true;
+    }
+    return line;
+  }
+};
+
+int parse_fastq(const char *p, size_t n, blasr_hip_fasta &out) {
+  TextStream f{p, n};
+  auto advance_to_title = [&]() {  // FASTAReader::AdvanceToTitleStart('@') (:90-101)
+    while (!f.eof && f.peek() != '@') f.get();
+    return !f.eof;
+  };
+  for (;;) {
+    if (f.eof) break;
+    if (!advance_to_title()) break;
+    (void)f.getline();  // ReadTitle (:41 of FASTQReader.h): overwritten by the one FASTAReader::GetNext reads below
+    // ---- FASTAReader::GetNext(seq, '@')
+    if (f.eof) break;
+    if (!advance_to_title()) break;
+    const std::string title = f.getline();
+    std::vector<uint8_t> seq;
+    while (!f.eof && f.peek() != '+') {  // (file.good() && !eof: nothing here sets failbit before eof)
+      const std::string line = f.getline();
+      for (char c : line) {
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n') continue;
+        seq.push_back((uint8_t)c);
+      }
+    }
+    // ---- back in FASTQReader::GetNext: the '+' line
+    const std::string plus = f.getline();
+    if (plus.empty() || plus[0] != '+') {
+      out.error = "ERROR in fastq format. Expecting '+' (the reference exits here)";
+      return BLASR_HIP_ERR_INVALID;
+    }
+    std::vector<uint8_t> qual;
+    if (!seq.empty()) {
+      // file.get(buf, length + 1): up to `length` characters, stopping BEFORE a newline
+      while (qual.size() < seq.size() && f.at < f.n && f.p[f.at] != '\n') qual.push_back((uint8_t)f.p[f.at++]);
+      if (qual.size() < seq.size()) {
+        if (f.at >= f.n) f.eof = true;
+        out.error = qual.empty() ? "empty quality line (the reference's stream fails and its next call never returns)"
+                                 : "fewer quality values than bases (the reference copies uninitialised memory)";
+        return BLASR_HIP_ERR_UNSUPPORTED;
+      }
+      (void)f.get();  // "get the \\n" -- whatever the next character is
+    }
+    out.titles.push_back(title.size() > 1 ? title.substr(1) : std::string());  // ReadTitle: the line without its '@'
+    out.seqs.push_back(std::move(seq));
+    out.quals.push_back(std::move(qual));
+  }
+  return BLASR_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out) {
+  if (!path || !out) return BLASR_HIP_ERR_INVALID;
+  *out = nullptr;
+  std::vector<char> buf;
+  if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  return blasr_hip_fastq_parse(buf.data(), (int64_t)buf.size(), out);
+}
+
+int blasr_hip_fastq_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+  if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_fasta *f = new blasr_hip_fasta();
+  const int rc = parse_fastq(text, (size_t)length, *f);
+  *out = f;  // (also on an error: the records before it and the message, blasr_hip_fasta_error)
+  return rc;
+}
+
+int blasr_hip_fastq_quality(const blasr_hip_fasta *f, int64_t i, const uint8_t **qual, int64_t *qual_length) {
+  if (!f || i < 0 || i >= (int64_t)f->quals.size()) return BLASR_HIP_ERR_INVALID;
+  if (qual) *qual = f->quals[(size_t)i].data();
+  if (qual_length) *qual_length = (int64_t)f->quals[(size_t)i].size();
+  return BLASR_HIP_OK;
+}
+
+const char *blasr_hip_fasta_error(const blasr_hip_fasta *f) { return f ? f->error.c_str() : ""; }
 
 int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out) {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;

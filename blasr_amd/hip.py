@@ -39,6 +39,7 @@ EXPORTS = [
     "blasr_hip_adopt_genome_device", "blasr_hip_held_bytes", "blasr_hip_sdp_last_bytes",
     "blasr_hip_fasta_read", "blasr_hip_fasta_parse", "blasr_hip_fasta_free", "blasr_hip_fasta_count",
     "blasr_hip_fasta_record", "blasr_hip_fasta_name", "blasr_hip_fasta_concatenate",
+    "blasr_hip_fastq_read", "blasr_hip_fastq_parse", "blasr_hip_fastq_quality", "blasr_hip_fasta_error",
     "blasr_hip_sa_read", "blasr_hip_sa_free", "blasr_hip_sa_arrays",
     "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
@@ -1321,6 +1322,37 @@ def read_fasta(path=None, text=None):
         title = C.string_at(t, tl.value)
         seq = np.frombuffer(C.string_at(s, sl.value), dtype=np.uint8).copy() if sl.value else np.zeros(0, np.uint8)
         out.append((title, seq))
+    lib.blasr_hip_fasta_free(h)
+    return out
+
+
+def read_fastq(path=None, text=None):
+    """A FASTQ file (or text) as the reference's FASTQReader::GetNext reads it in this fork (blasr_hip_fastq_read: NOT a
+    FASTQ parser, see include/blasr_hip.h): list of (title bytes, bases uint8 array, quality characters uint8 array).
+    Raises BlasrHipError where the reference exits or reads undefined memory."""
+    lib = load_library()
+    h = C.c_void_p()
+    if text is not None:
+        rc = lib.blasr_hip_fastq_parse(text, C.c_int64(len(text)), C.byref(h))
+    else:
+        rc = lib.blasr_hip_fastq_read(path.encode(), C.byref(h))
+    lib.blasr_hip_fasta_error.restype = C.c_char_p
+    lib.blasr_hip_fasta_error.argtypes = [C.c_void_p]
+    if rc != OK:
+        msg = lib.blasr_hip_fasta_error(h).decode() if h else "fastq_read"
+        if h:
+            lib.blasr_hip_fasta_free(h)
+        raise BlasrHipError(rc, msg)
+    lib.blasr_hip_fasta_count.restype = C.c_int64
+    out = []
+    for i in range(lib.blasr_hip_fasta_count(h)):
+        t, tl, s, sl, q, ql = C.c_char_p(), C.c_int64(), C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        lib.blasr_hip_fasta_record(h, C.c_int64(i), C.byref(t), C.byref(tl), C.byref(s), C.byref(sl))
+        lib.blasr_hip_fastq_quality(h, C.c_int64(i), C.byref(q), C.byref(ql))
+        title = C.string_at(t, tl.value)
+        seq = np.frombuffer(C.string_at(s, sl.value), dtype=np.uint8).copy() if sl.value else np.zeros(0, np.uint8)
+        qual = np.frombuffer(C.string_at(q, ql.value), dtype=np.uint8).copy() if ql.value else np.zeros(0, np.uint8)
+        out.append((title, seq, qual))
     lib.blasr_hip_fasta_free(h)
     return out
 

@@ -681,6 +681,18 @@ typedef struct blasr_hip_fasta blasr_hip_fasta;
 int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out);
 int blasr_hip_fasta_parse(const char *text, int64_t length, blasr_hip_fasta **out);
 int blasr_hip_fasta_free(blasr_hip_fasta *fasta);
+/* FASTQ input as the reference's FASTQReader::GetNext(FASTQSequence&) reads it (common/FASTQReader.h:27-66, dispatched
+ * by files/ReaderAgglomerate.h:250,279) -- which in this fork is not a FASTQ parser: after a title line it looks for
+ * the NEXT '@' (FASTAReader::GetNext(seq, '@'), :41), so a plain four-line file yields every second record, and an '@'
+ * among the quality characters starts a title there.  Restated as it behaves, because the binary's lines on FASTQ
+ * input are these.  The records come back through blasr_hip_fasta_count / _record / _name, their quality characters
+ * (one per base) through blasr_hip_fastq_quality.  Where the reference leaves defined ground -- a record without its
+ * '+' line (it exits), fewer quality characters than bases (it copies uninitialised memory; ERR_UNSUPPORTED) -- the
+ * call returns an error with the records read so far in *out and the reason in blasr_hip_fasta_error. */
+int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out);
+int blasr_hip_fastq_parse(const char *text, int64_t length, blasr_hip_fasta **out);
+int blasr_hip_fastq_quality(const blasr_hip_fasta *fasta, int64_t i, const uint8_t **qual, int64_t *qual_length);
+const char *blasr_hip_fasta_error(const blasr_hip_fasta *fasta);
 int64_t blasr_hip_fasta_count(const blasr_hip_fasta *fasta);
 /* Record i; the pointers stay valid until blasr_hip_fasta_free.  Any output may be NULL. */
 int blasr_hip_fasta_record(const blasr_hip_fasta *fasta, int64_t i, const char **title, int64_t *title_length,

@@ -531,6 +531,33 @@ int ref_read_fasta_records(const char *path, unsigned char *seqOut, long seqCap,
   return n;
 }
 
+// FASTQReader::GetNext(FASTQSequence&) over a file (common/FASTQReader.h:27-66): titles joined by '\n', bases and quality
+// characters back to back, lengths; returns the number of records (-1: buffers too small).  NB the reference exit(0)s
+// on a record without its '+' line: the tests call this in a forked child.
+int ref_read_fastq_records(const char *path, unsigned char *seqOut, unsigned char *qualOut, long seqCap, long *lengths,
+                           int maxRecords, char *titles, long titlesCap) {
+  string name(path);
+  FASTQReader reader;
+  reader.Initialize(name);
+  int n = 0;
+  long at = 0;
+  string all;
+  for (;;) {
+    FASTQSequence seq;
+    if (!reader.GetNext(seq)) break;
+    if (n >= maxRecords || at + (long)seq.length > seqCap) return -1;
+    memcpy(seqOut + at, seq.seq, seq.length);
+    if (seq.length > 0) memcpy(qualOut + at, seq.qual.data, seq.length);
+    at += seq.length;
+    lengths[n++] = seq.length;
+    all += seq.title ? string(seq.title, seq.titleLength) : string();
+    all += "\n";
+  }
+  if ((long)all.size() + 1 > titlesCap) return -1;
+  memcpy(titles, all.c_str(), all.size() + 1);
+  return n;
+}
+
 // SuffixArray::Read: the index array and the lookup table of a .sa file.  out[0] = length, out[1] = lookupTableLength,
 // out[2] = lookupPrefixLength
 int ref_read_sa(const char *path, unsigned *index, long indexCap, unsigned *startPos, unsigned *endPos, long tableCap,

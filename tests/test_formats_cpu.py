@@ -83,6 +83,98 @@ def test_fasta_against_the_reference_reader(tmp_path):
         assert bytes(seq[: sum(lengths[j] for j in range(k))]) == b"".join(bytes(s) for _, s in recs), i
 
 
+def _ref_fastq_in_child(path):
+    """The reference's FASTQReader over `path`, in a forked child (it exit(0)s on a malformed record): the list of
+    (title, bases, qualities), or None when the child left without an answer."""
+    import pickle
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child
+        os.close(r)
+        ref = C.CDLL(REFMAPPER_SO)
+        seq, qual = np.zeros(1 << 20, np.uint8), np.zeros(1 << 20, np.uint8)
+        lengths = (C.c_long * 256)()
+        titles = C.create_string_buffer(1 << 16)
+        k = ref.ref_read_fastq_records(path.encode(), seq.ctypes.data_as(C.c_void_p), qual.ctypes.data_as(C.c_void_p),
+                                       C.c_long(len(seq)), lengths, 256, titles, C.c_long(len(titles)))
+        recs, at = [], 0
+        tl = titles.value.split(b"\n")
+        for j in range(max(k, 0)):
+            recs.append((tl[j], bytes(seq[at: at + lengths[j]]), bytes(qual[at: at + lengths[j]])))
+            at += lengths[j]
+        os.write(w, pickle.dumps((k, recs)))
+        os._exit(7)
+    os.close(w)
+    blob = b""
+    while True:
+        piece = os.read(r, 1 << 16)
+        if not piece:
+            break
+        blob += piece
+    os.close(r)
+    os.waitpid(pid, 0)
+    return pickle.loads(blob) if blob else None
+
+
+@pytest.mark.skipif(not os.path.exists(REFMAPPER_SO), reason="oracle/_ref/libblasr_refmapper.so not built")
+def test_fastq_against_the_reference_reader(tmp_path):
+    """FASTQReader::GetNext(FASTQSequence&) of this fork is not a FASTQ parser (after a title it looks for the NEXT '@':
+    a four-line file yields every second record, an '@' among the qualities starts a title there): the library
+    restates what it does, pinned here against the reference's own reader on plain, multi-line, awkward and random
+    files; where the reference exits (no '+' line) the library returns ERR_INVALID."""
+    rng = np.random.default_rng(21)
+
+    def rec(name, n, qual_chars=b"!#5<EIJ", lines=1):
+        s = bytes(rng.choice(list(b"ACGTN"), n).astype(np.uint8))
+        q = bytes(rng.choice(list(qual_chars), n).astype(np.uint8))
+        body = b"\n".join(s[i::lines] if False else s[i * (n // lines + 1):(i + 1) * (n // lines + 1)] for i in range(lines))
+        return b"@" + name + b"\n" + body.strip(b"\n") + b"\n+\n" + q + b"\n", s, q
+
+    files = {}
+    plain = [rec(b"read%d/%d/0_%d" % (i, i, 40 + i), 40 + i) for i in range(6)]
+    files["plain"] = b"".join(r[0] for r in plain)
+    files["one_record"] = plain[0][0]
+    files["two_records"] = plain[0][0] + plain[1][0]
+    files["multi_line"] = b"".join(rec(b"m%d desc with spaces" % i, 90, lines=3)[0] for i in range(4))
+    files["at_in_quality"] = b"".join(rec(b"q%d" % i, 50, qual_chars=b"@AB5")[0] for i in range(5))
+    files["junk_first"] = b"# a comment\n\n" + files["plain"]
+    files["no_final_newline"] = files["plain"].rstrip(b"\n")
+    files["crlf_titles"] = files["plain"].replace(b"\n+\n", b"\r\n+\n")
+    files["plus_with_name"] = b"".join(r[0].replace(b"\n+\n", b"\n+again\n") for r in plain)
+    files["long_quality"] = b"@a\nACGT\n+\nIIII\n@b\nACGTAC\n+\nIIIIIIJJJ\n@c\nAC\n+\nII\n@d\nGG\n+\nJJ\n"
+    files["empty"] = b""
+    files["only_title"] = b"@x\n"
+    for k in range(8):  # random mixtures of well-formed records, some with '@' among the qualities
+        files["random%d" % k] = b"".join(rec(b"r%d_%d" % (k, i), int(rng.integers(1, 120)),
+                                             qual_chars=b"@!5I" if rng.integers(0, 2) else b"!5I",
+                                             lines=int(rng.integers(1, 4)))[0] for i in range(int(rng.integers(1, 9))))
+    checked = 0
+    for name, blob in files.items():
+        path = write(tmp_path, name + ".fastq", blob)
+        want = _ref_fastq_in_child(path)
+        try:
+            got = hip.read_fastq(path)
+        except hip.BlasrHipError as e:
+            # the reference exited (no answer from the child), or went on with uninitialised quality bytes
+            assert want is None or e.code == hip.ERR_UNSUPPORTED, (name, e)
+            continue
+        assert want is not None, name
+        k, recs = want
+        assert k == len(got), (name, k, len(got))
+        for (t, s_, q), (wt, ws, wq) in zip(got, recs):
+            assert (t, bytes(s_), bytes(q)) == (wt, ws, wq), name
+        checked += len(got)
+    assert checked >= 12
+    # what the behaviour means on a plain file: records 2, 4, 6 of six
+    got = hip.read_fastq(text=files["plain"])
+    assert [t for t, _, _ in got] == [b"read1/1/0_41", b"read3/3/0_43", b"read5/5/0_45"]
+    assert [bytes(s_) for _, s_, _ in got] == [plain[1][1], plain[3][1], plain[5][1]]
+    assert [bytes(q) for _, _, q in got] == [plain[1][2], plain[3][2], plain[5][2]]
+    with pytest.raises(hip.BlasrHipError) as e:  # a record whose '+' line is missing: the reference exits
+        hip.read_fastq(text=b"@a\nAC\n+\nII\n@b\nACGT\n")
+    assert e.value.code == hip.ERR_INVALID
+
+
 @pytest.mark.skipif(not (os.path.exists(SAWRITER) and os.path.exists(REFMAPPER_SO)), reason="reference tools not built")
 def test_suffix_array_file_of_sawriter(tmp_path):
     """A .sa written by the reference's sawriter for a two-contig genome: the library reads the same index array and

@@ -36,6 +36,10 @@ def main():
                          "anchoring, SDPAlign and the refine loop through the C ABI, the rest its own code) and compare its lines")
     ap.add_argument("--sam", action="store_true", help="compare SAM records (-sam: CIGAR, flags, tags) instead of -m 4 lines")
     ap.add_argument("--variants", action="store_true", help="cycle through non-default switches (see the table in main)")
+    ap.add_argument("--fastq", action="store_true",
+                    help="hand the reads over as a FASTQ file: the reference reads it with its FASTQReader (every second "
+                         "record of a four-line file, FASTQReader.h:27-66), the library with blasr_hip_fastq_read; with --sam "
+                         "the records carry the quality strings")
     args = ap.parse_args()
     import blasr_amd
     from blasr_amd import hip, synth
@@ -142,9 +146,25 @@ def main():
                     f.write(">contig%d\n" % i)
                     for k in range(0, len(s), 60):
                         f.write(s[k:k + 60] + "\n")
-            with open(os.path.join(tmp, "reads.fasta"), "w") as f:
+            reads_file = "reads.fastq" if args.fastq else "reads.fasta"
+            quals = None
+            names = ["read%d/%d/0_%d" % (r, r, len(rd)) for r, rd in enumerate(reads)]
+            with open(os.path.join(tmp, reads_file), "w") as f:
                 for r, rd in enumerate(reads):
-                    f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(rd), bytes(rd).decode()))
+                    if args.fastq:  # (no '@' among the qualities: this reader takes one for a title start; tests/test_formats_cpu.py)
+                        q = bytes(rng.choice(list(b"!+5?IJ"), len(rd)).astype(np.uint8)).decode()
+                        f.write("@%s\n%s\n+\n%s\n" % (names[r], bytes(rd).decode(), q))
+                    else:
+                        f.write(">%s\n%s\n" % (names[r], bytes(rd).decode()))
+            if args.fastq:  # what the reference's reader makes of the file is what gets mapped
+                try:
+                    recs = hip.read_fastq(os.path.join(tmp, reads_file))
+                except hip.BlasrHipError:
+                    totals["fastq_outside_the_readers_domain"] = totals.get("fastq_outside_the_readers_domain", 0) + 1
+                    continue  # (an '@' among the qualities left a record the reference reads undefined memory for)
+                names = [t.decode() for t, _, _ in recs]
+                reads = [sq for _, sq, _ in recs]
+                quals = [q for _, _, q in recs]
             var = variants[it % len(variants)] if args.variants else variants[0]
             if args.dump >= 0:
                 print("iteration %d: variant %s, switches %s, files in %s" % (it, var["name"], var["cli"], tmp))
@@ -153,7 +173,7 @@ def main():
 
             def run_reference(extra, nproc, exe=None):
                 path = os.path.join(tmp, "out.m4")
-                p = subprocess.run([exe or blasr, os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "genome.fasta")] +
+                p = subprocess.run([exe or blasr, os.path.join(tmp, reads_file), os.path.join(tmp, "genome.fasta")] +
                                    (["-sam"] if args.sam else ["-m", "4"]) +
                                    ["-bestn", "1", "-nproc", str(nproc), "-out", path] + extra,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -171,7 +191,7 @@ def main():
             # run under -nproc > 1 (its interval finder reads one element past the end of a match list, i.e. whatever the
             # thread's previous read left there): a difference only counts when the one-thread run shows it too
             # (run lazily: only a difference asks for it, and by then the files are gone -- so keep their text)
-            fasta_text = {k: open(os.path.join(tmp, k)).read() for k in ("reads.fasta", "genome.fasta")}
+            fasta_text = {k: open(os.path.join(tmp, k)).read() for k in (reads_file, "genome.fasta")}
             ref1 = {}
 
             def one_thread(name):
@@ -182,7 +202,7 @@ def main():
                         for k, v in fasta_text.items():
                             open(os.path.join(tmp1, k), "w").write(v)
                         path = os.path.join(tmp1, "out.m4")
-                        p1 = subprocess.run([blasr, os.path.join(tmp1, "reads.fasta"), os.path.join(tmp1, "genome.fasta")] +
+                        p1 = subprocess.run([blasr, os.path.join(tmp1, reads_file), os.path.join(tmp1, "genome.fasta")] +
                                             (["-sam"] if args.sam else ["-m", "4"]) + ["-bestn", "1", "-nproc", "1", "-out", path] +
                                             switches[name], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                         ref1[name] = None if p1.returncode != 0 else sorted(
@@ -234,14 +254,15 @@ def main():
                                                          params=prm, min_align_length=var.get("min_align_length", 0),
                                                          min_map_qv=var.get("min_map_qv", 0), for_picard=args.sam,
                                                          unaligned=unaligned)):
-                nm = "read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r]))
+                nm = "%s/0_%d" % (names[r], len(reads[r]))
                 if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
                     got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r],
+                                                 quality=None if quals is None else quals[r],
                                                  clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n") for h in hits]
                 else:
                     got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
             if args.sam:  # PrintUnalignedRead for the reads MapRead left without an alignment
-                got += [hip.sam_unaligned_line("read%d/%d/0_%d/0_%d" % (r, r, len(reads[r]), len(reads[r])), read_group[0],
+                got += [hip.sam_unaligned_line("%s/0_%d" % (names[r], len(reads[r])), read_group[0],
                                                reads[r], clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n")
                         for r in unaligned]
             mine[name] = sorted(got)
