@@ -68,7 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 4), help="BASELINE.json configs[] index")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="BASELINE.json configs[] index (3 = configs[2]'s workload as configs[3] states it: 1 M reads in all, "
+                         "sharded over the ranks -- strong scaling, 125 k reads per rank at 8 GPUs)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the config's: 100000; 6250 for config 4)")
     ap.add_argument("--read-len", type=int, default=0, help="template bases per read (0 = the config's)")
     ap.add_argument("--band", type=int, default=16)
@@ -108,7 +110,7 @@ def config_defaults(args):
     c = args.config
     d = dict(reads=100000, read_len=10000, ins=0.11, dele=0.04, sub=0.01, families=0, spurious=0.0, loose=0.0,
              max_unanchored=300, hg=False, spurious_span=None)
-    if c == 2:
+    if c in (2, 3):
         # the reference's anchoring reports exactly one interval for a 10 kb read of a repeat-free genome (blasrmc -V 1
         # on 40 such reads): what competes on hg19 are the other copies of repeats; a few short chance clusters on top
         d.update(families=4000, spurious=0.25, hg=True)
@@ -117,6 +119,9 @@ def config_defaults(args):
         # plus eight or nine CHANCE clusters per read spanning 5-29 kb of the read and 17-41 kb of unrelated genome
         d.update(reads=6250, read_len=30000, ins=0.10, dele=0.05, sub=0.01, families=0, spurious=8.0, loose=0.0,
                  max_unanchored=300, hg=False, spurious_span=(0.15, 0.9, 0.55, 1.3))
+    if c == 3:  # configs[3]: 1 M reads in all, a contiguous 1/N shard per rank
+        d["reads"] = 1000000 // max(int(os.environ.get("WORLD_SIZE", "1") or 1), args.gpus, 1)
+        d["total_reads"] = 1000000
     if args.reads > 0:
         d["reads"] = args.reads
     if args.read_len > 0:
@@ -130,7 +135,8 @@ def config_defaults(args):
 
 def workload_label(args, d, genome_len, n_contigs):
     """config.workload, built from what actually ran."""
-    names = {1: "configs[1]", 2: "configs[2]", 4: "configs[4] (per-GPU share)"}
+    names = {1: "configs[1]", 2: "configs[2]", 3: "configs[3] (1 M reads in all, this many per GPU: strong scaling)",
+             4: "configs[4] (per-GPU share)"}
     return ("%s: %d synthetic %.0f kb reads per GPU (ins %.0f%%/del %.0f%%/sub %.0f%%) vs a %d-base synthetic genome "
             "(%d contig%s%s), %d planted repeat families, %.2f chance clusters per read%s%s, -sdpTupleSize 11, band %d, "
             "SMRT matrix, ins=del=5, open=50, ext=0, nCandidates 10; timed step = windows + SDP + sort/filter + refine "
@@ -407,6 +413,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     red_dev = "cpu" if shared else dev
+    if world > 1 and not shared:
+        # one process per GPU: every rank must sit on a device of its own
+        mine = torch.tensor([torch.cuda.current_device()], device=dev, dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ids = sorted(int(t.item()) for t in seen)
+        if len(set(ids)) != world:
+            raise SystemExit("bench.py: ranks share devices %s without --share-gpus" % ids)
 
     import blasr_amd
     from blasr_amd import hip, synth
@@ -515,7 +529,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.config == 3 and args.reads <= 0 else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic, generated on the device in %.0f s: %d-base i.i.d. genome with %d planted repeat families "

@@ -3,6 +3,11 @@
 //   map_fasta reads.fasta genome.fasta genome.fasta.sa [bestn] [-extend]   the whole mapper: anchoring included
 //   map_fasta reads.fasta genome.fasta intervals.txt   [bestn] [-extend]   candidate intervals given (e.g. blasrmc -V 1's)
 // -extend: the reference's switch of that name (both ends of every SDP alignment extended before the filters)
+// -start S -stride N: the reference's switches of those names (Blasr.cpp:4057-4058, ReaderAgglomerate::Advance): reads S,
+//   S + N, S + 2N, ... of the file -- how one process per GPU shares a read file: rank r of N runs with -start r -stride N
+//   -device r, and the outputs concatenated in rank order hold the lines of the one-process run
+// -device D: the HIP device to run on (default 0)
+// reads.fastq / reads.fq instead of reads.fasta: read as the reference's FASTQReader reads it (blasr_hip_fastq_read)
 //
 // What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
 //   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
@@ -32,11 +37,15 @@ static void die(const char *what, blasr_hip_ctx *ctx) {
 
 int main(int argc, char **argv) {
   if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta (genome.fasta.sa | intervals.txt) [bestn]", NULL);
-  int bestn = 1, extend = 0;
+  int bestn = 1, extend = 0, start = 0, stride = 1, device = 0;
   for (int i = 4; i < argc; i++) {
     if (strcmp(argv[i], "-extend") == 0) extend = 1;
+    else if (strcmp(argv[i], "-start") == 0 && i + 1 < argc) start = atoi(argv[++i]);
+    else if (strcmp(argv[i], "-stride") == 0 && i + 1 < argc) stride = atoi(argv[++i]);
+    else if (strcmp(argv[i], "-device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
     else bestn = atoi(argv[i]);
   }
+  if (start < 0 || stride < 1) die("-start needs a value >= 0, -stride one >= 1", NULL);
   // ---- genome: contigs back to back, an N after each, upper case; the contig table; names up to the first blank
   blasr_hip_fasta *gf = NULL, *rf = NULL;
   if (blasr_hip_fasta_read(argv[2], &gf) != BLASR_HIP_OK) die("cannot read the genome", NULL);
@@ -53,28 +62,34 @@ int main(int argc, char **argv) {
     contigNames.push_back(buf);
   }
   // ---- reads
-  if (blasr_hip_fasta_read(argv[1], &rf) != BLASR_HIP_OK) die("cannot read the reads", NULL);
-  const int nReads = (int)blasr_hip_fasta_count(rf);
-  std::vector<blasr_hip_read> reads((size_t)nReads);
+  const size_t rl = strlen(argv[1]);
+  const bool fastq = (rl > 6 && strcmp(argv[1] + rl - 6, ".fastq") == 0) || (rl > 3 && strcmp(argv[1] + rl - 3, ".fq") == 0);
+  if ((fastq ? blasr_hip_fastq_read(argv[1], &rf) : blasr_hip_fasta_read(argv[1], &rf)) != BLASR_HIP_OK)
+    die(rf ? blasr_hip_fasta_error(rf) : "cannot read the reads", NULL);
+  const int nInFile = (int)blasr_hip_fasta_count(rf);
+  std::vector<blasr_hip_read> reads;
   std::vector<uint8_t> pool;
   std::vector<std::string> readNames;
-  for (int r = 0; r < nReads; r++) {
+  for (int r = start; r < nInFile; r += stride) {  // this process's share of the file (-start / -stride)
     const uint8_t *s;
     int64_t n;
     char buf[1024];
     blasr_hip_fasta_record(rf, r, NULL, NULL, &s, &n);
     blasr_hip_fasta_name(rf, r, buf, sizeof(buf));
-    reads[r].off = (int64_t)pool.size();
-    reads[r].length = (uint32_t)n;
-    reads[r].subread_start = 0;
-    reads[r].subread_end = (uint32_t)n;
-    reads[r].reserved = 0;
+    blasr_hip_read rd;
+    rd.off = (int64_t)pool.size();
+    rd.length = (uint32_t)n;
+    rd.subread_start = 0;
+    rd.subread_end = (uint32_t)n;
+    rd.reserved = 0;
+    reads.push_back(rd);
     pool.insert(pool.end(), s, s + n);
     // the reference appends the subread's coordinates to the name it prints (SMRTSequence title handling)
     readNames.push_back(std::string(buf) + "/0_" + std::to_string((long long)n));
   }
+  const int nReads = (int)reads.size();
   blasr_hip_ctx *ctx = NULL;
-  if (blasr_hip_create(0, &ctx) != BLASR_HIP_OK) die("no gfx950 device", NULL);
+  if (blasr_hip_create(device, &ctx) != BLASR_HIP_OK) die("no gfx950 device", NULL);
   if (blasr_hip_upload_genome(ctx, genome.data(), genomeLen, nContigs > 1 ? starts.data() : NULL, nContigs > 1 ? (int32_t)nContigs : 0))
     die("upload_genome", ctx);
   // ---- candidate intervals: from the reads (a .sa file given) or from a text file
@@ -123,7 +138,9 @@ int main(int argc, char **argv) {
     if (!f) die("cannot read the intervals", NULL);
     long long rd, st, en, qs, qe, sd;
     while (fscanf(f, "%lld %lld %lld %lld %lld %lld", &rd, &st, &en, &qs, &qe, &sd) == 6) {
-      blasr_hip_interval iv = {(uint32_t)st, (uint32_t)en, (uint32_t)qs, (uint32_t)qe, (int32_t)rd, (int32_t)sd};
+      // (the file numbers the reads as they stand in the read file: keep this process's, renumbered)
+      if (rd < start || (rd - start) % stride != 0 || (rd - start) / stride >= nReads) continue;
+      blasr_hip_interval iv = {(uint32_t)st, (uint32_t)en, (uint32_t)qs, (uint32_t)qe, (int32_t)((rd - start) / stride), (int32_t)sd};
       ivs.push_back(iv);
     }
     fclose(f);
