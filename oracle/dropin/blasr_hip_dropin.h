@@ -18,8 +18,43 @@
 // one context per mapping thread, like MappingBuffers (Blasr.cpp:3238): created by the holder MapReads declares
 static __thread blasr_hip_ctx *tlsHipCtx = NULL;
 
+// ---- -useGPU -gpuBatch B: MapRead for whole BLOCKS of reads ----------------------------
+// A mapping thread pulls B reads from the reader (each under the reader's semaphore, as before), hands the block to
+// the library in ONE call -- blasr_hip_map_from_reads_host: anchoring, interval finding, AlignIntervals, the filters
+// and RefineAlignments for every read of the block -- and then walks the block read by read through the REST of
+// MapReads unchanged (subread bookkeeping, StoreMapQVs, the printers): where MapReads calls MapRead it gets the
+// alignments the block call left for that read.  The threads share ONE context (the index is on the device once;
+// blocks of different threads queue at a mutex while the other threads read ahead and print).
+struct BlasrHipBlock {
+  std::vector<SMRTSequence> reads;
+  std::vector<AlignmentContext> contexts;
+  std::vector<blasr_hip_hit> hits;
+  std::vector<int64_t> hitOff;
+  std::vector<uint8_t> seqArena;
+  std::vector<uint32_t> opsArena;
+  size_t n, next;
+  long current;  // the read MapReads is working on
+  BlasrHipBlock() : n(0), next(0), current(-1) {}
+};
+static __thread BlasrHipBlock *tlsHipBlock = NULL;
+struct BlasrHipShared {
+  pthread_mutex_t mu;
+  blasr_hip_ctx *ctx;
+  int users;
+  std::vector<int32_t> countTable;
+  std::vector<uint32_t> seqStarts;
+};
+static BlasrHipShared gHipShared = {PTHREAD_MUTEX_INITIALIZER, NULL, 0};
+
 struct BlasrHipThreadContext {
-  BlasrHipThreadContext(bool use, int device) {
+  BlasrHipThreadContext(bool use, int device, int batch = 0) {
+    if (use && batch > 0) {
+      tlsHipBlock = new BlasrHipBlock;
+      pthread_mutex_lock(&gHipShared.mu);
+      gHipShared.users++;
+      pthread_mutex_unlock(&gHipShared.mu);
+      return;
+    }
     if (use && blasr_hip_create(device, &tlsHipCtx) != BLASR_HIP_OK) {
       cout << "ERROR, no gfx950 device for -useGPU." << endl;
       exit(1);
@@ -28,6 +63,16 @@ struct BlasrHipThreadContext {
   ~BlasrHipThreadContext() {
     if (tlsHipCtx != NULL) blasr_hip_destroy(tlsHipCtx);
     tlsHipCtx = NULL;
+    if (tlsHipBlock != NULL) {
+      delete tlsHipBlock;
+      tlsHipBlock = NULL;
+      pthread_mutex_lock(&gHipShared.mu);
+      if (--gHipShared.users == 0 && gHipShared.ctx != NULL) {
+        blasr_hip_destroy(gHipShared.ctx);
+        gHipShared.ctx = NULL;
+      }
+      pthread_mutex_unlock(&gHipShared.mu);
+    }
   }
 };
 
@@ -266,5 +311,191 @@ static void MapReadToGenomeGPU(T_GenomeSeq &genome, T_SuffixArrayT &sarray, T_Se
   for (int64_t i = listOff[1]; i < listOff[2]; i++) rcMatchPosList.push_back(ChainedMatchPos(anchors[i].t, anchors[i].q, anchors[i].l));
   numKeysMatched = (int)matchPosList.size();
   rcNumKeysMatched = (int)rcMatchPosList.size();
+}
+
+// (defined further down in Blasr.cpp)
+template <typename T_Sequence>
+bool GetNextReadThroughSemaphore(ReaderAgglomerate &reader, MappingParameters &params, T_Sequence &read, AlignmentContext &context);
+void AssignRefContigLocations(vector<T_AlignmentCandidate *> &alignmentPtrs, SequenceIndexDatabase<FASTQSequence> &seqdb,
+                              DNASequence &genome);
+
+// One block through the library.  Everything the library needs of the mapper's state is read here: the genome and its
+// contig table (seqdb), the suffix array the mapper loaded or built, the switches of MappingParameters.
+template <typename T_GenomeSeq, typename T_SuffixArrayT>
+static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixArrayT &sarray,
+                             SequenceIndexDatabase<FASTQSequence> &seqdb, MappingParameters &params) {
+  std::vector<blasr_hip_read> reads(blk.n);
+  std::vector<uint8_t> pool;
+  int64_t seqCap = 4096;
+  for (size_t r = 0; r < blk.n; r++) {
+    blasr_hip_read rd = {(int64_t)pool.size(), blk.reads[r].length, 0, blk.reads[r].length, 0};
+    reads[r] = rd;
+    pool.insert(pool.end(), blk.reads[r].seq, blk.reads[r].seq + blk.reads[r].length);
+    seqCap += 4 * (5 * (int64_t)blk.reads[r].length / 2 + 1024);
+  }
+  if (pool.empty()) pool.push_back('N');
+  blasr_hip_pipeline_params pp;
+  blasr_hip_pipeline_default_params(&pp);
+  pp.anchor.min_match_length = params.anchorParameters.minMatchLength;
+  pp.anchor.min_prefix_match_length = params.lookupTableLength;
+  pp.anchor.expand = params.anchorParameters.expand;
+  pp.anchor.max_anchors_per_position = params.anchorParameters.maxAnchorsPerPosition;
+  pp.anchor.advance_exact_matches = params.anchorParameters.advanceExactMatches;
+  pp.anchor.max_lcp_length = params.anchorParameters.maxLCPLength;
+  pp.anchor.use_lookup_table = params.anchorParameters.useLookupTable;
+  pp.anchor.stop_mapping_once_unique = params.anchorParameters.stopMappingOnceUnique;
+  pp.interval.n_candidates = params.nCandidates;
+  pp.interval.min_interval = params.minInterval;
+  pp.interval.indel_rate = params.indelRate;
+  pp.interval.remove_contained_intervals = params.removeContainedIntervals;
+  pp.map.window.approximate_max_insertion_rate = params.approximateMaxInsertionRate;
+  pp.map.window.extend_ends = params.extendEnds;
+  pp.map.window.do_global_alignment = params.doGlobalAlignment;
+  blasr_hip_sdp_params sp = {params.sdpTupleSize, params.sdpIns, params.sdpDel, (float)(params.indelRate * 3), 0 /* Local */,
+                             params.detailedSDPAlignment, params.extendFrontAlignment, params.sdpPrefix, params.recurse,
+                             params.recurseOver, params.sdpMaxAnchorsPerPosition};
+  pp.map.sdp = sp;
+  BlasrHipScoreParams(params, pp.map.score);
+  pp.map.band = params.bandSize;
+  pp.map.n_candidates = params.nCandidates;
+  pp.map.max_gap = params.maxGap;
+  pp.map.max_score = params.maxScore;
+  pp.map.min_pct_identity = params.minPctIdentity;
+  pp.map.sort_refined = params.sortRefinedAlignments;
+  pp.map.extend_alignments = params.extendAlignments;
+  pp.map.extend_band_size = params.extendBandSize;
+  pp.map.max_extend_dropoff = params.maxExtendDropoff;
+  blk.hits.resize(blk.n * (size_t)std::max(params.nCandidates, 1) + 1);
+  blk.hitOff.assign(blk.n + 1, 0);
+  pthread_mutex_lock(&gHipShared.mu);
+  if (gHipShared.ctx == NULL) {  // first block of the run: the index goes to the device, once for all threads
+    const int nSeqPos = seqdb.nSeqPos > 0 ? seqdb.nSeqPos : 2;
+    gHipShared.seqStarts.resize(nSeqPos);
+    for (int i = 0; i < nSeqPos; i++) gHipShared.seqStarts[i] = seqdb.nSeqPos > 0 ? seqdb.seqStartPos[i] : (i ? genome.length : 0);
+    const int nContigs = nSeqPos - 1;
+    gHipShared.countTable.resize((size_t)1 << (2 * params.lookupTableLength));
+    if (blasr_hip_create(params.gpuDevice, &gHipShared.ctx) != BLASR_HIP_OK ||
+        blasr_hip_upload_genome(gHipShared.ctx, (const uint8_t *)genome.seq, genome.length,
+                                nContigs > 1 ? gHipShared.seqStarts.data() : NULL, nContigs > 1 ? nContigs : 0) != BLASR_HIP_OK ||
+        blasr_hip_upload_suffix_array(gHipShared.ctx, sarray.index, sarray.length, sarray.startPosTable, sarray.endPosTable,
+                                      sarray.lookupTableLength, sarray.lookupPrefixLength) != BLASR_HIP_OK ||
+        blasr_hip_count_tuples_device(gHipShared.ctx, params.lookupTableLength, gHipShared.countTable.data()) != BLASR_HIP_OK) {
+      cout << "ERROR, GPU set-up failed: " << (gHipShared.ctx ? blasr_hip_last_error(gHipShared.ctx) : "no gfx950 device") << endl;
+      exit(1);
+    }
+  }
+  int rc = BLASR_HIP_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    blk.seqArena.resize((size_t)seqCap);
+    blk.opsArena.resize((size_t)seqCap);
+    blasr_hip_map_fetch fetch = {blk.seqArena.data(), seqCap, 0, blk.opsArena.data(), seqCap, 0};
+    int64_t nHits = 0, nIvs = 0;
+    rc = blasr_hip_map_from_reads_host(gHipShared.ctx, (const uint8_t *)genome.seq, gHipShared.seqStarts.data(),
+                                       (int32_t)gHipShared.seqStarts.size(), gHipShared.countTable.data(), params.lookupTableLength,
+                                       (int32_t)blk.n, reads.data(), pool.data(), (int64_t)pool.size(), &pp, blk.hits.data(),
+                                       (int64_t)blk.hits.size(), &nHits, blk.hitOff.data(), &fetch, NULL, 0, &nIvs);
+    if (rc != BLASR_HIP_ERR_CAPACITY) break;
+    seqCap = std::max(fetch.seq_used, fetch.ops_used) + 4096;  // (rare: the arenas were a guess)
+  }
+  if (rc != BLASR_HIP_OK) {
+    cout << "ERROR, GPU mapping of a block failed: " << blasr_hip_last_error(gHipShared.ctx) << endl;
+    exit(1);
+  }
+  pthread_mutex_unlock(&gHipShared.mu);
+}
+
+// Replaces GetNextReadThroughSemaphore in MapReads (Blasr.cpp:3253): the next read of the thread's block; a new block is
+// pulled from the reader and mapped when the last one is used up.
+template <typename T_GenomeSeq, typename T_SuffixArrayT>
+static bool BlasrHipNextRead(ReaderAgglomerate &reader, MappingParameters &params, SMRTSequence &read, AlignmentContext &context,
+                             T_GenomeSeq &genome, T_SuffixArrayT &sarray, SequenceIndexDatabase<FASTQSequence> &seqdb) {
+  if (tlsHipBlock == NULL) return GetNextReadThroughSemaphore(reader, params, read, context);
+  BlasrHipBlock &blk = *tlsHipBlock;
+  if (blk.next >= blk.n) {
+    blk.reads.resize((size_t)params.gpuBatch);
+    blk.contexts.resize((size_t)params.gpuBatch);
+    blk.n = blk.next = 0;
+    while (blk.n < (size_t)params.gpuBatch && GetNextReadThroughSemaphore(reader, params, blk.reads[blk.n], blk.contexts[blk.n]))
+      blk.n++;
+    if (blk.n == 0) return false;
+    BlasrHipMapBlock(blk, genome, sarray, seqdb, params);
+  }
+  read = blk.reads[blk.next];  // (a copy: MapReads frees its read at the end of every turn)
+  blk.reads[blk.next].Free();
+  context = blk.contexts[blk.next];
+  blk.current = (long)blk.next++;
+  return true;
+}
+
+// Replaces the MapRead call of MapReads' subread loop (Blasr.cpp:3470-3496) under -gpuBatch: the alignments the block
+// call left for the current read, as T_AlignmentCandidates in the state MapRead leaves them (:2615-2644).
+template <typename T_GenomeSeq>
+static void BlasrHipCandidatesOfCurrentRead(SMRTSequence &read, SMRTSequence &readRC, T_GenomeSeq &genome,
+                                            SequenceIndexDatabase<FASTQSequence> &seqdb, MappingParameters &params,
+                                            std::vector<T_AlignmentCandidate *> &alignmentPtrs) {
+  BlasrHipBlock &blk = *tlsHipBlock;
+  if (read.subreadStart != 0 || read.subreadEnd != read.length) {
+    cout << "ERROR, -gpuBatch maps whole reads (no region table)." << endl;
+    exit(1);
+  }
+  for (int64_t i = blk.hitOff[blk.current]; i < blk.hitOff[blk.current + 1]; i++) {
+    const blasr_hip_hit &h = blk.hits[i];
+    T_AlignmentCandidate *a = new T_AlignmentCandidate;
+    a->tStrand = h.t_strand;
+    a->qStrand = 0;
+    a->tIndex = h.t_index;
+    a->tLength = h.t_length;
+    a->qLength = h.q_length;
+    a->tName = params.useSeqDB ? seqdb.GetSpaceDelimitedName(h.t_index) : genome.GetName();  // Blasr.cpp:1290, :1302
+    DNASequence tSeq;
+    tSeq.seq = new Nucleotide[h.t_aligned_seq_length + 1];
+    memcpy(tSeq.seq, blk.seqArena.data() + h.t_off, h.t_aligned_seq_length);
+    tSeq.length = h.t_aligned_seq_length;
+    tSeq.deleteOnExit = true;
+    a->tAlignedSeq.TakeOwnership(tSeq);
+    FASTQSequence qSeq;
+    qSeq.ReferenceSubstring(read, h.q_aligned_seq_pos, h.q_aligned_seq_length);
+    a->ReassignQSequence(qSeq);
+    a->tAlignedSeqPos = h.t_aligned_seq_pos;
+    a->qAlignedSeqPos = h.q_aligned_seq_pos;
+    a->tAlignedSeqLength = h.t_aligned_seq_length;
+    a->qAlignedSeqLength = h.q_aligned_seq_length;
+    a->tPos = h.t_pos;
+    a->qPos = h.q_pos;
+    a->blocks.clear();
+    a->gaps.clear();
+    a->gaps.push_back(GapList());
+    DNALength q = 0, t = 0;
+    for (int o = 0; o < h.n_ops; o++) {
+      const uint32_t op = blk.opsArena[h.ops_off + o], len = BLASR_HIP_OP_LEN(op);
+      if (BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_M) {
+        Block b;
+        b.qPos = q;
+        b.tPos = t;
+        b.length = len;
+        a->blocks.push_back(b);
+        a->gaps.push_back(GapList());
+        q += len;
+        t += len;
+      } else if (BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_I) {
+        a->gaps.back().push_back(Gap(Gap::Target, len));
+        q += len;
+      } else {
+        a->gaps.back().push_back(Gap(Gap::Query, len));
+        t += len;
+      }
+    }
+    a->score = h.score;
+    a->nCells = h.n_cells;
+    a->nMatch = h.n_match;
+    a->nMismatch = h.n_mismatch;
+    a->nIns = h.n_ins;
+    a->nDel = h.n_del;
+    a->pctSimilarity = h.pct_similarity;
+    if (params.forPicard) a->OrderGapsByType();                           // Blasr.cpp:2618-2623
+    a->qName = a->tStrand == 0 ? read.GetName() : readRC.GetName();       // :2629-2638
+    alignmentPtrs.push_back(a);
+  }
+  AssignRefContigLocations(alignmentPtrs, seqdb, genome);                 // :2640
 }
 #endif

@@ -4,14 +4,18 @@ reference's alignment/Blasr.cpp and alignment/MappingParameters.h (made at build
 committed: oracle/_ref is git-ignored), adds oracle/dropin/blasr_hip_dropin.h (the new code, ours), and links
 -lblasr_hip into oracle/_ref/blasrmc_gpu.  The edits are the ones a maintainer would make:
 
-  MappingParameters.h   two fields: bool useGPU (false), int gpuDevice (0)
+  MappingParameters.h   three fields: bool useGPU (false), int gpuDevice (0), int gpuBatch (0)
   Blasr.cpp             #include of the helper before AlignIntervals
                         AlignIntervals (:1716-1724)   SDPAlign + ComputeAlignmentStats -> SDPAlignCandidateGPU under -useGPU
                         AlignIntervals (:1826, :1885) ExtendAlignmentForward / Reverse (-extend) -> ExtendAlignmentGPU under -useGPU
                         RefineAlignments (:2164-2181) the per-candidate loop -> RefineAlignmentsGPU under -useGPU
                         MapRead (:2279-2297)          the two MapReadToGenome calls -> MapReadToGenomeGPU under -useGPU
                         MapReads (:3238)              one blasr_hip context per mapping thread, next to MappingBuffers
-                        main (:4023)                  -useGPU / -gpuDevice registered with the command-line parser
+                        MapReads (:3253, :3470)       -gpuBatch B: reads are pulled B at a time and mapped by ONE library call
+                                                      (BlasrHipNextRead); where MapReads calls MapRead it takes the block's
+                                                      alignments of that read (BlasrHipCandidatesOfCurrentRead); everything
+                                                      after MapRead -- StoreMapQVs, the printers -- is the reference's own
+                        main (:4023)                  -useGPU / -gpuDevice / -gpuBatch registered with the command-line parser
 Usage: python oracle/make_dropin.py [reference checkout]   (default /root/reference)"""
 import os
 import re
@@ -37,8 +41,8 @@ def main():
     os.makedirs(build, exist_ok=True)
     # ---- MappingParameters.h
     mp = open(os.path.join(src, "MappingParameters.h")).read()
-    mp = patch_once(mp, "\tbool useGuidedAlign;\n", "\tbool useGuidedAlign;\n\tbool useGPU;\n\tint gpuDevice;\n", "the fields")
-    mp = patch_once(mp, "\t\tuseGuidedAlign = true;\n", "\t\tuseGuidedAlign = true;\n\t\tuseGPU = false;\n\t\tgpuDevice = 0;\n",
+    mp = patch_once(mp, "\tbool useGuidedAlign;\n", "\tbool useGuidedAlign;\n\tbool useGPU;\n\tint gpuDevice;\n\tint gpuBatch;\n", "the fields")
+    mp = patch_once(mp, "\t\tuseGuidedAlign = true;\n", "\t\tuseGuidedAlign = true;\n\t\tuseGPU = false;\n\t\tgpuDevice = 0;\n\t\tgpuBatch = 0;\n",
                     "the defaults")
     open(os.path.join(build, "MappingParameters.h"), "w").write(mp)
     # MappingIPC.h pulls MappingParameters.h in by a quoted include, i.e. from its own directory first: an unchanged
@@ -75,12 +79,23 @@ def main():
                     "genomePrefixLength - 1, extendedAlignmentReverse, params, true) :\n"
                     "                         ExtendAlignmentReverse(readPrefix, readPrefix.length-1,\n", "the reverse extension")
     bl = patch_once(bl, "  MappingBuffers mappingBuffers;\n  while (true) {\n",
-                    "  MappingBuffers mappingBuffers;\n  BlasrHipThreadContext hipThreadContext(params.useGPU, params.gpuDevice);\n"
+                    "  MappingBuffers mappingBuffers;\n  BlasrHipThreadContext hipThreadContext(params.useGPU, params.gpuDevice, params.gpuBatch);\n"
                     "  while (true) {\n", "MapReads")
+    # -gpuBatch: reads in blocks (the reader call of MapReads, :3253), MapRead's results from the block (:3470-3496)
+    bl = patch_once(bl, "      if (GetNextReadThroughSemaphore(*mapData->reader, params, smrtRead, alignmentContext) == false) {\n",
+                    "      if (BlasrHipNextRead(*mapData->reader, params, smrtRead, alignmentContext, genome, sarray, seqdb) == false) {\n",
+                    "MapReads' reader call")
+    m = re.search(r"        MapRead\(subreadSequence, subreadSequenceRC, \n.*?                mapData           // Some values that are shared\n"
+                  r"\s*// across threads\.\n\s*\);\n", bl, flags=re.S)
+    if not m:
+        raise SystemExit("make_dropin: the MapRead call of MapReads' subread loop was not found")
+    bl = (bl[:m.start()] + "        if (params.useGPU and params.gpuBatch > 0) {\n          BlasrHipCandidatesOfCurrentRead(subreadSequence, "
+          "subreadSequenceRC, genome, seqdb, params, alignmentPtrs);\n        } else {\n" + m.group(0) + "        }\n" + bl[m.end():])
     bl = patch_once(bl, '  clp.RegisterFlagOption("noUseGuidedAlign", (bool*)&params.useGuidedAlign, "");\n',
                     '  clp.RegisterFlagOption("noUseGuidedAlign", (bool*)&params.useGuidedAlign, "");\n'
                     '  clp.RegisterFlagOption("useGPU", &params.useGPU, "");\n'
-                    '  clp.RegisterIntOption("gpuDevice", &params.gpuDevice, "", CommandLineParser::NonNegativeInteger);\n', "main")
+                    '  clp.RegisterIntOption("gpuDevice", &params.gpuDevice, "", CommandLineParser::NonNegativeInteger);\n'
+                    '  clp.RegisterIntOption("gpuBatch", &params.gpuBatch, "", CommandLineParser::NonNegativeInteger);\n', "main")
     open(os.path.join(build, "Blasr_gpu.cpp"), "w").write(bl)
     out = os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu")
     cmd = ["g++", "-O3", "-std=c++11", "-w", "-I", build, "-I", os.path.join(ROOT, "oracle", "dropin"), "-I", os.path.join(ROOT, "include"),

@@ -68,6 +68,27 @@ def test_patched_reference_binary_under_extend(tmp_path):
     assert not bad, bad[:3]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["-gpuBatch", "16", "-nproc", "2"], ["-gpuBatch", "4096", "-nproc", "1"],
+                                   ["-gpuBatch", "7", "-nproc", "3", "-extend"]])
+def test_patched_reference_binary_mapping_blocks_of_reads(tmp_path, extra):
+    """-useGPU -gpuBatch B: MapReads pulls B reads at a time from the reader and ONE library call maps the block
+    (anchoring, intervals, AlignIntervals, filters, RefineAlignments); StoreMapQVs and the printers stay the
+    reference's own, fed with alignment candidates rebuilt from the block's hits.  The lines are the unpatched binary's
+    -- with blocks smaller than the file (several blocks per thread, threads sharing the one context), with one block
+    for everything, and under -extend."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/blasrmc_gpu not built (needs /root/reference at build time)")
+    want = write_inputs(str(tmp_path))
+    if "-extend" in extra:
+        want = sorted(bytes(np.load(os.path.join(ROOT, "tests", "golden", "m4_noisy_extend_golden.npz"))["lines"]).decode().splitlines())
+    p, got = run(str(tmp_path), ["-useGPU"] + extra)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]
+
+
 def test_patched_reference_binary_without_the_flag_is_the_reference(tmp_path):
     """Without -useGPU the patched binary takes the reference's own code (the patch only adds branches), and with it
     but without a device it fails loudly instead of falling back."""

@@ -210,7 +210,9 @@ def main():
                 return ref1[name]
             if args.dropin:
                 for name, extra in switches.items():
-                    got = run_reference(extra + ["-useGPU"], 2, os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu"))
+                    # (odd iterations: -gpuBatch, MapReads pulling blocks of reads through ONE library call each)
+                    got = run_reference(extra + ["-useGPU"] + (["-gpuBatch", str(int(rng.integers(1, 300)))] if it % 2 else []), 2,
+                                        os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu"))
                     if got is None or ref[name] is None:
                         totals["dropin_failed"] = totals.get("dropin_failed", 0) + (got is None)
                         continue
