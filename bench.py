@@ -87,10 +87,11 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpus", action="store_true",
                     help="let the ranks share the GPUs that exist (rank r on device r mod devices, gloo for the counters): "
                          "runs the N-rank path with the real device step on a box with fewer GPUs; the line says so")
-    ap.add_argument("--from-reads", type=int, default=0, metavar="STEPS",
+    ap.add_argument("--from-reads", type=int, default=-1, metavar="STEPS",
                     help="after the timed steps, also run STEPS passes of the WHOLE mapper from the reads alone (index "
-                         "built on the device, suffix-array anchoring, interval finding on the host, then the path) and "
-                         "report them as `end_to_end` (N=1 only; needs ~130 GB of HBM for an hg19-size genome)")
+                         "built on the device before the timed steps, suffix-array anchoring, interval finding, then the "
+                         "path) and report them as `end_to_end` (N=1 only; needs ~130 GB of HBM for an hg19-size genome).  "
+                         "-1 = 1 pass at the default workload (config 2, one GPU, the config's own read count), else 0")
     ap.add_argument("--extend", action="store_true",
                     help="the reference's -extend (Blasr.cpp:1749-1940): both ends of every SDP alignment extended before "
                          "the first filter.  NOT the headline configuration; the CPU leg then runs the reference's "
@@ -312,7 +313,8 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     # threads while the device searches the next sub-block, then the path on all the intervals found
     ap = ctx.anchor_params(min_match_length=14, min_prefix_match_length=8)  # Blasr's values for a sawriter index
     ip = hip.interval_params(threads=min(64, os.cpu_count() or 1))
-    pp = ctx.pipeline_params(reads_per_block=6250, anchor=ap, interval=ip, map=params)
+    per_block = 6250 if os.environ.get("BLASR_HIP_INTERVALS_HOST") else 100000
+    pp = ctx.pipeline_params(reads_per_block=per_block, anchor=ap, interval=ip, map=params)
     hits = np.zeros(10 * n_reads, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     stages = {}
@@ -329,7 +331,7 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
         iv_off = np.concatenate([[0], np.cumsum(np.bincount(ivs["read"], minlength=n_reads))])
         last = dict(anchors=int(pt["anchors"]), intervals=int(len(ivs)), timing=ctx.map_last_timing(), ivs=ivs, iv_off=iv_off)
     wall = (time.perf_counter() - t_all) / steps
-    n_blocks = -(-n_reads // 6250)
+    n_blocks = -(-n_reads // per_block)
     # how many reads have their true locus among the candidate intervals (the synthetic set-up knows it)
     true_iv = wl["intervals"][wl["kind"] == 0]
     found = 0
@@ -370,6 +372,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     d = config_defaults(args)
+    if args.from_reads < 0:  # the whole-mapper leg rides along on the driver's default line only
+        args.from_reads = 1 if (args.config == 2 and args.gpus == 1 and args.reads <= 0 and args.read_len <= 0 and
+                                args.genome_len <= 0 and not args.stub_device and not args.load_workload) else 0
 
     import numpy as np
     import torch

@@ -96,6 +96,19 @@ int blasr_hip_extend_candidates(blasr_hip_ctx *ctx, int n, const blasr_hip_inter
                                 DevBuf &newSeq, DevBuf &newBlocks, DevBuf &scratch, DevBuf &opsBuf,
                                 int64_t *blocks_used);
 
+// what the device's interval finder hands to the host (intervals_device.hip -> intervals_api.hip): the chain of one
+// cluster of anchors -- its first and last anchor, the sum of its anchors' lengths, their number
+struct blasr_hip_iv_cluster {
+  uint32_t first_t, first_q, first_l, last_t, last_q, last_l;
+  int32_t sum_l, count;
+};
+int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                                      int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                      int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_iv_cluster *clusters,
+                                      const int64_t *cluster_off, const blasr_hip_interval_params *params,
+                                      blasr_hip_interval *intervals, float *p_values, int64_t capacity,
+                                      int64_t *n_intervals, int64_t *read_interval_off);
+
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
 
 #define HIP_TRY(ctx, expr)                                                                            \

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/blasr_hip.h"
+#include "ctx.h"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -125,19 +126,23 @@ int p_match(const Genome &g, uint32_t startPos, uint32_t length, float &pMatch) 
 
 // ComputeLISPValue (LISPValue.h:84-172): POneOrMoreMatches (ScoreAnchors.h:90-107) always succeeds and hands back
 // whatever PMatch left in pMatch
-float lis_p_value(const Genome &g, const std::vector<Match> &lis, int &lisNBases, int &lisSize) {
-  lisNBases = 0;
-  for (size_t i = 0; i < lis.size(); i++) lisNBases += (int)lis[i].l;
-  lisSize = (int)lis.size();
+// (the chain enters only through its first anchor and its number of anchors)
+float lis_p_value_core(const Genome &g, uint32_t firstT, uint32_t firstL, size_t count) {
   float p = 1;
-  p_match(g, lis[0].t, lis[0].l, p);
-  if (lis.size() == 1) return p;
+  p_match(g, firstT, firstL, p);
+  if (count == 1) return p;
   float pChain = p;
-  for (size_t i = 1; i < lis.size(); i++) {
+  for (size_t i = 1; i < count; i++) {
     const float qLambda = 1 / (1.0 * g.length);
     pChain = pChain + log(qLambda);
   }
   return pChain;
+}
+float lis_p_value(const Genome &g, const std::vector<Match> &lis, int &lisNBases, int &lisSize) {
+  lisNBases = 0;
+  for (size_t i = 0; i < lis.size(); i++) lisNBases += (int)lis[i].l;
+  lisSize = (int)lis.size();
+  return lis_p_value_core(g, lis[0].t, lis[0].l, lis.size());
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -567,6 +572,87 @@ void intervals_of_read(const Genome &g, const blasr_hip_read &rd, const blasr_hi
 }
 
 }  // namespace
+
+// The END of FindMaxIncreasingInterval for a block of reads (FindMaxInterval.h:776-840) from the chains the device
+// found (intervals_device.hip): per cluster of anchors, in StoreLargestIntervals' order, the chain's first and last anchor,
+// the sum of its anchors' lengths and their number -> the chain's p-value (ComputeLISPValue: double-precision logarithms
+// of the host's libm, which is why this part stays here), the tests of :805-825, and the read's WeightedIntervalSet.
+int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                                      int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                      int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_iv_cluster *clusters,
+                                      const int64_t *cluster_off, const blasr_hip_interval_params *params,
+                                      blasr_hip_interval *intervals, float *p_values, int64_t capacity,
+                                      int64_t *n_intervals, int64_t *read_interval_off) {
+  Genome g{genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size};
+  const blasr_hip_interval_params &P = *params;
+  std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
+  std::vector<std::vector<float>> perReadP((size_t)n_reads);
+  int threads = P.threads > 0 ? P.threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  threads = std::max(1, std::min(threads, n_reads));
+  auto work = [&](int tid) {
+    for (int32_t r = tid; r < n_reads; r += threads) {
+      IntervalSet queue;
+      for (int strand = 0; strand < 2; strand++) {
+        int noOvpLisNBases = 0;  // (declared outside the loop over the clusters in the reference, :690)
+        for (int64_t c = cluster_off[2 * r + strand]; c < cluster_off[2 * r + strand + 1]; c++) {
+          const blasr_hip_iv_cluster &k = clusters[c];
+          const int lisSize = k.sum_l;  // MatchListWeight
+          float lisPValue = 0;
+          if (k.count > 0) {
+            lisPValue = lis_p_value_core(g, k.first_t, k.first_l, (size_t)k.count);
+            noOvpLisNBases = k.sum_l;
+          }
+          noOvpLisNBases += k.sum_l;  // (:822-825: added to again)
+          if (lisPValue < P.max_p_value && lisSize > 0 && noOvpLisNBases > P.min_interval) {
+            Interval iv;
+            iv.size = (uint32_t)k.sum_l;
+            iv.start = k.first_t;
+            iv.end = k.last_t + k.last_l;
+            iv.readIndex = strand;
+            iv.pValue = lisPValue;
+            iv.qStart = k.first_q;
+            iv.qEnd = k.last_q + k.last_l;
+            iv.qLength = reads[r].length;
+            iv.nAnchors = k.count;
+            iv.totalAnchorSize = noOvpLisNBases;
+            insert_interval(queue, (size_t)P.n_candidates, iv);
+          }
+        }
+      }
+      if (P.remove_contained_intervals) remove_contained(queue);
+      for (IntervalSet::iterator it = queue.begin(); it != queue.end(); ++it) {
+        blasr_hip_interval iv;
+        iv.start = it->start;
+        iv.end = it->end;
+        iv.q_start = it->qStart;
+        iv.q_end = it->qEnd;
+        iv.read = r;
+        iv.strand = it->readIndex;
+        perRead[(size_t)r].push_back(iv);
+        perReadP[(size_t)r].push_back(it->pValue);
+      }
+    }
+  };
+  if (threads == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+    for (auto &t : pool) t.join();
+  }
+  int64_t total = 0;
+  for (int32_t r = 0; r < n_reads; r++) {
+    read_interval_off[r] = total;
+    for (size_t i = 0; i < perRead[(size_t)r].size(); i++, total++)
+      if (total < capacity) {
+        intervals[total] = perRead[(size_t)r][i];
+        if (p_values) p_values[total] = perReadP[(size_t)r][i];
+      }
+  }
+  read_interval_off[n_reads] = total;
+  *n_intervals = total;
+  return total > capacity ? BLASR_HIP_ERR_CAPACITY : BLASR_HIP_OK;
+}
 
 extern "C" {
 

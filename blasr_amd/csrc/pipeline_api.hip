@@ -1,17 +1,22 @@
 // The whole of MapRead for a block of reads, from the reads alone (alignment/Blasr.cpp:2247-2644): the anchoring
 // (anchor_api.hip), the interval finding (intervals_api.hip) and the path (mapread_api.hip) strung together in C++.
 //
-// The reads go through the anchoring in sub-blocks.  While the device searches sub-block b + 1, the anchors of
-// sub-block b cross PCIe on the side stream into pinned memory and a host thread (which fans out over the reads) turns
-// them into candidate intervals -- the reference does both per read on every mapping thread; here the device stage and
-// the host stage of consecutive sub-blocks overlap.  The path then runs once on all the intervals found.
+// The reads go through the anchoring in sub-blocks, and since round 3 a sub-block's anchors never leave the device:
+// blasr_hip_find_intervals_device (intervals_device.hip) runs RemoveOverlappingAnchors, the window clustering and
+// GlobalChain as kernels right behind the anchor search, one 32-byte record per cluster of anchors comes back and the
+// host ends with the p-values and the interval sets.  The path then runs once on all the intervals found.
+// (BLASR_HIP_INTERVALS_HOST=1 keeps round 2's route for comparison: while the device searches sub-block b + 1 the anchors
+// of sub-block b cross PCIe on the side stream into pinned memory and a host thread, which fans out over the reads, turns
+// them into candidate intervals with blasr_hip_find_intervals.)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -23,8 +28,10 @@ namespace {
 struct Job {
   int32_t first, count;     // reads [first, first + count)
   int64_t anchorOff;        // first anchor of the sub-block in the pinned buffer
+  const blasr_hip_anchor *pinned;  // the pinned buffer as it was when the job was queued
   std::vector<int64_t> listOff;
   hipEvent_t copied;
+  int copyError;            // a copy of the sub-block's anchors failed
 };
 
 double now_ms() {
@@ -40,7 +47,7 @@ int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) {
   blasr_hip_anchor_default_params(&p->anchor);
   blasr_hip_interval_default_params(&p->interval);
   blasr_hip_map_default_params(&p->map);
-  p->reads_per_block = 6250;
+  p->reads_per_block = 100000;  // (round 2: 6250, sized for the host's interval finding to keep up with the device)
   p->reserved = 0;
   return BLASR_HIP_OK;
 }
@@ -71,8 +78,69 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   blasr_hip_anchor_params ap = params->anchor;
   ap.sorted = 1;
   ap.forward_only = 0;
-  const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 6250;
+  const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 100000;
   const double t0 = now_ms();
+
+  if (!getenv("BLASR_HIP_INTERVALS_HOST")) {
+    // ---- anchors and intervals of every sub-block on the device; the anchor buffer is the same for all of them
+    std::vector<blasr_hip_interval> ivs;
+    std::vector<int64_t> listOff, ivOff;
+    std::vector<blasr_hip_interval> blockIvs;
+    int64_t anchorsInAll = 0;
+    double ivMs = 0;
+    for (int32_t first = 0; first < n_reads; first += perBlock) {
+      const int32_t count = std::min(perBlock, n_reads - first);
+      listOff.assign(2 * (size_t)count + 1, 0);
+      int64_t blockBases = 0;
+      for (int32_t r = first; r < first + count; r++) blockBases += reads_host[r].length;
+      int64_t expect = 2 * blockBases + 4096, n = 0;
+      int rcA = BLASR_HIP_OK;
+      for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rcA = blasr_hip_ensure(ctx, ctx->pipeAnchors, sizeof(blasr_hip_anchor) * (size_t)expect)) != BLASR_HIP_OK) return rcA;
+        rcA = blasr_hip_anchor_reads_device(ctx, count, reads_host + first, read_pool_device, &ap, (blasr_hip_anchor *)ctx->pipeAnchors.p,
+                                            (int64_t)(ctx->pipeAnchors.bytes / sizeof(blasr_hip_anchor)), &n, listOff.data());
+        if (rcA != BLASR_HIP_ERR_CAPACITY) break;
+        expect = n + n / 8 + 1;  // (the count a short call returns)
+      }
+      if (rcA != BLASR_HIP_OK) return rcA;
+      anchorsInAll += n;
+      const double h0 = now_ms();
+      blockIvs.resize((size_t)count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
+      ivOff.assign((size_t)count + 1, 0);
+      int64_t nIv = 0;
+      const int rcI = blasr_hip_find_intervals_device(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
+                                                      count_tuple_size, count, reads_host + first, (const blasr_hip_anchor *)ctx->pipeAnchors.p,
+                                                      listOff.data(), &params->interval, blockIvs.data(), nullptr,
+                                                      (int64_t)blockIvs.size(), &nIv, ivOff.data());
+      if (rcI != BLASR_HIP_OK) return rcI;
+      ivMs += now_ms() - h0;
+      for (int64_t i = 0; i < nIv; i++) {
+        blockIvs[(size_t)i].read += first;
+        ivs.push_back(blockIvs[(size_t)i]);
+      }
+    }
+    const double t1 = now_ms();
+    const int64_t total = (int64_t)ivs.size();
+    if (n_intervals) *n_intervals = total;
+    if (intervals_out) memcpy(intervals_out, ivs.data(), sizeof(blasr_hip_interval) * (size_t)std::min(total, intervals_capacity));
+    int rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(total + 1));
+    if (rc != BLASR_HIP_OK) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, ivs.data(), sizeof(blasr_hip_interval) * (size_t)total, hipMemcpyHostToDevice));
+    rc = blasr_hip_map_reads_device(ctx, n_reads, reads_device, read_pool_device, (int32_t)total,
+                                    (const blasr_hip_interval *)ctx->pipeIntervals.p, &params->map, hits, hits_capacity, n_hits,
+                                    read_hit_off, fetch);
+    const double t3 = now_ms();
+    ctx->pipeMs[0] = (float)(t1 - t0);  // anchoring + interval finding of all sub-blocks
+    ctx->pipeMs[1] = 0;
+    ctx->pipeMs[2] = (float)(t3 - t1);  // the path
+    ctx->pipeMs[3] = (float)ivMs;       // of [0]: the interval finding (kernels + the host's end)
+    ctx->pipeCounters[0] = anchorsInAll;
+    ctx->pipeCounters[1] = total;
+    if (rc == BLASR_HIP_OK && intervals_out && total > intervals_capacity)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: %lld intervals, capacity %lld", (long long)total,
+                            (long long)intervals_capacity);
+    return rc;
+  }
 
   // ---- the host stage: one thread takes the sub-blocks in order
   std::mutex mu;
@@ -83,7 +151,6 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   std::vector<std::vector<blasr_hip_interval>> blockIvs;
   std::vector<std::vector<int64_t>> blockIvOff;
   double hostMs = 0;
-  const blasr_hip_anchor *pinned = nullptr;  // set before the first job is queued
   std::thread worker([&]() {
     for (;;) {
       Job *job = nullptr;
@@ -94,19 +161,29 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
         job = queue.front();
         queue.pop_front();
       }
-      (void)hipSetDevice(ctx->device);
-      (void)hipEventSynchronize(job->copied);
-      const double h0 = now_ms();
-      std::vector<blasr_hip_interval> ivs((size_t)job->count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
-      std::vector<int64_t> off((size_t)job->count + 1);
-      int64_t n = 0;
-      const int rc = blasr_hip_find_intervals(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
-                                              count_tuple_size, job->count, reads_host + job->first,
-                                              pinned + job->anchorOff, job->listOff.data(), nullptr, &params->interval,
-                                              ivs.data(), nullptr, (int64_t)ivs.size(), &n, off.data());
-      ivs.resize((size_t)std::max<int64_t>(n, 0));
-      for (auto &iv : ivs) iv.read += job->first;
-      hostMs += now_ms() - h0;
+      int rc = BLASR_HIP_OK;
+      std::vector<blasr_hip_interval> ivs;
+      std::vector<int64_t> off;
+      try {
+        // (a failed copy would leave stale anchors in the pinned buffer: the sub-block is an error then)
+        if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(job->copied) != hipSuccess || job->copyError)
+          rc = BLASR_HIP_ERR_HIP;
+        const double h0 = now_ms();
+        if (rc == BLASR_HIP_OK) {
+          ivs.resize((size_t)job->count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
+          off.resize((size_t)job->count + 1);
+          int64_t n = 0;
+          rc = blasr_hip_find_intervals(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                        job->count, reads_host + job->first, job->pinned + job->anchorOff, job->listOff.data(),
+                                        nullptr, &params->interval, ivs.data(), nullptr, (int64_t)ivs.size(), &n, off.data());
+          ivs.resize((size_t)std::max<int64_t>(n, 0));
+          for (auto &iv : ivs) iv.read += job->first;
+        }
+        hostMs += now_ms() - h0;
+      } catch (const std::bad_alloc &) {
+        rc = BLASR_HIP_ERR_NOMEM;
+        ivs.clear();
+      }
       std::lock_guard<std::mutex> lock(mu);
       if (rc != BLASR_HIP_OK && hostError == BLASR_HIP_OK) hostError = rc;
       blockIvs.push_back(std::move(ivs));
@@ -123,8 +200,11 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   };
 
   // ---- the device stage
-  std::vector<Job> jobs((size_t)((n_reads + perBlock - 1) / perBlock));
-  for (auto &j : jobs) j.copied = nullptr;
+  // (an exception in this thread after the worker has started must not reach std::terminate through its joinable
+  //  handle, nor cross the C boundary: the body below runs inside try / catch)
+  int rc = BLASR_HIP_OK;
+  int64_t used = 0;
+  std::vector<Job> jobs;
   struct Cleanup {
     std::vector<Job> &jobs;
     ~Cleanup() {
@@ -132,8 +212,13 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
         if (j.copied) (void)hipEventDestroy(j.copied);
     }
   } cleanup{jobs};
-  int64_t used = 0;
-  int rc = BLASR_HIP_OK;
+  try {
+  jobs.resize((size_t)((n_reads + perBlock - 1) / perBlock));
+  for (auto &j : jobs) {
+    j.copied = nullptr;
+    j.pinned = nullptr;
+    j.copyError = 0;
+  }
   for (size_t b = 0; b < jobs.size() && rc == BLASR_HIP_OK; b++) {
     Job &j = jobs[b];
     j.first = (int32_t)(b * (size_t)perBlock);
@@ -189,7 +274,7 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
         ctx->pipePinned = p;
         ctx->pipePinnedBytes = bytes;
       }
-      pinned = (const blasr_hip_anchor *)ctx->pipePinned;
+      j.pinned = (const blasr_hip_anchor *)ctx->pipePinned;
       j.anchorOff = used;
       if (hipEventCreateWithFlags(&j.copied, hipEventDisableTiming) != hipSuccess) {
         rc = blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_from_reads: event");
@@ -200,8 +285,9 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       //  transfer, not behind the whole sub-block's 30)
       for (int64_t at = 0; at < n; at += (64ll << 20) / (int64_t)sizeof(blasr_hip_anchor)) {
         const int64_t m = std::min<int64_t>(n - at, (64ll << 20) / (int64_t)sizeof(blasr_hip_anchor));
-        (void)hipMemcpyAsync((blasr_hip_anchor *)ctx->pipePinned + used + at, (blasr_hip_anchor *)ctx->pipeAnchors.p + used + at,
-                             sizeof(blasr_hip_anchor) * (size_t)m, hipMemcpyDeviceToHost, ctx->sideStream);
+        if (hipMemcpyAsync((blasr_hip_anchor *)ctx->pipePinned + used + at, (blasr_hip_anchor *)ctx->pipeAnchors.p + used + at,
+                           sizeof(blasr_hip_anchor) * (size_t)m, hipMemcpyDeviceToHost, ctx->sideStream) != hipSuccess)
+          j.copyError = 1;
       }
       (void)hipEventRecord(j.copied, ctx->sideStream);
       {
@@ -212,6 +298,10 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       used += n;
       break;
     }
+  }
+  } catch (const std::bad_alloc &) {
+    finish_worker();
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "map_from_reads: out of host memory");
   }
   const double t1 = now_ms();
   finish_worker();

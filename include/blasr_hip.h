@@ -813,6 +813,18 @@ int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const
                              blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
                              int64_t *read_interval_off);
 
+/* The same with the anchors in DEVICE memory (what blasr_hip_anchor_reads_device wrote, sorted = 1; list_off, reads and
+ * everything else host): RemoveOverlappingAnchors, the sliding window of StoreLargestIntervals and GlobalChain run as
+ * kernels over all lists of the block (blasr_amd/csrc/intervals_device.hip); one 32-byte record per cluster of anchors
+ * comes back, and the host ends with the chains' p-values (its libm's logarithms) and the interval sets.  The element
+ * the reference reads one past a list nothing was removed from (`stale` above) is taken as zeros. */
+int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length,
+                                    const uint32_t *seq_start_pos, int32_t n_seq_pos, const int32_t *count_table,
+                                    int32_t count_tuple_size, int32_t n_reads, const blasr_hip_read *reads,
+                                    const blasr_hip_anchor *anchors_device, const int64_t *list_off,
+                                    const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
+                                    float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off);
+
 /* ------------------------------------------------------------------------------------------------
  * next-4: the suffix array and its lookup table built on the device, and sawriter's file written.  Replaces
  * LarssonBuildSuffixArray + BuildLookupTable (common/datastructures/suffixarray/SuffixArray.h:256-269, :193-249) as
@@ -847,7 +859,7 @@ typedef struct blasr_hip_pipeline_params {
   blasr_hip_anchor_params anchor;      /* sorted / forward_only are forced to 1 / 0 */
   blasr_hip_interval_params interval;
   blasr_hip_map_params map;
-  int32_t reads_per_block;             /* 6250 */
+  int32_t reads_per_block;             /* 100000 */
   int32_t reserved;
 } blasr_hip_pipeline_params;
 int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *params);
