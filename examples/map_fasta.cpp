@@ -90,7 +90,8 @@ int main(int argc, char **argv) {
   const int nReads = (int)reads.size();
   blasr_hip_ctx *ctx = NULL;
   if (blasr_hip_create(device, &ctx) != BLASR_HIP_OK) die("no gfx950 device", NULL);
-  if (blasr_hip_upload_genome(ctx, genome.data(), genomeLen, nContigs > 1 ? starts.data() : NULL, nContigs > 1 ? (int32_t)nContigs : 0))
+  // (the contig table also for a single contig: tLength is the contig's length, Blasr.cpp:1291, not the genome's with its N)
+  if (blasr_hip_upload_genome(ctx, genome.data(), genomeLen, starts.data(), (int32_t)nContigs))
     die("upload_genome", ctx);
   // ---- candidate intervals: from the reads (a .sa file given) or from a text file
   std::vector<blasr_hip_interval> ivs;

@@ -10,6 +10,9 @@
 #ifndef BLASR_HIP_DROPIN_H_
 #define BLASR_HIP_DROPIN_H_
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 
 #include <vector>
 
@@ -30,11 +33,30 @@ struct BlasrHipBlock {
   std::vector<AlignmentContext> contexts;
   std::vector<blasr_hip_hit> hits;
   std::vector<int64_t> hitOff;
-  std::vector<uint8_t> seqArena;
-  std::vector<uint32_t> opsArena;
+  // the hits' aligned sequences and op lists: grow-only buffers, NOT zero-filled (gigabytes per block otherwise, and a
+  // page-fault storm when several threads do it at once)
+  uint8_t *seqArena;
+  uint32_t *opsArena;
+  int64_t arenaCap;
   size_t n, next;
   long current;  // the read MapReads is working on
-  BlasrHipBlock() : n(0), next(0), current(-1) {}
+  BlasrHipBlock() : seqArena(NULL), opsArena(NULL), arenaCap(0), n(0), next(0), current(-1) {}
+  ~BlasrHipBlock() {
+    free(seqArena);
+    free(opsArena);
+  }
+  void Reserve(int64_t cap) {
+    if (cap <= arenaCap) return;
+    free(seqArena);
+    free(opsArena);
+    seqArena = (uint8_t *)malloc((size_t)cap);
+    opsArena = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)cap);
+    arenaCap = cap;
+    if (!seqArena || !opsArena) {
+      cout << "ERROR, out of memory for a block's alignments." << endl;
+      exit(1);
+    }
+  }
 };
 static __thread BlasrHipBlock *tlsHipBlock = NULL;
 struct BlasrHipShared {
@@ -331,7 +353,7 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
     blasr_hip_read rd = {(int64_t)pool.size(), blk.reads[r].length, 0, blk.reads[r].length, 0};
     reads[r] = rd;
     pool.insert(pool.end(), blk.reads[r].seq, blk.reads[r].seq + blk.reads[r].length);
-    seqCap += 4 * (5 * (int64_t)blk.reads[r].length / 2 + 1024);
+    seqCap += 2 * (5 * (int64_t)blk.reads[r].length / 2 + 1024);  // (a guess: about two alignments per read; corrected below)
   }
   if (pool.empty()) pool.push_back('N');
   blasr_hip_pipeline_params pp;
@@ -367,6 +389,7 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
   pp.map.max_extend_dropoff = params.maxExtendDropoff;
   blk.hits.resize(blk.n * (size_t)std::max(params.nCandidates, 1) + 1);
   blk.hitOff.assign(blk.n + 1, 0);
+  blk.Reserve(seqCap);
   pthread_mutex_lock(&gHipShared.mu);
   if (gHipShared.ctx == NULL) {  // first block of the run: the index goes to the device, once for all threads
     const int nSeqPos = seqdb.nSeqPos > 0 ? seqdb.nSeqPos : 2;
@@ -375,8 +398,9 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
     const int nContigs = nSeqPos - 1;
     gHipShared.countTable.resize((size_t)1 << (2 * params.lookupTableLength));
     if (blasr_hip_create(params.gpuDevice, &gHipShared.ctx) != BLASR_HIP_OK ||
+        // (the contig table also for a single contig: tLength is the contig's length, Blasr.cpp:1291, not the genome's with its N)
         blasr_hip_upload_genome(gHipShared.ctx, (const uint8_t *)genome.seq, genome.length,
-                                nContigs > 1 ? gHipShared.seqStarts.data() : NULL, nContigs > 1 ? nContigs : 0) != BLASR_HIP_OK ||
+                                params.useSeqDB ? gHipShared.seqStarts.data() : NULL, params.useSeqDB ? nContigs : 0) != BLASR_HIP_OK ||
         blasr_hip_upload_suffix_array(gHipShared.ctx, sarray.index, sarray.length, sarray.startPosTable, sarray.endPosTable,
                                       sarray.lookupTableLength, sarray.lookupPrefixLength) != BLASR_HIP_OK ||
         blasr_hip_count_tuples_device(gHipShared.ctx, params.lookupTableLength, gHipShared.countTable.data()) != BLASR_HIP_OK) {
@@ -385,10 +409,11 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
     }
   }
   int rc = BLASR_HIP_OK;
+  struct timespec ts0, ts1;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   for (int attempt = 0; attempt < 2; attempt++) {
-    blk.seqArena.resize((size_t)seqCap);
-    blk.opsArena.resize((size_t)seqCap);
-    blasr_hip_map_fetch fetch = {blk.seqArena.data(), seqCap, 0, blk.opsArena.data(), seqCap, 0};
+    blk.Reserve(seqCap);
+    blasr_hip_map_fetch fetch = {blk.seqArena, blk.arenaCap, 0, blk.opsArena, blk.arenaCap, 0};
     int64_t nHits = 0, nIvs = 0;
     rc = blasr_hip_map_from_reads_host(gHipShared.ctx, (const uint8_t *)genome.seq, gHipShared.seqStarts.data(),
                                        (int32_t)gHipShared.seqStarts.size(), gHipShared.countTable.data(), params.lookupTableLength,
@@ -401,6 +426,9 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
     cout << "ERROR, GPU mapping of a block failed: " << blasr_hip_last_error(gHipShared.ctx) << endl;
     exit(1);
   }
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  if (getenv("BLASR_HIP_DROPIN_TRACE"))
+    fprintf(stderr, "[dropin] block of %zu reads mapped in %.1f ms\n", blk.n, (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) / 1e6);
   pthread_mutex_unlock(&gHipShared.mu);
 }
 
@@ -415,8 +443,13 @@ static bool BlasrHipNextRead(ReaderAgglomerate &reader, MappingParameters &param
     blk.reads.resize((size_t)params.gpuBatch);
     blk.contexts.resize((size_t)params.gpuBatch);
     blk.n = blk.next = 0;
+    struct timespec tr0, tr1;
+    clock_gettime(CLOCK_MONOTONIC, &tr0);
     while (blk.n < (size_t)params.gpuBatch && GetNextReadThroughSemaphore(reader, params, blk.reads[blk.n], blk.contexts[blk.n]))
       blk.n++;
+    clock_gettime(CLOCK_MONOTONIC, &tr1);
+    if (getenv("BLASR_HIP_DROPIN_TRACE"))
+      fprintf(stderr, "[dropin] %zu reads read in %.1f ms\n", blk.n, (tr1.tv_sec - tr0.tv_sec) * 1e3 + (tr1.tv_nsec - tr0.tv_nsec) / 1e6);
     if (blk.n == 0) return false;
     BlasrHipMapBlock(blk, genome, sarray, seqdb, params);
   }
@@ -449,7 +482,7 @@ static void BlasrHipCandidatesOfCurrentRead(SMRTSequence &read, SMRTSequence &re
     a->tName = params.useSeqDB ? seqdb.GetSpaceDelimitedName(h.t_index) : genome.GetName();  // Blasr.cpp:1290, :1302
     DNASequence tSeq;
     tSeq.seq = new Nucleotide[h.t_aligned_seq_length + 1];
-    memcpy(tSeq.seq, blk.seqArena.data() + h.t_off, h.t_aligned_seq_length);
+    memcpy(tSeq.seq, blk.seqArena + h.t_off, h.t_aligned_seq_length);
     tSeq.length = h.t_aligned_seq_length;
     tSeq.deleteOnExit = true;
     a->tAlignedSeq.TakeOwnership(tSeq);
