@@ -77,7 +77,6 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   blasr_hip_anchor_params ap = params->anchor;
   ap.sorted = 1;
-  ap.forward_only = 0;
   const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 100000;
   const double t0 = now_ms();
 

@@ -658,7 +658,7 @@ typedef uint16_t __attribute__((aligned(1))) unaligned_u16;
 // the other candidates of the wavefront wait.  The row above moves between the LDS ring and the global ring when the
 // width class changes (at most kF4MaxWidth + 2 columns either way).
 template <int kL, bool kExt0, bool kHybrid>
-__global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillArgs args) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void fillp_kernel(RefineBatchView batch, FillArgs args) {
   constexpr int kT = 64 / kL;      // candidates per wavefront
   constexpr int kC = kF4Pass / kL;  // cells per lane and pass
   typedef typename std::conditional<kHybrid, uint32_t, unsigned short>::type RowB;
@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
   int2 *gRingG[kT];
   int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0, myGMask = 0;
   bool myPrevGlobal = false;  // the row above lives in the global ring (the last row was a wide one)
+  int mySkipUntil = 0;        // rows up to this one were taken ahead of their turn (a run of wide rows, below)
   int2 *myGRing = nullptr;
   const uint8_t *myTSeq = nullptr;
   uint8_t *myArrows = nullptr;
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
       const int lo = rec.y, width = (int)(wb & kWidthMask), qc = (int)(wb >> kQcShift);
       const int hiC = lo + width - 1;
       const bool isWide = kHybrid && width > kF4MaxWidth;
-      const bool rowAll = myTask >= 0 && r <= myQ;
+      const bool rowAll = myTask >= 0 && r <= myQ && (!kHybrid || r > mySkipUntil);
       if (kHybrid) {
         const unsigned long long wideMask = __ballot(rowAll && isWide);
         if (wideMask != 0ull && args.exp != 2) {
@@ -870,6 +871,183 @@ __global__ __launch_bounds__(256) void fillp_kernel(RefineBatchView batch, FillA
             auto pair_of = [](int2 v) { return (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32); };
             auto int2_of = [](unsigned long long p) { return make_int2((int)(uint32_t)p, (int)(uint32_t)(p >> 32)); };
             const int gmask = gMaskG[g];
+            // ---- A RUN of wide rows, the row above in REGISTERS.  The wide rows of a guide come in runs -- the gap rows
+            // between two blocks (GuidedAlign.h:193-250), a few hundred columns each, whose first column moves by 0 or 1
+            // from row to row.  Through the global ring every one of them waits for the stores of the row before it (a
+            // round trip through L2 per row, three candidates of the wavefront idle meanwhile).  Here the whole run is
+            // taken at once, ahead of the other candidates' turn: three consecutive cells per lane, 192 columns per step
+            // (the narrow pass's arithmetic on 64 lanes), up to three steps per row, the row above held as cell (step,
+            // lane, j) = column base + 3 (64 step + lane) + j and handed on by a lane shift.  A row wider than 576
+            // columns, or one that starts more than one column further on, ends the run and takes the ring path below.
+            {
+              constexpr int kW = 3, kWStep = 64 * kW, kRunSteps = 3, kRunMax = kRunSteps * kWStep;
+              const int nG = min(64, qG[g] - r0 + 1);  // rows of candidate g in this batch
+              int run = 0;
+              if (wHi - wLo + 1 <= kRunMax && wPhi - wLo + 1 <= kRunMax && args.exp != 3) {
+                int pS[kRunSteps][kW], pI[kRunSteps][kW];
+                int base = wLo, prevLo = wPlo, prevHi = wPhi;
+#pragma unroll
+                for (int k = 0; k < kRunSteps; k++)
+#pragma unroll
+                  for (int j = 0; j < kW; j++) {
+                    const int c = wLo + kW * (64 * k + lane) + j;
+                    const bool valid = c >= wPlo && c <= wPhi;
+                    int2 v = make_int2(inf, inf);
+                    if (wGlobal) v = int2_of(gring[c & gmask]);
+                    else if (k == 0) v = ringLds[wave][g][c & (kF4Ring - 1)];  // (a narrow row ends within the first step)
+                    pS[k][j] = valid ? v.x : inf;
+                    pI[k][j] = valid ? v.y : inf;
+                  }
+                int leftS = inf;  // S of the row above at column base - 1
+                if (wLo - 1 >= wPlo && wLo - 1 <= wPhi)
+                  leftS = wGlobal ? (int)(uint32_t)gring[(wLo - 1) & gmask] : ringLds[wave][g][(wLo - 1) & (kF4Ring - 1)].x;
+                leftS = __builtin_amdgcn_readfirstlane(leftS);
+                GByte *aBase = (GByte *)arrowsG[g];
+                const GByte *wT = (const GByte *)tSeqG[g];
+                const int wTLen = tLenG[g], tLast = max(wTLen - 1, 0);
+                for (int ii = i; ii < nG; ii++) {
+                  const int2 rrec = rowA[wave][g][ii];
+                  const unsigned rwb = rowB[wave][g][ii];
+                  const int rLo = __builtin_amdgcn_readfirstlane(rrec.y);
+                  const int rWidth = __builtin_amdgcn_readfirstlane((int)(rwb & kWidthMask));
+                  const int rQc = __builtin_amdgcn_readfirstlane((int)(rwb >> kQcShift));
+                  const int rHi = rLo + rWidth - 1, d = rLo - base;
+                  if (rWidth <= kF4MaxWidth || rWidth > kRunMax || d < 0 || d > 1) break;
+                  GByte *rowArrows = aBase + (unsigned)__builtin_amdgcn_readfirstlane(rrec.x);
+                  // the values that cross a step's edge, before the steps overwrite them
+                  int e63[kRunSteps], f0S[kRunSteps + 1], f0I[kRunSteps + 1];
+#pragma unroll
+                  for (int k = 0; k < kRunSteps; k++) {
+                    e63[k] = __builtin_amdgcn_readlane(pS[k][kW - 1], 63);
+                    f0S[k] = __builtin_amdgcn_readlane(pS[k][0], 0);
+                    f0I[k] = __builtin_amdgcn_readlane(pI[k][0], 0);
+                  }
+                  f0S[kRunSteps] = f0I[kRunSteps] = inf;
+                  int wCarryA = inf, wCarryB = inf;
+#pragma unroll
+                  for (int k = 0; k < kRunSteps; k++) {
+                    if (rLo + kWStep * k > rHi) break;
+                    const int c0 = rLo + kW * (64 * k + lane);
+                    int tRaw[kW];
+#pragma unroll
+                    for (int j = 0; j < kW; j++) tRaw[j] = (int)wT[min(max(c0 + j, 0), tLast)];
+                    int upS[kW], upI[kW], diagS[kW];
+                    if (d == 0) {
+                      int dg = wave_shr1(pS[k][kW - 1], inf);
+                      dg = lane == 0 ? (k == 0 ? leftS : e63[k == 0 ? 0 : k - 1]) : dg;
+                      diagS[0] = dg;
+#pragma unroll
+                      for (int j = 0; j < kW; j++) {
+                        upS[j] = pS[k][j];
+                        upI[j] = pI[k][j];
+                        if (j > 0) diagS[j] = pS[k][j - 1];
+                      }
+                    } else {
+#pragma unroll
+                      for (int j = 0; j < kW; j++) {
+                        diagS[j] = pS[k][j];
+                        if (j + 1 < kW) {
+                          upS[j] = pS[k][j + 1];
+                          upI[j] = pI[k][j + 1];
+                        }
+                      }
+                      upS[kW - 1] = wave_shl1(pS[k][0], f0S[k + 1]);
+                      upI[kW - 1] = wave_shl1(pI[k][0], f0I[k + 1]);
+                    }
+                    int m[kW], vKey[kW], insEK[kW], preA[kW], preB[kW];
+#pragma unroll
+                    for (int j = 0; j < kW; j++) {
+                      const int c = c0 + j;
+                      const bool upValid = c <= prevHi, diagValid = c - 1 <= prevHi && c - 1 >= prevLo;  // (c >= rLo >= prevLo)
+                      upS[j] = upValid ? upS[j] : inf;
+                      upI[j] = upValid ? upI[j] : inf;
+                      diagS[j] = diagValid ? diagS[j] : inf;
+                      const int tCur = (c >= 0 && c < wTLen) ? tRaw[j] : 'N';
+                      m[j] = rQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur & 255], (rQc & 3) * 8, 8)
+                                     : matN[base_code((unsigned)tCur)];
+                      const int matchK = (m[j] << kShift) + diagS[j];
+                      const int insSK = upS[j] + (kIns + AR_UP);
+                      insEK[j] = upI[j] + (kExt + AR_INS_CLOSE);
+                      vKey[j] = min(matchK, min(insSK, insEK[j]));
+                      const int v = vKey[j] & ~kTagMask;
+                      const int ia = v - (kW * lane + j) * kDel;
+                      const int ib = kExt0 ? v : v - (kW * lane + j) * kExt;
+                      preA[j] = j == 0 ? ia : min(preA[j - 1], ia);
+                      preB[j] = j == 0 ? ib : min(preB[j - 1], ib);
+                    }
+                    int pa = preA[kW - 1], pb = preB[kW - 1];
+                    wave_prefix_min2(pa, pb);
+                    int ea = wave_shr1(pa, inf), eb = wave_shr1(pb, inf);
+                    if (k > 0) {
+                      ea = min(ea, wCarryA);
+                      eb = min(eb, wCarryB);
+                    }
+                    uint32_t arrowLo = 0, arrowHi = 0;
+#pragma unroll
+                    for (int j = 0; j < kW; j++) {
+                      const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
+                      const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
+                      const int aK = eaj + ((kW * lane + j) * kDel + AR_LEFT);                              // S[c-1] + del
+                      const int bK = ebj + ((kExt0 ? 0 : (kW * lane + j) * kExt) + kOpen + AR_DEL_CLOSE);  // D[c-1] + ext
+                      const int sKey = min(vKey[j], min(aK, bK));
+                      const int sv = sKey & ~kTagMask;
+                      const int openKey = sv + (kOpen + AR_I_OPEN);
+                      const int iKey = min(openKey, kExt0 ? upI[j] : insEK[j] & ~kTagMask);
+                      const int dFlag = openKey < bK ? AR_D_OPEN : 0;
+                      const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag) & kTagMask;
+                      if (j < 2) arrowLo |= arrow << (8 * j); else arrowHi = arrow;
+                      pS[k][j] = sv;  // (cells beyond the row's end hold what no later row takes for a cell: prevHi)
+                      pI[k][j] = iKey & ~kTagMask;
+                    }
+                    if (c0 <= rHi) {  // three arrows per lane; those beyond the row's end land in the next row's space
+                      typedef unaligned_u16 __attribute__((address_space(1))) GU16;
+                      GByte *ap = rowArrows + (c0 - rLo);
+                      *(GU16 *)ap = (uint16_t)arrowLo;
+                      ap[2] = (uint8_t)arrowHi;
+                    }
+                    wCarryA = min(wCarryA, __builtin_amdgcn_readlane(pa, 63)) + kWStep * kDel;
+                    wCarryB = min(wCarryB, __builtin_amdgcn_readlane(pb, 63)) + kWStep * kExt;
+                  }
+                  base = prevLo = rLo;
+                  prevHi = rHi;
+                  leftS = inf;  // (column base - 1 lies left of the row just made)
+                  run++;
+                }
+                if (run > 0) {
+                  // ---- the run's last row: to where the next row will look for it
+                  bool toNarrow = false;
+                  int keepLo = prevLo, keepHi = prevHi;
+                  if (i + run < nG) {
+                    const int nLo = __builtin_amdgcn_readfirstlane(rowA[wave][g][i + run].y);
+                    const int nWidth = __builtin_amdgcn_readfirstlane((int)((unsigned)rowB[wave][g][i + run] & kWidthMask));
+                    if (nWidth <= kF4MaxWidth) {
+                      toNarrow = true;
+                      keepLo = max(keepLo, nLo - 1);
+                      keepHi = min(keepHi, nLo + nWidth - 1);
+                    }
+                  }
+#pragma unroll
+                  for (int k = 0; k < kRunSteps; k++)
+#pragma unroll
+                    for (int j = 0; j < kW; j++) {
+                      const int c = base + kW * (64 * k + lane) + j;
+                      if (c >= keepLo && c <= keepHi) {
+                        if (toNarrow) ringLds[wave][g][c & (kF4Ring - 1)] = make_int2(pS[k][j], pI[k][j]);
+                        else gring[c & gmask] = pair_of(make_int2(pS[k][j], pI[k][j]));
+                      }
+                    }
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  if (grp == g) {
+                    myPlo = prevLo;
+                    myPhi = prevHi;
+                    myPrevGlobal = !toNarrow;
+                    mySkipUntil = r0 + i + run - 1;
+                  }
+                  continue;  // (the next candidate with a wide row at this index, if any)
+                }
+              }
+            }
             if (!wGlobal) {  // the row above is a narrow one: from the LDS ring into the global ring
               for (int c = wPlo + lane; c <= wPhi; c += 64) gring[c & gmask] = pair_of(ringLds[wave][g][c & (kF4Ring - 1)]);
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

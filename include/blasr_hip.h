@@ -856,7 +856,7 @@ int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capa
  * intervals_out (may be NULL): the candidate intervals found, read by read.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct blasr_hip_pipeline_params {
-  blasr_hip_anchor_params anchor;      /* sorted / forward_only are forced to 1 / 0 */
+  blasr_hip_anchor_params anchor;      /* sorted is forced to 1 */
   blasr_hip_interval_params interval;
   blasr_hip_map_params map;
   int32_t reads_per_block;             /* 100000 */

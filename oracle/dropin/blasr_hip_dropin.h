@@ -366,6 +366,7 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
   pp.anchor.max_lcp_length = params.anchorParameters.maxLCPLength;
   pp.anchor.use_lookup_table = params.anchorParameters.useLookupTable;
   pp.anchor.stop_mapping_once_unique = params.anchorParameters.stopMappingOnceUnique;
+  pp.anchor.forward_only = params.forwardOnly;
   pp.interval.n_candidates = params.nCandidates;
   pp.interval.min_interval = params.minInterval;
   pp.interval.indel_rate = params.indelRate;
