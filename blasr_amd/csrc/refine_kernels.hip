@@ -905,6 +905,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 GByte *aBase = (GByte *)arrowsG[g];
                 const GByte *wT = (const GByte *)tSeqG[g];
                 const int wTLen = tLenG[g], tLast = max(wTLen - 1, 0);
+                // The target bases of the 576 columns from `base` on, three to a register like the cells (byte j of
+                // tP[step] = the base of cell (step, lane, j)), loaded once per run and handed on by the same lane shift
+                // as the row above: a load at the head of every step would expose its whole latency, once per step.
+                uint32_t tP[kRunSteps];
+#pragma unroll
+                for (int k = 0; k < kRunSteps; k++) {
+                  uint32_t b[kW];
+#pragma unroll
+                  for (int j = 0; j < kW; j++) b[j] = (uint32_t)wT[min(max(wLo + kW * (64 * k + lane) + j, 0), tLast)];
+                  tP[k] = b[0] | (b[1] << 8) | (b[2] << 16);
+                }
                 for (int ii = i; ii < nG; ii++) {
                   const int2 rrec = rowA[wave][g][ii];
                   const unsigned rwb = rowB[wave][g][ii];
@@ -914,6 +925,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                   const int rHi = rLo + rWidth - 1, d = rLo - base;
                   if (rWidth <= kF4MaxWidth || rWidth > kRunMax || d < 0 || d > 1) break;
                   GByte *rowArrows = aBase + (unsigned)__builtin_amdgcn_readfirstlane(rrec.x);
+                  if (d == 1) {  // the window of bases moves one column on: column base + 576 enters at its end
+                    const uint32_t entering = (uint32_t)wT[min(max(base + kRunMax, 0), tLast)];
+                    uint32_t first[kRunSteps + 1];
+#pragma unroll
+                    for (int k = 0; k < kRunSteps; k++) first[k] = (uint32_t)__builtin_amdgcn_readlane((int)tP[k], 0) & 0xffu;
+                    first[kRunSteps] = entering;
+#pragma unroll
+                    for (int k = 0; k < kRunSteps; k++)
+                      tP[k] = (tP[k] >> 8) | (((uint32_t)wave_shl1((int)tP[k], (int)first[k + 1]) & 0xffu) << 16);
+                  }
                   // the values that cross a step's edge, before the steps overwrite them
                   int e63[kRunSteps], f0S[kRunSteps + 1], f0I[kRunSteps + 1];
 #pragma unroll
@@ -928,9 +949,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                   for (int k = 0; k < kRunSteps; k++) {
                     if (rLo + kWStep * k > rHi) break;
                     const int c0 = rLo + kW * (64 * k + lane);
-                    int tRaw[kW];
-#pragma unroll
-                    for (int j = 0; j < kW; j++) tRaw[j] = (int)wT[min(max(c0 + j, 0), tLast)];
                     int upS[kW], upI[kW], diagS[kW];
                     if (d == 0) {
                       int dg = wave_shr1(pS[k][kW - 1], inf);
@@ -962,7 +980,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                       upS[j] = upValid ? upS[j] : inf;
                       upI[j] = upValid ? upI[j] : inf;
                       diagS[j] = diagValid ? diagS[j] : inf;
-                      const int tCur = (c >= 0 && c < wTLen) ? tRaw[j] : 'N';
+                      const int tCur = (c >= 0 && c < wTLen) ? (int)((tP[k] >> (8 * j)) & 0xffu) : 'N';
                       m[j] = rQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur & 255], (rQc & 3) * 8, 8)
                                      : matN[base_code((unsigned)tCur)];
                       const int matchK = (m[j] << kShift) + diagS[j];
