@@ -913,7 +913,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 for (int k = 0; k < kRunSteps; k++) {
                   uint32_t b[kW];
 #pragma unroll
-                  for (int j = 0; j < kW; j++) b[j] = (uint32_t)wT[min(max(wLo + kW * (64 * k + lane) + j, 0), tLast)];
+                  for (int j = 0; j < kW; j++) {
+                    const int c = wLo + kW * (64 * k + lane) + j;
+                    b[j] = (uint32_t)wT[min(max(c, 0), tLast)];
+                    b[j] = (c >= 0 && c < wTLen) ? b[j] : (uint32_t)'N';  // (beyond the target: N, decided here once)
+                  }
                   tP[k] = b[0] | (b[1] << 8) | (b[2] << 16);
                 }
                 for (int ii = i; ii < nG; ii++) {
@@ -926,7 +930,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                   if (rWidth <= kF4MaxWidth || rWidth > kRunMax || d < 0 || d > 1) break;
                   GByte *rowArrows = aBase + (unsigned)__builtin_amdgcn_readfirstlane(rrec.x);
                   if (d == 1) {  // the window of bases moves one column on: column base + 576 enters at its end
-                    const uint32_t entering = (uint32_t)wT[min(max(base + kRunMax, 0), tLast)];
+                    uint32_t entering = (uint32_t)wT[min(max(base + kRunMax, 0), tLast)];
+                    entering = (base + kRunMax >= 0 && base + kRunMax < wTLen) ? entering : (uint32_t)'N';
                     uint32_t first[kRunSteps + 1];
 #pragma unroll
                     for (int k = 0; k < kRunSteps; k++) first[k] = (uint32_t)__builtin_amdgcn_readlane((int)tP[k], 0) & 0xffu;
@@ -980,9 +985,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                       upS[j] = upValid ? upS[j] : inf;
                       upI[j] = upValid ? upI[j] : inf;
                       diagS[j] = diagValid ? diagS[j] : inf;
-                      const int tCur = (c >= 0 && c < wTLen) ? (int)((tP[k] >> (8 * j)) & 0xffu) : 'N';
-                      m[j] = rQc < 4 ? (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur & 255], (rQc & 3) * 8, 8)
-                                     : matN[base_code((unsigned)tCur)];
+                      const int tCur = (int)((tP[k] >> (8 * j)) & 0xffu);
+                      if (rQc < 4) m[j] = (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur], (rQc & 3) * 8, 8);  // (uniform)
+                      else m[j] = matN[base_code((unsigned)tCur)];
                       const int matchK = (m[j] << kShift) + diagS[j];
                       const int insSK = upS[j] + (kIns + AR_UP);
                       insEK[j] = upI[j] + (kExt + AR_INS_CLOSE);
