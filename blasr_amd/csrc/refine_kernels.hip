@@ -977,14 +977,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                       upS[kW - 1] = wave_shl1(pS[k][0], f0S[k + 1]);
                       upI[kW - 1] = wave_shl1(pI[k][0], f0I[k + 1]);
                     }
+                    // cells of the row above that do not exist: only a step that reaches beyond that row's ends has any
+                    if (!(rLo + kWStep * k - 1 >= prevLo && rLo + kWStep * (k + 1) - 1 <= prevHi)) {
+#pragma unroll
+                      for (int j = 0; j < kW; j++) {
+                        const int c = c0 + j;
+                        const bool upValid = c <= prevHi, diagValid = c - 1 <= prevHi && c - 1 >= prevLo;  // (c >= rLo >= prevLo)
+                        upS[j] = upValid ? upS[j] : inf;
+                        upI[j] = upValid ? upI[j] : inf;
+                        diagS[j] = diagValid ? diagS[j] : inf;
+                      }
+                    }
                     int m[kW], vKey[kW], insEK[kW], preA[kW], preB[kW];
 #pragma unroll
                     for (int j = 0; j < kW; j++) {
-                      const int c = c0 + j;
-                      const bool upValid = c <= prevHi, diagValid = c - 1 <= prevHi && c - 1 >= prevLo;  // (c >= rLo >= prevLo)
-                      upS[j] = upValid ? upS[j] : inf;
-                      upI[j] = upValid ? upI[j] : inf;
-                      diagS[j] = diagValid ? diagS[j] : inf;
                       const int tCur = (int)((tP[k] >> (8 * j)) & 0xffu);
                       if (rQc < 4) m[j] = (int)__builtin_amdgcn_sbfe((int)packedByChar[tCur], (rQc & 3) * 8, 8);  // (uniform)
                       else m[j] = matN[base_code((unsigned)tCur)];
