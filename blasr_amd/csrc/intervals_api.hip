@@ -404,6 +404,7 @@ struct Interval {
   int readIndex;
   float pValue;
   int nAnchors, totalAnchorSize;
+  std::vector<uint32_t> chain;  // WeightedInterval::matches as (t, q, l) triplets -- only kept when the caller asks for them
 };
 struct IntervalByPValue {  // CompareWeightedIntervalByPValue (:121-131)
   bool operator()(const Interval &a, const Interval &b) const {
@@ -493,7 +494,7 @@ void remove_contained(IntervalSet &set) {
 // reference finds past the end of its vector).
 void find_max_increasing_interval(const Genome &g, int readDir, std::vector<Match> &pos, uint32_t nPos,
                                   uint32_t intervalLength, size_t nBest, const blasr_hip_interval_params &P,
-                                  uint32_t queryLength, IntervalSet &queue, Chainer &chainer) {
+                                  uint32_t queryLength, IntervalSet &queue, Chainer &chainer, bool keepChains) {
   if (nPos == 0) return;
   int noOvpLisSize = 0, noOvpLisNBases = 0;
   std::vector<uint32_t> start, end, lisIndices;
@@ -529,6 +530,10 @@ void find_max_increasing_interval(const Genome &g, int readDir, std::vector<Matc
       iv.qLength = queryLength;
       iv.nAnchors = noOvpLisSize;
       iv.totalAnchorSize = noOvpLisNBases;
+      if (keepChains) {
+        iv.chain.reserve(3 * lis.size());
+        for (size_t i = 0; i < lis.size(); i++) iv.chain.push_back(lis[i].t), iv.chain.push_back(lis[i].q), iv.chain.push_back(lis[i].l);
+      }
       insert_interval(queue, nBest, iv);
     }
   }
@@ -536,7 +541,8 @@ void find_max_increasing_interval(const Genome &g, int readDir, std::vector<Matc
 
 void intervals_of_read(const Genome &g, const blasr_hip_read &rd, const blasr_hip_anchor *anchors, const int64_t *off,
                        const blasr_hip_anchor *stale, const blasr_hip_interval_params &P, int readIndex,
-                       std::vector<blasr_hip_interval> &out, std::vector<float> &pValues) {
+                       std::vector<blasr_hip_interval> &out, std::vector<float> &pValues,
+                       std::vector<std::vector<uint32_t>> *chains) {
   // Blasr.cpp:2402-2406
   const uint32_t span = rd.subread_end - rd.subread_start;
   uint32_t intervalLength = (uint32_t)(span * (1 + P.indel_rate));
@@ -555,7 +561,7 @@ void intervals_of_read(const Genome &g, const blasr_hip_read &rd, const blasr_hi
     pos[(size_t)n] = stale ? Match{stale[strand].t, stale[strand].q, stale[strand].l, 0, -1} : Match{0, 0, 0, 0, -1};
     const uint32_t nPos = remove_overlapping_anchors(pos, (uint32_t)n);
     find_max_increasing_interval(g, strand, pos, nPos, intervalLength, (size_t)P.n_candidates, P, rd.length, queue,
-                                 chainer);
+                                 chainer, chains != nullptr);
   }
   if (P.remove_contained_intervals) remove_contained(queue);
   for (IntervalSet::iterator it = queue.begin(); it != queue.end(); ++it) {
@@ -568,6 +574,7 @@ void intervals_of_read(const Genome &g, const blasr_hip_read &rd, const blasr_hi
     iv.strand = it->readIndex;
     out.push_back(iv);
     pValues.push_back(it->pValue);
+    if (chains) chains->push_back(it->chain);
   }
 }
 
@@ -688,12 +695,15 @@ int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t
   return BLASR_HIP_OK;
 }
 
-int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
-                             int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
-                             const blasr_hip_read *reads, const blasr_hip_anchor *anchors, const int64_t *list_off,
-                             const blasr_hip_anchor *stale, const blasr_hip_interval_params *params,
-                             blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
-                             int64_t *read_interval_off) {
+int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                    int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_anchor *anchors,
+                                    const int64_t *list_off, const blasr_hip_anchor *stale,
+                                    const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
+                                    float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
+                                    uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) {
+  const bool keep = chains_used != nullptr;
+  if (keep && (chains_capacity < 0 || (chains_capacity > 0 && !chains) || (capacity > 0 && !chain_off))) return BLASR_HIP_ERR_INVALID;
   if (!genome || genome_length <= 0 || genome_length >= (1ll << 32) || !seq_start_pos || n_seq_pos < 1 || !count_table ||
       count_tuple_size < 1 || count_tuple_size > 14 || n_reads < 0 || !params || !n_intervals || !read_interval_off ||
       capacity < 0 || (capacity > 0 && !intervals) || (n_reads > 0 && (!reads || !list_off)))
@@ -707,12 +717,13 @@ int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const
   Genome g{genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size};
   std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
   std::vector<std::vector<float>> perReadP((size_t)n_reads);
+  std::vector<std::vector<std::vector<uint32_t>>> perReadChains(keep ? (size_t)n_reads : 0);
   int threads = params->threads > 0 ? params->threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   threads = std::max(1, std::min(threads, n_reads));
   auto work = [&](int tid) {
     for (int32_t r = tid; r < n_reads; r += threads)
       intervals_of_read(g, reads[r], anchors, list_off + 2 * r, stale ? stale + 2 * r : nullptr, *params, r,
-                        perRead[(size_t)r], perReadP[(size_t)r]);
+                        perRead[(size_t)r], perReadP[(size_t)r], keep ? &perReadChains[(size_t)r] : nullptr);
   };
   if (threads == 1) {
     work(0);
@@ -721,18 +732,41 @@ int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const
     for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
     for (auto &t : pool) t.join();
   }
-  int64_t total = 0;
+  int64_t total = 0, words = 0;
   for (int32_t r = 0; r < n_reads; r++) {
     read_interval_off[r] = total;
-    for (size_t i = 0; i < perRead[(size_t)r].size(); i++, total++)
+    for (size_t i = 0; i < perRead[(size_t)r].size(); i++, total++) {
       if (total < capacity) {
         intervals[total] = perRead[(size_t)r][i];
         if (p_values) p_values[total] = perReadP[(size_t)r][i];
       }
+      if (keep) {
+        const std::vector<uint32_t> &c = perReadChains[(size_t)r][i];
+        if (total < capacity) chain_off[total] = words / 3;
+        if (words + (int64_t)c.size() <= 3 * chains_capacity && !c.empty()) memcpy(chains + words, c.data(), sizeof(uint32_t) * c.size());
+        words += (int64_t)c.size();
+      }
+    }
   }
   read_interval_off[n_reads] = total;
   *n_intervals = total;
+  if (keep) {
+    if (total <= capacity && capacity > 0) chain_off[total] = words / 3;
+    *chains_used = words / 3;
+    if (words > 3 * chains_capacity) return BLASR_HIP_ERR_CAPACITY;
+  }
   return total > capacity ? BLASR_HIP_ERR_CAPACITY : BLASR_HIP_OK;
+}
+
+int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                             int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
+                             const blasr_hip_read *reads, const blasr_hip_anchor *anchors, const int64_t *list_off,
+                             const blasr_hip_anchor *stale, const blasr_hip_interval_params *params,
+                             blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
+                             int64_t *read_interval_off) {
+  return blasr_hip_find_intervals_chains(genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                         n_reads, reads, anchors, list_off, stale, params, intervals, p_values, capacity,
+                                         n_intervals, read_interval_off, nullptr, 0, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -175,6 +175,9 @@ int blasr_hip_map_default_params(blasr_hip_map_params *p) {
   p->max_score = -200;
   p->min_pct_identity = 0;
   p->sort_refined = 1;
+  p->refine_between_anchors_only = 0;  // MappingParameters.h:298
+  p->indel = 5;                        // :195
+  p->sdp_bypass_threshold = 1000000.0f;  // :316
   return BLASR_HIP_OK;
 }
 
@@ -211,6 +214,9 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
   if (prm->window.do_global_alignment)  // -global replaces the refiner by KBandAlign over the whole window (:811-831)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "map_reads: doGlobalAlignment is not built into the driver "
                           "(blasr_hip_windows_* and blasr_hip_kband_linear_* cover its pieces)");
+  if (prm->refine_between_anchors_only && n_iv > 0 && !prm->iv_chain_off)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_reads: refine_between_anchors_only needs the intervals' chained "
+                          "anchors (iv_chains / iv_chain_off, from blasr_hip_find_intervals_chains)");
   if (n_iv == 0) return BLASR_HIP_OK;
   if (!ctx->genome) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_reads: no genome resident");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -274,8 +280,22 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = blasr_hip_ensure(ctx, mb[MB_BLOCKS], sizeof(int32_t) * 3 * (size_t)blkCap))) return rc;
     blkCap = (int64_t)(mb[MB_BLOCKS].bytes / (3 * sizeof(int32_t)));
-    rc = blasr_hip_sdp_device(ctx, &sb, &prm->sdp, &prm->score, (blasr_hip_sdp_result *)mb[MB_SDPRES].p,
-                              (int32_t *)mb[MB_BLOCKS].p, blkCap, &blkUsed);
+    if (prm->refine_between_anchors_only) {  // -rbao (:1354-1712): alignments between the chained anchors instead
+      blasr_hip_rbao_params rp;
+      memset(&rp, 0, sizeof(rp));
+      rp.sdp = prm->sdp;
+      rp.score = prm->score;
+      rp.band = prm->band;
+      rp.indel = prm->indel;
+      rp.sdp_bypass_threshold = prm->sdp_bypass_threshold;
+      rc = blasr_hip_align_between_anchors_device(ctx, &sb, (const blasr_hip_window *)mb[MB_WIN].p, (uint32_t)ctx->genomeLen,
+                                                  prm->iv_chains, prm->iv_chain_off, &rp,
+                                                  (blasr_hip_sdp_result *)mb[MB_SDPRES].p, (int32_t *)mb[MB_BLOCKS].p, blkCap,
+                                                  &blkUsed);
+    } else {
+      rc = blasr_hip_sdp_device(ctx, &sb, &prm->sdp, &prm->score, (blasr_hip_sdp_result *)mb[MB_SDPRES].p,
+                                (int32_t *)mb[MB_BLOCKS].p, blkCap, &blkUsed);
+    }
     if (rc != BLASR_HIP_ERR_CAPACITY) break;
     blkCap = blkUsed + 64;  // rare: the blocks of the batch did not fit -- once more with what it takes
   }

@@ -195,7 +195,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     t.top = i;
     t.qOrg = 0;
     t.tOrg = 0;
-    t.flags = (sp->extend_front ? kSdpExtendFront : 0) | (sp->detailed ? kSdpDetailed : 0);
+    t.flags = (sp->extend_front ? kSdpExtendFront : 0) | (sp->detailed ? kSdpDetailed : 0) | ((sp->sw_align_type & 0xff) << kSdpSwTypeShift);
     t.pad = 0;
   }
   SdpTask *dTop = arena.keep<SdpTask>(n);  // (needed until the call ends, like everything the levels hand on)

@@ -20,10 +20,12 @@ struct SdpTask {
   int32_t maxPerPos;   // maxMatchesPerPosition
   int32_t top;         // index of the top-level candidate this call belongs to
   int32_t qOrg, tOrg;  // origin of the rectangle in the top-level candidate's coordinates
-  int32_t flags;       // kSdpExtendFront: extendFrontByLocalAlignment; kSdpDetailed: detailedAlignment
+  int32_t flags;       // kSdpExtendFront: extendFrontByLocalAlignment; kSdpDetailed: detailedAlignment; bits 8..15: sdp_sw_type
   int32_t pad;
 };
-enum { kSdpExtendFront = 1, kSdpDetailed = 2 };
+enum { kSdpExtendFront = 1, kSdpDetailed = 2, kSdpSwTypeShift = 8 };
+// bits 8..15 of flags: smithWatermanAlignType of the call when it is not the default (EndAnchored = 6, SDPAlign.h:116)
+__host__ __device__ inline int sdp_sw_type(int flags) { return ((flags >> kSdpSwTypeShift) & 0xff) ? ((flags >> kSdpSwTypeShift) & 0xff) : 6; }
 
 // SWAlign(Global) on a gap rectangle with q*t < noRecurseUnder (SDPAlign.h:502-504, :438-441)
 struct SwTask {

@@ -3264,7 +3264,9 @@ __global__ __launch_bounds__(256) void sdp_blocks_emit_kernel(SdpLevelArrays lv,
       if (lane == 0) putSw(atSw, 0, 0, fq, ft);
       atSw++;
     } else if (t.recurse != 0) {
-      if (lane == 0) putChild(atChild, 0, 0, fq, ft, kMinus4, t.prefix, 6 /* EndAnchored lands in this slot, :456 */, t.flags);
+      // smithWatermanAlignType lands in the maxMatchesPerPosition slot of this call (:456) -- EndAnchored = 6 unless the
+      // caller said otherwise (AlignSubstring, Blasr.cpp:1089: Global = 1) -- and the child's own is the default again
+      if (lane == 0) putChild(atChild, 0, 0, fq, ft, kMinus4, t.prefix, sdp_sw_type(t.flags), t.flags & 0xff);
       atChild++;
     }
   }

@@ -46,7 +46,8 @@ EXPORTS = [
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
     "blasr_hip_count_tuples_device", "blasr_hip_pipeline_default_params", "blasr_hip_map_from_reads_device", "blasr_hip_map_from_reads_host",
-    "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
+    "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains",
+    "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
 ]
 
 # include/blasr_hip.h: blasr_hip_kernel_record
@@ -179,7 +180,7 @@ class _SdpParams(C.Structure):
     _fields_ = [("word_size", C.c_int32), ("sdp_ins", C.c_int32), ("sdp_del", C.c_int32), ("indel_rate", C.c_float),
                 ("align_type", C.c_int32), ("detailed", C.c_int32), ("extend_front", C.c_int32),
                 ("prefix_length", C.c_int32), ("recurse", C.c_int32), ("recurse_over", C.c_int32),
-                ("max_per_position", C.c_int32)]
+                ("max_per_position", C.c_int32), ("sw_align_type", C.c_int32)]
 
 
 class _SdpBatch(C.Structure):
@@ -198,7 +199,14 @@ class _MapParams(C.Structure):
     _fields_ = [("window", _WindowParams), ("sdp", _SdpParams), ("score", _ScoreParams), ("band", C.c_int32),
                 ("n_candidates", C.c_int32), ("max_gap", C.c_int32), ("max_score", C.c_int32),
                 ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32), ("extend_alignments", C.c_int32),
-                ("extend_band_size", C.c_int32), ("max_extend_dropoff", C.c_int32), ("reserved", C.c_int32)]
+                ("extend_band_size", C.c_int32), ("max_extend_dropoff", C.c_int32),
+                ("refine_between_anchors_only", C.c_int32), ("indel", C.c_int32), ("sdp_bypass_threshold", C.c_float),
+                ("reserved", C.c_int32), ("iv_chains", C.c_void_p), ("iv_chain_off", C.c_void_p)]
+
+
+class _RbaoParams(C.Structure):
+    _fields_ = [("sdp", _SdpParams), ("score", _ScoreParams), ("band", C.c_int32), ("indel", C.c_int32),
+                ("sdp_bypass_threshold", C.c_float), ("reserved", C.c_int32)]
 
 
 class _AnchorParams(C.Structure):
@@ -236,7 +244,8 @@ class SdpParams:
     MappingParameters.h:192-361."""
 
     def __init__(self, k=11, sdp_ins=5, sdp_del=10, indel_rate=DEFAULT_INDEL_RATE, align_type=0, detailed=1,
-                 extend_front=0, prefix=50, recurse=2, recurse_over=1000, max_per_pos=0):
+                 extend_front=0, prefix=50, recurse=2, recurse_over=1000, max_per_pos=0, sw_align_type=0):
+        self.sw_align_type = sw_align_type
         self.k, self.sdp_ins, self.sdp_del, self.indel_rate = k, sdp_ins, sdp_del, indel_rate
         self.align_type, self.detailed, self.extend_front = align_type, detailed, extend_front
         self.prefix, self.recurse, self.recurse_over, self.max_per_pos = prefix, recurse, recurse_over, max_per_pos
@@ -247,6 +256,7 @@ class SdpParams:
         s.align_type, s.detailed, s.extend_front = self.align_type, self.detailed, self.extend_front
         s.prefix_length, s.recurse, s.recurse_over = self.prefix, self.recurse, self.recurse_over
         s.max_per_position = self.max_per_pos
+        s.sw_align_type = self.sw_align_type
         return s
 
 
@@ -357,6 +367,11 @@ def load_library():
                                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.POINTER(_IntervalParams), C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.POINTER(C.c_int64), C.c_void_p]
+        lib.blasr_hip_find_intervals_chains.argtypes = lib.blasr_hip_find_intervals.argtypes + [
+            C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
+        lib.blasr_hip_align_between_anchors_host.argtypes = [
+            C.c_void_p, C.POINTER(_SdpBatch), C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+            C.POINTER(_RbaoParams), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -845,6 +860,34 @@ class Context:
                                                            cs.ctypes.data if cs is not None else None, nc))
         self.genome_length = int(length)
 
+    # --- next-3: -rbao, AlignIntervals between the chained anchors (Blasr.cpp:1354-1712) ---
+    def align_between_anchors(self, seq, q_off, q_len, t_off, t_len, windows, chains, chain_off, sdp=None, score=None,
+                              band=16, indel=5, sdp_bypass_threshold=1000000.0, blocks_capacity=None):
+        """blasr_hip_align_between_anchors_host over what Context.windows returned and the intervals' chained anchors
+        (hip.find_intervals(chains=True)).  Returns (results SDP_RESULT_DTYPE, blocks (m, 3) int32) like sdp_align."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        q_off, t_off = np.ascontiguousarray(q_off, np.int64), np.ascontiguousarray(t_off, np.int64)
+        q_len, t_len = np.ascontiguousarray(q_len, np.int32), np.ascontiguousarray(t_len, np.int32)
+        windows = np.ascontiguousarray(windows, dtype=WINDOW_DTYPE)
+        chains = np.ascontiguousarray(chains, dtype=np.uint32)
+        chain_off = np.ascontiguousarray(chain_off, dtype=np.int64)
+        n = len(q_off)
+        sb = _SdpBatch()
+        sb.n, sb.seq, sb.q_off, sb.q_len = n, seq.ctypes.data, q_off.ctypes.data, q_len.ctypes.data
+        sb.t_off, sb.t_len = t_off.ctypes.data, t_len.ctypes.data
+        rp = _RbaoParams()
+        rp.sdp = (sdp or SdpParams()).as_struct()
+        rp.score = (score or ScoreParams()).as_struct()
+        rp.band, rp.indel, rp.sdp_bypass_threshold = band, indel, sdp_bypass_threshold
+        cap = int(np.minimum(q_len, t_len).sum() + 64) if blocks_capacity is None else int(blocks_capacity)
+        res = np.zeros(max(n, 1), dtype=SDP_RESULT_DTYPE)
+        blocks = np.zeros((max(cap, 1), 3), dtype=np.int32)
+        used = C.c_int64(0)
+        self._check(self.lib.blasr_hip_align_between_anchors_host(
+            self.handle, C.byref(sb), len(seq), windows.ctypes.data, C.c_uint32(self.genome_length), chains.ctypes.data,
+            chain_off.ctypes.data, C.byref(rp), res.ctypes.data, blocks.ctypes.data, cap, C.byref(used)))
+        return res[:n], blocks[: used.value]
+
     # --- MapRead from the intervals on (Blasr.cpp:2530-2644), C++ driver inside the library ---
     def map_params(self, **kw):
         """blasr_hip_map_params with the defaults of MappingParameters.h; keyword overrides: band, n_candidates,
@@ -874,15 +917,21 @@ class Context:
                     intervals=cnt[0], refined=cnt[1], aligned_reads=cnt[2], aligned_bases=cnt[3], dp_cells=cnt[4],
                     hits=cnt[5])
 
-    def map_reads(self, reads, read_pool, intervals, params=None, fetch=True):
+    def map_reads(self, reads, read_pool, intervals, params=None, fetch=True, chains=None):
         """blasr_hip_map_reads_host: reads READ_DTYPE, read_pool uint8, intervals INTERVAL_DTYPE (host arrays).
         Returns (hits HIT_DTYPE array, read_hit_off, seq arena, ops arena); with fetch the hits' q_off / t_off /
-        ops_off index the two arenas."""
+        ops_off index the two arenas.  chains: (chains, chain_off) of hip.find_intervals(chains=True), for
+        params.refine_between_anchors_only (-rbao)."""
         reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
         read_pool = np.ascontiguousarray(read_pool, dtype=np.uint8)
         intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
         params = params or self.map_params()
         n_reads, n_iv = len(reads), len(intervals)
+        if chains is not None:
+            ch = np.ascontiguousarray(chains[0], dtype=np.uint32)
+            choff = np.ascontiguousarray(chains[1], dtype=np.int64)
+            assert len(choff) == n_iv + 1
+            params.iv_chains, params.iv_chain_off = ch.ctypes.data, choff.ctypes.data
         cap = max(n_iv, 1)
         hits = np.zeros(cap, dtype=HIT_DTYPE)
         off = np.zeros(n_reads + 1, dtype=np.int64)
@@ -1302,8 +1351,10 @@ def read_count_table(path):
     return table, k.value
 
 
-def find_intervals(genome, seq_start_pos, count_table, reads, anchors, list_off, params=None, stale=None):
-    """blasr_hip_find_intervals: (intervals INTERVAL_DTYPE, read_interval_off, p_values)."""
+def find_intervals(genome, seq_start_pos, count_table, reads, anchors, list_off, params=None, stale=None, chains=False):
+    """blasr_hip_find_intervals: (intervals INTERVAL_DTYPE, read_interval_off, p_values); with chains=True
+    (blasr_hip_find_intervals_chains) two more: the intervals' chained anchors as an (m, 3) uint32 array of (t, q, l) and
+    chain_off (intervals + 1 entries) -- WeightedInterval::matches, what -rbao reads."""
     lib = load_library()
     genome = np.ascontiguousarray(genome, dtype=np.uint8)
     starts = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
@@ -1326,6 +1377,19 @@ def find_intervals(genome, seq_start_pos, count_table, reads, anchors, list_off,
                                       out.ctypes.data, pv.ctypes.data, cap, C.byref(need), off.ctypes.data)
     if rc != OK:
         raise BlasrHipError(rc, "find_intervals")
+    if chains:
+        ccap = max(len(anchors), 1)
+        ch = np.zeros((ccap, 3), dtype=np.uint32)
+        coff = np.zeros(cap + 1, dtype=np.int64)
+        cused = C.c_int64(0)
+        rc = lib.blasr_hip_find_intervals_chains(
+            genome.ctypes.data, len(genome), starts.ctypes.data, len(starts), table.ctypes.data, k, n, reads.ctypes.data,
+            anchors.ctypes.data if len(anchors) else None, list_off.ctypes.data, st.ctypes.data if st is not None else None,
+            C.byref(params), out.ctypes.data, pv.ctypes.data, cap, C.byref(need), off.ctypes.data, ch.ctypes.data,
+            C.c_int64(ccap), C.byref(cused), coff.ctypes.data)
+        if rc != OK:
+            raise BlasrHipError(rc, "find_intervals_chains")
+        return out[: need.value], off, pv[: need.value], ch[: cused.value], coff[: need.value + 1]
     return out[: need.value], off, pv[: need.value]
 
 

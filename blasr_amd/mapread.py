@@ -27,17 +27,19 @@ class Hit(dict):
     q_aligned_seq_pos, n_match, read_length, rank (its index among the read's alignments: 0 is the primary one)."""
 
 
-def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, anchor_params=None, interval_params=None):
+def candidate_intervals(ctx, genome, contig_starts, count_table, pool, reads, anchor_params=None, interval_params=None,
+                        chains=False):
     """MapRead up to AlignIntervals (Blasr.cpp:2279-2500): MapReadToGenome for both strands + SortMatchPosList on the
     device (the context holds the genome and its suffix array), then RemoveOverlappingAnchors /
     FindMaxIncreasingInterval / the interval set on the host.  Returns (intervals INTERVAL_DTYPE in the order
-    AlignIntervals walks them read by read, read_interval_off, p_values)."""
+    AlignIntervals walks them read by read, read_interval_off, p_values); with chains=True also the intervals' chained
+    anchors (chains, chain_off), which -rbao reads."""
     anchors, list_off = ctx.anchor_reads(reads, pool, anchor_params)
-    return hip.find_intervals(genome, contig_starts, count_table, reads, anchors, list_off, interval_params)
+    return hip.find_intervals(genome, contig_starts, count_table, reads, anchors, list_off, interval_params, chains=chains)
 
 
 def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard=False, bestn=None, params=None,
-              min_align_length=0, min_map_qv=0, unaligned=None):
+              min_align_length=0, min_map_qv=0, unaligned=None, chains=None):
     """reads: READ_DTYPE array over `pool`; intervals: INTERVAL_DTYPE array (any order, each naming its read).
     The context must hold the genome.  Returns, per read, the list of Hits the reference would print, best first
     (`unaligned`, a list, receives the reads MapRead left without any alignment).
@@ -48,7 +50,7 @@ def map_reads(ctx, genome_len, contig_starts, pool, reads, intervals, for_picard
     n_reads = len(reads)
     params = params or ctx.map_params()
     max_score = int(params.max_score)
-    hits, off, seq, ops = ctx.map_reads(reads, pool, intervals, params=params, fetch=True)
+    hits, off, seq, ops = ctx.map_reads(reads, pool, intervals, params=params, fetch=True, chains=chains)
     out = []
     for r in range(n_reads):
         mine = hits[int(off[r]): int(off[r + 1])]

@@ -40,7 +40,8 @@ extern "C" {
 
 /* 2: blasr_hip_map_params grew the -extend fields (and blasr_hip_pipeline_params with it); a caller built against
  * version 1 must be recompiled (compare blasr_hip_abi_version() with the header's value at start-up). */
-#define BLASR_HIP_ABI_VERSION 2
+/* 3: blasr_hip_sdp_params grew sw_align_type, blasr_hip_map_params the -rbao fields (and the chains' two pointers). */
+#define BLASR_HIP_ABI_VERSION 3
 
 typedef struct blasr_hip_ctx blasr_hip_ctx;
 
@@ -209,6 +210,9 @@ typedef struct blasr_hip_sdp_params {
   int32_t recurse;          /* params.recurse (2) */
   int32_t recurse_over;     /* params.recurseOver (1000) */
   int32_t max_per_position; /* params.sdpMaxAnchorsPerPosition (0) */
+  int32_t sw_align_type;    /* smithWatermanAlignType: 0 = SDPAlign's default (EndAnchored, SDPAlign.h:116); the one place it
+                               acts is the front fill's recursive call, where it lands in the maxMatchesPerPosition slot
+                               (:456).  AlignSubstring of -rbao passes Global = 1 (Blasr.cpp:1089) */
 } blasr_hip_sdp_params;
 
 /* Candidate i: query = seq[q_off[i] ..+q_len[i]) (alignment->qAlignedSeq, Blasr.cpp:1332-1336),
@@ -386,7 +390,16 @@ typedef struct blasr_hip_map_params {
                                     extended before the first filter (:1749-1940, blasr_hip_extend_* below) */
   int32_t extend_band_size;      /* params.extendBandSize (10) */
   int32_t max_extend_dropoff;    /* params.maxExtendDropoff (10) */
+  int32_t refine_between_anchors_only; /* params.refineBetweenAnchorsOnly (0), -rbao: AlignIntervals aligns between the
+                                    chained anchors of each interval instead of running SDPAlign over the whole window
+                                    (:1354-1712, blasr_hip_align_between_anchors_* below); needs iv_chains */
+  int32_t indel;                 /* params.indel (5): AffineKBandAlign's penalties in AlignSubstring (:1067-1070) */
+  float sdp_bypass_threshold;    /* params.sdpBypassThreshold (1000000.0) */
   int32_t reserved;
+  const uint32_t *iv_chains;     /* HOST: WeightedInterval::matches of the intervals, (t, q, l) triplets as
+                                    blasr_hip_find_intervals_chains hands them out; interval k's are
+                                    iv_chains[3 * iv_chain_off[k] .. 3 * iv_chain_off[k + 1]) */
+  const int64_t *iv_chain_off;   /* HOST: n_iv + 1 entries */
 } blasr_hip_map_params;
 
 /* One alignment MapRead keeps: the T_AlignmentCandidate fields after RefineAlignment's copy-back. */
@@ -551,6 +564,53 @@ int blasr_hip_extend_device(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *ba
 int blasr_hip_extend_host(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *batch,
                           const blasr_hip_extend_params *params, blasr_hip_refine_result *results, uint32_t *ops,
                           int64_t ops_capacity, int64_t *ops_used);
+
+/* ------------------------------------------------------------------------------------------------
+ * next-3, second piece: -rbao ("refine between anchors only", params.refineBetweenAnchorsOnly), the branch of
+ * AlignIntervals that replaces the ONE SDPAlign over the candidate's window by small alignments between consecutive
+ * chained anchors of the interval (alignment/Blasr.cpp:1354-1712).  Per candidate:
+ *   the anchors made relative to the window, flipped for a Reverse-strand window (:1385-1408); overlapping anchors
+ *   dropped (:1414-1439); runs of anchors cut where the diagonal moves by 25 or more and the best chain of runs kept
+ *   (:1443-1564, GAP = -0.1 a base of drift) -- host code, a few hundred anchors;
+ *   one AlignSubstring (:1050-1122) per gap between consecutive anchors (both gaps > 0, ratio within 1000, < 100000):
+ *   AffineKBandAlign, Global, k = bandSize, when a side is shorter than bandSize and the lengths are within 2x
+ *   (blasr_hip_kband_device), else SDPAlign (Global, extendFront, indelRate 0.25, smithWatermanAlignType Global; word
+ *   size 7 when window and subread are both under 1000 bases) + the two pinned end blocks + RefineAlignment on the
+ *   gap (blasr_hip_sdp_device + blasr_hip_refine_device) -- device batches over the gaps of all candidates;
+ *   AppendSubseqAlignment (:1124-1147), the last anchor, qPos / tPos taken out, abutting blocks merged (:1640-1705),
+ *   ComputeAlignmentStats of an alignment without gap lists (:1709) -- a kernel.
+ * What comes back is what blasr_hip_sdp_* returns for the default branch (results[i].score = 0: alignScore is never
+ * set here), so the rest of MapRead (filters, RefineAlignments, ...) runs unchanged behind it.  An interval whose
+ * anchors cover sdp_bypass_threshold of the subread would take the -sdpbypass branch (:1728-1739), which is not
+ * offered: BLASR_HIP_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct blasr_hip_rbao_params {
+  blasr_hip_sdp_params sdp;     /* word_size = sdpTupleSize, sdp_ins, sdp_del, detailed, prefix_length, recurse,
+                                   recurse_over, max_per_position as AlignIntervals has them; indel_rate, align_type,
+                                   extend_front and sw_align_type are set by the function (:1080-1089) */
+  blasr_hip_score_params score; /* distScoreFn of AlignIntervals (:1176-1178), and of RefineAlignment (:807-809) */
+  int32_t band;                 /* params.bandSize (16) */
+  int32_t indel;                /* params.indel (5) */
+  float sdp_bypass_threshold;   /* params.sdpBypassThreshold (1000000.0) */
+  int32_t reserved;
+} blasr_hip_rbao_params;
+
+/* batch, windows, results, blocks: DEVICE memory, laid out as for blasr_hip_windows_device / blasr_hip_sdp_device
+ * (candidate i: query = the subread, target = the window; windows[i] names the window's place and strand).
+ * chains / chain_off: HOST memory, candidate i's chained anchors as (t, q, l) triplets
+ * chains[3 * chain_off[i] .. 3 * chain_off[i + 1]) in the coordinates FindMaxIncreasingInterval leaves them in
+ * (blasr_hip_find_intervals_chains).  genome_length: DNASequence::length of the whole genome (MakeRCCoordinate). */
+int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch,
+                                           const blasr_hip_window *windows, uint32_t genome_length,
+                                           const uint32_t *chains, const int64_t *chain_off,
+                                           const blasr_hip_rbao_params *params, blasr_hip_sdp_result *results,
+                                           int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used);
+/* The same with everything in HOST memory (seq_bytes sizes the upload of batch->seq). */
+int blasr_hip_align_between_anchors_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch, int64_t seq_bytes,
+                                         const blasr_hip_window *windows, uint32_t genome_length,
+                                         const uint32_t *chains, const int64_t *chain_off,
+                                         const blasr_hip_rbao_params *params, blasr_hip_sdp_result *results,
+                                         int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used);
 
 /* ------------------------------------------------------------------------------------------------
  * Output epilogue, first pieces: host functions, no GPU work.
@@ -812,6 +872,19 @@ int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const
                              const blasr_hip_anchor *stale, const blasr_hip_interval_params *params,
                              blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
                              int64_t *read_interval_off);
+
+/* The same, and the chained anchors of every interval with it (WeightedInterval::matches: the `lis` vector of
+ * FindMaxIncreasingInterval, FindMaxInterval.h:776-833, which the -rbao branch of AlignIntervals reads): interval k's
+ * chain is chains[3 * chain_off[k] .. 3 * chain_off[k + 1]) as (t, q, l) triplets in the order of the chain; chain_off
+ * has capacity + 1 entries; *chains_used receives the number of triplets needed (BLASR_HIP_ERR_CAPACITY beyond
+ * chains_capacity). */
+int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
+                                    int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_anchor *anchors,
+                                    const int64_t *list_off, const blasr_hip_anchor *stale,
+                                    const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
+                                    float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
+                                    uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off);
 
 /* The same with the anchors in DEVICE memory (what blasr_hip_anchor_reads_device wrote, sorted = 1; list_off, reads and
  * everything else host): RemoveOverlappingAnchors, the sliding window of StoreLargestIntervals and GlobalChain run as

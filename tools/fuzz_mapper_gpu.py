@@ -40,6 +40,9 @@ def main():
                     help="hand the reads over as a FASTQ file: the reference reads it with its FASTQReader (every second "
                          "record of a four-line file, FASTQReader.h:27-66), the library with blasr_hip_fastq_read; with --sam "
                          "the records carry the quality strings")
+    ap.add_argument("--rbao", action="store_true",
+                    help="-rbao on both sides: AlignIntervals aligns between the chained anchors of each interval "
+                         "(Blasr.cpp:1354-1712; the library: blasr_hip_find_intervals_chains + refine_between_anchors_only)")
     args = ap.parse_args()
     import blasr_amd
     from blasr_amd import hip, synth
@@ -185,7 +188,8 @@ def main():
                         read_group[0] = x.split("ID:")[1].split("\t")[0]
                 return sorted(x for x in lines if not x.startswith("@"))
 
-            switches = {"plain": var["cli"], "extend": var["cli"] + ["-extend"]}
+            rbao_cli = ["-rbao"] if args.rbao else []
+            switches = {"plain": var["cli"] + rbao_cli, "extend": var["cli"] + rbao_cli + ["-extend"]}
             ref = {name: run_reference(extra, args.nproc) for name, extra in switches.items()}
             # the same once more on ONE thread, for the (rare) input on which the binary's own lines change from run to
             # run under -nproc > 1 (its interval finder reads one element past the end of a match list, i.e. whatever the
@@ -241,11 +245,16 @@ def main():
             rt[i] = (off, len(rd), 0, len(rd), 0)
             off += len(rd)
         pool = np.concatenate(reads)
-        ivs, _, _ = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt,
-                                                  anchor_params=ctx.anchor_params(**var.get("anchor", {})),
-                                                  interval_params=hip.interval_params(**var.get("interval", {})))
+        found = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt,
+                                              anchor_params=ctx.anchor_params(**var.get("anchor", {})),
+                                              interval_params=hip.interval_params(**var.get("interval", {})),
+                                              chains=args.rbao)
+        ivs = found[0]
+        chains = (found[3], found[4]) if args.rbao else None
         mine = {}
         mkw = dict(var.get("map", {}))
+        if args.rbao:
+            mkw["refine_between_anchors_only"] = 1
         if "sdp" in var:
             mkw["sdp"] = hip.SdpParams(**var["sdp"])
         if "score" in var:
@@ -255,7 +264,7 @@ def main():
             for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
                                                          params=prm, min_align_length=var.get("min_align_length", 0),
                                                          min_map_qv=var.get("min_map_qv", 0), for_picard=args.sam,
-                                                         unaligned=unaligned)):
+                                                         unaligned=unaligned, chains=chains)):
                 nm = "%s/0_%d" % (names[r], len(reads[r]))
                 if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
                     got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r],
@@ -301,6 +310,7 @@ def main():
     totals["seconds"] = round(time.time() - t0, 1)
     totals["seed"] = args.seed
     totals["format"] = "sam" if args.sam else "m4"
+    totals["rbao"] = bool(args.rbao)
     totals["by_variant"] = by_variant
     totals["examples"] = examples
     print(json.dumps(totals))
