@@ -80,7 +80,10 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 100000;
   const double t0 = now_ms();
 
-  if (!getenv("BLASR_HIP_INTERVALS_HOST")) {
+  // -rbao reads the intervals' chained anchors, which the host's interval finder hands out (blasr_hip_find_intervals_chains)
+  // and the device's does not yet: that switch takes the host route below
+  const bool wantChains = params->map.refine_between_anchors_only != 0;
+  if (!getenv("BLASR_HIP_INTERVALS_HOST") && !wantChains) {
     // ---- anchors and intervals of every sub-block on the device; the anchor buffer is the same for all of them
     std::vector<blasr_hip_interval> ivs;
     std::vector<int64_t> listOff, ivOff;
@@ -149,6 +152,8 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   int hostError = BLASR_HIP_OK;
   std::vector<std::vector<blasr_hip_interval>> blockIvs;
   std::vector<std::vector<int64_t>> blockIvOff;
+  std::vector<std::vector<uint32_t>> blockChains;     // (t, q, l) triplets of a sub-block's intervals, back to back
+  std::vector<std::vector<int64_t>> blockChainOff;    // per interval of the sub-block, + 1
   double hostMs = 0;
   std::thread worker([&]() {
     for (;;) {
@@ -162,7 +167,8 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       }
       int rc = BLASR_HIP_OK;
       std::vector<blasr_hip_interval> ivs;
-      std::vector<int64_t> off;
+      std::vector<int64_t> off, chainOff;
+      std::vector<uint32_t> chains;
       try {
         // (a failed copy would leave stale anchors in the pinned buffer: the sub-block is an error then)
         if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(job->copied) != hipSuccess || job->copyError)
@@ -172,9 +178,31 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
           ivs.resize((size_t)job->count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
           off.resize((size_t)job->count + 1);
           int64_t n = 0;
-          rc = blasr_hip_find_intervals(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
-                                        job->count, reads_host + job->first, job->pinned + job->anchorOff, job->listOff.data(),
-                                        nullptr, &params->interval, ivs.data(), nullptr, (int64_t)ivs.size(), &n, off.data());
+          if (wantChains) {
+            const int64_t nAnchors = job->listOff[2 * (size_t)job->count] - job->listOff[0];
+            int64_t chainsUsed = 0;
+            chains.resize(3 * (size_t)std::max<int64_t>(nAnchors, 1));  // (a chain is a subset of one list's anchors)
+            chainOff.assign(ivs.size() + 1, 0);
+            rc = blasr_hip_find_intervals_chains(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                                 job->count, reads_host + job->first, job->pinned + job->anchorOff,
+                                                 job->listOff.data(), nullptr, &params->interval, ivs.data(), nullptr,
+                                                 (int64_t)ivs.size(), &n, off.data(), chains.data(), (int64_t)(chains.size() / 3),
+                                                 &chainsUsed, chainOff.data());
+            if (rc == BLASR_HIP_ERR_CAPACITY && n <= (int64_t)ivs.size()) {  // (ten intervals of a read may share anchors)
+              chains.resize(3 * (size_t)chainsUsed);
+              rc = blasr_hip_find_intervals_chains(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                                   job->count, reads_host + job->first, job->pinned + job->anchorOff,
+                                                   job->listOff.data(), nullptr, &params->interval, ivs.data(), nullptr,
+                                                   (int64_t)ivs.size(), &n, off.data(), chains.data(), (int64_t)(chains.size() / 3),
+                                                   &chainsUsed, chainOff.data());
+            }
+            chains.resize(3 * (size_t)std::max<int64_t>(chainsUsed, 0));
+            chainOff.resize((size_t)std::max<int64_t>(n, 0) + 1);
+          } else {
+            rc = blasr_hip_find_intervals(genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                          job->count, reads_host + job->first, job->pinned + job->anchorOff, job->listOff.data(),
+                                          nullptr, &params->interval, ivs.data(), nullptr, (int64_t)ivs.size(), &n, off.data());
+          }
           ivs.resize((size_t)std::max<int64_t>(n, 0));
           for (auto &iv : ivs) iv.read += job->first;
         }
@@ -182,11 +210,15 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       } catch (const std::bad_alloc &) {
         rc = BLASR_HIP_ERR_NOMEM;
         ivs.clear();
+        chains.clear();
+        chainOff.assign(1, 0);
       }
       std::lock_guard<std::mutex> lock(mu);
       if (rc != BLASR_HIP_OK && hostError == BLASR_HIP_OK) hostError = rc;
       blockIvs.push_back(std::move(ivs));
       blockIvOff.push_back(std::move(off));
+      blockChains.push_back(std::move(chains));
+      blockChainOff.push_back(std::move(chainOff));
     }
   });
   auto finish_worker = [&]() {
@@ -318,8 +350,22 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   if (intervals_out) memcpy(intervals_out, ivs.data(), sizeof(blasr_hip_interval) * (size_t)std::min(total, intervals_capacity));
   if ((rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(total + 1))) != BLASR_HIP_OK) return rc;
   HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, ivs.data(), sizeof(blasr_hip_interval) * (size_t)total, hipMemcpyHostToDevice));
+  blasr_hip_map_params mapParams = params->map;
+  std::vector<uint32_t> allChains;
+  std::vector<int64_t> allChainOff;
+  if (wantChains) {  // the sub-blocks' chains back to back, like their intervals
+    allChainOff.reserve((size_t)total + 1);
+    for (size_t b = 0; b < blockIvs.size(); b++) {
+      const int64_t shift = (int64_t)(allChains.size() / 3);
+      for (size_t i = 0; i < blockIvs[b].size(); i++) allChainOff.push_back(shift + blockChainOff[b][i]);
+      allChains.insert(allChains.end(), blockChains[b].begin(), blockChains[b].end());
+    }
+    allChainOff.push_back((int64_t)(allChains.size() / 3));
+    mapParams.iv_chains = allChains.data();
+    mapParams.iv_chain_off = allChainOff.data();
+  }
   rc = blasr_hip_map_reads_device(ctx, n_reads, reads_device, read_pool_device, (int32_t)total,
-                                  (const blasr_hip_interval *)ctx->pipeIntervals.p, &params->map, hits, hits_capacity, n_hits,
+                                  (const blasr_hip_interval *)ctx->pipeIntervals.p, &mapParams, hits, hits_capacity, n_hits,
                                   read_hit_off, fetch);
   const double t3 = now_ms();
   ctx->pipeMs[0] = (float)(t1 - t0);  // anchoring of all sub-blocks (the host stage runs underneath)

@@ -388,6 +388,9 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
   pp.map.extend_alignments = params.extendAlignments;
   pp.map.extend_band_size = params.extendBandSize;
   pp.map.max_extend_dropoff = params.maxExtendDropoff;
+  pp.map.refine_between_anchors_only = params.refineBetweenAnchorsOnly;  // -rbao: the chained anchors come from the library's own interval finder
+  pp.map.indel = params.indel;
+  pp.map.sdp_bypass_threshold = params.sdpBypassThreshold;
   blk.hits.resize(blk.n * (size_t)std::max(params.nCandidates, 1) + 1);
   blk.hitOff.assign(blk.n + 1, 0);
   blk.Reserve(seqCap);

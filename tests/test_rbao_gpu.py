@@ -1,0 +1,111 @@
+"""-rbao (params.refineBetweenAnchorsOnly; SURVEY next-3): AlignIntervals aligns BETWEEN the chained anchors of each
+candidate interval instead of running SDPAlign over the whole window (alignment/Blasr.cpp:1354-1712: AlignSubstring
+:1050-1122 per gap -- AffineKBandAlign, or SDPAlign + pinned ends + RefineAlignment -- AppendSubseqAlignment, merge,
+statistics).  The library: the chained anchors out of blasr_hip_find_intervals_chains, the branch as
+blasr_hip_align_between_anchors_* inside blasr_hip_map_reads (refine_between_anchors_only = 1).  What must come out is
+what the REFERENCE BINARY prints under -rbao for the noisy fixture (tests/golden/make_m4_noisy_rbao_golden.py: 75 of
+its 80 lines differ from the default run's), byte for byte -- from the step-by-step route, from the one-call mapper,
+and from the patched reference binary mapping blocks of reads (-useGPU -gpuBatch -rbao)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import blasr_amd
+from blasr_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "m4_noisy_golden.npz")
+RBAO = os.path.join(ROOT, "tests", "golden", "m4_noisy_rbao_golden.npz")
+
+
+def fixture():
+    g = np.load(GOLDEN)
+    contigs = [g["contig0"], g["contig1"]]
+    genome = np.concatenate([contigs[0], [ord("N")], contigs[1], [ord("N")]]).astype(np.uint8)
+    starts = np.array([0, len(contigs[0]) + 1, len(genome)], dtype=np.uint32)
+    read_lens, pool = g["read_lens"], np.ascontiguousarray(g["reads"])
+    reads = np.zeros(len(read_lens), dtype=blasr_amd.READ_DTYPE)
+    off = 0
+    for i in range(len(read_lens)):
+        reads[i] = (off, int(read_lens[i]), 0, int(read_lens[i]), 0)
+        off += int(read_lens[i])
+    want_iv = np.zeros(len(g["intervals"]), dtype=blasr_amd.INTERVAL_DTYPE)
+    for k, (s, e, qs, qe, strand) in enumerate(g["intervals"]):
+        want_iv[k] = (int(s), int(e), int(qs), int(qe), int(g["owner"][k]), int(strand))
+    return genome, starts, reads, pool, read_lens, want_iv
+
+
+@pytest.mark.parametrize("extend", [0, 1])
+def test_m4_lines_of_noisy_reads_under_rbao(extend):
+    genome, starts, reads, pool, read_lens, want_iv = fixture()
+    want = bytes(np.load(RBAO)["lines_extend" if extend else "lines"]).decode().splitlines()
+    plain = bytes(np.load(GOLDEN)["lines"]).decode().splitlines()
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, starts)
+    ctx.build_suffix_array(8, download=False)
+    ivs, iv_off, _, chains, chain_off = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, reads,
+                                                                     chains=True)
+    assert np.array_equal(ivs, want_iv)  # the intervals are the reference's; their chains are what -rbao walks
+    assert len(chain_off) == len(ivs) + 1 and chain_off[-1] == len(chains) and np.all(np.diff(chain_off) >= 1)
+    for k in (0, len(ivs) // 2, len(ivs) - 1):  # an interval spans its chain (FindMaxInterval.h:826-831)
+        c = chains[int(chain_off[k]): int(chain_off[k + 1])]
+        assert int(c[0][0]) == int(ivs[k]["start"]) and int(c[-1][0] + c[-1][2]) == int(ivs[k]["end"])
+        assert int(c[0][1]) == int(ivs[k]["q_start"]) and int(c[-1][1] + c[-1][2]) == int(ivs[k]["q_end"])
+    params = ctx.map_params(refine_between_anchors_only=1, extend_alignments=extend)
+    got = []
+    for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, reads, ivs, bestn=1, params=params,
+                                                 chains=(chains, chain_off))):
+        name = "read%d/%d/0_%d/0_%d" % (r, r, int(read_lens[r]), int(read_lens[r]))
+        got += [blasr_amd.m4_record(h, name, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert len(got) == len(want) and not bad, (len(got), len(want), len(bad), bad[:3])
+    assert sum(a != b for a, b in zip(got, plain)) > 40  # and the switch did change the alignments
+    # the switch without the chains is refused, not ignored
+    with pytest.raises(hip.BlasrHipError):
+        ctx.map_reads(reads, pool, ivs, params=ctx.map_params(refine_between_anchors_only=1), fetch=False)
+    ctx.close()
+
+
+def test_the_one_call_mapper_under_rbao():
+    """blasr_hip_map_from_reads_device with map.refine_between_anchors_only: the chains travel from the interval finder to
+    the path inside the library; the hits are those of the step-by-step route."""
+    from blasr_testlib import DeviceMemory
+    genome, starts, reads, pool, read_lens, want_iv = fixture()
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, starts)
+    ctx.build_suffix_array(8, download=False)
+    table = ctx.count_tuples(8)
+    ivs, _, _, chains, chain_off = blasr_amd.candidate_intervals(ctx, genome, starts, table, pool, reads, chains=True)
+    want_hits, want_off, _, _ = ctx.map_reads(reads, pool, ivs, params=ctx.map_params(refine_between_anchors_only=1),
+                                              fetch=False, chains=(chains, chain_off))
+    mem = DeviceMemory()
+    d_reads, d_pool = mem.upload(reads.view(np.uint8)), mem.upload(pool)
+    hits = np.zeros(len(ivs) + 8, dtype=hip.HIT_DTYPE)
+    hit_off = np.zeros(len(reads) + 1, dtype=np.int64)
+    p = ctx.pipeline_params(reads_per_block=9)
+    p.map.refine_between_anchors_only = 1
+    n, got_iv = ctx.map_from_reads_device(genome, starts, table, reads, d_reads, d_pool, p, hits, hit_off,
+                                          intervals_capacity=len(ivs) + 8)
+    assert np.array_equal(got_iv, ivs)
+    assert n == len(want_hits) and np.array_equal(hit_off, want_off)
+    for f in ("read", "interval", "t_strand", "t_aligned_seq_pos", "q_pos", "t_pos", "score", "n_match", "n_ops"):
+        assert np.array_equal(hits[:n][f], want_hits[f]), f
+    mem.free()
+    ctx.close()
+
+
+def test_patched_reference_binary_mapping_blocks_of_reads_under_rbao(tmp_path):
+    from test_dropin_gpu import EXE, run, write_inputs
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/blasrmc_gpu not built (needs /root/reference at build time)")
+    write_inputs(str(tmp_path))
+    want = sorted(bytes(np.load(RBAO)["lines"]).decode().splitlines())
+    p, got = run(str(tmp_path), ["-useGPU", "-gpuBatch", "11", "-nproc", "2", "-rbao"])
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]

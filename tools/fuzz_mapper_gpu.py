@@ -215,7 +215,8 @@ def main():
             if args.dropin:
                 for name, extra in switches.items():
                     # (odd iterations: -gpuBatch, MapReads pulling blocks of reads through ONE library call each)
-                    got = run_reference(extra + ["-useGPU"] + (["-gpuBatch", str(int(rng.integers(1, 300)))] if it % 2 else []), 2,
+                    # (under --rbao always: without -gpuBatch the branch between the anchors stays the reference's own CPU code)
+                    got = run_reference(extra + ["-useGPU"] + (["-gpuBatch", str(int(rng.integers(1, 300)))] if it % 2 or args.rbao else []), 2,
                                         os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu"))
                     if got is None or ref[name] is None:
                         totals["dropin_failed"] = totals.get("dropin_failed", 0) + (got is None)
