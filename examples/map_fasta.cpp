@@ -3,6 +3,8 @@
 //   map_fasta reads.fasta genome.fasta genome.fasta.sa [bestn] [-extend]   the whole mapper: anchoring included
 //   map_fasta reads.fasta genome.fasta intervals.txt   [bestn] [-extend]   candidate intervals given (e.g. blasrmc -V 1's)
 // -extend: the reference's switch of that name (both ends of every SDP alignment extended before the filters)
+// -rbao:   the reference's switch of that name (alignments between the chained anchors instead of SDPAlign over the window;
+//          whole-mapper form only: the chained anchors come from the library's interval finder)
 // -start S -stride N: the reference's switches of those names (Blasr.cpp:4057-4058, ReaderAgglomerate::Advance): reads S,
 //   S + N, S + 2N, ... of the file -- how one process per GPU shares a read file: rank r of N runs with -start r -stride N
 //   -device r, and the outputs concatenated in rank order hold the lines of the one-process run
@@ -37,9 +39,10 @@ static void die(const char *what, blasr_hip_ctx *ctx) {
 
 int main(int argc, char **argv) {
   if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta (genome.fasta.sa | intervals.txt) [bestn]", NULL);
-  int bestn = 1, extend = 0, start = 0, stride = 1, device = 0;
+  int bestn = 1, extend = 0, rbao = 0, start = 0, stride = 1, device = 0;
   for (int i = 4; i < argc; i++) {
     if (strcmp(argv[i], "-extend") == 0) extend = 1;
+    else if (strcmp(argv[i], "-rbao") == 0) rbao = 1;
     else if (strcmp(argv[i], "-start") == 0 && i + 1 < argc) start = atoi(argv[++i]);
     else if (strcmp(argv[i], "-stride") == 0 && i + 1 < argc) stride = atoi(argv[++i]);
     else if (strcmp(argv[i], "-device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
@@ -117,6 +120,7 @@ int main(int argc, char **argv) {
     blasr_hip_pipeline_default_params(&pp);
     if (pp.anchor.min_match_length < (uint32_t)prefixLen) pp.anchor.min_match_length = (uint32_t)prefixLen;  // Blasr.cpp:4433-4436
     pp.map.extend_alignments = extend;
+    pp.map.refine_between_anchors_only = rbao;
     std::vector<int32_t> countTable((size_t)1 << 16);  // tuples of params.lookupTableLength = 8 bases (Blasr.cpp:4479-4482)
     if (blasr_hip_count_tuples_device(ctx, 8, countTable.data())) die("count_tuples", ctx);
     oneCall = true;

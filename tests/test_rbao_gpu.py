@@ -109,3 +109,24 @@ def test_patched_reference_binary_mapping_blocks_of_reads_under_rbao(tmp_path):
     assert len(got) == len(want) == 80
     bad = [(a, b) for a, b in zip(got, want) if a != b]
     assert not bad, bad[:3]
+
+
+def test_cpp_example_maps_under_rbao(tmp_path):
+    """examples/map_fasta -rbao: the C++ whole mapper over the C ABI alone (FASTA + .sa in, -m 4 lines out) with the
+    switch set in its pipeline parameters."""
+    from test_dropin_gpu import write_inputs
+    exe = os.path.join(ROOT, "examples", "map_fasta")
+    sawriter = os.path.join(ROOT, "oracle", "_ref", "sawritermc")
+    if not os.path.exists(exe) or not os.path.exists(sawriter):
+        pytest.skip("examples/map_fasta or oracle/_ref/sawritermc not built")
+    write_inputs(str(tmp_path))
+    want = sorted(bytes(np.load(RBAO)["lines"]).decode().splitlines())
+    fa = os.path.join(str(tmp_path), "genome.fasta")
+    subprocess.run([sawriter, fa + ".sa", fa, "-blt", "8"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run([exe, os.path.join(str(tmp_path), "reads.fasta"), fa, fa + ".sa", "1", "-rbao"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = sorted(p.stdout.decode().splitlines())
+    assert len(got) == len(want) == 80
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]
