@@ -86,6 +86,7 @@ struct AnchorArgs {
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
   const uint16_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
+  int noWin;            // BLASR_HIP_ANCHOR_NO_WIN: every probe of the companion array from global memory (as in round 2)
   int prefixLen;
   const uint8_t *pool;
   const AnchorSeg *seg;
@@ -124,6 +125,15 @@ __device__ __forceinline__ int segment_of(const int64_t *posOff, int nSeg, int64
 // sectors, and the steps after the first stay inside what the first one fetched.  The kernel is bound by HBM sectors
 // (DESIGN.md 2.8), so the entry is kept this small; searches deeper than prefix + kExtBases read index[] + genome[].
 constexpr int kExtBases = 6;
+// A lane whose lookup range is short copies that stretch of the companion array into LDS once (nine 16-byte loads, issued
+// together) and every later probe inside it reads LDS: the ~20 dependent sector loads of a position's binary searches
+// (each one a sector of its own by the time it is issued: PMC) become three sectors fetched side by side.
+constexpr int kWinEntries = 72;  // entries staged per lane: the range (~46 suffixes at hg19 size) + alignment to 16 bytes
+constexpr int kWinStride = 37;   // dwords per lane (36 + 1: an odd stride keeps the lanes' slots on different banks)
+struct ExtWin {
+  const uint16_t *lds;  // this lane's slot
+  uint32_t base, count; // array positions [base, base + count) are in it
+};
 
 __global__ __launch_bounds__(256) void anchor_ext_kernel(const uint8_t *genome, uint32_t tlen, const uint32_t *index,
                                                          int64_t n, int prefixLen, uint16_t *ext) {
@@ -146,17 +156,23 @@ __global__ __launch_bounds__(256) void anchor_ext_kernel(const uint8_t *genome, 
 
 // What the suffix at array position m holds `offset` bases in: 0..3 that base, 4 a base that is not ACGT, 5 nothing
 // (the suffix ends exactly there), 6 the suffix is shorter still.
-__device__ __forceinline__ int suffix_symbol(const AnchorArgs &a, const uint8_t *three, uint32_t m, uint32_t offset,
-                                             unsigned &probes) {
-  probes++;
+__device__ __forceinline__ int suffix_symbol(const AnchorArgs &a, const uint8_t *three, const ExtWin &win, uint32_t m,
+                                             uint32_t offset, unsigned &probes) {
   const uint32_t k = offset - (uint32_t)a.prefixLen;  // (wraps to a large number below the prefix)
   if (a.ext && k < (uint32_t)kExtBases) {
-    const uint32_t w = a.ext[m];
+    uint32_t w;
+    if (m - win.base < win.count) {
+      w = win.lds[m - win.base];
+    } else {
+      probes++;
+      w = a.ext[m];
+    }
     const uint32_t vl = (w >> 12) & 7u;
     if (k < vl) return (int)((w >> (2 * k)) & 3u);
     if (k == vl) return (w >> 15) ? 5 : 4;
     // (k > vl: not for a suffix of the current range; the general path answers)
   }
+  probes++;
   const uint32_t im = a.index[m];
   const uint32_t sufLen = a.tlen - im;
   if (sufLen == offset) return 5;
@@ -166,12 +182,12 @@ __device__ __forceinline__ int suffix_symbol(const AnchorArgs &a, const uint8_t 
 }
 
 // SearchLeftBound (SuffixArray.h:733-775)
-__device__ __forceinline__ uint32_t left_bound(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq,
-                                               uint32_t l, uint32_t r, unsigned &probes) {
+__device__ __forceinline__ uint32_t left_bound(const AnchorArgs &a, const uint8_t *three, const ExtWin &win, uint32_t offset,
+                                               int tq, uint32_t l, uint32_t r, unsigned &probes) {
   uint32_t ll = l, lr = r;
   while (ll < lr) {
     const uint32_t m = ll + ((lr - ll) >> 1);
-    const int sym = suffix_symbol(a, three, m, offset, probes);
+    const int sym = suffix_symbol(a, three, win, m, offset, probes);
     if (sym == 5) {
       ll = m + 1;
       continue;
@@ -186,12 +202,12 @@ __device__ __forceinline__ uint32_t left_bound(const AnchorArgs &a, const uint8_
 }
 
 // SearchRightBound (SuffixArray.h:777-816), with its early stop at a suffix that ends exactly at `offset`
-__device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq,
-                                                uint32_t l, uint32_t r, unsigned &probes) {
+__device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8_t *three, const ExtWin &win, uint32_t offset,
+                                                int tq, uint32_t l, uint32_t r, unsigned &probes) {
   uint32_t rl = l, rr = r;
   while (rl < rr) {
     const uint32_t m = rl + ((rr - rl) >> 1);
-    const int sym = suffix_symbol(a, three, m, offset, probes);
+    const int sym = suffix_symbol(a, three, win, m, offset, probes);
     if (sym == 5) {
       rr = m;
       break;
@@ -213,13 +229,13 @@ __device__ __forceinline__ uint32_t right_bound(const AnchorArgs &a, const uint8
 // ends at or before `offset` (symbols 5, 6: only possible without the lookup table, at the first bases) is where the
 // two searches of the reference differ from a plain ordering, so the pair is then computed as the reference does.
 // Returns true when the pair came from the plain descent (then, if l < r, the suffix at l holds tq at `offset`).
-__device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *three, uint32_t offset, int tq, uint32_t &l,
-                                            uint32_t &r, unsigned &probes) {
+__device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *three, const ExtWin &win, uint32_t offset,
+                                            int tq, uint32_t &l, uint32_t &r, unsigned &probes) {
   uint32_t lo = l, hi = r;
   bool plain = true;
   while (lo < hi && plain) {
     const uint32_t m = lo + ((hi - lo) >> 1);
-    const int s = suffix_symbol(a, three, m, offset, probes);
+    const int s = suffix_symbol(a, three, win, m, offset, probes);
     if (s >= 5) {
       plain = false;
     } else if (s < tq) {
@@ -230,7 +246,7 @@ __device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *
       uint32_t x = lo, y = m;  // the first suffix that holds tq
       while (x < y && plain) {
         const uint32_t mm = x + ((y - x) >> 1);
-        const int s2 = suffix_symbol(a, three, mm, offset, probes);
+        const int s2 = suffix_symbol(a, three, win, mm, offset, probes);
         if (s2 >= 5)
           plain = false;
         else if (s2 < tq)
@@ -241,7 +257,7 @@ __device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *
       uint32_t u = m + 1, v = hi;  // the first suffix beyond them
       while (u < v && plain) {
         const uint32_t mm = u + ((v - u) >> 1);
-        const int s2 = suffix_symbol(a, three, mm, offset, probes);
+        const int s2 = suffix_symbol(a, three, win, mm, offset, probes);
         if (s2 >= 5)
           plain = false;
         else if (s2 <= tq)
@@ -260,8 +276,8 @@ __device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *
     l = r = lo;
     return true;
   }
-  l = left_bound(a, three, offset, tq, l, r, probes);
-  r = right_bound(a, three, offset, tq, l, r, probes);
+  l = left_bound(a, three, win, offset, tq, l, r, probes);
+  r = right_bound(a, three, win, offset, tq, l, r, probes);
   return false;
 }
 
@@ -269,10 +285,15 @@ __device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *
 template <int kHist>
 __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   __shared__ uint8_t three[256];
+  __shared__ uint32_t extWin[256 * kWinStride];
   three[threadIdx.x] = kThreeBit.v[threadIdx.x];
   __syncthreads();
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= a.nPos) return;
+  ExtWin win;
+  win.lds = reinterpret_cast<const uint16_t *>(extWin + threadIdx.x * kWinStride);
+  win.base = 0;
+  win.count = 0;
   const int si = segment_of(a.posOff, a.nSeg, g);
   const AnchorSeg s = a.seg[si];
   const uint32_t p = s.start + (uint32_t)(g - a.posOff[si]);
@@ -302,6 +323,25 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       hl[0] = l;
       hr[0] = r;
       n = 1;
+      if (a.ext && !a.noWin && r - l <= (uint32_t)kWinEntries) {  // the range's stretch of the companion array -> this lane's slot
+        const uint32_t base = l & ~7u;
+        const uint32_t chunks = min((a.tlen - base) >> 3, (uint32_t)(kWinEntries / 8));
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.ext + base);
+        uint32_t *dst = extWin + threadIdx.x * kWinStride;
+        uint4 v[kWinEntries / 8];
+#pragma unroll
+        for (int c = 0; c < kWinEntries / 8; c++) v[c] = (uint32_t)c < chunks ? src[c] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < kWinEntries / 8; c++) {
+          dst[4 * c] = v[c].x;
+          dst[4 * c + 1] = v[c].y;
+          dst[4 * c + 2] = v[c].z;
+          dst[4 * c + 3] = v[c].w;
+        }
+        win.base = base;
+        win.count = chunks * 8;
+        probes += (chunks * 16 + 63) / 64;  // sectors fetched
+      }
     } else {
       lcp = 0;
       searching = false;
@@ -311,12 +351,12 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
     if (a.stopUnique && l == r - 1) break;
     if (a.maxLcp && lcp >= (uint32_t)a.maxLcp) break;
     // the next genome base is an N (a genome as Blasr holds it ends in one, so the array never runs past it)
-    if (suffix_symbol(a, three, l, lcp, probes) >= 4) break;
+    if (suffix_symbol(a, three, win, l, lcp, probes) >= 4) break;
     const int tq = three[strand_base(a.pool, s, p + lcp)];
-    const bool plain = equal_range(a, three, lcp, tq, l, r, probes);
+    const bool plain = equal_range(a, three, win, lcp, tq, l, r, probes);
     if (l == r) break;
     // (:1044-1051: the suffix at l must hold the read's base; after the plain descent it does by construction)
-    if (tq >= 4 || (!plain && suffix_symbol(a, three, l, lcp, probes) != tq)) break;
+    if (tq >= 4 || (!plain && suffix_symbol(a, three, win, l, lcp, probes) != tq)) break;
 #pragma unroll
     for (int i = kHist - 1; i > 0; i--) {
       hl[i] = hl[i - 1];
@@ -726,6 +766,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.startPos = ctx->saStartPos;
     a.endPos = ctx->saEndPos;
     a.ext = useExt ? ctx->saExt : nullptr;
+    a.noWin = getenv("BLASR_HIP_ANCHOR_NO_WIN") != nullptr;
     a.prefixLen = ctx->saPrefixLen;
     a.pool = read_pool;
     a.seg = dSeg;
