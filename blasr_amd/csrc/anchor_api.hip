@@ -86,6 +86,7 @@ struct AnchorArgs {
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
   const uint16_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
+  int exp;              // BLASR_HIP_ANCHOR_EXP: timing experiments with wrong results
   int noWin;            // BLASR_HIP_ANCHOR_NO_WIN: every probe of the companion array from global memory (as in round 2)
   int prefixLen;
   const uint8_t *pool;
@@ -130,6 +131,7 @@ constexpr int kExtBases = 6;
 // (each one a sector of its own by the time it is issued: PMC) become three sectors fetched side by side.
 constexpr int kWinEntries = 72;  // entries staged per lane: the range (~46 suffixes at hg19 size) + alignment to 16 bytes
 constexpr int kWinStride = 37;   // dwords per lane (36 + 1: an odd stride keeps the lanes' slots on different banks)
+typedef uint64_t u64u __attribute__((aligned(1)));  // an 8-byte load from any address
 struct ExtWin {
   const uint16_t *lds;  // this lane's slot
   uint32_t base, count; // array positions [base, base + count) are in it
@@ -323,9 +325,10 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       hl[0] = l;
       hr[0] = r;
       n = 1;
-      if (a.ext && !a.noWin && r - l <= (uint32_t)kWinEntries) {  // the range's stretch of the companion array -> this lane's slot
+      if (a.exp & 4) searching = false;
+      if (a.ext && !a.noWin && !(a.exp & 8) && r - l <= (uint32_t)kWinEntries) {  // the range's stretch of the companion array -> this lane's slot
         const uint32_t base = l & ~7u;
-        const uint32_t chunks = min((a.tlen - base) >> 3, (uint32_t)(kWinEntries / 8));
+        const uint32_t chunks = min(min((a.tlen - base) >> 3, (r - base + 7) >> 3), (uint32_t)(kWinEntries / 8));
         const uint4 *src = reinterpret_cast<const uint4 *>(a.ext + base);
         uint32_t *dst = extWin + threadIdx.x * kWinStride;
         uint4 v[kWinEntries / 8];
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   while (searching && l < r && lcp < queryLength) {  // SuffixArray.h:996-1067
     if (a.stopUnique && l == r - 1) break;
     if (a.maxLcp && lcp >= (uint32_t)a.maxLcp) break;
+    if ((a.exp & 2) && lcp >= (uint32_t)(a.prefixLen + kExtBases)) break;
     // the next genome base is an N (a genome as Blasr holds it ends in one, so the array never runs past it)
     if (suffix_symbol(a, three, win, l, lcp, probes) >= 4) break;
     const int tq = three[strand_base(a.pool, s, p + lcp)];
@@ -379,8 +383,38 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       uint32_t ext = mlen;
       int64_t refPos = (int64_t)a.index[ml] + ext - 1;
       int64_t queryPos = (int64_t)p + ext - 1;
-      bool extended = false;
-      while (refPos + 1 < (int64_t)a.tlen && queryPos + 1 < (int64_t)s.len) {
+      bool extended = false, ended = false;
+      // eight bases at a time while eight are left on both sides: one (unaligned) 8-byte load each instead of sixteen
+      // dependent byte loads; the first difference and the first 'N' by bit tricks
+      for (;;) {
+        const int64_t gAt = refPos + 1, qAt = queryPos + 1;
+        int64_t room = min((int64_t)a.tlen - gAt, (int64_t)s.len - qAt);
+        if (a.maxLcp != 0) room = min(room, (int64_t)a.maxLcp - (int64_t)ext);
+        if (room < 8 || (a.exp & 1)) break;
+        const uint64_t gw = *reinterpret_cast<const u64u *>(a.genome + gAt);
+        uint64_t qw;
+        if (s.strand) {
+          const uint64_t raw = *reinterpret_cast<const u64u *>(a.pool + s.off + ((int64_t)s.len - 1 - qAt) - 7);
+          qw = 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) qw |= (uint64_t)rc_nuc((uint8_t)(raw >> (8 * (7 - j)))) << (8 * j);
+        } else {
+          qw = *reinterpret_cast<const u64u *>(a.pool + s.off + qAt);
+        }
+        const uint64_t x = gw ^ qw, y = gw ^ 0x4E4E4E4E4E4E4E4Eull;  // 'N'
+        const uint64_t z = (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;  // lowest set bit: the first 'N'
+        const int firstDiff = x ? (__builtin_ctzll(x) >> 3) : 8, firstN = z ? (__builtin_ctzll(z) >> 3) : 8;
+        const int matched = min(firstDiff, firstN);
+        refPos += matched;
+        queryPos += matched;
+        ext += (uint32_t)matched;
+        extended = extended || matched > 0;
+        if (matched < 8) {
+          ended = true;
+          break;
+        }
+      }
+      while (!ended && refPos + 1 < (int64_t)a.tlen && queryPos + 1 < (int64_t)s.len) {
         const uint8_t gc = a.genome[refPos + 1];
         if (gc == 'N' || gc != strand_base(a.pool, s, (uint32_t)(queryPos + 1))) break;
         if (!(a.maxLcp == 0 || ext < (uint32_t)a.maxLcp)) break;
@@ -767,6 +801,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.endPos = ctx->saEndPos;
     a.ext = useExt ? ctx->saExt : nullptr;
     a.noWin = getenv("BLASR_HIP_ANCHOR_NO_WIN") != nullptr;
+    a.exp = getenv("BLASR_HIP_ANCHOR_EXP") ? atoi(getenv("BLASR_HIP_ANCHOR_EXP")) : 0;
     a.prefixLen = ctx->saPrefixLen;
     a.pool = read_pool;
     a.seg = dSeg;
