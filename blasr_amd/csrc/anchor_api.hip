@@ -86,6 +86,7 @@ struct AnchorArgs {
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
   const uint16_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
+  int qBits;            // sort keys are (t << qBits) | q: only the bits that can differ go through the radix passes
   int exp;              // BLASR_HIP_ANCHOR_EXP: timing experiments with wrong results
   int noWin;            // BLASR_HIP_ANCHOR_NO_WIN: every probe of the companion array from global memory (as in round 2)
   int prefixLen;
@@ -296,7 +297,11 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   win.lds = reinterpret_cast<const uint16_t *>(extWin + threadIdx.x * kWinStride);
   win.base = 0;
   win.count = 0;
-  const int si = segment_of(a.posOff, a.nSeg, g);
+  // the segment of the wavefront's first position by one search on the scalar unit; a lane beyond that segment's end
+  // (a wavefront that straddles lists) steps on from there
+  const int64_t g0 = (int64_t)blockIdx.x * 256 + (int64_t)(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) << 6);
+  int si = segment_of(a.posOff, a.nSeg, g0);
+  while (si + 1 < a.nSeg && g >= a.posOff[si + 1]) si++;
   const AnchorSeg s = a.seg[si];
   const uint32_t p = s.start + (uint32_t)(g - a.posOff[si]);
   const uint32_t queryLength = s.matchEnd - p;  // MapBySuffixArray.h:66
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
     // the reference's asserts (MapBySuffixArray.h:301-302)
     if ((uint64_t)t + len > a.tlen || len == 0 || a.genome[(uint64_t)t + len - 1] == 'N') atomicOr(error, 1);
     if (keys) {
-      keys[base + j] = ((uint64_t)t << 32) | sQ[w][lo];
+      keys[base + j] = ((uint64_t)t << a.qBits) | sQ[w][lo];
       vals[base + j] = len;
     } else {
       blasr_hip_anchor rec;
@@ -538,14 +543,14 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
   }
 }
 
-__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint64_t *keys, const uint32_t *vals,
+__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint64_t *keys, const uint32_t *vals, int qBits,
                                                           blasr_hip_anchor *out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
   blasr_hip_anchor rec;
-  rec.t = (uint32_t)(k >> 32);
-  rec.q = (uint32_t)k;
+  rec.t = (uint32_t)(k >> qBits);
+  rec.q = (uint32_t)(k & ((1ull << qBits) - 1));
   rec.l = vals[i];
   out[i] = rec;
 }
@@ -675,8 +680,10 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
   // looks at a later one, and a later one never changes an earlier one
   std::vector<AnchorSeg> segs((size_t)nLists);
   std::vector<int64_t> segPos((size_t)nLists, 0);
+  uint32_t longestRead = 1;
   for (int32_t r = 0; r < n_reads; r++) {
     const blasr_hip_read &rd = reads[r];
+    longestRead = std::max(longestRead, rd.length);
     if (rd.subread_start > rd.subread_end || rd.subread_end > rd.length || rd.off < 0)
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: read %d has a bad subread", r);
     for (int sd = 0; sd < 2; sd++) {
@@ -801,6 +808,8 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.endPos = ctx->saEndPos;
     a.ext = useExt ? ctx->saExt : nullptr;
     a.noWin = getenv("BLASR_HIP_ANCHOR_NO_WIN") != nullptr;
+    a.qBits = 1;  // q < the read's length
+    while (a.qBits < 32 && (longestRead >> a.qBits) != 0) a.qBits++;
     a.exp = getenv("BLASR_HIP_ANCHOR_EXP") ? atoi(getenv("BLASR_HIP_ANCHOR_EXP")) : 0;
     a.prefixLen = ctx->saPrefixLen;
     a.pool = read_pool;
@@ -863,19 +872,22 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
                          vals, out, dError);
       HIP_TRY(ctx, hipEventRecord(ev.e[2], st));
       if (sorted) {
+        int tBits = 1;
+        while (tBits < 32 && (a.tlen >> tBits) != 0) tBits++;
+        const unsigned sortBits = (unsigned)(a.qBits + tBits);  // (t < tlen, q < 2^qBits)
         rocprim::double_buffer<uint64_t> kb(keys, keysAlt);
         rocprim::double_buffer<uint32_t> vb(vals, valsAlt);
         size_t sortBytes = 0;
         HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
-                                                         dSegAnchor32, dSegAnchor32 + 1, 0, 64, st));
+                                                         dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
         // the position arrays are dead once the anchors are out: the sort's scratch goes over them
         void *sortTmp = dLo;
         if ((size_t)((char *)ctx->workspace + ctx->workspaceBytes - (char *)dLo) < sortBytes)
           return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: sort scratch of %zu bytes", sortBytes);
         HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(sortTmp, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
-                                                         dSegAnchor32, dSegAnchor32 + 1, 0, 64, st));
+                                                         dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
         hipLaunchKernelGGL(anchor_pack_kernel, dim3((unsigned)((pieceAnchors + 255) / 256)), dim3(256), 0, st, pieceAnchors,
-                           kb.current(), vb.current(), out);
+                           kb.current(), vb.current(), a.qBits, out);
       }
       HIP_TRY(ctx, hipEventRecord(ev.e[3], st));
       ev.emitted = true;
