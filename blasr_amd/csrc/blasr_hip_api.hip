@@ -414,9 +414,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       cur.wideBytes = 0;
       arrowB = rowB = arenaB = 0;
     };
-    for (int i = 0; i < n; i++) {
-      size_t a = 0, r = 0, ar = 0, w = 0;
-      int ringSize = 0;
+    auto need_of = [&](int i, size_t &a, size_t &r, size_t &ar, size_t &w, int &ringSize) {
+      a = r = ar = w = 0;
+      ringSize = 0;
       if (geo[i].status == 0) {
         a = align_up((size_t)geo[i].cells + 16, 64);  // + 16: the traceback reads 16-byte windows
         r = sizeof(int2) * ((size_t)geo[i].rows + 1);
@@ -427,8 +427,23 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
           w = align_up((size_t)ringSize * 12, 256);
         }
       }
-      const size_t need = a + r + r / 4 + ar + w + 1280;
-      if (cur.count > 0 && arrowB + rowB + rowB / 4 + arenaB + cur.wideBytes + need > budget) flush(i);
+      return a + r + r / 4 + ar + w + 1280;
+    };
+    // a batch that does not fit is cut into pieces of about the SAME size (every piece pays the kernels' tails once:
+    // a large piece and a small remainder cost more than two halves)
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      size_t a, r, ar, w;
+      int ringSize;
+      total += need_of(i, a, r, ar, w, ringSize);
+    }
+    const size_t pieces = std::max<size_t>((total + budget - 1) / budget, 1);
+    const size_t target = pieces > 1 ? std::min(budget, total / pieces + total / (pieces * 32) + (1u << 20)) : budget;
+    for (int i = 0; i < n; i++) {
+      size_t a = 0, r = 0, ar = 0, w = 0;
+      int ringSize = 0;
+      const size_t need = need_of(i, a, r, ar, w, ringSize);
+      if (cur.count > 0 && arrowB + rowB + rowB / 4 + arenaB + cur.wideBytes + need > target) flush(i);
       if (need > budget) {
         destroyEvents();
         return fail(ctx, BLASR_HIP_ERR_NOMEM, "candidate %d alone needs %zu bytes of workspace", i, need);

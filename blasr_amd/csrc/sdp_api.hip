@@ -40,6 +40,7 @@ struct Arena {
   std::vector<void *> overflowLevel, overflowKept;
   hipError_t err = hipSuccess;
   int64_t *highOut = nullptr;  // receives the high-water mark
+  const bool trace = getenv("BLASR_HIP_SDP_TRACE") != nullptr && atoi(getenv("BLASR_HIP_SDP_TRACE")) > 1;
   Arena(blasr_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {}
   Arena(const Arena &) = delete;
   Arena &operator=(const Arena &) = delete;
@@ -62,6 +63,7 @@ struct Arena {
   template <typename T>
   T *get(size_t n) {  // lives until release_level()
     const size_t bytes = rounded(n * sizeof(T));
+    if (trace && bytes >= (512u << 20)) fprintf(stderr, "[sdp arena] get %.2f GB (elements of %zu bytes) at %.2f GB\n", bytes / 1e9, sizeof(T), bottom / 1e9);
     if (bottom + bytes + top <= capacity()) {
       char *p = ctx->workspace + bottom;
       bottom += bytes;
@@ -73,6 +75,7 @@ struct Arena {
   template <typename T>
   T *keep(size_t n) {  // lives until the call ends
     const size_t bytes = rounded(n * sizeof(T));
+    if (trace && bytes >= (512u << 20)) fprintf(stderr, "[sdp arena] keep %.2f GB (elements of %zu bytes), kept so far %.2f GB\n", bytes / 1e9, sizeof(T), top / 1e9);
     if (bottom + bytes + top <= capacity()) {
       top += bytes;
       note();
@@ -482,7 +485,40 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   // q*t < noRecurseUnder bounds the blocks of one fill by min(q,t) <= sqrt(noRecurseUnder)
   int64_t perFill = 1;
   while (perFill * perFill < std::max(sp->recurse_over, 1)) perFill++;
-  const int64_t poolCap = poolTotal + swTotal * perFill + 16;
+  // the pool's capacity: a fill aligns at most min(q, t) columns, summed over the fills on the device (the bound
+  // swTotal * perFill is five times that on real batches, and these four arrays were the stage's high-water mark)
+  int64_t fillBlocks = 0;
+  {
+    int64_t *dSum = arena.get<int64_t>(outs.size() + 1);
+    ARENA_CHECK();
+    size_t redBytes = 0;
+    std::vector<int64_t> sums(outs.size(), 0);
+    for (size_t i = 0; i < outs.size(); i++) {
+      if (outs[i].swCount <= 0) continue;
+      const SwTask *sw = outs[i].sw;
+      auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), [sw] __device__(size_t j) {
+        return (int64_t)(sw[j].qLen < sw[j].tLen ? sw[j].qLen : sw[j].tLen);
+      });
+      size_t need = 0;
+      HIP_TRY(ctx, rocprim::reduce(nullptr, need, in, dSum + i, (int64_t)0, (size_t)outs[i].swCount, rocprim::plus<int64_t>(), st));
+      if (need > redBytes) redBytes = need;
+    }
+    void *redTmp = arena.get<char>(std::max<size_t>(redBytes, 256));
+    ARENA_CHECK();
+    for (size_t i = 0; i < outs.size(); i++) {
+      if (outs[i].swCount <= 0) continue;
+      const SwTask *sw = outs[i].sw;
+      auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), [sw] __device__(size_t j) {
+        return (int64_t)(sw[j].qLen < sw[j].tLen ? sw[j].qLen : sw[j].tLen);
+      });
+      size_t need = redBytes;
+      HIP_TRY(ctx, rocprim::reduce(redTmp, need, in, dSum + i, (int64_t)0, (size_t)outs[i].swCount, rocprim::plus<int64_t>(), st));
+      HIP_TRY(ctx, hipMemcpyAsync(&sums[i], dSum + i, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int64_t v : sums) fillBlocks += v;
+  }
+  const int64_t poolCap = poolTotal + std::min(fillBlocks, swTotal * perFill) + 16;
   uint64_t *poolKeys = arena.get<uint64_t>((size_t)poolCap), *poolVals = arena.get<uint64_t>((size_t)poolCap);
   uint64_t *poolKeysSorted = arena.get<uint64_t>((size_t)poolCap), *poolValsSorted = arena.get<uint64_t>((size_t)poolCap);
   ARENA_CHECK();
@@ -638,6 +674,12 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   while (first < n) {
     int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 16.0)), 1 << 16);
     if (forced) budgetBases = std::max<int64_t>(atoll(forced), 1);
+    else {  // what is left, in pieces of about the same size: every piece pays the levels' tails once
+      int64_t remaining = 0;
+      for (int i = first; i < n; i++) remaining += (int64_t)std::max(qLen[i], 0) + std::max(tLen[i], 0);
+      const int64_t piecesLeft = std::max<int64_t>((remaining + budgetBases - 1) / budgetBases, 1);
+      if (piecesLeft > 1) budgetBases = std::min(budgetBases, remaining / piecesLeft + remaining / (piecesLeft * 32) + 1);
+    }
     int cnt = 0;
     int64_t acc = 0;
     while (first + cnt < n && cnt < limitCount) {
@@ -656,6 +698,9 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     int64_t usedHere = 0, arenaHigh = 0;
     const int rc = sdp_device_chunk(ctx, &sub, sp, score, results + first, blocks ? blocks + 3 * std::min(used, blocksCap) : nullptr,
                                     left, &usedHere, used, &arenaHigh);
+    if (getenv("BLASR_HIP_SDP_TRACE"))
+      fprintf(stderr, "[sdp] piece of %d candidates, %lld bases: arena high-water %.2f GB (%.1f B per base), planned with %.1f B per base, rc %d\n", cnt,
+              (long long)acc, (double)arenaHigh / 1e9, acc > 0 ? (double)arenaHigh / (double)acc : 0.0, std::max(ctx->sdpBytesPerBase, 16.0), rc);
     if (acc > 0 && arenaHigh > 0 && !forced) {  // (an aborted piece reports what it had asked for so far: a lower bound)
       ctx->sdpBytesPerBase = std::max(ctx->sdpBytesPerBase * (rc == BLASR_HIP_OK ? 0.5 : 1.0), 1.25 * (double)arenaHigh / (double)acc);
       // what the NEXT call plans with is the figure of this call's largest piece: a small last piece carries the
