@@ -574,7 +574,8 @@ void launch_search(const AnchorArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(anchor_search_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
 }
 
-constexpr int64_t kPiecePositions = 48ll << 20;  // read positions searched per piece (24 bytes of arrays each)
+constexpr int64_t kPiecePositions = 192ll << 20;  // read positions searched per piece (24 bytes of arrays each): fewer, larger
+                                                   // pieces = fewer launch tails and host round trips (48 M: +18 ms per 100 k reads)
 constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort call (rocprim counts in 32 bits)
 
 }  // namespace
@@ -751,7 +752,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
   bool overflow = false;
   int64_t emitted = 0;  // anchors of the pieces so far
   int64_t first = 0;    // first list of the piece
-  int64_t pieceLimit = kPiecePositions;
+  int64_t pieceLimit = std::min<int64_t>(kPiecePositions, std::max<int64_t>(blasr_hip_workspace_reach(ctx) / 64, 1 << 20));  // (24 B of arrays + the sort's buffers)
   if (const char *e = getenv("BLASR_HIP_ANCHOR_PIECE")) pieceLimit = std::max<int64_t>(1, atoll(e));
   std::vector<int64_t> posOff;
   while (first < nLists) {

@@ -594,7 +594,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
   const blasr_hip_interval_params &P = *params;
   std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
   std::vector<std::vector<float>> perReadP((size_t)n_reads);
-  int threads = P.threads > 0 ? P.threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  int threads = P.threads > 0 ? P.threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   threads = std::max(1, std::min(threads, n_reads));
   auto work = [&](int tid) {
     for (int32_t r = tid; r < n_reads; r += threads) {

@@ -849,7 +849,7 @@ typedef struct blasr_hip_interval_params {
   float indel_rate;                   /* params.indelRate (0.30): intervalLength = subread * (1 + indelRate), at most +50000 */
   float max_p_value;                  /* log(0.5), set in MapRead (Blasr.cpp:2371) */
   int32_t remove_contained_intervals; /* params.removeContainedIntervals (0) */
-  int32_t threads;                    /* host threads over the reads; 0 = up to 16 */
+  int32_t threads;                    /* host threads over the reads; 0 = up to 16 (32 for the device route's host end) */
 } blasr_hip_interval_params;
 int blasr_hip_interval_default_params(blasr_hip_interval_params *params);
 /* TupleCountTable::AddSequenceTupleCountsLR (datastructures/tuplelists/TupleCountTable.h:63-73) as Blasr.cpp:4479-4482
