@@ -146,3 +146,39 @@ def test_anchors_and_intervals_reproduce_the_reference_binarys_candidate_interva
     assert len(ivs) == len(z["intervals"]) == 125
     for r in range(len(reads)):
         assert np.array_equal(as_rows(ivs[int(ioff[r]): int(ioff[r + 1])]).astype(np.int64), z["intervals"][z["owner"] == r]), r
+
+
+def test_the_chains_of_the_intervals():
+    """blasr_hip_find_intervals_chains: the same intervals, and with each its chained anchors (WeightedInterval::matches,
+    what -rbao reads): a subsequence of the strand's anchor list that advances in q and in t, from the interval's first
+    base to its last (FindMaxInterval.h:826-831), and whose lengths add up to at least minInterval."""
+    z = np.load(os.path.join(HERE, "golden", "intervals_golden.npz"))
+    genome, starts, reads = z["genome"], z["starts"], z["reads"]
+    a = np.zeros(len(z["anchors"]), hip.ANCHOR_DTYPE)
+    a["t"], a["q"], a["l"] = z["anchors"][:, 0], z["anchors"][:, 1], z["anchors"][:, 2]
+    st = np.zeros(len(z["stale"]), hip.ANCHOR_DTYPE)
+    st["t"], st["q"], st["l"] = z["stale"][:, 0], z["stale"][:, 1], z["stale"][:, 2]
+    ct = hip.count_tuples(genome, int(z["tuple_size"]))
+    list_off = z["list_off"]
+    seen = 0
+    for kw in (dict(), dict(n_candidates=3), dict(remove_contained_intervals=1)):
+        p = hip.interval_params(threads=2, **kw)
+        ivs, off, pv = hip.find_intervals(genome, starts, ct, reads, a, list_off, p, st)
+        ivs2, off2, pv2, chains, chain_off = hip.find_intervals(genome, starts, ct, reads, a, list_off, p, st, chains=True)
+        assert np.array_equal(ivs, ivs2) and np.array_equal(off, off2) and np.array_equal(pv, pv2)
+        assert len(chain_off) == len(ivs) + 1 and chain_off[0] == 0 and chain_off[-1] == len(chains)
+        for r in range(len(reads)):
+            for k in range(int(off[r]), int(off[r + 1])):
+                c = chains[int(chain_off[k]): int(chain_off[k + 1])].astype(np.int64)
+                assert len(c) >= 1
+                iv = ivs[k]
+                assert c[0, 0] == iv["start"] and c[-1, 0] + c[-1, 2] == iv["end"]
+                assert c[0, 1] == iv["q_start"] and c[-1, 1] + c[-1, 2] == iv["q_end"]
+                assert np.all(np.diff(c[:, 0]) > 0) and np.all(np.diff(c[:, 1]) > 0)
+                assert c[:, 2].sum() >= int(p.min_interval) or len(c) > 1
+                lst = 2 * r + int(iv["strand"])
+                mine = {(int(t), int(q)) for t, q in zip(a["t"][int(list_off[lst]): int(list_off[lst + 1])],
+                                                         a["q"][int(list_off[lst]): int(list_off[lst + 1])])}
+                assert all((int(t), int(q)) in mine for t, q, _ in c)
+                seen += 1
+    assert seen > 60
