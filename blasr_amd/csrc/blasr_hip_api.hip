@@ -590,7 +590,47 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
           s2[slot] = c.wideRingSize[(size_t)u];
         };
         const char *orderEnv = getenv("BLASR_HIP_HYBRID_ORDER");
-        if (!orderEnv || strcmp(orderEnv, "rows")) {
+        if (orderEnv && !strcmp(orderEnv, "lpt")) {
+          // The four candidates of a wavefront step through their narrow rows together, so a wavefront costs
+          // (its longest candidate's rows) x (a narrow step) + (the wide cells of all four): candidates of about the same
+          // LENGTH share a wavefront (bins of 256 neighbours in the order by rows), inside a bin the wide work is spread
+          // over its 64 wavefronts (heaviest first, each to the lightest wavefront with a free slot), and the wavefronts
+          // are launched heaviest first.
+          std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return geo[c.wideTasks[(size_t)a]].rows > geo[c.wideTasks[(size_t)b]].rows;
+          });
+          auto excess = [&](int32_t u) {
+            const TaskGeometry &g = geo[c.wideTasks[(size_t)u]];
+            return std::max<int64_t>(g.cells - 35 * (int64_t)g.rows, 0);
+          };
+          struct WaveSlot {
+            int32_t member[4];
+            int n;
+            int64_t wide, rows;
+          };
+          std::vector<WaveSlot> wavesAll;
+          for (int b0 = 0; b0 < nw; b0 += 256) {
+            const int nb = std::min(256, nw - b0), waves = (nb + 3) / 4;
+            std::stable_sort(order.begin() + b0, order.begin() + b0 + nb, [&](int32_t a, int32_t b) { return excess(a) > excess(b); });
+            std::vector<WaveSlot> ws((size_t)waves);
+            for (auto &w : ws) w.n = 0, w.wide = 0, w.rows = 0, w.member[0] = w.member[1] = w.member[2] = w.member[3] = -1;
+            for (int m = 0; m < nb; m++) {
+              const int32_t u = order[(size_t)(b0 + m)];
+              int best = -1;
+              for (int w = 0; w < waves; w++)
+                if (ws[(size_t)w].n < 4 && (best < 0 || ws[(size_t)w].wide < ws[(size_t)best].wide)) best = w;
+              WaveSlot &w = ws[(size_t)best];
+              w.member[w.n++] = u;
+              w.wide += excess(u);
+              w.rows = std::max<int64_t>(w.rows, geo[c.wideTasks[(size_t)u]].rows);
+            }
+            wavesAll.insert(wavesAll.end(), ws.begin(), ws.end());
+          }
+          auto weight = [](const WaveSlot &w) { return 131 * w.rows + (3 * w.wide) / 2; };  // (wavefront instructions, roughly)
+          std::stable_sort(wavesAll.begin(), wavesAll.end(), [&](const WaveSlot &a, const WaveSlot &b) { return weight(a) > weight(b); });
+          for (size_t w = 0; w < wavesAll.size(); w++)
+            for (int m = 0; m < wavesAll[w].n; m++) place(w * 4 + (size_t)m, wavesAll[w].member[m]);
+        } else if (!orderEnv || strcmp(orderEnv, "rows")) {
           std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
             return geo[c.wideTasks[(size_t)a]].cells > geo[c.wideTasks[(size_t)b]].cells;
           });

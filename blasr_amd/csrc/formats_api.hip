@@ -173,9 +173,78 @@ int parse_fastq(const char *p, size_t n, blasr_hip_fasta &out) {
   return BLASR_HIP_OK;
 }
 
+// Reads from a SAM file, as ReaderAgglomerate::GetNext(SMRTSequence&) takes them (files/ReaderAgglomerate.h:308-318):
+// SAMReader::ReadHeader (algorithms/alignment/readers/sam/SAMReader.h:119-155) consumes the leading lines that start
+// with '@'; after that EVERY line is a record (SAMReader::GetNextAlignment :180-195: getline + StoreValues): its first
+// eleven whitespace-separated words (`operator>>`: tabs or blanks alike) are QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT
+// TLEN SEQ QUAL (datastructures/alignmentset/SAMAlignment.h:142-192), and ConvertSAMToSMRTSequence
+// (SAMToSMRTSequence.h:53-98) makes the read of QNAME (title), SEQ (bases as they stand) and QUAL (none when "*"); the
+// subread is the whole read.  A line with fewer than eleven words, an empty one included, or a number that does not
+// parse makes the reference print "Error parsing alignment line" and exit(1): BLASR_HIP_ERR_INVALID here.  The optional
+// tags (zm, qs, qe, rq, np, sn and the rich quality values) do not reach the mapper's alignments and are not kept.
+int parse_sam_reads(const char *p, size_t n, blasr_hip_fasta &out) {
+  size_t at = 0;
+  while (at < n && p[at] == '@') {  // PeekLineIsHeader
+    while (at < n && p[at] != '\n') at++;
+    if (at < n) at++;
+  }
+  auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; };
+  auto is_uint = [](const std::string &w) {
+    if (w.empty() || w.size() > 9) return false;
+    for (char c : w)
+      if (c < '0' || c > '9') return false;
+    return true;
+  };
+  auto is_int = [&](const std::string &w) {
+    if (w.empty()) return false;
+    const size_t from = (w[0] == '-' || w[0] == '+') ? 1 : 0;
+    return is_uint(w.substr(from));
+  };
+  int64_t line = 0;
+  while (at < n) {
+    size_t e = at;
+    while (e < n && p[e] != '\n') e++;
+    std::vector<std::string> words;
+    size_t i = at;
+    while (i < e && words.size() < 11) {
+      while (i < e && is_space(p[i])) i++;
+      size_t j = i;
+      while (j < e && !is_space(p[j])) j++;
+      if (j > i) words.push_back(std::string(p + i, j - i));
+      i = j;
+    }
+    if (words.size() < 11 || !is_uint(words[1]) || !is_uint(words[3]) || !is_int(words[4]) || !is_int(words[7]) || !is_int(words[8])) {
+      out.error = "Error parsing alignment line " + std::to_string(line) + " (the reference exits here)";
+      return BLASR_HIP_ERR_INVALID;
+    }
+    out.titles.push_back(words[0]);
+    out.seqs.push_back(std::vector<uint8_t>(words[9].begin(), words[9].end()));
+    out.quals.push_back(words[10] == "*" ? std::vector<uint8_t>() : std::vector<uint8_t>(words[10].begin(), words[10].end()));
+    at = e < n ? e + 1 : n;
+    line++;
+  }
+  return BLASR_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int blasr_hip_sam_reads_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+  if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
+  blasr_hip_fasta *f = new blasr_hip_fasta();
+  const int rc = parse_sam_reads(text, (size_t)length, *f);
+  *out = f;  // (also on an error: the records before it and the message, blasr_hip_fasta_error)
+  return rc;
+}
+
+int blasr_hip_sam_reads_read(const char *path, blasr_hip_fasta **out) {
+  if (!path || !out) return BLASR_HIP_ERR_INVALID;
+  *out = nullptr;
+  std::vector<char> buf;
+  if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
+  return blasr_hip_sam_reads_parse(buf.data(), (int64_t)buf.size(), out);
+}
 
 int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out) {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;

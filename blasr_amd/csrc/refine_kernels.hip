@@ -940,15 +940,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                     for (int k = 0; k < kRunSteps; k++)
                       tP[k] = (tP[k] >> 8) | (((uint32_t)wave_shl1((int)tP[k], (int)first[k + 1]) & 0xffu) << 16);
                   }
-                  // the values that cross a step's edge, before the steps overwrite them
-                  int e63[kRunSteps], f0S[kRunSteps + 1], f0I[kRunSteps + 1];
-#pragma unroll
-                  for (int k = 0; k < kRunSteps; k++) {
-                    e63[k] = __builtin_amdgcn_readlane(pS[k][kW - 1], 63);
-                    f0S[k] = __builtin_amdgcn_readlane(pS[k][0], 0);
-                    f0I[k] = __builtin_amdgcn_readlane(pI[k][0], 0);
-                  }
-                  f0S[kRunSteps] = f0I[kRunSteps] = inf;
+                  // the values that cross a step's edge are read off just before they are needed: the last cell of the
+                  // step before (d = 0; saved before that step overwrote it) or the first cell of the step after (d = 1;
+                  // not yet overwritten) -- one or two uniform values alive instead of eleven
+                  int ePrevOld = inf;
                   int wCarryA = inf, wCarryB = inf;
 #pragma unroll
                   for (int k = 0; k < kRunSteps; k++) {
@@ -956,8 +951,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                     const int c0 = rLo + kW * (64 * k + lane);
                     int upS[kW], upI[kW], diagS[kW];
                     if (d == 0) {
+                      const int eOld = __builtin_amdgcn_readlane(pS[k][kW - 1], 63);
                       int dg = wave_shr1(pS[k][kW - 1], inf);
-                      dg = lane == 0 ? (k == 0 ? leftS : e63[k == 0 ? 0 : k - 1]) : dg;
+                      dg = lane == 0 ? (k == 0 ? leftS : ePrevOld) : dg;
+                      ePrevOld = eOld;
                       diagS[0] = dg;
 #pragma unroll
                       for (int j = 0; j < kW; j++) {
@@ -974,8 +971,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                           upI[j] = pI[k][j + 1];
                         }
                       }
-                      upS[kW - 1] = wave_shl1(pS[k][0], f0S[k + 1]);
-                      upI[kW - 1] = wave_shl1(pI[k][0], f0I[k + 1]);
+                      upS[kW - 1] = wave_shl1(pS[k][0], k + 1 < kRunSteps ? __builtin_amdgcn_readlane(pS[k + 1 < kRunSteps ? k + 1 : k][0], 0) : inf);
+                      upI[kW - 1] = wave_shl1(pI[k][0], k + 1 < kRunSteps ? __builtin_amdgcn_readlane(pI[k + 1 < kRunSteps ? k + 1 : k][0], 0) : inf);
                     }
                     // cells of the row above that do not exist: only a step that reaches beyond that row's ends has any
                     if (!(rLo + kWStep * k - 1 >= prevLo && rLo + kWStep * (k + 1) - 1 <= prevHi)) {

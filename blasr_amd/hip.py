@@ -47,7 +47,8 @@ EXPORTS = [
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
     "blasr_hip_count_tuples_device", "blasr_hip_pipeline_default_params", "blasr_hip_map_from_reads_device", "blasr_hip_map_from_reads_host",
     "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains",
-    "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
+    "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
+    "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
 ]
 
 # include/blasr_hip.h: blasr_hip_kernel_record
@@ -1415,16 +1416,23 @@ def read_fasta(path=None, text=None):
     return out
 
 
-def read_fastq(path=None, text=None):
+def read_sam_reads(path=None, text=None):
+    """The reads of a SAM file (or text) as the reference takes a `.sam` read file (blasr_hip_sam_reads_read): list of
+    (QNAME bytes, SEQ uint8 array, QUAL characters uint8 array -- empty for "*").  Raises BlasrHipError where the
+    reference exits (a line it cannot parse)."""
+    return read_fastq(path, text, _sam=True)
+
+
+def read_fastq(path=None, text=None, _sam=False):
     """A FASTQ file (or text) as the reference's FASTQReader::GetNext reads it in this fork (blasr_hip_fastq_read: NOT a
     FASTQ parser, see include/blasr_hip.h): list of (title bytes, bases uint8 array, quality characters uint8 array).
     Raises BlasrHipError where the reference exits or reads undefined memory."""
     lib = load_library()
     h = C.c_void_p()
     if text is not None:
-        rc = lib.blasr_hip_fastq_parse(text, C.c_int64(len(text)), C.byref(h))
+        rc = (lib.blasr_hip_sam_reads_parse if _sam else lib.blasr_hip_fastq_parse)(text, C.c_int64(len(text)), C.byref(h))
     else:
-        rc = lib.blasr_hip_fastq_read(path.encode(), C.byref(h))
+        rc = (lib.blasr_hip_sam_reads_read if _sam else lib.blasr_hip_fastq_read)(path.encode(), C.byref(h))
     lib.blasr_hip_fasta_error.restype = C.c_char_p
     lib.blasr_hip_fasta_error.argtypes = [C.c_void_p]
     if rc != OK:

@@ -9,7 +9,8 @@
 //   S + N, S + 2N, ... of the file -- how one process per GPU shares a read file: rank r of N runs with -start r -stride N
 //   -device r, and the outputs concatenated in rank order hold the lines of the one-process run
 // -device D: the HIP device to run on (default 0)
-// reads.fastq / reads.fq instead of reads.fasta: read as the reference's FASTQReader reads it (blasr_hip_fastq_read)
+// reads.fastq / reads.fq instead of reads.fasta: read as the reference's FASTQReader reads it (blasr_hip_fastq_read);
+// reads.sam: the records of a SAM file as the reference takes them for reads (blasr_hip_sam_reads_read)
 //
 // What the reference's MapReads does around MapRead (alignment/Blasr.cpp:3193-3917) with the library's pieces:
 //   genome      blasr_hip_fasta_read + blasr_hip_fasta_concatenate     (ReadAllSequencesIntoOne, ToUpper: Blasr.cpp:4329, 4354)
@@ -67,7 +68,8 @@ int main(int argc, char **argv) {
   // ---- reads
   const size_t rl = strlen(argv[1]);
   const bool fastq = (rl > 6 && strcmp(argv[1] + rl - 6, ".fastq") == 0) || (rl > 3 && strcmp(argv[1] + rl - 3, ".fq") == 0);
-  if ((fastq ? blasr_hip_fastq_read(argv[1], &rf) : blasr_hip_fasta_read(argv[1], &rf)) != BLASR_HIP_OK)
+  const bool samReads = rl > 4 && strcmp(argv[1] + rl - 4, ".sam") == 0;  // (a .sam read file: blasr_hip_sam_reads_read)
+  if ((samReads ? blasr_hip_sam_reads_read(argv[1], &rf) : fastq ? blasr_hip_fastq_read(argv[1], &rf) : blasr_hip_fasta_read(argv[1], &rf)) != BLASR_HIP_OK)
     die(rf ? blasr_hip_fasta_error(rf) : "cannot read the reads", NULL);
   const int nInFile = (int)blasr_hip_fasta_count(rf);
   std::vector<blasr_hip_read> reads;

@@ -752,6 +752,13 @@ int blasr_hip_fasta_free(blasr_hip_fasta *fasta);
 int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out);
 int blasr_hip_fastq_parse(const char *text, int64_t length, blasr_hip_fasta **out);
 int blasr_hip_fastq_quality(const blasr_hip_fasta *fasta, int64_t i, const uint8_t **qual, int64_t *qual_length);
+/* Reads from a SAM file (a `.sam` read file: files/ReaderAgglomerate.h:308-318, SAMReader::GetNextAlignment,
+ * SAMAlignment::StoreValues, ConvertSAMToSMRTSequence): the leading '@' lines are the header, every later line a record
+ * whose first eleven whitespace-separated words are QNAME ... SEQ QUAL; title = QNAME, bases = SEQ, qualities = QUAL's
+ * characters (blasr_hip_fastq_quality; none when "*"), the subread the whole read.  A line the reference exits on
+ * (fewer than eleven words, a number that does not parse): BLASR_HIP_ERR_INVALID, the records before it stay readable. */
+int blasr_hip_sam_reads_read(const char *path, blasr_hip_fasta **out);
+int blasr_hip_sam_reads_parse(const char *text, int64_t length, blasr_hip_fasta **out);
 const char *blasr_hip_fasta_error(const blasr_hip_fasta *fasta);
 int64_t blasr_hip_fasta_count(const blasr_hip_fasta *fasta);
 /* Record i; the pointers stay valid until blasr_hip_fasta_free.  Any output may be NULL. */

@@ -558,6 +558,36 @@ int ref_read_fastq_records(const char *path, unsigned char *seqOut, unsigned cha
   return n;
 }
 
+// ReaderAgglomerate::GetNext(SMRTSequence&) over a `.sam` read file (files/ReaderAgglomerate.h:198-203, :308-318): titles
+// joined by '\n', bases and STORED quality values back to back (0 where the read has none), lengths, hasQual flags; returns
+// the number of records (-1: buffers too small).  NB the reference exit(1)s on a line it cannot parse: forked child.
+int ref_read_sam_reads(const char *path, unsigned char *seqOut, unsigned char *qualOut, long seqCap, long *lengths, int *hasQual,
+                       int maxRecords, char *titles, long titlesCap) {
+  string name(path);
+  ReaderAgglomerate reader;
+  reader.SetReadFileName(name);
+  if (reader.Initialize() == 0) return -3;
+  int n = 0;
+  long at = 0;
+  string all;
+  for (;;) {
+    SMRTSequence seq;
+    if (!reader.GetNext(seq)) break;
+    if (n >= maxRecords || at + (long)seq.length > seqCap) return -1;
+    memcpy(seqOut + at, seq.seq, seq.length);
+    hasQual[n] = seq.qual.data != NULL;
+    for (unsigned i = 0; i < seq.length; i++) qualOut[at + i] = seq.qual.data ? seq.qual.data[i] : 0;
+    at += seq.length;
+    if (seq.subreadStart != 0 || seq.subreadEnd != seq.length) return -2;
+    lengths[n++] = seq.length;
+    all += seq.title ? string(seq.title, seq.titleLength) : string();
+    all += "\n";
+  }
+  if ((long)all.size() + 1 > titlesCap) return -1;
+  memcpy(titles, all.c_str(), all.size() + 1);
+  return n;
+}
+
 // SuffixArray::Read: the index array and the lookup table of a .sa file.  out[0] = length, out[1] = lookupTableLength,
 // out[2] = lookupPrefixLength
 int ref_read_sa(const char *path, unsigned *index, long indexCap, unsigned *startPos, unsigned *endPos, long tableCap,

@@ -252,3 +252,92 @@ def test_count_table_file_against_the_reference(tmp_path):
         ref.ref_ct_close(C.c_void_p(h2))
     with pytest.raises(hip.BlasrHipError):
         hip.read_count_table(os.path.join(str(tmp_path), "missing.ctab"))
+
+
+def _ref_sam_in_child(path):
+    """The reference's ReaderAgglomerate over a `.sam` read file, in a forked child (it exit(1)s on a line it cannot
+    parse): (count, [(title, bases, quality characters or b"")]) or None when the child left without an answer."""
+    import pickle
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child
+        os.close(r)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        ref = C.CDLL(REFMAPPER_SO)
+        seq, qual = np.zeros(1 << 20, np.uint8), np.zeros(1 << 20, np.uint8)
+        lengths = (C.c_long * 256)()
+        has_qual = (C.c_int * 256)()
+        titles = C.create_string_buffer(1 << 16)
+        k = ref.ref_read_sam_reads(path.encode(), seq.ctypes.data_as(C.c_void_p), qual.ctypes.data_as(C.c_void_p),
+                                   C.c_long(len(seq)), lengths, has_qual, 256, titles, C.c_long(len(titles)))
+        recs, at = [], 0
+        tl = titles.value.split(b"\n")
+        for j in range(max(k, 0)):
+            q = bytes((qual[at: at + lengths[j]] + 33).astype(np.uint8)) if has_qual[j] else b""  # stored = character - 33
+            recs.append((tl[j], bytes(seq[at: at + lengths[j]]), q))
+            at += lengths[j]
+        os.write(w, pickle.dumps((k, recs)))
+        os._exit(7)
+    os.close(w)
+    blob = b""
+    while True:
+        piece = os.read(r, 1 << 16)
+        if not piece:
+            break
+        blob += piece
+    os.close(r)
+    os.waitpid(pid, 0)
+    return pickle.loads(blob) if blob else None
+
+
+@pytest.mark.skipif(not os.path.exists(REFMAPPER_SO), reason="reference tools not built")
+def test_sam_read_files_against_the_reference_reader(tmp_path):
+    """A `.sam` file as READ input (files/ReaderAgglomerate.h:308-318): header lines skipped, every later line's first
+    eleven words parsed, title / bases / qualities as ConvertSAMToSMRTSequence leaves them -- against the reference's
+    own reader on plain, tagged, blank-separated and random files; where the reference exits (a short or empty line, a
+    word that is no number) the library returns ERR_INVALID."""
+    rng = np.random.default_rng(5)
+
+    def rec(name, n, qual=True, tags=b"", sep=b"\t", flag=b"4"):
+        s = bytes(rng.choice(list(b"ACGTNacgt"), n).astype(np.uint8))
+        q = bytes(rng.choice(list(b"!#5<EIJ"), n).astype(np.uint8)) if qual else b"*"  # (not '~': printed 93 is stored as another value, SAMQVConversion.h:30)
+        return sep.join([name, flag, b"*", b"0", b"0", b"*", b"*", b"0", b"0", s, q]) + (sep + tags if tags else b"") + b"\n"
+
+    head = b"@HD\tVN:1.4\tSO:unsorted\n@SQ\tSN:c1\tLN:1000\n@RG\tID:abc\tPU:movie1\n@PG\tID:x\n@CO\tany text\n"
+    files = {
+        "plain": head + b"".join(rec(b"m/%d/0_%d" % (i, 30 + i), 30 + i) for i in range(5)),
+        "no_header": b"".join(rec(b"r%d" % i, 20 + i) for i in range(3)),
+        "no_quality": head + rec(b"a", 25, qual=False) + rec(b"b", 26),
+        "tags": head + rec(b"m/7/0_40", 40, tags=b"RG:Z:abc\tzm:i:7\tqs:i:0\tqe:i:40\trq:f:0.85\tnp:i:1\tsn:B:f,4.5,5.5,6.5,7.5"),
+        "blanks": rec(b"x", 22, sep=b" ") + rec(b"y", 23, sep=b"  \t "),
+        "aligned_record": b"q1\t16\tc1\t101\t254\t10M\t=\t0\t-5\tACGTACGTAC\tIIIIIIIIII\tAS:i:-50\n",
+        "no_final_newline": (head + rec(b"a", 30) + rec(b"b", 31)).rstrip(b"\n"),
+        "empty": b"",
+        "only_header": head,
+        "blank_line_inside": rec(b"a", 20) + b"\n" + rec(b"b", 21),       # the reference exits on the empty line
+        "short_line": rec(b"a", 20) + b"b\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\n",  # ten words
+        "bad_number": rec(b"a", 20) + b"b\t4\t*\tzero\t0\t*\t*\t0\t0\tACGT\tIIII\n",
+        "header_after_records": rec(b"a", 20) + b"@CO\tlate\n" + rec(b"b", 21),
+    }
+    for k in range(6):
+        files["random%d" % k] = (head if rng.integers(0, 2) else b"") + b"".join(
+            rec(b"r%d_%d" % (k, i), int(rng.integers(1, 200)), qual=bool(rng.integers(0, 3)),
+                sep=b"\t" if rng.integers(0, 3) else b" ") for i in range(int(rng.integers(1, 9))))
+    checked = 0
+    for name, blob in files.items():
+        path = write(tmp_path, name + ".sam", blob)
+        want = _ref_sam_in_child(path)
+        try:
+            got = hip.read_sam_reads(path)
+        except hip.BlasrHipError as e:
+            assert want is None and e.code == hip.ERR_INVALID, (name, e, want)
+            continue
+        assert want is not None, name
+        k, recs = want
+        assert k == len(got), (name, k, len(got))
+        for (t, s_, q), (wt, ws, wq) in zip(got, recs):
+            assert (t, bytes(s_), bytes(q)) == (wt, ws, wq), name
+        checked += len(got)
+    assert checked >= 25
+    assert hip.read_sam_reads(text=files["plain"])[0][0] == b"m/0/0_30"

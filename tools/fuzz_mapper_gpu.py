@@ -40,6 +40,9 @@ def main():
                     help="hand the reads over as a FASTQ file: the reference reads it with its FASTQReader (every second "
                          "record of a four-line file, FASTQReader.h:27-66), the library with blasr_hip_fastq_read; with --sam "
                          "the records carry the quality strings")
+    ap.add_argument("--sam-reads", action="store_true",
+                    help="hand the reads over as a SAM file (unaligned records with qualities): the reference reads it through "
+                         "ReaderAgglomerate's SAM branch, the library with blasr_hip_sam_reads_read (-m 4 lines only)")
     ap.add_argument("--rbao", action="store_true",
                     help="-rbao on both sides: AlignIntervals aligns between the chained anchors of each interval "
                          "(Blasr.cpp:1354-1712; the library: blasr_hip_find_intervals_chains + refine_between_anchors_only)")
@@ -149,16 +152,24 @@ def main():
                     f.write(">contig%d\n" % i)
                     for k in range(0, len(s), 60):
                         f.write(s[k:k + 60] + "\n")
-            reads_file = "reads.fastq" if args.fastq else "reads.fasta"
+            reads_file = "reads.fastq" if args.fastq else ("reads.sam" if args.sam_reads else "reads.fasta")
             quals = None
             names = ["read%d/%d/0_%d" % (r, r, len(rd)) for r, rd in enumerate(reads)]
             with open(os.path.join(tmp, reads_file), "w") as f:
+                if args.sam_reads:
+                    f.write("@HD\tVN:1.4\n@RG\tID:fuzz\tPU:m\n")
                 for r, rd in enumerate(reads):
-                    if args.fastq:  # (no '@' among the qualities: this reader takes one for a title start; tests/test_formats_cpu.py)
+                    if args.sam_reads:
+                        q = bytes(rng.choice(list(b"!+5?IJ"), len(rd)).astype(np.uint8)).decode()
+                        f.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\tRG:Z:fuzz\n" % (names[r], bytes(rd).decode(), q))
+                    elif args.fastq:  # (no '@' among the qualities: this reader takes one for a title start; tests/test_formats_cpu.py)
                         q = bytes(rng.choice(list(b"!+5?IJ"), len(rd)).astype(np.uint8)).decode()
                         f.write("@%s\n%s\n+\n%s\n" % (names[r], bytes(rd).decode(), q))
                     else:
                         f.write(">%s\n%s\n" % (names[r], bytes(rd).decode()))
+            if args.sam_reads:
+                recs = hip.read_sam_reads(os.path.join(tmp, reads_file))
+                assert [t.decode() for t, _, _ in recs] == names and all(np.array_equal(a, b) for (_, a, _), b in zip(recs, reads))
             if args.fastq:  # what the reference's reader makes of the file is what gets mapped
                 try:
                     recs = hip.read_fastq(os.path.join(tmp, reads_file))
