@@ -107,7 +107,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
                                       int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_iv_cluster *clusters,
                                       const int64_t *cluster_off, const blasr_hip_interval_params *params,
                                       blasr_hip_interval *intervals, float *p_values, int64_t capacity,
-                                      int64_t *n_intervals, int64_t *read_interval_off);
+                                      int64_t *n_intervals, int64_t *read_interval_off, int64_t *cluster_of_interval = nullptr);
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
 

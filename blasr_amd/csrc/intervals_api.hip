@@ -405,6 +405,7 @@ struct Interval {
   float pValue;
   int nAnchors, totalAnchorSize;
   std::vector<uint32_t> chain;  // WeightedInterval::matches as (t, q, l) triplets -- only kept when the caller asks for them
+  int64_t cluster = -1;         // (device route: the cluster of anchors the interval came from)
 };
 struct IntervalByPValue {  // CompareWeightedIntervalByPValue (:121-131)
   bool operator()(const Interval &a, const Interval &b) const {
@@ -589,11 +590,12 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
                                       int32_t n_reads, const blasr_hip_read *reads, const blasr_hip_iv_cluster *clusters,
                                       const int64_t *cluster_off, const blasr_hip_interval_params *params,
                                       blasr_hip_interval *intervals, float *p_values, int64_t capacity,
-                                      int64_t *n_intervals, int64_t *read_interval_off) {
+                                      int64_t *n_intervals, int64_t *read_interval_off, int64_t *cluster_of_interval) {
   Genome g{genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size};
   const blasr_hip_interval_params &P = *params;
   std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
   std::vector<std::vector<float>> perReadP((size_t)n_reads);
+  std::vector<std::vector<int64_t>> perReadC(cluster_of_interval ? (size_t)n_reads : 0);
   int threads = P.threads > 0 ? P.threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   threads = std::max(1, std::min(threads, n_reads));
   auto work = [&](int tid) {
@@ -622,6 +624,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
             iv.qLength = reads[r].length;
             iv.nAnchors = k.count;
             iv.totalAnchorSize = noOvpLisNBases;
+            iv.cluster = c;
             insert_interval(queue, (size_t)P.n_candidates, iv);
           }
         }
@@ -637,6 +640,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
         iv.strand = it->readIndex;
         perRead[(size_t)r].push_back(iv);
         perReadP[(size_t)r].push_back(it->pValue);
+        if (cluster_of_interval) perReadC[(size_t)r].push_back(it->cluster);
       }
     }
   };
@@ -654,6 +658,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
       if (total < capacity) {
         intervals[total] = perRead[(size_t)r][i];
         if (p_values) p_values[total] = perReadP[(size_t)r][i];
+        if (cluster_of_interval) cluster_of_interval[total] = perReadC[(size_t)r][i];
       }
   }
   read_interval_off[n_reads] = total;

@@ -258,7 +258,7 @@ struct PointLess {   // Coordinate::operator< (BasicEndpoint.h:28-31)
 // The chain of one cluster (n >= 2 anchors at frag[0..n)), by one wavefront; P0 / P1: 2n points each, score / prev: n,
 // tree: 4n ints.  Returns through lane 0's out.
 __device__ void chain_cluster(const blasr_hip_anchor *frag, int n, Point *P0, Point *P1, int32_t *score, int32_t *prev,
-                              int32_t *tree, blasr_hip_iv_cluster &out, const bool byRank) {
+                              int32_t *tree, blasr_hip_iv_cluster &out, const bool byRank, uint32_t *chainOut) {
   const int lane = lane_id();
   const int N = 2 * n;
   for (int f = lane; f < n; f += 64) {  // FragmentSetToEndpoints (GlobalChain.h:8-21), scores = lengths (:114-116)
@@ -378,6 +378,14 @@ __device__ void chain_cluster(const blasr_hip_anchor *frag, int n, Point *P0, Po
     f = prev[f];
   }
   const blasr_hip_anchor first = frag[firstF];
+  if (chainOut) {  // the chain itself, first anchor first (WeightedInterval::matches; only -rbao asks for it)
+    int pos = count - 1;
+    for (int f2 = (int)(P[best].fs >> 1); f2 != -1; f2 = prev[f2], pos--)
+      if (lane == 0) {
+        const blasr_hip_anchor a = frag[f2];
+        chainOut[3 * pos] = a.t, chainOut[3 * pos + 1] = a.q, chainOut[3 * pos + 2] = a.l;
+      }
+  }
   out.first_t = first.t, out.first_q = first.q, out.first_l = first.l;
   out.last_t = last.t, out.last_q = last.q, out.last_l = last.l;
   out.sum_l = sumL;
@@ -394,7 +402,8 @@ __host__ __device__ constexpr size_t chain_bytes(int cap) { return (size_t)cap *
 template <int kCls>
 __global__ __launch_bounds__(256) void iv_chain_kernel(const blasr_hip_anchor *pos0, const uint32_t *newOff, const IvCluster *clusters,
                                                        const int32_t *order, const int32_t *classCount, char *globalScratch,
-                                                       const int64_t *scratchOff, blasr_hip_iv_cluster *out) {
+                                                       const int64_t *scratchOff, blasr_hip_iv_cluster *out, uint32_t *chains,
+                                                       const int64_t *chainSlot) {
   extern __shared__ uint4 ivChainLds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int wavesPerBlock = blockDim.x >> 6;
@@ -408,8 +417,10 @@ __global__ __launch_bounds__(256) void iv_chain_kernel(const blasr_hip_anchor *p
   blasr_hip_iv_cluster res;
   res.first_t = res.first_q = res.first_l = res.last_t = res.last_q = res.last_l = 0;
   res.sum_l = res.count = 0;
+  uint32_t *chainOut = chains ? chains + 3 * chainSlot[ci] : nullptr;  // room for the cluster's n anchors
   if (n == 1) {  // (:717-719: the chain of a single anchor is that anchor)
     const blasr_hip_anchor a = frag[0];
+    if (chainOut && lane == 0) chainOut[0] = a.t, chainOut[1] = a.q, chainOut[2] = a.l;
     res.first_t = res.last_t = a.t;
     res.first_q = res.last_q = a.q;
     res.first_l = res.last_l = a.l;
@@ -423,9 +434,22 @@ __global__ __launch_bounds__(256) void iv_chain_kernel(const blasr_hip_anchor *p
     int32_t *score = reinterpret_cast<int32_t *>(P1 + 2 * cap);
     int32_t *prev = score + cap;
     int32_t *tree = prev + cap;
-    chain_cluster(frag, n, P0, P1, score, prev, tree, res, kCls != 2);
+    chain_cluster(frag, n, P0, P1, score, prev, tree, res, kCls != 2, chainOut);
   }
   if (lane == 0) out[ci] = res;
+}
+
+// the chains of the clusters that became intervals, back to back: one wavefront per interval
+__global__ __launch_bounds__(256) void iv_gather_chains_kernel(int n, const int64_t *src, const int64_t *dst, const uint32_t *chains,
+                                                               uint32_t *out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t a = 3 * src[i], b = 3 * dst[i], words = 3 * (dst[i + 1] - dst[i]);
+  for (int64_t w = threadIdx.x & 63; w < words; w += 64) out[b + w] = chains[a + w];
+}
+__global__ __launch_bounds__(256) void iv_cluster_sizes_kernel(const IvCluster *clusters, int nClusters, int64_t *sizes) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nClusters) sizes[i] = (int64_t)(clusters[i].end - clusters[i].start);
 }
 
 // cluster sizes -> class of every cluster, class counts (wave-aggregated), and for class 2 its scratch bytes
@@ -450,12 +474,21 @@ using namespace blasr_hip;
 
 extern "C" {
 
-int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
-                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
-                                    const blasr_hip_read *reads, const blasr_hip_anchor *anchors_device, const int64_t *list_off,
-                                    const blasr_hip_interval_params *params, blasr_hip_interval *intervals, float *p_values,
-                                    int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off) {
+int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length,
+                                           const uint32_t *seq_start_pos, int32_t n_seq_pos, const int32_t *count_table,
+                                           int32_t count_tuple_size, int32_t n_reads, const blasr_hip_read *reads,
+                                           const blasr_hip_anchor *anchors_device, const int64_t *list_off,
+                                           const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
+                                           float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
+                                           uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
+  const bool wantChains = chains_used != nullptr;
+  if (wantChains) {
+    *chains_used = 0;
+    if (chains_capacity < 0 || (chains_capacity > 0 && !chains) || (capacity > 0 && !chain_off))
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "find_intervals_device: bad chain arguments");
+    for (int64_t i = 0; i <= capacity && chain_off; i++) chain_off[i] = 0;
+  }
   if (!genome || genome_length <= 0 || genome_length >= (1ll << 32) || !seq_start_pos || n_seq_pos < 1 || !count_table ||
       count_tuple_size < 1 || count_tuple_size > 14 || n_reads < 0 || !params || !n_intervals || !read_interval_off ||
       capacity < 0 || (capacity > 0 && !intervals) || (n_reads > 0 && (!reads || !list_off)))
@@ -549,6 +582,13 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
   HIP_TRY(ctx, hipGetLastError());
   const int nClusters = (int)cOff[(size_t)nLists];
   std::vector<blasr_hip_iv_cluster> summary((size_t)nClusters);
+  struct FreeDev {
+    void *p = nullptr;
+    ~FreeDev() {
+      if (p) (void)hipFree(p);
+    }
+  } chainsMem, chainSlotMem;        // -rbao only: every cluster's chain, in a slot as long as the cluster
+  std::vector<int64_t> chainSlot;   // the slots' offsets (triplets), nClusters + 1
   if (nClusters > 0) {
     // cluster records, classes and results behind the fixed part (the per-anchor arrays stay: the chains read dPos)
     size_t at2 = fixedBytes;
@@ -570,9 +610,9 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
       // (growing the workspace loses its contents: run again from the top with the room known -- rare, first call only)
       const int rc = blasr_hip_grow_workspace(ctx, at2 + at2 / 4);
       if (rc != BLASR_HIP_OK) return rc;
-      return blasr_hip_find_intervals_device(ctx, genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
-                                             n_reads, reads, anchors_device, list_off, params, intervals, p_values, capacity,
-                                             n_intervals, read_interval_off);
+      return blasr_hip_find_intervals_device_chains(ctx, genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                                    n_reads, reads, anchors_device, list_off, params, intervals, p_values, capacity,
+                                                    n_intervals, read_interval_off, chains, chains_capacity, chains_used, chain_off);
     }
     IvCluster *dCl = (IvCluster *)(w + oCl);
     int32_t *dCls = (int32_t *)(w + oCls), *dIdx = (int32_t *)(w + oIdx), *dIdxOut = (int32_t *)(w + oIdxOut),
@@ -591,6 +631,23 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
     }
     int32_t classCount[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(classCount, dTotals, sizeof(classCount), hipMemcpyDeviceToHost));
+    if (wantChains) {  // a slot per cluster (an exclusive scan of the clusters' sizes), then the memory
+      HIP_TRY(ctx, hipMalloc(&chainSlotMem.p, sizeof(int64_t) * 2 * ((size_t)nClusters + 1)));
+      int64_t *dSizes = (int64_t *)chainSlotMem.p, *dSlot = dSizes + nClusters + 1;
+      HIP_TRY(ctx, hipMemsetAsync(dSizes + nClusters, 0, sizeof(int64_t), st));
+      hipLaunchKernelGGL(iv_cluster_sizes_kernel, dim3((unsigned)((nClusters + 255) / 256)), dim3(256), 0, st, dCl, nClusters, dSizes);
+      size_t sb = 0;
+      HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, sb, dSizes, dSlot, (int64_t)0, (size_t)nClusters + 1, rocprim::plus<int64_t>(), st));
+      FreeDev scanTmp;
+      HIP_TRY(ctx, hipMalloc(&scanTmp.p, std::max<size_t>(sb, 256)));
+      HIP_TRY(ctx, rocprim::exclusive_scan(scanTmp.p, sb, dSizes, dSlot, (int64_t)0, (size_t)nClusters + 1, rocprim::plus<int64_t>(), st));
+      chainSlot.resize((size_t)nClusters + 1);
+      HIP_TRY(ctx, hipMemcpyAsync(chainSlot.data(), dSlot, sizeof(int64_t) * chainSlot.size(), hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      HIP_TRY(ctx, hipMalloc(&chainsMem.p, sizeof(uint32_t) * 3 * (size_t)std::max<int64_t>(chainSlot[(size_t)nClusters], 1)));
+    }
+    uint32_t *dChains = (uint32_t *)chainsMem.p;
+    const int64_t *dChainSlot = wantChains ? (const int64_t *)chainSlotMem.p + nClusters + 1 : nullptr;
     // class 2: scratch in global memory, sized per cluster
     char *dScratch = nullptr;
     int64_t *dScratchOff = nullptr;
@@ -627,13 +684,13 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
     }
     if (classCount[0] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<0>), dim3((unsigned)((classCount[0] + 3) / 4)), dim3(256), 4 * chain_bytes(kChainSmall), st, dPos,
-                         dNewOff, dCl, dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes);
+                         dNewOff, dCl, dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
     if (classCount[1] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<1>), dim3((unsigned)classCount[1]), dim3(64), chain_bytes(kChainMid), st, dPos, dNewOff, dCl,
-                         dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes);
+                         dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
     if (classCount[2] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<2>), dim3((unsigned)classCount[2]), dim3(64), 0, st, dPos, dNewOff, dCl, dIdxOut,
-                         (const int32_t *)dTotals, dScratch, dScratchOff, dRes);
+                         (const int32_t *)dTotals, dScratch, dScratchOff, dRes, dChains, dChainSlot);
     HIP_TRY(ctx, hipMemcpyAsync(summary.data(), dRes, sizeof(blasr_hip_iv_cluster) * summary.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
@@ -641,9 +698,51 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
   // ---- the host's end: p-values, the tests of FindMaxInterval.h:805-825, the interval sets
   std::vector<int64_t> cOff64((size_t)nLists + 1);
   for (int i = 0; i <= nLists; i++) cOff64[(size_t)i] = (int64_t)cOff[(size_t)i];
-  return blasr_hip_intervals_from_clusters(genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size, n_reads,
-                                           reads, summary.data(), cOff64.data(), params, intervals, p_values, capacity, n_intervals,
-                                           read_interval_off);
+  std::vector<int64_t> clusterOf(wantChains ? (size_t)std::max<int64_t>(capacity, 1) : 0);
+  const int rc = blasr_hip_intervals_from_clusters(genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                                   n_reads, reads, summary.data(), cOff64.data(), params, intervals, p_values, capacity,
+                                                   n_intervals, read_interval_off, wantChains ? clusterOf.data() : nullptr);
+  if (rc != BLASR_HIP_OK) return rc == BLASR_HIP_ERR_CAPACITY ? blasr_hip_fail(ctx, rc, "find_intervals_device: %lld intervals, room for %lld",
+                                                                                (long long)*n_intervals, (long long)capacity) : rc;
+  if (wantChains) {  // the chains of the clusters that became intervals, gathered on the device, one download
+    const int64_t nIv = *n_intervals;
+    std::vector<int64_t> src((size_t)nIv + 1, 0), dst((size_t)nIv + 1, 0);
+    for (int64_t k = 0; k < nIv; k++) {
+      const int64_t c = clusterOf[(size_t)k];
+      src[(size_t)k] = chainSlot[(size_t)c];
+      dst[(size_t)k + 1] = dst[(size_t)k] + summary[(size_t)c].count;
+    }
+    const int64_t total = dst[(size_t)nIv];
+    *chains_used = total;
+    for (int64_t k = 0; k <= nIv; k++) chain_off[k] = dst[(size_t)k];
+    if (total > chains_capacity)
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "find_intervals_device: %lld chained anchors, room for %lld", (long long)total,
+                            (long long)chains_capacity);
+    if (total > 0) {
+      FreeDev dIdx, dOut;
+      HIP_TRY(ctx, hipMalloc(&dIdx.p, sizeof(int64_t) * 2 * ((size_t)nIv + 1)));
+      HIP_TRY(ctx, hipMalloc(&dOut.p, sizeof(uint32_t) * 3 * (size_t)total));
+      int64_t *dSrc = (int64_t *)dIdx.p, *dDst = dSrc + nIv + 1;
+      HIP_TRY(ctx, hipMemcpyAsync(dSrc, src.data(), sizeof(int64_t) * ((size_t)nIv + 1), hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dDst, dst.data(), sizeof(int64_t) * ((size_t)nIv + 1), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(iv_gather_chains_kernel, dim3((unsigned)((nIv + 3) / 4)), dim3(256), 0, st, (int)nIv, dSrc, dDst,
+                         (const uint32_t *)chainsMem.p, (uint32_t *)dOut.p);
+      HIP_TRY(ctx, hipMemcpyAsync(chains, dOut.p, sizeof(uint32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
+  return BLASR_HIP_OK;
+}
+
+int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
+                                    int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
+                                    const blasr_hip_read *reads, const blasr_hip_anchor *anchors_device, const int64_t *list_off,
+                                    const blasr_hip_interval_params *params, blasr_hip_interval *intervals, float *p_values,
+                                    int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off) {
+  return blasr_hip_find_intervals_device_chains(ctx, genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
+                                                n_reads, reads, anchors_device, list_off, params, intervals, p_values, capacity,
+                                                n_intervals, read_interval_off, nullptr, 0, nullptr, nullptr);
 }
 
 }  // extern "C"

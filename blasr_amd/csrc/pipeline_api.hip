@@ -80,14 +80,15 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   const int32_t perBlock = params->reads_per_block > 0 ? params->reads_per_block : 100000;
   const double t0 = now_ms();
 
-  // -rbao reads the intervals' chained anchors, which the host's interval finder hands out (blasr_hip_find_intervals_chains)
-  // and the device's does not yet: that switch takes the host route below
+  // -rbao reads the intervals' chained anchors: both interval finders hand them out on request
   const bool wantChains = params->map.refine_between_anchors_only != 0;
-  if (!getenv("BLASR_HIP_INTERVALS_HOST") && !wantChains) {
+  if (!getenv("BLASR_HIP_INTERVALS_HOST")) {
     // ---- anchors and intervals of every sub-block on the device; the anchor buffer is the same for all of them
     std::vector<blasr_hip_interval> ivs;
     std::vector<int64_t> listOff, ivOff;
     std::vector<blasr_hip_interval> blockIvs;
+    std::vector<uint32_t> allChains, blockChains;     // (t, q, l) triplets of the intervals' chains, back to back
+    std::vector<int64_t> allChainOff, blockChainOff;  // one entry per interval, + 1
     int64_t anchorsInAll = 0;
     double ivMs = 0;
     for (int32_t first = 0; first < n_reads; first += perBlock) {
@@ -110,10 +111,32 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       blockIvs.resize((size_t)count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
       ivOff.assign((size_t)count + 1, 0);
       int64_t nIv = 0;
-      const int rcI = blasr_hip_find_intervals_device(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
-                                                      count_tuple_size, count, reads_host + first, (const blasr_hip_anchor *)ctx->pipeAnchors.p,
-                                                      listOff.data(), &params->interval, blockIvs.data(), nullptr,
-                                                      (int64_t)blockIvs.size(), &nIv, ivOff.data());
+      int rcI;
+      if (wantChains) {
+        int64_t chainsUsed = 0;
+        blockChains.resize(3 * (size_t)std::max<int64_t>(n, 1));  // (grown below when ten intervals of a read share anchors)
+        blockChainOff.assign(blockIvs.size() + 1, 0);
+        for (int attempt = 0; attempt < 2; attempt++) {
+          rcI = blasr_hip_find_intervals_device_chains(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
+                                                       count_tuple_size, count, reads_host + first,
+                                                       (const blasr_hip_anchor *)ctx->pipeAnchors.p, listOff.data(), &params->interval,
+                                                       blockIvs.data(), nullptr, (int64_t)blockIvs.size(), &nIv, ivOff.data(),
+                                                       blockChains.data(), (int64_t)(blockChains.size() / 3), &chainsUsed,
+                                                       blockChainOff.data());
+          if (rcI != BLASR_HIP_ERR_CAPACITY || nIv > (int64_t)blockIvs.size()) break;
+          blockChains.resize(3 * (size_t)chainsUsed);
+        }
+        if (rcI == BLASR_HIP_OK) {
+          const int64_t shift = (int64_t)(allChains.size() / 3);
+          for (int64_t i = 0; i < nIv; i++) allChainOff.push_back(shift + blockChainOff[(size_t)i]);
+          allChains.insert(allChains.end(), blockChains.begin(), blockChains.begin() + 3 * chainsUsed);
+        }
+      } else {
+        rcI = blasr_hip_find_intervals_device(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
+                                              count_tuple_size, count, reads_host + first, (const blasr_hip_anchor *)ctx->pipeAnchors.p,
+                                              listOff.data(), &params->interval, blockIvs.data(), nullptr,
+                                              (int64_t)blockIvs.size(), &nIv, ivOff.data());
+      }
       if (rcI != BLASR_HIP_OK) return rcI;
       ivMs += now_ms() - h0;
       for (int64_t i = 0; i < nIv; i++) {
@@ -128,8 +151,14 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
     int rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(total + 1));
     if (rc != BLASR_HIP_OK) return rc;
     HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, ivs.data(), sizeof(blasr_hip_interval) * (size_t)total, hipMemcpyHostToDevice));
+    blasr_hip_map_params mapParams = params->map;
+    if (wantChains) {
+      allChainOff.push_back((int64_t)(allChains.size() / 3));
+      mapParams.iv_chains = allChains.data();
+      mapParams.iv_chain_off = allChainOff.data();
+    }
     rc = blasr_hip_map_reads_device(ctx, n_reads, reads_device, read_pool_device, (int32_t)total,
-                                    (const blasr_hip_interval *)ctx->pipeIntervals.p, &params->map, hits, hits_capacity, n_hits,
+                                    (const blasr_hip_interval *)ctx->pipeIntervals.p, &mapParams, hits, hits_capacity, n_hits,
                                     read_hit_off, fetch);
     const double t3 = now_ms();
     ctx->pipeMs[0] = (float)(t1 - t0);  // anchoring + interval finding of all sub-blocks

@@ -46,7 +46,7 @@ EXPORTS = [
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
     "blasr_hip_count_tuples_device", "blasr_hip_pipeline_default_params", "blasr_hip_map_from_reads_device", "blasr_hip_map_from_reads_host",
-    "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains",
+    "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains", "blasr_hip_find_intervals_device_chains",
     "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
     "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
 ]
@@ -1103,10 +1103,10 @@ class Context:
                                                            off.ctypes.data))
         return need.value, off
 
-    def find_intervals_device(self, genome, seq_start_pos, count_table, reads, anchors_ptr, list_off, params=None):
+    def find_intervals_device(self, genome, seq_start_pos, count_table, reads, anchors_ptr, list_off, params=None, chains=False):
         """blasr_hip_find_intervals_device: the anchors stay on the device (anchors_ptr: raw address of the sorted anchor
         array blasr_hip_anchor_reads_device wrote); (intervals INTERVAL_DTYPE, read_interval_off, p_values) like
-        hip.find_intervals."""
+        hip.find_intervals; with chains=True (blasr_hip_find_intervals_device_chains) also (chains (m, 3) uint32, chain_off)."""
         genome = np.ascontiguousarray(genome, dtype=np.uint8)
         starts = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
         table = np.ascontiguousarray(count_table, dtype=np.int32)
@@ -1126,6 +1126,19 @@ class Context:
             C.c_int32(len(starts)), C.c_void_p(table.ctypes.data), C.c_int32(k), C.c_int32(n), C.c_void_p(reads.ctypes.data),
             C.c_void_p(anchors_ptr), C.c_void_p(list_off.ctypes.data), C.byref(params), C.c_void_p(out.ctypes.data),
             C.c_void_p(pv.ctypes.data), C.c_int64(cap), C.byref(need), C.c_void_p(off.ctypes.data)))
+        if chains:
+            ccap = max(int(list_off[-1] - list_off[0]), 1)
+            ch = np.zeros((ccap, 3), dtype=np.uint32)
+            coff = np.zeros(cap + 1, dtype=np.int64)
+            cused = C.c_int64(0)
+            self.lib.blasr_hip_find_intervals_device_chains.argtypes = None
+            self._check(self.lib.blasr_hip_find_intervals_device_chains(
+                self.handle, C.c_void_p(genome.ctypes.data), C.c_int64(len(genome)), C.c_void_p(starts.ctypes.data),
+                C.c_int32(len(starts)), C.c_void_p(table.ctypes.data), C.c_int32(k), C.c_int32(n), C.c_void_p(reads.ctypes.data),
+                C.c_void_p(anchors_ptr), C.c_void_p(list_off.ctypes.data), C.byref(params), C.c_void_p(out.ctypes.data),
+                C.c_void_p(pv.ctypes.data), C.c_int64(cap), C.byref(need), C.c_void_p(off.ctypes.data),
+                C.c_void_p(ch.ctypes.data), C.c_int64(ccap), C.byref(cused), C.c_void_p(coff.ctypes.data)))
+            return out[: need.value], off, pv[: need.value], ch[: cused.value], coff[: need.value + 1]
         return out[: need.value], off, pv[: need.value]
 
     def anchor_last_timing(self):

@@ -905,6 +905,17 @@ int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, i
                                     const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
                                     float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off);
 
+/* blasr_hip_find_intervals_device that also hands out the intervals' chained anchors, like blasr_hip_find_intervals_chains:
+ * the chain kernel writes every cluster's chain on the device, the chains of the clusters that became intervals are gathered
+ * there and come back in one copy (chains / chain_off: host memory). */
+int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length,
+                                           const uint32_t *seq_start_pos, int32_t n_seq_pos, const int32_t *count_table,
+                                           int32_t count_tuple_size, int32_t n_reads, const blasr_hip_read *reads,
+                                           const blasr_hip_anchor *anchors_device, const int64_t *list_off,
+                                           const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
+                                           float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
+                                           uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off);
+
 /* ------------------------------------------------------------------------------------------------
  * next-4: the suffix array and its lookup table built on the device, and sawriter's file written.  Replaces
  * LarssonBuildSuffixArray + BuildLookupTable (common/datastructures/suffixarray/SuffixArray.h:256-269, :193-249) as

@@ -33,6 +33,11 @@ def compare(ctx, genome, starts, ct, reads, anchors, off, kw, tag):
     assert np.array_equal(goff, woff), (tag, kw)
     assert np.array_equal(as_rows(got), as_rows(want)), (tag, kw)
     assert np.array_equal(gpv, wpv), (tag, kw)
+    # and the intervals' chained anchors (what -rbao reads), host against device
+    _, _, _, wch, wco = hip.find_intervals(genome, starts, ct, reads, anchors, off, p, chains=True)
+    buf = torch.from_numpy(anchors.view(np.uint8).copy() if len(anchors) else np.zeros(16, np.uint8)).cuda()
+    got2, _, _, gch, gco = ctx.find_intervals_device(genome, starts, ct, reads, buf.data_ptr(), off, p, chains=True)
+    assert np.array_equal(as_rows(got2), as_rows(want)) and np.array_equal(gco, wco) and np.array_equal(gch, wch), (tag, kw)
     return len(want)
 
 
