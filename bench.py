@@ -36,6 +36,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch starts the HIP runtime (blasr_hip_create says why)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

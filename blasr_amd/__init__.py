@@ -7,7 +7,13 @@ the reference's call surface (``RefineAlignments``, alignment/Blasr.cpp:2164).
 It contains no CPU implementation of the algorithms and never imports
 ``oracle/``: if the HIP library or a gfx950 device is missing, calls raise.
 """
-from .hip import (  # noqa: F401
+import os as _os
+
+# The library's streams need more hardware queues than the HIP runtime's default of four (blasr_hip_create says why); the
+# variable is read when the runtime starts, which a Python host does on its first torch.cuda / HIP call.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .hip import (  # noqa: F401,E402
     BlasrHipError,
     Context,
     LIB_PATH,

@@ -132,6 +132,12 @@ int blasr_hip_abi_version(void) { return BLASR_HIP_ABI_VERSION; }
 int blasr_hip_create(int device, blasr_hip_ctx **out) {
   if (!out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
+  // The sweep of an SDP level runs its four kernels side by side on four streams (sdp_kernels.hip: launch_sdp_chain), and
+  // the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise): two of the four then share
+  // a queue and run one after the other (10 ms per configs[2] step).  Eight queues, unless the caller has decided; this
+  // only takes effect when the HIP runtime has not been initialised yet (hosts that initialise it first -- torch -- set
+  // the variable themselves: bench.py, blasr_amd/__init__.py).
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
     (void)hipGetLastError();
