@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <functional>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
@@ -137,7 +138,8 @@ int blasr_hip_create(int device, blasr_hip_ctx **out) {
   // a queue and run one after the other (10 ms per configs[2] step).  Eight queues, unless the caller has decided; this
   // only takes effect when the HIP runtime has not been initialised yet (hosts that initialise it first -- torch -- set
   // the variable themselves: bench.py, blasr_amd/__init__.py).
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  static std::once_flag queuesOnce;  // (contexts are created from several mapping threads)
+  std::call_once(queuesOnce, []() { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
     (void)hipGetLastError();
