@@ -15,7 +15,9 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -241,6 +243,13 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "align_between_anchors: bandSize %d outside [1, 543]", prm->band);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  const bool trace = getenv("BLASR_HIP_RBAO_TRACE") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tPhase = now();
+  auto lap = [&](const char *what, size_t count) {
+    if (trace) fprintf(stderr, "[rbao] %-28s %9.1f ms  (%zu)\n", what, now() - tPhase, count);
+    tPhase = now();
+  };
 
   // ---- the candidates' geometry, on the host
   std::vector<blasr_hip_window> win((size_t)n);
@@ -293,6 +302,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "align_between_anchors: candidate %d takes the -sdpbypass "
                             "branch (its anchors cover sdp_bypass_threshold of the subread), which is not offered", i);
 
+  lap("anchors per candidate", (size_t)n);
   // ---- :1578-1634 the gaps that get an AlignSubstring
   std::vector<GapTask> gaps;
   for (int i = 0; i < n; i++) {
@@ -337,6 +347,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
     }
   }
 
+  lap("gap tasks", gaps.size());
   std::vector<int32_t> gapBlocks;  // (q, t, length) of every gap's blocks, relative to the candidate's window
   int rc;
   const size_t kChunk = 1u << 21;  // gap tasks per device batch
@@ -411,6 +422,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
     }
   }
 
+  lap("AffineKBandAlign gaps", gapBlocks.size() / 3);
   // ---- SDPAlign gaps, by word size: SDPAlign (Global), the pinned end blocks, RefineAlignment on the gap
   for (int pass = 0; pass < 2; pass++) {
     const int wordSize = pass == 0 ? prm->sdp.word_size : 7;
@@ -466,6 +478,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
         blkCap = blkUsed + 64;
       }
       if (rc) return rc;
+      lap("  SDPAlign batch", m);
       std::vector<blasr_hip_sdp_result> hres(m);
       std::vector<int32_t> hblk(3 * (size_t)std::max<int64_t>(blkUsed, 1));
       HIP_TRY(ctx, hipMemcpy(hres.data(), dres.p, sizeof(blasr_hip_sdp_result) * m, hipMemcpyDeviceToHost));
@@ -503,6 +516,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
         opsCap += (int64_t)(z[0] + z[2]) + (z[1] + z[2]) + 16;
       }
       const size_t nr = rTask.size();
+      lap("  pins and guides", nr);
       if (nr == 0) continue;
       Dev<int64_t> gq, gt, gbo;
       Dev<int32_t> gql, gtl, gnb, gblk;
@@ -542,6 +556,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
         opsCap = opsUsed + 64;
       }
       if (rc) return rc;
+      lap("  RefineAlignment batch", nr);
       std::vector<blasr_hip_refine_result> hr(nr);
       std::vector<uint32_t> hops((size_t)std::max<int64_t>(opsUsed, 1));
       HIP_TRY(ctx, hipMemcpy(hr.data(), gres.p, sizeof(blasr_hip_refine_result) * nr, hipMemcpyDeviceToHost));
@@ -560,6 +575,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
     }
   }
 
+  lap("SDPAlign + refine gaps", gapBlocks.size() / 3);
   // ---- :1578-1705 per candidate: anchors and gap alignments in order, qPos / tPos taken out, abutting blocks merged
   std::vector<blasr_hip_sdp_result> res((size_t)n);
   std::vector<int32_t> out;
@@ -622,6 +638,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
                      dMatrix.p, prm->score.ins, prm->score.del, prm->score.affine_open, prm->score.affine_extend, results);
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  lap("assembly + statistics", (size_t)total);
   return BLASR_HIP_OK;
 }
 

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--gpu-nproc", type=int, nargs="+", default=[1, 4])
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--switches", nargs="*", default=[], help="more switches for BOTH binaries, without their dash (e.g. rbao, extend)")
     ap.add_argument("--reference-mapping-s", type=float, default=0.0,
                     help="tuning runs: do not run the unpatched binary again, take this as its mapping time (no lines compared)")
     args = ap.parse_args()
@@ -44,7 +45,7 @@ def main():
     wl = synth.make_map_workload(genome, copies, args.reads, args.read_len, args.seed, dev, ins=0.11, dele=0.04, sub=0.01,
                                  max_unanchored=300, spurious=0.0, loose=0.0, spurious_span=None)
     g = genome.cpu().numpy()
-    out = dict(genome_bases=int(len(g)), reads=args.reads, read_len=args.read_len, batch=args.batch)
+    out = dict(genome_bases=int(len(g)), reads=args.reads, read_len=args.read_len, batch=args.batch, switches=args.switches)
     with tempfile.TemporaryDirectory() as tmp:
         fa = os.path.join(tmp, "genome.fasta")
         with open(fa, "wb") as f:
@@ -74,9 +75,10 @@ def main():
         def run(exe, reads_file, extra, tag):
             path = os.path.join(tmp, tag + ".m4")
             t0 = time.perf_counter()
-            p = subprocess.run([exe, os.path.join(tmp, reads_file), fa, "-sa", fa + ".sa", "-m", "4", "-bestn", "1", "-out", path] + extra,
+            p = subprocess.run([exe, os.path.join(tmp, reads_file), fa, "-sa", fa + ".sa", "-m", "4", "-bestn", "1", "-out", path] + extra +
+                               ["-" + x for x in args.switches],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, BLASR_HIP_DROPIN_TRACE="1"))
-            trace.extend(x for x in p.stdout.decode().splitlines() if x.startswith("[dropin]"))
+            trace.extend(x for x in p.stdout.decode().splitlines() if x.startswith("[dropin]") or x.startswith("[rbao]"))
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 return dt, None, p.stdout.decode()[-400:]
@@ -103,7 +105,7 @@ def main():
                 d["lines_that_differ"] = len(set(lines) ^ set(ref_lines))
             if lines is not None:
                 d["speedup_over_reference"] = round((t_ref - t_none) / max(t_g - t_g0, 1e-9), 1)
-            d["trace"] = trace[-12:]
+            d["trace"] = trace[-40:] if os.environ.get("BLASR_HIP_RBAO_TRACE") else trace[-12:]
             del trace[:]
             out["dropin"].append(d)
     print(json.dumps(out))
