@@ -689,15 +689,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   if (slot0 >= args.count) return;
 
   // ---- the candidates of this wavefront (uniform values), and each lane's own candidate
-  int taskG[kT], qG[kT];
-  const int2 *rowTabG[kT];
-  const unsigned short *rowMetaG[kT];
-  // hybrid variant: what the wavefront needs of a candidate when it takes one of its wide rows
-  int tEndG[kT], tLenG[kT], gMaskG[kT];
-  unsigned cellsG[kT];
-  const uint8_t *tSeqG[kT];
-  uint8_t *arrowsG[kT];
-  int2 *gRingG[kT];
+  int maxQ = 0;
+  int64_t myRowOff = 0;  // (the candidates' uniform values are read off their lanes: from_group below)
+  // hybrid variant: what the wavefront needs of a candidate when it takes one of its wide rows is read off that
+  // candidate's lanes when the moment comes (from_group below): as uniform arrays for four candidates these values alone
+  // were 40 scalar registers held through the whole kernel, and the narrow rows paid for them in spills
+  unsigned myCells = 0;
   int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myTLoaded = 0, myGMask = 0;
   bool myPrevGlobal = false;  // the row above lives in the global ring (the last row was a wide one)
   int mySkipUntil = 0;        // rows up to this one were taken ahead of their turn (a run of wide rows, below)
@@ -706,41 +703,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   uint8_t *myArrows = nullptr;
 #pragma unroll
   for (int g = 0; g < kT; g++) {
-    taskG[g] = -1;
-    qG[g] = 0;
-    rowTabG[g] = nullptr;
-    rowMetaG[g] = nullptr;
-    tEndG[g] = tLenG[g] = gMaskG[g] = 0;
-    cellsG[g] = 0;
-    tSeqG[g] = nullptr;
-    arrowsG[g] = nullptr;
-    gRingG[g] = nullptr;
     if (slot0 + g < args.count && args.taskList[slot0 + g] >= 0) {  // (the hybrid list has empty slots: -1)
       const int task = args.taskList[slot0 + g];
-      taskG[g] = task;
-      if (kHybrid) {
-        const int32_t *blk = batch.blocks + 3 * batch.blk_off[task];
-        const int nb = batch.n_blocks[task];
-        tEndG[g] = blk[3 * (nb - 1) + 1] + blk[3 * (nb - 1) + 2];
-        tLenG[g] = batch.t_len[task];
-        cellsG[g] = (unsigned)args.geo[task].cells;
-        tSeqG[g] = batch.seq + batch.t_off[task];
-        arrowsG[g] = args.arrows + args.arrowOff[task];
-        gMaskG[g] = args.wideRingSize[slot0 + g] - 1;
-        gRingG[g] = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot0 + g]);
-        if (grp == g) {
-          myGMask = gMaskG[g];
-          myGRing = gRingG[g];
-        }
+      if (kHybrid && grp == g) {
+        myCells = (unsigned)args.geo[task].cells;
+        myGMask = args.wideRingSize[slot0 + g] - 1;
+        myGRing = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot0 + g]);
       }
       const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
       const int nBlocks = batch.n_blocks[task];
       GuideCursor cur;
       guide_begin(cur, blocks, nBlocks, args.band);
-      qG[g] = cur.Q;
-      rowTabG[g] = args.rowTab + args.rowOff[task];
-      rowMetaG[g] = args.rowMeta + args.rowOff[task];
+      maxQ = max(maxQ, cur.Q);
       if (grp == g) {
+        myRowOff = args.rowOff[task];
         myTask = task;
         myQ = cur.Q;
         myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
@@ -752,9 +728,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
       }
     }
   }
-  int maxQ = 0;
-#pragma unroll
-  for (int g = 0; g < kT; g++) maxQ = max(maxQ, qG[g]);
+  // a value / a pointer of candidate g, uniform, from its first lane
+  auto from_group = [&](int v, int g) { return __builtin_amdgcn_readlane(v, g * kL); };
+  auto ptr_from_group = [&](const void *p, int g) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, g * kL);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), g * kL);
+    return ((uint64_t)hi << 32) | lo;
+  };
   int2 *ring = ringLds[wave][grp];
   uint32_t *ringT = ringTLds[wave][grp];
 
@@ -794,19 +775,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     bool nV = false;       // some query base of these rows is not ACGT
 #pragma unroll
     for (int g = 0; g < kT; g++) {
-      if (taskG[g] >= 0 && r0 <= qG[g]) {
-        const int nRows = min(64, qG[g] - r0 + 1);
+      const int qOfG = from_group(myQ, g);
+      if (from_group(myTask, g) >= 0 && r0 <= qOfG) {
+        const int nRows = min(64, qOfG - r0 + 1);
+        const int64_t rowOffOfG = (int64_t)ptr_from_group((const void *)(uint64_t)myRowOff, g);
+        const int2 *rowTabOfG = args.rowTab + rowOffOfG;
+        const unsigned short *rowMetaOfG = args.rowMeta + rowOffOfG;
         int lastV = INT32_MIN, loV = 0;
         if (lane < nRows) {
-          const int2 rec = rowTabG[g][r0 + lane];
-          const unsigned m = rowMetaG[g][r0 + lane];
+          const int2 rec = rowTabOfG[r0 + lane];
+          const unsigned m = rowMetaOfG[r0 + lane];
           int width = (int)(m & 0xfffu);
           const int qc = (int)(m >> 12);
           loV = rec.y;
           if (kHybrid && width == 0xfff) {  // saturated: the row's cells are what lies before the next row's first one
-            const unsigned next = r0 + lane < qG[g] ? (unsigned)rowTabG[g][r0 + lane + 1].x : cellsG[g];
+            const unsigned next = r0 + lane < qOfG ? (unsigned)rowTabOfG[r0 + lane + 1].x : (unsigned)from_group((int)myCells, g);
             const int hi = loV + (int)(next - (unsigned)rec.x) - 1;
-            width = min(hi, tEndG[g] - 1) - loV + 1;
+            width = min(hi, from_group(myTEnd, g) - 1) - loV + 1;
           }
           rowA[wave][g][lane] = rec;
           rowB[wave][g][lane] = (RowB)((unsigned)width | ((unsigned)qc << kQcShift));
@@ -867,10 +852,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             //  step then wait on -- which would serialise the prefetch of the next step behind this one)
             typedef unsigned long long __attribute__((address_space(1))) GPair;  // {S, I} of a ring entry
             typedef uint8_t __attribute__((address_space(1))) GByte;
-            GPair *gring = (GPair *)gRingG[g];
+            GPair *gring = (GPair *)ptr_from_group(myGRing, g);
             auto pair_of = [](int2 v) { return (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32); };
             auto int2_of = [](unsigned long long p) { return make_int2((int)(uint32_t)p, (int)(uint32_t)(p >> 32)); };
-            const int gmask = gMaskG[g];
+            const int gmask = from_group(myGMask, g);
+            const int tLenOfG = from_group(myTLen, g);
+            const uint64_t arrowsOfG = ptr_from_group(myArrows, g), tSeqOfG = ptr_from_group(myTSeq, g);
             // ---- A RUN of wide rows, the row above in REGISTERS.  The wide rows of a guide come in runs -- the gap rows
             // between two blocks (GuidedAlign.h:193-250), a few hundred columns each, whose first column moves by 0 or 1
             // from row to row.  Through the global ring every one of them waits for the stores of the row before it (a
@@ -881,7 +868,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             // columns, or one that starts more than one column further on, ends the run and takes the ring path below.
             {
               constexpr int kW = 3, kWStep = 64 * kW, kRunSteps = 3, kRunMax = kRunSteps * kWStep;
-              const int nG = min(64, qG[g] - r0 + 1);  // rows of candidate g in this batch
+              const int nG = min(64, from_group(myQ, g) - r0 + 1);  // rows of candidate g in this batch
               int run = 0;
               if (wHi - wLo + 1 <= kRunMax && wPhi - wLo + 1 <= kRunMax && args.exp != 3) {
                 int pS[kRunSteps][kW], pI[kRunSteps][kW];
@@ -902,9 +889,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 if (wLo - 1 >= wPlo && wLo - 1 <= wPhi)
                   leftS = wGlobal ? (int)(uint32_t)gring[(wLo - 1) & gmask] : ringLds[wave][g][(wLo - 1) & (kF4Ring - 1)].x;
                 leftS = __builtin_amdgcn_readfirstlane(leftS);
-                GByte *aBase = (GByte *)arrowsG[g];
-                const GByte *wT = (const GByte *)tSeqG[g];
-                const int wTLen = tLenG[g], tLast = max(wTLen - 1, 0);
+                GByte *aBase = (GByte *)arrowsOfG;
+                const GByte *wT = (const GByte *)tSeqOfG;
+                const int wTLen = tLenOfG, tLast = max(wTLen - 1, 0);
                 // The target bases of the 576 columns from `base` on, three to a register like the cells (byte j of
                 // tP[step] = the base of cell (step, lane, j)), loaded once per run and handed on by the same lane shift
                 // as the row above: a load at the head of every step would expose its whole latency, once per step.
@@ -1082,8 +1069,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             // its own columns (and one to their left); the candidate's last row only feeds the final score.  The
             // others are not stored -- most of a wide row, which nothing below it ever looks at.
             int keepLo = INT32_MIN, keepHi = INT32_MAX;
-            if (r == qG[g]) {
-              keepLo = keepHi = tEndG[g] - 1;
+            if (r == from_group(myQ, g)) {
+              keepLo = keepHi = from_group(myTEnd, g) - 1;
             } else if (i + 1 < 64) {
               const int nLo = rowA[wave][g][i + 1].y;
               const int nWidth = (int)((unsigned)rowB[wave][g][i + 1] & kWidthMask);
@@ -1092,9 +1079,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 keepHi = nLo + nWidth - 1;
               }
             }
-            GByte *wArrows = (GByte *)(arrowsG[g] + wRow);
-            const GByte *wT = (const GByte *)tSeqG[g];
-            const int wTLen = tLenG[g];
+            GByte *wArrows = (GByte *)(arrowsOfG + wRow);
+            const GByte *wT = (const GByte *)tSeqOfG;
+            const int wTLen = tLenOfG;
             ChunkCarry carry;
             carry.a = carry.b = carry.s = inf;
             int cDiag = 0;
