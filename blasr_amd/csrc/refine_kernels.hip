@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
       if (kHybrid) {
         const unsigned long long wideMask = __ballot(rowAll && isWide);
         if (wideMask != 0ull && args.exp != 2) {
-#pragma unroll
+#pragma unroll 1  // (one copy of the wide paths, not one per candidate slot: a quarter of the kernel's code)
           for (int g = 0; g < kT; g++) {
             if (((wideMask >> (g * kL)) & 1ull) == 0ull) continue;
             // ---- one wide row of candidate g, the whole wavefront on it (fill_kernel's ring path)
