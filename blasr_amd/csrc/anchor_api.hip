@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   uint32_t l = 0, r = a.tlen, lcp = 0;
   unsigned probes = 0;
   bool searching = true;
+  bool prefixUnchecked = true;  // the reported length may reach over bases nobody compared (see the emission)
   if (a.useLookup) {  // SuffixArray.h:954-990; DNATuple::FromStringLR (tuples/DNATuple.h:24-52)
     uint64_t tuple = 0;
     bool ok = true;
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       l = a.startPos[tuple];
       r = a.endPos[tuple];
       lcp = (uint32_t)a.prefixLen;
+      prefixUnchecked = tuple == 0 || a.minPrefix > (uint32_t)a.prefixLen;
     }
     if (ok && l < r) {
       hl[0] = l;
@@ -459,7 +461,12 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   }
   a.lo[g] = ml;
   a.cnt[g] = count;
-  a.len[g] = mlen;
+  // The reported length is minPrefix + (levels) - 1 or the extension's end: with a lookup table whose prefix is at least
+  // minPrefix every base under it was compared with the read's (so it is no N) -- except when the match started from the
+  // table's all-A word, under which BuildLookupTable also files the suffixes whose first bases make no tuple (it ignores
+  // FromStringLR's failure, SuffixArray.h:234-244).  The emission checks the reference's assert against the genome only
+  // where that is not so (bit 31): one random read per anchor less.
+  a.len[g] = mlen | (prefixUnchecked ? 0x80000000u : 0u);
   if (a.lcp) a.lcp[g] = lcp;
   if (a.probes) atomicAdd(a.probes, (unsigned long long)probes);
 }
@@ -527,9 +534,10 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
     }
     const uint32_t excl = lo ? sIncl[w][lo - 1] : 0;
     const uint32_t t = a.index[sLo[w][lo] + (j - excl)];
-    const uint32_t len = sLen[w][lo];
-    // the reference's asserts (MapBySuffixArray.h:301-302)
-    if ((uint64_t)t + len > a.tlen || len == 0 || a.genome[(uint64_t)t + len - 1] == 'N') atomicOr(error, 1);
+    const uint32_t lenWord = sLen[w][lo], len = lenWord & 0x7fffffffu;
+    // the reference's asserts (MapBySuffixArray.h:301-302); the base under the match's end is one the search compared
+    // with the read's (so no N) unless the match started from the all-A word of the lookup table (anchor_search_kernel)
+    if ((uint64_t)t + len > a.tlen || len == 0 || ((lenWord >> 31) != 0 && a.genome[(uint64_t)t + len - 1] == 'N')) atomicOr(error, 1);
     if (keys) {
       keys[base + j] = ((uint64_t)t << a.qBits) | sQ[w][lo];
       vals[base + j] = len;
