@@ -63,7 +63,10 @@ __device__ __forceinline__ int list_of(const int64_t *off, int nLists, int64_t i
 __global__ __launch_bounds__(256) void iv_mark_kernel(IvLists L, int64_t nAnchors, uint32_t *keep) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nAnchors) return;
-  const int li = list_of(L.listOff, L.nLists, i);
+  // the list of the wavefront's first anchor by one search on the scalar unit; a lane beyond that list's end steps on
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (int64_t)(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) << 6);
+  int li = list_of(L.listOff, L.nLists, i0);
+  while (li + 1 < L.nLists && i >= L.listOff[li + 1]) li++;
   const blasr_hip_anchor *list = L.anchors + L.listOff[li];
   const int64_t m = i - L.listOff[li];
   const blasr_hip_anchor am = list[m];
