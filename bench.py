@@ -484,8 +484,13 @@ def main():
     kacc = {}  # the refine stage's heavy kernels, each on its own (blasr_hip_refine_last_kernels), summed over the steps
 
     def step():
+        w0 = time.perf_counter()
         ctx.map_reads_device(n_reads, reads_t.data_ptr(), wl["pool"].data_ptr(), n_iv, iv_t.data_ptr(), params, hits, hit_off)
+        w1 = time.perf_counter()
         t = dict(ctx.map_last_timing())
+        if os.environ.get("BLASR_HIP_STEP_TRACE"):  # the call's wall time against the sum of its stages' timers
+            print("[step] call %.1f ms, stages %.1f ms" % ((w1 - w0) * 1e3, sum(t[k] for k in (
+                "windows_ms", "sdp_ms", "filter1_ms", "refine_ms", "filter2_ms", "fetch_ms"))), file=sys.stderr)
         t.update(ctx.sdp_last_timing())
         t.update(ctx.last_timing())
         f4 = ctx.last_fill4()

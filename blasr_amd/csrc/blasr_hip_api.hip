@@ -201,6 +201,8 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   for (auto &b : ctx->anchorBuf)
     if (b.p) (void)hipFree(b.p);
+  for (auto &b : ctx->mapHost)
+    if (b.p) (void)hipHostFree(b.p);
   if (ctx->saIndex) (void)hipFree(ctx->saIndex);
   if (ctx->saExt) (void)hipFree(ctx->saExt);
   if (ctx->anchorPinned) (void)hipHostFree(ctx->anchorPinned);

@@ -50,6 +50,13 @@ struct blasr_hip_ctx {
   // result records, block and op arenas, the trimmed refine batch
   enum { kMapBufs = 24 };
   DevBuf mapBuf[kMapBufs];
+  // the mapper's host-side arrays that receive device data (windows, lengths, SDP and refine records): pinned, grow-only
+  // and kept between calls -- as pageable std::vectors they cost a staged copy each and ~40 MB of fresh pages per call
+  enum { kMapHostBufs = 12 };
+  struct HostBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+  } mapHost[kMapHostBufs];
   float mapMs[6] = {0, 0, 0, 0, 0, 0};
   int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
   // the resident suffix array of the genome (blasr_hip_upload_suffix_array): index, the lookup table's ranges

@@ -88,6 +88,41 @@ float pct_of(int nMatch, int nMismatch, int nIns, int nDel) {
   return (float)((nMatch * 2.0) / (double)(cols + cols) * 100);
 }
 
+// A host array of the mapper that receives device data: a view of one of the context's pinned, grow-only buffers
+// (ctx.h: mapHost).  Not initialised: every element is written by the copy that fills it.
+template <typename T>
+struct PinnedArray {
+  T *p = nullptr;
+  size_t n = 0;
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2 };
+static_assert(MH_TLEN2 < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
+template <typename T>
+int pinned_array(blasr_hip_ctx *ctx, int slot, size_t count, PinnedArray<T> &out) {
+  blasr_hip_ctx::HostBuf &b = ctx->mapHost[slot];
+  const size_t bytes = sizeof(T) * std::max<size_t>(count, 1);
+  if (b.bytes < bytes) {
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "map_reads: %zu bytes of pinned host memory", want);
+    }
+    b.bytes = want;
+  }
+  out.p = (T *)b.p;
+  out.n = count;
+  return BLASR_HIP_OK;
+}
+
 // the trimmed batch of a refine_from_sdp call, carved from one context buffer
 struct TrimArrays {
   int64_t *qOff, *tOff, *blkOff;
@@ -225,7 +260,9 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
   int rc;
 
   // ---- the intervals' owners, on the host (grouping by read) -------------------------------------------------
-  std::vector<blasr_hip_interval> iv(n);
+  const double tEntry = now_ms();
+  PinnedArray<blasr_hip_interval> iv;
+  if ((rc = pinned_array(ctx, MH_IV, n, iv))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(iv.data(), intervals, sizeof(blasr_hip_interval) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   for (size_t k = 0; k < n; k++)
@@ -235,6 +272,7 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
 
   // ---- a-1: windows ----------------------------------------------------------------------------------------------
   double t0 = now_ms();
+  if (getenv("BLASR_HIP_MAP_TRACE")) fprintf(stderr, "[map] before the first stage: %.1f ms\n", t0 - tEntry);
   DevBuf *mb = ctx->mapBuf;
   if ((rc = blasr_hip_ensure(ctx, mb[MB_QOFF], sizeof(int64_t) * n))) return rc;
   if ((rc = blasr_hip_ensure(ctx, mb[MB_TOFF], sizeof(int64_t) * n))) return rc;
@@ -253,9 +291,12 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
     if (rc2) return rc2;
   }
   if (rc) return rc;
-  std::vector<blasr_hip_window> win(n);
-  std::vector<int32_t> qLen(n), tLen(n);
-  std::vector<int64_t> qOff(n), tOff(n);
+  PinnedArray<blasr_hip_window> win;
+  PinnedArray<int32_t> qLen, tLen;
+  PinnedArray<int64_t> qOff, tOff;
+  if ((rc = pinned_array(ctx, MH_WIN, n, win)) || (rc = pinned_array(ctx, MH_QLEN, n, qLen)) || (rc = pinned_array(ctx, MH_TLEN, n, tLen)) ||
+      (rc = pinned_array(ctx, MH_QOFF, n, qOff)) || (rc = pinned_array(ctx, MH_TOFF, n, tOff)))
+    return rc;
   HIP_TRY(ctx, hipMemcpyAsync(win.data(), mb[MB_WIN].p, sizeof(blasr_hip_window) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), mb[MB_QLEN].p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), mb[MB_TLEN].p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
@@ -323,7 +364,8 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
     HIP_TRY(ctx, hipMemcpyAsync(qOff.data(), mb[MB_QOFF].p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(tOff.data(), mb[MB_TOFF].p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
   }
-  std::vector<blasr_hip_sdp_result> sdp(n);
+  PinnedArray<blasr_hip_sdp_result> sdp;
+  if ((rc = pinned_array(ctx, MH_SDP, n, sdp))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(sdp.data(), mb[MB_SDPRES].p, sizeof(blasr_hip_sdp_result) * n, hipMemcpyDeviceToHost, st));
   std::vector<int32_t> hostBlocks;  // the maxGap rule of RemoveLowQualityAlignments reads the blocks
   if (prm->max_gap > 0 && blkUsed > 0) {
@@ -387,8 +429,10 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
 
   // ---- a-6 .. a-9: RefineAlignments on the survivors ----------------------------------------------------------
   const size_t ns = sel.size();
-  std::vector<blasr_hip_refine_result> ref(ns);
-  std::vector<int32_t> qLen2(ns), tLen2(ns);
+  PinnedArray<blasr_hip_refine_result> ref;
+  PinnedArray<int32_t> qLen2, tLen2;
+  if ((rc = pinned_array(ctx, MH_REF, ns, ref)) || (rc = pinned_array(ctx, MH_QLEN2, ns, qLen2)) || (rc = pinned_array(ctx, MH_TLEN2, ns, tLen2)))
+    return rc;
   if (ns > 0) {
     if ((rc = blasr_hip_ensure(ctx, mb[MB_SEL], sizeof(int32_t) * ns))) return rc;
     if ((rc = blasr_hip_ensure(ctx, mb[MB_REFRES], sizeof(blasr_hip_refine_result) * ns))) return rc;

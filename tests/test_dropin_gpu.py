@@ -97,7 +97,12 @@ def test_patched_reference_binary_without_the_flag_is_the_reference(tmp_path):
     want = write_inputs(str(tmp_path))
     p, got = run(str(tmp_path), ["-nproc", "2"])
     assert p.returncode == 0 and got == want
-    import torch
-    if not torch.cuda.is_available():
+    import ctypes as C
+    from blasr_amd import hip
+    lib, h = hip.load_library(), C.c_void_p()
+    have_device = lib.blasr_hip_create(0, C.byref(h)) == hip.OK  # (the library's own answer, not torch's)
+    if have_device:
+        lib.blasr_hip_destroy(h)
+    else:
         p, got = run(str(tmp_path), ["-useGPU"])
         assert p.returncode != 0 and b"no gfx950 device" in p.stdout
