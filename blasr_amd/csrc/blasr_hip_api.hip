@@ -357,7 +357,8 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   HIP_TRY(ctx, hipEventRecord(ev[0], st));
   launch_geometry(view, band, 0, n, dGeo, st);
   HIP_TRY(ctx, hipEventRecord(ev[1], st));
-  std::vector<TaskGeometry> geo(n);
+  PinnedArray<TaskGeometry> geo;  // (pinned and kept between calls, ctx.h)
+  if (int rcGeo = pinned_array(ctx, MH_GEO, (size_t)n, geo)) return rcGeo;
   HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo, sizeof(TaskGeometry) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());

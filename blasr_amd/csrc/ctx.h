@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -117,6 +118,42 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
                                       int64_t *n_intervals, int64_t *read_interval_off, int64_t *cluster_of_interval = nullptr);
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
+
+// A host array of the mapper that receives device data: a view of one of the context's pinned, grow-only buffers
+// (ctx.h: mapHost).  Not initialised: every element is written by the copy that fills it.
+template <typename T>
+struct PinnedArray {
+  T *p = nullptr;
+  size_t n = 0;
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2, MH_GEO, MH_SDP_TOP };
+static_assert(MH_SDP_TOP < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
+template <typename T>
+inline int pinned_array(blasr_hip_ctx *ctx, int slot, size_t count, PinnedArray<T> &out) {
+  blasr_hip_ctx::HostBuf &b = ctx->mapHost[slot];
+  const size_t bytes = sizeof(T) * std::max<size_t>(count, 1);
+  if (b.bytes < bytes) {
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "map_reads: %zu bytes of pinned host memory", want);
+    }
+    b.bytes = want;
+  }
+  out.p = (T *)b.p;
+  out.n = count;
+  return BLASR_HIP_OK;
+}
+
 
 #define HIP_TRY(ctx, expr)                                                                            \
   do {                                                                                                \

@@ -88,41 +88,6 @@ float pct_of(int nMatch, int nMismatch, int nIns, int nDel) {
   return (float)((nMatch * 2.0) / (double)(cols + cols) * 100);
 }
 
-// A host array of the mapper that receives device data: a view of one of the context's pinned, grow-only buffers
-// (ctx.h: mapHost).  Not initialised: every element is written by the copy that fills it.
-template <typename T>
-struct PinnedArray {
-  T *p = nullptr;
-  size_t n = 0;
-  T *data() { return p; }
-  const T *data() const { return p; }
-  size_t size() const { return n; }
-  T &operator[](size_t i) { return p[i]; }
-  const T &operator[](size_t i) const { return p[i]; }
-};
-enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2 };
-static_assert(MH_TLEN2 < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
-template <typename T>
-int pinned_array(blasr_hip_ctx *ctx, int slot, size_t count, PinnedArray<T> &out) {
-  blasr_hip_ctx::HostBuf &b = ctx->mapHost[slot];
-  const size_t bytes = sizeof(T) * std::max<size_t>(count, 1);
-  if (b.bytes < bytes) {
-    if (b.p) (void)hipHostFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
-    const size_t want = bytes + bytes / 4;
-    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      b.p = nullptr;
-      return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "map_reads: %zu bytes of pinned host memory", want);
-    }
-    b.bytes = want;
-  }
-  out.p = (T *)b.p;
-  out.n = count;
-  return BLASR_HIP_OK;
-}
-
 // the trimmed batch of a refine_from_sdp call, carved from one context buffer
 struct TrimArrays {
   int64_t *qOff, *tOff, *blkOff;
@@ -230,10 +195,29 @@ int blasr_hip_map_device_arenas(blasr_hip_ctx *ctx, const uint8_t **seq, const u
   return BLASR_HIP_OK;
 }
 
+static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                          const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
+                          const blasr_hip_map_params *prm, blasr_hip_hit *hits, int64_t hits_capacity,
+                          int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch);
+
 int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                                const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
                                const blasr_hip_map_params *prm, blasr_hip_hit *hits, int64_t hits_capacity,
                                int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch) {
+  const double t0 = now_ms();
+  const int rc = map_reads_impl(ctx, n_reads, reads, read_pool, n_iv, intervals, prm, hits, hits_capacity, n_hits, read_hit_off, fetch);
+  if (ctx && getenv("BLASR_HIP_MAP_TRACE")) {
+    float sum = 0;
+    for (int i = 0; i < 6; i++) sum += ctx->mapMs[i];
+    fprintf(stderr, "[map] the call: %.1f ms, its stages %.1f ms\n", now_ms() - t0, sum);
+  }
+  return rc;
+}
+
+static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
+                          const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
+                          const blasr_hip_map_params *prm, blasr_hip_hit *hits, int64_t hits_capacity,
+                          int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch) {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n_reads < 0 || n_iv < 0 || !prm || !n_hits || hits_capacity < 0 || (hits_capacity > 0 && !hits) ||
       (n_iv > 0 && (!reads || !read_pool || !intervals)))
@@ -579,6 +563,7 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
   if (read_hit_off) read_hit_off[n_reads] = nHits;
   double t5 = now_ms();
   ctx->mapMs[4] = (float)(t5 - t4);
+  if (getenv("BLASR_HIP_MAP_TRACE")) fprintf(stderr, "[map] stages done %.1f ms after the entry\n", t5 - tEntry);
   *n_hits = nHits;
   ctx->mapCounters[0] = n_iv;
   ctx->mapCounters[1] = (int64_t)ns;

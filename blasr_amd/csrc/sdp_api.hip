@@ -180,7 +180,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipMemcpyAsync(qLen.data(), b->q_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(tLen.data(), b->t_len, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  std::vector<SdpTask> top(n);
+  PinnedArray<SdpTask> top;  // (pinned and kept between calls, ctx.h: 14 MB at configs[2])
+  if (int rcTop = pinned_array(ctx, MH_SDP_TOP, (size_t)n, top)) return rcTop;
   for (int i = 0; i < n; i++) {
     if (qLen[i] < 0 || tLen[i] < 0 || qLen[i] >= (1 << 24) || tLen[i] >= (1 << 24)) {
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "candidate %d: sequence length outside [0, 2^24)", i);
