@@ -267,7 +267,7 @@ const char *blasr_hip_kernel_name(int kind, int ext0) {
     case BLASR_HIP_KERNEL_FILL_WAVE:
       return "blasr_hip::fill_kernel";
     case BLASR_HIP_KERNEL_TRACEBACK:
-      return "blasr_hip::traceback_kernel";
+      return "blasr_hip::traceback_kernel<8>";
   }
   return "";
 }

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -207,13 +208,31 @@ __global__ __launch_bounds__(256) void rbao_stats_kernel(int n, const uint8_t *s
   }
 }
 
+// fn(begin, end) over [0, n) on up to 16 host threads (the per-gap loops below run over ~10^5..10^6 gaps per call)
+template <typename F>
+void parallel_ranges(size_t n, F fn) {
+  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 16384) threads = 1;
+  if (threads == 1) {
+    fn((size_t)0, n);
+    return;
+  }
+  const size_t chunk = (n + threads - 1) / threads;
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; t++) {
+    const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
+    if (b < e) pool.emplace_back([=]() { fn(b, e); });
+  }
+  for (auto &t : pool) t.join();
+}
+
 // ops (M / I / D runs from (0, 0)) -> blocks, Alignment::ArrowPathToAlignment (Alignment.h:190-254)
-void ops_to_blocks(const uint32_t *ops, int nOps, uint32_t q0, uint32_t t0, std::vector<int32_t> &out) {
+void ops_to_blocks(const uint32_t *ops, int nOps, uint32_t q0, uint32_t t0, int32_t *out) {
   uint32_t q = q0, t = t0;
   for (int i = 0; i < nOps; i++) {
     const uint32_t len = ops[i] >> 2, ty = ops[i] & 3u;
     if (ty == BLASR_HIP_OP_M) {
-      out.push_back((int32_t)q), out.push_back((int32_t)t), out.push_back((int32_t)len);
+      *out++ = (int32_t)q, *out++ = (int32_t)t, *out++ = (int32_t)len;
       q += len, t += len;
     } else if (ty == BLASR_HIP_OP_I) {
       q += len;
@@ -221,6 +240,43 @@ void ops_to_blocks(const uint32_t *ops, int nOps, uint32_t q0, uint32_t t0, std:
       t += len;
     }
   }
+}
+
+// The blocks of a batch of op lists appended to gapBlocks, task j's place (firstBlock, nBlocks) noted in its gap:
+// counted, placed by a prefix sum, written by several threads.  addPos: the result's own qPos / tPos shift the blocks
+// (RefineAlignment's output, :888-914); returns the index of a task whose status is not 0, or -1.
+int64_t append_blocks_of(const std::vector<blasr_hip_refine_result> &res, const uint32_t *ops, const size_t *taskOf,
+                         std::vector<GapTask> &gaps, bool addPos, std::vector<int32_t> &gapBlocks) {
+  const size_t m = res.size();
+  std::vector<int64_t> at(m + 1, 0);
+  std::atomic<int64_t> bad(-1);
+  parallel_ranges(m, [&](size_t b, size_t e) {
+    for (size_t j = b; j < e; j++) {
+      const blasr_hip_refine_result &r = res[j];
+      if (r.status != 0) {
+        bad.store((int64_t)j);  // (any one of them will do for the message)
+        continue;
+      }
+      int64_t c = 0;
+      for (int i = 0; i < r.n_ops; i++) c += (ops[r.ops_off + i] & 3u) == BLASR_HIP_OP_M;
+      at[j + 1] = c;
+    }
+  });
+  if (bad.load() >= 0) return bad.load();
+  for (size_t j = 0; j < m; j++) at[j + 1] += at[j];
+  const size_t base = gapBlocks.size() / 3;
+  gapBlocks.resize(3 * (base + (size_t)at[m]));
+  parallel_ranges(m, [&](size_t b, size_t e) {
+    for (size_t j = b; j < e; j++) {
+      const blasr_hip_refine_result &r = res[j];
+      GapTask &g = gaps[taskOf[j]];
+      g.firstBlock = (int64_t)base + at[j];
+      g.nBlocks = (int32_t)(at[j + 1] - at[j]);
+      ops_to_blocks(ops + r.ops_off, r.n_ops, g.qPos + (addPos ? (uint32_t)r.q_pos : 0u), g.tPos + (addPos ? (uint32_t)r.t_pos : 0u),
+                    gapBlocks.data() + 3 * g.firstBlock);
+    }
+  });
+  return -1;
 }
 
 }  // namespace
@@ -408,16 +464,12 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
       std::vector<uint32_t> hops((size_t)std::max<int64_t>(used, 1));
       HIP_TRY(ctx, hipMemcpy(hres.data(), dres.p, sizeof(blasr_hip_refine_result) * m, hipMemcpyDeviceToHost));
       if (used > 0) HIP_TRY(ctx, hipMemcpy(hops.data(), dops.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost));
-      for (size_t j = 0; j < m; j++) {
-        GapTask &g = gaps[idx[c0 + j]];
-        const blasr_hip_refine_result &r = hres[j];
-        if (r.status != 0)
-          return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: AffineKBandAlign of a %d x %d gap of candidate %d: "
-                                "status %d", g.qGap, g.tGap, g.cand, r.status);
-        g.firstBlock = (int64_t)(gapBlocks.size() / 3);
-        // (a fresh T_AlignmentCandidate: qPos = tPos = 0, :1126-1136 add the gap's place)
-        ops_to_blocks(hops.data() + r.ops_off, r.n_ops, g.qPos, g.tPos, gapBlocks);
-        g.nBlocks = (int32_t)(gapBlocks.size() / 3 - (size_t)g.firstBlock);
+      // (a fresh T_AlignmentCandidate: qPos = tPos = 0, :1126-1136 add the gap's place)
+      const int64_t badK = append_blocks_of(hres, hops.data(), idx.data() + c0, gaps, false, gapBlocks);
+      if (badK >= 0) {
+        const GapTask &g = gaps[idx[c0 + (size_t)badK]];
+        return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: AffineKBandAlign of a %d x %d gap of candidate %d: "
+                              "status %d", g.qGap, g.tGap, g.cand, hres[(size_t)badK].status);
       }
     }
   }
@@ -485,37 +537,58 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
       if (blkUsed > 0) HIP_TRY(ctx, hipMemcpy(hblk.data(), dblk.p, sizeof(int32_t) * 3 * (size_t)blkUsed, hipMemcpyDeviceToHost));
       // :1094-1117 the alignment pinned to both ends of the gap, then RefineAlignment's guided branch (:831-915):
       // the sequences up to the end of the last block, the blocks as the guide
-      std::vector<int32_t> guide;
-      std::vector<int64_t> rq, rt, rblkOff;
-      std::vector<int32_t> rql, rtl, rnb;
-      std::vector<size_t> rTask;
-      int64_t opsCap = 0;
+      // (counted per gap, placed by prefix sums, written by several threads: ~10^5..10^6 gaps per call)
+      std::vector<int64_t> blkAt(m + 1, 0), taskAt(m + 1, 0);
+      int64_t badS = -1;
       for (size_t j = 0; j < m; j++) {
         const GapTask &g = gaps[idx[c0 + j]];
         const blasr_hip_sdp_result &r = hres[j];
-        if (r.status != 0)
-          return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: SDPAlign of a gap of candidate %d: status %d", g.cand, r.status);
-        if (r.n_blocks == 0) continue;  // nothing seeded: the gap stays open (:1092, :842-845, :1128)
-        const int32_t *src = hblk.data() + 3 * r.blk_off;
-        const size_t first = guide.size() / 3;
-        // (a Global SDPAlign leaves qPos = tPos = 0 and absolute block positions)
-        if (src[1] > 0 && src[0] > 0) guide.push_back(0), guide.push_back(0), guide.push_back(1);
-        for (int k = 0; k < 3 * r.n_blocks; k++) guide.push_back(src[k]);
-        const int32_t *last = src + 3 * (r.n_blocks - 1);
-        if (last[1] + last[2] < g.tGap && last[0] + last[2] < g.qGap)
-          guide.push_back(g.qGap - 1), guide.push_back(g.tGap - 1), guide.push_back(1);
-        const size_t nb = guide.size() / 3 - first;
-        const int32_t *z = guide.data() + 3 * (first + nb - 1);
-        rq.push_back(hq[j]);
-        rt.push_back(ht[j]);
-        rql.push_back(z[0] + z[2]);
-        rtl.push_back(z[1] + z[2]);
-        rblkOff.push_back((int64_t)first);
-        rnb.push_back((int32_t)nb);
-        rTask.push_back(idx[c0 + j]);
-        opsCap += (int64_t)(z[0] + z[2]) + (z[1] + z[2]) + 16;
+        if (r.status != 0) {
+          badS = (int64_t)j;
+          break;
+        }
+        int64_t nb = 0;
+        if (r.n_blocks > 0) {  // (else nothing seeded: the gap stays open, :1092, :842-845, :1128)
+          const int32_t *src = hblk.data() + 3 * r.blk_off, *last = src + 3 * (r.n_blocks - 1);
+          // (a Global SDPAlign leaves qPos = tPos = 0 and absolute block positions)
+          nb = r.n_blocks + ((src[1] > 0 && src[0] > 0) ? 1 : 0) + ((last[1] + last[2] < g.tGap && last[0] + last[2] < g.qGap) ? 1 : 0);
+        }
+        blkAt[j + 1] = blkAt[j] + nb;
+        taskAt[j + 1] = taskAt[j] + (nb > 0 ? 1 : 0);
       }
-      const size_t nr = rTask.size();
+      if (badS >= 0)
+        return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: SDPAlign of a gap of candidate %d: status %d",
+                              gaps[idx[c0 + (size_t)badS]].cand, hres[(size_t)badS].status);
+      const size_t nr = (size_t)taskAt[m];
+      std::vector<int32_t> guide(3 * (size_t)blkAt[m]);
+      std::vector<int64_t> rq(nr), rt(nr), rblkOff(nr);
+      std::vector<int32_t> rql(nr), rtl(nr), rnb(nr);
+      std::vector<size_t> rTask(nr);
+      parallel_ranges(m, [&](size_t jb, size_t je) {
+        for (size_t j = jb; j < je; j++) {
+          const int64_t nb = blkAt[j + 1] - blkAt[j];
+          if (nb == 0) continue;
+          const GapTask &g = gaps[idx[c0 + j]];
+          const blasr_hip_sdp_result &r = hres[j];
+          const int32_t *src = hblk.data() + 3 * r.blk_off, *last = src + 3 * (r.n_blocks - 1);
+          int32_t *dst = guide.data() + 3 * blkAt[j], *w = dst;
+          if (src[1] > 0 && src[0] > 0) *w++ = 0, *w++ = 0, *w++ = 1;  // :1107-1116 pinned to the beginning
+          memcpy(w, src, sizeof(int32_t) * 3 * (size_t)r.n_blocks);
+          w += 3 * r.n_blocks;
+          if (last[1] + last[2] < g.tGap && last[0] + last[2] < g.qGap) *w++ = g.qGap - 1, *w++ = g.tGap - 1, *w++ = 1;  // :1095-1104
+          const int32_t *z = dst + 3 * (nb - 1);
+          const size_t k = (size_t)taskAt[j];
+          rq[k] = hq[j];
+          rt[k] = ht[j];
+          rql[k] = z[0] + z[2];
+          rtl[k] = z[1] + z[2];
+          rblkOff[k] = blkAt[j];
+          rnb[k] = (int32_t)nb;
+          rTask[k] = idx[c0 + j];
+        }
+      });
+      int64_t opsCap = 0;
+      for (size_t k = 0; k < nr; k++) opsCap += (int64_t)rql[k] + rtl[k] + 16;
       lap("  pins and guides", nr);
       if (nr == 0) continue;
       Dev<int64_t> gq, gt, gbo;
@@ -561,68 +634,90 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
       std::vector<uint32_t> hops((size_t)std::max<int64_t>(opsUsed, 1));
       HIP_TRY(ctx, hipMemcpy(hr.data(), gres.p, sizeof(blasr_hip_refine_result) * nr, hipMemcpyDeviceToHost));
       if (opsUsed > 0) HIP_TRY(ctx, hipMemcpy(hops.data(), gops.p, sizeof(uint32_t) * (size_t)opsUsed, hipMemcpyDeviceToHost));
-      for (size_t j = 0; j < nr; j++) {
-        GapTask &g = gaps[rTask[j]];
-        const blasr_hip_refine_result &r = hr[j];
-        if (r.status != 0)
-          return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: RefineAlignment of a gap of candidate %d: status %d "
-                                "(the reference would exit: AffineGuidedAlign.h:394-408)", g.cand, r.status);
-        g.firstBlock = (int64_t)(gapBlocks.size() / 3);
-        // :888-914 then :1134-1135: the refined blocks start at (0, 0) of refinedAlignment.qPos / tPos
-        ops_to_blocks(hops.data() + r.ops_off, r.n_ops, g.qPos + (uint32_t)r.q_pos, g.tPos + (uint32_t)r.t_pos, gapBlocks);
-        g.nBlocks = (int32_t)(gapBlocks.size() / 3 - (size_t)g.firstBlock);
-      }
+      // :888-914 then :1134-1135: the refined blocks start at (0, 0) of refinedAlignment.qPos / tPos
+      const int64_t badR = append_blocks_of(hr, hops.data(), rTask.data(), gaps, true, gapBlocks);
+      if (badR >= 0)
+        return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: RefineAlignment of a gap of candidate %d: status %d "
+                              "(the reference would exit: AffineGuidedAlign.h:394-408)", gaps[rTask[(size_t)badR]].cand, hr[(size_t)badR].status);
     }
   }
 
   lap("SDPAlign + refine gaps", gapBlocks.size() / 3);
   // ---- :1578-1705 per candidate: anchors and gap alignments in order, qPos / tPos taken out, abutting blocks merged
   std::vector<blasr_hip_sdp_result> res((size_t)n);
-  std::vector<int32_t> out;
-  size_t gi = 0;
-  std::vector<int32_t> cur;
-  for (int i = 0; i < n; i++) {
-    const std::vector<Anchor> &m = anchors[(size_t)i];
-    cur.clear();
-    for (size_t a = 0; m.size() > 0 && a < m.size() - 1; a++) {
-      cur.push_back((int32_t)m[a].q), cur.push_back((int32_t)m[a].t), cur.push_back((int32_t)m[a].l);
-      if (gi < gaps.size() && gaps[gi].cand == i && gaps[gi].after == (int32_t)a) {
-        const GapTask &g = gaps[gi++];
-        cur.insert(cur.end(), gapBlocks.begin() + 3 * g.firstBlock, gapBlocks.begin() + 3 * (g.firstBlock + g.nBlocks));
+  std::vector<size_t> gapFirst((size_t)n + 1, gaps.size());  // the candidates' first gaps (the gaps are in candidate order)
+  for (size_t g = gaps.size(); g-- > 0;) gapFirst[(size_t)gaps[g].cand] = g;
+  for (int i = n - 1; i >= 0; i--)
+    if (gapFirst[(size_t)i] == gaps.size()) gapFirst[(size_t)i] = gapFirst[(size_t)i + 1];
+  std::vector<std::vector<int32_t>> perCand((size_t)n);
+  std::atomic<int> badCand(-1);
+  parallel_ranges((size_t)n, [&](size_t ib, size_t ie) {
+    std::vector<int32_t> cur;
+    for (size_t ii = ib; ii < ie; ii++) {
+      const int i = (int)ii;
+      const std::vector<Anchor> &m = anchors[ii];
+      size_t gi = gapFirst[ii];
+      cur.clear();
+      for (size_t a = 0; m.size() > 0 && a < m.size() - 1; a++) {
+        cur.push_back((int32_t)m[a].q), cur.push_back((int32_t)m[a].t), cur.push_back((int32_t)m[a].l);
+        if (gi < gaps.size() && gaps[gi].cand == i && gaps[gi].after == (int32_t)a) {
+          const GapTask &g = gaps[gi++];
+          cur.insert(cur.end(), gapBlocks.begin() + 3 * g.firstBlock, gapBlocks.begin() + 3 * (g.firstBlock + g.nBlocks));
+        }
       }
-    }
-    if (!m.empty()) {
-      const Anchor &z = m[m.size() - 1];
-      cur.push_back((int32_t)z.q), cur.push_back((int32_t)z.t), cur.push_back((int32_t)z.l);
-    }
-    blasr_hip_sdp_result &r = res[(size_t)i];
-    memset(&r, 0, sizeof(r));
-    r.blk_off = (int64_t)(out.size() / 3);
-    size_t nb = cur.size() / 3;
-    if (nb > 0) {
-      r.q_pos = cur[0];
-      r.t_pos = cur[1];
-      for (size_t k = 0; k < nb; k++) {
-        if (cur[3 * k] < r.q_pos || cur[3 * k + 1] < r.t_pos)
-          return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: a block of candidate %d starts before its first block "
-                                "(the reference asserts, :1672-1673)", i);
-        cur[3 * k] -= r.q_pos;
-        cur[3 * k + 1] -= r.t_pos;
+      if (!m.empty()) {
+        const Anchor &z = m[m.size() - 1];
+        cur.push_back((int32_t)z.q), cur.push_back((int32_t)z.t), cur.push_back((int32_t)z.l);
       }
-      size_t c = 0, next = 1;  // :1686-1697
-      while (next < nb) {
-        while (next < nb && cur[3 * c + 1] + cur[3 * c + 2] == cur[3 * next + 1] && cur[3 * c] + cur[3 * c + 2] == cur[3 * next]) {
-          cur[3 * c + 2] += cur[3 * next + 2];
-          cur[3 * next + 2] = 0;
+      blasr_hip_sdp_result &r = res[ii];
+      memset(&r, 0, sizeof(r));
+      const size_t nb = cur.size() / 3;
+      std::vector<int32_t> &mine = perCand[ii];
+      if (nb > 0) {
+        r.q_pos = cur[0];
+        r.t_pos = cur[1];
+        bool ok = true;
+        for (size_t k = 0; k < nb; k++) {
+          if (cur[3 * k] < r.q_pos || cur[3 * k + 1] < r.t_pos) ok = false;  // (the reference asserts, :1672-1673)
+          cur[3 * k] -= r.q_pos;
+          cur[3 * k + 1] -= r.t_pos;
+        }
+        if (!ok) {
+          badCand.store(i);
+          continue;
+        }
+        size_t c = 0, next = 1;  // :1686-1697
+        while (next < nb) {
+          while (next < nb && cur[3 * c + 1] + cur[3 * c + 2] == cur[3 * next + 1] && cur[3 * c] + cur[3 * c + 2] == cur[3 * next]) {
+            cur[3 * c + 2] += cur[3 * next + 2];
+            cur[3 * next + 2] = 0;
+            next += 1;
+          }
+          c = next;
           next += 1;
         }
-        c = next;
-        next += 1;
+        mine.reserve(cur.size());
+        for (size_t k = 0; k < nb; k++)  // :1698-1710
+          if (cur[3 * k + 2] != 0) mine.push_back(cur[3 * k]), mine.push_back(cur[3 * k + 1]), mine.push_back(cur[3 * k + 2]);
       }
-      for (size_t k = 0; k < nb; k++)  // :1698-1710
-        if (cur[3 * k + 2] != 0) out.push_back(cur[3 * k]), out.push_back(cur[3 * k + 1]), out.push_back(cur[3 * k + 2]);
+      r.n_blocks = (int32_t)(mine.size() / 3);
     }
-    r.n_blocks = (int32_t)(out.size() / 3 - (size_t)r.blk_off);
+  });
+  if (badCand.load() >= 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "align_between_anchors: a block of candidate %d starts before its first block "
+                          "(the reference asserts, :1672-1673)", badCand.load());
+  std::vector<int32_t> out;
+  {
+    int64_t at = 0;
+    for (int i = 0; i < n; i++) {
+      res[(size_t)i].blk_off = at;
+      at += res[(size_t)i].n_blocks;
+    }
+    out.resize(3 * (size_t)at);
+    parallel_ranges((size_t)n, [&](size_t ib, size_t ie) {
+      for (size_t ii = ib; ii < ie; ii++)
+        if (!perCand[ii].empty()) memcpy(out.data() + 3 * res[ii].blk_off, perCand[ii].data(), sizeof(int32_t) * perCand[ii].size());
+    });
   }
   const int64_t total = (int64_t)(out.size() / 3);
   if (blocks_used) *blocks_used = total;
