@@ -547,7 +547,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     int64_t magnitude = std::max<int64_t>(std::abs((int64_t)score->ins), std::abs((int64_t)score->del));
     for (int i = 0; i < 25; i++) magnitude = std::max<int64_t>(magnitude, std::abs((int64_t)score->matrix[i]));
     const bool smallOk = magnitude < (1 << 20);
-    const int bigBlocks = 128;
+    // (workgroups of sw_kernel, a lane per fill with its matrix in global scratch: 128 left half of the CUs without one;
+    //  at configs[2] the stage's fills + assembly take 78.7 / 73.8 / 72.3 / 72.9 ms with 128 / 256 / 512 / 1024)
+    const int bigBlocks = getenv("BLASR_HIP_SW_BLOCKS") ? std::max(1, atoi(getenv("BLASR_HIP_SW_BLOCKS"))) : 512;
     const int64_t lanes = (int64_t)bigBlocks * 256;
     uint8_t *scratch = arena.get<uint8_t>((size_t)(scratchPerLane * lanes));
     uint32_t *smallScratch = arena.get<uint32_t>((size_t)sw_small_scratch_words(sw_small_blocks(swMax)));
