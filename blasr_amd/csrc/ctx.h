@@ -53,7 +53,7 @@ struct blasr_hip_ctx {
   DevBuf mapBuf[kMapBufs];
   // the mapper's host-side arrays that receive device data (windows, lengths, SDP and refine records): pinned, grow-only
   // and kept between calls -- as pageable std::vectors they cost a staged copy each and ~40 MB of fresh pages per call
-  enum { kMapHostBufs = 12 };
+  enum { kMapHostBufs = 24 };
   struct HostBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -131,8 +131,9 @@ struct PinnedArray {
   T &operator[](size_t i) { return p[i]; }
   const T &operator[](size_t i) const { return p[i]; }
 };
-enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2, MH_GEO, MH_SDP_TOP };
-static_assert(MH_SDP_TOP < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
+enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2, MH_GEO, MH_SDP_TOP,
+       MH_FIRST, MH_BYREAD, MH_AT, MH_CAND, MH_ORDER, MH_LIVE, MH_SEL, MH_SELFIRST };
+static_assert(MH_SELFIRST < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
 template <typename T>
 inline int pinned_array(blasr_hip_ctx *ctx, int slot, size_t count, PinnedArray<T> &out) {
   blasr_hip_ctx::HostBuf &b = ctx->mapHost[slot];

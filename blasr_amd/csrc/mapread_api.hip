@@ -363,20 +363,28 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
 
   // ---- per read: the candidates as AlignIntervals leaves them, sort, first filter -------------------------------
   // candidates of a read in the order of its intervals (a counting sort over the owners: stable)
-  std::vector<int64_t> first((size_t)n_reads + 1, 0);
+  // (these arrays too live in the context between calls: 20 MB of fresh pages per call otherwise, and their unmapping)
+  PinnedArray<int64_t> first, at, selFirst;
+  PinnedArray<int32_t> byRead, order, live, sel;
+  PinnedArray<blasr_hip_candidate> cand;  // indexed like byRead (read-major)
+  if ((rc = pinned_array(ctx, MH_FIRST, (size_t)n_reads + 1, first)) || (rc = pinned_array(ctx, MH_AT, (size_t)n_reads + 1, at)) ||
+      (rc = pinned_array(ctx, MH_SELFIRST, (size_t)n_reads + 1, selFirst)) || (rc = pinned_array(ctx, MH_BYREAD, n, byRead)) ||
+      (rc = pinned_array(ctx, MH_ORDER, n, order)) ||  // per read: its slice holds the live candidates, as local indices
+      (rc = pinned_array(ctx, MH_LIVE, (size_t)std::max(n_reads, 1), live)) ||
+      (rc = pinned_array(ctx, MH_SEL, n, sel)) ||      // survivors of the first filter, read-major, in rank order
+      (rc = pinned_array(ctx, MH_CAND, n, cand)))
+    return rc;
+  memset(first.data(), 0, sizeof(int64_t) * ((size_t)n_reads + 1));
+  memset(selFirst.data(), 0, sizeof(int64_t) * ((size_t)n_reads + 1));
+  memset(live.data(), 0, sizeof(int32_t) * (size_t)std::max(n_reads, 1));
+  memset(cand.data(), 0, sizeof(blasr_hip_candidate) * n);
   for (size_t k = 0; k < n; k++) first[(size_t)iv[k].read + 1]++;
   for (int r = 0; r < n_reads; r++) first[(size_t)r + 1] += first[r];
-  std::vector<int32_t> byRead(n);
   {
-    std::vector<int64_t> at(first.begin(), first.end() - 1);
+    memcpy(at.data(), first.data(), sizeof(int64_t) * (size_t)n_reads);
     for (size_t k = 0; k < n; k++) byRead[(size_t)at[iv[k].read]++] = (int32_t)k;
   }
-  std::vector<blasr_hip_candidate> cand(n);  // indexed like byRead (read-major)
-  std::vector<int32_t> order(n);             // per read: its slice holds the live candidates, as local indices
-  std::vector<int32_t> live((size_t)n_reads, 0);
-  std::vector<int32_t> sel;                  // survivors of the first filter, read-major, in rank order
-  sel.reserve(n);
-  std::vector<int64_t> selFirst((size_t)n_reads + 1, 0);
+  size_t nSel = 0;
   for (int r = 0; r < n_reads; r++) {
     const int64_t f = first[r];
     const int32_t m = (int32_t)(first[(size_t)r + 1] - f);
@@ -404,15 +412,15 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
       if (cnt < 0) return blasr_hip_fail(ctx, cnt, "map_reads: first filter failed for read %d", r);
     }
     live[r] = cnt;
-    selFirst[r] = (int64_t)sel.size();
-    for (int32_t i = 0; i < cnt; i++) sel.push_back(byRead[(size_t)(f + order[(size_t)(f + i)])]);
+    selFirst[r] = (int64_t)nSel;
+    for (int32_t i = 0; i < cnt; i++) sel[nSel++] = byRead[(size_t)(f + order[(size_t)(f + i)])];
   }
-  selFirst[n_reads] = (int64_t)sel.size();
+  selFirst[n_reads] = (int64_t)nSel;
   double t3 = now_ms();
   ctx->mapMs[2] = (float)(t3 - t2);
 
   // ---- a-6 .. a-9: RefineAlignments on the survivors ----------------------------------------------------------
-  const size_t ns = sel.size();
+  const size_t ns = nSel;
   PinnedArray<blasr_hip_refine_result> ref;
   PinnedArray<int32_t> qLen2, tLen2;
   if ((rc = pinned_array(ctx, MH_REF, ns, ref)) || (rc = pinned_array(ctx, MH_QLEN2, ns, qLen2)) || (rc = pinned_array(ctx, MH_TLEN2, ns, tLen2)))
