@@ -132,8 +132,8 @@ struct PinnedArray {
   const T &operator[](size_t i) const { return p[i]; }
 };
 enum { MH_IV, MH_WIN, MH_QLEN, MH_TLEN, MH_QOFF, MH_TOFF, MH_SDP, MH_REF, MH_QLEN2, MH_TLEN2, MH_GEO, MH_SDP_TOP,
-       MH_FIRST, MH_BYREAD, MH_AT, MH_CAND, MH_ORDER, MH_LIVE, MH_SEL, MH_SELFIRST };
-static_assert(MH_SELFIRST < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
+       MH_FIRST, MH_BYREAD, MH_AT, MH_CAND, MH_ORDER, MH_LIVE, MH_SEL, MH_SELFIRST, MH_SLOT };
+static_assert(MH_SLOT < blasr_hip_ctx::kMapHostBufs, "mapHost slots");
 template <typename T>
 inline int pinned_array(blasr_hip_ctx *ctx, int slot, size_t count, PinnedArray<T> &out) {
   blasr_hip_ctx::HostBuf &b = ctx->mapHost[slot];

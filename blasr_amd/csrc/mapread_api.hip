@@ -18,7 +18,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
@@ -385,35 +387,61 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
     for (size_t k = 0; k < n; k++) byRead[(size_t)at[iv[k].read]++] = (int32_t)k;
   }
   size_t nSel = 0;
+  // (the reads are independent: several host threads over them; the survivors' list is put together afterwards)
+  std::atomic<int> badRead(-1), badCode(0);
+  auto filter_reads = [&](int r0, int r1) {
+    for (int r = r0; r < r1; r++) {
+      const int64_t f = first[r];
+      const int32_t m = (int32_t)(first[(size_t)r + 1] - f);
+      for (int32_t j = 0; j < m; j++) {
+        const int32_t k = byRead[(size_t)(f + j)];
+        const blasr_hip_sdp_result &s = sdp[k];
+        blasr_hip_candidate &c = cand[(size_t)(f + j)];
+        const int nb = s.status == 0 ? s.n_blocks : 0;
+        c.score = s.stats_score;
+        c.t_pos = (uint32_t)s.t_pos;
+        c.t_aligned_seq_pos = win[k].t_aligned_seq_pos;
+        c.t_end = 0;  // TEnd() is only read after the refinement
+        c.t_index = win[k].t_index;
+        c.t_strand = win[k].t_strand;
+        c.pct_similarity = pct_of(s.n_match, s.n_mismatch, s.n_ins, s.n_del);
+        c.n_blocks = nb;
+        c.blk_off = s.blk_off;
+        order[(size_t)(f + j)] = j;
+      }
+      int32_t cnt = m;
+      if (m > 0) {
+        blasr_hip_sort_candidates(&cand[(size_t)f], m, &order[(size_t)f]);                        // :2547
+        cnt = blasr_hip_remove_low_quality(&cand[(size_t)f], hostBlocks.empty() ? nullptr : hostBlocks.data(), m,
+                                           &order[(size_t)f], prm->n_candidates, prm->max_gap, prm->max_score);  // :2594
+        if (cnt < 0) {
+          badRead.store(r);
+          badCode.store(cnt);
+          cnt = 0;
+        }
+      }
+      live[r] = cnt;
+    }
+  };
+  {
+    const int threads = n_reads >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (threads == 1) {
+      filter_reads(0, n_reads);
+    } else {
+      std::vector<std::thread> pool;
+      const int chunk = (n_reads + threads - 1) / threads;
+      for (int t = 0; t < threads; t++) {
+        const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
+        if (r0 < r1) pool.emplace_back(filter_reads, r0, r1);
+      }
+      for (auto &t : pool) t.join();
+    }
+  }
+  if (badRead.load() >= 0) return blasr_hip_fail(ctx, badCode.load(), "map_reads: first filter failed for read %d", badRead.load());
   for (int r = 0; r < n_reads; r++) {
     const int64_t f = first[r];
-    const int32_t m = (int32_t)(first[(size_t)r + 1] - f);
-    for (int32_t j = 0; j < m; j++) {
-      const int32_t k = byRead[(size_t)(f + j)];
-      const blasr_hip_sdp_result &s = sdp[k];
-      blasr_hip_candidate &c = cand[(size_t)(f + j)];
-      const int nb = s.status == 0 ? s.n_blocks : 0;
-      c.score = s.stats_score;
-      c.t_pos = (uint32_t)s.t_pos;
-      c.t_aligned_seq_pos = win[k].t_aligned_seq_pos;
-      c.t_end = 0;  // TEnd() is only read after the refinement
-      c.t_index = win[k].t_index;
-      c.t_strand = win[k].t_strand;
-      c.pct_similarity = pct_of(s.n_match, s.n_mismatch, s.n_ins, s.n_del);
-      c.n_blocks = nb;
-      c.blk_off = s.blk_off;
-      order[(size_t)(f + j)] = j;
-    }
-    int32_t cnt = m;
-    if (m > 0) {
-      blasr_hip_sort_candidates(&cand[(size_t)f], m, &order[(size_t)f]);                        // :2547
-      cnt = blasr_hip_remove_low_quality(&cand[(size_t)f], hostBlocks.empty() ? nullptr : hostBlocks.data(), m,
-                                         &order[(size_t)f], prm->n_candidates, prm->max_gap, prm->max_score);  // :2594
-      if (cnt < 0) return blasr_hip_fail(ctx, cnt, "map_reads: first filter failed for read %d", r);
-    }
-    live[r] = cnt;
     selFirst[r] = (int64_t)nSel;
-    for (int32_t i = 0; i < cnt; i++) sel[nSel++] = byRead[(size_t)(f + order[(size_t)(f + i)])];
+    for (int32_t i = 0; i < live[r]; i++) sel[nSel++] = byRead[(size_t)(f + order[(size_t)(f + i)])];
   }
   selFirst[n_reads] = (int64_t)nSel;
   double t3 = now_ms();
@@ -464,56 +492,104 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
   int64_t nHits = 0, alignedReads = 0, alignedBases = 0, cells = 0;
   std::vector<FetchSeg> seqSegs, opsSegs;
   int64_t fetchSeq = 0, fetchOps = 0;
-  std::vector<int32_t> blocks2;  // per read, only under max_gap > 0
   for (size_t i = 0; i < ns; i++)
     if ((ref[i].status & (BLASR_HIP_TASK_EMPTY_GUIDE | BLASR_HIP_TASK_BAD_GUIDE)) == 0) cells += ref[i].n_cells;
+  // Per read and independent of the other reads (several host threads): the refined values copied back into its
+  // candidates, the sort, the two filters; live[r] becomes the number that survives, slotOf the refine record of each.
+  // The hits are then written in read order by one thread.
+  PinnedArray<int32_t> slotOf;  // candidate (read-major index) -> its refine record, -1 without one
+  if ((rc = pinned_array(ctx, MH_SLOT, n, slotOf))) return rc;
+  std::atomic<int> badRead2(-1), badCode2(0), badCand2(-1), badStatus2(0);
+  const bool tolerate = getenv("BLASR_HIP_EXP") != nullptr;  // (BLASR_HIP_EXP: timing experiments with wrong results)
+  auto refine_filters = [&](int r0, int r1) {
+    std::vector<int32_t> blocks2;  // per read, only under max_gap > 0
+    for (int r = r0; r < r1; r++) {
+      const int64_t f = first[r];
+      int32_t cnt = live[r];
+      const int32_t m = (int32_t)(first[(size_t)r + 1] - f);
+      for (int32_t j = 0; j < m; j++) slotOf[(size_t)(f + j)] = -1;
+      if (cnt == 0) continue;
+      blasr_hip_candidate *cr = &cand[(size_t)f];
+      int32_t *ord = &order[(size_t)f];
+      blocks2.clear();
+      bool failed = false;
+      for (int32_t i = 0; i < cnt; i++) {
+        const int32_t j = ord[i];
+        const size_t s = (size_t)(selFirst[r] + i);
+        const blasr_hip_refine_result &rr = ref[s];
+        if (rr.status & BLASR_HIP_TASK_EMPTY_GUIDE) continue;  // the reference leaves such a candidate as it is (:845)
+        if (rr.status != 0 && !tolerate) {
+          badRead2.store(r);
+          badCand2.store(byRead[(size_t)(f + j)]);
+          badStatus2.store(rr.status);
+          failed = true;
+          break;
+        }
+        slotOf[(size_t)(f + j)] = (int32_t)s;
+        blasr_hip_candidate &c = cr[j];
+        c.score = rr.score;
+        c.t_aligned_seq_pos += c.t_pos;  // :909 (tPos of the SDP alignment)
+        c.t_pos = (uint32_t)rr.t_pos;
+        c.t_end = (uint32_t)(rr.n_match + rr.n_mismatch + rr.n_del);  // TEnd(): the blocks start at 0 and end with one
+        c.pct_similarity = pct_of(rr.n_match, rr.n_mismatch, rr.n_ins, rr.n_del);
+        if (prm->max_gap > 0) {  // the refined blocks, rebuilt from the ops
+          c.blk_off = (int64_t)(blocks2.size() / 3);
+          int32_t q = 0, t = 0, nb = 0;
+          for (int32_t o = 0; o < rr.n_ops; o++) {
+            const uint32_t op = hostOps[(size_t)(rr.ops_off + o)], len = op >> 2;
+            if ((op & 3u) == BLASR_HIP_OP_M) {
+              blocks2.push_back(q), blocks2.push_back(t), blocks2.push_back((int32_t)len);
+              q += len, t += len, nb++;
+            } else if ((op & 3u) == BLASR_HIP_OP_I) q += len;
+            else t += len;
+          }
+          c.n_blocks = nb;
+        } else {
+          c.n_blocks = 1;  // (only "has blocks" is read below)
+        }
+      }
+      if (failed) {
+        live[r] = 0;
+        continue;
+      }
+      if (prm->sort_refined) blasr_hip_sort_candidates(cr, cnt, ord);
+      cnt = blasr_hip_remove_low_quality(cr, blocks2.empty() ? nullptr : blocks2.data(), cnt, ord, prm->n_candidates,
+                                         prm->max_gap, prm->max_score);
+      if (cnt >= 0) cnt = blasr_hip_remove_overlapping(cr, cnt, ord, prm->min_pct_identity);
+      if (cnt < 0) {
+        badRead2.store(r);
+        badCode2.store(cnt);
+        cnt = 0;
+      }
+      live[r] = cnt;
+    }
+  };
+  {
+    const int threads = n_reads >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (threads == 1) {
+      refine_filters(0, n_reads);
+    } else {
+      std::vector<std::thread> pool;
+      const int chunk = (n_reads + threads - 1) / threads;
+      for (int t = 0; t < threads; t++) {
+        const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
+        if (r0 < r1) pool.emplace_back(refine_filters, r0, r1);
+      }
+      for (auto &t : pool) t.join();
+    }
+  }
+  if (badStatus2.load() != 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_reads: candidate %d of read %d: refine status %d "
+                          "(the reference would exit: AffineGuidedAlign.h:394-408)", badCand2.load(), badRead2.load(), badStatus2.load());
+  if (badCode2.load() != 0) return blasr_hip_fail(ctx, badCode2.load(), "map_reads: a filter after the refinement failed for read %d", badRead2.load());
   for (int r = 0; r < n_reads; r++) {
     if (read_hit_off) read_hit_off[r] = nHits;
     const int64_t f = first[r];
-    int32_t cnt = live[r];
+    const int32_t cnt = live[r];
     if (cnt == 0) continue;
-    blasr_hip_candidate *cr = &cand[(size_t)f];
-    int32_t *ord = &order[(size_t)f];
-    const int32_t m = (int32_t)(first[(size_t)r + 1] - f);
-    std::vector<int32_t> slot((size_t)m, -1);  // local candidate -> its refine record
-    blocks2.clear();
-    for (int32_t i = 0; i < cnt; i++) {
-      const int32_t j = ord[i];
-      const size_t s = (size_t)(selFirst[r] + i);
-      const blasr_hip_refine_result &rr = ref[s];
-      if (rr.status & BLASR_HIP_TASK_EMPTY_GUIDE) continue;  // the reference leaves such a candidate as it is (:845)
-      if (rr.status != 0 && !getenv("BLASR_HIP_EXP"))  // (BLASR_HIP_EXP: timing experiments with wrong results)
-        return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_reads: candidate %d of read %d: refine status %d "
-                              "(the reference would exit: AffineGuidedAlign.h:394-408)", byRead[(size_t)(f + j)], r, rr.status);
-      slot[j] = (int32_t)s;
-      blasr_hip_candidate &c = cr[j];
-      c.score = rr.score;
-      c.t_aligned_seq_pos += c.t_pos;  // :909 (tPos of the SDP alignment)
-      c.t_pos = (uint32_t)rr.t_pos;
-      c.t_end = (uint32_t)(rr.n_match + rr.n_mismatch + rr.n_del);  // TEnd(): the blocks start at 0 and end with one
-      c.pct_similarity = pct_of(rr.n_match, rr.n_mismatch, rr.n_ins, rr.n_del);
-      if (prm->max_gap > 0) {  // the refined blocks, rebuilt from the ops
-        c.blk_off = (int64_t)(blocks2.size() / 3);
-        int32_t q = 0, t = 0, nb = 0;
-        for (int32_t o = 0; o < rr.n_ops; o++) {
-          const uint32_t op = hostOps[(size_t)(rr.ops_off + o)], len = op >> 2;
-          if ((op & 3u) == BLASR_HIP_OP_M) {
-            blocks2.push_back(q), blocks2.push_back(t), blocks2.push_back((int32_t)len);
-            q += len, t += len, nb++;
-          } else if ((op & 3u) == BLASR_HIP_OP_I) q += len;
-          else t += len;
-        }
-        c.n_blocks = nb;
-      } else {
-        c.n_blocks = 1;  // (only "has blocks" is read below)
-      }
-    }
-    if (prm->sort_refined) blasr_hip_sort_candidates(cr, cnt, ord);
-    cnt = blasr_hip_remove_low_quality(cr, blocks2.empty() ? nullptr : blocks2.data(), cnt, ord, prm->n_candidates,
-                                       prm->max_gap, prm->max_score);
-    if (cnt < 0) return blasr_hip_fail(ctx, cnt, "map_reads: second filter failed for read %d", r);
-    cnt = blasr_hip_remove_overlapping(cr, cnt, ord, prm->min_pct_identity);
-    if (cnt < 0) return blasr_hip_fail(ctx, cnt, "map_reads: overlap filter failed for read %d", r);
+    const blasr_hip_candidate *cr = &cand[(size_t)f];
+    const int32_t *ord = &order[(size_t)f];
+    const int32_t *slot = &slotOf[(size_t)f];
     int32_t kept = 0;
     for (int32_t i = 0; i < cnt; i++) {
       const int32_t j = ord[i];
