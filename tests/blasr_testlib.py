@@ -282,9 +282,15 @@ class MapperRef:
     def __init__(self):
         self.lib = C.CDLL(REFMAPPER_SO)
 
-    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11, extend=None):
-        """extend: None, or (extendBandSize, maxExtendDropoff) to run the reference's -extend step as well."""
+    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11, extend=None, rbao_chain=None):
+        """extend: None, or (extendBandSize, maxExtendDropoff) to run the reference's -extend step as well.
+        rbao_chain: None, or the interval's chained anchors ((m, 3) uint32: t, q, l) to run AlignIntervals' -rbao branch
+        (Blasr.cpp:1354-1712) on them instead of SDPAlign over the window."""
         genome, read = _u8(genome), _u8(read)
+        chain = None
+        if rbao_chain is not None:
+            chain = np.ascontiguousarray(rbao_chain, dtype=np.uint32).reshape(-1)
+            self.lib.ref_set_interval_matches(_pu(chain), len(chain) // 3, 1)
         cs = None if contigs is None else np.ascontiguousarray(contigs, dtype=np.uint32)
         out = np.zeros(16, dtype=np.int32)
         cap = len(genome) + 16
@@ -296,6 +302,8 @@ class MapperRef:
                                             int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
                                             C.c_float(rate), int(extend_ends), int(k), None if sw is None else _p(sw),
                                             _p(out), _p(tseq, C.c_ubyte), cap, _p(blocks), len(read) + 16)
+        if chain is not None:
+            self.lib.ref_set_interval_matches(None, 0, 0)
         assert rc == 0
         win = dict(zip(WINDOW_FIELDS, (int(v) & 0xffffffff for v in out[:7])))
         sdp = dict(qPos=int(out[7]), tPos=int(out[8]), blocks=blocks[: 3 * int(out[9])].reshape(-1, 3).copy(),

@@ -130,3 +130,41 @@ def test_cpp_example_maps_under_rbao(tmp_path):
     assert len(got) == len(want) == 80
     bad = [(a, b) for a, b in zip(got, want) if a != b]
     assert not bad, bad[:3]
+
+
+def test_the_branch_at_function_level_against_the_references_own_alignintervals():
+    """blasr_hip_align_between_anchors_host for the candidates of the noisy fixture, one by one against the REFERENCE's
+    own AlignIntervals with refineBetweenAnchorsOnly set and the interval's chain handed to it
+    (oracle/ref_mapper_harness.cpp: ref_set_interval_matches + ref_align_interval_ex): qPos / tPos, every block, and the
+    ComputeAlignmentStats fields of :1709."""
+    import blasr_testlib as T
+    ref = T.load_refmapper()
+    if ref is None:
+        pytest.skip("oracle/_ref/libblasr_refmapper.so not built (needs /root/reference at build time)")
+    genome, starts, reads, pool, read_lens, want_iv = fixture()
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome, starts)
+    ctx.build_suffix_array(8, download=False)
+    ivs, iv_off, _, chains, chain_off = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, reads,
+                                                                     chains=True)
+    seq, q_off, q_len, t_off, t_len, win = ctx.windows(ivs, reads, pool)
+    res, blocks = ctx.align_between_anchors(seq, q_off, q_len, t_off, t_len, win, chains, chain_off)
+    checked = with_gaps = 0
+    for k in range(len(ivs)):
+        iv = ivs[k]
+        r = int(iv["read"])
+        read = pool[int(reads[r]["off"]): int(reads[r]["off"]) + int(reads[r]["length"])]
+        chain = chains[int(chain_off[k]): int(chain_off[k + 1])]
+        w, tseq, sdp = ref.align_interval(genome, read, (0, len(read)),
+                                          (int(iv["start"]), int(iv["end"]), int(iv["q_start"]), int(iv["q_end"]), int(iv["strand"])),
+                                          contigs=starts, rbao_chain=chain)
+        mine = res[k]
+        b = blocks[int(mine["blk_off"]): int(mine["blk_off"]) + int(mine["n_blocks"])]
+        assert (int(mine["q_pos"]), int(mine["t_pos"])) == (sdp["qPos"], sdp["tPos"]), k
+        assert np.array_equal(b, sdp["blocks"]), k
+        assert (int(mine["stats_score"]), int(mine["n_match"]), int(mine["n_mismatch"]), int(mine["n_ins"]), int(mine["n_del"])) == \
+               (sdp["score"], sdp["nMatch"], sdp["nMismatch"], sdp["nIns"], sdp["nDel"]), k
+        checked += 1
+        with_gaps += int(len(b) > len(chain))
+    assert checked == len(ivs) == 125 and with_gaps > 60  # (most candidates have gaps that were aligned)
+    ctx.close()
