@@ -1375,12 +1375,12 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   __shared__ uint4 winLds[kB][kTbLanes];
   __shared__ uint32_t stepTab[96];
   // stepTab[state * 32 + arrow byte]: bits 0-1 the op to emit (0 when none), bit 2 column step, bit 3 leaves the row,
-  // bit 6 impossible arrow, bit 7 emits an op, bits 8.. the next state * 32
+  // bit 6 impossible arrow, bit 7 emits an op, bits 8.. the byte offset of the next state's 32 entries
   for (int t = threadIdx.x; t < 96; t += 64) {
     const int st = t >> 5, a = t & 31;
     const int at = st == 0 ? (a & 7) : (st == 1 ? 8 + ((a >> 3) & 1) : 10 + ((a >> 4) & 1));
     const unsigned e = tb_entry(at), op = e & 3u;
-    stepTab[t] = (op != 3u ? op | 0x80u : 0u) | (e & 0x4cu) | ((((e >> 4) & 3u) * 32u) << 8);
+    stepTab[t] = (op != 3u ? op | 0x80u : 0u) | (e & 0x4cu) | ((((e >> 4) & 3u) * 128u) << 8);
   }
   __syncthreads();
   const int idx = blockIdx.x * kTbLanes + threadIdx.x;
@@ -1400,9 +1400,10 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   uint32_t *codes = tb_codes_end(arrows, alive ? geo.cells : 0);  // grows downwards
 
   uint64_t acc = 0;  // ops not yet stored, oldest in the low bits
-  int fill = 0, nOps = 0;
+  int fill = 0;
+  uint32_t *const codesEnd = codes;
   int c = tEnd - 1;
-  unsigned state32 = 0;  // 32 x (0 = match matrix, 1 = affine ins, 2 = affine del)
+  unsigned stateOff = 0;  // 128 x (0 = match matrix, 1 = affine ins, 2 = affine del): where its entries start in stepTab
   unsigned badAcc = 0;
   int guard = 2 * (Q + (tEnd - tStart)) + 64;  // steps a walk can take at most (every step leaves a row, moves left or
   int status = 0;                              //  follows a close / open pair)
@@ -1439,9 +1440,9 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
         if (alive) winLds[j][slot] = W[j];
     }
     int j = 0;
-    for (;;) {
-      const bool on = alive && j < nHere && guard >= 0;
-      if (__ballot(on) == 0ull) break;
+    for (int trip = 0;; trip++) {
+      const bool on = j < nHere && guard >= 0;  // (nHere = 0 for a lane that is not alive)
+      if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
       if (on) {
         int i = c - c0 + j + 7;
         if ((unsigned)i >= (unsigned)kTbWin) {
@@ -1452,18 +1453,19 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
           for (int jj = j; jj < nHere; jj++) winLds[jj][slot] = window_at(rowTab[rTop - jj], c0 - jj - 7);
         }
         const unsigned a = reinterpret_cast<const uint8_t *>(&winLds[j][slot])[i];
-        const unsigned e = stepTab[state32 + (a & 31u)];
+        const unsigned e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(stepTab) + (stateOff + (a & 31u) * 4u));
         acc |= (uint64_t)(e & 3u) << (2 * fill);
         const int emits = (int)((e >> 7) & 1u);
         fill += emits;
-        nOps += emits;
         c -= (int)((e >> 2) & 1u);
         j += (int)((e >> 3) & 1u);
-        state32 = e >> 8;
+        stateOff = e >> 8;
         badAcc |= e;
         guard--;
       }
-      if (__ballot(on && fill >= 30) != 0ull) flush();  // many ops inside one batch (a long deletion run)
+      // many ops inside one batch (a long deletion run): a batch starts with fewer than sixteen ops pending and a trip
+      // adds one at most, so the first fourteen trips need no look
+      if (trip >= 14 && __builtin_amdgcn_ballot_w64(on && fill >= 30) != 0ull) flush();
     }
     if (alive) {
       if ((badAcc & 0x40u) != 0u || guard < 0) {  // an arrow the recurrence cannot have written: NoArrow (:394-408)
@@ -1475,7 +1477,6 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
         while (c >= tStart) {
           acc |= (uint64_t)OP_D << (2 * fill);
           fill++;
-          nOps++;
           c--;
           if (fill == 32) flush();
         }
@@ -1488,6 +1489,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
     for (int j = 0; j < kB; j++) RT[j] = RTn[j];
   }
   if (inRange) {
+    const int nOps = 16 * (int)(codesEnd - codes) + fill;  // sixteen to every dword stored, and those still pending
     if (geo.status == 0) {
       while (fill > 0) {  // the last, partly filled dwords
         *--codes = (uint32_t)acc;

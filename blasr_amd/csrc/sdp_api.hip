@@ -182,10 +182,12 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipStreamSynchronize(st));
   PinnedArray<SdpTask> top;  // (pinned and kept between calls, ctx.h: 14 MB at configs[2])
   if (int rcTop = pinned_array(ctx, MH_SDP_TOP, (size_t)n, top)) return rcTop;
+  int32_t maxQLen = 0;
   for (int i = 0; i < n; i++) {
     if (qLen[i] < 0 || tLen[i] < 0 || qLen[i] >= (1 << 24) || tLen[i] >= (1 << 24)) {
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "candidate %d: sequence length outside [0, 2^24)", i);
     }
+    maxQLen = std::max(maxQLen, qLen[i]);
     SdpTask &t = top[i];
     t.qOff = qOff[i];
     t.tOff = tOff[i];
@@ -600,16 +602,28 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     if (nPool >= (1ll << 32)) {
       return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED, "batch too large: %lld blocks", (long long)nPool);
     }
-    const unsigned endBit = (unsigned)(32 + bits_for((uint64_t)n));
+    // key = candidate << 32 | q: the bits between the longest query's and bit 32 are zero everywhere, so two stable
+    // sorts (by q, then by candidate) pass over the pool fewer times than one over bits 0 .. 32 + candidate bits
+    const unsigned qBits = (unsigned)bits_for((uint64_t)maxQLen), endBit = (unsigned)(32 + bits_for((uint64_t)n));
+    const bool twoSorts = (qBits + 7) / 8 + (endBit - 32 + 7) / 8 < (endBit + 7) / 8 && !getenv("BLASR_HIP_POOL_ONE_SORT");
     size_t sortBytes = 0;
     HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, sortBytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
                                            (size_t)nPool, 0u, endBit, st));
     void *sortTmp = arena.get<char>(sortBytes);
     ARENA_CHECK();
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(sortTmp, sortBytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
-                                           (size_t)nPool, 0u, endBit, st));
-    sortedKeys = poolKeysSorted;
-    sortedVals = poolValsSorted;
+    if (twoSorts) {
+      size_t bytes = sortBytes;
+      HIP_TRY(ctx, rocprim::radix_sort_pairs(sortTmp, bytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
+                                             (size_t)nPool, 0u, qBits, st));
+      bytes = sortBytes;
+      HIP_TRY(ctx, rocprim::radix_sort_pairs(sortTmp, bytes, poolKeysSorted, poolKeys, poolValsSorted, poolVals,
+                                             (size_t)nPool, 32u, endBit, st));
+    } else {
+      HIP_TRY(ctx, rocprim::radix_sort_pairs(sortTmp, sortBytes, poolKeys, poolKeysSorted, poolVals, poolValsSorted,
+                                             (size_t)nPool, 0u, endBit, st));
+      sortedKeys = poolKeysSorted;
+      sortedVals = poolValsSorted;
+    }
   }
   // blkOff[c] = first block of candidate c in the sorted pool (the pool is ordered by candidate)
   launch_pool_offsets(sortedKeys, nPool, n, blkOff, st);
