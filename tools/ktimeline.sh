@@ -7,7 +7,7 @@ OUT=$ROOT/$1
 shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt" -o k -- python3 "$ROOT/bench.py" "$@" \
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt" -o k -- python3 "$ROOT/bench.py" --from-reads 0 "$@" \
     > "$OUT/tl_bench.json" 2> "$OUT/kt.err"
 TRACE=$(find "$OUT/kt" -name '*kernel_trace.csv' | head -1)
 MS=$(python3 -c "import json,sys; print(json.loads(open('$OUT/tl_bench.json').read().strip().splitlines()[-1])['ms_per_step'])")

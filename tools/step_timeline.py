@@ -7,14 +7,14 @@ import sys
 
 
 def short(n):
-    n = n.replace("void ", "").replace("blasr_hip::", "")
+    n = n.replace("void ", "").replace("blasr_hip::", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0][:60]
 
 
 def main():
     rows = [r for r in csv.DictReader(open(sys.argv[1]))]
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Kernel_Name"]) for r in rows)
-    lib = [e for e in ev if "blasr_hip" in e[3] or "rocprim" in e[3]]
+    lib = [e for e in ev if "blasr_hip" in e[3] or "rocprim" in e[3] or "(anonymous namespace)::" in e[3]]
     t1 = max(e[1] for e in lib)
     t0 = t1 - int(float(sys.argv[2]) * 1e6)
     floor = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
