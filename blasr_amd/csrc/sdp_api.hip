@@ -246,6 +246,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.bigList = arena.get<int32_t>(nTasks + 1);
     lv.bigCount = lv.bigList + nTasks;
     lv.idxFlag = arena.get<int32_t>(nTasks);
+    lv.idxWave = arena.get<int32_t>((size_t)4 * nTasks);
     lv.fused = arena.get<int32_t>(nTasks);
     lv.chainList = nullptr;
     if (!getenv("BLASR_HIP_NO_CHAIN4")) {

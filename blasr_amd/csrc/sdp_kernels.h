@@ -77,6 +77,7 @@ struct SdpLevelArrays {
   int4 *colEnt;                 // per target column: {column, fragment, cost, x+y} of the column set's entry there
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)
   int32_t *idxFlag;             // per task: some query position has more than three matches
+  int32_t *idxWave;             // 4 per task: the middle fragments of each wavefront's share of the query (index kernel)
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain

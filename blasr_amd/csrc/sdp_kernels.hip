@@ -511,13 +511,8 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       out = lv.raw + lv.fragOff[idx];
       nP = lv.nRaw[3 * idx];
       nMall = lv.nRaw[3 * idx + 1];
-      int mine = 0;
-      for (int x = qlo + lane; x < qhi; x += 64) mine += (int)(hits[x] & 0xffffu);
-      for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-      if (lane == 0) L.part[8 + wv] = (uint32_t)mine;
-      __syncthreads();
       wBase = nP;
-      for (int w = 0; w < wv; w++) wBase += (int)L.part[8 + w];
+      for (int w = 0; w < wv; w++) wBase += lv.idxWave[4 * idx + w];
     }
     int nM = 0;
     bool many = false;  // some position with more than three matches
@@ -640,6 +635,8 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         lv.nRaw[3 * idx + 1] = (int)(L.part[8] + L.part[9] + L.part[10] + L.part[11]);
         lv.idxFlag[idx] = (int)(L.part[12] | L.part[13] | L.part[14] | L.part[15]);
       }
+      // (what each wavefront's share of the query matched: the write pass starts from these instead of summing `hits`)
+      if (!kWrite && lane < 4) lv.idxWave[4 * idx + lane] = (int)L.part[8 + lane];
     } else if (wv == 1) {
       const int n2 = small_part<kWrite>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
                                         suffixPos, ks, t.maxPerPos, out, nP + nMall);
@@ -652,7 +649,6 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
 // = 0, nearly all of them): every fragment is already spelled out in lv.hits, so this is a copy that needs no
 // index and no LDS -- a separate kernel so that its occupancy is not limited by the index's LDS footprint.
 __global__ __launch_bounds__(256) void sdp_match_index_copy_kernel(SdpLevelArrays lv, const uint8_t *seq) {
-  __shared__ int part[4];
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
   const int nBig = *lv.bigCount;
   for (int e = blockIdx.x; e < nBig; e += gridDim.x) {
@@ -667,14 +663,8 @@ __global__ __launch_bounds__(256) void sdp_match_index_copy_kernel(SdpLevelArray
     const uint64_t *hits = lv.hits + lv.qPosOff[idx];
     Frag *out = lv.raw + lv.fragOff[idx];
     const int nP = lv.nRaw[3 * idx], nMall = lv.nRaw[3 * idx + 1];
-    int mine = 0;
-    for (int x = qlo + lane; x < qhi; x += 64) mine += (int)(hits[x] & 0xffffu);
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    __syncthreads();
-    if (lane == 0) part[wv] = mine;
-    __syncthreads();
     int wBase = nP;
-    for (int w = 0; w < wv; w++) wBase += part[w];
+    for (int w = 0; w < wv; w++) wBase += lv.idxWave[4 * idx + w];
     for (int x0 = qlo; x0 < qhi; x0 += 64) {
       const int x = x0 + lane;
       uint64_t h = 0;
@@ -1295,17 +1285,27 @@ __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv
     const uint32_t xLow = f.x > (uint32_t)(k + 1) ? f.x - (uint32_t)(k + 1) : 0u;
     // the candidates are the few fragments just before i (sorted by x): walk back until x < xLow.  (diag, x)
     // pairs are unique, so the order in which they are looked at does not matter
+    // (eight at a time: the walk is a chain of loads otherwise -- a scattered invocation with a short word has thirty
+    //  candidates per fragment)
     int best = -1, bestDiag = 0;
     uint32_t bestX = 0;
-    for (int j = i - 1; j >= 0; j--) {
-      const Frag p = fr[j];
-      if (p.x < xLow) break;
-      if (p.x >= f.x) continue;  // the same row
-      const int d = (int)(p.y - p.x);
-      if (d <= fdiag && (best < 0 || d > bestDiag || (d == bestDiag && p.x > bestX))) {
-        best = j;
-        bestDiag = d;
-        bestX = p.x;
+    bool done = false;
+    constexpr int kBack = 8;
+    for (int j0 = i - 1; j0 >= 0 && !done; j0 -= kBack) {
+      uint2 p[kBack];
+#pragma unroll
+      for (int u = 0; u < kBack; u++) p[u] = *reinterpret_cast<const uint2 *>(fr + max(j0 - u, 0));  // {x, y}
+#pragma unroll
+      for (int u = 0; u < kBack; u++) {
+        const int j = j0 - u;
+        if (j < 0 || p[u].x < xLow) done = true;
+        if (done || p[u].x >= f.x) continue;  // (>= f.x: the same row)
+        const int d = (int)(p[u].y - p[u].x);
+        if (d <= fdiag && (best < 0 || d > bestDiag || (d == bestDiag && p[u].x > bestX))) {
+          best = j;
+          bestDiag = d;
+          bestX = p[u].x;
+        }
       }
     }
     lv.predCl[base + i] = best;
@@ -1832,14 +1832,20 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
   for (int w0 = 0; w0 < maxF; w0 += 16) {
     prvX = curX, prvY = curY, prvCost = curCost, prvLen = curLen;
     int flV = 0, fpV = -1, faV = -1;
+    // What the two fixed predecessors (the one of the diagonal class, the one above) add to their own cost depends on
+    // coordinates alone (:124-137, :150-163): worked out here, lane = fragment, once per window -- not in the sweep's
+    // serial part, where every lane of the group would repeat it for every fragment.
+    int pX = 0, pY = 0, aX = 0, aY = 0;
     curX = curY = 0;
     if (kPre) {
+      const int qx = gbp(preX, prePred), qy = gbp(preY, prePred), rx = gbp(preX, preAbove), ry = gbp(preY, preAbove);
       if (on && l < F) {
         curX = preX;
         curY = preY;
         flV = preLen;
         fpV = prePred;
         faV = preAbove;
+        pX = qx, pY = qy, aX = rx, aY = ry;
       }
     } else if (on && w0 + l < F) {
       const Frag f = C4_FR(w0 + l);
@@ -1848,23 +1854,31 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
       flV = (int)f.len;
       fpV = lv.predCl[base + w0 + l];
       faV = lv.above[base + w0 + l];
-    }
-    // fragment p of this group: from the two register windows, else from memory
-    auto view3 = [&](int p, bool need, int &vx, int &vy, int &vc) {
-      const int rel = p - w0;
-      const int xa = gbp(curX, rel), ya = gbp(curY, rel), ca = gbp(curCost, rel);
-      const int xb = gbp(prvX, rel + 16), yb = gbp(prvY, rel + 16), cb = gbp(prvCost, rel + 16);
-      vx = rel >= 0 ? xa : xb;
-      vy = rel >= 0 ? ya : yb;
-      vc = rel >= 0 ? ca : cb;
-      if (__ballot(need && rel < -16) != 0ull) {
-        if (need && rel < -16) {
-          const Frag f = C4_FR(p);
-          vx = (int)f.x;
-          vy = (int)f.y;
-          vc = C4_COST(p);
-        }
+      if (fpV >= 0) {
+        const Frag q = C4_FR(fpV);
+        pX = (int)q.x, pY = (int)q.y;
       }
+      if (faV >= 0) {
+        const Frag q = C4_FR(faV);
+        aX = (int)q.x, aY = (int)q.y;
+      }
+    }
+    int clS, caS;
+    {
+      int ov = (int)((uint32_t)k - (uint32_t)(curY - pY)) * prm.match;
+      if (ov > 0) ov = 0;
+      clS = ov + indel_penalty(curX, curY, pX, pY, prm.sdpIns, prm.sdpDel);
+      caS = (int)(((uint32_t)k - (uint32_t)(curY - aY)) * (uint32_t)prm.match +
+                  (uint32_t)indel_penalty(curX, curY, aX, aY, prm.sdpIns, prm.sdpDel));
+    }
+    // the cost of fragment p of this group: from the two register windows, else from memory
+    auto cost_of = [&](int p, bool need) {
+      const int rel = p - w0;
+      const int ca = gbp(curCost, rel), cb = gbp(prvCost, rel + 16);
+      int vc = rel >= 0 ? ca : cb;
+      if (__ballot(need && rel < -16) != 0ull)
+        if (need && rel < -16) vc = C4_COST(p);
+      return vc;
     };
     for (int j = 0; j < 16; j++) {
       const int i = w0 + j;
@@ -1874,10 +1888,31 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
       // ---- rows leaving the window: fragments with x <= f.x - k - 2 are retired first (:248-309)
       for (;;) {
         bool need = act && fTrail < i;
-        int ftx, fty, ftc;
-        view3(need ? fTrail : i, need, ftx, fty, ftc);
+        // (the test that ends the loop needs the row alone: column and cost are fetched when some group retires)
+        const int pT = need ? fTrail : i, relT = pT - w0;
+        int ftx, fty = 0, ftc = 0;
+        {
+          const int xa = gbp(curX, relT), xb = gbp(prvX, relT + 16);
+          ftx = relT >= 0 ? xa : xb;
+        }
+        const bool farT = need && relT < -16;
+        if (__ballot(farT) != 0ull) {
+          if (farT) {
+            const Frag f = C4_FR(pT);
+            ftx = (int)f.x;
+            fty = (int)f.y;
+            ftc = C4_COST(pT);
+          }
+        }
         need = need && (int64_t)ftx + k + 2 <= (int64_t)fx;
         if (__ballot(need) == 0ull) break;
+        {
+          const int ya = gbp(curY, relT), ca = gbp(curCost, relT), yb = gbp(prvY, relT + 16), cb = gbp(prvCost, relT + 16);
+          if (!farT) {
+            fty = relT >= 0 ? ya : yb;
+            ftc = relT >= 0 ? ca : cb;
+          }
+        }
         const bool validLane = nBase + l < n;
         const int tail0 = gbp(tail.x, 0);
         const int pos = nBase + gcount(validLane && tail.x < fty);
@@ -2020,20 +2055,17 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
       }
       const int clFrag = gbp(fpV, j), aboveIdx = gbp(faV, j);
       {
-        int px, py, pc;
+        const int clSj = gbp(clS, j), caSj = gbp(caS, j);
         const bool needCl = act && clFrag >= 0;
-        view3(needCl ? clFrag : i, needCl, px, py, pc);
+        const int pcl = cost_of(needCl ? clFrag : i, needCl);
         if (needCl) {
-          int ov = (int)((uint32_t)k - (uint32_t)(fy - py)) * prm.match;
-          if (ov > 0) ov = 0;
-          cl = pc + ov + indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel);
+          cl = (int)((uint32_t)pcl + (uint32_t)clSj);
           foundPrev = true;
         }
         const bool needCa = act && aboveIdx >= 0;
-        view3(needCa ? aboveIdx : i, needCa, px, py, pc);
+        const int pca = cost_of(needCa ? aboveIdx : i, needCa);
         if (needCa) {
-          ca = (int)((uint32_t)pc + ((uint32_t)k - (uint32_t)(fy - py)) * (uint32_t)prm.match +
-                     (uint32_t)indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel));
+          ca = (int)((uint32_t)pca + (uint32_t)caSj);
           foundPrev = true;
         }
       }
@@ -2284,6 +2316,7 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
   for (int w0 = 0; w0 < F; w0 += 64) {
     prev = cur;
     int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1;
+    int clS = 0, caS = 0;  // what the two fixed predecessors add to their own cost: coordinates only, lane = fragment
     if (w0 + lane < F) {
       const Frag f = fr[w0 + lane];
       fxV = (int)f.x;
@@ -2291,6 +2324,17 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
       flV = (int)f.len;
       fpV = predCl[w0 + lane];
       faV = above[w0 + lane];
+      if (fpV >= 0) {
+        const Frag q = fr[fpV];
+        int ov = (int)(fragmentLength - (uint32_t)(fyV - (int)q.y)) * prm.match;
+        if (ov > 0) ov = 0;
+        clS = ov + indel_penalty(fxV, fyV, (int)q.x, (int)q.y, prm.sdpIns, prm.sdpDel);
+      }
+      if (faV >= 0) {
+        const Frag q = fr[faV];
+        caS = (int)((fragmentLength - (uint32_t)(fyV - (int)q.y)) * (uint32_t)prm.match +
+                    (uint32_t)indel_penalty(fxV, fyV, (int)q.x, (int)q.y, prm.sdpIns, prm.sdpDel));
+      }
     }
     cur.x = fxV;
     cur.y = fyV;
@@ -2330,6 +2374,11 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
       if (p >= w0) return __builtin_amdgcn_readlane(cur.len, p - w0);
       if (p >= w0 - 64) return __builtin_amdgcn_readlane(prev.len, p - w0 + 64);
       return __builtin_amdgcn_readfirstlane(chainLen[p]);
+    };
+    auto view_cost = [&](int p) {
+      if (p >= w0) return __builtin_amdgcn_readlane(cur.cost, p - w0);
+      if (p >= w0 - 64) return __builtin_amdgcn_readlane(prev.cost, p - w0 + 64);
+      return __builtin_amdgcn_readfirstlane(cost[p]);
     };
     const int nHere = min(64, F - w0);
     for (int j = 0; j < nHere; j++) {
@@ -2403,17 +2452,12 @@ __device__ __forceinline__ void chain_sweep_bits(const SdpLevelArrays &lv, const
       }
       const int clFrag = __builtin_amdgcn_readlane(fpV, j);
       if (clFrag >= 0) {
-        const FragView p = view(clFrag);
-        int ov = (int)(fragmentLength - (uint32_t)(fy - p.y)) * prm.match;
-        if (ov > 0) ov = 0;
-        cl = p.cost + ov + indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel);
+        cl = (int)((uint32_t)view_cost(clFrag) + (uint32_t)__builtin_amdgcn_readlane(clS, j));
         foundPrev = true;
       }
       const int aboveIdx = __builtin_amdgcn_readlane(faV, j);
       if (aboveIdx >= 0) {
-        const FragView p = view(aboveIdx);
-        ca = (int)((uint32_t)p.cost + (fragmentLength - (uint32_t)(fy - p.y)) * (uint32_t)prm.match +
-                   (uint32_t)indel_penalty(fx, fy, p.x, p.y, prm.sdpIns, prm.sdpDel));
+        ca = (int)((uint32_t)view_cost(aboveIdx) + (uint32_t)__builtin_amdgcn_readlane(caS, j));
         foundPrev = true;
       }
       int mc = cl < ca ? cl : ca;
@@ -2534,6 +2578,7 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
   for (int w0 = 0; w0 < maxF; w0 += 16) {
     prvX = curX, prvY = curY, prvCost = curCost, prvLen = curLen;
     int flV = 0, fpV = -1, faV = -1;
+    int pX = 0, pY = 0, aX = 0, aY = 0;  // the two fixed predecessors' coordinates (chain4_body says why)
     curX = curY = 0;
     if (on && w0 + l < F) {
       const Frag f = lv.frags[base + w0 + l];
@@ -2542,21 +2587,32 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
       flV = (int)f.len;
       fpV = lv.predCl[base + w0 + l];
       faV = lv.above[base + w0 + l];
+      if (fpV >= 0) {
+        const Frag q = lv.frags[base + fpV];
+        pX = (int)q.x, pY = (int)q.y;
+      }
+      if (faV >= 0) {
+        const Frag q = lv.frags[base + faV];
+        aX = (int)q.x, aY = (int)q.y;
+      }
     }
-    // fragment p of this group: x, y, cost and chain length, from the two register windows, else from memory
-    auto view4 = [&](int p, bool need, int &vx, int &vy, int &vc, int &vl) {
+    int clS, caS;  // what they add to their own cost, lane = fragment
+    {
+      int ov = (int)((uint32_t)k - (uint32_t)(curY - pY)) * prm.match;
+      if (ov > 0) ov = 0;
+      clS = ov + indel_penalty(curX, curY, pX, pY, prm.sdpIns, prm.sdpDel);
+      caS = (int)(((uint32_t)k - (uint32_t)(curY - aY)) * (uint32_t)prm.match +
+                  (uint32_t)indel_penalty(curX, curY, aX, aY, prm.sdpIns, prm.sdpDel));
+    }
+    // fragment p of this group: cost and chain length, from the two register windows, else from memory
+    auto view2 = [&](int p, bool need, int &vc, int &vl) {
       const int rel = p - w0;
-      const int xa = gbp(curX, rel), ya = gbp(curY, rel), ca = gbp(curCost, rel), la = gbp(curLen, rel);
-      const int xb = gbp(prvX, rel + 16), yb = gbp(prvY, rel + 16), cb = gbp(prvCost, rel + 16), lb = gbp(prvLen, rel + 16);
-      vx = rel >= 0 ? xa : xb;
-      vy = rel >= 0 ? ya : yb;
+      const int ca = gbp(curCost, rel), la = gbp(curLen, rel);
+      const int cb = gbp(prvCost, rel + 16), lb = gbp(prvLen, rel + 16);
       vc = rel >= 0 ? ca : cb;
       vl = rel >= 0 ? la : lb;
       if (__ballot(need && rel < -16) != 0ull) {
         if (need && rel < -16) {
-          const Frag f = lv.frags[base + p];
-          vx = (int)f.x;
-          vy = (int)f.y;
           vc = lv.cost[base + p];
           vl = lv.chainLen[base + p];
         }
@@ -2570,10 +2626,28 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
       // ---- rows leaving the window: fragments with x <= f.x - k - 2 are retired first (:248-309)
       for (;;) {
         bool need = act && fTrail < i;
-        int ftx, fty, ftc, ftl;
-        view4(need ? fTrail : i, need, ftx, fty, ftc, ftl);
+        // (the test that ends the loop needs the row alone)
+        const int pT = need ? fTrail : i, relT = pT - w0;
+        int ftx, fty = 0, ftc, ftl;
+        {
+          const int xa = gbp(curX, relT), xb = gbp(prvX, relT + 16);
+          ftx = relT >= 0 ? xa : xb;
+        }
+        const bool farT = need && relT < -16;
+        if (__ballot(farT) != 0ull) {
+          if (farT) {
+            const Frag f = lv.frags[base + pT];
+            ftx = (int)f.x;
+            fty = (int)f.y;
+          }
+        }
         need = need && (int64_t)ftx + k + 2 <= (int64_t)fx;
         if (__ballot(need) == 0ull) break;
+        {
+          const int ya = gbp(curY, relT), yb = gbp(prvY, relT + 16);
+          if (!farT) fty = relT >= 0 ? ya : yb;
+        }
+        view2(pT, need, ftc, ftl);
         const int w = need ? fty >> 5 : 0;
         const uint32_t word = bits[w], bit = 1u << (fty & 31);
         const bool member = need && (word & bit) != 0u;
@@ -2635,20 +2709,18 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
       const int clFrag = gbp(fpV, j), aboveIdx = gbp(faV, j);
       int clLen = 0, caLen = 0;
       {
-        int px, py, pc;
+        const int clSj = gbp(clS, j), caSj = gbp(caS, j);
+        int pc;
         const bool needCl = act && clFrag >= 0;
-        view4(needCl ? clFrag : i, needCl, px, py, pc, clLen);
+        view2(needCl ? clFrag : i, needCl, pc, clLen);
         if (needCl) {
-          int ov = (int)((uint32_t)k - (uint32_t)(fy - py)) * prm.match;
-          if (ov > 0) ov = 0;
-          cl = pc + ov + indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel);
+          cl = (int)((uint32_t)pc + (uint32_t)clSj);
           foundPrev = true;
         }
         const bool needCa = act && aboveIdx >= 0;
-        view4(needCa ? aboveIdx : i, needCa, px, py, pc, caLen);
+        view2(needCa ? aboveIdx : i, needCa, pc, caLen);
         if (needCa) {
-          ca = (int)((uint32_t)pc + ((uint32_t)k - (uint32_t)(fy - py)) * (uint32_t)prm.match +
-                     (uint32_t)indel_penalty(fx, fy, px, py, prm.sdpIns, prm.sdpDel));
+          ca = (int)((uint32_t)pc + (uint32_t)caSj);
           foundPrev = true;
         }
       }
