@@ -306,8 +306,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       lv.hits = arena.get<uint64_t>((size_t)std::max<int64_t>(totalQ, 1));
       ARENA_CHECK();
     }
-    launch_sdp_match(lv, b->seq, false, st);
-    launch_sdp_match_index(lv, b->seq, false, st);
+    const bool matchSerial = getenv("BLASR_HIP_MATCH_SERIAL") != nullptr;
+    launch_sdp_match_all(lv, b->seq, false, st, matchSerial ? nullptr : ctx->auxStream, matchSerial ? nullptr : ctx->auxEvent);
     launch_sdp_gather_sizes(lv, 1, sizes, st);
     HIP_TRY(ctx, rocprim::exclusive_scan(tmp, tmpBytes, sizes, fragOff, (int64_t)0, (size_t)nTasks + 1,
                                          rocprim::plus<int64_t>(), st));
@@ -352,11 +352,19 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.colSet = arena.get<int4>(nf + 64);
     lv.tieList = arena.get<int32_t>(lv.n + 1);
     lv.tieCount = lv.tieList + lv.n;
+    // the general kernels beside the small ones (general_task in sdp_kernels.hip), unless the small ones are switched off
+    // (not at level 0, where nearly every invocation is a general one: a wavefront each balances better than a list)
+    const bool orderBeside = level > 0 && !getenv("BLASR_HIP_NO_SMALL4") && !getenv("BLASR_HIP_ORDER_SERIAL");
+    if (orderBeside) {
+      lv.leftList = arena.get<int32_t>(lv.n + 1);
+      lv.leftCount = lv.leftList + lv.n;
+      lv.bigGenList = arena.get<int32_t>(lv.n + 1);
+      lv.bigGenCount = lv.bigGenList + lv.n;
+    }
     lv.scratchA = arena.get<int32_t>(nf);
     lv.scratchB = arena.get<int32_t>(3 * nf);
     ARENA_CHECK();
-    launch_sdp_match(lv, b->seq, true, st);
-    launch_sdp_match_index(lv, b->seq, true, st);
+    launch_sdp_match_all(lv, b->seq, true, st, matchSerial ? nullptr : ctx->auxStream, matchSerial ? nullptr : ctx->auxEvent);
     {  // invocations with <= 64 fragments: order .. chain in one kernel; those with <= 16 four per wavefront, by size
       int32_t *smallOrder = nullptr;
       if (!getenv("BLASR_HIP_NO_SMALL4")) {
@@ -364,6 +372,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
         int32_t *sv = arena.get<int32_t>(nTasks);
         smallOrder = arena.get<int32_t>(nTasks);
         ARENA_CHECK();
+        if (orderBeside) HIP_TRY(ctx, hipMemsetAsync(lv.bigGenCount, 0, sizeof(int32_t), st));
         launch_sdp_small4_keys(lv, sk, sv, st);
         size_t sortBytes = 0;
         HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(nullptr, sortBytes, sk, skOut, sv, smallOrder, (size_t)nTasks, 0u, 5u, st));
@@ -371,12 +380,33 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
         ARENA_CHECK();
         HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, sk, skOut, sv, smallOrder, (size_t)nTasks, 0u, 5u, st));
       }
+      if (orderBeside) {
+        // the invocations with more than 64 raw fragments are never fused: their order .. above_predcl run on a side stream
+        // while the small kernels work through the rest
+        HIP_TRY(ctx, hipMemsetAsync(lv.leftCount, 0, sizeof(int32_t), st));
+        (void)hipEventRecord(ctx->auxEvent[0], st);
+        (void)hipStreamWaitEvent(ctx->auxStream[0], ctx->auxEvent[0], 0);
+        SdpLevelArrays big = lv;
+        big.generalMode = 2;
+        big.leftList = lv.bigGenList;
+        big.leftCount = lv.bigGenCount;
+        launch_sdp_order(big, ctx->auxStream[0]);
+        launch_sdp_yx_keys(big, ctx->auxStream[0]);
+        launch_sdp_sort_yx(big, yxKeysOut, yxIdxOut, ctx->auxStream[0]);
+        launch_sdp_above_predcl(big, ctx->auxStream[0]);
+        (void)hipEventRecord(ctx->auxEvent[1], ctx->auxStream[0]);
+      }
       launch_sdp_small(lv, prm, smallOrder, st);
+      if (orderBeside) {
+        (void)hipStreamWaitEvent(st, ctx->auxEvent[1], 0);
+        lv.generalMode = 2;  // what the small kernels left over (a tie among 17 .. 64 fragments: rare)
+      }
     }
     launch_sdp_order(lv, st);
     launch_sdp_yx_keys(lv, st);
     launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);
     launch_sdp_above_predcl(lv, st);
+    lv.generalMode = 0;
     tock(1);
 
     // ---- chain ----

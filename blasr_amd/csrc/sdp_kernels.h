@@ -79,6 +79,9 @@ struct SdpLevelArrays {
   int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *idxWave;             // 4 per task: the middle fragments of each wavefront's share of the query (index kernel)
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
+  int generalMode;              // which invocations sdp_order .. sdp_above_predcl take (general_task in sdp_kernels.hip)
+  int32_t *leftList, *leftCount;  // mode 2's list: what sdp_small_kernel could not fuse although it has <= 64 fragments
+  int32_t *bigGenList, *bigGenCount;  // the invocations with more than 64 raw fragments (sdp_small4_keys_kernel lists them)
   int4 *colSet;  // column set storage {column, fragment, cost, x+y}, one slot per fragment
   int32_t *chainEnd;                                      // n: last fragment of the reported chain
   int32_t *scratchA;                                      // per fragment: chain indices
@@ -101,7 +104,9 @@ struct SdpEmit {
 void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st);
 void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st);
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
-void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
+void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side = nullptr);
+void launch_sdp_match_all(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t *aux,
+                          hipEvent_t *ev);
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st);
 // order: the level's invocations sorted by launch_sdp_small4_keys' keys, descending (nullptr: no sdp_small4_kernel)
 void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st);

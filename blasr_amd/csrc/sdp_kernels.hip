@@ -81,6 +81,20 @@ __device__ __forceinline__ int wave_task_index() {
   return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 }
 
+// Which invocation a wavefront of the GENERAL kernels between the match and the sweep takes (sdp_order .. above_predcl:
+// those sdp_small4_kernel / sdp_small_kernel do not fuse), -1: none (any more).  lv.generalMode 0: a wavefront per
+// invocation of the level, after the small kernels, by lv.fused (level 0, where nearly all are general ones); 2: a fixed
+// grid striding over a list, lv.leftList -- first, BESIDE the small kernels, the invocations with more than 64 raw
+// fragments, which are never fused (sdp_small4_keys_kernel lists them), then what the small kernels left over of the rest
+// (<= 64 fragments, yet a tie that needs std::sort's schedule: rare).  At the recursion levels nine invocations in ten are
+// fused, and a wavefront each that finds nothing to do cost every one of these kernels a millisecond.
+__device__ __forceinline__ int general_task(const SdpLevelArrays &lv, int it) {
+  const int slot = wave_task_index() + it * (int)(gridDim.x * 4);
+  if (lv.generalMode == 2) return slot < *lv.leftCount ? lv.leftList[slot] : -1;
+  if (it > 0 || slot >= lv.n) return -1;
+  return lv.fused[slot] ? -1 : slot;
+}
+
 // ---------------------------------------------------------------------------
 // sdp_keys: every k-mer of the target whose k bases are all ACGT (DNATuple.h:308-359),
 // first base in the least-significant bits (FromStringRL :55-83)
@@ -232,19 +246,21 @@ __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, u
 
 __global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uint64_t *tmpKeys, uint32_t *tmpIdx) {
   __shared__ unsigned hist[4][512];
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
-  if (lv.fused[idx]) return;
-  const int lane = lane_id();
-  const int F = lv.nFrag[idx];
-  const int64_t base = lv.fragOff[idx];
-  bool inB;
-  // keys are y << 32 | x, already ordered by (x,y): a stable sort on the 24 bits of y gives (y,x) order
-  const int yBits = 32 - __builtin_clz((unsigned)max(lv.tasks[idx].tLen, 1));  // y < tLen
-  wave_radix_sort<true>(lv.yxKeys + base, tmpKeys + base, lv.yxIdx + base, tmpIdx + base, F, 32, 32 + yBits,
-                        hist[threadIdx.x >> 6], inB);
-  if (inB)
-    for (int i = lane; i < F; i += 64) lv.yxIdx[base + i] = tmpIdx[base + i];
+  for (int it = 0;; it++) {
+    const int idx = general_task(lv, it);
+    if (idx < 0) return;
+    const int lane = lane_id();
+    const int F = lv.nFrag[idx];
+    const int64_t base = lv.fragOff[idx];
+    bool inB;
+    // keys are y << 32 | x, already ordered by (x,y): a stable sort on the 24 bits of y gives (y,x) order
+    const int yBits = 32 - __builtin_clz((unsigned)max(lv.tasks[idx].tLen, 1));  // y < tLen
+    wave_radix_sort<true>(lv.yxKeys + base, tmpKeys + base, lv.yxIdx + base, tmpIdx + base, F, 32, 32 + yBits,
+                          hist[threadIdx.x >> 6], inB);
+    if (inB)
+      for (int i = lane; i < F; i += 64) lv.yxIdx[base + i] = tmpIdx[base + i];
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // small-word (<= 5) k-mer of s[p .. p+ks), or -1 when it holds a non-ACGT base
@@ -703,6 +719,7 @@ constexpr int kBucketBits = 11;  // LDS bucket index over the leading bits of th
 template <bool kWrite, bool kBuckets>
 __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const uint8_t *seq) {
   __shared__ uint32_t bucketStart[kBuckets ? 4 : 1][kBuckets ? (1 << kBucketBits) + 1 : 1];
+  __shared__ uint4 tinyT4[kBuckets ? 1 : 4][kBuckets ? 1 : kTinyT / 4];  // a tiny target's k-mers, by position
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
   const int lane = lane_id();
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   }
   int nM = 0;
   uint64_t *hits = lv.hits + lv.qPosOff[idx];  // per query position: first matching key | count << 32
-  const bool tiny = t.tLen <= kTinyT;
+  const bool tiny = !kBuckets && t.tLen <= kTinyT;  // (the instantiation with the bucket index only sees targets >= 256)
   if (tiny) {
     // the target's k-mers in registers (positions lane and lane + 64); every query k-mer is compared with
     // all of them in position order, which is the order of the sorted tuple list
@@ -762,9 +779,14 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
     };
     // count pass: per query position {count : 16, the first three target positions : 3 x 16} go to `hits`, so
     // the write pass is a copy unless some position has more than three matches
+    // The target's k-mers go to LDS once (0xffffffff where there is none: a k-mer has at most 22 bits) and every query
+    // lane walks them four to a read, in position order; lanes meet a branch only where some lane has a match.  (With the
+    // k-mers in registers and a v_readlane per target position the loop was a chain of twelve dependent scalar
+    // instructions per position.)
     bool haveT = false;
-    uint32_t tk0 = 0, tk1 = 0;
-    unsigned long long m0 = 0, m1 = 0;
+    uint32_t *tinyT = reinterpret_cast<uint32_t *>(tinyT4[kBuckets ? 0 : threadIdx.x >> 6]);
+    const uint4 *tinyQuads = tinyT4[kBuckets ? 0 : threadIdx.x >> 6];
+    const int nT = max(t.tLen - k + 1, 0);
     for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
       const int x = x0 + lane;
       const bool inQ = x + k <= t.qLen;
@@ -780,28 +802,38 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
       if (replay) {
         if (!haveT) {
           bool ok0, ok1;
-          tk0 = kmer_at(tSeq, lane, t.tLen, ok0);
-          tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
-          m0 = __ballot(ok0);
-          m1 = __ballot(ok1);
+          const uint32_t tk0 = kmer_at(tSeq, lane, t.tLen, ok0);
+          const uint32_t tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
+          tinyT[lane] = ok0 ? tk0 : 0xffffffffu;
+          tinyT[lane + 64] = ok1 ? tk1 : 0xffffffffu;
+          __builtin_amdgcn_wave_barrier();
           haveT = true;
         }
         bool okq;
         qk = kmer_at(qSeq, x, t.qLen, okq);
+        if (!okq) qk = 0xfffffffeu;  // (matches nothing)
         if (!kWrite) {
           uint64_t pos3 = 0;
-          for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
-            const int y = __builtin_ctzll(m);
-            if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
-              if (cnt < 3) pos3 |= (uint64_t)y << (16 * (cnt + 1));
-              cnt++;
-            }
-          }
-          for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
-            const int y = __builtin_ctzll(m);
-            if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
-              if (cnt < 3) pos3 |= (uint64_t)(y + 64) << (16 * (cnt + 1));
-              cnt++;
+          for (int y0 = 0; y0 < nT; y0 += 4) {
+            const uint4 tv = tinyQuads[y0 >> 2];
+            const bool e0 = tv.x == qk, e1 = tv.y == qk, e2 = tv.z == qk, e3 = tv.w == qk;
+            if (__ballot(e0 || e1 || e2 || e3) != 0ull) {
+              if (e0) {
+                if (cnt < 3) pos3 |= (uint64_t)y0 << (16 * (cnt + 1));
+                cnt++;
+              }
+              if (e1) {
+                if (cnt < 3) pos3 |= (uint64_t)(y0 + 1) << (16 * (cnt + 1));
+                cnt++;
+              }
+              if (e2) {
+                if (cnt < 3) pos3 |= (uint64_t)(y0 + 2) << (16 * (cnt + 1));
+                cnt++;
+              }
+              if (e3) {
+                if (cnt < 3) pos3 |= (uint64_t)(y0 + 3) << (16 * (cnt + 1));
+                cnt++;
+              }
             }
           }
           if (!okq || (t.maxPerPos != 0 && cnt > t.maxPerPos)) cnt = 0;
@@ -821,20 +853,11 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
             out[w++] = f;
           }
         } else {
-          for (unsigned long long m = m0; m != 0ull; m &= m - 1ull) {
-            const int y = __builtin_ctzll(m);
-            if ((uint32_t)__builtin_amdgcn_readlane((int)tk0, y) == qk) {
+          for (int y = 0; y < nT; y++)
+            if (tinyT[y] == qk) {
               f.y = (uint32_t)y;
               out[w++] = f;
             }
-          }
-          for (unsigned long long m = m1; m != 0ull; m &= m - 1ull) {
-            const int y = __builtin_ctzll(m);
-            if ((uint32_t)__builtin_amdgcn_readlane((int)tk1, y) == qk) {
-              f.y = (uint32_t)(y + 64);
-              out[w++] = f;
-            }
-          }
         }
       }
       nM += __builtin_amdgcn_readlane((int)incl, 63);
@@ -921,10 +944,7 @@ struct FragLess {
 struct RankLess {
   __device__ __forceinline__ bool operator()(uint32_t a, uint32_t b) const { return (a >> 16) < (b >> 16); }
 };
-__global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
-  if (lv.fused[idx]) return;  // sdp_small_kernel's
+__device__ __forceinline__ void order_task(const SdpLevelArrays &lv, const int idx) {
   const int lane = lane_id();
   const int nP = lv.nRaw[3 * idx], nM = lv.nRaw[3 * idx + 1], nS = lv.nRaw[3 * idx + 2];
   const Frag *P = lv.raw + lv.fragOff[idx], *M = P + nP, *S = M + nM;
@@ -962,6 +982,13 @@ __global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
     if (lane == 0) lv.nFrag[idx] = nAll;
   } else if (lane == 0) {
     lv.tieList[atomicAdd(lv.tieCount, 1)] = idx;  // rare: resolved by sdp_order_ties_kernel
+  }
+}
+__global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
+  for (int it = 0;; it++) {
+    const int idx = general_task(lv, it);  // (not sdp_small_kernel's)
+    if (idx < 0) return;
+    order_task(lv, idx);
   }
 }
 
@@ -1247,24 +1274,22 @@ __global__ __launch_bounds__(64) void sdp_order_ties_kernel(SdpLevelArrays lv, i
 // StoreAbove (SparseDynamicProgramming.h:55-68) and the sweep-set predecessor
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sdp_yx_keys_kernel(SdpLevelArrays lv) {
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
-  if (lv.fused[idx]) return;
-  const int lane = lane_id();
-  const int F = lv.nFrag[idx];
-  const int64_t base = lv.fragOff[idx];
-  for (int i = lane; i < F; i += 64) {
-    const Frag f = lv.frags[base + i];
-    lv.yxKeys[base + i] = ((uint64_t)f.y << 32) | f.x;
-    lv.yxIdx[base + i] = (uint32_t)i;
-    lv.above[base + i] = -1;
+  for (int it = 0;; it++) {
+    const int idx = general_task(lv, it);
+    if (idx < 0) return;
+    const int lane = lane_id();
+    const int F = lv.nFrag[idx];
+    const int64_t base = lv.fragOff[idx];
+    for (int i = lane; i < F; i += 64) {
+      const Frag f = lv.frags[base + i];
+      lv.yxKeys[base + i] = ((uint64_t)f.y << 32) | f.x;
+      lv.yxIdx[base + i] = (uint32_t)i;
+      lv.above[base + i] = -1;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv) {
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
-  if (lv.fused[idx]) return;
+__device__ __forceinline__ void above_predcl_task(const SdpLevelArrays &lv, const int idx) {
   const int lane = lane_id();
   const int F = lv.nFrag[idx];
   const int64_t base = lv.fragOff[idx];
@@ -1309,6 +1334,13 @@ __global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv
       }
     }
     lv.predCl[base + i] = best;
+  }
+}
+__global__ __launch_bounds__(256) void sdp_above_predcl_kernel(SdpLevelArrays lv) {
+  for (int it = 0;; it++) {
+    const int idx = general_task(lv, it);
+    if (idx < 0) return;
+    above_predcl_task(lv, idx);
   }
 }
 
@@ -2793,10 +2825,23 @@ constexpr int kSmall4Max = 16;
 // first.  sdp_small4_keys_kernel writes the sort keys.
 __global__ __launch_bounds__(256) void sdp_small4_keys_kernel(SdpLevelArrays lv, uint32_t *keys, int32_t *vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= lv.n) return;
-  const int nAll = lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2];
-  keys[i] = (uint32_t)min(nAll, kSmall4Max + 1);
-  vals[i] = i;
+  const int nAll = i < lv.n ? lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2] : 0;
+  if (i < lv.n) {
+    keys[i] = (uint32_t)min(nAll, kSmall4Max + 1);
+    vals[i] = i;
+  }
+  // the invocations no small kernel fuses (more than 64 raw fragments), as a list: the general kernels take them from
+  // there beside the small ones (general_task), instead of a wavefront per invocation of the level that mostly finds nothing
+  if (lv.bigGenList != nullptr) {
+    const bool big = nAll > 64;
+    const unsigned long long m = __ballot(big);
+    if (m != 0ull) {
+      int at = 0;
+      if (lane_id() == 0) at = atomicAdd(lv.bigGenCount, (int)__popcll(m));
+      at = __builtin_amdgcn_readfirstlane(at);
+      if (big) lv.bigGenList[at + (int)__popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+    }
+  }
 }
 __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, SdpParams prm, const int32_t *order) {
   const int lane = lane_id(), l = lane & 15, gb = lane & 48;
@@ -2950,7 +2995,10 @@ __global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpPa
   dup = dup && lane < nAll;
   const unsigned long long dupMask = __ballot(dup);
   if (dupMask != 0ull && nAll > 16) {
-    if (lane == 0) lv.fused[idx] = 0;
+    if (lane == 0) {
+      lv.fused[idx] = 0;
+      if (lv.leftList != nullptr) lv.leftList[atomicAdd(lv.leftCount, 1)] = idx;  // (general_task, mode 2)
+    }
     return;
   }
   if (lane == 0) lv.fused[idx] = 1;
@@ -3759,6 +3807,8 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
 // launchers
 // ---------------------------------------------------------------------------
 static dim3 wave_grid(int n) { return dim3((unsigned)((n + 3) / 4)); }
+// (the general kernels' grid: a wavefront per invocation, or -- general_task's mode 2 -- a fixed one that strides over a list)
+static dim3 general_grid(const SdpLevelArrays &lv) { return lv.generalMode == 2 ? dim3(2048) : wave_grid(lv.n); }
 
 void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
@@ -3767,14 +3817,35 @@ void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t s
   if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, tmp);
 }
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_yx_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, tmpKeys, tmpIdx);
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_yx_kernel, general_grid(lv), dim3(256), 0, st, lv, tmpKeys, tmpIdx);
 }
-void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
+void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side) {
   if (lv.n <= 0) return;
   if (write) hipLaunchKernelGGL((sdp_match_kernel<true, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
   else {
     hipLaunchKernelGGL((sdp_match_kernel<false, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
-    hipLaunchKernelGGL((sdp_match_kernel<false, true>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+    hipLaunchKernelGGL((sdp_match_kernel<false, true>), wave_grid(lv.n), dim3(256), 0, side ? side : st, lv, seq);
+  }
+}
+// The matchers take disjoint sets of invocations -- tiny and short targets (a wavefront each, bound by the latency of its
+// few loads with every wavefront slot taken), targets from 256 bases on (LDS bucket index) and the long ones (LDS k-mer
+// index, three size classes) -- so they run side by side: aux / ev as in launch_sdp_chain, or nullptr.
+void launch_sdp_match_all(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t *aux,
+                          hipEvent_t *ev) {
+  if (lv.n <= 0) return;
+  const bool fork = aux != nullptr && ev != nullptr;
+  if (!fork) {
+    launch_sdp_match(lv, seq, write, st, nullptr);
+    launch_sdp_match_index(lv, seq, write, st);
+    return;
+  }
+  (void)hipEventRecord(ev[0], st);
+  for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+  launch_sdp_match_index(lv, seq, write, aux[0]);
+  launch_sdp_match(lv, seq, write, st, aux[1]);
+  for (int i = 0; i < 2; i++) {
+    (void)hipEventRecord(ev[1 + i], aux[i]);
+    (void)hipStreamWaitEvent(st, ev[1 + i], 0);
   }
 }
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
@@ -3838,16 +3909,16 @@ void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.tieCount, 0, sizeof(int32_t), st);
-  hipLaunchKernelGGL(sdp_order_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+  hipLaunchKernelGGL(sdp_order_kernel, general_grid(lv), dim3(256), 0, st, lv);
   hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsSmall>, dim3((unsigned)std::min(lv.n, 4096)), dim3(64), 0, st, lv, 0);
   hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsCap>, dim3((unsigned)std::min(lv.n, 1024)), dim3(64), 0, st, lv,
                      kTieLdsSmall + 1);
 }
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_yx_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_yx_keys_kernel, general_grid(lv), dim3(256), 0, st, lv);
 }
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, wave_grid(lv.n), dim3(256), 0, st, lv);
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, general_grid(lv), dim3(256), 0, st, lv);
 }
 int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {

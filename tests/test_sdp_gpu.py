@@ -198,11 +198,15 @@ def test_alternative_kernels_agree(ctx, oracle, monkeypatch):
     """The library picks its kernels by size class; the switches BLASR_HIP_NO_INDEX (long targets through the
     sorted-key kernels instead of the LDS index), BLASR_HIP_NO_CHAIN4 (the sweep with one invocation per
     wavefront instead of four) and BLASR_HIP_NO_SMALL4 (invocations of at most 16 fragments one per wavefront
-    instead of four) force the general paths, which must give the same answers."""
+    instead of four) force the general paths, which must give the same answers.  BLASR_HIP_MATCH_SERIAL and
+    BLASR_HIP_ORDER_SERIAL put the kernels that otherwise run side by side (the matchers; the general order .. above
+    kernels and the small ones) back on one stream, one after the other."""
     rng = np.random.default_rng(206)
     pairs = [synth.make_pair(rng, n, flank=(0, 150)) for n in (1700, 2600, 5200)]
     want = [oracle.sdp_align(q, t) for q, t in pairs]
-    for env in ({}, {"BLASR_HIP_NO_INDEX": "1"}, {"BLASR_HIP_NO_CHAIN4": "1"}, {"BLASR_HIP_NO_SMALL4": "1"}):
+    for env in ({}, {"BLASR_HIP_NO_INDEX": "1"}, {"BLASR_HIP_NO_CHAIN4": "1"}, {"BLASR_HIP_NO_SMALL4": "1"},
+                {"BLASR_HIP_MATCH_SERIAL": "1"}, {"BLASR_HIP_ORDER_SERIAL": "1"},
+                {"BLASR_HIP_MATCH_SERIAL": "1", "BLASR_HIP_ORDER_SERIAL": "1", "BLASR_HIP_NO_INDEX": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = ctx.sdp(pairs)
