@@ -112,7 +112,7 @@ void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st);
 void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_t *order, hipStream_t st);
 int sdp_match_index_max_target(int device);
-void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st);
+void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side = nullptr);
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);

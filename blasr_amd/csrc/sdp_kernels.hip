@@ -3840,10 +3840,10 @@ void launch_sdp_match_all(const SdpLevelArrays &lv, const uint8_t *seq, bool wri
     return;
   }
   (void)hipEventRecord(ev[0], st);
-  for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
-  launch_sdp_match_index(lv, seq, write, aux[0]);
+  for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+  launch_sdp_match_index(lv, seq, write, aux[0], aux[2]);  // (the index's larger size classes on a stream of their own)
   launch_sdp_match(lv, seq, write, st, aux[1]);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     (void)hipEventRecord(ev[1 + i], aux[i]);
     (void)hipStreamWaitEvent(st, ev[1 + i], 0);
   }
@@ -3881,7 +3881,7 @@ int sdp_match_index_max_target(int device) {
     fprintf(stderr, "[sdp] LDS per workgroup %d (opt-in %d) -> indexed targets up to %d bases\n", plain, optin, tCap);
   return tCap;
 }
-void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st) {
+void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side) {
   if (lv.n <= 0 || lv.idxMaxT <= 0) return;
   // three size classes, so that the usual targets (<= kIdxSmallCap) get four workgroups per CU
   const int grid = std::min(lv.n, 1024);
@@ -3891,10 +3891,11 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
     if (c > 0 && caps[c] <= caps[c - 1]) break;
     const int minT = c == 0 ? 0 : caps[c - 1];
     const size_t bytes = (size_t)idx_lds_bytes(caps[c]);
+    hipStream_t s = (c > 0 && side) ? side : st;
     if (write)
-      hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
+      hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
     else
-      hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, st, lv, seq, caps[c], minT);
+      hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
   }
 }
 void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
