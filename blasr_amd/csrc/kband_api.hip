@@ -10,6 +10,16 @@
 //                           LDS and are updated in place; one packed arrow byte per cell goes to HBM.
 //   kband_traceback_kernel  one lane per task: the three-matrix walk of :299-391, run-length encoded into the
 //                           same op arena the guided refiner uses (M / I / D), then the shared compaction.
+// Bands wider than the LDS rows (-noUseGuidedAlign gives k ~ 1.3 k at 10 kb reads and ~ 2.7 k at 30 kb,
+// Blasr.cpp:991-1001, :699) take the second pair of kernels, which have no limit on k:
+//   kband_wide_kernel       the matrix in (q, t) coordinates, cut into strips of 256 target columns; a wavefront
+//                           sweeps a strip along anti-diagonals, lane = four adjacent columns, lane l one row
+//                           behind lane l-1.  Every neighbour of a cell is then a value of the step before (own
+//                           registers, or the lane to the left through one DPP shift): no scan, no LDS rows.
+//                           The strip's last column goes to the next strip through a small column buffer; one
+//                           arrow NIBBLE per cell goes to HBM, 16 bytes per lane per eight steps.
+//   kband_wide_traceback_kernel  one wavefront per task: windows of the nibble matrix staged in LDS (the path
+//                           crosses about five d-steps per lane), lane 0 walks them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,13 +43,19 @@ struct KbandGeo {
   int32_t qLen, tLen;  // after SetKBoundedLengths
   int32_t k, nCols;
   int32_t status;
-  int32_t pad;
+  int32_t wide;        // 1: kband_wide_kernel (strips of the (q, t) matrix), 0: kband_fill_kernel (band rows in LDS)
   int64_t cells;       // (qLen + 1) * nCols
   int64_t arenaWords;  // worst-case op count
+  int64_t arrowBytes;  // arrow storage: one byte per band cell, or (wide) nStrips * stepsPad * 128 nibble bytes
+  int32_t nStrips, stepsPad;  // wide only
 };
 
+// ---- the wide kernel's geometry: strips of kKwW target columns, lane = kKwC adjacent columns
+constexpr int kKwC = 4, kKwW = 64 * kKwC;
+
 __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *qLenIn, const int32_t *tLenIn,
-                                                         const int32_t *kIn, KbandGeo *geo) {
+                                                         const int32_t *kIn, KbandGeo *geo, int wideFromCols, int linear,
+                                                         int magnitude) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   KbandGeo g;
@@ -47,8 +63,13 @@ __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *q
   g.k = (int32_t)k;
   g.nCols = (int32_t)(2 * k + 1);
   g.status = 0;
-  g.pad = 0;
-  if (qLength <= 0 || tLength <= 0 || k < 1 || 2 * k + 1 > kKbMaxCols) {
+  g.wide = (!linear && 2 * k + 1 >= wideFromCols) ? 1 : 0;
+  g.nStrips = g.stepsPad = 0;
+  g.arrowBytes = 0;
+  // every real score stays below 2^25 (the strip kernel keeps them times four), so that kKbInf plus or minus one of
+  // them still compares as "no such cell"
+  if (qLength <= 0 || tLength <= 0 || k < 1 || (!g.wide && 2 * k + 1 > kKbMaxCols) || k > (1 << 24) ||
+      (qLength + tLength + 2) * (int64_t)max(magnitude, 1) >= (1 << 25)) {
     g.status = TASK_BAD_GUIDE;
     g.qLen = g.tLen = 0;
     g.cells = 0;
@@ -61,6 +82,13 @@ __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *q
     g.tLen = (int32_t)tLen;
     g.cells = (qLen + 1) * (2 * k + 1);
     g.arenaWords = qLen + tLen + 2 * k + 4;
+    g.arrowBytes = g.cells;
+    if (g.wide) {
+      // a strip's rows: q in [max(1, tA - k), min(qLen, tA + W - 1 + k)], 63 more steps for the lanes' skew
+      g.nStrips = (int32_t)((tLen + kKwW - 1) / kKwW);
+      g.stepsPad = (int32_t)((min(qLen, (int64_t)kKwW + 2 * k) + 63 + 7) & ~(int64_t)7);
+      g.arrowBytes = (int64_t)g.nStrips * g.stepsPad * 128;
+    }
   }
   geo[i] = g;
 }
@@ -78,6 +106,8 @@ struct KbandArgs {
   const int64_t *arenaOff;
   int32_t *opsStart;
   RefineResult *results;
+  int32_t *bound;            // wide only: per task two columns of (qLen + 2) scores, a strip's last column
+  const int64_t *boundOff;
 };
 
 __global__ __launch_bounds__(256) void kband_fill_kernel(KbandArgs a) {
@@ -90,7 +120,7 @@ __global__ __launch_bounds__(256) void kband_fill_kernel(KbandArgs a) {
   if (idx >= a.count) return;
   const int task = a.first + idx;
   const KbandGeo g = a.geo[task];
-  if (g.status != 0) return;
+  if (g.status != 0 || g.wide) return;
   int *S = rowS[wv], *I = rowI[wv], *H = rowH[wv];
   const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
   uint8_t *arrows = a.arrows + a.arrowOff[task];
@@ -196,6 +226,7 @@ __global__ __launch_bounds__(64) void kband_traceback_kernel(KbandArgs a) {
     a.opsStart[task] = 0;
     return;
   }
+  if (g.wide) return;  // kband_wide_traceback_kernel
   const uint8_t *arrows = a.arrows + a.arrowOff[task];
   uint32_t *arena = a.arena + a.arenaOff[task];
   const int k = g.k, nCols = g.nCols;
@@ -241,6 +272,308 @@ __global__ __launch_bounds__(64) void kband_traceback_kernel(KbandArgs a) {
   res.n_ops = status ? 0 : (int32_t)(g.arenaWords - pos);
   a.results[task] = res;
   a.opsStart[task] = pos;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The wide band: AffineKBandAlign with no limit on k.
+//
+// Coordinates are (q, t), 1-based, as in the reference's loops (:160-166); cell (q, t) is in the band when
+// |t - q| <= k and t <= tLen.  Strip s holds the columns tA .. tA + 255, tA = 1 + 256 s, and the rows
+// qLo = max(1, tA - k) .. qHi = min(qLen, tA + 255 + k) that meet the band in them.  Lane l owns the columns
+// tA + 4 l .. + 3 and works on row qLo + d - l at step d: what a cell reads (:171-245) is
+//   up   (q-1, t)    the lane's own value of the step before (registers pS / pI / pH),
+//   diag (q-1, t-1)  the same for the lane's columns 1..3; for column 0 the left lane's column 3 two steps ago,
+//   left (q,   t-1)  this step's value of the column before; for column 0 the left lane's column 3 one step ago,
+// so one DPP shift per step moves everything that crosses lanes.  Lane 0's left neighbour is the strip before
+// (column t = 0 for strip 0: q * insExtend + insOpen, :98-101, :143-146), read 64 rows at a time from the column
+// buffer that strip wrote; lane 63's column 3 is collected the same way and written 64 rows at a time.
+// Cells outside the band are computed like any other and hold garbage; every read INTO the band from outside
+// it is masked instead: `up` above the band's upper edge (t = q + k, the reference's `t < q + k` tests), `left`
+// below its lower edge (t = q - k, :218-220); a diagonal neighbour of a band cell is always a band cell or row 0 /
+// column 0.  Groups of eight steps in which no lane touches an edge run without the masks; groups in which some
+// lane has not started or has finished its rows run under EXEC so that idle lanes keep their state (row 0, or the
+// strip's last row -- the final score is read from there).
+// Arrow nibble: bits 0-1 pathMat, bit 2 insPathMat is AffineInsOpen, bit 3 hpInsPathMat is AffineHPInsOpen;
+// layout [strip][step / 8][lane] 16 bytes = eight steps x four columns.
+// ---------------------------------------------------------------------------------------------
+// Arithmetic: every score is kept times four, so that its two low bits can carry a tag.  The four candidates of
+// S get the tags 0 (match) 1 (deletion) 2 (insertion matrix) 3 (homopolymer matrix): ONE minimum then yields the
+// score and, in the low bits, the arrow with the reference's precedence on ties (:246-257: Diagonal, Left,
+// AffineInsClose, AffineHPInsClose); the values of the insertion matrices carry their tag all the time (2 and 3, the
+// same on both sides of every comparison between them), S is stripped of it.  Open-or-extend (:190-215, strict <) is the
+// sign of open - extend, appended to the arrow word by one v_alignbit.
+struct KwLane {
+  int pS[kKwC], pI[kKwC], pH[kKwC];  // the row above, this lane's columns (x 4; pI tagged 2, pH tagged 3)
+  int leftIn;                        // S(q, t0 - 1) of the current row
+  int info;                          // the row's query base: byte offset of its matrix row (code * 20), and bit 28 set
+                                     // when the base differs from the one before (no homopolymer extension, :180-188)
+  int tb[kKwC];                      // the columns' target bases: byte offset inside a matrix row (code * 4)
+  int eTop0;                         // column c may look up   <=> d - eTop0 > c
+};                                   //          may look left <=> d - eTop0 - 2k < c
+struct KwPenalties {                 // x 4, tags folded in
+  int hpOpenT;   // hpInsOpen * 4 + 3
+  int hpExt;     // hpInsExtend * 4
+  int insOpenT;  // insOpen * 4 + 2
+  int insExt;    // insExtend * 4
+  int delT;      // del * 4 + 1
+};
+enum { KW_I_OPEN = 8, KW_H_OPEN = 4 };  // the nibble: insPathMat is Open, hpInsPathMat is Open, two bits of pathMat
+
+__device__ __forceinline__ int kw_append_sign(int acc, int v) {  // (acc << 1) | (v < 0)
+  return (int)__builtin_amdgcn_alignbit((unsigned)acc, (unsigned)v, 31);
+}
+
+template <bool MASK>
+__device__ __forceinline__ unsigned kw_cells(KwLane &L, const char *mBytes, int d, int twoK, int leftPrev,
+                                             const KwPenalties &P) {
+  const int qoff = L.info & 0xff;
+  const int hpExtAdd = (L.info & ~0xff) + P.hpExt;  // + kKbInf outside a homopolymer
+  int m[kKwC];
+#pragma unroll
+  for (int c = 0; c < kKwC; c++) m[c] = *reinterpret_cast<const int *>(mBytes + qoff + L.tb[c]);
+  const int x = d - L.eTop0, y = x - twoK;
+  int diag = leftPrev, left = L.leftIn;
+  int pack = 0;
+#pragma unroll
+  for (int c = 0; c < kKwC; c++) {
+    const int upS = L.pS[c];
+    const int match = diag + m[c];
+    const int hpOpen = upS + P.hpOpenT, hpExt = L.pH[c] + hpExtAdd;
+    int minHp = min(hpOpen, hpExt);
+    const int insOpen = upS + P.insOpenT, insExt = L.pI[c] + P.insExt;
+    int minIns = min(insOpen, insExt);
+    int delScore = left + P.delT;
+    if (MASK) {
+      const bool upperOk = x > c;
+      minHp = upperOk ? minHp : kKbInf;
+      minIns = upperOk ? minIns : kKbInf;
+      delScore = (y < c) ? delScore : kKbInf;
+    }
+    const int tagged = min(min(match, delScore), min(minIns, minHp));
+    pack = kw_append_sign(pack, insOpen - insExt);
+    pack = kw_append_sign(pack, hpOpen - hpExt);
+    pack = (pack << 2) | (tagged & 3);
+    const int sc = tagged & ~3;
+    diag = upS;
+    left = sc;
+    L.pS[c] = sc;
+    L.pI[c] = minIns;
+    L.pH[c] = minHp;
+  }
+  return (unsigned)pack;
+}
+
+// eight steps d0 .. d0 + 7 of a strip; returns the lane's 16 bytes of arrows (dword j: steps 2j, 2j+1; a step's
+// four columns, column 0 in the highest nibble of its half)
+template <bool RAMP, bool MASK>
+__device__ __forceinline__ uint4 kw_group(KwLane &L, const char *mBytes, int d0, int lane, int nRows, int twoK,
+                                          const KwPenalties &P, int qBlock, int bBlock, int &outB, int32_t *bOut) {
+  unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int d = d0 + r;
+    const int newInfo = __builtin_amdgcn_readlane(qBlock, d & 63), edgeS = __builtin_amdgcn_readlane(bBlock, d & 63);
+    L.info = wave_shr1(L.info, newInfo);
+    const int leftPrev = L.leftIn;
+    L.leftIn = wave_shr1(L.pS[kKwC - 1], edgeS);
+    unsigned pack = 0;
+    if (RAMP) {
+      if ((unsigned)(d - lane) < (unsigned)nRows) pack = kw_cells<MASK>(L, mBytes, d, twoK, leftPrev, P);
+    } else {
+      pack = kw_cells<MASK>(L, mBytes, d, twoK, leftPrev, P);
+    }
+    acc[r >> 1] = (acc[r >> 1] << 16) | pack;
+    asm volatile("" : "+v"(acc[r >> 1]));  // the arrow word is built here, not sunk to the store after the eighth step
+    // the strip's last column, row rr of the strip: 64 rows per store
+    const int rr = d - 63;
+    if (!RAMP || (rr >= 0 && rr < nRows)) {
+      const int v63 = __builtin_amdgcn_readlane(L.pS[kKwC - 1], 63);
+      outB = lane == (rr & 63) ? v63 : outB;
+      if ((rr & 63) == 63 || (RAMP && rr == nRows - 1)) {
+        if (lane <= (rr & 63)) bOut[(rr & ~63) + lane] = outB;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return make_uint4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+__global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
+  __shared__ int m[32];
+  if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x] * 4;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0 || !g.wide) return;
+  const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
+  uint4 *arrows = reinterpret_cast<uint4 *>(a.arrows + a.arrowOff[task]);
+  int32_t *bound = a.bound + a.boundOff[task];
+  const int k = g.k, qLen = g.qLen, tLen = g.tLen, twoK = 2 * g.k, bStride = g.qLen + 2;
+  const char *mBytes = reinterpret_cast<const char *>(m);
+  const KwPenalties P{a.hpInsOpen * 4 + 3, a.hpInsExtend * 4, a.insOpen * 4 + 2, a.insExtend * 4, a.del * 4 + 1};
+  const int del4 = a.del * 4;
+  KwLane L;
+  for (int s = 0; s < g.nStrips; s++) {
+    const int tA = 1 + s * kKwW;
+    const int qLo = max(1, tA - k), qHi = min(qLen, tA + kKwW - 1 + k);
+    const int nRows = qHi - qLo + 1, nSteps = nRows + 63;
+    const int32_t *bIn = bound + ((s + 1) & 1) * bStride;
+    int32_t *bOut = bound + (s & 1) * bStride;
+    const int t0 = tA + kKwC * lane;
+#pragma unroll
+    for (int c = 0; c < kKwC; c++) {
+      const int t = t0 + c;
+      L.tb[c] = (t <= tLen ? base_code((unsigned)tSeq[t - 1]) : 4) * 4;
+      // the row above the strip's first: row 0 (:147-150, :127-132) when the strip starts at row 1, otherwise a
+      // row whose cells of these columns lie above the band (never looked at: the masks)
+      L.pS[c] = qLo == 1 ? t * del4 : kKbInf;
+      L.pI[c] = kKbInf;
+      L.pH[c] = kKbInf;
+    }
+    L.eTop0 = t0 - k - qLo + lane;
+    int firstDiag;  // S(qLo - 1, tA - 1)
+    if (qLo == 1) firstDiag = (tA - 1) * del4;
+    else firstDiag = __hip_atomic_load(bIn + qLo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    L.leftIn = wave_shr1(L.pS[kKwC - 1], firstDiag);
+    L.info = 0;
+    int qBlock = 0, bBlock = 0, outB = 0;
+    uint4 *arrowStrip = arrows + (int64_t)s * g.stepsPad * 8;
+    const int fastFrom = tA - k - qLo + 63 + kKwW, fastTo = tA + k - qLo;  // no lane at an edge: fastFrom <= d < fastTo
+    for (int d0 = 0; d0 < nSteps; d0 += 8) {
+      if ((d0 & 63) == 0) {  // the next 64 rows entering at lane 0: query bases, the left neighbour's column
+        const int q = qLo + d0 + lane;
+        int info = 0, left = kKbInf;
+        if (q <= qLen) {
+          const int raw = qSeq[q - 1];
+          const int prev = q >= 2 ? (int)qSeq[q - 2] : -1;
+          info = base_code((unsigned)raw) * 20 | (raw == prev ? 0 : kKbInf);
+          left = s == 0 ? (q * a.insExtend + a.insOpen) * 4
+                        : __hip_atomic_load(bIn + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        qBlock = info;
+        bBlock = left;
+      }
+      const bool ramp = d0 < 63 || d0 + 7 >= nRows;
+      const bool fast = !ramp && d0 >= fastFrom && d0 + 7 < fastTo;
+      uint4 out;
+      if (ramp) out = kw_group<true, true>(L, mBytes, d0, lane, nRows, twoK, P, qBlock, bBlock, outB, bOut + qLo);
+      else if (fast) out = kw_group<false, false>(L, mBytes, d0, lane, nRows, twoK, P, qBlock, bBlock, outB, bOut + qLo);
+      else out = kw_group<false, true>(L, mBytes, d0, lane, nRows, twoK, P, qBlock, bBlock, outB, bOut + qLo);
+      arrowStrip[(int64_t)(d0 >> 3) * 64 + lane] = out;
+    }
+    // the next strip reads this one's last column
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s == g.nStrips - 1) {  // optScore = S(qLen, tLen) (:301-304, :344): the lanes stopped on the strip's last row
+      const int lStar = (tLen - tA) >> 2, cStar = (tLen - tA) & 3;
+      int v = L.pS[0];
+      v = cStar == 1 ? L.pS[1] : v;
+      v = cStar == 2 ? L.pS[2] : v;
+      v = cStar == 3 ? L.pS[3] : v;
+      if (lane == lStar) {
+        RefineResult res;
+        memset(&res, 0, sizeof(res));
+        res.dp_score = v >> 2;
+        res.n_cells = (int32_t)min(g.cells, (int64_t)0x7fffffff);
+        a.results[task] = res;
+      }
+    }
+  }
+}
+
+// One wavefront per task.  The walk of :299-391 in (q, t): from (qLen, tLen) (Global, :301-304), Diagonal -> (q-1, t-1),
+// Left -> (q, t-1), an insertion matrix -> (q-1, t) until its Open arrow.  Column 0 and row 0 hold no stored arrows:
+// (q, 0) is AffineInsClose then q insertions (:98-101, :143-146), (0, t) is t Left arrows (:147-150).
+// In a strip's [step / 8][lane] layout a move lowers the step by 0..2 and the lane by 0..1, about five steps per lane:
+// a window of 16 step-groups x 32 lanes (8 KB) anchored at the current cell holds the next ~25 lanes of the path.
+__global__ __launch_bounds__(256) void kband_wide_traceback_kernel(KbandArgs a) {
+  __shared__ uint4 win[4][16 * 32];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0 || !g.wide) return;
+  const uint4 *arr = reinterpret_cast<const uint4 *>(a.arrows + a.arrowOff[task]);
+  uint32_t *arena = a.arena + a.arenaOff[task];
+  const int k = g.k;
+  int q = g.qLen, t = g.tLen, mat = 0, status = 0;
+  int pos = (int)g.arenaWords, curType = -1, curLen = 0;
+  auto emit = [&](int type, int n) {
+    if (n <= 0) return;
+    if (type == curType) curLen += n;
+    else {
+      if (curLen) {
+        --pos;
+        if (lane == 0) arena[pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+      }
+      curType = type;
+      curLen = n;
+    }
+  };
+  int guard = 2 * (g.qLen + g.tLen) + 8;
+  const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win[wv]);
+  while (q > 0 && t > 0 && status == 0) {
+    const int s = (t - 1) >> 8, lTop = ((t - 1) & 255) >> 2;
+    const int qLo = max(1, 1 + s * kKwW - k);
+    const int rowTop = (q - qLo + lTop) >> 3;
+    const uint4 *strip = arr + (int64_t)s * g.stepsPad * 8;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int id = lane + 64 * i, row = rowTop - (id >> 5), ln = lTop - (id & 31);
+      if (row >= 0 && ln >= 0) win[wv][id] = strip[(int64_t)row * 64 + ln];
+    }
+    __builtin_amdgcn_wave_barrier();
+    while (q > 0 && t > 0) {
+      const int col = (t - 1) & 255;
+      if (((t - 1) >> 8) != s) break;
+      const int l = col >> 2, cc = col & 3, d = q - qLo + l;
+      const int wr = rowTop - (d >> 3), wl = lTop - l;
+      if (wr > 15 || wl > 31) break;
+      if (--guard < 0 || d < 0) {  // cannot happen for a filled matrix
+        status = TASK_BAD_PATH;
+        break;
+      }
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)w32[(wr * 32 + wl) * 4 + ((d & 7) >> 1)]);
+      const int nib = (int)(word >> ((((d & 1) ^ 1) << 4) + (3 - cc) * 4)) & 15;
+      if (mat == 0) {
+        const int ar = nib & 3;
+        if (ar == KB_DIAG) {
+          emit(BLASR_HIP_OP_M, 1);
+          q--;
+          t--;
+        } else if (ar == KB_LEFT) {
+          emit(BLASR_HIP_OP_D, 1);
+          t--;
+        } else
+          mat = ar == KB_INS_CLOSE ? 1 : 2;
+      } else {
+        if (nib & (mat == 1 ? KW_I_OPEN : KW_H_OPEN)) mat = 0;
+        emit(BLASR_HIP_OP_I, 1);
+        q--;
+      }
+    }
+  }
+  if (status == 0) {
+    if (t == 0) emit(BLASR_HIP_OP_I, q);
+    else emit(BLASR_HIP_OP_D, t);
+  }
+  if (curLen) {
+    --pos;
+    if (lane == 0) arena[pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
+  }
+  if (lane == 0) {
+    RefineResult res = a.results[task];
+    res.status = status;
+    res.n_ops = status ? 0 : (int32_t)(g.arenaWords - pos);
+    a.results[task] = res;
+    a.opsStart[task] = pos;
+  }
 }
 
 
@@ -520,8 +853,12 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   HIP_TRY(ctx, hipMalloc(&dScoreOff.p, sizeof(int64_t) * (size_t)n));
   HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, hostMatrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(dTotal.p, 0, sizeof(int64_t), st));
+  // bands from this many columns on take the strip kernel (any k); below it the band's rows live in LDS.
+  // BLASR_HIP_KBAND_WIDE_COLS moves the switch (tests run the small vectors through the strip kernel with it)
+  int wideFromCols = kKbMaxCols + 1;
+  if (const char *e = getenv("BLASR_HIP_KBAND_WIDE_COLS")) wideFromCols = std::max(3, atoi(e));
   hipLaunchKernelGGL(kband_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, b->q_len, b->t_len, b->k,
-                     static_cast<KbandGeo *>(dGeo.p));
+                     static_cast<KbandGeo *>(dGeo.p), wideFromCols, lp ? 1 : 0, (int)magnitude);
   std::vector<KbandGeo> geo((size_t)n);
   HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo.p, sizeof(KbandGeo) * (size_t)n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -531,15 +868,19 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   struct Chunk {
     int first, count;
     int64_t arrowBytes, arenaWords, scoreWords;
+    bool wide;
   };
   std::vector<Chunk> chunks;
   int64_t maxBytes = 0;
   for (int i = 0; i < n;) {
-    Chunk c{i, 0, 0, 0, 0};
+    Chunk c{i, 0, 0, 0, 0, false};
     while (i < n) {
-      const int64_t ab = (geo[i].cells + 255) & ~(int64_t)255, aw = (geo[i].arenaWords + 63) & ~(int64_t)63;
-      // KBandAlign also keeps the last row and the column of t = tLen for the choice of the end cell
-      const int64_t sw = lp ? (((int64_t)geo[i].nCols + 2 * ((int64_t)geo[i].qLen + 1) + 63) & ~(int64_t)63) : 0;
+      const int64_t ab = (geo[i].arrowBytes + 255) & ~(int64_t)255, aw = (geo[i].arenaWords + 63) & ~(int64_t)63;
+      // KBandAlign also keeps the last row and the column of t = tLen for the choice of the end cell; the strip
+      // kernel two columns of scores between strips (the same offsets array serves both)
+      const int64_t sw = lp ? (((int64_t)geo[i].nCols + 2 * ((int64_t)geo[i].qLen + 1) + 63) & ~(int64_t)63)
+                            : (geo[i].wide ? ((2 * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
+      if (geo[i].wide) c.wide = true;
       if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw + c.scoreWords + sw) > limit) break;
       if (ab + 4 * (aw + sw) > limit)
         return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "kband: task %d needs %lld bytes of workspace", i,
@@ -616,8 +957,15 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     a.arenaOff = static_cast<int64_t *>(dArenaOff.p);
     a.opsStart = static_cast<int32_t *>(dOpsStart.p);
     a.results = dResults;
+    a.bound = reinterpret_cast<int32_t *>(ctx->workspace + c.arrowBytes + 4 * c.arenaWords);
+    a.boundOff = static_cast<int64_t *>(dScoreOff.p);
     hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+    if (c.wide) {
+      HIP_TRY(ctx, hipMemsetAsync(a.bound, 0, (size_t)(4 * c.scoreWords), st));
+      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
+    if (c.wide) hipLaunchKernelGGL(kband_wide_traceback_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
     launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), st);
     launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, st);
   }

@@ -67,13 +67,68 @@ def test_kband_chunked_workspace_and_errors(ctx, oracle):
     res = small.kband(pairs, ks)
     for (q, t), r in zip(pairs, res):
         assert same(r, affine_kband_align(oracle, q, t, 40))
-    # band too wide for the LDS rows: per-candidate status, the others still run
+    # a band too wide for the LDS rows takes the strip kernel, in the same call as a narrow one
     res = small.kband(pairs[:2], [40, 600])
+    assert same(res[0], affine_kband_align(oracle, pairs[0][0], pairs[0][1], 40))
+    assert same(res[1], affine_kband_align(oracle, pairs[1][0], pairs[1][1], 600))
+    # k < 1: per-candidate status, the others still run
+    res = small.kband(pairs[:2], [40, 0])
     assert res[0]["status"] == 0 and res[1]["status"] == blasr_amd.hip.TASK_BAD_GUIDE
     with pytest.raises(blasr_amd.BlasrHipError) as e:
         small.kband(pairs[:1], [40], ops_capacity=1)
     assert e.value.code == blasr_amd.hip.ERR_CAPACITY
     small.close()
+
+
+@pytest.fixture
+def strip_kernel_for_every_band(monkeypatch):
+    """kband_api.hip reads the switch per call: every band, however narrow, goes through kband_wide_kernel."""
+    monkeypatch.setenv("BLASR_HIP_KBAND_WIDE_COLS", "3")
+
+
+def test_kband_strip_kernel_matches_golden(ctx, strip_kernel_for_every_band):
+    test_kband_matches_golden(ctx)
+
+
+def test_kband_strip_kernel_matches_oracle_random(ctx, oracle, strip_kernel_for_every_band):
+    test_kband_matches_oracle_random(ctx, oracle)
+    # shapes around the strip geometry: 256 columns per strip, 64 rows per boundary block, eight steps per store
+    from blasr_amd import synth
+    rng = np.random.default_rng(21)
+    pairs, ks = [], []
+    for ql, k in [(255, 10), (256, 10), (257, 10), (511, 70), (513, 64), (1024, 128), (1300, 400), (700, 1000), (64, 5),
+                  (1, 3), (2, 1), (5, 300), (320, 31), (3000, 150)]:
+        q, t = synth.make_pair(rng, ql, flank=(0, 0))
+        pairs.append((q, t))
+        ks.append(k)
+        pairs.append((q, t[: max(1, len(t) - min(k, len(t) // 2))]))  # SetKBoundedLengths cuts the query
+        ks.append(k)
+        pairs.append((q[: max(1, len(q) - min(k, len(q) // 2))], t))  # ... or the target
+        ks.append(k)
+    pairs.append((np.frombuffer(b"ACGTNNNNACGTTTTTTTTTTTTACGNACGT" * 20, dtype=np.uint8),
+                  np.frombuffer(b"ACGTNNNACGTTTTTTTTTTACGNNACGT" * 20, dtype=np.uint8)))
+    ks.append(90)
+    res = ctx.kband(pairs, ks)
+    for (q, t), k, r in zip(pairs, ks, res):
+        assert same(r, affine_kband_align(oracle, q, t, k)), (len(q), len(t), k)
+    # other penalties and an asymmetric matrix
+    m = np.array([[-7, 3, 4, 5, 1], [6, -6, 2, 7, 0], [5, 4, -5, 3, 2], [2, 6, 7, -8, 0], [1, 0, 2, 0, 1]], dtype=np.int32)
+    for indel in (3, 8):
+        res = ctx.kband(pairs[:12], ks[:12], matrix=m, indel=indel)
+        for (q, t), k, r in zip(pairs[:12], ks[:12], res):
+            assert same(r, affine_kband_align(oracle, q, t, k, matrix=m, indel=indel)), (len(q), len(t), k, indel)
+
+
+@pytest.mark.parametrize("read_len,k", [(10000, 1300), (30000, 2700)])
+def test_kband_at_the_widths_noUseGuidedAlign_gives(ctx, oracle, read_len, k):
+    """-noUseGuidedAlign: k = max(10, |drift| * 1.5) * 1.2 (Blasr.cpp:991-1001, :699) is ~1.3 k for 10 kb reads and
+    ~2.7 k for 30 kb reads at 15 % indels (configs[2] / configs[4]): 2k+1 columns, far beyond the LDS rows."""
+    from blasr_amd import synth
+    rng = np.random.default_rng(read_len)
+    q, t = synth.make_pair(rng, read_len, ins=0.10, dele=0.05, sub=0.01, flank=(0, 0))
+    r = ctx.kband([(q, t)], [k])[0]
+    want = affine_kband_align(oracle, q, t, k)
+    assert same(r, want), (len(q), len(t), k, r["status"], r["score"], want["score"])
 
 
 def same_linear(r, want):
