@@ -268,6 +268,12 @@ const char *blasr_hip_kernel_name(int kind, int ext0) {
       return "blasr_hip::fill_kernel";
     case BLASR_HIP_KERNEL_TRACEBACK:
       return "blasr_hip::traceback_kernel<8>";
+    case BLASR_HIP_KERNEL_KBAND_STRIPS:
+      return "blasr_hip::kband_wide_kernel";
+    case BLASR_HIP_KERNEL_KBAND_TRACEBACK:
+      return "blasr_hip::kband_wide_traceback_kernel";
+    case BLASR_HIP_KERNEL_KBAND_ROWS:
+      return "blasr_hip::kband_fill_kernel";
   }
   return "";
 }

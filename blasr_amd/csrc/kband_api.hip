@@ -47,6 +47,7 @@ struct KbandGeo {
   int64_t cells;       // (qLen + 1) * nCols
   int64_t arenaWords;  // worst-case op count
   int64_t arrowBytes;  // arrow storage: one byte per band cell, or (wide) nStrips * stepsPad * 128 nibble bytes
+  int64_t realCells;   // band cells inside the matrix: sum over q = 1..qLen of min(tLen, q + k) - max(1, q - k) + 1
   int32_t nStrips, stepsPad;  // wide only
 };
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *q
     g.qLen = g.tLen = 0;
     g.cells = 0;
     g.arenaWords = 0;
+    g.realCells = 0;
   } else {
     int64_t qLen = qLength, tLen = tLength;  // KBandAlign.h:43-55
     if (tLength < qLength) qLen = min(qLength, tLength + k);
@@ -83,6 +85,12 @@ __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *q
     g.cells = (qLen + 1) * (2 * k + 1);
     g.arenaWords = qLen + tLen + 2 * k + 4;
     g.arrowBytes = g.cells;
+    {  // sum of min(tLen, q + k) over q: q + k up to q = tLen - k, tLen after; sum of max(1, q - k): 1 up to q = k + 1
+      const int64_t a = max((int64_t)0, min(qLen, tLen - k)), b = min(qLen, k + 1);
+      const int64_t hi = a * k + a * (a + 1) / 2 + (qLen - a) * tLen;
+      const int64_t lo = b + (qLen - b) * (qLen + b + 1) / 2 - (qLen - b) * k;
+      g.realCells = hi - lo + qLen;
+    }
     if (g.wide) {
       // a strip's rows: q in [max(1, tA - k), min(qLen, tA + W - 1 + k)], 63 more steps for the lanes' skew
       g.nStrips = (int32_t)((tLen + kKwW - 1) / kKwW);
@@ -106,7 +114,7 @@ struct KbandArgs {
   const int64_t *arenaOff;
   int32_t *opsStart;
   RefineResult *results;
-  int32_t *bound;            // wide only: per task two columns of (qLen + 2) scores, a strip's last column
+  int32_t *bound;            // wide only: per task nw + 1 columns of (qLen + 2) scores, a strip's last column
   const int64_t *boundOff;
 };
 
@@ -399,12 +407,47 @@ __device__ __forceinline__ uint4 kw_group(KwLane &L, const char *mBytes, int d0,
   return make_uint4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-__global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
+// One workgroup per task, NW = blockDim.x / 64 wavefronts: wavefront w sweeps the strips s = w, w + NW, ... and strip
+// s + 1 follows strip s a few 64-row blocks behind (it needs S(q, last column of s) for the rows it enters).  The
+// columns cross in HBM (NW + 1 buffers per task: strip s writes buffer s mod (NW + 1), which its reader, strip s + 1,
+// has long left when strip s + NW + 1 -- the same wavefront as s + 1 -- writes it again); how far a strip has got is
+// published in LDS: {strip, rows of it stored}.  A wavefront only ever waits for a strip with a smaller number, so
+// the waits cannot form a cycle; all wavefronts of a workgroup are resident together.
+struct KwProgress {
+  int strip[16], rows[16];
+};
+__device__ __forceinline__ void kw_publish(KwProgress *pg, int w, int strip, int rows, bool newStrip) {
+  // the stores of the column (and everything before them) have reached L2 before the count moves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (newStrip) {  // rows first: a reader that still sees the old strip number just waits a little longer
+    __hip_atomic_store(&pg->rows[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&pg->strip[w], strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __hip_atomic_store(&pg->rows[w], rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+__device__ __forceinline__ void kw_wait(const KwProgress *pg, int w, int strip, int rows) {
+  for (;;) {
+    const int st = __hip_atomic_load(&pg->strip[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int rw = __hip_atomic_load(&pg->rows[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (st > strip || (st == strip && rw >= rows)) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(1024) void kband_wide_kernel(KbandArgs a) {
   __shared__ int m[32];
+  __shared__ KwProgress progress;
+  const int nw = (int)(blockDim.x >> 6);
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
   if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x] * 4;
+  if (threadIdx.x < 16) {
+    progress.strip[threadIdx.x] = (int)threadIdx.x - nw;  // "the strip before my first": nothing of strip w is there yet
+    progress.rows[threadIdx.x] = 0;
+  }
   __syncthreads();
-  const int wv = threadIdx.x >> 6, lane = lane_id();
-  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+  const int idx = (int)blockIdx.x;
   if (idx >= a.count) return;
   const int task = a.first + idx;
   const KbandGeo g = a.geo[task];
@@ -416,13 +459,17 @@ __global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
   const char *mBytes = reinterpret_cast<const char *>(m);
   const KwPenalties P{a.hpInsOpen * 4 + 3, a.hpInsExtend * 4, a.insOpen * 4 + 2, a.insExtend * 4, a.del * 4 + 1};
   const int del4 = a.del * 4;
+  const int wPrev = (w + nw - 1) % nw;  // the wavefront that sweeps the strip to the left of mine
   KwLane L;
-  for (int s = 0; s < g.nStrips; s++) {
+  for (int s = w; s < g.nStrips; s += nw) {
     const int tA = 1 + s * kKwW;
     const int qLo = max(1, tA - k), qHi = min(qLen, tA + kKwW - 1 + k);
     const int nRows = qHi - qLo + 1, nSteps = nRows + 63;
-    const int32_t *bIn = bound + ((s + 1) & 1) * bStride;
-    int32_t *bOut = bound + (s & 1) * bStride;
+    // the strip to the left: its first row, and how many rows it has in all
+    const int qLoPrev = max(1, tA - kKwW - k), nRowsPrev = min(qLen, tA - 1 + k) - qLoPrev + 1;
+    const int32_t *bIn = bound + (int64_t)((s + nw) % (nw + 1)) * bStride;  // = (s - 1) mod (nw + 1)
+    int32_t *bOut = bound + (int64_t)(s % (nw + 1)) * bStride;
+    kw_publish(&progress, w, s, 0, true);
     const int t0 = tA + kKwC * lane;
 #pragma unroll
     for (int c = 0; c < kKwC; c++) {
@@ -437,7 +484,10 @@ __global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
     L.eTop0 = t0 - k - qLo + lane;
     int firstDiag;  // S(qLo - 1, tA - 1)
     if (qLo == 1) firstDiag = (tA - 1) * del4;
-    else firstDiag = __hip_atomic_load(bIn + qLo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      kw_wait(&progress, wPrev, s - 1, min(nRowsPrev, qLo - qLoPrev));
+      firstDiag = __hip_atomic_load(bIn + qLo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     L.leftIn = wave_shr1(L.pS[kKwC - 1], firstDiag);
     L.info = 0;
     int qBlock = 0, bBlock = 0, outB = 0;
@@ -446,6 +496,7 @@ __global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
     for (int d0 = 0; d0 < nSteps; d0 += 8) {
       if ((d0 & 63) == 0) {  // the next 64 rows entering at lane 0: query bases, the left neighbour's column
         const int q = qLo + d0 + lane;
+        if (s > 0) kw_wait(&progress, wPrev, s - 1, min(nRowsPrev, qLo + d0 + 64 - qLoPrev));
         int info = 0, left = kKbInf;
         if (q <= qLen) {
           const int raw = qSeq[q - 1];
@@ -464,10 +515,11 @@ __global__ __launch_bounds__(256) void kband_wide_kernel(KbandArgs a) {
       else if (fast) out = kw_group<false, false>(L, mBytes, d0, lane, nRows, twoK, P, qBlock, bBlock, outB, bOut + qLo);
       else out = kw_group<false, true>(L, mBytes, d0, lane, nRows, twoK, P, qBlock, bBlock, outB, bOut + qLo);
       arrowStrip[(int64_t)(d0 >> 3) * 64 + lane] = out;
+      // rows of the last column stored so far: through step d0 + 7, i.e. row d0 + 7 - 63 of the strip, in whole blocks
+      const int stored = min(nRows, (d0 + 8 - 63) & ~63);
+      if (d0 + 8 >= nSteps) kw_publish(&progress, w, s, nRows, false);
+      else if (stored > 0 && ((d0 + 8 - 63) & 63) < 8) kw_publish(&progress, w, s, stored, false);
     }
-    // the next strip reads this one's last column
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (s == g.nStrips - 1) {  // optScore = S(qLen, tLen) (:301-304, :344): the lanes stopped on the strip's last row
       const int lStar = (tLen - tA) >> 2, cStar = (tLen - tA) & 3;
       int v = L.pS[0];
@@ -864,6 +916,24 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   HIP_TRY(ctx, hipStreamSynchronize(st));
   // chunks of tasks whose arrow matrices + op arenas fit the workspace
   const int64_t limit = std::max<int64_t>(ctx->workspaceLimit, 1 << 20);
+  // wavefronts per task of the strip kernel: what fits the workspace at once should still put ~8 wavefronts on
+  // every CU (one 30 kb read at k = 2.7 k holds 86 MB of arrows)
+  int nw = 1;
+  {
+    int64_t nWide = 0, wideBytes = 0;
+    int maxStrips = 1;
+    for (int i = 0; i < n; i++)
+      if (geo[i].status == 0 && geo[i].wide) {
+        nWide++;
+        wideBytes += geo[i].arrowBytes;
+        maxStrips = std::max(maxStrips, geo[i].nStrips);
+      }
+    if (nWide > 0) {
+      const int64_t atOnce = std::max<int64_t>(1, std::min(nWide, limit / std::max<int64_t>(1, wideBytes / nWide)));
+      while (nw < 16 && atOnce * nw < 2048 && nw * 2 <= maxStrips) nw *= 2;
+      if (const char *e = getenv("BLASR_HIP_KBAND_WAVES")) nw = std::min(16, std::max(1, atoi(e)));
+    }
+  }
   std::vector<int64_t> arrowOff((size_t)n), arenaOff((size_t)n), scoreOff((size_t)n);
   struct Chunk {
     int first, count;
@@ -877,9 +947,9 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     while (i < n) {
       const int64_t ab = (geo[i].arrowBytes + 255) & ~(int64_t)255, aw = (geo[i].arenaWords + 63) & ~(int64_t)63;
       // KBandAlign also keeps the last row and the column of t = tLen for the choice of the end cell; the strip
-      // kernel two columns of scores between strips (the same offsets array serves both)
+      // kernel nw + 1 columns of scores between strips (the same offsets array serves both)
       const int64_t sw = lp ? (((int64_t)geo[i].nCols + 2 * ((int64_t)geo[i].qLen + 1) + 63) & ~(int64_t)63)
-                            : (geo[i].wide ? ((2 * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
+                            : (geo[i].wide ? (((nw + 1) * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
       if (geo[i].wide) c.wide = true;
       if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw + c.scoreWords + sw) > limit) break;
       if (ab + 4 * (aw + sw) > limit)
@@ -908,6 +978,24 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   HIP_TRY(ctx, hipMemcpyAsync(dArenaOff.p, arenaOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dScoreOff.p, scoreOff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
   RefineResult *dResults = reinterpret_cast<RefineResult *>(results);
+  for (int kd = 0; kd < BLASR_HIP_KERNEL_KINDS; kd++) {
+    ctx->kernelRec[kd] = blasr_hip_kernel_record();
+    ctx->kernelRec[kd].kind = kd;
+  }
+  for (int i = 0; i < n && !lp; i++) {
+    if (geo[i].status != 0) continue;
+    blasr_hip_kernel_record &r = ctx->kernelRec[geo[i].wide ? BLASR_HIP_KERNEL_KBAND_STRIPS : BLASR_HIP_KERNEL_KBAND_ROWS];
+    r.cells += geo[i].realCells;
+    r.candidates += 1;
+    r.algorithmic_bytes += (geo[i].wide ? geo[i].realCells / 2 : geo[i].realCells) + geo[i].qLen + geo[i].tLen;
+    if (geo[i].wide) {  // the walk: one nibble per step read (as whole 16-byte groups: a window's worth is the traffic)
+      blasr_hip_kernel_record &tb = ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK];
+      tb.cells += geo[i].realCells;
+      tb.candidates += 1;
+      tb.algorithmic_bytes += (int64_t)geo[i].qLen + geo[i].tLen;
+    }
+  }
+  hipEvent_t *ev = ctx->events;  // the context's own (one call at a time per context)
   for (const Chunk &c : chunks) {
     if (lp) {
       KbandLinearArgs a;
@@ -959,15 +1047,41 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     a.results = dResults;
     a.bound = reinterpret_cast<int32_t *>(ctx->workspace + c.arrowBytes + 4 * c.arenaWords);
     a.boundOff = static_cast<int64_t *>(dScoreOff.p);
+    HIP_TRY(ctx, hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipEventRecord(ev[1], st));
     if (c.wide) {
       HIP_TRY(ctx, hipMemsetAsync(a.bound, 0, (size_t)(4 * c.scoreWords), st));
-      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+      HIP_TRY(ctx, hipEventRecord(ev[2], st));
+      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)c.count), dim3((unsigned)(64 * nw)), 0, st, a);
+      HIP_TRY(ctx, hipEventRecord(ev[3], st));
     }
     hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
-    if (c.wide) hipLaunchKernelGGL(kband_wide_traceback_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+    if (c.wide) {
+      HIP_TRY(ctx, hipEventRecord(ev[4], st));
+      hipLaunchKernelGGL(kband_wide_traceback_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
+      HIP_TRY(ctx, hipEventRecord(ev[5], st));
+    }
     launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), st);
     launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // the kernels' times; the next chunk reuses the workspace
+    {
+      float t = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&t, ev[0], ev[1]));
+      if (ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].candidates > 0) {
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].ms += t;
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].launches += 1;
+      }
+      if (c.wide) {
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ev[2], ev[3]));
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ms += t;
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].launches += 1;
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ext0 = nw;  // wavefronts per task of these launches
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ev[4], ev[5]));
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].ms += t;
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].launches += 1;
+      }
+    }
   }
   int64_t total = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&total, dTotal.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -175,7 +175,13 @@ enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four 
        BLASR_HIP_KERNEL_FILL_HYBRID = 1, /* fillp_kernel<16, ext0, true>: candidates with wide rows */
        BLASR_HIP_KERNEL_FILL_WAVE = 2,   /* fill_kernel: one candidate per wavefront (compare-based variant) */
        BLASR_HIP_KERNEL_TRACEBACK = 3,   /* traceback_kernel */
-       BLASR_HIP_KERNEL_KINDS = 4 };
+       /* the k-band refiner (blasr_hip_kband_*): cells = the band cells inside the matrix, sum over the rows q of
+        * min(tLen, q + k) - max(1, q - k) + 1; algorithmic bytes = the arrows written (half a byte per cell in the
+        * strip kernel, one byte in the rows kernel) + the bases read */
+       BLASR_HIP_KERNEL_KBAND_STRIPS = 4,    /* kband_wide_kernel: bands of any width, strips of the (q, t) matrix */
+       BLASR_HIP_KERNEL_KBAND_TRACEBACK = 5, /* kband_wide_traceback_kernel */
+       BLASR_HIP_KERNEL_KBAND_ROWS = 6,      /* kband_fill_kernel: band rows in LDS, 2k+1 <= 1088 */
+       BLASR_HIP_KERNEL_KINDS = 7 };
 typedef struct blasr_hip_kernel_record {
   int32_t kind;
   int32_t launches;
@@ -185,7 +191,8 @@ typedef struct blasr_hip_kernel_record {
   int64_t cells;
   int64_t candidates;
 } blasr_hip_kernel_record;
-/* Fills out[0..min(n, capacity)) with the kinds that ran; returns their number n (or a negative error code). */
+/* Fills out[0..min(n, capacity)) with the kinds that ran in the last refine or k-band call; returns their number n
+ * (or a negative error code). */
 int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_record *out, int capacity);
 const char *blasr_hip_kernel_name(int kind, int ext0);
 /* Identifies the BUILD of the library: a hash over its sources taken by the Makefile.  Profiles collected with
