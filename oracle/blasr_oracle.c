@@ -1906,6 +1906,86 @@ int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char 
 }
 
 /* ------------------------------------------------------------------------- */
+/* a-11: RefineAlignment's branch under -noUseGuidedAlign (alignment/Blasr.cpp:917-1046)               */
+/* ------------------------------------------------------------------------- */
+/* ComputeDrift (AlignmentUtils.h:586-618): largest absolute running sum of (tGap - qGap) between
+ * consecutive blocks (the "common gap" the two-block form subtracts from both cancels, :593-599). */
+int bo_compute_drift(const int *blocks, int nBlocks) {
+  int drift = 0, maxDrift = 0;
+  for (int b = 0; b + 1 < nBlocks; b++) {
+    const int *cur = blocks + 3 * b, *next = cur + 3;
+    int tGap = (int)((uint32_t)next[1] - ((uint32_t)cur[1] + (uint32_t)cur[2]));
+    int qGap = (int)((uint32_t)next[0] - ((uint32_t)cur[0] + (uint32_t)cur[2]));
+    int common = 0;
+    if (tGap > 0 && qGap > 0) common = abs(tGap - qGap);
+    tGap -= common;
+    qGap -= common;
+    drift += tGap - qGap;
+    if (abs(drift) > maxDrift) maxDrift = abs(drift);
+  }
+  return maxDrift;
+}
+
+/* The candidate of one window after the SDP step (q, t = the window's query / target, the SDP alignment's
+ * qPos / tPos / blocks) through RefineAlignment with useGuidedAlign == false, qIsSubstring == true (:968-972):
+ *   sequences trimmed to the SDP extent (:968-981), k = bandSize or |drift| * 1.5, at least 10 (:990-1003),
+ *   PairwiseLocalAlign (:675-746): AffineKBandAlign(SMRTDistanceMatrix, indel + 2, indel - 3, indel + 2, indel - 1,
+ *   indel, k * 1.2, Global), ComputeAlignmentStats(alignment, q, t, distScoreFn) in its non-affine form.
+ * The reference's distScoreFn has no score matrix at that point (:689-690, SURVEY a-11): its printed score is
+ * uninitialised memory.  stats[0] here is what the same formula gives with matrix25 in place; everything else the
+ * reference leaves in the candidate is well defined and returned as it is there.
+ * out[0..7] = drift, k (before the factor), k handed to AffineKBandAlign, its return value, nMatch, nMismatch, nIns, nDel;
+ * the candidate's qPos / tPos are 0 afterwards (:1019, :1022), its sequences the trimmed ones. */
+int bo_refine_nonguided(const unsigned char *q, const unsigned char *t, int sdpQPos, int sdpTPos, const int *sdpBlocks,
+                        int nSdpBlocks, const int *matrix25, int ins, int del, int indel, int bandSize, int *out,
+                        int *statsScore, float *pct, int *qTrimLen, int *tTrimLen, int *blocks, int blockCap,
+                        int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                        int *nGapItems) {
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  *statsScore = 0;
+  *pct = 0;
+  *qTrimLen = *tTrimLen = 0;
+  *nBlocks = 0;
+  if (nGapLists) *nGapLists = 0;
+  if (nGapItems) *nGapItems = 0;
+  const int drift = bo_compute_drift(sdpBlocks, nSdpBlocks);
+  out[0] = drift;
+  if (nSdpBlocks == 0) return 0; /* :959-962: score = 0, nothing else changes */
+  const int *last = sdpBlocks + 3 * (nSdpBlocks - 1);
+  const int qLen = last[0] + last[2];                 /* :968-972 (qIsSubstring) */
+  const int tLen = last[1] + last[2] - sdpBlocks[1];  /* :979-981 */
+  const unsigned char *qs = q + sdpQPos, *ts = t + sdpTPos;
+  int k;
+  if (bandSize == 0) k = (int)(abs(drift) * 1.5); /* :991-996 */
+  else k = bandSize;
+  if (k < 10) k = 10; /* :1001-1003 */
+  out[1] = k;
+  const int kk = (int)(k * 1.2); /* :699: the double product converted to AffineKBandAlign's int parameter */
+  out[2] = kk;
+  int m[5][5];
+  for (int i = 0; i < 5; i++)
+    for (int j = 0; j < 5; j++) m[i][j] = matrix25[i * 5 + j];
+  aln_t a;
+  aln_init(&a);
+  out[3] = affine_kband_align(qs, (uint32_t)qLen, ts, (uint32_t)tLen, m, indel + 2, indel - 3, indel + 2, indel - 1, indel,
+                              kk, &a);
+  score_fn fn;
+  make_score_fn(&fn, matrix25, ins, del, 0, 0);
+  compute_alignment_stats(&a, qs, ts, &fn, 0); /* :740 */
+  *statsScore = a.score;
+  out[4] = a.nMatch;
+  out[5] = a.nMismatch;
+  out[6] = a.nIns;
+  out[7] = a.nDel;
+  *pct = a.pct;
+  *qTrimLen = qLen;
+  *tTrimLen = tLen;
+  int rc = flatten(&a, blocks, blockCap, nBlocks, gapCounts, gapListCap, nGapLists, gapItems, gapItemCap, nGapItems);
+  aln_free(&a);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------- */
 /* a-11: KBandAlign with a DistanceMatrixScoreFunction (algorithms/alignment/KBandAlign.h:74-403) */
 /* ------------------------------------------------------------------------- */
 /* AlignmentType (AlignmentUtils.h:14-58): Global 1, QueryFit 2, TargetFit 3, ..., Fit 7.

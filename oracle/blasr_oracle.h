@@ -106,6 +106,15 @@ int bo_affine_kband_align(const unsigned char *q, int qlen, const unsigned char 
                           int *blocks, int blockCap, int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists,
                           int *gapItems, int gapItemCap, int *nGapItems);
 
+/* a-11: ComputeDrift (AlignmentUtils.h:586-618) and RefineAlignment's -noUseGuidedAlign branch (Blasr.cpp:917-1046 with
+ * PairwiseLocalAlign :675-746) for one candidate; see blasr_oracle.c for the outputs. */
+int bo_compute_drift(const int *blocks, int nBlocks);
+int bo_refine_nonguided(const unsigned char *q, const unsigned char *t, int sdpQPos, int sdpTPos, const int *sdpBlocks,
+                        int nSdpBlocks, const int *matrix25, int ins, int del, int indel, int bandSize, int *out,
+                        int *statsScore, float *pct, int *qTrimLen, int *tTrimLen, int *blocks, int blockCap,
+                        int *nBlocks, int *gapCounts, int gapListCap, int *nGapLists, int *gapItems, int gapItemCap,
+                        int *nGapItems);
+
 /* a-11: KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403); alignType Global 1, QueryFit 2,
  * TargetFit 3, Fit 7; out[3] = score, qPos, tPos. */
 int bo_kband_align(const unsigned char *q, int qlen, const unsigned char *t, int tlen, const int *matrix25, int ins,

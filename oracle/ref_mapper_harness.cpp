@@ -32,6 +32,39 @@ void ref_set_interval_matches(const unsigned *tql, int n, int refineBetweenAncho
   g_refineBetweenAnchorsOnly = refineBetweenAnchorsOnly;
 }
 
+// What RefineAlignment (Blasr.cpp:799-1047) leaves in the candidate when it runs with useGuidedAlign == false
+// (-noUseGuidedAlign: ComputeDrift, the trimming, the k rule, PairwiseLocalAlign -> AffineKBandAlign).  Thread-local
+// request for the entry point below: set, call ref_align_interval_ex, read.  out[12]: tAlignedSeqPos,
+// tAlignedSeqLength, qAlignedSeqPos, qAlignedSeqLength, qPos, tPos, nBlocks, nGapLists, nMatch, nMismatch, nIns, nDel
+// -- NOT the score: PairwiseLocalAlign's score function has no matrix (:689-690), the value is uninitialised memory.
+struct RefineRequest {
+  int enabled, bandSize;
+  int *out;
+  float *pct;
+  int *blocks, blocksCap, *gapCounts, gapListCap, *gapItems, gapItemCap, nGapItems;
+  int rc;
+};
+static __thread RefineRequest g_refine = {0, 0, NULL, NULL, NULL, 0, NULL, 0, NULL, 0, 0, 0};
+void ref_request_nonguided_refine(int bandSize, int *out, float *pct, int *blocks, int blocksCap, int *gapCounts,
+                                  int gapListCap, int *gapItems, int gapItemCap) {
+  g_refine.enabled = out != NULL;
+  g_refine.bandSize = bandSize;
+  g_refine.out = out;
+  g_refine.pct = pct;
+  g_refine.blocks = blocks;
+  g_refine.blocksCap = blocksCap;
+  g_refine.gapCounts = gapCounts;
+  g_refine.gapListCap = gapListCap;
+  g_refine.gapItems = gapItems;
+  g_refine.gapItemCap = gapItemCap;
+  g_refine.nGapItems = 0;
+  g_refine.rc = 0;
+}
+int ref_nonguided_refine_status(int *nGapItems) {
+  *nGapItems = g_refine.nGapItems;
+  return g_refine.rc;
+}
+
 // extendSwitches: NULL, or {extendAlignments, extendBandSize, maxExtendDropoff} (-extend, Blasr.cpp:1749-1940)
 int ref_align_interval_ex(const unsigned char *genomeSeq, unsigned genomeLen, const unsigned char *readSeq,
                           unsigned readLen, unsigned subreadStart, unsigned subreadEnd, unsigned ivStart,
@@ -124,6 +157,47 @@ int ref_align_interval_ex(const unsigned char *genomeSeq, unsigned genomeLen, co
       blocksOut[3 * b] = (int)a.blocks[b].qPos;
       blocksOut[3 * b + 1] = (int)a.blocks[b].tPos;
       blocksOut[3 * b + 2] = (int)a.blocks[b].length;
+    }
+  }
+  if (g_refine.enabled) {  // RefineAlignments :2164-2181 hands the forward read to RefineAlignment for every candidate
+    params.useGuidedAlign = false;
+    params.bandSize = g_refine.bandSize;
+    RefineAlignment(read, genome, a, params, buffers);
+    int *o = g_refine.out;
+    o[0] = (int)a.tAlignedSeqPos;
+    o[1] = (int)a.tAlignedSeqLength;
+    o[2] = (int)a.qAlignedSeqPos;
+    o[3] = (int)a.qAlignedSeqLength;
+    o[4] = (int)a.qPos;
+    o[5] = (int)a.tPos;
+    o[6] = (int)a.blocks.size();
+    o[7] = (int)a.gaps.size();
+    o[8] = a.nMatch;
+    o[9] = a.nMismatch;
+    o[10] = a.nIns;
+    o[11] = a.nDel;
+    *g_refine.pct = a.pctSimilarity;
+    size_t items = 0;
+    for (size_t g = 0; g < a.gaps.size(); g++) items += a.gaps[g].size();
+    if ((int)a.blocks.size() > g_refine.blocksCap || (int)a.gaps.size() > g_refine.gapListCap ||
+        (int)items > g_refine.gapItemCap)
+      g_refine.rc = -1;
+    else {
+      for (size_t b = 0; b < a.blocks.size(); b++) {
+        g_refine.blocks[3 * b] = (int)a.blocks[b].qPos;
+        g_refine.blocks[3 * b + 1] = (int)a.blocks[b].tPos;
+        g_refine.blocks[3 * b + 2] = (int)a.blocks[b].length;
+      }
+      int at = 0;
+      for (size_t g = 0; g < a.gaps.size(); g++) {
+        g_refine.gapCounts[g] = (int)a.gaps[g].size();
+        for (size_t i = 0; i < a.gaps[g].size(); i++) {
+          g_refine.gapItems[2 * at] = (int)a.gaps[g][i].seq;
+          g_refine.gapItems[2 * at + 1] = a.gaps[g][i].length;
+          at++;
+        }
+      }
+      g_refine.nGapItems = at;
     }
   }
   delete alignments[0];

@@ -138,6 +138,44 @@ class Checker:
                     gapCounts=gap_counts[: ngl.value].copy(),
                     gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
 
+    def compute_drift(self, blocks):
+        """ComputeDrift (AlignmentUtils.h:586-618)."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+        f = self.fn("compute_drift")
+        f.restype = C.c_int
+        return f(_p(blocks), len(blocks))
+
+    def refine_nonguided(self, q, t, sdp, sc=None, indel=5, band=0):
+        """RefineAlignment under -noUseGuidedAlign (Blasr.cpp:917-1046) for the candidate of one window: q / t = the
+        window's query / target, sdp = its SDP alignment (qPos, tPos, blocks).  Returns drift, k, kband (the k handed to
+        AffineKBandAlign), dpScore, score (ComputeAlignmentStats' non-affine form WITH the matrix in place -- the
+        reference's own value is uninitialised memory), counts, pct, qs / ts (the trimmed sequences), blocks, gap lists;
+        the candidate's qPos / tPos are 0 afterwards."""
+        sc = sc or ScoreParams()
+        q, t = _u8(q), _u8(t)
+        sb = np.ascontiguousarray(sdp["blocks"], dtype=np.int32).reshape(-1, 3)
+        cap = len(q) + len(t) + 16
+        blocks = np.zeros(3 * cap, dtype=np.int32)
+        gap_counts, gap_items = np.zeros(cap, dtype=np.int32), np.zeros(2 * cap, dtype=np.int32)
+        out = np.zeros(8, dtype=np.int32)
+        pct = C.c_float(0)
+        score, ql, tl, nb, ngl, ngi = (C.c_int(0) for _ in range(6))
+        f = self.fn("refine_nonguided")
+        f.restype = C.c_int
+        rc = f(_p(q, C.c_ubyte), _p(t, C.c_ubyte), int(sdp["qPos"]), int(sdp["tPos"]), _p(sb), len(sb), _p(sc.matrix), sc.ins,
+               sc.dele, int(indel), int(band), _p(out), C.byref(score), C.byref(pct), C.byref(ql), C.byref(tl), _p(blocks), cap,
+               C.byref(nb), _p(gap_counts), cap, C.byref(ngl), _p(gap_items), cap, C.byref(ngi))
+        assert rc == 0, rc
+        qs = q[int(sdp["qPos"]): int(sdp["qPos"]) + ql.value]
+        ts = t[int(sdp["tPos"]): int(sdp["tPos"]) + tl.value]
+        kk = int(out[2])
+        q_len = min(len(qs), len(ts) + kk) if len(ts) < len(qs) else len(qs)  # SetKBoundedLengths (KBandAlign.h:36-56)
+        return dict(drift=int(out[0]), k=int(out[1]), kband=kk, dpScore=int(out[3]), score=score.value, nMatch=int(out[4]),
+                    nMismatch=int(out[5]), nIns=int(out[6]), nDel=int(out[7]), pct=pct.value, qPos=0, tPos=0, qs=qs, ts=ts,
+                    nCells=(q_len + 1) * (2 * kk + 1) if len(sb) else 0,
+                    blocks=blocks[: 3 * nb.value].reshape(-1, 3).copy(), gapCounts=gap_counts[: ngl.value].copy(),
+                    gapItems=gap_items[: 2 * ngi.value].reshape(-1, 2).copy())
+
     def refine_candidate(self, q, t, sc=None, sp=None, band=16):
         """SDPAlign(Local) -> stats -> AffineGuidedAlign -> stats for one candidate window (oracle only)."""
         sc, sp = sc or ScoreParams(), sp or SdpParams()
@@ -208,6 +246,18 @@ def ops_from_alignment(res):
             for j in range(starts[b + 1], starts[b + 2]):
                 ops.append((1 if gi[j, 0] == GAP_TARGET else 2, int(gi[j, 1])))
     return ops
+
+
+def ops_with_leading_gaps(res):
+    """As ops_from_alignment, for an alignment that keeps its first gap list (AffineKBandAlign's: ArrowPathToAlignment
+    without RemoveAlignmentPrefixGaps; the gap run behind the last block is dropped there, Alignment.h:190-254)."""
+    ops = []
+    gc, gi = res["gapCounts"], res["gapItems"]
+    starts = np.concatenate([[0], np.cumsum(gc)])
+    if len(gc) and len(res["blocks"]):
+        for j in range(starts[0], starts[1]):
+            ops.append((1 if gi[j, 0] == GAP_TARGET else 2, int(gi[j, 1])))
+    return ops + ops_from_alignment(res)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -282,7 +332,8 @@ class MapperRef:
     def __init__(self):
         self.lib = C.CDLL(REFMAPPER_SO)
 
-    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11, extend=None, rbao_chain=None):
+    def align_interval(self, genome, read, subread, iv, contigs=None, rate=1.3, extend_ends=1, k=11, extend=None, rbao_chain=None,
+                       nonguided_band=None):
         """extend: None, or (extendBandSize, maxExtendDropoff) to run the reference's -extend step as well.
         rbao_chain: None, or the interval's chained anchors ((m, 3) uint32: t, q, l) to run AlignIntervals' -rbao branch
         (Blasr.cpp:1354-1712) on them instead of SDPAlign over the window."""
@@ -297,6 +348,12 @@ class MapperRef:
         tseq = np.zeros(cap, dtype=np.uint8)
         blocks = np.zeros(3 * (len(read) + 16), dtype=np.int32)
         sw = None if extend is None else np.array([1, int(extend[0]), int(extend[1])], np.int32)
+        if nonguided_band is not None:  # RefineAlignment with useGuidedAlign == false on the candidate afterwards
+            r_out, r_pct = np.zeros(12, np.int32), C.c_float(0)
+            r_cap = len(read) + 16
+            r_blocks, r_gc, r_gi = np.zeros(3 * r_cap, np.int32), np.zeros(r_cap, np.int32), np.zeros(2 * 2 * r_cap, np.int32)
+            self.lib.ref_request_nonguided_refine(int(nonguided_band), _p(r_out), C.byref(r_pct), _p(r_blocks), r_cap, _p(r_gc),
+                                                  r_cap, _p(r_gi), 2 * r_cap)
         rc = self.lib.ref_align_interval_ex(_p(genome, C.c_ubyte), len(genome), _p(read, C.c_ubyte), len(read),
                                             int(subread[0]), int(subread[1]), int(iv[0]), int(iv[1]), int(iv[2]),
                                             int(iv[3]), int(iv[4]), _pu(cs), 0 if cs is None else len(cs) - 1,
@@ -308,6 +365,17 @@ class MapperRef:
         win = dict(zip(WINDOW_FIELDS, (int(v) & 0xffffffff for v in out[:7])))
         sdp = dict(qPos=int(out[7]), tPos=int(out[8]), blocks=blocks[: 3 * int(out[9])].reshape(-1, 3).copy(),
                    score=int(out[10]), nMatch=int(out[11]), nMismatch=int(out[12]), nIns=int(out[13]), nDel=int(out[14]))
+        if nonguided_band is not None:
+            ngi = C.c_int(0)
+            assert self.lib.ref_nonguided_refine_status(C.byref(ngi)) == 0
+            self.lib.ref_request_nonguided_refine(0, None, None, None, 0, None, 0, None, 0)
+            o = [int(v) for v in r_out]
+            refined = dict(tAlignedSeqPos=o[0] & 0xffffffff, tAlignedSeqLength=o[1], qAlignedSeqPos=o[2], qAlignedSeqLength=o[3],
+                           qPos=o[4], tPos=o[5], nMatch=o[8], nMismatch=o[9], nIns=o[10], nDel=o[11], pct=r_pct.value,
+                           blocks=r_blocks[: 3 * o[6]].reshape(-1, 3).copy(), gapCounts=r_gc[: o[7]].copy(),
+                           gapItems=r_gi[: 2 * ngi.value].reshape(-1, 2).copy())
+            # (out[0..] were written before the refinement; tseq is the candidate's target afterwards: the trimmed one)
+            return win, tseq[: int(out[1])].copy(), sdp, refined
         return win, tseq[: int(out[1])].copy(), sdp
 
     def post_filter(self, op, score, t_pos, t_aligned_seq_pos, t_index, t_strand, pct, blocks, blk_off, n_blocks,
@@ -1189,3 +1257,21 @@ def ref_find_intervals(ref, ct_handle, genome, starts, read_len, s0, s1, fwd, rc
                                vp(pv), C.c_long(cap))
     assert k <= cap
     return out[: 5 * k].reshape(k, 5), pv[:k]
+
+
+def nonguided_golden_cases():
+    """tests/golden/nonguided_golden.npz (made by the reference's RefineAlignment with useGuidedAlign == false):
+    the genome and, per candidate, read / subread / interval / contigs / bandSize and what the reference left behind."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nonguided_golden.npz"))
+    cases = []
+    for i in range(int(g["n"])):
+        p = "c%d_" % i
+        par = [int(v) for v in g[p + "par"]]
+        f = [int(v) for v in g[p + "fields"]]
+        cases.append(dict(read=g[p + "read"], subread=(par[0], par[1]), iv=tuple(par[2:7]), band=par[7],
+                          contigs=g[p + "contigs"] if len(g[p + "contigs"]) else None,
+                          want=dict(tAlignedSeqPos=f[0], tAlignedSeqLength=f[1], qAlignedSeqPos=f[2], qAlignedSeqLength=f[3],
+                                    qPos=f[4], tPos=f[5], nMatch=f[6], nMismatch=f[7], nIns=f[8], nDel=f[9],
+                                    pct=np.float32(g[p + "pct"]), blocks=g[p + "blocks"], gapCounts=g[p + "gapCounts"],
+                                    gapItems=g[p + "gapItems"])))
+    return g["genome"], cases

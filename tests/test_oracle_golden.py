@@ -102,3 +102,23 @@ def test_oracle_extend_matches_golden(oracle):
         assert np.array_equal(r["gapItems"], g["e%d_gapItems" % i]), i
         seen.add((rev, len(r["blocks"]) > 0))
     assert seen == {(0, False), (0, True), (1, False), (1, True)}
+
+
+def test_oracle_nonguided_refine_matches_golden(oracle):
+    """a-11, the whole -noUseGuidedAlign branch of RefineAlignment (Blasr.cpp:917-1046): the oracle's restatement
+    against what the reference's own function left in 40 candidates (tests/golden/make_nonguided_golden.py)."""
+    from blasr_testlib import MapperOracle, nonguided_golden_cases
+    genome, cases = nonguided_golden_cases()
+    mo = MapperOracle()
+    for i, c in enumerate(cases):
+        win, tseq = mo.window(genome, len(c["read"]), c["subread"], c["iv"], c["contigs"])
+        q = c["read"][win["qAlignedSeqPos"]: win["qAlignedSeqPos"] + win["qAlignedSeqLength"]]
+        sdp = oracle.sdp_align(q, tseq)
+        got, w = oracle.refine_nonguided(q, tseq, sdp, band=c["band"]), c["want"]
+        assert w["tAlignedSeqPos"] == (win["tAlignedSeqPos"] + sdp["tPos"]) & 0xffffffff, i
+        assert w["qAlignedSeqPos"] == win["qAlignedSeqPos"] + sdp["qPos"], i
+        assert (w["tAlignedSeqLength"], w["qAlignedSeqLength"], w["qPos"], w["tPos"]) == (len(got["ts"]), len(got["qs"]), 0, 0), i
+        assert all(w[f] == got[f] for f in ("nMatch", "nMismatch", "nIns", "nDel")), i
+        assert w["pct"] == np.float32(got["pct"]), i
+        assert np.array_equal(w["blocks"], got["blocks"]) and np.array_equal(w["gapCounts"], got["gapCounts"]) and \
+            np.array_equal(w["gapItems"], got["gapItems"]), i

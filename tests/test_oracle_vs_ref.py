@@ -150,3 +150,41 @@ def test_epilogue_pieces_against_the_reference_printers():
                                lqs=c["low_quality_suffix"], subread_start=c["subread_start"],
                                subread_end=c["subread_end"], q_align_start=derived[0], q_align_end=derived[1])
         assert orc.sam_line(c, cig, clips, derived) == line, it
+
+
+def test_nonguided_refine_branch_against_the_reference_RefineAlignment(oracle):
+    """a-11, the whole branch: the reference's own RefineAlignment with useGuidedAlign == false (Blasr.cpp:917-1046:
+    ComputeDrift, the trimming, k = |drift| * 1.5 or bandSize, PairwiseLocalAlign -> AffineKBandAlign(k * 1.2)) on the
+    candidate its AlignIntervals built, against the oracle's restatement: the window's position and length fields, qPos /
+    tPos, blocks, gap lists, the four counts and the identity -- everything but the score, which the reference computes
+    with a matrix it never initialised (SURVEY a-11)."""
+    from blasr_testlib import MapperOracle, load_refmapper, random_interval_case
+    refm = load_refmapper()
+    if refm is None:
+        pytest.skip("oracle/_ref/libblasr_refmapper.so not built")
+    mo = MapperOracle()
+    rng = np.random.default_rng(31)
+    genome = synth.random_genome(60000, 5)
+    n_wide = 0
+    for it in range(36):
+        read, subread, iv, contigs = random_interval_case(rng, genome, it)
+        band = [0, 0, 20][it % 3]
+        win, tseq, sdp, want = refm.align_interval(genome, read, subread, iv, contigs, nonguided_band=band)
+        q = read[win["qAlignedSeqPos"]: win["qAlignedSeqPos"] + win["qAlignedSeqLength"]]
+        mine_sdp = oracle.sdp_align(q, tseq)
+        assert np.array_equal(mine_sdp["blocks"], sdp["blocks"])
+        if len(sdp["blocks"]) == 0:
+            continue
+        got = oracle.refine_nonguided(q, tseq, sdp, band=band)
+        assert got["k"] == (band if band else max(10, int(abs(oracle.compute_drift(sdp["blocks"])) * 1.5)))
+        n_wide += got["kband"] > 40
+        assert want["tAlignedSeqPos"] == (win["tAlignedSeqPos"] + sdp["tPos"]) & 0xffffffff
+        assert want["qAlignedSeqPos"] == win["qAlignedSeqPos"] + sdp["qPos"]
+        assert (want["tAlignedSeqLength"], want["qAlignedSeqLength"]) == (len(got["ts"]), len(got["qs"]))
+        assert (want["qPos"], want["tPos"]) == (0, 0)
+        for f in ("nMatch", "nMismatch", "nIns", "nDel"):
+            assert want[f] == got[f], (it, f)
+        assert np.float32(want["pct"]) == np.float32(got["pct"])
+        assert np.array_equal(want["blocks"], got["blocks"]), it
+        assert np.array_equal(want["gapCounts"], got["gapCounts"]) and np.array_equal(want["gapItems"], got["gapItems"]), it
+    assert n_wide >= 3
