@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void kband_plan_kernel(int n, const int32_t *q
   // them still compares as "no such cell"
   if (qLength <= 0 || tLength <= 0 || k < 1 || (!g.wide && 2 * k + 1 > kKbMaxCols) || k > (1 << 24) ||
       (qLength + tLength + 2) * (int64_t)max(magnitude, 1) >= (1 << 25)) {
-    g.status = TASK_BAD_GUIDE;
+    // nothing to align at all: the candidate had no blocks (the callers treat it as the reference does, Blasr.cpp:959-962)
+    g.status = (qLength == 0 && tLength == 0 && k >= 1) ? TASK_EMPTY_GUIDE : TASK_BAD_GUIDE;
     g.qLen = g.tLen = 0;
     g.cells = 0;
     g.arenaWords = 0;
@@ -241,7 +242,10 @@ __global__ __launch_bounds__(64) void kband_traceback_kernel(KbandArgs a) {
   int q = g.qLen, t = k - (g.qLen - g.tLen);
   int pos = (int)g.arenaWords;  // filled from the back, so the ops come out in forward order
   int curType = -1, curLen = 0, mat = 0, status = 0;
+  // the walk starts at the alignment's END: gap columns met before the first Diagonal arrow form the gap list behind
+  // the last block, which ArrowPathToAlignment empties (Alignment.h:246-250) -- they are not emitted
   auto emit = [&](int type) {
+    if (curType < 0 && type != BLASR_HIP_OP_M) return;
     if (type == curType) curLen++;
     else {
       if (curLen) arena[--pos] = ((uint32_t)curLen << 2) | (uint32_t)curType;
@@ -555,8 +559,8 @@ __global__ __launch_bounds__(256) void kband_wide_traceback_kernel(KbandArgs a) 
   const int k = g.k;
   int q = g.qLen, t = g.tLen, mat = 0, status = 0;
   int pos = (int)g.arenaWords, curType = -1, curLen = 0;
-  auto emit = [&](int type, int n) {
-    if (n <= 0) return;
+  auto emit = [&](int type, int n) {  // (gap columns before the first Diagonal arrow: the emptied last gap list)
+    if (n <= 0 || (curType < 0 && type != BLASR_HIP_OP_M)) return;
     if (type == curType) curLen += n;
     else {
       if (curLen) {
@@ -628,6 +632,84 @@ __global__ __launch_bounds__(256) void kband_wide_traceback_kernel(KbandArgs a) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ComputeAlignmentStats (AlignmentUtils.h:535-584) on a k-band result, as PairwiseLocalAlign calls it (Blasr.cpp:740):
+// the alignment keeps its first gap list (no RemoveAlignmentPrefixGaps), its columns are gaps[0], then blocks and gap
+// lists in turn (CreateAlignmentStrings :448-533); the op list ends with the last block.  One wavefront per task, lane =
+// op, prefix sums over the op list instead of the walk.  Score (ComputeAlignmentScore :60-124): the matrix over the
+// aligned columns, and per gap column ins / del (non-affine, the form of :740), or per maximal gap run the cheaper of
+// the linear cost of its last column's kind and open + length * extend (affine).
+// ---------------------------------------------------------------------------------------------
+struct KbandStatsArgs {
+  int n;
+  const uint8_t *seq;
+  const int64_t *qOff, *tOff;
+  RefineResult *results;
+  const uint32_t *ops;
+  const int32_t *matrix;
+  int ins, del, open, ext, useAffine;
+};
+
+__global__ __launch_bounds__(256) void kband_stats_kernel(KbandStatsArgs a) {
+  __shared__ int matrix[25];
+  if (threadIdx.x < 25) matrix[threadIdx.x] = a.matrix[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= a.n) return;
+  RefineResult res = a.results[task];
+  if (res.status != 0) return;
+  const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
+  const uint32_t *ops = a.ops + res.ops_off;
+  const int nOps = res.n_ops;
+  int qBase = res.q_pos, tBase = res.t_pos;
+  int matchSum = 0, nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0, gapScore = 0;
+  for (int c0 = 0; c0 < nOps; c0 += 64) {
+    const int i = c0 + lane;
+    const uint32_t op = i < nOps ? ops[i] : 0u;
+    const int ty = (int)(op & 3u), len = (int)(op >> 2);
+    const unsigned qAdv = ty != BLASR_HIP_OP_D ? (unsigned)len : 0u, tAdv = ty != BLASR_HIP_OP_I ? (unsigned)len : 0u;
+    const unsigned qIncl = wave_prefix_sum(qAdv), tIncl = wave_prefix_sum(tAdv);
+    if (ty == BLASR_HIP_OP_M) {
+      const uint8_t *qp = qSeq + qBase + (int)(qIncl - qAdv), *tp = tSeq + tBase + (int)(tIncl - tAdv);
+      for (int j = 0; j < len; j++) {
+        const int qc = base_code(qp[j]), tc = base_code(tp[j]);
+        matchSum += matrix[qc * 5 + tc];
+        if (qc == tc) nMatch++; else nMismatch++;
+      }
+    } else if (i < nOps) {
+      if (ty == BLASR_HIP_OP_I) nIns += len; else nDel += len;
+      if (!a.useAffine) {
+        gapScore += len * (ty == BLASR_HIP_OP_I ? a.ins : a.del);
+      } else if ((ops[i + 1] & 3u) == BLASR_HIP_OP_M) {  // last op of a maximal gap run (a block follows every run)
+        int runLen = len;
+        for (int b = i - 1; b >= 0 && (ops[b] & 3u) != BLASR_HIP_OP_M; b--) runLen += (int)(ops[b] >> 2);
+        const int linear = (ty == BLASR_HIP_OP_D ? a.del : a.ins) * runLen;
+        const int affine = runLen * a.ext + a.open;
+        gapScore += (linear < affine) ? linear : affine;
+      }
+    }
+    qBase += (int)__builtin_amdgcn_readlane((int)qIncl, 63);
+    tBase += (int)__builtin_amdgcn_readlane((int)tIncl, 63);
+  }
+  int score = matchSum + gapScore;
+  for (int off = 32; off > 0; off >>= 1) {
+    score += __shfl_xor(score, off);
+    nMatch += __shfl_xor(nMatch, off);
+    nMismatch += __shfl_xor(nMismatch, off);
+    nIns += __shfl_xor(nIns, off);
+    nDel += __shfl_xor(nDel, off);
+  }
+  if (lane == 0) {
+    res.score = score;
+    res.n_match = nMatch;
+    res.n_mismatch = nMismatch;
+    res.n_ins = nIns;
+    res.n_del = nDel;
+    a.results[task] = res;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // KBandAlign with a DistanceMatrixScoreFunction (KBandAlign.h:74-403): one matrix, linear gaps, alignment
@@ -1161,6 +1243,39 @@ int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, con
                          blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
   if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   return kband_run_host(ctx, b, p, nullptr, results, ops, ops_capacity, ops_used);
+}
+int blasr_hip_kband_stats_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_score_params *score,
+                                 int32_t use_affine, blasr_hip_refine_result *results, const uint32_t *ops) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !score || b->n < 0 || (b->n > 0 && (!b->seq || !b->q_off || !b->t_off || !results || !ops)))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband_stats: bad arguments");
+  if (b->n == 0) return BLASR_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  struct Dev {
+    void *p = nullptr;
+    ~Dev() {
+      if (p) (void)hipFree(p);
+    }
+  } dMatrix;
+  HIP_TRY(ctx, hipMalloc(&dMatrix.p, sizeof(int32_t) * 32));
+  HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, score->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, ctx->stream));
+  KbandStatsArgs a;
+  a.n = b->n;
+  a.seq = b->seq;
+  a.qOff = b->q_off;
+  a.tOff = b->t_off;
+  a.results = reinterpret_cast<RefineResult *>(results);
+  a.ops = ops;
+  a.matrix = static_cast<int32_t *>(dMatrix.p);
+  a.ins = score->ins;
+  a.del = score->del;
+  a.open = score->affine_open;
+  a.ext = score->affine_extend;
+  a.useAffine = use_affine != 0;
+  hipLaunchKernelGGL(kband_stats_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(256), 0, ctx->stream, a);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  return BLASR_HIP_OK;
 }
 int blasr_hip_kband_linear_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b,
                                   const blasr_hip_kband_linear_params *p, blasr_hip_refine_result *results,

@@ -31,9 +31,10 @@ namespace {
 // slots of blasr_hip_ctx::mapBuf
 enum {
   MB_SEQ = 0, MB_QOFF, MB_QLEN, MB_TOFF, MB_TLEN, MB_WIN, MB_SDPRES, MB_BLOCKS, MB_SEL, MB_REFRES, MB_OPS, MB_TRIM,
-  MB_FETCH_LIST, MB_FETCH_SEQ, MB_FETCH_OPS, MB_H_READS, MB_H_POOL, MB_H_IVS, MB_X_SEQ, MB_X_BLOCKS, MB_X_TMP, MB_X_OPS
+  MB_FETCH_LIST, MB_FETCH_SEQ, MB_FETCH_OPS, MB_H_READS, MB_H_POOL, MB_H_IVS, MB_X_SEQ, MB_X_BLOCKS, MB_X_TMP, MB_X_OPS,
+  MB_KBAND_K
 };
-static_assert(MB_X_OPS < blasr_hip_ctx::kMapBufs, "mapBuf slots");
+static_assert(MB_KBAND_K < blasr_hip_ctx::kMapBufs, "mapBuf slots");
 
 // Candidate i of the refine call = candidate sel[i] of the SDP batch, trimmed to its SDP extent
 // (tSeq.Copy(tAlignedSeq, tPos, last.tPos + last.length), qSeq.ReferenceSubstring(query, qAlignedSeqPos + qPos,
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void sdp_trim_kernel(int n, const int32_t *sel
                                                        const int64_t *tOff, const blasr_hip_sdp_result *res,
                                                        const int32_t *blocks, int64_t *qOff2, int32_t *qLen2,
                                                        int64_t *tOff2, int32_t *tLen2, int64_t *blkOff2,
-                                                       int32_t *nBlk2) {
+                                                       int32_t *nBlk2, int lessFirstT) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int src = sel ? sel[i] : i;
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void sdp_trim_kernel(int n, const int32_t *sel
     const int32_t *last = blocks + 3 * (r.blk_off + nb - 1);
     ql = last[0] + last[2];
     tl = last[1] + last[2];
+    if (lessFirstT) tl -= blocks[3 * r.blk_off + 1];  // the k-band branch: ... - blocks[0].tPos (Blasr.cpp:979-981)
   }
   qOff2[i] = qOff[src] + r.q_pos;
   tOff2[i] = tOff[src] + r.t_pos;
@@ -60,6 +62,28 @@ __global__ __launch_bounds__(256) void sdp_trim_kernel(int n, const int32_t *sel
   tLen2[i] = tl;
   blkOff2[i] = r.blk_off;
   nBlk2[i] = nb;
+}
+
+// The band of RefineAlignment's k-band branch (alignment/Blasr.cpp:943, :990-1003, :699): ComputeDrift over the SDP
+// blocks (AlignmentUtils.h:586-618: the largest absolute running sum of tGap - qGap between consecutive blocks), k =
+// bandSize or, when that is 0, |drift| * 1.5, at least 10; AffineKBandAlign then gets k * 1.2 -- both products in double
+// precision and cut to int, as the reference's conversions do.
+__global__ __launch_bounds__(256) void sdp_drift_band_kernel(int n, const int64_t *blkOff, const int32_t *nBlk,
+                                                             const int32_t *blocks, int bandSize, int32_t *kOut) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int nb = nBlk[i];
+  const int32_t *b = blocks + 3 * blkOff[i];
+  int drift = 0, maxDrift = 0;
+  for (int j = 0; j + 1 < nb; j++) {
+    const int tGap = (int)((uint32_t)b[3 * j + 4] - ((uint32_t)b[3 * j + 1] + (uint32_t)b[3 * j + 2]));
+    const int qGap = (int)((uint32_t)b[3 * j + 3] - ((uint32_t)b[3 * j] + (uint32_t)b[3 * j + 2]));
+    drift += tGap - qGap;  // (the common gap :593-597 subtracts from both cancels)
+    maxDrift = max(maxDrift, abs(drift));
+  }
+  int k = bandSize == 0 ? (int)(maxDrift * 1.5) : bandSize;
+  if (k < 10) k = 10;
+  kOut[i] = (int)(k * 1.2);
 }
 
 struct FetchSeg {
@@ -131,7 +155,7 @@ int blasr_hip_refine_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_bat
   int rc = carve_trim(ctx, n_sel, t);
   if (rc) return rc;
   hipLaunchKernelGGL(sdp_trim_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, ctx->stream, n_sel, sel,
-                     b->q_off, b->t_off, sdp_results, blocks, t.qOff, t.qLen, t.tOff, t.tLen, t.blkOff, t.nBlk);
+                     b->q_off, b->t_off, sdp_results, blocks, t.qOff, t.qLen, t.tOff, t.tLen, t.blkOff, t.nBlk, 0);
   blasr_hip_refine_batch rb;
   rb.n = n_sel;
   rb.seq = b->seq;
@@ -143,6 +167,50 @@ int blasr_hip_refine_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_bat
   rb.blk_off = t.blkOff;
   rb.n_blocks = t.nBlk;
   return blasr_hip_refine_device(ctx, &rb, band, score, results, ops, ops_capacity, ops_used);
+}
+
+int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b,
+                                    const blasr_hip_sdp_result *sdp_results, const int32_t *blocks, int32_t n_sel,
+                                    const int32_t *sel, int32_t band, int32_t indel, const blasr_hip_score_params *score,
+                                    blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
+                                    int64_t *ops_used) {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!b || !score || n_sel < 0 || band < 0 || ops_capacity < 0 || (!sel && n_sel != b->n))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband_from_sdp: bad argument");
+  if (ops_used) *ops_used = 0;
+  if (n_sel == 0) return BLASR_HIP_OK;
+  if (!b->seq || !b->q_off || !b->t_off || !sdp_results || !blocks || !results)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband_from_sdp: null pointer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TrimArrays t;
+  int rc = carve_trim(ctx, n_sel, t);
+  if (rc) return rc;
+  if ((rc = blasr_hip_ensure(ctx, ctx->mapBuf[MB_KBAND_K], sizeof(int32_t) * (size_t)n_sel))) return rc;
+  int32_t *k = (int32_t *)ctx->mapBuf[MB_KBAND_K].p;
+  const dim3 grid((unsigned)((n_sel + 255) / 256));
+  hipLaunchKernelGGL(sdp_trim_kernel, grid, dim3(256), 0, ctx->stream, n_sel, sel, b->q_off, b->t_off, sdp_results, blocks,
+                     t.qOff, t.qLen, t.tOff, t.tLen, t.blkOff, t.nBlk, 1);
+  hipLaunchKernelGGL(sdp_drift_band_kernel, grid, dim3(256), 0, ctx->stream, n_sel, t.blkOff, t.nBlk, blocks, band, k);
+  blasr_hip_kband_batch kb;
+  kb.n = n_sel;
+  kb.seq = b->seq;
+  kb.q_off = t.qOff;
+  kb.q_len = t.qLen;
+  kb.t_off = t.tOff;
+  kb.t_len = t.tLen;
+  kb.k = k;
+  blasr_hip_kband_params kp;  // PairwiseLocalAlign's call (:695-703)
+  memcpy(kp.matrix, score->matrix, sizeof(kp.matrix));
+  kp.hp_ins_open = indel + 2;
+  kp.hp_ins_extend = indel - 3;
+  kp.ins_open = indel + 2;
+  kp.ins_extend = indel - 1;
+  kp.del = indel;
+  int64_t used = 0;
+  rc = blasr_hip_kband_device(ctx, &kb, &kp, results, ops, ops_capacity, &used);
+  if (ops_used) *ops_used = used;
+  if (rc) return rc;
+  return blasr_hip_kband_stats_device(ctx, &kb, score, 0, results, ops);  // :740
 }
 
 int blasr_hip_map_default_params(blasr_hip_map_params *p) {
@@ -180,6 +248,7 @@ int blasr_hip_map_default_params(blasr_hip_map_params *p) {
   p->refine_between_anchors_only = 0;  // MappingParameters.h:298
   p->indel = 5;                        // :195
   p->sdp_bypass_threshold = 1000000.0f;  // :316
+  p->use_guided_align = 1;               // :310
   return BLASR_HIP_OK;
 }
 
@@ -463,10 +532,16 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
     for (int attempt = 0; attempt < 2; attempt++) {
       if ((rc = blasr_hip_ensure(ctx, mb[MB_OPS], sizeof(uint32_t) * (size_t)opsCap))) return rc;
       opsCap = (int64_t)(mb[MB_OPS].bytes / sizeof(uint32_t));
-      rc = blasr_hip_refine_from_sdp_device(ctx, &sb, (const blasr_hip_sdp_result *)mb[MB_SDPRES].p,
-                                            (const int32_t *)mb[MB_BLOCKS].p, (int32_t)ns, (const int32_t *)mb[MB_SEL].p,
-                                            prm->band, &prm->score, (blasr_hip_refine_result *)mb[MB_REFRES].p,
-                                            (uint32_t *)mb[MB_OPS].p, opsCap, &opsUsed);
+      if (prm->use_guided_align)
+        rc = blasr_hip_refine_from_sdp_device(ctx, &sb, (const blasr_hip_sdp_result *)mb[MB_SDPRES].p,
+                                              (const int32_t *)mb[MB_BLOCKS].p, (int32_t)ns, (const int32_t *)mb[MB_SEL].p,
+                                              prm->band, &prm->score, (blasr_hip_refine_result *)mb[MB_REFRES].p,
+                                              (uint32_t *)mb[MB_OPS].p, opsCap, &opsUsed);
+      else  // -noUseGuidedAlign: RefineAlignment's k-band branch (:917-1046)
+        rc = blasr_hip_kband_from_sdp_device(ctx, &sb, (const blasr_hip_sdp_result *)mb[MB_SDPRES].p,
+                                             (const int32_t *)mb[MB_BLOCKS].p, (int32_t)ns, (const int32_t *)mb[MB_SEL].p,
+                                             prm->band, prm->indel, &prm->score, (blasr_hip_refine_result *)mb[MB_REFRES].p,
+                                             (uint32_t *)mb[MB_OPS].p, opsCap, &opsUsed);
       if (rc != BLASR_HIP_ERR_CAPACITY) break;
       opsCap = opsUsed + 64;
     }
@@ -517,7 +592,10 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
         const int32_t j = ord[i];
         const size_t s = (size_t)(selFirst[r] + i);
         const blasr_hip_refine_result &rr = ref[s];
-        if (rr.status & BLASR_HIP_TASK_EMPTY_GUIDE) continue;  // the reference leaves such a candidate as it is (:845)
+        if (rr.status & BLASR_HIP_TASK_EMPTY_GUIDE) {  // no blocks: the guided branch leaves the candidate as it is
+          if (!prm->use_guided_align) cr[j].score = 0;  // (:845), the k-band branch sets its score to 0 (:959-962)
+          continue;
+        }
         if (rr.status != 0 && !tolerate) {
           badRead2.store(r);
           badCand2.store(byRead[(size_t)(f + j)]);

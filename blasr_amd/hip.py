@@ -49,6 +49,7 @@ EXPORTS = [
     "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains", "blasr_hip_find_intervals_device_chains",
     "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
     "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
+    "blasr_hip_kband_stats_device", "blasr_hip_kband_from_sdp_device",
 ]
 
 # include/blasr_hip.h: blasr_hip_kernel_record
@@ -202,7 +203,7 @@ class _MapParams(C.Structure):
                 ("min_pct_identity", C.c_float), ("sort_refined", C.c_int32), ("extend_alignments", C.c_int32),
                 ("extend_band_size", C.c_int32), ("max_extend_dropoff", C.c_int32),
                 ("refine_between_anchors_only", C.c_int32), ("indel", C.c_int32), ("sdp_bypass_threshold", C.c_float),
-                ("reserved", C.c_int32), ("iv_chains", C.c_void_p), ("iv_chain_off", C.c_void_p)]
+                ("use_guided_align", C.c_int32), ("iv_chains", C.c_void_p), ("iv_chain_off", C.c_void_p)]
 
 
 class _RbaoParams(C.Structure):

@@ -387,7 +387,8 @@ typedef struct blasr_hip_map_params {
   blasr_hip_window_params window;
   blasr_hip_sdp_params sdp;      /* as AlignIntervals passes them (:1716-1722) */
   blasr_hip_score_params score;  /* SMRTDistanceMatrix + InitializeScoreFunction (:807-809) */
-  int32_t band;                  /* params.bandSize (16) */
+  int32_t band;                  /* params.bandSize (16 once MakeSane has run with useGuidedAlign, MappingParameters.h:395-397;
+                                    0 under -noUseGuidedAlign unless -bandSize was given: k then follows the drift) */
   int32_t n_candidates;          /* params.nCandidates (10) */
   int32_t max_gap;               /* params.maxGap (0) */
   int32_t max_score;             /* params.maxScore (-200) */
@@ -402,7 +403,13 @@ typedef struct blasr_hip_map_params {
                                     (:1354-1712, blasr_hip_align_between_anchors_* below); needs iv_chains */
   int32_t indel;                 /* params.indel (5): AffineKBandAlign's penalties in AlignSubstring (:1067-1070) */
   float sdp_bypass_threshold;    /* params.sdpBypassThreshold (1000000.0) */
-  int32_t reserved;
+  int32_t use_guided_align;      /* params.useGuidedAlign (1).  0 = -noUseGuidedAlign: RefineAlignment's other branch
+                                    (alignment/Blasr.cpp:917-1046): ComputeDrift over the SDP blocks, k = band or, when band
+                                    is 0, |drift| * 1.5, at least 10; PairwiseLocalAlign (:675-746) = AffineKBandAlign with
+                                    k * 1.2 and the penalties of `indel`, then ComputeAlignmentStats in its non-affine form.
+                                    The hits' q_pos / t_pos are 0 and their ops keep the leading gap list.  Their score is
+                                    that formula with score.matrix in place (the reference's is uninitialised memory,
+                                    see blasr_hip_kband_stats_device) */
   const uint32_t *iv_chains;     /* HOST: WeightedInterval::matches of the intervals, (t, q, l) triplets as
                                     blasr_hip_find_intervals_chains hands them out; interval k's are
                                     iv_chains[3 * iv_chain_off[k] .. 3 * iv_chain_off[k + 1]) */
@@ -455,6 +462,16 @@ int blasr_hip_map_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hi
                              blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
                              blasr_hip_map_fetch *fetch);
 /* Defaults of MappingParameters.h (the values every field comment above names). */
+/* RefineAlignment's k-band branch (-noUseGuidedAlign, alignment/Blasr.cpp:917-1046) on the SDP stage's device records,
+ * the counterpart of blasr_hip_refine_from_sdp_device: candidate i = candidate sel[i] of the SDP batch trimmed to its SDP
+ * extent (:968-981), its band from ComputeDrift over its blocks (band = params.bandSize, 0: |drift| * 1.5; at least 10;
+ * times 1.2, :990-1003, :699), AffineKBandAlign with the penalties PairwiseLocalAlign derives from `indel` (:695-699),
+ * ComputeAlignmentStats in its non-affine form (:740, see blasr_hip_kband_stats_device).  All pointers device memory. */
+int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *batch,
+                                    const blasr_hip_sdp_result *sdp_results, const int32_t *blocks, int32_t n_sel,
+                                    const int32_t *sel, int32_t band, int32_t indel, const blasr_hip_score_params *score,
+                                    blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
+                                    int64_t *ops_used);
 int blasr_hip_map_default_params(blasr_hip_map_params *params);
 /* Wall time (ms) of the stages of the last map call: [0] windows, [1] SDP, [2] sort + first filter (host),
  * [3] refine, [4] sort + the two filters (host), [5] fetch; counters: [0] candidate intervals, [1] candidates
@@ -483,8 +500,10 @@ typedef struct blasr_hip_kband_params {
 } blasr_hip_kband_params;
 
 /* Candidate i: query / target as for the guided refiner (trimmed to the SDP extent, Blasr.cpp:968-981),
- * k[i] = the band half-width handed to AffineKBandAlign (k * 1.2 of :699; 2k+1 <= 1088 here, else the
- * candidate gets BLASR_HIP_TASK_BAD_GUIDE). */
+ * k[i] = the band half-width handed to AffineKBandAlign (k * 1.2 of :699), any k >= 1: bands up to 1088 columns
+ * keep their rows in LDS, wider ones (-noUseGuidedAlign gives k ~ 1.3 k for 10 kb reads and ~ 2.7 k for 30 kb ones)
+ * are swept as strips of the (q, t) matrix.  (rows + columns + 2) * the largest penalty must stay below 2^25, else the
+ * candidate gets BLASR_HIP_TASK_BAD_GUIDE. */
 typedef struct blasr_hip_kband_batch {
   int32_t n;
   const uint8_t *seq;
@@ -496,16 +515,25 @@ typedef struct blasr_hip_kband_batch {
 } blasr_hip_kband_batch;
 
 /* Results reuse blasr_hip_refine_result: dp_score = the function's return value, n_cells = (qLen+1)(2k+1),
- * q_pos = t_pos = 0, ops as for the guided refiner but WITHOUT RemoveAlignmentPrefixGaps (leading gap
- * ops form Alignment.gaps[0]; ArrowPathToAlignment drops a trailing gap run, Alignment.h:190-254).
- * The statistics fields are 0: the reference computes them with an uninitialised score matrix here
- * (Blasr.cpp:689-690), so they are not defined. */
+ * q_pos = t_pos = 0, ops as for the guided refiner but WITHOUT RemoveAlignmentPrefixGaps: leading gap ops form
+ * Alignment.gaps[0]; the op list ends with the last block (ArrowPathToAlignment empties the gap list behind it,
+ * Alignment.h:190-254).  The statistics fields are 0 until blasr_hip_kband_stats_device fills them. */
 int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
                            const blasr_hip_kband_params *params, blasr_hip_refine_result *results, uint32_t *ops,
                            int64_t ops_capacity, int64_t *ops_used);
 int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
                          const blasr_hip_kband_params *params, blasr_hip_refine_result *results, uint32_t *ops,
                          int64_t ops_capacity, int64_t *ops_used);
+
+/* ComputeAlignmentStats (algorithms/alignment/AlignmentUtils.h:535-584) on the results of blasr_hip_kband_device, as
+ * PairwiseLocalAlign calls it (alignment/Blasr.cpp:740; use_affine = 0 there): score, n_match, n_mismatch, n_ins,
+ * n_del of every result with status 0.  `ops` is the arena blasr_hip_kband_device compacted the op lists into
+ * (device memory, as `results`).  NB the reference makes this call with a score function whose 5x5 matrix was never
+ * initialised (Blasr.cpp:689-690; contrast :807-809): the score it prints under -noUseGuidedAlign is uninitialised
+ * memory.  Here `score` carries the matrix; the counts do not depend on it. */
+int blasr_hip_kband_stats_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *batch,
+                                 const blasr_hip_score_params *score, int32_t use_affine,
+                                 blasr_hip_refine_result *results, const uint32_t *ops);
 
 /* KBandAlign with a DistanceMatrixScoreFunction (algorithms/alignment/KBandAlign.h:74-403): the banded,
  * linear-gap aligner behind -doGlobalAlignment (alignment/Blasr.cpp:819-823, Global) and behind

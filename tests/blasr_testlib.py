@@ -958,7 +958,8 @@ def oracle_extend_candidate(oracle, genome, contigs, read, w, q, tseq, s, sc, ba
 
 
 def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=16, n_candidates=10, max_gap=0,
-                     max_score=-200, min_pct=0.0, sp=None, sc=None, extend=False, extend_band=10, extend_drops=10):
+                     max_score=-200, min_pct=0.0, sp=None, sc=None, extend=False, extend_band=10, extend_drops=10,
+                     guided=True, indel=5):
     """reads / intervals: the product's READ_DTYPE / INTERVAL_DTYPE arrays.  Returns, per read, the alignments
     MapRead keeps (best first) as dicts: interval, the hit record's fields, q / t (aligned sequences), ops."""
     sp, sc = sp or SdpParams(), sc or ScoreParams()
@@ -1016,7 +1017,11 @@ def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=1
                 continue
             qs = x["q"][x["sdp"]["qPos"]: x["sdp"]["qPos"] + bl[-1, 0] + bl[-1, 2]]
             ts = x["t"][x["sdp"]["tPos"]: x["sdp"]["tPos"] + bl[-1, 1] + bl[-1, 2]]
-            rr = oracle.affine_guided_align(qs, ts, bl, sc, band)
+            if guided:
+                rr = oracle.affine_guided_align(qs, ts, bl, sc, band)
+            else:  # -noUseGuidedAlign: RefineAlignment's k-band branch (Blasr.cpp:917-1046); `band` = params.bandSize
+                rr = oracle.refine_nonguided(x["q"], x["t"], x["sdp"], sc, indel, band)
+                qs, ts = rr["qs"], rr["ts"]
             x.update(refined=rr, qs=qs, ts=ts, score=rr["score"], pct=np.float32(rr["pct"]), t_pos=rr["tPos"],
                      t_aligned_seq_pos=x["win"]["tAlignedSeqPos"] + x["sdp"]["tPos"], blocks=rr["blocks"],
                      t_end=(int(rr["blocks"][-1, 1] + rr["blocks"][-1, 2]) if len(rr["blocks"]) else 0))
@@ -1034,7 +1039,8 @@ def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=1
                             score=x["score"],  # the refined score, or maxScore where the maxGap rule flagged it (:2041)
                             n_match=rr["nMatch"], n_mismatch=rr["nMismatch"], n_ins=rr["nIns"],
                             n_del=rr["nDel"], n_cells=rr["nCells"], pct_similarity=np.float32(rr["pct"]),
-                            q=x["qs"], t=x["ts"], ops=[(l << 2) | ty for ty, l in ops_from_alignment(rr)]))
+                            q=x["qs"], t=x["ts"],
+                            ops=[(l << 2) | ty for ty, l in (ops_from_alignment(rr) if guided else ops_with_leading_gaps(rr))]))
     return out
 
 

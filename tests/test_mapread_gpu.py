@@ -56,6 +56,54 @@ def test_map_reads_against_oracle_composition(oracle, kw):
     ctx.close()
 
 
+@pytest.mark.parametrize("kw", [dict(band=0), dict(band=0, n_candidates=2), dict(band=25), dict(band=0, indel=4, max_score=-1000)])
+def test_map_reads_without_guided_align_against_oracle_composition(oracle, kw):
+    """use_guided_align = 0 (-noUseGuidedAlign): RefineAlignment's k-band branch (Blasr.cpp:917-1046) inside the mapper --
+    ComputeDrift, the trimming, k from the drift or from bandSize, AffineKBandAlign(k * 1.2), the non-affine statistics --
+    against MapRead composed from the oracle's pieces; every field, sequence and op list of every hit."""
+    rng = np.random.default_rng(80)
+    genome, pool, reads, ivs = repeat_genome_case(rng, 40)
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome)
+    params = ctx.map_params(use_guided_align=0, **kw)
+    hits, off, seq, ops = ctx.map_reads(reads, pool, ivs, params=params)
+    want = oracle_map_reads(oracle, MapperOracle(), genome, None, pool, reads, ivs, band=params.band,
+                            n_candidates=params.n_candidates, max_score=params.max_score, guided=False, indel=params.indel)
+    check_hits(hits, off, seq, ops, want)
+    assert sum(len(w) for w in want) >= 30 and all(int(h["q_pos"]) == 0 and int(h["t_pos"]) == 0 for h in hits)
+    ctx.close()
+
+
+def test_map_reads_without_guided_align_matches_the_reference_RefineAlignment():
+    """The same branch against what the reference's OWN RefineAlignment (useGuidedAlign == false) left in 40 candidates
+    (tests/golden/nonguided_golden.npz): positions, lengths, blocks, gap lists, counts, identity.  (Not the score: the
+    reference computes it with a matrix it never initialised, SURVEY a-11.)"""
+    from blasr_testlib import nonguided_golden_cases
+    genome, cases = nonguided_golden_cases()
+    ctx = blasr_amd.Context(0)
+    n_wide = 0
+    for i, c in enumerate(cases):
+        ctx.upload_genome(genome, c["contigs"])
+        reads = np.zeros(1, dtype=blasr_amd.READ_DTYPE)
+        reads[0] = (0, len(c["read"]), c["subread"][0], c["subread"][1], 0)
+        ivs = np.zeros(1, dtype=blasr_amd.INTERVAL_DTYPE)
+        ivs[0] = (c["iv"][0], c["iv"][1], c["iv"][2], c["iv"][3], 0, c["iv"][4])
+        params = ctx.map_params(use_guided_align=0, band=c["band"], max_score=1 << 30, n_candidates=10)
+        hits, off, seq, ops = ctx.map_reads(reads, c["read"], ivs, params=params)
+        assert len(hits) == 1, i
+        h, w = hits[0], c["want"]
+        for f, g in (("t_aligned_seq_pos", "tAlignedSeqPos"), ("t_aligned_seq_length", "tAlignedSeqLength"),
+                     ("q_aligned_seq_pos", "qAlignedSeqPos"), ("q_aligned_seq_length", "qAlignedSeqLength"), ("q_pos", "qPos"),
+                     ("t_pos", "tPos"), ("n_match", "nMatch"), ("n_mismatch", "nMismatch"), ("n_ins", "nIns"), ("n_del", "nDel")):
+            assert int(h[f]) == w[g], (i, f, int(h[f]), w[g])
+        assert np.float32(h["pct_similarity"]) == w["pct"], i
+        blocks, gc, gi = hip.ops_to_alignment(ops[int(h["ops_off"]): int(h["ops_off"]) + int(h["n_ops"])])
+        assert np.array_equal(blocks, w["blocks"]) and np.array_equal(gc, w["gapCounts"]) and np.array_equal(gi, w["gapItems"]), i
+        n_wide += int(h["n_cells"]) > 200 * int(h["q_aligned_seq_length"])
+    assert n_wide >= 2  # bands of more than 200 columns occur
+    ctx.close()
+
+
 def test_map_reads_with_contigs_and_empty_inputs(oracle):
     rng = np.random.default_rng(78)
     genome, pool, reads, ivs = repeat_genome_case(rng, 20, genome_len=120000)
