@@ -76,11 +76,20 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the config's: 100000; 6250 for config 4)")
     ap.add_argument("--read-len", type=int, default=0, help="template bases per read (0 = the config's)")
     ap.add_argument("--band", type=int, default=16)
+    ap.add_argument("--no-guided", action="store_true",
+                    help="the reference's -noUseGuidedAlign: the survivors go through RefineAlignment's k-band branch "
+                         "(Blasr.cpp:917-1046: band from the SDP alignment's drift, AffineKBandAlign, ~1.3 k at 10 kb and "
+                         "~2.7 k at 30 kb reads) instead of AffineGuidedAlign -- configs[4]'s 'wide k-band' form")
+    ap.add_argument("--kband", type=int, default=0, help="with --no-guided: params.bandSize (0 = from the drift, the default)")
+    ap.add_argument("--other-configs", type=int, default=-1, metavar="STEPS",
+                    help="after the line's own workload, also run configs[1], configs[4] and configs[4] --no-guided for STEPS "
+                         "steps each (child processes, each with its own parity sample and CPU leg) and report them as "
+                         "`other_configs`.  -1 = 3 on the driver's default line (config 2, one GPU, default sizes), else 0")
     ap.add_argument("--families", type=int, default=-1, help="repeat families planted in the genome (-1 = the config's)")
     ap.add_argument("--spurious", type=float, default=-1.0, help="mean chance clusters per read (-1 = the config's)")
     ap.add_argument("--genome-len", type=int, default=0, help="override the genome length (single contig)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the host cores (0 = skip, -1 = auto)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (0 = min(8, cores))")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host threads of the CPU baseline (0 = all the host's cores)")
     ap.add_argument("--blasrmc-reads", type=int, default=-1,
                     help="reads mapped by the reference binary (oracle/_ref/blasrmc) as a second baseline (0 = skip)")
     ap.add_argument("--workspace-gb", type=float, default=200.0,
@@ -141,7 +150,7 @@ def workload_label(args, d, genome_len, n_contigs):
     names = {1: "configs[1]", 2: "configs[2]", 3: "configs[3] (1 M reads in all, this many per GPU: strong scaling)",
              4: "configs[4] (per-GPU share)"}
     return ("%s: %d synthetic %.0f kb reads per GPU (ins %.0f%%/del %.0f%%/sub %.0f%%) vs a %d-base synthetic genome "
-            "(%d contig%s%s), %d planted repeat families, %.2f chance clusters per read%s%s, -sdpTupleSize 11, band %d, "
+            "(%d contig%s%s), %d planted repeat families, %.2f chance clusters per read%s%s, -sdpTupleSize 11, %s, "
             "SMRT matrix, ins=del=5, open=50, ext=0, nCandidates 10; timed step = windows + SDP + sort/filter + refine "
             "+ sort/filters" % (
                 names[args.config], d["reads"], d["read_len"] / 1e3, d["ins"] * 100, d["dele"] * 100, d["sub"] * 100,
@@ -150,7 +159,9 @@ def workload_label(args, d, genome_len, n_contigs):
                 " (long: %.0f-%.0f%% of the read against %.0f-%.0f%% of its length of unrelated genome)"
                 % tuple(100 * x for x in d["spurious_span"]) if d["spurious_span"] else "",
                 ", intervals loosened by up to %.0f%% of the read per side" % (d["loose"] * 100) if d["loose"] else "",
-                args.band)) + (" (run with -extend: ExtendAlignmentForward / Reverse before the first filter)"
+                ("-noUseGuidedAlign (RefineAlignment's k-band branch: bandSize %d%s, AffineKBandAlign with indel 5)"
+                 % (args.kband, " = from the SDP alignment's drift" if args.kband == 0 else "")) if args.no_guided
+                else "band %d" % args.band)) + (" (run with -extend: ExtendAlignmentForward / Reverse before the first filter)"
                                if args.extend else "")
 
 
@@ -170,7 +181,7 @@ def launch_ranks(args):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baselines (checker code: never on the product path)
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, extend=False):
+def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, extend=False, guided=True):
     """The path for the first `n_reads` reads of the same workload on the host cores: every candidate interval
     through the reference's OWN SDPAlign + ComputeAlignmentStats, the survivors through its AffineGuidedAlign +
     ComputeAlignmentStats (oracle/_ref/libblasr_ref.so, built from the reference's sources where they lie: kind
@@ -196,7 +207,7 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, exte
         rd = reads[r: r + 1].copy()
         p = pool[int(rd["off"][0]): int(rd["off"][0]) + int(rd["length"][0])]
         rd["off"] = 0
-        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band, extend=extend)[0]
+        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band, extend=extend, guided=guided)[0]
 
     t0 = time.perf_counter()
     if cores <= 1:
@@ -220,9 +231,10 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, exte
                 want = x[f] if f != "interval" else int(glob[x[f]])
                 ok = ok and h[f] == want
         mismatches += not ok
-    what = ("the reference's own SDPAlign + %sAffineGuidedAlign + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
-            % ("ExtendAlignmentForward / Reverse + " if extend else "")
-            if ref is not None else "the oracle's restatement of SDP + %srefine" % ("extension + " if extend else ""))
+    refiner = "AffineGuidedAlign" if guided else "ComputeDrift / band rule + AffineKBandAlign (-noUseGuidedAlign)"
+    what = ("the reference's own SDPAlign + %s%s + ComputeAlignmentStats (oracle/_ref/libblasr_ref.so)"
+            % ("ExtendAlignmentForward / Reverse + " if extend else "", refiner)
+            if ref is not None else "the oracle's restatement of SDP + %s%s" % ("extension + " if extend else "", refiner))
     return dict(value=aligned / dt, unit="bases/s", cores=max(cores, 1), kind="reference" if ref is not None else "port",
                 sample="first %d reads of the same workload (%d candidate intervals) through %s, windows / sort / filters "
                        "through the oracle (%.1f s on %d host thread%s, %.1f ms/read per thread)"
@@ -362,6 +374,36 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     return out
 
 
+def other_configs(steps):
+    """configs[1], configs[4] and configs[4] under -noUseGuidedAlign, each through this same script as a child process
+    (fresh context, own inputs, own parity sample against the CPU checker), cut down to the figures of a bench line."""
+    runs = (("configs[1]", ["--config", "1"]), ("configs[4]", ["--config", "4"]),
+            ("configs[4] -noUseGuidedAlign (wide k-band)", ["--config", "4", "--no-guided"]))
+    res = {}
+    for name, flags in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "1",
+               "--from-reads", "0", "--blasrmc-reads", "0", "--other-configs", "0"] + flags
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        except subprocess.TimeoutExpired:
+            res[name] = {"error": "timed out after 900 s"}
+            continue
+        line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not line:
+            res[name] = {"error": "exit %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+            continue
+        o = json.loads(line[-1])
+        keep = ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "gcups_per_gpu", "stage_ms_per_step", "roofline",
+                "refine_rooflines", "sdp_rooflines", "cpu_baseline", "device_memory_held_gb", "build_id")
+        res[name] = {k: o[k] for k in keep if k in o}
+        res[name]["config"] = {k: o["config"][k] for k in ("workload", "reads_per_gpu", "read_len", "refiner",
+                                                           "candidate_intervals_per_gpu", "candidates_refined_per_gpu",
+                                                           "aligned_reads") if k in o["config"]}
+        res[name]["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
+    return res
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -374,6 +416,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     d = config_defaults(args)
+    default_line = (args.config == 2 and args.gpus == 1 and args.reads <= 0 and args.read_len <= 0 and args.genome_len <= 0 and
+                    not args.stub_device and not args.load_workload and not args.no_guided and not args.extend)
+    if args.other_configs < 0:
+        args.other_configs = 3 if default_line else 0
     if args.from_reads < 0:  # the whole-mapper leg rides along on the driver's default line only
         args.from_reads = 1 if (args.config == 2 and args.gpus == 1 and args.reads <= 0 and args.read_len <= 0 and
                                 args.genome_len <= 0 and not args.stub_device and not args.load_workload) else 0
@@ -477,7 +523,10 @@ def main():
         t0 = time.perf_counter()
         ctx.build_suffix_array(13, download=False)
         wl["index_build_s"] = round(time.perf_counter() - t0, 2)
-    params = ctx.map_params(band=args.band, extend_alignments=1 if args.extend else 0)
+    if args.no_guided:
+        params = ctx.map_params(band=args.kband, use_guided_align=0, extend_alignments=1 if args.extend else 0)
+    else:
+        params = ctx.map_params(band=args.band, extend_alignments=1 if args.extend else 0)
     hits = np.zeros(n_iv, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     acc = {}
@@ -533,7 +582,8 @@ def main():
 
         kinds = np.bincount(wl["kind"], minlength=3)
         out = {
-            "metric": "aligned bases/sec (refine path: windows + SDP chaining + guided banded affine DP + filters), GCUPS per GPU",
+            "metric": "aligned bases/sec (refine path: windows + SDP chaining + %s + filters), GCUPS per GPU"
+                      % ("k-band affine DP (-noUseGuidedAlign)" if args.no_guided else "guided banded affine DP"),
             "value": value,
             "unit": "bases/s",
             "n_gpus": world,
@@ -549,7 +599,8 @@ def main():
                     % (t_gen, G, d["families"], n_copies, n_reads, n_iv,
                        kinds[0], kinds[1], kinds[2]),
             "config": {"workload": workload_label(args, d, G, len(starts) - 1),
-                       "reads_per_gpu": n_reads, "read_len": d["read_len"], "band": args.band,
+                       "reads_per_gpu": n_reads, "read_len": d["read_len"], "band": args.kband if args.no_guided else args.band,
+                       "refiner": "AffineKBandAlign" if args.no_guided else "AffineGuidedAlign",
                        "candidate_intervals_per_gpu": n_iv, "candidates_refined_per_gpu": int(last["refined"]),
                        "reads": totals["reads"], "aligned_reads": totals["aligned_reads"], "hits_per_gpu": int(last["hits"])},
             "gcups_per_gpu": totals["dp_cells"] / world * K / elapsed / 1e9,
@@ -610,23 +661,46 @@ def main():
                                                    insts * VALU_CYCLES["slow"] / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3)]
                     rl["valu_wave_instructions_per_launch"] = insts
                 rl["pmc_profile"] = pmc_path
+            if name == "blasr_hip::kband_wide_kernel" and "valu_issue_frac" not in rl:
+                # no counters of this build at hand: the instruction count from the kernel's ISA instead (a
+                # step of four cells per lane is 86 wave64 instructions in the unmasked loop, 106 in the masked one, which
+                # ~15 % of the steps of a k = 1.3-2.7 k band take), each lane-step covering 4 x 64 cells
+                insts = a["cells"] / a["launches"] / 256.0 * (0.85 * 86 + 0.15 * 106)
+                rl["valu_issue_frac"] = insts * cyc / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3)
+                rl["valu_issue_frac_source"] = "instruction count of the ISA x cells (no PMC pass of this build)"
+                rl["valu_wave_instructions_per_launch"] = insts
+            # which roof binds: the larger of the two fractions (the contract's figures stay the HBM ones)
+            if rl.get("valu_issue_frac", 0.0) > rl["frac"]:
+                rl["bound"] = "valu"
             lines.append(rl)
         lines.sort(key=lambda r: -r["avg_launch_ms"] * r["launches_per_step"])
         if lines:
             out["roofline"] = dict(lines[0])
-            out["roofline"]["limiter"] = ("VALU issue (integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
-                                          "instruction, profiles/r02_valu_rate.txt): valu_issue_frac is the roof that binds, "
-                                          "the HBM fraction is what the contract asks for")
+            if out["roofline"]["bound"] == "valu":
+                out["roofline"]["limiter"] = ("VALU issue (integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
+                                              "instruction, profiles/r02_valu_rate.txt): valu_issue_frac is the roof that "
+                                              "binds; achieved / peak / frac are the HBM figures the contract asks for")
             out["roofline"]["fill_stage_gcups"] = acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0
             out["refine_rooflines"] = lines[1:]
         if world == 1:
-            cores = args.cpu_cores if args.cpu_cores > 0 else min(8, os.cpu_count() or 1)
-            ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, int(2400 * 10000 / d["read_len"]) // max(1, round(n_iv / n_reads)))
+            cores = args.cpu_cores if args.cpu_cores > 0 else (os.cpu_count() or 1)
+            # ~10-30 s of host work on `cores` threads: 4.95 ms per 10 kb candidate through SDP + guided refine on one
+            # core, 455 ms per 30 kb one; the k-band refiner takes 0.46 s (10 kb) to 4.4 s (30 kb) per read
+            if args.no_guided and args.cpu_cores <= 0:
+                # the reference's AffineKBandAlign keeps six 4-byte arrays of (q + 1)(2k + 1) cells per thread (3.9 GB for
+                # a 30 kb read at k = 2.7 k): no more threads than fit 64 GB of host memory
+                k_est = 0.09 * d["read_len"] if args.kband == 0 else 1.2 * args.kband
+                cores = max(1, min(cores, int(64e9 / (24.0 * d["read_len"] * (2 * k_est + 1)))))
+            per_read_s = (0.005 * (d["read_len"] / 1e4) ** 2.5 * max(1.0, n_iv / n_reads) +
+                          (0.46 * (d["read_len"] / 1e4) ** 2 if args.no_guided else 0.0))
+            ns = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(2400, int(20.0 * cores / per_read_s)))
             ns = min(ns, n_reads)
             if ns > 0:
-                out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.band, hits, hit_off, cores, args.extend)
+                out["cpu_baseline"] = cpu_baseline(wl, genome, starts, ns, args.kband if args.no_guided else args.band, hits,
+                                                   hit_off, cores, args.extend, guided=not args.no_guided)
             # >= 10 s of signal: 32 threads of the reference binary map ~7 M bases/s of these reads
-            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else min(n_reads, max(8, 80000000 // d["read_len"]))
+            nb = args.blasrmc_reads if args.blasrmc_reads >= 0 else (0 if args.no_guided else
+                                                                     min(n_reads, max(8, 80000000 // d["read_len"])))
             if nb > 0:
                 ncores = os.cpu_count() or 1
                 b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores), args.extend, device_index)
@@ -638,10 +712,19 @@ def main():
                 if "cpu_baseline_whole_blasr" in out and out["cpu_baseline_whole_blasr"].get("reads_per_s"):
                     out["end_to_end"]["vs_whole_blasr"] = (out["end_to_end"]["reads_per_s"] /
                                                            out["cpu_baseline_whole_blasr"]["reads_per_s"])
+        if args.other_configs > 0 and world == 1:
+            # the other single-GPU configurations on the same line: each as a child process of its own (this process's
+            # context and tensors are released first: configs[4] wants the workspace)
+            ctx.close()
+            ctx = None
+            del genome, wl, reads_t, iv_t
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(args.other_configs)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

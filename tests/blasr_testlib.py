@@ -154,6 +154,25 @@ class Checker:
         sc = sc or ScoreParams()
         q, t = _u8(q), _u8(t)
         sb = np.ascontiguousarray(sdp["blocks"], dtype=np.int32).reshape(-1, 3)
+        if not hasattr(self.lib, self.prefix + "refine_nonguided"):
+            # the reference build (oracle/_ref/libblasr_ref.so) exports its templates one by one: the branch composed
+            # from its own AffineKBandAlign and ComputeAlignmentStats, the drift and the band rule as Blasr.cpp:943-1003
+            if len(sb) == 0:
+                return dict(drift=0, k=0, kband=0, dpScore=0, score=0, nMatch=0, nMismatch=0, nIns=0, nDel=0, pct=0.0, qPos=0,
+                            tPos=0, qs=q[:0], ts=t[:0], nCells=0, blocks=sb, gapCounts=np.zeros(0, np.int32),
+                            gapItems=np.zeros((0, 2), np.int32))
+            gaps = (sb[1:, 1] - sb[:-1, 1] - sb[:-1, 2]).astype(np.int64) - (sb[1:, 0] - sb[:-1, 0] - sb[:-1, 2])
+            drift = int(np.abs(np.cumsum(gaps)).max()) if len(gaps) else 0
+            k = max(10, int(drift * 1.5) if band == 0 else band)
+            kk = int(k * 1.2)
+            qs = q[int(sdp["qPos"]): int(sdp["qPos"]) + int(sb[-1, 0] + sb[-1, 2])]
+            ts = t[int(sdp["tPos"]): int(sdp["tPos"]) + int(sb[-1, 1] + sb[-1, 2] - sb[0, 1])]
+            a = affine_kband_align(self, qs, ts, kk, matrix=sc.matrix, indel=indel)
+            st = self.compute_alignment_stats(qs, ts, 0, 0, a["blocks"], a["gapCounts"], a["gapItems"], sc=sc, affine=0)
+            q_len = min(len(qs), len(ts) + kk) if len(ts) < len(qs) else len(qs)
+            return dict(drift=drift, k=k, kband=kk, dpScore=a["score"], score=st["score"], nMatch=st["nMatch"],
+                        nMismatch=st["nMismatch"], nIns=st["nIns"], nDel=st["nDel"], pct=st["pct"], qPos=0, tPos=0, qs=qs, ts=ts,
+                        nCells=(q_len + 1) * (2 * kk + 1), blocks=a["blocks"], gapCounts=a["gapCounts"], gapItems=a["gapItems"])
         cap = len(q) + len(t) + 16
         blocks = np.zeros(3 * cap, dtype=np.int32)
         gap_counts, gap_items = np.zeros(cap, dtype=np.int32), np.zeros(2 * cap, dtype=np.int32)

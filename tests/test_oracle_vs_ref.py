@@ -188,3 +188,21 @@ def test_nonguided_refine_branch_against_the_reference_RefineAlignment(oracle):
         assert np.array_equal(want["blocks"], got["blocks"]), it
         assert np.array_equal(want["gapCounts"], got["gapCounts"]) and np.array_equal(want["gapItems"], got["gapItems"]), it
     assert n_wide >= 3
+
+
+def test_nonguided_branch_composed_from_the_reference_templates(oracle, ref):
+    """bench.py's CPU leg for --no-guided runs the branch with the reference's OWN AffineKBandAlign and
+    ComputeAlignmentStats templates (oracle/_ref/libblasr_ref.so; the drift and band rule in between are three lines):
+    that composition equals the oracle's single function, score included (both carry the matrix)."""
+    rng = np.random.default_rng(41)
+    keys = ("drift", "k", "kband", "dpScore", "score", "nMatch", "nMismatch", "nIns", "nDel", "nCells", "blocks", "gapCounts",
+            "gapItems", "qs", "ts")
+    for it in range(12):
+        q, t = synth.make_pair(rng, int(rng.integers(200, 3000)), ins=0.10, dele=0.05, flank=(0, int(rng.integers(0, 150))))
+        sdp = ref.sdp_align(q, t)
+        if len(sdp["blocks"]) == 0:
+            continue
+        band = [0, 0, 30][it % 3]
+        a, b = oracle.refine_nonguided(q, t, sdp, band=band), ref.refine_nonguided(q, t, sdp, band=band)
+        assert first_difference(a, b, keys) is None, (it, first_difference(a, b, keys))
+        assert np.float32(a["pct"]) == np.float32(b["pct"])
