@@ -117,6 +117,7 @@ struct KbandArgs {
   RefineResult *results;
   int32_t *bound;            // wide only: per task nw + 1 columns of (qLen + 2) scores, a strip's last column
   const int64_t *boundOff;
+  int64_t cellsPerWave;      // wide only: a task gets ceil(its cells / this) wavefronts, at most blockDim / 64
 };
 
 __global__ __launch_bounds__(256) void kband_fill_kernel(KbandArgs a) {
@@ -443,19 +444,23 @@ __device__ __forceinline__ void kw_wait(const KwProgress *pg, int w, int strip, 
 __global__ __launch_bounds__(1024) void kband_wide_kernel(KbandArgs a) {
   __shared__ int m[32];
   __shared__ KwProgress progress;
-  const int nw = (int)(blockDim.x >> 6);
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+  const int idx = (int)blockIdx.x;
+  if (idx >= a.count) return;
+  const int task = a.first + idx;
+  const KbandGeo g = a.geo[task];
+  if (g.status != 0 || !g.wide) return;
+  // wavefronts of this task: by its size, so that the launch's wavefronts all carry about the same number of cells (one
+  // outlier -- a candidate whose SDP alignment drifted far -- would otherwise run long after the others have finished)
+  const int nw = (int)min((int64_t)min((int)(blockDim.x >> 6), g.nStrips),
+                          max((int64_t)1, (g.realCells + a.cellsPerWave / 2) / a.cellsPerWave));
   if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x] * 4;
   if (threadIdx.x < 16) {
     progress.strip[threadIdx.x] = (int)threadIdx.x - nw;  // "the strip before my first": nothing of strip w is there yet
     progress.rows[threadIdx.x] = 0;
   }
   __syncthreads();
-  const int idx = (int)blockIdx.x;
-  if (idx >= a.count) return;
-  const int task = a.first + idx;
-  const KbandGeo g = a.geo[task];
-  if (g.status != 0 || !g.wide) return;
+  if (w >= nw) return;
   const uint8_t *qSeq = a.seq + a.qOff[task], *tSeq = a.seq + a.tOff[task];
   uint4 *arrows = reinterpret_cast<uint4 *>(a.arrows + a.arrowOff[task]);
   int32_t *bound = a.bound + a.boundOff[task];
@@ -987,9 +992,10 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   HIP_TRY(ctx, hipMalloc(&dScoreOff.p, sizeof(int64_t) * (size_t)n));
   HIP_TRY(ctx, hipMemcpyAsync(dMatrix.p, hostMatrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(dTotal.p, 0, sizeof(int64_t), st));
-  // bands from this many columns on take the strip kernel (any k); below it the band's rows live in LDS.
+  // bands from this many columns on take the strip kernel (any k); below it the band's rows live in LDS (which is also
+  // the only form KBandAlign's four alignment types exist in: their bands stay within kKbMaxCols).
   // BLASR_HIP_KBAND_WIDE_COLS moves the switch (tests run the small vectors through the strip kernel with it)
-  int wideFromCols = kKbMaxCols + 1;
+  int wideFromCols = 100;  // measured (tools/exp_kband_sweep.sh, 10 kb reads): 294 against 237 Gcells/s at k = 60, 1174 against 297 at k = 543
   if (const char *e = getenv("BLASR_HIP_KBAND_WIDE_COLS")) wideFromCols = std::max(3, atoi(e));
   hipLaunchKernelGGL(kband_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, b->q_len, b->t_len, b->k,
                      static_cast<KbandGeo *>(dGeo.p), wideFromCols, lp ? 1 : 0, (int)magnitude);
@@ -998,24 +1004,22 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   HIP_TRY(ctx, hipStreamSynchronize(st));
   // chunks of tasks whose arrow matrices + op arenas fit the workspace
   const int64_t limit = std::max<int64_t>(ctx->workspaceLimit, 1 << 20);
-  // wavefronts per task of the strip kernel: what fits the workspace at once should still put ~8 wavefronts on
-  // every CU (one 30 kb read at k = 2.7 k holds 86 MB of arrows)
-  int nw = 1;
+  // wavefronts per task of the strip kernel (one 30 kb read at k = 2.7 k holds 86 MB of arrows: what fits the workspace at
+  // once is far fewer tasks than the chip holds wavefronts).  The buffers are sized for the most a task can get; how many
+  // it does get is decided per chunk from the chunk's cells (cellsPerWave below).
+  int nwMax = 1;
   {
-    int64_t nWide = 0, wideBytes = 0;
+    int64_t nWide = 0;
     int maxStrips = 1;
     for (int i = 0; i < n; i++)
       if (geo[i].status == 0 && geo[i].wide) {
         nWide++;
-        wideBytes += geo[i].arrowBytes;
         maxStrips = std::max(maxStrips, geo[i].nStrips);
       }
-    if (nWide > 0) {
-      const int64_t atOnce = std::max<int64_t>(1, std::min(nWide, limit / std::max<int64_t>(1, wideBytes / nWide)));
-      while (nw < 16 && atOnce * nw < 2048 && nw * 2 <= maxStrips) nw *= 2;
-      if (const char *e = getenv("BLASR_HIP_KBAND_WAVES")) nw = std::min(16, std::max(1, atoi(e)));
-    }
+    if (nWide > 0) nwMax = std::min(16, maxStrips);
+    if (const char *e = getenv("BLASR_HIP_KBAND_WAVES")) nwMax = std::min(16, std::max(1, atoi(e)));
   }
+  const int nw = nwMax;
   std::vector<int64_t> arrowOff((size_t)n), arenaOff((size_t)n), scoreOff((size_t)n);
   struct Chunk {
     int first, count;
@@ -1129,13 +1133,26 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     a.results = dResults;
     a.bound = reinterpret_cast<int32_t *>(ctx->workspace + c.arrowBytes + 4 * c.arenaWords);
     a.boundOff = static_cast<int64_t *>(dScoreOff.p);
+    a.cellsPerWave = 1;
     HIP_TRY(ctx, hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
     HIP_TRY(ctx, hipEventRecord(ev[1], st));
     if (c.wide) {
+      // about kKwWaves wavefronts in all (83 registers: 5 per SIMD, 5120 on the chip), each with the same share of cells
+      int64_t chunkCells = 0, largest = 0;
+      for (int i = c.first; i < c.first + c.count; i++)
+        if (geo[i].status == 0 && geo[i].wide) {
+          chunkCells += geo[i].realCells;
+          largest = std::max(largest, geo[i].realCells);
+        }
+      int targetWaves = 4096;  // four per SIMD: 1.26 Tcells/s at 3072-4096, 0.98 at 5120 and beyond (1024 30 kb reads, k = 2.7 k)
+      if (const char *e = getenv("BLASR_HIP_KBAND_TARGET_WAVES")) targetWaves = std::max(1, atoi(e));
+      a.cellsPerWave = std::max<int64_t>(chunkCells / targetWaves, 1 << 20);
+      if (getenv("BLASR_HIP_KBAND_WAVES")) a.cellsPerWave = 1;  // experiments: every task gets nwMax wavefronts
+      const int nwLaunch = (int)std::min<int64_t>(nw, std::max<int64_t>(1, (largest + a.cellsPerWave / 2) / a.cellsPerWave));
       HIP_TRY(ctx, hipMemsetAsync(a.bound, 0, (size_t)(4 * c.scoreWords), st));
       HIP_TRY(ctx, hipEventRecord(ev[2], st));
-      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)c.count), dim3((unsigned)(64 * nw)), 0, st, a);
+      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)c.count), dim3((unsigned)(64 * nwLaunch)), 0, st, a);
       HIP_TRY(ctx, hipEventRecord(ev[3], st));
     }
     hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
@@ -1158,7 +1175,7 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
         HIP_TRY(ctx, hipEventElapsedTime(&t, ev[2], ev[3]));
         ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ms += t;
         ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].launches += 1;
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ext0 = nw;  // wavefronts per task of these launches
+        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ext0 = nw;  // most wavefronts a task could get
         HIP_TRY(ctx, hipEventElapsedTime(&t, ev[4], ev[5]));
         ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].ms += t;
         ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].launches += 1;

@@ -54,3 +54,28 @@ def test_configs4_generator_against_the_reference_functions():
     d = run_bench("--config", "4", "--reads", "60", "--cpu-sample", "60")
     assert "configs[4]" in d["config"]["workload"] and d["config"]["candidate_intervals_per_gpu"] >= 60 * 8
     check_line(d, 60)
+
+
+def test_configs1_generator_against_the_reference_functions():
+    """configs[1]: 10 kb reads against an E. coli-sized genome, one candidate per read (the narrow fill only)."""
+    d = run_bench("--config", "1", "--reads", "2000", "--cpu-sample", "2000")
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["candidate_intervals_per_gpu"] == 2000
+    cb = d["cpu_baseline"]
+    assert cb["parity_checked"] == 2000 and cb["parity_mismatches"] == 0, cb
+    assert d["config"]["aligned_reads"] == 2000 and d["roofline"]["bound"] in ("hbm", "valu")
+
+
+def test_configs4_wide_kband_form_against_the_reference_templates():
+    """configs[4] as `-noUseGuidedAlign` runs it ("wide k-band"): 30 kb reads, the survivors through RefineAlignment's k-band
+    branch (k ~ 2.7 k from the SDP alignment's drift) inside the timed step; every hit against the same branch run with the
+    reference's own AffineKBandAlign / ComputeAlignmentStats templates."""
+    d = run_bench("--config", "4", "--no-guided", "--reads", "24", "--cpu-sample", "12")
+    assert "-noUseGuidedAlign" in d["config"]["workload"] and d["config"]["refiner"] == "AffineKBandAlign"
+    cb = d["cpu_baseline"]
+    assert cb["parity_checked"] == 12 and cb["parity_mismatches"] == 0, cb
+    assert d["config"]["aligned_reads"] == 24
+    lines = [d["roofline"]] + d["refine_rooflines"]
+    assert d["roofline"]["kernel"] == "blasr_hip::kband_wide_kernel" and d["roofline"]["bound"] == "valu"
+    assert d["roofline"]["kernel_gcups"] > 0 and any(r["kernel"] == "blasr_hip::kband_wide_traceback_kernel" for r in lines)
+    # bands of the width the config is named for
+    assert d["roofline"]["algorithmic_bytes_per_launch"] / d["roofline"]["candidates_per_launch"] > 30000 * 2000 / 2

@@ -90,6 +90,22 @@ def test_kband_strip_kernel_matches_golden(ctx, strip_kernel_for_every_band):
     test_kband_matches_golden(ctx)
 
 
+@pytest.mark.parametrize("waves", [2, 3, 16])
+def test_kband_strip_kernel_with_several_wavefronts_per_task(ctx, oracle, strip_kernel_for_every_band, monkeypatch, waves):
+    """The strips of one task as a pipeline over `waves` wavefronts (normally chosen from the task's size): every task of
+    the small vectors gets that many, whether or not it has as many strips."""
+    monkeypatch.setenv("BLASR_HIP_KBAND_WAVES", str(waves))
+    test_kband_matches_golden(ctx)
+    from blasr_amd import synth
+    rng = np.random.default_rng(waves)
+    pairs, ks = [], []
+    for ql, k in [(700, 40), (1500, 100), (2600, 30), (4000, 300), (900, 700)]:
+        pairs.append(synth.make_pair(rng, ql, flank=(0, 0)))
+        ks.append(k)
+    for (q, t), k, r in zip(pairs, ks, ctx.kband(pairs, ks)):
+        assert same(r, affine_kband_align(oracle, q, t, k)), (len(q), len(t), k, waves)
+
+
 def test_kband_strip_kernel_matches_oracle_random(ctx, oracle, strip_kernel_for_every_band):
     test_kband_matches_oracle_random(ctx, oracle)
     # shapes around the strip geometry: 256 columns per strip, 64 rows per boundary block, eight steps per store
