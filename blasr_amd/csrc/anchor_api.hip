@@ -590,7 +590,7 @@ constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort c
 
 extern "C" {
 
-int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) {
+int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   p->min_match_length = 14;
   p->min_prefix_match_length = 8;
@@ -603,11 +603,11 @@ int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) {
   p->forward_only = 0;
   p->sorted = 1;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int64_t length,
                                   const uint32_t *start_pos_table, const uint32_t *end_pos_table,
-                                  int64_t lookup_table_length, int32_t lookup_prefix_length) {
+                                  int64_t lookup_table_length, int32_t lookup_prefix_length) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!index || length <= 0 || length >= (1ll << 32) || lookup_table_length < 0 || lookup_prefix_length < 0 ||
       lookup_prefix_length > 16 ||
@@ -638,21 +638,21 @@ int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int
   ctx->saTableLen = lookup_table_length;
   ctx->saPrefixLen = lookup_prefix_length;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
-int blasr_hip_anchor_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[4]) {
+int blasr_hip_anchor_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[4]) try {
   if (!ctx || !ms || !counters) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) {
     ms[i] = ctx->anchorMs[i];
     counters[i] = ctx->anchorCounters[i];
   }
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                                   const uint8_t *read_pool, const blasr_hip_anchor_params *params,
                                   blasr_hip_anchor *anchors, int64_t capacity, int64_t *n_anchors,
-                                  int64_t *list_off) {
+                                  int64_t *list_off) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n_reads < 0 || !params || !n_anchors || !list_off || capacity < 0 || (capacity > 0 && !anchors) ||
       (n_reads > 0 && (!reads || !read_pool)))
@@ -932,12 +932,12 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "anchor_reads: %lld anchors, capacity %lld", (long long)emitted,
                           (long long)capacity);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_anchor_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                                 const uint8_t *read_pool, int64_t read_pool_bytes,
                                 const blasr_hip_anchor_params *params, blasr_hip_anchor *anchors, int64_t capacity,
-                                int64_t *n_anchors, int64_t *list_off) {
+                                int64_t *n_anchors, int64_t *list_off) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (read_pool_bytes < 0 || (read_pool_bytes > 0 && !read_pool) || capacity < 0 || (capacity > 0 && !anchors))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads_host: bad arguments");
@@ -965,6 +965,6 @@ int blasr_hip_anchor_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr
   if (*n_anchors > 0)
     HIP_TRY(ctx, hipMemcpy(anchors, dAnchors, sizeof(blasr_hip_anchor) * (size_t)*n_anchors, hipMemcpyDeviceToHost));
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

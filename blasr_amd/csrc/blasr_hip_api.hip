@@ -28,7 +28,12 @@ int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx) ctx->lastError = buf;
+  if (ctx) {
+    try {
+      ctx->lastError = buf;
+    } catch (...) {  // (the message needs memory too; the code still goes back)
+    }
+  }
   return code;
 }
 #define fail blasr_hip_fail
@@ -130,16 +135,24 @@ extern "C" {
 
 int blasr_hip_abi_version(void) { return BLASR_HIP_ABI_VERSION; }
 
-int blasr_hip_create(int device, blasr_hip_ctx **out) {
+int blasr_hip_create(int device, blasr_hip_ctx **out) try {
   if (!out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   // The sweep of an SDP level runs its four kernels side by side on four streams (sdp_kernels.hip: launch_sdp_chain), and
-  // the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise): two of the four then share
-  // a queue and run one after the other (10 ms per configs[2] step).  Eight queues, unless the caller has decided; this
-  // only takes effect when the HIP runtime has not been initialised yet (hosts that initialise it first -- torch -- set
-  // the variable themselves: bench.py, blasr_amd/__init__.py).
-  static std::once_flag queuesOnce;  // (contexts are created from several mapping threads)
-  std::call_once(queuesOnce, []() { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+  // the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise, read once when the runtime
+  // starts): with four, two of the kernels share a queue and run one after the other (10 ms per configs[2] step).  The
+  // library does not touch the process environment: the HOST sets GPU_MAX_HW_QUEUES=8 before its first HIP call
+  // (INTEGRATION.md 4'; bench.py, blasr_amd/__init__.py, examples/map_fasta.cpp and the drop-in's main do).  Say so once
+  // where it was not done.
+  {
+    static std::once_flag queuesOnce;
+    std::call_once(queuesOnce, []() {
+      const char *q = getenv("GPU_MAX_HW_QUEUES");
+      if ((!q || atoi(q) < 8) && getenv("BLASR_HIP_SDP_TRACE"))
+        fprintf(stderr, "[blasr_hip] GPU_MAX_HW_QUEUES is %s: the SDP sweep's four kernels will share hardware queues "
+                        "(set it to 8 before the first HIP call)\n", q ? q : "unset");
+    });
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
     (void)hipGetLastError();
@@ -172,9 +185,9 @@ int blasr_hip_create(int device, blasr_hip_ctx **out) {
     }
   *out = ctx;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_destroy(blasr_hip_ctx *ctx) {
+int blasr_hip_destroy(blasr_hip_ctx *ctx) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) {
@@ -214,17 +227,17 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) {
   if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   delete ctx;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 const char *blasr_hip_last_error(const blasr_hip_ctx *ctx) { return ctx ? ctx->lastError.c_str() : "null context"; }
 
-int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes) {
+int blasr_hip_set_workspace_limit(blasr_hip_ctx *ctx, int64_t bytes) try {
   if (!ctx || bytes < (1 << 20)) return BLASR_HIP_ERR_INVALID;
   ctx->workspaceLimit = bytes;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
-int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
+int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) try {
   if (!ctx) return 0;
   int64_t total = (int64_t)ctx->workspaceBytes;
   for (const auto &b : ctx->mapBuf) total += (int64_t)b.bytes;
@@ -233,21 +246,21 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) {
   total += (int64_t)ctx->pipeAnchors.bytes + (int64_t)ctx->pipeIntervals.bytes;
   total += (ctx->saExt ? 6 : 4) * ctx->saLen + 8 * ctx->saTableLen;
   return total;
-}
+} BLASR_HIP_CATCH_CODE
 
 void *blasr_hip_stream(blasr_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *launches, int64_t *algorithmic_bytes,
-                                int64_t *cells) {
+                                int64_t *cells) try {
   if (!ctx || !ms || !launches || !algorithmic_bytes || !cells) return BLASR_HIP_ERR_INVALID;
   *ms = ctx->fill4Ms;
   *launches = ctx->fill4Launches;
   *algorithmic_bytes = ctx->fill4Bytes;
   *cells = ctx->fill4Cells;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_record *out, int capacity) {
+int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_record *out, int capacity) try {
   if (!ctx || (!out && capacity > 0) || capacity < 0) return BLASR_HIP_ERR_INVALID;
   int n = 0;
   for (int k = 0; k < BLASR_HIP_KERNEL_KINDS; k++) {
@@ -256,7 +269,7 @@ int blasr_hip_refine_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_kernel_rec
     n++;
   }
   return n;
-}
+} BLASR_HIP_CATCH_CODE
 
 const char *blasr_hip_kernel_name(int kind, int ext0) {
   switch (kind) {
@@ -283,16 +296,16 @@ const char *blasr_hip_kernel_name(int kind, int ext0) {
 #endif
 const char *blasr_hip_build_id(void) { return BLASR_HIP_BUILD_ID; }
 
-int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
+int blasr_hip_refine_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) ms[i] = ctx->ms[i];
   for (int i = 0; i < 3; i++) counters[i] = ctx->counters[i];
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b, int32_t band,
                             const blasr_hip_score_params *score, blasr_hip_refine_result *results,
-                            uint32_t *ops, int64_t opsCapacity, int64_t *opsUsed) {
+                            uint32_t *ops, int64_t opsCapacity, int64_t *opsUsed) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !score || b->n < 0 || band < 0 || opsCapacity < 0) return fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
   if (opsUsed) *opsUsed = 0;
@@ -871,11 +884,11 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     return fail(ctx, BLASR_HIP_ERR_CAPACITY, "ops arena too small: need %lld, have %lld", (long long)total,
                 (long long)opsCapacity);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b, int32_t band,
                           const blasr_hip_score_params *score, blasr_hip_refine_result *results, uint32_t *ops,
-                          int64_t opsCapacity, int64_t *opsUsed) {
+                          int64_t opsCapacity, int64_t *opsUsed) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !score || b->n < 0) return fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
   if (opsUsed) *opsUsed = 0;
@@ -931,6 +944,6 @@ int blasr_hip_refine_host(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b, i
   const int64_t copyOps = std::min(used, opsCapacity);
   if (copyOps > 0) HIP_TRY(ctx, hipMemcpy(ops, dOps.p, sizeof(uint32_t) * (size_t)copyOps, hipMemcpyDeviceToHost));
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

@@ -5,11 +5,15 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
+#include "abi_guard.h"
 
 // A grow-only device buffer owned by the context (freed in blasr_hip_destroy).
 struct DevBuf {

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/blasr_hip.h"
+#include "abi_guard.h"
 
 namespace {
 
@@ -49,7 +50,7 @@ extern "C" {
 
 int blasr_hip_ref_contig_location(uint32_t t_aligned_seq_pos, uint32_t t_aligned_seq_length, int32_t t_strand,
                                   const uint32_t *seq_start_pos, int32_t n_seq_pos, uint32_t genome_length,
-                                  int32_t *contig, uint32_t *contig_pos) {
+                                  int32_t *contig, uint32_t *contig_pos) try {
   if (!seq_start_pos || n_seq_pos < 1 || !contig || !contig_pos) return BLASR_HIP_ERR_INVALID;
   // SequenceIndexDatabase::SearchForIndex (SequenceIndexDatabase.h:108-118)
   auto search = [&](uint32_t pos) -> int {
@@ -73,12 +74,12 @@ int blasr_hip_ref_contig_location(uint32_t t_aligned_seq_pos, uint32_t t_aligned
     *contig_pos = t_aligned_seq_pos - reverseOffset;
   }
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_cigar(const uint8_t *q_aligned_seq, const uint8_t *t_aligned_seq, int32_t q_pos, int32_t t_pos,
                     const uint32_t *ops, int64_t n_ops, const int32_t *blocks, int64_t n_blocks,
                     const blasr_hip_cigar_params *p, char *cigar, int64_t cigar_cap, int64_t *cigar_len,
-                    uint32_t clips[4]) {
+                    uint32_t clips[4]) try {
   if (!q_aligned_seq || !t_aligned_seq || !p || !cigar_len || (!ops && !blocks)) return BLASR_HIP_ERR_INVALID;
   if ((ops && n_ops <= 0) || (!ops && n_blocks <= 0)) return BLASR_HIP_ERR_INVALID;  // the printers skip empty ones
   uint32_t prefixSoft = 0, suffixSoft = 0, prefixHard = 0, suffixHard = 0;
@@ -177,19 +178,19 @@ int blasr_hip_cigar(const uint8_t *q_aligned_seq, const uint8_t *t_aligned_seq, 
   if (!cigar || (int64_t)s.size() + 1 > cigar_cap) return BLASR_HIP_ERR_CAPACITY;
   memcpy(cigar, s.c_str(), s.size() + 1);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_alignment_is_printed(int32_t score, float pct_similarity, uint32_t t_aligned_seq_length, int32_t map_qv,
-                                   const blasr_hip_print_params *p) {
+                                   const blasr_hip_print_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   if (score > p->max_score) return 0;                                // :2958
   if (pct_similarity < p->min_pct_identity) return 0;                // :2964 (float against float)
   if (t_aligned_seq_length < (uint32_t)p->min_align_length) return 0;  // :2970 (DNALength against int: unsigned)
   if (map_qv < p->min_map_qv) return 0;                              // :2976
   return 1;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_m4_line(const blasr_hip_m4_fields *f, char *line, int64_t line_cap, int64_t *line_len) {
+int blasr_hip_m4_line(const blasr_hip_m4_fields *f, char *line, int64_t line_cap, int64_t *line_len) try {
   if (!f || !f->q_name || !f->t_name || !line_len) return BLASR_HIP_ERR_INVALID;
   // ostream << float prints like %g with six significant digits
   char buf[96];
@@ -202,7 +203,7 @@ int blasr_hip_m4_line(const blasr_hip_m4_fields *f, char *line, int64_t line_cap
   if (!line || (int64_t)s.size() + 1 > line_cap) return BLASR_HIP_ERR_CAPACITY;
   memcpy(line, s.c_str(), s.size() + 1);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"
 

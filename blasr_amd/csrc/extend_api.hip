@@ -796,7 +796,7 @@ int blasr_hip_extend_candidates(blasr_hip_ctx *ctx, int n, const blasr_hip_inter
 
 extern "C" {
 
-int blasr_hip_extend_default_params(blasr_hip_extend_params *p) {
+int blasr_hip_extend_default_params(blasr_hip_extend_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   memset(p, 0, sizeof(*p));
   static const int32_t smrt[25] = {-5, 6, 6, 6, 0, 6, -5, 6, 6, 0, 6, 6, -5, 6, 0, 6, 6, 6, -5, 0, 0, 0, 0, 0, 0};
@@ -807,15 +807,15 @@ int blasr_hip_extend_default_params(blasr_hip_extend_params *p) {
   p->min_extend_n_bases = 1;              // Blasr.cpp:1833
   p->max_n_drops = 10;                    // params.maxExtendDropoff (MappingParameters.h:270)
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_extend_device(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *b, const blasr_hip_extend_params *p,
-                            blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+                            blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) try {
   return extend_run(ctx, b, p, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_extend_host(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *b, const blasr_hip_extend_params *p,
-                          blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+                          blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !p || !ops_used || b->n < 0 || ops_capacity < 0 ||
       (b->n > 0 && (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !b->q_pos || !b->t_pos ||
@@ -869,6 +869,6 @@ int blasr_hip_extend_host(blasr_hip_ctx *ctx, const blasr_hip_extend_batch *b, c
   if (copyOps > 0) HIP_TRY(ctx, hipMemcpyAsync(ops, dOps.p, sizeof(uint32_t) * (size_t)copyOps, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/blasr_hip.h"
+#include "abi_guard.h"
 
 struct blasr_hip_fasta {
   std::vector<std::string> titles;
@@ -230,48 +231,48 @@ int parse_sam_reads(const char *p, size_t n, blasr_hip_fasta &out) {
 
 extern "C" {
 
-int blasr_hip_sam_reads_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+int blasr_hip_sam_reads_parse(const char *text, int64_t length, blasr_hip_fasta **out) try {
   if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
   blasr_hip_fasta *f = new blasr_hip_fasta();
   const int rc = parse_sam_reads(text, (size_t)length, *f);
   *out = f;  // (also on an error: the records before it and the message, blasr_hip_fasta_error)
   return rc;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_sam_reads_read(const char *path, blasr_hip_fasta **out) {
+int blasr_hip_sam_reads_read(const char *path, blasr_hip_fasta **out) try {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   std::vector<char> buf;
   if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
   return blasr_hip_sam_reads_parse(buf.data(), (int64_t)buf.size(), out);
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out) {
+int blasr_hip_fastq_read(const char *path, blasr_hip_fasta **out) try {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   std::vector<char> buf;
   if (!read_file(path, buf)) return BLASR_HIP_ERR_INVALID;
   return blasr_hip_fastq_parse(buf.data(), (int64_t)buf.size(), out);
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_fastq_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+int blasr_hip_fastq_parse(const char *text, int64_t length, blasr_hip_fasta **out) try {
   if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
   blasr_hip_fasta *f = new blasr_hip_fasta();
   const int rc = parse_fastq(text, (size_t)length, *f);
   *out = f;  // (also on an error: the records before it and the message, blasr_hip_fasta_error)
   return rc;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_fastq_quality(const blasr_hip_fasta *f, int64_t i, const uint8_t **qual, int64_t *qual_length) {
+int blasr_hip_fastq_quality(const blasr_hip_fasta *f, int64_t i, const uint8_t **qual, int64_t *qual_length) try {
   if (!f || i < 0 || i >= (int64_t)f->quals.size()) return BLASR_HIP_ERR_INVALID;
   if (qual) *qual = f->quals[(size_t)i].data();
   if (qual_length) *qual_length = (int64_t)f->quals[(size_t)i].size();
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-const char *blasr_hip_fasta_error(const blasr_hip_fasta *f) { return f ? f->error.c_str() : ""; }
+const char *blasr_hip_fasta_error(const blasr_hip_fasta *f) try { return f ? f->error.c_str() : ""; } BLASR_HIP_CATCH_NULL
 
-int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out) {
+int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out) try {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   std::vector<char> buf;
@@ -280,34 +281,34 @@ int blasr_hip_fasta_read(const char *path, blasr_hip_fasta **out) {
   parse_fasta(buf.data(), buf.size(), *f);
   *out = f;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_fasta_parse(const char *text, int64_t length, blasr_hip_fasta **out) {
+int blasr_hip_fasta_parse(const char *text, int64_t length, blasr_hip_fasta **out) try {
   if ((!text && length > 0) || length < 0 || !out) return BLASR_HIP_ERR_INVALID;
   blasr_hip_fasta *f = new blasr_hip_fasta();
   parse_fasta(text, (size_t)length, *f);
   *out = f;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_fasta_free(blasr_hip_fasta *f) {
+int blasr_hip_fasta_free(blasr_hip_fasta *f) try {
   delete f;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int64_t blasr_hip_fasta_count(const blasr_hip_fasta *f) { return f ? (int64_t)f->seqs.size() : 0; }
+int64_t blasr_hip_fasta_count(const blasr_hip_fasta *f) try { return f ? (int64_t)f->seqs.size() : 0; } BLASR_HIP_CATCH_CODE
 
 int blasr_hip_fasta_record(const blasr_hip_fasta *f, int64_t i, const char **title, int64_t *title_length,
-                           const uint8_t **seq, int64_t *seq_length) {
+                           const uint8_t **seq, int64_t *seq_length) try {
   if (!f || i < 0 || i >= (int64_t)f->seqs.size()) return BLASR_HIP_ERR_INVALID;
   if (title) *title = f->titles[(size_t)i].c_str();
   if (title_length) *title_length = (int64_t)f->titles[(size_t)i].size();
   if (seq) *seq = f->seqs[(size_t)i].data();
   if (seq_length) *seq_length = (int64_t)f->seqs[(size_t)i].size();
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int64_t blasr_hip_fasta_name(const blasr_hip_fasta *f, int64_t i, char *name, int64_t capacity) {
+int64_t blasr_hip_fasta_name(const blasr_hip_fasta *f, int64_t i, char *name, int64_t capacity) try {
   // FASTASequence::GetName (FASTASequence.h:36-52): the title up to its first blank
   if (!f || i < 0 || i >= (int64_t)f->titles.size()) return BLASR_HIP_ERR_INVALID;
   const std::string &t = f->titles[(size_t)i];
@@ -319,10 +320,10 @@ int64_t blasr_hip_fasta_name(const blasr_hip_fasta *f, int64_t i, char *name, in
     name[c] = 0;
   }
   return (int64_t)n;
-}
+} BLASR_HIP_CATCH_CODE
 
 int64_t blasr_hip_fasta_concatenate(const blasr_hip_fasta *f, int to_upper, uint8_t *genome, int64_t capacity,
-                                    uint32_t *seq_start_pos) {
+                                    uint32_t *seq_start_pos) try {
   if (!f) return BLASR_HIP_ERR_INVALID;
   int64_t total = 0;
   for (auto &s : f->seqs) total += (int64_t)s.size() + 1;
@@ -355,9 +356,9 @@ int64_t blasr_hip_fasta_concatenate(const blasr_hip_fasta *f, int to_upper, uint
     genome[at++] = 'N';
   }
   return total;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) {
+int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) try {
   if (!path || !out) return BLASR_HIP_ERR_INVALID;
   *out = nullptr;
   std::vector<char> buf;
@@ -414,15 +415,15 @@ int blasr_hip_sa_read(const char *path, blasr_hip_sa **out) {
   }
   *out = sa;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_sa_free(blasr_hip_sa *sa) {
+int blasr_hip_sa_free(blasr_hip_sa *sa) try {
   delete sa;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t *length, const uint32_t **start_pos_table,
-                        const uint32_t **end_pos_table, int64_t *lookup_table_length, int32_t *lookup_prefix_length) {
+                        const uint32_t **end_pos_table, int64_t *lookup_table_length, int32_t *lookup_prefix_length) try {
   if (!sa) return BLASR_HIP_ERR_INVALID;
   if (index) *index = sa->index.data();
   if (length) *length = (int64_t)sa->index.size();
@@ -431,11 +432,11 @@ int blasr_hip_sa_arrays(const blasr_hip_sa *sa, const uint32_t **index, int64_t 
   if (lookup_table_length) *lookup_table_length = sa->lookupTableLength;
   if (lookup_prefix_length) *lookup_prefix_length = (int32_t)sa->lookupPrefixLength;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 // TupleCountTable::Write / Read (datastructures/tuplelists/TupleCountTable.h:75-90): the .ctab file Blasr looks for
 // next to the genome (Blasr.cpp:4463-4477) -- countTableLength, nTuples, tupleSize, the counts (all int32).
-int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t tuple_size) {
+int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t tuple_size) try {
   if (!path || !count_table || tuple_size < 1 || tuple_size > 15) return BLASR_HIP_ERR_INVALID;
   FILE *f = fopen(path, "wb");
   if (!f) return BLASR_HIP_ERR_INVALID;
@@ -446,10 +447,10 @@ int blasr_hip_ctab_write(const char *path, const int32_t *count_table, int32_t t
             fwrite(count_table, 4, (size_t)len, f) == (size_t)len;
   ok = fclose(f) == 0 && ok;
   return ok ? BLASR_HIP_OK : BLASR_HIP_ERR_INVALID;
-}
+} BLASR_HIP_CATCH_CODE
 
 // Returns the number of counts the file holds (with count_table == NULL or too small a capacity nothing is copied).
-int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capacity, int32_t *tuple_size) {
+int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capacity, int32_t *tuple_size) try {
   if (!path) return BLASR_HIP_ERR_INVALID;
   FILE *f = fopen(path, "rb");
   if (!f) return BLASR_HIP_ERR_INVALID;
@@ -463,6 +464,6 @@ int64_t blasr_hip_ctab_read(const char *path, int32_t *count_table, int64_t capa
   }
   fclose(f);
   return out;
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"

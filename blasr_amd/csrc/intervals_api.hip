@@ -596,7 +596,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
   std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
   std::vector<std::vector<float>> perReadP((size_t)n_reads);
   std::vector<std::vector<int64_t>> perReadC(cluster_of_interval ? (size_t)n_reads : 0);
-  int threads = P.threads > 0 ? P.threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  int threads = blasr_hip_host_threads(P.threads > 0 ? P.threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
   threads = std::max(1, std::min(threads, n_reads));
   auto work = [&](int tid) {
     for (int32_t r = tid; r < n_reads; r += threads) {
@@ -644,13 +644,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
       }
     }
   };
-  if (threads == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
-    for (auto &t : pool) t.join();
-  }
+  if (const int trc = blasr_hip_run_threads(threads, work)) return trc;  // (a worker ran out of memory)
   int64_t total = 0;
   for (int32_t r = 0; r < n_reads; r++) {
     read_interval_off[r] = total;
@@ -668,7 +662,7 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
 
 extern "C" {
 
-int blasr_hip_interval_default_params(blasr_hip_interval_params *p) {
+int blasr_hip_interval_default_params(blasr_hip_interval_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   p->n_candidates = 10;
   p->min_interval = 100;
@@ -677,9 +671,9 @@ int blasr_hip_interval_default_params(blasr_hip_interval_params *p) {
   p->remove_contained_intervals = 0;
   p->threads = 0;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t tuple_size, int32_t *count_table) {
+int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t tuple_size, int32_t *count_table) try {
   if (!genome || genome_length < 0 || tuple_size < 1 || tuple_size > 14 || !count_table) return BLASR_HIP_ERR_INVALID;
   const int64_t entries = 1ll << (2 * tuple_size);
   memset(count_table, 0, sizeof(int32_t) * (size_t)entries);
@@ -698,7 +692,7 @@ int blasr_hip_count_tuples(const uint8_t *genome, int64_t genome_length, int32_t
     if (valid >= tuple_size) count_table[tuple]++;
   }
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
                                     int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
@@ -706,7 +700,7 @@ int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length
                                     const int64_t *list_off, const blasr_hip_anchor *stale,
                                     const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
                                     float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
-                                    uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) {
+                                    uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) try {
   const bool keep = chains_used != nullptr;
   if (keep && (chains_capacity < 0 || (chains_capacity > 0 && !chains) || (capacity > 0 && !chain_off))) return BLASR_HIP_ERR_INVALID;
   if (!genome || genome_length <= 0 || genome_length >= (1ll << 32) || !seq_start_pos || n_seq_pos < 1 || !count_table ||
@@ -723,20 +717,14 @@ int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length
   std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
   std::vector<std::vector<float>> perReadP((size_t)n_reads);
   std::vector<std::vector<std::vector<uint32_t>>> perReadChains(keep ? (size_t)n_reads : 0);
-  int threads = params->threads > 0 ? params->threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  int threads = blasr_hip_host_threads(params->threads > 0 ? params->threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
   threads = std::max(1, std::min(threads, n_reads));
   auto work = [&](int tid) {
     for (int32_t r = tid; r < n_reads; r += threads)
       intervals_of_read(g, reads[r], anchors, list_off + 2 * r, stale ? stale + 2 * r : nullptr, *params, r,
                         perRead[(size_t)r], perReadP[(size_t)r], keep ? &perReadChains[(size_t)r] : nullptr);
   };
-  if (threads == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
-    for (auto &t : pool) t.join();
-  }
+  if (const int trc = blasr_hip_run_threads(threads, work)) return trc;  // (a worker ran out of memory)
   int64_t total = 0, words = 0;
   for (int32_t r = 0; r < n_reads; r++) {
     read_interval_off[r] = total;
@@ -761,17 +749,17 @@ int blasr_hip_find_intervals_chains(const uint8_t *genome, int64_t genome_length
     if (words > 3 * chains_capacity) return BLASR_HIP_ERR_CAPACITY;
   }
   return total > capacity ? BLASR_HIP_ERR_CAPACITY : BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_find_intervals(const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
                              int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
                              const blasr_hip_read *reads, const blasr_hip_anchor *anchors, const int64_t *list_off,
                              const blasr_hip_anchor *stale, const blasr_hip_interval_params *params,
                              blasr_hip_interval *intervals, float *p_values, int64_t capacity, int64_t *n_intervals,
-                             int64_t *read_interval_off) {
+                             int64_t *read_interval_off) try {
   return blasr_hip_find_intervals_chains(genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
                                          n_reads, reads, anchors, list_off, stale, params, intervals, p_values, capacity,
                                          n_intervals, read_interval_off, nullptr, 0, nullptr, nullptr);
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"

@@ -456,12 +456,15 @@ __global__ __launch_bounds__(256) void iv_cluster_sizes_kernel(const IvCluster *
 }
 
 // cluster sizes -> class of every cluster, class counts (wave-aggregated), and for class 2 its scratch bytes
-__global__ __launch_bounds__(256) void iv_classify_kernel(const IvCluster *clusters, int nClusters, int32_t *cls, int32_t *classCount) {
+// midCap: the largest cluster that may take the 72 KB LDS kernel (kChainMid where the device grants that much to a
+// workgroup, kChainSmall -- no cluster at all -- where it does not: those then run with their scratch in global memory)
+__global__ __launch_bounds__(256) void iv_classify_kernel(const IvCluster *clusters, int nClusters, int32_t *cls, int32_t *classCount,
+                                                          int midCap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int c = -1;
   if (i < nClusters) {
     const int n = (int)(clusters[i].end - clusters[i].start);
-    c = n <= kChainSmall ? 0 : (n <= kChainMid ? 1 : 2);
+    c = n <= kChainSmall ? 0 : (n <= midCap ? 1 : 2);
     cls[i] = c;
   }
   for (int k = 0; k < 3; k++) {
@@ -483,7 +486,7 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
                                            const blasr_hip_anchor *anchors_device, const int64_t *list_off,
                                            const blasr_hip_interval_params *params, blasr_hip_interval *intervals,
                                            float *p_values, int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off,
-                                           uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) {
+                                           uint32_t *chains, int64_t chains_capacity, int64_t *chains_used, int64_t *chain_off) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   const bool wantChains = chains_used != nullptr;
   if (wantChains) {
@@ -624,7 +627,20 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
     hipLaunchKernelGGL((iv_windows_kernel<true>), dim3(gridL), dim3(64), 0, st, dPos, dNewOff, dPast, nLists, dSeq, n_seq_pos, dLen,
                        params->min_interval, dCount, dCOff, dCl, (IvCluster *)(w + oFew));
     HIP_TRY(ctx, hipMemsetAsync(dTotals, 0, 64, st));
-    hipLaunchKernelGGL(iv_classify_kernel, dim3((unsigned)((nClusters + 255) / 256)), dim3(256), 0, st, dCl, nClusters, dCls, (int32_t *)dTotals);
+    // the mid-size kernel needs 72 KB of LDS per workgroup, above the 64 KB a kernel gets unasked: the opt-in is a property
+    // of the (function, device) pair, so it is made on every call for the context's device and its answer is looked at
+    int midCap = kChainMid;
+    {
+      int optin = 0;
+      if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, ctx->device) != hipSuccess) optin = 0;
+      if (optin < (int)chain_bytes(kChainMid) ||
+          hipFuncSetAttribute(reinterpret_cast<const void *>(&iv_chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)chain_bytes(kChainMid)) != hipSuccess)
+        midCap = kChainSmall;
+      (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(iv_classify_kernel, dim3((unsigned)((nClusters + 255) / 256)), dim3(256), 0, st, dCl, nClusters, dCls,
+                       (int32_t *)dTotals, midCap);
     {  // order = the clusters by class (a stable two-bit sort of their indices)
       std::vector<int32_t> iota((size_t)nClusters);
       for (int i = 0; i < nClusters; i++) iota[(size_t)i] = i;
@@ -678,13 +694,6 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
       dScratch = (char *)scratchMem.p;
       dScratchOff = (int64_t *)scratchOffMem.p;
     }
-    static bool ldsOptIn = false;
-    if (!ldsOptIn) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&iv_chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)chain_bytes(kChainMid));
-      (void)hipGetLastError();
-      ldsOptIn = true;
-    }
     if (classCount[0] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<0>), dim3((unsigned)((classCount[0] + 3) / 4)), dim3(256), 4 * chain_bytes(kChainSmall), st, dPos,
                          dNewOff, dCl, dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
@@ -736,16 +745,16 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
     }
   }
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_find_intervals_device(blasr_hip_ctx *ctx, const uint8_t *genome, int64_t genome_length, const uint32_t *seq_start_pos,
                                     int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
                                     const blasr_hip_read *reads, const blasr_hip_anchor *anchors_device, const int64_t *list_off,
                                     const blasr_hip_interval_params *params, blasr_hip_interval *intervals, float *p_values,
-                                    int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off) {
+                                    int64_t capacity, int64_t *n_intervals, int64_t *read_interval_off) try {
   return blasr_hip_find_intervals_device_chains(ctx, genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
                                                 n_reads, reads, anchors_device, list_off, params, intervals, p_values, capacity,
                                                 n_intervals, read_interval_off, nullptr, 0, nullptr, nullptr);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

@@ -1252,17 +1252,17 @@ int kband_run_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const bla
 extern "C" {
 
 int blasr_hip_kband_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
-                           blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+                           blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) try {
   if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   return kband_run(ctx, b, p, nullptr, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 int blasr_hip_kband_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_kband_params *p,
-                         blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+                         blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) try {
   if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   return kband_run_host(ctx, b, p, nullptr, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 int blasr_hip_kband_stats_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hip_score_params *score,
-                                 int32_t use_affine, blasr_hip_refine_result *results, const uint32_t *ops) {
+                                 int32_t use_affine, blasr_hip_refine_result *results, const uint32_t *ops) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !score || b->n < 0 || (b->n > 0 && (!b->seq || !b->q_off || !b->t_off || !results || !ops)))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband_stats: bad arguments");
@@ -1293,18 +1293,18 @@ int blasr_hip_kband_stats_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 int blasr_hip_kband_linear_device(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b,
                                   const blasr_hip_kband_linear_params *p, blasr_hip_refine_result *results,
-                                  uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) {
+                                  uint32_t *ops, int64_t ops_capacity, int64_t *ops_used) try {
   if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   return kband_run(ctx, b, nullptr, p, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 int blasr_hip_kband_linear_host(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b,
                                 const blasr_hip_kband_linear_params *p, blasr_hip_refine_result *results, uint32_t *ops,
-                                int64_t ops_capacity, int64_t *ops_used) {
+                                int64_t ops_capacity, int64_t *ops_used) try {
   if (ctx && !p) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband: bad arguments");
   return kband_run_host(ctx, b, nullptr, p, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

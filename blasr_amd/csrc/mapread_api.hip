@@ -142,7 +142,7 @@ int blasr_hip_refine_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_bat
                                      const blasr_hip_sdp_result *sdp_results, const int32_t *blocks, int32_t n_sel,
                                      const int32_t *sel, int32_t band, const blasr_hip_score_params *score,
                                      blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
-                                     int64_t *ops_used) {
+                                     int64_t *ops_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !score || n_sel < 0 || band < 0 || ops_capacity < 0 || (!sel && n_sel != b->n))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "refine_from_sdp: bad argument");
@@ -167,13 +167,13 @@ int blasr_hip_refine_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_bat
   rb.blk_off = t.blkOff;
   rb.n_blocks = t.nBlk;
   return blasr_hip_refine_device(ctx, &rb, band, score, results, ops, ops_capacity, ops_used);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b,
                                     const blasr_hip_sdp_result *sdp_results, const int32_t *blocks, int32_t n_sel,
                                     const int32_t *sel, int32_t band, int32_t indel, const blasr_hip_score_params *score,
                                     blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
-                                    int64_t *ops_used) {
+                                    int64_t *ops_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !score || n_sel < 0 || band < 0 || ops_capacity < 0 || (!sel && n_sel != b->n))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "kband_from_sdp: bad argument");
@@ -211,9 +211,9 @@ int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batc
   if (ops_used) *ops_used = used;
   if (rc) return rc;
   return blasr_hip_kband_stats_device(ctx, &kb, score, 0, results, ops);  // :740
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
-int blasr_hip_map_default_params(blasr_hip_map_params *p) {
+int blasr_hip_map_default_params(blasr_hip_map_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   memset(p, 0, sizeof(*p));
   p->window.approximate_max_insertion_rate = 1.30f;  // MappingParameters.h
@@ -250,21 +250,21 @@ int blasr_hip_map_default_params(blasr_hip_map_params *p) {
   p->sdp_bypass_threshold = 1000000.0f;  // :316
   p->use_guided_align = 1;               // :310
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_map_last_timing(const blasr_hip_ctx *ctx, float ms[6], int64_t counters[6]) {
+int blasr_hip_map_last_timing(const blasr_hip_ctx *ctx, float ms[6], int64_t counters[6]) try {
   if (!ctx || !ms || !counters) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 6; i++) ms[i] = ctx->mapMs[i];
   for (int i = 0; i < 6; i++) counters[i] = ctx->mapCounters[i];
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_map_device_arenas(blasr_hip_ctx *ctx, const uint8_t **seq, const uint32_t **ops) {
+int blasr_hip_map_device_arenas(blasr_hip_ctx *ctx, const uint8_t **seq, const uint32_t **ops) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (seq) *seq = (const uint8_t *)ctx->mapBuf[MB_SEQ].p;
   if (ops) *ops = (const uint32_t *)ctx->mapBuf[MB_OPS].p;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                           const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
@@ -274,7 +274,7 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
 int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                                const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
                                const blasr_hip_map_params *prm, blasr_hip_hit *hits, int64_t hits_capacity,
-                               int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch) {
+                               int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch) try {
   const double t0 = now_ms();
   const int rc = map_reads_impl(ctx, n_reads, reads, read_pool, n_iv, intervals, prm, hits, hits_capacity, n_hits, read_hit_off, fetch);
   if (ctx && getenv("BLASR_HIP_MAP_TRACE")) {
@@ -283,7 +283,7 @@ int blasr_hip_map_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_
     fprintf(stderr, "[map] the call: %.1f ms, its stages %.1f ms\n", now_ms() - t0, sum);
   }
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_read *reads,
                           const uint8_t *read_pool, int32_t n_iv, const blasr_hip_interval *intervals,
@@ -493,18 +493,13 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
     }
   };
   {
-    const int threads = n_reads >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    if (threads == 1) {
-      filter_reads(0, n_reads);
-    } else {
-      std::vector<std::thread> pool;
-      const int chunk = (n_reads + threads - 1) / threads;
-      for (int t = 0; t < threads; t++) {
-        const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
-        if (r0 < r1) pool.emplace_back(filter_reads, r0, r1);
-      }
-      for (auto &t : pool) t.join();
-    }
+    const int threads = n_reads >= 8192 ? blasr_hip_host_threads((int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+    const int chunk = (n_reads + threads - 1) / threads;
+    const int trc = blasr_hip_run_threads(threads, [&](int t) {
+      const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
+      if (r0 < r1) filter_reads(r0, r1);
+    });
+    if (trc) return blasr_hip_fail(ctx, trc, "map_reads: a filter thread failed (out of host memory)");
   }
   if (badRead.load() >= 0) return blasr_hip_fail(ctx, badCode.load(), "map_reads: first filter failed for read %d", badRead.load());
   for (int r = 0; r < n_reads; r++) {
@@ -643,18 +638,13 @@ static int map_reads_impl(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hip_r
     }
   };
   {
-    const int threads = n_reads >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    if (threads == 1) {
-      refine_filters(0, n_reads);
-    } else {
-      std::vector<std::thread> pool;
-      const int chunk = (n_reads + threads - 1) / threads;
-      for (int t = 0; t < threads; t++) {
-        const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
-        if (r0 < r1) pool.emplace_back(refine_filters, r0, r1);
-      }
-      for (auto &t : pool) t.join();
-    }
+    const int threads = n_reads >= 8192 ? blasr_hip_host_threads((int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+    const int chunk = (n_reads + threads - 1) / threads;
+    const int trc = blasr_hip_run_threads(threads, [&](int t) {
+      const int r0 = std::min(n_reads, t * chunk), r1 = std::min(n_reads, r0 + chunk);
+      if (r0 < r1) refine_filters(r0, r1);
+    });
+    if (trc) return blasr_hip_fail(ctx, trc, "map_reads: a filter thread failed (out of host memory)");
   }
   if (badStatus2.load() != 0)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "map_reads: candidate %d of read %d: refine status %d "
@@ -775,7 +765,7 @@ int blasr_hip_map_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hi
                              const uint8_t *read_pool, int64_t read_pool_bytes, int32_t n_iv,
                              const blasr_hip_interval *intervals, const blasr_hip_map_params *prm,
                              blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
-                             blasr_hip_map_fetch *fetch) {
+                             blasr_hip_map_fetch *fetch) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n_reads < 0 || n_iv < 0 || read_pool_bytes < 0 || (n_reads > 0 && !reads) || (read_pool_bytes > 0 && !read_pool) ||
       (n_iv > 0 && !intervals))
@@ -794,6 +784,6 @@ int blasr_hip_map_reads_host(blasr_hip_ctx *ctx, int32_t n_reads, const blasr_hi
   return blasr_hip_map_reads_device(ctx, n_reads, (const blasr_hip_read *)mb[MB_H_READS].p,
                                     (const uint8_t *)mb[MB_H_POOL].p, n_iv, (const blasr_hip_interval *)mb[MB_H_IVS].p,
                                     prm, hits, hits_capacity, n_hits, read_hit_off, fetch);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

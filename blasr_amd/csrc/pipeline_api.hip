@@ -42,7 +42,7 @@ double now_ms() {
 
 extern "C" {
 
-int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) {
+int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   blasr_hip_anchor_default_params(&p->anchor);
   blasr_hip_interval_default_params(&p->interval);
@@ -50,15 +50,15 @@ int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) {
   p->reads_per_block = 100000;  // (round 2: 6250, sized for the host's interval finding to keep up with the device)
   p->reserved = 0;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_pipeline_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[2]) {
+int blasr_hip_pipeline_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[2]) try {
   if (!ctx || !ms || !counters) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) ms[i] = ctx->pipeMs[i];
   counters[0] = ctx->pipeCounters[0];
   counters[1] = ctx->pipeCounters[1];
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
                                     int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size,
@@ -66,7 +66,7 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
                                     const uint8_t *read_pool_device, const blasr_hip_pipeline_params *params,
                                     blasr_hip_hit *hits, int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off,
                                     blasr_hip_map_fetch *fetch, blasr_hip_interval *intervals_out,
-                                    int64_t intervals_capacity, int64_t *n_intervals) {
+                                    int64_t intervals_capacity, int64_t *n_intervals) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!genome_host || !seq_start_pos || n_seq_pos < 1 || !count_table || n_reads < 0 || !params || !n_hits ||
       (n_reads > 0 && (!reads_host || !reads_device || !read_pool_device)) || (hits_capacity > 0 && !hits) ||
@@ -244,10 +244,14 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
       }
       std::lock_guard<std::mutex> lock(mu);
       if (rc != BLASR_HIP_OK && hostError == BLASR_HIP_OK) hostError = rc;
-      blockIvs.push_back(std::move(ivs));
-      blockIvOff.push_back(std::move(off));
-      blockChains.push_back(std::move(chains));
-      blockChainOff.push_back(std::move(chainOff));
+      try {  // (the lists of lists grow here: nothing may leave this thread)
+        blockIvs.push_back(std::move(ivs));
+        blockIvOff.push_back(std::move(off));
+        blockChains.push_back(std::move(chains));
+        blockChainOff.push_back(std::move(chainOff));
+      } catch (...) {
+        if (hostError == BLASR_HIP_OK) hostError = BLASR_HIP_ERR_NOMEM;
+      }
     }
   });
   auto finish_worker = [&]() {
@@ -258,6 +262,10 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
     cv.notify_all();
     if (worker.joinable()) worker.join();
   };
+  struct JoinOnExit {  // an exception on this thread must not find the worker still running (std::terminate)
+    decltype(finish_worker) &f;
+    ~JoinOnExit() { f(); }
+  } joinOnExit{finish_worker};
 
   // ---- the device stage
   // (an exception in this thread after the worker has started must not reach std::terminate through its joinable
@@ -407,14 +415,14 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: %lld intervals, capacity %lld", (long long)total,
                           (long long)intervals_capacity);
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_map_from_reads_host(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,
                                   int32_t n_seq_pos, const int32_t *count_table, int32_t count_tuple_size, int32_t n_reads,
                                   const blasr_hip_read *reads, const uint8_t *read_pool, int64_t read_pool_bytes,
                                   const blasr_hip_pipeline_params *params, blasr_hip_hit *hits, int64_t hits_capacity,
                                   int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch,
-                                  blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals) {
+                                  blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n_reads < 0 || read_pool_bytes < 0 || (n_reads > 0 && (!reads || !read_pool)))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "map_from_reads_host: bad arguments");
@@ -436,6 +444,6 @@ int blasr_hip_map_from_reads_host(blasr_hip_ctx *ctx, const uint8_t *genome_host
                                          reads, (const blasr_hip_read *)dReads.p, (const uint8_t *)dPool.p, params, hits,
                                          hits_capacity, n_hits, read_hit_off, fetch, intervals_out, intervals_capacity,
                                          n_intervals);
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
@@ -211,19 +212,15 @@ __global__ __launch_bounds__(256) void rbao_stats_kernel(int n, const uint8_t *s
 // fn(begin, end) over [0, n) on up to 16 host threads (the per-gap loops below run over ~10^5..10^6 gaps per call)
 template <typename F>
 void parallel_ranges(size_t n, F fn) {
-  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  unsigned threads = (unsigned)blasr_hip_host_threads((int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
   if (n < 16384) threads = 1;
-  if (threads == 1) {
-    fn((size_t)0, n);
-    return;
-  }
   const size_t chunk = (n + threads - 1) / threads;
-  std::vector<std::thread> pool;
-  for (unsigned t = 0; t < threads; t++) {
+  const int rc = blasr_hip_run_threads((int)threads, [&](int t) {
     const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
-    if (b < e) pool.emplace_back([=]() { fn(b, e); });
-  }
-  for (auto &t : pool) t.join();
+    if (b < e) fn(b, e);
+  });
+  if (rc == BLASR_HIP_ERR_NOMEM) throw std::bad_alloc();  // back on the caller's thread: the entry point's handler reports it
+  if (rc) throw std::runtime_error("a worker thread failed");
 }
 
 // ops (M / I / D runs from (0, 0)) -> blocks, Alignment::ArrowPathToAlignment (Alignment.h:190-254)
@@ -287,7 +284,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
                                            const blasr_hip_window *windows, uint32_t genome_length,
                                            const uint32_t *chains, const int64_t *chain_off,
                                            const blasr_hip_rbao_params *prm, blasr_hip_sdp_result *results,
-                                           int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used) {
+                                           int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || b->n < 0 || !prm || blocks_capacity < 0 || (b->n > 0 && (!b->seq || !b->q_off || !b->q_len || !b->t_off ||
       !b->t_len || !windows || !chain_off || !results)) || (blocks_capacity > 0 && !blocks))
@@ -325,7 +322,7 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
   std::vector<std::vector<Anchor>> anchors((size_t)n);
   std::vector<int> bypass((size_t)n, 0);
   {
-    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned threads = (unsigned)blasr_hip_host_threads((int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
     threads = (unsigned)std::max(1, std::min<int>((int)threads, n / 64 + 1));
     auto work = [&](unsigned tid) {
       for (int i = (int)tid; i < n; i += (int)threads) {
@@ -345,13 +342,8 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
         prepare_anchors(m, win[(size_t)i], genome_length);
       }
     };
-    if (threads == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> pool;
-      for (unsigned t = 0; t < threads; t++) pool.emplace_back(work, t);
-      for (auto &t : pool) t.join();
-    }
+    if (const int trc = blasr_hip_run_threads((int)threads, work))
+      return blasr_hip_fail(ctx, trc, "align_between_anchors: a worker thread failed (out of host memory)");
   }
   for (int i = 0; i < n; i++)
     if (bypass[(size_t)i])
@@ -735,13 +727,13 @@ int blasr_hip_align_between_anchors_device(blasr_hip_ctx *ctx, const blasr_hip_s
   HIP_TRY(ctx, hipGetLastError());
   lap("assembly + statistics", (size_t)total);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_align_between_anchors_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, int64_t seq_bytes,
                                          const blasr_hip_window *windows, uint32_t genome_length,
                                          const uint32_t *chains, const int64_t *chain_off,
                                          const blasr_hip_rbao_params *prm, blasr_hip_sdp_result *results,
-                                         int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used) {
+                                         int32_t *blocks, int64_t blocks_capacity, int64_t *blocks_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || b->n < 0 || seq_bytes < 0 || blocks_capacity < 0 || (b->n > 0 && (!b->seq || !b->q_off || !b->q_len || !b->t_off ||
       !b->t_len || !windows || !results)) || (blocks_capacity > 0 && !blocks))
@@ -783,6 +775,6 @@ int blasr_hip_align_between_anchors_host(blasr_hip_ctx *ctx, const blasr_hip_sdp
   HIP_TRY(ctx, hipMemcpy(results, dRes.p, sizeof(blasr_hip_sdp_result) * n, hipMemcpyDeviceToHost));
   if (used > 0) HIP_TRY(ctx, hipMemcpy(blocks, dblk.p, sizeof(int32_t) * 3 * (size_t)used, hipMemcpyDeviceToHost));
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

@@ -138,7 +138,7 @@ struct Dev {
 extern "C" {
 
 int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_length, uint32_t *index_out,
-                                 uint32_t *start_pos_out, uint32_t *end_pos_out) {
+                                 uint32_t *start_pos_out, uint32_t *end_pos_out) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!ctx->genome) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "build_suffix_array: no genome uploaded");
   if (lookup_prefix_length < 0 || lookup_prefix_length > 14)
@@ -245,9 +245,9 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   if (start_pos_out) memcpy(start_pos_out, startPos.data(), 4 * (size_t)tableLen);
   if (end_pos_out) memcpy(end_pos_out, endPos.data(), 4 * (size_t)tableLen);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
-int blasr_hip_count_tuples_device(blasr_hip_ctx *ctx, int32_t tuple_size, int32_t *count_table) {
+int blasr_hip_count_tuples_device(blasr_hip_ctx *ctx, int32_t tuple_size, int32_t *count_table) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!ctx->genome || tuple_size < 1 || tuple_size > 14 || !count_table)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "count_tuples_device: no genome, or bad arguments");
@@ -261,11 +261,11 @@ int blasr_hip_count_tuples_device(blasr_hip_ctx *ctx, int32_t tuple_size, int32_
   HIP_TRY(ctx, hipMemcpyAsync(count_table, table.p, 4 * (size_t)entries, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 // SuffixArray::Write (SuffixArray.h:505-532) with the component list sawriter writes: the array and the lookup table
 int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, const uint32_t *start_pos_table,
-                       const uint32_t *end_pos_table, int64_t lookup_table_length, int32_t lookup_prefix_length) {
+                       const uint32_t *end_pos_table, int64_t lookup_table_length, int32_t lookup_prefix_length) try {
   if (!path || !index || length <= 0 || length >= (1ll << 32) || lookup_table_length < 0 ||
       (lookup_table_length > 0 && (!start_pos_table || !end_pos_table)))
     return BLASR_HIP_ERR_INVALID;
@@ -282,6 +282,6 @@ int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, 
          fwrite(end_pos_table, 4, (size_t)tableLen, f) == (size_t)tableLen;
   ok = fclose(f) == 0 && ok;
   return ok ? BLASR_HIP_OK : BLASR_HIP_ERR_INVALID;
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"

@@ -126,18 +126,18 @@ int bits_for(uint64_t v) {
 
 extern "C" {
 
-int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) {
+int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t counters[3]) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) ms[i] = ctx->sdpMs[i];
   for (int i = 0; i < 3; i++) counters[i] = ctx->sdpCounters[i];
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
-int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]) {
+int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]) try {
   if (!ctx || !bytes) return BLASR_HIP_ERR_INVALID;
   for (int i = 0; i < 4; i++) bytes[i] = ctx->sdpBytes[i];
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"
 
@@ -683,7 +683,7 @@ extern "C" {
 
 int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
                          const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
-                         int64_t blocksCap, int64_t *blocksUsed) {
+                         int64_t blocksCap, int64_t *blocksUsed) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !sp || !score || b->n < 0 || blocksCap < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
   if (blocksUsed) *blocksUsed = 0;
@@ -783,11 +783,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "blocks arena too small: need %lld, have %lld", (long long)used,
                           (long long)blocksCap);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const blasr_hip_sdp_params *sp,
                        const blasr_hip_score_params *score, blasr_hip_sdp_result *results, int32_t *blocks,
-                       int64_t blocksCap, int64_t *blocksUsed) {
+                       int64_t blocksCap, int64_t *blocksUsed) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (!b || !sp || !score || b->n < 0) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "bad argument");
   if (blocksUsed) *blocksUsed = 0;
@@ -837,6 +837,6 @@ int blasr_hip_sdp_host(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const b
   if (copyBlocks > 0)
     HIP_TRY(ctx, hipMemcpy(blocks, dBlocks.p, sizeof(int32_t) * 3 * (size_t)copyBlocks, hipMemcpyDeviceToHost));
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"

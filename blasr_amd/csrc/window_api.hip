@@ -157,7 +157,7 @@ void drop_genome(blasr_hip_ctx *ctx) {
 extern "C" {
 
 int blasr_hip_adopt_genome_device(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length,
-                                  const uint32_t *contig_starts_host, int32_t n_contigs) {
+                                  const uint32_t *contig_starts_host, int32_t n_contigs) try {
   if (!ctx || !ascii || length <= 0 || length >= (1ll << 32) || n_contigs < 0 || (contig_starts_host && n_contigs < 1))
     return ctx ? blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "adopt_genome: bad arguments") : BLASR_HIP_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -172,10 +172,10 @@ int blasr_hip_adopt_genome_device(blasr_hip_ctx *ctx, const uint8_t *ascii, int6
   ctx->genomeOwned = false;
   ctx->genomeLen = length;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_upload_genome(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t length, const uint32_t *contig_starts,
-                            int32_t n_contigs) {
+                            int32_t n_contigs) try {
   if (!ctx || !ascii || length <= 0 || length >= (1ll << 32) || n_contigs < 0 || (contig_starts && n_contigs < 1))
     return ctx ? blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "upload_genome: bad arguments") : BLASR_HIP_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -192,13 +192,13 @@ int blasr_hip_upload_genome(blasr_hip_ctx *ctx, const uint8_t *ascii, int64_t le
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->genomeLen = length;
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_windows_device(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_interval *intervals,
                              const blasr_hip_read *reads, const uint8_t *read_pool,
                              const blasr_hip_window_params *params, uint8_t *seq_out, int64_t seq_capacity,
                              int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len,
-                             blasr_hip_window *windows, int64_t *seq_used) {
+                             blasr_hip_window *windows, int64_t *seq_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n < 0 || !params || !seq_used || (n > 0 && (!intervals || !reads || !read_pool || !seq_out || !q_off || !q_len ||
                                                   !t_off || !t_len || !windows)))
@@ -247,13 +247,13 @@ int blasr_hip_windows_device(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_inte
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "windows: %lld bytes needed, %lld provided", (long long)total,
                           (long long)seq_capacity);
   return BLASR_HIP_OK;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_windows_host(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_interval *intervals, int32_t n_reads,
                            const blasr_hip_read *reads, const uint8_t *read_pool, int64_t read_pool_bytes,
                            const blasr_hip_window_params *params, uint8_t *seq_out, int64_t seq_capacity,
                            int64_t *q_off, int32_t *q_len, int64_t *t_off, int32_t *t_len,
-                           blasr_hip_window *windows, int64_t *seq_used) {
+                           blasr_hip_window *windows, int64_t *seq_used) try {
   if (!ctx) return BLASR_HIP_ERR_INVALID;
   if (n < 0 || n_reads < 0 || read_pool_bytes < 0 || seq_capacity < 0 || !params || !seq_used)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "windows: bad arguments");
@@ -300,14 +300,14 @@ int blasr_hip_windows_host(blasr_hip_ctx *ctx, int32_t n, const blasr_hip_interv
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return rc;
-}
+} BLASR_HIP_CATCH_CTX(ctx)
 
 // ---------------------------------------------------------------------------------------------
 // a-10 (host).  The reference sorts a vector of candidate pointers with std::sort; sorting the index
 // list with the same comparator through the same libstdc++ algorithm performs the same swaps, so ties
 // (equal score and equal tPos + tAlignedSeqPos) fall the same way.
 // ---------------------------------------------------------------------------------------------
-int blasr_hip_sort_candidates(const blasr_hip_candidate *cands, int32_t n, int32_t *order) {
+int blasr_hip_sort_candidates(const blasr_hip_candidate *cands, int32_t n, int32_t *order) try {
   if (n < 0 || (n > 0 && (!cands || !order))) return BLASR_HIP_ERR_INVALID;
   std::sort(order, order + n, [cands](int32_t l, int32_t r) {  // SortAlignmentPointersByScore, Blasr.cpp:226-236
     const blasr_hip_candidate &lhs = cands[l], &rhs = cands[r];
@@ -315,10 +315,10 @@ int blasr_hip_sort_candidates(const blasr_hip_candidate *cands, int32_t n, int32
     return lhs.score < rhs.score;
   });
   return n;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_remove_low_quality(blasr_hip_candidate *cands, const int32_t *blocks, int32_t n, int32_t *order,
-                                 int32_t n_candidates, int32_t max_gap, int32_t max_score) {
+                                 int32_t n_candidates, int32_t max_gap, int32_t max_score) try {
   if (n < 0 || (n > 0 && (!cands || !order))) return BLASR_HIP_ERR_INVALID;
   const int32_t lim = std::min(n_candidates, n);  // MIN(params.nCandidates, alignmentPtrs.size()), :2027
   for (int32_t i = 0; i < lim; i++) {
@@ -338,10 +338,10 @@ int blasr_hip_remove_low_quality(blasr_hip_candidate *cands, const int32_t *bloc
     if (c.n_blocks == 0 || c.score > max_score) return i;  // this one and all after it are removed (:2048-2068)
   }
   return n;
-}
+} BLASR_HIP_CATCH_CODE
 
 int blasr_hip_remove_overlapping(const blasr_hip_candidate *cands, int32_t n, int32_t *order,
-                                 float min_pct_identity) {
+                                 float min_pct_identity) try {
   if (n < 0 || (n > 0 && (!cands || !order))) return BLASR_HIP_ERR_INVALID;
   std::vector<unsigned char> contained((size_t)std::max(n, 1), 0);
   for (int32_t i = 0; i + 1 < n; i++) {
@@ -364,6 +364,6 @@ int blasr_hip_remove_overlapping(const blasr_hip_candidate *cands, int32_t n, in
   for (int32_t i = 0; i < n; i++)
     if (!contained[i]) order[kept++] = order[i];
   return kept;
-}
+} BLASR_HIP_CATCH_CODE
 
 }  // extern "C"

@@ -39,6 +39,7 @@ static void die(const char *what, blasr_hip_ctx *ctx) {
 }
 
 int main(int argc, char **argv) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);  // before the first HIP call (INTEGRATION.md 4'): the library leaves the environment alone
   if (argc < 4) die("usage: map_fasta reads.fasta genome.fasta (genome.fasta.sa | intervals.txt) [bestn]", NULL);
   int bestn = 1, extend = 0, rbao = 0, start = 0, stride = 1, device = 0;
   for (int i = 4; i < argc; i++) {

@@ -41,7 +41,10 @@ extern "C" {
 /* 2: blasr_hip_map_params grew the -extend fields (and blasr_hip_pipeline_params with it); a caller built against
  * version 1 must be recompiled (compare blasr_hip_abi_version() with the header's value at start-up). */
 /* 3: blasr_hip_sdp_params grew sw_align_type, blasr_hip_map_params the -rbao fields (and the chains' two pointers). */
-#define BLASR_HIP_ABI_VERSION 3
+/* 4: blasr_hip_map_params' reserved word became use_guided_align (a caller that fills the struct by hand instead of through
+ * blasr_hip_map_default_params would get the k-band refiner with its old 0); BLASR_HIP_ERR_INTERNAL; the k-band entry points
+ * take bands of any width and report TASK_EMPTY_GUIDE for an empty candidate. */
+#define BLASR_HIP_ABI_VERSION 4
 
 typedef struct blasr_hip_ctx blasr_hip_ctx;
 
@@ -52,7 +55,9 @@ enum blasr_hip_status {
   BLASR_HIP_ERR_HIP = -3,         /* a HIP runtime call failed (see blasr_hip_last_error) */
   BLASR_HIP_ERR_NOMEM = -4,       /* device workspace could not grow */
   BLASR_HIP_ERR_UNSUPPORTED = -5, /* parameters outside the kernel's domain */
-  BLASR_HIP_ERR_CAPACITY = -6     /* caller-provided output arena too small */
+  BLASR_HIP_ERR_CAPACITY = -6,    /* caller-provided output arena too small */
+  BLASR_HIP_ERR_INTERNAL = -7     /* a C++ exception other than bad_alloc was caught at the boundary (no exception ever
+                                     crosses it: bad_alloc comes back as BLASR_HIP_ERR_NOMEM) */
 };
 
 /* per-candidate status bits in result records */

@@ -16,6 +16,7 @@ committed: oracle/_ref is git-ignored), adds oracle/dropin/blasr_hip_dropin.h (t
                                                       alignments of that read (BlasrHipCandidatesOfCurrentRead); everything
                                                       after MapRead -- StoreMapQVs, the printers -- is the reference's own
                         main (:4023)                  -useGPU / -gpuDevice / -gpuBatch registered with the command-line parser
+                        main (:3947)                  setenv("GPU_MAX_HW_QUEUES", "8", 0) before anything touches HIP
 Usage: python oracle/make_dropin.py [reference checkout]   (default /root/reference)"""
 import os
 import re
@@ -96,6 +97,9 @@ def main():
                     '  clp.RegisterFlagOption("useGPU", &params.useGPU, "");\n'
                     '  clp.RegisterIntOption("gpuDevice", &params.gpuDevice, "", CommandLineParser::NonNegativeInteger);\n'
                     '  clp.RegisterIntOption("gpuBatch", &params.gpuBatch, "", CommandLineParser::NonNegativeInteger);\n', "main")
+    # the HIP runtime reads GPU_MAX_HW_QUEUES once, when it starts: the host asks for eight before anything else (INTEGRATION.md 4')
+    bl = patch_once(bl, "int main(int argc, char* argv[]) {\n",
+                    'int main(int argc, char* argv[]) {\n  setenv("GPU_MAX_HW_QUEUES", "8", 0);\n', "main's first line")
     open(os.path.join(build, "Blasr_gpu.cpp"), "w").write(bl)
     out = os.path.join(ROOT, "oracle", "_ref", "blasrmc_gpu")
     cmd = ["g++", "-O3", "-std=c++11", "-w", "-I", build, "-I", os.path.join(ROOT, "oracle", "dropin"), "-I", os.path.join(ROOT, "include"),

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(hip.EXPORTS) == names
-    assert lib.blasr_hip_abi_version() == 3
+    assert lib.blasr_hip_abi_version() == 4
 
 
 def test_result_record_layout_matches_header():
@@ -108,3 +108,39 @@ def test_ops_decode_to_blocks_and_gaps():
     assert blocks.tolist() == [[0, 0, 5], [7, 6, 3]]
     assert gc.tolist() == [0, 2, 0]
     assert gi.tolist() == [[hip.GAP_TARGET, 2], [hip.GAP_QUERY, 1]]
+
+
+def test_no_exception_crosses_the_abi_when_host_memory_runs_out():
+    """no exception crosses the C ABI.  A child process caps its address space (RLIMIT_AS) and asks the host
+    side of the interval finder -- std::vectors per read, a pool of std::threads -- for more than that: the call comes
+    back with BLASR_HIP_ERR_NOMEM (every entry point is a function-try-block, the pool's threads catch in their own body
+    and fall back to the caller's thread when no thread can be had), the process does not abort."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+import blasr_amd
+from blasr_amd import hip
+lib = blasr_amd.load_library()
+n = 12000000                                  # reads: the call sizes several vectors of vectors by it
+genome = np.frombuffer(b"ACGT" * 64, dtype=np.uint8)
+starts = np.array([0, len(genome)], dtype=np.uint32)
+table = np.zeros(1 << 16, dtype=np.int32)
+reads = np.zeros(n, dtype=hip.READ_DTYPE)
+list_off = np.zeros(2 * n + 1, dtype=np.int64)
+out = np.zeros(16, dtype=hip.INTERVAL_DTYPE)
+off = np.zeros(n + 1, dtype=np.int64)
+need = C.c_int64(0)
+params = hip.interval_params(threads=8)
+used = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (used + (96 << 20), used + (96 << 20)))
+rc = lib.blasr_hip_find_intervals(genome.ctypes.data, len(genome), starts.ctypes.data, len(starts), table.ctypes.data, 8, n,
+                                  reads.ctypes.data, None, list_off.ctypes.data, None, C.byref(params), out.ctypes.data, None, 16,
+                                  C.byref(need), off.ctypes.data)
+print("rc", rc)
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode()[-2000:])  # not SIGABRT from std::terminate
+    assert "rc -4" in p.stdout.decode(), (p.stdout.decode(), p.stderr.decode()[-2000:])
