@@ -7,6 +7,7 @@
 //   blasr_hip_map_qvs               StoreMapQVs and its helpers         alignment/Blasr.cpp:2647-2950
 //   blasr_hip_sam_line              SAMOutput::PrintAlignment           printers/SAMPrinter.h:29-105, 418-548
 //   blasr_hip_order_gaps_by_type    Alignment::OrderGapsByType          datastructures/alignment/Alignment.h:255-317
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -366,7 +367,11 @@ extern "C" int blasr_hip_map_qvs(const blasr_hip_mapqv_alignment *alns, int32_t 
         int phred;
         if (expo == 0) phred = 0;
         else if (diff == 0) phred = kMaxPhred;
-        else phred = -10 * log10(diff);  // Phred (utils/PhredUtils.h:10-13), truncated
+        else {  // Phred (utils/PhredUtils.h:10-13), truncated.  diff can come out negative (exp rounds above 1): the
+          // reference then converts a NaN to int -- what x86's cvttsd2si gives for it (INT_MIN), spelled out
+          const double v = -10 * log10(diff);
+          phred = (v != v || v >= 2147483648.0 || v < -2147483648.0) ? INT_MIN : (int)v;
+        }
         if (phred > kMaxPhred) phred = kMaxPhred;
         if (phred < 0) phred = 0;
         map_qv[*it] = phred;

@@ -16,7 +16,9 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblasr_hip.so")
+# BLASR_HIP_LIBRARY: another build of the same library (tools/sanitized_cpu_tests.sh loads libblasr_hip_san.so, the host side
+# under ASan / UBSan); never anything but a build of blasr_amd/csrc
+LIB_PATH = os.environ.get("BLASR_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libblasr_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 TASK_EMPTY_GUIDE, TASK_BAD_GUIDE, TASK_BAD_PATH, TASK_OPS_OVERFLOW = 1, 2, 4, 8

@@ -2596,7 +2596,10 @@ void bo_store_map_qvs(int n, const unsigned char *const *qSeqs, const unsigned c
         int phred;
         if (expo == 0) phred = 0;
         else if (diff == 0) phred = 254;
-        else phred = -10 * log10(diff);
+        else { /* diff < 0 happens (exp rounds above 1): NaN to int is what cvttsd2si gives, INT_MIN -- spelled out */
+          double v = -10 * log10(diff);
+          phred = (v != v || v >= 2147483648.0 || v < -2147483648.0) ? INT_MIN : (int)v;
+        }
         if (phred > 254) phred = 254;
         if (phred < 0) phred = 0;
         mapQV[i] = phred;
@@ -2776,14 +2779,18 @@ static void sa_bounds_push(sa_bounds *b, long l, long r) {
 static unsigned sa_store_lcp_bounds(const unsigned char *target, long targetLength, const unsigned *index,
                                     const unsigned *startPosTable, const unsigned *endPosTable,
                                     int lookupPrefixLength, const unsigned char *query, unsigned queryLength,
-                                    int useLookupTable, int maxMatchLength, int stopOnceUnique, sa_bounds *b) {
+                                    unsigned queryAvail, int useLookupTable, int maxMatchLength, int stopOnceUnique,
+                                    sa_bounds *b) {
   long l = 0, r = targetLength;
   unsigned lcpLength = 0;
   if (useLookupTable && startPosTable != NULL) {
     /* DNATuple::FromStringLR (tuples/DNATuple.h:24-52) */
     unsigned long tuple = 0;
     for (int i = 0; i < lookupPrefixLength; i++) {
-      if (!g_isactg[query[i]]) return 0;
+      /* With a table prefix longer than minPrefixMatchLength the reference reads up to prefix - min bytes PAST the read's
+       * buffer at the last positions (its own ASan report).  What it finds there is not defined; a byte that is
+       * not there counts as "not a base" here (what a zero after the buffer gives the reference), and is not read. */
+      if ((unsigned)i >= queryAvail || !g_isactg[query[i]]) return 0;
       tuple = (tuple << 2) + (unsigned long)g_two[query[i]];
     }
     l = startPosTable[tuple];
@@ -2838,7 +2845,8 @@ long bo_map_read_to_genome(const unsigned char *genome, unsigned genomeLength, c
       b.n = 0;
       unsigned lcpLength =
           sa_store_lcp_bounds(genome, (long)genomeLength, saIndex, startPosTable, endPosTable, lookupPrefixLength,
-                              read + p, matchEnd - p, useLookupTable, maxLCPLength, stopMappingOnceUnique, &b);
+                              read + p, matchEnd - p, readLength - p, useLookupTable, maxLCPLength, stopMappingOnceUnique,
+                              &b);
       matchLow[m] = matchHigh[m] = matchLength[m] = 0;
       if (b.n > 0) {
         long lcpSearchLength = b.n;

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libblasr_oracle.so")
+ORACLE_SO = os.environ.get("BLASR_ORACLE_SO") or os.path.join(ROOT, "oracle", "libblasr_oracle.so")  # (the sanitizer build)
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libblasr_ref.so")
 
 LOCAL, GLOBAL = 0, 1
