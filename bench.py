@@ -305,6 +305,72 @@ def blasrmc_baseline(wl, genome_t, n_reads, read_len, cores, extend=False, devic
                        % (cores, n_reads, starts[-1], t_index, wall["reads"], wall["none"], len(names)))
 
 
+def blasrmc_true_genome(ctx, wl, genome_t, starts, n_reads, cores, extend=False):
+    """The reference BINARY on the configuration as stated: oracle/_ref/blasrmc -nproc <cores> -m 4 -bestn 1 -sa on the
+    first `n_reads` reads against a FASTA of the WHOLE genome of the run (the hg19-size one at configs[2]) and the .sa file
+    of that genome -- the index resident on the device, written by blasr_hip_sa_write_resident (sawriter's file byte for
+    byte: tests/test_sa_build_gpu.py).  Wall time less a zero-read run (which loads genome and index the same way).
+    Needs ~5 x the genome in temporary disk space and ~5.5 x in host memory; returns None where the box has not got them."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "blasrmc")
+    G = int(genome_t.numel())
+    if not os.path.exists(exe) or n_reads <= 0:
+        return None
+    tmp_root = tempfile.gettempdir()
+    try:
+        free_disk = shutil.disk_usage(tmp_root).free
+        free_mem = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (OSError, ValueError):
+        return None
+    if free_disk < 6 * G + (1 << 30) or free_mem < 7 * G + (4 << 30):
+        return dict(skipped="not enough room for the whole genome's FASTA and index (%.0f GB of disk, %.0f GB of memory free; "
+                            "%.0f and %.0f wanted)" % (free_disk / 1e9, free_mem / 1e9, 6 * G / 1e9, 7 * G / 1e9))
+    reads = wl["reads"][:n_reads]
+    pool = wl["pool"][: int(reads["off"][-1] + reads["length"][-1])].cpu().numpy()
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        fa = os.path.join(tmp, "genome.fasta")
+        with open(fa, "wb") as f:
+            for c in range(len(starts) - 1):  # a contig's bases without the N the reader appends after every record
+                f.write(b">contig%d\n" % c)
+                a, b = int(starts[c]), int(starts[c + 1]) - 1
+                for at in range(a, b, 1 << 28):
+                    f.write(genome_t[at: min(b, at + (1 << 28))].cpu().numpy().tobytes())
+                f.write(b"\n")
+        ctx.write_resident_suffix_array(fa + ".sa")
+        t_files = time.perf_counter() - t0
+        with open(os.path.join(tmp, "reads.fasta"), "w") as f:
+            for r in range(n_reads):
+                s = pool[int(reads["off"][r]): int(reads["off"][r]) + int(reads["length"][r])]
+                f.write(">read%d/%d/0_%d\n%s\n" % (r, r, len(s), bytes(s).decode()))
+        open(os.path.join(tmp, "none.fasta"), "w").write(">none/0/0_4\nACGT\n")
+        wall = {}
+        for tag, rf in (("none", "none.fasta"), ("reads", "reads.fasta")):
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([exe, os.path.join(tmp, rf), fa, "-sa", fa + ".sa", "-m", "4", "-bestn", "1", "-nproc", str(cores),
+                                    "-out", os.path.join(tmp, tag + ".m4")] + (["-extend"] if extend else []),
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+            except subprocess.TimeoutExpired:
+                return dict(error="blasrmc on the whole genome: no end after 1500 s")
+            wall[tag] = time.perf_counter() - t0
+            if p.returncode != 0:
+                return dict(error="blasrmc exit %d" % p.returncode)
+        lines = open(os.path.join(tmp, "reads.m4")).read().splitlines()
+    dt = max(wall["reads"] - wall["none"], 1e-9)
+    names = set(int(x.split("/", 1)[0][4:]) for x in lines)
+    aligned = sum(int(reads["length"][r]) for r in names)
+    return dict(value=aligned / dt, unit="bases/s", cores=cores, kind="reference binary", reads_per_s=n_reads / dt, signal_s=dt,
+                genome_bases=G,
+                sample="oracle/_ref/blasrmc -nproc %d -m 4 -bestn 1 -sa on the first %d reads against the run's WHOLE genome "
+                       "(%d bases in %d contigs; FASTA and the device-built index written in %.0f s): %.1f s wall less %.1f s "
+                       "of a zero-read run (genome + index load), %d reads reported; whole BLASR incl. anchoring, not only the path"
+                       % (cores, n_reads, G, len(starts) - 1, t_files, wall["reads"], wall["none"], len(names)))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -415,6 +481,8 @@ def main():
                          % (args.gpus, world, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:  # one process per GPU: the library's host-side pools (filters, interval finder) share the node's cores
+        os.environ.setdefault("BLASR_HIP_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
     d = config_defaults(args)
     default_line = (args.config == 2 and args.gpus == 1 and args.reads <= 0 and args.read_len <= 0 and args.genome_len <= 0 and
                     not args.stub_device and not args.load_workload and not args.no_guided and not args.extend)
@@ -571,7 +639,11 @@ def main():
 
     # the only collective of the path: one all-reduce of the per-rank counters (RCCL over xGMI)
     totals = shard.reduce_counters(n_reads, last["aligned_reads"], last["aligned_bases"], last["dp_cells"], device=red_dev)
+    own_elapsed = elapsed
     elapsed = shard.max_over_ranks(elapsed, device=red_dev)
+    K_ = max(args.steps, 1)
+    rank_ms = shard.per_rank([own_elapsed / K_ * 1e3, acc["windows_ms"] / K_, acc["sdp_ms"] / K_, acc["filter1_ms"] / K_,
+                              acc["refine_ms"] / K_, acc["filter2_ms"] / K_, float(last["refined"])], device=red_dev)
 
     if rank == 0:
         K = args.steps
@@ -627,6 +699,10 @@ def main():
                 for name, b, m in (("keys_sort", "keys_bytes", "keys_ms"), ("match_order", "match_bytes", "match_ms"),
                                    ("chain", "chain_bytes", "chain_ms"), ("blocks_fills_assembly", "blocks_bytes", "blocks_ms"))},
             "device_memory_held_gb": ctx.held_bytes() / 2**30,
+            # every rank's own figures (the step's wall time is the slowest rank's)
+            "per_rank_ms_per_step": [dict(zip(("step", "windows", "sdp", "filters_after_sdp", "refine", "filters",
+                                               "candidates_refined"), r)) for r in rank_ms],
+            "host_threads_per_rank": int(os.environ.get("BLASR_HIP_HOST_THREADS", "0")) or None,
         }
         if shared:
             out["physical_gpus"] = n_dev
@@ -703,7 +779,14 @@ def main():
                                                                      min(n_reads, max(8, 80000000 // d["read_len"])))
             if nb > 0:
                 ncores = os.cpu_count() or 1
-                b = blasrmc_baseline(wl, genome, nb, d["read_len"], min(32, ncores), args.extend, device_index)
+                b = None
+                if args.from_reads > 0:  # the genome's index is resident: the reference binary on the genome as stated
+                    b = blasrmc_true_genome(ctx, wl, genome, starts, nb, ncores, args.extend)
+                    if b is not None and "value" not in b:
+                        out["cpu_baseline_whole_blasr_on_the_whole_genome"] = b  # why not
+                        b = None
+                if b is None:  # a FASTA of the reads' own loci instead (the index of 3 Gbases takes 18 GB of disk and memory)
+                    b = blasrmc_baseline(wl, genome, nb, d["read_len"], ncores, args.extend, device_index)
                 if b is not None:
                     out["cpu_baseline_whole_blasr"] = b
             if args.from_reads > 0:

@@ -284,4 +284,41 @@ int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, 
   return ok ? BLASR_HIP_OK : BLASR_HIP_ERR_INVALID;
 } BLASR_HIP_CATCH_CODE
 
+// The same file from the index that is resident on the context's device (blasr_hip_build_suffix_array /
+// blasr_hip_upload_suffix_array left it there): the array comes down in pieces of 256 MB and goes straight to the file,
+// so a 3.1 Gbase genome's 12.4 GB index never needs a host array of its own.
+int blasr_hip_sa_write_resident(blasr_hip_ctx *ctx, const char *path) try {
+  if (!ctx) return BLASR_HIP_ERR_INVALID;
+  if (!path) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "sa_write_resident: no path");
+  if (!ctx->saIndex || ctx->saLen <= 0)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "sa_write_resident: no suffix array resident on this context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  FILE *f = fopen(path, "wb");
+  if (!f) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "sa_write_resident: cannot open %s", path);
+  const bool table = ctx->saTableLen > 0 && ctx->saStartPos && ctx->saEndPos;
+  const uint32_t magic = 0xacac0001u;
+  const int32_t comp[2] = {1, table ? 1 : 0};
+  const uint32_t len = (uint32_t)ctx->saLen, tableLen = (uint32_t)ctx->saTableLen, prefix = (uint32_t)ctx->saPrefixLen;
+  bool ok = fwrite(&magic, 4, 1, f) == 1 && fwrite(comp, 4, 2, f) == 2 && fwrite(&len, 4, 1, f) == 1;
+  const size_t piece = (size_t)64 << 20;  // elements
+  std::vector<uint32_t> buf(std::min<size_t>(piece, (size_t)std::max<int64_t>(ctx->saLen, ctx->saTableLen)));
+  hipError_t he = hipSuccess;
+  auto stream_out = [&](const uint32_t *dev, size_t n) {
+    for (size_t at = 0; at < n && ok && he == hipSuccess; at += buf.size()) {
+      const size_t m = std::min(buf.size(), n - at);
+      he = hipMemcpy(buf.data(), dev + at, 4 * m, hipMemcpyDeviceToHost);
+      if (he == hipSuccess) ok = fwrite(buf.data(), 4, m, f) == m;
+    }
+  };
+  stream_out(ctx->saIndex, (size_t)ctx->saLen);
+  if (ok && table && he == hipSuccess) {
+    ok = fwrite(&tableLen, 4, 1, f) == 1 && fwrite(&prefix, 4, 1, f) == 1;
+    stream_out(ctx->saStartPos, (size_t)tableLen);
+    stream_out(ctx->saEndPos, (size_t)tableLen);
+  }
+  ok = fclose(f) == 0 && ok;
+  if (he != hipSuccess) return blasr_hip_fail(ctx, BLASR_HIP_ERR_HIP, "sa_write_resident: %s", hipGetErrorString(he));
+  return ok ? BLASR_HIP_OK : blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "sa_write_resident: writing %s failed", path);
+} BLASR_HIP_CATCH_CTX(ctx)
+
 }  // extern "C"

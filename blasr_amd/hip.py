@@ -51,7 +51,7 @@ EXPORTS = [
     "blasr_hip_pipeline_last_timing", "blasr_hip_find_intervals_device", "blasr_hip_find_intervals_chains", "blasr_hip_find_intervals_device_chains",
     "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
     "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
-    "blasr_hip_kband_stats_device", "blasr_hip_kband_from_sdp_device",
+    "blasr_hip_kband_stats_device", "blasr_hip_kband_from_sdp_device", "blasr_hip_sa_write_resident",
 ]
 
 # include/blasr_hip.h: blasr_hip_kernel_record
@@ -1009,6 +1009,11 @@ class Context:
         if download:
             return dict(index=idx, start_pos_table=sp, end_pos_table=ep, lookup_prefix_length=lookup_prefix_length)
         return None
+
+    def write_resident_suffix_array(self, path):
+        """blasr_hip_sa_write_resident: the index resident on the device as sawriter's .sa file."""
+        self.lib.blasr_hip_sa_write_resident.argtypes = [C.c_void_p, C.c_char_p]
+        self._check(self.lib.blasr_hip_sa_write_resident(self.handle, path.encode()))
 
     def count_tuples(self, tuple_size=8):
         """The tuple count table of the uploaded genome, counted on the device (= hip.count_tuples of the same genome)."""

@@ -40,3 +40,14 @@ def max_over_ranks(seconds, device="cpu", group=None):
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def per_rank(values, device="cpu", group=None):
+    """Every rank's list of floats, gathered on all ranks: a list (one entry per rank) of lists.  bench.py prints the ranks'
+    own step and stage times with it, so that a scaling line explains itself (a slow rank, a slow stage of one rank)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        out = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size(group))]
+        torch.distributed.all_gather(out, t, group=group)
+        return [[float(x) for x in o.tolist()] for o in out]
+    return [[float(x) for x in t.tolist()]]

@@ -969,6 +969,10 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
                                  uint32_t *start_pos_out, uint32_t *end_pos_out);
 int blasr_hip_sa_write(const char *path, const uint32_t *index, int64_t length, const uint32_t *start_pos_table,
                        const uint32_t *end_pos_table, int64_t lookup_table_length, int32_t lookup_prefix_length);
+/* The same file from the index resident on the context's device (after blasr_hip_build_suffix_array or
+ * blasr_hip_upload_suffix_array), streamed to the file in pieces: sawriter's output for the resident genome without a
+ * host copy of the 4 bytes per base. */
+int blasr_hip_sa_write_resident(blasr_hip_ctx *ctx, const char *path);
 
 /* The .ctab file of a tuple count table (TupleCountTable::Write / Read, datastructures/tuplelists/TupleCountTable.h:75-90;
  * Blasr.cpp:4463-4477 picks up <genome>.ctab): blasr_hip_ctab_read returns the number of counts in the file (< 0 on

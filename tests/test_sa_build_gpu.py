@@ -51,6 +51,8 @@ def test_suffix_array_and_lookup_table_equal_sawriters(tmp_path):
             mine = fa + ".%d.mine.sa" % blt
             hip.write_suffix_array(mine, got)
             assert open(mine, "rb").read() == open(ref_path, "rb").read(), (gi, blt)
+            ctx.write_resident_suffix_array(mine + "2")  # the resident copy, streamed from the device to the file
+            assert open(mine + "2", "rb").read() == open(ref_path, "rb").read(), (gi, blt)
     ctx.close()
 
 

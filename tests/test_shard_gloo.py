@@ -28,6 +28,8 @@ def _worker(rank, world, port, n_reads, out):
     total = shard.reduce_counters(len(mine), len(aligned), int(aligned.sum()), int(mine.sum()) * 34)
     t = shard.max_over_ranks(1.0 + rank)
     stride_total = shard.reduce_counters(len(strided), 0, int(strided.sum()), 0)
+    ranks = shard.per_rank([10.0 + rank, 2.5 * rank])
+    assert ranks == [[10.0, 0.0], [11.0, 2.5]], ranks  # every rank sees every rank's figures
     if rank == 0:
         out.put((total, t, stride_total))
     dist.destroy_process_group()
