@@ -207,7 +207,7 @@ def cpu_baseline(wl, genome_t, starts, n_reads, band, hits, hit_off, cores, exte
         rd = reads[r: r + 1].copy()
         p = pool[int(rd["off"][0]): int(rd["off"][0]) + int(rd["length"][0])]
         rd["off"] = 0
-        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band, extend=extend, guided=guided)[0]
+        return oracle_map_reads(engine, mo, genome, contigs, p, rd, mine, band=band, extend=extend, guided=guided, with_ops=False)[0]
 
     t0 = time.perf_counter()
     if cores <= 1:

@@ -978,7 +978,7 @@ def oracle_extend_candidate(oracle, genome, contigs, read, w, q, tseq, s, sc, ba
 
 def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=16, n_candidates=10, max_gap=0,
                      max_score=-200, min_pct=0.0, sp=None, sc=None, extend=False, extend_band=10, extend_drops=10,
-                     guided=True, indel=5):
+                     guided=True, indel=5, with_ops=True):
     """reads / intervals: the product's READ_DTYPE / INTERVAL_DTYPE arrays.  Returns, per read, the alignments
     MapRead keeps (best first) as dicts: interval, the hit record's fields, q / t (aligned sequences), ops."""
     sp, sc = sp or SdpParams(), sc or ScoreParams()
@@ -1059,7 +1059,8 @@ def oracle_map_reads(oracle, mo, genome, contigs, pool, reads, intervals, band=1
                             n_match=rr["nMatch"], n_mismatch=rr["nMismatch"], n_ins=rr["nIns"],
                             n_del=rr["nDel"], n_cells=rr["nCells"], pct_similarity=np.float32(rr["pct"]),
                             q=x["qs"], t=x["ts"],
-                            ops=[(l << 2) | ty for ty, l in (ops_from_alignment(rr) if guided else ops_with_leading_gaps(rr))]))
+                            ops=[(l << 2) | ty for ty, l in (ops_from_alignment(rr) if guided else ops_with_leading_gaps(rr))]
+                            if with_ops else None))  # (a Python loop per op: bench.py's many-threaded CPU leg leaves it out)
     return out
 
 
