@@ -442,6 +442,28 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
         at += cnt[c];
       }
       fprintf(stderr, "\n");
+      if (atoi(getenv("BLASR_HIP_SDP_TRACE")) >= 1) {  // where the fragments are: per category, invocations and fragments by size
+        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4];
+        std::vector<int32_t> list((size_t)std::max(total, 1)), nf((size_t)nTasks);
+        HIP_TRY(ctx, hipMemcpy(list.data(), lv.chainList, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(nf.data(), lv.nFrag, sizeof(int32_t) * (size_t)nTasks, hipMemcpyDeviceToHost));
+        int pos = 0;
+        for (int c = 4; c >= 0; c--) {
+          long long inv[10] = {0}, fr[10] = {0};
+          for (int i = 0; i < cnt[c]; i++) {
+            const int f = nf[(size_t)list[(size_t)(pos + i)]];
+            int b = 0;
+            while (b < 9 && f > (64 << b)) b++;
+            inv[b]++;
+            fr[b] += f;
+          }
+          pos += cnt[c];
+          if (cnt[c] == 0) continue;
+          fprintf(stderr, "[sdp]   category %d by fragments (<=64,128,...,16384,more): ", c);
+          for (int b = 0; b < 10; b++) fprintf(stderr, "%lld/%lldk ", inv[b], fr[b] / 1000);
+          fprintf(stderr, "\n");
+        }
+      }
     }
 
     // ---- blocks, gap-fill jobs, next level ----
