@@ -338,13 +338,9 @@ __device__ __forceinline__ int kw_append_sign(int acc, int v) {  // (acc << 1) |
 }
 
 template <bool MASK>
-__device__ __forceinline__ unsigned kw_cells(KwLane &L, const char *mBytes, int d, int twoK, int leftPrev,
+__device__ __forceinline__ unsigned kw_cells(KwLane &L, const int (&m)[kKwC], int info, int d, int twoK, int leftPrev,
                                              const KwPenalties &P) {
-  const int qoff = L.info & 0xff;
-  const int hpExtAdd = (L.info & ~0xff) + P.hpExt;  // + kKbInf outside a homopolymer
-  int m[kKwC];
-#pragma unroll
-  for (int c = 0; c < kKwC; c++) m[c] = *reinterpret_cast<const int *>(mBytes + qoff + L.tb[c]);
+  const int hpExtAdd = (info & ~0xff) + P.hpExt;  // + kKbInf outside a homopolymer
   const int x = d - L.eTop0, y = x - twoK;
   int diag = leftPrev, left = L.leftIn;
   int pack = 0;
@@ -377,24 +373,40 @@ __device__ __forceinline__ unsigned kw_cells(KwLane &L, const char *mBytes, int 
   return (unsigned)pack;
 }
 
+// the four substitution scores of a step: the row's query base against the lane's target bases (25 ints in LDS)
+__device__ __forceinline__ void kw_lookup(const KwLane &L, const char *mBytes, int info, int (&m)[kKwC]) {
+  const int qoff = info & 0xff;
+#pragma unroll
+  for (int c = 0; c < kKwC; c++) m[c] = *reinterpret_cast<const int *>(mBytes + qoff + L.tb[c]);
+}
+
 // eight steps d0 .. d0 + 7 of a strip; returns the lane's 16 bytes of arrows (dword j: steps 2j, 2j+1; a step's
-// four columns, column 0 in the highest nibble of its half)
+// four columns, column 0 in the highest nibble of its half).  The substitution scores of step d + 1 are looked up while
+// step d computes (the row's base reaches the lane one step ahead of the row), so that only the first step of a group
+// waits for LDS.
 template <bool RAMP, bool MASK>
 __device__ __forceinline__ uint4 kw_group(KwLane &L, const char *mBytes, int d0, int lane, int nRows, int twoK,
                                           const KwPenalties &P, int qBlock, int bBlock, int &outB, int32_t *bOut) {
   unsigned acc[4] = {0, 0, 0, 0};
+  int info = wave_shr1(L.info, __builtin_amdgcn_readlane(qBlock, d0 & 63));
+  int m[kKwC];
+  kw_lookup(L, mBytes, info, m);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int d = d0 + r;
-    const int newInfo = __builtin_amdgcn_readlane(qBlock, d & 63), edgeS = __builtin_amdgcn_readlane(bBlock, d & 63);
-    L.info = wave_shr1(L.info, newInfo);
+    int infoNext = info, mNext[kKwC] = {0, 0, 0, 0};
+    if (r < 7) {
+      infoNext = wave_shr1(info, __builtin_amdgcn_readlane(qBlock, (d + 1) & 63));
+      kw_lookup(L, mBytes, infoNext, mNext);
+    }
+    const int edgeS = __builtin_amdgcn_readlane(bBlock, d & 63);
     const int leftPrev = L.leftIn;
     L.leftIn = wave_shr1(L.pS[kKwC - 1], edgeS);
     unsigned pack = 0;
     if (RAMP) {
-      if ((unsigned)(d - lane) < (unsigned)nRows) pack = kw_cells<MASK>(L, mBytes, d, twoK, leftPrev, P);
+      if ((unsigned)(d - lane) < (unsigned)nRows) pack = kw_cells<MASK>(L, m, info, d, twoK, leftPrev, P);
     } else {
-      pack = kw_cells<MASK>(L, mBytes, d, twoK, leftPrev, P);
+      pack = kw_cells<MASK>(L, m, info, d, twoK, leftPrev, P);
     }
     acc[r >> 1] = (acc[r >> 1] << 16) | pack;
     asm volatile("" : "+v"(acc[r >> 1]));  // the arrow word is built here, not sunk to the store after the eighth step
@@ -407,8 +419,12 @@ __device__ __forceinline__ uint4 kw_group(KwLane &L, const char *mBytes, int d0,
         if (lane <= (rr & 63)) bOut[(rr & ~63) + lane] = outB;
       }
     }
+    info = infoNext;
+#pragma unroll
+    for (int c = 0; c < kKwC; c++) m[c] = mNext[c];
     __builtin_amdgcn_sched_barrier(0);
   }
+  L.info = info;
   return make_uint4(acc[0], acc[1], acc[2], acc[3]);
 }
 
