@@ -117,7 +117,9 @@ struct KbandArgs {
   RefineResult *results;
   int32_t *bound;            // wide only: per task nw + 1 columns of (qLen + 2) scores, a strip's last column
   const int64_t *boundOff;
-  int64_t cellsPerWave;      // wide only: a task gets ceil(its cells / this) wavefronts, at most blockDim / 64
+  int64_t cellsPerWave;      // wide only: a task gets its cells / this wavefronts (rounded as waveRound says), at most blockDim / 64
+  int64_t waveRound;         // added before the division: cellsPerWave - 1 rounds up, cellsPerWave / 2 to the nearest
+  int maxWaves;              // no task gets more (the column buffers between strips are sized for this many + 1)
 };
 
 __global__ __launch_bounds__(256) void kband_fill_kernel(KbandArgs a) {
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(1024) void kband_wide_kernel(KbandArgs a) {
   if (g.status != 0 || !g.wide) return;
   // wavefronts of this task: by its size, so that the launch's wavefronts all carry about the same number of cells (one
   // outlier -- a candidate whose SDP alignment drifted far -- would otherwise run long after the others have finished)
-  const int nw = (int)min((int64_t)min((int)(blockDim.x >> 6), g.nStrips),
-                          max((int64_t)1, (g.realCells + a.cellsPerWave / 2) / a.cellsPerWave));
+  const int nw = (int)min((int64_t)min(min((int)(blockDim.x >> 6), a.maxWaves), g.nStrips),
+                          max((int64_t)1, (g.realCells + a.waveRound) / a.cellsPerWave));
   if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x] * 4;
   if (threadIdx.x < 16) {
     progress.strip[threadIdx.x] = (int)threadIdx.x - nw;  // "the strip before my first": nothing of strip w is there yet
@@ -1044,6 +1046,20 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   };
   std::vector<Chunk> chunks;
   int64_t maxBytes = 0;
+  // The strip kernel's chunks run as TWO lanes, each on a half of the workspace and on a stream of its own (even chunks /
+  // odd chunks): a chunk ends in a tail -- its largest task has all its wavefronts in one workgroup, i.e. on one CU, and
+  // runs long after the others are done (578 ms for a chunk whose work is 245 ms at configs[4]) -- and the other lane's
+  // chunk fills the device under it.  One chunk (everything fits) stays one chunk.
+  bool twoLanes = false;
+  if (!lp) {
+    int64_t need = 0;
+    for (int i = 0; i < n; i++)
+      if (geo[i].status == 0)
+        need += ((geo[i].arrowBytes + 255) & ~(int64_t)255) + 4 * ((geo[i].arenaWords + 63) & ~(int64_t)63) +
+                (geo[i].wide ? 4 * (((nw + 1) * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
+    twoLanes = need > limit && !getenv("BLASR_HIP_KBAND_ONE_LANE");
+  }
+  const int64_t chunkLimit = twoLanes ? limit / 2 : limit;
   for (int i = 0; i < n;) {
     Chunk c{i, 0, 0, 0, 0, false};
     while (i < n) {
@@ -1053,7 +1069,7 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
       const int64_t sw = lp ? (((int64_t)geo[i].nCols + 2 * ((int64_t)geo[i].qLen + 1) + 63) & ~(int64_t)63)
                             : (geo[i].wide ? (((nw + 1) * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
       if (geo[i].wide) c.wide = true;
-      if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw + c.scoreWords + sw) > limit) break;
+      if (c.count > 0 && c.arrowBytes + ab + 4 * (c.arenaWords + aw + c.scoreWords + sw) > chunkLimit) break;
       if (ab + 4 * (aw + sw) > limit)
         return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "kband: task %d needs %lld bytes of workspace", i,
                               (long long)(ab + 4 * (aw + sw)));
@@ -1069,6 +1085,20 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     maxBytes = std::max(maxBytes, c.arrowBytes + 4 * (c.arenaWords + c.scoreWords) + 1024);
     chunks.push_back(c);
   }
+  if (twoLanes) {  // the chunks whose largest task is largest first: the long tails then lie under later chunks, not at the end
+    auto largest_of = [&](const Chunk &c) {
+      int64_t m = 0;
+      for (int i = c.first; i < c.first + c.count; i++)
+        if (geo[i].status == 0) m = std::max(m, geo[i].realCells);
+      return m;
+    };
+    std::vector<std::pair<int64_t, Chunk>> keyed;
+    for (const Chunk &c : chunks) keyed.emplace_back(-largest_of(c), c);
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int64_t, Chunk> &x, const std::pair<int64_t, Chunk> &y) { return x.first < y.first; });
+    for (size_t i = 0; i < chunks.size(); i++) chunks[i] = keyed[i].second;
+  }
+  const int64_t laneBytes = (maxBytes + 255) & ~(int64_t)255;  // a lane's share of the workspace
+  if (twoLanes) maxBytes = 2 * laneBytes;
   if (ctx->workspaceBytes < (size_t)maxBytes) {
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     ctx->workspace = nullptr;
@@ -1097,7 +1127,31 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
       tb.algorithmic_bytes += (int64_t)geo[i].qLen + geo[i].tLen;
     }
   }
-  hipEvent_t *ev = ctx->events;  // the context's own (one call at a time per context)
+  hipEvent_t *ev = ctx->events;  // the context's own (one call at a time per context): six per lane
+  int inFlight[2] = {-1, -1};    // the chunk each lane is working on
+  // waits for a lane's chunk and adds its kernels' times to the records
+  auto collect = [&](int ci, int laneIx) -> int {
+    const Chunk &cc = chunks[(size_t)ci];
+    hipEvent_t *lev = ev + 6 * laneIx;
+    HIP_TRY(ctx, hipStreamSynchronize(laneIx ? ctx->sideStream : ctx->stream));
+    float t = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&t, lev[0], lev[1]));
+    if (ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].candidates > 0) {
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].ms += t;
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].launches += 1;
+    }
+    if (cc.wide) {
+      HIP_TRY(ctx, hipEventElapsedTime(&t, lev[2], lev[3]));
+      if (getenv("BLASR_HIP_KBAND_TRACE")) fprintf(stderr, "[kband]   chunk %d: strip kernel %.1f ms\n", ci, t);
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ms += t;
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].launches += 1;
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ext0 = nw;  // most wavefronts a task could get
+      HIP_TRY(ctx, hipEventElapsedTime(&t, lev[4], lev[5]));
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].ms += t;
+      ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].launches += 1;
+    }
+    return BLASR_HIP_OK;
+  };
   for (const Chunk &c : chunks) {
     if (lp) {
       KbandLinearArgs a;
@@ -1128,6 +1182,16 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
       HIP_TRY(ctx, hipStreamSynchronize(st));  // the next chunk reuses the workspace
       continue;
     }
+    // ---- AffineKBandAlign: chunk ci on lane ci & 1 (its half of the workspace, its stream, its six events)
+    const int ci = (int)(&c - chunks.data());
+    const int laneIx = twoLanes ? (ci & 1) : 0;
+    hipStream_t ls = laneIx ? ctx->sideStream : st;
+    hipEvent_t *lev = ev + 6 * laneIx;
+    char *wsBase = ctx->workspace + (twoLanes ? laneIx * laneBytes : 0);
+    if (inFlight[laneIx] >= 0) {  // the lane's chunk before this one: its times, before its events are recorded again
+      const int rcPrev = collect(inFlight[laneIx], laneIx);
+      if (rcPrev) return rcPrev;
+    }
     KbandArgs a;
     a.first = c.first;
     a.count = c.count;
@@ -1141,62 +1205,68 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
     a.seq = b->seq;
     a.qOff = b->q_off;
     a.tOff = b->t_off;
-    a.arrows = reinterpret_cast<uint8_t *>(ctx->workspace);
+    a.arrows = reinterpret_cast<uint8_t *>(wsBase);
     a.arrowOff = static_cast<int64_t *>(dArrowOff.p);
-    a.arena = reinterpret_cast<uint32_t *>(ctx->workspace + c.arrowBytes);
+    a.arena = reinterpret_cast<uint32_t *>(wsBase + c.arrowBytes);
     a.arenaOff = static_cast<int64_t *>(dArenaOff.p);
     a.opsStart = static_cast<int32_t *>(dOpsStart.p);
     a.results = dResults;
-    a.bound = reinterpret_cast<int32_t *>(ctx->workspace + c.arrowBytes + 4 * c.arenaWords);
+    a.bound = reinterpret_cast<int32_t *>(wsBase + c.arrowBytes + 4 * c.arenaWords);
     a.boundOff = static_cast<int64_t *>(dScoreOff.p);
     a.cellsPerWave = 1;
-    HIP_TRY(ctx, hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
-    HIP_TRY(ctx, hipEventRecord(ev[1], st));
+    a.waveRound = 0;
+    a.maxWaves = nw;
+    if (ci == 0 && twoLanes) {  // the side stream starts behind what the main one has queued so far (plan, uploads)
+      HIP_TRY(ctx, hipEventRecord(ctx->auxEvent[0], st));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ctx->auxEvent[0], 0));
+    }
+    HIP_TRY(ctx, hipEventRecord(lev[0], ls));
+    hipLaunchKernelGGL(kband_fill_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, ls, a);
+    HIP_TRY(ctx, hipEventRecord(lev[1], ls));
     if (c.wide) {
-      // about kKwWaves wavefronts in all (83 registers: 5 per SIMD, 5120 on the chip), each with the same share of cells
+      // about 4096 wavefronts in all (89 registers: 5 per SIMD, 5120 on the chip), each with the same share of cells
       int64_t chunkCells = 0, largest = 0;
       for (int i = c.first; i < c.first + c.count; i++)
         if (geo[i].status == 0 && geo[i].wide) {
           chunkCells += geo[i].realCells;
           largest = std::max(largest, geo[i].realCells);
         }
-      int targetWaves = 4096;  // four per SIMD: 1.26 Tcells/s at 3072-4096, 0.98 at 5120 and beyond (1024 30 kb reads, k = 2.7 k)
+      int targetWaves = 4096;  // four per SIMD: 1.26 Tcells/s at 3072-4096, 0.98 at 5120 and beyond (1024 reads of 30 kb, k = 2.7 k);
+                               // with two lanes 4096 per lane again (refine stage of configs[4]: 929 ms against 1076 at 3072)
       if (const char *e = getenv("BLASR_HIP_KBAND_TARGET_WAVES")) targetWaves = std::max(1, atoi(e));
       a.cellsPerWave = std::max<int64_t>(chunkCells / targetWaves, 1 << 20);
       if (getenv("BLASR_HIP_KBAND_WAVES")) a.cellsPerWave = 1;  // experiments: every task gets nwMax wavefronts
-      const int nwLaunch = (int)std::min<int64_t>(nw, std::max<int64_t>(1, (largest + a.cellsPerWave / 2) / a.cellsPerWave));
-      HIP_TRY(ctx, hipMemsetAsync(a.bound, 0, (size_t)(4 * c.scoreWords), st));
-      HIP_TRY(ctx, hipEventRecord(ev[2], st));
-      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)c.count), dim3((unsigned)(64 * nwLaunch)), 0, st, a);
-      HIP_TRY(ctx, hipEventRecord(ev[3], st));
+      a.waveRound = a.cellsPerWave / 2;
+      const int nwLaunch = (int)std::min<int64_t>(nw, std::max<int64_t>(1, (largest + a.waveRound) / a.cellsPerWave));
+      if (getenv("BLASR_HIP_KBAND_TRACE"))
+        fprintf(stderr, "[kband] chunk %d (lane %d) of %d tasks, %.1f Gcells (largest %.2f), %lld cells per wavefront, workgroups of "
+                        "%d wavefronts\n", ci, laneIx, c.count, chunkCells / 1e9, largest / 1e9, (long long)a.cellsPerWave, nwLaunch);
+      HIP_TRY(ctx, hipMemsetAsync(a.bound, 0, (size_t)(4 * c.scoreWords), ls));
+      HIP_TRY(ctx, hipEventRecord(lev[2], ls));
+      hipLaunchKernelGGL(kband_wide_kernel, dim3((unsigned)c.count), dim3((unsigned)(64 * nwLaunch)), 0, ls, a);
+      HIP_TRY(ctx, hipEventRecord(lev[3], ls));
     }
-    hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(kband_traceback_kernel, dim3((unsigned)((c.count + 63) / 64)), dim3(64), 0, ls, a);
     if (c.wide) {
-      HIP_TRY(ctx, hipEventRecord(ev[4], st));
-      hipLaunchKernelGGL(kband_wide_traceback_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, st, a);
-      HIP_TRY(ctx, hipEventRecord(ev[5], st));
+      HIP_TRY(ctx, hipEventRecord(lev[4], ls));
+      hipLaunchKernelGGL(kband_wide_traceback_kernel, dim3((unsigned)((c.count + 3) / 4)), dim3(256), 0, ls, a);
+      HIP_TRY(ctx, hipEventRecord(lev[5], ls));
     }
-    launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), st);
-    launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, st);
-    HIP_TRY(ctx, hipStreamSynchronize(st));  // the kernels' times; the next chunk reuses the workspace
-    {
-      float t = 0;
-      HIP_TRY(ctx, hipEventElapsedTime(&t, ev[0], ev[1]));
-      if (ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].candidates > 0) {
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].ms += t;
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_ROWS].launches += 1;
-      }
-      if (c.wide) {
-        HIP_TRY(ctx, hipEventElapsedTime(&t, ev[2], ev[3]));
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ms += t;
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].launches += 1;
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_STRIPS].ext0 = nw;  // most wavefronts a task could get
-        HIP_TRY(ctx, hipEventElapsedTime(&t, ev[4], ev[5]));
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].ms += t;
-        ctx->kernelRec[BLASR_HIP_KERNEL_KBAND_TRACEBACK].launches += 1;
-      }
+    // the op lists go to the caller's arena in chunk order: this chunk's scan starts from the total the one before left
+    if (ci > 0 && twoLanes) HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->auxEvent[1 + ((ci - 1) & 1)], 0));
+    launch_scan_ops(dResults, c.first, c.count, ops_capacity, static_cast<int64_t *>(dTotal.p), ls);
+    launch_compact_ops(dResults, c.first, c.count, a.arena, a.arenaOff, a.opsStart, ops, ls);
+    if (twoLanes) HIP_TRY(ctx, hipEventRecord(ctx->auxEvent[1 + (ci & 1)], ls));
+    inFlight[laneIx] = ci;
+  }
+  for (int laneIx = 0; laneIx < 2; laneIx++)
+    if (inFlight[laneIx] >= 0) {
+      const int rcLast = collect(inFlight[laneIx], laneIx);
+      if (rcLast) return rcLast;
     }
+  if (twoLanes) {  // the main stream goes on behind the side stream's last chunk
+    HIP_TRY(ctx, hipEventRecord(ctx->auxEvent[0], ctx->sideStream));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->auxEvent[0], 0));
   }
   int64_t total = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&total, dTotal.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--workspace-gb", type=float, default=100.0)
     ap.add_argument("--check", type=int, default=0, help="compare this many results with the oracle")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--k-spread", type=float, default=0.0, help="k of task i = k * exp(N(0, spread)): the bands of a real batch differ")
     args = ap.parse_args()
     if args.waves:
         os.environ["BLASR_HIP_KBAND_WAVES"] = str(args.waves)
@@ -31,12 +32,15 @@ def main():
     distinct = min(args.reads, 64)  # the kernels' time does not depend on the bases; the generator's does
     base = [synth.make_pair(rng, args.len, ins=0.10, dele=0.05, sub=0.01, flank=(0, 0)) for _ in range(distinct)]
     pairs = [base[i % distinct] for i in range(args.reads)]
+    ks = [args.k] * len(pairs)
+    if args.k_spread > 0:
+        ks = [max(10, int(args.k * float(np.exp(rng.normal(0, args.k_spread))))) for _ in pairs]
     ctx = blasr_amd.Context(0)
     ctx.set_workspace_limit(int(args.workspace_gb * (1 << 30)))
     out = []
     for it in range(args.repeat):
         t0 = time.time()
-        res = ctx.kband(pairs, [args.k] * len(pairs))
+        res = ctx.kband(pairs, ks)
         wall = time.time() - t0
         recs = ctx.last_kernels()
         for r in recs:
