@@ -710,7 +710,7 @@ def main():
                            "not a scaling measurement" % (world, n_dev, "" if n_dev == 1 else "s"))
         build = hip.build_id()
         out["build_id"] = build
-        pmc_path, pmc = pmc_for(args.config, n_reads, d["read_len"], args.band, build)
+        pmc_path, pmc = pmc_for(args.config, n_reads, d["read_len"], args.kband if args.no_guided else args.band, build)
         cyc = VALU_CYCLES["slow"] * VALU_CYCLES["slow_share"] + VALU_CYCLES["fast"] * (1 - VALU_CYCLES["slow_share"])
         lines = []
         for name, a in kacc.items():

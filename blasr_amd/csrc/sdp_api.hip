@@ -742,7 +742,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   int64_t largestAcc = 0;
   double largestPerBase = 0;
   while (first < n) {
-    int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 8.0)), 1 << 16);
+    int64_t budgetBases = std::max<int64_t>((int64_t)(blasr_hip_workspace_reach(ctx) / std::max(ctx->sdpBytesPerBase, 16.0)), 1 << 16);
     if (forced) budgetBases = std::max<int64_t>(atoll(forced), 1);
     else {  // what is left, in pieces of about the same size: every piece pays the levels' tails once
       int64_t remaining = 0;
@@ -770,7 +770,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
                                     left, &usedHere, used, &arenaHigh);
     if (getenv("BLASR_HIP_SDP_TRACE"))
       fprintf(stderr, "[sdp] piece of %d candidates, %lld bases: arena high-water %.2f GB (%.1f B per base), planned with %.1f B per base, rc %d\n", cnt,
-              (long long)acc, (double)arenaHigh / 1e9, acc > 0 ? (double)arenaHigh / (double)acc : 0.0, std::max(ctx->sdpBytesPerBase, 8.0), rc);
+              (long long)acc, (double)arenaHigh / 1e9, acc > 0 ? (double)arenaHigh / (double)acc : 0.0, std::max(ctx->sdpBytesPerBase, 16.0), rc);
     if (acc > 0 && arenaHigh > 0 && !forced) {  // (an aborted piece reports what it had asked for so far: a lower bound)
       ctx->sdpBytesPerBase = std::max(ctx->sdpBytesPerBase * (rc == BLASR_HIP_OK ? 0.5 : 1.0), 1.25 * (double)arenaHigh / (double)acc);
       // what the NEXT call plans with is the figure of this call's largest piece: a small last piece carries the
