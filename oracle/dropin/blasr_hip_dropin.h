@@ -247,6 +247,115 @@ static void RefineAlignmentsGPU(T_Sequence &query, std::vector<T_AlignmentCandid
   if (params.sortRefinedAlignments)  // Blasr.cpp:2178-2180
     std::sort(alignmentPtrs.begin(), alignmentPtrs.end(), SortAlignmentPointersByScore());
 }
+// The loop of RefineAlignments under -noUseGuidedAlign: RefineAlignment's k-band branch (Blasr.cpp:917-1046) for all
+// candidates of the read in one batch.  The host does what the branch does around its one heavy call -- ComputeDrift (the
+// reference's own function), the trimming (:968-981), the band rule (:990-1003), the bookkeeping of :1005-1043 -- and
+// PairwiseLocalAlign's AffineKBandAlign (:695-703) runs on the device.  The statistics are the reference's own
+// ComputeAlignmentStats in the non-affine form PairwiseLocalAlign uses (:740), but with the score matrix in place: the
+// reference makes that call with a matrix it never initialised (:689-690), so its score there is uninitialised memory.
+template <typename T_Sequence>
+static void RefineAlignmentsKBandGPU(T_Sequence &query, std::vector<T_AlignmentCandidate *> &alignmentPtrs,
+                                     MappingParameters &params) {
+  std::vector<uint8_t> seq;
+  std::vector<int64_t> qOff, tOff;
+  std::vector<int32_t> qLen, tLen, kBand, owner;
+  for (UInt i = 0; i < alignmentPtrs.size(); i++) {
+    T_AlignmentCandidate &c = *alignmentPtrs[i];
+    if (c.blocks.size() == 0) {  // :959-962
+      c.score = 0;
+      continue;
+    }
+    const int drift = ComputeDrift(c);
+    const int last = (int)c.blocks.size() - 1;
+    const DNALength qn = c.blocks[last].qPos + c.blocks[last].length;                       // :968-972 (qIsSubstring)
+    const DNALength tn = c.blocks[last].tPos + c.blocks[last].length - c.blocks[0].tPos;   // :979-981
+    int k = params.bandSize == 0 ? (int)(abs(drift) * 1.5) : params.bandSize;               // :990-996
+    if (k < 10) k = 10;                                                                     // :1001-1003
+    qOff.push_back(seq.size());
+    qLen.push_back(qn);
+    seq.insert(seq.end(), &query.seq[c.qAlignedSeqPos + c.qPos], &query.seq[c.qAlignedSeqPos + c.qPos] + qn);
+    tOff.push_back(seq.size());
+    tLen.push_back(tn);
+    seq.insert(seq.end(), &c.tAlignedSeq.seq[c.tPos], &c.tAlignedSeq.seq[c.tPos] + tn);
+    kBand.push_back((int)(k * 1.2));                                                        // :699
+    owner.push_back((int32_t)i);
+  }
+  const int n = (int)owner.size();
+  if (n > 0) {
+    blasr_hip_kband_batch batch = {n, seq.data(), qOff.data(), qLen.data(), tOff.data(), tLen.data(), kBand.data()};
+    blasr_hip_kband_params kp;  // :695-699
+    for (int a = 0; a < 5; a++)
+      for (int b = 0; b < 5; b++) kp.matrix[a * 5 + b] = SMRTDistanceMatrix[a][b];
+    kp.hp_ins_open = params.indel + 2;
+    kp.hp_ins_extend = params.indel - 3;
+    kp.ins_open = params.indel + 2;
+    kp.ins_extend = params.indel - 1;
+    kp.del = params.indel;
+    std::vector<blasr_hip_refine_result> res(n);
+    std::vector<uint32_t> ops(seq.size() + 4 * (size_t)n + 16);
+    int64_t used = 0;
+    int rc = blasr_hip_kband_host(tlsHipCtx, &batch, &kp, res.data(), ops.data(), (int64_t)ops.size(), &used);
+    if (rc != BLASR_HIP_OK) {
+      cout << "ERROR, GPU k-band refine failed: " << blasr_hip_last_error(tlsHipCtx) << endl;
+      exit(1);
+    }
+    DistanceMatrixScoreFunction<DNASequence, FASTQSequence> distScoreFn;
+    params.InitializeScoreFunction(distScoreFn);
+    distScoreFn.InitializeScoreMatrix(SMRTDistanceMatrix);  // (what :689-690 leaves out)
+    for (int j = 0; j < n; j++) {
+      T_AlignmentCandidate &c = *alignmentPtrs[owner[j]];
+      if (res[j].status) {
+        cout << "ERROR, the k-band refiner rejected a candidate (status " << res[j].status << ")" << endl;
+        exit(1);
+      }
+      // :1005-1043: the candidate now describes the trimmed sequences
+      DNASequence tSeq;
+      tSeq.Copy(c.tAlignedSeq, c.tPos, tLen[j]);
+      FASTQSequence qSeq;
+      qSeq.ReferenceSubstring(query, c.qAlignedSeqPos + c.qPos, qLen[j]);
+      const VectorIndex lastSDPBlock = c.blocks.size() - 1;
+      c.tAlignedSeqPos += c.tPos;
+      c.tAlignedSeqLength = c.blocks[lastSDPBlock].tPos + c.blocks[lastSDPBlock].length - c.blocks[0].tPos;
+      c.tPos = 0;
+      c.qAlignedSeqPos += c.qPos;
+      c.qAlignedSeqLength = c.blocks[lastSDPBlock].qPos + c.blocks[lastSDPBlock].length - c.blocks[0].qPos;
+      c.qPos = 0;
+      c.blocks.clear();
+      c.tAlignedSeq.Free();
+      c.tAlignedSeq.TakeOwnership(tSeq);
+      c.ReassignQSequence(qSeq);
+      // PairwiseLocalAlign: the arrow path as ArrowPathToAlignment leaves it (Alignment.h:190-254: a gap list in front of
+      // the first block and one behind every block, the last one empty)
+      c.gaps.clear();
+      c.gaps.push_back(GapList());
+      DNALength q = 0, t = 0;
+      for (int o = 0; o < res[j].n_ops; o++) {
+        uint32_t op = ops[res[j].ops_off + o], len = BLASR_HIP_OP_LEN(op);
+        if (BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_M) {
+          Block b;
+          b.qPos = q;
+          b.tPos = t;
+          b.length = len;
+          c.blocks.push_back(b);
+          c.gaps.push_back(GapList());
+          q += len;
+          t += len;
+        } else if (BLASR_HIP_OP_TYPE(op) == BLASR_HIP_OP_I) {
+          c.gaps.back().push_back(Gap(Gap::Target, len));
+          q += len;
+        } else {
+          c.gaps.back().push_back(Gap(Gap::Query, len));
+          t += len;
+        }
+      }
+      c.score = res[j].dp_score;  // :705
+      ComputeAlignmentStats(c, c.qAlignedSeq.seq, c.tAlignedSeq.seq, distScoreFn);  // :740
+    }
+  }
+  if (params.sortRefinedAlignments)  // Blasr.cpp:2178-2180
+    std::sort(alignmentPtrs.begin(), alignmentPtrs.end(), SortAlignmentPointersByScore());
+}
+
 // Replaces ExtendAlignmentForward / ExtendAlignmentReverse under -extend (Blasr.cpp:1826-1838, 1885-1897): one call, one
 // task.  The arrow path comes back as ops; the alignment is rebuilt with the reference's own ArrowPathToAlignment.
 template <typename T_Query, typename T_Ref>
@@ -380,6 +489,7 @@ static void BlasrHipMapBlock(BlasrHipBlock &blk, T_GenomeSeq &genome, T_SuffixAr
   pp.map.sdp = sp;
   BlasrHipScoreParams(params, pp.map.score);
   pp.map.band = params.bandSize;
+  pp.map.use_guided_align = params.useGuidedAlign ? 1 : 0;  // -noUseGuidedAlign: RefineAlignment's k-band branch on the device
   pp.map.n_candidates = params.nCandidates;
   pp.map.max_gap = params.maxGap;
   pp.map.max_score = params.maxScore;

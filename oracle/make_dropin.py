@@ -8,7 +8,8 @@ committed: oracle/_ref is git-ignored), adds oracle/dropin/blasr_hip_dropin.h (t
   Blasr.cpp             #include of the helper before AlignIntervals
                         AlignIntervals (:1716-1724)   SDPAlign + ComputeAlignmentStats -> SDPAlignCandidateGPU under -useGPU
                         AlignIntervals (:1826, :1885) ExtendAlignmentForward / Reverse (-extend) -> ExtendAlignmentGPU under -useGPU
-                        RefineAlignments (:2164-2181) the per-candidate loop -> RefineAlignmentsGPU under -useGPU
+                        RefineAlignments (:2164-2181) the per-candidate loop -> RefineAlignmentsGPU (guided) or RefineAlignmentsKBandGPU
+                                                      (-noUseGuidedAlign) under -useGPU
                         MapRead (:2279-2297)          the two MapReadToGenome calls -> MapReadToGenomeGPU under -useGPU
                         MapReads (:3238)              one blasr_hip context per mapping thread, next to MappingBuffers
                         MapReads (:3253, :3470)       -gpuBatch B: reads are pulled B at a time and mapped by ONE library call
@@ -63,7 +64,8 @@ def main():
           "        } else {\n" + m.group(0) + "        }\n" + bl[m.end():])
     bl = patch_once(bl, "  UInt i;\n  for (i = 0; i < alignmentPtrs.size(); i++ ) {\n    RefineAlignment(*bothQueryStrands[0], genome, "
                         "*alignmentPtrs[i], params, mappingBuffers);\n  }\n",
-                    "  if (params.useGPU) {\n    RefineAlignmentsGPU(*bothQueryStrands[0], alignmentPtrs, params);\n    return;\n  }\n"
+                    "  if (params.useGPU and !params.doGlobalAlignment) {\n    if (params.useGuidedAlign) RefineAlignmentsGPU(*bothQueryStrands[0], "
+                    "alignmentPtrs, params);\n    else RefineAlignmentsKBandGPU(*bothQueryStrands[0], alignmentPtrs, params);\n    return;\n  }\n"
                     "  UInt i;\n  for (i = 0; i < alignmentPtrs.size(); i++ ) {\n    RefineAlignment(*bothQueryStrands[0], genome, "
                     "*alignmentPtrs[i], params, mappingBuffers);\n  }\n", "RefineAlignments")
     bl = patch_once(bl, "    if (params.useSuffixArray) {\n      params.anchorParameters.lcpBoundsOutPtr = mapData->lcpBoundsOutPtr;\n",

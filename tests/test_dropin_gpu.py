@@ -89,6 +89,36 @@ def test_patched_reference_binary_mapping_blocks_of_reads(tmp_path, extra):
     assert not bad, bad[:3]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["-nproc", "2"], ["-gpuBatch", "16", "-nproc", "2"]])
+def test_patched_reference_binary_with_the_kband_refiner(tmp_path, extra):
+    """-useGPU -noUseGuidedAlign: RefineAlignment's k-band branch (Blasr.cpp:917-1046) through blasr_hip_kband_host
+    (per-read mode) or inside the mapping call (-gpuBatch, use_guided_align = 0).  The unpatched binary computes that
+    branch's score with an uninitialised matrix (Blasr.cpp:689-690): its score column is stack garbage and a third of
+    the reads fail its score cut-off on it (tests/golden/make_m4_noisy_nonguided_golden.py).  So: all 80 reads print
+    here, with a score that is the alignment's; the two modes and two runs print the same lines; and where the unpatched
+    binary printed the same candidate its identity and its four coordinates are ours."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/blasrmc_gpu not built (needs /root/reference at build time)")
+    write_inputs(str(tmp_path))
+    ref = bytes(np.load(os.path.join(ROOT, "tests", "golden", "m4_noisy_nonguided_golden.npz"))["lines"]).decode().splitlines()
+    p, got = run(str(tmp_path), ["-useGPU", "-noUseGuidedAlign"] + extra)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    assert len(got) == 80
+    p2, again = run(str(tmp_path), ["-useGPU", "-noUseGuidedAlign", "-nproc", "1"])
+    assert p2.returncode == 0 and again == got
+    ours = {line.split()[0]: line.split() for line in got}
+    same = 0
+    for line in ref:
+        f = line.split()
+        g = ours[f[0]]
+        assert -40000 < int(g[2]) < 0  # (a score of this alignment, not of the stack)
+        if (f[1], f[4], f[8]) == (g[1], g[4], g[8]) and abs(int(f[9]) - int(g[9])) < 2000:  # the same candidate
+            assert f[3:12] == g[3:12], (line, " ".join(g))
+            same += 1
+    assert same >= len(ref) // 2  # (36 of 54; the others are candidates the garbage score preferred)
+
+
 def test_patched_reference_binary_without_the_flag_is_the_reference(tmp_path):
     """Without -useGPU the patched binary takes the reference's own code (the patch only adds branches), and with it
     but without a device it fails loudly instead of falling back."""
