@@ -279,6 +279,8 @@ const char *blasr_hip_kernel_name(int kind, int ext0) {
       return ext0 ? "blasr_hip::fillp_kernel<16, true, true>" : "blasr_hip::fillp_kernel<16, false, true>";
     case BLASR_HIP_KERNEL_FILL_WAVE:
       return "blasr_hip::fill_kernel";
+    case BLASR_HIP_KERNEL_FILL_EIGHT:
+      return "blasr_hip::fill8_kernel";
     case BLASR_HIP_KERNEL_TRACEBACK:
       return "blasr_hip::traceback_kernel<8>";
     case BLASR_HIP_KERNEL_KBAND_STRIPS:
@@ -598,6 +600,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     // The few candidates with rows too wide for LDS (global ring) are a long, thin kernel: it goes on the side
     // stream, underneath fill_kernel's launch (after fillp_kernel when that runs, so its launch is timed alone).
     bool wideLaunched = false, timedFill4 = false, timedWide = false, timedFill1 = false;
+    int timedNarrowKind = BLASR_HIP_KERNEL_FILL_NARROW;
     auto launch_wide = [&]() -> int {
       if (c.wideTasks.empty()) return 0;
       int nw = (int)c.wideTasks.size();
@@ -764,16 +767,21 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         f4.taskList = dList4;
         f4.count = (int)list4.size();
         HIP_TRY(ctx, hipEventRecord(evF4[0], st));
-        launch_fill4(view, f4, getenv("BLASR_HIP_FILL_LANES8") ? 8 : 16, st);
+        // fill8_kernel's domain: extension penalty 0, matrix entries that fit 6 bits, columns that fit its 20-bit row records
+        bool six = getenv("BLASR_HIP_FILL_LANES16") == nullptr && score->affine_extend == 0 && longest < (1 << 20) - 4096;
+        for (int i = 0; i < 25; i++) six = six && score->matrix[i] >= -32 && score->matrix[i] <= 31;
+        const int narrowKind = six ? BLASR_HIP_KERNEL_FILL_EIGHT : BLASR_HIP_KERNEL_FILL_NARROW;
+        launch_fill4(view, f4, six ? 8 : 16, st);
         HIP_TRY(ctx, hipEventRecord(evF4[1], st));
         timedFill4 = true;
         for (int32_t i : list4) {
           fill4Bytes += geo[i].cells + (int64_t)geo[i].rows + geo[i].tSpan + 8 * (int64_t)geo[i].rows;
           fill4Cells += geo[i].cells;
-          count_fill(BLASR_HIP_KERNEL_FILL_NARROW, geo[i]);
+          count_fill(narrowKind, geo[i]);
         }
         ctx->fill4Launches += 1;
-        ctx->kernelRec[BLASR_HIP_KERNEL_FILL_NARROW].launches += 1;
+        ctx->kernelRec[narrowKind].launches += 1;
+        timedNarrowKind = narrowKind;
       }
       rc = launch_wide();
       if (rc) return rc;
@@ -798,7 +806,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         float t4 = 0;
         (void)hipEventElapsedTime(&t4, evF4[0], evF4[1]);
         ctx->fill4Ms += t4;
-        ctx->kernelRec[BLASR_HIP_KERNEL_FILL_NARROW].ms += t4;
+        ctx->kernelRec[timedNarrowKind].ms += t4;
       }
     } else {
       HIP_TRY(ctx, hipEventRecord(evF1[0], st));

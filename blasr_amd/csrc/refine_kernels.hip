@@ -1291,9 +1291,244 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     args.dpScore[myTask] =
         (kHybrid && myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
 }
+// ---------------------------------------------------------------------------
+// fill8_kernel: the candidates of fillp_kernel<16, true, false> (every row <= kF4MaxWidth cells, extension penalty 0) once
+// more, EIGHT to a wavefront and each AT ITS OWN ROW.
+//
+// 72 % of the narrow rows are the band's own 33 cells and 94 % have at most 40: eight lanes x five cells cover such a row in one
+// pass with 7 idle slots where 16 x 3 has 15, and the per-pass bookkeeping (row record, scan, addresses, stores) is paid once for
+// eight rows.  What made the 8-lane instantiation of fillp_kernel lose was the lockstep: a row beyond the pass width sent the
+// whole wavefront through another pass, and with eight candidates 41 % of the row steps had one.  Here a candidate that needs
+// another pass simply stays on its row while the others go on -- row, pass and carries are per-lane state, the loop runs until the
+// last candidate is through (the list is sorted by rows, so they end together).
+// LDS is what limits the resident wavefronts, so a candidate has exactly 1280 bytes of it (four workgroups per CU):
+//   * the {S, I} ring of 128 columns (1024 bytes), updated in place as in fillp_kernel;
+//   * the staging ring holds the target's CODES x 6, one byte per column (128 bytes); a row's substitution scores are then 6-bit
+//     fields of ONE register, the matrix row of its query base (any query code, N included; matrix entries within [-32, 31],
+//     checked by the caller);
+//   * a window of 16 row records, 8 bytes each (128 bytes): {arrow offset, first column - tStart + 1 : 20 | width : 8 | query
+//     code : 3} (target spans below 2^20, checked by the caller).
+// The loop itself issues no loads from memory (a load inside it would wait for the arrow stores before it, every step): when one
+// candidate has run out of records or of staged columns, ALL of them top up as far as their window / ring holds.
+// The recurrence, the tagged keys and the arrow byte are fillp_kernel's.
+// ---------------------------------------------------------------------------
+constexpr int kF8Pass = 40;
+constexpr int kF8Rows = 16;
+constexpr int kF8Clean = 8;   // = the lanes of a candidate: one entry each
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void fill8_kernel(RefineBatchView batch, FillArgs args) {
+  constexpr int kL = 8, kT = 8, kC = kF8Pass / kL, kPass = kF8Pass;
+  __shared__ int2 ringLds[4][kT][kF4Ring];
+  __shared__ uint8_t ringTLds[4][kT][kF4RingT];
+  __shared__ uint2 rowWin[4][kT][kF8Rows];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int grp = lane / kL, l = lane % kL;
+  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * kT;
+  if (slot0 >= args.count) return;
+  int2 *ring = ringLds[wave][grp];
+  uint8_t *ringT = ringTLds[wave][grp];
+  uint2 *win = rowWin[wave][grp];
+  // lane qc (0..4, N = 4; any other code reads N's) holds the matrix row of query code qc, 6 bits per target code: a row's
+  // register is fetched from that lane (ds_bpermute: the crossbar, no LDS behind it)
+  uint32_t row6Table = 0;
+#pragma unroll
+  for (int tc = 0; tc < 5; tc++) row6Table |= (uint32_t)(args.matrix[min(lane, 4) * 5 + tc] & 0x3f) << (6 * tc);
+
+  int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myBase = 0;
+  const int2 *tab = nullptr;
+  const unsigned short *meta = nullptr;
+  const uint8_t *myTSeq = nullptr;
+  uint8_t *myArrows = nullptr;
+  if (slot0 + grp < args.count) myTask = args.taskList[slot0 + grp];
+  if (myTask >= 0) {
+    const int32_t *blocks = batch.blocks + 3 * batch.blk_off[myTask];
+    const int nBlocks = batch.n_blocks[myTask];
+    GuideCursor cur;
+    guide_begin(cur, blocks, nBlocks, args.band);
+    myQ = cur.Q;
+    myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+    myTLen = batch.t_len[myTask];
+    myTSeq = batch.seq + batch.t_off[myTask];
+    myArrows = args.arrows + args.arrowOff[myTask];
+    tab = args.rowTab + args.rowOff[myTask];
+    meta = args.rowMeta + args.rowOff[myTask];
+    myBase = cur.tStart - 1;
+    myPlo = myBase;
+    myPhi = myPlo + guide_row0_tpost(cur);
+  }
+  const int inf = 1 << 30;
+  const int kIns = args.ins << kShift, kDel = args.del << kShift, kOpen = args.open << kShift;
+  int pDel[kC];
+#pragma unroll
+  for (int j = 0; j < kC; j++) pDel[j] = (kC * l + j) * kDel;
+  // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open
+  // The kF8Clean entries behind a row's last cell are set to "no cell" when the row is done: the next row reads that far beyond
+  // the row above without a test per cell (a row that reaches further sends the wavefront through the tests, below).
+  if (myTask >= 0) {
+    for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+    ring[(myPhi + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);
+  }
+  int myTLoaded = (myPlo < 0 ? 0 : myPlo) & ~3;  // columns below it are staged; whole dwords of codes
+  const int tLast = max(myTLen - 1, 0);
+  __builtin_amdgcn_wave_barrier();
+
+  int myRow = 1, myPass = 0, stagedEnd = 1;  // records of rows below stagedEnd (and not below myRow) are in the window
+  int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
+  bool alive = myTask >= 0 && myRow <= myQ;
+  uint2 recCur = make_uint2(0u, 0u);
+  while (__ballot(alive) != 0ull) {
+    // ---- row records: when one candidate has used up its window, all of them fill theirs
+    if (__ballot(alive && myRow >= stagedEnd) != 0ull) {
+      if (alive) {
+        const int newEnd = min(myRow + kF8Rows, myQ + 1);
+#pragma unroll
+        for (int k = 0; k < kF8Rows / kL; k++) {
+          const int r = stagedEnd + l + kL * k;
+          if (r < newEnd) {
+            const int2 rec = tab[r];
+            const unsigned m = meta[r];
+            win[r & (kF8Rows - 1)] =  // (the query code as the byte address of its lane in row6Table)
+                make_uint2((unsigned)rec.x, (unsigned)(rec.y - myBase) | ((m & 0xffu) << 20) | (min(m >> 12, 4u) << 28));
+          }
+        }
+        stagedEnd = newEnd;
+      }
+      __builtin_amdgcn_wave_barrier();
+      recCur = win[myRow & (kF8Rows - 1)];
+    }
+    const uint2 recNext = win[(myRow + 1) & (kF8Rows - 1)];  // (the row after this one, if the window has it)
+    const int lo = myBase + (int)(recCur.y & 0xfffffu), width = (int)((recCur.y >> 20) & 0xffu);
+    const int hiC = lo + width - 1;
+    // ---- the target's codes: when one candidate has run out, all of them stage as far as their ring holds
+    if (__ballot(alive && hiC >= myTLoaded) != 0ull) {
+      if (alive) {
+        myTLoaded = max(myTLoaded, lo & ~3);
+        const int limit = (lo & ~3) + kF4RingT;  // the first column whose slot still holds one this row may read
+        const int c = myTLoaded + 16 * l;
+        uint32_t b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = (uint32_t)myTSeq[min(c + k, tLast)];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int cc = c + 4 * k4 + k;
+            const int code = cc < myTLen ? base_code(b[4 * k4 + k]) : 4;
+            w |= (uint32_t)(code * 6) << (8 * k);
+          }
+          if (c + 4 * k4 < limit) *reinterpret_cast<uint32_t *>(&ringT[(c + 4 * k4) & (kF4RingT - 1)]) = w;
+        }
+        myTLoaded = min(myTLoaded + 16 * kL, limit);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- one pass of my candidate's row: columns cb .. cb + 39
+    uint8_t *arrowRow = myArrows + recCur.x;
+    const int cb = lo + kPass * myPass, c0 = cb + kC * l;
+    int upS[kC], upI[kC], diagS[kC];
+    int d0 = ring[(c0 - 1) & (kF4Ring - 1)].x;
+    d0 = (myPass > 0 && l == 0) ? carryDiag : d0;  // column cb-1 was overwritten by the pass before
+    d0 = c0 - 1 >= myPlo ? d0 : inf;               // (lane 0 of a row that starts where the row above did)
+    int lastRaw = 0;
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int2 up = ring[(c0 + j) & (kF4Ring - 1)];
+      if (j == kC - 1) lastRaw = up.x;
+      upS[j] = up.x;
+      upI[j] = up.y;
+    }
+    if (__ballot(alive && hiC > myPhi + kF8Clean) != 0ull) {  // (rare) entries beyond the cleaned ones are stale
+      d0 = c0 - 1 <= myPhi ? d0 : inf;
+#pragma unroll
+      for (int j = 0; j < kC; j++) {
+        const bool upValid = c0 + j <= myPhi;  // c >= lo >= plo always
+        upS[j] = upValid ? upS[j] : inf;
+        upI[j] = upValid ? upI[j] : inf;
+      }
+    }
+    diagS[0] = d0;
+#pragma unroll
+    for (int j = 1; j < kC; j++) diagS[j] = upS[j - 1];
+    const uint32_t row6 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((recCur.y >> 26) & 0x1cu), (int)row6Table);
+    int vKey[kC], preA[kC], preB[kC];
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int m = (int)__builtin_amdgcn_sbfe((int)row6, (unsigned)ringT[(c0 + j) & (kF4RingT - 1)], 6);
+      const int matchK = (m << kShift) + diagS[j];
+      const int insSK = upS[j] + (kIns + AR_UP);
+      const int insEK = upI[j] + AR_INS_CLOSE;
+      vKey[j] = min(matchK, min(insSK, insEK));
+      const int v = vKey[j] & ~kTagMask;
+      const int ia = v - pDel[j];
+      preA[j] = j == 0 ? ia : min(preA[j - 1], ia);  // inclusive over this lane's cells
+      preB[j] = j == 0 ? v : min(preB[j - 1], v);
+    }
+    int pa = preA[kC - 1], pb = preB[kC - 1];
+    group_prefix_min2<kL>(pa, pb);  // inclusive over the lanes of the candidate
+    eaKeep = dpp<0x111, 0xf>(eaKeep, pa);
+    ebKeep = dpp<0x111, 0xf>(ebKeep, pb);
+    int ea = l == 0 ? inf : eaKeep, eb = l == 0 ? inf : ebKeep;
+    ea = myPass > 0 ? min(ea, carryA) : ea;
+    eb = myPass > 0 ? min(eb, carryB) : eb;
+    uint32_t arrowLo = 0, arrowHi = 0;
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
+      const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
+      const int aK = eaj + (pDel[j] + AR_LEFT);           // S[c-1] + del
+      const int bK = ebj + (kOpen + AR_DEL_CLOSE);         // D[c-1] + ext
+      const int sKey = min(vKey[j], min(aK, bK));
+      const int sv = sKey & ~kTagMask;
+      const int openKey = sv + (kOpen + AR_I_OPEN);
+      const int iKey = min(openKey, upI[j]);               // (ring entries carry no tag)
+      const int dFlag = openKey < bK ? AR_D_OPEN : 0;
+      // the arrow byte = the tags of the three keys (S tags in bits 0-2, the open flags in bits 3-4, nothing else below
+      // kShift): the OR of the keys, its low byte picked by v_perm, masked once per dword
+      const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag);
+      if (j == 0) arrowLo = arrow;
+      else if (j == 1) arrowLo = __builtin_amdgcn_perm(arrow, arrowLo, 0x0c0c0400u);   // {cell 0, cell 1, 0, 0}
+      else if (j == 2) arrowHi = arrow;
+      else if (j == 3) arrowLo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(arrow, arrowHi, 0x04000c0cu), arrowLo, 0x07060100u) & 0x1f1f1f1fu;
+      else arrowHi = arrow & kTagMask;
+      if (alive) ring[(c0 + j) & (kF4Ring - 1)] = make_int2(sv, iKey & ~kTagMask);
+    }
+    // ---- arrows: five consecutive bytes per lane; bytes beyond the row's end spill into the next row's space (or the slack
+    // after the last row) and are overwritten when that row is stored
+    if (alive && c0 <= hiC) {
+      uint8_t *ap = arrowRow + (c0 - lo);
+      *(unaligned_u32 *)ap = arrowLo;
+      ap[4] = (uint8_t)arrowHi;
+    }
+    const bool more = alive && cb + kPass <= hiC;
+    if (alive && !more) ring[(hiC + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);  // (after the cells' own writes)
+    if (__ballot(more) != 0ull) {  // carries into the next 40 columns
+      const int last = (lane | (kL - 1)) * 4;
+      const int ta = __builtin_amdgcn_ds_bpermute(last, pa), tb = __builtin_amdgcn_ds_bpermute(last, pb);
+      carryA = (myPass > 0 ? min(carryA, ta) : ta) + kPass * kDel;
+      carryB = myPass > 0 ? min(carryB, tb) : tb;
+      carryDiag = __builtin_amdgcn_ds_bpermute(last, lastRaw);  // the raw S of column cb+39, for lane 0
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (alive) {
+      if (more) {
+        myPass++;
+      } else {
+        myPass = 0;
+        myRow++;
+        myPlo = lo;
+        myPhi = hiC;
+        recCur = recNext;
+      }
+    }
+    alive = alive && myRow <= myQ;
+  }
+  // ---- S[Q][tEnd-1] (:481-483): a candidate's ring is not written after its last row
+  if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
+    args.dpScore[myTask] = ring[(myTEnd - 1) & (kF4Ring - 1)].x >> kShift;
+}
+
 template __global__ void fillp_kernel<16, true, false>(RefineBatchView, FillArgs);
 template __global__ void fillp_kernel<16, false, false>(RefineBatchView, FillArgs);
-template __global__ void fillp_kernel<8, false, false>(RefineBatchView, FillArgs);
 template __global__ void fillp_kernel<16, true, true>(RefineBatchView, FillArgs);
 template __global__ void fillp_kernel<16, false, true>(RefineBatchView, FillArgs);
 
@@ -1783,8 +2018,8 @@ void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes,
     hipLaunchKernelGGL((fillp_kernel<16, true, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else if (lanes == 16)
     hipLaunchKernelGGL((fillp_kernel<16, false, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
-  else
-    hipLaunchKernelGGL((fillp_kernel<8, false, false>), dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+  else  // (the caller has checked fill8_kernel's domain: extension 0, matrix entries within 6 bits)
+    hipLaunchKernelGGL(fill8_kernel, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
 }
 // the candidates with wide rows: args.taskList = the list, args.wideRingOff / wideRingSize indexed like it
 void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {

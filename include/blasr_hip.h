@@ -176,7 +176,8 @@ int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *la
  * processed.  Fill kernels: 1 B per band cell (arrows out) + the bases read + 8 B per row record;
  * traceback: one 16-byte arrow window + one 8-byte row record per row walked.  `kind` names the kernel:
  * blasr_hip_kernel_name(kind) is its full instantiation as rocprofv3 prints it. */
-enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four candidates per wavefront */
+enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four candidates per wavefront (extension penalty
+                                            != 0, or a matrix entry outside [-32, 31]; else FILL_EIGHT runs) */
        BLASR_HIP_KERNEL_FILL_HYBRID = 1, /* fillp_kernel<16, ext0, true>: candidates with wide rows */
        BLASR_HIP_KERNEL_FILL_WAVE = 2,   /* fill_kernel: one candidate per wavefront (compare-based variant) */
        BLASR_HIP_KERNEL_TRACEBACK = 3,   /* traceback_kernel */
@@ -186,7 +187,8 @@ enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four 
        BLASR_HIP_KERNEL_KBAND_STRIPS = 4,    /* kband_wide_kernel: bands of any width, strips of the (q, t) matrix */
        BLASR_HIP_KERNEL_KBAND_TRACEBACK = 5, /* kband_wide_traceback_kernel */
        BLASR_HIP_KERNEL_KBAND_ROWS = 6,      /* kband_fill_kernel: band rows in LDS, 2k+1 <= 1088 */
-       BLASR_HIP_KERNEL_KINDS = 7 };
+       BLASR_HIP_KERNEL_FILL_EIGHT = 7,      /* fill8_kernel: the narrow candidates, eight per wavefront, each at its own row */
+       BLASR_HIP_KERNEL_KINDS = 8 };
 typedef struct blasr_hip_kernel_record {
   int32_t kind;
   int32_t launches;

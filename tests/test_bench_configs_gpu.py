@@ -36,7 +36,7 @@ def check_line(d, n_reads):
     cost = [r["avg_launch_ms"] * r["launches_per_step"] for r in lines]
     assert cost[0] == max(cost) and all(r["achieved"] > 0 and r["algorithmic_bytes_per_launch"] > 0 for r in lines)
     names = [r["kernel"] for r in lines]
-    assert any(n.startswith("blasr_hip::traceback_kernel") for n in names) and any("fillp_kernel<16, true, false>" in n for n in names)
+    assert any(n.startswith("blasr_hip::traceback_kernel") for n in names) and any("fill8_kernel" in n for n in names)
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-12
     # traffic only from a PMC profile of this very build and workload
     assert d["roofline"]["traffic"] is None or d["roofline"]["pmc_profile"].startswith("profiles/")

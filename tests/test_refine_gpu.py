@@ -160,11 +160,12 @@ def test_unsupported_gap_costs_are_rejected(ctx):
     assert e.value.code == hip.ERR_CAPACITY
 
 
-@pytest.mark.parametrize("switch", ["BLASR_HIP_NO_FILL4", "BLASR_HIP_FILL_LANES8"])
+@pytest.mark.parametrize("switch", ["BLASR_HIP_NO_FILL4", "BLASR_HIP_FILL_LANES16"])
 def test_alternative_fill_kernels_agree(ctx, golden, monkeypatch, switch):
-    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront) instead of fillp_kernel<16>
-    (four per wavefront); BLASR_HIP_FILL_LANES8 selects fillp_kernel<8> (eight per wavefront).  The same goldens
-    must come out of all of them."""
+    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront); BLASR_HIP_FILL_LANES16 keeps
+    the narrow candidates on fillp_kernel<16> (four per wavefront, in lockstep) instead of fill8_kernel (eight per
+    wavefront, each at its own row: the default when the extension penalty is 0).  The same goldens must come out of
+    all of them."""
     cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
              and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
     b = blasr_amd.RefineBatch()
@@ -178,10 +179,10 @@ def test_alternative_fill_kernels_agree(ctx, golden, monkeypatch, switch):
 
 @pytest.mark.parametrize("lanes8", [False, True])
 def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
-    """fillp_kernel packs four (or eight) candidates of different lengths and widths into one wavefront; rows of
-    up to 112 cells take up to three passes."""
-    if lanes8:
-        monkeypatch.setenv("BLASR_HIP_FILL_LANES8", "1")
+    """fill8_kernel / fillp_kernel pack eight / four candidates of different lengths and widths into one wavefront;
+    rows of up to 112 cells take up to three passes (of 40 / 48 columns)."""
+    if not lanes8:
+        monkeypatch.setenv("BLASR_HIP_FILL_LANES16", "1")
     rng = np.random.default_rng(77)
     b = blasr_amd.RefineBatch()
     want = []

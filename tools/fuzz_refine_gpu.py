@@ -1,7 +1,11 @@
 """Randomised parity fuzz of the refine stage's fill kernels on guides with jumps (the hybrid fillp_kernel's domain) against
 the oracle's AffineGuidedAlign: guides of 2-8 short exact blocks with gaps of 0-6000 columns / rows in either direction,
 back to back or in the first rows, mixed with plain noisy pairs so that the candidates of a wavefront differ.
-    python tools/fuzz_refine_gpu.py SEED BATCHES"""
+    python tools/fuzz_refine_gpu.py SEED BATCHES
+    python tools/fuzz_refine_gpu.py SEED BATCHES narrow
+"narrow" is fill8_kernel's domain instead: batches of up to 200 noisy pairs of 30-4000 bases whose guides have gaps of at most
+~75 columns (rows of up to 112 cells: one to three passes of 40 columns, candidates of one wavefront at different rows), with N
+bases in either sequence, targets that end inside the band, and random bands."""
 import os
 import sys
 import time
@@ -20,6 +24,7 @@ from golden_cases import REFINE_KEYS, first_difference  # noqa: E402
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     batches = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    narrow = len(sys.argv) > 3 and sys.argv[3] == "narrow"
     rng = np.random.default_rng(seed)
     oracle = T.load_oracle()
     ctx = blasr_amd.Context(0)
@@ -27,7 +32,27 @@ def main():
     t0 = time.time()
     for _ in range(batches):
         b, want = blasr_amd.RefineBatch(), []
-        for it in range(int(rng.integers(1, 40))):
+        band = 16
+        if narrow:
+            band = int(rng.choice([16, 16, 8, 12, 20]))
+            for it in range(int(rng.integers(1, 200))):
+                big = None
+                if rng.integers(0, 3) == 0:
+                    big = (str(rng.choice(["del", "ins"])), int(rng.integers(5, 76)))
+                q, t = synth.make_pair(rng, int(rng.integers(30, 4000)), flank=(0, int(rng.integers(0, 60))), big_indel=big)
+                for seq in (q, t):
+                    if rng.integers(0, 6) == 0:
+                        seq[rng.integers(0, len(seq), size=int(rng.integers(1, 6)))] = ord("N")
+                s = oracle.sdp_align(q, t)
+                bl = s["blocks"]
+                if len(bl) == 0:
+                    continue
+                qs = np.ascontiguousarray(q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]])
+                cut = int(rng.integers(0, 3)) == 0  # the reference's window, or a target that ends with the last block
+                ts = np.ascontiguousarray(t[s["tPos"]: (s["tPos"] + bl[-1, 1] + bl[-1, 2]) if cut else len(t)])
+                b.add(qs, ts, bl)
+                want.append(oracle.affine_guided_align(qs, ts, bl, band=band))
+        for it in range(0 if narrow else int(rng.integers(1, 40))):
             if rng.integers(0, 4) == 0:  # a plain noisy pair with the SDP blocks of the oracle as its guide
                 q, t = synth.make_pair(rng, int(rng.integers(100, 3000)))
                 s = oracle.sdp_align(q, t)
@@ -58,7 +83,7 @@ def main():
             want.append(oracle.affine_guided_align(np.ascontiguousarray(qs), np.ascontiguousarray(ts), bl))
         if not want:
             continue
-        got = ctx.refine(b)
+        got = ctx.refine(b, band=band)
         for i, (g, w) in enumerate(zip(got, want)):
             total += 1
             if g.status != 0 or first_difference(g.as_dict(), w, REFINE_KEYS) is not None:
