@@ -204,6 +204,77 @@ def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
         assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, i
 
 
+def _guide_with_gaps(rng, gaps, block=40, n_base=False):
+    """A query / target pair whose guide is exact blocks of `block` bases separated by the given gaps ((q, t) unaligned
+    bases each): the rows behind a target gap of g columns are 33 + g cells wide."""
+    q, t, blocks = [], [], []
+    qp = tp = 0
+    for k, (gq, gt) in enumerate(list(gaps) + [(0, 0)]):
+        seg = synth.random_genome(block, int(rng.integers(1, 1 << 30)))
+        q.append(seg)
+        t.append(seg.copy())
+        blocks.append([qp, tp, block])
+        qp += block
+        tp += block
+        if k < len(gaps):
+            q.append(synth.random_genome(gq, int(rng.integers(1, 1 << 30))))
+            t.append(synth.random_genome(gt, int(rng.integers(1, 1 << 30))))
+            qp += gq
+            tp += gt
+    q, t = np.concatenate(q), np.concatenate(t)
+    if n_base:
+        q[rng.integers(0, len(q), size=3)] = ord("N")
+        t[rng.integers(0, len(t), size=3)] = ord("N")
+    return np.ascontiguousarray(q), np.ascontiguousarray(t), np.array(blocks, dtype=np.int32)
+
+
+@pytest.mark.parametrize("lanes16", [False, True])
+def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes16):
+    """fill8_kernel's edges one by one: rows of exactly 40 / 41 / 80 / 81 / 112 cells (one, two, three passes of 40 columns:
+    target gaps of 7 / 8 / 47 / 48 / 79 columns behind a 33-cell band), a row that grows by more than the eight cleaned
+    ring entries, query gaps (the band stands still), N in both sequences (the fifth row / field of the 6-bit matrix
+    registers), more candidates than one wavefront's eight and fewer, a band of 8 and of 20 -- and matrix entries at the
+    6-bit limits (-32, 31), then beyond them (32: the launch falls back to fillp_kernel<16>).  Everything against the
+    oracle; with BLASR_HIP_FILL_LANES16 the same through the four-per-wavefront kernel."""
+    if lanes16:
+        monkeypatch.setenv("BLASR_HIP_FILL_LANES16", "1")
+    rng = np.random.default_rng(20261004)
+    shapes = [[(0, 7)], [(0, 8)], [(0, 47)], [(0, 48)], [(0, 79)], [(0, 7), (0, 79), (0, 8)], [(30, 0)], [(5, 60), (60, 5)],
+              [(0, 20), (0, 40), (0, 60), (0, 79)], [(3, 3)] * 12, [(0, 79)] * 4, [(70, 79)], [(0, 1), (0, 9), (0, 10)]]
+    for band in (16, 8, 20):
+        b = blasr_amd.RefineBatch()
+        want = []
+        for k, gaps in enumerate(shapes):
+            q, t, blocks = _guide_with_gaps(rng, gaps, block=int(rng.integers(12, 60)), n_base=(k % 3 == 0))
+            b.add(q, t, blocks)
+            want.append(oracle.affine_guided_align(q, t, blocks, band=band))
+        got = ctx.refine(b, band=band)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.status == 0, (band, i)
+            assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, (band, i)
+        if not lanes16 and band == 16:
+            names = [k["name"] for k in ctx.last_kernels()]
+            assert any("fill8_kernel" in n for n in names), names
+    # the matrix at the limits of the 6-bit fields, and one entry beyond them
+    for lim, kernel in ((31, "fill8_kernel"), (32, "fillp_kernel<16")):
+        m = np.array(SMRT_MATRIX, dtype=np.int32).copy()
+        m[0, 1] = lim
+        m[2, 2] = -32
+        m[4, 3] = lim - 1
+        sc = blasr_amd.ScoreParams(m, 5, 5, 50, 0)
+        b = blasr_amd.RefineBatch()
+        want = []
+        for gaps in shapes[:6]:
+            q, t, blocks = _guide_with_gaps(rng, gaps, n_base=True)
+            b.add(q, t, blocks)
+            want.append(oracle.affine_guided_align(q, t, blocks, sc=sc))
+        got = ctx.refine(b, score=sc)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.status == 0 and first_difference(g.as_dict(), w, REFINE_KEYS) is None, (lim, i)
+        if not lanes16:
+            assert any(kernel in k["name"] for k in ctx.last_kernels()), (lim, [k["name"] for k in ctx.last_kernels()])
+
+
 @pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4"])
 def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch):
     """Guides whose consecutive blocks drift by hundreds to thousands of columns (what SDPAlign(Local) makes of a repeat

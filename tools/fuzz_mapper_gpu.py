@@ -303,6 +303,27 @@ def main():
             if diff and one_thread(name) is not None and not (set(one_thread(name)) ^ b):
                 totals["reference_unstable_under_nproc"] = totals.get("reference_unstable_under_nproc", 0) + 1
                 diff = 0
+            if diff and not args.sam and not args.fastq and not args.sam_reads:
+                # The same leak carries over from one read to the next inside ONE thread as well (what a read's match list
+                # leaves behind is what the next read's interval finder finds past the end of its own): a read whose lines
+                # differ is mapped once more ALONE, by a fresh process; a difference only counts when that run shows it too.
+                stay = 0
+                for rid in sorted({x.split()[0].split("/")[0] for x in a ^ b}):
+                    r = int(rid[4:])
+                    with tempfile.TemporaryDirectory() as tmp1:
+                        open(os.path.join(tmp1, "genome.fasta"), "w").write(fasta_text["genome.fasta"])
+                        open(os.path.join(tmp1, "one.fasta"), "w").write(">%s\n%s\n" % (names[r], bytes(reads[r]).decode()))
+                        path = os.path.join(tmp1, "out.m4")
+                        p1 = subprocess.run([blasr, os.path.join(tmp1, "one.fasta"), os.path.join(tmp1, "genome.fasta"), "-m", "4",
+                                             "-bestn", "1", "-nproc", "1", "-out", path] + switches[name],
+                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                        alone = set(open(path).read().splitlines()) if p1.returncode == 0 and os.path.exists(path) else None
+                    ours = {x for x in b if x.split()[0].split("/")[0] == rid}
+                    if alone is not None and alone == ours:
+                        totals["reference_depends_on_the_read_before"] = totals.get("reference_depends_on_the_read_before", 0) + 1
+                    else:
+                        stay += len({x for x in a ^ b if x.split()[0].split("/")[0] == rid})
+                diff = stay
             totals["bad_" + name] += diff
             v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
             v["lines"] += len(ref[name])
