@@ -1842,7 +1842,9 @@ __global__ __launch_bounds__(256) void runs_kernel(RefineBatchView batch, TraceA
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stats_kernel(RefineBatchView batch, TraceArgs args) {
   __shared__ int matrix[25];
+  __shared__ uint8_t codeOf[256];
   if (threadIdx.x < 25) matrix[threadIdx.x] = args.matrix[threadIdx.x];
+  codeOf[threadIdx.x] = (uint8_t)base_code((unsigned)threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + wave;
@@ -1864,11 +1866,7 @@ __global__ __launch_bounds__(256) void stats_kernel(RefineBatchView batch, Trace
     const unsigned qIncl = wave_prefix_sum(qAdv), tIncl = wave_prefix_sum(tAdv);
     if (ty == OP_M) {
       const uint8_t *qp = qSeq + qBase + (int)(qIncl - qAdv), *tp = tSeq + tBase + (int)(tIncl - tAdv);
-      for (int j = 0; j < len; j++) {
-        const int qc = base_code(qp[j]), tc = base_code(tp[j]);
-        matchSum += matrix[qc * 5 + tc];
-        if (qc == tc) nMatch++; else nMismatch++;  // ThreeBit equality: N against N counts as a match
-      }
+      score_columns(qp, tp, len, matrix, codeOf, matchSum, nMatch, nMismatch);
     } else if (i < nOps) {
       if (ty == OP_I) nIns += len; else nDel += len;
       if ((ops[i + 1] & 3u) == OP_M) {

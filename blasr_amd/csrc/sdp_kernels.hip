@@ -3717,7 +3717,9 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
                                                          SdpResult *results, int32_t *blocks, int64_t blocksCap,
                                                          int64_t blkBase) {
   __shared__ int m[25];
+  __shared__ uint8_t codeOf[256];
   if (threadIdx.x < 25) m[threadIdx.x] = matrix[threadIdx.x];
+  codeOf[threadIdx.x] = (uint8_t)base_code((unsigned)threadIdx.x);
   __syncthreads();
   const int idx = wave_task_index();
   if (idx >= n) return;
@@ -3743,11 +3745,7 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
   const bool fits = b0 + nb <= blocksCap;
   int blockScore = 0, nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0, gapScore = 0, commonScore = 0;
   auto columns = [&](int q, int tt, int len, int &scoreAcc) {
-    for (int j = 0; j < len; j++) {
-      const int qc = base_code(qSeq[q + j]), tc = base_code(tSeq[tt + j]);
-      scoreAcc += m[qc * 5 + tc];
-      if (qc == tc) nMatch++; else nMismatch++;
-    }
+    score_columns(qSeq + q, tSeq + tt, len, m, codeOf, scoreAcc, nMatch, nMismatch);
   };
   auto gapRun = [&](int len, bool deletion) {
     if (len <= 0) return;

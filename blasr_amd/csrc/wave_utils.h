@@ -60,5 +60,31 @@ __device__ __forceinline__ int base_code(unsigned c) {
   return code;
 }
 
+// The substitution scores and the match / mismatch counts of `len` aligned columns of one lane (ComputeAlignmentScore's
+// inner loop, AlignmentUtils.h:60-124): four columns per pair of (unaligned) dword loads, the codes from a 256-entry table in
+// LDS (lut[c] = base_code(c)), the scores from the 5 x 5 matrix in LDS.  ThreeBit equality: N against N counts as a match.
+__device__ __forceinline__ void score_columns(const uint8_t *qp, const uint8_t *tp, int len, const int *matrixLds,
+                                              const uint8_t *lutLds, int &score, int &nMatch, int &nMismatch) {
+  int j = 0, same = 0;
+  for (; j + 4 <= len; j += 4) {
+    uint32_t qw, tw;
+    __builtin_memcpy(&qw, qp + j, 4);
+    __builtin_memcpy(&tw, tp + j, 4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int qc = lutLds[(qw >> (8 * k)) & 0xffu], tc = lutLds[(tw >> (8 * k)) & 0xffu];
+      score += matrixLds[qc * 5 + tc];
+      same += qc == tc ? 1 : 0;
+    }
+  }
+  for (; j < len; j++) {
+    const int qc = lutLds[qp[j]], tc = lutLds[tp[j]];
+    score += matrixLds[qc * 5 + tc];
+    same += qc == tc ? 1 : 0;
+  }
+  nMatch += same;
+  nMismatch += max(len, 0) - same;
+}
+
 }  // namespace blasr_hip
 #endif
