@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void window_gather_kernel(int n, const blasr_h
                                                             const int64_t *offs, int64_t capacity, uint8_t *seqOut,
                                                             int64_t *qOff, int32_t *qLen, int64_t *tOff,
                                                             int32_t *tLen) {
+  __shared__ uint8_t rcOf[256];  // ReverseComplementNuc by character
+  rcOf[threadIdx.x] = rc_nuc((uint8_t)threadIdx.x);
+  __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (i >= n) return;
   const int lane = lane_id();
@@ -128,12 +131,37 @@ __global__ __launch_bounds__(256) void window_gather_kernel(int n, const blasr_h
   const blasr_hip_interval iv = intervals[i];
   const uint8_t *q = readPool + reads[iv.read].off + p.qStart;
   uint8_t *dq = seqOut + at, *dt = dq + p.qLen;
-  for (uint32_t j = lane; j < p.qLen; j += 64) dq[j] = q[j];
+  // sixteen bytes per lane and trip (unaligned loads and stores: the pools have no alignment), the tail byte by byte
+  auto copy = [&](uint8_t *dst, const uint8_t *src, uint32_t len) {
+    uint32_t j = 16u * lane;
+    for (; j + 16u <= len; j += 16u * 64u) {
+      uint4 v;
+      __builtin_memcpy(&v, src + j, 16);
+      __builtin_memcpy(dst + j, &v, 16);
+    }
+    const uint32_t done = len & ~15u;
+    if (done + lane < len) dst[done + lane] = src[done + lane];
+  };
+  copy(dq, q, p.qLen);
   const uint8_t *g = genome + p.fwdStart;
   if (iv.strand == 1) {
-    for (uint32_t j = lane; j < p.tLen; j += 64) dt[j] = rc_nuc(g[p.tLen - 1u - j]);
+    // CopyAsRC: output bytes j .. j+15 are the complements of source bytes tLen-1-j .. tLen-16-j
+    uint32_t j = 16u * lane;
+    for (; j + 16u <= p.tLen; j += 16u * 64u) {
+      uint32_t w[4], o[4];
+      __builtin_memcpy(w, g + (p.tLen - 16u - j), 16);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t x = w[3 - k];  // its highest byte comes first
+        o[k] = (uint32_t)rcOf[x >> 24] | (uint32_t)rcOf[(x >> 16) & 0xffu] << 8 | (uint32_t)rcOf[(x >> 8) & 0xffu] << 16 |
+               (uint32_t)rcOf[x & 0xffu] << 24;
+      }
+      __builtin_memcpy(dt + j, o, 16);
+    }
+    const uint32_t done = p.tLen & ~15u;
+    if (done + lane < p.tLen) dt[done + lane] = rcOf[g[p.tLen - 1u - (done + lane)]];
   } else {
-    for (uint32_t j = lane; j < p.tLen; j += 64) dt[j] = g[j];
+    copy(dt, g, p.tLen);
   }
 }
 
