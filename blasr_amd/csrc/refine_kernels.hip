@@ -1654,9 +1654,17 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
   };
 
   // RT[j] = record of the j-th row of the current batch (rows rTop, rTop-1, ...), RTn the same for the next one
+  // (two rows' records per 16-byte load: rows a - 1 and a are neighbours in the table, and record 0 exists, unused)
+  static_assert(kB % 2 == 0, "row records are fetched in pairs");
+  auto load_pair = [&](int a, int2 &recA, int2 &recBelow) {  // the records of rows a and a - 1
+    int4 v;
+    __builtin_memcpy(&v, (alive && a >= 1) ? reinterpret_cast<const void *>(rowTab + (a - 1)) : reinterpret_cast<const void *>(anyRec), 16);
+    recA = make_int2(v.z, v.w);
+    recBelow = make_int2(v.x, v.y);
+  };
   int2 RT[kB], RTn[kB];
 #pragma unroll
-  for (int j = 0; j < kB; j++) RT[j] = *((alive && Q - j >= 1) ? rowTab + (Q - j) : anyRec);
+  for (int j = 0; j < kB; j += 2) load_pair(Q - j, RT[j], RT[j + 1]);
 
   int rTop = Q;
   while (__any(alive)) {
@@ -1669,7 +1677,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(RefineBatchView batch, Tr
       for (int j = 0; j < kB; j++)
         W[j] = load_window(j < nHere ? arrows + (int64_t)(RT[j].x + (c0 - j - 7 - RT[j].y)) : arrows);
 #pragma unroll
-      for (int j = 0; j < kB; j++) RTn[j] = *((alive && rTop - kB - j >= 1) ? rowTab + (rTop - kB - j) : anyRec);
+      for (int j = 0; j < kB; j += 2) load_pair(rTop - kB - j, RTn[j], RTn[j + 1]);
 #pragma unroll
       for (int j = 0; j < kB; j++)
         if (alive) winLds[j][slot] = W[j];
