@@ -426,13 +426,21 @@ __device__ __forceinline__ int idx_end(const uint32_t *cnt, int b) { return (int
 
 __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool big = false;
-  if (i < lv.n) big = task_uses_index(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT);
+  bool big = false, mid = false;
+  if (i < lv.n) {
+    big = task_uses_index(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT);
+    mid = !big && lv.tasks[i].tLen >= 256;  // sdp_match_kernel<false, true>'s
+  }
   const unsigned long long mask = __ballot(big);
   int base = 0;
   if (mask != 0ull && lane_id() == 0) base = atomicAdd(lv.bigCount, (int)__popcll(mask));
   base = __builtin_amdgcn_readfirstlane(base);
   if (big) lv.bigList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+  const unsigned long long maskM = __ballot(mid);
+  int baseM = 0;
+  if (maskM != 0ull && lane_id() == 0) baseM = atomicAdd(lv.midCount, (int)__popcll(maskM));
+  baseM = __builtin_amdgcn_readfirstlane(baseM);
+  if (mid) lv.midList[baseM + __popcll(maskM & ((1ull << lane_id()) - 1ull))] = i;
 }
 
 // The count pass leaves, per query position, {match count : 16, the first three target positions : 3 x 16} in
@@ -716,12 +724,33 @@ constexpr int kBucketBits = 11;  // LDS bucket index over the leading bits of th
 
 // kBuckets: the count pass of targets >= 256 bases narrows its binary searches with a bucket index in LDS (32 KB
 // per workgroup); everything else runs in the instantiation without it, at full occupancy.
+// The bucket instantiation strides over ITS list (sdp_classify_kernel's midList) with a fixed grid: at the recursion levels it
+// is one invocation in a hundred, and a workgroup with 32 KB of LDS per four invocations of the level, nearly all of which
+// returned at once, took as long to get through the dispatcher (20 ms) as the other matchers take to do their work.
+template <bool kWrite, bool kBuckets>
+__device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8_t *seq, const int idx, uint32_t *bucketLds,
+                                           const uint4 *tinyQuadsLds);
 template <bool kWrite, bool kBuckets>
 __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const uint8_t *seq) {
   __shared__ uint32_t bucketStart[kBuckets ? 4 : 1][kBuckets ? (1 << kBucketBits) + 1 : 1];
   __shared__ uint4 tinyT4[kBuckets ? 1 : 4][kBuckets ? 1 : kTinyT / 4];  // a tiny target's k-mers, by position
+  uint32_t *bucketLds = bucketStart[kBuckets ? threadIdx.x >> 6 : 0];
+  const uint4 *tinyLds = tinyT4[kBuckets ? 0 : threadIdx.x >> 6];
+  if (kBuckets) {
+    const int nMid = *lv.midCount;
+    for (int e = wave_task_index(); e < nMid; e += (int)gridDim.x * 4) {
+      match_task<kWrite, kBuckets>(lv, seq, lv.midList[e], bucketLds, tinyLds);
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  match_task<kWrite, kBuckets>(lv, seq, idx, bucketLds, tinyLds);
+}
+template <bool kWrite, bool kBuckets>
+__device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8_t *seq, const int idx, uint32_t *bucketLds,
+                                           const uint4 *tinyQuadsLds) {
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
   if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // sdp_match_index_kernel's
@@ -748,7 +777,7 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
   const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
   const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
   const bool useBuckets = kBuckets;  // (t.tLen <= kTinyT takes the register path below)
-  uint32_t *bucket = bucketStart[kBuckets ? threadIdx.x >> 6 : 0];
+  uint32_t *bucket = bucketLds;
   if (useBuckets) {
     const int nB = 1 << bBits;
     for (int b = lane; b <= nB; b += 64) bucket[b] = (uint32_t)t.tLen;
@@ -784,8 +813,8 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
     // k-mers in registers and a v_readlane per target position the loop was a chain of twelve dependent scalar
     // instructions per position.)
     bool haveT = false;
-    uint32_t *tinyT = reinterpret_cast<uint32_t *>(tinyT4[kBuckets ? 0 : threadIdx.x >> 6]);
-    const uint4 *tinyQuads = tinyT4[kBuckets ? 0 : threadIdx.x >> 6];
+    uint32_t *tinyT = reinterpret_cast<uint32_t *>(const_cast<uint4 *>(tinyQuadsLds));
+    const uint4 *tinyQuads = tinyQuadsLds;
     const int nT = max(t.tLen - k + 1, 0);
     for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
       const int x = x0 + lane;
@@ -863,7 +892,68 @@ __global__ __launch_bounds__(256) void sdp_match_kernel(SdpLevelArrays lv, const
       nM += __builtin_amdgcn_readlane((int)incl, 63);
     }
   }
-  for (int x0 = 0; !tiny && x0 + k <= t.qLen; x0 += 64) {
+  // The count pass over the sorted keys, TWO query positions per lane and trip and their four binary searches (first key
+  // >= k-mer, first key > k-mer, for either position) in lockstep: every step of a search is a dependent read of `keys`,
+  // and one position's two searches one after the other were sixteen round trips per trip where the range is a whole
+  // 255-base target -- which is what these kernels' time was (VALU issue 0.02 - 0.26).  Counting does not care about the
+  // order of the positions; the write pass below keeps its own.
+  for (int x0 = 0; !kWrite && !tiny && x0 + k <= t.qLen; x0 += 128) {
+    int sLo[4], sHi[4];
+    uint64_t sKey[4];
+    bool okP[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int x = x0 + 64 * u + lane;
+      uint64_t kmer = 0;
+      bool ok = x + k <= t.qLen;
+      for (int j = 0; j < k; j++) {
+        const int c = base_code(qSeq[min(x + j, t.qLen - 1)]);
+        ok = ok && c < 4;
+        kmer |= (uint64_t)(c & 3) << (2 * j);
+      }
+      int rLo = 0, rHi = ok ? t.tLen : 0;
+      if (useBuckets && ok) {
+        const int b = (int)(kmer >> (2 * k - bBits));
+        rLo = (int)bucket[b];
+        rHi = (int)bucket[b + 1];
+      }
+      okP[u] = ok;
+      sLo[2 * u] = sLo[2 * u + 1] = rLo;
+      sHi[2 * u] = sHi[2 * u + 1] = rHi;
+      sKey[2 * u] = kmer << kPosBits;
+      sKey[2 * u + 1] = (kmer + 1) << kPosBits;
+    }
+    for (;;) {
+      bool any = false;
+      uint64_t v[4];
+      int mid[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        mid[s4] = (sLo[s4] + sHi[s4]) >> 1;
+        const bool open = sLo[s4] < sHi[s4];
+        any = any || open;
+        v[s4] = open ? keys[mid[s4]] : 0ull;  // (four reads in flight)
+      }
+      if (__ballot(any) == 0ull) break;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++)
+        if (sLo[s4] < sHi[s4]) {
+          if (v[s4] < sKey[s4]) sLo[s4] = mid[s4] + 1;
+          else sHi[s4] = mid[s4];
+        }
+    }
+    int cntBoth = 0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int x = x0 + 64 * u + lane;
+      int cnt = okP[u] ? sLo[2 * u + 1] - sLo[2 * u] : 0;
+      if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
+      if (x + k <= t.qLen) hits[x] = (uint64_t)(uint32_t)(okP[u] ? sLo[2 * u] : 0) | ((uint64_t)(uint32_t)cnt << 32);
+      cntBoth += cnt;
+    }
+    nM += (int)__builtin_amdgcn_readlane((int)wave_prefix_sum((unsigned)cntBoth), 63);
+  }
+  for (int x0 = 0; kWrite && !tiny && x0 + k <= t.qLen; x0 += 64) {
     const int x = x0 + lane;
     int lo = 0, cnt = 0;
     if (x + k <= t.qLen) {
@@ -3822,7 +3912,8 @@ void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, 
   if (write) hipLaunchKernelGGL((sdp_match_kernel<true, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
   else {
     hipLaunchKernelGGL((sdp_match_kernel<false, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
-    hipLaunchKernelGGL((sdp_match_kernel<false, true>), wave_grid(lv.n), dim3(256), 0, side ? side : st, lv, seq);
+    hipLaunchKernelGGL((sdp_match_kernel<false, true>), dim3((unsigned)std::min((lv.n + 3) / 4, 4096)), dim3(256), 0,
+                       side ? side : st, lv, seq);  // (a fixed grid over its list)
   }
 }
 // The matchers take disjoint sets of invocations -- tiny and short targets (a wavefront each, bound by the latency of its
@@ -3849,6 +3940,7 @@ void launch_sdp_match_all(const SdpLevelArrays &lv, const uint8_t *seq, bool wri
 void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.bigCount, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(lv.midCount, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(sdp_classify_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
 }
 int sdp_match_index_max_target(int device) {
