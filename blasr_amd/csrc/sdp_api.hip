@@ -247,6 +247,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.bigCount = lv.bigList + nTasks;
     lv.midList = arena.get<int32_t>(nTasks + 1);
     lv.midCount = lv.midList + nTasks;
+    lv.keyList = arena.get<int32_t>(nTasks + 1);
+    lv.keyCount = lv.keyList + nTasks;
     lv.idxFlag = arena.get<int32_t>(nTasks);
     lv.idxWave = arena.get<int32_t>((size_t)4 * nTasks);
     lv.fused = arena.get<int32_t>(nTasks);

@@ -66,6 +66,7 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int32_t *bigList, *bigCount;  // those tasks
+  int32_t *keyList, *keyCount;  // the tasks whose targets get sorted k-mer keys (sdp_keys_kernel, sdp_sort_keys_kernel)
   int32_t *midList, *midCount;  // the tasks of sdp_match_kernel's bucket instantiation (targets >= 256 bases, not indexed)
   // The sweep's invocations (not fused, >= 1 fragment), sorted by category and fragment count, and the five category
   // counts: chainCount[0] sdp_chain4_kernel's; [1..4] the invocations whose fragments scatter over the rectangle (the

@@ -99,14 +99,15 @@ __device__ __forceinline__ int general_task(const SdpLevelArrays &lv, int it) {
 // sdp_keys: every k-mer of the target whose k bases are all ACGT (DNATuple.h:308-359),
 // first base in the least-significant bits (FromStringRL :55-83)
 // ---------------------------------------------------------------------------
+// (a fixed grid over sdp_classify_kernel's keyList: at the recursion levels most targets are tiny and have no keys)
 __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const uint8_t *seq) {
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
+  const int nKeyed = *lv.keyCount;
+  for (int e = wave_task_index(); e < nKeyed; e += (int)gridDim.x * 4) {
+  const int idx = lv.keyList[e];
   const int lane = lane_id();
   const SdpTask t = lv.tasks[idx];
   uint64_t *keys = lv.keys + lv.keyOff[idx];
   const uint8_t *tSeq = seq + t.tOff;
-  if (!task_needs_keys(t.tLen, t.k, lv.idxMaxT)) return;
   const uint64_t invalid = 1ull << (kPosBits + 2 * t.k);
   for (int p0 = 0; p0 < t.tLen; p0 += 64) {
     const int p = p0 + lane;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
       }
       keys[p] = key;
     }
+  }
   }
 }
 
@@ -232,16 +234,19 @@ __device__ void wave_radix_sort(uint64_t *keysA, uint64_t *keysB, uint32_t *vals
 
 __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, uint64_t *tmp) {
   __shared__ unsigned hist[4][512];
-  const int idx = wave_task_index();
-  if (idx >= lv.n) return;
-  const int lane = lane_id();
-  const SdpTask t = lv.tasks[idx];
-  if (!task_needs_keys(t.tLen, t.k, lv.idxMaxT)) return;
-  uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
-  bool inB;
-  wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
-  if (inB)
-    for (int i = lane; i < t.tLen; i += 64) a[i] = b[i];
+  const int nKeyed = *lv.keyCount;
+  for (int e = wave_task_index(); e < nKeyed; e += (int)gridDim.x * 4) {
+    const int idx = lv.keyList[e];
+    const int lane = lane_id();
+    const SdpTask t = lv.tasks[idx];
+    uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
+    bool inB;
+    wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
+    if (inB)
+      for (int i = lane; i < t.tLen; i += 64) a[i] = b[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 __global__ __launch_bounds__(256) void sdp_sort_yx_kernel(SdpLevelArrays lv, uint64_t *tmpKeys, uint32_t *tmpIdx) {
@@ -436,6 +441,12 @@ __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
   if (mask != 0ull && lane_id() == 0) base = atomicAdd(lv.bigCount, (int)__popcll(mask));
   base = __builtin_amdgcn_readfirstlane(base);
   if (big) lv.bigList[base + __popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+  const bool keyed = i < lv.n && task_needs_keys(lv.tasks[i].tLen, lv.tasks[i].k, lv.idxMaxT);
+  const unsigned long long maskK = __ballot(keyed);
+  int baseK = 0;
+  if (maskK != 0ull && lane_id() == 0) baseK = atomicAdd(lv.keyCount, (int)__popcll(maskK));
+  baseK = __builtin_amdgcn_readfirstlane(baseK);
+  if (keyed) lv.keyList[baseK + __popcll(maskK & ((1ull << lane_id()) - 1ull))] = i;
   const unsigned long long maskM = __ballot(mid);
   int baseM = 0;
   if (maskM != 0ull && lane_id() == 0) baseM = atomicAdd(lv.midCount, (int)__popcll(maskM));
@@ -3054,9 +3065,26 @@ __global__ __launch_bounds__(256) void sdp_chain_kernel(SdpLevelArrays lv, SdpPa
 // replayed; it is left to the general kernels (lv.fused[idx] = 0).  With <= 16 elements std::sort is a plain
 // insertion sort, i.e. stable, so the first of the duplicates in prefix | middle | suffix order survives.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpParams prm, int minAll) {
+__device__ __forceinline__ void small_task(const SdpLevelArrays &lv, const SdpParams &prm, const int idx, const int minAll);
+// With sdp_small4_kernel's order (the invocations sorted by min(fragments, 17), largest first) the kernel strides over the
+// head of that list with a fixed grid and stops at the first invocation that is sdp_small4_kernel's: at the recursion levels
+// nine invocations in ten are, and a wavefront each that returned at once was most of this kernel's time.
+__global__ __launch_bounds__(256) void sdp_small_kernel(SdpLevelArrays lv, SdpParams prm, int minAll, const int32_t *order) {
+  if (order != nullptr) {
+    for (int e = wave_task_index(); e < lv.n; e += (int)gridDim.x * 4) {
+      const int idx = order[e];
+      if (lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2] < minAll) return;
+      small_task(lv, prm, idx, minAll);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   const int idx = wave_task_index();
   if (idx >= lv.n) return;
+  small_task(lv, prm, idx, minAll);
+}
+__device__ __forceinline__ void small_task(const SdpLevelArrays &lv, const SdpParams &prm, const int idx, const int minAll) {
   const int lane = lane_id();
   const int nAll = lv.nRaw[3 * idx] + lv.nRaw[3 * idx + 1] + lv.nRaw[3 * idx + 2];
   if (nAll < minAll) return;  // sdp_small4_kernel's
@@ -3899,10 +3927,10 @@ static dim3 wave_grid(int n) { return dim3((unsigned)((n + 3) / 4)); }
 static dim3 general_grid(const SdpLevelArrays &lv) { return lv.generalMode == 2 ? dim3(2048) : wave_grid(lv.n); }
 
 void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_keys_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, seq);
 }
 void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st) {
-  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_keys_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, tmp);
+  if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_keys_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, tmp);
 }
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_yx_kernel, general_grid(lv), dim3(256), 0, st, lv, tmpKeys, tmpIdx);
@@ -3941,6 +3969,7 @@ void launch_sdp_classify(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.bigCount, 0, sizeof(int32_t), st);
   (void)hipMemsetAsync(lv.midCount, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(lv.keyCount, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(sdp_classify_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
 }
 int sdp_match_index_max_target(int device) {
@@ -3995,7 +4024,10 @@ void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_
   if (lv.n <= 0) return;
   const bool small4 = order != nullptr;
   if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p, order);
-  hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, small4 ? kSmall4Max + 1 : 0);
+  if (small4)
+    hipLaunchKernelGGL(sdp_small_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, p, kSmall4Max + 1, order);
+  else
+    hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, 0, order);
 }
 void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n <= 0) return;
