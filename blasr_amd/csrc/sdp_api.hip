@@ -427,8 +427,15 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       ARENA_CHECK();
       HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, ck, ckOut, cv, lv.chainList, (size_t)nTasks, 0u, 32u, st));
     }
-    if (getenv("BLASR_HIP_CHAIN_SERIAL")) launch_sdp_chain(lv, prm, st);
-    else launch_sdp_chain(lv, prm, st, ctx->auxStream, ctx->auxEvent);
+    int32_t chainCounts[5] = {0, 0, 0, 0, 0};
+    const int32_t *countsForGrids = nullptr;
+    if (lv.chainList != nullptr && !getenv("BLASR_HIP_CHAIN_FULL_GRIDS")) {  // (one small copy and a wait: the kernels' grids)
+      HIP_TRY(ctx, hipMemcpyAsync(chainCounts, lv.chainCount, sizeof(chainCounts), hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      countsForGrids = chainCounts;
+    }
+    if (getenv("BLASR_HIP_CHAIN_SERIAL")) launch_sdp_chain(lv, prm, st, nullptr, nullptr, countsForGrids);
+    else launch_sdp_chain(lv, prm, st, ctx->auxStream, ctx->auxEvent, countsForGrids);
     tock(2);
     if (getenv("BLASR_HIP_SDP_TRACE") && lv.chainList != nullptr) {  // the sweep's categories and its largest invocations
       int32_t cnt[5] = {0, 0, 0, 0, 0};

@@ -123,7 +123,7 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st);
 // aux / ev: three more streams and four events (fork, three joins), or nullptr: everything on st, one after the other
 void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st, hipStream_t *aux = nullptr,
-                      hipEvent_t *ev = nullptr);
+                      hipEvent_t *ev = nullptr, const int32_t *counts = nullptr);
 // counts: 4 ints per task {blocks, SWAlign fills, recursive jobs, 0}
 void launch_sdp_blocks_build(const SdpLevelArrays &lv, const SdpParams &p, int32_t *counts, hipStream_t st);
 void launch_sdp_blocks_emit(const SdpLevelArrays &lv, const SdpParams &p, const SdpEmit &e, const int32_t *counts,

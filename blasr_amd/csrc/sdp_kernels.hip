@@ -4049,8 +4049,16 @@ void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *va
   (void)hipMemsetAsync(lv.chainCount, 0, 5 * sizeof(int32_t), st);  // one count per category
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
-void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st, hipStream_t *aux, hipEvent_t *ev) {
+// counts: the five category counts as the host read them (nullptr: grids sized for the whole level).  At the recursion levels
+// one invocation in a hundred is swept by these kernels, and a 64 KB workgroup per four invocations of the level that returns at
+// once is not free: the dispatcher was what the four kernels waited for.
+void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t st, hipStream_t *aux, hipEvent_t *ev,
+                      const int32_t *counts) {
   if (lv.n <= 0) return;
+  auto grid_for = [&](int cat, int perGroup) {  // workgroups of four wavefronts, perGroup invocations per wavefront
+    const int n = counts ? counts[cat] : lv.n;
+    return dim3((unsigned)std::max((n + 4 * perGroup - 1) / (4 * perGroup), 1));
+  };
   if (lv.chainList != nullptr) {  // the list is sorted by category and size (launch_sdp_chain_list + sort)
     if (lv.colEnt != nullptr) {  // the scattered ones (the device knows how many of each kind: the grids are upper bounds)
       // The categories are disjoint sets of invocations and the long ones are serial chains whose kernels end in a
@@ -4062,11 +4070,12 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
         s0 = aux[0], s1 = aux[1], s2 = aux[2];
       }
-      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, wave_grid(lv.n), dim3(256), 0, s0, lv, p);
-      hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, wave_grid(lv.n), dim3(256), 0, s1, lv, p);
-      hipLaunchKernelGGL(sdp_chain_bits4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, s2, lv, p);
-      if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, wave_grid(lv.n), dim3(256), 0, s2, lv, p);
-      hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+      if (!counts || counts[4] > 0) hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
+      if (!counts || counts[3] > 0)
+        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, grid_for(3, 1), dim3(256), 0, s1, lv, p);
+      if (!counts || counts[2] > 0) hipLaunchKernelGGL(sdp_chain_bits4_kernel, grid_for(2, 4), dim3(256), 0, s2, lv, p);
+      if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, grid_for(1, 1), dim3(256), 0, s2, lv, p);
+      if (!counts || counts[0] > 0) hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
       if (fork)
         for (int i = 0; i < 3; i++) {
           (void)hipEventRecord(ev[1 + i], aux[i]);
@@ -4074,7 +4083,7 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         }
       return;
     }
-    hipLaunchKernelGGL(sdp_chain4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p);
+    hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
     hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);
   }
