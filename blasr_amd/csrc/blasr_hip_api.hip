@@ -376,13 +376,29 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   // ---- geometry -------------------------------------------------------------
   TaskGeometry *dGeo = reinterpret_cast<TaskGeometry *>(ctx->workspace + oGeo);
   HIP_TRY(ctx, hipEventRecord(ev[0], st));
-  launch_geometry(view, band, 0, n, dGeo, st);
+  launch_geometry(view, band, 0, n, dGeo, st, getenv("BLASR_HIP_GEOMETRY_WALK") != nullptr);
   HIP_TRY(ctx, hipEventRecord(ev[1], st));
   PinnedArray<TaskGeometry> geo;  // (pinned and kept between calls, ctx.h)
   if (int rcGeo = pinned_array(ctx, MH_GEO, (size_t)n, geo)) return rcGeo;
   HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo, sizeof(TaskGeometry) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  if (getenv("BLASR_HIP_GEOMETRY_CHECK")) {  // the closed forms of geometry_blocks_kernel against the walk over the rows
+    std::vector<TaskGeometry> walked((size_t)n);
+    launch_geometry(view, band, 0, n, dGeo, st, true);
+    HIP_TRY(ctx, hipMemcpyAsync(walked.data(), dGeo, sizeof(TaskGeometry) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) {
+      const TaskGeometry &a = geo[i], &w = walked[(size_t)i];
+      const bool same = a.status == w.status && (a.status != 0 || (a.cells == w.cells && a.rows == w.rows &&
+                                                                    a.maxWidth == w.maxWidth && a.tSpan == w.tSpan));
+      if (!same)
+        return fail(ctx, BLASR_HIP_ERR_INTERNAL,
+                    "geometry check: candidate %d: blocks {status %d, cells %lld, rows %d, widest %d, span %d}, walk {%d, %lld, %d, %d, %d}",
+                    i, a.status, (long long)a.cells, a.rows, a.maxWidth, a.tSpan, w.status, (long long)w.cells, w.rows, w.maxWidth,
+                    w.tSpan);
+    }
+  }
   {
     float t = 0;
     (void)hipEventElapsedTime(&t, ev[0], ev[1]);

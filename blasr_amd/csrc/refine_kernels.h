@@ -83,7 +83,7 @@ struct TraceArgs {
 };
 
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
-                     hipStream_t stream);
+                     hipStream_t stream, bool walkRows = false);
 // the row records of candidates [first, first+count): rowTab / rowMeta at rowOff[candidate] + row
 void launch_geometry_rows(const RefineBatchView &batch, int band, int first, int count, const TaskGeometry *geo,
                           int2 *rowTab, const int64_t *rowOff, unsigned short *rowMeta, hipStream_t stream);

@@ -214,6 +214,151 @@ __global__ __launch_bounds__(256) void geometry_kernel(RefineBatchView batch, in
 }
 
 // ---------------------------------------------------------------------------
+// geometry_blocks_kernel: geometry_kernel's answers -- rows, cells, widest row, validation -- WITHOUT the walk over the rows:
+// lane = guide block.  Inside a block (and in the gap rows behind it) the centre column moves by 0 or 1 per row and
+// lo_r = max(lo_{r-1}, t_r - cap_r) (guide_group), so the rows of block b are a handful of arithmetic series once the lo it
+// starts with is known, and that lo is a running maximum over the blocks before it:
+//   L0(b) = max(tStart - 1, A(0), .., A(b-1)),   A(b) = the largest t_r - cap_r among b's own rows
+//     rows 1 .. len-1 of the block: cap = band, t = bt + off           -> bt + len - 1 - band          (len > 1)
+//     the qGap gap rows behind it:  cap = 250,  t = bt + len + min(i, diagLen) -> t_last - 250         (qGap > 0)
+//   row 0 of the block (cap none):  width = bt + band + drift - L0 + 1
+//   rows 1 .. len-1:                width = bt + off + P - max(L0, bt + off - band) + 1,   P = min(250, band)
+//   gap row i:                      width = t_i + G - max(Lb, t_i - 250) + 1,  G = min(250, band + |tGap - qGap|),
+//                                   Lb = max(L0, bt + len - 1 - band [len > 1])
+// Every piece is linear in the row, so its sum, its smallest and its largest width are closed forms.  The sums must equal
+// geometry_rows_kernel's exactly (the arrow slabs are sized from them): BLASR_HIP_GEOMETRY_CHECK runs geometry_kernel as
+// well and compares every candidate.
+// ---------------------------------------------------------------------------
+struct SeriesAcc {
+  int64_t cells;
+  int minW, maxW;
+  __device__ __forceinline__ void constant(int64_t n, int w) {  // n rows of width w
+    if (n <= 0) return;
+    cells += n * (int64_t)w;
+    minW = min(minW, w);
+    maxW = max(maxW, w);
+  }
+  __device__ __forceinline__ void rising(int64_t n, int first) {  // n rows of width first, first + 1, ...
+    if (n <= 0) return;
+    cells += n * (int64_t)first + n * (n - 1) / 2;
+    minW = min(minW, first);
+    maxW = max(maxW, first + (int)(n - 1));
+  }
+};
+__global__ __launch_bounds__(256) void geometry_blocks_kernel(RefineBatchView batch, int band, int first, int count,
+                                                                TaskGeometry *geo) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (idx >= count) return;
+  const int task = first + idx;
+  const int nBlocks = batch.n_blocks[task];
+  TaskGeometry out;
+  out.rows = 0;
+  out.cells = 0;
+  out.maxWidth = 0;
+  out.status = 0;
+  out.tSpan = 0;
+  if (nBlocks <= 0) {
+    out.status = TASK_EMPTY_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
+  }
+  const int32_t *blocks = batch.blocks + 3 * batch.blk_off[task];
+  const int qLen = batch.q_len[task], tLen = batch.t_len[task];
+  const int qStart = blocks[0], tStart = blocks[1];
+  const int P = min(250, band);
+  const int drift0 = abs(tStart - qStart);
+  SeriesAcc acc;
+  acc.cells = 0;
+  acc.minW = INT32_MAX;
+  acc.maxW = INT32_MIN;
+  bool bad = false;
+  int loCarry = tStart - 1;  // L0 of the next chunk's first block
+  for (int b0 = 0; b0 < nBlocks; b0 += 64) {
+    const int b = b0 + lane;
+    const bool have = b < nBlocks;
+    int bq = 0, bt = 0, bl = 1, nq = 0, nt = 0, pq = 0, pt = 0, pl = 0;
+    if (have) {
+      bq = blocks[3 * b], bt = blocks[3 * b + 1], bl = blocks[3 * b + 2];
+      // validation: blocks ordered, non-overlapping in q and t, positive length, inside both sequences
+      if (bq < 0 || bt < 0 || bl <= 0 || (int64_t)bq + bl > qLen || (int64_t)bt + bl > tLen) bad = true;
+      if (b + 1 < nBlocks) {
+        nq = blocks[3 * b + 3], nt = blocks[3 * b + 4];
+        if (nq < (int64_t)bq + bl || nt < (int64_t)bt + bl) bad = true;
+      }
+      if (b > 0) pq = blocks[3 * b - 3], pt = blocks[3 * b - 2], pl = blocks[3 * b - 1];
+    }
+    if (__ballot(bad) != 0ull) break;  // (what follows assumes an ordered guide)
+    const bool hasNext = have && b + 1 < nBlocks;
+    const int qGap = hasNext ? nq - (bq + bl) : 0, tGap = hasNext ? nt - (bt + bl) : 0;
+    const int diagLen = max(min(qGap, tGap), 0);
+    const int T0 = bt + bl;
+    const int tLast = T0 + min(qGap - 1, diagLen);  // centre of the last gap row (qGap > 0)
+    int A = INT32_MIN;
+    if (have && bl > 1) A = bt + bl - 1 - band;
+    if (have && qGap > 0) A = max(A, tLast - 250);
+    // exclusive running maximum over the blocks
+    const int incl = wave_prefix_max(A);
+    int L0 = wave_shr1(incl, INT32_MIN);
+    L0 = max(L0, loCarry);
+    loCarry = max(loCarry, __builtin_amdgcn_readlane(incl, 63));
+    if (have) {
+      // row 0 of the block
+      const int drift = b == 0 ? drift0 : abs((bt - (pt + pl)) - (bq - (pq + pl)));
+      acc.constant(1, bt + band + drift - L0 + 1);
+      // rows 1 .. bl-1: width bt + off + P - L0 + 1 while bt + off - band < L0, then P + band + 1
+      {
+        const int64_t n = bl - 1;
+        const int64_t o1 = (int64_t)L0 - bt + band;  // first off with bt + off - band >= L0
+        const int64_t nA = min(max(o1 - 1, (int64_t)0), n);
+        acc.rising(nA, bt + 1 + P - L0 + 1);
+        acc.constant(n - nA, P + band + 1);
+      }
+      if (qGap > 0) {
+        const int Lb = bl > 1 ? max(L0, bt + bl - 1 - band) : L0;
+        const int G = min(250, band + abs(tGap - qGap));
+        // gap rows 0 .. n1-1: t = T0 + i; then t = T0 + diagLen
+        const int64_t n1 = min((int64_t)qGap, (int64_t)diagLen + 1);
+        const int64_t g1 = (int64_t)Lb - T0 + 250;  // first i with T0 + i - 250 >= Lb
+        const int64_t nA = min(max(g1, (int64_t)0), n1);
+        acc.rising(nA, T0 + G - Lb + 1);
+        acc.constant(n1 - nA, G + 251);
+        const int Tc = T0 + diagLen;
+        acc.constant((int64_t)qGap - n1, Tc + G - max(Lb, Tc - 250) + 1);
+      }
+    }
+  }
+  if (__ballot(bad) != 0ull) {
+    out.status = TASK_BAD_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
+  }
+  // row 0 of the matrix (AffineGuidedAlign.h:126-135): tPost = max(drift, band), tPre = 0
+  const int tPost0 = drift0 > band ? drift0 : band;
+  int64_t cells = acc.cells;
+  int minW = acc.minW, maxW = acc.maxW;
+  for (int off = 32; off > 0; off >>= 1) {
+    cells += __shfl_xor(cells, off);
+    minW = min(minW, __shfl_xor(minW, off));
+    maxW = max(maxW, __shfl_xor(maxW, off));
+  }
+  cells += tPost0 + 1;
+  // the kernels address a candidate's cells with 32 bits: refuse a candidate whose band would wrap them, or with a row of
+  // negative or absurd width (geometry_kernel's rule)
+  if (minW < 0 || maxW >= (1 << 24) || cells >= ((int64_t)1 << 31) - 64) {
+    out.status = TASK_BAD_GUIDE;
+    if (lane == 0) geo[task] = out;
+    return;
+  }
+  out.rows = blocks[3 * (nBlocks - 1)] + blocks[3 * (nBlocks - 1) + 2] - qStart;
+  out.cells = cells;
+  out.maxWidth = max(maxW, tPost0 + 1);
+  out.tSpan = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2] - tStart;
+  if (lane == 0) geo[task] = out;
+}
+
+// ---------------------------------------------------------------------------
 // geometry_rows_kernel: the second walk over the guide, once the chunk plan has given every candidate its place in
 // the workspace: the row records {matrix offset of the row's first cell, first column} and, per row, its number of
 // cells (those with t >= tEnd left out, AffineGuidedAlign.h:268-269) and the query base's code.  The fill kernels
@@ -1992,9 +2137,12 @@ void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigne
   hipLaunchKernelGGL(row_hist_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args, hist);
 }
 void launch_geometry(const RefineBatchView &batch, int band, int first, int count, TaskGeometry *geo,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool walkRows) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
+  if (walkRows)
+    hipLaunchKernelGGL(geometry_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
+  else
+    hipLaunchKernelGGL(geometry_blocks_kernel, dim3((count + 3) / 4), dim3(256), 0, stream, batch, band, first, count, geo);
 }
 void launch_geometry_rows(const RefineBatchView &batch, int band, int first, int count, const TaskGeometry *geo,
                           int2 *rowTab, const int64_t *rowOff, unsigned short *rowMeta, hipStream_t stream) {

@@ -228,6 +228,45 @@ def _guide_with_gaps(rng, gaps, block=40, n_base=False):
     return np.ascontiguousarray(q), np.ascontiguousarray(t), np.array(blocks, dtype=np.int32)
 
 
+def test_block_geometry_equals_the_row_walk(ctx, monkeypatch):
+    """geometry_blocks_kernel sizes every candidate's arrow slab from closed forms per guide block (cells, widest row, rows,
+    validation) where geometry_kernel walked all rows.  BLASR_HIP_GEOMETRY_CHECK runs the walk as well and fails the call
+    on the first candidate whose answers differ: guides with gaps of 0 .. 7000 rows / columns in either direction and both
+    at once, blocks of one base, gaps back to back, a first block far from the origin, bands 0 .. 300, and guides that are not
+    guides (overlapping, unordered, outside the sequences: the same TASK_BAD_GUIDE either way)."""
+    monkeypatch.setenv("BLASR_HIP_GEOMETRY_CHECK", "1")
+    rng = np.random.default_rng(20261005)
+    for band in (16, 0, 1, 5, 40, 250, 300):
+        b = blasr_amd.RefineBatch()
+        for it in range(60):
+            nb = int(rng.integers(1, 12))
+            gaps = []
+            for _ in range(nb - 1):
+                kind = int(rng.integers(0, 5))
+                g = int(rng.choice([0, 1, 2, 17, 33, 100, 249, 250, 251, 600, 3000, 7000]))
+                h = int(rng.choice([0, 1, 5, 40, 250, 700]))
+                gaps.append([(g, 0), (0, g), (g, g), (g, h), (h, g)][kind])
+            q, t, blocks = _guide_with_gaps(rng, gaps, block=int(rng.choice([1, 1, 2, 7, 30, 200])))
+            if it % 7 == 3:  # the guide starts away from the origin of both sequences
+                dq, dt = int(rng.integers(0, 400)), int(rng.integers(0, 400))
+                q = np.concatenate([synth.random_genome(dq, it + 1), q])
+                t = np.concatenate([synth.random_genome(dt, it + 2), t])
+                blocks = blocks + np.array([dq, dt, 0], dtype=np.int32)
+            if it % 11 == 5 and len(blocks) > 1:  # not a guide
+                blocks = blocks.copy()
+                how = it % 3
+                if how == 0:
+                    blocks[1, 0] = blocks[0, 0]           # overlapping in q
+                elif how == 1:
+                    blocks[[0, 1]] = blocks[[1, 0]]       # unordered
+                else:
+                    blocks[-1, 2] += len(t)               # beyond the target
+            b.add(np.ascontiguousarray(q), np.ascontiguousarray(t), blocks)
+        got = ctx.refine(b, band=band)  # (raises when the two geometries differ)
+        assert len(got) == 60
+        assert any(g.status != 0 for g in got) and any(g.status == 0 for g in got)
+
+
 @pytest.mark.parametrize("lanes16", [False, True])
 def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes16):
     """fill8_kernel's edges one by one: rows of exactly 40 / 41 / 80 / 81 / 112 cells (one, two, three passes of 40 columns:
