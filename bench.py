@@ -27,7 +27,11 @@ With N>1 every rank maps its own shard of the same size against its own replica 
 data-path collective; one RCCL all-reduce of the run counters at the end).  `python bench.py --gpus N` started
 without a launcher starts its N ranks itself (fresh child processes, before anything touches a GPU).
 
-Prints ONE JSON line on rank 0.
+Output on rank 0: the LAST stdout line is ONE compact JSON object (< 4 KB: the driver keeps an 8 KB tail) with the
+contract's fields, `roofline` (the step's dominant kernel), `cpu_baseline` and a five-field stub per other configuration.
+Everything else -- every kernel's roofline entry, the SDP phases, the whole-mapper leg, the reference binary's baseline, the
+other configurations' full records -- goes to EARLIER stdout lines ("[bench detail] <key>: <json>") and, whole, to
+--detail-out (default gpurun_out/bench_detail.json).
 """
 import argparse
 import json
@@ -112,6 +116,8 @@ def parse_args(argv=None):
     ap.add_argument("--load-workload", default="", metavar="PATH",
                     help="read the inputs a --save-workload run wrote instead of generating them (rocprofv3 --pmc dies "
                          "inside torch's generator on this image: tools/pmc_config.sh profiles a loaded workload)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), metavar="PATH",
+                    help="where the FULL record goes (the last stdout line is the compact one); '' = nowhere")
     ap.add_argument("--stub-device", action="store_true",
                     help="CPU-only dry run of the launch / shard / reduce code (gloo, no device step): for the tests")
     return ap.parse_args(argv)
@@ -445,29 +451,138 @@ def other_configs(steps):
     (fresh context, own inputs, own parity sample against the CPU checker), cut down to the figures of a bench line."""
     runs = (("configs[1]", ["--config", "1"]), ("configs[4]", ["--config", "4"]),
             ("configs[4] -noUseGuidedAlign (wide k-band)", ["--config", "4", "--no-guided"]))
+    import tempfile
     res = {}
     for name, flags in runs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "1",
-               "--from-reads", "0", "--blasrmc-reads", "0", "--other-configs", "0"] + flags
-        t0 = time.perf_counter()
-        try:
-            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-        except subprocess.TimeoutExpired:
-            res[name] = {"error": "timed out after 900 s"}
-            continue
-        line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-        if p.returncode != 0 or not line:
-            res[name] = {"error": "exit %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
-            continue
-        o = json.loads(line[-1])
+        with tempfile.TemporaryDirectory() as tmp:
+            detail = os.path.join(tmp, "detail.json")
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "1",
+                   "--from-reads", "0", "--blasrmc-reads", "0", "--other-configs", "0", "--detail-out", detail] + flags
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            except subprocess.TimeoutExpired:
+                res[name] = {"error": "timed out after 900 s"}
+                continue
+            if p.returncode != 0 or not os.path.exists(detail):
+                res[name] = {"error": "exit %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+                continue
+            o = json.load(open(detail))  # the child's FULL record (its last stdout line is the compact one)
         keep = ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "gcups_per_gpu", "stage_ms_per_step", "roofline",
-                "refine_rooflines", "sdp_rooflines", "cpu_baseline", "device_memory_held_gb", "build_id")
+                "roofline_of_the_largest_refine_kernel", "kernel_rooflines", "sdp_rooflines", "cpu_baseline",
+                "device_memory_held_gb", "build_id")
         res[name] = {k: o[k] for k in keep if k in o}
         res[name]["config"] = {k: o["config"][k] for k in ("workload", "reads_per_gpu", "read_len", "refiner",
                                                            "candidate_intervals_per_gpu", "candidates_refined_per_gpu",
                                                            "aligned_reads") if k in o["config"]}
         res[name]["wall_s_of_the_child"] = round(time.perf_counter() - t0, 1)
     return res
+
+# ---------------------------------------------------------------------------------------------------------------
+# the driver's line: compact, < 4 KB (the driver parses the last stdout line out of an 8 KB tail)
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _sig(x, digits=5):
+    """Floats to `digits` significant figures (the full-precision numbers are in the detail record)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if d is not None and k in d}
+
+
+ROOFLINE_KEYS = ("kernel", "stage", "bound", "achieved", "peak", "unit", "frac", "traffic", "valu_issue_frac", "avg_launch_ms",
+                 "launches_per_step", "ms_per_step", "concurrent_launches", "share_of_step", "stage_frac", "stage_gcups",
+                 "salu_over_valu")
+CPU_KEYS = ("value", "unit", "cores", "kind", "parity_checked", "parity_mismatches")
+
+
+def other_config_stub(o):
+    """The five fields an other configuration leaves on the driver's line."""
+    if "error" in o:
+        return {"error": str(o["error"])[:120]}
+    rl, cb = o.get("roofline") or {}, o.get("cpu_baseline") or {}
+    return {"ms_per_step": _sig(o.get("ms_per_step")), "value": _sig(o.get("value")), "roofline_frac": _sig(rl.get("frac")),
+            "roofline_kernel": rl.get("kernel"), "parity_mismatches": cb.get("parity_mismatches"),
+            "parity_checked": cb.get("parity_checked")}
+
+
+def compact_line(out, detail_path=None):
+    """The full record `out` cut down to the one line the driver reads: the contract's fields, `roofline` of the step's
+    dominant kernel, `cpu_baseline`, the wall time of the stages, a stub per other configuration.  Raises when the result
+    would not fit LINE_LIMIT bytes (tests/test_bench_line_cpu.py feeds it full records)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype"))
+    line["data"] = "synthetic (generated on the device from seeds; see the detail record)"
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("reads_per_gpu", "read_len", "band", "refiner", "candidate_intervals_per_gpu",
+                                 "candidates_refined_per_gpu", "reads", "aligned_reads", "hits_per_gpu"))
+    line["config"]["workload"] = cfg.get("workload_short") or str(cfg.get("workload", ""))[:240]
+    if "gcups_per_gpu" in out:
+        line["gcups_per_gpu"] = _sig(out["gcups_per_gpu"])
+    if out.get("stage_ms_per_step"):
+        line["stage_ms_per_step"] = {k: _sig(v, 4) for k, v in out["stage_ms_per_step"].items()}
+    rl = out.get("roofline")
+    line["roofline"] = _pick(rl, ROOFLINE_KEYS) if rl else None
+    if out.get("roofline_of_the_largest_refine_kernel"):
+        line["roofline_of_the_largest_refine_kernel"] = _pick(out["roofline_of_the_largest_refine_kernel"],
+                                                              ("kernel", "bound", "frac", "valu_issue_frac", "avg_launch_ms",
+                                                               "launches_per_step", "traffic"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, CPU_KEYS)
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    wb = out.get("cpu_baseline_whole_blasr")
+    if wb:
+        line["cpu_baseline_whole_blasr"] = _pick(wb, ("value", "unit", "cores", "kind", "reads_per_s", "genome_bases", "error"))
+    ee = out.get("end_to_end")
+    if ee:
+        line["end_to_end"] = _pick(ee, ("ms_per_step", "reads_per_s", "aligned_bases_per_s", "vs_whole_blasr"))
+    if out.get("other_configs"):
+        line["other_configs"] = {name: other_config_stub(o) for name, o in out["other_configs"].items()}
+    for k in ("device_memory_held_gb", "build_id", "physical_gpus", "rccl_ranks", "counters_backend"):
+        if k in out:
+            line[k] = _sig(out[k])
+    if out.get("per_rank_ms_per_step") and out.get("n_gpus", 1) > 1:
+        line["per_rank_ms_per_step"] = [_sig(r.get("step"), 4) for r in out["per_rank_ms_per_step"]]
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:  # drop the optional parts, largest first, rather than print a line the driver cannot read
+        for k in ("stage_ms_per_step", "end_to_end", "cpu_baseline_whole_blasr", "roofline_of_the_largest_refine_kernel",
+                  "per_rank_ms_per_step"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    if len(text) >= LINE_LIMIT:
+        raise ValueError("bench.py: the driver's line would be %d bytes (limit %d)" % (len(text), LINE_LIMIT))
+    return text
+
+
+def emit(out, detail_path):
+    """Detail first (earlier stdout lines + the detail file), the compact line LAST."""
+    rel = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            rel = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+        except OSError as e:
+            print("[bench detail] could not write %s: %s" % (detail_path, e))
+    for k, v in out.items():
+        if isinstance(v, (dict, list)):
+            print("[bench detail] %s: %s" % (k, json.dumps(v)))
+    sys.stdout.flush()
+    print(compact_line(out, rel))
+    sys.stdout.flush()
 
 
 def main():
@@ -599,6 +714,7 @@ def main():
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     acc = {}
     kacc = {}  # the refine stage's heavy kernels, each on its own (blasr_hip_refine_last_kernels), summed over the steps
+    sacc = {}  # the SDP stage's (blasr_hip_sdp_last_kernels)
 
     def step():
         w0 = time.perf_counter()
@@ -618,6 +734,11 @@ def main():
             a = kacc.setdefault(kr["name"], dict(ms=0.0, launches=0, bytes=0, cells=0, candidates=0))
             for f in a:
                 a[f] += kr[f]
+        for kr in ctx.sdp_last_kernels():  # the SDP stage's heavy kernels, timed the same way (blasr_hip_sdp_last_kernels)
+            a = sacc.setdefault(kr["name"], dict(ms=0.0, launches=0, bytes=0, fragments=0, invocations=0, concurrent=1))
+            for f in ("ms", "launches", "bytes", "fragments", "invocations"):
+                a[f] += kr[f]
+            a["concurrent"] = max(a["concurrent"], kr["concurrent"])
         return t
 
     def barrier():
@@ -629,6 +750,7 @@ def main():
         step()
     acc.clear()
     kacc.clear()
+    sacc.clear()
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -687,10 +809,10 @@ def main():
                 "refine_traceback_stats": acc["traceback_ms"] / K, "refine_compact": acc["compact_ms"] / K},
             "sdp_counters_per_step": {"sdpalign_invocations": acc["invocations"] // K,
                                       "fragments": acc["fragments"] // K, "swalign_fills": acc["sw_fills"] // K},
-            # the dominant kernel of the step = the refine kernel with the largest HIP-event time (filled in below from
-            # blasr_hip_refine_last_kernels: every heavy refine kernel timed on its own, on the stream it ran on, with the
-            # algorithmic bytes of exactly the candidates it processed); the others follow in refine_rooflines
-            "roofline": None, "refine_rooflines": None,
+            # the dominant kernel of the step = the kernel with the largest HIP-event time, whatever stage it is in (filled in
+            # below from blasr_hip_refine_last_kernels and blasr_hip_sdp_last_kernels: every heavy kernel timed on its own, on
+            # the stream it ran on, with the algorithmic bytes of exactly what it processed); all of them in kernel_rooflines
+            "roofline": None, "kernel_rooflines": None,
             # the SDP phases against the same roof: algorithmic bytes by SURVEY.md 8(d)'s model over HIP-event time
             "sdp_rooflines": {
                 name: {"bound": "hbm", "achieved": gbps(acc[b], acc[m]), "peak": 8000.0, "unit": "GB/s",
@@ -747,17 +869,63 @@ def main():
                 rl["valu_wave_instructions_per_launch"] = insts
             # which roof binds: the larger of the two fractions (the contract's figures stay the HBM ones)
             if rl.get("valu_issue_frac", 0.0) > rl["frac"]:
-                rl["bound"] = "valu"
+                # (from a count of the ISA instead of counters of this build: said so, and not asserted by any test)
+                rl["bound"] = "valu (modelled)" if "valu_issue_frac_source" in rl else "valu"
+            rl["stage"] = "refine"
+            if name == "blasr_hip::kband_wide_kernel" and a["launches"] > K:
+                # the chunks of a k-band batch run as two lanes on two streams: the launches overlap, so a
+                # launch's own time is that of a shared device; the stage-level figure is the one to read
+                rl["concurrent_launches"] = 2
+                if acc["fill_ms"] > 0:
+                    rl["stage_achieved"] = gbps(a["bytes"], acc["fill_ms"])
+                    rl["stage_frac"] = rl["stage_achieved"] / 8000.0
+                    rl["stage_gcups"] = a["cells"] / (acc["fill_ms"] / 1e3) / 1e9
             lines.append(rl)
-        lines.sort(key=lambda r: -r["avg_launch_ms"] * r["launches_per_step"])
+        for name, a in sacc.items():  # the SDP stage's kernels: 8(d)'s byte model over their own HIP-event time
+            if a["ms"] <= 0 or a["launches"] <= 0:
+                continue
+            ach = gbps(a["bytes"], a["ms"])
+            rl = {"bound": "hbm", "kernel": name, "stage": "sdp", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                  "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                  "launches_per_step": a["launches"] / K, "avg_launch_ms": a["ms"] / a["launches"],
+                  "fragments_per_step": a["fragments"] / K, "invocations_per_step": a["invocations"] / K}
+            if a["concurrent"] > 1:
+                rl["concurrent_launches"] = a["concurrent"]
+            # the counters of the kernels the record covers (a PMC profile is one step: tools/pmc_config.sh), per bracket
+            parts = [x if x.startswith("blasr_hip::") else "blasr_hip::" + x for x in name.split(" + ")]
+            mine = [v for kn, v in pmc.items() if any(kn == x or kn.startswith(x + "<") or kn.startswith(x.replace("_kernel", "_copy_kernel"))
+                                                      for x in parts)]
+            if mine:
+                if all(v.get("hbm_bytes") is not None for v in mine):
+                    rl["traffic"] = sum(v["hbm_bytes"] for v in mine) / max(rl["launches_per_step"], 1)
+                    rl["traffic_over_algorithmic"] = rl["traffic"] / max(rl["algorithmic_bytes_per_launch"], 1)
+                valu, salu = sum(v.get("SQ_INSTS_VALU", 0) for v in mine), sum(v.get("SQ_INSTS_SALU", 0) for v in mine)
+                if valu > 0:
+                    rl["salu_over_valu"] = salu / valu
+                    if a["fragments"] > 0:
+                        rl["wave_instructions_per_fragment"] = (valu + salu) / (a["fragments"] / K)
+                rl["pmc_profile"] = pmc_path
+            # a serial chain per invocation: neither an HBM nor a VALU-issue roof binds it
+            if "chain" in name or "small" in name:
+                rl["bound_note"] = "latency of a serial dependency chain per invocation; achieved / peak / frac are the HBM figures"
+            lines.append(rl)
+        step_ms = elapsed / K * 1e3
+        for rl in lines:
+            rl["ms_per_step"] = rl["avg_launch_ms"] * rl["launches_per_step"]
+            rl["share_of_step"] = rl["ms_per_step"] / step_ms
+        lines.sort(key=lambda r: -r["ms_per_step"])
         if lines:
             out["roofline"] = dict(lines[0])
             if out["roofline"]["bound"] == "valu":
                 out["roofline"]["limiter"] = ("VALU issue (integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
                                               "instruction, profiles/r02_valu_rate.txt): valu_issue_frac is the roof that "
                                               "binds; achieved / peak / frac are the HBM figures the contract asks for")
-            out["roofline"]["fill_stage_gcups"] = acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0
-            out["refine_rooflines"] = lines[1:]
+            out["kernel_rooflines"] = lines
+            refine_lines = [r for r in lines if r["stage"] == "refine"]
+            if refine_lines and refine_lines[0]["kernel"] != lines[0]["kernel"]:
+                out["roofline_of_the_largest_refine_kernel"] = dict(refine_lines[0])
+            if refine_lines:
+                out["fill_stage_gcups"] = acc["cells"] / (acc["fill_ms"] / 1e3) / 1e9 if acc["fill_ms"] > 0 else 0.0
         if world == 1:
             cores = args.cpu_cores if args.cpu_cores > 0 else (os.cpu_count() or 1)
             # ~10-30 s of host work on `cores` threads: 4.95 ms per 10 kb candidate through SDP + guided refine on one
@@ -803,7 +971,7 @@ def main():
             del genome, wl, reads_t, iv_t
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args.other_configs)
-        print(json.dumps(out))
+        emit(out, args.detail_out)
     if dist is not None:
         dist.destroy_process_group()
     if ctx is not None:

@@ -207,6 +207,8 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) try {
     }
   for (auto &e : ctx->auxEvent)
     if (e) (void)hipEventDestroy(e);
+  for (auto &e : ctx->sdpEventPool)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->workspace) (void)hipFree(ctx->workspace);
   if (ctx->genome && ctx->genomeOwned) (void)hipFree(ctx->genome);
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);

@@ -44,6 +44,10 @@ struct blasr_hip_ctx {
   float sdpMs[4] = {0, 0, 0, 0};
   int64_t sdpCounters[3] = {0, 0, 0};
   int64_t sdpBytes[4] = {0, 0, 0, 0};
+  // every heavy SDP kernel on its own (blasr_hip_sdp_last_kernels); the events its launches are bracketed with are
+  // created on demand and kept (destroyed with the context)
+  blasr_hip_sdp_kernel_record sdpKernelRec[BLASR_HIP_SDP_KERNEL_KINDS] = {};
+  std::vector<hipEvent_t> sdpEventPool;
   double sdpBytesPerBase = 48.0;  // level arrays per base of query + target, as the last pieces needed them
   // the resident genome (ASCII) and its contig table, for the window gather
   uint8_t *genome = nullptr;

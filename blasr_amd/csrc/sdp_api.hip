@@ -139,6 +139,32 @@ int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]) try {
   return BLASR_HIP_OK;
 } BLASR_HIP_CATCH_CODE
 
+int blasr_hip_sdp_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_sdp_kernel_record *out, int capacity) try {
+  if (!ctx || (!out && capacity > 0) || capacity < 0) return BLASR_HIP_ERR_INVALID;
+  int n = 0;
+  for (int k = 0; k < BLASR_HIP_SDP_KERNEL_KINDS; k++) {
+    if (ctx->sdpKernelRec[k].launches <= 0) continue;
+    if (n < capacity) out[n] = ctx->sdpKernelRec[k];
+    n++;
+  }
+  return n;
+} BLASR_HIP_CATCH_CODE
+
+const char *blasr_hip_sdp_kernel_name(int kind) {
+  switch (kind) {  // (as rocprofv3 prints the kernel that dominates the record)
+    case BLASR_HIP_SDP_KERNEL_MATCH_INDEX: return "blasr_hip::sdp_match_index_kernel";
+    case BLASR_HIP_SDP_KERNEL_MATCH_SHORT: return "blasr_hip::sdp_match_kernel";
+    case BLASR_HIP_SDP_KERNEL_SMALL: return "blasr_hip::sdp_small4_kernel + sdp_small_kernel";
+    case BLASR_HIP_SDP_KERNEL_CHAIN4: return "blasr_hip::sdp_chain4_kernel";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL: return "blasr_hip::sdp_chain_bits_kernel<512>";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE: return "blasr_hip::sdp_chain_bits_kernel<4096>";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS4: return "blasr_hip::sdp_chain_bits4_kernel";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_ROWS: return "blasr_hip::sdp_chain_rows_kernel";
+    case BLASR_HIP_SDP_KERNEL_FILLS: return "blasr_hip::sw_small_kernel + sw_kernel";
+  }
+  return "";
+}
+
 }  // extern "C"
 
 namespace {
@@ -207,7 +233,13 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   SdpTask *dTop = arena.keep<SdpTask>(n);  // (needed until the call ends, like everything the levels hand on)
   int32_t *dMatrix = arena.keep<int32_t>(32);
   Counters *dCounters = arena.keep<Counters>(1);
+  unsigned long long *dKernelSums = arena.keep<unsigned long long>(3 * BLASR_HIP_SDP_KERNEL_KINDS);
   ARENA_CHECK();
+  HIP_TRY(ctx, hipMemsetAsync(dKernelSums, 0, sizeof(unsigned long long) * 3 * BLASR_HIP_SDP_KERNEL_KINDS, st));
+  SdpSpans spans;
+  spans.pool = &ctx->sdpEventPool;
+  float kMs[BLASR_HIP_SDP_KERNEL_KINDS] = {};
+  int32_t kLaunches[BLASR_HIP_SDP_KERNEL_KINDS] = {}, kConcurrent[BLASR_HIP_SDP_KERNEL_KINDS] = {};
   HIP_TRY(ctx, hipMemcpyAsync(dTop, top.data(), sizeof(SdpTask) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dMatrix, score->matrix, sizeof(int32_t) * 25, hipMemcpyHostToDevice, st));
 
@@ -240,6 +272,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     memset(&lv, 0, sizeof(lv));
     lv.n = nTasks;
     lv.tasks = dTasks;
+    lv.kernelSums = dKernelSums;
+    lv.spans = &spans;
     // ---- k-mer keys of the targets, sorted per task ----
     tick();
     lv.idxMaxT = idxMaxT;
@@ -411,6 +445,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);
     launch_sdp_above_predcl(lv, st);
     lv.generalMode = 0;
+    launch_sdp_kernel_sums(lv, st);
     tock(1);
 
     // ---- chain ----
@@ -458,6 +493,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
         std::vector<int32_t> list((size_t)std::max(total, 1)), nf((size_t)nTasks);
         HIP_TRY(ctx, hipMemcpy(list.data(), lv.chainList, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(nf.data(), lv.nFrag, sizeof(int32_t) * (size_t)nTasks, hipMemcpyDeviceToHost));
+        std::vector<SdpTask> hostTasks((size_t)nTasks);
+        HIP_TRY(ctx, hipMemcpy(hostTasks.data(), dTasks, sizeof(SdpTask) * (size_t)nTasks, hipMemcpyDeviceToHost));
         int pos = 0;
         for (int c = 4; c >= 0; c--) {
           long long inv[10] = {0}, fr[10] = {0};
@@ -472,6 +509,19 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
           if (cnt[c] == 0) continue;
           fprintf(stderr, "[sdp]   category %d by fragments (<=64,128,...,16384,more): ", c);
           for (int b = 0; b < 10; b++) fprintf(stderr, "%lld/%lldk ", inv[b], fr[b] / 1000);
+          fprintf(stderr, "\n");
+          // fragments per query row (the sweep scores a row's fragments against one state of the column set): fragments of
+          // the category by their invocation's nFrag / qLen
+          long long dens[7] = {0};
+          for (int i = 0; i < cnt[c]; i++) {
+            const int ti = list[(size_t)(pos - cnt[c] + i)];
+            const double d = (double)nf[(size_t)ti] / std::max(hostTasks[(size_t)ti].qLen, 1);
+            int b = 0;
+            while (b < 6 && d >= (0.5 * (1 << b))) b++;
+            dens[b] += nf[(size_t)ti];
+          }
+          fprintf(stderr, "[sdp]   category %d fragments by fragments per row (<0.5,<1,<2,<4,<8,<16,more): ", c);
+          for (int b = 0; b < 7; b++) fprintf(stderr, "%lldk ", dens[b] / 1000);
           fprintf(stderr, "\n");
         }
       }
@@ -521,6 +571,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
     tock(3);
+    spans.collect(kMs, kLaunches, kConcurrent, BLASR_HIP_SDP_KERNEL_KINDS);  // (every stream of the level was joined and waited for)
     Counters hc;
     memset(&hc, 0, sizeof(hc));
     hc.pool = (unsigned long long)emitTotals[0];
@@ -644,8 +695,10 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       size_t bytes = swSortBytes;
       HIP_TRY(ctx, rocprim::radix_sort_pairs(swSortTmp, bytes, swKeys, swKeysSorted, swIdx, swOrder, (size_t)lo.swCount,
                                              0u, 13u, st));
+      spans.begin(BLASR_HIP_SDP_KERNEL_FILLS, st);
       launch_sw_small(lo.sw, swOrder, lo.swCount, nBigL, b->seq, dMatrix, prm, smallScratch, e, st);
       launch_sw(lo.sw, swOrder, lo.swCount, nBigL, bigBlocks, b->seq, dMatrix, prm, scratch, scratchPerLane, parkOff, e, st);
+      spans.end(st);
     }
   }
   Counters hc;
@@ -698,6 +751,32 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipGetLastError());
   tock(3);
   phaseBytes[3] += nPool * 12;
+  {  // the heavy kernels one by one: times from the brackets, what they processed from the device's sums
+    spans.collect(kMs, kLaunches, kConcurrent, BLASR_HIP_SDP_KERNEL_KINDS);
+    unsigned long long sums[3 * BLASR_HIP_SDP_KERNEL_KINDS];
+    HIP_TRY(ctx, hipMemcpy(sums, dKernelSums, sizeof(sums), hipMemcpyDeviceToHost));
+    for (int kd = 0; kd < BLASR_HIP_SDP_KERNEL_KINDS; kd++) {
+      blasr_hip_sdp_kernel_record &r = ctx->sdpKernelRec[kd];
+      r.kind = kd;
+      r.launches += kLaunches[kd];
+      r.ms += kMs[kd];
+      r.concurrent = std::max(r.concurrent, kConcurrent[kd]);
+      int64_t fr = (int64_t)sums[3 * kd], inv = (int64_t)sums[3 * kd + 1], qp = (int64_t)sums[3 * kd + 2], bytes = 0;
+      if (kd == BLASR_HIP_SDP_KERNEL_FILLS) {  // a fill reads its two sides and writes at most min(q, t) blocks of 12 B
+        fr = inv = swTotal;
+        bytes = fillBlocks * (2 + 12);
+      } else if (kd == BLASR_HIP_SDP_KERNEL_MATCH_INDEX || kd == BLASR_HIP_SDP_KERNEL_MATCH_SHORT) {
+        bytes = qp * 8 + fr * 16;  // (8 B per query position, 16 B per fragment written)
+      } else if (kd == BLASR_HIP_SDP_KERNEL_SMALL) {
+        bytes = fr * 16 * 2;       // fragments ordered and swept in one kernel
+      } else {
+        bytes = fr * 16;           // 16 B per fragment read by the sweep
+      }
+      r.fragments += fr;
+      r.invocations += inv;
+      r.algorithmic_bytes += bytes;
+    }
+  }
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
   for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = phaseBytes[i];
   ctx->sdpCounters[0] = totalInvocations;
@@ -723,6 +802,7 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = 0;
   for (int i = 0; i < 3; i++) ctx->sdpCounters[i] = 0;
   for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = 0;
+  for (auto &r : ctx->sdpKernelRec) r = blasr_hip_sdp_kernel_record();
   const int n = b->n;
   if (n == 0) return BLASR_HIP_OK;
   if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))

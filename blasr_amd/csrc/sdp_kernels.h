@@ -6,7 +6,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace blasr_hip {
+
+// Host side: HIP-event brackets around the stage's heavy kernels, each on the stream it is launched on
+// (blasr_hip_sdp_last_kernels).  begin() / end() enclose the launches of ONE kind on ONE stream; collect() -- after the
+// streams were joined and synchronised -- adds the elapsed times to the records.
+struct SdpSpans {
+  struct Span {
+    int kind, concurrent;
+    hipEvent_t a, b;
+  };
+  std::vector<hipEvent_t> *pool = nullptr;  // the context's events, grow-only
+  size_t used = 0;
+  std::vector<Span> spans;
+  Span cur = {-1, 0, nullptr, nullptr};
+  hipEvent_t take();
+  void begin(int kind, hipStream_t s, int concurrent = 1);
+  void end(hipStream_t s);
+  // ms[kind] += elapsed, launches[kind]++, concurrent[kind] = max; forgets the spans (their events are reused)
+  void collect(float *ms, int32_t *launches, int32_t *concurrent, int kinds);
+};
 
 // One SDPAlign invocation (SDPAlign.h:95-626): a top-level candidate or a
 // recursive call on a gap rectangle.
@@ -88,6 +109,10 @@ struct SdpLevelArrays {
   int32_t *chainEnd;                                      // n: last fragment of the reported chain
   int32_t *scratchA;                                      // per fragment: chain indices
   int32_t *scratchB;                                      // 3 per fragment: candidate blocks
+  // per kernel kind (BLASR_HIP_SDP_KERNEL_*) three sums over the invocations it takes: {fragments, invocations, query
+  // positions}, accumulated on the device (launch_sdp_kernel_sums, launch_sdp_chain_list); null: not wanted
+  unsigned long long *kernelSums;
+  SdpSpans *spans;  // host only: the launch functions bracket their heavy kernels with it (null: no timing)
 };
 
 struct SdpEmit {
@@ -148,6 +173,8 @@ void launch_sdp_finish(int n, const SdpTask *tasks, const uint8_t *seq, const ui
                        const int32_t *matrix, int ins, int del, int open, int ext, SdpResult *results, int32_t *blocks,
                        int64_t blocksCap, int64_t blkBase, hipStream_t st);
 void launch_pool_offsets(const uint64_t *poolKeys, int64_t nPool, int n, int64_t *off, hipStream_t st);
+// the matchers' and the fused small kernels' sums for lv.kernelSums (after the match write pass and launch_sdp_small)
+void launch_sdp_kernel_sums(const SdpLevelArrays &lv, hipStream_t st);
 // widest target sdp_chain_bits_kernel takes (its bitmap lives in LDS)
 int sdp_chain_bits_max_target();
 // tLen (or the three raw fragment counts summed, or nFrag; 4: the column slots of lv.colEnt) of every task as int64,

@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "../../include/blasr_hip.h"
 #include "introsort_replay.h"
 #include "sdp_kernels.h"
 #include "wave_utils.h"
@@ -1900,6 +1901,17 @@ __device__ __forceinline__ int4 *uniform_ptr(int4 *p, int srcLane) {
   return reinterpret_cast<int4 *>(((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)wave_prefix_sum(v), 63); }
+// which record (BLASR_HIP_SDP_KERNEL_*) the sweep kernel of a category of the sorted list fills
+__host__ __device__ inline int chain_category_kind(int cat) {
+  switch (cat) {
+    case 0: return BLASR_HIP_SDP_KERNEL_CHAIN4;
+    case 2: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS4;
+    case 3: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL;
+    case 4: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE;
+  }
+  return -1;  // (1: sdp_chain_wide_kernel, tests only)
+}
 // The invocations sdp_chain4_kernel takes, as (fragment count, index) pairs for a descending sort: the four of a
 // wavefront then have about the same number of fragments (the wavefront runs as long as its longest) and the long
 // ones start first.  Entries that are not taken get the key 0 and end up behind the list.
@@ -1926,7 +1938,49 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
   }
   for (int c = 0; c < 5; c++) {
     const unsigned long long m = __ballot(take && cat == c);
-    if (m != 0ull && lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
+    if (m == 0ull) continue;
+    if (lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
+    if (lv.kernelSums != nullptr) {  // what the category's kernel will have swept (blasr_hip_sdp_last_kernels)
+      const int kind = chain_category_kind(c);
+      const unsigned fr = wave_sum_u32(take && cat == c ? (unsigned)lv.nFrag[i] : 0u);
+      const unsigned qp = wave_sum_u32(take && cat == c ? (unsigned)lv.tasks[i].qLen : 0u);
+      if (lane_id() == 0 && kind >= 0) {
+        atomicAdd(lv.kernelSums + 3 * kind + 0, (unsigned long long)fr);
+        atomicAdd(lv.kernelSums + 3 * kind + 1, (unsigned long long)__popcll(m));
+        atomicAdd(lv.kernelSums + 3 * kind + 2, (unsigned long long)qp);
+      }
+    }
+  }
+}
+
+// The matchers' and the fused small kernels' invocations, for lv.kernelSums: a long target goes through
+// sdp_match_index_kernel, any other through sdp_match_kernel (fragments: the raw ones they wrote); a fused invocation
+// was ordered and swept by sdp_small4_kernel / sdp_small_kernel (fragments: the kept ones).
+__global__ __launch_bounds__(256) void sdp_kernel_sums_kernel(SdpLevelArrays lv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < lv.n;
+  int cls = -1;
+  unsigned raw = 0, q = 0, kept = 0;
+  bool fused = false;
+  if (in) {
+    const SdpTask t = lv.tasks[i];
+    cls = task_uses_index(t.tLen, t.k, lv.idxMaxT) ? BLASR_HIP_SDP_KERNEL_MATCH_INDEX : BLASR_HIP_SDP_KERNEL_MATCH_SHORT;
+    raw = (unsigned)(lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2]);
+    q = (unsigned)t.qLen;
+    fused = lv.fused[i] != 0;
+    kept = (unsigned)lv.nFrag[i];
+  }
+  for (int c = 0; c < 3; c++) {
+    const int kind = c == 0 ? BLASR_HIP_SDP_KERNEL_MATCH_INDEX : (c == 1 ? BLASR_HIP_SDP_KERNEL_MATCH_SHORT : BLASR_HIP_SDP_KERNEL_SMALL);
+    const bool mine = in && (c == 2 ? fused : cls == kind);
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) continue;
+    const unsigned fr = wave_sum_u32(mine ? (c == 2 ? kept : raw) : 0u), qp = wave_sum_u32(mine ? q : 0u);
+    if (lane_id() == 0) {
+      atomicAdd(lv.kernelSums + 3 * kind + 0, (unsigned long long)fr);
+      atomicAdd(lv.kernelSums + 3 * kind + 1, (unsigned long long)__popcll(m));
+      atomicAdd(lv.kernelSums + 3 * kind + 2, (unsigned long long)qp);
+    }
   }
 }
 
@@ -3922,6 +3976,55 @@ __global__ __launch_bounds__(256) void sdp_finish_kernel(int n, const SdpTask *t
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+hipEvent_t SdpSpans::take() {
+  if (pool == nullptr) return nullptr;
+  if (used == pool->size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    pool->push_back(e);
+  }
+  return (*pool)[used++];
+}
+void SdpSpans::begin(int kind, hipStream_t s, int concurrent) {
+  cur = Span{kind, concurrent, take(), take()};
+  if (cur.a != nullptr && cur.b != nullptr) (void)hipEventRecord(cur.a, s);
+}
+void SdpSpans::end(hipStream_t s) {
+  if (cur.kind < 0 || cur.a == nullptr || cur.b == nullptr) return;
+  (void)hipEventRecord(cur.b, s);
+  spans.push_back(cur);
+  cur.kind = -1;
+}
+void SdpSpans::collect(float *ms, int32_t *launches, int32_t *concurrent, int kinds) {
+  for (const Span &sp : spans) {
+    float t = 0;
+    if (sp.kind >= kinds || hipEventElapsedTime(&t, sp.a, sp.b) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    ms[sp.kind] += t;
+    launches[sp.kind]++;
+    concurrent[sp.kind] = std::max(concurrent[sp.kind], sp.concurrent);
+  }
+  spans.clear();
+  used = 0;
+}
+namespace {
+struct SpanScope {  // brackets the launches of one kind on one stream
+  SdpSpans *sp;
+  hipStream_t s;
+  SpanScope(const SdpLevelArrays &lv, int kind, hipStream_t st, int concurrent = 1) : sp(lv.spans), s(st) {
+    if (sp) sp->begin(kind, s, concurrent);
+  }
+  ~SpanScope() {
+    if (sp) sp->end(s);
+  }
+};
+}  // namespace
+
 static dim3 wave_grid(int n) { return dim3((unsigned)((n + 3) / 4)); }
 // (the general kernels' grid: a wavefront per invocation, or -- general_task's mode 2 -- a fixed one that strides over a list)
 static dim3 general_grid(const SdpLevelArrays &lv) { return lv.generalMode == 2 ? dim3(2048) : wave_grid(lv.n); }
@@ -3937,9 +4040,16 @@ void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *t
 }
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side) {
   if (lv.n <= 0) return;
-  if (write) hipLaunchKernelGGL((sdp_match_kernel<true, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
-  else {
-    hipLaunchKernelGGL((sdp_match_kernel<false, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  const int conc = side ? 3 : 1;  // (beside the index matcher's two streams, launch_sdp_match_all)
+  if (write) {
+    SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_MATCH_SHORT, st, conc);
+    hipLaunchKernelGGL((sdp_match_kernel<true, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+  } else {
+    {
+      SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_MATCH_SHORT, st, conc);
+      hipLaunchKernelGGL((sdp_match_kernel<false, false>), wave_grid(lv.n), dim3(256), 0, st, lv, seq);
+    }
+    SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_MATCH_SHORT, side ? side : st, conc);
     hipLaunchKernelGGL((sdp_match_kernel<false, true>), dim3((unsigned)std::min((lv.n + 3) / 4, 4096)), dim3(256), 0,
                        side ? side : st, lv, seq);  // (a fixed grid over its list)
   }
@@ -4005,16 +4115,22 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
   // three size classes, so that the usual targets (<= kIdxSmallCap) get four workgroups per CU
   const int grid = std::min(lv.n, 1024);
   const int caps[3] = {std::min(kIdxSmallCap, lv.idxMaxT), std::min(kIdxMidCap, lv.idxMaxT), lv.idxMaxT};
-  if (write) hipLaunchKernelGGL(sdp_match_index_copy_kernel, dim3(std::min(lv.n, 8192)), dim3(256), 0, st, lv, seq);
-  for (int c = 0; c < 3; c++) {
-    if (c > 0 && caps[c] <= caps[c - 1]) break;
-    const int minT = c == 0 ? 0 : caps[c - 1];
-    const size_t bytes = (size_t)idx_lds_bytes(caps[c]);
-    hipStream_t s = (c > 0 && side) ? side : st;
-    if (write)
-      hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
-    else
-      hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
+  const int conc = side ? 3 : 1;
+  // (one bracket per stream: the copy kernel and the first size class on `st`, the larger classes on `side`)
+  for (int part = 0; part < (side ? 2 : 1); part++) {
+    hipStream_t s = part == 0 ? st : side;
+    SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_MATCH_INDEX, s, conc);
+    if (part == 0 && write) hipLaunchKernelGGL(sdp_match_index_copy_kernel, dim3(std::min(lv.n, 8192)), dim3(256), 0, st, lv, seq);
+    for (int c = 0; c < 3; c++) {
+      if (c > 0 && caps[c] <= caps[c - 1]) break;
+      if (side && (c > 0) != (part == 1)) continue;
+      const int minT = c == 0 ? 0 : caps[c - 1];
+      const size_t bytes = (size_t)idx_lds_bytes(caps[c]);
+      if (write)
+        hipLaunchKernelGGL(sdp_match_index_kernel<true>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
+      else
+        hipLaunchKernelGGL(sdp_match_index_kernel<false>, dim3(grid), dim3(256), bytes, s, lv, seq, caps[c], minT);
+    }
   }
 }
 void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
@@ -4023,6 +4139,7 @@ void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *v
 void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_t *order, hipStream_t st) {
   if (lv.n <= 0) return;
   const bool small4 = order != nullptr;
+  SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_SMALL, st, lv.generalMode == 0 && lv.leftList != nullptr ? 2 : 1);
   if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p, order);
   if (small4)
     hipLaunchKernelGGL(sdp_small_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, p, kSmall4Max + 1, order);
@@ -4044,6 +4161,10 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_above_predcl_kernel, general_grid(lv), dim3(256), 0, st, lv);
 }
 int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
+void launch_sdp_kernel_sums(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n > 0 && lv.kernelSums != nullptr)
+    hipLaunchKernelGGL(sdp_kernel_sums_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
+}
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.chainCount, 0, 5 * sizeof(int32_t), st);  // one count per category
@@ -4070,12 +4191,26 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
         s0 = aux[0], s1 = aux[1], s2 = aux[2];
       }
-      if (!counts || counts[4] > 0) hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
-      if (!counts || counts[3] > 0)
+      int conc = 0;  // how many of the sweep's kernels run side by side
+      for (int c : {0, 2, 3, 4}) conc += (!counts || counts[c] > 0) ? 1 : 0;
+      if (!fork) conc = 1;
+      if (!counts || counts[4] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE, s0, conc);
+        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
+      }
+      if (!counts || counts[3] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL, s1, conc);
         hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, grid_for(3, 1), dim3(256), 0, s1, lv, p);
-      if (!counts || counts[2] > 0) hipLaunchKernelGGL(sdp_chain_bits4_kernel, grid_for(2, 4), dim3(256), 0, s2, lv, p);
+      }
+      if (!counts || counts[2] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS4, s2, conc);
+        hipLaunchKernelGGL(sdp_chain_bits4_kernel, grid_for(2, 4), dim3(256), 0, s2, lv, p);
+      }
       if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, grid_for(1, 1), dim3(256), 0, s2, lv, p);
-      if (!counts || counts[0] > 0) hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
+      if (!counts || counts[0] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN4, st, conc);
+        hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
+      }
       if (fork)
         for (int i = 0; i < 3; i++) {
           (void)hipEventRecord(ev[1 + i], aux[i]);
@@ -4083,6 +4218,7 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         }
       return;
     }
+    SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN4, st);
     hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
   } else {  // one invocation per wavefront (BLASR_HIP_NO_CHAIN4)
     hipLaunchKernelGGL(sdp_chain_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p);

@@ -52,8 +52,12 @@ EXPORTS = [
     "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
     "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
     "blasr_hip_kband_stats_device", "blasr_hip_kband_from_sdp_device", "blasr_hip_sa_write_resident",
+    "blasr_hip_sdp_last_kernels", "blasr_hip_sdp_kernel_name",
 ]
 
+# include/blasr_hip.h: blasr_hip_sdp_kernel_record
+SDP_KERNEL_RECORD_DTYPE = np.dtype([("kind", "<i4"), ("launches", "<i4"), ("ms", "<f4"), ("concurrent", "<i4"),
+                                    ("algorithmic_bytes", "<i8"), ("fragments", "<i8"), ("invocations", "<i8")])
 # include/blasr_hip.h: blasr_hip_kernel_record
 KERNEL_RECORD_DTYPE = np.dtype([("kind", "<i4"), ("launches", "<i4"), ("ms", "<f4"), ("ext0", "<i4"),
                                 ("algorithmic_bytes", "<i8"), ("cells", "<i8"), ("candidates", "<i8")])
@@ -1278,6 +1282,20 @@ class Context:
         return [dict(name=self.lib.blasr_hip_kernel_name(int(r["kind"]), int(r["ext0"])).decode(), kind=int(r["kind"]),
                      ms=float(r["ms"]), launches=int(r["launches"]), bytes=int(r["algorithmic_bytes"]),
                      cells=int(r["cells"]), candidates=int(r["candidates"])) for r in rec[:n]]
+
+    def sdp_last_kernels(self):
+        """Every heavy kernel of the last SDP call on its own (blasr_hip_sdp_last_kernels): HIP-event ms on the stream it
+        ran on, launches (brackets), how many kernels ran beside it, algorithmic bytes / fragments / invocations."""
+        rec = np.zeros(16, dtype=SDP_KERNEL_RECORD_DTYPE)
+        self.lib.blasr_hip_sdp_last_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.blasr_hip_sdp_kernel_name.argtypes = [C.c_int]
+        self.lib.blasr_hip_sdp_kernel_name.restype = C.c_char_p
+        n = self.lib.blasr_hip_sdp_last_kernels(self.handle, rec.ctypes.data, len(rec))
+        if n < 0:
+            self._check(n)
+        return [dict(name=self.lib.blasr_hip_sdp_kernel_name(int(r["kind"])).decode(), kind=int(r["kind"]), ms=float(r["ms"]),
+                     launches=int(r["launches"]), concurrent=int(r["concurrent"]), bytes=int(r["algorithmic_bytes"]),
+                     fragments=int(r["fragments"]), invocations=int(r["invocations"])) for r in rec[:n]]
 
     def sdp_last_timing(self):
         ms = (C.c_float * 4)()

@@ -44,7 +44,9 @@ extern "C" {
 /* 4: blasr_hip_map_params' reserved word became use_guided_align (a caller that fills the struct by hand instead of through
  * blasr_hip_map_default_params would get the k-band refiner with its old 0); BLASR_HIP_ERR_INTERNAL; the k-band entry points
  * take bands of any width and report TASK_EMPTY_GUIDE for an empty candidate. */
-#define BLASR_HIP_ABI_VERSION 4
+/* 5: blasr_hip_sdp_last_kernels / blasr_hip_sdp_kernel_name (every heavy SDP kernel timed on the stream it ran on); no
+ * struct of version 4 changed. */
+#define BLASR_HIP_ABI_VERSION 5
 
 typedef struct blasr_hip_ctx blasr_hip_ctx;
 
@@ -274,6 +276,34 @@ int blasr_hip_sdp_last_timing(const blasr_hip_ctx *ctx, float ms[4], int64_t cou
  * radix passes, [1] (qLen-k+1) x 8 B of query k-mers + 16 B per fragment written, [2] 16 B per fragment read by the
  * sweep, [3] 12 B per block. */
 int blasr_hip_sdp_last_bytes(const blasr_hip_ctx *ctx, int64_t bytes[4]);
+/* The heavy kernels of the last SDP call, each on its own: HIP events around every launch on the stream it ran on,
+ * summed over the recursion levels (and the pieces of a batch taken in pieces).  The sweep (SDPLongestCommonSubsequence,
+ * sdp/SparseDynamicProgramming.h:70-322) is split by the kernel that took an invocation; algorithmic bytes by SURVEY.md
+ * 8(d)'s model for the invocations the kernel processed: a sweep kernel 16 B per fragment read; a matcher 8 B per query
+ * position + 16 B per fragment written.  `concurrent` = how many kernels of the stage ran side by side with this one on
+ * other streams (their times overlap: the sum over the records exceeds the phase's wall time). */
+enum { BLASR_HIP_SDP_KERNEL_MATCH_INDEX = 0, /* sdp_match_index_kernel<false> + <true> + the copy kernel: targets >= 1536 bases */
+       BLASR_HIP_SDP_KERNEL_MATCH_SHORT = 1, /* sdp_match_kernel: the other targets */
+       BLASR_HIP_SDP_KERNEL_SMALL = 2,       /* sdp_small4_kernel + sdp_small_kernel: order .. sweep of <= 64 fragments, fused */
+       BLASR_HIP_SDP_KERNEL_CHAIN4 = 3,      /* sdp_chain4_kernel: near-diagonal invocations, four per wavefront */
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL = 4, /* sdp_chain_bits_kernel<512>: scattered, target <= 16384 columns */
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE = 5, /* sdp_chain_bits_kernel<4096> */
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS4 = 6, /* sdp_chain_bits4_kernel: short scattered invocations, four per wavefront */
+       BLASR_HIP_SDP_KERNEL_CHAIN_ROWS = 7,  /* sdp_chain_rows_kernel: scattered invocations with several fragments per query row,
+                                                a whole sweep row per step */
+       BLASR_HIP_SDP_KERNEL_FILLS = 8,       /* sw_small_kernel + sw_kernel: SWAlign(Global) gap fills */
+       BLASR_HIP_SDP_KERNEL_KINDS = 9 };
+typedef struct blasr_hip_sdp_kernel_record {
+  int32_t kind;
+  int32_t launches;
+  float ms;
+  int32_t concurrent;
+  int64_t algorithmic_bytes;
+  int64_t fragments;    /* fragments (sweep kernels, matchers) or fills */
+  int64_t invocations;  /* SDPAlign invocations the kernel took */
+} blasr_hip_sdp_kernel_record;
+int blasr_hip_sdp_last_kernels(const blasr_hip_ctx *ctx, blasr_hip_sdp_kernel_record *out, int capacity);
+const char *blasr_hip_sdp_kernel_name(int kind);
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -3,8 +3,9 @@ under the driver's GPU tests: a reduced number of reads of configs[2] (hg19-size
 competing repeat copies, chance clusters) and of configs[4] (30 kb reads at 15 % indels with eight long chance clusters
 per read -- the scattered-sweep regime of the SDP stage), every hit of every read compared with the reference's own
 SDPAlign / AffineGuidedAlign / ComputeAlignmentStats (oracle/_ref/libblasr_ref.so; the oracle's restatement where that
-build is absent) composed into MapRead by the checker.  The same run pins the shape of the bench line: `roofline` names
-the refine kernel with the largest measured time, the others follow in `refine_rooflines`."""
+build is absent) composed into MapRead by the checker.  The same run pins the shape of the bench output: the driver's line
+(the last one, < 4 KB) and the full record beside it, whose `roofline` names the kernel with the largest measured time of
+either stage; all of them follow in `kernel_rooflines`."""
 import json
 import os
 import subprocess
@@ -18,25 +19,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(*argv):
+    """One run of bench.py: the driver's line (the LAST stdout line; the only one that starts like a JSON object) is checked
+    for its size, and the full record the run left in --detail-out is what the tests look into."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--blasrmc-reads", "0"]
-                       + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [json.loads(x) for x in p.stdout.decode().splitlines() if x.startswith("{")]
-    assert len(lines) == 1
-    return lines[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--blasrmc-reads", "0",
+                            "--detail-out", detail] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        out = p.stdout.decode().splitlines()
+        lines = [x for x in out if x.startswith("{")]
+        assert len(lines) == 1 and out[-1] == lines[0]
+        assert len(lines[0]) < 4096, len(lines[0])  # the driver reads it out of an 8 KB tail (round 4's was 20 KB: unparsed)
+        line = json.loads(lines[0])
+        d = json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "build_id"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(d["value"], rel=1e-3) and line["roofline"]["kernel"] == d["roofline"]["kernel"]
+    assert line["cpu_baseline"]["parity_mismatches"] == d["cpu_baseline"]["parity_mismatches"]
+    return d
 
 
 def check_line(d, n_reads):
     cb = d["cpu_baseline"]
     assert cb["parity_checked"] == n_reads and cb["parity_mismatches"] == 0, cb
     assert d["config"]["aligned_reads"] == n_reads
-    # the line names the refine kernel that took the longest, with the bytes of exactly its candidates
-    lines = [d["roofline"]] + d["refine_rooflines"]
+    # the line names the kernel that took the longest -- of either stage -- with the bytes of exactly what it processed
+    lines = d["kernel_rooflines"]
     cost = [r["avg_launch_ms"] * r["launches_per_step"] for r in lines]
-    assert cost[0] == max(cost) and all(r["achieved"] > 0 and r["algorithmic_bytes_per_launch"] > 0 for r in lines)
+    assert d["roofline"]["kernel"] == lines[0]["kernel"] and cost[0] == max(cost)
+    assert all(r["achieved"] > 0 and r["algorithmic_bytes_per_launch"] > 0 for r in lines), lines
     names = [r["kernel"] for r in lines]
     assert any(n.startswith("blasr_hip::traceback_kernel") for n in names) and any("fill8_kernel" in n for n in names)
+    # the SDP stage's kernels are in the same list, timed on their own streams
+    sdp = [r for r in lines if r["stage"] == "sdp"]
+    assert any("sdp_chain" in r["kernel"] for r in sdp) and any("sdp_match" in r["kernel"] for r in sdp)
+    assert all(r["fragments_per_step"] > 0 for r in sdp if "chain" in r["kernel"])
+    chain_ms = sum(r["ms_per_step"] for r in sdp if "sdp_chain" in r["kernel"])
+    # (side by side on four streams: their sum is at least the phase's wall time less the list's sort, and not absurdly more)
+    assert 0.5 * d["stage_ms_per_step"]["sdp_chain"] <= chain_ms + 5.0 and chain_ms <= 4.5 * d["stage_ms_per_step"]["sdp_chain"] + 5.0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-12
     # traffic only from a PMC profile of this very build and workload
     assert d["roofline"]["traffic"] is None or d["roofline"]["pmc_profile"].startswith("profiles/")
@@ -47,7 +70,7 @@ def test_configs2_generator_against_the_reference_functions():
     d = run_bench("--config", "2", "--reads", "1500", "--cpu-sample", "1500")
     assert "configs[2]" in d["config"]["workload"] and d["config"]["candidate_intervals_per_gpu"] > 1500
     check_line(d, 1500)
-    assert any("fillp_kernel<16, true, true>" in r["kernel"] for r in [d["roofline"]] + d["refine_rooflines"])
+    assert any("fillp_kernel<16, true, true>" in r["kernel"] for r in d["kernel_rooflines"])
 
 
 def test_configs4_generator_against_the_reference_functions():
@@ -74,8 +97,9 @@ def test_configs4_wide_kband_form_against_the_reference_templates():
     cb = d["cpu_baseline"]
     assert cb["parity_checked"] == 12 and cb["parity_mismatches"] == 0, cb
     assert d["config"]["aligned_reads"] == 24
-    lines = [d["roofline"]] + d["refine_rooflines"]
-    assert d["roofline"]["kernel"] == "blasr_hip::kband_wide_kernel" and d["roofline"]["bound"] == "valu"
-    assert d["roofline"]["kernel_gcups"] > 0 and any(r["kernel"] == "blasr_hip::kband_wide_traceback_kernel" for r in lines)
+    lines = d["kernel_rooflines"]
+    kb = [r for r in lines if r["kernel"] == "blasr_hip::kband_wide_kernel"][0]
+    assert kb["bound"] in ("valu", "hbm", "valu (modelled)")
+    assert kb["kernel_gcups"] > 0 and any(r["kernel"] == "blasr_hip::kband_wide_traceback_kernel" for r in lines)
     # bands of the width the config is named for
-    assert d["roofline"]["algorithmic_bytes_per_launch"] / d["roofline"]["candidates_per_launch"] > 30000 * 2000 / 2
+    assert kb["algorithmic_bytes_per_launch"] / kb["candidates_per_launch"] > 30000 * 2000 / 2
