@@ -437,26 +437,22 @@ __device__ __forceinline__ uint4 kw_group(KwLane &L, const char *mBytes, int d0,
 // published in LDS: {strip, rows of it stored}.  A wavefront only ever waits for a strip with a smaller number, so
 // the waits cannot form a cycle; all wavefronts of a workgroup are resident together.
 struct KwProgress {
-  int strip[16], rows[16];
+  unsigned long long word[16];  // per wavefront: (strip << 32) | rows of it stored -- ONE word, so that a reader can never
+                                // pair a new strip number with the previous strip's row count
 };
 __device__ __forceinline__ void kw_publish(KwProgress *pg, int w, int strip, int rows, bool newStrip) {
   // the stores of the column (and everything before them) have reached L2 before the count moves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (newStrip) {  // rows first: a reader that still sees the old strip number just waits a little longer
-    __hip_atomic_store(&pg->rows[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&pg->strip[w], strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else {
-    __hip_atomic_store(&pg->rows[w], rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
+  const unsigned long long v = ((unsigned long long)(unsigned)strip << 32) | (unsigned)(newStrip ? 0 : rows);
+  __hip_atomic_store(&pg->word[w], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void kw_wait(const KwProgress *pg, int w, int strip, int rows) {
   for (;;) {
-    const int st = __hip_atomic_load(&pg->strip[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int rw = __hip_atomic_load(&pg->rows[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long v = __hip_atomic_load(&pg->word[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int st = (int)(v >> 32), rw = (int)(unsigned)v;
     if (st > strip || (st == strip && rw >= rows)) break;
     __builtin_amdgcn_s_sleep(8);
   }
-  asm volatile("" ::: "memory");
 }
 
 __global__ __launch_bounds__(1024) void kband_wide_kernel(KbandArgs a) {
@@ -474,8 +470,8 @@ __global__ __launch_bounds__(1024) void kband_wide_kernel(KbandArgs a) {
                           max((int64_t)1, (g.realCells + a.waveRound) / a.cellsPerWave));
   if (threadIdx.x < 25) m[threadIdx.x] = a.matrix[threadIdx.x] * 4;
   if (threadIdx.x < 16) {
-    progress.strip[threadIdx.x] = (int)threadIdx.x - nw;  // "the strip before my first": nothing of strip w is there yet
-    progress.rows[threadIdx.x] = 0;
+    // "the strip before my first": nothing of strip w is there yet
+    progress.word[threadIdx.x] = (unsigned long long)(unsigned)((int)threadIdx.x - nw) << 32;
   }
   __syncthreads();
   if (w >= nw) return;
@@ -1058,6 +1054,13 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
         need += ((geo[i].arrowBytes + 255) & ~(int64_t)255) + 4 * ((geo[i].arenaWords + 63) & ~(int64_t)63) +
                 (geo[i].wide ? 4 * (((nw + 1) * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0);
     twoLanes = need > limit && !getenv("BLASR_HIP_KBAND_ONE_LANE");
+    // a lane gets half the limit: a task that needs more than that (it would be accepted as a chunk of its own and make
+    // the two lanes together exceed the limit the host set) keeps everything on one lane
+    for (int i = 0; i < n && twoLanes; i++)
+      if (geo[i].status == 0 &&
+          ((geo[i].arrowBytes + 255) & ~(int64_t)255) + 4 * ((geo[i].arenaWords + 63) & ~(int64_t)63) +
+                  (geo[i].wide ? 4 * (((nw + 1) * ((int64_t)geo[i].qLen + 2) + 63) & ~(int64_t)63) : 0) + 1024 > limit / 2)
+        twoLanes = false;
   }
   const int64_t chunkLimit = twoLanes ? limit / 2 : limit;
   for (int i = 0; i < n;) {
@@ -1099,6 +1102,9 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
   }
   const int64_t laneBytes = (maxBytes + 255) & ~(int64_t)255;  // a lane's share of the workspace
   if (twoLanes) maxBytes = 2 * laneBytes;
+  if (maxBytes > limit + 4096)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INTERNAL, "kband: the chunk plan needs %lld bytes, the workspace limit is %lld",
+                          (long long)maxBytes, (long long)limit);
   if (ctx->workspaceBytes < (size_t)maxBytes) {
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     ctx->workspace = nullptr;
@@ -1127,6 +1133,17 @@ int kband_run(blasr_hip_ctx *ctx, const blasr_hip_kband_batch *b, const blasr_hi
       tb.algorithmic_bytes += (int64_t)geo[i].qLen + geo[i].tLen;
     }
   }
+  // every way out of the loop below -- an error of a launch, of collect(), of a copy -- leaves BOTH streams idle: the
+  // other lane's chunk may still be queued on the side stream, on a workspace the next call reuses (or frees)
+  struct JoinLanes {
+    blasr_hip_ctx *c;
+    bool on;
+    ~JoinLanes() {
+      if (!on) return;
+      (void)hipStreamSynchronize(c->sideStream);
+      (void)hipStreamSynchronize(c->stream);
+    }
+  } joinLanes{ctx, twoLanes};
   hipEvent_t *ev = ctx->events;  // the context's own (one call at a time per context): six per lane
   int inFlight[2] = {-1, -1};    // the chunk each lane is working on
   // waits for a lane's chunk and adds its kernels' times to the records

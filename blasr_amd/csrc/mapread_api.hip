@@ -213,6 +213,13 @@ int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batc
   return blasr_hip_kband_stats_device(ctx, &kb, score, 0, results, ops);  // :740
 } BLASR_HIP_CATCH_CTX(ctx)
 
+int blasr_hip_map_set_no_guided_align(blasr_hip_map_params *p, int32_t band_given) try {
+  if (!p) return BLASR_HIP_ERR_INVALID;
+  p->use_guided_align = 0;
+  if (!band_given) p->band = 0;  // (MakeSane sets 16 only with useGuidedAlign, MappingParameters.h:533-545)
+  return BLASR_HIP_OK;
+} BLASR_HIP_CATCH_CODE
+
 int blasr_hip_map_default_params(blasr_hip_map_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
   memset(p, 0, sizeof(*p));

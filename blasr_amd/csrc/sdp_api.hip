@@ -157,6 +157,7 @@ const char *blasr_hip_sdp_kernel_name(int kind) {
     case BLASR_HIP_SDP_KERNEL_SMALL: return "blasr_hip::sdp_small4_kernel + sdp_small_kernel";
     case BLASR_HIP_SDP_KERNEL_CHAIN4: return "blasr_hip::sdp_chain4_kernel";
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL: return "blasr_hip::sdp_chain_bits_kernel<512>";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID: return "blasr_hip::sdp_chain_bits_kernel<2048>";
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE: return "blasr_hip::sdp_chain_bits_kernel<4096>";
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS4: return "blasr_hip::sdp_chain_bits4_kernel";
     case BLASR_HIP_SDP_KERNEL_CHAIN_ROWS: return "blasr_hip::sdp_chain_rows_kernel";
@@ -288,7 +289,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.fused = arena.get<int32_t>(nTasks);
     lv.chainList = nullptr;
     if (!getenv("BLASR_HIP_NO_CHAIN4")) {
-      lv.chainList = arena.get<int32_t>(nTasks + 5);
+      lv.chainList = arena.get<int32_t>(nTasks + kChainCats);
       lv.chainCount = lv.chainList + nTasks;
       if (const char *e = getenv("BLASR_HIP_CHAIN_SCATTER")) lv.scatterMode = atoi(e);
     }
@@ -462,7 +463,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       ARENA_CHECK();
       HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(sortTmp, sortBytes, ck, ckOut, cv, lv.chainList, (size_t)nTasks, 0u, 32u, st));
     }
-    int32_t chainCounts[5] = {0, 0, 0, 0, 0};
+    int32_t chainCounts[kChainCats] = {};
     const int32_t *countsForGrids = nullptr;
     if (lv.chainList != nullptr && !getenv("BLASR_HIP_CHAIN_FULL_GRIDS")) {  // (one small copy and a wait: the kernels' grids)
       HIP_TRY(ctx, hipMemcpyAsync(chainCounts, lv.chainCount, sizeof(chainCounts), hipMemcpyDeviceToHost, st));
@@ -473,12 +474,12 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     else launch_sdp_chain(lv, prm, st, ctx->auxStream, ctx->auxEvent, countsForGrids);
     tock(2);
     if (getenv("BLASR_HIP_SDP_TRACE") && lv.chainList != nullptr) {  // the sweep's categories and its largest invocations
-      int32_t cnt[5] = {0, 0, 0, 0, 0};
+      int32_t cnt[kChainCats] = {};
       HIP_TRY(ctx, hipMemcpy(cnt, lv.chainCount, sizeof(cnt), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[sdp] level %d sweep: chain4 %d, wide %d, bits4 %d, bits %d, bits-large %d;", level, cnt[0], cnt[1],
-              cnt[2], cnt[3], cnt[4]);
+      fprintf(stderr, "[sdp] level %d sweep: chain4 %d, wide %d, bits4 %d, bits %d, bits-mid %d, bits-large %d, rows %d;", level, cnt[0],
+              cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6]);
       int at = 0;
-      for (int c = 4; c >= 0; c--) {
+      for (int c = kChainCats - 1; c >= 0; c--) {
         if (cnt[c] > 0) {
           int32_t first = 0, nf = 0;
           HIP_TRY(ctx, hipMemcpy(&first, lv.chainList + at, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -489,14 +490,15 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       }
       fprintf(stderr, "\n");
       if (atoi(getenv("BLASR_HIP_SDP_TRACE")) >= 1) {  // where the fragments are: per category, invocations and fragments by size
-        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4];
+        int total = 0;
+        for (int c = 0; c < kChainCats; c++) total += cnt[c];
         std::vector<int32_t> list((size_t)std::max(total, 1)), nf((size_t)nTasks);
         HIP_TRY(ctx, hipMemcpy(list.data(), lv.chainList, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(nf.data(), lv.nFrag, sizeof(int32_t) * (size_t)nTasks, hipMemcpyDeviceToHost));
         std::vector<SdpTask> hostTasks((size_t)nTasks);
         HIP_TRY(ctx, hipMemcpy(hostTasks.data(), dTasks, sizeof(SdpTask) * (size_t)nTasks, hipMemcpyDeviceToHost));
         int pos = 0;
-        for (int c = 4; c >= 0; c--) {
+        for (int c = kChainCats - 1; c >= 0; c--) {
           long long inv[10] = {0}, fr[10] = {0};
           for (int i = 0; i < cnt[c]; i++) {
             const int f = nf[(size_t)list[(size_t)(pos + i)]];

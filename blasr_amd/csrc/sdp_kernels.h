@@ -70,6 +70,7 @@ struct SdpParams {
   int ins, del;    // score function gap costs (SWAlign)
 };
 
+constexpr int kChainCats = 8;  // categories of the sweep's sorted list (SdpLevelArrays::chainCount)
 struct SdpLevelArrays {
   int n;
   const SdpTask *tasks;
@@ -89,11 +90,12 @@ struct SdpLevelArrays {
   int32_t *bigList, *bigCount;  // those tasks
   int32_t *keyList, *keyCount;  // the tasks whose targets get sorted k-mer keys (sdp_keys_kernel, sdp_sort_keys_kernel)
   int32_t *midList, *midCount;  // the tasks of sdp_match_kernel's bucket instantiation (targets >= 256 bases, not indexed)
-  // The sweep's invocations (not fused, >= 1 fragment), sorted by category and fragment count, and the five category
-  // counts: chainCount[0] sdp_chain4_kernel's; [1..4] the invocations whose fragments scatter over the rectangle (the
-  // recursion's Global calls: unrelated sequence gives chance matches anywhere), which come FIRST in the list:
-  // [4] sdp_chain_bits_kernel with a large target, [3] with a small one, [2] sdp_chain_bits4_kernel, [1]
-  // sdp_chain_wide_kernel.  chainList null: everything through sdp_chain_kernel.
+  // The sweep's invocations (not fused, >= 1 fragment), sorted by category (descending) and fragment count, and the
+  // kChainCats category counts: chainCount[0] sdp_chain4_kernel's; the others are the invocations whose fragments scatter
+  // over the rectangle (the recursion's Global calls: unrelated sequence gives chance matches anywhere), which come FIRST
+  // in the list: [6] sdp_chain_rows_kernel, [5] sdp_chain_bits_kernel with a target beyond 65536 columns, [4] beyond
+  // 16384, [3] a smaller one, [2] sdp_chain_bits4_kernel, [1] sdp_chain_wide_kernel.  chainList null: everything through
+  // sdp_chain_kernel.
   int32_t *chainList, *chainCount;
   int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront
   const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)

@@ -68,6 +68,7 @@ constexpr int kTinyT = 128;
 // most 64 raw fragments, and only without ties above 16), on a target the LDS bitmap spans.
 constexpr int kBitsMaxTarget = 131072;
 constexpr int kBitsSmallTarget = 16384;  // sdp_chain_bits_kernel's small instantiation (2 KB of LDS per wavefront)
+constexpr int kBitsMidTarget = 65536;    // ... and its middle one (8 KB: five workgroups of four wavefronts per CU; the large one, 16 KB, two)
 constexpr int kBits4Target = 4096;   // sdp_chain_bits4_kernel: columns (128 words of LDS per invocation) ...
 constexpr int kBits4MaxFrags = 1024; // ... and fragments of the invocations it takes
 constexpr int kWideSets = 8;         // register sets of 64 column-set entries in sdp_chain_wide_kernel
@@ -500,11 +501,14 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       __syncthreads();
       // ---- bucket sizes (two sixteen-bit counters to a word: a target has < 65536 positions, nothing carries over)
       const int nKmerT = t.tLen - k + 1;
-      for (int p = tid; p < nKmerT; p += 256)
-        if (bad_window(L.tBad, p, kMask) == 0u) {
-          const int d = idx_bucket(code_window(L.tCodes, p, kmerMask));
-          atomicAdd(&L.cnt[d >> 1], 1u << ((d & 1) * 16));
-        }
+      // (two positions per thread and trip: the LDS round trips of the two overlap)
+      for (int p = tid; p < nKmerT; p += 512) {
+        const int pb = p + 256;
+        const bool okA = bad_window(L.tBad, p, kMask) == 0u, okB = pb < nKmerT && bad_window(L.tBad, min(pb, nKmerT - 1), kMask) == 0u;
+        const int dA = idx_bucket(code_window(L.tCodes, p, kmerMask)), dB = idx_bucket(code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask));
+        if (okA) atomicAdd(&L.cnt[dA >> 1], 1u << ((dA & 1) * 16));
+        if (okB) atomicAdd(&L.cnt[dB >> 1], 1u << ((dB & 1) * 16));
+      }
       __syncthreads();
       {  // exclusive scan over the buckets, sixteen per thread: every bucket's counter becomes its first slot
         uint32_t w[8], sum = 0;
@@ -527,12 +531,16 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       }
       __syncthreads();
       // ---- scatter: a position takes the next slot of its bucket, whichever lane comes first
-      for (int p = tid; p < nKmerT; p += 256)
-        if (bad_window(L.tBad, p, kMask) == 0u) {
-          const int d = idx_bucket(code_window(L.tCodes, p, kmerMask));
-          const uint32_t old = atomicAdd(&L.cnt[d >> 1], 1u << ((d & 1) * 16));
-          L.ent[(old >> ((d & 1) * 16)) & 0xffffu] = (uint16_t)p;
-        }
+      for (int p = tid; p < nKmerT; p += 512) {
+        const int pb = p + 256;
+        const bool okA = bad_window(L.tBad, p, kMask) == 0u, okB = pb < nKmerT && bad_window(L.tBad, min(pb, nKmerT - 1), kMask) == 0u;
+        const int dA = idx_bucket(code_window(L.tCodes, p, kmerMask)), dB = idx_bucket(code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask));
+        uint32_t oldA = 0, oldB = 0;
+        if (okA) oldA = atomicAdd(&L.cnt[dA >> 1], 1u << ((dA & 1) * 16));
+        if (okB) oldB = atomicAdd(&L.cnt[dB >> 1], 1u << ((dB & 1) * 16));
+        if (okA) L.ent[(oldA >> ((dA & 1) * 16)) & 0xffffu] = (uint16_t)p;
+        if (okB) L.ent[(oldB >> ((dB & 1) * 16)) & 0xffffu] = (uint16_t)pb;
+      }
       __syncthreads();
     }
     const uint32_t *ends = L.cnt;  // the fill pointers have run to their buckets' ends
@@ -562,6 +570,69 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
           reinterpret_cast<uint16_t *>(qBad)[wi] = (uint16_t)bd;
         }
         __builtin_amdgcn_wave_barrier();
+      }
+      if (!kWrite) {
+        // Count pass: TWO blocks of 64 positions per trip (the chains of LDS round trips -- bucket bounds, entries, the
+        // k-mers at the entries -- of the two overlap), and the walk without a branch: a candidate that is outside the
+        // bucket or holds another k-mer becomes "no position" (all ones) and goes through the same three-element insertion
+        // network as a match -- which keeps the three SMALLEST matching positions in order; with more than three matches
+        // only the count is used (the write pass walks the bucket again, lv.idxFlag).
+        constexpr int kU = 2;
+        for (int j = 0; j < 16; j += kU) {
+          if (c0 + 64 * j >= qhi) break;
+          int xs[kU], bs[kU], be[kU], g[kU], cnt[kU];
+          uint32_t km[kU], p0[kU], p1[kU], p2[kU];
+          bool on[kU];
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            xs[u] = c0 + 64 * (j + u) + lane;
+            on[u] = xs[u] < qhi;
+            const int rel = min(xs[u] - c0, 1023);
+            const bool ok = on[u] && bad_window(qBad, rel, kMask) == 0u;
+            km[u] = code_window(qCodes, rel, kmerMask);
+            const int b = idx_bucket(km[u]);
+            const int lo = idx_end(ends, max(b - 1, 0)), hi = idx_end(ends, b);
+            bs[u] = ok ? (b ? lo : 0) : 0;
+            be[u] = ok ? hi : 0;
+            g[u] = bs[u] & ~3;
+            cnt[u] = 0;
+            p0[u] = p1[u] = p2[u] = 0xffffffffu;
+          }
+          while (g[0] < be[0] || g[1] < be[1]) {
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+              const uint2 v = *reinterpret_cast<const uint2 *>(L.ent + (g[u] < be[u] ? g[u] : 0));  // (a finished walk: masked below)
+              const uint32_t pos4[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const int i = g[u] + e;
+                const bool in = i >= bs[u] && i < be[u];
+                const uint32_t tp = in ? pos4[e] : 0u;
+                const bool hit = in && code_window(L.tCodes, (int)tp, kmerMask) == km[u];
+                const uint32_t v0 = hit ? tp : 0xffffffffu;
+                cnt[u] += hit ? 1 : 0;
+                const uint32_t a = min(p0[u], v0), r1 = max(p0[u], v0);
+                const uint32_t m = min(p1[u], r1), r2 = max(p1[u], r1);
+                p0[u] = a;
+                p1[u] = m;
+                p2[u] = min(p2[u], r2);
+              }
+              g[u] += 4;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            int c = cnt[u];
+            const uint64_t pos3 = ((uint64_t)(c > 0 ? p0[u] & 0xffffu : 0u) << 16) | ((uint64_t)(c > 1 ? p1[u] & 0xffffu : 0u) << 32) |
+                                  ((uint64_t)(c > 2 ? p2[u] & 0xffffu : 0u) << 48);
+            if (t.maxPerPos != 0 && c > t.maxPerPos) c = 0;
+            if (c > 0xffff) c = 0xffff;  // cannot happen: a bucket holds < 65536 entries
+            if (on[u]) hits[xs[u]] = c ? (pos3 | (uint64_t)c) : 0ull;
+            many = many || c > 3;
+            nM += c;
+          }
+        }
+        continue;
       }
       for (int j = 0; j < 16; j++) {
         const int x0 = c0 + 64 * j;
@@ -1908,9 +1979,17 @@ __host__ __device__ inline int chain_category_kind(int cat) {
     case 0: return BLASR_HIP_SDP_KERNEL_CHAIN4;
     case 2: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS4;
     case 3: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL;
-    case 4: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE;
+    case 4: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID;
+    case 5: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE;
+    case 6: return BLASR_HIP_SDP_KERNEL_CHAIN_ROWS;
   }
   return -1;  // (1: sdp_chain_wide_kernel, tests only)
+}
+// where a category starts in the sorted list: behind the categories with a larger number
+__device__ __forceinline__ int chain_list_start(const SdpLevelArrays &lv, int cat) {
+  int at = 0;
+  for (int c = kChainCats - 1; c > cat; c--) at += lv.chainCount[c];
+  return at;
 }
 // The invocations sdp_chain4_kernel takes, as (fragment count, index) pairs for a descending sort: the four of a
 // wavefront then have about the same number of fragments (the wavefront runs as long as its longest) and the long
@@ -1924,19 +2003,20 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     // (a task that is not fused has more than 16 raw fragments, so it was given its column slots)
     scatter = take && lv.colEnt != nullptr && lv.colOff[i + 1] > lv.colOff[i];
   }
-  // categories, in the order of the sorted list: 4 bitmap sweep, a wavefront each, target beyond kBitsSmallTarget
-  // columns; 3 the same with a smaller target (a quarter of the LDS); 2 bitmap sweep four per wavefront (small target,
-  // few fragments: the bulk); 1 the 512-register sweep (tests only: BLASR_HIP_CHAIN_SCATTER=1); 0 sdp_chain4_kernel
+  // categories, in the order of the sorted list: 5 / 4 / 3 bitmap sweep, a wavefront each, by the size of the target (the
+  // bitmap's LDS decides how many wavefronts a CU holds); 2 bitmap sweep four per wavefront (small target, few fragments:
+  // the bulk); 1 the 512-register sweep (tests only: BLASR_HIP_CHAIN_SCATTER=1); 0 sdp_chain4_kernel
   int cat = 0;
   if (scatter) {
     const int tl = lv.tasks[i].tLen;
-    cat = lv.scatterMode == 1 ? 1 : (tl > kBitsSmallTarget ? 4 : ((tl > kBits4Target || lv.nFrag[i] > kBits4MaxFrags || lv.scatterMode == 2) ? 3 : 2));
+    const int bySize = tl > kBitsMidTarget ? 5 : (tl > kBitsSmallTarget ? 4 : 3);
+    cat = lv.scatterMode == 1 ? 1 : ((bySize > 3 || tl > kBits4Target || lv.nFrag[i] > kBits4MaxFrags || lv.scatterMode == 2) ? bySize : 2);
   }
   if (i < lv.n) {
     keys[i] = take ? (((uint32_t)cat << 29) | (uint32_t)min(lv.nFrag[i], (1 << 29) - 1)) : 0u;
     vals[i] = i;
   }
-  for (int c = 0; c < 5; c++) {
+  for (int c = 0; c < kChainCats; c++) {
     const unsigned long long m = __ballot(take && cat == c);
     if (m == 0ull) continue;
     if (lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
@@ -2311,7 +2391,7 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
 __global__ __launch_bounds__(256, 8) void sdp_chain4_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int lane = lane_id();
   const int nList = lv.chainCount[0];  // the list starts with the scattered ones
-  const int nScatter = lv.chainCount[1] + lv.chainCount[2] + lv.chainCount[3] + lv.chainCount[4];
+  const int nScatter = chain_list_start(lv, 0);
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;  // slot of group 0: the whole wavefront is beyond the list
   const bool on = slot < nList;
@@ -2694,9 +2774,9 @@ __global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, 
   __shared__ uint32_t bits[4][kWords];
   const int wave = threadIdx.x >> 6;
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
-  const bool large = kWords == kBitsWords;  // the list: [large targets | small targets | ...]
-  if (slot >= lv.chainCount[large ? 4 : 3]) return;
-  const int idx = lv.chainList[(large ? 0 : lv.chainCount[4]) + slot];
+  constexpr int cat = kWords == kBitsWords ? 5 : (kWords == kBitsMidTarget / 32 ? 4 : 3);  // the list: [.. | large | middle | small | ..]
+  if (slot >= lv.chainCount[cat]) return;
+  const int idx = lv.chainList[chain_list_start(lv, cat) + slot];
   chain_sweep_bits(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], bits[wave]);
 }
 
@@ -2957,7 +3037,7 @@ __global__ __launch_bounds__(256, 8) void sdp_chain_bits4_kernel(SdpLevelArrays 
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;
   const bool on = slot < nList;
-  chain_bits4_body<kBits4Target / 32>(lv, prm, on, on ? lv.chainList[lv.chainCount[4] + lv.chainCount[3] + slot] : 0,
+  chain_bits4_body<kBits4Target / 32>(lv, prm, on, on ? lv.chainList[chain_list_start(lv, 2) + slot] : 0,
                                       bits[wave][lane >> 4]);
 }
 
@@ -2966,7 +3046,7 @@ __global__ __launch_bounds__(256, 8) void sdp_chain_bits4_kernel(SdpLevelArrays 
 __global__ __launch_bounds__(256) void sdp_chain_wide_kernel(SdpLevelArrays lv, SdpParams prm) {
   const int slot = wave_task_index();
   if (slot >= lv.chainCount[1]) return;
-  const int idx = lv.chainList[lv.chainCount[4] + lv.chainCount[3] + lv.chainCount[2] + slot];
+  const int idx = lv.chainList[chain_list_start(lv, 1) + slot];
   chain_sweep<false, kWideSets>(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], 0, 0, 0, -1, -1);
 }
 
@@ -4005,6 +4085,7 @@ void SdpSpans::collect(float *ms, int32_t *launches, int32_t *concurrent, int ki
       (void)hipGetLastError();
       continue;
     }
+    if (getenv("BLASR_HIP_SDP_TRACE")) fprintf(stderr, "[sdp]   span %s: %.2f ms\n", blasr_hip_sdp_kernel_name(sp.kind), t);
     ms[sp.kind] += t;
     launches[sp.kind]++;
     concurrent[sp.kind] = std::max(concurrent[sp.kind], sp.concurrent);
@@ -4167,7 +4248,7 @@ void launch_sdp_kernel_sums(const SdpLevelArrays &lv, hipStream_t st) {
 }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;
-  (void)hipMemsetAsync(lv.chainCount, 0, 5 * sizeof(int32_t), st);  // one count per category
+  (void)hipMemsetAsync(lv.chainCount, 0, kChainCats * sizeof(int32_t), st);  // one count per category
   hipLaunchKernelGGL(sdp_chain_list_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, keys, vals);
 }
 // counts: the five category counts as the host read them (nullptr: grids sized for the whole level).  At the recursion levels
@@ -4192,11 +4273,15 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         s0 = aux[0], s1 = aux[1], s2 = aux[2];
       }
       int conc = 0;  // how many of the sweep's kernels run side by side
-      for (int c : {0, 2, 3, 4}) conc += (!counts || counts[c] > 0) ? 1 : 0;
+      for (int c : {0, 2, 3, 4, 5}) conc += (!counts || counts[c] > 0) ? 1 : 0;
       if (!fork) conc = 1;
-      if (!counts || counts[4] > 0) {
+      if (!counts || counts[5] > 0) {
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE, s0, conc);
-        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
+        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(5, 1), dim3(256), 0, s0, lv, p);
+      }
+      if (!counts || counts[4] > 0) {  // (on the large ones' stream: those are rare, and the hardware queues are few)
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID, s0, conc);
+        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsMidTarget / 32>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
       }
       if (!counts || counts[3] > 0) {
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL, s1, conc);

@@ -52,7 +52,7 @@ EXPORTS = [
     "blasr_hip_align_between_anchors_device", "blasr_hip_align_between_anchors_host",
     "blasr_hip_sam_reads_read", "blasr_hip_sam_reads_parse", "blasr_hip_refine_last_kernels", "blasr_hip_kernel_name", "blasr_hip_build_id",
     "blasr_hip_kband_stats_device", "blasr_hip_kband_from_sdp_device", "blasr_hip_sa_write_resident",
-    "blasr_hip_sdp_last_kernels", "blasr_hip_sdp_kernel_name",
+    "blasr_hip_sdp_last_kernels", "blasr_hip_sdp_kernel_name", "blasr_hip_map_set_no_guided_align",
 ]
 
 # include/blasr_hip.h: blasr_hip_sdp_kernel_record
@@ -913,6 +913,10 @@ class Context:
             p.window.extend_ends = int(kw.pop("extend_ends"))
         if "do_global" in kw:
             p.window.do_global_alignment = int(kw.pop("do_global"))
+        # MakeSane (MappingParameters.h:533-545) sets bandSize = 16 only WITH useGuidedAlign; under -noUseGuidedAlign the
+        # reference leaves it 0 and RefineAlignment takes k from the SDP alignment's drift (Blasr.cpp:991-1001)
+        if not kw.get("use_guided_align", 1):
+            self.lib.blasr_hip_map_set_no_guided_align(C.byref(p), C.c_int32(1 if "band" in kw else 0))
         for k, v in kw.items():
             setattr(p, k, v)
         return p

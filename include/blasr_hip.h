@@ -287,12 +287,12 @@ enum { BLASR_HIP_SDP_KERNEL_MATCH_INDEX = 0, /* sdp_match_index_kernel<false> + 
        BLASR_HIP_SDP_KERNEL_SMALL = 2,       /* sdp_small4_kernel + sdp_small_kernel: order .. sweep of <= 64 fragments, fused */
        BLASR_HIP_SDP_KERNEL_CHAIN4 = 3,      /* sdp_chain4_kernel: near-diagonal invocations, four per wavefront */
        BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL = 4, /* sdp_chain_bits_kernel<512>: scattered, target <= 16384 columns */
-       BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE = 5, /* sdp_chain_bits_kernel<4096> */
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE = 5, /* sdp_chain_bits_kernel<4096>: target <= 131072 columns */
        BLASR_HIP_SDP_KERNEL_CHAIN_BITS4 = 6, /* sdp_chain_bits4_kernel: short scattered invocations, four per wavefront */
-       BLASR_HIP_SDP_KERNEL_CHAIN_ROWS = 7,  /* sdp_chain_rows_kernel: scattered invocations with several fragments per query row,
-                                                a whole sweep row per step */
+       BLASR_HIP_SDP_KERNEL_CHAIN_ROWS = 7,  /* sdp_chain_rows_kernel: scattered invocations, a batch of sweep rows per step */
        BLASR_HIP_SDP_KERNEL_FILLS = 8,       /* sw_small_kernel + sw_kernel: SWAlign(Global) gap fills */
-       BLASR_HIP_SDP_KERNEL_KINDS = 9 };
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID = 9, /* sdp_chain_bits_kernel<2048>: target <= 65536 columns */
+       BLASR_HIP_SDP_KERNEL_KINDS = 10 };
 typedef struct blasr_hip_sdp_kernel_record {
   int32_t kind;
   int32_t launches;
@@ -510,6 +510,11 @@ int blasr_hip_kband_from_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batc
                                     blasr_hip_refine_result *results, uint32_t *ops, int64_t ops_capacity,
                                     int64_t *ops_used);
 int blasr_hip_map_default_params(blasr_hip_map_params *params);
+/* The switch -noUseGuidedAlign as MappingParameters::MakeSane leaves the parameters (MappingParameters.h:533-545: bandSize
+ * becomes 16 only WITH useGuidedAlign): use_guided_align = 0 and, unless the caller has set a band of its own (band_given
+ * != 0, the reference's -bandSize), band = 0 -- k then follows the SDP alignment's drift (alignment/Blasr.cpp:991-1001).
+ * Call it on a struct blasr_hip_map_default_params filled; setting use_guided_align = 0 by hand keeps band = 16. */
+int blasr_hip_map_set_no_guided_align(blasr_hip_map_params *params, int32_t band_given);
 /* Wall time (ms) of the stages of the last map call: [0] windows, [1] SDP, [2] sort + first filter (host),
  * [3] refine, [4] sort + the two filters (host), [5] fetch; counters: [0] candidate intervals, [1] candidates
  * refined, [2] reads with an alignment, [3] bases of those reads, [4] band cells of the refined candidates,
