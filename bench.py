@@ -551,6 +551,8 @@ def compact_line(out, detail_path=None):
             line[k] = _sig(out[k])
     if out.get("per_rank_ms_per_step") and out.get("n_gpus", 1) > 1:
         line["per_rank_ms_per_step"] = [_sig(r.get("step"), 4) for r in out["per_rank_ms_per_step"]]
+    if out.get("note"):
+        line["note"] = str(out["note"])[:200]
     if detail_path:
         line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
@@ -826,6 +828,9 @@ def main():
                                                "candidates_refined"), r)) for r in rank_ms],
             "host_threads_per_rank": int(os.environ.get("BLASR_HIP_HOST_THREADS", "0")) or None,
         }
+        # how the ranks' counters were reduced: RCCL (one process per GPU, `nccl` backend) or gloo (--share-gpus)
+        out["rccl_ranks"] = world if (world > 1 and not shared) else 0
+        out["counters_backend"] = None if world == 1 else ("gloo" if shared else "nccl")
         if shared:
             out["physical_gpus"] = n_dev
             out["note"] = ("%d ranks SHARE %d GPU%s (--share-gpus, counters over gloo): a run of the multi-rank path, "

@@ -19,6 +19,9 @@ using namespace blasr_hip;
 
 static_assert(sizeof(SdpResult) == sizeof(blasr_hip_sdp_result), "result record layout");
 
+#ifdef BLASR_IDX_CLOCKS
+namespace blasr_hip { void sdp_print_idx_clocks(); }
+#endif
 namespace {
 
 // Two-ended bump allocator over the context's ONE grow-only workspace (the region the refine stage uses after this
@@ -278,6 +281,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     // ---- k-mer keys of the targets, sorted per task ----
     tick();
     lv.idxMaxT = idxMaxT;
+    lv.noIdxFilter = getenv("BLASR_HIP_NO_IDX_FILTER") ? 1 : 0;
     lv.bigList = arena.get<int32_t>(nTasks + 1);
     lv.bigCount = lv.bigList + nTasks;
     lv.midList = arena.get<int32_t>(nTasks + 1);
@@ -779,6 +783,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       r.algorithmic_bytes += bytes;
     }
   }
+#ifdef BLASR_IDX_CLOCKS
+  sdp_print_idx_clocks();
+#endif
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
   for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = phaseBytes[i];
   ctx->sdpCounters[0] = totalInvocations;

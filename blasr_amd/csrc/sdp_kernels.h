@@ -87,6 +87,7 @@ struct SdpLevelArrays {
   uint32_t *yxIdx;
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
+  int noIdxFilter;              // tests / experiments (BLASR_HIP_NO_IDX_FILTER): the index matcher's count pass without its filter
   int32_t *bigList, *bigCount;  // those tasks
   int32_t *keyList, *keyCount;  // the tasks whose targets get sorted k-mer keys (sdp_keys_kernel, sdp_sort_keys_kernel)
   int32_t *midList, *midCount;  // the tasks of sdp_match_kernel's bucket instantiation (targets >= 256 bases, not indexed)

@@ -369,11 +369,17 @@ __device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, 
 // ordered in registers, the rare longer lists are sorted where they are written.
 // ---------------------------------------------------------------------------
 struct IdxLds {
-  uint32_t *tCodes, *tBad, *cnt, *qStage, *part;
+  uint32_t *tCodes, *tBad, *cnt, *qStage, *part, *filt;
   uint8_t *lut;
-  uint16_t *ent;  // bucket by bucket: target positions
+  uint16_t *ent;   // bucket by bucket: target positions
+  uint16_t *list;  // per wavefront: the positions of its chunk of the query whose k-mer passed the filter
 };
-__host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
+// The count pass's FILTER: one bit per hash of a k-mer (kIdxFilterBits of them), set for every k-mer of the target.  A query
+// position whose bit is clear matches nothing and never walks a bucket; the positions that pass (a seventh of the ones
+// without a match for a 10 kb target and an 11-base word) are listed and walked 64 to a trip -- the walk runs as long as the LONGEST bucket among its
+// 64 lanes, and with every position in it a wavefront spent five sixths of its walk steps on lanes with nothing left to do.
+constexpr int kIdxFilterBits = 65536;
+__host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 9 */) {
   int at = 0;
   offs[0] = at, at += tCap / 16 + 4;          // tCodes
   offs[1] = at, at += tCap / 32 + 4;          // tBad
@@ -381,13 +387,18 @@ __host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 7 */) {
   offs[3] = at, at += 4 * 104;                // qStage: per wavefront 66 code words + 34 bad words
   offs[4] = at, at += 16;                     // part
   offs[5] = at, at += 64;                     // lut
+  offs[7] = at, at += kIdxFilterBits / 32;    // filt
+  offs[8] = at, at += 4 * 256;                // list: per wavefront 512 positions of two bytes
   at = (at + 3) & ~3;
   offs[6] = at, at += tCap / 2 + 8;           // ent (16-byte aligned)
   return at;
 }
 int64_t idx_lds_bytes(int tCap) {
-  int offs[7];
+  int offs[9];
   return (int64_t)idx_lds_words(tCap, offs) * 4;
+}
+__device__ __forceinline__ int idx_filter(uint32_t kmer) {  // (exact for words of up to seven bases)
+  return (int)((kmer ^ (kmer >> 16) ^ (kmer >> 9)) & (uint32_t)(kIdxFilterBits - 1));
 }
 // 16 consecutive bases starting at p0 -> 16 x 2-bit codes and 16 "not ACGT / outside" bits
 __device__ __forceinline__ void stage16(const uint8_t *s, int len, int p0, const uint8_t *lut, uint32_t &codes,
@@ -459,14 +470,35 @@ __global__ __launch_bounds__(256) void sdp_classify_kernel(SdpLevelArrays lv) {
 // The count pass leaves, per query position, {match count : 16, the first three target positions : 3 x 16} in
 // lv.hits; the write pass turns that into fragments and rebuilds the index only for a task in which some
 // position has more than three matches (lv.idxFlag).
+#ifdef BLASR_IDX_CLOCKS  // experiment: where a workgroup of the index matcher spends its cycles (make EXTRA=-DBLASR_IDX_CLOCKS)
+__device__ unsigned long long g_idxClocks[16];
+#define IDX_CLOCK(slot)                                                            \
+  do {                                                                             \
+    const unsigned long long now_ = clock64();                                     \
+    if (threadIdx.x == 0) atomicAdd(&g_idxClocks[(kWrite ? 8 : 0) + (slot)], now_ - clk_); \
+    clk_ = now_;                                                                   \
+  } while (0)
+void sdp_print_idx_clocks() {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_idxClocks), sizeof(h)) != hipSuccess) return;
+  fprintf(stderr, "[idx clocks] count pass: pack %llu count %llu scan %llu scatter %llu query %llu tail %llu tasks %llu | write pass: pack %llu count %llu "
+                  "scan %llu scatter %llu query %llu tail %llu tasks %llu (Mcycles of thread 0, summed over workgroups)\n",
+          h[0] >> 20, h[1] >> 20, h[2] >> 20, h[3] >> 20, h[4] >> 20, h[5] >> 20, h[6], h[8] >> 20, h[9] >> 20, h[10] >> 20, h[11] >> 20, h[12] >> 20,
+          h[13] >> 20, h[14]);
+}
+#else
+#define IDX_CLOCK(slot) do { } while (0)
+#endif
 template <bool kWrite>
 __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv, const uint8_t *seq, int tCap, int minT) {
   extern __shared__ uint4 idxLdsRaw4[];  // 16-byte aligned
   uint32_t *idxLdsRaw = reinterpret_cast<uint32_t *>(idxLdsRaw4);
   IdxLds L;
   {
-    int offs[7];
+    int offs[9];
     idx_lds_words(tCap, offs);
+    L.filt = idxLdsRaw + offs[7];
+    L.list = reinterpret_cast<uint16_t *>(idxLdsRaw + offs[8]);
     L.tCodes = idxLdsRaw + offs[0];
     L.tBad = idxLdsRaw + offs[1];
     L.cnt = idxLdsRaw + offs[2];
@@ -489,6 +521,14 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     const uint32_t kmerMask = (1u << (2 * k)) - 1u, kMask = (1u << k) - 1u;
     if (kWrite && lv.idxFlag[idx] == 0) continue;  // sdp_match_index_copy_kernel's
     const bool build = true;
+    // the filter pays where few of the query's positions pass it: a target with far fewer k-mers than the filter has bits
+    // (and than there are k-mers of that length at all: a five-base word on a long target passes everywhere)
+    const int kmerSpace = 2 * k >= 16 ? kIdxFilterBits : (1 << (2 * k));
+    const bool useFilter = !kWrite && (int64_t)(t.tLen - k + 1) * 2 < (int64_t)min(kmerSpace, kIdxFilterBits) && !lv.noIdxFilter;
+#ifdef BLASR_IDX_CLOCKS
+    unsigned long long clk_ = clock64();
+    if (threadIdx.x == 0) atomicAdd(&g_idxClocks[(kWrite ? 8 : 0) + 6], 1ull);
+#endif
     if (build) {
       // ---- the target, packed
       for (int wi = tid; wi < (t.tLen + 15) / 16 + 2; wi += 256) {
@@ -498,18 +538,28 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         reinterpret_cast<uint16_t *>(L.tBad)[wi] = (uint16_t)bd;
       }
       for (int i = tid; i < kIdxBuckets / 2 + 4; i += 256) L.cnt[i] = 0;
+      if (useFilter)
+        for (int i = tid; i < kIdxFilterBits / 32; i += 256) L.filt[i] = 0;
       __syncthreads();
+      IDX_CLOCK(0);
       // ---- bucket sizes (two sixteen-bit counters to a word: a target has < 65536 positions, nothing carries over)
       const int nKmerT = t.tLen - k + 1;
       // (two positions per thread and trip: the LDS round trips of the two overlap)
       for (int p = tid; p < nKmerT; p += 512) {
         const int pb = p + 256;
         const bool okA = bad_window(L.tBad, p, kMask) == 0u, okB = pb < nKmerT && bad_window(L.tBad, min(pb, nKmerT - 1), kMask) == 0u;
-        const int dA = idx_bucket(code_window(L.tCodes, p, kmerMask)), dB = idx_bucket(code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask));
+        const uint32_t kmA = code_window(L.tCodes, p, kmerMask), kmB = code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask);
+        const int dA = idx_bucket(kmA), dB = idx_bucket(kmB);
         if (okA) atomicAdd(&L.cnt[dA >> 1], 1u << ((dA & 1) * 16));
         if (okB) atomicAdd(&L.cnt[dB >> 1], 1u << ((dB & 1) * 16));
+        if (useFilter) {
+          const int fA = idx_filter(kmA), fB = idx_filter(kmB);
+          if (okA) atomicOr(&L.filt[fA >> 5], 1u << (fA & 31));
+          if (okB) atomicOr(&L.filt[fB >> 5], 1u << (fB & 31));
+        }
       }
       __syncthreads();
+      IDX_CLOCK(1);
       {  // exclusive scan over the buckets, sixteen per thread: every bucket's counter becomes its first slot
         uint32_t w[8], sum = 0;
 #pragma unroll
@@ -530,6 +580,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         }
       }
       __syncthreads();
+      IDX_CLOCK(2);
       // ---- scatter: a position takes the next slot of its bucket, whichever lane comes first
       for (int p = tid; p < nKmerT; p += 512) {
         const int pb = p + 256;
@@ -542,6 +593,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         if (okB) L.ent[(oldB >> ((dB & 1) * 16)) & 0xffffu] = (uint16_t)pb;
       }
       __syncthreads();
+      IDX_CLOCK(3);
     }
     const uint32_t *ends = L.cnt;  // the fill pointers have run to their buckets' ends
     // ---- the query against the index
@@ -570,6 +622,85 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
           reinterpret_cast<uint16_t *>(qBad)[wi] = (uint16_t)bd;
         }
         __builtin_amdgcn_wave_barrier();
+      }
+      if (!kWrite && useFilter) {
+        // Count pass with the filter.  Pass 1: every position of the chunk tests its bit; the ones that fail are done (no
+        // match), the others are listed.  Pass 2: the listed positions, two blocks of 64 per trip, walk their buckets.
+        uint16_t *list = L.list + wv * 512;
+        for (int half = 0; half < 2; half++) {  // (the list holds 512 positions: the staged chunk in two halves)
+        int nSurv = 0;
+        for (int j = 8 * half; j < 8 * half + 8; j++) {
+          const int x0 = c0 + 64 * j;
+          if (x0 >= qhi) break;
+          const int x = x0 + lane;
+          const bool on = x < qhi;
+          const int rel = min(x - c0, 1023);
+          const uint32_t km = code_window(qCodes, rel, kmerMask);
+          const int f = idx_filter(km);
+          const bool surv = on && bad_window(qBad, rel, kMask) == 0u && ((L.filt[f >> 5] >> (f & 31)) & 1u) != 0u;
+          const unsigned long long m = __ballot(surv);
+          if (surv) list[nSurv + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)rel;
+          if (on && !surv) hits[x] = 0ull;
+          nSurv += (int)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int kU = 2;
+        for (int base = 0; base < nSurv; base += 64 * kU) {
+          int xs[kU], bs[kU], be[kU], g[kU], cnt[kU];
+          uint32_t km[kU], p0[kU], p1[kU], p2[kU];
+          bool on[kU];
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int sIdx = base + 64 * u + lane;
+            on[u] = sIdx < nSurv;
+            const int rel = on[u] ? (int)list[sIdx] : 0;
+            xs[u] = c0 + rel;
+            km[u] = code_window(qCodes, rel, kmerMask);
+            const int b = idx_bucket(km[u]);
+            const int lo = idx_end(ends, max(b - 1, 0)), hi = idx_end(ends, b);
+            bs[u] = on[u] ? (b ? lo : 0) : 0;
+            be[u] = on[u] ? hi : 0;
+            g[u] = bs[u] & ~3;
+            cnt[u] = 0;
+            p0[u] = p1[u] = p2[u] = 0xffffffffu;
+          }
+          while (g[0] < be[0] || g[1] < be[1]) {
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+              const uint2 v = *reinterpret_cast<const uint2 *>(L.ent + (g[u] < be[u] ? g[u] : 0));  // (a finished walk: masked below)
+              const uint32_t pos4[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const int i = g[u] + e;
+                const bool in = i >= bs[u] && i < be[u];
+                const uint32_t tp = in ? pos4[e] : 0u;
+                const bool hit = in && code_window(L.tCodes, (int)tp, kmerMask) == km[u];
+                const uint32_t v0 = hit ? tp : 0xffffffffu;
+                cnt[u] += hit ? 1 : 0;
+                const uint32_t a = min(p0[u], v0), r1 = max(p0[u], v0);
+                const uint32_t m = min(p1[u], r1), r2 = max(p1[u], r1);
+                p0[u] = a;
+                p1[u] = m;
+                p2[u] = min(p2[u], r2);
+              }
+              g[u] += 4;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            int c = cnt[u];
+            const uint64_t pos3 = ((uint64_t)(c > 0 ? p0[u] & 0xffffu : 0u) << 16) | ((uint64_t)(c > 1 ? p1[u] & 0xffffu : 0u) << 32) |
+                                  ((uint64_t)(c > 2 ? p2[u] & 0xffffu : 0u) << 48);
+            if (t.maxPerPos != 0 && c > t.maxPerPos) c = 0;
+            if (c > 0xffff) c = 0xffff;  // cannot happen: a bucket holds < 65536 entries
+            if (on[u]) hits[xs[u]] = c ? (pos3 | (uint64_t)c) : 0ull;
+            many = many || c > 3;
+            nM += c;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        }
+        continue;
       }
       if (!kWrite) {
         // Count pass: TWO blocks of 64 positions per trip (the chains of LDS round trips -- bucket bounds, entries, the
@@ -718,6 +849,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         }
       }
     }
+    IDX_CLOCK(4);
     // ---- prefix and suffix parts (SDPAlign.h:148-182), wavefront 0 and 1
     const int prefixLength = min(t.tLen, t.prefix);
     const int suffixLength = min(t.tLen - prefixLength, t.prefix);
@@ -749,6 +881,7 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
                                         suffixPos, ks, t.maxPerPos, out, nP + nMall);
       if (!kWrite && lane == 0) lv.nRaw[3 * idx + 2] = n2;
     }
+    IDX_CLOCK(5);
   }
 }
 
@@ -2037,30 +2170,35 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
 // sdp_match_index_kernel, any other through sdp_match_kernel (fragments: the raw ones they wrote); a fused invocation
 // was ordered and swept by sdp_small4_kernel / sdp_small_kernel (fragments: the kept ones).
 __global__ __launch_bounds__(256) void sdp_kernel_sums_kernel(SdpLevelArrays lv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = i < lv.n;
-  int cls = -1;
-  unsigned raw = 0, q = 0, kept = 0;
-  bool fused = false;
-  if (in) {
-    const SdpTask t = lv.tasks[i];
-    cls = task_uses_index(t.tLen, t.k, lv.idxMaxT) ? BLASR_HIP_SDP_KERNEL_MATCH_INDEX : BLASR_HIP_SDP_KERNEL_MATCH_SHORT;
-    raw = (unsigned)(lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2]);
-    q = (unsigned)t.qLen;
-    fused = lv.fused[i] != 0;
-    kept = (unsigned)lv.nFrag[i];
-  }
-  for (int c = 0; c < 3; c++) {
-    const int kind = c == 0 ? BLASR_HIP_SDP_KERNEL_MATCH_INDEX : (c == 1 ? BLASR_HIP_SDP_KERNEL_MATCH_SHORT : BLASR_HIP_SDP_KERNEL_SMALL);
-    const bool mine = in && (c == 2 ? fused : cls == kind);
-    const unsigned long long m = __ballot(mine);
-    if (m == 0ull) continue;
-    const unsigned fr = wave_sum_u32(mine ? (c == 2 ? kept : raw) : 0u), qp = wave_sum_u32(mine ? q : 0u);
-    if (lane_id() == 0) {
-      atomicAdd(lv.kernelSums + 3 * kind + 0, (unsigned long long)fr);
-      atomicAdd(lv.kernelSums + 3 * kind + 1, (unsigned long long)__popcll(m));
-      atomicAdd(lv.kernelSums + 3 * kind + 2, (unsigned long long)qp);
+  // a fixed grid striding over the level's invocations, every thread with its own nine sums: one round of atomics per
+  // WORKGROUP (a round per wavefront of a grid over ten million invocations cost 12 ms a level in contended atomics)
+  __shared__ unsigned long long part[4][9];
+  unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < lv.n; i += gridDim.x * blockDim.x) {
+    const int tLen = lv.tasks[i].tLen, k = lv.tasks[i].k, qLen = lv.tasks[i].qLen;
+    const int c = task_uses_index(tLen, k, lv.idxMaxT) ? 0 : 1;
+    acc[3 * c + 0] += (unsigned)(lv.nRaw[3 * i] + lv.nRaw[3 * i + 1] + lv.nRaw[3 * i + 2]);
+    acc[3 * c + 1] += 1;
+    acc[3 * c + 2] += (unsigned)qLen;
+    if (lv.fused[i] != 0) {
+      acc[6] += (unsigned)lv.nFrag[i];
+      acc[7] += 1;
+      acc[8] += (unsigned)qLen;
     }
+  }
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    unsigned long long v = acc[j];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) part[wv][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int j = (int)threadIdx.x;
+    const int kind = j < 3 ? BLASR_HIP_SDP_KERNEL_MATCH_INDEX : (j < 6 ? BLASR_HIP_SDP_KERNEL_MATCH_SHORT : BLASR_HIP_SDP_KERNEL_SMALL);
+    const unsigned long long v = part[0][j] + part[1][j] + part[2][j] + part[3][j];
+    if (v != 0ull) atomicAdd(lv.kernelSums + 3 * kind + j % 3, v);
   }
 }
 
@@ -4244,7 +4382,7 @@ void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st) {
 int sdp_chain_bits_max_target() { return kBitsMaxTarget; }
 void launch_sdp_kernel_sums(const SdpLevelArrays &lv, hipStream_t st) {
   if (lv.n > 0 && lv.kernelSums != nullptr)
-    hipLaunchKernelGGL(sdp_kernel_sums_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv);
+    hipLaunchKernelGGL(sdp_kernel_sums_kernel, dim3((unsigned)std::min((lv.n + 255) / 256, 1024)), dim3(256), 0, st, lv);
 }
 void launch_sdp_chain_list(const SdpLevelArrays &lv, uint32_t *keys, int32_t *vals, hipStream_t st) {
   if (lv.n <= 0) return;

@@ -251,3 +251,30 @@ def test_bench_with_two_ranks_on_the_devices_there_are():
     import torch
     if torch.cuda.device_count() < 2:
         assert d["physical_gpus"] == torch.cuda.device_count() and "SHARE" in d["note"]
+
+
+def test_bench_with_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """`bench.py --gpus 2` as the driver launches it on a multi-GPU node: one process per GPU, `torch.distributed` with the
+    `nccl` backend (= RCCL), the distinct-device check, one all-reduce of the counters.  Skipped on a one-GPU box -- the
+    first box with two GPUs runs the branch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import pytest
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the RCCL branch needs two devices (the gloo form of the same path runs above)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "1", "--reads", "600", "--read-len", "3000",
+                        "--genome-len", "400000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--blasrmc-reads", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [json.loads(x) for x in p.stdout.decode().splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and len(p.stdout.decode().splitlines()[-1]) < 4096
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["counters_backend"] == "nccl"
+    assert d["config"]["reads"] == 1200 and d["config"]["aligned_reads"] == 1200 and len(d["per_rank_ms_per_step"]) == 2
