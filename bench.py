@@ -412,7 +412,7 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
         n_hits, ivs = ctx.map_from_reads_device(genome_h, seq_starts, count_table, reads, wl["reads_t"].data_ptr(), pool_ptr,
                                                 pp, hits, hit_off, intervals_capacity=10 * n_reads)
         pt = ctx.pipeline_last_timing()
-        for k in ("anchoring_ms", "wait_for_intervals_ms", "path_ms", "host_intervals_ms"):
+        for k in ("anchoring_ms", "wait_for_intervals_ms", "path_ms", "host_intervals_ms"):  # (host_intervals_ms: the interval finding)
             stages[k] = stages.get(k, 0.0) + pt[k] / 1e3
         iv_off = np.concatenate([[0], np.cumsum(np.bincount(ivs["read"], minlength=n_reads))])
         last = dict(anchors=int(pt["anchors"]), intervals=int(len(ivs)), timing=ctx.map_last_timing(), ivs=ivs, iv_off=iv_off)
@@ -430,14 +430,20 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     sampled = len(range(0, len(true_iv), max(1, len(true_iv) // 2000)))
     tm = last["timing"]
     out.update({
-        "what": "reads -> hits in one C++ call (blasr_hip_map_from_reads_device): MapReadToGenome x 2 strands + "
-                "SortMatchPosList on the device, anchors to pinned host memory, RemoveOverlappingAnchors / "
-                "FindMaxIncreasingInterval / interval set on %d host threads (sub-block b on the host while the device "
-                "anchors sub-block b + 1), then the timed path of the metric on the intervals found (instead of the "
-                "synthetic ones)" % ip.threads,
+        "what": ("reads -> hits in one C++ call (blasr_hip_map_from_reads_device): MapReadToGenome x 2 strands + "
+                 "SortMatchPosList on the device; the anchors never leave it: RemoveOverlappingAnchors, the window clustering and "
+                 "GlobalChain run as kernels right behind the search (intervals_device.hip) and one 32-byte record per cluster "
+                 "comes back; the host (%d threads) ends with the p-values and the interval sets; then the timed path of the "
+                 "metric on the intervals found (instead of the synthetic ones)" % ip.threads
+                 if not os.environ.get("BLASR_HIP_INTERVALS_HOST") else
+                 "reads -> hits in one C++ call, round 2's route (BLASR_HIP_INTERVALS_HOST): anchors to pinned host memory, "
+                 "the interval finder on %d host threads beside the device's search of the next sub-block" % ip.threads),
         "steps": steps, "ms_per_step": wall * 1e3, "reads_per_s": n_reads / wall,
         "aligned_bases_per_s": tm["aligned_bases"] / wall,
         "stage_ms_per_step": {k: v / steps * 1e3 for k, v in stages.items()},
+        # the anchor stage on its own (blasr_hip_anchor_last_timing, last sub-block of the last pass): the suffix-array
+        # search is what anchoring_ms is made of; `interval_finding_ms` (kernels + the host's end) is inside anchoring_ms
+        "anchor_stage_ms": {k: round(float(v), 2) for k, v in ctx.anchor_last_timing().items() if k.endswith("_ms")},
         "anchors_per_step": last["anchors"], "candidate_intervals": last["intervals"], "hits": int(tm["hits"]),
         "aligned_reads": int(tm["aligned_reads"]),
         "anchor_blocks": n_blocks,
