@@ -1866,9 +1866,11 @@ __device__ __forceinline__ int indel_penalty(int x1, int y1, int x2, int y2, int
 }
 // (int)sqrt((double)d) for 0 <= d < 2^31, without the double-precision pipeline
 __device__ __forceinline__ int isqrt_floor(int d) {
+  // the single-precision root is off by one at most (d < 2^31 rounds to 24 bits: 2^-25 of the root, which is < 46341), so one
+  // step down and one step up settle it; s, s + 1 < 2^24 and their squares < 2^32: the full-rate 24-bit multiply is exact
   int s = (int)sqrtf((float)d);
-  while ((long long)s * s > d) s--;
-  while ((long long)(s + 1) * (s + 1) <= d) s++;
+  s -= (__umul24((unsigned)s, (unsigned)s) > (unsigned)d) ? 1 : 0;
+  s += (__umul24((unsigned)(s + 1), (unsigned)(s + 1)) <= (unsigned)d) ? 1 : 0;
   return s;
 }
 
@@ -2450,9 +2452,7 @@ __device__ __forceinline__ void chain4_body(const SdpLevelArrays &lv, const SdpP
         }
         if (have) {
           const int d = abs((fx + fy) - atw);
-          int s = (int)sqrtf((float)d);
-          s -= ((unsigned)s * (unsigned)s > (unsigned)d) ? 1 : 0;
-          s += ((unsigned)(s + 1) * (unsigned)(s + 1) <= (unsigned)d) ? 1 : 0;
+          const int s = isqrt_floor(d);
           cpFrag = aty;
           cp = atz + s - fl;
           foundPrev = true;
@@ -3102,9 +3102,7 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
           if (have) at = ent[pc];
         if (have) {
           const int d = abs((fx + fy) - at.w);
-          int sq = (int)sqrtf((float)d);
-          sq -= ((unsigned)sq * (unsigned)sq > (unsigned)d) ? 1 : 0;
-          sq += ((unsigned)(sq + 1) * (unsigned)(sq + 1) <= (unsigned)d) ? 1 : 0;
+          const int sq = isqrt_floor(d);
           cpFrag = at.y;
           cpLen = at.x;
           cp = at.z + sq - fl;

@@ -2,10 +2,10 @@
 # parity soak of the final kernels against the reference's own functions (bench.py's cpu_baseline check) on other
 # seeds / mixes than the default line, both refiners; then the whole mapper against the reference binary on random inputs
 # usage (repo root): bash tools/soak.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/${TAG}_soak
 mkdir -p $OUT
-run() { name=$1; shift; python bench.py --from-reads 0 --other-configs 0 --blasrmc-reads 0 --steps 1 --warmup 0 "$@" > $OUT/$name.json 2> $OUT/$name.err; python -c "
+run() { name=$1; shift; python bench.py --from-reads 0 --other-configs 0 --blasrmc-reads 0 --steps 1 --warmup 0 --detail-out $OUT/$name.json "$@" > $OUT/$name.log 2> $OUT/$name.err; python -c "
 import json; d=json.load(open('$OUT/$name.json')); c=d['cpu_baseline']; print('$name', round(d['ms_per_step'],1), c['parity_checked'], c['parity_mismatches'], c['sample'][:90])"; }
 {
 run c4_seed11 --config 4 --reads 2000 --seed 11 --cpu-sample 400
