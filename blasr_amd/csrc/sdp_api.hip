@@ -22,6 +22,9 @@ static_assert(sizeof(SdpResult) == sizeof(blasr_hip_sdp_result), "result record 
 #ifdef BLASR_IDX_CLOCKS
 namespace blasr_hip { void sdp_print_idx_clocks(); }
 #endif
+#ifdef BLASR_ROWS_CLOCKS
+namespace blasr_hip { void sdp_print_rows_clocks(); }
+#endif
 namespace {
 
 // Two-ended bump allocator over the context's ONE grow-only workspace (the region the refine stage uses after this
@@ -296,6 +299,16 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       lv.chainList = arena.get<int32_t>(nTasks + kChainCats);
       lv.chainCount = lv.chainList + nTasks;
       if (const char *e = getenv("BLASR_HIP_CHAIN_SCATTER")) lv.scatterMode = atoi(e);
+      // a row per step for the scattered invocations with >= 4 fragments per query row on average and >= 1024 fragments
+      // (BLASR_HIP_CHAIN_ROWS="minFrags,densityX2"; "0" switches the kernel off; BLASR_HIP_ROWS_PRIO raises its wavefronts'
+      // priority).  configs[4], three runs each on one box: sweep 528-530 ms with it, 544-646 without (profiles/NOTES.md)
+      lv.rowsNoPrio = getenv("BLASR_HIP_ROWS_PRIO") ? 0 : 1;
+      lv.rowsMinFrags = 1024;
+      lv.rowsDensityX2 = 8;
+      if (const char *e = getenv("BLASR_HIP_CHAIN_ROWS")) {
+        lv.rowsMinFrags = atoi(e);
+        if (const char *c = strchr(e, ',')) lv.rowsDensityX2 = atoi(c + 1);
+      }
     }
     ARENA_CHECK();
     launch_sdp_classify(lv, st);
@@ -785,6 +798,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   }
 #ifdef BLASR_IDX_CLOCKS
   sdp_print_idx_clocks();
+#endif
+#ifdef BLASR_ROWS_CLOCKS
+  sdp_print_rows_clocks();
 #endif
   for (int i = 0; i < 4; i++) ctx->sdpMs[i] = phaseMs[i];
   for (int i = 0; i < 4; i++) ctx->sdpBytes[i] = phaseBytes[i];

@@ -98,7 +98,11 @@ struct SdpLevelArrays {
   // 16384, [3] a smaller one, [2] sdp_chain_bits4_kernel, [1] sdp_chain_wide_kernel.  chainList null: everything through
   // sdp_chain_kernel.
   int32_t *chainList, *chainCount;
-  int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront
+  int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront;
+                                // 3 sdp_chain_rows_kernel, all of them
+  int rowsNoPrio;                   // experiments (BLASR_HIP_ROWS_NO_PRIO): sdp_chain_rows_kernel without its raised wave priority
+  int rowsMinFrags, rowsDensityX2;  // sdp_chain_rows_kernel takes the scattered invocations with at least rowsMinFrags fragments and
+                                    // rowsDensityX2 / 2 fragments per query row on average (rowsMinFrags 0: none)
   const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)
   int4 *colEnt;                 // per target column: {column, fragment, cost, x+y} of the column set's entry there
   int32_t *fused;               // per task: sdp_small_kernel did order .. chain (<= 64 raw fragments)

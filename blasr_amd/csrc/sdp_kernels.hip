@@ -2146,6 +2146,11 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     const int tl = lv.tasks[i].tLen;
     const int bySize = tl > kBitsMidTarget ? 5 : (tl > kBitsSmallTarget ? 4 : 3);
     cat = lv.scatterMode == 1 ? 1 : ((bySize > 3 || tl > kBits4Target || lv.nFrag[i] > kBits4MaxFrags || lv.scatterMode == 2) ? bySize : 2);
+    // the long invocations with several fragments per query row: a row per step (sdp_chain_rows_kernel)
+    const int nf = lv.nFrag[i];
+    if (lv.scatterMode == 3 || (lv.scatterMode == 0 && lv.rowsMinFrags > 0 && nf >= lv.rowsMinFrags &&
+                                (int64_t)2 * nf >= (int64_t)lv.rowsDensityX2 * lv.tasks[i].qLen))
+      cat = 6;
   }
   if (i < lv.n) {
     keys[i] = take ? (((uint32_t)cat << 29) | (uint32_t)min(lv.nFrag[i], (1 << 29) - 1)) : 0u;
@@ -2916,6 +2921,435 @@ __global__ __launch_bounds__(256) void sdp_chain_bits_kernel(SdpLevelArrays lv, 
   if (slot >= lv.chainCount[cat]) return;
   const int idx = lv.chainList[chain_list_start(lv, cat) + slot];
   chain_sweep_bits(lv, prm, idx, lv.tasks[idx], lv.nFrag[idx], bits[wave]);
+}
+
+// ---------------------------------------------------------------------------
+// sdp_chain_rows: the sweep with a whole ROW per step, for the scattered invocations whose rows hold several fragments
+// (the recursion's Global calls with a five- or seven-base word on long rectangles: four to sixteen chance matches per
+// query row; the longest of them are what a level waits for).
+//
+// The reference scores every fragment of sweep row x against ONE state of the column set -- it inserts nothing into colSet
+// while it scores a row (SparseDynamicProgramming.h:112-236) -- and retires the fragments of trail row x - k - 1 one after
+// the other in y order (:248-309).  Here a row is scored lane = fragment: the column predecessors are independent look-ups
+// in a three-level bitmap over the target's columns (LDS), one round of entry loads for the row; the only dependency
+// inside a row is `above` when it is the fragment just before it in the row (StoreAbove :55-68), resolved in rounds.  A
+// trail row is retired lane = fragment: fragment j reads columns >= y_j only (membership of y_j, the successors it deletes),
+// fragment i < j writes [y_i, reach_i] (its column and the successors it deleted), so when reach_i < y_j for every i < j the
+// two commute: all pending fragments are evaluated against the same state (reads only), the longest prefix whose members
+// commute is applied (disjoint ranges: LDS atomics), the rest is evaluated again.  tests/chain_rows_model.c states this
+// formulation on the CPU and compares it with the reference's loop fragment by fragment.
+// ---------------------------------------------------------------------------
+struct RowBits {
+  uint32_t *l0, *l1, *l2;  // LDS: a bit per column / per word of l0 / per word of l1 (kRowsWords / 32 / 1024 words)
+};
+constexpr int kRowsWords = kBitsMaxTarget / 32;  // 4096 words of 32 columns
+constexpr int kRowsCache = 0;                    // entries of the row sweep's cost cache ({column, cost} by column mod this; 0: none.
+                                                 //  4096 entries make a lone invocation 8 % faster and the step slower: 32 KB more
+                                                 //  LDS per wavefront is LDS the other sweep kernels of the level do not get)
+constexpr int kRowsDel = 12;                     // deleted successors a lane records per evaluation (3 KB)
+__device__ __forceinline__ uint32_t bits_above(int b) { return b >= 31 ? 0u : (~0u << (b + 1)); }   // bits > b
+__device__ __forceinline__ uint32_t bits_upto(int b) { return b >= 31 ? ~0u : ((2u << b) - 1u); }   // bits <= b
+__device__ __forceinline__ uint32_t bits_below(int b) { return (1u << b) - 1u; }                      // bits < b (b <= 31)
+// the smallest member > y, or -1 (every lane its own column; ok = the lane asks)
+__device__ __forceinline__ int rb_succ_gt(const RowBits &s, int y, bool ok) {
+  y = ok ? y : 0;
+  const int w = y >> 5, w1 = w >> 5, w2 = w1 >> 5;
+  const uint32_t m0 = s.l0[w] & bits_above(y & 31);
+  // (the next word rides along with the first round of reads: with a member every 20-60 columns the successor is in this
+  //  word or the next nine times in ten, and the answer needs no second round trip)
+  const uint32_t mNext = s.l0[min(w + 1, kRowsWords - 1)];
+  const bool nextOk = w + 1 < kRowsWords && mNext != 0u;
+  const uint32_t m1 = s.l1[w1] & bits_above(w & 31);
+  const uint4 t2 = *reinterpret_cast<const uint4 *>(s.l2);
+  const uint32_t q[4] = {t2.x, t2.y, t2.z, t2.w};
+  if (__ballot(ok && m0 == 0u && !nextOk) == 0ull) {
+    int r = nextOk ? ((w + 1) << 5) + __ffs((int)mNext) - 1 : -1;
+    if (m0) r = (w << 5) + __ffs((int)m0) - 1;
+    return ok ? r : -1;
+  }
+  // the first group (word of l1) with a member word beyond w1
+  int g = -1;
+#pragma unroll
+  for (int i = 3; i >= 0; i--) {
+    const uint32_t m = i == w2 ? (q[i] & bits_above(w1 & 31)) : (i > w2 ? q[i] : 0u);
+    g = m ? (i << 5) + __ffs((int)m) - 1 : g;
+  }
+  const uint32_t far1 = s.l1[g < 0 ? 0 : g];
+  int wN = -1;
+  if (g >= 0) wN = (g << 5) + __ffs((int)(far1 | 0x80000000u)) - 1;  // (far1 != 0 when the structure is consistent)
+  if (m1) wN = (w1 << 5) + __ffs((int)m1) - 1;
+  const uint32_t far0 = s.l0[wN < 0 ? 0 : wN];
+  int r = -1;
+  if (wN >= 0 && far0) r = (wN << 5) + __ffs((int)far0) - 1;
+  if (m0) r = (w << 5) + __ffs((int)m0) - 1;
+  return ok ? r : -1;
+}
+// the largest member <= y, or -1
+__device__ __forceinline__ int rb_pred_le(const RowBits &s, int y, bool ok) {
+  y = ok ? y : 0;
+  const int w = y >> 5, w1 = w >> 5, w2 = w1 >> 5;
+  const uint32_t m0 = s.l0[w] & bits_upto(y & 31);
+  const uint32_t mPrev = s.l0[max(w - 1, 0)];
+  const bool prevOk = w > 0 && mPrev != 0u;
+  const uint32_t m1 = s.l1[w1] & bits_below(w & 31);
+  const uint4 t2 = *reinterpret_cast<const uint4 *>(s.l2);
+  const uint32_t q[4] = {t2.x, t2.y, t2.z, t2.w};
+  if (__ballot(ok && m0 == 0u && !prevOk) == 0ull) {
+    int r = prevOk ? ((w - 1) << 5) + 31 - __clz((int)mPrev) : -1;
+    if (m0) r = (w << 5) + 31 - __clz((int)m0);
+    return ok ? r : -1;
+  }
+  int g = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t m = i == w2 ? (q[i] & bits_below(w1 & 31)) : (i < w2 ? q[i] : 0u);
+    g = m ? (i << 5) + 31 - __clz((int)m) : g;
+  }
+  const uint32_t far1 = s.l1[g < 0 ? 0 : g];
+  int wN = -1;
+  if (g >= 0) wN = (g << 5) + 31 - __clz((int)(far1 | 1u));
+  if (m1) wN = (w1 << 5) + 31 - __clz((int)m1);
+  const uint32_t far0 = s.l0[wN < 0 ? 0 : wN];
+  int r = -1;
+  if (wN >= 0 && far0) r = (wN << 5) + 31 - __clz((int)far0);
+  if (m0) r = (w << 5) + 31 - __clz((int)m0);
+  return ok ? r : -1;
+}
+// (LDS operations of a wavefront are carried out in order; this keeps the compiler from moving reads across the writes of
+//  other lanes, which it cannot see as dependencies)
+__device__ __forceinline__ void rb_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+#ifdef BLASR_ROWS_CLOCKS  // experiment: where a row step's cycles go (make EXTRA=-DBLASR_ROWS_CLOCKS, tools/chain_bench.py)
+__device__ unsigned long long g_rowsClocks[16];
+#define ROWS_CLOCK(slot)                         \
+  do {                                           \
+    const unsigned long long now_ = clock64();   \
+    rclk[slot] += now_ - rclk_;                  \
+    rclk_ = now_;                                \
+  } while (0)
+#define ROWS_COUNT(slot, n) (rclk[slot] += (unsigned long long)(n))
+void sdp_print_rows_clocks() {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rowsClocks), sizeof(h)) != hipSuccess) return;
+  fprintf(stderr, "[rows clocks] kcycles: load %llu retire-fetch %llu evaluate %llu walk %llu prefix %llu clear %llu set+store %llu query %llu score %llu "
+                  "window-end %llu | rows %llu retired-rows %llu rounds %llu walk-iterations %llu clear-iterations %llu score-rounds %llu\n",
+          h[0] >> 10, h[1] >> 10, h[2] >> 10, h[3] >> 10, h[4] >> 10, h[5] >> 10, h[6] >> 10, h[7] >> 10, h[8] >> 10, h[9] >> 10, h[10], h[11],
+          h[12], h[13], h[14], h[15]);
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rowsClocks), z, sizeof(z));
+}
+#else
+#define ROWS_CLOCK(slot) do { } while (0)
+#define ROWS_COUNT(slot, n) do { } while (0)
+#endif
+__global__ __launch_bounds__(64) void sdp_chain_rows_kernel(SdpLevelArrays lv, SdpParams prm) {
+  __shared__ __attribute__((aligned(16))) uint32_t ldsBits[kRowsWords + kRowsWords / 32 + 4];
+  // The costs of the entries, a second time, in LDS: {column, cost} by column mod kRowsCache, written (one 8-byte store: tag
+  // and cost cannot part) whenever an entry is stored.  A retirement reads costs only -- of its own column's entry, of the
+  // successors it walks over -- and with them in LDS a step of that walk is three LDS round trips instead of three and one
+  // through L2; a slot that another column has taken since is a miss and goes to memory, which stays the truth.
+  __shared__ uint2 costCache[kRowsCache > 0 ? kRowsCache : 1];
+  // what a retirement's walk found to delete, per lane (the first kRowsDel of a run; a longer run is walked again)
+  __shared__ int delList[kRowsDel][64];
+  const int slot = (int)blockIdx.x;
+  if (slot >= lv.chainCount[6]) return;
+  // These are the level's longest invocations and this is a vector program of ~1000 instructions per row: on a CU it shares
+  // with thirty wavefronts of the other sweep kernels it waited its turn for every one of them (the kernel three times as
+  // slow as alone).  Its wavefronts go first.
+  if (!lv.rowsNoPrio) __builtin_amdgcn_s_setprio(3);
+  const int idx = lv.chainList[chain_list_start(lv, 6) + slot];
+  const SdpTask t = lv.tasks[idx];
+  const int F = lv.nFrag[idx];
+  const int lane = lane_id();
+  const int64_t base = lv.fragOff[idx];
+  const Frag *fr = lv.frags + base;
+  int *cost = lv.cost + base, *chainPrev = lv.chainPrev + base, *chainLen = lv.chainLen + base;
+  const int *predCl = lv.predCl + base, *above = lv.above + base;
+  int4 *ent = lv.colEnt + lv.colOff[idx];  // the entry of a member column: {chain length, fragment, cost, x + y}
+  RowBits cols;
+  cols.l0 = ldsBits;
+  cols.l1 = ldsBits + kRowsWords;
+  cols.l2 = ldsBits + kRowsWords + kRowsWords / 32;
+  for (int w = lane; w < kRowsWords + kRowsWords / 32 + 4; w += 64) ldsBits[w] = 0;
+  for (int w = lane; w < kRowsCache; w += 64) costCache[w] = make_uint2(0xffffffffu, 0u);
+  rb_sync();
+  // the cost of member column `col` (want: the lane asks)
+  auto cost_of_col = [&](int col, bool want) {
+    int v = 0;
+    if (kRowsCache > 0) {
+      const uint2 cv = costCache[want ? col & (kRowsCache - 1) : 0];
+      const bool miss = want && cv.x != (uint32_t)col;
+      v = (int)cv.y;
+      if (__ballot(miss) != 0ull)
+        if (miss) v = ent[col].z;
+    } else if (want) {
+      v = ent[col].z;
+    }
+    return v;
+  };
+  const int k = t.k;
+  const uint32_t fragmentLength = (uint32_t)k, weight = (uint32_t)k;
+  int fTrail = 0;
+  // per lane: the best cost / the longest chain among the fragments this lane scored, each at its lowest index (the
+  // reference's running minimum and maximum use strict comparisons: the best value at its lowest index)
+  int bestCost = INT32_MAX, bestCostIdx = INT32_MAX, bestLenIdx = INT32_MAX;
+  uint32_t bestLen = 0;
+  int curCost = 0, curLen = 0, curPrev = -1, prevCost = 0, prevLen = 0;
+  int rw0 = -64, rxV = 0, ryV = 0;  // the retirements' window: fragments rw0 + lane, their row and column
+#ifdef BLASR_ROWS_CLOCKS
+  unsigned long long rclk[16] = {}, rclk_ = clock64();
+#endif
+  for (int w0 = 0; w0 < F; w0 += 64) {
+    prevCost = curCost;
+    prevLen = curLen;
+    int fxV = 0, fyV = 0, flV = 0, fpV = -1, faV = -1, clS = 0, caS = 0;
+    const bool inWin = w0 + lane < F;
+    if (inWin) {
+      const Frag f = fr[w0 + lane];
+      fxV = (int)f.x;
+      fyV = (int)f.y;
+      flV = (int)f.len;
+      fpV = predCl[w0 + lane];
+      faV = above[w0 + lane];
+      if (fpV >= 0) {  // what the two fixed predecessors add to their own cost: coordinates only
+        const Frag q = fr[fpV];
+        int ov = (int)(fragmentLength - (uint32_t)(fyV - (int)q.y)) * prm.match;
+        if (ov > 0) ov = 0;
+        clS = ov + indel_penalty(fxV, fyV, (int)q.x, (int)q.y, prm.sdpIns, prm.sdpDel);
+      }
+      if (faV >= 0) {
+        const Frag q = fr[faV];
+        caS = (int)((fragmentLength - (uint32_t)(fyV - (int)q.y)) * (uint32_t)prm.match +
+                    (uint32_t)indel_penalty(fxV, fyV, (int)q.x, (int)q.y, prm.sdpIns, prm.sdpDel));
+      }
+    }
+    curCost = 0, curLen = 0, curPrev = -1;
+    const int nHere = min(64, F - w0);
+    ROWS_CLOCK(0);
+    // cost / chain length of fragment p (< the row being scored), per lane: this window, the one before, or memory
+    auto cost_len_of = [&](int p, bool want, int &c, int &l) {
+      const int rel = p - w0;
+      const int vc = __builtin_amdgcn_ds_bpermute((rel & 63) << 2, curCost), vl = __builtin_amdgcn_ds_bpermute((rel & 63) << 2, curLen);
+      const int pc = __builtin_amdgcn_ds_bpermute((rel & 63) << 2, prevCost), pl = __builtin_amdgcn_ds_bpermute((rel & 63) << 2, prevLen);
+      c = rel >= 0 ? vc : pc;
+      l = rel >= 0 ? vl : pl;
+      const bool far = want && rel < -64;
+      if (__ballot(far) != 0ull) {  // (stored at the end of its window, two windows ago or earlier)
+        if (far) {
+          c = cost[p];
+          l = chainLen[p];
+        }
+      }
+    };
+    for (int j = 0; j < nHere;) {
+      const int fx = __builtin_amdgcn_readlane(fxV, j);
+      const unsigned long long rowMask = __ballot(inWin && lane >= j && fxV == fx);  // (sorted by x: contiguous from j)
+      const int jEnd = j + (int)__popcll(rowMask);
+      // ---- rows leaving the window: fragments with x <= fx - k - 2 are retired before row fx is scored (:248-309)
+      while (fTrail < w0 + j) {
+        if (fTrail >= rw0 + 64) {
+          rw0 = fTrail;
+          rxV = 0, ryV = 0;
+          if (rw0 + lane < F) {
+            const Frag f = fr[rw0 + lane];
+            rxV = (int)f.x;
+            ryV = (int)f.y;
+          }
+        }
+        const int rl = fTrail - rw0;
+        const int tx = __builtin_amdgcn_readlane(rxV, rl);
+        if ((int64_t)tx + k + 2 > (int64_t)fx) break;
+        const unsigned long long retMask = __ballot(lane >= rl && rw0 + lane < w0 + j && rxV == tx);
+        const bool mine = ((retMask >> lane) & 1ull) != 0ull;
+        const int fi = rw0 + lane;
+        int c = 0, len = 0;
+        cost_len_of(fi, mine, c, len);
+        ROWS_CLOCK(1);
+        ROWS_COUNT(11, 1);
+        // -- the row (or the piece of it the window holds), increasing y: evaluate / longest commuting prefix / apply
+        unsigned long long pending = retMask;
+        while (pending != 0ull) {
+          const bool pend = ((pending >> lane) & 1ull) != 0ull;
+          const bool member = pend && ((cols.l0[pend ? ryV >> 5 : 0] >> (ryV & 31)) & 1u) != 0u;
+          const int exist = cost_of_col(ryV, member);
+          const bool store = pend && (!member || exist < c);  // sic (:260-267): replaced only when the existing entry is CHEAPER
+          int reach = ryV, nDel = 0;
+          int s = rb_succ_gt(cols, ryV, store);
+          bool act = store && s >= 0;
+          ROWS_CLOCK(2);
+          ROWS_COUNT(12, 1);
+          while (__ballot(act) != 0ull) {  // delete the costlier successors: every lane walks its own run
+            const int sc = cost_of_col(s, act);
+            const bool del = act && sc > c;
+            if (del && nDel < kRowsDel) delList[nDel][lane] = s;
+            nDel += del ? 1 : 0;
+            reach = del ? s : reach;
+            const int nx = rb_succ_gt(cols, s, del);
+            s = del ? nx : s;
+            act = del && nx >= 0;
+            ROWS_COUNT(13, 1);
+          }
+          ROWS_CLOCK(3);
+          // the longest prefix of pending lanes whose writes stay left of the next lane's column
+          const int wr = store ? reach : -1;
+          const int incl = wave_prefix_max(pend ? wr : -1);
+          const int excl = wave_shr1(incl, -1);
+          const unsigned long long dirty = __ballot(pend && excl >= ryV);
+          const unsigned long long applyMask = dirty ? (pending & ((1ull << __builtin_ctzll(dirty)) - 1ull)) : pending;
+          const bool app = ((applyMask >> lane) & 1ull) != 0ull && store;
+          ROWS_CLOCK(4);
+          // their writes: the deleted successors' bits first -- the columns the walk listed (no look-up between two of them:
+          // the atomics of consecutive list entries are independent), a run beyond the list walked again from its last
+          // entry -- then the own column
+          {
+            rb_sync();
+            const int nList = app ? min(nDel, kRowsDel) : 0;
+            const int longest = wave_max(nList);
+            auto clear_col = [&](int tcol) {
+              const int w = tcol >> 5;
+              const uint32_t bit = 1u << (tcol & 31);
+              const uint32_t old = atomicAnd(&cols.l0[w], ~bit);
+              if ((old & ~bit) == 0u) {
+                const uint32_t bit1 = 1u << (w & 31);
+                const uint32_t old1 = atomicAnd(&cols.l1[w >> 5], ~bit1);
+                if ((old1 & ~bit1) == 0u) atomicAnd(&cols.l2[w >> 10], ~(1u << ((w >> 5) & 31)));
+              }
+            };
+            for (int i = 0; i < longest; i++) {
+              const int tcol = delList[i][lane];
+              if (i < nList) clear_col(tcol);
+              ROWS_COUNT(14, 1);
+            }
+            if (__ballot(app && nDel > kRowsDel) != 0ull) {  // (rare: a run longer than the list)
+              rb_sync();
+              int tcol = app && nDel > kRowsDel ? delList[kRowsDel - 1][lane] : 0;
+              bool go = app && nDel > kRowsDel;
+              while (__ballot(go) != 0ull) {
+                const int nx = rb_succ_gt(cols, tcol, go && tcol < reach);
+                go = go && nx >= 0 && nx <= reach;
+                tcol = nx;
+                if (go) clear_col(tcol);
+                rb_sync();
+              }
+            }
+          }
+          rb_sync();
+          ROWS_CLOCK(5);
+          if (app) {
+            const int w = ryV >> 5;
+            atomicOr(&cols.l0[w], 1u << (ryV & 31));
+            atomicOr(&cols.l1[w >> 5], 1u << (w & 31));
+            atomicOr(&cols.l2[w >> 10], 1u << ((w >> 5) & 31));
+            ent[ryV] = make_int4(len, fi, c, rxV + ryV);
+            if (kRowsCache > 0) costCache[ryV & (kRowsCache - 1)] = make_uint2((uint32_t)ryV, (uint32_t)c);
+          }
+          rb_sync();  // (the entries are read again by the next evaluation and by the row's queries)
+          ROWS_CLOCK(6);
+          pending &= ~applyMask;
+        }
+        fTrail += (int)__popcll(retMask);
+      }
+      // ---- score the row's lanes: column predecessors against the set as it stands, then the three candidates (:112-236)
+      {
+        const bool row = ((rowMask >> lane) & 1ull) != 0ull;
+        const int pc = rb_pred_le(cols, fyV, row);
+        int4 at = make_int4(0, 0, 0, 0);
+        if (pc >= 0) at = ent[pc];
+        int clCost = 0, clLen = 0, caCost = 0, caLen = 0;
+        cost_len_of(fpV, row && fpV >= 0, clCost, clLen);
+        // `above` inside this very piece of the row (the fragment just before it in the row) waits for its turn
+        bool wait = row && faV >= w0 + j;
+        cost_len_of(faV, row && faV >= 0 && !wait, caCost, caLen);
+        bool todo = row;
+        ROWS_CLOCK(7);
+        ROWS_COUNT(10, 1);
+        while (__ballot(todo) != 0ull) {
+          // (a lane whose `above` is in this piece of the row goes once that lane HAS BEEN scored, i.e. in a later round than
+          //  it; the permutes are carried out by every lane: a lane that is switched off reads as zero)
+          const int aRel = (faV - w0) & 63;
+          const bool aboveTodo = __builtin_amdgcn_ds_bpermute(aRel << 2, (int)todo) != 0;
+          const int aCost = __builtin_amdgcn_ds_bpermute(aRel << 2, curCost), aLen = __builtin_amdgcn_ds_bpermute(aRel << 2, curLen);
+          const bool now = todo && !(wait && aboveTodo);
+          if (wait) {
+            caCost = aCost;
+            caLen = aLen;
+          }
+          int cp = INT32_MAX, cl = INT32_MAX, ca = INT32_MAX;
+          bool found = false;
+          if (pc >= 0) {
+            cp = at.z + isqrt_floor(abs((fxV + fyV) - at.w)) - flV;
+            found = true;
+          }
+          if (fpV >= 0) {
+            cl = (int)((uint32_t)clCost + (uint32_t)clS);
+            found = true;
+          }
+          if (faV >= 0) {
+            ca = (int)((uint32_t)caCost + (uint32_t)caS);
+            found = true;
+          }
+          int mc = cl < ca ? cl : ca;
+          if (cp < mc) mc = cp;
+          int myCost, myPrev;
+          uint32_t myLen;
+          if (found && (t.type == 1 || (t.type == 0 && mc < 0))) {
+            myCost = (int)((uint32_t)mc - weight);
+            if (mc == cp) myPrev = at.y, myLen = (uint32_t)at.x + 1u;
+            else if (mc == cl) myPrev = fpV, myLen = (uint32_t)clLen + 1u;
+            else myPrev = faV, myLen = (uint32_t)caLen + 1u;
+          } else {
+            myPrev = -1;
+            myLen = 1;
+            if (t.type == 1)
+              myCost = (int)((uint32_t)(fxV + fyV) * (uint32_t)prm.sdpDel + fragmentLength * (uint32_t)prm.match - weight);
+            else myCost = (int)(fragmentLength * (uint32_t)prm.match - weight);
+          }
+          if (now) {
+            curCost = myCost;
+            curLen = (int)myLen;
+            curPrev = myPrev;
+            const int i = w0 + lane;
+            if (bestCost > myCost) bestCost = myCost, bestCostIdx = i;
+            if (myLen > bestLen) bestLen = myLen, bestLenIdx = i;
+          }
+          todo = todo && !now;
+          ROWS_COUNT(15, 1);
+        }
+        ROWS_CLOCK(8);
+      }
+      j = jEnd;
+    }
+    if (inWin) {
+      cost[w0 + lane] = curCost;
+      chainPrev[w0 + lane] = curPrev;
+      chainLen[w0 + lane] = curLen;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    ROWS_CLOCK(9);
+  }
+#ifdef BLASR_ROWS_CLOCKS
+  if (lane == 0)
+    for (int i = 0; i < 16; i++) atomicAdd(&g_rowsClocks[i], rclk[i]);
+#endif
+  // the minimum cost (Local) / the longest chain (Global), each at its lowest index
+  int endIdx;
+  if (t.type == 0) {
+    int v = bestCost;
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    int i = bestCost == v ? bestCostIdx : INT32_MAX;
+    for (int off = 32; off > 0; off >>= 1) i = min(i, __shfl_xor(i, off));
+    endIdx = i == INT32_MAX ? -1 : i;
+  } else {
+    uint32_t v = bestLen;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    int i = (bestLen == v && v > 0) ? bestLenIdx : INT32_MAX;
+    for (int off = 32; off > 0; off >>= 1) i = min(i, __shfl_xor(i, off));
+    endIdx = i == INT32_MAX ? -1 : i;
+  }
+  if (lane == 0) lv.chainEnd[idx] = endIdx;
 }
 
 // ---------------------------------------------------------------------------
@@ -4409,13 +4843,20 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         s0 = aux[0], s1 = aux[1], s2 = aux[2];
       }
       int conc = 0;  // how many of the sweep's kernels run side by side
-      for (int c : {0, 2, 3, 4, 5}) conc += (!counts || counts[c] > 0) ? 1 : 0;
+      for (int c : {0, 2, 3, 4, 5, 6}) conc += (!counts || counts[c] > 0) ? 1 : 0;
       if (!fork) conc = 1;
-      if (!counts || counts[5] > 0) {
-        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE, s0, conc);
-        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(5, 1), dim3(256), 0, s0, lv, p);
+      if (!counts || counts[6] > 0) {  // (the level's longest invocations: first, on the main stream)
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_ROWS, st, conc);
+        hipLaunchKernelGGL(sdp_chain_rows_kernel, dim3((unsigned)std::max(counts ? counts[6] : lv.n, 1)), dim3(64), 0, st, lv, p);
       }
-      if (!counts || counts[4] > 0) {  // (on the large ones' stream: those are rare, and the hardware queues are few)
+      // (the largest targets on the MAIN stream, where sdp_chain4_kernel has nothing at the levels that have them: a handful
+      //  of invocations, but the longest of the level -- 137 k fragments, 258 ms at configs[4] -- and behind them on one
+      //  stream the middle class waited its 250 ms out: 736 ms of sweep instead of ~490)
+      if (!counts || counts[5] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE, st, conc);
+        hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsWords>, grid_for(5, 1), dim3(256), 0, st, lv, p);
+      }
+      if (!counts || counts[4] > 0) {
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID, s0, conc);
         hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsMidTarget / 32>, grid_for(4, 1), dim3(256), 0, s0, lv, p);
       }

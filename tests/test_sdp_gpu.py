@@ -280,8 +280,9 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
     stats = [as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])) for (q, t), w in zip(pairs, want)]
     # the scattered invocations through the bitmap sweep four per wavefront (default) and one per wavefront (2), the
     # 512-register sweep (1), and without any of them (the register-tail sweep of chain4)
+    # ... and a row per step (3: sdp_chain_rows_kernel for every scattered invocation)
     for env, val in ((None, None), ("BLASR_HIP_CHAIN_SCATTER", "1"), ("BLASR_HIP_CHAIN_SCATTER", "2"),
-                     ("BLASR_HIP_NO_CHAIN_BITS", "1")):
+                     ("BLASR_HIP_CHAIN_SCATTER", "3"), ("BLASR_HIP_NO_CHAIN_BITS", "1")):
         if env:
             monkeypatch.setenv(env, val)
         got = ctx.sdp(pairs)
@@ -302,10 +303,50 @@ def test_unrelated_sequences_against_oracle(ctx, oracle, monkeypatch):
         osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
         sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
         want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]
-        for mode in ("0", "1", "2"):
+        for mode in ("0", "1", "2", "3"):
             monkeypatch.setenv("BLASR_HIP_CHAIN_SCATTER", mode)
             got = ctx.sdp(rect, sdp=sp)
             monkeypatch.delenv("BLASR_HIP_CHAIN_SCATTER")
             for i, ((q, t), g, w) in enumerate(zip(rect, got, want)):
                 st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
                 _check(g, w, st, "rectangle k=%d %d mode %s" % (k, i, mode))
+
+
+def test_dense_rows_through_the_row_sweep(ctx, oracle, monkeypatch):
+    """sdp_chain_rows_kernel where its lanes interact: low-complexity sequence (runs of a base, two- and three-letter
+    alphabets) gives rows of dozens of fragments, retired rows whose fragments delete each other's successors (the
+    commuting-prefix rule has to cut), equal costs, and fragments whose `above` is the fragment just before them in the same
+    row.  Global calls with short words, as the recursion issues them; every scattered invocation through the row sweep
+    (BLASR_HIP_CHAIN_SCATTER=3) and through the default kernels, against the oracle."""
+    from blasr_testlib import SdpParams as OSdp
+    rng = np.random.default_rng(777)
+
+    def lowcomplex(n, letters, run):
+        out = np.empty(n, dtype=np.uint8)
+        at = 0
+        while at < n:
+            c = ord("ACGT"[int(rng.integers(0, letters))])
+            r = int(rng.integers(1, run + 1))
+            out[at: at + r] = c
+            at += r
+        return out
+
+    def as_list(st):
+        return [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]]
+
+    for k in (5, 7):
+        rect = []
+        for i in range(10):
+            letters, run = (2, 3) if i % 3 == 0 else ((3, 4) if i % 3 == 1 else (4, 6))
+            rect.append((lowcomplex(int(rng.integers(150, 900)), letters, run), lowcomplex(int(rng.integers(200, 1500)), letters, run)))
+        rect.append((synth.random_genome(3000, 1234 + k), synth.random_genome(5000, 4321 + k)))  # ~ 3 k rows of 5 (k = 5)
+        osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
+        sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
+        want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]
+        for mode in ("3", "0"):
+            monkeypatch.setenv("BLASR_HIP_CHAIN_SCATTER", mode)
+            got = ctx.sdp(rect, sdp=sp)
+            monkeypatch.delenv("BLASR_HIP_CHAIN_SCATTER")
+            for i, ((q, t), g, w) in enumerate(zip(rect, got, want)):
+                st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
+                _check(g, w, st, "dense rows k=%d %d mode %s" % (k, i, mode))
