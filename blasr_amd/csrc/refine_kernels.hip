@@ -1012,7 +1012,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             // lane, j) = column base + 3 (64 step + lane) + j and handed on by a lane shift.  A row wider than 576
             // columns, or one that starts more than one column further on, ends the run and takes the ring path below.
             {
+#ifdef BLASR_WIDE5  // experiment (make EXTRA=-DBLASR_WIDE5): five cells per lane, two steps of 320 columns
+              constexpr int kW = 5, kWStep = 64 * kW, kRunSteps = 2, kRunMax = kRunSteps * kWStep;
+#else
               constexpr int kW = 3, kWStep = 64 * kW, kRunSteps = 3, kRunMax = kRunSteps * kWStep;
+#endif
               const int nG = min(64, from_group(myQ, g) - r0 + 1);  // rows of candidate g in this batch
               int run = 0;
               if (wHi - wLo + 1 <= kRunMax && wPhi - wLo + 1 <= kRunMax && args.exp != 3) {
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 // The target bases of the 576 columns from `base` on, three to a register like the cells (byte j of
                 // tP[step] = the base of cell (step, lane, j)), loaded once per run and handed on by the same lane shift
                 // as the row above: a load at the head of every step would expose its whole latency, once per step.
-                uint32_t tP[kRunSteps];
+                uint64_t tP[kRunSteps];
 #pragma unroll
                 for (int k = 0; k < kRunSteps; k++) {
                   uint32_t b[kW];
@@ -1050,7 +1054,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                     b[j] = (uint32_t)wT[min(max(c, 0), tLast)];
                     b[j] = (c >= 0 && c < wTLen) ? b[j] : (uint32_t)'N';  // (beyond the target: N, decided here once)
                   }
-                  tP[k] = b[0] | (b[1] << 8) | (b[2] << 16);
+                  tP[k] = 0;
+#pragma unroll
+                  for (int j = 0; j < kW; j++) tP[k] |= (uint64_t)b[j] << (8 * j);
                 }
                 for (int ii = i; ii < nG; ii++) {
                   const int2 rrec = rowA[wave][g][ii];
@@ -1066,11 +1072,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                     entering = (base + kRunMax >= 0 && base + kRunMax < wTLen) ? entering : (uint32_t)'N';
                     uint32_t first[kRunSteps + 1];
 #pragma unroll
-                    for (int k = 0; k < kRunSteps; k++) first[k] = (uint32_t)__builtin_amdgcn_readlane((int)tP[k], 0) & 0xffu;
+                    for (int k = 0; k < kRunSteps; k++) first[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tP[k], 0) & 0xffu;
                     first[kRunSteps] = entering;
 #pragma unroll
                     for (int k = 0; k < kRunSteps; k++)
-                      tP[k] = (tP[k] >> 8) | (((uint32_t)wave_shl1((int)tP[k], (int)first[k + 1]) & 0xffu) << 16);
+                      tP[k] = (tP[k] >> 8) | ((uint64_t)((uint32_t)wave_shl1((int)(uint32_t)tP[k], (int)first[k + 1]) & 0xffu) << (8 * (kW - 1)));
                   }
                   // the values that cross a step's edge are read off just before they are needed: the last cell of the
                   // step before (d = 0; saved before that step overwrote it) or the first cell of the step after (d = 1;
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                       ea = min(ea, wCarryA);
                       eb = min(eb, wCarryB);
                     }
-                    uint32_t arrowLo = 0, arrowHi = 0;
+                    uint32_t arrowLo = 0, arrowHi = 0;  // (cells 0 .. kW - 2 in arrowLo, the last one in arrowHi)
 #pragma unroll
                     for (int j = 0; j < kW; j++) {
                       const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
@@ -1153,15 +1159,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                       const int iKey = min(openKey, kExt0 ? upI[j] : insEK[j] & ~kTagMask);
                       const int dFlag = openKey < bK ? AR_D_OPEN : 0;
                       const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag) & kTagMask;
-                      if (j < 2) arrowLo |= arrow << (8 * j); else arrowHi = arrow;
+                      if (j < kW - 1) arrowLo |= arrow << (8 * j); else arrowHi = arrow;
                       pS[k][j] = sv;  // (cells beyond the row's end hold what no later row takes for a cell: prevHi)
                       pI[k][j] = iKey & ~kTagMask;
                     }
                     if (c0 <= rHi) {  // three arrows per lane; those beyond the row's end land in the next row's space
                       typedef unaligned_u16 __attribute__((address_space(1))) GU16;
                       GByte *ap = rowArrows + (c0 - rLo);
-                      *(GU16 *)ap = (uint16_t)arrowLo;
-                      ap[2] = (uint8_t)arrowHi;
+                      if (kW == 3) {
+                        *(GU16 *)ap = (uint16_t)arrowLo;
+                      } else {
+                        typedef unaligned_u32 __attribute__((address_space(1))) GU32;
+                        *(GU32 *)ap = arrowLo;
+                      }
+                      ap[kW - 1] = (uint8_t)arrowHi;
                     }
                     wCarryA = min(wCarryA, __builtin_amdgcn_readlane(pa, 63)) + kWStep * kDel;
                     wCarryB = min(wCarryB, __builtin_amdgcn_readlane(pb, 63)) + kWStep * kExt;
