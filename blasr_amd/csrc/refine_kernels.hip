@@ -1708,29 +1708,13 @@ template __global__ void fill_kernel<true, false>(RefineBatchView, FillArgs);
 constexpr int kTbWin = 16;  // bytes per prefetched arrow window
 
 __device__ __forceinline__ uint4 load_window(const uint8_t *p) {
-#ifdef BLASR_TB_UNALIGNED  // (round 4's form: one 16-byte load at a byte address, which the memory pipeline takes apart)
+  // unaligned 16-byte load (global memory allows it); p + 16 stays inside the candidate's arrow slab.
+  // (Round 5 measured the aligned alternatives -- the window starts at a byte address -- at configs[2]: two 16-byte-aligned
+  //  loads and a funnel shift through selects 119 ms (115 registers, scratch), a dword-aligned 16-byte load + one dword and
+  //  four v_alignbit 43.1 ms, this load 39.1 ms: the misalignment is not what keeps the texture addresser busy.)
   uint4 v;
   __builtin_memcpy(&v, p, 16);
   return v;
-#else
-  // The window starts at a BYTE address (an arrow is a byte, a row starts wherever the row before it ended): as one
-  // 16-byte load it is an unaligned access, which the texture addresser serves dword by dword -- 58 % busy with this
-  // kernel's windows alone.  Two ALIGNED 16-byte loads around it and a funnel shift in registers instead; the bytes read
-  // beyond the window (up to 15 before, 16 behind: the slab's own slack, the neighbouring slab, the workspace's fixed part
-  // in front of the first slab) are never looked at.
-  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-  const uint4 *q = reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
-  const uint4 lo = q[0], hi = q[1];
-  const unsigned s4 = (unsigned)(a >> 2) & 3u, sb = ((unsigned)a & 3u) * 8u;
-  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  uint32_t t[7], u[5];
-#pragma unroll
-  for (int k = 0; k < 7; k++) t[k] = (s4 & 1u) ? w[k + 1] : w[k];
-#pragma unroll
-  for (int k = 0; k < 5; k++) u[k] = (s4 & 2u) ? t[k + 2] : t[k];  // u[k] = w[k + s4]
-  return make_uint4(__builtin_amdgcn_alignbit(u[1], u[0], sb), __builtin_amdgcn_alignbit(u[2], u[1], sb),
-                    __builtin_amdgcn_alignbit(u[3], u[2], sb), __builtin_amdgcn_alignbit(u[4], u[3], sb));
-#endif
 }
 __device__ __forceinline__ unsigned window_byte(const uint4 &w, int i) {  // 0 <= i < 16
   const uint32_t lo = (i & 4) ? w.y : w.x, hi = (i & 4) ? w.w : w.z;
