@@ -285,6 +285,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     tick();
     lv.idxMaxT = idxMaxT;
     lv.noIdxFilter = getenv("BLASR_HIP_NO_IDX_FILTER") ? 1 : 0;
+    lv.idxFilterX2 = getenv("BLASR_HIP_IDX_FILTER_X2") ? std::max(1, atoi(getenv("BLASR_HIP_IDX_FILTER_X2"))) : 2;
     lv.bigList = arena.get<int32_t>(nTasks + 1);
     lv.bigCount = lv.bigList + nTasks;
     lv.midList = arena.get<int32_t>(nTasks + 1);

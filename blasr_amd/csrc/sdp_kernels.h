@@ -88,6 +88,7 @@ struct SdpLevelArrays {
   int32_t *cost, *chainPrev, *chainLen, *predCl, *above;  // per fragment
   int idxMaxT;                  // targets up to this length (and >= 1536) are matched by sdp_match_index_kernel
   int noIdxFilter;              // tests / experiments (BLASR_HIP_NO_IDX_FILTER): the index matcher's count pass without its filter
+  int idxFilterX2;              // the filter is used where the target's k-mers x idxFilterX2 / 2 < the filter's bits (default 2: fewer k-mers than bits; configs[4], 30 kb windows: match + order 347 / 332 ms with 4, 321 / 319 with 2)
   int32_t *bigList, *bigCount;  // those tasks
   int32_t *keyList, *keyCount;  // the tasks whose targets get sorted k-mer keys (sdp_keys_kernel, sdp_sort_keys_kernel)
   int32_t *midList, *midCount;  // the tasks of sdp_match_kernel's bucket instantiation (targets >= 256 bases, not indexed)

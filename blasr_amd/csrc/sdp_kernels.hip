@@ -521,10 +521,10 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
     const uint32_t kmerMask = (1u << (2 * k)) - 1u, kMask = (1u << k) - 1u;
     if (kWrite && lv.idxFlag[idx] == 0) continue;  // sdp_match_index_copy_kernel's
     const bool build = true;
-    // the filter pays where few of the query's positions pass it: a target with far fewer k-mers than the filter has bits
+    // the filter pays where not every position of the query passes it: a target with fewer k-mers than the filter has bits
     // (and than there are k-mers of that length at all: a five-base word on a long target passes everywhere)
     const int kmerSpace = 2 * k >= 16 ? kIdxFilterBits : (1 << (2 * k));
-    const bool useFilter = !kWrite && (int64_t)(t.tLen - k + 1) * 2 < (int64_t)min(kmerSpace, kIdxFilterBits) && !lv.noIdxFilter;
+    const bool useFilter = !kWrite && (int64_t)(t.tLen - k + 1) * lv.idxFilterX2 < (int64_t)2 * min(kmerSpace, kIdxFilterBits) && !lv.noIdxFilter;
 #ifdef BLASR_IDX_CLOCKS
     unsigned long long clk_ = clock64();
     if (threadIdx.x == 0) atomicAdd(&g_idxClocks[(kWrite ? 8 : 0) + 6], 1ull);
