@@ -379,6 +379,8 @@ struct IdxLds {
 // without a match for a 10 kb target and an 11-base word) are listed and walked 64 to a trip -- the walk runs as long as the LONGEST bucket among its
 // 64 lanes, and with every position in it a wavefront spent five sixths of its walk steps on lanes with nothing left to do.
 constexpr int kIdxFilterBits = 65536;
+constexpr int kIdxSortCap = 16;  // matches of one query position the write pass orders in LDS (in the filter's words: 256 x 32 bytes)
+static_assert(256 * kIdxSortCap * 2 <= kIdxFilterBits / 8, "the write pass sorts in the filter's words");
 __host__ __device__ inline int idx_lds_words(int tCap, int *offs /* 9 */) {
   int at = 0;
   offs[0] = at, at += tCap / 16 + 4;          // tCodes
@@ -827,6 +829,28 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
           if (cnt > 0 && cnt <= 3) {
             for (int u = 0; u < cnt; u++) {
               f.y = (uint32_t)((h >> (16 * (u + 1))) & 0xffffu);
+              out[w++] = f;
+            }
+          } else if (cnt > 3 && cnt <= kIdxSortCap) {
+            // Up to sixteen matches of a position are ordered in LDS (the filter's words are free in the write pass: 32 bytes
+            // per thread) and go out in one run.  With a seven-base word on a 16-64 kb target nearly every position of every
+            // invocation comes this way, and ordering them in the output -- a dependent load of the fragment before per step
+            // of the insertion -- made the write pass of configs[4]'s level 1 longer than its count pass.
+            uint16_t *mine = reinterpret_cast<uint16_t *>(L.filt) + tid * kIdxSortCap;
+            int n = 0;
+            for (int i = bs; i < be; i++) {
+              const uint32_t tp = L.ent[i];
+              if (code_window(L.tCodes, (int)tp, kmerMask) == km && n < kIdxSortCap) {
+                int at = n++;
+                while (at > 0 && mine[at - 1] > tp) {
+                  mine[at] = mine[at - 1];
+                  at--;
+                }
+                mine[at] = (uint16_t)tp;
+              }
+            }
+            for (int u = 0; u < n; u++) {
+              f.y = (uint32_t)mine[u];
               out[w++] = f;
             }
           } else if (cnt > 3) {  // only in a task whose index was rebuilt
