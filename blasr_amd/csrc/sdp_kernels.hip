@@ -2180,18 +2180,30 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     keys[i] = take ? (((uint32_t)cat << 29) | (uint32_t)min(lv.nFrag[i], (1 << 29) - 1)) : 0u;
     vals[i] = i;
   }
-  for (int c = 0; c < kChainCats; c++) {
-    const unsigned long long m = __ballot(take && cat == c);
-    if (m == 0ull) continue;
-    if (lane_id() == 0) atomicAdd(lv.chainCount + c, (int)__popcll(m));
-    if (lv.kernelSums != nullptr) {  // what the category's kernel will have swept (blasr_hip_sdp_last_kernels)
+  // the category counts (and, for blasr_hip_sdp_last_kernels, what each category's kernel will have swept), summed per
+  // WORKGROUP in LDS and added with one round of atomics: a round per wavefront and category took this kernel from 0.3 to 4.6 ms
+  // per configs[2] step (ten million invocations a level at the recursion levels, nearly all of them fused)
+  __shared__ unsigned long long acc[kChainCats][3];
+  if (threadIdx.x < kChainCats * 3) acc[threadIdx.x / 3][threadIdx.x % 3] = 0ull;
+  __syncthreads();
+  if (__ballot(take) != 0ull && take) {
+    atomicAdd(&acc[cat][0], 1ull);
+    if (lv.kernelSums != nullptr) {
+      atomicAdd(&acc[cat][1], (unsigned long long)(unsigned)lv.nFrag[i]);
+      atomicAdd(&acc[cat][2], (unsigned long long)(unsigned)lv.tasks[i].qLen);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kChainCats) {
+    const int c = (int)threadIdx.x;
+    const unsigned long long cntC = acc[c][0];
+    if (cntC != 0ull) {
+      atomicAdd(lv.chainCount + c, (int)cntC);
       const int kind = chain_category_kind(c);
-      const unsigned fr = wave_sum_u32(take && cat == c ? (unsigned)lv.nFrag[i] : 0u);
-      const unsigned qp = wave_sum_u32(take && cat == c ? (unsigned)lv.tasks[i].qLen : 0u);
-      if (lane_id() == 0 && kind >= 0) {
-        atomicAdd(lv.kernelSums + 3 * kind + 0, (unsigned long long)fr);
-        atomicAdd(lv.kernelSums + 3 * kind + 1, (unsigned long long)__popcll(m));
-        atomicAdd(lv.kernelSums + 3 * kind + 2, (unsigned long long)qp);
+      if (lv.kernelSums != nullptr && kind >= 0) {
+        atomicAdd(lv.kernelSums + 3 * kind + 0, acc[c][1]);
+        atomicAdd(lv.kernelSums + 3 * kind + 1, cntC);
+        atomicAdd(lv.kernelSums + 3 * kind + 2, acc[c][2]);
       }
     }
   }
