@@ -399,8 +399,14 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
     # threads while the device searches the next sub-block, then the path on all the intervals found
     ap = ctx.anchor_params(min_match_length=14, min_prefix_match_length=8)  # Blasr's values for a sawriter index
     ip = hip.interval_params(threads=min(64, os.cpu_count() or 1))
-    per_block = 6250 if os.environ.get("BLASR_HIP_INTERVALS_HOST") else 100000
-    pp = ctx.pipeline_params(reads_per_block=per_block, anchor=ap, interval=ip, map=params)
+    # BLASR_HIP_PIPE="reads per sub-block,overlap": the default is the serial form (anchor everything, then ONE call of the
+    # path); "25000,1" runs the path on sub-blocks of 25 000 reads beside the anchoring of the next one
+    # (blasr_hip_pipeline_params.overlap) -- same hits, and measured slower on one MI355X: 1312 against 1154 ms, the search
+    # and the path's kernels slow each other down by as much as they overlap (profiles/NOTES.md, round 5)
+    per_block, overlap = (int(v) for v in os.environ.get("BLASR_HIP_PIPE", "100000,0").split(","))
+    if os.environ.get("BLASR_HIP_INTERVALS_HOST"):
+        per_block, overlap = 6250, 0
+    pp = ctx.pipeline_params(reads_per_block=per_block, anchor=ap, interval=ip, map=params, overlap=overlap)
     hits = np.zeros(10 * n_reads, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(n_reads + 1, dtype=np.int64)
     stages = {}
@@ -418,6 +424,18 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
         last = dict(anchors=int(pt["anchors"]), intervals=int(len(ivs)), timing=ctx.map_last_timing(), ivs=ivs, iv_off=iv_off)
     wall = (time.perf_counter() - t_all) / steps
     n_blocks = -(-n_reads // per_block)
+    same_as_serial = None
+    if overlap and per_block < n_reads:
+        # the overlapped form against the serial one (every sub-block anchored, then ONE call of the path), untimed: every
+        # field of every hit but the three arena offsets, and the hits' places
+        hits2, off2 = np.zeros_like(hits), np.zeros_like(hit_off)
+        ps = ctx.pipeline_params(reads_per_block=n_reads, anchor=ap, interval=ip, map=params, overlap=0)
+        n2, _ = ctx.map_from_reads_device(genome_h, seq_starts, count_table, reads, wl["reads_t"].data_ptr(), pool_ptr, ps,
+                                          hits2, off2)
+        fields = [f for f in hits.dtype.names if f not in ("ops_off", "q_off", "t_off")]
+        same_as_serial = bool(n2 == n_hits and np.array_equal(off2, hit_off) and
+                              all(np.array_equal(hits[:n_hits][f], hits2[:n2][f]) for f in fields))
+        del hits2
     # how many reads have their true locus among the candidate intervals (the synthetic set-up knows it)
     true_iv = wl["intervals"][wl["kind"] == 0]
     found = 0
@@ -444,6 +462,8 @@ def end_to_end(ctx, genome_t, starts, wl, params, steps, dev):
         # the anchor stage on its own (blasr_hip_anchor_last_timing, last sub-block of the last pass): the suffix-array
         # search is what anchoring_ms is made of; `interval_finding_ms` (kernels + the host's end) is inside anchoring_ms
         "anchor_stage_ms": {k: round(float(v), 2) for k, v in ctx.anchor_last_timing().items() if k.endswith("_ms")},
+        "reads_per_sub_block": per_block, "overlap": bool(overlap and per_block < n_reads),
+        "hits_equal_the_serial_form": same_as_serial,
         "anchors_per_step": last["anchors"], "candidate_intervals": last["intervals"], "hits": int(tm["hits"]),
         "aligned_reads": int(tm["aligned_reads"]),
         "anchor_blocks": n_blocks,

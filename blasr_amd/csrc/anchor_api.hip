@@ -588,7 +588,70 @@ constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort c
 
 }  // namespace
 
+void blasr_hip_drop_index(blasr_hip_ctx *ctx) {
+  if (ctx->saOwned) {
+    if (ctx->saIndex) (void)hipFree(ctx->saIndex);
+    if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
+    if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
+    if (ctx->saExt) (void)hipFree(ctx->saExt);
+  }
+  ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
+  ctx->saExt = nullptr;
+  ctx->saExtGenome = ctx->saExtIndex = nullptr;
+  ctx->saOwned = true;
+  ctx->saLen = ctx->saTableLen = 0;
+  ctx->saPrefixLen = 0;
+}
+
+int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st) {
+  if (ctx->saExt && ctx->saExtGenome == ctx->genome && ctx->saExtIndex == ctx->saIndex) return BLASR_HIP_OK;
+  if (!ctx->saOwned)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: the borrowed index was not made for this context's genome");
+  if (ctx->saExt) (void)hipFree(ctx->saExt);
+  ctx->saExt = nullptr;
+  HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint16_t) * (size_t)ctx->saLen));
+  hipLaunchKernelGGL(anchor_ext_kernel, dim3((unsigned)((ctx->saLen + 255) / 256)), dim3(256), 0, st, ctx->genome,
+                     (uint32_t)ctx->genomeLen, ctx->saIndex, ctx->saLen, ctx->saPrefixLen, ctx->saExt);
+  ctx->saExtGenome = ctx->genome;
+  ctx->saExtIndex = ctx->saIndex;
+  return BLASR_HIP_OK;
+}
+
 extern "C" {
+
+int blasr_hip_borrow_index(blasr_hip_ctx *ctx, blasr_hip_ctx *from) try {
+  if (!ctx || !from || ctx == from) return ctx ? blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "borrow_index: bad arguments") : BLASR_HIP_ERR_INVALID;
+  if (ctx->device != from->device)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "borrow_index: the contexts are on devices %d and %d", ctx->device, from->device);
+  if (!from->genome || !from->saIndex || from->saLen != from->genomeLen)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "borrow_index: the other context holds no genome with its suffix array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!getenv("BLASR_HIP_ANCHOR_NO_EXT")) {  // made by the owner, so that both search the same array
+    const int rc = blasr_hip_ensure_index_ext(from, from->stream);
+    if (rc != BLASR_HIP_OK) return blasr_hip_fail(ctx, rc, "borrow_index: %s", from->lastError.c_str());
+    HIP_TRY(ctx, hipStreamSynchronize(from->stream));
+  }
+  std::vector<uint32_t> starts;
+  if (from->contigStarts && from->nContigs > 0) {
+    starts.resize((size_t)from->nContigs + 1);
+    HIP_TRY(ctx, hipMemcpy(starts.data(), from->contigStarts, sizeof(uint32_t) * starts.size(), hipMemcpyDeviceToHost));
+  }
+  const int rc = blasr_hip_adopt_genome_device(ctx, from->genome, from->genomeLen, starts.empty() ? nullptr : starts.data(),
+                                               starts.empty() ? 0 : from->nContigs);
+  if (rc != BLASR_HIP_OK) return rc;
+  blasr_hip_drop_index(ctx);
+  ctx->saIndex = from->saIndex;
+  ctx->saStartPos = from->saStartPos;
+  ctx->saEndPos = from->saEndPos;
+  ctx->saExt = from->saExt;
+  ctx->saExtGenome = from->saExt ? ctx->genome : nullptr;
+  ctx->saExtIndex = from->saExt ? ctx->saIndex : nullptr;
+  ctx->saLen = from->saLen;
+  ctx->saTableLen = from->saTableLen;
+  ctx->saPrefixLen = from->saPrefixLen;
+  ctx->saOwned = false;
+  return BLASR_HIP_OK;
+} BLASR_HIP_CATCH_CTX(ctx)
 
 int blasr_hip_anchor_default_params(blasr_hip_anchor_params *p) try {
   if (!p) return BLASR_HIP_ERR_INVALID;
@@ -615,13 +678,7 @@ int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int
        (!start_pos_table || !end_pos_table || lookup_table_length != (1ll << (2 * lookup_prefix_length)))))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "upload_suffix_array: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->saIndex) (void)hipFree(ctx->saIndex);
-  if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
-  if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
-  ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
-  ctx->saExtIndex = nullptr;  // (the companion array of the old index is stale)
-  ctx->saLen = ctx->saTableLen = 0;
-  ctx->saPrefixLen = 0;
+  blasr_hip_drop_index(ctx);
   HIP_TRY(ctx, hipMalloc(&ctx->saIndex, sizeof(uint32_t) * (size_t)length));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->saIndex, index, sizeof(uint32_t) * (size_t)length, hipMemcpyHostToDevice,
                               ctx->stream));
@@ -719,14 +776,9 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
 
   // the companion array of the index, made once per (genome, index) pair
   const bool useExt = !getenv("BLASR_HIP_ANCHOR_NO_EXT");
-  if (useExt && (!ctx->saExt || ctx->saExtGenome != ctx->genome || ctx->saExtIndex != ctx->saIndex)) {
-    if (ctx->saExt) (void)hipFree(ctx->saExt);
-    ctx->saExt = nullptr;
-    HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint16_t) * (size_t)ctx->saLen));
-    hipLaunchKernelGGL(anchor_ext_kernel, dim3((unsigned)((ctx->saLen + 255) / 256)), dim3(256), 0, st, ctx->genome,
-                       (uint32_t)ctx->genomeLen, ctx->saIndex, ctx->saLen, ctx->saPrefixLen, ctx->saExt);
-    ctx->saExtGenome = ctx->genome;
-    ctx->saExtIndex = ctx->saIndex;
+  if (useExt) {
+    const int rc = blasr_hip_ensure_index_ext(ctx, st);
+    if (rc != BLASR_HIP_OK) return rc;
   }
   {  // pinned results: one int64 per list boundary of the largest piece (never more than all lists)
     const size_t want = sizeof(int64_t) * ((size_t)nLists + 2);

@@ -218,15 +218,14 @@ int blasr_hip_destroy(blasr_hip_ctx *ctx) try {
     if (b.p) (void)hipFree(b.p);
   for (auto &b : ctx->mapHost)
     if (b.p) (void)hipHostFree(b.p);
-  if (ctx->saIndex) (void)hipFree(ctx->saIndex);
-  if (ctx->saExt) (void)hipFree(ctx->saExt);
+  if (ctx->pipeHelper) (void)blasr_hip_destroy(ctx->pipeHelper);  // (it borrows this context's genome and index)
+  ctx->pipeHelper = nullptr;
+  blasr_hip_drop_index(ctx);
   if (ctx->anchorPinned) (void)hipHostFree(ctx->anchorPinned);
   if (ctx->pipePinned) (void)hipHostFree(ctx->pipePinned);
   if (ctx->pipeAnchors.p) (void)hipFree(ctx->pipeAnchors.p);
   if (ctx->pipeIntervals.p) (void)hipFree(ctx->pipeIntervals.p);
   if (ctx->anchorFlags) (void)hipFree(ctx->anchorFlags);
-  if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
-  if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
   delete ctx;
   return BLASR_HIP_OK;
 } BLASR_HIP_CATCH_CTX(ctx)
@@ -246,7 +245,8 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) try {
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
   for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
   total += (int64_t)ctx->pipeAnchors.bytes + (int64_t)ctx->pipeIntervals.bytes;
-  total += (ctx->saExt ? 6 : 4) * ctx->saLen + 8 * ctx->saTableLen;
+  if (ctx->saOwned) total += (ctx->saExt ? 6 : 4) * ctx->saLen + 8 * ctx->saTableLen;
+  if (ctx->pipeHelper) total += blasr_hip_held_bytes(ctx->pipeHelper);
   return total;
 } BLASR_HIP_CATCH_CODE
 

@@ -70,6 +70,7 @@ struct blasr_hip_ctx {
   int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
   // the resident suffix array of the genome (blasr_hip_upload_suffix_array): index, the lookup table's ranges
   uint32_t *saIndex = nullptr, *saStartPos = nullptr, *saEndPos = nullptr;
+  bool saOwned = true;  // false: index, lookup table and companion array belong to another context (blasr_hip_borrow_index)
   int64_t saLen = 0, saTableLen = 0;
   int saPrefixLen = 0;
   // per array position, the bases that follow the lookup prefix (anchor_api.hip: the search reads them instead of
@@ -87,6 +88,9 @@ struct blasr_hip_ctx {
   DevBuf pipeAnchors, pipeIntervals;
   void *pipePinned = nullptr;
   size_t pipePinnedBytes = 0;
+  // the overlapped form of that driver: a second context on the same device (own streams, workspace and anchor
+  // buffers; genome and index borrowed) on which a host thread anchors sub-block b + 1 while this one runs the path on b
+  blasr_hip_ctx *pipeHelper = nullptr;
   float pipeMs[4] = {0, 0, 0, 0};
   int64_t pipeCounters[2] = {0, 0};
   enum { kAnchorBufs = 4 };
@@ -126,6 +130,11 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
                                       int64_t *n_intervals, int64_t *read_interval_off, int64_t *cluster_of_interval = nullptr);
 
 int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
+
+// index array, lookup table and companion array of the context: freed when they are its own, forgotten either way
+void blasr_hip_drop_index(blasr_hip_ctx *ctx);
+// the companion array of the resident index (anchor_api.hip), made once per (genome, index) pair
+int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st);
 
 // A host array of the mapper that receives device data: a view of one of the context's pinned, grow-only buffers
 // (ctx.h: mapHost).  Not initialised: every element is written by the copy that fills it.

@@ -38,6 +38,90 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// what every sub-block of a call shares
+struct PipeCall {
+  const uint8_t *genomeHost;
+  const uint32_t *seqStartPos;
+  int32_t nSeqPos;
+  const int32_t *countTable;
+  int32_t countTupleSize;
+  const blasr_hip_read *readsHost;
+  const uint8_t *readPoolDevice;
+  const blasr_hip_anchor_params *anchor;
+  const blasr_hip_interval_params *interval;
+  bool wantChains;
+};
+
+// a sub-block's candidate intervals (read indices relative to the sub-block) and, for -rbao, their chains
+struct BlockOut {
+  std::vector<blasr_hip_interval> ivs;
+  std::vector<uint32_t> chains;    // (t, q, l) triplets, back to back
+  std::vector<int64_t> chainOff;   // one entry per interval, + 1
+  std::vector<int64_t> listOff, ivOff;
+  int64_t anchors = 0;
+  double ivMs = 0;                 // the interval finding (kernels + the host's end)
+};
+
+// MapReadToGenome x 2 + SortMatchPosList, then the interval finder, for reads [first, first + count) on context c: the
+// anchors stay in c's buffer, the intervals come back
+int anchor_block(blasr_hip_ctx *c, const PipeCall &k, int32_t first, int32_t count, BlockOut &o) {
+  o.listOff.assign(2 * (size_t)count + 1, 0);
+  int64_t blockBases = 0;
+  for (int32_t r = first; r < first + count; r++) blockBases += k.readsHost[r].length;
+  int64_t expect = 2 * blockBases + 4096, n = 0;
+  int rcA = BLASR_HIP_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rcA = blasr_hip_ensure(c, c->pipeAnchors, sizeof(blasr_hip_anchor) * (size_t)expect)) != BLASR_HIP_OK) return rcA;
+    rcA = blasr_hip_anchor_reads_device(c, count, k.readsHost + first, k.readPoolDevice, k.anchor,
+                                        (blasr_hip_anchor *)c->pipeAnchors.p,
+                                        (int64_t)(c->pipeAnchors.bytes / sizeof(blasr_hip_anchor)), &n, o.listOff.data());
+    if (rcA != BLASR_HIP_ERR_CAPACITY) break;
+    expect = n + n / 8 + 1;  // (the count a short call returns)
+  }
+  if (rcA != BLASR_HIP_OK) return rcA;
+  o.anchors = n;
+  const double h0 = now_ms();
+  o.ivs.resize((size_t)count * (size_t)std::max(k.interval->n_candidates, 1) + 1);
+  o.ivOff.assign((size_t)count + 1, 0);
+  o.chains.clear();
+  o.chainOff.clear();
+  int64_t nIv = 0;
+  int rcI;
+  if (k.wantChains) {
+    int64_t chainsUsed = 0;
+    o.chains.resize(3 * (size_t)std::max<int64_t>(n, 1));  // (grown below when ten intervals of a read share anchors)
+    o.chainOff.assign(o.ivs.size() + 1, 0);
+    for (int attempt = 0; attempt < 2; attempt++) {
+      rcI = blasr_hip_find_intervals_device_chains(c, k.genomeHost, c->genomeLen, k.seqStartPos, k.nSeqPos, k.countTable,
+                                                   k.countTupleSize, count, k.readsHost + first,
+                                                   (const blasr_hip_anchor *)c->pipeAnchors.p, o.listOff.data(), k.interval,
+                                                   o.ivs.data(), nullptr, (int64_t)o.ivs.size(), &nIv, o.ivOff.data(),
+                                                   o.chains.data(), (int64_t)(o.chains.size() / 3), &chainsUsed,
+                                                   o.chainOff.data());
+      if (rcI != BLASR_HIP_ERR_CAPACITY || nIv > (int64_t)o.ivs.size()) break;
+      o.chains.resize(3 * (size_t)chainsUsed);
+    }
+    if (rcI == BLASR_HIP_OK) {
+      o.chains.resize(3 * (size_t)chainsUsed);
+      o.chainOff.resize((size_t)nIv + 1);
+    }
+  } else {
+    rcI = blasr_hip_find_intervals_device(c, k.genomeHost, c->genomeLen, k.seqStartPos, k.nSeqPos, k.countTable,
+                                          k.countTupleSize, count, k.readsHost + first,
+                                          (const blasr_hip_anchor *)c->pipeAnchors.p, o.listOff.data(), k.interval,
+                                          o.ivs.data(), nullptr, (int64_t)o.ivs.size(), &nIv, o.ivOff.data());
+  }
+  if (rcI != BLASR_HIP_OK) return rcI;
+  o.ivs.resize((size_t)nIv);
+  o.ivMs = now_ms() - h0;
+  return BLASR_HIP_OK;
+}
+
+int map_from_reads_overlapped(blasr_hip_ctx *ctx, const PipeCall &call, int32_t perBlock, int32_t n_reads,
+                              const blasr_hip_read *reads_device, const blasr_hip_map_params &map, blasr_hip_hit *hits,
+                              int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch,
+                              blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals);
+
 }  // namespace
 
 extern "C" {
@@ -48,7 +132,7 @@ int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *p) try {
   blasr_hip_interval_default_params(&p->interval);
   blasr_hip_map_default_params(&p->map);
   p->reads_per_block = 100000;  // (round 2: 6250, sized for the host's interval finding to keep up with the device)
-  p->reserved = 0;
+  p->overlap = 0;
   return BLASR_HIP_OK;
 } BLASR_HIP_CATCH_CODE
 
@@ -83,65 +167,32 @@ int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_ho
   // -rbao reads the intervals' chained anchors: both interval finders hand them out on request
   const bool wantChains = params->map.refine_between_anchors_only != 0;
   if (!getenv("BLASR_HIP_INTERVALS_HOST")) {
+    PipeCall call{genome_host, seq_start_pos, n_seq_pos, count_table, count_tuple_size, reads_host, read_pool_device, &ap,
+                  &params->interval, wantChains};
+    if (params->overlap != 0 && n_reads > perBlock && !getenv("BLASR_HIP_PIPE_SERIAL"))
+      return map_from_reads_overlapped(ctx, call, perBlock, n_reads, reads_device, params->map, hits, hits_capacity, n_hits,
+                                       read_hit_off, fetch, intervals_out, intervals_capacity, n_intervals);
     // ---- anchors and intervals of every sub-block on the device; the anchor buffer is the same for all of them
     std::vector<blasr_hip_interval> ivs;
-    std::vector<int64_t> listOff, ivOff;
-    std::vector<blasr_hip_interval> blockIvs;
-    std::vector<uint32_t> allChains, blockChains;     // (t, q, l) triplets of the intervals' chains, back to back
-    std::vector<int64_t> allChainOff, blockChainOff;  // one entry per interval, + 1
+    std::vector<uint32_t> allChains;     // (t, q, l) triplets of the intervals' chains, back to back
+    std::vector<int64_t> allChainOff;    // one entry per interval, + 1
+    BlockOut blk;
     int64_t anchorsInAll = 0;
     double ivMs = 0;
     for (int32_t first = 0; first < n_reads; first += perBlock) {
       const int32_t count = std::min(perBlock, n_reads - first);
-      listOff.assign(2 * (size_t)count + 1, 0);
-      int64_t blockBases = 0;
-      for (int32_t r = first; r < first + count; r++) blockBases += reads_host[r].length;
-      int64_t expect = 2 * blockBases + 4096, n = 0;
-      int rcA = BLASR_HIP_OK;
-      for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rcA = blasr_hip_ensure(ctx, ctx->pipeAnchors, sizeof(blasr_hip_anchor) * (size_t)expect)) != BLASR_HIP_OK) return rcA;
-        rcA = blasr_hip_anchor_reads_device(ctx, count, reads_host + first, read_pool_device, &ap, (blasr_hip_anchor *)ctx->pipeAnchors.p,
-                                            (int64_t)(ctx->pipeAnchors.bytes / sizeof(blasr_hip_anchor)), &n, listOff.data());
-        if (rcA != BLASR_HIP_ERR_CAPACITY) break;
-        expect = n + n / 8 + 1;  // (the count a short call returns)
-      }
-      if (rcA != BLASR_HIP_OK) return rcA;
-      anchorsInAll += n;
-      const double h0 = now_ms();
-      blockIvs.resize((size_t)count * (size_t)std::max(params->interval.n_candidates, 1) + 1);
-      ivOff.assign((size_t)count + 1, 0);
-      int64_t nIv = 0;
-      int rcI;
+      const int rcB = anchor_block(ctx, call, first, count, blk);
+      if (rcB != BLASR_HIP_OK) return rcB;
+      anchorsInAll += blk.anchors;
+      ivMs += blk.ivMs;
       if (wantChains) {
-        int64_t chainsUsed = 0;
-        blockChains.resize(3 * (size_t)std::max<int64_t>(n, 1));  // (grown below when ten intervals of a read share anchors)
-        blockChainOff.assign(blockIvs.size() + 1, 0);
-        for (int attempt = 0; attempt < 2; attempt++) {
-          rcI = blasr_hip_find_intervals_device_chains(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
-                                                       count_tuple_size, count, reads_host + first,
-                                                       (const blasr_hip_anchor *)ctx->pipeAnchors.p, listOff.data(), &params->interval,
-                                                       blockIvs.data(), nullptr, (int64_t)blockIvs.size(), &nIv, ivOff.data(),
-                                                       blockChains.data(), (int64_t)(blockChains.size() / 3), &chainsUsed,
-                                                       blockChainOff.data());
-          if (rcI != BLASR_HIP_ERR_CAPACITY || nIv > (int64_t)blockIvs.size()) break;
-          blockChains.resize(3 * (size_t)chainsUsed);
-        }
-        if (rcI == BLASR_HIP_OK) {
-          const int64_t shift = (int64_t)(allChains.size() / 3);
-          for (int64_t i = 0; i < nIv; i++) allChainOff.push_back(shift + blockChainOff[(size_t)i]);
-          allChains.insert(allChains.end(), blockChains.begin(), blockChains.begin() + 3 * chainsUsed);
-        }
-      } else {
-        rcI = blasr_hip_find_intervals_device(ctx, genome_host, ctx->genomeLen, seq_start_pos, n_seq_pos, count_table,
-                                              count_tuple_size, count, reads_host + first, (const blasr_hip_anchor *)ctx->pipeAnchors.p,
-                                              listOff.data(), &params->interval, blockIvs.data(), nullptr,
-                                              (int64_t)blockIvs.size(), &nIv, ivOff.data());
+        const int64_t shift = (int64_t)(allChains.size() / 3);
+        for (size_t i = 0; i < blk.ivs.size(); i++) allChainOff.push_back(shift + blk.chainOff[i]);
+        allChains.insert(allChains.end(), blk.chains.begin(), blk.chains.end());
       }
-      if (rcI != BLASR_HIP_OK) return rcI;
-      ivMs += now_ms() - h0;
-      for (int64_t i = 0; i < nIv; i++) {
-        blockIvs[(size_t)i].read += first;
-        ivs.push_back(blockIvs[(size_t)i]);
+      for (auto iv : blk.ivs) {
+        iv.read += first;
+        ivs.push_back(iv);
       }
     }
     const double t1 = now_ms();
@@ -447,3 +498,210 @@ int blasr_hip_map_from_reads_host(blasr_hip_ctx *ctx, const uint8_t *genome_host
 } BLASR_HIP_CATCH_CTX(ctx)
 
 }  // extern "C"
+
+namespace {
+
+// The overlapped form (blasr_hip_pipeline_params.overlap): a host thread anchors the sub-blocks one after the other on
+// the helper context -- its own streams, workspace and anchor buffers; the genome and the index are the caller's -- and
+// this thread runs the path on sub-block b as soon as its intervals are there, while the helper is already searching for
+// sub-block b + 1.  The search waits for random sectors of HBM most of the time and the path's kernels for their own
+// instructions, so the device takes less for the two side by side than for one after the other.  MapRead is a function
+// of one read (alignment/Blasr.cpp:2247-2644): the hits are those of the serial form, in its order.
+int map_from_reads_overlapped(blasr_hip_ctx *ctx, const PipeCall &call, int32_t perBlock, int32_t n_reads,
+                              const blasr_hip_read *reads_device, const blasr_hip_map_params &map, blasr_hip_hit *hits,
+                              int64_t hits_capacity, int64_t *n_hits, int64_t *read_hit_off, blasr_hip_map_fetch *fetch,
+                              blasr_hip_interval *intervals_out, int64_t intervals_capacity, int64_t *n_intervals) {
+  const double t0 = now_ms();
+  // ---- the helper context
+  blasr_hip_ctx *h = ctx->pipeHelper;
+  if (!h) {
+    const int rc = blasr_hip_create(ctx->device, &h);
+    if (rc != BLASR_HIP_OK) return blasr_hip_fail(ctx, rc, "map_from_reads: no helper context");
+    ctx->pipeHelper = h;
+    // (full-size pieces of the search need 12 GB of workspace: anchor_api.hip's pieceLimit)
+    h->workspaceLimit = std::min<int64_t>(ctx->workspaceLimit, 16ll << 30);
+  }
+  const bool wantExt = !getenv("BLASR_HIP_ANCHOR_NO_EXT");
+  if (h->genome != ctx->genome || h->genomeLen != ctx->genomeLen || h->saIndex != ctx->saIndex ||
+      h->saStartPos != ctx->saStartPos || h->saLen != ctx->saLen || h->saPrefixLen != ctx->saPrefixLen ||
+      (wantExt && (!h->saExt || h->saExt != ctx->saExt))) {
+    const int rc = blasr_hip_borrow_index(h, ctx);
+    if (rc != BLASR_HIP_OK) return blasr_hip_fail(ctx, rc, "map_from_reads: %s", h->lastError.c_str());
+  }
+
+  const int nBlocks = (n_reads + perBlock - 1) / perBlock;
+  std::vector<BlockOut> blocks((size_t)nBlocks);
+  std::vector<int> state((size_t)nBlocks, 0);  // 0 not yet, 1 ready, < 0 the anchoring's error code
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false;
+  double anchorBusyMs = 0, ivMs = 0;
+  float anchorMs[4] = {0, 0, 0, 0};
+  int64_t anchorCounters[4] = {0, 0, 0, 0};
+  std::thread helper([&]() {
+    int rc = hipSetDevice(h->device) == hipSuccess ? BLASR_HIP_OK : BLASR_HIP_ERR_HIP;
+    for (int b = 0; b < nBlocks; b++) {
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        if (stop) rc = BLASR_HIP_ERR_INTERNAL;
+      }
+      if (rc == BLASR_HIP_OK) {
+        const double a0 = now_ms();
+        const int32_t first = b * perBlock;
+        try {
+          rc = anchor_block(h, call, first, std::min(perBlock, n_reads - first), blocks[(size_t)b]);
+        } catch (const std::bad_alloc &) {
+          rc = BLASR_HIP_ERR_NOMEM;
+        } catch (...) {
+          rc = BLASR_HIP_ERR_INTERNAL;
+        }
+        anchorBusyMs += now_ms() - a0;
+        ivMs += blocks[(size_t)b].ivMs;
+        for (int i = 0; i < 4; i++) {
+          anchorMs[i] += h->anchorMs[i];
+          anchorCounters[i] += h->anchorCounters[i];
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        state[(size_t)b] = rc == BLASR_HIP_OK ? 1 : rc;
+      }
+      cv.notify_all();
+    }
+  });
+  struct JoinOnExit {  // nothing may leave this function with the helper still running
+    std::thread &t;
+    std::mutex &mu;
+    bool &stop;
+    ~JoinOnExit() {
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        stop = true;
+      }
+      if (t.joinable()) t.join();
+    }
+  } joinOnExit{helper, mu, stop};
+
+  // ---- the path, sub-block by sub-block
+  int rc = BLASR_HIP_OK;
+  bool hitsShort = false, fetchShort = false;
+  int64_t hitsUsed = 0, ivsUsed = 0, seqUsed = 0, opsUsed = 0;
+  double waitMs = 0, pathMs = 0;
+  float mapMs[6] = {0, 0, 0, 0, 0, 0};
+  int64_t mapCounters[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nBlocks && rc == BLASR_HIP_OK; b++) {
+    const double w0 = now_ms();
+    int st;
+    {
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&]() { return state[(size_t)b] != 0; });
+      st = state[(size_t)b];
+    }
+    const double w1 = now_ms();
+    waitMs += w1 - w0;
+    if (st < 0) {
+      rc = blasr_hip_fail(ctx, st, "map_from_reads: sub-block %d: %s", b, h->lastError.c_str());
+      break;
+    }
+    BlockOut &o = blocks[(size_t)b];
+    const int32_t first = b * perBlock, count = std::min(perBlock, n_reads - first);
+    const int64_t nIv = (int64_t)o.ivs.size();
+    if ((rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(nIv + 1))) != BLASR_HIP_OK) break;
+    HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, o.ivs.data(), sizeof(blasr_hip_interval) * (size_t)nIv, hipMemcpyHostToDevice));
+    blasr_hip_map_params mapParams = map;
+    if (call.wantChains) {
+      mapParams.iv_chains = o.chains.data();
+      mapParams.iv_chain_off = o.chainOff.data();
+    }
+    blasr_hip_map_fetch sub = {nullptr, 0, 0, nullptr, 0, 0};
+    if (fetch) {
+      sub.seq = fetch->seq ? fetch->seq + std::min(seqUsed, fetch->seq_capacity) : nullptr;
+      sub.seq_capacity = std::max<int64_t>(fetch->seq_capacity - seqUsed, 0);
+      sub.ops = fetch->ops ? fetch->ops + std::min(opsUsed, fetch->ops_capacity) : nullptr;
+      sub.ops_capacity = std::max<int64_t>(fetch->ops_capacity - opsUsed, 0);
+    }
+    const int64_t room = std::max<int64_t>(hits_capacity - hitsUsed, 0);
+    int64_t nh = 0;
+    int rcM = blasr_hip_map_reads_device(ctx, count, reads_device + first, call.readPoolDevice, (int32_t)nIv,
+                                         (const blasr_hip_interval *)ctx->pipeIntervals.p, &mapParams,
+                                         hits ? hits + std::min(hitsUsed, hits_capacity) : nullptr, room, &nh,
+                                         read_hit_off ? read_hit_off + first : nullptr, fetch ? &sub : nullptr);
+    if (rcM == BLASR_HIP_ERR_CAPACITY) {  // the counts are valid: go on, so that the caller learns what the whole call needs
+      if (nh > room) hitsShort = true;
+      else fetchShort = true;
+      rcM = BLASR_HIP_OK;
+    }
+    if (rcM != BLASR_HIP_OK) {
+      rc = rcM;
+      break;
+    }
+    const int64_t got = std::min(nh, room);
+    for (int64_t i = 0; i < got; i++) {
+      blasr_hip_hit &x = hits[hitsUsed + i];
+      x.read += first;
+      x.interval += (int32_t)ivsUsed;
+      if (fetch) {
+        x.ops_off += opsUsed;
+        x.q_off += seqUsed;
+        x.t_off += seqUsed;
+      }
+    }
+    if (read_hit_off)
+      for (int32_t r = 0; r <= count; r++) read_hit_off[first + r] += hitsUsed;
+    if (intervals_out)
+      for (int64_t i = 0; i < nIv && ivsUsed + i < intervals_capacity; i++) {
+        intervals_out[ivsUsed + i] = o.ivs[(size_t)i];
+        intervals_out[ivsUsed + i].read += first;
+      }
+    hitsUsed += nh;
+    ivsUsed += nIv;
+    if (fetch) {
+      seqUsed += sub.seq_used;
+      opsUsed += sub.ops_used;
+    }
+    for (int i = 0; i < 6; i++) {
+      mapMs[i] += ctx->mapMs[i];
+      mapCounters[i] += ctx->mapCounters[i];
+    }
+    BlockOut().ivs.swap(o.ivs);  // (a sub-block's lists are not needed again)
+    std::vector<uint32_t>().swap(o.chains);
+    pathMs += now_ms() - w1;
+  }
+  if (rc != BLASR_HIP_OK) return rc;  // (joinOnExit stops the helper)
+  helper.join();
+  *n_hits = hitsUsed;
+  if (n_intervals) *n_intervals = ivsUsed;
+  if (fetch) {
+    fetch->seq_used = seqUsed;
+    fetch->ops_used = opsUsed;
+  }
+  int64_t anchorsInAll = 0;
+  for (auto &o : blocks) anchorsInAll += o.anchors;
+  for (int i = 0; i < 6; i++) {
+    ctx->mapMs[i] = mapMs[i];
+    ctx->mapCounters[i] = mapCounters[i];
+  }
+  for (int i = 0; i < 4; i++) {
+    ctx->anchorMs[i] = anchorMs[i];
+    ctx->anchorCounters[i] = anchorCounters[i];
+  }
+  ctx->pipeMs[0] = (float)anchorBusyMs;  // the helper's time in anchoring + interval finding (under the path, except [1])
+  ctx->pipeMs[1] = (float)waitMs;        // this thread waiting for a sub-block's intervals
+  ctx->pipeMs[2] = (float)pathMs;        // the path's calls
+  ctx->pipeMs[3] = (float)ivMs;          // of [0]: the interval finding
+  ctx->pipeCounters[0] = anchorsInAll;
+  ctx->pipeCounters[1] = ivsUsed;
+  (void)t0;
+  if (hitsShort)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: %lld hits, capacity %lld", (long long)hitsUsed,
+                          (long long)hits_capacity);
+  if (fetchShort)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: the fetch arenas need %lld bytes and %lld ops",
+                          (long long)seqUsed, (long long)opsUsed);
+  if (intervals_out && ivsUsed > intervals_capacity)
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_CAPACITY, "map_from_reads: %lld intervals, capacity %lld", (long long)ivsUsed,
+                          (long long)intervals_capacity);
+  return BLASR_HIP_OK;
+}
+
+}  // namespace

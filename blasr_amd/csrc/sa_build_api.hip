@@ -188,13 +188,7 @@ int blasr_hip_build_suffix_array(blasr_hip_ctx *ctx, int32_t lookup_prefix_lengt
   }
 
   // ---- install: the index array stays resident for the anchor stage
-  if (ctx->saIndex) (void)hipFree(ctx->saIndex);
-  if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
-  if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
-  ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
-  ctx->saExtIndex = nullptr;  // (the companion array of the old index is stale)
-  ctx->saLen = ctx->saTableLen = 0;
-  ctx->saPrefixLen = 0;
+  blasr_hip_drop_index(ctx);
   HIP_TRY(ctx, hipMalloc(&ctx->saIndex, 4 * (size_t)n));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->saIndex, sa.current(), 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
   ctx->saLen = n;

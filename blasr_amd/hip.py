@@ -43,7 +43,7 @@ EXPORTS = [
     "blasr_hip_fasta_record", "blasr_hip_fasta_name", "blasr_hip_fasta_concatenate",
     "blasr_hip_fastq_read", "blasr_hip_fastq_parse", "blasr_hip_fastq_quality", "blasr_hip_fasta_error",
     "blasr_hip_sa_read", "blasr_hip_sa_free", "blasr_hip_sa_arrays",
-    "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_anchor_reads_device",
+    "blasr_hip_anchor_default_params", "blasr_hip_upload_suffix_array", "blasr_hip_borrow_index", "blasr_hip_anchor_reads_device",
     "blasr_hip_anchor_reads_host", "blasr_hip_anchor_last_timing",
     "blasr_hip_interval_default_params", "blasr_hip_count_tuples", "blasr_hip_find_intervals",
     "blasr_hip_build_suffix_array", "blasr_hip_sa_write", "blasr_hip_ctab_write", "blasr_hip_ctab_read",
@@ -231,7 +231,7 @@ class _IntervalParams(C.Structure):
 
 class _PipelineParams(C.Structure):
     _fields_ = [("anchor", _AnchorParams), ("interval", _IntervalParams), ("map", _MapParams),
-                ("reads_per_block", C.c_int32), ("reserved", C.c_int32)]
+                ("reads_per_block", C.c_int32), ("overlap", C.c_int32)]
 
 
 # blasr_hip_anchor: MatchPos t, q, l
@@ -993,6 +993,12 @@ class Context:
         return used.value
 
     # --- next-1, device half: MapReadToGenome over the suffix array (MapBySuffixArray.h:217-311) ---
+    def borrow_index(self, other):
+        """blasr_hip_borrow_index: anchor in the genome and the suffix array `other` (a Context on the same device) holds."""
+        self.lib.blasr_hip_borrow_index.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.lib.blasr_hip_borrow_index(self.handle, other.handle))
+        self._index_owner = other  # (keeps it alive)
+
     def upload_suffix_array(self, sa):
         """sa: what read_suffix_array returns (index, start_pos_table, end_pos_table, lookup_prefix_length)."""
         idx = np.ascontiguousarray(sa["index"], dtype=np.uint32)
@@ -1030,7 +1036,7 @@ class Context:
         self._check(self.lib.blasr_hip_count_tuples_device(self.handle, tuple_size, table.ctypes.data))
         return table
 
-    def pipeline_params(self, reads_per_block=None, anchor=None, interval=None, map=None):
+    def pipeline_params(self, reads_per_block=None, anchor=None, interval=None, map=None, overlap=0):
         p = _PipelineParams()
         self.lib.blasr_hip_pipeline_default_params.argtypes = [C.POINTER(_PipelineParams)]
         self.lib.blasr_hip_pipeline_default_params(C.byref(p))
@@ -1042,14 +1048,16 @@ class Context:
             p.map = map
         if reads_per_block:
             p.reads_per_block = int(reads_per_block)
+        p.overlap = int(overlap)
         return p
 
     def map_from_reads_device(self, genome_host, seq_start_pos, count_table, reads, reads_ptr, read_pool_ptr, params, hits,
-                              read_hit_off=None, intervals_capacity=0):
+                              read_hit_off=None, intervals_capacity=0, fetch_capacity=0):
         """blasr_hip_map_from_reads_device: anchoring in sub-blocks overlapped with the host's interval finding, then the
         path.  genome_host / seq_start_pos / count_table: host arrays (the interval finder's); reads: host READ_DTYPE
         array, reads_ptr / read_pool_ptr: the same table and the pool on the device; hits: HIT_DTYPE host array to fill.
-        Returns (number of hits, intervals INTERVAL_DTYPE array or None)."""
+        Returns (number of hits, intervals INTERVAL_DTYPE array or None); with fetch_capacity (bytes of sequence = number of
+        ops) also the two host arenas the hits' q_off / t_off / ops_off index."""
         genome_host = np.ascontiguousarray(genome_host, dtype=np.uint8)
         starts = np.ascontiguousarray(seq_start_pos, dtype=np.uint32)
         table = np.ascontiguousarray(count_table, dtype=np.int32)
@@ -1061,10 +1069,17 @@ class Context:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                       C.c_void_p, C.c_void_p, C.POINTER(_PipelineParams), C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        fetch = None
+        if fetch_capacity:
+            seq, ops = np.zeros(fetch_capacity, np.uint8), np.zeros(fetch_capacity, np.uint32)
+            fetch = _MapFetch(seq.ctypes.data, fetch_capacity, 0, ops.ctypes.data, fetch_capacity, 0)
         self._check(f(self.handle, genome_host.ctypes.data, starts.ctypes.data, len(starts), table.ctypes.data, k, len(reads),
                       reads.ctypes.data, C.c_void_p(reads_ptr), C.c_void_p(read_pool_ptr), C.byref(params), hits.ctypes.data,
-                      len(hits), C.byref(n_hits), read_hit_off.ctypes.data if read_hit_off is not None else None, None,
+                      len(hits), C.byref(n_hits), read_hit_off.ctypes.data if read_hit_off is not None else None,
+                      C.byref(fetch) if fetch is not None else None,
                       ivs.ctypes.data if ivs is not None else None, intervals_capacity, C.byref(n_iv)))
+        if fetch is not None:
+            return n_hits.value, (ivs[: n_iv.value] if ivs is not None else None), seq[: fetch.seq_used], ops[: fetch.ops_used]
         return n_hits.value, (ivs[: n_iv.value] if ivs is not None else None)
 
     def pipeline_last_timing(self):

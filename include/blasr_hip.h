@@ -46,7 +46,8 @@ extern "C" {
  * take bands of any width and report TASK_EMPTY_GUIDE for an empty candidate. */
 /* 5: blasr_hip_sdp_last_kernels / blasr_hip_sdp_kernel_name (every heavy SDP kernel timed on the stream it ran on); no
  * struct of version 4 changed. */
-#define BLASR_HIP_ABI_VERSION 5
+/* 6: blasr_hip_borrow_index; blasr_hip_pipeline_params' reserved word became `overlap` (0 keeps version 5's behaviour). */
+#define BLASR_HIP_ABI_VERSION 6
 
 typedef struct blasr_hip_ctx blasr_hip_ctx;
 
@@ -898,6 +899,12 @@ int blasr_hip_anchor_default_params(blasr_hip_anchor_params *params);
 int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int64_t length,
                                   const uint32_t *start_pos_table, const uint32_t *end_pos_table,
                                   int64_t lookup_table_length, int32_t lookup_prefix_length);
+/* A second context on the same device that anchors in the genome and the index `from` holds, without a copy of either
+ * (one context per mapping thread next to its MappingBuffers, alignment/Blasr.cpp:3238, all reading the one SuffixArray
+ * of main(), :4360-4440): genome, contig table, index array, lookup table and the search's companion array are shared,
+ * streams, workspace and result buffers are the context's own.  `from` must outlive the borrower or the borrower must
+ * borrow again after `from` has uploaded / built another index. */
+int blasr_hip_borrow_index(blasr_hip_ctx *ctx, blasr_hip_ctx *from);
 /* reads: HOST table; read_pool: device (forward strands, ASCII); anchors: device, at most capacity records;
  * *n_anchors receives the number needed (BLASR_HIP_ERR_CAPACITY when it exceeds capacity; nothing is valid then).
  * list_off (host, 2 * n_reads + 1 entries): list 2r is read r's matchPosList, list 2r+1 its rcMatchPosList (q on the
@@ -1032,7 +1039,11 @@ typedef struct blasr_hip_pipeline_params {
   blasr_hip_interval_params interval;
   blasr_hip_map_params map;
   int32_t reads_per_block;             /* 100000 */
-  int32_t reserved;
+  /* 0: every sub-block is anchored, then the path runs once on all the intervals found.  1: the path runs sub-block by
+   * sub-block while a host thread anchors the next one on a helper context of the same device (the search is bound by
+   * the latency of random sectors, the path by its instructions: side by side they take less than one after the other).
+   * Same hits in the same order; without fetch arenas blasr_hip_map_device_arenas then holds the LAST sub-block only. */
+  int32_t overlap;
 } blasr_hip_pipeline_params;
 int blasr_hip_pipeline_default_params(blasr_hip_pipeline_params *params);
 int blasr_hip_map_from_reads_device(blasr_hip_ctx *ctx, const uint8_t *genome_host, const uint32_t *seq_start_pos,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(hip.EXPORTS) == names
-    assert lib.blasr_hip_abi_version() == 5
+    assert lib.blasr_hip_abi_version() == 6
 
 
 def test_result_record_layout_matches_header():

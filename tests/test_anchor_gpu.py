@@ -190,3 +190,33 @@ def test_anchor_edges():
     with pytest.raises(hip.BlasrHipError):
         ctx.anchor_reads(wrong, pool, p)
     ctx.close()
+
+
+def test_a_second_context_anchors_in_a_borrowed_index():
+    """blasr_hip_borrow_index: a context with its own streams and buffers that searches the genome and the suffix array
+    another context of the same device holds -- the golden lists again, from both contexts, and the refusals."""
+    z, sa = golden_case()
+    genome, reads, pool = z["genome"], z["reads"], z["pool"]
+    owner = blasr_amd.Context(0)
+    owner.upload_genome(genome)
+    owner.upload_suffix_array(sa)
+    other = blasr_amd.Context(0)
+    with pytest.raises(hip.BlasrHipError):  # nothing to anchor in yet
+        other.anchor_reads(reads, pool)
+    other.borrow_index(owner)
+    held = other.held_bytes()
+    assert held < len(genome)  # (neither the genome nor the 4 bytes per base of the index are counted twice)
+    p = owner.anchor_params(min_match_length=12)
+    a0, off0 = owner.anchor_reads(reads, pool, p)
+    a1, off1 = other.anchor_reads(reads, pool, p)
+    assert len(a0) > 1000 and np.array_equal(off0, off1) and np.array_equal(as_triples(a0), as_triples(a1))
+    with pytest.raises(hip.BlasrHipError):
+        other.borrow_index(other)
+    empty = blasr_amd.Context(0)
+    with pytest.raises(hip.BlasrHipError):
+        other.borrow_index(empty)
+    empty.close()
+    other.close()  # (frees nothing of the owner's)
+    a2, off2 = owner.anchor_reads(reads, pool, p)
+    assert np.array_equal(as_triples(a0), as_triples(a2))
+    owner.close()

@@ -118,11 +118,12 @@ def run_end_to_end(own_intervals, tmp_path=None):
 
 
 @pytest.mark.skipif(not os.path.exists(SAWRITER), reason="oracle/_ref/sawritermc not built (the suffix array's writer)")
-@pytest.mark.parametrize("reads_per_block,extend", [(7, 0), (1000, 0), (13, 1)])
-def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_per_block, extend):
-    """blasr_hip_map_from_reads_device (anchoring in sub-blocks overlapped with the host's interval finding, then the
-    path, in C++): the reference binary's 125 candidate intervals and the hits of the step-by-step route, for sub-blocks
-    of 7 reads (12 of them in flight) and for one sub-block."""
+@pytest.mark.parametrize("reads_per_block,extend,overlap", [(7, 0, 0), (1000, 0, 0), (13, 1, 0), (7, 0, 1), (13, 1, 1), (79, 0, 1)])
+def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_per_block, extend, overlap):
+    """blasr_hip_map_from_reads_device (anchoring in sub-blocks, then the path, in C++): the reference binary's 125
+    candidate intervals and the hits of the step-by-step route, for sub-blocks of 7 reads and for one sub-block; with
+    `overlap` the path runs sub-block by sub-block beside the anchoring of the next one on the helper context -- same
+    hits, same order, and the fetched sequences and op lists of every sub-block where the shifted offsets say."""
     from blasr_testlib import DeviceMemory
     g = np.load(GOLDEN)
     contigs = [g["contig0"], g["contig1"]]
@@ -144,16 +145,26 @@ def test_the_one_call_mapper_finds_the_same_intervals_and_hits(tmp_path, reads_p
     d_reads, d_pool = mem.upload(reads.view(np.uint8)), mem.upload(pool)
     hits = np.zeros(len(want_iv) + 8, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(len(reads) + 1, dtype=np.int64)
-    p = ctx.pipeline_params(reads_per_block=reads_per_block)
+    p = ctx.pipeline_params(reads_per_block=reads_per_block, overlap=overlap)
     p.map.extend_alignments = extend  # -extend travels with the path's parameters
-    n, ivs = ctx.map_from_reads_device(genome, starts, ctx.count_tuples(8), reads, d_reads, d_pool, p, hits, hit_off,
-                                       intervals_capacity=len(want_iv) + 8)
+    n, ivs, seq, ops = ctx.map_from_reads_device(genome, starts, ctx.count_tuples(8), reads, d_reads, d_pool, p, hits, hit_off,
+                                                 intervals_capacity=len(want_iv) + 8, fetch_capacity=4 << 20)
     assert np.array_equal(ivs, want_iv)
     t = ctx.pipeline_last_timing()
     assert t["intervals"] == len(want_iv) and t["anchors"] > 10000
-    want_hits, want_off, _, _ = ctx.map_reads(reads, pool, want_iv, params=ctx.map_params(extend_alignments=extend), fetch=False)
+    want_hits, want_off, want_seq, want_ops = ctx.map_reads(reads, pool, want_iv, params=ctx.map_params(extend_alignments=extend))
     assert n == len(want_hits) and np.array_equal(hit_off, want_off)
     for f in ("read", "interval", "t_strand", "t_aligned_seq_pos", "q_pos", "t_pos", "score", "n_match", "n_ops"):
         assert np.array_equal(hits[:n][f], want_hits[f]), f
+    assert len(seq) == len(want_seq) and len(ops) == len(want_ops)
+    for a, b in zip(hits[:n], want_hits):  # (the arenas may be laid out differently: compare what the offsets point at)
+        assert np.array_equal(ops[a["ops_off"]: a["ops_off"] + a["n_ops"]], want_ops[b["ops_off"]: b["ops_off"] + b["n_ops"]])
+        for f, ln in (("q_off", "q_aligned_seq_length"), ("t_off", "t_aligned_seq_length")):
+            assert np.array_equal(seq[a[f]: a[f] + a[ln]], want_seq[b[f]: b[f] + b[ln]]), f
+    if overlap:  # too little room is reported with what the WHOLE call needs
+        small = np.zeros(3, dtype=hip.HIT_DTYPE)
+        with pytest.raises(hip.BlasrHipError) as e:
+            ctx.map_from_reads_device(genome, starts, ctx.count_tuples(8), reads, d_reads, d_pool, p, small, hit_off)
+        assert e.value.code == hip.ERR_CAPACITY and "%d hits" % n in str(e.value)
     mem.free()
     ctx.close()

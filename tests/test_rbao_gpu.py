@@ -70,7 +70,8 @@ def test_m4_lines_of_noisy_reads_under_rbao(extend):
     ctx.close()
 
 
-def test_the_one_call_mapper_under_rbao():
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_the_one_call_mapper_under_rbao(overlap):
     """blasr_hip_map_from_reads_device with map.refine_between_anchors_only: the chains travel from the interval finder to
     the path inside the library; the hits are those of the step-by-step route."""
     from blasr_testlib import DeviceMemory
@@ -86,7 +87,7 @@ def test_the_one_call_mapper_under_rbao():
     d_reads, d_pool = mem.upload(reads.view(np.uint8)), mem.upload(pool)
     hits = np.zeros(len(ivs) + 8, dtype=hip.HIT_DTYPE)
     hit_off = np.zeros(len(reads) + 1, dtype=np.int64)
-    p = ctx.pipeline_params(reads_per_block=9)
+    p = ctx.pipeline_params(reads_per_block=9, overlap=overlap)
     p.map.refine_between_anchors_only = 1
     n, got_iv = ctx.map_from_reads_device(genome, starts, table, reads, d_reads, d_pool, p, hits, hit_off,
                                           intervals_capacity=len(ivs) + 8)
