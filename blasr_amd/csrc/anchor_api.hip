@@ -85,8 +85,8 @@ struct AnchorArgs {
   const uint8_t *genome;
   uint32_t tlen;
   const uint32_t *index, *startPos, *endPos;
+  const uint2 *ranges;  // {startPos, endPos} of a lookup word side by side: one random sector per position instead of two
   const uint16_t *ext;  // per array position: the kExtBases bases after the lookup prefix (or null)
-  int qBits;            // sort keys are (t << qBits) | q: only the bits that can differ go through the radix passes
   int exp;              // BLASR_HIP_ANCHOR_EXP: timing experiments with wrong results
   int noWin;            // BLASR_HIP_ANCHOR_NO_WIN: every probe of the companion array from global memory (as in round 2)
   int prefixLen;
@@ -323,8 +323,14 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       tuple = (tuple << 2) + (uint64_t)(c & 3);
     }
     if (ok) {
-      l = a.startPos[tuple];
-      r = a.endPos[tuple];
+      if (a.ranges) {
+        const uint2 lr = a.ranges[tuple];
+        l = lr.x;
+        r = lr.y;
+      } else {
+        l = a.startPos[tuple];
+        r = a.endPos[tuple];
+      }
       lcp = (uint32_t)a.prefixLen;
       prefixUnchecked = tuple == 0 || a.minPrefix > (uint32_t)a.prefixLen;
     }
@@ -382,13 +388,16 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   // LocateAnchorBoundsInSuffixArray's heuristics (MapBySuffixArray.h:93-204).  (Its loop at :104-109 never runs: a
   // pair is only stored with low < high.)
   uint32_t ml = 0, mh = 0, mlen = 0;
+  uint32_t uniqueAt = 0xffffffffu, uniqueT = 0;  // the array position whose suffix the extension looked up, and that suffix
   if (n > 0) {
     ml = hl[0];
     mh = hr[0];
     mlen = a.minPrefix + n - 1;
     if (ml + 1 == mh) {  // unique: follow the genome as far as it agrees with the read
       uint32_t ext = mlen;
-      int64_t refPos = (int64_t)a.index[ml] + ext - 1;
+      uniqueAt = ml;
+      uniqueT = a.index[ml];
+      int64_t refPos = (int64_t)uniqueT + ext - 1;
       int64_t queryPos = (int64_t)p + ext - 1;
       bool extended = false, ended = false;
       // eight bases at a time while eight are left on both sides: one (unaligned) 8-byte load each instead of sixteen
@@ -459,14 +468,17 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       if (mlen < a.minMatch) count = 1;
     }
   }
-  a.lo[g] = ml;
+  // a single anchor whose suffix the extension has already looked up: the emission gets the genome position itself
+  // (bit 30 of the length word) instead of the place in the index array to read it from -- a random sector per anchor less
+  const bool known = count == 1 && ml == uniqueAt && !(a.exp & 16);
+  a.lo[g] = known ? uniqueT : ml;
   a.cnt[g] = count;
   // The reported length is minPrefix + (levels) - 1 or the extension's end: with a lookup table whose prefix is at least
   // minPrefix every base under it was compared with the read's (so it is no N) -- except when the match started from the
   // table's all-A word, under which BuildLookupTable also files the suffixes whose first bases make no tuple (it ignores
   // FromStringLR's failure, SuffixArray.h:234-244).  The emission checks the reference's assert against the genome only
   // where that is not so (bit 31): one random read per anchor less.
-  a.len[g] = mlen | (prefixUnchecked ? 0x80000000u : 0u);
+  a.len[g] = mlen | (prefixUnchecked ? 0x80000000u : 0u) | (known ? 0x40000000u : 0u);
   if (a.lcp) a.lcp[g] = lcp;
   if (a.probes) atomicAdd(a.probes, (unsigned long long)probes);
 }
@@ -497,10 +509,12 @@ __global__ __launch_bounds__(256) void anchor_seg_offsets_kernel(int nSeg, const
   segAnchor32[s] = (uint32_t)v;
 }
 
-// One wavefront per 64 consecutive positions, one lane per anchor.  sorted: (t << 32 | q) keys and length values for
-// the sort; else the records themselves.
-__global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const int64_t *anchorOff, uint64_t *keys,
-                                                          uint32_t *vals, blasr_hip_anchor *out, int *error) {
+// One wavefront per 64 consecutive positions, one lane per anchor.  sorted: t as the key and (length << 32 | q) as the
+// value of a STABLE sort -- a list's anchors leave this kernel in the order of their read positions, so anchors with the
+// same t come out of the sort by q, which is SortMatchPosList's order (t, then q) with 32 key bits through the radix passes
+// instead of 32 + the bits of q; else the records themselves.
+__global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const int64_t *anchorOff, uint32_t *keys,
+                                                          uint64_t *vals, blasr_hip_anchor *out, int *error) {
   __shared__ uint32_t sIncl[4][64], sLo[4][64], sLen[4][64], sQ[4][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t g0 = ((int64_t)blockIdx.x * 4 + w) * 64;
@@ -533,14 +547,14 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
         lo = mid + 1;
     }
     const uint32_t excl = lo ? sIncl[w][lo - 1] : 0;
-    const uint32_t t = a.index[sLo[w][lo] + (j - excl)];
-    const uint32_t lenWord = sLen[w][lo], len = lenWord & 0x7fffffffu;
+    const uint32_t lenWord = sLen[w][lo], len = lenWord & 0x3fffffffu;
+    const uint32_t t = (lenWord & 0x40000000u) ? sLo[w][lo] : a.index[sLo[w][lo] + (j - excl)];
     // the reference's asserts (MapBySuffixArray.h:301-302); the base under the match's end is one the search compared
     // with the read's (so no N) unless the match started from the all-A word of the lookup table (anchor_search_kernel)
     if ((uint64_t)t + len > a.tlen || len == 0 || ((lenWord >> 31) != 0 && a.genome[(uint64_t)t + len - 1] == 'N')) atomicOr(error, 1);
     if (keys) {
-      keys[base + j] = ((uint64_t)t << a.qBits) | sQ[w][lo];
-      vals[base + j] = len;
+      keys[base + j] = t;
+      vals[base + j] = ((uint64_t)len << 32) | sQ[w][lo];
     } else {
       blasr_hip_anchor rec;
       rec.t = t;
@@ -551,15 +565,15 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
   }
 }
 
-__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint64_t *keys, const uint32_t *vals, int qBits,
+__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint32_t *keys, const uint64_t *vals,
                                                           blasr_hip_anchor *out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t k = keys[i];
+  const uint64_t v = vals[i];
   blasr_hip_anchor rec;
-  rec.t = (uint32_t)(k >> qBits);
-  rec.q = (uint32_t)(k & ((1ull << qBits) - 1));
-  rec.l = vals[i];
+  rec.t = keys[i];
+  rec.q = (uint32_t)v;
+  rec.l = (uint32_t)(v >> 32);
   out[i] = rec;
 }
 
@@ -588,8 +602,16 @@ constexpr int64_t kSortLimit = 1ll << 30;        // anchors per segmented sort c
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void anchor_ranges_kernel(const uint32_t *startPos, const uint32_t *endPos, int64_t n, uint2 *ranges) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ranges[i] = make_uint2(startPos[i], endPos[i]);
+}
+}  // namespace
+
 void blasr_hip_drop_index(blasr_hip_ctx *ctx) {
   if (ctx->saOwned) {
+    if (ctx->saRanges) (void)hipFree(ctx->saRanges);
     if (ctx->saIndex) (void)hipFree(ctx->saIndex);
     if (ctx->saStartPos) (void)hipFree(ctx->saStartPos);
     if (ctx->saEndPos) (void)hipFree(ctx->saEndPos);
@@ -597,6 +619,7 @@ void blasr_hip_drop_index(blasr_hip_ctx *ctx) {
   }
   ctx->saIndex = ctx->saStartPos = ctx->saEndPos = nullptr;
   ctx->saExt = nullptr;
+  ctx->saRanges = nullptr;
   ctx->saExtGenome = ctx->saExtIndex = nullptr;
   ctx->saOwned = true;
   ctx->saLen = ctx->saTableLen = 0;
@@ -609,6 +632,13 @@ int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st) {
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "anchor_reads: the borrowed index was not made for this context's genome");
   if (ctx->saExt) (void)hipFree(ctx->saExt);
   ctx->saExt = nullptr;
+  if (ctx->saRanges) (void)hipFree(ctx->saRanges);
+  ctx->saRanges = nullptr;
+  if (ctx->saTableLen > 0) {  // the lookup table's two arrays as one of pairs (the search reads both ends of a word's range)
+    HIP_TRY(ctx, hipMalloc(&ctx->saRanges, sizeof(uint2) * (size_t)ctx->saTableLen));
+    hipLaunchKernelGGL(anchor_ranges_kernel, dim3((unsigned)((ctx->saTableLen + 255) / 256)), dim3(256), 0, st, ctx->saStartPos,
+                       ctx->saEndPos, ctx->saTableLen, ctx->saRanges);
+  }
   HIP_TRY(ctx, hipMalloc(&ctx->saExt, sizeof(uint16_t) * (size_t)ctx->saLen));
   hipLaunchKernelGGL(anchor_ext_kernel, dim3((unsigned)((ctx->saLen + 255) / 256)), dim3(256), 0, st, ctx->genome,
                      (uint32_t)ctx->genomeLen, ctx->saIndex, ctx->saLen, ctx->saPrefixLen, ctx->saExt);
@@ -644,6 +674,7 @@ int blasr_hip_borrow_index(blasr_hip_ctx *ctx, blasr_hip_ctx *from) try {
   ctx->saStartPos = from->saStartPos;
   ctx->saEndPos = from->saEndPos;
   ctx->saExt = from->saExt;
+  ctx->saRanges = from->saRanges;
   ctx->saExtGenome = from->saExt ? ctx->genome : nullptr;
   ctx->saExtIndex = from->saExt ? ctx->saIndex : nullptr;
   ctx->saLen = from->saLen;
@@ -867,10 +898,9 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     a.index = ctx->saIndex;
     a.startPos = ctx->saStartPos;
     a.endPos = ctx->saEndPos;
+    a.ranges = useLookup && !getenv("BLASR_HIP_ANCHOR_TWO_TABLES") ? ctx->saRanges : nullptr;
     a.ext = useExt ? ctx->saExt : nullptr;
     a.noWin = getenv("BLASR_HIP_ANCHOR_NO_WIN") != nullptr;
-    a.qBits = 1;  // q < the read's length
-    while (a.qBits < 32 && (longestRead >> a.qBits) != 0) a.qBits++;
     a.exp = getenv("BLASR_HIP_ANCHOR_EXP") ? atoi(getenv("BLASR_HIP_ANCHOR_EXP")) : 0;
     a.prefixLen = ctx->saPrefixLen;
     a.pool = read_pool;
@@ -914,8 +944,8 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     if (emitted + pieceAnchors > capacity) overflow = true;
     if (!overflow && pieceAnchors > 0) {
       blasr_hip_anchor *out = anchors + emitted;
-      uint64_t *keys = nullptr, *keysAlt = nullptr;
-      uint32_t *vals = nullptr, *valsAlt = nullptr;
+      uint32_t *keys = nullptr, *keysAlt = nullptr;
+      uint64_t *vals = nullptr, *valsAlt = nullptr;
       if (sorted) {
         if (pieceAnchors > kSortLimit)
           return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: %lld anchors in one piece of %d lists; lower BLASR_HIP_ANCHOR_PIECE",
@@ -924,10 +954,10 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
           const int rc = blasr_hip_ensure(ctx, ctx->anchorBuf[b], (size_t)pieceAnchors * (b < 2 ? 8 : 4));
           if (rc != BLASR_HIP_OK) return rc;
         }
-        keys = (uint64_t *)ctx->anchorBuf[0].p;
-        keysAlt = (uint64_t *)ctx->anchorBuf[1].p;
-        vals = (uint32_t *)ctx->anchorBuf[2].p;
-        valsAlt = (uint32_t *)ctx->anchorBuf[3].p;
+        vals = (uint64_t *)ctx->anchorBuf[0].p;
+        valsAlt = (uint64_t *)ctx->anchorBuf[1].p;
+        keys = (uint32_t *)ctx->anchorBuf[2].p;
+        keysAlt = (uint32_t *)ctx->anchorBuf[3].p;
       }
       hipLaunchKernelGGL(anchor_emit_kernel, dim3((unsigned)((nPos + 255) / 256)), dim3(256), 0, st, a, dAnchorOff, keys,
                          vals, out, dError);
@@ -935,9 +965,9 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
       if (sorted) {
         int tBits = 1;
         while (tBits < 32 && (a.tlen >> tBits) != 0) tBits++;
-        const unsigned sortBits = (unsigned)(a.qBits + tBits);  // (t < tlen, q < 2^qBits)
-        rocprim::double_buffer<uint64_t> kb(keys, keysAlt);
-        rocprim::double_buffer<uint32_t> vb(vals, valsAlt);
+        const unsigned sortBits = (unsigned)tBits;  // (t < tlen)
+        rocprim::double_buffer<uint32_t> kb(keys, keysAlt);
+        rocprim::double_buffer<uint64_t> vb(vals, valsAlt);
         size_t sortBytes = 0;
         HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
                                                          dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
@@ -948,7 +978,7 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
         HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(sortTmp, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
                                                          dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
         hipLaunchKernelGGL(anchor_pack_kernel, dim3((unsigned)((pieceAnchors + 255) / 256)), dim3(256), 0, st, pieceAnchors,
-                           kb.current(), vb.current(), a.qBits, out);
+                           kb.current(), vb.current(), out);
       }
       HIP_TRY(ctx, hipEventRecord(ev.e[3], st));
       ev.emitted = true;

@@ -245,7 +245,7 @@ int64_t blasr_hip_held_bytes(const blasr_hip_ctx *ctx) try {
   if (ctx->genome && ctx->genomeOwned) total += ctx->genomeLen;
   for (const auto &b : ctx->anchorBuf) total += (int64_t)b.bytes;
   total += (int64_t)ctx->pipeAnchors.bytes + (int64_t)ctx->pipeIntervals.bytes;
-  if (ctx->saOwned) total += (ctx->saExt ? 6 : 4) * ctx->saLen + 8 * ctx->saTableLen;
+  if (ctx->saOwned) total += (ctx->saExt ? 6 : 4) * ctx->saLen + (ctx->saRanges ? 16 : 8) * ctx->saTableLen;
   if (ctx->pipeHelper) total += blasr_hip_held_bytes(ctx->pipeHelper);
   return total;
 } BLASR_HIP_CATCH_CODE

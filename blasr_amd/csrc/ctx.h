@@ -76,6 +76,7 @@ struct blasr_hip_ctx {
   // per array position, the bases that follow the lookup prefix (anchor_api.hip: the search reads them instead of
   // index[] + genome[]); built at the first anchor call for the (genome, index) pair it was made from
   uint16_t *saExt = nullptr;
+  uint2 *saRanges = nullptr;  // made with it: {saStartPos[w], saEndPos[w]} side by side
   const void *saExtGenome = nullptr, *saExtIndex = nullptr;
   // anchor stage: what the host needs back after each piece (the lists' first anchors) is written by the device
   // straight into pinned host memory -- no copy queued behind other transfers; the probe count and the assert flag
