@@ -593,13 +593,24 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
                                       int64_t *n_intervals, int64_t *read_interval_off, int64_t *cluster_of_interval) {
   Genome g{genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size};
   const blasr_hip_interval_params &P = *params;
-  std::vector<std::vector<blasr_hip_interval>> perRead((size_t)n_reads);
-  std::vector<std::vector<float>> perReadP((size_t)n_reads);
-  std::vector<std::vector<int64_t>> perReadC(cluster_of_interval ? (size_t)n_reads : 0);
+  // a thread takes a run of consecutive reads and writes what it finds back to back into its own arrays (a vector or three
+  // per READ were 300 k allocations a call at configs[2]: most of this function's 20 ms)
+  struct Found {
+    std::vector<blasr_hip_interval> ivs;
+    std::vector<float> p;
+    std::vector<int64_t> cluster;
+    std::vector<int32_t> perRead;  // intervals of each read of the run
+  };
   int threads = blasr_hip_host_threads(P.threads > 0 ? P.threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
   threads = std::max(1, std::min(threads, n_reads));
+  std::vector<Found> found((size_t)threads);
+  const int32_t perThread = (n_reads + threads - 1) / threads;
   auto work = [&](int tid) {
-    for (int32_t r = tid; r < n_reads; r += threads) {
+    Found &f = found[(size_t)tid];
+    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)tid * perThread, n_reads);
+    const int32_t r1 = (int32_t)std::min<int64_t>((int64_t)r0 + perThread, n_reads);
+    f.perRead.reserve((size_t)(r1 - r0));
+    for (int32_t r = r0; r < r1; r++) {
       IntervalSet queue;
       for (int strand = 0; strand < 2; strand++) {
         int noOvpLisNBases = 0;  // (declared outside the loop over the clusters in the reference, :690)
@@ -630,7 +641,8 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
         }
       }
       if (P.remove_contained_intervals) remove_contained(queue);
-      for (IntervalSet::iterator it = queue.begin(); it != queue.end(); ++it) {
+      int32_t mine = 0;
+      for (IntervalSet::iterator it = queue.begin(); it != queue.end(); ++it, mine++) {
         blasr_hip_interval iv;
         iv.start = it->start;
         iv.end = it->end;
@@ -638,22 +650,28 @@ int blasr_hip_intervals_from_clusters(const uint8_t *genome, int64_t genome_leng
         iv.q_end = it->qEnd;
         iv.read = r;
         iv.strand = it->readIndex;
-        perRead[(size_t)r].push_back(iv);
-        perReadP[(size_t)r].push_back(it->pValue);
-        if (cluster_of_interval) perReadC[(size_t)r].push_back(it->cluster);
+        f.ivs.push_back(iv);
+        f.p.push_back(it->pValue);
+        if (cluster_of_interval) f.cluster.push_back(it->cluster);
       }
+      f.perRead.push_back(mine);
     }
   };
   if (const int trc = blasr_hip_run_threads(threads, work)) return trc;  // (a worker ran out of memory)
   int64_t total = 0;
-  for (int32_t r = 0; r < n_reads; r++) {
-    read_interval_off[r] = total;
-    for (size_t i = 0; i < perRead[(size_t)r].size(); i++, total++)
-      if (total < capacity) {
-        intervals[total] = perRead[(size_t)r][i];
-        if (p_values) p_values[total] = perReadP[(size_t)r][i];
-        if (cluster_of_interval) cluster_of_interval[total] = perReadC[(size_t)r][i];
-      }
+  for (int tid = 0; tid < threads; tid++) {  // (the threads' runs of reads follow each other)
+    const Found &f = found[(size_t)tid];
+    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)tid * perThread, n_reads);
+    size_t at = 0;
+    for (size_t k = 0; k < f.perRead.size(); k++) {
+      read_interval_off[r0 + (int32_t)k] = total;
+      for (int32_t i = 0; i < f.perRead[k]; i++, at++, total++)
+        if (total < capacity) {
+          intervals[total] = f.ivs[at];
+          if (p_values) p_values[total] = f.p[at];
+          if (cluster_of_interval) cluster_of_interval[total] = f.cluster[at];
+        }
+    }
   }
   read_interval_off[n_reads] = total;
   *n_intervals = total;

@@ -34,6 +34,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/blasr_hip.h"
@@ -514,6 +515,16 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
   if (nAnchors > 0 && !anchors_device) return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "find_intervals_device: no anchors");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  // BLASR_HIP_IV_TRACE: wall time between the call's synchronisation points
+  const bool ivTrace = getenv("BLASR_HIP_IV_TRACE") != nullptr;
+  auto ivNow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double ivT = ivNow();
+  auto ivMark = [&](const char *what) {
+    if (!ivTrace) return;
+    const double t = ivNow();
+    fprintf(stderr, "[iv] %-28s %8.2f ms\n", what, t - ivT);
+    ivT = t;
+  };
   // ---- host-side tables: list offsets from 0, the window length of every read (Blasr.cpp:2402-2406)
   std::vector<int64_t> off((size_t)nLists + 1);
   for (int i = 0; i <= nLists; i++) off[(size_t)i] = list_off[i] - base;
@@ -575,6 +586,7 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
     HIP_TRY(ctx, hipMemcpyAsync(&totalKept, dSlot + nAnchors, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
+  ivMark("tables, mark, scan, compact");
   hipLaunchKernelGGL(iv_lists_kernel, dim3((unsigned)((nLists + 256) / 256)), dim3(256), 0, st, L, dKeep, dSlot, totalKept, dNewOff, dPast);
   // ---- StoreLargestIntervals: count, scan, write
   const unsigned gridL = (unsigned)((nLists + 63) / 64);
@@ -587,6 +599,7 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   const int nClusters = (int)cOff[(size_t)nLists];
+  ivMark("lists, windows (count), scan");
   std::vector<blasr_hip_iv_cluster> summary((size_t)nClusters);
   struct FreeDev {
     void *p = nullptr;
@@ -650,6 +663,7 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
     }
     int32_t classCount[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(classCount, dTotals, sizeof(classCount), hipMemcpyDeviceToHost));
+    ivMark("windows (write), classes");
     if (wantChains) {  // a slot per cluster (an exclusive scan of the clusters' sizes), then the memory
       HIP_TRY(ctx, hipMalloc(&chainSlotMem.p, sizeof(int64_t) * 2 * ((size_t)nClusters + 1)));
       int64_t *dSizes = (int64_t *)chainSlotMem.p, *dSlot = dSizes + nClusters + 1;
@@ -694,18 +708,32 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
       dScratch = (char *)scratchMem.p;
       dScratchOff = (int64_t *)scratchOffMem.p;
     }
+    // the mid-size clusters' kernel holds two wavefronts a CU (72 KB of LDS each): it runs on a side stream beside the small
+    // clusters' one instead of in front of it (17 + 12 ms one after the other at configs[2])
+    const bool beside = classCount[0] > 0 && classCount[1] > 0 && ctx->auxStream[0] && ctx->auxEvent[0] && ctx->auxEvent[1];
+    hipStream_t stMid = beside ? ctx->auxStream[0] : st;
+    if (beside) {
+      HIP_TRY(ctx, hipEventRecord(ctx->auxEvent[0], st));
+      HIP_TRY(ctx, hipStreamWaitEvent(stMid, ctx->auxEvent[0], 0));
+    }
+    if (classCount[1] > 0)
+      hipLaunchKernelGGL((iv_chain_kernel<1>), dim3((unsigned)classCount[1]), dim3(64), chain_bytes(kChainMid), stMid, dPos, dNewOff, dCl,
+                         dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
     if (classCount[0] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<0>), dim3((unsigned)((classCount[0] + 3) / 4)), dim3(256), 4 * chain_bytes(kChainSmall), st, dPos,
                          dNewOff, dCl, dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
-    if (classCount[1] > 0)
-      hipLaunchKernelGGL((iv_chain_kernel<1>), dim3((unsigned)classCount[1]), dim3(64), chain_bytes(kChainMid), st, dPos, dNewOff, dCl,
-                         dIdxOut, (const int32_t *)dTotals, nullptr, nullptr, dRes, dChains, dChainSlot);
+    if (beside) {
+      HIP_TRY(ctx, hipEventRecord(ctx->auxEvent[1], stMid));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->auxEvent[1], 0));
+    }
     if (classCount[2] > 0)
       hipLaunchKernelGGL((iv_chain_kernel<2>), dim3((unsigned)classCount[2]), dim3(64), 0, st, dPos, dNewOff, dCl, dIdxOut,
                          (const int32_t *)dTotals, dScratch, dScratchOff, dRes, dChains, dChainSlot);
     HIP_TRY(ctx, hipMemcpyAsync(summary.data(), dRes, sizeof(blasr_hip_iv_cluster) * summary.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
+    if (ivTrace) fprintf(stderr, "[iv] %d clusters: %d small, %d mid, %d large\n", nClusters, classCount[0], classCount[1], classCount[2]);
+    ivMark("chains");
   }
   // ---- the host's end: p-values, the tests of FindMaxInterval.h:805-825, the interval sets
   std::vector<int64_t> cOff64((size_t)nLists + 1);
@@ -714,6 +742,7 @@ int blasr_hip_find_intervals_device_chains(blasr_hip_ctx *ctx, const uint8_t *ge
   const int rc = blasr_hip_intervals_from_clusters(genome, genome_length, seq_start_pos, n_seq_pos, count_table, count_tuple_size,
                                                    n_reads, reads, summary.data(), cOff64.data(), params, intervals, p_values, capacity,
                                                    n_intervals, read_interval_off, wantChains ? clusterOf.data() : nullptr);
+  ivMark("host: p-values, interval sets");
   if (rc != BLASR_HIP_OK) return rc == BLASR_HIP_ERR_CAPACITY ? blasr_hip_fail(ctx, rc, "find_intervals_device: %lld intervals, room for %lld",
                                                                                 (long long)*n_intervals, (long long)capacity) : rc;
   if (wantChains) {  // the chains of the clusters that became intervals, gathered on the device, one download
