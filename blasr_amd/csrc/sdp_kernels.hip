@@ -55,8 +55,10 @@ constexpr int kPosBits = 24;  // target positions < 2^24 (checked on the host)
 constexpr int kIdxBuckets = 4096;
 constexpr int kIdxMinT = 1536;   // shorter targets keep the wavefront-per-task kernels
 constexpr int kIdxMaxK = 13;     // 2k bits of k-mer + 2*15 bits of shift must fit a 64-bit window
-constexpr int kIdxSmallCap = 12288;  // targets up to this size: < 40 KB of LDS per workgroup, four workgroups per CU
-constexpr int kIdxMidCap = 20480;    // ... and up to this: three
+constexpr int kIdxSmallCap = 12288;  // targets up to this size: 52 KB of LDS per workgroup with the filter and its list, three
+                                     // workgroups per CU (measured by padding the allocation: two cost + 9 ms of match + order at
+                                     // configs[2], one + 30; a fourth would take the filter, half the buckets and the list to fit)
+constexpr int kIdxMidCap = 20480;    // ... and up to this: two
 
 __host__ __device__ inline bool task_uses_index(int tLen, int k, int idxMaxT) {
   return tLen >= kIdxMinT && tLen <= idxMaxT && k <= kIdxMaxK;
@@ -546,18 +548,28 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       IDX_CLOCK(0);
       // ---- bucket sizes (two sixteen-bit counters to a word: a target has < 65536 positions, nothing carries over)
       const int nKmerT = t.tLen - k + 1;
-      // (two positions per thread and trip: the LDS round trips of the two overlap)
-      for (int p = tid; p < nKmerT; p += 512) {
-        const int pb = p + 256;
-        const bool okA = bad_window(L.tBad, p, kMask) == 0u, okB = pb < nKmerT && bad_window(L.tBad, min(pb, nKmerT - 1), kMask) == 0u;
-        const uint32_t kmA = code_window(L.tCodes, p, kmerMask), kmB = code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask);
-        const int dA = idx_bucket(kmA), dB = idx_bucket(kmB);
-        if (okA) atomicAdd(&L.cnt[dA >> 1], 1u << ((dA & 1) * 16));
-        if (okB) atomicAdd(&L.cnt[dB >> 1], 1u << ((dB & 1) * 16));
+      // (four positions per thread and trip: their LDS round trips overlap)
+      constexpr int kBU = 4;
+      for (int p = tid; p < nKmerT; p += 256 * kBU) {
+        bool ok[kBU];
+        uint32_t km[kBU];
+#pragma unroll
+        for (int u = 0; u < kBU; u++) {
+          const int pu = p + 256 * u, pc = min(pu, nKmerT - 1);
+          ok[u] = pu < nKmerT && bad_window(L.tBad, pc, kMask) == 0u;
+          km[u] = code_window(L.tCodes, pc, kmerMask);
+        }
+#pragma unroll
+        for (int u = 0; u < kBU; u++) {
+          const int d = idx_bucket(km[u]);
+          if (ok[u]) atomicAdd(&L.cnt[d >> 1], 1u << ((d & 1) * 16));
+        }
         if (useFilter) {
-          const int fA = idx_filter(kmA), fB = idx_filter(kmB);
-          if (okA) atomicOr(&L.filt[fA >> 5], 1u << (fA & 31));
-          if (okB) atomicOr(&L.filt[fB >> 5], 1u << (fB & 31));
+#pragma unroll
+          for (int u = 0; u < kBU; u++) {
+            const int f = idx_filter(km[u]);
+            if (ok[u]) atomicOr(&L.filt[f >> 5], 1u << (f & 31));
+          }
         }
       }
       __syncthreads();
@@ -584,15 +596,24 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
       __syncthreads();
       IDX_CLOCK(2);
       // ---- scatter: a position takes the next slot of its bucket, whichever lane comes first
-      for (int p = tid; p < nKmerT; p += 512) {
-        const int pb = p + 256;
-        const bool okA = bad_window(L.tBad, p, kMask) == 0u, okB = pb < nKmerT && bad_window(L.tBad, min(pb, nKmerT - 1), kMask) == 0u;
-        const int dA = idx_bucket(code_window(L.tCodes, p, kmerMask)), dB = idx_bucket(code_window(L.tCodes, min(pb, nKmerT - 1), kmerMask));
-        uint32_t oldA = 0, oldB = 0;
-        if (okA) oldA = atomicAdd(&L.cnt[dA >> 1], 1u << ((dA & 1) * 16));
-        if (okB) oldB = atomicAdd(&L.cnt[dB >> 1], 1u << ((dB & 1) * 16));
-        if (okA) L.ent[(oldA >> ((dA & 1) * 16)) & 0xffffu] = (uint16_t)p;
-        if (okB) L.ent[(oldB >> ((dB & 1) * 16)) & 0xffffu] = (uint16_t)pb;
+      for (int p = tid; p < nKmerT; p += 256 * kBU) {
+        bool ok[kBU];
+        int d[kBU];
+        uint32_t old[kBU];
+#pragma unroll
+        for (int u = 0; u < kBU; u++) {
+          const int pu = p + 256 * u, pc = min(pu, nKmerT - 1);
+          ok[u] = pu < nKmerT && bad_window(L.tBad, pc, kMask) == 0u;
+          d[u] = idx_bucket(code_window(L.tCodes, pc, kmerMask));
+        }
+#pragma unroll
+        for (int u = 0; u < kBU; u++) {
+          old[u] = 0;
+          if (ok[u]) old[u] = atomicAdd(&L.cnt[d[u] >> 1], 1u << ((d[u] & 1) * 16));
+        }
+#pragma unroll
+        for (int u = 0; u < kBU; u++)
+          if (ok[u]) L.ent[(old[u] >> ((d[u] & 1) * 16)) & 0xffffu] = (uint16_t)(p + 256 * u);
       }
       __syncthreads();
       IDX_CLOCK(3);
@@ -631,19 +652,32 @@ __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv,
         uint16_t *list = L.list + wv * 512;
         for (int half = 0; half < 2; half++) {  // (the list holds 512 positions: the staged chunk in two halves)
         int nSurv = 0;
-        for (int j = 8 * half; j < 8 * half + 8; j++) {
-          const int x0 = c0 + 64 * j;
-          if (x0 >= qhi) break;
-          const int x = x0 + lane;
-          const bool on = x < qhi;
-          const int rel = min(x - c0, 1023);
-          const uint32_t km = code_window(qCodes, rel, kmerMask);
-          const int f = idx_filter(km);
-          const bool surv = on && bad_window(qBad, rel, kMask) == 0u && ((L.filt[f >> 5] >> (f & 31)) & 1u) != 0u;
-          const unsigned long long m = __ballot(surv);
-          if (surv) list[nSurv + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)rel;
-          if (on && !surv) hits[x] = 0ull;
-          nSurv += (int)__popcll(m);
+        // (four blocks of 64 positions per trip: their chains of LDS round trips -- the window of codes, the bad bits, the
+        //  filter word -- are in flight together; one after the other a wavefront waited out each of them, at four per SIMD)
+        for (int j = 8 * half; j < 8 * half + 8; j += 4) {
+          if (c0 + 64 * j >= qhi) break;
+          int rel4[4];
+          bool on4[4];
+          uint32_t km4[4], bad4[4], word4[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int x = c0 + 64 * (j + u) + lane;
+            on4[u] = x < qhi;
+            rel4[u] = min(x - c0, 1023);
+            km4[u] = code_window(qCodes, rel4[u], kmerMask);
+            bad4[u] = bad_window(qBad, rel4[u], kMask);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) word4[u] = L.filt[idx_filter(km4[u]) >> 5];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int f = idx_filter(km4[u]);
+            const bool surv = on4[u] && bad4[u] == 0u && ((word4[u] >> (f & 31)) & 1u) != 0u;
+            const unsigned long long m = __ballot(surv);
+            if (surv) list[nSurv + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)rel4[u];
+            if (on4[u] && !surv) hits[c0 + rel4[u]] = 0ull;
+            nSurv += (int)__popcll(m);
+          }
         }
         __builtin_amdgcn_wave_barrier();
         constexpr int kU = 2;
