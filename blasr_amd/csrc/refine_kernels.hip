@@ -1468,11 +1468,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
 // candidate has run out of records or of staged columns, ALL of them top up as far as their window / ring holds.
 // The recurrence, the tagged keys and the arrow byte are fillp_kernel's.
 // ---------------------------------------------------------------------------
-#ifdef BLASR_FILL_RANGE  // experiment (make EXTRA=-DBLASR_FILL_RANGE): how far apart the values of a row are, in score units --
-// would the recurrence fit 16-bit keys relative to a per-row base?  [0] max over rows of (max - min) of S and I over the
-// row's cells, [1] max |row minimum - the minimum of the row before|, [2] rows seen, [3] rows with a range above 500
-__device__ unsigned long long g_fillRange[4];
-#endif
 constexpr int kF8Pass = 40;
 constexpr int kF8Rows = 16;
 constexpr int kF8Clean = 8;   // = the lanes of a candidate: one entry each
@@ -1532,9 +1527,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   const int tLast = max(myTLen - 1, 0);
   __builtin_amdgcn_wave_barrier();
 
-#ifdef BLASR_FILL_RANGE
-  int rngMin = inf, rngMax = -inf, rngPrev = inf;
-#endif
   int myRow = 1, myPass = 0, stagedEnd = 1;  // records of rows below stagedEnd (and not below myRow) are in the window
   int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
   bool alive = myTask >= 0 && myRow <= myQ;
@@ -1655,36 +1647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
       else if (j == 3) arrowLo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(arrow, arrowHi, 0x04000c0cu), arrowLo, 0x07060100u) & 0x1f1f1f1fu;
       else arrowHi = arrow & kTagMask;
       if (alive) ring[(c0 + j) & (kF4Ring - 1)] = make_int2(sv, iKey & ~kTagMask);
-#ifdef BLASR_FILL_RANGE
-      if (alive && c0 + j <= hiC) {  // (values near `inf` are cells nothing reaches)
-        const int iv = iKey & ~kTagMask;
-        if (sv < (1 << 29)) rngMin = min(rngMin, sv), rngMax = max(rngMax, sv);
-        if (iv < (1 << 29)) rngMin = min(rngMin, iv), rngMax = max(rngMax, iv);
-      }
-#endif
     }
-#ifdef BLASR_FILL_RANGE
-    {
-      int lo8 = rngMin, hi8 = rngMax;
-      for (int off = 1; off < kL; off <<= 1) {
-        lo8 = min(lo8, __shfl_xor(lo8, off));
-        hi8 = max(hi8, __shfl_xor(hi8, off));
-      }
-      const bool rowDone = alive && !(cb + kPass <= hiC);
-      if (rowDone && l == 0 && hi8 >= lo8) {
-        const long long range = ((long long)hi8 - lo8) >> kShift;
-        atomicMax(&g_fillRange[0], (unsigned long long)range);
-        if (rngPrev != inf) atomicMax(&g_fillRange[1], (unsigned long long)(abs(lo8 - rngPrev) >> kShift));
-        atomicAdd(&g_fillRange[2], 1ull);
-        if (range > 500) atomicAdd(&g_fillRange[3], 1ull);
-      }
-      if (rowDone) {
-        rngPrev = lo8;
-        rngMin = inf;
-        rngMax = -inf;
-      }
-    }
-#endif
     // ---- arrows: five consecutive bytes per lane; bytes beyond the row's end spill into the next row's space (or the slack
     // after the last row) and are overwritten when that row is stored
     if (alive && c0 <= hiC) {
@@ -2223,15 +2186,8 @@ void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes,
     hipLaunchKernelGGL((fillp_kernel<16, true, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else if (lanes == 16)
     hipLaunchKernelGGL((fillp_kernel<16, false, false>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
-  else {  // (the caller has checked fill8_kernel's domain: extension 0, matrix entries within 6 bits)
+  else  // (the caller has checked fill8_kernel's domain: extension 0, matrix entries within 6 bits)
     hipLaunchKernelGGL(fill8_kernel, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
-#ifdef BLASR_FILL_RANGE
-    unsigned long long h[4];
-    if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fillRange), sizeof(h)) == hipSuccess)
-      fprintf(stderr, "[fill range] widest row range %llu, largest step of the row minimum %llu, rows %llu, rows with a range above 500: %llu\n",
-              h[0], h[1], h[2], h[3]);
-#endif
-  }
 }
 // the candidates with wide rows: args.taskList = the list, args.wideRingOff / wideRingSize indexed like it
 void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {
