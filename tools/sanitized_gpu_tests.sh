@@ -37,9 +37,17 @@ c.close()" > "$OUT/asan_probe.log" 2>&1
   fi
 fi
 # ---- 2. UBSan alone
+#      (rocPRIM's own headers add an offset to a null pointer when asked for their scratch size -- device_segmented_radix_sort.hpp:211,
+#       instantiated in anchor_api.hip: for the anchoring tests the library is built with that one check recoverable,
+#         make -C blasr_amd/csrc SAN=ubsan CXXFLAGS="-O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fno-omit-frame-pointer \
+#              -fsanitize=undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -fsanitize-recover=pointer-overflow"
+#       and every "runtime error" line that does not name a rocprim header fails the pass; -s: a report must not end in pytest's capture)
 if [ -f "$ROOT/blasr_amd/libblasr_hip_ubsan.so" ]; then
-  UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 BLASR_HIP_LIBRARY="$ROOT/blasr_amd/libblasr_hip_ubsan.so" \
-    timeout 2000 python3 -m pytest $TESTS -x -q -m gpu -k "$SEL" > "$OUT/ubsan_pytest.log" 2>&1
+  UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0 BLASR_HIP_LIBRARY="$ROOT/blasr_amd/libblasr_hip_ubsan.so" \
+    timeout 2000 python3 -m pytest $TESTS -x -q -s -m gpu -k "$SEL" > "$OUT/ubsan_pytest.log" 2>&1
   echo "ubsan gpu tests rc $?" | tee -a "$OUT/ubsan_pytest.log"
-  tail -5 "$OUT/ubsan_pytest.log"
+  grep "runtime error" "$OUT/ubsan_pytest.log" | sort | uniq -c > "$OUT/ubsan_reports.txt"
+  echo "reports outside rocprim: $(grep -v "include/rocprim/" "$OUT/ubsan_reports.txt" | wc -l)" | tee -a "$OUT/ubsan_pytest.log"
+  cat "$OUT/ubsan_reports.txt" | cut -c1-240
+  grep -E "passed|failed" "$OUT/ubsan_pytest.log" | tail -2
 fi
