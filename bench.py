@@ -523,7 +523,7 @@ def _pick(d, keys):
     return {k: _sig(d[k]) for k in keys if d is not None and k in d}
 
 
-ROOFLINE_KEYS = ("kernel", "stage", "bound", "achieved", "peak", "unit", "frac", "traffic", "valu_issue_frac", "avg_launch_ms",
+ROOFLINE_KEYS = ("kernel", "stage", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "valu_issue_frac", "avg_launch_ms",
                  "launches_per_step", "ms_per_step", "concurrent_launches", "share_of_step", "stage_frac", "stage_gcups",
                  "salu_over_valu")
 CPU_KEYS = ("value", "unit", "cores", "kind", "parity_checked", "parity_mismatches")
@@ -898,10 +898,11 @@ def main():
                 rl["valu_issue_frac"] = insts * cyc / (SIMDS * CLOCK_HZ * per_launch_ms / 1e3)
                 rl["valu_issue_frac_source"] = "instruction count of the ISA x cells (no PMC pass of this build)"
                 rl["valu_wave_instructions_per_launch"] = insts
-            # which roof binds: the larger of the two fractions (the contract's figures stay the HBM ones)
+            # `bound` stays the contract's ("hbm" | "mfma": this integer path has no MFMA work, its roof of the two is HBM) and the
+            # figures stay the HBM ones; what actually limits the kernel goes beside it: vector issue where that fraction (PMC
+            # of this build, or -- said so -- a count of the ISA) exceeds the HBM fraction
             if rl.get("valu_issue_frac", 0.0) > rl["frac"]:
-                # (from a count of the ISA instead of counters of this build: said so, and not asserted by any test)
-                rl["bound"] = "valu (modelled)" if "valu_issue_frac_source" in rl else "valu"
+                rl["limiter"] = "valu issue (modelled)" if "valu_issue_frac_source" in rl else "valu issue"
             rl["stage"] = "refine"
             if name == "blasr_hip::kband_wide_kernel" and a["launches"] > K:
                 # the chunks of a k-band batch run as two lanes on two streams: the launches overlap, so a
@@ -947,10 +948,10 @@ def main():
         lines.sort(key=lambda r: -r["ms_per_step"])
         if lines:
             out["roofline"] = dict(lines[0])
-            if out["roofline"]["bound"] == "valu":
-                out["roofline"]["limiter"] = ("VALU issue (integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
-                                              "instruction, profiles/r02_valu_rate.txt): valu_issue_frac is the roof that "
-                                              "binds; achieved / peak / frac are the HBM figures the contract asks for")
+            if out["roofline"].get("limiter", "").startswith("valu issue"):
+                out["roofline"]["limiter_note"] = ("integer min / compare / DPP forms issue at 4.1-4.4 cycles per wave64 "
+                                                   "instruction (profiles/r02_valu_rate.txt): valu_issue_frac is what binds; "
+                                                   "bound / achieved / peak / frac are the HBM figures the contract asks for")
             out["kernel_rooflines"] = lines
             refine_lines = [r for r in lines if r["stage"] == "refine"]
             if refine_lines and refine_lines[0]["kernel"] != lines[0]["kernel"]:
