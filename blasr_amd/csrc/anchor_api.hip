@@ -513,8 +513,11 @@ __global__ __launch_bounds__(256) void anchor_seg_offsets_kernel(int nSeg, const
 // value of a STABLE sort -- a list's anchors leave this kernel in the order of their read positions, so anchors with the
 // same t come out of the sort by q, which is SortMatchPosList's order (t, then q) with 32 key bits through the radix passes
 // instead of 32 + the bits of q; else the records themselves.
+// (Val = uint32_t where every read of the batch is shorter than 65536 bases: length and q in sixteen bits each, a third less
+//  for the sort to move.)
+template <typename Val>
 __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const int64_t *anchorOff, uint32_t *keys,
-                                                          uint64_t *vals, blasr_hip_anchor *out, int *error) {
+                                                          Val *vals, blasr_hip_anchor *out, int *error) {
   __shared__ uint32_t sIncl[4][64], sLo[4][64], sLen[4][64], sQ[4][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t g0 = ((int64_t)blockIdx.x * 4 + w) * 64;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
     if ((uint64_t)t + len > a.tlen || len == 0 || ((lenWord >> 31) != 0 && a.genome[(uint64_t)t + len - 1] == 'N')) atomicOr(error, 1);
     if (keys) {
       keys[base + j] = t;
-      vals[base + j] = ((uint64_t)len << 32) | sQ[w][lo];
+      vals[base + j] = sizeof(Val) == 8 ? (Val)(((uint64_t)len << 32) | sQ[w][lo]) : (Val)((len << 16) | sQ[w][lo]);
     } else {
       blasr_hip_anchor rec;
       rec.t = t;
@@ -565,15 +568,16 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
   }
 }
 
-__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint32_t *keys, const uint64_t *vals,
+template <typename Val>
+__global__ __launch_bounds__(256) void anchor_pack_kernel(int64_t n, const uint32_t *keys, const Val *vals,
                                                           blasr_hip_anchor *out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint64_t v = vals[i];
   blasr_hip_anchor rec;
   rec.t = keys[i];
-  rec.q = (uint32_t)v;
-  rec.l = (uint32_t)(v >> 32);
+  rec.q = sizeof(Val) == 8 ? (uint32_t)v : (uint32_t)(v & 0xffffu);
+  rec.l = sizeof(Val) == 8 ? (uint32_t)(v >> 32) : (uint32_t)(v >> 16);
   out[i] = rec;
 }
 
@@ -959,26 +963,37 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
         keys = (uint32_t *)ctx->anchorBuf[2].p;
         keysAlt = (uint32_t *)ctx->anchorBuf[3].p;
       }
-      hipLaunchKernelGGL(anchor_emit_kernel, dim3((unsigned)((nPos + 255) / 256)), dim3(256), 0, st, a, dAnchorOff, keys,
-                         vals, out, dError);
+      const bool narrowVals = sorted && longestRead < 65536u && !getenv("BLASR_HIP_ANCHOR_WIDE_VALUES");
+      if (narrowVals)
+        hipLaunchKernelGGL(anchor_emit_kernel<uint32_t>, dim3((unsigned)((nPos + 255) / 256)), dim3(256), 0, st, a, dAnchorOff, keys,
+                           (uint32_t *)vals, out, dError);
+      else
+        hipLaunchKernelGGL(anchor_emit_kernel<uint64_t>, dim3((unsigned)((nPos + 255) / 256)), dim3(256), 0, st, a, dAnchorOff, keys,
+                           vals, out, dError);
       HIP_TRY(ctx, hipEventRecord(ev.e[2], st));
       if (sorted) {
         int tBits = 1;
         while (tBits < 32 && (a.tlen >> tBits) != 0) tBits++;
         const unsigned sortBits = (unsigned)tBits;  // (t < tlen)
-        rocprim::double_buffer<uint32_t> kb(keys, keysAlt);
-        rocprim::double_buffer<uint64_t> vb(vals, valsAlt);
-        size_t sortBytes = 0;
-        HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
-                                                         dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
         // the position arrays are dead once the anchors are out: the sort's scratch goes over them
         void *sortTmp = dLo;
-        if ((size_t)((char *)ctx->workspace + ctx->workspaceBytes - (char *)dLo) < sortBytes)
-          return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: sort scratch of %zu bytes", sortBytes);
-        HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(sortTmp, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
-                                                         dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
-        hipLaunchKernelGGL(anchor_pack_kernel, dim3((unsigned)((pieceAnchors + 255) / 256)), dim3(256), 0, st, pieceAnchors,
-                           kb.current(), vb.current(), out);
+        const size_t sortRoom = (size_t)((char *)ctx->workspace + ctx->workspaceBytes - (char *)dLo);
+        auto sort_and_pack = [&](auto *v0, auto *v1) -> int {
+          typedef typename std::remove_pointer<decltype(v0)>::type Val;
+          rocprim::double_buffer<uint32_t> kb(keys, keysAlt);
+          rocprim::double_buffer<Val> vb(v0, v1);
+          size_t sortBytes = 0;
+          HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(nullptr, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
+                                                           dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
+          if (sortRoom < sortBytes) return blasr_hip_fail(ctx, BLASR_HIP_ERR_NOMEM, "anchor_reads: sort scratch of %zu bytes", sortBytes);
+          HIP_TRY(ctx, rocprim::segmented_radix_sort_pairs(sortTmp, sortBytes, kb, vb, (unsigned)pieceAnchors, (unsigned)nSeg,
+                                                           dSegAnchor32, dSegAnchor32 + 1, 0, sortBits, st));
+          hipLaunchKernelGGL(anchor_pack_kernel<Val>, dim3((unsigned)((pieceAnchors + 255) / 256)), dim3(256), 0, st, pieceAnchors,
+                             kb.current(), vb.current(), out);
+          return BLASR_HIP_OK;
+        };
+        const int rcS = narrowVals ? sort_and_pack((uint32_t *)vals, (uint32_t *)valsAlt) : sort_and_pack(vals, valsAlt);
+        if (rcS != BLASR_HIP_OK) return rcS;
       }
       HIP_TRY(ctx, hipEventRecord(ev.e[3], st));
       ev.emitted = true;

@@ -220,3 +220,25 @@ def test_a_second_context_anchors_in_a_borrowed_index():
     a2, off2 = owner.anchor_reads(reads, pool, p)
     assert np.array_equal(as_triples(a0), as_triples(a2))
     owner.close()
+
+
+def test_sort_values_of_either_width(monkeypatch):
+    """SortMatchPosList on the device: t is the key of a stable sort, (length, q) its value -- 32 bits where every read of the
+    batch is shorter than 65 536 bases, 64 otherwise (BLASR_HIP_ANCHOR_WIDE_VALUES forces those): the same lists, and the
+    golden ones."""
+    z, sa = golden_case()
+    genome, reads, pool = z["genome"], z["reads"], z["pool"]
+    ctx = blasr_amd.Context(0)
+    ctx.upload_genome(genome)
+    ctx.upload_suffix_array(sa)
+    p = ctx.anchor_params(min_match_length=10, max_anchors_per_position=50)
+    a0, off0 = ctx.anchor_reads(reads, pool, p)
+    monkeypatch.setenv("BLASR_HIP_ANCHOR_WIDE_VALUES", "1")
+    a1, off1 = ctx.anchor_reads(reads, pool, p)
+    assert len(a0) > 1000 and np.array_equal(off0, off1) and np.array_equal(as_triples(a0), as_triples(a1))
+    # sorted by (t, q) inside every list
+    for i in range(len(off0) - 1):
+        seg = a0[off0[i]: off0[i + 1]]
+        key = seg["t"].astype(np.int64) << 32 | seg["q"].astype(np.int64)
+        assert np.all(key[1:] > key[:-1])
+    ctx.close()
