@@ -519,7 +519,7 @@ template <typename Val>
 __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const int64_t *anchorOff, uint32_t *keys,
                                                           Val *vals, blasr_hip_anchor *out, int *error) {
   __shared__ uint32_t sIncl[4][64], sLo[4][64], sLen[4][64], sQ[4][64];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int64_t g0 = ((int64_t)blockIdx.x * 4 + w) * 64;
   if (g0 >= a.nPos) return;
   const int64_t g = g0 + lane;
@@ -527,10 +527,15 @@ __global__ __launch_bounds__(256) void anchor_emit_kernel(AnchorArgs a, const in
   const uint32_t incl = wave_prefix_sum(c);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   if (total == 0) return;
+  // the list of the wavefront's first position by one search on the scalar unit; a lane beyond that list's end steps on from
+  // there (as in the search kernel: a search per lane was eighteen dependent loads at the head of every wavefront)
   uint32_t q = 0;
-  if (c) {
-    const int si = segment_of(a.posOff, a.nSeg, g);
-    q = a.seg[si].start + (uint32_t)(g - a.posOff[si]);
+  {
+    int si = segment_of(a.posOff, a.nSeg, g0);
+    if (c) {
+      while (si + 1 < a.nSeg && g >= a.posOff[si + 1]) si++;
+      q = a.seg[si].start + (uint32_t)(g - a.posOff[si]);
+    }
   }
   sIncl[w][lane] = incl;
   sLo[w][lane] = g < a.nPos ? a.lo[g] : 0;
