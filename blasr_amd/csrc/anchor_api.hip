@@ -102,8 +102,11 @@ struct AnchorArgs {
   unsigned long long *probes;   // optional: probes of the index array
 };
 
-__device__ __forceinline__ uint8_t strand_base(const uint8_t *pool, const AnchorSeg &s, uint32_t at) {
-  return s.strand ? rc_nuc(pool[s.off + (int64_t)(s.len - 1 - at)]) : pool[s.off + (int64_t)at];
+// ThreeBit of the strand's base at `at`: the forward read's byte through the table of its strand (three: 512 entries,
+// the second half for the complement)
+__device__ __forceinline__ int strand_code(const uint8_t *pool, const AnchorSeg &s, uint32_t at, const uint8_t *three) {
+  const uint32_t raw = pool[s.off + (int64_t)(s.strand ? s.len - 1 - at : at)];
+  return three[raw + (s.strand ? 256u : 0u)];
 }
 
 // the segment a position of the piece belongs to: the last s with posOff[s] <= g
@@ -287,9 +290,16 @@ __device__ __forceinline__ bool equal_range(const AnchorArgs &a, const uint8_t *
 // kHist: how many of the latest (low, high) pairs stay in registers = max(expand, 1) + 1
 template <int kHist>
 __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
-  __shared__ uint8_t three[256];
+  // three[c]: ThreeBit of a base; three[256 + c]: ThreeBit of its reverse complement; rcChar[c]: the reverse complement
+  // itself -- a read base of the minus strand is then ONE table read like one of the plus strand (ReverseComplementNuc as
+  // eleven compare-and-select pairs cost a minus-strand position ~600 of its ~2 000 vector instructions: thirteen times for
+  // the lookup word, once per descent, eight times per step of the extension)
+  __shared__ uint8_t three[512];
+  __shared__ uint8_t rcChar[256];
   __shared__ uint32_t extWin[256 * kWinStride];
   three[threadIdx.x] = kThreeBit.v[threadIdx.x];
+  rcChar[threadIdx.x] = rc_nuc((uint8_t)threadIdx.x);
+  three[256 + threadIdx.x] = kThreeBit.v[rc_nuc((uint8_t)threadIdx.x)];
   __syncthreads();
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= a.nPos) return;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
     uint64_t tuple = 0;
     bool ok = true;
     for (int i = 0; i < a.prefixLen; i++) {
-      const int c = three[strand_base(a.pool, s, p + (uint32_t)i)];
+      const int c = strand_code(a.pool, s, p + (uint32_t)i, three);
       ok = ok && c < 4;
       tuple = (tuple << 2) + (uint64_t)(c & 3);
     }
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
     if ((a.exp & 2) && lcp >= (uint32_t)(a.prefixLen + kExtBases)) break;
     // the next genome base is an N (a genome as Blasr holds it ends in one, so the array never runs past it)
     if (suffix_symbol(a, three, win, l, lcp, probes) >= 4) break;
-    const int tq = three[strand_base(a.pool, s, p + lcp)];
+    const int tq = strand_code(a.pool, s, p + lcp, three);
     const bool plain = equal_range(a, three, win, lcp, tq, l, r, probes);
     if (l == r) break;
     // (:1044-1051: the suffix at l must hold the read's base; after the plain descent it does by construction)
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
           const uint64_t raw = *reinterpret_cast<const u64u *>(a.pool + s.off + ((int64_t)s.len - 1 - qAt) - 7);
           qw = 0;
 #pragma unroll
-          for (int j = 0; j < 8; j++) qw |= (uint64_t)rc_nuc((uint8_t)(raw >> (8 * (7 - j)))) << (8 * j);
+          for (int j = 0; j < 8; j++) qw |= (uint64_t)rcChar[(uint8_t)(raw >> (8 * (7 - j)))] << (8 * j);
         } else {
           qw = *reinterpret_cast<const u64u *>(a.pool + s.off + qAt);
         }
@@ -432,7 +442,8 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
       }
       while (!ended && refPos + 1 < (int64_t)a.tlen && queryPos + 1 < (int64_t)s.len) {
         const uint8_t gc = a.genome[refPos + 1];
-        if (gc == 'N' || gc != strand_base(a.pool, s, (uint32_t)(queryPos + 1))) break;
+        const uint8_t rawQ = a.pool[s.off + (int64_t)(s.strand ? s.len - 1 - (uint32_t)(queryPos + 1) : (uint32_t)(queryPos + 1))];
+        if (gc == 'N' || gc != (s.strand ? rcChar[rawQ] : rawQ)) break;
         if (!(a.maxLcp == 0 || ext < (uint32_t)a.maxLcp)) break;
         refPos++;
         queryPos++;
