@@ -327,10 +327,28 @@ __global__ __launch_bounds__(256) void anchor_search_kernel(AnchorArgs a) {
   if (a.useLookup) {  // SuffixArray.h:954-990; DNATuple::FromStringLR (tuples/DNATuple.h:24-52)
     uint64_t tuple = 0;
     bool ok = true;
-    for (int i = 0; i < a.prefixLen; i++) {
-      const int c = strand_code(a.pool, s, p + (uint32_t)i, three);
-      ok = ok && c < 4;
-      tuple = (tuple << 2) + (uint64_t)(c & 3);
+    if (a.prefixLen >= 8 && a.prefixLen <= 16) {
+      // the word's bases by two (overlapping) 8-byte loads inside the read instead of a byte load each: bytes [0, 8) and
+      // [prefixLen - 8, prefixLen) of the word -- on the minus strand the same stretch of the forward read, walked backwards
+      const int n = a.prefixLen;
+      const int64_t at0 = s.off + (int64_t)(s.strand ? s.len - 1 - (p + (uint32_t)n - 1u) : p);
+      const uint64_t w0 = *reinterpret_cast<const u64u *>(a.pool + at0), w1 = *reinterpret_cast<const u64u *>(a.pool + at0 + (n - 8));
+      const uint32_t tab = s.strand ? 256u : 0u;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (i >= n) break;
+        const int k = s.strand ? n - 1 - i : i;  // byte of the stretch that holds base i of the word
+        const uint32_t raw = (uint32_t)((k < 8 ? w0 >> (8 * k) : w1 >> (8 * (k - (n - 8)))) & 0xffu);
+        const int c = three[raw + tab];
+        ok = ok && c < 4;
+        tuple = (tuple << 2) + (uint64_t)(c & 3);
+      }
+    } else {
+      for (int i = 0; i < a.prefixLen; i++) {
+        const int c = strand_code(a.pool, s, p + (uint32_t)i, three);
+        ok = ok && c < 4;
+        tuple = (tuple << 2) + (uint64_t)(c & 3);
+      }
     }
     if (ok) {
       if (a.ranges) {
