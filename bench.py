@@ -539,10 +539,33 @@ def other_config_stub(o):
             "parity_checked": cb.get("parity_checked")}
 
 
-def compact_line(out, detail_path=None):
+def minimal_line(out, detail_path=None, note=None):
+    """The last resort of emit(): the contract's fields alone, every free-text field cut short -- a run of several minutes
+    must not end without the driver's line because an optional part of the record grew."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype"))
+    line["metric"] = str(line.get("metric", ""))[:200]
+    line["data"] = "synthetic"
+    line["config"] = {"workload": str((out.get("config") or {}).get("workload_short") or (out.get("config") or {}).get("workload", ""))[:160]}
+    rl = out.get("roofline")
+    line["roofline"] = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")) if rl else None
+    if line["roofline"] and "kernel" in line["roofline"]:
+        line["roofline"]["kernel"] = str(line["roofline"]["kernel"])[:80]
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "parity_checked", "parity_mismatches")) if cb else None
+    if "build_id" in out:
+        line["build_id"] = str(out["build_id"])[:16]
+    if detail_path:
+        line["detail"] = str(detail_path)[:200]
+    line["truncated"] = str(note or "the full line did not fit")[:120]
+    return json.dumps(line, separators=(",", ":"))
+
+
+def compact_line(out, detail_path=None, strict=True):
     """The full record `out` cut down to the one line the driver reads: the contract's fields, `roofline` of the step's
-    dominant kernel, `cpu_baseline`, the wall time of the stages, a stub per other configuration.  Raises when the result
-    would not fit LINE_LIMIT bytes (tests/test_bench_line_cpu.py feeds it full records)."""
+    dominant kernel, `cpu_baseline`, the wall time of the stages, a stub per other configuration.  When the result would
+    not fit LINE_LIMIT bytes even without its optional parts: raises (strict; tests/test_bench_line_cpu.py feeds it full
+    records) or falls back to minimal_line (emit(): a finished run always prints a line the driver can read)."""
     line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype"))
     line["data"] = "synthetic (generated on the device from seeds; see the detail record)"
@@ -590,7 +613,9 @@ def compact_line(out, detail_path=None):
             if len(text) < LINE_LIMIT:
                 break
     if len(text) >= LINE_LIMIT:
-        raise ValueError("bench.py: the driver's line would be %d bytes (limit %d)" % (len(text), LINE_LIMIT))
+        if strict:
+            raise ValueError("bench.py: the driver's line would be %d bytes (limit %d)" % (len(text), LINE_LIMIT))
+        text = minimal_line(out, detail_path, "the compact line would be %d bytes (limit %d)" % (len(text), LINE_LIMIT))
     return text
 
 
@@ -609,7 +634,11 @@ def emit(out, detail_path):
         if isinstance(v, (dict, list)):
             print("[bench detail] %s: %s" % (k, json.dumps(v)))
     sys.stdout.flush()
-    print(compact_line(out, rel))
+    try:
+        text = compact_line(out, rel, strict=False)
+    except Exception as e:  # (a malformed optional part must not cost the run its line either)
+        text = minimal_line(out, rel, "compact_line failed: %s" % e)
+    print(text)
     sys.stdout.flush()
 
 

@@ -660,8 +660,16 @@ void blasr_hip_drop_index(blasr_hip_ctx *ctx) {
   ctx->saRanges = nullptr;
   ctx->saExtGenome = ctx->saExtIndex = nullptr;
   ctx->saOwned = true;
+  ctx->saBorrowedFrom = nullptr;
+  ctx->saBorrowedEpoch = 0;
+  ctx->indexEpoch++;
   ctx->saLen = ctx->saTableLen = 0;
   ctx->saPrefixLen = 0;
+}
+
+// A borrowed index is only good while its owner still holds what was borrowed (the owner outlives the borrower: blasr_hip.h).
+bool blasr_hip_borrowed_index_is_current(const blasr_hip_ctx *ctx) {
+  return ctx->saOwned || (ctx->saBorrowedFrom && ctx->saBorrowedFrom->indexEpoch == ctx->saBorrowedEpoch);
 }
 
 int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st) {
@@ -672,6 +680,7 @@ int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st) {
   ctx->saExt = nullptr;
   if (ctx->saRanges) (void)hipFree(ctx->saRanges);
   ctx->saRanges = nullptr;
+  ctx->indexEpoch++;  // (the companion arrays a borrower holds are gone)
   if (ctx->saTableLen > 0) {  // the lookup table's two arrays as one of pairs (the search reads both ends of a word's range)
     HIP_TRY(ctx, hipMalloc(&ctx->saRanges, sizeof(uint2) * (size_t)ctx->saTableLen));
     hipLaunchKernelGGL(anchor_ranges_kernel, dim3((unsigned)((ctx->saTableLen + 255) / 256)), dim3(256), 0, st, ctx->saStartPos,
@@ -719,6 +728,8 @@ int blasr_hip_borrow_index(blasr_hip_ctx *ctx, blasr_hip_ctx *from) try {
   ctx->saTableLen = from->saTableLen;
   ctx->saPrefixLen = from->saPrefixLen;
   ctx->saOwned = false;
+  ctx->saBorrowedFrom = from;
+  ctx->saBorrowedEpoch = from->indexEpoch;
   return BLASR_HIP_OK;
 } BLASR_HIP_CATCH_CTX(ctx)
 
@@ -843,6 +854,9 @@ int blasr_hip_anchor_reads_device(blasr_hip_ctx *ctx, int32_t n_reads, const bla
     }
   }
 
+  if (!blasr_hip_borrowed_index_is_current(ctx))
+    return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID,
+                          "anchor_reads: the context the index was borrowed from has replaced it since (borrow again)");
   // the companion array of the index, made once per (genome, index) pair
   const bool useExt = !getenv("BLASR_HIP_ANCHOR_NO_EXT");
   if (useExt) {

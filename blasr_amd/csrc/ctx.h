@@ -71,6 +71,12 @@ struct blasr_hip_ctx {
   // the resident suffix array of the genome (blasr_hip_upload_suffix_array): index, the lookup table's ranges
   uint32_t *saIndex = nullptr, *saStartPos = nullptr, *saEndPos = nullptr;
   bool saOwned = true;  // false: index, lookup table and companion array belong to another context (blasr_hip_borrow_index)
+  // Counts every change of what a borrower would share -- genome, index array, lookup table, companion arrays (drop_genome,
+  // blasr_hip_drop_index, blasr_hip_ensure_index_ext).  A borrower keeps the owner and the count it borrowed at: an address
+  // that was freed and handed out again compares equal, the count does not.
+  uint64_t indexEpoch = 0;
+  const blasr_hip_ctx *saBorrowedFrom = nullptr;
+  uint64_t saBorrowedEpoch = 0;
   int64_t saLen = 0, saTableLen = 0;
   int saPrefixLen = 0;
   // per array position, the bases that follow the lookup prefix (anchor_api.hip: the search reads them instead of
@@ -136,6 +142,8 @@ int blasr_hip_fail(blasr_hip_ctx *ctx, int code, const char *fmt, ...);
 void blasr_hip_drop_index(blasr_hip_ctx *ctx);
 // the companion array of the resident index (anchor_api.hip), made once per (genome, index) pair
 int blasr_hip_ensure_index_ext(blasr_hip_ctx *ctx, hipStream_t st);
+// false when the index was borrowed and its owner has replaced or rebuilt any of it since (ctx.h: indexEpoch)
+bool blasr_hip_borrowed_index_is_current(const blasr_hip_ctx *ctx);
 
 // A host array of the mapper that receives device data: a view of one of the context's pinned, grow-only buffers
 // (ctx.h: mapHost).  Not initialised: every element is written by the copy that fills it.

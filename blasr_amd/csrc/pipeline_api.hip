@@ -519,12 +519,21 @@ int map_from_reads_overlapped(blasr_hip_ctx *ctx, const PipeCall &call, int32_t 
     if (rc != BLASR_HIP_OK) return blasr_hip_fail(ctx, rc, "map_from_reads: no helper context");
     ctx->pipeHelper = h;
     // (full-size pieces of the search need 12 GB of workspace: anchor_api.hip's pieceLimit)
-    h->workspaceLimit = std::min<int64_t>(ctx->workspaceLimit, 16ll << 30);
   }
+  // The caller's limit is what the TWO contexts may hold together, and it may have changed since the helper was made: both
+  // limits are set again on every call -- the helper a quarter of it, at most the 16 GB its largest pieces ask for, this
+  // context the rest for the call's duration.
+  struct LimitScope {
+    blasr_hip_ctx *c;
+    int64_t saved;
+    ~LimitScope() { c->workspaceLimit = saved; }
+  } limitScope{ctx, ctx->workspaceLimit};
+  h->workspaceLimit = std::min<int64_t>(ctx->workspaceLimit / 4, 16ll << 30);
+  ctx->workspaceLimit -= h->workspaceLimit;
   const bool wantExt = !getenv("BLASR_HIP_ANCHOR_NO_EXT");
-  if (h->genome != ctx->genome || h->genomeLen != ctx->genomeLen || h->saIndex != ctx->saIndex ||
-      h->saStartPos != ctx->saStartPos || h->saLen != ctx->saLen || h->saPrefixLen != ctx->saPrefixLen ||
-      (wantExt && (!h->saExt || h->saExt != ctx->saExt))) {
+  // what the helper borrowed is compared by the owner's epoch, not by addresses (one freed and handed out again would pass)
+  if (h->saBorrowedFrom != ctx || h->saBorrowedEpoch != ctx->indexEpoch || h->genome != ctx->genome ||
+      (wantExt && !ctx->saExt)) {
     const int rc = blasr_hip_borrow_index(h, ctx);
     if (rc != BLASR_HIP_OK) return blasr_hip_fail(ctx, rc, "map_from_reads: %s", h->lastError.c_str());
   }
@@ -607,7 +616,10 @@ int map_from_reads_overlapped(blasr_hip_ctx *ctx, const PipeCall &call, int32_t 
     const int32_t first = b * perBlock, count = std::min(perBlock, n_reads - first);
     const int64_t nIv = (int64_t)o.ivs.size();
     if ((rc = blasr_hip_ensure(ctx, ctx->pipeIntervals, sizeof(blasr_hip_interval) * (size_t)(nIv + 1))) != BLASR_HIP_OK) break;
-    HIP_TRY(ctx, hipMemcpy(ctx->pipeIntervals.p, o.ivs.data(), sizeof(blasr_hip_interval) * (size_t)nIv, hipMemcpyHostToDevice));
+    // (on the path's own stream: a copy on the null stream would wait for the helper's search as well)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pipeIntervals.p, o.ivs.data(), sizeof(blasr_hip_interval) * (size_t)nIv, hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the mapper's side streams read the intervals too)
     blasr_hip_map_params mapParams = map;
     if (call.wantChains) {
       mapParams.iv_chains = o.chains.data();

@@ -302,8 +302,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       if (const char *e = getenv("BLASR_HIP_CHAIN_SCATTER")) lv.scatterMode = atoi(e);
       // a row per step for the scattered invocations with >= 4 fragments per query row on average and >= 1024 fragments
       // (BLASR_HIP_CHAIN_ROWS="minFrags,densityX2"; "0" switches the kernel off; BLASR_HIP_ROWS_PRIO raises its wavefronts'
-      // priority).  configs[4], three runs each on one box: sweep 528-530 ms with it, 544-646 without (profiles/NOTES.md)
-      lv.rowsNoPrio = getenv("BLASR_HIP_ROWS_PRIO") ? 0 : 1;
+      // priority, which is NOT the default).  configs[4], three runs each on one box: sweep 528-530 ms with it, 544-646 without (profiles/NOTES.md)
+      lv.rowsPrio = getenv("BLASR_HIP_ROWS_PRIO") != nullptr ? 1 : 0;
       lv.rowsMinFrags = 1024;
       lv.rowsDensityX2 = 8;
       if (const char *e = getenv("BLASR_HIP_CHAIN_ROWS")) {

@@ -101,7 +101,7 @@ struct SdpLevelArrays {
   int32_t *chainList, *chainCount;
   int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront;
                                 // 3 sdp_chain_rows_kernel, all of them
-  int rowsNoPrio;                   // experiments (BLASR_HIP_ROWS_NO_PRIO): sdp_chain_rows_kernel without its raised wave priority
+  int rowsPrio;                     // experiments (BLASR_HIP_ROWS_PRIO): sdp_chain_rows_kernel's wavefronts at a raised priority (default: not raised)
   int rowsMinFrags, rowsDensityX2;  // sdp_chain_rows_kernel takes the scattered invocations with at least rowsMinFrags fragments and
                                     // rowsDensityX2 / 2 fragments per query row on average (rowsMinFrags 0: none)
   const int64_t *colOff;        // n+1: first column slot of a task in colEnt (tLen slots for a task that may scatter)

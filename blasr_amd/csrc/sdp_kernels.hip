@@ -3128,8 +3128,9 @@ __global__ __launch_bounds__(64) void sdp_chain_rows_kernel(SdpLevelArrays lv, S
   if (slot >= lv.chainCount[6]) return;
   // These are the level's longest invocations and this is a vector program of ~1000 instructions per row: on a CU it shares
   // with thirty wavefronts of the other sweep kernels it waited its turn for every one of them (the kernel three times as
-  // slow as alone).  Its wavefronts go first.
-  if (!lv.rowsNoPrio) __builtin_amdgcn_s_setprio(3);
+  // slow as alone).  A raised wave priority halves the kernel's own time and does not shorten the level (profiles/NOTES.md,
+  // round 5), so the DEFAULT is the ordinary priority; BLASR_HIP_ROWS_PRIO=1 raises it.
+  if (lv.rowsPrio) __builtin_amdgcn_s_setprio(3);
   const int idx = lv.chainList[chain_list_start(lv, 6) + slot];
   const SdpTask t = lv.tasks[idx];
   const int F = lv.nFrag[idx];
@@ -4836,9 +4837,12 @@ void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool w
   // three size classes, so that the usual targets (<= kIdxSmallCap) get four workgroups per CU
   const int grid = std::min(lv.n, 1024);
   const int caps[3] = {std::min(kIdxSmallCap, lv.idxMaxT), std::min(kIdxMidCap, lv.idxMaxT), lv.idxMaxT};
-  const int conc = side ? 3 : 1;
-  // (one bracket per stream: the copy kernel and the first size class on `st`, the larger classes on `side`)
-  for (int part = 0; part < (side ? 2 : 1); part++) {
+  // (one bracket per stream that gets a launch: the copy kernel and the first size class on `st`, the larger classes -- where
+  //  the level has any -- on `side`; `concurrent` = the streams this kernel's launches are spread over, + 1 for the matchers
+  //  of the shorter targets that run beside them)
+  const bool sideUsed = side != nullptr && caps[1] > caps[0];
+  const int conc = side ? (sideUsed ? 3 : 2) : 1;
+  for (int part = 0; part < (sideUsed ? 2 : 1); part++) {
     hipStream_t s = part == 0 ? st : side;
     SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_MATCH_INDEX, s, conc);
     if (part == 0 && write) hipLaunchKernelGGL(sdp_match_index_copy_kernel, dim3(std::min(lv.n, 8192)), dim3(256), 0, st, lv, seq);

@@ -175,6 +175,7 @@ void drop_genome(blasr_hip_ctx *ctx) {
   if (ctx->contigStarts) (void)hipFree(ctx->contigStarts);
   ctx->genome = nullptr;
   ctx->saExtGenome = nullptr;  // (anchor_api.hip's companion array was made from this genome)
+  ctx->indexEpoch++;           // (what a borrower shares has changed: blasr_hip_borrow_index)
   ctx->genomeOwned = true;
   ctx->contigStarts = nullptr;
   ctx->genomeLen = 0;

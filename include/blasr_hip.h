@@ -902,8 +902,10 @@ int blasr_hip_upload_suffix_array(blasr_hip_ctx *ctx, const uint32_t *index, int
 /* A second context on the same device that anchors in the genome and the index `from` holds, without a copy of either
  * (one context per mapping thread next to its MappingBuffers, alignment/Blasr.cpp:3238, all reading the one SuffixArray
  * of main(), :4360-4440): genome, contig table, index array, lookup table and the search's companion array are shared,
- * streams, workspace and result buffers are the context's own.  `from` must outlive the borrower or the borrower must
- * borrow again after `from` has uploaded / built another index. */
+ * streams, workspace and result buffers are the context's own.  `from` must outlive the borrower, and it must be IDLE
+ * during this call (no call on it from another thread: the companion arrays of its index are made on its stream here when
+ * it has not anchored yet).  After `from` has uploaded / built another genome or index the borrower must borrow again: its
+ * anchor calls fail with BLASR_HIP_ERR_INVALID until it has (the owner counts such changes; addresses are not compared). */
 int blasr_hip_borrow_index(blasr_hip_ctx *ctx, blasr_hip_ctx *from);
 /* reads: HOST table; read_pool: device (forward strands, ASCII); anchors: device, at most capacity records;
  * *n_anchors receives the number needed (BLASR_HIP_ERR_CAPACITY when it exceeds capacity; nothing is valid then).

@@ -216,6 +216,14 @@ def test_a_second_context_anchors_in_a_borrowed_index():
     with pytest.raises(hip.BlasrHipError):
         other.borrow_index(empty)
     empty.close()
+    # the owner replaces its index: the borrower's pointers are stale, and it is told so instead of searching freed memory
+    # (the owner counts its changes; an address handed out again by the allocator would compare equal)
+    owner.upload_suffix_array(sa)
+    with pytest.raises(hip.BlasrHipError, match="borrow again"):
+        other.anchor_reads(reads, pool, p)
+    other.borrow_index(owner)
+    a3, off3 = other.anchor_reads(reads, pool, p)
+    assert np.array_equal(off0, off3) and np.array_equal(as_triples(a0), as_triples(a3))
     other.close()  # (frees nothing of the owner's)
     a2, off2 = owner.anchor_reads(reads, pool, p)
     assert np.array_equal(as_triples(a0), as_triples(a2))

@@ -79,3 +79,28 @@ def test_no_record_means_an_error_not_an_oversized_line():
         assert "limit" in str(e)
     else:
         raise AssertionError("a line beyond the limit was returned")
+
+
+def test_emit_falls_back_to_a_minimal_line_instead_of_losing_the_run(tmp_path):
+    """A finished run always ends with a line the driver can parse: what does not fit is dropped down to the contract's fields."""
+    rec = full_record()
+    rec["other_configs"] = {"configuration %d %s" % (i, "n" * 60): rec["other_configs"]["configs[1]"] for i in range(40)}
+    rec["metric"] = rec["metric"] + " " + "m" * 5000
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(rec, str(tmp_path / "detail.json"))
+    last = buf.getvalue().splitlines()[-1]
+    assert len(last) < bench.LINE_LIMIT
+    line = json.loads(last)
+    assert line["truncated"] and abs(line["value"] - rec["value"]) < 1e-4 * rec["value"]
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "config",
+              "roofline", "cpu_baseline", "build_id"):
+        assert k in line, k
+    assert abs(line["roofline"]["frac"] - rec["roofline"]["frac"]) < 1e-5 and line["cpu_baseline"]["parity_mismatches"] == 0
+    # a malformed optional part is no reason either
+    rec2 = full_record()
+    rec2["other_configs"] = ["not", "a", "dict"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(rec2, None)
+    assert json.loads(buf.getvalue().splitlines()[-1])["truncated"].startswith("compact_line failed")
