@@ -361,7 +361,13 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       phaseBytes[1] += totalQ * 8;
       lv.qPosOff = qPosOff;
       lv.hits = arena.get<uint64_t>((size_t)std::max<int64_t>(totalQ, 1));
+      if (k >= 16) {  // (k: the level's largest word) the query's tuples as StoreMatchingPositions makes them (sdp_kernels.hip: kKeyBases)
+        uint64_t *qWords = arena.get<uint64_t>((size_t)std::max<int64_t>(totalQ, 1));
+        lv.qWords = qWords;
+        phaseBytes[1] += totalQ * 8;
+      }
       ARENA_CHECK();
+      launch_sdp_query_words(lv, b->seq, st);
     }
     const bool matchSerial = getenv("BLASR_HIP_MATCH_SERIAL") != nullptr;
     launch_sdp_match_all(lv, b->seq, false, st, matchSerial ? nullptr : ctx->auxStream, matchSerial ? nullptr : ctx->auxEvent);
@@ -833,10 +839,11 @@ int blasr_hip_sdp_device(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const
   if (n == 0) return BLASR_HIP_OK;
   if (!b->seq || !b->q_off || !b->q_len || !b->t_off || !b->t_len || !results || (!blocks && blocksCap > 0))
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_INVALID, "null pointer in batch");
-  if ((sp->align_type != 0 && sp->align_type != 1) || sp->word_size < 1 || sp->word_size > 16 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
+  if ((sp->align_type != 0 && sp->align_type != 1) || sp->word_size < 1 || sp->word_size > 32 || sp->recurse < 0 || sp->prefix_length < 0 || sp->sdp_ins <= -64 ||
       sp->sdp_ins >= 64 || sp->sdp_del <= -64 || sp->sdp_del >= 64)
     return blasr_hip_fail(ctx, BLASR_HIP_ERR_UNSUPPORTED,
-                          "SDP parameters outside the device domain (align_type Local/Global, 1 <= word_size <= 16, "
+                          "SDP parameters outside the device domain (align_type Local/Global, 1 <= word_size <= 32 -- a tuple is 64 bits, "
+                          "tuples/DNATuple.h:55-94 --, "
                           "|sdp_ins|, |sdp_del| < 64)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // ---- chunks.  The level arrays take ~35 bytes per base of query + target (fragments, keys, the sweep's arrays,

@@ -78,6 +78,7 @@ struct SdpLevelArrays {
   uint64_t *keys;          // target k-mer keys, sorted per task
   const int64_t *qPosOff;  // n+1, exclusive scan of qLen
   uint64_t *hits;          // per query position: index of the first matching key | match count << 32
+  uint64_t *qWords;        // per query position (same offsets): the reference's query tuple, where words have >= 16 bases; else nullptr
   int32_t *nRaw;           // 3n: prefix / middle / suffix fragment counts
   const int64_t *fragOff;  // n+1, exclusive scan of the raw fragment counts
   Frag *raw;               // prefix | middle | suffix fragments as StoreMatchingPositions emits them
@@ -137,6 +138,8 @@ struct SdpEmit {
 };
 
 void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st);
+// the query's tuples as StoreMatchingPositions makes them, for the invocations with words of sixteen bases and more (lv.qWords)
+void launch_sdp_query_words(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st);
 void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st);
 void launch_sdp_sort_yx(const SdpLevelArrays &lv, uint64_t *tmpKeys, uint32_t *tmpIdx, hipStream_t st);
 void launch_sdp_match(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side = nullptr);

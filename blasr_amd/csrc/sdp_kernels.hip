@@ -77,8 +77,29 @@ constexpr int kWideSets = 8;         // register sets of 64 column-set entries i
 __host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragments) {
   return t.type == 1 && rawFragments > 16 && t.tLen <= kBitsMaxTarget;
 }
+// Words of kKeyBases bases and more (-sdpTupleSize 16 .. 32; a tuple is 64 bits, tuples/DNATuple.h:55-94).  Two things change
+// there.  (i) The sort key of a target position holds the tuple's LOW 32 bits -- the word's first sixteen bases; with kPosBits
+// of position and the "no tuple here" bit that is the 64 bits of a key -- and the tuple's upper half is compared on the target's
+// bases when the keys agree (target_tuple_high).  The list is sorted by (tuple, position) (DNATuple.h:147-154) and positions
+// only leave it, so matches, their order, counts and maxMatchesPerPosition stay the reference's.  (ii) The QUERY's tuples are
+// not its words: StoreMatchingPositions (TupleMatching.h:37-61) makes the first tuple of a clean stretch with FromStringRL
+// (64-bit, exact) and every later one with ShiftAddRL (DNATuple.h:85-94), `tuple += (TwoBit[nuc] << ((tupleSize-1)*2))` with
+// `static int TwoBit[]` (NucConversion.h:7): a 32-bit shift by 30 and more.  Undefined in C++; what the reference's builds
+// compute is the count mod 32 and the int sign-extended into the sum, a recurrence over the whole stretch
+// (sdp_query_words_kernel restates it, one lane per invocation; oracle/blasr_oracle.c: store_matching_positions; pinned to the
+// reference built here by tests/golden/long_words_golden.npz).
+constexpr int kKeyBases = 16;
+__host__ __device__ inline int key_bases(int k) { return k < kKeyBases ? k : kKeyBases; }
+// (the tiny targets' register path keeps a word in 32 bits with two values set aside for "no word": words of fewer than 16 bases)
+__host__ __device__ inline bool task_is_tiny(int tLen, int k) { return tLen <= kTinyT && k < kKeyBases; }
 __host__ __device__ inline bool task_needs_keys(int tLen, int k, int idxMaxT) {
-  return tLen > kTinyT && !task_uses_index(tLen, k, idxMaxT);
+  return !task_is_tiny(tLen, k) && !task_uses_index(tLen, k, idxMaxT);
+}
+// bits 32 .. 2k - 1 of the tuple of the k-base word at t (all ACGT): its bases 16 .. k - 1
+__device__ __forceinline__ uint32_t target_tuple_high(const uint8_t *t, int k) {
+  uint32_t v = 0;
+  for (int j = kKeyBases; j < k; j++) v |= (uint32_t)(base_code(t[j]) & 3) << (2 * (j - kKeyBases));
+  return v;
 }
 
 __device__ __forceinline__ int wave_task_index() {
@@ -112,7 +133,8 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
   const SdpTask t = lv.tasks[idx];
   uint64_t *keys = lv.keys + lv.keyOff[idx];
   const uint8_t *tSeq = seq + t.tOff;
-  const uint64_t invalid = 1ull << (kPosBits + 2 * t.k);
+  const int kk = key_bases(t.k);
+  const uint64_t invalid = 1ull << (kPosBits + 2 * kk);
   for (int p0 = 0; p0 < t.tLen; p0 += 64) {
     const int p = p0 + lane;
     if (p < t.tLen) {
@@ -123,13 +145,55 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
         for (int j = 0; j < t.k; j++) {
           const int c = base_code(tSeq[p + j]);
           ok = ok && c < 4;
-          kmer |= (uint64_t)(c & 3) << (2 * j);
+          if (j < kk) kmer |= (uint64_t)(c & 3) << (2 * j);
         }
         if (ok) key = (kmer << kPosBits) | (uint64_t)p;
       }
       keys[p] = key;
     }
   }
+  }
+}
+
+// The query's tuples of the invocations with words of sixteen bases and more, as the reference's StoreMatchingPositions makes
+// them (see kKeyBases above): one LANE per invocation walks its query.  Position s has a tuple iff its window is ACGT
+// throughout (the matchers test that themselves); the first tuple of such a stretch is the word, the later ones follow
+// ShiftAddRL's 32-bit shift as compiled.  qWords[s] = the tuple, for every window of the query.
+__global__ __launch_bounds__(256) void sdp_query_words_kernel(SdpLevelArrays lv, const uint8_t *seq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lv.n) return;
+  const SdpTask t = lv.tasks[i];
+  const int k = t.k;
+  if (k < kKeyBases) return;
+  const uint8_t *q = seq + t.qOff;
+  uint64_t *w = lv.qWords + lv.qPosOff[i];
+  const int sh = (2 * (k - 1)) & 31;
+  bool res = false;  // the position before had a tuple (TupleMatching.h:44-47)
+  uint64_t tup = 0;
+  int lastBad = -1;  // the last base that is not ACGT among q[0 .. s + k - 1]
+  for (int j = 0; j < k - 1 && j < t.qLen; j++)
+    if (base_code(q[j]) >= 4) lastBad = j;
+  for (int s = 0; s + k <= t.qLen; s++) {
+    const int c = base_code(q[s + k - 1]);
+    if (c >= 4) lastBad = s + k - 1;
+    if (res) {  // ShiftAddRL (DNATuple.h:85-94)
+      if (c >= 4) {
+        res = false;
+      } else {
+        tup >>= 2;
+        tup += (uint64_t)(int64_t)(int32_t)((uint32_t)c << sh);
+      }
+    }
+    if (!res && lastBad < s) {  // FromStringRL (:55-83): the last base in the highest bits
+      tup = 0;
+      for (int j = k - 1; j > 0; j--) {
+        tup += (uint64_t)(base_code(q[s + j]) & 3);
+        tup <<= 2;
+      }
+      tup += (uint64_t)(base_code(q[s]) & 3);
+      res = true;
+    }
+    w[s] = tup;
   }
 }
 
@@ -245,7 +309,7 @@ __global__ __launch_bounds__(256) void sdp_sort_keys_kernel(SdpLevelArrays lv, u
     const SdpTask t = lv.tasks[idx];
     uint64_t *a = lv.keys + lv.keyOff[idx], *b = tmp + lv.keyOff[idx];
     bool inB;
-    wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * t.k + 1, hist[threadIdx.x >> 6], inB);
+    wave_radix_sort<false>(a, b, nullptr, nullptr, t.tLen, kPosBits, kPosBits + 2 * key_bases(t.k) + 1, hist[threadIdx.x >> 6], inB);
     if (inB)
       for (int i = lane; i < t.tLen; i += 64) a[i] = b[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1048,8 +1112,9 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
   // middle (part 1): the whole query against the sorted k-mer keys of the whole target.
   // For long targets the binary search is narrowed by a bucket index over the leading k-mer bits that the
   // wavefront builds in LDS from the sorted keys (one pass), instead of ~2 x log2(tLen) dependent HBM reads.
-  const int bBits = 2 * k < kBucketBits ? 2 * k : kBucketBits;
-  const int bShift = kPosBits + 2 * k - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
+  const int kk = key_bases(k);  // (the bases of a word the keys hold; a longer word's other bases are compared below)
+  const int bBits = 2 * kk < kBucketBits ? 2 * kk : kBucketBits;
+  const int bShift = kPosBits + 2 * kk - bBits;  // key >> bShift = bucket (invalid keys land beyond the last bucket)
   const bool useBuckets = kBuckets;  // (t.tLen <= kTinyT takes the register path below)
   uint32_t *bucket = bucketLds;
   if (useBuckets) {
@@ -1065,7 +1130,8 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
   }
   int nM = 0;
   uint64_t *hits = lv.hits + lv.qPosOff[idx];  // per query position: first matching key | count << 32
-  const bool tiny = !kBuckets && t.tLen <= kTinyT;  // (the instantiation with the bucket index only sees targets >= 256)
+  const uint64_t *qWords = k >= kKeyBases ? lv.qWords + lv.qPosOff[idx] : nullptr;
+  const bool tiny = !kBuckets && task_is_tiny(t.tLen, k);  // (the instantiation with the bucket index only sees targets >= 256)
   if (tiny) {
     // the target's k-mers in registers (positions lane and lane + 64); every query k-mer is compared with
     // all of them in position order, which is the order of the sorted tuple list
@@ -1175,6 +1241,7 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
     int sLo[4], sHi[4];
     uint64_t sKey[4];
     bool okP[2];
+    uint32_t qHigh[2] = {0u, 0u};
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int x = x0 + 64 * u + lane;
@@ -1183,11 +1250,16 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
       for (int j = 0; j < k; j++) {
         const int c = base_code(qSeq[min(x + j, t.qLen - 1)]);
         ok = ok && c < 4;
-        kmer |= (uint64_t)(c & 3) << (2 * j);
+        if (j < kk) kmer |= (uint64_t)(c & 3) << (2 * j);
+      }
+      if (k >= kKeyBases) {  // the reference's tuple of this position, not the word (sdp_query_words_kernel)
+        const uint64_t word = ok ? qWords[x] : 0ull;
+        kmer = word & 0xffffffffull;
+        qHigh[u] = (uint32_t)(word >> 32);
       }
       int rLo = 0, rHi = ok ? t.tLen : 0;
       if (useBuckets && ok) {
-        const int b = (int)(kmer >> (2 * k - bBits));
+        const int b = (int)(kmer >> (2 * kk - bBits));
         rLo = (int)bucket[b];
         rHi = (int)bucket[b + 1];
       }
@@ -1221,6 +1293,14 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
     for (int u = 0; u < 2; u++) {
       const int x = x0 + 64 * u + lane;
       int cnt = okP[u] ? sLo[2 * u + 1] - sLo[2 * u] : 0;
+      if (k >= kKeyBases && cnt > 0) {  // equal keys: the tuples agree in their low halves -- count those that agree throughout
+        int pass = 0;
+        for (int j = 0; j < cnt; j++) {
+          const int y = (int)(keys[sLo[2 * u] + j] & ((1ull << kPosBits) - 1));
+          pass += target_tuple_high(tSeq + y, k) == qHigh[u] ? 1 : 0;
+        }
+        cnt = pass;
+      }
       if (t.maxPerPos != 0 && cnt > t.maxPerPos) cnt = 0;
       if (x + k <= t.qLen) hits[x] = (uint64_t)(uint32_t)(okP[u] ? sLo[2 * u] : 0) | ((uint64_t)(uint32_t)cnt << 32);
       cntBoth += cnt;
@@ -1241,12 +1321,12 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
         for (int j = 0; j < k; j++) {
           const int c = base_code(qSeq[x + j]);
           ok = ok && c < 4;
-          kmer |= (uint64_t)(c & 3) << (2 * j);
+          if (j < kk) kmer |= (uint64_t)(c & 3) << (2 * j);
         }
         if (ok) {
           int rLo = 0, rHi = t.tLen;
           if (useBuckets) {
-            const int b = (int)(kmer >> (2 * k - bBits));
+            const int b = (int)(kmer >> (2 * kk - bBits));
             rLo = (int)bucket[b];
             rHi = (int)bucket[b + 1];
           }
@@ -1261,13 +1341,18 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
     const unsigned incl = wave_prefix_sum((unsigned)cnt);
     if (kWrite && cnt > 0) {
       int w = written + nM + (int)incl - cnt;
-      for (int j = 0; j < cnt; j++) {
+      // (a word of sixteen bases and more: `lo` is the first equal KEY and `cnt` the keys behind it whose tuples agree
+      //  throughout -- the count pass found that many, so the walk ends)
+      const uint32_t high = k >= kKeyBases ? (uint32_t)(qWords[x] >> 32) : 0u;
+      for (int j = 0, done = 0; done < cnt; j++) {
         Frag f;
         f.x = (uint32_t)x;
         f.y = (uint32_t)(keys[lo + j] & ((1ull << kPosBits) - 1));
         f.len = (uint32_t)k;
         f.pad = 0;
+        if (k >= kKeyBases && target_tuple_high(tSeq + f.y, k) != high) continue;
         out[w++] = f;
+        done++;
       }
     }
     nM += __builtin_amdgcn_readlane((int)incl, 63);
@@ -4753,6 +4838,10 @@ static dim3 general_grid(const SdpLevelArrays &lv) { return lv.generalMode == 2 
 
 void launch_sdp_keys(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_keys_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, seq);
+}
+void launch_sdp_query_words(const SdpLevelArrays &lv, const uint8_t *seq, hipStream_t st) {
+  if (lv.n > 0 && lv.qWords != nullptr)
+    hipLaunchKernelGGL(sdp_query_words_kernel, dim3((unsigned)((lv.n + 255) / 256)), dim3(256), 0, st, lv, seq);
 }
 void launch_sdp_sort_keys(const SdpLevelArrays &lv, uint64_t *tmp, hipStream_t st) {
   if (lv.n > 0) hipLaunchKernelGGL(sdp_sort_keys_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, tmp);

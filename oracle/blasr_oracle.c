@@ -854,37 +854,60 @@ static void fvec_push(fvec_t *fv, uint32_t x, uint32_t y, uint32_t weight, uint3
 }
 
 /* StoreMatchingPositions (TupleMatching.h:37-61): note ThreeBit (not IsACTG)
- * decides k-mer validity on the query side; identical on ACGTN input. */
+ * decides k-mer validity on the query side; identical on ACGTN input.
+ *
+ * Words of 16 bases and more.  The query's tuples are NOT built the way the target's are: the first one of a clean stretch
+ * comes from FromStringRL (DNATuple.h:55-83, 64-bit arithmetic, exact), every later one from ShiftAddRL (:85-94),
+ *     tuple >>= 2;  tuple += (TwoBit[nuc] << ((tm.tupleSize-1)*2));
+ * and TwoBit is `static int[]` (NucConversion.h:7): the shift is done in 32-bit int.  For tupleSize == 16 a G or T shifted by
+ * 30 overflows int; from 17 on the count is >= 32.  Both are undefined in C++; what every build of the reference on x86-64
+ * (and AArch64) computes is the shift with its count taken mod 32 and the int result sign-extended into the 64-bit sum --
+ * `sall %cl, %eax; cltq; addq` -- so that from 16 bases on the query's tuples after the first of a stretch are not its words
+ * and match the target's (which ARE its words, DNATuple.h:308-359) only by accident.  The recurrence is restated as
+ * compiled; tests/test_oracle_vs_ref.py and tests/golden/long_words_golden.npz pin it to the reference built here. */
 static void store_matching_positions(const unsigned char *qs, uint32_t qn, int k, const ptuple_t *tl,
                                      int tn, int maxMatches, uint32_t xOff, uint32_t yOff,
                                      uint32_t weight, uint32_t length, fvec_t *out) {
   if (k < 1 || qn < (uint32_t)k) return;
-  uint32_t run = 0;
+  int res = 0; /* the previous position had a tuple (TupleMatching.h:44-47) */
   uint64_t tup = 0;
-  for (uint32_t i = 0; i < qn; i++) {
-    if (g_three[qs[i]] <= 3) {
-      run++;
-      tup >>= 2;
-      tup += ((uint64_t)g_two[qs[i]]) << (2 * (k - 1));
-      if (run >= (uint32_t)k) {
-        uint32_t s = i + 1 - k;
-        int lo = 0, hi = tn;
-        while (lo < hi) {
-          int mid = (lo + hi) / 2;
-          if (tl[mid].tuple < tup)
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-        int end = lo;
-        while (end < tn && tl[end].tuple == tup) end++;
-        if (maxMatches == 0 || end - lo <= maxMatches)
-          for (int j = lo; j < end; j++) fvec_push(out, s + xOff, tl[j].pos + yOff, weight, length);
+  const int sh = (2 * (k - 1)) & 31;
+  for (uint32_t s = 0; s + (uint32_t)k <= qn; s++) {
+    if (res) { /* ShiftAddRL with the base that enters the window */
+      const unsigned char nuc = qs[s + k - 1];
+      if (g_three[nuc] > 3) {
+        res = 0;
+      } else {
+        tup >>= 2;
+        tup += (uint64_t)(int64_t)(int32_t)((uint32_t)g_two[nuc] << sh);
       }
-    } else {
-      run = 0;
-      tup = 0;
     }
+    if (!res) { /* FromStringRL: only a window of ACGT has a tuple */
+      int clean = 1;
+      for (int j = 0; j < k; j++) clean = clean && g_three[qs[s + j]] <= 3;
+      if (clean) {
+        tup = 0;
+        for (int j = k - 1; j > 0; j--) {
+          tup += (uint64_t)g_two[qs[s + j]];
+          tup <<= 2;
+        }
+        tup += (uint64_t)g_two[qs[s]];
+        res = 1;
+      }
+    }
+    if (!res) continue;
+    int lo = 0, hi = tn;
+    while (lo < hi) {
+      int mid = (lo + hi) / 2;
+      if (tl[mid].tuple < tup)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    int end = lo;
+    while (end < tn && tl[end].tuple == tup) end++;
+    if (maxMatches == 0 || end - lo <= maxMatches)
+      for (int j = lo; j < end; j++) fvec_push(out, s + xOff, tl[j].pos + yOff, weight, length);
   }
 }
 

@@ -1301,3 +1301,50 @@ def nonguided_golden_cases():
                                     pct=np.float32(g[p + "pct"]), blocks=g[p + "blocks"], gapCounts=g[p + "gapCounts"],
                                     gapItems=g[p + "gapItems"])))
     return g["genome"], cases
+
+
+def long_word_cases(rng, n=60):
+    """(query, target, SdpParams) for -sdpTupleSize 14 .. 32 (a tuple is 64 bits, tuples/DNATuple.h:55-94): pairs clean enough
+    to share words of that length; targets of every size class of the device's matchers (under 129 bases, under 256, up to a few
+    thousand); tandem repeats whose copies agree in their first sixteen bases and differ behind them, or not at all (many equal
+    words per position, maxMatchesPerPosition); runs of N; both alignment types; recursion (the children's words are k - 4
+    and k / 2 bases: above sixteen too)."""
+    from blasr_amd import synth
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    cases = []
+    for it in range(n):
+        kind = it % 6
+        k = int(rng.integers(14, 33)) if it >= 8 else (16, 17, 19, 20, 24, 31, 32, 32)[it]
+        qlen = int({0: rng.integers(20, 120), 1: rng.integers(100, 250), 2: rng.integers(200, 1400)}.get(kind, rng.integers(300, 5000)))
+        er = dict(ins=float(rng.uniform(0, 0.03)), dele=float(rng.uniform(0, 0.02)), sub=float(rng.uniform(0, 0.01)))
+        flank = (0, 0) if kind in (0, 1) and it % 2 else (0, int(rng.integers(0, 60)))
+        q, t = synth.make_pair(rng, qlen, flank=flank, n_run=int(rng.integers(1, 12)) if kind == 4 else None, **er)
+        if kind in (3, 5):  # a tandem repeat planted in both: units of 18 .. 40 bases
+            unit = acgt[rng.integers(0, 4, size=int(rng.integers(18, 41)))]
+            copies = int(rng.integers(3, 12))
+            rep = np.tile(unit, copies)
+            if kind == 5:  # every other copy differs in one base behind the sixteenth
+                for c in range(1, copies, 2):
+                    at = c * len(unit) + int(rng.integers(16, len(unit)))
+                    rep[at] = acgt[(int(np.searchsorted(acgt, rep[at])) + 1) % 4]
+            q, t = q.copy(), t.copy()
+            aq, at_ = int(rng.integers(0, max(1, len(q) - len(rep)))), int(rng.integers(0, max(1, len(t) - len(rep))))
+            q[aq: aq + len(rep)] = rep[: len(q) - aq]
+            t[at_: at_ + len(rep)] = rep[: len(t) - at_]
+        sp = SdpParams(k=k, align_type=int(rng.integers(0, 2)), recurse=int(rng.integers(0, 3)),
+                       recurse_over=int(rng.choice([100, 1000])), max_per_pos=int(rng.choice([0, 0, 2, 5])),
+                       prefix=int(rng.choice([0, 20, 50])), detailed=int(rng.integers(0, 2)) if it % 5 == 0 else 1)
+        cases.append((np.ascontiguousarray(q), np.ascontiguousarray(t), sp))
+    return cases
+
+
+def long_word_golden_cases():
+    """tests/golden/long_words_golden.npz (the reference's own SDPAlign on long_word_cases; make_long_words_golden.py)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "long_words_golden.npz"))
+    out = []
+    for i in range(int(g["n"])):
+        p = "c%d_" % i
+        v = [int(x) for x in g[p + "par"]]
+        sp = SdpParams(k=v[0], align_type=v[1], recurse=v[2], recurse_over=v[3], max_per_pos=v[4], prefix=v[5], detailed=v[6])
+        out.append((g[p + "q"], g[p + "t"], sp, dict(score=v[7], qPos=v[8], tPos=v[9], blocks=g[p + "blocks"].reshape(-1, 3))))
+    return out

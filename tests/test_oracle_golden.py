@@ -122,3 +122,14 @@ def test_oracle_nonguided_refine_matches_golden(oracle):
         assert w["pct"] == np.float32(got["pct"]), i
         assert np.array_equal(w["blocks"], got["blocks"]) and np.array_equal(w["gapCounts"], got["gapCounts"]) and \
             np.array_equal(w["gapItems"], got["gapItems"]), i
+
+
+def test_words_of_up_to_32_bases_golden(oracle):
+    """tests/golden/long_words_golden.npz: the reference's SDPAlign with -sdpTupleSize 14 .. 32."""
+    from blasr_testlib import long_word_golden_cases
+    from golden_cases import first_difference
+    cases = long_word_golden_cases()
+    assert len(cases) >= 40 and max(sp.k for _, _, sp, _ in cases) == 32
+    for i, (q, t, sp, want) in enumerate(cases):
+        got = oracle.sdp_align(q, t, None, sp)
+        assert first_difference(got, want, ["score", "qPos", "tPos", "blocks"]) is None, (i, vars(sp))

@@ -60,6 +60,18 @@ def test_parameter_variety_sweep(oracle, ref):
         assert first_difference(a2, b2, REFINE_KEYS) is None, it
 
 
+def test_words_of_up_to_32_bases(oracle, ref):
+    """-sdpTupleSize beyond 16 (a tuple is 64 bits, tuples/DNATuple.h:55-94): the oracle's tuples against the reference's, on
+    the cases the device's tests use (blasr_testlib.long_word_cases)."""
+    from blasr_testlib import long_word_cases
+    some = 0
+    for it, (q, t, sp) in enumerate(long_word_cases(np.random.default_rng(31), 90)):
+        a, b = oracle.sdp_align(q, t, None, sp), ref.sdp_align(q, t, None, sp)
+        assert first_difference(a, b, ["score", "qPos", "tPos", "blocks"]) is None, (it, vars(sp))
+        some += len(b["blocks"]) > 0
+    assert some >= 60
+
+
 def test_long_noisy_reads(oracle, ref):
     rng = np.random.default_rng(13)
     for qlen, er in ((10000, dict(ins=0.11, dele=0.04, sub=0.01)), (20000, dict(ins=0.10, dele=0.05, sub=0.01))):

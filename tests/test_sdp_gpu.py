@@ -131,10 +131,34 @@ def test_extend_front_and_coarse_alignment_on_noisy_reads(ctx, oracle):
 
 
 def test_unsupported_parameters_are_rejected(ctx):
-    q = np.frombuffer(b"ACGTACGTACGTACGTACGT", np.uint8)
-    with pytest.raises(blasr_amd.BlasrHipError) as e:
-        ctx.sdp([(q, q)], blasr_amd.SdpParams(k=17))
-    assert e.value.code == blasr_amd.hip.ERR_UNSUPPORTED
+    q = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT", np.uint8)
+    for k in (0, 33):  # (a tuple is 64 bits: the reference's own shifts are undefined beyond 32 bases)
+        with pytest.raises(blasr_amd.BlasrHipError) as e:
+            ctx.sdp([(q, q)], blasr_amd.SdpParams(k=k))
+        assert e.value.code == blasr_amd.hip.ERR_UNSUPPORTED
+
+
+def test_words_of_up_to_32_bases(ctx, oracle):
+    """-sdpTupleSize 14 .. 32 (tuples/DNATuple.h:55-94): the sort key holds a word's first sixteen bases, the rest is
+    compared on the sequences.  The reference's own results (tests/golden/long_words_golden.npz), one by one and as a batch
+    of mixed word sizes is not possible -- the word size is the call's --, then random cases against the oracle."""
+    from blasr_testlib import long_word_cases, long_word_golden_cases
+    n = 0
+    for i, (q, t, sp, want) in enumerate(long_word_golden_cases()):
+        got = ctx.sdp([(q, t)], _sdp_params(sp))[0]
+        assert got["status"] == 0, i
+        assert (got["score"], got["qPos"], got["tPos"]) == (want["score"], want["qPos"], want["tPos"]), (i, vars(sp))
+        assert np.array_equal(got["blocks"], want["blocks"]), (i, vars(sp))
+        n += len(want["blocks"]) > 0
+    assert n >= 30
+    cases = long_word_cases(np.random.default_rng(207), 120)
+    for k in sorted({sp.k for _, _, sp in cases}):  # batches by word size, the other parameters those of the batch's first case
+        group = [(q, t) for q, t, sp in cases if sp.k == k]
+        sp0 = next(sp for _, _, sp in cases if sp.k == k)
+        for (q, t), g in zip(group, ctx.sdp(group, _sdp_params(sp0))):
+            w = oracle.sdp_align(q, t, None, sp0)
+            st = oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"])
+            _check(g, w, [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]], (k, len(q), len(t)))
 
 
 def _repetitive_pair(rng, qlen, unit_len, copies):
