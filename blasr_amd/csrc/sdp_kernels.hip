@@ -86,8 +86,8 @@ __host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragme
 // (64-bit, exact) and every later one with ShiftAddRL (DNATuple.h:85-94), `tuple += (TwoBit[nuc] << ((tupleSize-1)*2))` with
 // `static int TwoBit[]` (NucConversion.h:7): a 32-bit shift by 30 and more.  Undefined in C++; what the reference's builds
 // compute is the count mod 32 and the int sign-extended into the sum, a recurrence over the whole stretch
-// (sdp_query_words_kernel restates it, one lane per invocation; oracle/blasr_oracle.c: store_matching_positions; pinned to the
-// reference built here by tests/golden/long_words_golden.npz).
+// (sdp_query_words_kernel restates it, one lane per invocation; pinned to the reference built from its own sources by
+// tests/golden/long_words_golden.npz).
 constexpr int kKeyBases = 16;
 __host__ __device__ inline int key_bases(int k) { return k < kKeyBases ? k : kKeyBases; }
 // (the tiny targets' register path keeps a word in 32 bits with two values set aside for "no word": words of fewer than 16 bases)
