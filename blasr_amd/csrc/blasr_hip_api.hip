@@ -278,6 +278,7 @@ const char *blasr_hip_kernel_name(int kind, int ext0) {
     case BLASR_HIP_KERNEL_FILL_NARROW:
       return ext0 ? "blasr_hip::fillp_kernel<16, true, false>" : "blasr_hip::fillp_kernel<16, false, false>";
     case BLASR_HIP_KERNEL_FILL_HYBRID:
+      if (ext0 == 2) return "blasr_hip::fillh8_kernel";
       return ext0 ? "blasr_hip::fillp_kernel<16, true, true>" : "blasr_hip::fillp_kernel<16, false, true>";
     case BLASR_HIP_KERNEL_FILL_WAVE:
       return "blasr_hip::fill_kernel";
@@ -346,9 +347,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
                oArenaOff = carve(sizeof(int64_t) * n);
   const size_t oOpsStart = carve(sizeof(int32_t) * n), oDp = carve(sizeof(int32_t) * n);
   const size_t oMatrix = carve(sizeof(int32_t) * 25), oTotal = carve(sizeof(int64_t));
-  // (+ 4: the hybrid kernel's list is padded to whole wavefronts)
-  const size_t oWideTasks = carve(sizeof(int32_t) * ((size_t)n + 4)), oWideOff = carve(sizeof(int64_t) * ((size_t)n + 4)),
-               oWideSize = carve(sizeof(int32_t) * ((size_t)n + 4));
+  // (+ 8: the hybrid kernels' list is padded to whole wavefronts of four or eight candidates)
+  const size_t oWideTasks = carve(sizeof(int32_t) * ((size_t)n + 8)), oWideOff = carve(sizeof(int64_t) * ((size_t)n + 8)),
+               oWideSize = carve(sizeof(int32_t) * ((size_t)n + 8));
   const size_t oList4 = carve(sizeof(int32_t) * n), oList1 = carve(sizeof(int32_t) * n);
   const size_t fixedBytes = off;
   // first make room for the fixed part + a modest variable part; grown below once the geometry is known
@@ -435,6 +436,12 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   // wavefront, wide rows by the whole wavefront through a global ring) unless switched off
   const bool hybrid = packed && !getenv("BLASR_HIP_NO_HYBRID");
   const int wideOver = hybrid ? fill4_max_width() : kLdsMaxWidth;
+  // fill8_kernel's domain (extension penalty 0, matrix entries that fit 6 bits, columns that fit its 20-bit row records): the
+  // narrow list runs eight candidates per wavefront, each at its own row, and so do the narrow rows of the hybrid list
+  // (fillh8_kernel, round 6; BLASR_HIP_HYBRID4 keeps fillp_kernel<16, ., true>, four in lockstep)
+  bool six = packed && getenv("BLASR_HIP_FILL_LANES16") == nullptr && score->affine_extend == 0 && longest < (1 << 20) - 4096;
+  for (int i = 0; i < 25; i++) six = six && score->matrix[i] >= -32 && score->matrix[i] <= 31;
+  const bool hybrid8 = hybrid && six && !getenv("BLASR_HIP_HYBRID4");
 
   // ---- plan: contiguous chunks of candidates that fit the workspace ----------
   Plan plan;
@@ -632,15 +639,16 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         //  wavefronts; kept for experiments.)
         std::vector<int32_t> order((size_t)nw);
         for (int u = 0; u < nw; u++) order[(size_t)u] = u;
-        const int W = (nw + 3) / 4;
-        std::vector<int32_t> t2((size_t)W * 4, -1), s2((size_t)W * 4, 512);
-        std::vector<int64_t> o2((size_t)W * 4, 0);
+        const int G = hybrid8 ? 8 : 4;  // candidates per wavefront
+        const int W = (nw + G - 1) / G;
+        std::vector<int32_t> t2((size_t)W * G, -1), s2((size_t)W * G, 512);
+        std::vector<int64_t> o2((size_t)W * G, 0);
         auto place = [&](size_t slot, int32_t u) {
           t2[slot] = c.wideTasks[(size_t)u];
           o2[slot] = c.wideRingOff[(size_t)u];
           s2[slot] = c.wideRingSize[(size_t)u];
         };
-        const char *orderEnv = getenv("BLASR_HIP_HYBRID_ORDER");
+        const char *orderEnv = hybrid8 ? nullptr : getenv("BLASR_HIP_HYBRID_ORDER");  // (the experiments are the four-form's)
         if (orderEnv && !strcmp(orderEnv, "lpt")) {
           // The four candidates of a wavefront step through their narrow rows together, so a wavefront costs
           // (its longest candidate's rows) x (a narrow step) + (the wide cells of all four): candidates of about the same
@@ -685,7 +693,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
           std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
             return geo[c.wideTasks[(size_t)a]].cells > geo[c.wideTasks[(size_t)b]].cells;
           });
-          for (int p = 0; p < nw; p++) place((size_t)(p % W) * 4 + (size_t)(p / W), order[(size_t)p]);
+          for (int p = 0; p < nw; p++) place((size_t)(p % W) * G + (size_t)(p / W), order[(size_t)p]);
         } else {
           std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
             return geo[c.wideTasks[(size_t)a]].rows > geo[c.wideTasks[(size_t)b]].rows;
@@ -703,7 +711,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         c.wideTasks.swap(t2);
         c.wideRingOff.swap(o2);
         c.wideRingSize.swap(s2);
-        nw = W * 4;
+        nw = W * G;
       }
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
@@ -729,10 +737,11 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       for (int32_t t : c.wideTasks)
         if (t >= 0) count_fill(wideKind, geo[t]);
       ctx->kernelRec[wideKind].launches += 1;
+      if (hybrid8) ctx->kernelRec[wideKind].ext0 = 2;  // (blasr_hip_kernel_name: fillh8_kernel)
       if (getenv("BLASR_HIP_FILL_SERIAL")) {  // measurement: every fill kernel alone on the main stream
         HIP_TRY(ctx, hipEventRecord(evHy[0], st));
         if (hybrid)
-          launch_fill_hybrid(view, fw, st);
+          launch_fill_hybrid(view, fw, st, hybrid8);
         else
           launch_fill(view, fw, true, fast, st);
         HIP_TRY(ctx, hipEventRecord(evHy[1], st));
@@ -743,7 +752,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->sideStream, ev[7], 0));  // the uploads and everything before them
       HIP_TRY(ctx, hipEventRecord(evHy[0], ctx->sideStream));
       if (hybrid)
-        launch_fill_hybrid(view, fw, ctx->sideStream);
+        launch_fill_hybrid(view, fw, ctx->sideStream, hybrid8);
       else
         launch_fill(view, fw, true, fast, ctx->sideStream);
       HIP_TRY(ctx, hipEventRecord(evHy[1], ctx->sideStream));
@@ -785,9 +794,6 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         f4.taskList = dList4;
         f4.count = (int)list4.size();
         HIP_TRY(ctx, hipEventRecord(evF4[0], st));
-        // fill8_kernel's domain: extension penalty 0, matrix entries that fit 6 bits, columns that fit its 20-bit row records
-        bool six = getenv("BLASR_HIP_FILL_LANES16") == nullptr && score->affine_extend == 0 && longest < (1 << 20) - 4096;
-        for (int i = 0; i < 25; i++) six = six && score->matrix[i] >= -32 && score->matrix[i] <= 31;
         const int narrowKind = six ? BLASR_HIP_KERNEL_FILL_EIGHT : BLASR_HIP_KERNEL_FILL_NARROW;
         launch_fill4(view, f4, six ? 8 : 16, st);
         HIP_TRY(ctx, hipEventRecord(evF4[1], st));

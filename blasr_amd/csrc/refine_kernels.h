@@ -92,7 +92,8 @@ void launch_fill(const RefineBatchView &batch, const FillArgs &args, bool global
 // four candidates per wavefront (tagged-key variant only); args.taskList / args.count name the candidates
 void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes, hipStream_t stream);
 int fill4_max_width();
-void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream);
+// eight: fillh8_kernel (the list padded to eight candidates per wavefront, fill8_kernel's domain), else fillp_kernel<16, ., true> (four)
+void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream, bool eight = false);
 // trace only: row-width histogram of the candidates of args.taskList (10 classes x 4 counters)
 void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigned long long *hist, hipStream_t stream);
 // afterWalk (may be null): recorded behind traceback_kernel, before runs_kernel / stats_kernel

@@ -1683,6 +1683,577 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     args.dpScore[myTask] = ring[(myTEnd - 1) & (kF4Ring - 1)].x >> kShift;
 }
 
+// ---------------------------------------------------------------------------
+// fillh8_kernel: the hybrid list (candidates with a row wider than kF4MaxWidth) in fill8_kernel's form.
+//
+// The hybrid instantiation of fillp_kernel steps its four candidates through their narrow rows in lockstep: 131 vector
+// instructions per pass of four rows, and 40 % of those row steps carry a second pass because ONE of the four rows is wider
+// than 48 columns (the hybrid list's narrow rows: 57 % at most 33 cells, 19 % 34-40, 4 % 41-48, 8 % 49-112) -- 0.97
+// wavefront instructions per narrow cell where fill8_kernel spends 0.81.  Here the narrow rows ARE fill8_kernel's: eight
+// candidates per wavefront, eight lanes x five cells each, every candidate at its own row and pass, 1280 bytes of LDS per
+// candidate (ring, staged codes, a window of sixteen row records) and no load from memory inside the loop.  A candidate that
+// meets a WIDE row hands the wavefront to the wide paths -- the other seven wait, as the other three did; the time the
+// wavefront spends there is the same either way -- which are fillp_kernel's: a RUN of wide rows with the row above in
+// registers (three cells per lane, 192 columns per step, up to 576), or one row through the candidate's ring in global memory.
+// What those paths need of the following rows (a run is found by looking at them) comes from memory when the wavefront
+// ENTERS the wide mode, lane = row, sixty-four records in one round trip, and is read off the lanes (v_readlane) -- the
+// 8-lane layout has no LDS for fillp_kernel's 64-row batches.  A piece (a run, or one row) per entry; the candidate comes back
+// to its narrow rows with the row above in its LDS ring, the eight entries behind it set to "no cell" as fill8_kernel's rows
+// leave them.  The wide paths take their substitution scores like the narrow rows: 6-bit fields of ONE register, the matrix
+// row of the query base (uniform in a wide row), indexed by the target's code x 6 -- no table in LDS, so the kernel has exactly
+// fill8_kernel's 40 KB per workgroup.  Domain: fill8_kernel's (extension penalty 0, matrix entries within [-32, 31], target
+// spans below 2^20); other parameters keep fillp_kernel<16, ., true>.
+// ---------------------------------------------------------------------------
+constexpr int kH8Wide = 255;  // the width field of a window record whose row is a wide one (the true width comes from memory)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void fillh8_kernel(RefineBatchView batch, FillArgs args) {
+  constexpr int kL = 8, kT = 8, kC = kF8Pass / kL, kPass = kF8Pass;
+  __shared__ int2 ringLds[4][kT][kF4Ring];
+  __shared__ uint8_t ringTLds[4][kT][kF4RingT];
+  __shared__ uint2 rowWin[4][kT][kF8Rows];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int grp = lane / kL, l = lane % kL;
+  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * kT;
+  if (slot0 >= args.count) return;
+  int2 *ring = ringLds[wave][grp];
+  uint8_t *ringT = ringTLds[wave][grp];
+  uint2 *win = rowWin[wave][grp];
+  // lane qc (0..4, N = 4) holds the matrix row of query code qc, 6 bits per target code (fill8_kernel)
+  uint32_t row6Table = 0;
+#pragma unroll
+  for (int tc = 0; tc < 5; tc++) row6Table |= (uint32_t)(args.matrix[min(lane, 4) * 5 + tc] & 0x3f) << (6 * tc);
+
+  int myTask = -1, myQ = 0, myTEnd = 0, myTLen = 0, myPlo = 0, myPhi = -1, myBase = 0, myGMask = 0;
+  unsigned myCells = 0;
+  bool myPrevGlobal = false;  // the row above lives in the candidate's ring in global memory
+  const int2 *tab = nullptr;
+  const unsigned short *meta = nullptr;
+  const uint8_t *myTSeq = nullptr;
+  uint8_t *myArrows = nullptr;
+  int2 *myGRing = nullptr;
+  if (slot0 + grp < args.count) myTask = args.taskList[slot0 + grp];  // (the list has empty slots: -1)
+  if (myTask >= 0) {
+    const int32_t *blocks = batch.blocks + 3 * batch.blk_off[myTask];
+    const int nBlocks = batch.n_blocks[myTask];
+    GuideCursor cur;
+    guide_begin(cur, blocks, nBlocks, args.band);
+    myQ = cur.Q;
+    myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+    myTLen = batch.t_len[myTask];
+    myTSeq = batch.seq + batch.t_off[myTask];
+    myArrows = args.arrows + args.arrowOff[myTask];
+    tab = args.rowTab + args.rowOff[myTask];
+    meta = args.rowMeta + args.rowOff[myTask];
+    myBase = cur.tStart - 1;
+    myPlo = myBase;
+    myPhi = myPlo + guide_row0_tpost(cur);
+    myCells = (unsigned)args.geo[myTask].cells;
+    myGMask = args.wideRingSize[slot0 + grp] - 1;
+    myGRing = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot0 + grp]);
+  }
+  const int inf = 1 << 30;
+  const int kIns = args.ins << kShift, kDel = args.del << kShift, kOpen = args.open << kShift;
+  int pDel[kC];
+#pragma unroll
+  for (int j = 0; j < kC; j++) pDel[j] = (kC * l + j) * kDel;
+  // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open; a wide row 0 goes to the global ring
+  if (myTask >= 0) {
+    if (myPhi - myPlo + 1 > kF4MaxWidth) {
+      for (int c = myPlo + l; c <= myPhi; c += kL) myGRing[c & myGMask] = make_int2((c - myPlo) * kDel, kOpen);
+      myPrevGlobal = true;
+    } else {
+      for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+      ring[(myPhi + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);
+    }
+  }
+  int myTLoaded = (myPlo < 0 ? 0 : myPlo) & ~3;  // columns below it are staged; whole dwords of codes
+  const int tLast = max(myTLen - 1, 0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // a value / a pointer of candidate g, uniform, from its first lane
+  auto from_group = [&](int v, int g) { return __builtin_amdgcn_readlane(v, g * kL); };
+  auto ptr_from_group = [&](const void *p, int g) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, g * kL);
+    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), g * kL);
+    return ((uint64_t)hi32 << 32) | lo32;
+  };
+
+  int myRow = 1, myPass = 0, stagedEnd = 1;  // records of rows below stagedEnd (and not below myRow) are in the window
+  int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
+  bool alive = myTask >= 0 && myRow <= myQ;
+  uint2 recCur = make_uint2(0u, 0u);
+  while (__ballot(alive) != 0ull) {
+    // ---- row records: when one candidate has used up its window, all of them fill theirs
+    if (__ballot(alive && myRow >= stagedEnd) != 0ull) {
+      if (alive) {
+        const int newEnd = min(myRow + kF8Rows, myQ + 1);
+#pragma unroll
+        for (int k = 0; k < kF8Rows / kL; k++) {
+          const int r = stagedEnd + l + kL * k;
+          if (r < newEnd) {
+            const int2 rec = tab[r];
+            const unsigned m = meta[r];
+            const unsigned w = m & 0xfffu;
+            win[r & (kF8Rows - 1)] = make_uint2((unsigned)rec.x, (unsigned)(rec.y - myBase) |
+                                                                     ((w > (unsigned)kF4MaxWidth ? (unsigned)kH8Wide : w) << 20) |
+                                                                     (min(m >> 12, 4u) << 28));
+          }
+        }
+        stagedEnd = newEnd;
+      }
+      __builtin_amdgcn_wave_barrier();
+      recCur = win[myRow & (kF8Rows - 1)];
+    }
+    const int lo = myBase + (int)(recCur.y & 0xfffffu), width = (int)((recCur.y >> 20) & 0xffu);
+    const int hiC = lo + width - 1;
+    // ---- wide rows: the wavefront takes them one candidate after the other, a piece (a run, or one row) each
+    const unsigned long long wideMask = __ballot(alive && width > kF4MaxWidth);
+    if (wideMask != 0ull) {
+#pragma unroll 1
+      for (int g = 0; g < kT; g++) {
+        if (((wideMask >> (g * kL)) & 1ull) == 0ull) continue;
+        const int src = g * kL;
+        const int wRow = __builtin_amdgcn_readlane(myRow, src), wQ = __builtin_amdgcn_readlane(myQ, src);
+        const int nG = min(64, wQ - wRow + 1);  // rows of candidate g from this one on, as far as the lanes hold them
+        const int tEndOfG = from_group(myTEnd, g), tLenOfG = from_group(myTLen, g), gmask = from_group(myGMask, g);
+        const int wPlo = __builtin_amdgcn_readlane(myPlo, src), wPhi = __builtin_amdgcn_readlane(myPhi, src);
+        const bool wGlobal = __builtin_amdgcn_readlane((int)myPrevGlobal, src) != 0;
+        const uint64_t arrowsOfG = ptr_from_group(myArrows, g), tSeqOfG = ptr_from_group(myTSeq, g);
+        // ---- the records of rows wRow .. wRow + 63, lane = row: {arrow offset, first column, width, query code}
+        int recX = 0, recLo = 0, recW = 0, recQc = 0;
+        {
+          const int2 *tabG = (const int2 *)ptr_from_group(tab, g);
+          const unsigned short *metaG = (const unsigned short *)ptr_from_group(meta, g);
+          if (lane < nG) {
+            const int2 rec = tabG[wRow + lane];
+            const unsigned m = metaG[wRow + lane];
+            int w = (int)(m & 0xfffu);
+            if (w == 0xfff) {  // saturated: the row's cells are what lies before the next row's first one
+              const unsigned next = wRow + lane < wQ ? (unsigned)tabG[wRow + lane + 1].x : (unsigned)from_group((int)myCells, g);
+              const int hi = rec.y + (int)(next - (unsigned)rec.x) - 1;
+              w = min(hi, tEndOfG - 1) - rec.y + 1;
+            }
+            recX = rec.x;
+            recLo = rec.y;
+            recW = w;
+            recQc = (int)min(m >> 12, 4u);
+          }
+        }
+        const int wLo = __builtin_amdgcn_readlane(recLo, 0), wHi = wLo + __builtin_amdgcn_readlane(recW, 0) - 1;
+        // (explicitly global: as generic pointers these become FLAT accesses, whose lgkmcnt the LDS reads then wait on)
+        typedef unsigned long long __attribute__((address_space(1))) GPair;  // {S, I} of a ring entry
+        typedef uint8_t __attribute__((address_space(1))) GByte;
+        GPair *gring = (GPair *)ptr_from_group(myGRing, g);
+        auto pair_of = [](int2 v) { return (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32); };
+        auto int2_of = [](unsigned long long p) { return make_int2((int)(uint32_t)p, (int)(uint32_t)(p >> 32)); };
+        // target code x 6 of column c (N = 4 beyond the target's ends too)
+        auto code6_at = [&](const GByte *wT, int c) {
+          const uint32_t b = (uint32_t)wT[min(max(c, 0), max(tLenOfG - 1, 0))];
+          return (uint32_t)((c >= 0 && c < tLenOfG) ? base_code(b) : 4) * 6u;
+        };
+        int consumed = 0;     // rows this piece takes
+        bool toNarrow = false;
+        int newPlo = wPlo, newPhi = wPhi;
+        // ---- A RUN of wide rows, the row above in REGISTERS (fillp_kernel's run path: three consecutive cells per lane, 192
+        // columns per step, up to three steps per row; cell (step, lane, j) = column base + 3 (64 step + lane) + j)
+        {
+          constexpr int kW = 3, kWStep = 64 * kW, kRunSteps = 3, kRunMax = kRunSteps * kWStep;
+          int run = 0;
+          if (wHi - wLo + 1 <= kRunMax && wPhi - wLo + 1 <= kRunMax) {
+            int pS[kRunSteps][kW], pI[kRunSteps][kW];
+            int base = wLo, prevLo = wPlo, prevHi = wPhi;
+#pragma unroll
+            for (int k = 0; k < kRunSteps; k++)
+#pragma unroll
+              for (int j = 0; j < kW; j++) {
+                const int c = wLo + kW * (64 * k + lane) + j;
+                const bool valid = c >= wPlo && c <= wPhi;
+                int2 v = make_int2(inf, inf);
+                if (wGlobal) v = int2_of(gring[c & gmask]);
+                else if (k == 0) v = ringLds[wave][g][c & (kF4Ring - 1)];  // (a narrow row ends within the first step)
+                pS[k][j] = valid ? v.x : inf;
+                pI[k][j] = valid ? v.y : inf;
+              }
+            int leftS = inf;  // S of the row above at column base - 1
+            if (wLo - 1 >= wPlo && wLo - 1 <= wPhi)
+              leftS = wGlobal ? (int)(uint32_t)gring[(wLo - 1) & gmask] : ringLds[wave][g][(wLo - 1) & (kF4Ring - 1)].x;
+            leftS = __builtin_amdgcn_readfirstlane(leftS);
+            GByte *aBase = (GByte *)arrowsOfG;
+            const GByte *wT = (const GByte *)tSeqOfG;
+            // the target's codes x 6 of the 576 columns from `base` on, three to a register like the cells, loaded once per
+            // run and handed on by the same lane shift as the row above
+            uint32_t tP[kRunSteps];
+#pragma unroll
+            for (int k = 0; k < kRunSteps; k++) {
+              tP[k] = 0;
+#pragma unroll
+              for (int j = 0; j < kW; j++) tP[k] |= code6_at(wT, wLo + kW * (64 * k + lane) + j) << (8 * j);
+            }
+            for (int ii = 0; ii < nG; ii++) {
+              const int rLo = __builtin_amdgcn_readlane(recLo, ii), rWidth = __builtin_amdgcn_readlane(recW, ii);
+              const int rHi = rLo + rWidth - 1, d = rLo - base;
+              if (rWidth <= kF4MaxWidth || rWidth > kRunMax || d < 0 || d > 1) break;
+              const uint32_t row6 = (uint32_t)__builtin_amdgcn_readlane((int)row6Table, __builtin_amdgcn_readlane(recQc, ii));
+              GByte *rowArrows = aBase + (unsigned)__builtin_amdgcn_readlane(recX, ii);
+              if (d == 1) {  // the window of codes moves one column on: column base + 576 enters at its end
+                uint32_t first[kRunSteps + 1];
+#pragma unroll
+                for (int k = 0; k < kRunSteps; k++) first[k] = (uint32_t)__builtin_amdgcn_readlane((int)tP[k], 0) & 0xffu;
+                first[kRunSteps] = (uint32_t)__builtin_amdgcn_readfirstlane((int)code6_at(wT, base + kRunMax));
+#pragma unroll
+                for (int k = 0; k < kRunSteps; k++)
+                  tP[k] = (tP[k] >> 8) | (((uint32_t)wave_shl1((int)tP[k], (int)first[k + 1]) & 0xffu) << (8 * (kW - 1)));
+              }
+              int ePrevOld = inf;
+              int wCarryA = inf, wCarryB = inf;
+#pragma unroll
+              for (int k = 0; k < kRunSteps; k++) {
+                if (rLo + kWStep * k > rHi) break;
+                const int c0 = rLo + kW * (64 * k + lane);
+                int upS[kW], upI[kW], diagS[kW];
+                if (d == 0) {
+                  const int eOld = __builtin_amdgcn_readlane(pS[k][kW - 1], 63);
+                  int dg = wave_shr1(pS[k][kW - 1], inf);
+                  dg = lane == 0 ? (k == 0 ? leftS : ePrevOld) : dg;
+                  ePrevOld = eOld;
+                  diagS[0] = dg;
+#pragma unroll
+                  for (int j = 0; j < kW; j++) {
+                    upS[j] = pS[k][j];
+                    upI[j] = pI[k][j];
+                    if (j > 0) diagS[j] = pS[k][j - 1];
+                  }
+                } else {
+#pragma unroll
+                  for (int j = 0; j < kW; j++) {
+                    diagS[j] = pS[k][j];
+                    if (j + 1 < kW) {
+                      upS[j] = pS[k][j + 1];
+                      upI[j] = pI[k][j + 1];
+                    }
+                  }
+                  upS[kW - 1] = wave_shl1(pS[k][0], k + 1 < kRunSteps ? __builtin_amdgcn_readlane(pS[k + 1 < kRunSteps ? k + 1 : k][0], 0) : inf);
+                  upI[kW - 1] = wave_shl1(pI[k][0], k + 1 < kRunSteps ? __builtin_amdgcn_readlane(pI[k + 1 < kRunSteps ? k + 1 : k][0], 0) : inf);
+                }
+                // cells of the row above that do not exist: only a step that reaches beyond that row's ends has any
+                if (!(rLo + kWStep * k - 1 >= prevLo && rLo + kWStep * (k + 1) - 1 <= prevHi)) {
+#pragma unroll
+                  for (int j = 0; j < kW; j++) {
+                    const int c = c0 + j;
+                    const bool upValid = c <= prevHi, diagValid = c - 1 <= prevHi && c - 1 >= prevLo;  // (c >= rLo >= prevLo)
+                    upS[j] = upValid ? upS[j] : inf;
+                    upI[j] = upValid ? upI[j] : inf;
+                    diagS[j] = diagValid ? diagS[j] : inf;
+                  }
+                }
+                int vKey[kW], preA[kW], preB[kW];
+#pragma unroll
+                for (int j = 0; j < kW; j++) {
+                  const int m = (int)__builtin_amdgcn_sbfe((int)row6, (tP[k] >> (8 * j)) & 0xffu, 6);
+                  const int matchK = (m << kShift) + diagS[j];
+                  const int insSK = upS[j] + (kIns + AR_UP);
+                  const int insEK = upI[j] + AR_INS_CLOSE;
+                  vKey[j] = min(matchK, min(insSK, insEK));
+                  const int v = vKey[j] & ~kTagMask;
+                  const int ia = v - (kW * lane + j) * kDel;
+                  preA[j] = j == 0 ? ia : min(preA[j - 1], ia);
+                  preB[j] = j == 0 ? v : min(preB[j - 1], v);
+                }
+                int pa = preA[kW - 1], pb = preB[kW - 1];
+                wave_prefix_min2(pa, pb);
+                int ea = wave_shr1(pa, inf), eb = wave_shr1(pb, inf);
+                if (k > 0) {
+                  ea = min(ea, wCarryA);
+                  eb = min(eb, wCarryB);
+                }
+                uint32_t arrowLo = 0, arrowHi = 0;  // (cells 0 .. kW - 2 in arrowLo, the last one in arrowHi)
+#pragma unroll
+                for (int j = 0; j < kW; j++) {
+                  const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
+                  const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
+                  const int aK = eaj + ((kW * lane + j) * kDel + AR_LEFT);  // S[c-1] + del
+                  const int bK = ebj + (kOpen + AR_DEL_CLOSE);              // D[c-1] + ext
+                  const int sKey = min(vKey[j], min(aK, bK));
+                  const int sv = sKey & ~kTagMask;
+                  const int openKey = sv + (kOpen + AR_I_OPEN);
+                  const int iKey = min(openKey, upI[j]);
+                  const int dFlag = openKey < bK ? AR_D_OPEN : 0;
+                  const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag) & kTagMask;
+                  if (j < kW - 1) arrowLo |= arrow << (8 * j); else arrowHi = arrow;
+                  pS[k][j] = sv;  // (cells beyond the row's end hold what no later row takes for a cell: prevHi)
+                  pI[k][j] = iKey & ~kTagMask;
+                }
+                if (c0 <= rHi) {  // three arrows per lane; those beyond the row's end land in the next row's space
+                  typedef unaligned_u16 __attribute__((address_space(1))) GU16;
+                  GByte *ap = rowArrows + (c0 - rLo);
+                  *(GU16 *)ap = (uint16_t)arrowLo;
+                  ap[kW - 1] = (uint8_t)arrowHi;
+                }
+                wCarryA = min(wCarryA, __builtin_amdgcn_readlane(pa, 63)) + kWStep * kDel;
+                wCarryB = min(wCarryB, __builtin_amdgcn_readlane(pb, 63));
+              }
+              base = prevLo = rLo;
+              prevHi = rHi;
+              leftS = inf;  // (column base - 1 lies left of the row just made)
+              run++;
+            }
+            if (run > 0) {
+              // ---- the run's last row: to where the next row will look for it
+              int keepLo = prevLo, keepHi = prevHi;
+              if (run < nG) {
+                const int nLo = __builtin_amdgcn_readlane(recLo, run), nWidth = __builtin_amdgcn_readlane(recW, run);
+                if (nWidth <= kF4MaxWidth) {
+                  toNarrow = true;
+                  keepLo = max(keepLo, nLo - 1);
+                  keepHi = min(keepHi, nLo + nWidth - 1);
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < kRunSteps; k++)
+#pragma unroll
+                for (int j = 0; j < kW; j++) {
+                  const int c = base + kW * (64 * k + lane) + j;
+                  if (c >= keepLo && c <= keepHi) {
+                    if (toNarrow) ringLds[wave][g][c & (kF4Ring - 1)] = make_int2(pS[k][j], pI[k][j]);
+                    else gring[c & gmask] = pair_of(make_int2(pS[k][j], pI[k][j]));
+                  }
+                }
+              // (the entries behind it that the narrow rows read without a test: "no cell")
+              if (toNarrow && lane < kF8Clean) ringLds[wave][g][(keepHi + 1 + lane) & (kF4Ring - 1)] = make_int2(inf, inf);
+              consumed = run;
+              newPlo = prevLo;
+              newPhi = toNarrow ? keepHi : prevHi;
+            }
+          }
+        }
+        if (consumed == 0) {
+          // ---- ONE wide row through the candidate's ring in global memory (fill_kernel's step, 64 columns at a time): a row
+          // wider than a run holds, or one that starts more than a column further on
+          const int wQc = __builtin_amdgcn_readlane(recQc, 0);
+          const uint32_t row6 = (uint32_t)__builtin_amdgcn_readlane((int)row6Table, wQc);
+          if (!wGlobal) {  // the row above is a narrow one: from the LDS ring into the global ring
+            for (int c = wPlo + lane; c <= wPhi; c += 64) gring[c & gmask] = pair_of(ringLds[wave][g][c & (kF4Ring - 1)]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+          // which of this row's {S, I} the next row can read: a narrow one only its own columns (and one to their left); the
+          // candidate's last row only feeds the final score
+          int keepLo = INT32_MIN, keepHi = INT32_MAX;
+          if (wRow == wQ) {
+            keepLo = keepHi = tEndOfG - 1;
+          } else if (nG > 1) {
+            const int nLo = __builtin_amdgcn_readlane(recLo, 1), nWidth = __builtin_amdgcn_readlane(recW, 1);
+            if (nWidth <= kF4MaxWidth) {
+              keepLo = nLo - 1;
+              keepHi = nLo + nWidth - 1;
+            }
+          }
+          GByte *wArrows = (GByte *)(arrowsOfG + (unsigned)__builtin_amdgcn_readlane(recX, 0));
+          const GByte *wT = (const GByte *)tSeqOfG;
+          RowConsts<true> kc;
+          kc.inf = inf;
+          kc.ins = kIns;
+          kc.del = kDel;
+          kc.open = kOpen;
+          kc.ext = 0;
+          kc.laneDel = lane * kDel;
+          kc.laneExt = 0;
+          ChunkCarry carry;
+          carry.a = carry.b = carry.s = inf;
+          int cDiag = 0;
+          // the target bases and the row above run one step ahead of their use, two sets of registers taking turns, the
+          // loads of the step after issued unconditionally (fillp_kernel's wide step)
+          const int tLastG = max(tLenOfG - 1, 0);
+          int tA = (int)wT[min(max(wLo + lane, 0), tLastG)], tB = 'N';
+          int2 upA = int2_of(gring[(wLo + lane) & gmask]), upB = make_int2(inf, inf);
+          if (wLo <= wPhi + 1 && lane == 0) cDiag = (int)(uint32_t)gring[(wLo - 1) & gmask];
+          auto wideStep = [&](const int cb, const int tRaw, int2 up, int &tNext, int2 &upNext) {
+            const int c = cb + lane;
+            const bool active = c <= wHi;
+            int sd = inf;
+            tNext = (int)wT[min(max(c + 64, 0), tLastG)];
+            upNext = int2_of(gring[(c + 64) & gmask]);
+            const int code = (c >= 0 && c < tLenOfG) ? base_code((unsigned)tRaw) : 4;
+            if (cb <= wPhi + 1) {
+              sd = wave_shr1(up.x, inf);
+              sd = (lane == 0) ? __builtin_amdgcn_readfirstlane(cDiag) : sd;
+              cDiag = __builtin_amdgcn_readlane(up.x, 63);
+              const bool upValid = c <= wPhi, diagValid = (c - 1 <= wPhi) && (c > wPlo);
+              up.x = upValid ? up.x : inf;
+              up.y = upValid ? up.y : inf;
+              sd = diagValid ? sd : inf;
+            } else {  // beyond the row above there is nothing: whatever the ring slot held is not it
+              up = make_int2(inf, inf);
+            }
+            const int mm = (int)__builtin_amdgcn_sbfe((int)row6, (unsigned)(code * 6), 6);
+            int sv, iv, arrow;
+            row_chunk<true, false>(kc, carry, active, up.x, up.y, sd, mm, sv, iv, arrow);
+            if (active) {
+              if (c >= keepLo && c <= keepHi) gring[c & gmask] = pair_of(make_int2(sv, iv));
+              wArrows[c - wLo] = (uint8_t)arrow;
+            }
+          };
+          for (int cb = wLo; cb <= wHi; cb += 128) {
+            wideStep(cb, tA, upA, tB, upB);
+            if (cb + 64 <= wHi) wideStep(cb + 64, tB, upB, tA, upA);
+          }
+          consumed = 1;
+          newPlo = wLo;
+          newPhi = wHi;
+        }
+        // (this piece's stores are read by the rows after it only: one wait for all of them)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (grp == g) {
+          myPlo = newPlo;
+          myPhi = newPhi;
+          myPrevGlobal = !toNarrow;
+          myRow += consumed;
+          myPass = 0;
+          alive = myRow <= myQ;
+          if (myRow >= stagedEnd) stagedEnd = myRow;       // (the window is filled from there at the head of the loop)
+          else recCur = win[myRow & (kF8Rows - 1)];
+        }
+      }
+      continue;
+    }
+    // ---- back to narrow rows from a wide one that went to the global ring: the columns this row reads of it, into the LDS ring
+    if (__ballot(alive && myPrevGlobal) != 0ull) {
+      if (alive && myPrevGlobal) {
+        const int last = min(hiC, myPhi);
+        for (int c = lo - 1 + l; c <= last; c += kL)
+          if (c >= myPlo) ring[c & (kF4Ring - 1)] = myGRing[c & myGMask];
+        ring[(last + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);
+        myPhi = last;
+        myPrevGlobal = false;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const uint2 recNext = win[(myRow + 1) & (kF8Rows - 1)];  // (the row after this one, if the window has it)
+    // ---- the target's codes: when one candidate has run out, all of them stage as far as their ring holds
+    if (__ballot(alive && hiC >= myTLoaded) != 0ull) {
+      if (alive) {
+        myTLoaded = max(myTLoaded, lo & ~3);
+        const int limit = (lo & ~3) + kF4RingT;  // the first column whose slot still holds one this row may read
+        const int c = myTLoaded + 16 * l;
+        uint32_t b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = (uint32_t)myTSeq[min(c + k, tLast)];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int cc = c + 4 * k4 + k;
+            const int code = cc < myTLen ? base_code(b[4 * k4 + k]) : 4;
+            w |= (uint32_t)(code * 6) << (8 * k);
+          }
+          if (c + 4 * k4 < limit) *reinterpret_cast<uint32_t *>(&ringT[(c + 4 * k4) & (kF4RingT - 1)]) = w;
+        }
+        myTLoaded = min(myTLoaded + 16 * kL, limit);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- one pass of my candidate's row: columns cb .. cb + 39 (fill8_kernel's)
+    uint8_t *arrowRow = myArrows + recCur.x;
+    const int cb = lo + kPass * myPass, c0 = cb + kC * l;
+    int upS[kC], upI[kC], diagS[kC];
+    int d0 = ring[(c0 - 1) & (kF4Ring - 1)].x;
+    d0 = (myPass > 0 && l == 0) ? carryDiag : d0;  // column cb-1 was overwritten by the pass before
+    d0 = c0 - 1 >= myPlo ? d0 : inf;               // (lane 0 of a row that starts where the row above did)
+    int lastRaw = 0;
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int2 up = ring[(c0 + j) & (kF4Ring - 1)];
+      if (j == kC - 1) lastRaw = up.x;
+      upS[j] = up.x;
+      upI[j] = up.y;
+    }
+    if (__ballot(alive && hiC > myPhi + kF8Clean) != 0ull) {  // (rare) entries beyond the cleaned ones are stale
+      d0 = c0 - 1 <= myPhi ? d0 : inf;
+#pragma unroll
+      for (int j = 0; j < kC; j++) {
+        const bool upValid = c0 + j <= myPhi;  // c >= lo >= plo always
+        upS[j] = upValid ? upS[j] : inf;
+        upI[j] = upValid ? upI[j] : inf;
+      }
+    }
+    diagS[0] = d0;
+#pragma unroll
+    for (int j = 1; j < kC; j++) diagS[j] = upS[j - 1];
+    const uint32_t row6 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((recCur.y >> 26) & 0x1cu), (int)row6Table);
+    int vKey[kC], preA[kC], preB[kC];
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int m = (int)__builtin_amdgcn_sbfe((int)row6, (unsigned)ringT[(c0 + j) & (kF4RingT - 1)], 6);
+      const int matchK = (m << kShift) + diagS[j];
+      const int insSK = upS[j] + (kIns + AR_UP);
+      const int insEK = upI[j] + AR_INS_CLOSE;
+      vKey[j] = min(matchK, min(insSK, insEK));
+      const int v = vKey[j] & ~kTagMask;
+      const int ia = v - pDel[j];
+      preA[j] = j == 0 ? ia : min(preA[j - 1], ia);  // inclusive over this lane's cells
+      preB[j] = j == 0 ? v : min(preB[j - 1], v);
+    }
+    int pa = preA[kC - 1], pb = preB[kC - 1];
+    group_prefix_min2<kL>(pa, pb);  // inclusive over the lanes of the candidate
+    eaKeep = dpp<0x111, 0xf>(eaKeep, pa);
+    ebKeep = dpp<0x111, 0xf>(ebKeep, pb);
+    int ea = l == 0 ? inf : eaKeep, eb = l == 0 ? inf : ebKeep;
+    ea = myPass > 0 ? min(ea, carryA) : ea;
+    eb = myPass > 0 ? min(eb, carryB) : eb;
+    uint32_t arrowLo = 0, arrowHi = 0;
+#pragma unroll
+    for (int j = 0; j < kC; j++) {
+      const int eaj = j == 0 ? ea : min(ea, preA[j - 1]);
+      const int ebj = j == 0 ? eb : min(eb, preB[j - 1]);
+      const int aK = eaj + (pDel[j] + AR_LEFT);           // S[c-1] + del
+      const int bK = ebj + (kOpen + AR_DEL_CLOSE);         // D[c-1] + ext
+      const int sKey = min(vKey[j], min(aK, bK));
+      const int sv = sKey & ~kTagMask;
+      const int openKey = sv + (kOpen + AR_I_OPEN);
+      const int iKey = min(openKey, upI[j]);               // (ring entries carry no tag)
+      const int dFlag = openKey < bK ? AR_D_OPEN : 0;
+      const uint32_t arrow = (uint32_t)(sKey | iKey | dFlag);
+      if (j == 0) arrowLo = arrow;
+      else if (j == 1) arrowLo = __builtin_amdgcn_perm(arrow, arrowLo, 0x0c0c0400u);   // {cell 0, cell 1, 0, 0}
+      else if (j == 2) arrowHi = arrow;
+      else if (j == 3) arrowLo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(arrow, arrowHi, 0x04000c0cu), arrowLo, 0x07060100u) & 0x1f1f1f1fu;
+      else arrowHi = arrow & kTagMask;
+      if (alive) ring[(c0 + j) & (kF4Ring - 1)] = make_int2(sv, iKey & ~kTagMask);
+    }
+    if (alive && c0 <= hiC) {
+      uint8_t *ap = arrowRow + (c0 - lo);
+      *(unaligned_u32 *)ap = arrowLo;
+      ap[4] = (uint8_t)arrowHi;
+    }
+    const bool more = alive && cb + kPass <= hiC;
+    if (alive && !more) ring[(hiC + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);  // (after the cells' own writes)
+    if (__ballot(more) != 0ull) {  // carries into the next 40 columns
+      const int last = (lane | (kL - 1)) * 4;
+      const int ta = __builtin_amdgcn_ds_bpermute(last, pa), tb = __builtin_amdgcn_ds_bpermute(last, pb);
+      carryA = (myPass > 0 ? min(carryA, ta) : ta) + kPass * kDel;
+      carryB = myPass > 0 ? min(carryB, tb) : tb;
+      carryDiag = __builtin_amdgcn_ds_bpermute(last, lastRaw);  // the raw S of column cb+39, for lane 0
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (alive) {
+      if (more) {
+        myPass++;
+      } else {
+        myPass = 0;
+        myRow++;
+        myPlo = lo;
+        myPhi = hiC;
+        recCur = recNext;
+      }
+    }
+    alive = alive && myRow <= myQ;
+  }
+  // ---- S[Q][tEnd-1] (:481-483): a candidate's ring is not written after its last row
+  if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
+    args.dpScore[myTask] = (myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
+}
+
 template __global__ void fillp_kernel<16, true, false>(RefineBatchView, FillArgs);
 template __global__ void fillp_kernel<16, false, false>(RefineBatchView, FillArgs);
 template __global__ void fillp_kernel<16, true, true>(RefineBatchView, FillArgs);
@@ -2190,9 +2761,11 @@ void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes,
     hipLaunchKernelGGL(fill8_kernel, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
 }
 // the candidates with wide rows: args.taskList = the list, args.wideRingOff / wideRingSize indexed like it
-void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream) {
+void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream, bool eight) {
   if (args.count <= 0) return;
-  if (args.ext == 0)
+  if (eight)  // (the list padded to eight candidates per wavefront; the caller has checked fill8_kernel's domain)
+    hipLaunchKernelGGL(fillh8_kernel, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+  else if (args.ext == 0)
     hipLaunchKernelGGL((fillp_kernel<16, true, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else
     hipLaunchKernelGGL((fillp_kernel<16, false, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);

@@ -181,7 +181,8 @@ int blasr_hip_refine_last_fill4(const blasr_hip_ctx *ctx, float *ms, int64_t *la
  * blasr_hip_kernel_name(kind) is its full instantiation as rocprofv3 prints it. */
 enum { BLASR_HIP_KERNEL_FILL_NARROW = 0, /* fillp_kernel<16, ext0, false>: four candidates per wavefront (extension penalty
                                             != 0, or a matrix entry outside [-32, 31]; else FILL_EIGHT runs) */
-       BLASR_HIP_KERNEL_FILL_HYBRID = 1, /* fillp_kernel<16, ext0, true>: candidates with wide rows */
+       BLASR_HIP_KERNEL_FILL_HYBRID = 1, /* candidates with wide rows: fillh8_kernel (eight per wavefront, each at its own row;
+                                            the record's ext0 is 2 then) or, outside fill8_kernel's domain, fillp_kernel<16, ext0, true> */
        BLASR_HIP_KERNEL_FILL_WAVE = 2,   /* fill_kernel: one candidate per wavefront (compare-based variant) */
        BLASR_HIP_KERNEL_TRACEBACK = 3,   /* traceback_kernel */
        /* the k-band refiner (blasr_hip_kband_*): cells = the band cells inside the matrix, sum over the rows q of
@@ -196,7 +197,7 @@ typedef struct blasr_hip_kernel_record {
   int32_t kind;
   int32_t launches;
   float ms;
-  int32_t ext0;               /* 1: the affine_extend == 0 instantiation ran */
+  int32_t ext0;               /* 1: the affine_extend == 0 instantiation ran; 2 (FILL_HYBRID only): fillh8_kernel ran */
   int64_t algorithmic_bytes;
   int64_t cells;
   int64_t candidates;
