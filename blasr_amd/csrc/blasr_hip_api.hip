@@ -351,6 +351,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   const size_t oWideTasks = carve(sizeof(int32_t) * ((size_t)n + 8)), oWideOff = carve(sizeof(int64_t) * ((size_t)n + 8)),
                oWideSize = carve(sizeof(int32_t) * ((size_t)n + 8));
   const size_t oList4 = carve(sizeof(int32_t) * n), oList1 = carve(sizeof(int32_t) * n);
+  const size_t oQueue = carve(256);  // fillh8_kernel's queue counter
   const size_t fixedBytes = off;
   // first make room for the fixed part + a modest variable part; grown below once the geometry is known
   int rc = ensure_workspace(ctx, fixedBytes);
@@ -573,6 +574,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   int64_t *dWideOff = reinterpret_cast<int64_t *>(ws + oWideOff);
   int32_t *dWideSize = reinterpret_cast<int32_t *>(ws + oWideSize);
   int32_t *dList4 = reinterpret_cast<int32_t *>(ws + oList4), *dList1 = reinterpret_cast<int32_t *>(ws + oList1);
+  int32_t *dQueue = reinterpret_cast<int32_t *>(ws + oQueue);
   HIP_TRY(ctx, hipMemcpyAsync(dArrowOff, plan.arrowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dRowOff, plan.rowOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dArenaOff, plan.arenaOff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
@@ -619,6 +621,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.wideRings = reinterpret_cast<uint8_t *>(pWide);
     fa.taskList = nullptr;
     fa.exp = getenv("BLASR_HIP_EXP") ? atoi(getenv("BLASR_HIP_EXP")) : 0;
+    fa.queue = dQueue;
+    fa.groups = 8;
+    fa.gridGroups = 1;
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
     // the row records of the chunk's candidates, now that they have their place in the workspace
     launch_geometry_rows(view, band, c.first, c.count, dGeo, fa.rowTab, dRowOff, reinterpret_cast<unsigned short *>(pMeta), st);
@@ -639,17 +644,32 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         //  wavefronts; kept for experiments.)
         std::vector<int32_t> order((size_t)nw);
         for (int u = 0; u < nw; u++) order[(size_t)u] = u;
-        const int G = hybrid8 ? 8 : 4;  // candidates per wavefront
-        const int W = (nw + G - 1) / G;
-        std::vector<int32_t> t2((size_t)W * G, -1), s2((size_t)W * G, 512);
-        std::vector<int64_t> o2((size_t)W * G, 0);
+        const int G = 4;  // candidates per wavefront of fillp_kernel<16, ., true>
+        const int W = hybrid8 ? nw : (nw + G - 1) / G;
+        std::vector<int32_t> t2((size_t)W * (hybrid8 ? 1 : G), -1), s2((size_t)W * (hybrid8 ? 1 : G), 512);
+        std::vector<int64_t> o2((size_t)W * (hybrid8 ? 1 : G), 0);
         auto place = [&](size_t slot, int32_t u) {
           t2[slot] = c.wideTasks[(size_t)u];
           o2[slot] = c.wideRingOff[(size_t)u];
           s2[slot] = c.wideRingSize[(size_t)u];
         };
         const char *orderEnv = hybrid8 ? nullptr : getenv("BLASR_HIP_HYBRID_ORDER");  // (the experiments are the four-form's)
-        if (orderEnv && !strcmp(orderEnv, "lpt")) {
+        if (hybrid8) {
+          // fillh8_kernel takes the list as a QUEUE, a group of eight lanes a candidate at a time: largest first (by cells), so
+          // that what is handed out last is small.  No padding, no placement.  The order only has to be about right: a counting
+          // sort over the cells' leading sixteen bits, stable in the candidate index (a comparison sort of configs[2]'s 186 k
+          // candidates took the host longer than the row records take the device).
+          int64_t maxCells = 1;
+          for (int u = 0; u < nw; u++) maxCells = std::max<int64_t>(maxCells, geo[c.wideTasks[(size_t)u]].cells);
+          int shift = 0;
+          while ((maxCells >> shift) >= 65536) shift++;
+          std::vector<int32_t> head(65537, 0);
+          auto bucket = [&](int32_t u) { return 65535 - (int)(geo[c.wideTasks[(size_t)u]].cells >> shift); };
+          for (int u = 0; u < nw; u++) head[(size_t)bucket(u) + 1]++;
+          for (int b = 0; b < 65536; b++) head[(size_t)b + 1] += head[(size_t)b];
+          for (int u = 0; u < nw; u++) order[(size_t)head[(size_t)bucket(u)]++] = u;
+          for (int p = 0; p < nw; p++) place((size_t)p, order[(size_t)p]);
+        } else if (orderEnv && !strcmp(orderEnv, "lpt")) {
           // The four candidates of a wavefront step through their narrow rows together, so a wavefront costs
           // (its longest candidate's rows) x (a narrow step) + (the wide cells of all four): candidates of about the same
           // LENGTH share a wavefront (bins of 256 neighbours in the order by rows), inside a bin the wide work is spread
@@ -711,7 +731,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         c.wideTasks.swap(t2);
         c.wideRingOff.swap(o2);
         c.wideRingSize.swap(s2);
-        nw = W * G;
+        nw = hybrid8 ? nw : W * G;
       }
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
@@ -719,6 +739,36 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       FillArgs fw = fa;
       fw.count = nw;
       if (hybrid) fw.taskList = dWideTasks;
+      if (hybrid8) {
+        // as many workgroups as the device holds at once (four per compute unit: 40 KB of LDS each), fewer for a short list;
+        // a list that cannot give every resident wavefront eight candidates uses fewer groups per wavefront
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int resident = std::max(cus, 1) * 4;
+        if (const char *e = getenv("BLASR_HIP_H8_GRID")) fw.gridGroups = std::max(atoi(e), 1);
+        else fw.gridGroups = std::min(resident, (nw + 31) / 32 * 8);
+        fw.groups = std::min(8, std::max(1, (nw + 4 * fw.gridGroups - 1) / (4 * fw.gridGroups)));
+        if (const char *e = getenv("BLASR_HIP_H8_GROUPS")) fw.groups = std::min(8, std::max(atoi(e), 1));
+        HIP_TRY(ctx, hipMemsetAsync(dQueue, 0, sizeof(int32_t), st));
+      }
+      if (hybrid && getenv("BLASR_HIP_DUMP_HYBRID")) {  // the list as launched, per slot {passes, narrow rows, wide rows, wide steps, rows, cells}
+        int4 *dProf = nullptr;
+        std::vector<int4> hProf((size_t)nw);
+        HIP_TRY(ctx, hipMalloc((void **)&dProf, sizeof(int4) * (size_t)nw));
+        launch_row_profile(view, fw, dProf, st);
+        HIP_TRY(ctx, hipMemcpyAsync(hProf.data(), dProf, sizeof(int4) * (size_t)nw, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        (void)hipFree(dProf);
+        if (FILE *f = fopen(getenv("BLASR_HIP_DUMP_HYBRID"), "wb")) {
+          for (int u = 0; u < nw; u++) {
+            const int32_t t = c.wideTasks[(size_t)u];
+            const int64_t rec[6] = {hProf[(size_t)u].x, hProf[(size_t)u].y, hProf[(size_t)u].z, hProf[(size_t)u].w,
+                                    t >= 0 ? geo[t].rows : 0, t >= 0 ? geo[t].cells : 0};
+            fwrite(rec, sizeof(rec), 1, f);
+          }
+          fclose(f);
+        }
+      }
       if (hybrid && getenv("BLASR_HIP_REFINE_TRACE")) {  // where the hybrid kernel's cells are, by row width
         unsigned long long *dHist = nullptr, hHist[40];
         HIP_TRY(ctx, hipMalloc((void **)&dHist, sizeof(hHist)));
@@ -771,7 +821,19 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       // (the device waits for list4: a counting sort over the row counts, stable in the candidate index; list1 is
       // sorted while fillp_kernel runs)
       std::vector<int32_t> list4, list1;
-      {
+      // ONE queue for both lists (round 6): fillh8_kernel takes the narrow candidates too -- they simply never meet a wide row --
+      // behind the hybrid ones (the list is sorted by cells), so that the stage has one tail instead of two kernels' side by side
+      // (BLASR_HIP_H8_SPLIT keeps fill8_kernel for the narrow list, on the main stream beside fillh8_kernel's hybrid list)
+      const bool h8All = hybrid8 && getenv("BLASR_HIP_H8_SPLIT") == nullptr;
+      if (h8All) {
+        const int w4 = fill4_max_width();
+        for (int i = c.first; i < c.first + c.count; i++)
+          if (geo[i].status == 0 && geo[i].maxWidth <= w4) {
+            c.wideTasks.push_back(i);
+            c.wideRingOff.push_back(0);
+            c.wideRingSize.push_back(512);
+          }
+      } else {
         const int w4 = fill4_max_width();
         int32_t maxRows = 0;
         for (int i = c.first; i < c.first + c.count; i++)

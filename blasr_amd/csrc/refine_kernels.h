@@ -64,6 +64,10 @@ struct FillArgs {
   const int32_t *wideRingSize;
   uint8_t *wideRings;
   int exp;  // experiments (BLASR_HIP_EXP): timing only, results are wrong
+  // fillh8_kernel: the list is a queue -- `queue` counts the slots handed out (zero at launch), `groups` of the eight 8-lane
+  // groups of a wavefront take candidates, `gridGroups` workgroups are launched (the resident ones, or fewer)
+  int *queue;
+  int groups, gridGroups;
 };
 
 struct TraceArgs {
@@ -95,6 +99,8 @@ int fill4_max_width();
 // eight: fillh8_kernel (the list padded to eight candidates per wavefront, fill8_kernel's domain), else fillp_kernel<16, ., true> (four)
 void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream, bool eight = false);
 // trace only: row-width histogram of the candidates of args.taskList (10 classes x 4 counters)
+// trace only (BLASR_HIP_DUMP_HYBRID): per list slot {narrow passes of 40 columns, narrow rows, wide rows, wide steps of 192}
+void launch_row_profile(const RefineBatchView &batch, const FillArgs &args, int4 *out, hipStream_t stream);
 void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigned long long *hist, hipStream_t stream);
 // afterWalk (may be null): recorded behind traceback_kernel, before runs_kernel / stats_kernel
 void launch_traceback(const RefineBatchView &batch, const TraceArgs &args, hipStream_t stream, hipEvent_t afterWalk = nullptr);

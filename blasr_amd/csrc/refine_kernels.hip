@@ -1712,8 +1712,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   __shared__ uint2 rowWin[4][kT][kF8Rows];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int grp = lane / kL, l = lane % kL;
-  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * kT;
-  if (slot0 >= args.count) return;
   int2 *ring = ringLds[wave][grp];
   uint8_t *ringT = ringTLds[wave][grp];
   uint2 *win = rowWin[wave][grp];
@@ -1730,45 +1728,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   const uint8_t *myTSeq = nullptr;
   uint8_t *myArrows = nullptr;
   int2 *myGRing = nullptr;
-  if (slot0 + grp < args.count) myTask = args.taskList[slot0 + grp];  // (the list has empty slots: -1)
-  if (myTask >= 0) {
-    const int32_t *blocks = batch.blocks + 3 * batch.blk_off[myTask];
-    const int nBlocks = batch.n_blocks[myTask];
-    GuideCursor cur;
-    guide_begin(cur, blocks, nBlocks, args.band);
-    myQ = cur.Q;
-    myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
-    myTLen = batch.t_len[myTask];
-    myTSeq = batch.seq + batch.t_off[myTask];
-    myArrows = args.arrows + args.arrowOff[myTask];
-    tab = args.rowTab + args.rowOff[myTask];
-    meta = args.rowMeta + args.rowOff[myTask];
-    myBase = cur.tStart - 1;
-    myPlo = myBase;
-    myPhi = myPlo + guide_row0_tpost(cur);
-    myCells = (unsigned)args.geo[myTask].cells;
-    myGMask = args.wideRingSize[slot0 + grp] - 1;
-    myGRing = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot0 + grp]);
-  }
   const int inf = 1 << 30;
   const int kIns = args.ins << kShift, kDel = args.del << kShift, kOpen = args.open << kShift;
   int pDel[kC];
 #pragma unroll
   for (int j = 0; j < kC; j++) pDel[j] = (kC * l + j) * kDel;
-  // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open; a wide row 0 goes to the global ring
-  if (myTask >= 0) {
-    if (myPhi - myPlo + 1 > kF4MaxWidth) {
-      for (int c = myPlo + l; c <= myPhi; c += kL) myGRing[c & myGMask] = make_int2((c - myPlo) * kDel, kOpen);
-      myPrevGlobal = true;
-    } else {
-      for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
-      ring[(myPhi + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);
-    }
-  }
-  int myTLoaded = (myPlo < 0 ? 0 : myPlo) & ~3;  // columns below it are staged; whole dwords of codes
-  const int tLast = max(myTLen - 1, 0);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  int myTLoaded = 0, tLast = 0;
   // a value / a pointer of candidate g, uniform, from its first lane
   auto from_group = [&](int v, int g) { return __builtin_amdgcn_readlane(v, g * kL); };
   auto ptr_from_group = [&](const void *p, int g) {
@@ -1780,9 +1745,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
 
   int myRow = 1, myPass = 0, stagedEnd = 1;  // records of rows below stagedEnd (and not below myRow) are in the window
   int carryA = inf, carryB = inf, carryDiag = inf, eaKeep = inf, ebKeep = inf;
-  bool alive = myTask >= 0 && myRow <= myQ;
+  bool alive = false;
+  // The list is a QUEUE (args.queue counts what was handed out): a group of eight lanes that is through with its candidate
+  // takes the next one, whatever the other seven groups of its wavefront are doing.  A wavefront's narrow rows then never wait
+  // for its longest candidate (with eight fixed candidates per wavefront a fifth of the narrow lane-passes of configs[2] were
+  // idle ones) and the launch has no last round of half-empty compute units: the wavefronts end together, when the list does.
+  // The list is sorted by cells, largest first.  args.groups (1 .. 8): the groups of a wavefront that take candidates -- a list
+  // too short to give every resident wavefront eight uses fewer, so that wide rows of different candidates do not queue up
+  // behind each other in one wavefront while other compute units are empty.
+  bool drained = grp >= args.groups;
   uint2 recCur = make_uint2(0u, 0u);
-  while (__ballot(alive) != 0ull) {
+  for (;;) {
+    if (__ballot(!alive && !drained) != 0ull) {
+      if (!alive && !drained) {
+        // ---- S[Q][tEnd-1] of the candidate that is done (:481-483): its ring is not written after its last row
+        if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
+          args.dpScore[myTask] =
+              (myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
+        myTask = -1;
+        int slot = 0;
+        if (l == 0) slot = atomicAdd(args.queue, 1);
+        slot = __builtin_amdgcn_ds_bpermute((lane & ~(kL - 1)) * 4, slot);
+        if (slot >= args.count) {
+          drained = true;
+        } else {
+          myTask = args.taskList[slot];
+        }
+        if (myTask >= 0) {
+          const int32_t *blocks = batch.blocks + 3 * batch.blk_off[myTask];
+          const int nBlocks = batch.n_blocks[myTask];
+          GuideCursor cur;
+          guide_begin(cur, blocks, nBlocks, args.band);
+          myQ = cur.Q;
+          myTEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+          myTLen = batch.t_len[myTask];
+          myTSeq = batch.seq + batch.t_off[myTask];
+          myArrows = args.arrows + args.arrowOff[myTask];
+          tab = args.rowTab + args.rowOff[myTask];
+          meta = args.rowMeta + args.rowOff[myTask];
+          myBase = cur.tStart - 1;
+          myPlo = myBase;
+          myPhi = myPlo + guide_row0_tpost(cur);
+          myCells = (unsigned)args.geo[myTask].cells;
+          myGMask = args.wideRingSize[slot] - 1;
+          myGRing = reinterpret_cast<int2 *>(args.wideRings + args.wideRingOff[slot]);
+          // ---- row 0 (AffineGuidedAlign.h:166-208): S = del * distance from tStart-1, I = open; a wide row 0 goes to the global ring
+          myPrevGlobal = myPhi - myPlo + 1 > kF4MaxWidth;
+          if (myPrevGlobal) {
+            for (int c = myPlo + l; c <= myPhi; c += kL) myGRing[c & myGMask] = make_int2((c - myPlo) * kDel, kOpen);
+          } else {
+            for (int c = myPlo + l; c <= myPhi; c += kL) ring[c & (kF4Ring - 1)] = make_int2((c - myPlo) * kDel, kOpen);
+            ring[(myPhi + 1 + l) & (kF4Ring - 1)] = make_int2(inf, inf);
+          }
+          myTLoaded = (myPlo < 0 ? 0 : myPlo) & ~3;  // columns below it are staged; whole dwords of codes
+          tLast = max(myTLen - 1, 0);
+          myRow = 1;
+          myPass = 0;
+          stagedEnd = 1;
+          alive = myRow <= myQ;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;  // (a group whose candidate has no rows takes another)
+    }
+    if (__ballot(alive) == 0ull) break;  // (every group is through and the list is empty)
     // ---- row records: when one candidate has used up its window, all of them fill theirs
     if (__ballot(alive && myRow >= stagedEnd) != 0ull) {
       if (alive) {
@@ -2249,9 +2276,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     }
     alive = alive && myRow <= myQ;
   }
-  // ---- S[Q][tEnd-1] (:481-483): a candidate's ring is not written after its last row
-  if (myTask >= 0 && l == 0 && myTEnd - 1 >= myPlo && myTEnd - 1 <= myPhi)
-    args.dpScore[myTask] = (myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
 }
 
 template __global__ void fillp_kernel<16, true, false>(RefineBatchView, FillArgs);
@@ -2714,9 +2738,49 @@ __global__ __launch_bounds__(256) void row_hist_kernel(RefineBatchView batch, Fi
   }
 }
 
+// row_profile_kernel (BLASR_HIP_DUMP_HYBRID only): per slot of a task list {passes of 40 columns of its narrow rows, its narrow
+// rows, its wide rows, their steps of 192 columns} -- what a wavefront of fillh8_kernel spends on the candidate (tools/hybrid_order.py)
+__global__ __launch_bounds__(256) void row_profile_kernel(RefineBatchView batch, FillArgs args, int4 *out) {
+  const int lane = lane_id();
+  const int idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (idx >= args.count) return;
+  const int task = args.taskList[idx];
+  int passes = 0, narrow = 0, wide = 0, steps = 0;
+  if (task >= 0) {
+    const TaskGeometry geo = args.geo[task];
+    const int2 *rowTab = args.rowTab + args.rowOff[task];
+    const int32_t *blk = batch.blocks + 3 * batch.blk_off[task];
+    const int nb = batch.n_blocks[task];
+    const int tEnd = blk[3 * (nb - 1) + 1] + blk[3 * (nb - 1) + 2];
+    for (int r = 1 + lane; r <= geo.rows; r += 64) {
+      const unsigned next = r < geo.rows ? (unsigned)rowTab[r + 1].x : (unsigned)geo.cells;
+      const int lo = rowTab[r].y, hi = lo + (int)(next - (unsigned)rowTab[r].x) - 1;
+      const int w = max(min(hi, tEnd - 1) - lo + 1, 0);
+      if (w > kF4MaxWidth) {
+        wide++;
+        steps += (w + 191) / 192;
+      } else {
+        narrow++;
+        passes += max((w + kF8Pass - 1) / kF8Pass, 1);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    passes += __shfl_xor(passes, off);
+    narrow += __shfl_xor(narrow, off);
+    wide += __shfl_xor(wide, off);
+    steps += __shfl_xor(steps, off);
+  }
+  if (lane == 0) out[idx] = make_int4(passes, narrow, wide, steps);
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
+void launch_row_profile(const RefineBatchView &batch, const FillArgs &args, int4 *out, hipStream_t stream) {
+  if (args.count <= 0) return;
+  hipLaunchKernelGGL(row_profile_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args, out);
+}
 void launch_row_hist(const RefineBatchView &batch, const FillArgs &args, unsigned long long *hist, hipStream_t stream) {
   if (args.count <= 0) return;
   hipLaunchKernelGGL(row_hist_kernel, dim3((args.count + 3) / 4), dim3(256), 0, stream, batch, args, hist);
@@ -2763,8 +2827,8 @@ void launch_fill4(const RefineBatchView &batch, const FillArgs &args, int lanes,
 // the candidates with wide rows: args.taskList = the list, args.wideRingOff / wideRingSize indexed like it
 void launch_fill_hybrid(const RefineBatchView &batch, const FillArgs &args, hipStream_t stream, bool eight) {
   if (args.count <= 0) return;
-  if (eight)  // (the list padded to eight candidates per wavefront; the caller has checked fill8_kernel's domain)
-    hipLaunchKernelGGL(fillh8_kernel, dim3((args.count + 31) / 32), dim3(256), 0, stream, batch, args);
+  if (eight)  // (the list as a queue, args.queue zeroed by the caller, who has checked fill8_kernel's domain)
+    hipLaunchKernelGGL(fillh8_kernel, dim3((unsigned)args.gridGroups), dim3(256), 0, stream, batch, args);
   else if (args.ext == 0)
     hipLaunchKernelGGL((fillp_kernel<16, true, true>), dim3((args.count + 15) / 16), dim3(256), 0, stream, batch, args);
   else

@@ -160,12 +160,13 @@ def test_unsupported_gap_costs_are_rejected(ctx):
     assert e.value.code == hip.ERR_CAPACITY
 
 
-@pytest.mark.parametrize("switch", ["BLASR_HIP_NO_FILL4", "BLASR_HIP_FILL_LANES16"])
+@pytest.mark.parametrize("switch", ["BLASR_HIP_NO_FILL4", "BLASR_HIP_FILL_LANES16", "BLASR_HIP_H8_SPLIT", "BLASR_HIP_HYBRID4"])
 def test_alternative_fill_kernels_agree(ctx, golden, monkeypatch, switch):
-    """BLASR_HIP_NO_FILL4 sends every candidate through fill_kernel (one per wavefront); BLASR_HIP_FILL_LANES16 keeps
-    the narrow candidates on fillp_kernel<16> (four per wavefront, in lockstep) instead of fill8_kernel (eight per
-    wavefront, each at its own row: the default when the extension penalty is 0).  The same goldens must come out of
-    all of them."""
+    """The default (extension penalty 0, 6-bit matrix): ONE queue of all candidates through fillh8_kernel (eight per wavefront,
+    each group of eight lanes a candidate at a time, each at its own row).  BLASR_HIP_H8_SPLIT: the narrow candidates through
+    fill8_kernel (eight fixed candidates per wavefront) beside it; BLASR_HIP_HYBRID4: the candidates with wide rows through
+    fillp_kernel<16, ., true> (four in lockstep); BLASR_HIP_FILL_LANES16: fillp_kernel<16> for both lists;
+    BLASR_HIP_NO_FILL4: every candidate through fill_kernel (one per wavefront).  The same goldens must come out of all of them."""
     cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
              and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
     b = blasr_amd.RefineBatch()
@@ -177,12 +178,14 @@ def test_alternative_fill_kernels_agree(ctx, golden, monkeypatch, switch):
     monkeypatch.delenv(switch)
 
 
-@pytest.mark.parametrize("lanes8", [False, True])
+@pytest.mark.parametrize("lanes8", [False, True, "split"])
 def test_many_candidates_of_ragged_lengths(ctx, oracle, monkeypatch, lanes8):
-    """fill8_kernel / fillp_kernel pack eight / four candidates of different lengths and widths into one wavefront;
-    rows of up to 112 cells take up to three passes (of 40 / 48 columns)."""
+    """fillh8_kernel (a queue; "split": fill8_kernel, eight fixed candidates) / fillp_kernel pack eight / four candidates of
+    different lengths and widths into one wavefront; rows of up to 112 cells take up to three passes (of 40 / 48 columns)."""
     if not lanes8:
         monkeypatch.setenv("BLASR_HIP_FILL_LANES16", "1")
+    if lanes8 == "split":
+        monkeypatch.setenv("BLASR_HIP_H8_SPLIT", "1")
     rng = np.random.default_rng(77)
     b = blasr_amd.RefineBatch()
     want = []
@@ -267,14 +270,18 @@ def test_block_geometry_equals_the_row_walk(ctx, monkeypatch):
         assert any(g.status != 0 for g in got) and any(g.status == 0 for g in got)
 
 
-@pytest.mark.parametrize("lanes16", [False, True])
+@pytest.mark.parametrize("lanes16", [False, True, "split"])
 def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes16):
-    """fill8_kernel's edges one by one: rows of exactly 40 / 41 / 80 / 81 / 112 cells (one, two, three passes of 40 columns:
+    """The edges of the eight-lane narrow pass (fillh8_kernel's by default, fill8_kernel's under BLASR_HIP_H8_SPLIT) one by one: rows of exactly 40 / 41 / 80 / 81 / 112 cells (one, two, three passes of 40 columns:
     target gaps of 7 / 8 / 47 / 48 / 79 columns behind a 33-cell band), a row that grows by more than the eight cleaned
     ring entries, query gaps (the band stands still), N in both sequences (the fifth row / field of the 6-bit matrix
     registers), more candidates than one wavefront's eight and fewer, a band of 8 and of 20 -- and matrix entries at the
     6-bit limits (-32, 31), then beyond them (32: the launch falls back to fillp_kernel<16>).  Everything against the
     oracle; with BLASR_HIP_FILL_LANES16 the same through the four-per-wavefront kernel."""
+    narrow_kernel = "fillh8_kernel"
+    if lanes16 == "split":
+        monkeypatch.setenv("BLASR_HIP_H8_SPLIT", "1")
+        lanes16, narrow_kernel = False, "fill8_kernel"
     if lanes16:
         monkeypatch.setenv("BLASR_HIP_FILL_LANES16", "1")
     rng = np.random.default_rng(20261004)
@@ -293,9 +300,9 @@ def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes1
             assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, (band, i)
         if not lanes16 and band == 16:
             names = [k["name"] for k in ctx.last_kernels()]
-            assert any("fill8_kernel" in n for n in names), names
+            assert any(narrow_kernel in n for n in names), names
     # the matrix at the limits of the 6-bit fields, and one entry beyond them
-    for lim, kernel in ((31, "fill8_kernel"), (32, "fillp_kernel<16")):
+    for lim, kernel in ((31, narrow_kernel), (32, "fillp_kernel<16")):
         m = np.array(SMRT_MATRIX, dtype=np.int32).copy()
         m[0, 1] = lim
         m[2, 2] = -32
@@ -314,7 +321,7 @@ def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes1
             assert any(kernel in k["name"] for k in ctx.last_kernels()), (lim, [k["name"] for k in ctx.last_kernels()])
 
 
-@pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4"])
+@pytest.mark.parametrize("switch", [None, "BLASR_HIP_H8_SPLIT", "BLASR_HIP_HYBRID4", "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4"])
 def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch):
     """Guides whose consecutive blocks drift by hundreds to thousands of columns (what SDPAlign(Local) makes of a repeat
     copy the read overlaps only in part: it chains on through chance fragments): rows of band + |drift| cells, on
