@@ -359,6 +359,63 @@ def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch
         monkeypatch.delenv(switch)
 
 
+@pytest.mark.parametrize("grid", [None, ("1", "8"), ("1", "1"), ("2", "3")])
+def test_fillh8_wide_pieces_and_the_queue(ctx, oracle, monkeypatch, grid):
+    """fillh8_kernel's own edges (round 6).  The wide mode takes a PIECE per entry: runs of wide rows longer than the 64
+    records a wavefront holds (query and target both unaligned for 150 rows: three pieces), rows wider than a run's 576
+    columns (one row through the ring in global memory, then back to narrow rows from there), consecutive wide rows that
+    start more than a column apart (blocks of one and two bases behind target gaps), a wide row 0 (a first block far off the
+    origin's diagonal), a wide LAST row, N in a wide row's query base and target.  The list is a QUEUE: with a grid of one
+    workgroup (32 groups of eight lanes, or 4 with one group per wavefront, or 24) the 70 candidates go round several times
+    and a group takes wide and narrow candidates one after the other; by default a short list uses one group per wavefront.
+    Everything against the oracle."""
+    if grid:
+        monkeypatch.setenv("BLASR_HIP_H8_GRID", grid[0])
+        monkeypatch.setenv("BLASR_HIP_H8_GROUPS", grid[1])
+    rng = np.random.default_rng(20261007)
+    shapes = [[(150, 200)], [(70, 400)], [(150, 200), (3, 3), (120, 330)], [(0, 900)], [(0, 640), (0, 20)], [(40, 1300), (0, 0)],
+              [(0, 200)] * 5, [(5, 300), (0, 130), (200, 0)], [(64, 180)], [(65, 180)], [(129, 260)], [(0, 113)], [(0, 112)],
+              [(300, 300)], [(10, 576 - 33)], [(10, 577 - 33)], [(0, 7)], [(3, 3)] * 6]
+    b, want = blasr_amd.RefineBatch(), []
+
+    def add(q, t, blocks):
+        b.add(q, t, blocks)
+        want.append(oracle.affine_guided_align(q, t, blocks))
+    for rep in range(3):
+        for k, gaps in enumerate(shapes):
+            block = int(rng.choice([1, 2, 12, 40, 90])) if rep else 40
+            q, t, blocks = _guide_with_gaps(rng, gaps, block=block, n_base=(k % 4 == 1))
+            add(q, t, blocks)
+    # a wide row 0: the guide starts 300 columns into the target (tStart - qStart = 300 > the band)
+    for off in (150, 300, 700):
+        q, t, blocks = _guide_with_gaps(rng, [(0, 40)], block=60)
+        t = np.ascontiguousarray(np.concatenate([synth.random_genome(off, int(rng.integers(1, 1 << 30))), t]))
+        blocks = blocks.copy()
+        blocks[:, 1] += off
+        add(q, t, blocks)
+    # a wide last row: the last block is one base behind a target gap
+    for gt in (200, 600, 1000):
+        q, t, blocks = _guide_with_gaps(rng, [(0, 30), (2, gt)], block=50)
+        blocks = blocks.copy()
+        blocks[-1, 2] = 1
+        add(np.ascontiguousarray(q[: blocks[-1, 0] + 1]), np.ascontiguousarray(t[: blocks[-1, 1] + 1]), blocks)
+    # plain noisy pairs in between (narrow candidates in the same queue)
+    for it in range(10):
+        q, t = synth.make_pair(rng, int(rng.integers(100, 2500)))
+        s = oracle.sdp_align(q, t)
+        bl = s["blocks"]
+        if len(bl):
+            add(np.ascontiguousarray(q[s["qPos"]: s["qPos"] + bl[-1, 0] + bl[-1, 2]]),
+                np.ascontiguousarray(t[s["tPos"]: s["tPos"] + bl[-1, 1] + bl[-1, 2]]), bl)
+    got = ctx.refine(b)
+    assert len(got) >= 70
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.status == 0, i
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, (i, grid)
+    names = [k["name"] for k in ctx.last_kernels()]
+    assert any("fillh8_kernel" in n for n in names) and not any("fill8_kernel" in n or "fillp_kernel" in n for n in names), names
+
+
 @pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID"])
 def test_guides_with_several_gaps_share_wavefronts(ctx, oracle, monkeypatch, switch):
     """What the hybrid fill kernel is for (candidates whose rows are narrow except where the guide jumps): guides of
