@@ -382,16 +382,99 @@ __global__ __launch_bounds__(256) void geometry_rows_kernel(RefineBatchView batc
   GuideCursor g;
   guide_begin(g, blocks, nBlocks, band);
   const int tEnd = blocks[3 * (nBlocks - 1) + 1] + blocks[3 * (nBlocks - 1) + 2];
+  // guide_group's arithmetic (the geometry of rows r0 .. r0 + 63, lane = row) with ONE round trip to memory per group and that
+  // one issued a group ahead (round 6).  guide_group reads the first rows of the next 64 blocks, finds every row's block from
+  // them, and then GATHERS that block, the one before and the one after it from memory again: two dependent round trips per 64
+  // rows, which is what this kernel's 12 ms per configs[2] step were (170 groups per candidate, eight wavefronts per SIMD
+  // waiting).  A row's block is one of the 64 whose triplets lane j has just read (block nextBlock + j) or the one the group
+  // before ended in, so the three blocks come off the lanes (ds_bpermute) or out of a carried triplet; and the blocks the NEXT
+  // group will look at are known as soon as this group has counted its block starts.
+  auto load_triplet = [&](int b, int &q, int &t, int &l) {
+    q = INT32_MAX;  // (no such block: it starts in no group)
+    t = l = 0;
+    if (b < nBlocks) {
+      q = blocks[3 * b];
+      t = blocks[3 * b + 1];
+      l = blocks[3 * b + 2];
+    }
+  };
+  int nq, nt, nl;  // block g.nextBlock + lane
+  load_triplet(lane, nq, nt, nl);
+  int cq = 0, ct = 0, cl = 0;  // the block the group before ended in (uniform; none before the first group)
   for (int r0 = 1; r0 <= g.Q; r0 += 64) {
-    int t, lo, hi;
-    unsigned rs;
-    guide_group(g, r0, flagScratch[wave], t, lo, hi, rs);
-    if (r0 + lane <= g.Q) {
+    const int r = r0 + lane;
+    const bool rowValid = r <= g.Q;
+    const int bq0 = nq, bt0 = nt, bl0 = nl, base = g.nextBlock;
+    // ---- which blocks start inside this group?  (a block owns at least one row, so at most 64 of them)
+    flagScratch[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int rb = bq0 == INT32_MAX ? INT32_MAX : bq0 - g.qStart + 1;
+    const bool starts = rb < r0 + 64;
+    if (starts) flagScratch[wave][rb - r0] = 1;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long startMask = __ballot(flagScratch[wave][lane] != 0);
+    __builtin_amdgcn_wave_barrier();
+    const int nStarts = (int)__popcll(__ballot(starts));
+    g.nextBlock = base + nStarts;
+    // the next group's blocks: their loads are in flight while this group is worked out
+    load_triplet(g.nextBlock + lane, nq, nt, nl);
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int rel = (int)__popcll(startMask & le) - 1;  // my block is base + rel: -1 = the carried one
+    auto off_lane = [&](int v, int j) { return __builtin_amdgcn_ds_bpermute((j & 63) << 2, v); };
+    int t = 0, cap = 0, tPost = 0;
+    {
+      // (every lane takes part in the permutes; what an invalid row gets is not used)
+      const int mq = off_lane(bq0, rel), mt = off_lane(bt0, rel), ml = off_lane(bl0, rel);
+      const int pe = off_lane(bq0 + bl0, rel - 1), pf = off_lane(bt0 + bl0, rel - 1);  // the block before: q + len, t + len
+      const int sq = off_lane(bq0, rel + 1), st = off_lane(bt0, rel + 1);              // the block after
+      const int bq = rel >= 0 ? mq : cq, bt = rel >= 0 ? mt : ct, bl = rel >= 0 ? ml : cl;
+      const int pqe = rel >= 1 ? pe : cq + cl, pte = rel >= 1 ? pf : ct + cl;
+      if (rowValid) {
+        const int qpos = g.qStart + r - 1;
+        const int off = qpos - bq;
+        if (off < bl) {
+          t = bt + off;
+          if (off == 0) {  // first row of a block: tPre = reach (uncapped), tPost = band + |drift of the gap before| (:161-165)
+            int drift;
+            if (base + rel == 0) drift = abs(g.tStart - g.qStart);
+            else drift = abs((bt - pte) - (bq - pqe));  // ComputeDrift = tGap - qGap (AlignmentUtils.h:586-600)
+            cap = -1;  // none
+            tPost = g.band + drift;
+          } else {
+            cap = g.band;
+            tPost = min(250, g.band);
+          }
+        } else {  // gap rows between this block and the next (:193-250): min(qGap, tGap) diagonal rows, then straight down
+          const int qGap = sq - (bq + bl), tGap = st - (bt + bl);
+          const int diagLen = max(min(qGap, tGap), 0);
+          const int gi = off - bl;
+          t = bt + bl + min(gi, diagLen);
+          cap = 250;
+          tPost = min(250, g.band + abs(tGap - qGap));
+        }
+      }
+    }
+    if (nStarts > 0) {  // the block this group ends in
+      cq = __builtin_amdgcn_readlane(bq0, nStarts - 1);
+      ct = __builtin_amdgcn_readlane(bt0, nStarts - 1);
+      cl = __builtin_amdgcn_readlane(bl0, nStarts - 1);
+    }
+    // lo_r = max over rows j <= r of (t_j - cap_j), seeded with the carried lo
+    const int reachFloor = (rowValid && cap >= 0) ? t - cap : INT32_MIN;
+    const int lo = max(wave_prefix_max(reachFloor), g.loCarry);
+    const int hi = t + tPost;
+    const unsigned len = rowValid ? (unsigned)(hi - lo + 1) : 0u;
+    const unsigned incl = wave_prefix_sum(len);
+    const unsigned rs = g.cellCarry + incl - len;
+    const int lastLane = min(63, g.Q - r0);
+    g.loCarry = __builtin_amdgcn_readlane(lo, lastLane < 0 ? 0 : lastLane);
+    g.cellCarry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (rowValid) {
       const int width = min(hi, tEnd - 1) - lo + 1;
-      const int qc = base_code(qSeq[g.qStart + r0 - 1 + lane]);
-      rows[r0 + lane] = make_int2((int)rs, lo);
-      meta[r0 + lane] = (unsigned short)(min(max(width, 0), 0xfff) | (qc << 12));  // (a width beyond 4095 saturates: wide rows
-    }                                                                             //  are not fillp_kernel's)
+      const int qc = base_code(qSeq[g.qStart + r - 1]);
+      rows[r] = make_int2((int)rs, lo);
+      meta[r] = (unsigned short)(min(max(width, 0), 0xfff) | (qc << 12));  // (a width beyond 4095 saturates: wide rows
+    }                                                                       //  are not fillp_kernel's)
   }
 }
 
