@@ -102,6 +102,30 @@ __device__ __forceinline__ uint32_t target_tuple_high(const uint8_t *t, int k) {
   return v;
 }
 
+// The k-base words at positions p0 + lane of a sequence of `len` bases (2 bits per base, the first base lowest: FromStringRL,
+// DNATuple.h:55-83); ok = the window lies inside the sequence and is ACGT throughout.  ONE byte load per lane (two for the
+// k - 1 lanes whose windows reach into the next 64 positions): lane p reads base p0 + p and takes the bases behind it off the
+// lanes above, a DPP wave_shl:1 per base.  The loops this replaces -- for (j < k) code(seq[p + j]), k known only at run time
+// -- compile to a byte load AND ITS WAIT per base: up to eleven dependent round trips to memory per word, which is what the
+// matchers of the short targets spent their time on (phase clocks, round 6: 22 of the 26 us of a tiny invocation).
+__device__ __forceinline__ uint64_t words_at(const uint8_t *s, int len, int p0, int k, bool &ok) {
+  const int lane = lane_id();
+  int c0 = 4, c1 = 4;  // the codes of positions p0 + lane and p0 + 64 + lane (4: not ACGT, or beyond the sequence)
+  if (p0 + lane < len) c0 = base_code(s[p0 + lane]);
+  if (lane < k - 1 && p0 + 64 + lane < len) c1 = base_code(s[p0 + 64 + lane]);
+  uint64_t v = 0;
+  int any = 0;
+  for (int j = 0; j < k; j++) {
+    v |= (uint64_t)(c0 & 3) << (2 * j);
+    any |= c0;
+    const int edge = __builtin_amdgcn_readlane(c1, 0);
+    c0 = dpp<0x130, 0xf>(edge, c0);  // lane i takes lane i + 1's, lane 63 the first of the next 64
+    c1 = dpp<0x130, 0xf>(4, c1);
+  }
+  ok = any < 4;
+  return v;
+}
+
 __device__ __forceinline__ int wave_task_index() {
   return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 }
@@ -135,22 +159,12 @@ __global__ __launch_bounds__(256) void sdp_keys_kernel(SdpLevelArrays lv, const 
   const uint8_t *tSeq = seq + t.tOff;
   const int kk = key_bases(t.k);
   const uint64_t invalid = 1ull << (kPosBits + 2 * kk);
+  const uint64_t keyMask = kk < 32 ? (1ull << (2 * kk)) - 1ull : ~0ull;
   for (int p0 = 0; p0 < t.tLen; p0 += 64) {
     const int p = p0 + lane;
-    if (p < t.tLen) {
-      uint64_t key = invalid | (uint64_t)p;
-      if (p + t.k <= t.tLen) {
-        uint64_t kmer = 0;
-        bool ok = true;
-        for (int j = 0; j < t.k; j++) {
-          const int c = base_code(tSeq[p + j]);
-          ok = ok && c < 4;
-          if (j < kk) kmer |= (uint64_t)(c & 3) << (2 * j);
-        }
-        if (ok) key = (kmer << kPosBits) | (uint64_t)p;
-      }
-      keys[p] = key;
-    }
+    bool ok;
+    const uint64_t word = words_at(tSeq, t.tLen, p0, t.k, ok);
+    if (p < t.tLen) keys[p] = ok ? (((word & keyMask) << kPosBits) | (uint64_t)p) : (invalid | (uint64_t)p);
   }
   }
 }
@@ -371,12 +385,28 @@ __device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, 
   if (qn <= 64 && tn <= 64) {
     const int ny = tn - ks + 1;
     if (ny <= 0 || qn < ks) return 0;
+    // The words of both parts from ONE byte load per lane and sequence: lane p reads base p, the bases behind it come off the
+    // lanes above (DPP wave_shl:1, one step per base of the word).  small_kmer's loop -- a byte load per base with an exit at
+    // the first base that is not ACGT -- is a chain of up to five DEPENDENT round trips to memory, and this function ran four
+    // such chains per invocation (both sequences, prefix and suffix part): at the recursion levels, where a wavefront's whole
+    // life is one tiny invocation, that chain was most of the 27 us a wavefront of the short-target matcher took.
     int tk = -2, qk = -1;
-    if (lane < ny) {
-      tk = small_kmer(ts, lane, ks);
-      if (tk < 0) tk = -2;
+    {
+      int tc = 4, qc = 4;  // (4: not ACGT, or beyond the part)
+      if (lane < tn) tc = base_code(ts[lane]);
+      if (lane < qn) qc = base_code(qs[lane]);
+      int tv = 0, qv = 0, tAny = 0, qAny = 0;
+      for (int j = 0; j < ks; j++) {
+        tv |= (tc & 3) << (2 * j);
+        qv |= (qc & 3) << (2 * j);
+        tAny |= tc;
+        qAny |= qc;
+        tc = dpp<0x130, 0xf>(4, tc);  // lane i takes lane i + 1's, lane 63 "not ACGT"
+        qc = dpp<0x130, 0xf>(4, qc);
+      }
+      if (lane < ny && tAny < 4) tk = tv;
+      if (lane + ks <= qn && qAny < 4) qk = qv;
     }
-    if (lane + ks <= qn) qk = small_kmer(qs, lane, ks);
     int cnt = 0;
     for (int y = 0; y < ny; y++) cnt += __builtin_amdgcn_readlane(tk, y) == qk;
     if (maxPerPos != 0 && cnt > maxPerPos) cnt = 0;
@@ -546,7 +576,20 @@ __device__ unsigned long long g_idxClocks[16];
     if (threadIdx.x == 0) atomicAdd(&g_idxClocks[(kWrite ? 8 : 0) + (slot)], now_ - clk_); \
     clk_ = now_;                                                                   \
   } while (0)
+__device__ unsigned long long g_tinyClocks[8];
+#define TINY_CLOCK(slot)                                                                 \
+  do {                                                                                   \
+    const unsigned long long now_ = clock64();                                           \
+    tph_[(slot)] += now_ - tclk_;  /* (in registers: the atomics wait for the end) */    \
+    tclk_ = now_;                                                                        \
+  } while (0)
 void sdp_print_idx_clocks() {
+  {
+    unsigned long long t[8];
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_tinyClocks), sizeof(t)) == hipSuccess)
+      fprintf(stderr, "[tiny clocks] count pass of the tiny-target matcher, per sampled invocation: task+setup %llu prefix %llu target words %llu query+walk %llu suffix %llu cycles; %llu sampled\n",
+              t[0] / (t[6] + 1), t[1] / (t[6] + 1), t[2] / (t[6] + 1), t[3] / (t[6] + 1), t[5] / (t[6] + 1), t[6]);
+  }
   unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_idxClocks), sizeof(h)) != hipSuccess) return;
   fprintf(stderr, "[idx clocks] count pass: pack %llu count %llu scan %llu scatter %llu query %llu tail %llu tasks %llu | write pass: pack %llu count %llu "
@@ -556,6 +599,7 @@ void sdp_print_idx_clocks() {
 }
 #else
 #define IDX_CLOCK(slot) do { } while (0)
+#define TINY_CLOCK(slot) do { } while (0)
 #endif
 template <bool kWrite>
 __global__ __launch_bounds__(256) void sdp_match_index_kernel(SdpLevelArrays lv, const uint8_t *seq, int tCap, int minT) {
@@ -1090,9 +1134,15 @@ template <bool kWrite, bool kBuckets>
 __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8_t *seq, const int idx, uint32_t *bucketLds,
                                            const uint4 *tinyQuadsLds) {
   const int lane = lane_id();
+#ifdef BLASR_IDX_CLOCKS
+  unsigned long long tclk_ = clock64(), tph_[6] = {0, 0, 0, 0, 0, 0};
+#endif
   const SdpTask t = lv.tasks[idx];
   if (task_uses_index(t.tLen, t.k, lv.idxMaxT)) return;  // sdp_match_index_kernel's
   if ((!kWrite && t.tLen >= 256) != kBuckets) return;    // the other instantiation's
+#ifdef BLASR_IDX_CLOCKS
+  const bool tinyClk_ = !kWrite && !kBuckets && task_is_tiny(t.tLen, t.k);
+#endif
   const uint8_t *qSeq = seq + t.qOff, *tSeq = seq + t.tOff;
   const uint64_t *keys = lv.keys + lv.keyOff[idx];
   const int k = t.k, ks = k < 5 ? k : 5;
@@ -1106,8 +1156,10 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
   Frag *out = kWrite ? lv.raw + lv.fragOff[idx] : nullptr;
   int written = 0;  // uniform running count
 
+  TINY_CLOCK(0);
   const int nP = small_part<kWrite>(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0, ks, t.maxPerPos, out, written);
   written += nP;
+  TINY_CLOCK(1);
 
   // middle (part 1): the whole query against the sorted k-mer keys of the whole target.
   // For long targets the binary search is narrowed by a bucket index over the leading k-mer bits that the
@@ -1135,17 +1187,7 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
   if (tiny) {
     // the target's k-mers in registers (positions lane and lane + 64); every query k-mer is compared with
     // all of them in position order, which is the order of the sorted tuple list
-    auto kmer_at = [&](const uint8_t *sq, int p, int len, bool &ok) {
-      uint32_t v = 0;
-      ok = p + k <= len;
-      if (ok)
-        for (int j = 0; j < k; j++) {
-          const int c = base_code(sq[p + j]);
-          ok = ok && c < 4;
-          v |= (uint32_t)(c & 3) << (2 * j);
-        }
-      return v;
-    };
+    // (the words of 64 consecutive positions at a time: words_at, one load per lane)
     // count pass: per query position {count : 16, the first three target positions : 3 x 16} go to `hits`, so
     // the write pass is a copy unless some position has more than three matches
     // The target's k-mers go to LDS once (0xffffffff where there is none: a k-mer has at most 22 bits) and every query
@@ -1171,15 +1213,16 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
       if (replay) {
         if (!haveT) {
           bool ok0, ok1;
-          const uint32_t tk0 = kmer_at(tSeq, lane, t.tLen, ok0);
-          const uint32_t tk1 = kmer_at(tSeq, lane + 64, t.tLen, ok1);
+          const uint32_t tk0 = (uint32_t)words_at(tSeq, t.tLen, 0, k, ok0);
+          const uint32_t tk1 = (uint32_t)words_at(tSeq, t.tLen, 64, k, ok1);
           tinyT[lane] = ok0 ? tk0 : 0xffffffffu;
           tinyT[lane + 64] = ok1 ? tk1 : 0xffffffffu;
           __builtin_amdgcn_wave_barrier();
           haveT = true;
+          TINY_CLOCK(2);
         }
         bool okq;
-        qk = kmer_at(qSeq, x, t.qLen, okq);
+        qk = (uint32_t)words_at(qSeq, t.qLen, x0, k, okq);
         if (!okq) qk = 0xfffffffeu;  // (matches nothing)
         if (!kWrite) {
           uint64_t pos3 = 0;
@@ -1245,13 +1288,9 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int x = x0 + 64 * u + lane;
-      uint64_t kmer = 0;
-      bool ok = x + k <= t.qLen;
-      for (int j = 0; j < k; j++) {
-        const int c = base_code(qSeq[min(x + j, t.qLen - 1)]);
-        ok = ok && c < 4;
-        if (j < kk) kmer |= (uint64_t)(c & 3) << (2 * j);
-      }
+      bool ok;
+      uint64_t kmer = words_at(qSeq, t.qLen, x0 + 64 * u, k, ok);
+      if (kk < 32) kmer &= (1ull << (2 * kk)) - 1ull;
       if (k >= kKeyBases) {  // the reference's tuple of this position, not the word (sdp_query_words_kernel)
         const uint64_t word = ok ? qWords[x] : 0ull;
         kmer = word & 0xffffffffull;
@@ -1358,8 +1397,16 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
     nM += __builtin_amdgcn_readlane((int)incl, 63);
   }
   written += nM;
+  TINY_CLOCK(3);
   const int nS = small_part<kWrite>(qSeq + qSuffixPos, qSuffixLength, tSeq + suffixPos, suffixLength, qSuffixPos,
                                     suffixPos, ks, t.maxPerPos, out, written);
+  TINY_CLOCK(5);
+#ifdef BLASR_IDX_CLOCKS
+  if (tinyClk_ && lane == 0 && (idx & 63) == 0) {  // (a sample: one invocation in 64)
+    for (int c_ = 0; c_ < 6; c_++) atomicAdd(&g_tinyClocks[c_], tph_[c_]);
+    atomicAdd(&g_tinyClocks[6], 1ull);
+  }
+#endif
   if (!kWrite && lane == 0) {
     lv.nRaw[3 * idx] = nP;
     lv.nRaw[3 * idx + 1] = nM;
