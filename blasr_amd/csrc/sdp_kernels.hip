@@ -108,11 +108,8 @@ __device__ __forceinline__ uint32_t target_tuple_high(const uint8_t *t, int k) {
 // lanes above, a DPP wave_shl:1 per base.  The loops this replaces -- for (j < k) code(seq[p + j]), k known only at run time
 // -- compile to a byte load AND ITS WAIT per base: up to eleven dependent round trips to memory per word, which is what the
 // matchers of the short targets spent their time on (phase clocks, round 6: 22 of the 26 us of a tiny invocation).
-__device__ __forceinline__ uint64_t words_at(const uint8_t *s, int len, int p0, int k, bool &ok) {
-  const int lane = lane_id();
-  int c0 = 4, c1 = 4;  // the codes of positions p0 + lane and p0 + 64 + lane (4: not ACGT, or beyond the sequence)
-  if (p0 + lane < len) c0 = base_code(s[p0 + lane]);
-  if (lane < k - 1 && p0 + 64 + lane < len) c1 = base_code(s[p0 + 64 + lane]);
+// (the same from codes already in registers: c0 / c1 = base_code of positions p0 + lane / p0 + 64 + lane, 4 beyond the sequence)
+__device__ __forceinline__ uint64_t words_from_codes(int c0, int c1, int k, bool &ok) {
   uint64_t v = 0;
   int any = 0;
   for (int j = 0; j < k; j++) {
@@ -124,6 +121,17 @@ __device__ __forceinline__ uint64_t words_at(const uint8_t *s, int len, int p0, 
   }
   ok = any < 4;
   return v;
+}
+// the code of base p of a sequence, 4 beyond its end: an UNCONDITIONAL load (index clamped) so that several of them are in
+// flight together -- behind a branch each the compiler waits for every one in turn
+__device__ __forceinline__ int code_or_none(const uint8_t *s, int len, int p) {
+  const int c = base_code(s[min(p, max(len - 1, 0))]);
+  return p < len ? c : 4;
+}
+__device__ __forceinline__ uint64_t words_at(const uint8_t *s, int len, int p0, int k, bool &ok) {
+  const int lane = lane_id();
+  const int c0 = code_or_none(s, len, p0 + lane), c1 = code_or_none(s, len, p0 + 64 + lane);
+  return words_from_codes(c0, c1, k, ok);
 }
 
 __device__ __forceinline__ int wave_task_index() {
@@ -377,6 +385,27 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t *a, int n, uint64_
 // prefix / suffix part of StoreMatchingPositions for one wavefront: every query position's small k-mer
 // against every target position's.  With both parts <= 64 bases (sdpPrefixLength is 50 by default) the
 // target k-mers sit one per lane and are read with v_readlane.
+// small_part's count for parts of at most 64 bases whose codes are in registers already (lane p: the code of base p of either
+// part, 4 beyond it): the number of (query position, target position) pairs with equal words of ks bases
+__device__ __forceinline__ int small_part_count(int tc, int qc, int tn, int qn, int ks, int maxPerPos) {
+  const int lane = lane_id();
+  const int ny = tn - ks + 1;
+  if (ks < 1 || ny <= 0 || qn < ks) return 0;
+  int tv = 0, qv = 0, tAny = 0, qAny = 0;
+  for (int j = 0; j < ks; j++) {
+    tv |= (tc & 3) << (2 * j);
+    qv |= (qc & 3) << (2 * j);
+    tAny |= tc;
+    qAny |= qc;
+    tc = dpp<0x130, 0xf>(4, tc);
+    qc = dpp<0x130, 0xf>(4, qc);
+  }
+  const int tk = (lane < ny && tAny < 4) ? tv : -2, qk = (lane + ks <= qn && qAny < 4) ? qv : -1;
+  int cnt = 0;
+  for (int y = 0; y < ny; y++) cnt += __builtin_amdgcn_readlane(tk, y) == qk;
+  if (maxPerPos != 0 && cnt > maxPerPos) cnt = 0;
+  return __builtin_amdgcn_readlane((int)wave_prefix_sum((unsigned)cnt), 63);
+}
 template <bool kWrite>
 __device__ int small_part(const uint8_t *qs, int qn, const uint8_t *ts, int tn, int xOff, int yOff, int ks,
                           int maxPerPos, Frag *out, int written) {
@@ -1157,6 +1186,83 @@ __device__ __forceinline__ void match_task(const SdpLevelArrays &lv, const uint8
   int written = 0;  // uniform running count
 
   TINY_CLOCK(0);
+  if (!kWrite && !kBuckets && task_is_tiny(t.tLen, k) && t.prefix <= 64 && t.tLen > 0 && t.qLen > 0) {
+    // ---- The count pass of a TINY invocation (target of at most 128 bases: nine invocations in ten at the recursion levels,
+    // a wavefront each, and what those levels' match phase waits for).  Everything it reads of the two sequences -- the
+    // target's 128 bases, the query's first 128, the two suffix parts -- is six byte loads per lane, ISSUED TOGETHER: one
+    // round trip, where the general path below has one per part (prefix, target words, query words, suffix), each behind the
+    // arithmetic of the part before.  The prefix parts are the sequences' first bases: no loads of their own.
+    const int t0 = code_or_none(tSeq, t.tLen, lane), t1 = code_or_none(tSeq, t.tLen, 64 + lane);
+    int q0 = code_or_none(qSeq, t.qLen, lane), q1 = code_or_none(qSeq, t.qLen, 64 + lane);
+    // (an empty suffix part reads a base of the sequence itself: its code is not used)
+    const int tS = code_or_none(suffixLength > 0 ? tSeq + suffixPos : tSeq, suffixLength, lane);
+    const int qS = code_or_none(qSuffixLength > 0 ? qSeq + qSuffixPos : qSeq, qSuffixLength, lane);
+    uint64_t *hitsT = lv.hits + lv.qPosOff[idx];
+    uint32_t *tinyT = reinterpret_cast<uint32_t *>(const_cast<uint4 *>(tinyQuadsLds));
+    const int nPre = small_part_count(lane < prefixLength ? t0 : 4, lane < qPrefixLength ? q0 : 4, prefixLength, qPrefixLength, ks,
+                                      t.maxPerPos);
+    TINY_CLOCK(1);
+    {
+      bool ok0, ok1;
+      const uint32_t tk0 = (uint32_t)words_from_codes(t0, t1, k, ok0), tk1 = (uint32_t)words_from_codes(t1, 4, k, ok1);
+      tinyT[lane] = ok0 ? tk0 : 0xffffffffu;
+      tinyT[lane + 64] = ok1 ? tk1 : 0xffffffffu;
+      __builtin_amdgcn_wave_barrier();
+    }
+    TINY_CLOCK(2);
+    const int nT = max(t.tLen - k + 1, 0);
+    int nMid = 0;
+    for (int x0 = 0; x0 + k <= t.qLen; x0 += 64) {
+      const int x = x0 + lane;
+      bool okq;
+      uint32_t qk = (uint32_t)words_from_codes(q0, q1, k, okq);
+      q0 = q1;  // (the next 64 positions: one more load per trip, rare -- a tiny target's query is seldom longer than 128 bases)
+      q1 = x0 + 128 < t.qLen ? code_or_none(qSeq, t.qLen, x0 + 128 + lane) : 4;
+      if (!okq) qk = 0xfffffffeu;  // (matches nothing)
+      int cnt = 0;
+      uint64_t pos3 = 0;
+      for (int y0 = 0; y0 < nT; y0 += 4) {
+        const uint4 tv = tinyQuadsLds[y0 >> 2];
+        const bool e0 = tv.x == qk, e1 = tv.y == qk, e2 = tv.z == qk, e3 = tv.w == qk;
+        if (__ballot(e0 || e1 || e2 || e3) != 0ull) {
+          if (e0) {
+            if (cnt < 3) pos3 |= (uint64_t)y0 << (16 * (cnt + 1));
+            cnt++;
+          }
+          if (e1) {
+            if (cnt < 3) pos3 |= (uint64_t)(y0 + 1) << (16 * (cnt + 1));
+            cnt++;
+          }
+          if (e2) {
+            if (cnt < 3) pos3 |= (uint64_t)(y0 + 2) << (16 * (cnt + 1));
+            cnt++;
+          }
+          if (e3) {
+            if (cnt < 3) pos3 |= (uint64_t)(y0 + 3) << (16 * (cnt + 1));
+            cnt++;
+          }
+        }
+      }
+      if (!okq || (t.maxPerPos != 0 && cnt > t.maxPerPos)) cnt = 0;
+      if (x + k <= t.qLen) hitsT[x] = cnt ? (pos3 | (uint64_t)cnt) : 0ull;
+      nMid += __builtin_amdgcn_readlane((int)wave_prefix_sum((unsigned)cnt), 63);
+    }
+    TINY_CLOCK(3);
+    const int nSuf = small_part_count(tS, qS, suffixLength, qSuffixLength, ks, t.maxPerPos);
+    if (lane == 0) {
+      lv.nRaw[3 * idx] = nPre;
+      lv.nRaw[3 * idx + 1] = nMid;
+      lv.nRaw[3 * idx + 2] = nSuf;
+    }
+    TINY_CLOCK(5);
+#ifdef BLASR_IDX_CLOCKS
+    if (tinyClk_ && lane == 0 && (idx & 63) == 0) {
+      for (int c_ = 0; c_ < 6; c_++) atomicAdd(&g_tinyClocks[c_], tph_[c_]);
+      atomicAdd(&g_tinyClocks[6], 1ull);
+    }
+#endif
+    return;
+  }
   const int nP = small_part<kWrite>(qSeq, qPrefixLength, tSeq, prefixLength, 0, 0, ks, t.maxPerPos, out, written);
   written += nP;
   TINY_CLOCK(1);
