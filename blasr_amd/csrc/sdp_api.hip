@@ -603,9 +603,12 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     hc.pool = (unsigned long long)emitTotals[0];
     hc.sw = (unsigned long long)emitTotals[1];
     hc.child = (unsigned long long)emitTotals[2];
-    if (getenv("BLASR_HIP_SDP_TRACE"))
-      fprintf(stderr, "[sdp] level %d: tasks %d keys %lld frags %lld -> blocks %llu sw %llu children %llu\n", level,
-              nTasks, (long long)totalKeys, (long long)nFragTotal, hc.pool, hc.sw, hc.child);
+    if (getenv("BLASR_HIP_SDP_TRACE")) {
+      int32_t nTies = 0;  // invocations whose three fragment lists share an (x, y): sdp_order_ties_kernel's
+      (void)hipMemcpy(&nTies, lv.tieCount, sizeof(int32_t), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[sdp] level %d: tasks %d keys %lld frags %lld -> blocks %llu sw %llu children %llu; %d invocations with ties\n", level,
+              nTasks, (long long)totalKeys, (long long)nFragTotal, hc.pool, hc.sw, hc.child, nTies);
+    }
     LevelOut lo;
     lo.poolKeys = e.poolKeys;
     lo.poolVals = e.poolVals;
