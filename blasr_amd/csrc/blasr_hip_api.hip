@@ -634,6 +634,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     auto launch_wide = [&]() -> int {
       if (c.wideTasks.empty()) return 0;
       int nw = (int)c.wideTasks.size();
+      int h8Grid = 1, h8Groups = 8, h8FirstRound = 0;
       if (hybrid) {
         // A wavefront takes the wide rows of its four candidates one after the other, so the heavy candidates (by
         // cells) must not share one: sorted by cells, candidate p of the order goes to wavefront p mod W, so every
@@ -644,6 +645,11 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         //  wavefronts; kept for experiments.)
         std::vector<int32_t> order((size_t)nw);
         for (int u = 0; u < nw; u++) order[(size_t)u] = u;
+        // fillh8_kernel's launch: as many workgroups as the device holds at once (four per compute unit: 40 KB of LDS each),
+        // fewer for a short list; a list that cannot give every resident wavefront eight candidates uses fewer groups of it
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int h8Resident = std::max(cus, 1) * 4;
         const int G = 4;  // candidates per wavefront of fillp_kernel<16, ., true>
         const int W = hybrid8 ? nw : (nw + G - 1) / G;
         std::vector<int32_t> t2((size_t)W * (hybrid8 ? 1 : G), -1), s2((size_t)W * (hybrid8 ? 1 : G), 512);
@@ -668,7 +674,26 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
           for (int u = 0; u < nw; u++) head[(size_t)bucket(u) + 1]++;
           for (int b = 0; b < 65536; b++) head[(size_t)b + 1] += head[(size_t)b];
           for (int u = 0; u < nw; u++) order[(size_t)head[(size_t)bucket(u)]++] = u;
-          for (int p = 0; p < nw; p++) place((size_t)p, order[(size_t)p]);
+          // The first round: as many candidates as the launch has groups of eight lanes, DEALT -- wavefront w gets ranks w,
+          // w + W, w + 2 W, ... of the order, one of the heaviest and ever lighter ones -- because a wavefront takes the wide rows
+          // of its candidates one after the other.  Behind it the order itself, handed out as groups become free.
+          h8Grid = std::min(h8Resident, (nw + 31) / 32 * 8);
+          if (const char *e = getenv("BLASR_HIP_H8_GRID")) h8Grid = std::max(atoi(e), 1);
+          h8Groups = std::min(8, std::max(1, (nw + 4 * h8Grid - 1) / (4 * h8Grid)));
+          if (const char *e = getenv("BLASR_HIP_H8_GROUPS")) h8Groups = std::min(8, std::max(atoi(e), 1));
+          const int slots = 4 * h8Grid * h8Groups;       // groups that take candidates
+          const int R = std::min(nw, slots);             // candidates of the first round
+          const int Wn = (R + h8Groups - 1) / h8Groups;  // wavefronts that get any
+          h8FirstRound = Wn * h8Groups;
+          t2.assign((size_t)(h8FirstRound + (nw - R)), -1);
+          s2.assign(t2.size(), 512);
+          o2.assign(t2.size(), 0);
+          for (int w = 0; w < Wn; w++)
+            for (int g = 0; g < h8Groups; g++) {
+              const int rank = g * Wn + w;
+              if (rank < R) place((size_t)(w * h8Groups + g), order[(size_t)rank]);
+            }
+          for (int p = R; p < nw; p++) place((size_t)(h8FirstRound + (p - R)), order[(size_t)p]);
         } else if (orderEnv && !strcmp(orderEnv, "lpt")) {
           // The four candidates of a wavefront step through their narrow rows together, so a wavefront costs
           // (its longest candidate's rows) x (a narrow step) + (the wide cells of all four): candidates of about the same
@@ -731,7 +756,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         c.wideTasks.swap(t2);
         c.wideRingOff.swap(o2);
         c.wideRingSize.swap(s2);
-        nw = hybrid8 ? nw : W * G;
+        nw = hybrid8 ? (int)c.wideTasks.size() : W * G;
       }
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
@@ -740,15 +765,9 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
       fw.count = nw;
       if (hybrid) fw.taskList = dWideTasks;
       if (hybrid8) {
-        // as many workgroups as the device holds at once (four per compute unit: 40 KB of LDS each), fewer for a short list;
-        // a list that cannot give every resident wavefront eight candidates uses fewer groups per wavefront
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const int resident = std::max(cus, 1) * 4;
-        if (const char *e = getenv("BLASR_HIP_H8_GRID")) fw.gridGroups = std::max(atoi(e), 1);
-        else fw.gridGroups = std::min(resident, (nw + 31) / 32 * 8);
-        fw.groups = std::min(8, std::max(1, (nw + 4 * fw.gridGroups - 1) / (4 * fw.gridGroups)));
-        if (const char *e = getenv("BLASR_HIP_H8_GROUPS")) fw.groups = std::min(8, std::max(atoi(e), 1));
+        fw.gridGroups = h8Grid;
+        fw.groups = h8Groups;
+        fw.firstRound = h8FirstRound;
         HIP_TRY(ctx, hipMemsetAsync(dQueue, 0, sizeof(int32_t), st));
       }
       if (hybrid && getenv("BLASR_HIP_DUMP_HYBRID")) {  // the list as launched, per slot {passes, narrow rows, wide rows, wide steps, rows, cells}

@@ -68,6 +68,7 @@ struct FillArgs {
   // groups of a wavefront take candidates, `gridGroups` workgroups are launched (the resident ones, or fewer)
   int *queue;
   int groups, gridGroups;
+  int firstRound;  // the list's first slots have fixed owners (wavefront w, group g: slot w * groups + g); the queue hands out the rest
 };
 
 struct TraceArgs {

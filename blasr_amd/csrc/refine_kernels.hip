@@ -1837,6 +1837,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
   // too short to give every resident wavefront eight uses fewer, so that wide rows of different candidates do not queue up
   // behind each other in one wavefront while other compute units are empty.
   bool drained = grp >= args.groups;
+  bool firstFetch = true;
   uint2 recCur = make_uint2(0u, 0u);
   for (;;) {
     if (__ballot(!alive && !drained) != 0ull) {
@@ -1846,9 +1847,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
           args.dpScore[myTask] =
               (myPrevGlobal ? myGRing[(myTEnd - 1) & myGMask].x : ring[(myTEnd - 1) & (kF4Ring - 1)].x) >> kShift;
         myTask = -1;
+        // The FIRST candidate of a group has a fixed place in the list -- wavefront w, group g: slot w * groups + g -- so that
+        // the host can deal the heaviest candidates to different wavefronts (a wavefront takes its candidates' wide rows one
+        // after the other: with the eight heaviest in one of them a list of a few ten thousand candidates took as long as
+        // that wavefront); the others come from the queue, which starts behind the first round.
         int slot = 0;
-        if (l == 0) slot = atomicAdd(args.queue, 1);
-        slot = __builtin_amdgcn_ds_bpermute((lane & ~(kL - 1)) * 4, slot);
+        if (firstFetch) {
+          slot = (int)(blockIdx.x * 4 + wave) * args.groups + grp;
+          if (slot >= args.firstRound) slot = args.count;  // (no such slot: from the queue next time round)
+          firstFetch = false;
+          if (slot >= args.count) {
+            if (l == 0) slot = args.firstRound + atomicAdd(args.queue, 1);
+            slot = __builtin_amdgcn_ds_bpermute((lane & ~(kL - 1)) * 4, slot);
+          }
+        } else {
+          if (l == 0) slot = args.firstRound + atomicAdd(args.queue, 1);
+          slot = __builtin_amdgcn_ds_bpermute((lane & ~(kL - 1)) * 4, slot);
+        }
         if (slot >= args.count) {
           drained = true;
         } else {
