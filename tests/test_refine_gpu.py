@@ -416,6 +416,35 @@ def test_fillh8_wide_pieces_and_the_queue(ctx, oracle, monkeypatch, grid):
     assert any("fillh8_kernel" in n for n in names) and not any("fill8_kernel" in n or "fillp_kernel" in n for n in names), names
 
 
+@pytest.mark.parametrize("band", [0, 1, 39, 40, 55, 56, 60, 120, 300])
+def test_fillh8_bands_from_none_to_every_row_wide(ctx, oracle, band):
+    """The band decides what `fillh8_kernel` sees: with 39 / 40 columns either side a plain row has 79 / 81 cells (two and three
+    passes of 40), with 55 / 56 it has 111 / 113 -- the last narrow width and the first WIDE one: from there on every row of every
+    candidate is a wide row (runs as long as the candidate, row 0 included), and with 300 a row is beyond what a run holds (one row
+    at a time through the ring in global memory).  Batches of noisy pairs and guides with gaps, against the oracle."""
+    rng = np.random.default_rng(3100 + band)
+    b, want = blasr_amd.RefineBatch(), []
+    for it in range(14):
+        if it % 3 == 2:
+            q, t, blocks = _guide_with_gaps(rng, [(int(rng.integers(0, 90)), int(rng.integers(0, 400)))] * int(rng.integers(1, 4)),
+                                            block=int(rng.integers(5, 70)), n_base=(it % 2 == 0))
+        else:
+            q, t = synth.make_pair(rng, int(rng.integers(60, 1200)), flank=(0, int(rng.integers(0, 60))))
+            s = oracle.sdp_align(q, t)
+            blocks = s["blocks"]
+            if len(blocks) == 0:
+                continue
+            q = np.ascontiguousarray(q[s["qPos"]: s["qPos"] + blocks[-1, 0] + blocks[-1, 2]])
+            t = np.ascontiguousarray(t[s["tPos"]: s["tPos"] + blocks[-1, 1] + blocks[-1, 2]])
+        b.add(q, t, blocks)
+        want.append(oracle.affine_guided_align(q, t, blocks, band=band))
+    got = ctx.refine(b, band=band)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.status == 0, (band, i)
+        assert first_difference(g.as_dict(), w, REFINE_KEYS) is None, (band, i)
+    assert any("fillh8_kernel" in k["name"] for k in ctx.last_kernels())
+
+
 @pytest.mark.parametrize("switch", [None, "BLASR_HIP_NO_HYBRID"])
 def test_guides_with_several_gaps_share_wavefronts(ctx, oracle, monkeypatch, switch):
     """What the hybrid fill kernel is for (candidates whose rows are narrow except where the guide jumps): guides of
