@@ -71,8 +71,14 @@ constexpr int kTinyT = 128;
 constexpr int kBitsMaxTarget = 131072;
 constexpr int kBitsSmallTarget = 16384;  // sdp_chain_bits_kernel's small instantiation (2 KB of LDS per wavefront)
 constexpr int kBitsMidTarget = 65536;    // ... and its middle one (8 KB: five workgroups of four wavefronts per CU; the large one, 16 KB, two)
-constexpr int kBits4Target = 4096;   // sdp_chain_bits4_kernel: columns (128 words of LDS per invocation) ...
-constexpr int kBits4MaxFrags = 1024; // ... and fragments of the invocations it takes
+#ifndef BLASR_BITS4_COLS
+#define BLASR_BITS4_COLS 4096
+#endif
+constexpr int kBits4Target = BLASR_BITS4_COLS;   // sdp_chain_bits4_kernel: columns (128 words of LDS per invocation) ...
+#ifndef BLASR_BITS4_FRAGS
+#define BLASR_BITS4_FRAGS 4096
+#endif
+constexpr int kBits4MaxFrags = BLASR_BITS4_FRAGS; // ... and fragments of the invocations it takes
 constexpr int kWideSets = 8;         // register sets of 64 column-set entries in sdp_chain_wide_kernel
 __host__ __device__ inline bool task_may_scatter(const SdpTask &t, int rawFragments) {
   return t.type == 1 && rawFragments > 16 && t.tLen <= kBitsMaxTarget;
