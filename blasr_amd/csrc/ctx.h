@@ -26,9 +26,9 @@ struct blasr_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t sideStream = nullptr;  // long thin kernels that can run underneath the main ones
   // the sweep's kernels of one recursion level work on disjoint invocations: they run side by side (sdp_api.hip)
-  enum { kAuxStreams = 3 };
-  hipStream_t auxStream[kAuxStreams] = {nullptr, nullptr, nullptr};
-  hipEvent_t auxEvent[kAuxStreams + 1] = {nullptr, nullptr, nullptr, nullptr};  // [0] fork, [1..] joins
+  enum { kAuxStreams = 4 };
+  hipStream_t auxStream[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t auxEvent[kAuxStreams + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0] fork, [1..] joins
   hipEvent_t events[16] = {};        // timing / cross-stream events of the refine call, created with the context
   char *workspace = nullptr;
   size_t workspaceBytes = 0;

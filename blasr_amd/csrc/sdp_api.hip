@@ -165,7 +165,8 @@ const char *blasr_hip_sdp_kernel_name(int kind) {
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL: return "blasr_hip::sdp_chain_bits_kernel<512>";
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID: return "blasr_hip::sdp_chain_bits_kernel<2048>";
     case BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE: return "blasr_hip::sdp_chain_bits_kernel<4096>";
-    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS4: return "blasr_hip::sdp_chain_bits4_kernel";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS4: return "blasr_hip::sdp_chain_bits4_kernel<false>";
+    case BLASR_HIP_SDP_KERNEL_CHAIN_BITS4_WIDE: return "blasr_hip::sdp_chain_bits4_kernel<true>";
     case BLASR_HIP_SDP_KERNEL_CHAIN_ROWS: return "blasr_hip::sdp_chain_rows_kernel";
     case BLASR_HIP_SDP_KERNEL_FILLS: return "blasr_hip::sw_small_kernel + sw_kernel";
   }
@@ -189,7 +190,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
   HIP_TRY(ctx, hipEventCreate(&ev.a));
   HIP_TRY(ctx, hipEventCreate(&ev.b));
   hipEvent_t evA = ev.a, evB = ev.b;
-  float phaseMs[4] = {0, 0, 0, 0};
+  float phaseMs[4] = {0, 0, 0, 0}, levelMs[4] = {0, 0, 0, 0};  // (levelMs: the level at hand, for BLASR_HIP_SDP_TRACE)
   int64_t phaseBytes[4] = {0, 0, 0, 0};  // algorithmic bytes by SURVEY 8(d)'s model, see blasr_hip_sdp_last_bytes
   auto tick = [&]() { (void)hipEventRecord(evA, st); };
   auto tock = [&](int phase) {
@@ -198,6 +199,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     float t = 0;
     (void)hipEventElapsedTime(&t, evA, evB);
     phaseMs[phase] += t;
+    levelMs[phase] += t;
   };
 #define ARENA_CHECK()                                                                                        \
   do {                                                                                                       \
@@ -303,6 +305,7 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       // a row per step for the scattered invocations with >= 4 fragments per query row on average and >= 1024 fragments
       // (BLASR_HIP_CHAIN_ROWS="minFrags,densityX2"; "0" switches the kernel off; BLASR_HIP_ROWS_PRIO raises its wavefronts'
       // priority, which is NOT the default).  configs[4], three runs each on one box: sweep 528-530 ms with it, 544-646 without (profiles/NOTES.md)
+      lv.bits4Wide = getenv("BLASR_HIP_BITS4_WIDE") != nullptr ? atoi(getenv("BLASR_HIP_BITS4_WIDE")) : 4096;
       lv.rowsPrio = getenv("BLASR_HIP_ROWS_PRIO") != nullptr ? 1 : 0;
       lv.rowsMinFrags = 1024;
       lv.rowsDensityX2 = 8;
@@ -500,8 +503,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     if (getenv("BLASR_HIP_SDP_TRACE") && lv.chainList != nullptr) {  // the sweep's categories and its largest invocations
       int32_t cnt[kChainCats] = {};
       HIP_TRY(ctx, hipMemcpy(cnt, lv.chainCount, sizeof(cnt), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[sdp] level %d sweep: chain4 %d, wide %d, bits4 %d, bits %d, bits-mid %d, bits-large %d, rows %d;", level, cnt[0],
-              cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6]);
+      fprintf(stderr, "[sdp] level %d sweep: chain4 %d, wide %d, bits4 %d + %d with the larger map, bits %d, bits-mid %d, bits-large %d, rows %d;",
+              level, cnt[0], cnt[1], cnt[2], cnt[7], cnt[3], cnt[4], cnt[5], cnt[6]);
       int at = 0;
       for (int c = kChainCats - 1; c >= 0; c--) {
         if (cnt[c] > 0) {
@@ -608,6 +611,9 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
       (void)hipMemcpy(&nTies, lv.tieCount, sizeof(int32_t), hipMemcpyDeviceToHost);
       fprintf(stderr, "[sdp] level %d: tasks %d keys %lld frags %lld -> blocks %llu sw %llu children %llu; %d invocations with ties\n", level,
               nTasks, (long long)totalKeys, (long long)nFragTotal, hc.pool, hc.sw, hc.child, nTies);
+      fprintf(stderr, "[sdp] level %d: keys + sort %.1f ms, match + order %.1f, sweep %.1f, blocks %.1f\n", level, levelMs[0], levelMs[1],
+              levelMs[2], levelMs[3]);
+      for (float &m : levelMs) m = 0;
     }
     LevelOut lo;
     lo.poolKeys = e.poolKeys;

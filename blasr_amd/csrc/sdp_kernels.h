@@ -97,11 +97,13 @@ struct SdpLevelArrays {
   // kChainCats category counts: chainCount[0] sdp_chain4_kernel's; the others are the invocations whose fragments scatter
   // over the rectangle (the recursion's Global calls: unrelated sequence gives chance matches anywhere), which come FIRST
   // in the list: [6] sdp_chain_rows_kernel, [5] sdp_chain_bits_kernel with a target beyond 65536 columns, [4] beyond
-  // 16384, [3] a smaller one, [2] sdp_chain_bits4_kernel, [1] sdp_chain_wide_kernel.  chainList null: everything through
+  // 16384, [3] a smaller one, [2] sdp_chain_bits4_kernel, [7] the same with the larger map, [1] sdp_chain_wide_kernel.  chainList null: everything through
   // sdp_chain_kernel.
   int32_t *chainList, *chainCount;
   int scatterMode;              // tests: 1 the scattered invocations take sdp_chain_wide_kernel; 2 the bitmap sweep one per wavefront;
                                 // 3 sdp_chain_rows_kernel, all of them
+  int bits4Wide;                // the scattered invocations of at most this many fragments on targets of 4097 .. 16384 columns go four per
+                                // wavefront too (category 7; BLASR_HIP_BITS4_WIDE, 0: they keep a wavefront each, category 3)
   int rowsPrio;                     // experiments (BLASR_HIP_ROWS_PRIO): sdp_chain_rows_kernel's wavefronts at a raised priority (default: not raised)
   int rowsMinFrags, rowsDensityX2;  // sdp_chain_rows_kernel takes the scattered invocations with at least rowsMinFrags fragments and
                                     // rowsDensityX2 / 2 fragments per query row on average (rowsMinFrags 0: none)

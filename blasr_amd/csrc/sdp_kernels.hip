@@ -2419,6 +2419,7 @@ __host__ __device__ inline int chain_category_kind(int cat) {
     case 4: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID;
     case 5: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE;
     case 6: return BLASR_HIP_SDP_KERNEL_CHAIN_ROWS;
+    case 7: return BLASR_HIP_SDP_KERNEL_CHAIN_BITS4_WIDE;
   }
   return -1;  // (1: sdp_chain_wide_kernel, tests only)
 }
@@ -2448,6 +2449,8 @@ __global__ __launch_bounds__(256) void sdp_chain_list_kernel(SdpLevelArrays lv, 
     const int tl = lv.tasks[i].tLen;
     const int bySize = tl > kBitsMidTarget ? 5 : (tl > kBitsSmallTarget ? 4 : 3);
     cat = lv.scatterMode == 1 ? 1 : ((bySize > 3 || tl > kBits4Target || lv.nFrag[i] > kBits4MaxFrags || lv.scatterMode == 2) ? bySize : 2);
+    // (a target of up to 16384 columns with few fragments: four per wavefront as well, with the larger map -- category 7)
+    if (cat == 3 && lv.scatterMode == 0 && lv.nFrag[i] <= min(lv.bits4Wide, kBits4MaxFrags)) cat = 7;
     // the long invocations with several fragments per query row: a row per step (sdp_chain_rows_kernel)
     const int nf = lv.nFrag[i];
     if (lv.scatterMode == 3 || (lv.scatterMode == 0 && lv.rowsMinFrags > 0 && nf >= lv.rowsMinFrags &&
@@ -3914,16 +3917,18 @@ __device__ __forceinline__ void chain_bits4_body(const SdpLevelArrays &lv, const
   if (on && l == 0) lv.chainEnd[idx] = type == 0 ? minIdx : maxLenIdx;
 }
 
-// category 2 of the chain list (small targets, few fragments), four per wavefront
-__global__ __launch_bounds__(256, 8) void sdp_chain_bits4_kernel(SdpLevelArrays lv, SdpParams prm) {
-  __shared__ uint32_t bits[4][4][kBits4Target / 32];
+// category 2 of the chain list (small targets, few fragments), four per wavefront; kWide: category 7, the targets of up to
+// kBitsSmallTarget columns with as few fragments (32 KB of maps per workgroup: five workgroups per CU instead of eight)
+template <bool kWide>
+__global__ __launch_bounds__(256, kWide ? 4 : 8) void sdp_chain_bits4_kernel(SdpLevelArrays lv, SdpParams prm) {
+  constexpr int kWords = (kWide ? kBitsSmallTarget : kBits4Target) / 32, kCat = kWide ? 7 : 2;
+  __shared__ uint32_t bits[4][4][kWords];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int nList = lv.chainCount[2];
+  const int nList = lv.chainCount[kCat];
   const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave)) * 4 + (lane >> 4);
   if (__builtin_amdgcn_readfirstlane(slot) >= nList) return;
   const bool on = slot < nList;
-  chain_bits4_body<kBits4Target / 32>(lv, prm, on, on ? lv.chainList[chain_list_start(lv, 2) + slot] : 0,
-                                      bits[wave][lane >> 4]);
+  chain_bits4_body<kWords>(lv, prm, on, on ? lv.chainList[chain_list_start(lv, kCat) + slot] : 0, bits[wave][lane >> 4]);
 }
 
 // sdp_chain_wide: one scattered invocation per wavefront, the sweep of sdp_chain_kernel with 256 entries of the column
@@ -5158,14 +5163,14 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
       // The categories are disjoint sets of invocations and the long ones are serial chains whose kernels end in a
       // tail of a few wavefronts: side by side the throughput-bound kernels (chain4, bits4) fill the device under it.
       const bool fork = aux != nullptr && ev != nullptr;
-      hipStream_t s0 = st, s1 = st, s2 = st;
+      hipStream_t s0 = st, s1 = st, s2 = st, s3 = st;
       if (fork) {
         (void)hipEventRecord(ev[0], st);
-        for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
-        s0 = aux[0], s1 = aux[1], s2 = aux[2];
+        for (int i = 0; i < 4; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+        s0 = aux[0], s1 = aux[1], s2 = aux[2], s3 = aux[3];
       }
       int conc = 0;  // how many of the sweep's kernels run side by side
-      for (int c : {0, 2, 3, 4, 5, 6}) conc += (!counts || counts[c] > 0) ? 1 : 0;
+      for (int c : {0, 2, 3, 4, 5, 6, 7}) conc += (!counts || counts[c] > 0) ? 1 : 0;
       if (!fork) conc = 1;
       if (!counts || counts[6] > 0) {  // (the level's longest invocations: first, on the main stream)
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_ROWS, st, conc);
@@ -5186,9 +5191,15 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL, s1, conc);
         hipLaunchKernelGGL(sdp_chain_bits_kernel<kBitsSmallTarget / 32>, grid_for(3, 1), dim3(256), 0, s1, lv, p);
       }
+      // (the two bits4 kernels on a stream each: one after the other -- as kernels bound by the same unit usually go on this device
+      //  -- the level waited for both tails, 144 against 118 ms of sweep per configs[2] step)
+      if (!counts || counts[7] > 0) {
+        SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS4_WIDE, s3, conc);
+        hipLaunchKernelGGL(sdp_chain_bits4_kernel<true>, grid_for(7, 4), dim3(256), 0, s3, lv, p);
+      }
       if (!counts || counts[2] > 0) {
         SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_CHAIN_BITS4, s2, conc);
-        hipLaunchKernelGGL(sdp_chain_bits4_kernel, grid_for(2, 4), dim3(256), 0, s2, lv, p);
+        hipLaunchKernelGGL(sdp_chain_bits4_kernel<false>, grid_for(2, 4), dim3(256), 0, s2, lv, p);
       }
       if (lv.scatterMode == 1) hipLaunchKernelGGL(sdp_chain_wide_kernel, grid_for(1, 1), dim3(256), 0, s2, lv, p);
       if (!counts || counts[0] > 0) {
@@ -5196,7 +5207,7 @@ void launch_sdp_chain(const SdpLevelArrays &lv, const SdpParams &p, hipStream_t 
         hipLaunchKernelGGL(sdp_chain4_kernel, grid_for(0, 4), dim3(256), 0, st, lv, p);
       }
       if (fork)
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 4; i++) {
           (void)hipEventRecord(ev[1 + i], aux[i]);
           (void)hipStreamWaitEvent(st, ev[1 + i], 0);
         }

@@ -290,11 +290,12 @@ enum { BLASR_HIP_SDP_KERNEL_MATCH_INDEX = 0, /* sdp_match_index_kernel<false> + 
        BLASR_HIP_SDP_KERNEL_CHAIN4 = 3,      /* sdp_chain4_kernel: near-diagonal invocations, four per wavefront */
        BLASR_HIP_SDP_KERNEL_CHAIN_BITS_SMALL = 4, /* sdp_chain_bits_kernel<512>: scattered, target <= 16384 columns */
        BLASR_HIP_SDP_KERNEL_CHAIN_BITS_LARGE = 5, /* sdp_chain_bits_kernel<4096>: target <= 131072 columns */
-       BLASR_HIP_SDP_KERNEL_CHAIN_BITS4 = 6, /* sdp_chain_bits4_kernel: short scattered invocations, four per wavefront */
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS4 = 6, /* sdp_chain_bits4_kernel<false>: short scattered invocations, four per wavefront (target <= 4096 columns) */
        BLASR_HIP_SDP_KERNEL_CHAIN_ROWS = 7,  /* sdp_chain_rows_kernel: scattered invocations, a batch of sweep rows per step */
        BLASR_HIP_SDP_KERNEL_FILLS = 8,       /* sw_small_kernel + sw_kernel: SWAlign(Global) gap fills */
        BLASR_HIP_SDP_KERNEL_CHAIN_BITS_MID = 9, /* sdp_chain_bits_kernel<2048>: target <= 65536 columns */
-       BLASR_HIP_SDP_KERNEL_KINDS = 10 };
+       BLASR_HIP_SDP_KERNEL_CHAIN_BITS4_WIDE = 10, /* sdp_chain_bits4_kernel<true>: the same on targets of 4097 .. 16384 columns */
+       BLASR_HIP_SDP_KERNEL_KINDS = 11 };
 typedef struct blasr_hip_sdp_kernel_record {
   int32_t kind;
   int32_t launches;

@@ -374,3 +374,35 @@ def test_dense_rows_through_the_row_sweep(ctx, oracle, monkeypatch):
             for i, ((q, t), g, w) in enumerate(zip(rect, got, want)):
                 st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
                 _check(g, w, st, "dense rows k=%d %d mode %s" % (k, i, mode))
+
+
+def test_scattered_invocations_on_targets_of_4097_to_16384_columns(ctx, oracle, monkeypatch):
+    """The bitmap sweep four per wavefront with the larger map (sdp_chain_bits4_kernel<true>: category 7 of the sweep's
+    list -- few fragments on a target of 4097 .. 16384 columns): Global calls with short words on random rectangles of
+    that shape, with the category (default), with half its fragment bound and without it (BLASR_HIP_BITS4_WIDE=0: a
+    wavefront each), against the oracle; the kernel's record says whether it ran."""
+    from blasr_testlib import SdpParams as OSdp
+    rng = np.random.default_rng(20260)
+
+    def as_list(st):
+        return [st["score"], st["nMatch"], st["nMismatch"], st["nIns"], st["nDel"]]
+
+    for k, shapes in ((7, ((2500, 12000), (900, 16384), (3000, 4097), (1200, 9000), (5000, 12000), (40, 5000))),
+                      (5, ((150, 6000), (100, 9000), (60, 16000)))):
+        rect = [(synth.random_genome(q, 3000 + 17 * i + k), synth.random_genome(t, 4000 + 19 * i + k)) for i, (q, t) in enumerate(shapes)]
+        rect += [(synth.random_genome(int(rng.integers(300, 1500)), 5000 + i), synth.random_genome(int(rng.integers(4100, 16000)), 6000 + i))
+                 for i in range(6)]
+        osp = OSdp(k=k, align_type=GLOBAL, prefix=0, recurse=1)
+        sp = blasr_amd.SdpParams(k=k, align_type=1, prefix=0, recurse=1)
+        want = [oracle.sdp_align(q, t, None, osp) for q, t in rect]
+        for bound in (None, "2000", "0"):
+            if bound is not None:
+                monkeypatch.setenv("BLASR_HIP_BITS4_WIDE", bound)
+            got = ctx.sdp(rect, sdp=sp)
+            if bound is not None:
+                monkeypatch.delenv("BLASR_HIP_BITS4_WIDE")
+            ran = [r for r in ctx.sdp_last_kernels() if r["name"].endswith("sdp_chain_bits4_kernel<true>")]
+            assert (len(ran) == 1 and ran[0]["invocations"] > 0) == (bound != "0"), (k, bound, ran)
+            for i, ((q, t), g, w) in enumerate(zip(rect, got, want)):
+                st = as_list(oracle.compute_alignment_stats(q, t, w["qPos"], w["tPos"], w["blocks"]))
+                _check(g, w, st, "wide bits4 k=%d %d bound %s" % (k, i, bound))
