@@ -2,6 +2,7 @@
 // Host-side only: context, grow-only device workspace, batch planning and the
 // kernel sequence of one refine call.  There is deliberately no CPU path here:
 // without a gfx950 device every entry point returns BLASR_HIP_ERR_NO_DEVICE.
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -379,6 +380,15 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
 
   // ---- geometry -------------------------------------------------------------
   TaskGeometry *dGeo = reinterpret_cast<TaskGeometry *>(ctx->workspace + oGeo);
+  const bool planTrace = getenv("BLASR_HIP_PLAN_TRACE") != nullptr;
+  auto hostNow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double pt0 = hostNow();
+  auto planMark = [&](const char *what) {
+    if (!planTrace) return;
+    const double t = hostNow();
+    fprintf(stderr, "[plan] %s: %.3f ms\n", what, t - pt0);
+    pt0 = t;
+  };
   HIP_TRY(ctx, hipEventRecord(ev[0], st));
   launch_geometry(view, band, 0, n, dGeo, st, getenv("BLASR_HIP_GEOMETRY_WALK") != nullptr);
   HIP_TRY(ctx, hipEventRecord(ev[1], st));
@@ -387,6 +397,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   HIP_TRY(ctx, hipMemcpyAsync(geo.data(), dGeo, sizeof(TaskGeometry) * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  planMark("geometry kernel + copy to the host");
   if (getenv("BLASR_HIP_GEOMETRY_CHECK")) {  // the closed forms of geometry_blocks_kernel against the walk over the rows
     std::vector<TaskGeometry> walked((size_t)n);
     launch_geometry(view, band, 0, n, dGeo, st, true);
@@ -444,6 +455,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
   for (int i = 0; i < 25; i++) six = six && score->matrix[i] >= -32 && score->matrix[i] <= 31;
   const bool hybrid8 = hybrid && six && !getenv("BLASR_HIP_HYBRID4");
 
+  planMark("totals + domain");
   // ---- plan: contiguous chunks of candidates that fit the workspace ----------
   Plan plan;
   plan.arrowOff.resize(n);
@@ -489,18 +501,85 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     };
     // a batch that does not fit is cut into pieces of about the SAME size (every piece pays the kernels' tails once:
     // a large piece and a small remainder cost more than two halves)
-    size_t total = 0;
-    for (int i = 0; i < n; i++) {
-      size_t a, r, ar, w;
-      int ringSize;
-      total += need_of(i, a, r, ar, w, ringSize);
+    // What every candidate needs, side by side on the host's threads (the three offset arrays hold the SIZES until the loop
+    // below turns them into offsets): the device has nothing to do while the host plans, and one thread took 3.7 ms over
+    // configs[2]'s 186 k candidates.
+    std::vector<int32_t> ringOf((size_t)n);
+    int planThreads = n >= 16384 ? blasr_hip_host_threads((int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+    if (const char *e = getenv("BLASR_HIP_PLAN_THREADS")) planThreads = std::max(1, std::min(atoi(e), std::max(n, 1)));  // (tests: small batches through the threaded plan)
+    struct PartSums {
+      size_t need = 0, a = 0, r = 0, ar = 0, w = 0, nWide = 0;
+    };
+    std::vector<PartSums> part((size_t)planThreads);
+    {
+      const int trc = blasr_hip_run_threads(planThreads, [&](int th) {
+        const int lo = (int)((int64_t)n * th / planThreads), hi = (int)((int64_t)n * (th + 1) / planThreads);
+        PartSums s;
+        for (int i = lo; i < hi; i++) {
+          size_t a, r, ar, w;
+          int ringSize;
+          s.need += need_of(i, a, r, ar, w, ringSize);
+          plan.arrowOff[i] = (int64_t)a;
+          plan.rowOff[i] = (int64_t)r;
+          plan.arenaOff[i] = (int64_t)ar;
+          ringOf[(size_t)i] = ringSize;
+          s.a += a, s.r += r, s.ar += ar, s.w += w, s.nWide += ringSize ? 1 : 0;
+        }
+        part[(size_t)th] = s;
+      });
+      if (trc) {
+        destroyEvents();
+        return fail(ctx, trc, "the refine planner's threads");
+      }
     }
+    size_t total = 0;
+    for (const PartSums &v : part) total += v.need;
     const size_t pieces = std::max<size_t>((total + budget - 1) / budget, 1);
     const size_t target = pieces > 1 ? std::min(budget, total / pieces + total / (pieces * 32) + (1u << 20)) : budget;
+    if (pieces == 1 && planThreads > 1) {
+      // one piece (the usual case): the offsets are the running sums of the sizes, every thread from its part's start
+      std::vector<PartSums> start((size_t)planThreads);
+      PartSums run;
+      for (int th = 0; th < planThreads; th++) {
+        start[(size_t)th] = run;
+        const PartSums &v = part[(size_t)th];
+        run.a += v.a, run.r += v.r, run.ar += v.ar, run.w += v.w, run.nWide += v.nWide;
+      }
+      cur.wideTasks.resize(run.nWide);
+      cur.wideRingOff.resize(run.nWide);
+      cur.wideRingSize.resize(run.nWide);
+      const int trc = blasr_hip_run_threads(planThreads, [&](int th) {
+        const int lo = (int)((int64_t)n * th / planThreads), hi = (int)((int64_t)n * (th + 1) / planThreads);
+        PartSums s = start[(size_t)th];
+        for (int i = lo; i < hi; i++) {
+          const size_t a = (size_t)plan.arrowOff[i], r = (size_t)plan.rowOff[i], ar = (size_t)plan.arenaOff[i];
+          const int ringSize = ringOf[(size_t)i];
+          plan.arrowOff[i] = (int64_t)s.a;
+          plan.rowOff[i] = (int64_t)(s.r / sizeof(int2));
+          plan.arenaOff[i] = (int64_t)(s.ar / sizeof(uint32_t));
+          s.a += a, s.r += r, s.ar += ar;
+          if (ringSize) {
+            cur.wideTasks[s.nWide] = i;
+            cur.wideRingOff[s.nWide] = (int64_t)s.w;
+            cur.wideRingSize[s.nWide] = ringSize;
+            s.nWide++;
+            s.w += align_up((size_t)ringSize * 12, 256);
+          }
+        }
+      });
+      if (trc) {
+        destroyEvents();
+        return fail(ctx, trc, "the refine planner's threads");
+      }
+      arrowB = run.a, rowB = run.r, arenaB = run.ar;
+      cur.wideBytes = run.w;
+      cur.count = n;
+    } else
     for (int i = 0; i < n; i++) {
-      size_t a = 0, r = 0, ar = 0, w = 0;
-      int ringSize = 0;
-      const size_t need = need_of(i, a, r, ar, w, ringSize);
+      const size_t a = (size_t)plan.arrowOff[i], r = (size_t)plan.rowOff[i], ar = (size_t)plan.arenaOff[i];
+      const int ringSize = ringOf[(size_t)i];
+      const size_t w = ringSize ? align_up((size_t)ringSize * 12, 256) : 0;
+      const size_t need = a + r + r / 4 + ar + w + 1280;
       if (cur.count > 0 && arrowB + rowB + rowB / 4 + arenaB + cur.wideBytes + need > target) flush(i);
       if (need > budget) {
         destroyEvents();
@@ -549,6 +628,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         fprintf(stderr, "[refine] widest row <= %d: %lld candidates, %lld rows, %lld cells (%.1f per row)\n", edges[b],
                 (long long)cnt[b], (long long)rows[b], (long long)cells[b], (double)cells[b] / (double)rows[b]);
   }
+  planMark("chunk plan");
   size_t maxChunk = 0;
   for (auto &c : plan.chunks) maxChunk = std::max(maxChunk, c.bytes);
   const size_t oVar = fixedBytes;
@@ -624,6 +704,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
     fa.queue = dQueue;
     fa.groups = 8;
     fa.gridGroups = 1;
+    planMark("uploads enqueued + chunk bases");
     HIP_TRY(ctx, hipEventRecord(ev[2], st));
     // the row records of the chunk's candidates, now that they have their place in the workspace
     launch_geometry_rows(view, band, c.first, c.count, dGeo, fa.rowTab, dRowOff, reinterpret_cast<unsigned short *>(pMeta), st);
@@ -758,6 +839,7 @@ int blasr_hip_refine_device(blasr_hip_ctx *ctx, const blasr_hip_refine_batch *b,
         c.wideRingSize.swap(s2);
         nw = hybrid8 ? (int)c.wideTasks.size() : W * G;
       }
+      planMark("fill list (order, placement)");
       HIP_TRY(ctx, hipMemcpyAsync(dWideTasks, c.wideTasks.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideOff, c.wideRingOff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, st));
       HIP_TRY(ctx, hipMemcpyAsync(dWideSize, c.wideRingSize.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, st));

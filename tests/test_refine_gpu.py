@@ -47,7 +47,10 @@ def test_golden_vectors_as_one_batch(ctx, golden):
         assert first_difference(got.as_dict(), c.expected_refine(), REFINE_KEYS) is None, c.name
 
 
-def test_chunked_workspace_gives_identical_results(golden):
+@pytest.mark.parametrize("plan_threads", [None, "4"])
+def test_chunked_workspace_gives_identical_results(golden, monkeypatch, plan_threads):
+    if plan_threads:  # (the candidates' sizes by four host threads, the pieces cut by one: what a batch of 16 k candidates and more gets)
+        monkeypatch.setenv("BLASR_HIP_PLAN_THREADS", plan_threads)
     cases = [c for c in golden_cases(golden) if c.has_refine and c.band == 16
              and np.array_equal(c.sc.matrix, SMRT_MATRIX) and c.sc.affine_open == 50]
     b = blasr_amd.RefineBatch()
@@ -321,13 +324,14 @@ def test_fill8_pass_boundaries_and_domain_edges(ctx, oracle, monkeypatch, lanes1
             assert any(kernel in k["name"] for k in ctx.last_kernels()), (lim, [k["name"] for k in ctx.last_kernels()])
 
 
-@pytest.mark.parametrize("switch", [None, "BLASR_HIP_H8_SPLIT", "BLASR_HIP_HYBRID4", "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4"])
+@pytest.mark.parametrize("switch", [None, "BLASR_HIP_H8_SPLIT", "BLASR_HIP_HYBRID4", "BLASR_HIP_NO_HYBRID", "BLASR_HIP_NO_FILL4", "BLASR_HIP_PLAN_THREADS"])
 def test_guides_with_large_drift_against_oracle(ctx, oracle, monkeypatch, switch):
     """Guides whose consecutive blocks drift by hundreds to thousands of columns (what SDPAlign(Local) makes of a repeat
     copy the read overlaps only in part: it chains on through chance fragments): rows of band + |drift| cells, on
-    both sides of what the LDS ring holds (192 cells; the global-memory ring beyond), against the oracle."""
+    both sides of what the LDS ring holds (192 cells; the global-memory ring beyond), against the oracle.
+    BLASR_HIP_PLAN_THREADS: the planner's offsets by three host threads, as it takes batches of 16 k candidates and more."""
     if switch:
-        monkeypatch.setenv(switch, "1")
+        monkeypatch.setenv(switch, "3" if switch == "BLASR_HIP_PLAN_THREADS" else "1")
     rng = np.random.default_rng(909)
     b, want = blasr_amd.RefineBatch(), []
     for drift in (150, 400, 900, 1500, 3000, 4500, 6000):
