@@ -418,6 +418,8 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
     lv.colSet = arena.get<int4>(nf + 64);
     lv.tieList = arena.get<int32_t>(lv.n + 1);
     lv.tieCount = lv.tieList + lv.n;
+    lv.cleanList = nullptr;
+    lv.cleanCount = nullptr;
     // the general kernels beside the small ones (general_task in sdp_kernels.hip), unless the small ones are switched off
     // (not at level 0, where nearly every invocation is a general one: a wavefront each balances better than a list)
     const bool orderBeside = level > 0 && !getenv("BLASR_HIP_NO_SMALL4") && !getenv("BLASR_HIP_ORDER_SERIAL");
@@ -468,10 +470,42 @@ int sdp_device_chunk(blasr_hip_ctx *ctx, const blasr_hip_sdp_batch *b, const bla
         lv.generalMode = 2;  // what the small kernels left over (a tie among 17 .. 64 fragments: rare)
       }
     }
-    launch_sdp_order(lv, st);
-    launch_sdp_yx_keys(lv, st);
-    launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);
-    launch_sdp_above_predcl(lv, st);
+    if (lv.generalMode == 0 && lv.n >= 4096 && !getenv("BLASR_HIP_TIES_SERIAL") && ctx->auxStream[1] && ctx->auxEvent[0] && ctx->auxEvent[2]) {
+      // A level whose invocations are all general ones (the top level: windows of kilobases): half of configs[2]'s have a
+      // fragment in two of their three lists -- an alignment that starts in the window's first bases -- and the replay of
+      // std::sort's schedule for them (one wavefront each, mostly one lane of it: 8 ms at a twentieth of the issue slots) ran
+      // alone on the device, before the (y, x) sort and the static predecessors of ALL invocations.  The invocations
+      // sdp_order_kernel orders itself go on at once (its list), the others follow the replay on another stream.
+      lv.cleanList = arena.get<int32_t>(lv.n + 1);
+      ARENA_CHECK();
+      lv.cleanCount = lv.cleanList + lv.n;
+      launch_sdp_order(lv, st, false);
+      hipStream_t sTies = ctx->auxStream[1];
+      (void)hipEventRecord(ctx->auxEvent[0], st);
+      (void)hipStreamWaitEvent(sTies, ctx->auxEvent[0], 0);
+      SdpLevelArrays part = lv;
+      part.generalMode = 2;
+      part.leftList = lv.tieList;
+      part.leftCount = lv.tieCount;
+      launch_sdp_order_ties(lv, sTies);
+      launch_sdp_yx_keys(part, sTies);
+      launch_sdp_sort_yx(part, yxKeysOut, yxIdxOut, sTies);
+      launch_sdp_above_predcl(part, sTies);
+      (void)hipEventRecord(ctx->auxEvent[2], sTies);
+      part.leftList = lv.cleanList;
+      part.leftCount = lv.cleanCount;
+      launch_sdp_yx_keys(part, st);
+      launch_sdp_sort_yx(part, yxKeysOut, yxIdxOut, st);
+      launch_sdp_above_predcl(part, st);
+      (void)hipStreamWaitEvent(st, ctx->auxEvent[2], 0);
+      lv.cleanList = nullptr;
+      lv.cleanCount = nullptr;
+    } else {
+      launch_sdp_order(lv, st);
+      launch_sdp_yx_keys(lv, st);
+      launch_sdp_sort_yx(lv, yxKeysOut, yxIdxOut, st);
+      launch_sdp_above_predcl(lv, st);
+    }
     lv.generalMode = 0;
     launch_sdp_kernel_sums(lv, st);
     tock(1);

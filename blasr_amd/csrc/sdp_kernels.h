@@ -113,6 +113,8 @@ struct SdpLevelArrays {
   int32_t *idxFlag;             // per task: some query position has more than three matches
   int32_t *idxWave;             // 4 per task: the middle fragments of each wavefront's share of the query (index kernel)
   int32_t *tieList, *tieCount;  // tasks whose fragment lists share an (x,y), see sdp_order_ties_kernel
+  int32_t *cleanList, *cleanCount;  // (or null) the tasks sdp_order_kernel ordered itself: what sdp_yx_keys .. sdp_above_predcl take
+                                    // while sdp_order_ties_kernel replays the others' sort on another stream (sdp_api.hip)
   int generalMode;              // which invocations sdp_order .. sdp_above_predcl take (general_task in sdp_kernels.hip)
   int32_t *leftList, *leftCount;  // mode 2's list: what sdp_small_kernel could not fuse although it has <= 64 fragments
   int32_t *bigGenList, *bigGenCount;  // the invocations with more than 64 raw fragments (sdp_small4_keys_kernel lists them)
@@ -153,7 +155,8 @@ void launch_sdp_small4_keys(const SdpLevelArrays &lv, uint32_t *keys, int32_t *v
 void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_t *order, hipStream_t st);
 int sdp_match_index_max_target(int device);
 void launch_sdp_match_index(const SdpLevelArrays &lv, const uint8_t *seq, bool write, hipStream_t st, hipStream_t side = nullptr);
-void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st);
+void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st, bool tiesToo = true);
+void launch_sdp_order_ties(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_yx_keys(const SdpLevelArrays &lv, hipStream_t st);
 void launch_sdp_above_predcl(const SdpLevelArrays &lv, hipStream_t st);
 // the (fragment count, index) pairs of the invocations sdp_chain4_kernel takes; sorted descending by the caller into

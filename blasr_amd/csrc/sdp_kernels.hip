@@ -1587,9 +1587,12 @@ __device__ __forceinline__ void order_task(const SdpLevelArrays &lv, const int i
       const uint64_t key = frag_key(S[i]);
       out[i + lower_bound_frag(P, nP, key) + lower_bound_frag(M, nM, key)] = S[i];
     }
-    if (lane == 0) lv.nFrag[idx] = nAll;
+    if (lane == 0) {
+      lv.nFrag[idx] = nAll;
+      if (lv.cleanList != nullptr) lv.cleanList[atomicAdd(lv.cleanCount, 1)] = idx;
+    }
   } else if (lane == 0) {
-    lv.tieList[atomicAdd(lv.tieCount, 1)] = idx;  // rare: resolved by sdp_order_ties_kernel
+    lv.tieList[atomicAdd(lv.tieCount, 1)] = idx;  // resolved by sdp_order_ties_kernel
   }
 }
 __global__ __launch_bounds__(256) void sdp_order_kernel(SdpLevelArrays lv) {
@@ -3968,9 +3971,14 @@ __global__ __launch_bounds__(256) void sdp_small4_keys_kernel(SdpLevelArrays lv,
     }
   }
 }
+__device__ __forceinline__ void small4_slots(const SdpLevelArrays &lv, const SdpParams &prm, const int32_t *order, const int slot0);
 __global__ __launch_bounds__(256, 8) void sdp_small4_kernel(SdpLevelArrays lv, SdpParams prm, const int32_t *order) {
+  // (a grid of fewer workgroups than the level has slots strides over them: launch_sdp_small)
+  for (int b = (int)blockIdx.x; b * 16 < lv.n; b += (int)gridDim.x)
+    small4_slots(lv, prm, order, __builtin_amdgcn_readfirstlane((int)(b * 4 + (threadIdx.x >> 6))) * 4);
+}
+__device__ __forceinline__ void small4_slots(const SdpLevelArrays &lv, const SdpParams &prm, const int32_t *order, const int slot0) {
   const int lane = lane_id(), l = lane & 15, gb = lane & 48;
-  const int slot0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * 4;
   if (slot0 >= lv.n) return;
   const int slot = slot0 + (lane >> 4);
   const int idx0 = order[slot0];  // any valid invocation, for the lanes without one
@@ -5118,16 +5126,27 @@ void launch_sdp_small(const SdpLevelArrays &lv, const SdpParams &p, const int32_
   if (lv.n <= 0) return;
   const bool small4 = order != nullptr;
   SpanScope sc(lv, BLASR_HIP_SDP_KERNEL_SMALL, st, lv.generalMode == 0 && lv.leftList != nullptr ? 2 : 1);
-  if (small4) hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)((lv.n + 15) / 16)), dim3(256), 0, st, lv, p, order);
+  // (sdp_small4_kernel with a fixed grid striding over the level's slots -- ten million invocations a level, 650 k workgroups as a
+  //  grid of one each: match + order 133.9 -> 131.3 ms per configs[2] step with 3072 .. 16384 workgroups, 137 with 1024;
+  //  BLASR_HIP_SMALL4_GRID=0: a workgroup per sixteen invocations)
+  static const int s4Grid = getenv("BLASR_HIP_SMALL4_GRID") ? atoi(getenv("BLASR_HIP_SMALL4_GRID")) : 4096;
+  if (small4)
+    hipLaunchKernelGGL(sdp_small4_kernel, dim3((unsigned)(s4Grid > 0 ? std::min((lv.n + 15) / 16, s4Grid) : (lv.n + 15) / 16)), dim3(256), 0,
+                       st, lv, p, order);
   if (small4)
     hipLaunchKernelGGL(sdp_small_kernel, dim3((unsigned)std::min((lv.n + 3) / 4, 8192)), dim3(256), 0, st, lv, p, kSmall4Max + 1, order);
   else
     hipLaunchKernelGGL(sdp_small_kernel, wave_grid(lv.n), dim3(256), 0, st, lv, p, 0, order);
 }
-void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st) {
+void launch_sdp_order(const SdpLevelArrays &lv, hipStream_t st, bool tiesToo) {
   if (lv.n <= 0) return;
   (void)hipMemsetAsync(lv.tieCount, 0, sizeof(int32_t), st);
+  if (lv.cleanList != nullptr) (void)hipMemsetAsync(lv.cleanCount, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(sdp_order_kernel, general_grid(lv), dim3(256), 0, st, lv);
+  if (tiesToo) launch_sdp_order_ties(lv, st);
+}
+void launch_sdp_order_ties(const SdpLevelArrays &lv, hipStream_t st) {
+  if (lv.n <= 0) return;
   hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsSmall>, dim3((unsigned)std::min(lv.n, 4096)), dim3(64), 0, st, lv, 0);
   hipLaunchKernelGGL(sdp_order_ties_kernel<kTieLdsCap>, dim3((unsigned)std::min(lv.n, 1024)), dim3(64), 0, st, lv,
                      kTieLdsSmall + 1);
