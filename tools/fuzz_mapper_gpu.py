@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--sam-reads", action="store_true",
                     help="hand the reads over as a SAM file (unaligned records with qualities): the reference reads it through "
                          "ReaderAgglomerate's SAM branch, the library with blasr_hip_sam_reads_read (-m 4 lines only)")
+    ap.add_argument("--only-it", type=int, default=-1, metavar="IT", help="map iteration IT alone (the others only draw their data)")
+    ap.add_argument("--repeat", type=int, default=1, help="with --only-it: the library's leg that many times (a fresh context each), "
+                                                           "every run compared; for differences that come and go")
     ap.add_argument("--rbao", action="store_true",
                     help="-rbao on both sides: AlignIntervals aligns between the chained anchors of each interval "
                          "(Blasr.cpp:1354-1712; the library: blasr_hip_find_intervals_chains + refine_between_anchors_only)")
@@ -183,6 +186,8 @@ def main():
             if args.dump >= 0:
                 print("iteration %d: variant %s, switches %s, files in %s" % (it, var["name"], var["cli"], tmp))
                 return
+            if args.only_it >= 0 and it != args.only_it:
+                continue
             read_group = [""]
 
             def run_reference(extra, nproc, exe=None):
@@ -241,103 +246,114 @@ def main():
                         examples.append(dict(it=it, mode=name, variant=var["name"], leg="dropin",
                                              only_reference=[x[:300] for x in sorted(set(ref[name]) - set(got))[:2]],
                                              only_dropin=[x[:300] for x in sorted(set(got) - set(ref[name]))[:2]]))
-        # the library, from the reads alone
-        parts, starts = [], [0]
-        for c in contigs:
-            parts += [c, np.array([ord("N")], np.uint8)]
-            starts.append(starts[-1] + len(c) + 1)
-        genome = np.concatenate(parts).astype(np.uint8)
-        starts = np.array(starts, dtype=np.uint32)
-        ctx = blasr_amd.Context(0)
-        ctx.upload_genome(genome, starts)
-        ctx.build_suffix_array(8, download=False)  # what blasrmc builds on the fly (Blasr.cpp:4407-4420)
-        rt = np.zeros(len(reads), dtype=blasr_amd.READ_DTYPE)
-        off = 0
-        for i, rd in enumerate(reads):
-            rt[i] = (off, len(rd), 0, len(rd), 0)
-            off += len(rd)
-        pool = np.concatenate(reads)
-        found = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt,
-                                              anchor_params=ctx.anchor_params(**var.get("anchor", {})),
-                                              interval_params=hip.interval_params(**var.get("interval", {})),
-                                              chains=args.rbao)
-        ivs = found[0]
-        chains = (found[3], found[4]) if args.rbao else None
-        mine = {}
-        mkw = dict(var.get("map", {}))
-        if args.rbao:
-            mkw["refine_between_anchors_only"] = 1
-        if "sdp" in var:
-            mkw["sdp"] = hip.SdpParams(**var["sdp"])
-        if "score" in var:
-            mkw["score"] = hip.ScoreParams(**var["score"])
-        for name, prm in (("plain", ctx.map_params(**mkw)), ("extend", ctx.map_params(extend_alignments=1, **mkw))):
-            got, unaligned = [], []
-            for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
-                                                         params=prm, min_align_length=var.get("min_align_length", 0),
-                                                         min_map_qv=var.get("min_map_qv", 0), for_picard=args.sam,
-                                                         unaligned=unaligned, chains=chains)):
-                nm = "%s/0_%d" % (names[r], len(reads[r]))
-                if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
-                    got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r],
-                                                 quality=None if quals is None else quals[r],
-                                                 clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n") for h in hits]
-                else:
-                    got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
-            if args.sam:  # PrintUnalignedRead for the reads MapRead left without an alignment
-                got += [hip.sam_unaligned_line("%s/0_%d" % (names[r], len(reads[r])), read_group[0],
-                                               reads[r], clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n")
-                        for r in unaligned]
-            mine[name] = sorted(got)
-        ctx.close()
-        totals["iters"] += 1
-        totals["reads"] += len(reads)
-        for name in ("plain", "extend"):
-            if ref[name] is None:
-                totals.setdefault("reference_failed_" + name, 0)
-                totals["reference_failed_" + name] += 1
-                continue
-            totals["lines_" + name] += len(ref[name])
-            a, b = set(ref[name]), set(mine[name])
-            diff = len(a ^ b)
-            if diff and one_thread(name) is not None and not (set(one_thread(name)) ^ b):
-                totals["reference_unstable_under_nproc"] = totals.get("reference_unstable_under_nproc", 0) + 1
-                diff = 0
-            if diff and not args.sam and not args.fastq and not args.sam_reads:
-                # The same leak carries over from one read to the next inside ONE thread as well (what a read's match list
-                # leaves behind is what the next read's interval finder finds past the end of its own): a read whose lines
-                # differ is mapped once more ALONE, by a fresh process; a difference only counts when that run shows it too.
-                stay = 0
-                for rid in sorted({x.split()[0].split("/")[0] for x in a ^ b}):
-                    r = int(rid[4:])
-                    with tempfile.TemporaryDirectory() as tmp1:
-                        open(os.path.join(tmp1, "genome.fasta"), "w").write(fasta_text["genome.fasta"])
-                        open(os.path.join(tmp1, "one.fasta"), "w").write(">%s\n%s\n" % (names[r], bytes(reads[r]).decode()))
-                        path = os.path.join(tmp1, "out.m4")
-                        p1 = subprocess.run([blasr, os.path.join(tmp1, "one.fasta"), os.path.join(tmp1, "genome.fasta"), "-m", "4",
-                                             "-bestn", "1", "-nproc", "1", "-out", path] + switches[name],
-                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                        alone = set(open(path).read().splitlines()) if p1.returncode == 0 and os.path.exists(path) else None
-                    ours = {x for x in b if x.split()[0].split("/")[0] == rid}
-                    if alone is not None and alone == ours:
-                        totals["reference_depends_on_the_read_before"] = totals.get("reference_depends_on_the_read_before", 0) + 1
+        for _rep in range(args.repeat if args.only_it >= 0 else 1):
+            # the library, from the reads alone
+            parts, starts = [], [0]
+            for c in contigs:
+                parts += [c, np.array([ord("N")], np.uint8)]
+                starts.append(starts[-1] + len(c) + 1)
+            genome = np.concatenate(parts).astype(np.uint8)
+            starts = np.array(starts, dtype=np.uint32)
+            ctx = blasr_amd.Context(0)
+            ctx.upload_genome(genome, starts)
+            ctx.build_suffix_array(8, download=False)  # what blasrmc builds on the fly (Blasr.cpp:4407-4420)
+            rt = np.zeros(len(reads), dtype=blasr_amd.READ_DTYPE)
+            off = 0
+            for i, rd in enumerate(reads):
+                rt[i] = (off, len(rd), 0, len(rd), 0)
+                off += len(rd)
+            pool = np.concatenate(reads)
+            found = blasr_amd.candidate_intervals(ctx, genome, starts, ctx.count_tuples(8), pool, rt,
+                                                  anchor_params=ctx.anchor_params(**var.get("anchor", {})),
+                                                  interval_params=hip.interval_params(**var.get("interval", {})),
+                                                  chains=args.rbao)
+            ivs = found[0]
+            chains = (found[3], found[4]) if args.rbao else None
+            mine = {}
+            mkw = dict(var.get("map", {}))
+            if args.rbao:
+                mkw["refine_between_anchors_only"] = 1
+            if "sdp" in var:
+                mkw["sdp"] = hip.SdpParams(**var["sdp"])
+            if "score" in var:
+                mkw["score"] = hip.ScoreParams(**var["score"])
+            for name, prm in (("plain", ctx.map_params(**mkw)), ("extend", ctx.map_params(extend_alignments=1, **mkw))):
+                got, unaligned = [], []
+                for r, hits in enumerate(blasr_amd.map_reads(ctx, len(genome), starts, pool, rt, ivs, bestn=var.get("bestn", 1),
+                                                             params=prm, min_align_length=var.get("min_align_length", 0),
+                                                             min_map_qv=var.get("min_map_qv", 0), for_picard=args.sam,
+                                                             unaligned=unaligned, chains=chains)):
+                    nm = "%s/0_%d" % (names[r], len(reads[r]))
+                    if args.sam:  # -sam switches forPicard on (MappingParameters.h:488-491)
+                        got += [blasr_amd.sam_record(h, nm, "contig%d" % h["contig"], read_group[0], reads[r],
+                                                     quality=None if quals is None else quals[r],
+                                                     clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n") for h in hits]
                     else:
-                        stay += len({x for x in a ^ b if x.split()[0].split("/")[0] == rid})
-                diff = stay
-            totals["bad_" + name] += diff
-            v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
-            v["lines"] += len(ref[name])
-            v["bad"] += diff
-            if diff and args.sam and len(examples) < 6:  # which fields of a record differ
-                byname = {x.split("\t")[0]: x for x in b - a}
-                for x in sorted(a - b)[:2]:
-                    y = byname.get(x.split("\t")[0])
-                    if y is not None:
-                        fx, fy = x.split("\t"), y.split("\t")
-                        examples.append(dict(it=it, mode=name, variant=var["name"], fields=[
-                            (i, u[:60], v[:60]) for i, (u, v) in enumerate(zip(fx, fy)) if u != v], n=(len(fx), len(fy))))
-            if diff and len(examples) < 6:
-                examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=[x[:500] for x in sorted(a - b)[:2]], only_library=[x[:500] for x in sorted(b - a)[:2]]))
+                        got += [blasr_amd.m4_record(h, nm, "contig%d" % h["contig"]).rstrip("\n") for h in hits]
+                if args.sam:  # PrintUnalignedRead for the reads MapRead left without an alignment
+                    got += [hip.sam_unaligned_line("%s/0_%d" % (names[r], len(reads[r])), read_group[0],
+                                                   reads[r], clipping=var.get("clipping", hip.CLIP_NONE)).rstrip("\n")
+                            for r in unaligned]
+                mine[name] = sorted(got)
+            ctx.close()
+            totals["iters"] += 1
+            totals["reads"] += len(reads)
+            for name in ("plain", "extend"):
+                if ref[name] is None:
+                    totals.setdefault("reference_failed_" + name, 0)
+                    totals["reference_failed_" + name] += 1
+                    continue
+                totals["lines_" + name] += len(ref[name])
+                a, b = set(ref[name]), set(mine[name])
+                diff = len(a ^ b)
+                if diff and one_thread(name) is not None and not (set(one_thread(name)) ^ b):
+                    totals["reference_unstable_under_nproc"] = totals.get("reference_unstable_under_nproc", 0) + 1
+                    diff = 0
+                if diff and not args.fastq and not args.sam_reads:
+                    # The same leak carries over from one read to the next inside ONE thread as well (what a read's match list
+                    # leaves behind is what the next read's interval finder finds past the end of its own): a read whose lines
+                    # differ is mapped once more ALONE, by a fresh process; a difference only counts when that run shows it too.
+                    # (-sam: the file keeps its name, the read group's ID is made from it; the lone run's record of a read it
+                    #  leaves unaligned counts as a line like any other.)
+                    stay = 0
+                    for rid in sorted({x.split()[0].split("/")[0] for x in a ^ b}):
+                        r = int(rid[4:])
+                        with tempfile.TemporaryDirectory() as tmp1:
+                            open(os.path.join(tmp1, "genome.fasta"), "w").write(fasta_text["genome.fasta"])
+                            one = os.path.join(tmp1, "one.fasta")
+                            open(one, "w").write(">%s\n%s\n" % (names[r], bytes(reads[r]).decode()))
+                            path = os.path.join(tmp1, "out.m4")
+                            p1 = subprocess.run([blasr, one, os.path.join(tmp1, "genome.fasta")] + (["-sam"] if args.sam else ["-m", "4"]) +
+                                                ["-bestn", "1", "-nproc", "1", "-out", path] + switches[name],
+                                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                            alone = ({x for x in open(path).read().splitlines() if not x.startswith("@")}
+                                     if p1.returncode == 0 and os.path.exists(path) else None)
+                        ours = {x for x in b if x.split()[0].split("/")[0] == rid}
+                        if args.sam and alone is not None:  # (the read group's ID is an MD5 of the file's PATH: not part of the comparison)
+                            import re
+                            alone = {re.sub(r"\tRG:Z:[0-9a-f]+", "", x) for x in alone}
+                            ours = {re.sub(r"\tRG:Z:[0-9a-f]+", "", x) for x in ours}
+                        if alone is not None and alone == ours:
+                            totals["reference_depends_on_the_read_before"] = totals.get("reference_depends_on_the_read_before", 0) + 1
+                        else:
+                            stay += len({x for x in a ^ b if x.split()[0].split("/")[0] == rid})
+                    diff = stay
+                totals["bad_" + name] += diff
+                if args.only_it >= 0:
+                    print("[rep %d] %s: %d differ %s" % (_rep, name, diff, sorted({x.split("\t")[0] for x in a ^ b})[:4]), file=sys.stderr)
+                v = by_variant.setdefault(var["name"], dict(lines=0, bad=0))
+                v["lines"] += len(ref[name])
+                v["bad"] += diff
+                if diff and args.sam and len(examples) < 6:  # which fields of a record differ
+                    byname = {x.split("\t")[0]: x for x in b - a}
+                    for x in sorted(a - b)[:2]:
+                        y = byname.get(x.split("\t")[0])
+                        if y is not None:
+                            fx, fy = x.split("\t"), y.split("\t")
+                            examples.append(dict(it=it, mode=name, variant=var["name"], fields=[
+                                (i, u[:60], v[:60]) for i, (u, v) in enumerate(zip(fx, fy)) if u != v], n=(len(fx), len(fy))))
+                if diff and len(examples) < 6:
+                    examples.append(dict(it=it, mode=name, variant=var["name"], only_reference=[x[:500] for x in sorted(a - b)[:2]], only_library=[x[:500] for x in sorted(b - a)[:2]]))
         if ref["plain"] is not None and ref["extend"] is not None:
             totals["changed_by_extend"] += len(set(ref["plain"]) ^ set(ref["extend"])) // 2
     totals["seconds"] = round(time.time() - t0, 1)
